@@ -1,0 +1,224 @@
+"""bench.py — BPR-MF training throughput on MI355X (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--optimizer sgd|adam|rmsprop]
+
+A "step" is one pass of the hot path over one batch of B = 4096 synthetic (user, pos, neg) triples:
+gather -> score -> BPR gradient -> scatter into the dense gradient -> optimizer update (exactly
+the work of MFEngine.train_single_batch in the reference, beta_rec/models/mf.py:92-119).  Inputs
+(triples + permutation) are resident in HBM when the timed region starts; the K timed steps are
+enqueued by the library's epoch driver and bracketed by barrier + synchronize on both sides.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# BASELINE.json configs[1] / SURVEY.md §8 C2
+U, I, D, B = 6040, 3706, 64, 4096
+LR = 0.05
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec peak)
+
+
+def algorithmic_bytes_per_triple(dim):
+    """indices 3*8 B + 3 row reads + 3 row writes of (dim+1) fp32."""
+    return 24 + 24 * (dim + 1)
+
+
+def synth_triples(n, seed):
+    """MovieLens-1M-shaped synthetic: uniform users, Zipf(1.0) positives over a seeded permutation
+    of the items, uniform negatives."""
+    g = torch.Generator().manual_seed(seed)
+    users = torch.randint(0, U, (n,), generator=g)
+    p = 1.0 / torch.arange(1, I + 1, dtype=torch.float64)
+    pos = torch.randperm(I, generator=g)[torch.multinomial(p / p.sum(), n, True, generator=g)]
+    neg = torch.randint(0, I, (n,), generator=g)
+    return users, pos, neg
+
+
+def make_engine(device, optimizer):
+    import beta_recsys_amd as hp
+
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str=str(device), optimizer=optimizer,
+                         lr=LR, batch_size=B, loss="bpr"),
+           "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
+    torch.manual_seed(2020)
+    with contextlib.redirect_stdout(io.StringIO()):
+        return hp.MFEngine(cfg)
+
+
+def run_epoch(eng, batcher):
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng.train_an_epoch(batcher, 0)
+
+
+def kernel_timing(eng, triples, n_launch=200):
+    """Average duration of ONE launch of the dominant kernel (BPR grad: gather+score+scatter),
+    measured live with HIP events on the stream the kernel is launched on."""
+    import ctypes
+
+    from beta_recsys_amd import _lib
+
+    lib = eng._setup()
+    m = eng.model
+    users, pos, neg = (t[:B].contiguous() for t in triples)
+    w, g = m.tables(), m.tables(eng._g_flat)
+    st = _lib.stream_ptr(m.flat.device)
+    args = (ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), None, B,
+            1.0 / B, 0.0, _lib.ptr(eng._stats), _lib.ptr(eng._scratch), eng._scratch.numel(), st)
+    for _ in range(20):
+        _lib.check(lib.hiprec_mf_bpr_grad(*args))
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(n_launch)]
+    for a, b in evs:
+        a.record()
+        _lib.check(lib.hiprec_mf_bpr_grad(*args))
+        b.record()
+    torch.cuda.synchronize()
+    per = sorted(a.elapsed_time(b) for a, b in evs)  # ms
+    eng._g_flat.zero_()
+    eng.load_optimizer_state(0)
+    return float(np.mean(per)) * 1e-3, float(per[len(per) // 2]) * 1e-3  # seconds: mean, median
+
+
+def cpu_baseline(budget_s=12.0):
+    """The reference's CPU path (PyTorch ops, dense autograd, torch.optim) on this box's host
+    cores, timed on a bounded sample of the same workload: oracle/torch_port.py, kind "port"."""
+    from oracle import mf_numpy as onp
+    from oracle.torch_port import TorchMFPort
+
+    torch.manual_seed(0)
+    port = TorchMFPort(onp.init_params(U, I, D, seed=0), "sgd", LR, "bpr")
+    n_batches = 64
+    users, pos, neg = synth_triples(n_batches * B, seed=1)
+    batches = [(users[i * B:(i + 1) * B], pos[i * B:(i + 1) * B], neg[i * B:(i + 1) * B])
+               for i in range(n_batches)]
+    for i in range(5):
+        port.step(batches[i])
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        port.step(batches[steps % n_batches])
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": steps * B / dt, "unit": "triples/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{steps} sgd steps of batch {B} (same C2 workload) in {dt:.1f} s, "
+                      f"PyTorch-CPU op sequence of the reference on {os.cpu_count()} logical cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adam", "rmsprop"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device(f"cuda:{local_rank}")
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+
+    import beta_recsys_amd as hp
+
+    # Path shards by independent triples: every rank trains its own shard of the interaction
+    # stream (weak scaling, per-GPU batch fixed at B).  See DESIGN.md (multi-GPU).
+    eng = make_engine(device, args.optimizer)
+    n_total = (args.warmup + args.steps) * B
+    users, pos, neg = (t.to(device) for t in synth_triples(n_total, seed=100 + rank))
+    gen = torch.Generator().manual_seed(7 + rank)
+    nw = args.warmup * B
+    warm = hp.DeviceTripleBatcher(users[:nw], pos[:nw], neg[:nw], B, generator=gen)
+    timed = hp.DeviceTripleBatcher(users[nw:], pos[nw:], neg[nw:], B, generator=gen)
+
+    if args.warmup > 0:
+        run_epoch(eng, warm)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_epoch(eng, timed)  # exactly args.steps steps
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert len(timed) == args.steps
+    if dist_on:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        k_mean, k_med = kernel_timing(eng, (users, pos, neg))
+        bpt = algorithmic_bytes_per_triple(D)
+        achieved = bpt * B / k_mean / 1e9
+        out = {
+            "metric": "training interactions/sec (BPR triples)",
+            "value": world * args.steps * B / dt,
+            "unit": "triples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BPR-MF, MovieLens-1M-shaped synthetic (BASELINE configs[1]): 6040 users x "
+                            "3706 items, dim 64, batch 4096 triples/GPU, uniform users, Zipf(1.0) "
+                            "positives, uniform negatives",
+                "optimizer": args.optimizer, "lr": LR, "loss": "bpr", "batch_per_gpu": B,
+                "global_batch": B * world,
+                "parallelism": "1 process per GPU" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "mf_bpr_grad_kernel (gather + score + BPR grad + atomic scatter)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": bpt * B,
+                "kernel_us_mean": k_mean * 1e6,
+                "kernel_us_median": k_med * 1e6,
+                "traffic": None,
+                "step_frac": (world * args.steps * B / dt) / world * bpt / (HBM_PEAK_GBS * 1e9),
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,11 @@
+"""hiprec — MI355X-native embedding-table training hot path for beta-recsys models.
+
+Host-side mirrors of the reference's engine modules (``beta_rec.models.{torch_engine,mf,...}``)
+over the C-ABI HIP library ``libhiprec.so`` (``csrc/``, declared in ``include/hiprec.h``).
+Import as ``beta_recsys_amd`` (see the shim package of that name at the repository root).
+"""
+__version__ = "0.1.0"
+
+from . import _lib  # noqa: F401
+from .torch_engine import HipOptimizer, ModelEngine  # noqa: F401
+from .mf import MF, DeviceTripleBatcher, MFEngine, gather_rows  # noqa: F401

@@ -1,0 +1,144 @@
+"""ctypes binding of libhiprec.so (declared in include/hiprec.h).
+
+The HIP library is THE product path: there is no CPU fallback.  If the shared object is missing or
+a symbol is absent, loading fails loudly with a RuntimeError naming the build command.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64
+from ctypes import c_size_t, c_uint32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhiprec.so")
+
+OPT_SGD, OPT_ADAM, OPT_RMSPROP = 0, 1, 2
+OPT_KINDS = {"sgd": OPT_SGD, "adam": OPT_ADAM, "rmsprop": OPT_RMSPROP}
+
+STATUS_USER_OOB, STATUS_ITEM_OOB, STATUS_ROW_OOB = 1, 2, 4
+
+
+class MfTables(Structure):
+    """hiprec_mf_tables (include/hiprec.h)."""
+
+    _fields_ = [
+        ("user_emb", c_void_p),
+        ("item_emb", c_void_p),
+        ("user_bias", c_void_p),
+        ("item_bias", c_void_p),
+        ("global_bias", c_void_p),
+        ("n_users", c_int64),
+        ("n_items", c_int64),
+        ("dim", c_int32),
+        ("_pad", c_int32),
+    ]
+
+
+class Stats(Structure):
+    """hiprec_stats (include/hiprec.h) — host-side mirror used to decode a device copy."""
+
+    _fields_ = [
+        ("loss", c_float),
+        ("reg", c_float),
+        ("loss_sum", c_double),
+        ("reg_sum", c_double),
+        ("step", c_int64),
+        ("beta1", c_double),
+        ("beta2", c_double),
+        ("beta1_pow", c_double),
+        ("beta2_pow", c_double),
+        ("status", c_uint32),
+        ("_pad", c_uint32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol of include/hiprec.h must be listed here
+_P = c_void_p
+_T = POINTER(MfTables)
+SIGNATURES = {
+    "hiprec_version": (c_int, []),
+    "hiprec_last_error": (c_char_p, []),
+    "hiprec_stats_bytes": (c_size_t, []),
+    "hiprec_scratch_bytes": (c_size_t, [c_int64]),
+    "hiprec_stats_reset": (c_int, [_P, c_double, c_double, _P]),
+    "hiprec_stats_advance_step": (c_int, [_P, _P]),
+    "hiprec_stats_begin_epoch": (c_int, [_P, _P]),
+    "hiprec_gather_rows": (c_int, [_P, c_int64, c_int32, _P, c_int64, _P, _P, _P]),
+    "hiprec_mf_predict": (c_int, [_T, _P, _P, c_int64, _P, _P, _P]),
+    "hiprec_mf_bpr_grad": (
+        c_int,
+        [_T, _T, _P, _P, _P, _P, c_int64, c_float, c_float, _P, _P, c_size_t, _P],
+    ),
+    "hiprec_mf_bce_grad": (
+        c_int,
+        [_T, _T, _P, _P, _P, _P, c_int64, c_float, c_float, _P, _P, c_size_t, _P],
+    ),
+    "hiprec_finalize_stats": (c_int, [_P, _P, _P]),
+    "hiprec_opt_dense_step": (
+        c_int,
+        [c_int, _P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, _P, _P, _P],
+    ),
+    "hiprec_mf_sgd_rows": (
+        c_int,
+        [_T, _T, _P, _P, _P, _P, c_int64, c_double, _P, _P, c_int32, _P, _P, _P],
+    ),
+    "hiprec_mf_bpr_epoch": (
+        c_int,
+        [_T, _T, _P, _P, _P, _P, c_int64, c_int64, c_float, c_int]
+        + [c_double, c_double, c_double, c_double]
+        + [_P, _P, _P, _P, c_int64, _P, _P, c_int32, _P, _P, c_size_t, _P],
+    ),
+}
+
+_lib = None
+
+
+class HiprecError(RuntimeError):
+    """A libhiprec call returned a non-zero code."""
+
+
+def load():
+    """Load libhiprec.so (once) and attach the prototypes.  Fails loudly when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libhiprec.so not found at {LIB_PATH}: the HIP extension is the only compute path of "
+            "this package (there is no CPU fallback). Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950)."
+        )
+    # torch must be imported first so that libamdhip64.so.7 resolves to the runtime torch already
+    # loaded (one HIP runtime per process: streams and device pointers are shared with torch).
+    import torch  # noqa: F401
+
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise RuntimeError(f"libhiprec.so does not export {name}; rebuild it") from exc
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.hiprec_stats_bytes() != ctypes.sizeof(Stats):
+        raise RuntimeError("hiprec_stats layout mismatch between _lib.py and libhiprec.so")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Raise HiprecError for a non-zero return code of a libhiprec call."""
+    if rc != 0:
+        msg = load().hiprec_last_error()
+        raise HiprecError(f"libhiprec call failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor as c_void_p (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_ptr(device):
+    """Current torch stream of `device` as a hipStream_t (c_void_p)."""
+    import torch
+
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,167 @@
+// Shared device/host helpers for libhiprec (gfx950 only: wave64, DPP, hardware fp32 atomics).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/hiprec.h"
+
+namespace hiprec {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kBlock = 256;        // 4 waves = one per SIMD
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kMaxBlocks = 2048;   // 256 CUs x 8 blocks; grid-stride beyond that
+constexpr size_t kScratchBytes = 16 + sizeof(float) * 2 * kMaxBlocks;
+
+// scratch block layout: header + per-block {loss, reg} partial sums of the last *_grad call
+struct Scratch {
+  uint32_t n_partials;
+  uint32_t _pad[3];
+  float2 partials[kMaxBlocks];
+};
+static_assert(sizeof(Scratch) == kScratchBytes, "scratch layout");
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define HIPREC_TRY(expr)                                   \
+  do {                                                     \
+    hipError_t _e = (expr);                                \
+    if (_e != hipSuccess) return hiprec::hip_fail(_e, #expr); \
+  } while (0)
+
+#define HIPREC_REQUIRE(cond, ...)        \
+  do {                                   \
+    if (!(cond)) {                       \
+      hiprec::set_error(__VA_ARGS__);    \
+      return HIPREC_E_BADARG;            \
+    }                                    \
+  } while (0)
+
+inline int grid_for_waves(int64_t n_waves) {
+  int64_t blocks = (n_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (blocks < 1) blocks = 1;
+  if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+  return static_cast<int>(blocks);
+}
+
+inline int grid_for_threads(int64_t n_threads) {
+  int64_t blocks = (n_threads + kBlock - 1) / kBlock;
+  if (blocks < 1) blocks = 1;
+  if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+  return static_cast<int>(blocks);
+}
+
+#if defined(__HIPCC__)
+
+// ---- wave64 all-reduce (sum) on the VALU: 4 DPP steps inside each 16-lane row, then the four row
+// totals are read back through SGPRs.  No LDS traffic, result uniform across the wave.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false);
+  return v + __builtin_bit_cast(float, moved);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  v = dpp_add<0x140>(v);  // row_mirror -> every lane of a row holds the row total
+  int iv = __builtin_bit_cast(int, v);
+  float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+  float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+  float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+  float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+__device__ __forceinline__ int wave_in_block() {
+  return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+}
+
+__device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & 63; }
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+  // lowers to global_atomic_add_f32 (no return) under -munsafe-fp-atomics
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ float sigmoid_f32(float s) { return 1.0f / (1.0f + expf(-s)); }
+
+// -logsigmoid(x) and sigmoid(-x) the way ATen computes them (min(x,0) - log1p(exp(-|x|)))
+__device__ __forceinline__ float neg_logsigmoid(float x, float* sig_neg_x) {
+  float z = expf(-fabsf(x));
+  float frac = z / (1.0f + z);
+  *sig_neg_x = x < 0.0f ? 1.0f - frac : frac;
+  return log1pf(z) - fminf(x, 0.0f);
+}
+
+// Block-level reduction of per-wave values and publication of this block's partial sums.
+// `loss_w` is wave-uniform; `reg_lane` is a per-lane partial.
+__device__ __forceinline__ void publish_partials(float loss_w, float reg_lane, float inv_batch,
+                                                 Scratch* scratch) {
+  __shared__ float s_loss[kWavesPerBlock];
+  __shared__ float s_reg[kWavesPerBlock];
+  float reg_w = wave_sum(reg_lane);
+  const int w = wave_in_block();
+  if (lane_id() == 0) {
+    s_loss[w] = loss_w;
+    s_reg[w] = reg_w;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float l = 0.f, r = 0.f;
+#pragma unroll
+    for (int i = 0; i < kWavesPerBlock; ++i) {
+      l += s_loss[i];
+      r += s_reg[i];
+    }
+    scratch->partials[blockIdx.x] = make_float2(l * inv_batch, r * inv_batch);
+    if (blockIdx.x == 0) scratch->n_partials = gridDim.x;
+  }
+}
+
+// Run by block 0 of the kernel that FOLLOWS a *_grad kernel: deterministic reduction of the
+// per-block partials into the device stats.
+__device__ __forceinline__ void finalize_partials(hiprec_stats* stats, const Scratch* scratch) {
+  __shared__ double s_l[kBlock];
+  __shared__ double s_r[kBlock];
+  const uint32_t n = scratch->n_partials;
+  double l = 0.0, r = 0.0;
+  for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+    float2 p = scratch->partials[i];
+    l += p.x;
+    r += p.y;
+  }
+  s_l[threadIdx.x] = l;
+  s_r[threadIdx.x] = r;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (static_cast<int>(threadIdx.x) < s) {
+      s_l[threadIdx.x] += s_l[threadIdx.x + s];
+      s_r[threadIdx.x] += s_r[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    stats->loss = static_cast<float>(s_l[0]);
+    stats->reg = static_cast<float>(s_r[0]);
+    stats->loss_sum += static_cast<double>(static_cast<float>(s_l[0]));
+    stats->reg_sum += static_cast<double>(static_cast<float>(s_r[0]));
+  }
+}
+
+// One thread per *_grad launch: t <- t+1 and the running beta powers used by Adam's bias correction
+// (kept on the device so that a captured graph of steps can be replayed).
+__device__ __forceinline__ void advance_step(hiprec_stats* stats) {
+  stats->step += 1;
+  stats->beta1_pow *= stats->beta1;
+  stats->beta2_pow *= stats->beta2;
+}
+
+#endif  // __HIPCC__
+
+}  // namespace hiprec

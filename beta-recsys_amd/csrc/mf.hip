@@ -1,0 +1,439 @@
+// MF (matrix factorisation) hot path for gfx950: gather -> score -> BPR/BCE gradient -> scatter.
+//
+// Replaces, op for op, the PyTorch sequence of beta_rec/models/mf.py:32-55 (MF.forward, called
+// twice per BPR step), beta_rec/models/torch_engine.py:92-121 (bpr_loss / bce_loss) and the
+// autograd backward of mf.py:117 (8x embedding_dense_backward into dense gradients).
+//
+// Mapping: one 64-lane wavefront per triple, one lane per embedding column (dim 64 = exactly one
+// dword per lane, so a row read is ONE coalesced 256-B global_load_dword and a row of gradient is
+// ONE global_atomic_add_f32 wave instruction).  Index triples are wave-uniform -> scalar loads.
+// The two dot products are reduced on the VALU with DPP (no LDS round trip); loss / regularizer
+// partial sums stay in registers across the grid-stride loop and are published once per block.
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace hiprec {
+
+struct RowAccess {
+  const float* __restrict__ user_emb;
+  const float* __restrict__ item_emb;
+  const float* __restrict__ user_bias;
+  const float* __restrict__ item_bias;
+  const float* __restrict__ global_bias;
+};
+
+// NPL = embedding columns held per lane (dim <= 64*NPL).  NPL == 0: any dim, rows are re-read
+// (from L1/L2) in the gradient phase instead of being held in registers.
+template <int NPL>
+__global__ __launch_bounds__(kBlock) void mf_bpr_grad_kernel(
+    hiprec_mf_tables w, hiprec_mf_tables g, const int64_t* __restrict__ users,
+    const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
+    const int64_t* __restrict__ perm, int64_t batch, float inv_batch, float reg_coef,
+    hiprec_stats* stats, Scratch* scratch) {
+  const int lane = lane_id();
+  const int D = w.dim;
+  const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const float gb = *w.global_bias;
+
+  float loss_acc = 0.f;  // wave-uniform
+  float reg_acc = 0.f;   // per lane
+  float gb_acc = 0.f;    // wave-uniform: d(loss)/d(global_bias)
+
+  if (blockIdx.x == 0 && threadIdx.x == 0) advance_step(stats);
+
+  for (int64_t t = wave0; t < batch; t += n_waves) {
+    const int64_t j = perm ? perm[t] : t;
+    const int64_t u = users[j], p = pos[j], n = neg[j];
+    const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(w.n_users);
+    const bool i_ok = static_cast<uint64_t>(p) < static_cast<uint64_t>(w.n_items) &&
+                      static_cast<uint64_t>(n) < static_cast<uint64_t>(w.n_items);
+    if (!(u_ok && i_ok)) {
+      if (lane == 0)
+        atomicOr(&stats->status,
+                 (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
+      continue;
+    }
+    const float* ur = w.user_emb + u * D;
+    const float* pr = w.item_emb + p * D;
+    const float* nr = w.item_emb + n * D;
+    float* gur = g.user_emb + u * D;
+    float* gpr = g.item_emb + p * D;
+    float* gnr = g.item_emb + n * D;
+
+    float dp = 0.f, dn = 0.f;
+    float uu[NPL > 0 ? NPL : 1], pp[NPL > 0 ? NPL : 1], nn[NPL > 0 ? NPL : 1];
+    if constexpr (NPL > 0) {
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        const int c = lane + kWave * k;
+        const bool in = c < D;
+        uu[k] = in ? ur[c] : 0.f;
+        pp[k] = in ? pr[c] : 0.f;
+        nn[k] = in ? nr[c] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        dp += uu[k] * pp[k];
+        dn += uu[k] * nn[k];
+        reg_acc += 2.f * uu[k] * uu[k] + pp[k] * pp[k] + nn[k] * nn[k];
+      }
+    } else {
+      for (int c = lane; c < D; c += kWave) {
+        const float a = ur[c], b = pr[c], d = nr[c];
+        dp += a * b;
+        dn += a * d;
+        reg_acc += 2.f * a * a + b * b + d * d;
+      }
+    }
+    dp = wave_sum(dp);
+    dn = wave_sum(dn);
+
+    const float bu = w.user_bias[u], bp = w.item_bias[p], bn = w.item_bias[n];
+    // mf.py:43-48: sigmoid(sum + u_bias + i_bias + global_bias)
+    const float yp = sigmoid_f32(((dp + bu) + bp) + gb);
+    const float yn = sigmoid_f32(((dn + bu) + bn) + gb);
+    // torch_engine.py:104-105: -mean(logsigmoid(pos - neg))
+    float sig_neg_x;
+    const float nls = neg_logsigmoid(yp - yn, &sig_neg_x);
+    const float delta = -sig_neg_x * inv_batch;       // dL/d(yp) ; dL/d(yn) = -delta
+    const float dpos = delta * ((1.f - yp) * yp);     // through the sigmoid
+    const float dneg = -delta * ((1.f - yn) * yn);
+    // mf.py:116 batch_loss = loss + reg*regularizer; user terms appear in both forward calls
+    const float ru = 4.f * reg_coef * inv_batch, ri = 2.f * reg_coef * inv_batch;
+
+    if constexpr (NPL > 0) {
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        const int c = lane + kWave * k;
+        if (c < D) {
+          atomic_add_f32(gur + c, (dpos * pp[k] + dneg * nn[k]) + ru * uu[k]);
+          atomic_add_f32(gpr + c, dpos * uu[k] + ri * pp[k]);
+          atomic_add_f32(gnr + c, dneg * uu[k] + ri * nn[k]);
+        }
+      }
+    } else {
+      for (int c = lane; c < D; c += kWave) {
+        const float a = ur[c], b = pr[c], d = nr[c];
+        atomic_add_f32(gur + c, (dpos * b + dneg * d) + ru * a);
+        atomic_add_f32(gpr + c, dpos * a + ri * b);
+        atomic_add_f32(gnr + c, dneg * a + ri * d);
+      }
+    }
+    if (lane == 0) {
+      atomic_add_f32(g.user_bias + u, (dpos + dneg) + ru * bu);
+      atomic_add_f32(g.item_bias + p, dpos + ri * bp);
+      atomic_add_f32(g.item_bias + n, dneg + ri * bn);
+      reg_acc += 2.f * bu * bu + bp * bp + bn * bn;
+    }
+    loss_acc += nls;
+    gb_acc += dpos + dneg;
+  }
+
+  // d(loss)/d(global_bias): one atomic per block
+  __shared__ float s_gb[kWavesPerBlock];
+  if (lane == 0) s_gb[wave_in_block()] = gb_acc;
+  publish_partials(loss_acc, reg_acc, inv_batch, scratch);  // contains a __syncthreads()
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kWavesPerBlock; ++i) s += s_gb[i];
+    if (s != 0.f) atomic_add_f32(g.global_bias, s);
+  }
+}
+
+template <int NPL>
+__global__ __launch_bounds__(kBlock) void mf_bce_grad_kernel(
+    hiprec_mf_tables w, hiprec_mf_tables g, const int64_t* __restrict__ users,
+    const int64_t* __restrict__ items, const float* __restrict__ ratings,
+    const int64_t* __restrict__ perm, int64_t batch, float inv_batch, float reg_coef,
+    hiprec_stats* stats, Scratch* scratch) {
+  const int lane = lane_id();
+  const int D = w.dim;
+  const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const float gb = *w.global_bias;
+
+  float loss_acc = 0.f, reg_acc = 0.f, gb_acc = 0.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) advance_step(stats);
+
+  for (int64_t t = wave0; t < batch; t += n_waves) {
+    const int64_t j = perm ? perm[t] : t;
+    const int64_t u = users[j], i = items[j];
+    const float r = ratings[j];
+    const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(w.n_users);
+    const bool i_ok = static_cast<uint64_t>(i) < static_cast<uint64_t>(w.n_items);
+    if (!(u_ok && i_ok)) {
+      if (lane == 0)
+        atomicOr(&stats->status,
+                 (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
+      continue;
+    }
+    const float* ur = w.user_emb + u * D;
+    const float* ir = w.item_emb + i * D;
+    float* gur = g.user_emb + u * D;
+    float* gir = g.item_emb + i * D;
+
+    float dot = 0.f;
+    float uu[NPL > 0 ? NPL : 1], ii[NPL > 0 ? NPL : 1];
+    if constexpr (NPL > 0) {
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        const int c = lane + kWave * k;
+        const bool in = c < D;
+        uu[k] = in ? ur[c] : 0.f;
+        ii[k] = in ? ir[c] : 0.f;
+        dot += uu[k] * ii[k];
+        reg_acc += uu[k] * uu[k] + ii[k] * ii[k];
+      }
+    } else {
+      for (int c = lane; c < D; c += kWave) {
+        const float a = ur[c], b = ir[c];
+        dot += a * b;
+        reg_acc += a * a + b * b;
+      }
+    }
+    dot = wave_sum(dot);
+    const float bu = w.user_bias[u], bi = w.item_bias[i];
+    const float y = sigmoid_f32(((dot + bu) + bi) + gb);
+    // torch.nn.BCELoss (mean): -(r*max(log y,-100) + (1-r)*max(log(1-y),-100))
+    const float ly = fmaxf(logf(y), -100.f);
+    const float l1y = fmaxf(log1pf(-y), -100.f);
+    const float loss_k = -(r * ly + (1.f - r) * l1y);
+    // ATen binary_cross_entropy_backward, then sigmoid_backward
+    const float gy = (y - r) / fmaxf((1.f - y) * y, 1e-12f) * inv_batch;
+    const float ds = gy * ((1.f - y) * y);
+    const float rr = 2.f * reg_coef * inv_batch;
+
+    if constexpr (NPL > 0) {
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        const int c = lane + kWave * k;
+        if (c < D) {
+          atomic_add_f32(gur + c, ds * ii[k] + rr * uu[k]);
+          atomic_add_f32(gir + c, ds * uu[k] + rr * ii[k]);
+        }
+      }
+    } else {
+      for (int c = lane; c < D; c += kWave) {
+        const float a = ur[c], b = ir[c];
+        atomic_add_f32(gur + c, ds * b + rr * a);
+        atomic_add_f32(gir + c, ds * a + rr * b);
+      }
+    }
+    if (lane == 0) {
+      atomic_add_f32(g.user_bias + u, ds + rr * bu);
+      atomic_add_f32(g.item_bias + i, ds + rr * bi);
+      reg_acc += bu * bu + bi * bi;
+    }
+    loss_acc += loss_k;
+    gb_acc += ds;
+  }
+
+  __shared__ float s_gb[kWavesPerBlock];
+  if (lane == 0) s_gb[wave_in_block()] = gb_acc;
+  publish_partials(loss_acc, reg_acc, inv_batch, scratch);
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kWavesPerBlock; ++i) s += s_gb[i];
+    if (s != 0.f) atomic_add_f32(g.global_bias, s);
+  }
+}
+
+// scores[k] = sigmoid(<U[u], I[i]> + bu + bi + g)   (MF.predict, mf.py:57-70)
+__global__ __launch_bounds__(kBlock) void mf_predict_kernel(hiprec_mf_tables w,
+                                                            const int64_t* __restrict__ users,
+                                                            const int64_t* __restrict__ items,
+                                                            int64_t n, float* __restrict__ scores,
+                                                            hiprec_stats* stats) {
+  const int lane = lane_id();
+  const int D = w.dim;
+  const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const float gb = *w.global_bias;
+  for (int64_t t = wave0; t < n; t += n_waves) {
+    const int64_t u = users[t], i = items[t];
+    const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(w.n_users);
+    const bool i_ok = static_cast<uint64_t>(i) < static_cast<uint64_t>(w.n_items);
+    if (!(u_ok && i_ok)) {
+      if (lane == 0) {
+        atomicOr(&stats->status,
+                 (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
+        scores[t] = __builtin_nanf("");
+      }
+      continue;
+    }
+    const float* ur = w.user_emb + u * D;
+    const float* ir = w.item_emb + i * D;
+    float dot = 0.f;
+    for (int c = lane; c < D; c += kWave) dot += ur[c] * ir[c];
+    dot = wave_sum(dot);
+    if (lane == 0) scores[t] = sigmoid_f32(((dot + w.user_bias[u]) + w.item_bias[i]) + gb);
+  }
+}
+
+// Exact SGD on the rows a batch touched.  One wave per triple; for each of its (up to) three rows
+// lane 0 races for the row's stamp, the single winner applies w -= lr*g and clears g.
+__device__ __forceinline__ void sgd_row(float* __restrict__ wrow, float* __restrict__ grow,
+                                        float* wb, float* gb, int D, float lr, int32_t* stamp_slot,
+                                        int32_t stamp, int lane) {
+  int won = 0;
+  if (lane == 0) won = atomicExch(stamp_slot, stamp) != stamp;
+  won = __builtin_amdgcn_readfirstlane(won);
+  if (!won) return;
+  for (int c = lane; c < D; c += kWave) {
+    const float gv = grow[c];
+    wrow[c] = wrow[c] - lr * gv;
+    grow[c] = 0.f;
+  }
+  if (lane == 0) {
+    const float gv = *gb;
+    *wb = *wb - lr * gv;
+    *gb = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void mf_sgd_rows_kernel(
+    hiprec_mf_tables w, hiprec_mf_tables g, const int64_t* __restrict__ users,
+    const int64_t* __restrict__ items_a, const int64_t* __restrict__ items_b,
+    const int64_t* __restrict__ perm, int64_t batch, float lr, int32_t* user_stamp,
+    int32_t* item_stamp, int32_t stamp, hiprec_stats* stats, const Scratch* scratch) {
+  const int lane = lane_id();
+  const int D = w.dim;
+  const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  for (int64_t t = wave0; t < batch; t += n_waves) {
+    const int64_t j = perm ? perm[t] : t;
+    const int64_t u = users[j], a = items_a[j];
+    const int64_t b = items_b ? items_b[j] : a;
+    if (static_cast<uint64_t>(u) >= static_cast<uint64_t>(w.n_users) ||
+        static_cast<uint64_t>(a) >= static_cast<uint64_t>(w.n_items) ||
+        static_cast<uint64_t>(b) >= static_cast<uint64_t>(w.n_items))
+      continue;  // flagged by the grad kernel, which skipped it too
+    sgd_row(w.user_emb + u * D, g.user_emb + u * D, w.user_bias + u, g.user_bias + u, D, lr,
+            user_stamp + u, stamp, lane);
+    sgd_row(w.item_emb + a * D, g.item_emb + a * D, w.item_bias + a, g.item_bias + a, D, lr,
+            item_stamp + a, stamp, lane);
+    if (items_b)
+      sgd_row(w.item_emb + b * D, g.item_emb + b * D, w.item_bias + b, g.item_bias + b, D, lr,
+              item_stamp + b, stamp, lane);
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+      const float gv = *g.global_bias;
+      *w.global_bias = *w.global_bias - lr * gv;
+      *g.global_bias = 0.f;
+    }
+    if (scratch) finalize_partials(stats, scratch);
+  }
+}
+
+static int check_tables(const hiprec_mf_tables* w, const char* name) {
+  HIPREC_REQUIRE(w != nullptr, "%s is NULL", name);
+  HIPREC_REQUIRE(w->user_emb && w->item_emb && w->user_bias && w->item_bias && w->global_bias,
+                 "%s has a NULL tensor pointer", name);
+  HIPREC_REQUIRE(w->n_users > 0 && w->n_items > 0 && w->dim > 0,
+                 "%s has non-positive n_users/n_items/dim (%lld, %lld, %d)", name,
+                 (long long)w->n_users, (long long)w->n_items, w->dim);
+  return 0;
+}
+
+static int check_same_shape(const hiprec_mf_tables* w, const hiprec_mf_tables* g) {
+  HIPREC_REQUIRE(w->n_users == g->n_users && w->n_items == g->n_items && w->dim == g->dim,
+                 "weight and gradient tables differ in shape");
+  return 0;
+}
+
+template <typename Launch>
+static int dispatch_npl(int dim, Launch&& launch) {
+  if (dim <= 64) launch(std::integral_constant<int, 1>{});
+  else if (dim <= 128) launch(std::integral_constant<int, 2>{});
+  else if (dim <= 256) launch(std::integral_constant<int, 4>{});
+  else launch(std::integral_constant<int, 0>{});
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, "kernel launch");
+}
+
+}  // namespace hiprec
+
+using namespace hiprec;
+
+extern "C" int hiprec_mf_bpr_grad(const hiprec_mf_tables* w, const hiprec_mf_tables* g,
+                                  const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                  const int64_t* perm, int64_t batch, float inv_batch,
+                                  float reg_coef, hiprec_stats* stats, void* scratch,
+                                  size_t scratch_bytes, void* stream) {
+  if (int rc = check_tables(w, "w")) return rc;
+  if (int rc = check_tables(g, "g")) return rc;
+  if (int rc = check_same_shape(w, g)) return rc;
+  HIPREC_REQUIRE(users && pos && neg && stats && scratch, "NULL index/stats/scratch pointer");
+  HIPREC_REQUIRE(batch >= 0, "negative batch");
+  if (scratch_bytes < kScratchBytes) {
+    set_error("scratch too small: %zu < %zu", scratch_bytes, kScratchBytes);
+    return HIPREC_E_SCRATCH;
+  }
+  const int grid = grid_for_waves(batch);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  auto* sc = static_cast<Scratch*>(scratch);
+  return dispatch_npl(w->dim, [&](auto npl) {
+    mf_bpr_grad_kernel<decltype(npl)::value><<<grid, kBlock, 0, s>>>(
+        *w, *g, users, pos, neg, perm, batch, inv_batch, reg_coef, stats, sc);
+  });
+}
+
+extern "C" int hiprec_mf_bce_grad(const hiprec_mf_tables* w, const hiprec_mf_tables* g,
+                                  const int64_t* users, const int64_t* items, const float* ratings,
+                                  const int64_t* perm, int64_t batch, float inv_batch,
+                                  float reg_coef, hiprec_stats* stats, void* scratch,
+                                  size_t scratch_bytes, void* stream) {
+  if (int rc = check_tables(w, "w")) return rc;
+  if (int rc = check_tables(g, "g")) return rc;
+  if (int rc = check_same_shape(w, g)) return rc;
+  HIPREC_REQUIRE(users && items && ratings && stats && scratch,
+                 "NULL index/ratings/stats/scratch pointer");
+  HIPREC_REQUIRE(batch >= 0, "negative batch");
+  if (scratch_bytes < kScratchBytes) {
+    set_error("scratch too small: %zu < %zu", scratch_bytes, kScratchBytes);
+    return HIPREC_E_SCRATCH;
+  }
+  const int grid = grid_for_waves(batch);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  auto* sc = static_cast<Scratch*>(scratch);
+  return dispatch_npl(w->dim, [&](auto npl) {
+    mf_bce_grad_kernel<decltype(npl)::value><<<grid, kBlock, 0, s>>>(
+        *w, *g, users, items, ratings, perm, batch, inv_batch, reg_coef, stats, sc);
+  });
+}
+
+extern "C" int hiprec_mf_predict(const hiprec_mf_tables* w, const int64_t* users,
+                                 const int64_t* items, int64_t n, float* scores,
+                                 hiprec_stats* stats, void* stream) {
+  if (int rc = check_tables(w, "w")) return rc;
+  HIPREC_REQUIRE(n >= 0, "negative n");
+  if (n == 0) return 0;
+  HIPREC_REQUIRE(users && items && scores && stats, "NULL pointer");
+  mf_predict_kernel<<<grid_for_waves(n), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      *w, users, items, n, scores, stats);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_mf_sgd_rows(const hiprec_mf_tables* w, const hiprec_mf_tables* g,
+                                  const int64_t* users, const int64_t* items_a,
+                                  const int64_t* items_b, const int64_t* perm, int64_t batch,
+                                  double lr, int32_t* user_stamp, int32_t* item_stamp,
+                                  int32_t stamp, hiprec_stats* stats, const void* scratch,
+                                  void* stream) {
+  if (int rc = check_tables(w, "w")) return rc;
+  if (int rc = check_tables(g, "g")) return rc;
+  if (int rc = check_same_shape(w, g)) return rc;
+  HIPREC_REQUIRE(users && items_a && user_stamp && item_stamp && stats, "NULL pointer");
+  HIPREC_REQUIRE(batch >= 0, "negative batch");
+  mf_sgd_rows_kernel<<<grid_for_waves(batch), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      *w, *g, users, items_a, items_b, perm, batch, static_cast<float>(lr), user_stamp, item_stamp, stamp, stats,
+      static_cast<const Scratch*>(scratch));
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}

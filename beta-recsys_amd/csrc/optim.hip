@@ -1,0 +1,134 @@
+// Dense optimizer sweeps: torch.optim.{SGD,Adam,RMSprop}.step() as configured by
+// beta_rec/models/torch_engine.py:23-39 (only `lr` given => Adam betas (0.9, 0.999), eps 1e-8,
+// RMSprop alpha 0.99 eps 1e-8, no momentum, no weight decay, no amsgrad).
+//
+// nn.Embedding is non-sparse in the reference, so autograd produces DENSE gradients and Adam /
+// RMSprop move every element whose moments are non-zero on every step, touched by the batch or
+// not.  Parity therefore needs a sweep over the whole parameter buffer; it is fused with the next
+// step's zero_grad (g is cleared as it is consumed): 16-B vectors, grid-stride, pure HBM stream of
+// 28 B/element (Adam: read w,m,v,g + write w,m,v,g=0 -> 32 B with the clear).
+//
+// The arithmetic follows torch/optim/adam.py::_single_tensor_adam and rmsprop.py op by op in fp32;
+// step-dependent scalars (bias corrections) are derived on the device from hiprec_stats so that a
+// captured hipGraph of steps stays replayable.
+#include "common.hpp"
+
+namespace hiprec {
+
+// Scalars exactly as the reference's python doubles become fp32 inside the ATen ops:
+// (float)lr, (float)beta2, (float)(1 - beta1), (float)(1 - beta2), (float)eps.
+struct OptScalars {
+  double lr_d;
+  float lr, beta2, omb1, omb2, eps;
+};
+
+template <int KIND>
+__device__ __forceinline__ void opt_update(float& w, float& g, float& m, float& v,
+                                           const OptScalars s, float step_size, float bc2_sqrt) {
+  if constexpr (KIND == HIPREC_OPT_SGD) {
+    w = w - s.lr * g;  // param.add_(grad, alpha=-lr)
+  } else if constexpr (KIND == HIPREC_OPT_ADAM) {
+    m = m + s.omb1 * (g - m);                       // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * s.beta2 + (s.omb2 * g) * g;               // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+    const float denom = sqrtf(v) / bc2_sqrt + s.eps;  // (sqrt(v)/sqrt(bc2)).add_(eps)
+    w = w + (-step_size * m) / denom;                 // param.addcdiv_(m, denom, value=-step_size)
+  } else {
+    v = v * s.beta2 + (s.omb2 * g) * g;               // square_avg.mul_(alpha).addcmul_(g,g,1-alpha)
+    const float avg = sqrtf(v) + s.eps;               // square_avg.sqrt().add_(eps)
+    w = w + (-s.lr * g) / avg;                        // param.addcdiv_(grad, avg, value=-lr)
+  }
+  g = 0.f;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void opt_dense_kernel(float* __restrict__ w,
+                                                           float* __restrict__ g,
+                                                           float* __restrict__ m,
+                                                           float* __restrict__ v, int64_t n,
+                                                           OptScalars s, hiprec_stats* stats,
+                                                           const Scratch* scratch) {
+  float step_size = s.lr, bc2_sqrt = 1.f;
+  if constexpr (KIND == HIPREC_OPT_ADAM) {
+    // bias_correction1 = 1 - beta1**t ; step_size = lr / bc1 ; bc2_sqrt = sqrt(1 - beta2**t)
+    // (python doubles in torch, then rounded to fp32 when they enter the tensor ops)
+    const double bc1 = 1.0 - stats->beta1_pow;
+    const double bc2 = 1.0 - stats->beta2_pow;
+    step_size = static_cast<float>(s.lr_d / bc1);
+    bc2_sqrt = static_cast<float>(sqrt(bc2));
+  }
+  const int64_t tid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  const int64_t n4 = n >> 2;
+  float4* w4 = reinterpret_cast<float4*>(w);
+  float4* g4 = reinterpret_cast<float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  for (int64_t i = tid; i < n4; i += stride) {
+    float4 wv = w4[i], gv = g4[i];
+    float4 mv = make_float4(0, 0, 0, 0), vv = make_float4(0, 0, 0, 0);
+    if constexpr (KIND == HIPREC_OPT_ADAM) mv = m4[i];
+    if constexpr (KIND != HIPREC_OPT_SGD) vv = v4[i];
+    opt_update<KIND>(wv.x, gv.x, mv.x, vv.x, s, step_size, bc2_sqrt);
+    opt_update<KIND>(wv.y, gv.y, mv.y, vv.y, s, step_size, bc2_sqrt);
+    opt_update<KIND>(wv.z, gv.z, mv.z, vv.z, s, step_size, bc2_sqrt);
+    opt_update<KIND>(wv.w, gv.w, mv.w, vv.w, s, step_size, bc2_sqrt);
+    w4[i] = wv;
+    g4[i] = gv;
+    if constexpr (KIND == HIPREC_OPT_ADAM) m4[i] = mv;
+    if constexpr (KIND != HIPREC_OPT_SGD) v4[i] = vv;
+  }
+  for (int64_t i = (n4 << 2) + tid; i < n; i += stride) {  // scalar tail (< 4 elements)
+    float wv = w[i], gv = g[i], mv = 0.f, vv = 0.f;
+    if constexpr (KIND == HIPREC_OPT_ADAM) mv = m[i];
+    if constexpr (KIND != HIPREC_OPT_SGD) vv = v[i];
+    opt_update<KIND>(wv, gv, mv, vv, s, step_size, bc2_sqrt);
+    w[i] = wv;
+    g[i] = gv;
+    if constexpr (KIND == HIPREC_OPT_ADAM) m[i] = mv;
+    if constexpr (KIND != HIPREC_OPT_SGD) v[i] = vv;
+  }
+  if (blockIdx.x == 0 && scratch) finalize_partials(stats, scratch);
+}
+
+}  // namespace hiprec
+
+using namespace hiprec;
+
+extern "C" int hiprec_opt_dense_step(int kind, float* w, float* g, float* m, float* v, int64_t n,
+                                     double lr, double beta1, double beta2, double eps,
+                                     hiprec_stats* stats, const void* scratch, void* stream) {
+  HIPREC_REQUIRE(w && g && stats, "NULL w/g/stats");
+  HIPREC_REQUIRE(n >= 0, "negative n");
+  HIPREC_REQUIRE((reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(g) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(m) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(v) & 15) == 0,
+                 "flat buffers must be 16-byte aligned");
+  const OptScalars s{lr,
+                     static_cast<float>(lr),
+                     static_cast<float>(beta2),
+                     static_cast<float>(1.0 - beta1),
+                     static_cast<float>(1.0 - beta2),
+                     static_cast<float>(eps)};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int grid = grid_for_threads((n + 3) / 4);
+  const auto* sc = static_cast<const Scratch*>(scratch);
+  switch (kind) {
+    case HIPREC_OPT_SGD:
+      opt_dense_kernel<HIPREC_OPT_SGD><<<grid, kBlock, 0, st>>>(w, g, m, v, n, s, stats, sc);
+      break;
+    case HIPREC_OPT_ADAM:
+      HIPREC_REQUIRE(m && v, "adam needs exp_avg / exp_avg_sq buffers");
+      opt_dense_kernel<HIPREC_OPT_ADAM><<<grid, kBlock, 0, st>>>(w, g, m, v, n, s, stats, sc);
+      break;
+    case HIPREC_OPT_RMSPROP:
+      HIPREC_REQUIRE(v, "rmsprop needs a square_avg buffer");
+      opt_dense_kernel<HIPREC_OPT_RMSPROP><<<grid, kBlock, 0, st>>>(w, g, m, v, n, s, stats, sc);
+      break;
+    default:
+      set_error("unknown optimizer kind %d", kind);
+      return HIPREC_E_UNSUPPORTED;
+  }
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,169 @@
+// Library plumbing: error strings, device stats helpers, bit-exact row gather and the
+// epoch-level driver that enqueues a whole MFEngine.train_an_epoch (beta_rec/models/mf.py:121-139)
+// without returning to the host between batches.
+#include <cstring>
+
+#include "common.hpp"
+
+namespace hiprec {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  set_error("HIP error %d (%s) in %s", static_cast<int>(e), hipGetErrorString(e), what);
+  return static_cast<int>(e);
+}
+
+__global__ void stats_reset_kernel(hiprec_stats* s, double b1, double b2) {
+  s->loss = 0.f;
+  s->reg = 0.f;
+  s->loss_sum = 0.0;
+  s->reg_sum = 0.0;
+  s->step = 0;
+  s->beta1 = b1;
+  s->beta2 = b2;
+  s->beta1_pow = 1.0;
+  s->beta2_pow = 1.0;
+  s->status = 0u;
+  s->_pad = 0u;
+}
+
+__global__ void stats_begin_epoch_kernel(hiprec_stats* s) {
+  s->loss_sum = 0.0;
+  s->reg_sum = 0.0;
+}
+
+__global__ void stats_advance_kernel(hiprec_stats* s) { advance_step(s); }
+
+__global__ __launch_bounds__(kBlock) void finalize_kernel(hiprec_stats* s, const Scratch* sc) {
+  finalize_partials(s, sc);
+}
+
+// out[k, :] = table[idx[k], :] — a pure copy, hence bit-exact.  VEC floats per thread.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __restrict__ table,
+                                                             int64_t n_rows, int dim,
+                                                             const int64_t* __restrict__ idx,
+                                                             int64_t n, float* __restrict__ out,
+                                                             hiprec_stats* stats) {
+  const int per_row = dim / VEC;
+  const int64_t total = n * per_row;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < total;
+       e += stride) {
+    const int64_t k = e / per_row;
+    const int c = static_cast<int>(e - k * per_row);
+    const int64_t r = idx[k];
+    if (static_cast<uint64_t>(r) >= static_cast<uint64_t>(n_rows)) {
+      if (c == 0) atomicOr(&stats->status, HIPREC_STATUS_ROW_OOB);
+      continue;
+    }
+    if constexpr (VEC == 4) {
+      reinterpret_cast<float4*>(out)[e] =
+          reinterpret_cast<const float4*>(table + r * dim)[c];
+    } else {
+      out[e] = table[r * dim + c];
+    }
+  }
+}
+
+}  // namespace hiprec
+
+using namespace hiprec;
+
+extern "C" int hiprec_version(void) { return HIPREC_VERSION; }
+extern "C" const char* hiprec_last_error(void) { return g_err; }
+extern "C" size_t hiprec_stats_bytes(void) { return sizeof(hiprec_stats); }
+extern "C" size_t hiprec_scratch_bytes(int64_t) { return kScratchBytes; }
+
+extern "C" int hiprec_stats_reset(hiprec_stats* stats, double beta1, double beta2, void* stream) {
+  HIPREC_REQUIRE(stats, "NULL stats");
+  stats_reset_kernel<<<1, 1, 0, static_cast<hipStream_t>(stream)>>>(stats, beta1, beta2);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_stats_begin_epoch(hiprec_stats* stats, void* stream) {
+  HIPREC_REQUIRE(stats, "NULL stats");
+  stats_begin_epoch_kernel<<<1, 1, 0, static_cast<hipStream_t>(stream)>>>(stats);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_stats_advance_step(hiprec_stats* stats, void* stream) {
+  HIPREC_REQUIRE(stats, "NULL stats");
+  stats_advance_kernel<<<1, 1, 0, static_cast<hipStream_t>(stream)>>>(stats);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_finalize_stats(hiprec_stats* stats, const void* scratch, void* stream) {
+  HIPREC_REQUIRE(stats && scratch, "NULL stats/scratch");
+  finalize_kernel<<<1, kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      stats, static_cast<const Scratch*>(scratch));
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_gather_rows(const float* table, int64_t n_rows, int32_t dim,
+                                  const int64_t* idx, int64_t n, float* out, hiprec_stats* stats,
+                                  void* stream) {
+  HIPREC_REQUIRE(n >= 0 && n_rows > 0 && dim > 0, "bad sizes");
+  if (n == 0) return 0;
+  HIPREC_REQUIRE(table && idx && out && stats, "NULL pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec4 = (dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(table) & 15) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  if (vec4) {
+    gather_rows_kernel<4><<<grid_for_threads(n * (dim / 4)), kBlock, 0, st>>>(table, n_rows, dim,
+                                                                             idx, n, out, stats);
+  } else {
+    gather_rows_kernel<1><<<grid_for_threads(n * dim), kBlock, 0, st>>>(table, n_rows, dim, idx,
+                                                                       n, out, stats);
+  }
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_mf_bpr_epoch(const hiprec_mf_tables* w, const hiprec_mf_tables* g,
+                                   const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                   const int64_t* perm, int64_t n_triples, int64_t batch,
+                                   float reg_coef, int kind,
+                                   double lr, double beta1, double beta2, double eps,
+                                   float* flat_w, float* flat_g, float* flat_m, float* flat_v,
+                                   int64_t n_flat, int32_t* user_stamp, int32_t* item_stamp,
+                                   int32_t first_stamp, hiprec_stats* stats, void* scratch,
+                                   size_t scratch_bytes, void* stream) {
+  HIPREC_REQUIRE(n_triples >= 0 && batch > 0, "bad n_triples/batch");
+  const bool rows_sgd = (kind == HIPREC_OPT_SGD) && user_stamp && item_stamp;
+  if (!rows_sgd) HIPREC_REQUIRE(flat_w && flat_g && n_flat > 0, "dense optimizer needs flat buffers");
+  if (int rc = hiprec_stats_begin_epoch(stats, stream)) return rc;
+  int32_t stamp = first_stamp;
+  for (int64_t off = 0; off < n_triples; off += batch, ++stamp) {
+    const int64_t b = (n_triples - off < batch) ? (n_triples - off) : batch;  // drop_last=False
+    const float inv_b = 1.0f / static_cast<float>(b);
+    const int64_t* pm = perm ? perm + off : nullptr;
+    const int64_t* uu = perm ? users : users + off;
+    const int64_t* pp = perm ? pos : pos + off;
+    const int64_t* nn = perm ? neg : neg + off;
+    if (int rc = hiprec_mf_bpr_grad(w, g, uu, pp, nn, pm, b, inv_b, reg_coef, stats, scratch,
+                                    scratch_bytes, stream))
+      return rc;
+    int rc;
+    if (rows_sgd)
+      rc = hiprec_mf_sgd_rows(w, g, uu, pp, nn, pm, b, lr, user_stamp, item_stamp, stamp, stats,
+                              scratch, stream);
+    else
+      rc = hiprec_opt_dense_step(kind, flat_w, flat_g, flat_m, flat_v, n_flat, lr, beta1, beta2,
+                                 eps, stats, scratch, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}

@@ -1,0 +1,560 @@
+"""Drop-in ``MF`` / ``MFEngine`` for beta_rec/models/mf.py, backed by libhiprec.so (HIP, gfx950).
+
+Interface parity with the reference (file:line = /root/reference/beta_rec/...):
+
+* ``MF(config)``            models/mf.py:12-30  — same config keys, same state_dict keys / shapes,
+  same initial weights for the same torch seed (the RNG is consumed in the same order).
+* ``MF.forward / predict``  models/mf.py:32-70
+* ``MFEngine(config)``      models/mf.py:76-90  — incl. quirk Q1 (``reg`` read from the TOP-level
+  config, hence 0.0 for every shipped config).
+* ``train_single_batch``    models/mf.py:92-119 — returns ``(loss, regularizer)`` python floats.
+* ``train_an_epoch``        models/mf.py:121-139 — same print / ``writer.add_scalar`` tags.
+
+What differs is where the arithmetic runs: the gather -> score -> BPR/BCE gradient -> scatter ->
+optimizer pipeline is ``csrc/mf.hip`` + ``csrc/optim.hip``; PyTorch only owns the memory.  All five
+parameter tensors are views into ONE flat fp32 buffer so that the dense optimizers sweep a single
+contiguous range, and so are the gradient accumulator and the optimizer moments.
+"""
+import ctypes
+import time
+from functools import wraps
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import Parameter
+
+from . import _lib
+from .torch_engine import ModelEngine
+
+
+def timeit(method):
+    """Same console contract as beta_rec/utils/common_util.py:215-245."""
+
+    @wraps(method)
+    def wrapper(*args, **kw):
+        ts = time.time()
+        result = method(*args, **kw)
+        te = time.time()
+        if "log_time" in kw:
+            name = kw.get("log_name", method.__name__.upper())
+            kw["log_time"][name] = int((te - ts) * 1000)
+        else:
+            print("Execute [{}] method costing {:2.2f} ms".format(method.__name__, (te - ts) * 1000))
+        return result
+
+    return wrapper
+
+
+class _Table(nn.Module):
+    """nn.Embedding look-alike whose ``weight`` is a view into the model's flat buffer."""
+
+    def __init__(self, weight_view):
+        super().__init__()
+        self.weight = Parameter(weight_view, requires_grad=False)
+
+    @property
+    def num_embeddings(self):
+        return self.weight.shape[0]
+
+    @property
+    def embedding_dim(self):
+        return self.weight.shape[1]
+
+    def forward(self, idx):
+        """Row gather (bit-exact copy) through hiprec_gather_rows."""
+        return gather_rows(self.weight, idx)
+
+    def extra_repr(self):
+        return f"{self.num_embeddings}, {self.embedding_dim}"
+
+
+def _new_stats(device, beta1=0.9, beta2=0.999):
+    lib = _lib.load()
+    stats = torch.zeros(ctypes.sizeof(_lib.Stats), dtype=torch.uint8, device=device)
+    _lib.check(lib.hiprec_stats_reset(_lib.ptr(stats), beta1, beta2, _lib.stream_ptr(device)))
+    return stats
+
+
+def read_stats(stats_tensor):
+    """Copy the device hiprec_stats block to the host (synchronises) and decode it."""
+    raw = stats_tensor.cpu().numpy().tobytes()
+    return _lib.Stats.from_buffer_copy(raw)
+
+
+def raise_on_status(status):
+    """Turn sticky device status bits into the IndexError PyTorch would have raised."""
+    if status:
+        which = []
+        if status & _lib.STATUS_USER_OOB:
+            which.append("user")
+        if status & _lib.STATUS_ITEM_OOB:
+            which.append("item")
+        if status & _lib.STATUS_ROW_OOB:
+            which.append("row")
+        raise IndexError("index out of range in self (" + "/".join(which) + " index)")
+
+
+_gather_stats = {}
+
+
+def gather_rows(table, idx):
+    """out[k] = table[idx[k]] on the GPU, bit-exact (nn.Embedding.forward)."""
+    if table.device.type != "cuda":
+        raise RuntimeError("gather_rows: HIP path only (no CPU fallback)")
+    lib = _lib.load()
+    dev = table.device
+    idx = torch.as_tensor(idx, dtype=torch.int64, device=dev).contiguous()
+    flat_idx = idx.reshape(-1)
+    out = torch.empty((flat_idx.numel(), table.shape[1]), dtype=torch.float32, device=dev)
+    key = (dev.type, dev.index)
+    if key not in _gather_stats:
+        _gather_stats[key] = _new_stats(dev)
+    stats = _gather_stats[key]
+    _lib.check(
+        lib.hiprec_gather_rows(
+            _lib.ptr(table), table.shape[0], table.shape[1], _lib.ptr(flat_idx),
+            flat_idx.numel(), _lib.ptr(out), _lib.ptr(stats), _lib.stream_ptr(dev),
+        )
+    )
+    return out.reshape(*idx.shape, table.shape[1])
+
+
+class MF(nn.Module):
+    """Matrix factorisation model, parameter-compatible with beta_rec/models/mf.py:9-70."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.device = self.config["device_str"]
+        self.stddev = self.config["stddev"] if "stddev" in self.config else 0.1
+        self.n_users = int(self.config["n_users"])
+        self.n_items = int(self.config["n_items"])
+        self.emb_dim = int(self.config["emb_dim"])
+        U, I, D = self.n_users, self.n_items, self.emb_dim
+        self._sizes = (U * D, I * D, U, I, 1)
+        flat = torch.empty(sum(self._sizes), dtype=torch.float32)
+        ue, ie, ub, ib, gb = self._views(flat)
+        # Consume the torch RNG exactly like mf.py:21-30: four nn.Embedding constructors draw
+        # N(0,1) for their weights, biases are zero-filled, then the two tables are re-drawn.
+        ue.normal_(0, 1)
+        ie.normal_(0, 1)
+        ub.normal_(0, 1)
+        ib.normal_(0, 1)
+        ub.fill_(0.0)
+        ib.fill_(0.0)
+        gb.fill_(0.0)
+        ue.normal_(0, self.stddev)
+        ie.normal_(0, self.stddev)
+        self._flat = flat
+        self.user_emb = _Table(ue)
+        self.item_emb = _Table(ie)
+        self.user_bias = _Table(ub)
+        self.item_bias = _Table(ib)
+        self.global_bias = Parameter(gb, requires_grad=False)
+        self._stats = None
+
+    # ---- flat-buffer plumbing -------------------------------------------------------------
+    def _views(self, flat):
+        U, I, D = self.n_users, self.n_items, self.emb_dim
+        o = np.cumsum((0,) + self._sizes)
+        return (
+            flat[o[0]:o[1]].view(U, D),
+            flat[o[1]:o[2]].view(I, D),
+            flat[o[2]:o[3]].view(U, 1),
+            flat[o[3]:o[4]].view(I, 1),
+            flat[o[4]:o[5]],
+        )
+
+    def _rebind(self, flat):
+        ue, ie, ub, ib, gb = self._views(flat)
+        self._flat = flat
+        self.user_emb.weight.data = ue
+        self.item_emb.weight.data = ie
+        self.user_bias.weight.data = ub
+        self.item_bias.weight.data = ib
+        self.global_bias.data = gb
+
+    def _apply(self, fn, recurse=True):
+        """``.to() / .cuda() / .float()``: move the flat buffer once and re-point the views."""
+        new_flat = fn(self._flat)
+        if new_flat.dtype != torch.float32:
+            raise TypeError("hiprec MF keeps fp32 parameters (the reference trains in fp32)")
+        if new_flat is not self._flat:
+            self._rebind(new_flat.contiguous())
+            self._stats = None
+        return self
+
+    @property
+    def flat(self):
+        """The flat fp32 buffer [user_emb | item_emb | user_bias | item_bias | global_bias]."""
+        return self._flat
+
+    def tables(self, flat=None):
+        """hiprec_mf_tables over this model's layout (``flat`` defaults to the parameters)."""
+        ue, ie, ub, ib, gb = self._views(self._flat if flat is None else flat)
+        return _lib.MfTables(
+            ue.data_ptr(), ie.data_ptr(), ub.data_ptr(), ib.data_ptr(), gb.data_ptr(),
+            self.n_users, self.n_items, self.emb_dim, 0,
+        )
+
+    def _require_hip(self):
+        if self._flat.device.type != "cuda":
+            raise RuntimeError(
+                "hiprec MF computes on an MI355X through libhiprec.so only; parameters are on "
+                f"{self._flat.device} and there is deliberately no CPU fallback"
+            )
+        if self._stats is None:
+            self._stats = _new_stats(self._flat.device)
+        return _lib.load()
+
+    # ---- reference API ---------------------------------------------------------------------
+    def forward(self, batch_data):
+        """mf.py:32-55 without autograd: ``(sigmoid scores, regularizer)``."""
+        users, items = batch_data
+        dev = self._flat.device
+        users = torch.as_tensor(users, dtype=torch.int64, device=dev).contiguous()
+        items = torch.as_tensor(items, dtype=torch.int64, device=dev).contiguous()
+        scores = self._scores(users, items)
+        u, i = self.user_emb(users), self.item_emb(items)
+        bu, bi = self.user_bias(users), self.item_bias(items)
+        regularizer = ((u ** 2).sum() + (i ** 2).sum() + (bu ** 2).sum() + (bi ** 2).sum()) / max(
+            users.numel(), 1
+        )
+        return scores, regularizer
+
+    def _scores(self, users, items):
+        lib = self._require_hip()
+        dev = self._flat.device
+        n = users.numel()
+        if items.numel() != n:
+            raise ValueError("users and items must have the same length")
+        scores = torch.empty(n, dtype=torch.float32, device=dev)
+        tabs = self.tables()
+        _lib.check(
+            lib.hiprec_mf_predict(
+                ctypes.byref(tabs), _lib.ptr(users), _lib.ptr(items), n, _lib.ptr(scores),
+                _lib.ptr(self._stats), _lib.stream_ptr(dev),
+            )
+        )
+        return scores
+
+    def predict(self, users, items):
+        """mf.py:57-70: numpy / list ids in, score tensor on the device out."""
+        dev = self._flat.device
+        users_t = torch.as_tensor(np.asarray(users), dtype=torch.int64).to(dev).contiguous()
+        items_t = torch.as_tensor(np.asarray(items), dtype=torch.int64).to(dev).contiguous()
+        scores = self._scores(users_t.reshape(-1), items_t.reshape(-1))
+        st = read_stats(self._stats)
+        if st.status:
+            _lib.check(_lib.load().hiprec_stats_reset(_lib.ptr(self._stats), 0.9, 0.999,
+                                                      _lib.stream_ptr(dev)))
+            raise_on_status(st.status)
+        return scores
+
+
+class DeviceTripleBatcher:
+    """Device-resident replacement for ``DataLoader(PairwiseNegativeDataset, shuffle=True)``.
+
+    beta_rec/data/base_data.py:247-253 builds three int64 tensors and lets the DataLoader index them
+    element by element (the reference's end-to-end bottleneck).  Here the arrays
+    stay in HBM, a fresh permutation is drawn per epoch and the grad kernel reads its batch through
+    ``perm[]`` — no collate.  Iterating it yields ``(users, pos, neg)`` batches like the DataLoader.
+    """
+
+    def __init__(self, users, pos_items, neg_items, batch_size, shuffle=True, generator=None):
+        self.user_tensor = torch.as_tensor(users, dtype=torch.int64).contiguous()
+        dev = self.user_tensor.device
+        self.pos_item_tensor = torch.as_tensor(pos_items, dtype=torch.int64, device=dev).contiguous()
+        self.neg_item_tensor = torch.as_tensor(neg_items, dtype=torch.int64, device=dev).contiguous()
+        if not (len(self.user_tensor) == len(self.pos_item_tensor) == len(self.neg_item_tensor)):
+            raise ValueError("users / pos_items / neg_items differ in length")
+        self.batch_size = int(batch_size)
+        self.shuffle = shuffle
+        self.generator = generator
+
+    def __len__(self):
+        n = len(self.user_tensor)
+        return (n + self.batch_size - 1) // self.batch_size
+
+    def permutation(self):
+        """One epoch's visiting order (int64, on the triples' device); None = sequential."""
+        if not self.shuffle:
+            return None
+        n = len(self.user_tensor)
+        dev = self.user_tensor.device
+        if self.generator is not None:
+            return torch.randperm(n, generator=self.generator).to(dev)
+        return torch.randperm(n, device=dev)
+
+    def __iter__(self):
+        perm = self.permutation()
+        n = len(self.user_tensor)
+        for off in range(0, n, self.batch_size):
+            if perm is None:
+                sl = slice(off, min(off + self.batch_size, n))
+                yield self.user_tensor[sl], self.pos_item_tensor[sl], self.neg_item_tensor[sl]
+            else:
+                idx = perm[off:off + self.batch_size]
+                yield self.user_tensor[idx], self.pos_item_tensor[idx], self.neg_item_tensor[idx]
+
+
+def _print_config_table(config, tag):
+    print("-" * 80)
+    print(tag)
+    for k, v in config.items():
+        print(f"  {k:<16} {v}")
+    print("-" * 80)
+
+
+class MFEngine(ModelEngine):
+    """Engine with the surface of beta_rec/models/mf.py:73-139, computing through libhiprec."""
+
+    # SGD keeps every untouched row bit-identical, so it may either sweep the whole flat buffer
+    # (cheap while it is cache-resident) or visit only the rows the batch touched.
+    ROWS_SGD_MIN_BYTES = 64 << 20
+
+    def __init__(self, config):
+        self.config = config
+        _print_config_table(config["model"], tag="MF model config")
+        self.model = MF(config["model"])
+        # Quirk Q1 (mf.py:81-83): the key is looked up in the TOP-level config, so this is 0.0 for
+        # every shipped config even when config["model"]["reg"] is set.  Reproduced on purpose.
+        self.reg = config["model"]["reg"] if "reg" in config else 0.0
+        self.batch_size = config["model"]["batch_size"]
+        super(MFEngine, self).__init__(config)
+        self.model.to(self.device)
+        self.loss = self.config["model"]["loss"] if "loss" in self.config["model"] else "bpr"
+        print(f"using {self.loss} loss...")
+        self._buffers_ready = False
+        self._stamp = 1
+
+    # ---- buffers ---------------------------------------------------------------------------
+    def _setup(self):
+        lib = self.require_hip()
+        if self._buffers_ready and self._g_flat.device == self.model.flat.device:
+            return lib
+        flat = self.model.flat
+        dev = flat.device
+        self._g_flat = torch.zeros_like(flat)
+        self.optimizer.allocate_state(flat)
+        self._scratch = torch.zeros(lib.hiprec_scratch_bytes(0), dtype=torch.uint8, device=dev)
+        self._stats = _new_stats(dev, self.optimizer.beta1 or 0.9, self.optimizer.beta2 or 0.999)
+        mode = self.config["model"].get("sgd_mode", "auto")
+        rows = self.optimizer.name == "sgd" and (
+            mode == "rows" or (mode == "auto" and flat.numel() * 4 >= self.ROWS_SGD_MIN_BYTES)
+        )
+        self._rows_sgd = rows
+        if rows:
+            self._user_stamp = torch.zeros(self.model.n_users, dtype=torch.int32, device=dev)
+            self._item_stamp = torch.zeros(self.model.n_items, dtype=torch.int32, device=dev)
+        else:
+            self._user_stamp = self._item_stamp = None
+        self._buffers_ready = True
+        return lib
+
+    def _take_stamps(self, n):
+        if self._stamp + n >= 2**31 - 1:
+            self._user_stamp.zero_()
+            self._item_stamp.zero_()
+            self._stamp = 1
+        first = self._stamp
+        self._stamp += n
+        return first
+
+    def _as_index(self, t):
+        return torch.as_tensor(t, device=self.device).to(torch.int64).contiguous()
+
+    # ---- one step ---------------------------------------------------------------------------
+    def _prepare_batch(self, batch_data):
+        """Validate the loss kind and the batch, move indices to the device (int64, contiguous)."""
+        if self.loss == "bpr":
+            users, a_items, third = (self._as_index(x) for x in batch_data)
+        elif self.loss == "bce":
+            users, a_items = (self._as_index(x) for x in batch_data[:2])
+            third = torch.as_tensor(batch_data[2], device=self.device).to(torch.float32).contiguous()
+        else:
+            raise RuntimeError(
+                f"Unsupported loss type {self.loss}, try other options: 'bpr' or 'bce'"
+            )
+        B = users.numel()
+        if not (a_items.numel() == B and third.numel() == B):
+            raise ValueError("batch tensors differ in length")
+        if B == 0:
+            raise ValueError("empty batch")
+        if B == 1:
+            # Quirk Q4 (mf.py:44): .squeeze() drops the batch dim of a single-sample batch and
+            # torch.sum(dim=1) raises; the reference cannot train on a batch of one.
+            raise IndexError("Dimension out of range (expected to be in range of [-1, 0], but got 1)")
+        return users, a_items, third
+
+    def _enqueue_grad(self, lib, users, a_items, third):
+        """zero_grad + forward + backward: dense gradient of the batch into self._g_flat."""
+        m = self.model
+        st = _lib.stream_ptr(m.flat.device)
+        w, g = m.tables(), m.tables(self._g_flat)
+        B = users.numel()
+        fn = lib.hiprec_mf_bpr_grad if self.loss == "bpr" else lib.hiprec_mf_bce_grad
+        _lib.check(fn(
+            ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(a_items), _lib.ptr(third),
+            None, B, 1.0 / B, float(self.reg), _lib.ptr(self._stats), _lib.ptr(self._scratch),
+            self._scratch.numel(), st))
+
+    def _enqueue_step(self, batch_data):
+        """Enqueue grad + optimizer kernels for one batch; returns nothing and does not sync."""
+        users, a_items, third = self._prepare_batch(batch_data)
+        lib = self._setup()
+        m = self.model
+        st = _lib.stream_ptr(m.flat.device)
+        self._enqueue_grad(lib, users, a_items, third)
+        opt = self.optimizer
+        if self._rows_sgd:
+            w, g = m.tables(), m.tables(self._g_flat)
+            b_items = third if self.loss == "bpr" else None
+            _lib.check(lib.hiprec_mf_sgd_rows(
+                ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(a_items),
+                _lib.ptr(b_items), None, users.numel(), opt.lr, _lib.ptr(self._user_stamp),
+                _lib.ptr(self._item_stamp), self._take_stamps(1), _lib.ptr(self._stats),
+                _lib.ptr(self._scratch), st))
+        else:
+            _lib.check(lib.hiprec_opt_dense_step(
+                opt.kind, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),
+                _lib.ptr(opt.exp_avg_sq), m.flat.numel(), opt.lr, opt.beta1, opt.beta2, opt.eps,
+                _lib.ptr(self._stats), _lib.ptr(self._scratch), st))
+
+    def backward_only(self, batch_data):
+        """zero_grad + forward + backward WITHOUT the optimizer step (what autograd leaves in
+        ``p.grad`` in the reference).  Returns ``(loss, regularizer, grads)`` with ``grads`` a dict
+        keyed like ``state_dict``; the accumulator is cleared again afterwards.  Note that like
+        every grad call it advances the optimizer clock by one."""
+        users, a_items, third = self._prepare_batch(batch_data)
+        lib = self._setup()
+        self._enqueue_grad(lib, users, a_items, third)
+        _lib.check(lib.hiprec_finalize_stats(
+            _lib.ptr(self._stats), _lib.ptr(self._scratch), _lib.stream_ptr(self.model.flat.device)))
+        st = self._sync_stats()
+        ue, ie, ub, ib, gb = (v.clone() for v in self.model._views(self._g_flat))
+        self._g_flat.zero_()
+        grads = {"global_bias": gb, "user_emb.weight": ue, "item_emb.weight": ie,
+                 "user_bias.weight": ub, "item_bias.weight": ib}
+        return st.loss, st.reg, grads
+
+    def load_optimizer_state(self, step, exp_avg=None, exp_avg_sq=None):
+        """Restore the optimizer clock and moments (the reference never persists them —
+        torch_engine.py:70-73 — so this is an extension used for resume and for tests).
+        ``exp_avg`` / ``exp_avg_sq`` are dicts keyed like ``state_dict`` (or None for zeros)."""
+        lib = self._setup()
+        opt, m = self.optimizer, self.model
+        dev = m.flat.device
+        _lib.check(lib.hiprec_stats_reset(
+            _lib.ptr(self._stats), opt.beta1 or 0.9, opt.beta2 or 0.999, _lib.stream_ptr(dev)))
+        for _ in range(int(step)):
+            _lib.check(lib.hiprec_stats_advance_step(_lib.ptr(self._stats), _lib.stream_ptr(dev)))
+        for buf, src in ((opt.exp_avg, exp_avg), (opt.exp_avg_sq, exp_avg_sq)):
+            if buf is None:
+                continue
+            if src is None:
+                buf.zero_()
+                continue
+            ue, ie, ub, ib, gb = m._views(buf)
+            for view, key in ((gb, "global_bias"), (ue, "user_emb.weight"), (ie, "item_emb.weight"),
+                              (ub, "user_bias.weight"), (ib, "item_bias.weight")):
+                view.copy_(torch.as_tensor(src[key], dtype=torch.float32).reshape(view.shape))
+
+    def optimizer_state(self):
+        """(step, exp_avg dict | None, exp_avg_sq dict | None) — counterpart of the loader above."""
+        self._setup()
+        st = read_stats(self._stats)
+        out = []
+        for buf in (self.optimizer.exp_avg, self.optimizer.exp_avg_sq):
+            if buf is None:
+                out.append(None)
+                continue
+            ue, ie, ub, ib, gb = self.model._views(buf)
+            out.append({"global_bias": gb.clone(), "user_emb.weight": ue.clone(),
+                        "item_emb.weight": ie.clone(), "user_bias.weight": ub.clone(),
+                        "item_bias.weight": ib.clone()})
+        return st.step, out[0], out[1]
+
+    def _sync_stats(self):
+        st = read_stats(self._stats)
+        if st.status:
+            # clear the sticky bits, keep the optimizer clock
+            raw = self._stats.cpu()
+            off = _lib.Stats.status.offset
+            raw[off:off + 4] = 0
+            self._stats.copy_(raw)
+            raise_on_status(st.status)
+        return st
+
+    def train_single_batch(self, batch_data):
+        """mf.py:92-119: one optimisation step; returns ``(loss, regularizer)`` floats."""
+        assert hasattr(self, "model"), "Please specify the exact model !"
+        self._enqueue_step(batch_data)
+        st = self._sync_stats()
+        return st.loss, st.reg
+
+    # ---- one epoch --------------------------------------------------------------------------
+    def _resident_triples(self, train_loader):
+        """(users, pos, neg, perm) when the loader's data is resident and can be batched on device."""
+        if isinstance(train_loader, DeviceTripleBatcher):
+            ds, perm = train_loader, train_loader.permutation()
+        else:
+            ds = getattr(train_loader, "dataset", None)
+            if ds is None or not all(
+                hasattr(ds, a) for a in ("user_tensor", "pos_item_tensor", "neg_item_tensor")
+            ):
+                return None
+            if getattr(train_loader, "drop_last", False) or train_loader.batch_sampler is None:
+                return None
+            # draw the visiting order from the loader's own sampler so that the batches are the
+            # ones DataLoader(shuffle=True) would have produced (base_data.py:253); the first draw
+            # mirrors _BaseDataLoaderIter's base-seed draw to keep the global RNG in step.
+            torch.empty((), dtype=torch.int64).random_()
+            order = list(iter(train_loader.sampler))
+            perm = torch.as_tensor(order, dtype=torch.int64)
+        dev = self.device
+        users = ds.user_tensor.to(dev, torch.int64).contiguous()
+        pos = ds.pos_item_tensor.to(dev, torch.int64).contiguous()
+        neg = ds.neg_item_tensor.to(dev, torch.int64).contiguous()
+        perm = None if perm is None else perm.to(dev).contiguous()
+        bs = train_loader.batch_size
+        return users, pos, neg, perm, int(bs)
+
+    @timeit
+    def train_an_epoch(self, train_loader, epoch_id):
+        """mf.py:121-139.  One host sync per epoch instead of two per step."""
+        assert hasattr(self, "model"), "Please specify the exact model !"
+        self.model.train()
+        lib = self._setup()
+        dev = self.model.flat.device
+        st_ptr = _lib.stream_ptr(dev)
+        resident = self._resident_triples(train_loader) if self.loss == "bpr" else None
+        if resident is not None:
+            users, pos, neg, perm, bs = resident
+            n = users.numel()
+            n_run = n - 1 if n % bs == 1 else n  # Q4: a trailing batch of one raises (below)
+            m, opt = self.model, self.optimizer
+            w, g = m.tables(), m.tables(self._g_flat)
+            n_batches = (n_run + bs - 1) // bs
+            first = self._take_stamps(n_batches) if self._rows_sgd else 0
+            _lib.check(lib.hiprec_mf_bpr_epoch(
+                ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg),
+                _lib.ptr(perm), n_run, bs, float(self.reg), opt.kind, opt.lr, opt.beta1, opt.beta2,
+                opt.eps, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),
+                _lib.ptr(opt.exp_avg_sq), m.flat.numel(), _lib.ptr(self._user_stamp),
+                _lib.ptr(self._item_stamp), first, _lib.ptr(self._stats),
+                _lib.ptr(self._scratch), self._scratch.numel(), st_ptr))
+            st = self._sync_stats()
+            if n_run != n:
+                raise IndexError(
+                    "Dimension out of range (expected to be in range of [-1, 0], but got 1)")
+        else:
+            _lib.check(lib.hiprec_stats_begin_epoch(_lib.ptr(self._stats), st_ptr))
+            for batch_data in train_loader:
+                self._enqueue_step(batch_data)
+            st = self._sync_stats()
+        loss, total_loss, regularizer = st.loss, st.loss_sum, st.reg_sum
+        print(f"[Training Epoch {epoch_id}], Loss {loss}, Regularizer {regularizer}")
+        self.writer.add_scalar("model/loss", total_loss, epoch_id)
+        self.writer.add_scalar("model/regularizer", regularizer, epoch_id)

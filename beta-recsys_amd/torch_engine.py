@@ -1,0 +1,145 @@
+"""Host-side mirror of beta_rec/models/torch_engine.py:6-121 (``ModelEngine``).
+
+Same constructor contract, attributes (``model optimizer device writer config``) and methods
+(``save_checkpoint resume_checkpoint bpr_loss bce_loss``) as the reference base class, so
+``beta_rec.core.train_engine.TrainEngine._train`` (core/train_engine.py:225-240) and
+``Recommender.load`` (core/recommender.py:46-56) keep working unchanged.  The optimizer object is a
+thin descriptor: the arithmetic of ``torch.optim.{SGD,Adam,RMSprop}.step`` runs in
+``csrc/optim.hip`` on flat state buffers owned here.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+
+class _NullWriter:
+    """Stand-in for tensorboardX.SummaryWriter when tensorboardX is not installed."""
+
+    def __init__(self, log_dir=None):
+        self.log_dir = log_dir
+        self.scalars = []
+
+    def add_scalar(self, tag, value, step=None):
+        self.scalars.append((tag, value, step))
+
+    def close(self):
+        pass
+
+
+def make_writer(log_dir):
+    """SummaryWriter(log_dir=...) as torch_engine.py:19-21, or a recording no-op."""
+    try:
+        from tensorboardX import SummaryWriter  # type: ignore
+
+        return SummaryWriter(log_dir=log_dir)
+    except Exception:  # tensorboardX is absent in this image
+        return _NullWriter(log_dir)
+
+
+class HipOptimizer:
+    """Descriptor + state of the optimizer torch_engine.py:23-39 would have built.
+
+    Only ``lr`` is configurable in the reference; everything else is the torch default:
+    Adam betas (0.9, 0.999) eps 1e-8; RMSprop alpha 0.99 eps 1e-8; SGD momentum 0.
+    State lives in flat fp32 buffers laid out like the model's flat parameter buffer.
+    """
+
+    DEFAULTS = {
+        "sgd": dict(beta1=0.0, beta2=0.0, eps=0.0),
+        "adam": dict(beta1=0.9, beta2=0.999, eps=1e-8),
+        "rmsprop": dict(beta1=0.0, beta2=0.99, eps=1e-8),  # beta2 plays alpha
+    }
+
+    def __init__(self, name, lr):
+        if name not in _lib.OPT_KINDS:
+            raise ValueError(
+                f"Unsupported optimizer {name!r}: the engine supports 'sgd', 'adam', 'rmsprop' "
+                "(beta_rec/models/torch_engine.py:23-39)"
+            )
+        self.name = name
+        self.kind = _lib.OPT_KINDS[name]
+        self.lr = float(lr)
+        d = self.DEFAULTS[name]
+        self.beta1, self.beta2, self.eps = d["beta1"], d["beta2"], d["eps"]
+        self.exp_avg = None      # Adam m           (flat, zeros)
+        self.exp_avg_sq = None   # Adam v / RMSprop square_avg
+        self.defaults = {"lr": self.lr}
+        if name == "adam":
+            self.defaults.update(betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False)
+        elif name == "rmsprop":
+            self.defaults.update(alpha=0.99, eps=1e-8, weight_decay=0, momentum=0, centered=False)
+        else:
+            self.defaults.update(momentum=0, dampening=0, weight_decay=0, nesterov=False)
+        self.param_groups = [dict(self.defaults)]
+
+    def allocate_state(self, flat_like):
+        """Zero state buffers matching the flat parameter buffer."""
+        if self.name == "adam":
+            self.exp_avg = torch.zeros_like(flat_like)
+            self.exp_avg_sq = torch.zeros_like(flat_like)
+        elif self.name == "rmsprop":
+            self.exp_avg_sq = torch.zeros_like(flat_like)
+
+    def zero_grad(self):
+        """No-op: the HIP optimizer kernels clear the gradient buffer as they consume it."""
+
+    def __repr__(self):
+        return f"HipOptimizer({self.name}, lr={self.lr})"
+
+
+class ModelEngine(object):
+    """Meta engine; subclasses must set ``self.model`` before calling ``__init__``."""
+
+    def __init__(self, config):
+        """Mirror of torch_engine.py:12-21: device, optimizer, model.to(device), writer."""
+        self.config = config
+        self.set_device()
+        self.set_optimizer()
+        self.model.to(self.device)
+        print(self.model)
+        self.writer = make_writer(config["system"]["run_dir"])
+
+    def set_optimizer(self):
+        """torch_engine.py:23-39; unknown names raise ValueError early instead of AttributeError later."""
+        self.optimizer = HipOptimizer(
+            self.config["model"]["optimizer"], self.config["model"]["lr"]
+        )
+
+    def set_device(self):
+        """torch_engine.py:41-45."""
+        self.device = torch.device(self.config["model"]["device_str"])
+        self.model.device = self.device
+        print("Setting device for torch_engine", self.device)
+
+    def require_hip(self):
+        """The compute path is HIP only; refuse to run anywhere else."""
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError(
+                f"hiprec engines run on an MI355X through libhiprec.so; device {self.device} has no "
+                "HIP path and there is deliberately no CPU fallback"
+            )
+        return _lib.load()
+
+    def save_checkpoint(self, model_dir):
+        """torch_engine.py:70-73: torch.save(model.state_dict(), path)."""
+        assert hasattr(self, "model"), "Please specify the exact model !"
+        torch.save(self.model.state_dict(), model_dir)
+
+    def resume_checkpoint(self, model_dir, model=None):
+        """torch_engine.py:76-90."""
+        assert hasattr(self, "model"), "Please specify the exact model !"
+        print("loading model from:", model_dir)
+        state_dict = torch.load(model_dir, map_location=self.device)
+        target = self.model if model is None else model
+        target.load_state_dict(state_dict)
+        target.to(self.device)
+        return target
+
+    def bpr_loss(self, pos_scores, neg_scores):
+        """torch_engine.py:92-106 on caller-supplied score tensors (utility, not the fused path)."""
+        return -torch.mean(F.logsigmoid(pos_scores - neg_scores))
+
+    def bce_loss(self, scores, ratings):
+        """torch_engine.py:108-121 on caller-supplied score tensors (utility, not the fused path)."""
+        return torch.nn.BCELoss()(scores, ratings)

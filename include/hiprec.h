@@ -1,0 +1,169 @@
+/*
+ * hiprec.h — C ABI of libhiprec.so, the MI355X (gfx950) embedding-table training hot path
+ * for beta-recsys models (MF / GMF / MLP / NeuMF / LightGCN).
+ *
+ * The reference (beta-team/beta-recsys v0.3.2) is pure Python/PyTorch and has NO FFI of its own;
+ * the boundary it offers is the duck-type of beta_rec/models/torch_engine.py:6-121 (ModelEngine).
+ * Every entry point below replaces one stretch of PyTorch ops issued by that engine family; the
+ * reference file:line each one stands in for is cited on the declaration.  INTEGRATION.md shows the
+ * ctypes stub a beta-recsys maintainer would add.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, >0 = hipError_t, <0 = HIPREC_E_*;
+ *     hiprec_last_error() returns a thread-local, human-readable message for the last failure.
+ *   - no C++ exceptions cross the ABI, no torch types in signatures: plain pointers and sizes.
+ *   - every pointer is a DEVICE pointer on the current HIP device unless the name ends in _host.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises.
+ *   - the library allocates NOTHING: tables, gradient accumulators, optimizer state, row stamps and
+ *     the scratch block are owned by the caller (PyTorch tensors in the Python host layer).
+ *   - floats are fp32, indices are int64 (torch.LongTensor, beta_rec/data/base_data.py:247-251).
+ *   - index validation: an out-of-range index never touches memory; the triple/sample is skipped
+ *     and a bit is OR-ed into the device status word (HIPREC_STATUS_*), which the host layer turns
+ *     into IndexError (PyTorch's behaviour for nn.Embedding).
+ */
+#ifndef HIPREC_H
+#define HIPREC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPREC_VERSION 100 /* 0.1.0 */
+
+/* negative library error codes */
+#define HIPREC_E_BADARG (-1)   /* null pointer, negative size, unsupported dim ... */
+#define HIPREC_E_SCRATCH (-2)  /* scratch block too small */
+#define HIPREC_E_UNSUPPORTED (-3)
+
+/* bits of the device status word */
+#define HIPREC_STATUS_USER_OOB 1u
+#define HIPREC_STATUS_ITEM_OOB 2u
+#define HIPREC_STATUS_ROW_OOB 4u
+
+/* optimizer kinds, beta_rec/models/torch_engine.py:23-39 (only `lr` is ever set there) */
+#define HIPREC_OPT_SGD 0
+#define HIPREC_OPT_ADAM 1
+#define HIPREC_OPT_RMSPROP 2
+
+/* The five parameter tensors of beta_rec/models/mf.py:21-25 (MF.__init__), or any buffer set of
+ * the same shape (gradient accumulators).  Row-major fp32. */
+typedef struct hiprec_mf_tables {
+  float* user_emb;    /* [n_users, dim] */
+  float* item_emb;    /* [n_items, dim] */
+  float* user_bias;   /* [n_users]      (nn.Embedding(n_users, 1)) */
+  float* item_bias;   /* [n_items] */
+  float* global_bias; /* [1] */
+  int64_t n_users;
+  int64_t n_items;
+  int32_t dim;
+  int32_t _pad;
+} hiprec_mf_tables;
+
+/* Device-resident step statistics, one per engine.  All fields live on the device so a whole epoch
+ * can be enqueued without a host round trip (the reference syncs twice per step for
+ * loss.item()/regularizer.item(), beta_rec/models/mf.py:119). */
+typedef struct hiprec_stats {
+  float loss;        /* last step: BPR / BCE loss (mean over the batch) */
+  float reg;         /* last step: MF regularizer, mf.py:49-54 summed over both forward calls */
+  double loss_sum;   /* += loss every step (train_an_epoch's total_loss, mf.py:134-139) */
+  double reg_sum;    /* += reg every step */
+  int64_t step;      /* optimizer step counter t; every *_grad call advances it by one */
+  double beta1;      /* Adam betas (set by hiprec_stats_reset) and their running powers */
+  double beta2;      /*   beta^t, kept on the device so a captured graph of steps stays valid */
+  double beta1_pow;
+  double beta2_pow;
+  uint32_t status;   /* HIPREC_STATUS_* bits, sticky until cleared by the host */
+  uint32_t _pad;
+} hiprec_stats;
+
+int hiprec_version(void);
+const char* hiprec_last_error(void);
+size_t hiprec_stats_bytes(void);            /* sizeof(hiprec_stats) for the host layer */
+/* bytes of scratch needed by any *_grad / *_step call on a batch of `batch` units */
+size_t hiprec_scratch_bytes(int64_t batch);
+/* reset stats to {loss 0, reg 0, sums 0, step 0, betas as given, powers 1, status 0} */
+int hiprec_stats_reset(hiprec_stats* stats, double beta1, double beta2, void* stream);
+/* t <- t+1 without a *_grad call (stand-alone use of hiprec_opt_dense_step) */
+int hiprec_stats_advance_step(hiprec_stats* stats, void* stream);
+/* zero only the epoch accumulators loss_sum/reg_sum (start of train_an_epoch, mf.py:131-132) */
+int hiprec_stats_begin_epoch(hiprec_stats* stats, void* stream);
+
+/* ---- bit-exact row gather: out[k,:] = table[idx[k],:]  (nn.Embedding.forward, mf.py:39-42;
+ *      ncf.py:54-57; lightgcn.py:134-136).  dim floats per row. */
+int hiprec_gather_rows(const float* table, int64_t n_rows, int32_t dim, const int64_t* idx,
+                       int64_t n, float* out, hiprec_stats* stats, void* stream);
+
+/* ---- MF forward for scoring: MF.predict / MF.forward under no_grad (mf.py:32-48, 57-70).
+ *      scores[k] = sigmoid(<U[u_k], I[i_k]> + bu[u_k] + bi[i_k] + g) */
+int hiprec_mf_predict(const hiprec_mf_tables* w, const int64_t* users, const int64_t* items,
+                      int64_t n, float* scores, hiprec_stats* stats, void* stream);
+
+/* ---- MF BPR forward + backward (mf.py:101-107,116-117; torch_engine.py:104-105).
+ * Accumulates the DENSE gradient of the batch-mean BPR loss into `g` (same layout as `w`; the
+ * caller guarantees it is zero on entry, exactly like optimizer.zero_grad()+backward()).
+ * Triple k of the batch is (users[j], pos[j], neg[j]) with j = perm ? perm[k] : k — the optional
+ * permutation is the device-side batcher replacing DataLoader(shuffle=True) (base_data.py:253).
+ * Writes per-block partial (loss, reg) sums to scratch; the optimizer call that follows (or
+ * hiprec_finalize_stats) reduces them into stats.  inv_batch is 1/B of the (global) batch;
+ * reg_coef is MFEngine.reg (mf.py:81-83,116 — always 0.0 in the reference).  */
+int hiprec_mf_bpr_grad(const hiprec_mf_tables* w, const hiprec_mf_tables* g, const int64_t* users,
+                       const int64_t* pos, const int64_t* neg, const int64_t* perm, int64_t batch,
+                       float inv_batch, float reg_coef, hiprec_stats* stats, void* scratch,
+                       size_t scratch_bytes, void* stream);
+
+/* ---- MF BCE forward + backward (mf.py:108-111; torch_engine.py:108-121, BCELoss mean, log
+ * clamped at -100 like PyTorch).  ratings fp32. */
+int hiprec_mf_bce_grad(const hiprec_mf_tables* w, const hiprec_mf_tables* g, const int64_t* users,
+                       const int64_t* items, const float* ratings, const int64_t* perm,
+                       int64_t batch, float inv_batch, float reg_coef, hiprec_stats* stats,
+                       void* scratch, size_t scratch_bytes, void* stream);
+
+/* Reduce the per-block partials left in scratch by the last *_grad call into stats
+ * (loss, reg, loss_sum += loss, reg_sum += reg).  Only needed when no optimizer call follows. */
+int hiprec_finalize_stats(hiprec_stats* stats, const void* scratch, void* stream);
+
+/* ---- dense optimizer step over one flat fp32 buffer (torch.optim.{SGD,Adam,RMSprop}.step with the
+ * defaults torch_engine.py:23-39 leaves in place: Adam betas (0.9,0.999) eps 1e-8, RMSprop alpha
+ * 0.99 eps 1e-8, no momentum / weight decay).  Applies the update to w[0:n], updates the state
+ * (m = exp_avg, v = exp_avg_sq / square_avg; may be NULL for kinds that do not use them) and
+ * ZEROES g[0:n] (the next step's zero_grad).  Uses t = stats->step (already advanced by the
+ * preceding *_grad call) and the running beta powers in stats (Adam: beta1/beta2 must equal the
+ * values given to hiprec_stats_reset; RMSprop: beta2 = alpha).  Hyper-parameters are doubles, as
+ * the python floats of the reference are, and are rounded to fp32 exactly where ATen rounds them.
+ * When scratch != NULL it also finalizes the partials of the preceding *_grad call. */
+int hiprec_opt_dense_step(int kind, float* w, float* g, float* m, float* v, int64_t n, double lr,
+                          double beta1, double beta2, double eps, hiprec_stats* stats,
+                          const void* scratch, void* stream);
+
+/* ---- exact SGD restricted to the rows a batch touched (SGD with momentum 0 leaves every other
+ * row bit-identical: torch_engine.py:26-29).  For each distinct row of the batch:
+ * w[row] -= lr*g[row]; g[row] = 0.  `user_stamp` [n_users] / `item_stamp` [n_items] are int32
+ * arrays owned by the caller, zero-initialised once; `stamp` must be a value never used before
+ * for these arrays (the host passes a running step counter starting at 1).  */
+int hiprec_mf_sgd_rows(const hiprec_mf_tables* w, const hiprec_mf_tables* g, const int64_t* users,
+                       const int64_t* items_a, const int64_t* items_b, const int64_t* perm,
+                       int64_t batch, double lr, int32_t* user_stamp, int32_t* item_stamp,
+                       int32_t stamp, hiprec_stats* stats, const void* scratch, void* stream);
+
+/* ---- one whole epoch of MF-BPR training enqueued back to back (MFEngine.train_an_epoch,
+ * mf.py:121-139, with the DataLoader replaced by perm[] slices of the resident triple arrays;
+ * the last batch is short, drop_last=False as base_data.py:253).  `flat_*` are the flat buffers
+ * that hold all five tensors of w / g / state contiguously (n_flat floats) when the optimizer is
+ * dense; for kind == SGD with user_stamp != NULL the touched-rows path is used instead.
+ * first_stamp.. first_stamp+n_batches-1 are consumed as stamps.  */
+int hiprec_mf_bpr_epoch(const hiprec_mf_tables* w, const hiprec_mf_tables* g, const int64_t* users,
+                        const int64_t* pos, const int64_t* neg, const int64_t* perm,
+                        int64_t n_triples, int64_t batch, float reg_coef, int kind, double lr,
+                        double beta1,
+                        double beta2, double eps, float* flat_w, float* flat_g, float* flat_m,
+                        float* flat_v, int64_t n_flat, int32_t* user_stamp, int32_t* item_stamp,
+                        int32_t first_stamp, hiprec_stats* stats, void* scratch,
+                        size_t scratch_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPREC_H */

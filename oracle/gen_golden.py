@@ -1,0 +1,249 @@
+"""ORACLE tooling (test infrastructure): capture golden vectors from the REAL reference.
+
+Runs only in the build container, where /root/reference exists; the reference itself never
+travels (no source, no bytecode) — only the small .npz fixtures written to tests/golden/ do.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+Imports beta_rec.models.mf / beta_rec.data.data_loaders from /root/reference with the two
+in-process shims SURVEY.md §8c lists (a no-op ``tensorboardX`` module; the numpy aliases removed in
+numpy 1.24) and drives the reference's own ``MFEngine`` on seeded synthetic inputs.
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+KEYS = ("global_bias", "user_emb.weight", "item_emb.weight", "user_bias.weight", "item_bias.weight")
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    tb = types.ModuleType("tensorboardX")
+
+    class SummaryWriter:  # records scalars so the epoch fixture can pin them
+        def __init__(self, *a, **k):
+            self.scalars = []
+
+        def add_scalar(self, tag, value, step=None):
+            self.scalars.append((tag, float(value), step))
+
+    tb.SummaryWriter = SummaryWriter
+    sys.modules["tensorboardX"] = tb
+    for name, typ in (("int", int), ("long", int), ("float", float), ("bool", bool)):
+        if not hasattr(np, name):
+            setattr(np, name, typ)
+    sys.path.insert(0, REF)
+    from beta_rec.data.data_loaders import PairwiseNegativeDataset, RatingDataset
+    from beta_rec.models.mf import MFEngine
+
+    return MFEngine, PairwiseNegativeDataset, RatingDataset
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def make_config(U, I, D, optimizer, loss, lr, B, **extra):
+    model = dict(n_users=U, n_items=I, emb_dim=D, device_str="cpu", optimizer=optimizer, lr=lr,
+                 batch_size=B, loss=loss)
+    model.update(extra)
+    return {"model": model, "system": {"run_dir": "/tmp/hiprec_golden_runs"}}
+
+
+def zipf_items(rng, n, I):
+    p = 1.0 / np.arange(1, I + 1)
+    p /= p.sum()
+    return rng.permutation(I)[rng.choice(I, size=n, p=p)]
+
+
+def state_np(model, prefix):
+    return {f"{prefix}/{k}": v.detach().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def perturb_biases(model, rng):
+    """The reference starts biases at 0; nudge them so the fixtures exercise every term."""
+    with torch.no_grad():
+        model.user_bias.weight.copy_(torch.from_numpy(
+            (rng.standard_normal(model.user_bias.weight.shape) * 0.01).astype(np.float32)))
+        model.item_bias.weight.copy_(torch.from_numpy(
+            (rng.standard_normal(model.item_bias.weight.shape) * 0.01).astype(np.float32)))
+        model.global_bias.fill_(0.05)
+
+
+def steps_fixture(MFEngine, name, U, I, D, B, optimizer, loss, lr, n_steps, seed, top_reg=None):
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    cfg = make_config(U, I, D, optimizer, loss, lr, B)
+    if top_reg is not None:
+        # quirk Q1 (models/mf.py:81-83): `reg` only takes effect when the key ALSO exists at the
+        # top level of the config; this fixture pins the L2 term's gradient for that case.
+        cfg["reg"] = top_reg
+        cfg["model"]["reg"] = top_reg
+    eng = quiet(MFEngine, cfg)
+    assert eng.reg == (top_reg if top_reg is not None else 0.0)
+    perturb_biases(eng.model, rng)
+    out = {"meta": np.array([U, I, D, B, n_steps], dtype=np.int64),
+           "optimizer": np.array(optimizer), "loss_kind": np.array(loss), "lr": np.array(lr),
+           "reg_coef": np.array(0.0 if top_reg is None else top_reg)}
+    out.update(state_np(eng.model, "w0"))
+    grads_seen = []
+    orig_step = eng.optimizer.step
+
+    def capturing_step(*a, **k):
+        grads_seen.append({n: (p.grad.detach().numpy().copy() if p.grad is not None
+                               else np.zeros(tuple(p.shape), np.float32))
+                           for n, p in eng.model.named_parameters()})
+        return orig_step(*a, **k)
+
+    eng.optimizer.step = capturing_step
+    users = rng.integers(0, U, size=(n_steps, B))
+    a_items = np.stack([zipf_items(rng, B, I) for _ in range(n_steps)])
+    if loss == "bpr":
+        third = rng.integers(0, I, size=(n_steps, B))
+    else:
+        third = (rng.random((n_steps, B)) < 0.3).astype(np.float32)
+    losses, regs = [], []
+    for s in range(n_steps):
+        batch = (torch.from_numpy(users[s]), torch.from_numpy(a_items[s]),
+                 torch.from_numpy(third[s]))
+        l, r = eng.train_single_batch(batch)
+        losses.append(l)
+        regs.append(r)
+        out.update(state_np(eng.model, f"w{s + 1}"))
+        for k, v in grads_seen[-1].items():
+            out[f"g{s + 1}/{k}"] = v
+        # optimizer state after this step (exp_avg / exp_avg_sq / square_avg), per parameter
+        for pname, p in eng.model.named_parameters():
+            pst = eng.optimizer.state.get(p, {})
+            for sk, tag in (("exp_avg", "m"), ("exp_avg_sq", "v"), ("square_avg", "v")):
+                if sk in pst:
+                    out[f"{tag}{s + 1}/{pname}"] = pst[sk].detach().numpy().copy()
+    out["users"], out["items_a"], out["third"] = users, a_items, third
+    out["losses"] = np.array(losses, dtype=np.float64)
+    out["regs"] = np.array(regs, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: losses {losses}")
+
+
+def kat_fixture(MFEngine):
+    """The tiny known-answer vector of SURVEY.md §8c."""
+    eng = quiet(MFEngine, make_config(4, 5, 4, "sgd", "bpr", 0.1, 3))
+    with torch.no_grad():
+        eng.model.user_emb.weight.copy_(((torch.arange(16).reshape(4, 4) % 7) - 3) * 0.1)
+        eng.model.item_emb.weight.copy_(((torch.arange(20).reshape(5, 4) % 5) - 2) * 0.2)
+        eng.model.user_bias.weight.copy_((torch.arange(4) * 0.01).reshape(4, 1))
+        eng.model.item_bias.weight.copy_((-torch.arange(5) * 0.02).reshape(5, 1))
+        eng.model.global_bias.fill_(0.05)
+    out = state_np(eng.model, "w0")
+    u, p, n = torch.tensor([0, 2, 2]), torch.tensor([1, 3, 0]), torch.tensor([4, 1, 3])
+    l, r = eng.train_single_batch((u, p, n))
+    out.update(state_np(eng.model, "w1"))
+    out.update(users=u.numpy(), pos=p.numpy(), neg=n.numpy(), loss=np.array(l), reg=np.array(r))
+    np.savez_compressed(os.path.join(OUT, "mf_kat.npz"), **out)
+    print("mf_kat:", l, r)
+
+
+def init_fixture(MFEngine):
+    """Initial weights for a given torch seed (models/mf.py:21-30 RNG consumption order)."""
+    out = {}
+    for tag, (U, I, D, seed) in {"a": (11, 7, 5, 2020), "b": (40, 33, 64, 7)}.items():
+        torch.manual_seed(seed)
+        eng = quiet(MFEngine, make_config(U, I, D, "sgd", "bpr", 0.1, 3))
+        out[f"{tag}/meta"] = np.array([U, I, D, seed], dtype=np.int64)
+        out.update(state_np(eng.model, f"{tag}/w"))
+    np.savez_compressed(os.path.join(OUT, "mf_init.npz"), **out)
+    print("mf_init written")
+
+
+def predict_fixture(MFEngine):
+    rng = np.random.default_rng(5)
+    torch.manual_seed(5)
+    U, I, D = 53, 47, 64
+    eng = quiet(MFEngine, make_config(U, I, D, "sgd", "bpr", 0.1, 3))
+    perturb_biases(eng.model, rng)
+    users = rng.integers(0, U, size=301)
+    items = rng.integers(0, I, size=301)
+    scores = eng.model.predict(users, items).numpy()
+    out = state_np(eng.model, "w")
+    out.update(users=users, items=items, scores=scores)
+    np.savez_compressed(os.path.join(OUT, "mf_predict.npz"), **out)
+    print("mf_predict written")
+
+
+def epoch_fixture(MFEngine, PairwiseNegativeDataset, name, optimizer, seed):
+    """One train_an_epoch through the reference's own DataLoader(shuffle=True): pins the batch
+    composition rule (shuffle per epoch, last batch short), the (loss, reg) sequence, the
+    add_scalar values and the final weights (models/mf.py:121-139, data/base_data.py:247-253)."""
+    from torch.utils.data import DataLoader
+
+    rng = np.random.default_rng(seed)
+    U, I, D, B, N = 31, 29, 8, 16, 103
+    torch.manual_seed(seed)
+    eng = quiet(MFEngine, make_config(U, I, D, optimizer, "bpr", 0.05, B))
+    perturb_biases(eng.model, rng)
+    users = rng.integers(0, U, size=N)
+    pos = zipf_items(rng, N, I)
+    neg = rng.integers(0, I, size=N)
+    out = state_np(eng.model, "w0")
+    ds = PairwiseNegativeDataset(torch.LongTensor(users), torch.LongTensor(pos),
+                                 torch.LongTensor(neg))
+    loader = DataLoader(ds, batch_size=B, shuffle=True)
+    seen, results = [], []
+    orig = eng.train_single_batch
+
+    def recording(batch):
+        seen.append(torch.stack([b.clone() for b in batch]).numpy())
+        res = orig(batch)
+        results.append(res)
+        return res
+
+    eng.train_single_batch = recording
+    torch.manual_seed(seed + 1)  # the state the test must start the epoch from
+    quiet(eng.train_an_epoch, loader, 0)
+    out.update(state_np(eng.model, "w1"))
+    out.update(users=users, pos=pos, neg=neg,
+               meta=np.array([U, I, D, B, N, seed + 1], dtype=np.int64),
+               optimizer=np.array(optimizer),
+               batch_sizes=np.array([s.shape[1] for s in seen], dtype=np.int64),
+               batches=np.concatenate(seen, axis=1),
+               losses=np.array([r[0] for r in results]), regs=np.array([r[1] for r in results]),
+               scalar_loss=np.array([s[1] for s in eng.writer.scalars if s[0] == "model/loss"]),
+               scalar_reg=np.array([s[1] for s in eng.writer.scalars
+                                    if s[0] == "model/regularizer"]))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: {len(seen)} batches, sizes {[s.shape[1] for s in seen]}")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    MFEngine, PairwiseNegativeDataset, _ = import_reference()
+    kat_fixture(MFEngine)
+    init_fixture(MFEngine)
+    predict_fixture(MFEngine)
+    for opt, lr in (("sgd", 0.05), ("adam", 0.05), ("rmsprop", 0.01)):
+        steps_fixture(MFEngine, f"mf_bpr_{opt}", 97, 61, 64, 37, opt, "bpr", lr, 3, seed=11)
+    steps_fixture(MFEngine, "mf_bce_sgd", 97, 61, 64, 37, "sgd", "bce", 0.05, 3, seed=12)
+    steps_fixture(MFEngine, "mf_bce_adam", 97, 61, 64, 37, "adam", "bce", 0.05, 3, seed=13)
+    # embedding widths that exercise every kernel specialisation (<=64, <=128, <=256, generic)
+    steps_fixture(MFEngine, "mf_bpr_sgd_d4", 23, 19, 4, 9, "sgd", "bpr", 0.1, 2, seed=14)
+    steps_fixture(MFEngine, "mf_bpr_sgd_d100", 23, 19, 100, 9, "sgd", "bpr", 0.1, 2, seed=15)
+    steps_fixture(MFEngine, "mf_bpr_adam_d200", 23, 19, 200, 9, "adam", "bpr", 0.05, 2, seed=16)
+    steps_fixture(MFEngine, "mf_bpr_sgd_d300", 23, 19, 300, 9, "sgd", "bpr", 0.1, 2, seed=17)
+    steps_fixture(MFEngine, "mf_bpr_sgd_reg", 23, 19, 64, 9, "sgd", "bpr", 0.1, 2, seed=18,
+                  top_reg=0.01)
+    steps_fixture(MFEngine, "mf_bce_sgd_reg", 23, 19, 64, 9, "sgd", "bce", 0.1, 2, seed=19,
+                  top_reg=0.01)
+    epoch_fixture(MFEngine, PairwiseNegativeDataset, "mf_epoch_adam", "adam", seed=21)
+    epoch_fixture(MFEngine, PairwiseNegativeDataset, "mf_epoch_sgd", "sgd", seed=22)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+"""Shared helpers for the parity tests."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KEYS = ("global_bias", "user_emb.weight", "item_emb.weight", "user_bias.weight", "item_bias.weight")
+
+# north_star tolerance: 1e-5 relative on fp32 loss / grad (BASELINE.json); integer gathers bit-exact
+REL = 1e-5
+EPS32 = float(np.finfo(np.float32).eps)
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def params(gold, prefix):
+    return {k: gold[f"{prefix}/{k}"].astype(np.float32).copy() for k in KEYS}
+
+
+def assert_scalar_close(got, ref, rel=REL, what=""):
+    assert abs(float(got) - float(ref)) <= rel * abs(float(ref)) + 1e-12, (
+        f"{what}: got {got!r}, reference {ref!r}, rel err {abs(got - ref) / max(abs(ref), 1e-30):.3e}")
+
+
+def grad_scale_floor(key, batch):
+    """Natural magnitude of the TERMS a bias gradient sums.  d(loss)/d(bias) adds per-sample terms
+    of size <= 0.25/B with opposite signs (positive vs negative item), so the result can be orders
+    of magnitude below its terms and its fp32 rounding error is relative to the terms, not to the
+    cancelled result: global_bias sums 2B of them (two partial sums of ~0.125 each)."""
+    if key == "global_bias":
+        return 0.125
+    if key.endswith("bias.weight"):
+        return 0.25 / batch
+    return 0.0
+
+
+def assert_tensor_close(got, ref, rel=REL, what="", scale_floor=0.0):
+    """max|got-ref| <= rel * max(max|ref|, scale_floor)  (error relative to the tensor's scale)."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
+    scale = max(np.abs(ref).max() if ref.size else 0.0, scale_floor)
+    err = np.abs(got - ref).max() if ref.size else 0.0
+    assert err <= rel * scale + 1e-30, f"{what}: max err {err:.3e} > {rel:g} * scale {scale:.3e}"
+
+
+def assert_update_close(w0, got, ref, rel=REL, what=""):
+    """Compare the UPDATE (w_new - w_old): tolerance rel * max|update| plus a few ulps of the
+    weights themselves (the update is added to an fp32 weight)."""
+    w0, got, ref = (np.asarray(a, dtype=np.float64) for a in (w0, got, ref))
+    upd_scale = np.abs(ref - w0).max()
+    w_scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    tol = rel * upd_scale + 4 * EPS32 * w_scale
+    assert err <= tol, (f"{what}: max err {err:.3e} > tol {tol:.3e} "
+                        f"(update scale {upd_scale:.3e}, weight scale {w_scale:.3e})")
+
+
+def golden_opt_state(gold, step, opt):
+    """Optimizer state of the reference AFTER `step` steps, in oracle/mf_numpy.py's format."""
+    from oracle import mf_numpy as onp
+
+    w_like = params(gold, "w0")
+    st = onp.new_opt_state(w_like, opt)
+    st["step"] = step
+    if step > 0:
+        if opt == "adam":
+            st["exp_avg"] = params(gold, f"m{step}")
+            st["exp_avg_sq"] = params(gold, f"v{step}")
+        elif opt == "rmsprop":
+            st["square_avg"] = params(gold, f"v{step}")
+    return st
+
+
+def copy_state(st):
+    return {k: ({kk: vv.copy() for kk, vv in v.items()} if isinstance(v, dict) else v)
+            for k, v in st.items()}
+
+
+def optimizer_band(w_prev, st_prev, g_ref, opt, lr, batch, rel=REL):
+    """Elementwise forward-error band of one optimizer step for a gradient that is within the
+    stated tolerance (rel * its scale) of the reference gradient.
+
+    Adam / RMSprop divide by sqrt(v)+eps: where |g| is not >> eps = 1e-8 the update is
+    ill-conditioned (d update / d g ~ lr/eps), so a gradient that is correct to 1e-5 relative can
+    legitimately move such an element by far more than 1e-5 of the update scale.  The band is
+    |step(g + d) - step(g - d)| with d = rel * scale(g), evaluated with the oracle."""
+    from oracle import mf_numpy as onp
+
+    outs = []
+    for sign in (+1.0, -1.0):
+        w = onp.copy_params(w_prev)
+        st = copy_state(st_prev)
+        g = {}
+        for k in KEYS:
+            scale = max(float(np.abs(g_ref[k]).max()), grad_scale_floor(k, batch))
+            g[k] = (g_ref[k] + np.float32(sign * rel * scale)).astype(np.float32)
+        onp.opt_step(w, g, st, opt, lr)
+        outs.append(w)
+    return {k: np.abs(outs[0][k].astype(np.float64) - outs[1][k].astype(np.float64)) for k in KEYS}
+
+
+def assert_step_close(w_prev, got, ref, band, rel=REL, what=""):
+    """|got - ref| <= rel*max|ref - w_prev| + 4 ulp(max|w|) + band   (elementwise)."""
+    w_prev, got, ref = (np.asarray(a, dtype=np.float64) for a in (w_prev, got, ref))
+    tol = rel * np.abs(ref - w_prev).max() + 4 * EPS32 * np.abs(ref).max() + band
+    err = np.abs(got - ref)
+    bad = err > tol
+    assert not bad.any(), (f"{what}: {int(bad.sum())} elements out of tolerance, worst err "
+                           f"{err[bad].max():.3e} vs tol {tol[bad][np.argmax(err[bad])]:.3e}")

@@ -1,0 +1,188 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol include/hiprec.h declares, and
+the host-side mirror of the reference interface behaves like beta_rec.models.{torch_engine,mf}
+where no compute is involved.  No kernel is launched here."""
+import contextlib
+import ctypes
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import KEYS, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_engine(U=11, I=7, D=5, optimizer="sgd", loss="bpr", **extra):
+    import beta_recsys_amd as hp
+
+    model = dict(n_users=U, n_items=I, emb_dim=D, device_str="cpu", optimizer=optimizer, lr=0.05,
+                 batch_size=4, loss=loss)
+    cfg = {"model": model, "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+    cfg.update(extra)
+    with contextlib.redirect_stdout(io.StringIO()):
+        return hp.MFEngine(cfg)
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "hiprec.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hiprec_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from beta_recsys_amd import _lib
+
+    names = declared_functions()
+    assert len(names) >= 15
+    lib = _lib.load()
+    for n in names:
+        assert hasattr(lib, n), f"libhiprec.so does not export {n}"
+        assert n in _lib.SIGNATURES, f"_lib.py has no prototype for {n}"
+    assert set(_lib.SIGNATURES) == set(names), "prototypes for symbols the header does not declare"
+    assert lib.hiprec_version() == 100
+    assert lib.hiprec_stats_bytes() == ctypes.sizeof(_lib.Stats)
+    assert lib.hiprec_scratch_bytes(4096) >= 16
+
+
+def test_bad_arguments_return_error_codes_without_a_gpu():
+    """Argument validation happens before any HIP call, so it can be checked on the CPU box."""
+    from beta_recsys_amd import _lib
+
+    lib = _lib.load()
+    rc = lib.hiprec_gather_rows(None, 10, 4, None, 5, None, None, None)
+    assert rc == -1 and b"NULL" in lib.hiprec_last_error()
+    rc = lib.hiprec_opt_dense_step(7, None, None, None, None, 4, 0.1, 0.9, 0.999, 1e-8, None, None, None)
+    assert rc == -1
+    with pytest.raises(_lib.HiprecError):
+        _lib.check(rc)
+    t = _lib.MfTables(0, 0, 0, 0, 0, 4, 5, 8, 0)
+    rc = lib.hiprec_mf_predict(ctypes.byref(t), None, None, 3, None, None, None)
+    assert rc == -1 and b"NULL tensor pointer" in lib.hiprec_last_error()
+
+
+def test_mf_initial_weights_match_reference_for_same_seed():
+    """MF.__init__ consumes the torch RNG like models/mf.py:21-30 -> bit-identical init."""
+    g = load_golden("mf_init")
+    for tag in ("a", "b"):
+        U, I, D, seed = (int(x) for x in g[f"{tag}/meta"])
+        torch.manual_seed(seed)
+        eng = make_engine(U, I, D)
+        sd = eng.model.state_dict()
+        assert list(sd.keys()) == list(KEYS)
+        for k in KEYS:
+            assert tuple(sd[k].shape) == g[f"{tag}/w/{k}"].shape
+            assert np.array_equal(sd[k].numpy(), g[f"{tag}/w/{k}"]), f"{tag} {k} differs"
+
+
+def test_parameters_are_views_of_one_flat_buffer():
+    eng = make_engine(6, 5, 4)
+    m = eng.model
+    U, I, D = 6, 5, 4
+    assert m.flat.numel() == (U + I) * (D + 1) + 1
+    assert m.user_emb.weight.data_ptr() == m.flat.data_ptr()
+    assert m.item_emb.weight.data_ptr() == m.flat.data_ptr() + 4 * U * D
+    assert m.global_bias.data_ptr() == m.flat.data_ptr() + 4 * ((U + I) * (D + 1))
+    # load_state_dict copies in place: the views stay attached
+    sd = {k: torch.full_like(v, 0.5) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    assert float(m.flat.min()) == 0.5 and float(m.flat.max()) == 0.5
+    # .to() re-binds every view to the moved buffer
+    m.to(torch.device("cpu"))
+    m.flat[0] = 7.0
+    assert float(m.user_emb.weight[0, 0]) == 7.0
+    with pytest.raises(TypeError):
+        m.half()
+    t = m.tables()
+    assert (t.n_users, t.n_items, t.dim) == (U, I, D) and t.user_emb == m.flat.data_ptr()
+
+
+def test_engine_surface_and_quirks():
+    eng = make_engine(optimizer="adam")
+    for attr in ("model", "optimizer", "device", "writer", "config", "batch_size", "loss", "reg"):
+        assert hasattr(eng, attr)
+    assert eng.loss == "bpr" and eng.device == torch.device("cpu")
+    assert eng.optimizer.defaults["betas"] == (0.9, 0.999) and eng.optimizer.defaults["eps"] == 1e-8
+    # quirk Q1: model-level reg is ignored unless the key also exists at the top level
+    cfg_model_reg = make_engine()
+    cfg_model_reg.config["model"]["reg"] = 0.001
+    assert make_engine().reg == 0.0
+    import beta_recsys_amd as hp
+    cfg = {"model": dict(n_users=3, n_items=3, emb_dim=2, device_str="cpu", optimizer="sgd", lr=0.1,
+                         batch_size=2, reg=0.001), "system": {"run_dir": "/tmp/x"}}
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert hp.MFEngine(cfg).reg == 0.0
+        cfg["reg"] = 1
+        assert hp.MFEngine(cfg).reg == 0.001
+    # losses helpers mirror torch_engine.py:92-121
+    p, n = torch.tensor([0.7, 0.2]), torch.tensor([0.1, 0.4])
+    assert torch.allclose(eng.bpr_loss(p, n), -torch.nn.functional.logsigmoid(p - n).mean())
+    assert torch.allclose(eng.bce_loss(p, torch.tensor([1.0, 0.0])),
+                          torch.nn.BCELoss()(p, torch.tensor([1.0, 0.0])))
+
+
+def test_unknown_optimizer_and_no_cpu_fallback():
+    with pytest.raises(ValueError, match="Unsupported optimizer"):
+        make_engine(optimizer="adagrad")
+    eng = make_engine()
+    batch = (torch.tensor([0, 1]), torch.tensor([0, 1]), torch.tensor([1, 2]))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        eng.train_single_batch(batch)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        eng.model.predict(np.array([0]), np.array([0]))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        eng.train_an_epoch([batch], 0)
+    eng.loss = "hinge"
+    with pytest.raises(RuntimeError, match="Unsupported loss type"):
+        eng.train_single_batch(batch)
+    eng.loss = "bpr"
+    with pytest.raises(IndexError):  # quirk Q4: a batch of one cannot be trained on
+        eng.train_single_batch((torch.tensor([0]), torch.tensor([0]), torch.tensor([1])))
+
+
+def test_checkpoint_format(tmp_path):
+    """torch.save(state_dict) with the reference's keys / shapes (torch_engine.py:70-90)."""
+    eng = make_engine(9, 8, 6)
+    path = str(tmp_path / "mf.model")
+    eng.save_checkpoint(path)
+    sd = torch.load(path)
+    assert list(sd.keys()) == list(KEYS)
+    assert sd["user_emb.weight"].shape == (9, 6) and sd["item_bias.weight"].shape == (8, 1)
+    assert sd["global_bias"].shape == (1,)
+    other = make_engine(9, 8, 6)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = other.resume_checkpoint(path)
+    assert model is other.model
+    for k in KEYS:
+        assert torch.equal(other.model.state_dict()[k], sd[k])
+    # a stock torch module with the reference's layout can load it, and vice versa
+    ref_like = torch.nn.ModuleDict({"user_emb": torch.nn.Embedding(9, 6), "item_emb": torch.nn.Embedding(8, 6),
+                                    "user_bias": torch.nn.Embedding(9, 1), "item_bias": torch.nn.Embedding(8, 1)})
+    ref_like.global_bias = torch.nn.Parameter(torch.zeros(1))
+    ref_like.load_state_dict(sd)
+    other.model.load_state_dict(ref_like.state_dict())
+
+
+def test_device_triple_batcher_composition():
+    import beta_recsys_amd as hp
+
+    n, bs = 103, 16
+    u = torch.arange(n)
+    b = hp.DeviceTripleBatcher(u, u + 1000, u + 2000, bs, generator=torch.Generator().manual_seed(1))
+    batches = list(b)
+    assert len(b) == len(batches) == 7
+    assert [len(x[0]) for x in batches] == [16] * 6 + [7]  # drop_last=False
+    seen = torch.cat([x[0] for x in batches])
+    assert sorted(seen.tolist()) == list(range(n))  # a permutation: every triple exactly once
+    assert seen.tolist() != list(range(n))
+    for x in batches:
+        assert torch.equal(x[1], x[0] + 1000) and torch.equal(x[2], x[0] + 2000)
+        assert all(t.dtype == torch.int64 for t in x)
+    seq = hp.DeviceTripleBatcher(u, u, u, bs, shuffle=False)
+    assert seq.permutation() is None
+    assert torch.cat([x[0] for x in seq]).tolist() == list(range(n))
+    with pytest.raises(ValueError):
+        hp.DeviceTripleBatcher(u, u[:-1], u, bs)

@@ -1,0 +1,412 @@
+"""GPU parity tests of the MF hot path: libhiprec (HIP, through the C ABI) vs the golden vectors
+captured from the real reference, vs the numpy oracle on seeded inputs, and size-independent
+properties at BASELINE's full C2 shape (6040 x 3706, dim 64, batch 4096).
+
+Tolerances (BASELINE.json north_star): bit-exact on the index gather; 1e-5 relative on fp32
+loss / gradients (relative to the tensor's scale, see helpers.py); optimizer updates within 1e-5
+of the update scale plus the conditioning band of helpers.optimizer_band.
+"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import KEYS, assert_scalar_close, assert_step_close, assert_tensor_close
+from helpers import golden_opt_state, grad_scale_floor, load_golden, optimizer_band, params
+from oracle import mf_numpy as onp
+
+pytestmark = pytest.mark.gpu
+
+STEP_CASES = ["mf_bpr_sgd", "mf_bpr_adam", "mf_bpr_rmsprop", "mf_bce_sgd", "mf_bce_adam",
+              "mf_bpr_sgd_d4", "mf_bpr_sgd_d100", "mf_bpr_adam_d200", "mf_bpr_sgd_d300",
+              "mf_bpr_sgd_reg", "mf_bce_sgd_reg"]
+
+
+def make_engine(U, I, D, optimizer, loss, lr, B, reg=None, **model_extra):
+    import beta_recsys_amd as hp
+
+    model = dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer=optimizer, lr=lr,
+                 batch_size=B, loss=loss)
+    model.update(model_extra)
+    cfg = {"model": model, "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+    if reg is not None:
+        cfg["reg"] = reg
+        cfg["model"]["reg"] = reg
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = hp.MFEngine(cfg)
+    return eng
+
+
+def load_weights(eng, w):
+    eng.model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
+
+
+def get_weights(eng):
+    return {k: v.detach().cpu().numpy() for k, v in eng.model.state_dict().items()}
+
+
+def engine_for_case(g, **extra):
+    U, I, D, B, _ = (int(x) for x in g["meta"])
+    reg = float(g["reg_coef"]) or None
+    return make_engine(U, I, D, str(g["optimizer"]), str(g["loss_kind"]), float(g["lr"]), B,
+                       reg=reg, **extra)
+
+
+def batch_of(g, s, device="cpu"):
+    return tuple(torch.from_numpy(g[k][s]).to(device) for k in ("users", "items_a", "third"))
+
+
+# ---- gather: integer-indexed copy must be bit-exact ---------------------------------------------
+
+@pytest.mark.parametrize("dim", [1, 4, 63, 64, 100, 128, 256])
+def test_gather_rows_bit_exact(hip_device, dim):
+    import beta_recsys_amd as hp
+
+    gen = torch.Generator().manual_seed(dim)
+    table = torch.randn(1000, dim, generator=gen)
+    idx = torch.randint(0, 1000, (4097,), generator=gen)
+    idx[:10] = idx[0]  # duplicates
+    out = hp.gather_rows(table.to(hip_device), idx.to(hip_device))
+    assert torch.equal(out.cpu(), table[idx]), "gather must be a bit-exact copy"
+    out2 = hp.gather_rows(table.to(hip_device), idx[:0].to(hip_device))
+    assert out2.shape == (0, dim)
+
+
+def test_gather_rows_2d_index_and_oob(hip_device):
+    import beta_recsys_amd as hp
+    from beta_recsys_amd import mf as hmf
+
+    table = torch.arange(40, dtype=torch.float32).reshape(10, 4).to(hip_device)
+    idx = torch.tensor([[0, 9], [3, 3]])
+    out = hp.gather_rows(table, idx)
+    assert out.shape == (2, 2, 4)
+    assert torch.equal(out.cpu(), table.cpu()[idx])
+    hp.gather_rows(table, torch.tensor([1, 10]))  # 10 is out of range
+    key = (hip_device.type, hip_device.index)
+    st = hmf.read_stats(hmf._gather_stats[key])
+    assert st.status & hp._lib.STATUS_ROW_OOB
+    hmf._gather_stats.pop(key)
+
+
+# ---- golden vectors from the real reference -----------------------------------------------------
+
+def test_known_answer_vector(hip_device):
+    g = load_golden("mf_kat")
+    eng = make_engine(4, 5, 4, "sgd", "bpr", 0.1, 3)
+    load_weights(eng, params(g, "w0"))
+    loss, reg = eng.train_single_batch(tuple(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
+    assert_scalar_close(loss, float(g["loss"]), what="loss")
+    assert_scalar_close(reg, float(g["reg"]), what="reg")
+    w = get_weights(eng)
+    for k in KEYS:
+        assert_step_close(g[f"w0/{k}"], w[k], g[f"w1/{k}"], 0.0, what=k)
+    assert np.array_equal(w["user_emb.weight"][[1, 3]], g["w0/user_emb.weight"][[1, 3]])
+
+
+@pytest.mark.parametrize("case", STEP_CASES)
+def test_step_matches_reference(hip_device, case):
+    """Each step in isolation from the reference's own weights + optimizer state: loss, reg,
+    dense gradients, updated weights and updated moments."""
+    g = load_golden(case)
+    B, n_steps = int(g["meta"][3]), int(g["meta"][4])
+    opt, lr = str(g["optimizer"]), float(g["lr"])
+    eng = engine_for_case(g)
+    for s in range(n_steps):
+        w_prev = params(g, f"w{s}")
+        st_prev = golden_opt_state(g, s, opt)
+        g_ref = params(g, f"g{s + 1}")
+        # (1) gradients as autograd leaves them
+        load_weights(eng, w_prev)
+        loss, reg, grads = eng.backward_only(batch_of(g, s))
+        assert_scalar_close(loss, g["losses"][s], what=f"loss step {s}")
+        assert_scalar_close(reg, g["regs"][s], what=f"reg step {s}")
+        for k in KEYS:
+            assert_tensor_close(grads[k].cpu().numpy(), g_ref[k], what=f"grad {k} step {s}",
+                                scale_floor=grad_scale_floor(k, B))
+        assert float(eng._g_flat.abs().max()) == 0.0
+        # (2) the full step
+        eng.load_optimizer_state(s, st_prev.get("exp_avg"),
+                                 st_prev.get("exp_avg_sq", st_prev.get("square_avg")))
+        loss2, reg2 = eng.train_single_batch(batch_of(g, s))
+        assert_scalar_close(loss2, g["losses"][s], what=f"loss (step) {s}")
+        assert_scalar_close(reg2, g["regs"][s], what=f"reg (step) {s}")
+        band = optimizer_band(w_prev, st_prev, g_ref, opt, lr, B)
+        w = get_weights(eng)
+        for k in KEYS:
+            assert_step_close(w_prev[k], w[k], g[f"w{s + 1}/{k}"], band[k],
+                              what=f"weights {k} step {s}")
+        assert float(eng._g_flat.abs().max()) == 0.0, "optimizer must leave the grad buffer zeroed"
+        step, m, v = eng.optimizer_state()
+        assert step == s + 1
+        ref_next = golden_opt_state(g, s + 1, opt)
+        for name, got in (("exp_avg", m), ("exp_avg_sq", v), ("square_avg", v)):
+            if name in ref_next and got is not None:
+                for k in KEYS:
+                    floor = grad_scale_floor(k, B)
+                    assert_tensor_close(got[k].cpu().numpy(), ref_next[name][k], 4e-5,
+                                        f"{name} {k} step {s}",
+                                        scale_floor=floor if name == "exp_avg" else floor ** 2)
+
+
+@pytest.mark.parametrize("case", ["mf_bpr_sgd", "mf_bpr_adam", "mf_bpr_rmsprop", "mf_bce_adam"])
+def test_multi_step_trajectory(hip_device, case):
+    """All steps chained on the GPU (its own state): optimizer clock and bias correction."""
+    g = load_golden(case)
+    n_steps, lr = int(g["meta"][4]), float(g["lr"])
+    eng = engine_for_case(g)
+    load_weights(eng, params(g, "w0"))
+    for s in range(n_steps):
+        loss, reg = eng.train_single_batch(batch_of(g, s, "cuda:0"))
+        assert_scalar_close(loss, g["losses"][s], 2e-5, f"loss step {s}")
+        assert_scalar_close(reg, g["regs"][s], 2e-5, f"reg step {s}")
+    w = get_weights(eng)
+    for k in KEYS:
+        frac_bad = np.mean(np.abs(w[k] - g[f"w{n_steps}/{k}"]) > 1e-3 * lr + 1e-6)
+        assert frac_bad < 0.01, f"{k}: {frac_bad:.3%} of elements off trajectory"
+
+
+@pytest.mark.parametrize("case", ["mf_bpr_sgd", "mf_bce_sgd", "mf_bpr_sgd_d300", "mf_bpr_sgd_reg"])
+def test_sgd_touched_rows_mode(hip_device, case):
+    """SGD restricted to the rows a batch touched: same result as the reference's dense step and
+    every untouched row bit-identical (torch_engine.py:26-29, momentum 0)."""
+    g = load_golden(case)
+    n_steps = int(g["meta"][4])
+    eng = engine_for_case(g, sgd_mode="rows")
+    for s in range(n_steps):
+        w_prev = params(g, f"w{s}")
+        load_weights(eng, w_prev)
+        loss, reg = eng.train_single_batch(batch_of(g, s))
+        assert eng._rows_sgd
+        assert_scalar_close(loss, g["losses"][s], what=f"loss step {s}")
+        w = get_weights(eng)
+        for k in KEYS:
+            assert_step_close(w_prev[k], w[k], g[f"w{s + 1}/{k}"], 0.0, what=f"{k} step {s}")
+        users = np.unique(g["users"][s])
+        items = np.unique(g["items_a"][s]) if str(g["loss_kind"]) == "bce" else np.unique(
+            np.concatenate([g["items_a"][s], g["third"][s].astype(np.int64)]))
+        u_rest = np.setdiff1d(np.arange(w_prev["user_emb.weight"].shape[0]), users)
+        i_rest = np.setdiff1d(np.arange(w_prev["item_emb.weight"].shape[0]), items)
+        assert np.array_equal(w["user_emb.weight"][u_rest], w_prev["user_emb.weight"][u_rest])
+        assert np.array_equal(w["item_emb.weight"][i_rest], w_prev["item_emb.weight"][i_rest])
+        assert np.array_equal(w["user_bias.weight"][u_rest], w_prev["user_bias.weight"][u_rest])
+        assert float(eng._g_flat.abs().max()) == 0.0
+
+
+def test_predict_matches_reference(hip_device):
+    g = load_golden("mf_predict")
+    eng = make_engine(53, 47, 64, "sgd", "bpr", 0.1, 3)
+    load_weights(eng, {k: g[f"w/{k}"] for k in KEYS})
+    scores = eng.model.predict(g["users"], g["items"])  # numpy ids, as EvalEngine.predict passes
+    assert isinstance(scores, torch.Tensor) and scores.device.type == "cuda"
+    got = scores.flatten().to(torch.device("cpu")).detach().numpy()  # eval_engine.py:258-264
+    assert_tensor_close(got, g["scores"], what="scores")
+    fscores, reg = eng.model.forward((torch.from_numpy(g["users"]), torch.from_numpy(g["items"])))
+    assert_tensor_close(fscores.cpu().numpy(), g["scores"], what="forward scores")
+    _, ref_reg, _ = onp.mf_forward({k: g[f"w/{k}"] for k in KEYS}, g["users"], g["items"])
+    assert_scalar_close(float(reg), float(ref_reg), what="forward regularizer")
+
+
+@pytest.mark.parametrize("case", ["mf_epoch_adam", "mf_epoch_sgd"])
+def test_epoch_through_dataloader_matches_reference(hip_device, case):
+    """train_an_epoch fed with the reference's own kind of loader
+    (DataLoader(PairwiseNegativeDataset, shuffle=True), base_data.py:247-253): same batch
+    composition for the same torch seed, same add_scalar values, same final weights."""
+    from torch.utils.data import DataLoader, Dataset
+
+    class PairwiseNegativeDataset(Dataset):  # same fields as data/data_loaders.py:30-53
+        def __init__(self, u, p, n):
+            self.user_tensor, self.pos_item_tensor, self.neg_item_tensor = u, p, n
+
+        def __getitem__(self, i):
+            return self.user_tensor[i], self.pos_item_tensor[i], self.neg_item_tensor[i]
+
+        def __len__(self):
+            return self.user_tensor.size(0)
+
+    g = load_golden(case)
+    U, I, D, B, N, seed = (int(x) for x in g["meta"])
+    opt = str(g["optimizer"])
+    ds = PairwiseNegativeDataset(*(torch.LongTensor(g[k]) for k in ("users", "pos", "neg")))
+    for mode in ("resident", "iterable"):
+        eng = make_engine(U, I, D, opt, "bpr", 0.05, B)
+        load_weights(eng, params(g, "w0"))
+        loader = DataLoader(ds, batch_size=B, shuffle=True)
+        torch.manual_seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()) as out:
+            if mode == "resident":
+                eng.train_an_epoch(loader, 0)
+            else:  # any iterable of batches goes through the per-batch path
+                eng.train_an_epoch(list(loader), 0)
+        text = out.getvalue()
+        assert "[Training Epoch 0], Loss" in text and "Execute [train_an_epoch]" in text
+        scal = dict((t, v) for t, v, _ in eng.writer.scalars) if hasattr(eng.writer, "scalars") else None
+        if scal is not None:
+            assert_scalar_close(scal["model/loss"], float(g["scalar_loss"][0]), 2e-5, "sum loss")
+            assert_scalar_close(scal["model/regularizer"], float(g["scalar_reg"][0]), 2e-5, "sum reg")
+        w = get_weights(eng)
+        tol = 2e-3 if opt == "adam" else 1e-6
+        for k in KEYS:
+            frac_bad = np.mean(np.abs(w[k] - g[f"w1/{k}"]) > tol)
+            assert frac_bad < 0.01, f"{mode} {k}: {frac_bad:.3%} elements differ (batch order?)"
+
+
+def test_epoch_per_batch_sequence(hip_device):
+    """Feed the reference's exact batches one by one: per-batch (loss, reg) sequence."""
+    g = load_golden("mf_epoch_sgd")
+    U, I, D, B, N, _ = (int(x) for x in g["meta"])
+    eng = make_engine(U, I, D, "sgd", "bpr", 0.05, B)
+    load_weights(eng, params(g, "w0"))
+    off = 0
+    for j, bs in enumerate(g["batch_sizes"]):
+        bt = g["batches"][:, off:off + bs]
+        off += bs
+        loss, reg = eng.train_single_batch(tuple(torch.from_numpy(bt[r]) for r in range(3)))
+        assert_scalar_close(loss, g["losses"][j], 2e-5, f"loss batch {j}")
+        assert_scalar_close(reg, g["regs"][j], 2e-5, f"reg batch {j}")
+    w = get_weights(eng)
+    for k in KEYS:
+        assert_tensor_close(w[k], g[f"w1/{k}"], 1e-5, f"final {k}")
+
+
+# ---- error behaviour ----------------------------------------------------------------------------
+
+def test_out_of_range_index_raises_indexerror(hip_device):
+    eng = make_engine(10, 10, 8, "sgd", "bpr", 0.1, 4)
+    ok = (torch.tensor([1, 2]), torch.tensor([3, 4]), torch.tensor([5, 6]))
+    eng.train_single_batch(ok)
+    with pytest.raises(IndexError):
+        eng.train_single_batch((torch.tensor([1, 10]), torch.tensor([3, 4]), torch.tensor([5, 6])))
+    with pytest.raises(IndexError):
+        eng.train_single_batch((torch.tensor([1, 2]), torch.tensor([3, -1]), torch.tensor([5, 6])))
+    loss, _ = eng.train_single_batch(ok)  # the engine stays usable
+    assert np.isfinite(loss)
+    with pytest.raises(IndexError):
+        eng.model.predict(np.array([0, 11]), np.array([0, 1]))
+
+
+def test_batch_of_one_and_bad_loss(hip_device):
+    eng = make_engine(10, 10, 8, "sgd", "bpr", 0.1, 4)
+    with pytest.raises(IndexError):  # quirk Q4
+        eng.train_single_batch((torch.tensor([1]), torch.tensor([3]), torch.tensor([5])))
+    eng.loss = "hinge"
+    with pytest.raises(RuntimeError, match="Unsupported loss type"):
+        eng.train_single_batch((torch.tensor([1, 2]), torch.tensor([3, 4]), torch.tensor([5, 6])))
+
+
+def test_checkpoint_roundtrip_on_device(hip_device, tmp_path):
+    eng = make_engine(20, 15, 16, "adam", "bpr", 0.05, 4)
+    batch = (torch.tensor([1, 2, 3]), torch.tensor([3, 4, 5]), torch.tensor([5, 6, 7]))
+    eng.train_single_batch(batch)
+    path = str(tmp_path / "mf.model")
+    eng.save_checkpoint(path)
+    sd = torch.load(path, map_location="cpu")
+    assert list(sd.keys()) == list(KEYS)
+    eng2 = make_engine(20, 15, 16, "adam", "bpr", 0.05, 4)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng2.resume_checkpoint(path)
+    for k in KEYS:
+        assert torch.equal(eng2.model.state_dict()[k].cpu(), sd[k])
+    assert eng2.model.flat.is_cuda and eng2.model.user_emb.weight.data_ptr() == eng2.model.flat.data_ptr()
+
+
+# ---- full size (BASELINE configs[1]: 6040 x 3706, dim 64, batch 4096) ----------------------------
+
+C2 = dict(U=6040, I=3706, D=64, B=4096)
+
+
+def c2_batch(seed):
+    rng = np.random.default_rng(seed)
+    U, I, B = C2["U"], C2["I"], C2["B"]
+    p = 1.0 / np.arange(1, I + 1)
+    p /= p.sum()
+    users = rng.integers(0, U, B)
+    pos = rng.permutation(I)[rng.choice(I, B, p=p)]
+    neg = rng.integers(0, I, B)
+    return users, pos, neg
+
+
+def test_full_size_step_vs_oracle(hip_device):
+    """One C2 batch: HIP loss / reg / dense gradients vs the numpy oracle, then an SGD step."""
+    w0 = onp.init_params(C2["U"], C2["I"], C2["D"], seed=3)
+    users, pos, neg = c2_batch(4)
+    loss_ref, reg_ref, g_ref = onp.mf_bpr_grads(w0, users, pos, neg)
+    eng = make_engine(C2["U"], C2["I"], C2["D"], "sgd", "bpr", 0.05, C2["B"])
+    load_weights(eng, w0)
+    batch = tuple(torch.from_numpy(a) for a in (users, pos, neg))
+    loss, reg, grads = eng.backward_only(batch)
+    assert_scalar_close(loss, loss_ref, what="loss")
+    assert_scalar_close(reg, reg_ref, what="reg")
+    for k in KEYS:
+        assert_tensor_close(grads[k].cpu().numpy(), g_ref[k], what=f"grad {k}",
+                            scale_floor=grad_scale_floor(k, C2["B"]))
+    # conservation: every per-triple term d+ + d- lands once in user_bias, item_bias, global_bias
+    gu = float(grads["user_bias.weight"].double().sum())
+    gi = float(grads["item_bias.weight"].double().sum())
+    gg = float(grads["global_bias"].double().sum())
+    assert abs(gu - gg) < 1e-6 and abs(gi - gg) < 1e-6
+    eng.train_single_batch(batch)
+    w = get_weights(eng)
+    w_ref = onp.copy_params(w0)
+    onp.opt_step(w_ref, g_ref, onp.new_opt_state(w_ref, "sgd"), "sgd", 0.05)
+    for k in KEYS:
+        assert_step_close(w0[k], w[k], w_ref[k], 0.0, what=f"sgd {k}")
+    untouched = np.setdiff1d(np.arange(C2["U"]), users)
+    assert np.array_equal(w["user_emb.weight"][untouched], w0["user_emb.weight"][untouched])
+
+
+@pytest.mark.parametrize("opt,lr", [("adam", 0.05), ("rmsprop", 0.01)])
+def test_full_size_dense_optimizer_vs_oracle(hip_device, opt, lr):
+    """Two chained C2 steps of a dense optimizer against the oracle (second step exercises
+    non-zero moments on rows the batch does not touch)."""
+    w_ref = onp.init_params(C2["U"], C2["I"], C2["D"], seed=5)
+    eng = make_engine(C2["U"], C2["I"], C2["D"], opt, "bpr", lr, C2["B"])
+    load_weights(eng, w_ref)
+    st = onp.new_opt_state(w_ref, opt)
+    for s in range(2):
+        users, pos, neg = c2_batch(10 + s)
+        w_prev = onp.copy_params(w_ref)
+        st_prev = {k: ({kk: vv.copy() for kk, vv in v.items()} if isinstance(v, dict) else v)
+                   for k, v in st.items()}
+        loss_ref, reg_ref, g_ref = onp.mf_bpr_grads(w_ref, users, pos, neg)
+        onp.opt_step(w_ref, g_ref, st, opt, lr)
+        load_weights(eng, w_prev)  # isolate the step: start from the oracle's state
+        eng.load_optimizer_state(s, st_prev.get("exp_avg"),
+                                 st_prev.get("exp_avg_sq", st_prev.get("square_avg")))
+        loss, reg = eng.train_single_batch(tuple(torch.from_numpy(a) for a in (users, pos, neg)))
+        assert_scalar_close(loss, loss_ref, what=f"loss {s}")
+        assert_scalar_close(reg, reg_ref, what=f"reg {s}")
+        band = optimizer_band(w_prev, st_prev, g_ref, opt, lr, C2["B"])
+        w = get_weights(eng)
+        for k in KEYS:
+            assert_step_close(w_prev[k], w[k], w_ref[k], band[k], what=f"{opt} {k} step {s}")
+
+
+def test_full_size_epoch_resident_equals_per_batch(hip_device):
+    """Idempotence of the batching layer at full size: the fused epoch driver (device-side
+    permutation) and the per-batch path fed with the same permutation give the same weights."""
+    import beta_recsys_amd as hp
+
+    rng = np.random.default_rng(0)
+    N = 3 * C2["B"] + 77
+    users = rng.integers(0, C2["U"], N)
+    pos = rng.integers(0, C2["I"], N)
+    neg = rng.integers(0, C2["I"], N)
+    w0 = onp.init_params(C2["U"], C2["I"], C2["D"], seed=9)
+    gen = torch.Generator().manual_seed(123)
+    batcher = hp.DeviceTripleBatcher(torch.from_numpy(users).cuda(), torch.from_numpy(pos).cuda(),
+                                     torch.from_numpy(neg).cuda(), C2["B"], generator=gen)
+    results = []
+    for mode in ("resident", "list"):
+        eng = make_engine(C2["U"], C2["I"], C2["D"], "sgd", "bpr", 0.05, C2["B"])
+        load_weights(eng, w0)
+        gen.manual_seed(123)
+        with contextlib.redirect_stdout(io.StringIO()):
+            eng.train_an_epoch(batcher if mode == "resident" else list(batcher), 0)
+        results.append((get_weights(eng), dict((t, v) for t, v, _ in eng.writer.scalars)))
+    (wa, sa), (wb, sb) = results
+    for k in KEYS:
+        assert_tensor_close(wa[k], wb[k], 1e-6, f"{k}")
+    assert_scalar_close(sa["model/loss"], sb["model/loss"], 1e-6, "epoch loss")
+    assert len(batcher) == 4
