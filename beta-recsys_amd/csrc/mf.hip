@@ -131,16 +131,8 @@ __global__ __launch_bounds__(kBlock) void mf_bpr_grad_kernel(
     gb_acc += dpos + dneg;
   }
 
-  // d(loss)/d(global_bias): one atomic per block
-  __shared__ float s_gb[kWavesPerBlock];
-  if (lane == 0) s_gb[wave_in_block()] = gb_acc;
-  publish_partials(loss_acc, reg_acc, inv_batch, scratch);  // contains a __syncthreads()
-  if (threadIdx.x == 0) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < kWavesPerBlock; ++i) s += s_gb[i];
-    if (s != 0.f) atomic_add_f32(g.global_bias, s);
-  }
+  // d(loss)/d(global_bias) goes out with the per-block partials (no same-address atomics)
+  publish_partials(loss_acc, reg_acc, gb_acc, inv_batch, scratch);
 }
 
 template <int NPL>
@@ -231,15 +223,7 @@ __global__ __launch_bounds__(kBlock) void mf_bce_grad_kernel(
     gb_acc += ds;
   }
 
-  __shared__ float s_gb[kWavesPerBlock];
-  if (lane == 0) s_gb[wave_in_block()] = gb_acc;
-  publish_partials(loss_acc, reg_acc, inv_batch, scratch);
-  if (threadIdx.x == 0) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < kWavesPerBlock; ++i) s += s_gb[i];
-    if (s != 0.f) atomic_add_f32(g.global_bias, s);
-  }
+  publish_partials(loss_acc, reg_acc, gb_acc, inv_batch, scratch);
 }
 
 // scores[k] = sigmoid(<U[u], I[i]> + bu + bi + g)   (MF.predict, mf.py:57-70)
@@ -321,12 +305,12 @@ __global__ __launch_bounds__(kBlock) void mf_sgd_rows_kernel(
               item_stamp + b, stamp, lane);
   }
   if (blockIdx.x == 0) {
+    const float gb_part = scratch ? finalize_partials(stats, scratch) : 0.f;
     if (threadIdx.x == 0) {
-      const float gv = *g.global_bias;
+      const float gv = *g.global_bias + gb_part;
       *w.global_bias = *w.global_bias - lr * gv;
       *g.global_bias = 0.f;
     }
-    if (scratch) finalize_partials(stats, scratch);
   }
 }
 

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(kBlock) void opt_dense_kernel(float* __restrict__ w
                                                            float* __restrict__ m,
                                                            float* __restrict__ v, int64_t n,
                                                            OptScalars s, hiprec_stats* stats,
-                                                           const Scratch* scratch) {
+                                                           const Scratch* scratch,
+                                                           int64_t scalar_index) {
   float step_size = s.lr, bc2_sqrt = 1.f;
   if constexpr (KIND == HIPREC_OPT_ADAM) {
     // bias_correction1 = 1 - beta1**t ; step_size = lr / bc1 ; bc2_sqrt = sqrt(1 - beta2**t)
@@ -59,11 +60,18 @@ __global__ __launch_bounds__(kBlock) void opt_dense_kernel(float* __restrict__ w
   const int64_t tid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   const int64_t n4 = n >> 2;
+  // The element at scalar_index (MF's global_bias) receives its gradient through the scratch
+  // partials of the preceding *_grad call.  Its 16-B vector (or tail element) is left out of the
+  // sweep and updated by thread 0 of block 0 once the partials are reduced.
+  const bool deferred = scratch != nullptr && scalar_index >= 0 && scalar_index < n;
+  const int64_t skip4 = (deferred && scalar_index < (n4 << 2)) ? (scalar_index >> 2) : -1;
+  const int64_t skip1 = (deferred && scalar_index >= (n4 << 2)) ? scalar_index : -1;
   float4* w4 = reinterpret_cast<float4*>(w);
   float4* g4 = reinterpret_cast<float4*>(g);
   float4* m4 = reinterpret_cast<float4*>(m);
   float4* v4 = reinterpret_cast<float4*>(v);
   for (int64_t i = tid; i < n4; i += stride) {
+    if (i == skip4) continue;
     float4 wv = w4[i], gv = g4[i];
     float4 mv = make_float4(0, 0, 0, 0), vv = make_float4(0, 0, 0, 0);
     if constexpr (KIND == HIPREC_OPT_ADAM) mv = m4[i];
@@ -77,8 +85,8 @@ __global__ __launch_bounds__(kBlock) void opt_dense_kernel(float* __restrict__ w
     if constexpr (KIND == HIPREC_OPT_ADAM) m4[i] = mv;
     if constexpr (KIND != HIPREC_OPT_SGD) v4[i] = vv;
   }
-  for (int64_t i = (n4 << 2) + tid; i < n; i += stride) {  // scalar tail (< 4 elements)
-    float wv = w[i], gv = g[i], mv = 0.f, vv = 0.f;
+  auto scalar_update = [&](int64_t i, float extra_g) {
+    float wv = w[i], gv = g[i] + extra_g, mv = 0.f, vv = 0.f;
     if constexpr (KIND == HIPREC_OPT_ADAM) mv = m[i];
     if constexpr (KIND != HIPREC_OPT_SGD) vv = v[i];
     opt_update<KIND>(wv, gv, mv, vv, s, step_size, bc2_sqrt);
@@ -86,8 +94,21 @@ __global__ __launch_bounds__(kBlock) void opt_dense_kernel(float* __restrict__ w
     g[i] = gv;
     if constexpr (KIND == HIPREC_OPT_ADAM) m[i] = mv;
     if constexpr (KIND != HIPREC_OPT_SGD) v[i] = vv;
+  };
+  for (int64_t i = (n4 << 2) + tid; i < n; i += stride) {  // scalar tail (< 4 elements)
+    if (i != skip1) scalar_update(i, 0.f);
   }
-  if (blockIdx.x == 0 && scratch) finalize_partials(stats, scratch);
+  if (blockIdx.x == 0 && scratch) {
+    const float gb_part = finalize_partials(stats, scratch);
+    if (threadIdx.x == 0 && deferred) {
+      if (skip4 >= 0) {
+        for (int64_t i = skip4 << 2; i < (skip4 << 2) + 4; ++i)
+          scalar_update(i, i == scalar_index ? gb_part : 0.f);
+      } else {
+        scalar_update(skip1, gb_part);
+      }
+    }
+  }
 }
 
 }  // namespace hiprec
@@ -96,7 +117,8 @@ using namespace hiprec;
 
 extern "C" int hiprec_opt_dense_step(int kind, float* w, float* g, float* m, float* v, int64_t n,
                                      double lr, double beta1, double beta2, double eps,
-                                     hiprec_stats* stats, const void* scratch, void* stream) {
+                                     hiprec_stats* stats, const void* scratch,
+                                     int64_t scalar_index, void* stream) {
   HIPREC_REQUIRE(w && g && stats, "NULL w/g/stats");
   HIPREC_REQUIRE(n >= 0, "negative n");
   HIPREC_REQUIRE((reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
@@ -115,15 +137,18 @@ extern "C" int hiprec_opt_dense_step(int kind, float* w, float* g, float* m, flo
   const auto* sc = static_cast<const Scratch*>(scratch);
   switch (kind) {
     case HIPREC_OPT_SGD:
-      opt_dense_kernel<HIPREC_OPT_SGD><<<grid, kBlock, 0, st>>>(w, g, m, v, n, s, stats, sc);
+      opt_dense_kernel<HIPREC_OPT_SGD><<<grid, kBlock, 0, st>>>(w, g, m, v, n, s, stats, sc,
+                                                                scalar_index);
       break;
     case HIPREC_OPT_ADAM:
       HIPREC_REQUIRE(m && v, "adam needs exp_avg / exp_avg_sq buffers");
-      opt_dense_kernel<HIPREC_OPT_ADAM><<<grid, kBlock, 0, st>>>(w, g, m, v, n, s, stats, sc);
+      opt_dense_kernel<HIPREC_OPT_ADAM><<<grid, kBlock, 0, st>>>(w, g, m, v, n, s, stats, sc,
+                                                                scalar_index);
       break;
     case HIPREC_OPT_RMSPROP:
       HIPREC_REQUIRE(v, "rmsprop needs a square_avg buffer");
-      opt_dense_kernel<HIPREC_OPT_RMSPROP><<<grid, kBlock, 0, st>>>(w, g, m, v, n, s, stats, sc);
+      opt_dense_kernel<HIPREC_OPT_RMSPROP><<<grid, kBlock, 0, st>>>(w, g, m, v, n, s, stats, sc,
+                                                                scalar_index);
       break;
     default:
       set_error("unknown optimizer kind %d", kind);

@@ -42,8 +42,10 @@ __global__ void stats_begin_epoch_kernel(hiprec_stats* s) {
 
 __global__ void stats_advance_kernel(hiprec_stats* s) { advance_step(s); }
 
-__global__ __launch_bounds__(kBlock) void finalize_kernel(hiprec_stats* s, const Scratch* sc) {
-  finalize_partials(s, sc);
+__global__ __launch_bounds__(kBlock) void finalize_kernel(hiprec_stats* s, const Scratch* sc,
+                                                          float* g_scalar) {
+  const float gb_part = finalize_partials(s, sc);
+  if (threadIdx.x == 0 && g_scalar) *g_scalar += gb_part;
 }
 
 // out[k, :] = table[idx[k], :] — a pure copy, hence bit-exact.  VEC floats per thread.
@@ -104,10 +106,11 @@ extern "C" int hiprec_stats_advance_step(hiprec_stats* stats, void* stream) {
   return 0;
 }
 
-extern "C" int hiprec_finalize_stats(hiprec_stats* stats, const void* scratch, void* stream) {
+extern "C" int hiprec_finalize_stats(hiprec_stats* stats, const void* scratch, float* g_scalar,
+                                     void* stream) {
   HIPREC_REQUIRE(stats && scratch, "NULL stats/scratch");
   finalize_kernel<<<1, kBlock, 0, static_cast<hipStream_t>(stream)>>>(
-      stats, static_cast<const Scratch*>(scratch));
+      stats, static_cast<const Scratch*>(scratch), g_scalar);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
@@ -162,7 +165,7 @@ extern "C" int hiprec_mf_bpr_epoch(const hiprec_mf_tables* w, const hiprec_mf_ta
                               scratch, stream);
     else
       rc = hiprec_opt_dense_step(kind, flat_w, flat_g, flat_m, flat_v, n_flat, lr, beta1, beta2,
-                                 eps, stats, scratch, stream);
+                                 eps, stats, scratch, w->global_bias - flat_w, stream);
     if (rc) return rc;
   }
   return 0;

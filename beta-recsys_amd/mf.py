@@ -420,7 +420,7 @@ class MFEngine(ModelEngine):
             _lib.check(lib.hiprec_opt_dense_step(
                 opt.kind, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),
                 _lib.ptr(opt.exp_avg_sq), m.flat.numel(), opt.lr, opt.beta1, opt.beta2, opt.eps,
-                _lib.ptr(self._stats), _lib.ptr(self._scratch), st))
+                _lib.ptr(self._stats), _lib.ptr(self._scratch), m.flat.numel() - 1, st))
 
     def backward_only(self, batch_data):
         """zero_grad + forward + backward WITHOUT the optimizer step (what autograd leaves in
@@ -430,8 +430,10 @@ class MFEngine(ModelEngine):
         users, a_items, third = self._prepare_batch(batch_data)
         lib = self._setup()
         self._enqueue_grad(lib, users, a_items, third)
+        g_global = self.model._views(self._g_flat)[4]
         _lib.check(lib.hiprec_finalize_stats(
-            _lib.ptr(self._stats), _lib.ptr(self._scratch), _lib.stream_ptr(self.model.flat.device)))
+            _lib.ptr(self._stats), _lib.ptr(self._scratch), _lib.ptr(g_global),
+            _lib.stream_ptr(self.model.flat.device)))
         st = self._sync_stats()
         ue, ie, ub, ib, gb = (v.clone() for v in self.model._views(self._g_flat))
         self._g_flat.zero_()
@@ -521,36 +523,56 @@ class MFEngine(ModelEngine):
         bs = train_loader.batch_size
         return users, pos, neg, perm, int(bs)
 
+    def prepare_epoch(self, train_loader):
+        """Stage one epoch's inputs in HBM: resident triple arrays + this epoch's visiting order.
+        Returns an opaque tuple for :meth:`run_prepared_epoch`, or None when the loader's data
+        cannot be batched on the device (then train_an_epoch falls back to iterating it)."""
+        if self.loss != "bpr":
+            return None
+        return self._resident_triples(train_loader)
+
+    def run_prepared_epoch(self, prepared, sync=True):
+        """Enqueue every step of a prepared epoch (hiprec_mf_bpr_epoch).  With ``sync=False`` nothing
+        is read back; call :meth:`epoch_stats` later."""
+        lib = self._setup()
+        users, pos, neg, perm, bs = prepared
+        n = users.numel()
+        n_run = n - 1 if n % bs == 1 else n  # Q4: a trailing batch of one raises (below)
+        m, opt = self.model, self.optimizer
+        w, g = m.tables(), m.tables(self._g_flat)
+        n_batches = (n_run + bs - 1) // bs
+        first = self._take_stamps(n_batches) if self._rows_sgd else 0
+        _lib.check(lib.hiprec_mf_bpr_epoch(
+            ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg),
+            _lib.ptr(perm), n_run, bs, float(self.reg), opt.kind, opt.lr, opt.beta1, opt.beta2,
+            opt.eps, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),
+            _lib.ptr(opt.exp_avg_sq), m.flat.numel(), _lib.ptr(self._user_stamp),
+            _lib.ptr(self._item_stamp), first, _lib.ptr(self._stats),
+            _lib.ptr(self._scratch), self._scratch.numel(), _lib.stream_ptr(m.flat.device)))
+        if not sync:
+            return None
+        st = self._sync_stats()
+        if n_run != n:
+            raise IndexError(
+                "Dimension out of range (expected to be in range of [-1, 0], but got 1)")
+        return st
+
+    def epoch_stats(self):
+        """Synchronise and return the device statistics (loss, reg, loss_sum, reg_sum, step)."""
+        return self._sync_stats()
+
     @timeit
     def train_an_epoch(self, train_loader, epoch_id):
         """mf.py:121-139.  One host sync per epoch instead of two per step."""
         assert hasattr(self, "model"), "Please specify the exact model !"
         self.model.train()
         lib = self._setup()
-        dev = self.model.flat.device
-        st_ptr = _lib.stream_ptr(dev)
-        resident = self._resident_triples(train_loader) if self.loss == "bpr" else None
-        if resident is not None:
-            users, pos, neg, perm, bs = resident
-            n = users.numel()
-            n_run = n - 1 if n % bs == 1 else n  # Q4: a trailing batch of one raises (below)
-            m, opt = self.model, self.optimizer
-            w, g = m.tables(), m.tables(self._g_flat)
-            n_batches = (n_run + bs - 1) // bs
-            first = self._take_stamps(n_batches) if self._rows_sgd else 0
-            _lib.check(lib.hiprec_mf_bpr_epoch(
-                ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg),
-                _lib.ptr(perm), n_run, bs, float(self.reg), opt.kind, opt.lr, opt.beta1, opt.beta2,
-                opt.eps, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),
-                _lib.ptr(opt.exp_avg_sq), m.flat.numel(), _lib.ptr(self._user_stamp),
-                _lib.ptr(self._item_stamp), first, _lib.ptr(self._stats),
-                _lib.ptr(self._scratch), self._scratch.numel(), st_ptr))
-            st = self._sync_stats()
-            if n_run != n:
-                raise IndexError(
-                    "Dimension out of range (expected to be in range of [-1, 0], but got 1)")
+        prepared = self.prepare_epoch(train_loader)
+        if prepared is not None:
+            st = self.run_prepared_epoch(prepared)
         else:
-            _lib.check(lib.hiprec_stats_begin_epoch(_lib.ptr(self._stats), st_ptr))
+            _lib.check(lib.hiprec_stats_begin_epoch(
+                _lib.ptr(self._stats), _lib.stream_ptr(self.model.flat.device)))
             for batch_data in train_loader:
                 self._enqueue_step(batch_data)
             st = self._sync_stats()

@@ -122,8 +122,10 @@ int hiprec_mf_bce_grad(const hiprec_mf_tables* w, const hiprec_mf_tables* g, con
                        void* scratch, size_t scratch_bytes, void* stream);
 
 /* Reduce the per-block partials left in scratch by the last *_grad call into stats
- * (loss, reg, loss_sum += loss, reg_sum += reg).  Only needed when no optimizer call follows. */
-int hiprec_finalize_stats(hiprec_stats* stats, const void* scratch, void* stream);
+ * (loss, reg, loss_sum += loss, reg_sum += reg) and add the scalar-bias gradient they carry to
+ * *g_scalar (the global_bias slot of `g`; may be NULL).  Only needed when no optimizer call
+ * follows: hiprec_opt_dense_step / hiprec_mf_sgd_rows do the same reduction themselves. */
+int hiprec_finalize_stats(hiprec_stats* stats, const void* scratch, float* g_scalar, void* stream);
 
 /* ---- dense optimizer step over one flat fp32 buffer (torch.optim.{SGD,Adam,RMSprop}.step with the
  * defaults torch_engine.py:23-39 leaves in place: Adam betas (0.9,0.999) eps 1e-8, RMSprop alpha
@@ -133,10 +135,12 @@ int hiprec_finalize_stats(hiprec_stats* stats, const void* scratch, void* stream
  * preceding *_grad call) and the running beta powers in stats (Adam: beta1/beta2 must equal the
  * values given to hiprec_stats_reset; RMSprop: beta2 = alpha).  Hyper-parameters are doubles, as
  * the python floats of the reference are, and are rounded to fp32 exactly where ATen rounds them.
- * When scratch != NULL it also finalizes the partials of the preceding *_grad call. */
+ * When scratch != NULL it also finalizes the partials of the preceding *_grad call; the gradient
+ * of the scalar parameter at w[scalar_index] (MF's global_bias; -1 = none) arrives through those
+ * partials and is added before that element is updated. */
 int hiprec_opt_dense_step(int kind, float* w, float* g, float* m, float* v, int64_t n, double lr,
                           double beta1, double beta2, double eps, hiprec_stats* stats,
-                          const void* scratch, void* stream);
+                          const void* scratch, int64_t scalar_index, void* stream);
 
 /* ---- exact SGD restricted to the rows a batch touched (SGD with momentum 0 leaves every other
  * row bit-identical: torch_engine.py:26-29).  For each distinct row of the batch:

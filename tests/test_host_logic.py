@@ -55,7 +55,8 @@ def test_bad_arguments_return_error_codes_without_a_gpu():
     lib = _lib.load()
     rc = lib.hiprec_gather_rows(None, 10, 4, None, 5, None, None, None)
     assert rc == -1 and b"NULL" in lib.hiprec_last_error()
-    rc = lib.hiprec_opt_dense_step(7, None, None, None, None, 4, 0.1, 0.9, 0.999, 1e-8, None, None, None)
+    rc = lib.hiprec_opt_dense_step(7, None, None, None, None, 4, 0.1, 0.9, 0.999, 1e-8, None, None, -1,
+                                   None)
     assert rc == -1
     with pytest.raises(_lib.HiprecError):
         _lib.check(rc)
