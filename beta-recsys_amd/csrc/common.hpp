@@ -14,6 +14,9 @@ constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kBlock = 256;        // 4 waves = one per SIMD
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kMaxBlocks = 2048;   // 256 CUs x 8 blocks; grid-stride beyond that
+constexpr int kAggWaves = 16;      // waves per block of the gradient kernels (one triple per wave)
+constexpr int kAggBlock = kAggWaves * kWave;
+constexpr int kAggMaxBlocks = 512; // 2 x 16-wave blocks per CU
 constexpr size_t kScratchBytes = 16 + sizeof(float) * 4 * kMaxBlocks;
 
 // scratch block layout: header + per-block {loss, reg, d(loss)/d(scalar bias), -} partial sums of
@@ -86,6 +89,10 @@ __device__ __forceinline__ int wave_in_block() {
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & 63; }
 
+__device__ __forceinline__ void lds_add_f32(float* p, float v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_f32
+}
+
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
   // lowers to global_atomic_add_f32 (no return) under -munsafe-fp-atomics
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -103,11 +110,12 @@ __device__ __forceinline__ float neg_logsigmoid(float x, float* sig_neg_x) {
 
 // Block-level reduction of per-wave values and publication of this block's partial sums.
 // `loss_w` and `gb_w` (already scaled by 1/B) are wave-uniform; `reg_lane` is a per-lane partial.
+template <int NW>
 __device__ __forceinline__ void publish_partials(float loss_w, float reg_lane, float gb_w,
                                                  float inv_batch, Scratch* scratch) {
-  __shared__ float s_loss[kWavesPerBlock];
-  __shared__ float s_reg[kWavesPerBlock];
-  __shared__ float s_gb[kWavesPerBlock];
+  __shared__ float s_loss[NW];
+  __shared__ float s_reg[NW];
+  __shared__ float s_gb[NW];
   float reg_w = wave_sum(reg_lane);
   const int w = wave_in_block();
   if (lane_id() == 0) {
@@ -119,7 +127,7 @@ __device__ __forceinline__ void publish_partials(float loss_w, float reg_lane, f
   if (threadIdx.x == 0) {
     float l = 0.f, r = 0.f, b = 0.f;
 #pragma unroll
-    for (int i = 0; i < kWavesPerBlock; ++i) {
+    for (int i = 0; i < NW; ++i) {
       l += s_loss[i];
       r += s_reg[i];
       b += s_gb[i];

@@ -253,6 +253,20 @@ class MF(nn.Module):
         return scores
 
 
+def sort_within_batches(perm, items, batch_size, n_items):
+    """Reorder each batch's slice of the visiting order so that equal items are adjacent.
+
+    Batch composition is unchanged (batch k still holds perm[k*bs:(k+1)*bs] as a set), and the
+    loss / gradient of a batch are sums over its triples, so only fp summation order moves.  The
+    gradient kernels merge adjacent equal items in LDS (csrc/mf.hip), which removes the same-row
+    atomic serialisation that popular (Zipf) items otherwise cause."""
+    n = items.numel()
+    idx = torch.arange(n, device=items.device) if perm is None else perm
+    key = torch.div(torch.arange(n, device=items.device), batch_size, rounding_mode="floor")
+    key = key * int(n_items) + items[idx]
+    return idx[torch.argsort(key)].contiguous()
+
+
 class DeviceTripleBatcher:
     """Device-resident replacement for ``DataLoader(PairwiseNegativeDataset, shuffle=True)``.
 
@@ -313,6 +327,7 @@ class MFEngine(ModelEngine):
     # SGD keeps every untouched row bit-identical, so it may either sweep the whole flat buffer
     # (cheap while it is cache-resident) or visit only the rows the batch touched.
     ROWS_SGD_MIN_BYTES = 64 << 20
+    SORT_MIN_BATCH = 256
 
     def __init__(self, config):
         self.config = config
@@ -378,6 +393,11 @@ class MFEngine(ModelEngine):
                 f"Unsupported loss type {self.loss}, try other options: 'bpr' or 'bce'"
             )
         B = users.numel()
+        if B >= self.SORT_MIN_BATCH and a_items.numel() == B and third.numel() == B:
+            # group equal (positive) items: the grad kernel merges adjacent duplicates in LDS
+            # before touching the dense gradient; a sum over the batch does not depend on order
+            order = torch.argsort(a_items)
+            users, a_items, third = users[order], a_items[order], third[order]
         if not (a_items.numel() == B and third.numel() == B):
             raise ValueError("batch tensors differ in length")
         if B == 0:
@@ -520,8 +540,10 @@ class MFEngine(ModelEngine):
         pos = ds.pos_item_tensor.to(dev, torch.int64).contiguous()
         neg = ds.neg_item_tensor.to(dev, torch.int64).contiguous()
         perm = None if perm is None else perm.to(dev).contiguous()
-        bs = train_loader.batch_size
-        return users, pos, neg, perm, int(bs)
+        bs = int(train_loader.batch_size)
+        if bs >= self.SORT_MIN_BATCH:
+            perm = sort_within_batches(perm, pos, bs, self.model.n_items)
+        return users, pos, neg, perm, bs
 
     def prepare_epoch(self, train_loader):
         """Stage one epoch's inputs in HBM: resident triple arrays + this epoch's visiting order.
