@@ -64,20 +64,22 @@ def stage(eng, batcher):
     return prepared
 
 
-def kernel_timing(eng, triples, n_launch=200):
+def kernel_timing(eng, prepared, n_launch=200):
     """Average duration of ONE launch of the dominant kernel (BPR grad: gather+score+scatter),
-    measured live with HIP events on the stream the kernel is launched on."""
+    measured live with HIP events on the stream the kernel is launched on.  It is launched exactly
+    as the epoch driver launches it: one batch of the staged epoch, read through perm[]."""
     import ctypes
 
     from beta_recsys_amd import _lib
 
     lib = eng._setup()
     m = eng.model
-    users, pos, neg = (t[:B].contiguous() for t in triples)
+    users, pos, neg, perm, _ = prepared
     w, g = m.tables(), m.tables(eng._g_flat)
     st = _lib.stream_ptr(m.flat.device)
-    args = (ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), None, B,
-            1.0 / B, 0.0, _lib.ptr(eng._stats), _lib.ptr(eng._scratch), eng._scratch.numel(), st)
+    args = (ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg),
+            _lib.ptr(perm), B, 1.0 / B, 0.0, _lib.ptr(eng._stats), _lib.ptr(eng._scratch),
+            eng._scratch.numel(), st)
     for _ in range(20):
         _lib.check(lib.hiprec_mf_bpr_grad(*args))
     torch.cuda.synchronize()
@@ -180,7 +182,7 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        k_mean, k_med = kernel_timing(eng, (users, pos, neg))
+        k_mean, k_med = kernel_timing(eng, prepared)
         bpt = algorithmic_bytes_per_triple(D)
         achieved = bpt * B / k_mean / 1e9
         out = {

@@ -543,6 +543,10 @@ class MFEngine(ModelEngine):
         bs = int(train_loader.batch_size)
         if bs >= self.SORT_MIN_BATCH:
             perm = sort_within_batches(perm, pos, bs, self.model.n_items)
+        if perm is not None:
+            # lay the epoch out in visiting order (what DataLoader's collate does per batch, done
+            # once per epoch on the device): the kernels then read their batch contiguously
+            users, pos, neg, perm = users[perm], pos[perm], neg[perm], None
         return users, pos, neg, perm, bs
 
     def prepare_epoch(self, train_loader):
