@@ -83,6 +83,15 @@ def kernel_timing(eng, prepared, n_launch=200):
     for _ in range(20):
         _lib.check(lib.hiprec_mf_bpr_grad(*args))
     torch.cuda.synchronize()
+    # (a) back-to-back launches between ONE event pair: duration + the ~1 us launch-to-launch gap
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n_launch):
+        _lib.check(lib.hiprec_mf_bpr_grad(*args))
+    b.record()
+    torch.cuda.synchronize()
+    back_to_back = a.elapsed_time(b) / n_launch * 1e-3
+    # (b) one event pair per launch: includes the event packets themselves (upper bound)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
            for _ in range(n_launch)]
     for a, b in evs:
@@ -93,7 +102,7 @@ def kernel_timing(eng, prepared, n_launch=200):
     per = sorted(a.elapsed_time(b) for a, b in evs)  # ms
     eng._g_flat.zero_()
     eng.load_optimizer_state(0)
-    return float(np.mean(per)) * 1e-3, float(per[len(per) // 2]) * 1e-3  # seconds: mean, median
+    return back_to_back, float(per[len(per) // 2]) * 1e-3  # seconds
 
 
 def cpu_baseline(budget_s=12.0):
@@ -214,8 +223,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": bpt * B,
-                "kernel_us_mean": k_mean * 1e6,
-                "kernel_us_median": k_med * 1e6,
+                "kernel_us": k_mean * 1e6,
+                "kernel_us_event_pair_median": k_med * 1e6,
                 "traffic": None,
                 "step_frac": (world * args.steps * B / dt) / world * bpt / (HBM_PEAK_GBS * 1e9),
             },

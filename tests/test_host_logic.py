@@ -187,3 +187,35 @@ def test_device_triple_batcher_composition():
     assert torch.cat([x[0] for x in seq]).tolist() == list(range(n))
     with pytest.raises(ValueError):
         hp.DeviceTripleBatcher(u, u[:-1], u, bs)
+
+
+def test_compat_install_routes_reference_imports(tmp_path, monkeypatch):
+    """A package laid out like beta_rec resolves `from ..models.mf import MFEngine` to the mirror."""
+    import importlib
+    import sys
+
+    import beta_recsys_amd as hp
+    from beta_recsys_amd import compat
+
+    root = tmp_path / "fake"
+    (root / "beta_rec" / "models").mkdir(parents=True)
+    (root / "beta_rec" / "recommenders").mkdir(parents=True)
+    (root / "beta_rec" / "__init__.py").write_text("")
+    (root / "beta_rec" / "models" / "__init__.py").write_text("")
+    (root / "beta_rec" / "models" / "mf.py").write_text("raise ImportError('the reference module must not load')\n")
+    (root / "beta_rec" / "recommenders" / "__init__.py").write_text("")
+    (root / "beta_rec" / "recommenders" / "matrix_factorization.py").write_text(
+        "from ..models.mf import MFEngine\nfrom beta_rec.models.torch_engine import ModelEngine\n")
+    monkeypatch.syspath_prepend(str(root))
+    saved = {k: v for k, v in sys.modules.items() if k.startswith("beta_rec")}
+    for k in saved:
+        del sys.modules[k]
+    try:
+        assert compat.install() == ["beta_rec.models.torch_engine", "beta_rec.models.mf"]
+        m = importlib.import_module("beta_rec.recommenders.matrix_factorization")
+        assert m.MFEngine is hp.MFEngine and m.ModelEngine is hp.ModelEngine
+    finally:
+        compat.uninstall()
+        for k in [k for k in sys.modules if k.startswith("beta_rec.") or k == "beta_rec"]:
+            del sys.modules[k]
+        sys.modules.update(saved)
