@@ -207,7 +207,7 @@ def test_compat_install_routes_reference_imports(tmp_path, monkeypatch):
     (root / "beta_rec" / "recommenders" / "matrix_factorization.py").write_text(
         "from ..models.mf import MFEngine\nfrom beta_rec.models.torch_engine import ModelEngine\n")
     monkeypatch.syspath_prepend(str(root))
-    saved = {k: v for k, v in sys.modules.items() if k.startswith("beta_rec")}
+    saved = {k: v for k, v in sys.modules.items() if k == "beta_rec" or k.startswith("beta_rec.")}
     for k in saved:
         del sys.modules[k]
     try:
