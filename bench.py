@@ -149,7 +149,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
-    dist_on = world > 1
+    # HIPREC_BENCH_FORCE_SHARDED=1 exercises the N>1 code path on a single GPU (world size 1)
+    dist_on = world > 1 or os.environ.get("HIPREC_BENCH_FORCE_SHARDED") == "1"
     if dist_on:
         import torch.distributed as dist
 
@@ -157,38 +158,66 @@ def main():
 
     import beta_recsys_amd as hp
 
-    # Path shards by independent triples: every rank trains its own shard of the interaction
-    # stream (weak scaling, per-GPU batch fixed at B).  See DESIGN.md (multi-GPU).
-    eng = make_engine(device, args.optimizer)
     n_total = (args.warmup + args.steps) * B
     users, pos, neg = (t.to(device) for t in synth_triples(n_total, seed=100 + rank))
     torch.manual_seed(7 + rank)  # device-side randperm per epoch
     nw = args.warmup * B
-    warm = hp.DeviceTripleBatcher(users[:nw], pos[:nw], neg[:nw], B)
-    timed = hp.DeviceTripleBatcher(users[nw:], pos[nw:], neg[nw:], B)
+    prepared = None
+    if not dist_on:
+        eng = make_engine(device, args.optimizer)
+        warm = hp.DeviceTripleBatcher(users[:nw], pos[:nw], neg[:nw], B)
+        timed = hp.DeviceTripleBatcher(users[nw:], pos[nw:], neg[nw:], B)
+        if args.warmup > 0:
+            eng.run_prepared_epoch(stage(eng, warm))
+        prepared = stage(eng, timed)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.run_prepared_epoch(prepared, sync=False)  # enqueues exactly args.steps steps
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert len(timed) == args.steps
+        st = eng.epoch_stats()
+        assert st.step == args.warmup + args.steps, (st.step, args.warmup + args.steps)
+        assert np.isfinite(st.loss_sum) and 0.3 < st.loss_sum / args.steps < 1.4, st.loss_sum
+    else:
+        # N > 1: tables row-sharded over the ranks (owner = row mod N), every rank feeds B triples
+        # per step (weak scaling, global batch N*B), triples / item rows / item gradients are
+        # routed with all-to-all over RCCL (beta-recsys_amd/sharded.py).
+        from beta_recsys_amd.sharded import ShardedMFEngine
 
-    if args.warmup > 0:
-        eng.run_prepared_epoch(stage(eng, warm))
-    prepared = stage(eng, timed)
-    torch.cuda.synchronize()
-    if dist_on:
+        cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str=str(device),
+                             optimizer=args.optimizer, lr=LR, batch_size=B, loss="bpr"),
+               "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
+        torch.manual_seed(2020)
+        with contextlib.redirect_stdout(io.StringIO()):
+            seng = ShardedMFEngine(cfg)
+        perm = torch.randperm(n_total, device=device)
+        users, pos, neg = users[perm], pos[perm], neg[perm]
+
+        def run(lo, n_steps):
+            last = None
+            for sidx in range(n_steps):
+                sl = slice(lo + sidx * B, lo + (sidx + 1) * B)
+                last = seng.train_single_batch((users[sl], pos[sl], neg[sl]), sync=False)
+            return last
+
+        run(0, args.warmup)
+        torch.cuda.synchronize()
         dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.run_prepared_epoch(prepared, sync=False)  # enqueues exactly args.steps steps
-    torch.cuda.synchronize()
-    if dist_on:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(nw, args.steps)
+        torch.cuda.synchronize()
         dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert len(timed) == args.steps
-    st = eng.epoch_stats()
-    assert st.step == args.warmup + args.steps, (st.step, args.warmup + args.steps)
-    assert np.isfinite(st.loss_sum) and 0.3 < st.loss_sum / args.steps < 1.4, st.loss_sum
-    if dist_on:
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        seng.k.check_status()
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if rank == 0:  # roofline of the dominant kernel: measured on a single-GPU engine
+            eng = make_engine(device, args.optimizer)
+            prepared = stage(eng, hp.DeviceTripleBatcher(users[:4 * B], pos[:4 * B], neg[:4 * B], B))
 
     if rank == 0:
         k_mean, k_med = kernel_timing(eng, prepared)
@@ -213,7 +242,9 @@ def main():
                             "positives, uniform negatives",
                 "optimizer": args.optimizer, "lr": LR, "loss": "bpr", "batch_per_gpu": B,
                 "global_batch": B * world,
-                "parallelism": "1 process per GPU" if world > 1 else "single GPU",
+                "parallelism": (f"row-sharded tables over {world} GPUs (owner = row mod {world}), "
+                                "all-to-all routing of triples / item rows / item gradients over RCCL"
+                                if world > 1 else "single GPU"),
             },
             "roofline": {
                 "bound": "hbm",

@@ -63,6 +63,7 @@ SIGNATURES = {
     "hiprec_stats_advance_step": (c_int, [_P, _P]),
     "hiprec_stats_begin_epoch": (c_int, [_P, _P]),
     "hiprec_gather_rows": (c_int, [_P, c_int64, c_int32, _P, c_int64, _P, _P, _P]),
+    "hiprec_scatter_add_rows": (c_int, [_P, c_int64, c_int32, _P, _P, c_int64, c_int64, _P, _P]),
     "hiprec_mf_predict": (c_int, [_T, _P, _P, c_int64, _P, _P, _P]),
     "hiprec_mf_bpr_grad": (
         c_int,

@@ -76,9 +76,45 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __rest
   }
 }
 
+// table[idx[k], :] += src[k, :]  (and nothing when idx[k] is out of range): the owner-side
+// accumulation of gradient rows returned by the all-to-all in the row-sharded engine.  One wave per
+// source row, lanes over columns, hardware fp32 atomics (rows of different peers may coincide).
+__global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(float* __restrict__ table,
+                                                                  int64_t n_rows, int dim,
+                                                                  const int64_t* __restrict__ idx,
+                                                                  const float* __restrict__ src,
+                                                                  int64_t src_stride, int64_t n,
+                                                                  hiprec_stats* stats) {
+  const int lane = lane_id();
+  const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  for (int64_t k = wave0; k < n; k += n_waves) {
+    const int64_t r = idx[k];
+    if (static_cast<uint64_t>(r) >= static_cast<uint64_t>(n_rows)) {
+      if (lane == 0) atomicOr(&stats->status, HIPREC_STATUS_ROW_OOB);
+      continue;
+    }
+    const float* s = src + k * src_stride;
+    float* d = table + r * dim;
+    for (int c = lane; c < dim; c += kWave) atomic_add_f32(d + c, s[c]);
+  }
+}
+
 }  // namespace hiprec
 
 using namespace hiprec;
+
+extern "C" int hiprec_scatter_add_rows(float* table, int64_t n_rows, int32_t dim,
+                                       const int64_t* idx, const float* src, int64_t src_stride,
+                                       int64_t n, hiprec_stats* stats, void* stream) {
+  HIPREC_REQUIRE(n >= 0 && n_rows > 0 && dim > 0 && src_stride >= dim, "bad sizes");
+  if (n == 0) return 0;
+  HIPREC_REQUIRE(table && idx && src && stats, "NULL pointer");
+  scatter_add_rows_kernel<<<grid_for_waves(n), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      table, n_rows, dim, idx, src, src_stride, n, stats);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
 
 extern "C" int hiprec_version(void) { return HIPREC_VERSION; }
 extern "C" const char* hiprec_last_error(void) { return g_err; }

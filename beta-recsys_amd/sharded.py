@@ -1,0 +1,295 @@
+"""Row-sharded BPR-MF training across the GPUs of one node.
+
+The reference is single-device only (no ``torch.distributed`` anywhere); this is the MI355X-native
+scale-out of the same step.  One process per GPU, ``torch.distributed`` over RCCL/xGMI (backend
+"nccl"); the CPU tests drive the same host code over gloo with the oracle standing in for the HIP
+kernels.
+
+Partitioning:  ``owner(row) = row mod R`` for BOTH tables (and their bias tables); local index
+``row // R``.  ``global_bias`` is replicated and its gradient all-reduced.
+
+One step on a global batch (every rank contributes its local batch ``b_r``; ``1/B`` uses the global
+``B`` so the result equals the single-process reference on the concatenated batch up to fp32
+summation order):
+
+    A2A-1  triples -> owner(user)                           24 B / triple
+    A2A-2  item ids -> owner(item), rows (+bias) back       2·(D+1)·4 B / triple
+    step   the single-GPU gradient kernel on (local user shard, fetched item rows)
+    A2A-3  item-row gradients -> owner(item), scatter-add   2·(D+1)·4 B / triple
+    all-reduce of (loss, reg, d loss / d global_bias)       3 floats
+    local dense optimizer sweep over the shard
+
+xGMI is point-to-point (7 links per GPU): an all-to-all drives all links at once, which is why the
+exchange is expressed as all-to-all rather than ring collectives.
+"""
+import contextlib
+import ctypes
+import io
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .mf import MF, _new_stats, raise_on_status, read_stats
+from .torch_engine import HipOptimizer
+
+KEYS = ("global_bias", "user_emb.weight", "item_emb.weight", "user_bias.weight", "item_bias.weight")
+
+
+def shard_rows(n_rows, rank, world):
+    """Number of rows owned by ``rank`` under owner(row) = row mod world."""
+    return (n_rows - rank + world - 1) // world
+
+
+class HipKernels:
+    """The product compute backend: libhiprec through the C ABI (no fallback)."""
+
+    def __init__(self, device):
+        if device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError(
+                "ShardedMFEngine computes through libhiprec.so on an MI355X; there is deliberately "
+                f"no CPU fallback (device {device})")
+        self.lib = _lib.load()
+        self.device = device
+        self.stats = _new_stats(device)
+        self.scratch = torch.zeros(self.lib.hiprec_scratch_bytes(0), dtype=torch.uint8, device=device)
+
+    def _st(self):
+        return _lib.stream_ptr(self.device)
+
+    def reset_clock(self, beta1, beta2):
+        _lib.check(self.lib.hiprec_stats_reset(_lib.ptr(self.stats), beta1, beta2, self._st()))
+
+    def gather_rows(self, table, idx):
+        out = torch.empty((idx.numel(), table.shape[1]), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.hiprec_gather_rows(
+            _lib.ptr(table), table.shape[0], table.shape[1], _lib.ptr(idx), idx.numel(),
+            _lib.ptr(out), _lib.ptr(self.stats), self._st()))
+        return out
+
+    def scatter_add_rows(self, table, idx, src):
+        _lib.check(self.lib.hiprec_scatter_add_rows(
+            _lib.ptr(table), table.shape[0], table.shape[1], _lib.ptr(idx), _lib.ptr(src),
+            src.stride(0), idx.numel(), _lib.ptr(self.stats), self._st()))
+
+    def bpr_grad(self, w, g, users, pos, neg, inv_batch, reg_coef):
+        """w / g: dicts of tensors keyed like state_dict (item tables = the fetched rows).
+        Returns a float32 tensor [loss_part, reg_part, d_global_bias_part] on the device."""
+        def tables(t):
+            return _lib.MfTables(
+                t["user_emb.weight"].data_ptr(), t["item_emb.weight"].data_ptr(),
+                t["user_bias.weight"].data_ptr(), t["item_bias.weight"].data_ptr(),
+                t["global_bias"].data_ptr(), t["user_emb.weight"].shape[0],
+                t["item_emb.weight"].shape[0], t["user_emb.weight"].shape[1], 0)
+
+        wt, gt = tables(w), tables(g)
+        gb_part = torch.zeros(1, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.hiprec_mf_bpr_grad(
+            ctypes.byref(wt), ctypes.byref(gt), _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), None,
+            users.numel(), inv_batch, reg_coef, _lib.ptr(self.stats), _lib.ptr(self.scratch),
+            self.scratch.numel(), self._st()))
+        _lib.check(self.lib.hiprec_finalize_stats(
+            _lib.ptr(self.stats), _lib.ptr(self.scratch), _lib.ptr(gb_part), self._st()))
+        head = self.stats[:8].view(torch.float32)  # hiprec_stats.loss, .reg
+        return torch.cat([head, gb_part])
+
+    def advance_clock(self):
+        """A rank that received no triple this step still has to tick the optimizer clock."""
+        _lib.check(self.lib.hiprec_stats_advance_step(_lib.ptr(self.stats), self._st()))
+
+    def opt_step(self, opt, flat_w, flat_g, step):
+        # the clock is advanced by bpr_grad (one grad call per step), `step` is informational
+        _lib.check(self.lib.hiprec_opt_dense_step(
+            opt.kind, _lib.ptr(flat_w), _lib.ptr(flat_g), _lib.ptr(opt.exp_avg),
+            _lib.ptr(opt.exp_avg_sq), flat_w.numel(), opt.lr, opt.beta1, opt.beta2, opt.eps,
+            _lib.ptr(self.stats), None, -1, self._st()))
+
+    def check_status(self):
+        st = read_stats(self.stats)
+        if st.status:
+            raw = self.stats.cpu()
+            off = _lib.Stats.status.offset
+            raw[off:off + 4] = 0
+            self.stats.copy_(raw)
+            raise_on_status(st.status)
+
+
+class ShardedMFEngine:
+    """BPR-MF with row-sharded tables; the surface follows ``MFEngine`` where it makes sense."""
+
+    def __init__(self, config, process_group=None, kernels=None, full_state=None):
+        self.config = config
+        self.pg = process_group
+        self.world = dist.get_world_size(self.pg)
+        self.rank = dist.get_rank(self.pg)
+        mc = config["model"]
+        self.n_users, self.n_items, self.emb_dim = int(mc["n_users"]), int(mc["n_items"]), int(mc["emb_dim"])
+        self.device = torch.device(mc["device_str"])
+        self.loss = mc["loss"] if "loss" in mc else "bpr"
+        if self.loss != "bpr":
+            raise RuntimeError(f"Unsupported loss type {self.loss} for the sharded engine: 'bpr' only")
+        self.reg = config["model"]["reg"] if "reg" in config else 0.0  # quirk Q1, as MFEngine
+        self.optimizer = HipOptimizer(mc["optimizer"], mc["lr"])
+        R, r = self.world, self.rank
+        local_cfg = dict(mc)
+        local_cfg["n_users"] = shard_rows(self.n_users, r, R)
+        local_cfg["n_items"] = shard_rows(self.n_items, r, R)
+        if full_state is None:
+            # Same initial model on every world size: draw the full tables like the single-process
+            # model does (same torch seed -> same weights), keep this rank's rows.
+            with contextlib.redirect_stdout(io.StringIO()):
+                full = MF(dict(mc, device_str="cpu"))
+            full_state = full.state_dict()
+        with torch.random.fork_rng(devices=[]):
+            self.model = MF(local_cfg)
+        self.load_full_state_dict(full_state)
+        self.model.to(self.device)
+        self.k = kernels if kernels is not None else HipKernels(self.device)
+        self.k.reset_clock(self.optimizer.beta1 or 0.9, self.optimizer.beta2 or 0.999)
+        self._g_flat = torch.zeros_like(self.model.flat)
+        self.optimizer.allocate_state(self.model.flat)
+        self.step_count = 0
+        self.last = (float("nan"), float("nan"))
+
+    # ---- state ------------------------------------------------------------------------------
+    def load_full_state_dict(self, full_state):
+        """Keep rows ``rank::world`` of a full (reference-format) state_dict."""
+        R, r = self.world, self.rank
+        local = {}
+        for k in KEYS:
+            v = torch.as_tensor(full_state[k], dtype=torch.float32)
+            local[k] = v if k == "global_bias" else v[r::R]
+        self.model.load_state_dict(local)
+
+    def gather_full_state_dict(self):
+        """All-gather the shards into a reference-compatible state_dict (every rank gets it; rank 0
+        typically ``torch.save``s it — the checkpoint format of torch_engine.py:70-73)."""
+        R = self.world
+        full = {}
+        for k, v in self.model.state_dict().items():
+            if k == "global_bias":
+                full[k] = v.detach().clone()
+                continue
+            n_total = self.n_users if k.startswith("user") else self.n_items
+            rows_max = shard_rows(n_total, 0, R)
+            pad = torch.zeros((rows_max,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+            pad[: v.shape[0]] = v
+            parts = [torch.empty_like(pad) for _ in range(R)]
+            dist.all_gather(parts, pad, group=self.pg)
+            out = torch.empty((n_total,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+            for q in range(R):
+                out[q::R] = parts[q][: shard_rows(n_total, q, R)]
+            full[k] = out
+        return full
+
+    # ---- exchange helpers -------------------------------------------------------------------
+    def _exchange_counts(self, counts):
+        """counts[q] = how many items I send to rank q  ->  how many I receive from each rank."""
+        recv = torch.empty_like(counts)
+        dist.all_to_all_single(recv, counts, group=self.pg)
+        return recv
+
+    def _a2a(self, send, send_counts, recv_counts):
+        """Variable-size all-to-all of rows (first dim split by the per-rank counts)."""
+        out = torch.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype,
+                          device=send.device)
+        dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(recv_counts),
+                               input_split_sizes=list(send_counts), group=self.pg)
+        return out
+
+    def _bucket(self, owner):
+        """Stable grouping by destination rank: (order, send_counts host list)."""
+        order = torch.argsort(owner, stable=True)
+        counts = torch.bincount(owner, minlength=self.world)
+        return order, counts
+
+    # ---- one step ---------------------------------------------------------------------------
+    def train_single_batch(self, batch_data, sync=True):
+        """One optimisation step on the GLOBAL batch formed by every rank's ``batch_data``.
+        Returns ``(loss, regularizer)`` of the global batch (identical on every rank)."""
+        R = self.world
+        dev = self.device
+        users, pos, neg = (torch.as_tensor(x, device=dev).to(torch.int64).contiguous()
+                           for x in batch_data)
+        b_local = torch.tensor([users.numel()], dtype=torch.int64, device=dev)
+        dist.all_reduce(b_local, group=self.pg)
+        B = int(b_local.item())
+        if B < 2:
+            raise IndexError("Dimension out of range (expected to be in range of [-1, 0], but got 1)")
+
+        # A2A-1: triples to the rank that owns the user row
+        order, counts = self._bucket(users % R)
+        send = torch.stack([users, pos, neg], dim=1)[order]
+        recv_counts = self._exchange_counts(counts)
+        sc, rc = counts.tolist(), recv_counts.tolist()
+        mine = self._a2a(send, sc, rc)
+        u_g, p_g, n_g = mine[:, 0].contiguous(), mine[:, 1].contiguous(), mine[:, 2].contiguous()
+        b_r = u_g.numel()
+
+        # A2A-2: fetch the item rows (slot k = pos of triple k, slot b_r + k = its neg)
+        items = torch.cat([p_g, n_g])
+        iorder, icounts = self._bucket(items % R)
+        req = items[iorder]
+        irecv_counts = self._exchange_counts(icounts)
+        isc, irc = icounts.tolist(), irecv_counts.tolist()
+        incoming = self._a2a(req, isc, irc)          # ids of MY rows that peers ask for
+        m = self.model
+        local_idx = torch.div(incoming, R, rounding_mode="floor")
+        D = self.emb_dim
+        payload = torch.cat([self.k.gather_rows(m.item_emb.weight.data, local_idx),
+                             self.k.gather_rows(m.item_bias.weight.data, local_idx)], dim=1)
+        fetched_sorted = self._a2a(payload, irc, isc)   # rows come back in request order
+        fetched = torch.empty_like(fetched_sorted)
+        fetched[iorder] = fetched_sorted
+
+        # the single-GPU gradient kernel on (local user shard, fetched item rows)
+        w = {"user_emb.weight": m.user_emb.weight.data, "user_bias.weight": m.user_bias.weight.data,
+             "global_bias": m.global_bias.data,
+             "item_emb.weight": fetched[:, :D].contiguous(),
+             "item_bias.weight": fetched[:, D:].contiguous()}
+        gue, gie, gub, gib, ggb = m._views(self._g_flat)
+        g_rows = torch.zeros((2 * b_r, D), dtype=torch.float32, device=dev)
+        g_bias = torch.zeros((2 * b_r, 1), dtype=torch.float32, device=dev)
+        g = {"user_emb.weight": gue, "user_bias.weight": gub, "global_bias": ggb,
+             "item_emb.weight": g_rows, "item_bias.weight": g_bias}
+        slots = torch.arange(2 * b_r, dtype=torch.int64, device=dev)
+        u_loc = torch.div(u_g, R, rounding_mode="floor")
+        if b_r > 0:
+            part = self.k.bpr_grad(w, g, u_loc, slots[:b_r].contiguous(), slots[b_r:].contiguous(),
+                                   1.0 / B, float(self.reg))
+        else:
+            part = torch.zeros(3, dtype=torch.float32, device=dev)
+            self.k.advance_clock()
+
+        # A2A-3: item-row gradients back to their owners, scatter-add into the local dense gradient
+        gpayload = torch.cat([g_rows, g_bias], dim=1)[iorder]
+        gincoming = self._a2a(gpayload, isc, irc)
+        if gincoming.shape[0] > 0:
+            self.k.scatter_add_rows(gie, local_idx, gincoming[:, :D])
+            self.k.scatter_add_rows(gib, local_idx, gincoming[:, D:])
+
+        # loss, regularizer and d loss / d global_bias are sums over all ranks
+        dist.all_reduce(part, group=self.pg)
+        ggb += part[2]
+        self.step_count += 1
+        self.k.opt_step(self.optimizer, m.flat, self._g_flat, self.step_count)
+        if not sync:
+            self._pending = part
+            return None
+        self.k.check_status()
+        loss, reg = float(part[0]), float(part[1])
+        self.last = (loss, reg)
+        return loss, reg
+
+    def train_an_epoch(self, train_loader, epoch_id):
+        """Every rank iterates its own shard of the interaction stream; all loaders must yield the
+        same number of batches (one collective step per batch)."""
+        total_loss, total_reg, loss = 0.0, 0.0, float("nan")
+        for batch in train_loader:
+            loss, reg = self.train_single_batch(batch)
+            total_loss += loss
+            total_reg += reg
+        if self.rank == 0:
+            print(f"[Training Epoch {epoch_id}], Loss {loss}, Regularizer {total_reg}")
+        return total_loss, total_reg

@@ -96,6 +96,14 @@ int hiprec_stats_begin_epoch(hiprec_stats* stats, void* stream);
 int hiprec_gather_rows(const float* table, int64_t n_rows, int32_t dim, const int64_t* idx,
                        int64_t n, float* out, hiprec_stats* stats, void* stream);
 
+/* ---- table[idx[k], :] += src[k, 0:dim]  (src rows are src_stride floats apart).  Owner-side
+ *      accumulation of the gradient rows that come back through the all-to-all of the row-sharded
+ *      engine; the single-process reference does this inside
+ *      embedding_dense_backward (mf.py:117). */
+int hiprec_scatter_add_rows(float* table, int64_t n_rows, int32_t dim, const int64_t* idx,
+                            const float* src, int64_t src_stride, int64_t n, hiprec_stats* stats,
+                            void* stream);
+
 /* ---- MF forward for scoring: MF.predict / MF.forward under no_grad (mf.py:32-48, 57-70).
  *      scores[k] = sigmoid(<U[u_k], I[i_k]> + bu[u_k] + bi[i_k] + g) */
 int hiprec_mf_predict(const hiprec_mf_tables* w, const int64_t* users, const int64_t* items,

@@ -58,15 +58,21 @@ def _scatter_forward_grads(g, users, items, ds, cache, reg_coef, B):
     g["global_bias"][0] += ds.sum(dtype=F32)
 
 
-def mf_bpr_grads(w, users, pos, neg, reg_coef=0.0):
+def mf_bpr_grads(w, users, pos, neg, reg_coef=0.0, global_batch=None):
     """BPR branch of MFEngine.train_single_batch (models/mf.py:101-107,116-117) + bpr_loss
-    (models/torch_engine.py:104-105): returns (loss, regularizer, dense grads)."""
+    (models/torch_engine.py:104-105): returns (loss, regularizer, dense grads).
+
+    ``global_batch``: when these triples are only one rank's part of a larger batch, the mean is
+    over that global batch (the returned loss / regularizer / grads are then this part's share)."""
     users, pos, neg = (np.asarray(a, dtype=np.int64) for a in (users, pos, neg))
-    B = len(users)
+    B = len(users) if global_batch is None else int(global_batch)
     yp, reg_p, cp = mf_forward(w, users, pos)
     yn, reg_n, cn = mf_forward(w, users, neg)
+    if global_batch is not None:
+        scale = F32(len(users)) / F32(B)
+        reg_p, reg_n = F32(reg_p * scale), F32(reg_n * scale)
     x = (yp - yn).astype(F32)
-    loss = F32(-logsigmoid(x).mean(dtype=F32))
+    loss = F32(-logsigmoid(x).sum(dtype=F32) / F32(B))
     # d/dx of -mean(logsigmoid(x)) = -sigmoid(-x)/B
     delta = (-sigmoid(-x) / F32(B)).astype(F32)
     d_pos = (delta * (yp * (F32(1) - yp))).astype(F32)

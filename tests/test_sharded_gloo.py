@@ -1,0 +1,138 @@
+"""World-size-2 test of the row-sharded engine's HOST logic on CPU (gloo): triple routing, item-row
+fetch, gradient return, all-reduce, shard bookkeeping.  The HIP kernels cannot run here, so the
+oracle stands in for them through the engine's kernel-backend seam (tests may use the oracle; the
+product default is HipKernels, which refuses to run without a GPU)."""
+import contextlib
+import io
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import KEYS, assert_scalar_close, assert_tensor_close
+from oracle import mf_numpy as onp
+
+
+class OracleKernels:
+    """numpy-oracle implementation of the sharded engine's kernel backend (CPU tensors)."""
+
+    def __init__(self):
+        self.st = None
+
+    def reset_clock(self, beta1, beta2):
+        self.clock = 0
+
+    def gather_rows(self, table, idx):
+        return table[idx].clone()
+
+    def scatter_add_rows(self, table, idx, src):
+        table.index_add_(0, idx, src.contiguous())
+
+    def bpr_grad(self, w, g, users, pos, neg, inv_batch, reg_coef):
+        wn = {k: v.numpy() for k, v in w.items()}
+        B = int(round(1.0 / inv_batch))
+        loss, reg, grads = onp.mf_bpr_grads(wn, users.numpy(), pos.numpy(), neg.numpy(), reg_coef,
+                                            global_batch=B)
+        for k in ("user_emb.weight", "item_emb.weight", "user_bias.weight", "item_bias.weight"):
+            g[k] += torch.from_numpy(grads[k])
+        self.clock += 1
+        return torch.tensor([loss, reg, grads["global_bias"][0]], dtype=torch.float32)
+
+    def advance_clock(self):
+        self.clock += 1
+
+    def opt_step(self, opt, flat_w, flat_g, step):
+        if self.st is None:
+            self.st = onp.new_opt_state({"flat": flat_w.numpy()}, opt.name)
+        w = {"flat": flat_w.numpy()}  # shares memory with the tensor: in-place update
+        onp.opt_step(w, {"flat": flat_g.numpy()}, self.st, opt.name, opt.lr)
+        flat_g.zero_()
+
+    def check_status(self):
+        pass
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def make_config(U, I, D, optimizer, lr):
+    return {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cpu", optimizer=optimizer,
+                          lr=lr, batch_size=8, loss="bpr"),
+            "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+
+
+def worker(rank, world, port, optimizer, lr, splits, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import beta_recsys_amd  # noqa: F401
+        from beta_recsys_amd.sharded import ShardedMFEngine
+
+        U, I, D = 23, 19, 8
+        w0 = onp.init_params(U, I, D, seed=7)
+        rng = np.random.default_rng(100)
+        with contextlib.redirect_stdout(io.StringIO()):
+            eng = ShardedMFEngine(make_config(U, I, D, optimizer, lr), kernels=OracleKernels(),
+                                  full_state={k: torch.from_numpy(v) for k, v in w0.items()})
+        losses = []
+        batches = []
+        for split in splits:
+            B = sum(split)
+            users, pos, neg = rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)
+            pos[: B // 3] = pos[0]  # a popular item: many rows fetched from one owner
+            batches.append((users, pos, neg))
+            lo = sum(split[:rank])
+            sl = slice(lo, lo + split[rank])
+            losses.append(eng.train_single_batch((users[sl], pos[sl], neg[sl])))
+        full = eng.gather_full_state_dict()
+        if rank == 0:
+            torch.save({"losses": losses, "full": {k: v.numpy() for k, v in full.items()},
+                        "batches": batches, "w0": w0}, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("optimizer,lr", [("sgd", 0.1), ("adam", 0.05), ("rmsprop", 0.01)])
+def test_two_rank_sharded_step_equals_single_process(tmp_path, optimizer, lr):
+    splits = [(10, 10), (13, 7), (20, 0), (1, 1)]  # even, uneven, one empty rank, tiny
+    out_path = str(tmp_path / "out.pt")
+    mp.spawn(worker, args=(2, free_port(), optimizer, lr, splits, out_path), nprocs=2, join=True)
+    res = torch.load(out_path, weights_only=False)
+    w = onp.copy_params(res["w0"])
+    st = onp.new_opt_state(w, optimizer)
+    for (users, pos, neg), (loss, reg) in zip(res["batches"], res["losses"]):
+        ref_loss, ref_reg = onp.mf_train_step(w, st, (users, pos, neg), "bpr", optimizer, lr)
+        assert_scalar_close(loss, ref_loss, 2e-5, "loss")
+        assert_scalar_close(reg, ref_reg, 2e-5, "reg")
+    tol = 1e-6 if optimizer == "sgd" else 2e-3
+    for k in KEYS:
+        frac_bad = np.mean(np.abs(res["full"][k] - w[k]) > tol)
+        assert frac_bad < 0.01, f"{k}: {frac_bad:.2%} of elements differ from the single-process run"
+        assert res["full"][k].shape == w[k].shape
+
+
+def test_shard_bookkeeping():
+    from beta_recsys_amd.sharded import shard_rows
+
+    for n in (1, 7, 8, 23, 6040):
+        for world in (1, 2, 3, 8):
+            sizes = [shard_rows(n, r, world) for r in range(world)]
+            assert sum(sizes) == n
+            assert sizes == [len(range(r, n, world)) for r in range(world)]
+
+
+def test_sharded_engine_refuses_cpu_without_backend():
+    """The product backend is HIP-only: constructing it on a CPU device fails loudly."""
+    from beta_recsys_amd.sharded import HipKernels
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        HipKernels(torch.device("cpu"))
