@@ -137,6 +137,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adam", "rmsprop"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--multi-gpu", default="auto", choices=["auto", "replicated", "sharded"],
+                    help="N>1: replicate small tables (gradient all-reduce) or row-shard them "
+                         "(all-to-all routing); auto = replicated below 64 MB of parameters")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,22 +186,33 @@ def main():
         # N > 1: tables row-sharded over the ranks (owner = row mod N), every rank feeds B triples
         # per step (weak scaling, global batch N*B), triples / item rows / item gradients are
         # routed with all-to-all over RCCL (beta-recsys_amd/sharded.py).
+        from beta_recsys_amd.replicated import ReplicatedMFEngine
         from beta_recsys_amd.sharded import ShardedMFEngine
 
         cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str=str(device),
                              optimizer=args.optimizer, lr=LR, batch_size=B, loss="bpr"),
                "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
+        param_bytes = 4 * ((U + I) * (D + 1) + 1)
+        mode = args.multi_gpu
+        if mode == "auto":
+            mode = "replicated" if param_bytes < (64 << 20) else "sharded"
         torch.manual_seed(2020)
         with contextlib.redirect_stdout(io.StringIO()):
-            seng = ShardedMFEngine(cfg)
+            seng = ShardedMFEngine(cfg) if mode == "sharded" else ReplicatedMFEngine(cfg)
         perm = torch.randperm(n_total, device=device)
         users, pos, neg = users[perm], pos[perm], neg[perm]
+        if mode == "sharded":
+            step_fn = lambda batch: seng.train_single_batch(batch, sync=False)  # noqa: E731
+            check_fn = seng.k.check_status
+        else:
+            step_fn = seng._enqueue_step
+            check_fn = seng.epoch_stats
 
         def run(lo, n_steps):
             last = None
             for sidx in range(n_steps):
                 sl = slice(lo + sidx * B, lo + (sidx + 1) * B)
-                last = seng.train_single_batch((users[sl], pos[sl], neg[sl]), sync=False)
+                last = step_fn((users[sl], pos[sl], neg[sl]))
             return last
 
         run(0, args.warmup)
@@ -211,7 +225,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        seng.k.check_status()
+        check_fn()
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -219,6 +233,13 @@ def main():
             eng = make_engine(device, args.optimizer)
             prepared = stage(eng, hp.DeviceTripleBatcher(users[:4 * B], pos[:4 * B], neg[:4 * B], B))
 
+    parallelism = "single GPU"
+    if dist_on:
+        parallelism = (f"row-sharded tables over {world} GPUs (owner = row mod {world}), all-to-all "
+                       "routing of triples / item rows / item gradients over RCCL"
+                       if mode == "sharded" else
+                       f"dp{world}: replicated 2.5 MB tables, one RCCL all-reduce of the dense "
+                       "gradient per step, global batch = N x 4096")
     if rank == 0:
         k_mean, k_med = kernel_timing(eng, prepared)
         bpt = algorithmic_bytes_per_triple(D)
@@ -242,9 +263,7 @@ def main():
                             "positives, uniform negatives",
                 "optimizer": args.optimizer, "lr": LR, "loss": "bpr", "batch_per_gpu": B,
                 "global_batch": B * world,
-                "parallelism": (f"row-sharded tables over {world} GPUs (owner = row mod {world}), "
-                                "all-to-all routing of triples / item rows / item gradients over RCCL"
-                                if world > 1 else "single GPU"),
+                "parallelism": parallelism,
             },
             "roofline": {
                 "bound": "hbm",

@@ -1,0 +1,97 @@
+"""Data-parallel BPR-MF with REPLICATED tables: the multi-GPU mode for tables that fit one GPU's
+caches (BASELINE configs[1]: 2.5 MB of parameters).
+
+Sharding a 2.5 MB model (sharded.py) costs three dependent all-to-alls per 12-µs step; for small
+tables it is cheaper to keep a full replica per GPU, let every rank run the fused gradient kernel
+on its own batch shard and sum the dense gradients with ONE all-reduce over RCCL/xGMI:
+
+    grad kernel on the local b triples, 1/B with the GLOBAL batch B = world · b
+    all-reduce( [ dense gradient | loss part | reg part ] )        (P + 2 floats, one collective)
+    identical dense optimizer sweep on every replica
+
+The sum over ranks of per-rank partial gradients (each scaled by the global 1/B) is exactly the
+reference's gradient on the concatenated global batch, so the replicas stay bit-identical to each
+other and equal to the single-process result up to fp32 summation order (SURVEY.md §8e semantics).
+Large tables (BASELINE configs[3]) use the row-sharded engine instead.
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .mf import MFEngine, read_stats
+
+
+def allreduce_sum_(buf, group=None):
+    """In-place sum of ``buf`` over the process group (RCCL on GPUs, gloo in the CPU tests)."""
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf
+
+
+class ReplicatedMFEngine(MFEngine):
+    """``MFEngine`` whose step sums gradients over a process group before the optimizer sweep."""
+
+    def __init__(self, config, process_group=None):
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        super().__init__(config)
+        # every replica starts from rank 0's weights (the same seed gives the same init anyway)
+        if self.model.flat.device.type == "cuda":
+            dist.broadcast(self.model.flat, src=0, group=self.pg)
+
+    def _setup(self):
+        fresh = not self._buffers_ready
+        lib = super()._setup()
+        if fresh or self._g_ext.device != self.model.flat.device:
+            P = self.model.flat.numel()
+            # gradient accumulator with two trailing slots for the (loss, reg) partial sums so that
+            # one collective moves everything
+            self._g_ext = torch.zeros(P + 2, dtype=torch.float32, device=self.model.flat.device)
+            self._g_flat = self._g_ext[:P]
+            self._epoch_acc = torch.zeros(2, dtype=torch.float64, device=self.model.flat.device)
+            self._rows_sgd = False  # replicas always take the dense sweep
+        return lib
+
+    def _enqueue_step(self, batch_data):
+        users, a_items, third = self._prepare_batch(batch_data)
+        lib = self._setup()
+        m, opt = self.model, self.optimizer
+        dev = m.flat.device
+        st = _lib.stream_ptr(dev)
+        P = m.flat.numel()
+        w, g = m.tables(), m.tables(self._g_flat)
+        B_global = users.numel() * self.world  # every rank feeds the same local batch size
+        fn = lib.hiprec_mf_bpr_grad if self.loss == "bpr" else lib.hiprec_mf_bce_grad
+        _lib.check(fn(
+            ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(a_items), _lib.ptr(third),
+            None, users.numel(), 1.0 / B_global, float(self.reg), _lib.ptr(self._stats),
+            _lib.ptr(self._scratch), self._scratch.numel(), st))
+        _lib.check(lib.hiprec_finalize_stats(
+            _lib.ptr(self._stats), _lib.ptr(self._scratch), _lib.ptr(self._g_ext[P - 1:]), st))
+        head = self._stats[:8].view(torch.float32)          # this rank's (loss, reg) share
+        self._g_ext[P:].copy_(head)
+        allreduce_sum_(self._g_ext, self.pg)
+        head.copy_(self._g_ext[P:])                          # stats now hold the global values
+        self._epoch_acc += self._g_ext[P:].double()
+        _lib.check(lib.hiprec_opt_dense_step(
+            opt.kind, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),
+            _lib.ptr(opt.exp_avg_sq), P, opt.lr, opt.beta1, opt.beta2, opt.eps,
+            _lib.ptr(self._stats), None, -1, st))
+
+    def prepare_epoch(self, train_loader):
+        """Replicas iterate their loader batch by batch (one collective per step)."""
+        return None
+
+    def train_an_epoch(self, train_loader, epoch_id):
+        self._setup()
+        self._epoch_acc.zero_()
+        for batch_data in train_loader:
+            self._enqueue_step(batch_data)
+        st = self._sync_stats()
+        total_loss, total_reg = (float(x) for x in self._epoch_acc.cpu())
+        if self.rank == 0:
+            print(f"[Training Epoch {epoch_id}], Loss {st.loss}, Regularizer {total_reg}")
+        self.writer.add_scalar("model/loss", total_loss, epoch_id)
+        self.writer.add_scalar("model/regularizer", total_reg, epoch_id)

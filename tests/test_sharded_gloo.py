@@ -136,3 +136,36 @@ def test_sharded_engine_refuses_cpu_without_backend():
 
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         HipKernels(torch.device("cpu"))
+
+
+def dp_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from beta_recsys_amd.replicated import allreduce_sum_
+
+        U, I, D, b = 17, 13, 8, 12
+        w = onp.init_params(U, I, D, seed=2)
+        rng = np.random.default_rng(5)
+        users, pos, neg = (rng.integers(0, n, world * b) for n in (U, I, I))
+        sl = slice(rank * b, (rank + 1) * b)
+        loss, reg, g = onp.mf_bpr_grads(w, users[sl], pos[sl], neg[sl], global_batch=world * b)
+        buf = torch.from_numpy(np.concatenate([g[k].ravel() for k in KEYS] + [[loss, reg]]).astype(np.float32))
+        allreduce_sum_(buf)
+        if rank == 0:
+            torch.save({"buf": buf.numpy(), "w": w, "batch": (users, pos, neg)}, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicated_gradient_sum_equals_global_batch_gradient(tmp_path):
+    """The identity the replicated engine rests on: sum over ranks of per-rank gradients scaled by
+    the GLOBAL 1/B == the reference's gradient on the concatenated batch."""
+    out_path = str(tmp_path / "dp.pt")
+    mp.spawn(dp_worker, args=(2, free_port(), out_path), nprocs=2, join=True)
+    res = torch.load(out_path, weights_only=False)
+    loss, reg, g = onp.mf_bpr_grads(res["w"], *res["batch"])
+    ref = np.concatenate([g[k].ravel() for k in KEYS] + [[loss, reg]])
+    assert_tensor_close(res["buf"], ref, 1e-5, "all-reduced [grad | loss | reg]")

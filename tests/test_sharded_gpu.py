@@ -55,3 +55,36 @@ def test_sharded_step_with_hip_kernels(nccl_group, optimizer, lr):
     for k in KEYS:
         frac_bad = np.mean(np.abs(full[k].cpu().numpy() - w[k]) > tol)
         assert frac_bad < 0.01, f"{k}: {frac_bad:.2%} differ"
+
+
+@pytest.mark.parametrize("optimizer,lr", [("sgd", 0.1), ("adam", 0.05)])
+def test_replicated_engine_with_hip_kernels(nccl_group, optimizer, lr):
+    """Replicated data-parallel mode at world size 1: all-reduce with itself, then the dense sweep."""
+    from beta_recsys_amd.replicated import ReplicatedMFEngine
+
+    U, I, D, B = 300, 200, 64, 512
+    w0 = onp.init_params(U, I, D, seed=4)
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer=optimizer,
+                         lr=lr, batch_size=B, loss="bpr"),
+           "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = ReplicatedMFEngine(cfg)
+    eng.model.load_state_dict({k: torch.from_numpy(v) for k, v in w0.items()})
+    w = onp.copy_params(w0)
+    st = onp.new_opt_state(w, optimizer)
+    rng = np.random.default_rng(1)
+    batches = []
+    for _ in range(3):
+        batch = (rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B))
+        batches.append(tuple(torch.from_numpy(a) for a in batch))
+        loss, reg = eng.train_single_batch(batches[-1])
+        ref_loss, ref_reg = onp.mf_train_step(w, st, batch, "bpr", optimizer, lr)
+        assert_scalar_close(loss, ref_loss, 2e-5, "loss")
+        assert_scalar_close(reg, ref_reg, 2e-5, "reg")
+    got = {k: v.cpu().numpy() for k, v in eng.model.state_dict().items()}
+    tol = 1e-6 if optimizer == "sgd" else 2e-3
+    for k in KEYS:
+        assert np.mean(np.abs(got[k] - w[k]) > tol) < 0.01, k
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng.train_an_epoch(batches, 1)
+    assert len(eng.writer.scalars) == 2
