@@ -200,6 +200,11 @@ def main():
         with contextlib.redirect_stdout(io.StringIO()):
             seng = ShardedMFEngine(cfg) if mode == "sharded" else ReplicatedMFEngine(cfg)
         perm = torch.randperm(n_total, device=device)
+        if mode == "replicated":  # stage the epoch like the single-GPU path: batches sorted by item
+            from beta_recsys_amd.mf import sort_within_batches
+
+            perm = sort_within_batches(perm, pos, B, I)
+            seng.presorted = True
         users, pos, neg = users[perm], pos[perm], neg[perm]
         if mode == "sharded":
             step_fn = lambda batch: seng.train_single_batch(batch, sync=False)  # noqa: E731

@@ -147,6 +147,7 @@ class MF(nn.Module):
         ue.normal_(0, self.stddev)
         ie.normal_(0, self.stddev)
         self._flat = flat
+        self._table_cache = {}
         self.user_emb = _Table(ue)
         self.item_emb = _Table(ie)
         self.user_bias = _Table(ub)
@@ -192,11 +193,18 @@ class MF(nn.Module):
 
     def tables(self, flat=None):
         """hiprec_mf_tables over this model's layout (``flat`` defaults to the parameters)."""
-        ue, ie, ub, ib, gb = self._views(self._flat if flat is None else flat)
-        return _lib.MfTables(
-            ue.data_ptr(), ie.data_ptr(), ub.data_ptr(), ib.data_ptr(), gb.data_ptr(),
-            self.n_users, self.n_items, self.emb_dim, 0,
-        )
+        flat = self._flat if flat is None else flat
+        base = flat.data_ptr()
+        cached = self._table_cache.get(base)
+        if cached is None:
+            o = np.cumsum((0,) + self._sizes) * 4
+            cached = _lib.MfTables(
+                base + int(o[0]), base + int(o[1]), base + int(o[2]), base + int(o[3]),
+                base + int(o[4]), self.n_users, self.n_items, self.emb_dim, 0)
+            if len(self._table_cache) > 8:
+                self._table_cache.clear()
+            self._table_cache[base] = cached
+        return cached
 
     def _require_hip(self):
         if self._flat.device.type != "cuda":
@@ -328,6 +336,7 @@ class MFEngine(ModelEngine):
     # (cheap while it is cache-resident) or visit only the rows the batch touched.
     ROWS_SGD_MIN_BYTES = 64 << 20
     SORT_MIN_BATCH = 256
+    presorted = False  # set when the caller already grouped equal items (sort_within_batches)
 
     def __init__(self, config):
         self.config = config
@@ -393,7 +402,8 @@ class MFEngine(ModelEngine):
                 f"Unsupported loss type {self.loss}, try other options: 'bpr' or 'bce'"
             )
         B = users.numel()
-        if B >= self.SORT_MIN_BATCH and a_items.numel() == B and third.numel() == B:
+        if (B >= self.SORT_MIN_BATCH and not self.presorted and a_items.numel() == B
+                and third.numel() == B):
             # group equal (positive) items: the grad kernel merges adjacent duplicates in LDS
             # before touching the dense gradient; a sum over the batch does not depend on order
             order = torch.argsort(a_items)
