@@ -9,3 +9,4 @@ __version__ = "0.1.0"
 from . import _lib  # noqa: F401
 from .torch_engine import HipOptimizer, ModelEngine  # noqa: F401
 from .mf import MF, DeviceTripleBatcher, MFEngine, gather_rows  # noqa: F401
+from .ncf import GMF, MLP, GMFEngine, MLPEngine, NeuMF, NeuMFEngine  # noqa: F401

@@ -51,6 +51,27 @@ class Stats(Structure):
     ]
 
 
+NCF_MAX_LAYERS = 8
+
+
+class NcfPlan(Structure):
+    """hiprec_ncf_plan (include/hiprec.h)."""
+
+    _fields_ = (
+        [(n, c_void_p) for n in ("user_mlp", "item_mlp", "user_mf", "item_mf",
+                                 "g_user_mlp", "g_item_mlp", "g_user_mf", "g_item_mf")]
+        + [("n_users", c_int64), ("n_items", c_int64),
+           ("dim_mlp", c_int32), ("dim_mf", c_int32), ("n_layers", c_int32), ("relu_input", c_int32),
+           ("layer_in", c_int32 * NCF_MAX_LAYERS), ("layer_out", c_int32 * NCF_MAX_LAYERS),
+           ("fc_w", c_void_p * NCF_MAX_LAYERS), ("fc_b", c_void_p * NCF_MAX_LAYERS),
+           ("g_fc_w", c_void_p * NCF_MAX_LAYERS), ("g_fc_b", c_void_p * NCF_MAX_LAYERS),
+           ("out_w", c_void_p), ("out_b", c_void_p), ("g_out_w", c_void_p), ("g_out_b", c_void_p),
+           ("max_batch", c_int64),
+           ("act", c_void_p * (NCF_MAX_LAYERS + 1)), ("dact", c_void_p * (NCF_MAX_LAYERS + 1)),
+           ("mf", c_void_p), ("dmf", c_void_p), ("scores", c_void_p)]
+    )
+
+
 # name -> (restype, argtypes); every symbol of include/hiprec.h must be listed here
 _P = c_void_p
 _T = POINTER(MfTables)
@@ -82,6 +103,16 @@ SIGNATURES = {
     "hiprec_mf_sgd_rows": (
         c_int,
         [_T, _T, _P, _P, _P, _P, c_int64, c_double, _P, _P, c_int32, _P, _P, _P],
+    ),
+    "hiprec_ncf_plan_bytes": (c_size_t, []),
+    "hiprec_gemm_f32": (
+        c_int,
+        [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P],
+    ),
+    "hiprec_ncf_forward": (c_int, [POINTER(NcfPlan), _P, _P, c_int64, _P, _P]),
+    "hiprec_ncf_grad": (
+        c_int,
+        [POINTER(NcfPlan), _P, _P, _P, c_int64, c_float, _P, _P, c_size_t, _P],
     ),
     "hiprec_mf_bpr_epoch": (
         c_int,
@@ -123,6 +154,8 @@ def load():
         fn.argtypes = argtypes
     if lib.hiprec_stats_bytes() != ctypes.sizeof(Stats):
         raise RuntimeError("hiprec_stats layout mismatch between _lib.py and libhiprec.so")
+    if lib.hiprec_ncf_plan_bytes() != ctypes.sizeof(NcfPlan):
+        raise RuntimeError("hiprec_ncf_plan layout mismatch between _lib.py and libhiprec.so")
     _lib = lib
     return lib
 

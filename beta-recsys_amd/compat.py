@@ -11,6 +11,9 @@ import sys
 MIRRORS = {
     "beta_rec.models.torch_engine": "torch_engine",
     "beta_rec.models.mf": "mf",
+    "beta_rec.models.ncf": "ncf",
+    "beta_rec.models.gmf": "ncf",
+    "beta_rec.models.mlp": "ncf",
 }
 
 

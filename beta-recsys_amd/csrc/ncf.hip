@@ -1,0 +1,396 @@
+// NCF family (NeuMF / GMF / MLP) training step for gfx950.
+//
+// Replaces the PyTorch op sequence of beta_rec/models/ncf.py:52-71 (NeuMF.forward),
+// models/gmf.py:29-36, models/mlp.py:40-51, the BCELoss of models/ncf.py:92,116 and the autograd
+// backward of models/ncf.py:117 (dense gradients for four embedding tables and the tower).
+//
+//   gather      one wave per sample: H0 = [relu](cat(Um[u], Im[i])),  MF = Ug[u] * Ig[i]
+//   tower fwd   H_l = relu(H_{l-1} W_l^T + b_l)        exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
+//   head        logit = [H_L | MF] . w_out + b_out, sigmoid, BCE, d logit, dH_L, dMF, d w_out
+//   tower bwd   dW_l = dZ_l^T H_{l-1} ;  db_l = colsum(dZ_l) ;  dZ_{l-1} = (dZ_l W_l) * [H_{l-1} > 0]
+//   scatter     atomics of the four embedding-row gradients into the dense gradient tables
+//
+// The GEMMs are tiny (M = batch 4096, N,K <= 256) and launch-bound; the tile kernel below is a plain
+// LDS-staged 64x64x32 MFMA tile with fused bias / ReLU / ReLU-mask epilogues — fp32 in, fp32
+// accumulate, bitwise an fmaf chain in k order (no TF32-like path exists on gfx950, and the parity
+// tolerance of 1e-5 rules out bf16).
+#include "common.hpp"
+
+namespace hiprec {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kTM = 64, kTN = 64, kTK = 32;
+
+enum GemmMode { kNT = 0, kNN = 1, kTNm = 2 };
+
+// C[M,N] = epilogue( op(A) * op(B) )
+//   MODE kNT : A is [M,K] (lda), B is [N,K] (ldb)          C = A B^T      (forward: H W^T)
+//   MODE kNN : A is [M,K] (lda), B is [K,N] (ldb)          C = A B        (dgrad:   dZ W)
+//   MODE kTNm: A is [K,M] (lda), B is [K,N] (ldb)          C = A^T B      (wgrad:   dZ^T H)
+// epilogue: + bias[n] (if bias) ; relu (if relu) ; * [mask[m,n] > 0] (if mask)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void gemm_f32_kernel(int M, int N, int K,
+                                                          const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ B, int ldb,
+                                                          float* __restrict__ C, int ldc,
+                                                          const float* __restrict__ bias, int relu,
+                                                          const float* __restrict__ mask, int ldm) {
+  __shared__ float As[kTM][kTK + 1];
+  __shared__ float Bs[kTK][kTN + 1];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * kTM, n0 = blockIdx.x * kTN;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (int k0 = 0; k0 < K; k0 += kTK) {
+    // stage A tile: As[m][k] = op(A)(m0+m, k0+k)
+    for (int e = tid; e < kTM * kTK; e += kBlock) {
+      int m, k;
+      if (MODE == kTNm) { m = e % kTM; k = e / kTM; } else { k = e % kTK; m = e / kTK; }
+      const int gm = m0 + m, gk = k0 + k;
+      float v = 0.f;
+      if (gm < M && gk < K)
+        v = (MODE == kTNm) ? A[static_cast<int64_t>(gk) * lda + gm]
+                           : A[static_cast<int64_t>(gm) * lda + gk];
+      As[m][k] = v;
+    }
+    // stage B tile: Bs[k][n] = op(B)(k0+k, n0+n)
+    for (int e = tid; e < kTK * kTN; e += kBlock) {
+      int n, k;
+      if (MODE == kNT) { k = e % kTK; n = e / kTK; } else { n = e % kTN; k = e / kTN; }
+      const int gn = n0 + n, gk = k0 + k;
+      float v = 0.f;
+      if (gn < N && gk < K)
+        v = (MODE == kNT) ? B[static_cast<int64_t>(gn) * ldb + gk]
+                          : B[static_cast<int64_t>(gk) * ldb + gn];
+      Bs[k][n] = v;
+    }
+    __syncthreads();
+    // lane l feeds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]
+    const int i = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < kTK; kk += 2) {
+      const float a = As[wm * 32 + i][kk + kh];
+      const float b = Bs[kk + kh][wn * 32 + i];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int col = lane & 31;
+  const int gn = n0 + wn * 32 + col;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int gm = m0 + wm * 32 + row;
+    if (gm < M && gn < N) {
+      float v = acc[r];
+      if (bias) v += bias[gn];
+      if (relu) v = fmaxf(v, 0.f);
+      if (mask) v = mask[static_cast<int64_t>(gm) * ldm + gn] > 0.f ? v : 0.f;
+      C[static_cast<int64_t>(gm) * ldc + gn] = v;
+    }
+  }
+}
+
+static int launch_gemm(int mode, int M, int N, int K, const float* A, int lda, const float* B,
+                       int ldb, float* C, int ldc, const float* bias, int relu, const float* mask,
+                       int ldm, hipStream_t st) {
+  if (M <= 0 || N <= 0) return 0;
+  dim3 grid((N + kTN - 1) / kTN, (M + kTM - 1) / kTM);
+  switch (mode) {
+    case kNT:
+      gemm_f32_kernel<kNT><<<grid, kBlock, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldm);
+      break;
+    case kNN:
+      gemm_f32_kernel<kNN><<<grid, kBlock, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldm);
+      break;
+    case kTNm:
+      gemm_f32_kernel<kTNm><<<grid, kBlock, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldm);
+      break;
+    default:
+      set_error("bad gemm mode %d", mode);
+      return HIPREC_E_BADARG;
+  }
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---- gather: H0[b] = [relu](cat(Um[u], Im[i])),  MF[b] = Ug[u] * Ig[i] ------------------------------
+__global__ __launch_bounds__(kBlock) void ncf_gather_kernel(hiprec_ncf_plan p,
+                                                            const int64_t* __restrict__ users,
+                                                            const int64_t* __restrict__ items,
+                                                            int64_t batch, hiprec_stats* stats) {
+  const int lane = lane_id();
+  const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int Dm = p.dim_mlp, E = p.dim_mf;
+  for (int64_t b = wave0; b < batch; b += n_waves) {
+    const int64_t u = users[b], i = items[b];
+    const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(p.n_users);
+    const bool i_ok = static_cast<uint64_t>(i) < static_cast<uint64_t>(p.n_items);
+    const bool ok = u_ok && i_ok;
+    if (!ok && lane == 0)
+      atomicOr(&stats->status,
+               (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
+    if (Dm > 0) {
+      float* h0 = p.act[0] + b * (2 * Dm);
+      for (int c = lane; c < Dm; c += kWave) {
+        float a = ok ? p.user_mlp[u * Dm + c] : 0.f;
+        float d = ok ? p.item_mlp[i * Dm + c] : 0.f;
+        if (p.relu_input) { a = fmaxf(a, 0.f); d = fmaxf(d, 0.f); }
+        h0[c] = a;
+        h0[Dm + c] = d;
+      }
+    }
+    if (E > 0) {
+      float* mf = p.mf + b * E;
+      for (int c = lane; c < E; c += kWave)
+        mf[c] = ok ? p.user_mf[u * E + c] * p.item_mf[i * E + c] : 0.f;
+    }
+  }
+}
+
+// ---- head: logit, sigmoid, BCE, d logit, dH_L (masked), dMF, d w_out, d b_out ------------------------
+// one wave per sample; d w_out is accumulated per lane over the wave's samples, then one atomic per
+// (block, column).  TRAIN = false: scores only.
+template <bool TRAIN>
+__global__ __launch_bounds__(kBlock) void ncf_head_kernel(hiprec_ncf_plan p,
+                                                          const float* __restrict__ ratings,
+                                                          int64_t batch, float inv_batch,
+                                                          hiprec_stats* stats, Scratch* scratch) {
+  __shared__ float s_gw[kWavesPerBlock][256 + 1];
+  const int lane = lane_id();
+  const int wv = wave_in_block();
+  const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wv;
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int L = p.n_layers;
+  const int nH = (p.dim_mlp > 0) ? p.layer_out[L - 1] : 0;  // width of the tower output
+  const int E = p.dim_mf;
+  const int nV = nH + E;                                    // affine_output in_features (<= 256+...)
+  const float* hL = nH > 0 ? p.act[L] : nullptr;
+  const float bo = *p.out_b;
+  float loss_acc = 0.f, gb_acc = 0.f;
+  float gw[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // columns lane, lane+64, ... (nV <= 320)
+
+  if (TRAIN && blockIdx.x == 0 && threadIdx.x == 0) advance_step(stats);
+
+  for (int64_t b = wave0; b < batch; b += n_waves) {
+    float part = 0.f;
+    float vec[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int c = lane + kWave * k;
+      float v = 0.f;
+      if (c < nH) v = hL[b * nH + c];
+      else if (c < nV) v = p.mf[b * E + (c - nH)];
+      vec[k] = v;
+      if (c < nV) part += v * p.out_w[c];
+    }
+    const float logit = wave_sum(part) + bo;
+    const float y = sigmoid_f32(logit);
+    if (lane == 0) p.scores[b] = y;
+    if (!TRAIN) continue;
+    const float r = ratings[b];
+    const float ly = fmaxf(logf(y), -100.f);
+    const float l1y = fmaxf(log1pf(-y), -100.f);
+    loss_acc += -(r * ly + (1.f - r) * l1y);
+    const float gy = (y - r) / fmaxf((1.f - y) * y, 1e-12f) * inv_batch;
+    const float dl = gy * ((1.f - y) * y);
+    gb_acc += dl;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int c = lane + kWave * k;
+      if (c < nV) gw[k] += dl * vec[k];
+      if (c < nH) {
+        // d loss / d z_L = d h_L * [h_L > 0]  (ReLU of the last Linear, applied twice in NeuMF)
+        p.dact[L][b * nH + c] = vec[k] > 0.f ? dl * p.out_w[c] : 0.f;
+      } else if (c < nV) {
+        p.dmf[b * E + (c - nH)] = dl * p.out_w[c];
+      }
+    }
+  }
+  if (!TRAIN) return;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int c = lane + kWave * k;
+    if (c < 256) s_gw[wv][c] = gw[k];
+  }
+  // loss partial (reg slot unused = 0); d b_out travels in the scalar-gradient slot
+  publish_partials<kWavesPerBlock>(loss_acc, 0.f, gb_acc, inv_batch, scratch);
+  for (int c = threadIdx.x; c < nV && c < 256; c += kBlock) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) s += s_gw[w][c];
+    if (s != 0.f) atomic_add_f32(p.g_out_w + c, s);
+  }
+  if (nV > 256) {  // rare wide heads: straight per-wave atomics for the tail columns
+    const int c = lane + 256;
+    if (c < nV && gw[4] != 0.f) atomic_add_f32(p.g_out_w + c, gw[4]);
+  }
+}
+
+// ---- column sums: out[n] += sum_m X[m, n]   (bias gradients) ---------------------------------------
+__global__ __launch_bounds__(kBlock) void colsum_kernel(const float* __restrict__ X, int M, int N,
+                                                        float* __restrict__ out) {
+  const int rows_per_block = 64;
+  const int m0 = blockIdx.x * rows_per_block;
+  const int m1 = min(M, m0 + rows_per_block);
+  for (int n = threadIdx.x; n < N; n += kBlock) {
+    float s = 0.f;
+    for (int m = m0; m < m1; ++m) s += X[static_cast<int64_t>(m) * N + n];
+    if (s != 0.f) atomic_add_f32(out + n, s);
+  }
+}
+
+// ---- scatter of the embedding-row gradients ---------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void ncf_scatter_kernel(hiprec_ncf_plan p,
+                                                             const int64_t* __restrict__ users,
+                                                             const int64_t* __restrict__ items,
+                                                             int64_t batch) {
+  const int lane = lane_id();
+  const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int Dm = p.dim_mlp, E = p.dim_mf;
+  for (int64_t b = wave0; b < batch; b += n_waves) {
+    const int64_t u = users[b], i = items[b];
+    if (static_cast<uint64_t>(u) >= static_cast<uint64_t>(p.n_users) ||
+        static_cast<uint64_t>(i) >= static_cast<uint64_t>(p.n_items))
+      continue;  // flagged by the gather kernel
+    if (Dm > 0) {
+      const float* dx = p.dact[0] + b * (2 * Dm);  // already masked by [x > 0] when relu_input
+      for (int c = lane; c < Dm; c += kWave) {
+        atomic_add_f32(p.g_user_mlp + u * Dm + c, dx[c]);
+        atomic_add_f32(p.g_item_mlp + i * Dm + c, dx[Dm + c]);
+      }
+    }
+    if (E > 0) {
+      const float* dmf = p.dmf + b * E;
+      for (int c = lane; c < E; c += kWave) {
+        const float d = dmf[c];
+        atomic_add_f32(p.g_user_mf + u * E + c, d * p.item_mf[i * E + c]);
+        atomic_add_f32(p.g_item_mf + i * E + c, d * p.user_mf[u * E + c]);
+      }
+    }
+  }
+}
+
+static int check_plan(const hiprec_ncf_plan* p, int64_t batch, bool train) {
+  HIPREC_REQUIRE(p != nullptr, "NULL plan");
+  HIPREC_REQUIRE(p->n_users > 0 && p->n_items > 0, "bad table sizes");
+  HIPREC_REQUIRE(p->dim_mlp >= 0 && p->dim_mf >= 0 && (p->dim_mlp > 0 || p->dim_mf > 0),
+                 "plan has neither an MLP nor a GMF half");
+  HIPREC_REQUIRE(batch >= 0 && batch <= p->max_batch, "batch %lld exceeds the plan's workspace (%lld)",
+                 (long long)batch, (long long)p->max_batch);
+  HIPREC_REQUIRE(p->out_w && p->out_b && p->scores, "NULL head pointers");
+  if (p->dim_mlp > 0) {
+    HIPREC_REQUIRE(p->n_layers >= 1 && p->n_layers <= HIPREC_NCF_MAX_LAYERS, "bad n_layers");
+    HIPREC_REQUIRE(p->user_mlp && p->item_mlp && p->act[0], "NULL MLP pointers");
+    HIPREC_REQUIRE(p->layer_in[0] == 2 * p->dim_mlp, "layer_in[0] != 2*dim_mlp");
+    for (int l = 0; l < p->n_layers; ++l) {
+      HIPREC_REQUIRE(p->fc_w[l] && p->fc_b[l] && p->act[l + 1], "NULL tower pointer at layer %d", l);
+      if (l > 0) HIPREC_REQUIRE(p->layer_in[l] == p->layer_out[l - 1], "layer widths do not chain");
+      if (train) HIPREC_REQUIRE(p->g_fc_w[l] && p->g_fc_b[l] && p->dact[l + 1], "NULL grad pointer");
+    }
+    if (train) HIPREC_REQUIRE(p->dact[0] && p->g_user_mlp && p->g_item_mlp, "NULL MLP grad pointers");
+  }
+  if (p->dim_mf > 0) {
+    HIPREC_REQUIRE(p->user_mf && p->item_mf && p->mf, "NULL GMF pointers");
+    if (train) HIPREC_REQUIRE(p->dmf && p->g_user_mf && p->g_item_mf, "NULL GMF grad pointers");
+  }
+  const int nV = (p->dim_mlp > 0 ? p->layer_out[p->n_layers - 1] : 0) + p->dim_mf;
+  HIPREC_REQUIRE(nV <= 320, "affine_output wider than 320 inputs is not supported (got %d)", nV);
+  if (train) HIPREC_REQUIRE(p->g_out_w && p->g_out_b, "NULL head grad pointers");
+  return 0;
+}
+
+static int forward(const hiprec_ncf_plan* p, const int64_t* users, const int64_t* items,
+                   int64_t batch, hiprec_stats* stats, hipStream_t st) {
+  ncf_gather_kernel<<<grid_for_waves(batch), kBlock, 0, st>>>(*p, users, items, batch, stats);
+  HIPREC_TRY(hipGetLastError());
+  if (p->dim_mlp > 0) {
+    for (int l = 0; l < p->n_layers; ++l) {
+      if (int rc = launch_gemm(kNT, static_cast<int>(batch), p->layer_out[l], p->layer_in[l],
+                               p->act[l], p->layer_in[l], p->fc_w[l], p->layer_in[l], p->act[l + 1],
+                               p->layer_out[l], p->fc_b[l], /*relu=*/1, nullptr, 0, st))
+        return rc;
+    }
+  }
+  return 0;
+}
+
+}  // namespace hiprec
+
+using namespace hiprec;
+
+extern "C" size_t hiprec_ncf_plan_bytes(void) { return sizeof(hiprec_ncf_plan); }
+
+extern "C" int hiprec_gemm_f32(int mode, int M, int N, int K, const float* A, int lda,
+                               const float* B, int ldb, float* C, int ldc, const float* bias,
+                               int relu, const float* mask, int ldm, void* stream) {
+  HIPREC_REQUIRE(M >= 0 && N >= 0 && K >= 0, "negative GEMM size");
+  if (M == 0 || N == 0) return 0;
+  HIPREC_REQUIRE(A && B && C, "NULL GEMM operand");
+  return launch_gemm(mode, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldm,
+                     static_cast<hipStream_t>(stream));
+}
+
+extern "C" int hiprec_ncf_forward(const hiprec_ncf_plan* plan, const int64_t* users,
+                                  const int64_t* items, int64_t batch, hiprec_stats* stats,
+                                  void* stream) {
+  if (int rc = check_plan(plan, batch, false)) return rc;
+  if (batch == 0) return 0;
+  HIPREC_REQUIRE(users && items && stats, "NULL pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (int rc = forward(plan, users, items, batch, stats, st)) return rc;
+  ncf_head_kernel<false><<<grid_for_waves(batch), kBlock, 0, st>>>(*plan, nullptr, batch, 0.f, stats,
+                                                                   nullptr);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users,
+                               const int64_t* items, const float* ratings, int64_t batch,
+                               float inv_batch, hiprec_stats* stats, void* scratch,
+                               size_t scratch_bytes, void* stream) {
+  if (int rc = check_plan(plan, batch, true)) return rc;
+  HIPREC_REQUIRE(batch > 0, "empty batch");
+  HIPREC_REQUIRE(users && items && ratings && stats && scratch, "NULL pointer");
+  if (scratch_bytes < kScratchBytes) {
+    set_error("scratch too small: %zu < %zu", scratch_bytes, kScratchBytes);
+    return HIPREC_E_SCRATCH;
+  }
+  const hiprec_ncf_plan* p = plan;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int B = static_cast<int>(batch);
+  if (int rc = forward(p, users, items, batch, stats, st)) return rc;
+  ncf_head_kernel<true><<<grid_for_waves(batch), kBlock, 0, st>>>(
+      *p, ratings, batch, inv_batch, stats, static_cast<Scratch*>(scratch));
+  HIPREC_TRY(hipGetLastError());
+  if (p->dim_mlp > 0) {
+    for (int l = p->n_layers - 1; l >= 0; --l) {
+      const int nin = p->layer_in[l], nout = p->layer_out[l];
+      // dW_l = dZ_l^T H_{l-1}      (the gradient buffer is all-zero between steps: plain store)
+      if (int rc = launch_gemm(kTNm, nout, nin, B, p->dact[l + 1], nout, p->act[l], nin, p->g_fc_w[l],
+                               nin, nullptr, 0, nullptr, 0, st))
+        return rc;
+      colsum_kernel<<<(B + 63) / 64, kBlock, 0, st>>>(p->dact[l + 1], B, nout, p->g_fc_b[l]);
+      HIPREC_TRY(hipGetLastError());
+      // dZ_{l-1} = (dZ_l W_l) * [H_{l-1} > 0]; for l == 0 the mask is the ReLU NeuMF applies to the
+      // raw embeddings (quirk Q7) and is absent for the stand-alone MLP
+      const float* mask = (l > 0 || p->relu_input) ? p->act[l] : nullptr;
+      if (int rc = launch_gemm(kNN, B, nin, nout, p->dact[l + 1], nout, p->fc_w[l], nin, p->dact[l],
+                               nin, nullptr, 0, mask, nin, st))
+        return rc;
+    }
+  }
+  ncf_scatter_kernel<<<grid_for_waves(batch), kBlock, 0, st>>>(*p, users, items, batch);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}

@@ -175,6 +175,56 @@ int hiprec_mf_bpr_epoch(const hiprec_mf_tables* w, const hiprec_mf_tables* g, co
                         int32_t first_stamp, hiprec_stats* stats, void* scratch,
                         size_t scratch_bytes, void* stream);
 
+/* ======================= NCF family: NeuMF / GMF / MLP (models/ncf.py, gmf.py, mlp.py) ============ */
+
+#define HIPREC_NCF_MAX_LAYERS 8
+
+/* Everything one NCF-family step touches: the four embedding tables, the tower, the head, their
+ * gradient accumulators (same shapes, all-zero between steps) and a caller-owned activation
+ * workspace for up to max_batch samples.  A half that the model does not have is dim 0 / NULL:
+ *   NeuMF (models/ncf.py:24-50)  dim_mlp = emb_dim*2^(L-1), dim_mf = emb_dim, relu_input = 1 (quirk Q7)
+ *   MLP   (models/mlp.py:22-38)  dim_mf = 0, relu_input = 0
+ *   GMF   (models/gmf.py:19-27)  dim_mlp = 0, n_layers = 0
+ * Linear layer l is fc_w[l] [layer_out[l], layer_in[l]] row-major (nn.Linear) + fc_b[l];
+ * affine_output is out_w [layer_out[L-1] + dim_mf] (tower part first, as torch.cat([mlp, mf])). */
+typedef struct hiprec_ncf_plan {
+  float *user_mlp, *item_mlp, *user_mf, *item_mf;
+  float *g_user_mlp, *g_item_mlp, *g_user_mf, *g_item_mf;
+  int64_t n_users, n_items;
+  int32_t dim_mlp, dim_mf, n_layers, relu_input;
+  int32_t layer_in[HIPREC_NCF_MAX_LAYERS], layer_out[HIPREC_NCF_MAX_LAYERS];
+  float *fc_w[HIPREC_NCF_MAX_LAYERS], *fc_b[HIPREC_NCF_MAX_LAYERS];
+  float *g_fc_w[HIPREC_NCF_MAX_LAYERS], *g_fc_b[HIPREC_NCF_MAX_LAYERS];
+  float *out_w, *out_b, *g_out_w, *g_out_b;
+  int64_t max_batch;
+  float* act[HIPREC_NCF_MAX_LAYERS + 1];  /* act[0] = [B, 2*dim_mlp] (ReLU-ed if relu_input), act[l] = H_l */
+  float* dact[HIPREC_NCF_MAX_LAYERS + 1]; /* d loss / d (pre-activation), same shapes */
+  float *mf, *dmf;                        /* [B, dim_mf] */
+  float* scores;                          /* [B] sigmoid outputs */
+} hiprec_ncf_plan;
+
+size_t hiprec_ncf_plan_bytes(void); /* sizeof(hiprec_ncf_plan), for binding-layout checks */
+
+/* ---- exact-fp32 MFMA GEMM with fused epilogue (the nn.Linear forward / backward of the tower):
+ * mode 0: C = A[M,K] B[N,K]^T   mode 1: C = A[M,K] B[K,N]   mode 2: C = A[K,M]^T B[K,N];
+ * then C += bias[n] (if bias), relu (if relu), C *= [mask[m,n] > 0] (if mask). */
+int hiprec_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                    float* C, int ldc, const float* bias, int relu, const float* mask, int ldm,
+                    void* stream);
+
+/* ---- model.forward / predict under no_grad (ncf.py:52-78): plan->scores[0:batch] = sigmoid(logit) */
+int hiprec_ncf_forward(const hiprec_ncf_plan* plan, const int64_t* users, const int64_t* items,
+                       int64_t batch, hiprec_stats* stats, void* stream);
+
+/* ---- zero_grad + forward + BCELoss(mean) + backward of {NeuMF,GMF,MLP}Engine.train_single_batch
+ * (ncf.py:100-120, gmf.py:60-80, mlp.py:76-96) with dropout 0.  Dense gradients are accumulated
+ * into the plan's g_* buffers; the loss partials and d loss/d affine_output.bias are left in
+ * scratch for the optimizer call that follows (hiprec_opt_dense_step with scalar_index = position
+ * of affine_output.bias in the flat buffer) or for hiprec_finalize_stats. */
+int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users, const int64_t* items,
+                    const float* ratings, int64_t batch, float inv_batch, hiprec_stats* stats,
+                    void* scratch, size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -245,5 +245,71 @@ def main():
     epoch_fixture(MFEngine, PairwiseNegativeDataset, "mf_epoch_sgd", "sgd", seed=22)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--ncf" not in sys.argv:
     main()
+
+
+# ---- NCF family (models/ncf.py, gmf.py, mlp.py) ----------------------------------------------------
+
+def ncf_config(U, I, E, L, optimizer, lr, B, model="ncf_end"):
+    return {"model": dict(n_users=U, n_items=I, emb_dim=E, dropout=0.0, device_str="cpu",
+                          optimizer=optimizer, lr=lr, batch_size=B, model=model,
+                          mlp_config={"n_layers": L, "name": "mlp", "save_name": "mlp.model"},
+                          gmf_config={"name": "gmf", "save_name": "gmf.model"}),
+            "system": {"run_dir": "/tmp/hiprec_golden_runs", "model_save_dir": "/tmp/hiprec_golden_runs"}}
+
+
+def ncf_steps_fixture(engine_cls, name, kind, U, I, E, L, B, optimizer, lr, n_steps, seed):
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    eng = quiet(engine_cls, ncf_config(U, I, E, L, optimizer, lr, B))
+    out = {"meta": np.array([U, I, E, L, B, n_steps, seed], dtype=np.int64), "kind": np.array(kind),
+           "optimizer": np.array(optimizer), "lr": np.array(lr)}
+    out.update(state_np(eng.model, "w0"))  # also pins the init (quirk Q8) for this torch seed
+    grads_seen = []
+    orig_step = eng.optimizer.step
+
+    def capturing_step(*a, **k):
+        grads_seen.append({n: p.grad.detach().numpy().copy() for n, p in eng.model.named_parameters()})
+        return orig_step(*a, **k)
+
+    eng.optimizer.step = capturing_step
+    users = rng.integers(0, U, size=(n_steps, B))
+    items = np.stack([zipf_items(rng, B, I) for _ in range(n_steps)])
+    ratings = (rng.random((n_steps, B)) < 0.25).astype(np.float32)
+    losses = []
+    for s in range(n_steps):
+        losses.append(eng.train_single_batch(torch.from_numpy(users[s]), torch.from_numpy(items[s]),
+                                             torch.from_numpy(ratings[s])))
+        out.update(state_np(eng.model, f"w{s + 1}"))
+        for k, v in grads_seen[-1].items():
+            out[f"g{s + 1}/{k}"] = v
+        for pname, p in eng.model.named_parameters():
+            pst = eng.optimizer.state.get(p, {})
+            for sk, tag in (("exp_avg", "m"), ("exp_avg_sq", "v"), ("square_avg", "v")):
+                if sk in pst:
+                    out[f"{tag}{s + 1}/{pname}"] = pst[sk].detach().numpy().copy()
+    # scores of the final model on a fixed probe (model.predict contract)
+    pu, pi = rng.integers(0, U, 64), rng.integers(0, I, 64)
+    out["probe_users"], out["probe_items"] = pu, pi
+    out["probe_scores"] = eng.model.predict(pu, pi).numpy()
+    out.update(users=users, items=items, ratings=ratings, losses=np.array(losses, dtype=np.float64))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: losses {losses}")
+
+
+def main_ncf():
+    import_reference()
+    from beta_rec.models.gmf import GMFEngine
+    from beta_rec.models.mlp import MLPEngine
+    from beta_rec.models.ncf import NeuMFEngine
+
+    ncf_steps_fixture(NeuMFEngine, "ncf_neumf_adam", "neumf", 53, 41, 8, 3, 37, "adam", 1e-3, 3, seed=31)
+    ncf_steps_fixture(NeuMFEngine, "ncf_neumf_sgd_e32", "neumf", 40, 30, 32, 3, 50, "sgd", 0.05, 2, seed=32)
+    ncf_steps_fixture(NeuMFEngine, "ncf_neumf_rmsprop_l2", "neumf", 29, 31, 6, 2, 21, "rmsprop", 1e-3, 2, seed=33)
+    ncf_steps_fixture(GMFEngine, "ncf_gmf_adam", "gmf", 53, 41, 8, 3, 37, "adam", 1e-3, 3, seed=34)
+    ncf_steps_fixture(MLPEngine, "ncf_mlp_adam", "mlp", 53, 41, 8, 3, 37, "adam", 1e-3, 3, seed=35)
+
+
+if __name__ == "__main__" and "--ncf" in sys.argv:
+    main_ncf()

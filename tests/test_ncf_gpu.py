@@ -1,0 +1,179 @@
+"""GPU parity tests of the NCF family (NeuMF / GMF / MLP): libhiprec through the C ABI vs golden
+vectors captured from the real reference and vs the numpy oracle at BASELINE's C3 shape.
+
+Tolerances: 1e-5 relative (to the tensor's scale) on loss and gradients — the fp32 MFMA is an exact
+fmaf chain, only the summation order differs from MKL's; optimizer updates within 1e-5 of the update
+scale plus the Adam/RMSprop conditioning band (see tests/helpers.py::optimizer_band)."""
+import contextlib
+import ctypes
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import EPS32, assert_scalar_close, assert_tensor_close, load_golden
+from oracle import ncf_numpy as onc
+from test_host_logic import ncf_config
+from test_oracle_golden_ncf import opt_state, params
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("ncf_neumf_adam", "NeuMFEngine"), ("ncf_neumf_sgd_e32", "NeuMFEngine"),
+         ("ncf_neumf_rmsprop_l2", "NeuMFEngine"), ("ncf_gmf_adam", "GMFEngine"),
+         ("ncf_mlp_adam", "MLPEngine")]
+
+
+def bias_floor(k):
+    return 0.05 if k.endswith("bias") else 0.0
+
+
+def make_engine(engine, U, I, E, L, optimizer, lr, B):
+    import beta_recsys_amd as hp
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        return getattr(hp, engine)(ncf_config(U, I, E, L, optimizer, lr, B, device="cuda:0"))
+
+
+def load_weights(eng, w):
+    eng.model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
+
+
+def get_weights(eng):
+    return {k: v.detach().cpu().numpy() for k, v in eng.model.state_dict().items()}
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(64, 64, 32), (100, 37, 70), (4096, 128, 256), (1, 1, 1), (33, 129, 5)])
+def test_gemm_f32_mfma_all_modes(hip_device, mode, shape):
+    """Exact-fp32 MFMA GEMM vs numpy with ASYMMETRIC operands (catches transposed fragments)."""
+    from beta_recsys_amd import _lib
+
+    lib = _lib.load()
+    M, N, K = shape
+    rng = np.random.default_rng(M * 7 + N * 3 + K + mode)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    b = rng.standard_normal((K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    mask = rng.standard_normal((M, N)).astype(np.float32)
+    A = torch.from_numpy(a if mode != 2 else np.ascontiguousarray(a.T)).cuda()      # mode 2: [K, M]
+    Bm = torch.from_numpy(np.ascontiguousarray(b.T) if mode == 0 else b).cuda()     # mode 0: [N, K]
+    st = _lib.stream_ptr(hip_device)
+    for use_bias, relu, use_mask in ((False, 0, False), (True, 1, False), (False, 0, True), (True, 1, True)):
+        C = torch.full((M, N), float("nan"), device="cuda")
+        mk = torch.from_numpy(mask).cuda()
+        bs = torch.from_numpy(bias).cuda()
+        _lib.check(lib.hiprec_gemm_f32(
+            mode, M, N, K, _lib.ptr(A), A.shape[1], _lib.ptr(Bm), Bm.shape[1], _lib.ptr(C), N,
+            _lib.ptr(bs) if use_bias else None, relu, _lib.ptr(mk) if use_mask else None, N, st))
+        ref = a.astype(np.float64) @ b.astype(np.float64)
+        if use_bias:
+            ref = ref + bias
+        if relu:
+            ref = np.maximum(ref, 0)
+        if use_mask:
+            ref = ref * (mask > 0)
+        scale = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64) + 1.0
+        err = np.abs(C.cpu().numpy() - ref)
+        assert np.all(err <= 4 * EPS32 * scale * np.sqrt(K) + 1e-6), (mode, shape, err.max())
+
+
+@pytest.mark.parametrize("case,engine", CASES)
+def test_ncf_step_matches_reference(hip_device, case, engine):
+    g = load_golden(case)
+    U, I, E, L, B, n_steps, _ = (int(x) for x in g["meta"])
+    kind, opt, lr = str(g["kind"]), str(g["optimizer"]), float(g["lr"])
+    eng = make_engine(engine, U, I, E, L, opt, lr, B)
+    for s in range(n_steps):
+        w_prev = params(g, f"w{s}")
+        st_prev = opt_state(g, s, opt, w_prev)
+        g_ref = params(g, f"g{s + 1}")
+        batch = (torch.from_numpy(g["users"][s]), torch.from_numpy(g["items"][s]),
+                 torch.from_numpy(g["ratings"][s]))
+        load_weights(eng, w_prev)
+        loss, grads = eng.backward_only(*batch)
+        assert_scalar_close(loss, g["losses"][s], what=f"loss step {s}")
+        for k in g_ref:
+            assert_tensor_close(grads[k].cpu().numpy(), g_ref[k], 2e-5, f"grad {k} step {s}",
+                                scale_floor=bias_floor(k))
+        assert float(eng._g_flat.abs().max()) == 0.0
+        # full step from the reference's own optimizer state
+        eng.load_optimizer_state(s, st_prev.get("exp_avg"),
+                                 st_prev.get("exp_avg_sq", st_prev.get("square_avg")))
+        loss2 = eng.train_single_batch(*batch)
+        assert_scalar_close(loss2, g["losses"][s], what=f"loss (step) {s}")
+        # conditioning band: oracle step with the reference gradient perturbed by +/- 1e-5 * scale
+        outs = []
+        for sign in (1.0, -1.0):
+            ww = {k: v.copy() for k, v in w_prev.items()}
+            stc = {k: ({kk: vv.copy() for kk, vv in v.items()} if isinstance(v, dict) else v)
+                   for k, v in st_prev.items()}
+            gp = {k: (g_ref[k] + np.float32(sign * 2e-5 * max(np.abs(g_ref[k]).max(), bias_floor(k))))
+                  for k in g_ref}
+            onc.opt_step(ww, gp, stc, opt, lr)
+            outs.append(ww)
+        w = get_weights(eng)
+        for k in w_prev:
+            ref = g[f"w{s + 1}/{k}"].astype(np.float64)
+            band = np.abs(outs[0][k].astype(np.float64) - outs[1][k])
+            tol = 1e-5 * np.abs(ref - w_prev[k]).max() + 4 * EPS32 * np.abs(ref).max() + band
+            err = np.abs(w[k] - ref)
+            assert np.all(err <= tol), f"weights {k} step {s}: worst {err.max():.3e}"
+        assert float(eng._g_flat.abs().max()) == 0.0
+    # model.predict contract on the final reference weights
+    load_weights(eng, params(g, f"w{n_steps}"))
+    scores = eng.model.predict(g["probe_users"], g["probe_items"])
+    assert isinstance(scores, torch.Tensor) and scores.shape == g["probe_scores"].shape
+    got = scores.flatten().to(torch.device("cpu")).detach().numpy()
+    assert_tensor_close(got, g["probe_scores"].reshape(-1), what="probe scores")
+
+
+def test_ncf_trajectory_and_epoch(hip_device):
+    """Three chained Adam steps through train_an_epoch: optimizer clock, prints, add_scalar."""
+    g = load_golden("ncf_neumf_adam")
+    U, I, E, L, B, n_steps, _ = (int(x) for x in g["meta"])
+    eng = make_engine("NeuMFEngine", U, I, E, L, "adam", float(g["lr"]), B)
+    load_weights(eng, params(g, "w0"))
+    batches = [(torch.from_numpy(g["users"][s]), torch.from_numpy(g["items"][s]),
+                torch.from_numpy(g["ratings"][s].astype(np.float64)))  # loader ratings may be double
+               for s in range(n_steps)]
+    with contextlib.redirect_stdout(io.StringIO()) as out:
+        eng.train_an_epoch(batches, 0)
+    assert "[Training Epoch 0], Loss" in out.getvalue()
+    (tag, total, ep), = eng.writer.scalars
+    assert tag == "model/loss" and ep == 0
+    assert_scalar_close(total, float(np.sum(g["losses"])), 2e-5, "epoch loss sum")
+    w = get_weights(eng)
+    for k in w:
+        frac_bad = np.mean(np.abs(w[k] - g[f"w{n_steps}/{k}"]) > 1e-3 * float(g["lr"]) + 1e-6)
+        assert frac_bad < 0.01, f"{k}: {frac_bad:.2%} of elements off trajectory"
+
+
+def test_ncf_errors(hip_device):
+    eng = make_engine("NeuMFEngine", 10, 10, 4, 2, "adam", 1e-3, 8)
+    ok = (torch.tensor([1, 2, 3]), torch.tensor([3, 4, 5]), torch.tensor([1.0, 0.0, 1.0]))
+    assert np.isfinite(eng.train_single_batch(*ok))
+    with pytest.raises(IndexError):
+        eng.train_single_batch(torch.tensor([1, 10]), torch.tensor([3, 4]), torch.tensor([1.0, 0.0]))
+    assert np.isfinite(eng.train_single_batch(*ok))
+    one = eng.train_single_batch(torch.tensor([1]), torch.tensor([2]), torch.tensor([1.0]))
+    assert np.isfinite(one)  # unlike MF, a batch of one is legal for the NCF family
+
+
+def test_ncf_full_size_c3_vs_oracle(hip_device):
+    """BASELINE configs[2]: ML-1M shape, emb_dim 32 (tower 256->128->64->32), batch 4096."""
+    U, I, E, L, B = 6040, 3706, 32, 3, 4096
+    torch.manual_seed(5)
+    eng = make_engine("NeuMFEngine", U, I, E, L, "adam", 1e-3, B)
+    w = get_weights(eng)
+    rng = np.random.default_rng(6)
+    users, items = rng.integers(0, U, B), rng.integers(0, I, B)
+    ratings = (rng.random(B) < 0.2).astype(np.float32)
+    loss_ref, g_ref, _ = onc.ncf_grads(w, users, items, ratings, "neumf")
+    loss, grads = eng.backward_only(torch.from_numpy(users), torch.from_numpy(items),
+                                    torch.from_numpy(ratings))
+    assert_scalar_close(loss, loss_ref, what="loss")
+    for k in g_ref:
+        assert_tensor_close(grads[k].cpu().numpy(), g_ref[k], 2e-5, f"grad {k}", scale_floor=bias_floor(k))
+    scores = eng.model.predict(users[:1000], items[:1000]).cpu().numpy()
+    assert_tensor_close(scores, onc.ncf_predict(w, users[:1000], items[:1000], "neumf"), what="scores")
