@@ -130,6 +130,48 @@ def cpu_baseline(budget_s=12.0):
                       f"PyTorch-CPU op sequence of the reference on {os.cpu_count()} logical cpus"}
 
 
+def bench_ncf(args, device):
+    """BASELINE configs[2]: NeuMF (GMF + MLP [128, 64, 32] <=> emb_dim 32, quirk Q9) on the ML-1M
+    shape, batch 4096 (user, item, rating) samples with 1 positive : 4 negatives, Adam lr 1e-3."""
+    import beta_recsys_amd as hp
+
+    E, L = 32, 3
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=E, dropout=0.0, device_str=str(device),
+                         optimizer="adam", lr=1e-3, batch_size=B, model="ncf_end",
+                         mlp_config={"n_layers": L}, gmf_config={}),
+           "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
+    torch.manual_seed(2020)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = hp.NeuMFEngine(cfg)
+    n_total = (args.warmup + args.steps) * B
+    users, items, _ = (t.to(device) for t in synth_triples(n_total, seed=100))
+    ratings = (torch.rand(n_total, device=device) < 0.2).float()
+
+    def run(lo, n):
+        for k in range(n):
+            sl = slice(lo + k * B, lo + (k + 1) * B)
+            eng._enqueue_step(users[sl], items[sl], ratings[sl])
+
+    run(0, args.warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.warmup * B, args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = eng._sync_stats()
+    flops = 3 * 2 * (256 * 128 + 128 * 64 + 64 * 32 + 64)  # fwd + dgrad + wgrad per sample
+    out = {"metric": "training interactions/sec (NCF samples)", "value": args.steps * B / dt,
+           "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "NeuMF (BASELINE configs[2]): 6040 x 3706, emb_dim 32 => tables "
+                                  "128/128/32/32, tower 256->128->64->32, head 64->1, batch 4096, adam 1e-3",
+                      "last_loss": st.loss},
+           "mfma": {"flops_per_sample": flops, "achieved_tflops": args.steps * B * flops / dt / 1e12,
+                    "peak_fp32_mfma_tflops": 157.3}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +179,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adam", "rmsprop"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="mf", choices=["mf", "ncf"],
+                    help="mf = BASELINE configs[1] (the headline); ncf = configs[2] (NeuMF, emb_dim 32)")
     ap.add_argument("--multi-gpu", default="auto", choices=["auto", "replicated", "sharded"],
                     help="N>1: replicate small tables (gradient all-reduce) or row-shard them "
                          "(all-to-all routing); auto = replicated below 64 MB of parameters")
@@ -160,6 +204,9 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     import beta_recsys_amd as hp
+
+    if args.workload == "ncf":
+        return bench_ncf(args, device)
 
     n_total = (args.warmup + args.steps) * B
     users, pos, neg = (t.to(device) for t in synth_triples(n_total, seed=100 + rank))

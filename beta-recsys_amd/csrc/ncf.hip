@@ -48,14 +48,19 @@ __global__ __launch_bounds__(kBlock) void gemm_f32_kernel(int M, int N, int K,
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  for (int k0 = 0; k0 < K; k0 += kTK) {
+  // split-K: blockIdx.z owns a kTK-aligned slice of K and adds its partial product atomically
+  // (wgrad has K = batch and only a handful of output tiles; C must then be zero on entry)
+  const int k_per = ((K + static_cast<int>(gridDim.z) - 1) / static_cast<int>(gridDim.z) + kTK - 1) / kTK * kTK;
+  const int k_begin = static_cast<int>(blockIdx.z) * k_per;
+  const int k_end = min(K, k_begin + k_per);
+  for (int k0 = k_begin; k0 < k_end; k0 += kTK) {
     // stage A tile: As[m][k] = op(A)(m0+m, k0+k)
     for (int e = tid; e < kTM * kTK; e += kBlock) {
       int m, k;
       if (MODE == kTNm) { m = e % kTM; k = e / kTM; } else { k = e % kTK; m = e / kTK; }
       const int gm = m0 + m, gk = k0 + k;
       float v = 0.f;
-      if (gm < M && gk < K)
+      if (gm < M && gk < k_end)
         v = (MODE == kTNm) ? A[static_cast<int64_t>(gk) * lda + gm]
                            : A[static_cast<int64_t>(gm) * lda + gk];
       As[m][k] = v;
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void gemm_f32_kernel(int M, int N, int K,
       if (MODE == kNT) { k = e % kTK; n = e / kTK; } else { n = e % kTN; k = e / kTN; }
       const int gn = n0 + n, gk = k0 + k;
       float v = 0.f;
-      if (gn < N && gk < K)
+      if (gn < N && gk < k_end)
         v = (MODE == kNT) ? B[static_cast<int64_t>(gn) * ldb + gk]
                           : B[static_cast<int64_t>(gk) * ldb + gn];
       Bs[k][n] = v;
@@ -94,16 +99,29 @@ __global__ __launch_bounds__(kBlock) void gemm_f32_kernel(int M, int N, int K,
       if (bias) v += bias[gn];
       if (relu) v = fmaxf(v, 0.f);
       if (mask) v = mask[static_cast<int64_t>(gm) * ldm + gn] > 0.f ? v : 0.f;
-      C[static_cast<int64_t>(gm) * ldc + gn] = v;
+      if (gridDim.z > 1) {
+        if (v != 0.f) atomic_add_f32(C + static_cast<int64_t>(gm) * ldc + gn, v);
+      } else {
+        C[static_cast<int64_t>(gm) * ldc + gn] = v;
+      }
     }
   }
 }
 
 static int launch_gemm(int mode, int M, int N, int K, const float* A, int lda, const float* B,
                        int ldb, float* C, int ldc, const float* bias, int relu, const float* mask,
-                       int ldm, hipStream_t st) {
+                       int ldm, hipStream_t st, bool split_k = false) {
   if (M <= 0 || N <= 0) return 0;
   dim3 grid((N + kTN - 1) / kTN, (M + kTM - 1) / kTM);
+  // split K when the output has too few tiles to fill 256 CUs (only legal without an epilogue,
+  // into a zero-initialised C: the weight-gradient GEMMs)
+  if (split_k && !bias && !relu && !mask) {
+    const int tiles = grid.x * grid.y;
+    int z = (512 + tiles - 1) / tiles;
+    const int max_z = (K + 4 * kTK - 1) / (4 * kTK);  // at least 4 k-tiles per slice
+    if (z > max_z) z = max_z;
+    if (z > 1) grid.z = z;
+  }
   switch (mode) {
     case kNT:
       gemm_f32_kernel<kNT><<<grid, kBlock, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldm);
@@ -239,11 +257,12 @@ __global__ __launch_bounds__(kBlock) void ncf_head_kernel(hiprec_ncf_plan p,
 // ---- column sums: out[n] += sum_m X[m, n]   (bias gradients) ---------------------------------------
 __global__ __launch_bounds__(kBlock) void colsum_kernel(const float* __restrict__ X, int M, int N,
                                                         float* __restrict__ out) {
-  const int rows_per_block = 64;
+  const int rows_per_block = 16;
   const int m0 = blockIdx.x * rows_per_block;
   const int m1 = min(M, m0 + rows_per_block);
   for (int n = threadIdx.x; n < N; n += kBlock) {
     float s = 0.f;
+#pragma unroll 4
     for (int m = m0; m < m1; ++m) s += X[static_cast<int64_t>(m) * N + n];
     if (s != 0.f) atomic_add_f32(out + n, s);
   }
@@ -378,9 +397,9 @@ extern "C" int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users
       const int nin = p->layer_in[l], nout = p->layer_out[l];
       // dW_l = dZ_l^T H_{l-1}      (the gradient buffer is all-zero between steps: plain store)
       if (int rc = launch_gemm(kTNm, nout, nin, B, p->dact[l + 1], nout, p->act[l], nin, p->g_fc_w[l],
-                               nin, nullptr, 0, nullptr, 0, st))
+                               nin, nullptr, 0, nullptr, 0, st, /*split_k=*/true))
         return rc;
-      colsum_kernel<<<(B + 63) / 64, kBlock, 0, st>>>(p->dact[l + 1], B, nout, p->g_fc_b[l]);
+      colsum_kernel<<<(B + 15) / 16, kBlock, 0, st>>>(p->dact[l + 1], B, nout, p->g_fc_b[l]);
       HIPREC_TRY(hipGetLastError());
       // dZ_{l-1} = (dZ_l W_l) * [H_{l-1} > 0]; for l == 0 the mask is the ReLU NeuMF applies to the
       // raw embeddings (quirk Q7) and is absent for the stand-alone MLP
