@@ -10,3 +10,4 @@ from . import _lib  # noqa: F401
 from .torch_engine import HipOptimizer, ModelEngine  # noqa: F401
 from .mf import MF, DeviceTripleBatcher, MFEngine, gather_rows  # noqa: F401
 from .ncf import GMF, MLP, GMFEngine, MLPEngine, NeuMF, NeuMFEngine  # noqa: F401
+from .lightgcn import LightGCN, LightGCNEngine  # noqa: F401

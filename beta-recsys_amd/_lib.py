@@ -72,6 +72,21 @@ class NcfPlan(Structure):
     )
 
 
+class Csr(Structure):
+    """hiprec_csr (include/hiprec.h)."""
+
+    _fields_ = [("rowptr", c_void_p), ("col", c_void_p), ("val", c_void_p), ("eid", c_void_p),
+                ("n_rows", c_int64), ("nnz", c_int64)]
+
+
+class LightGcnPlan(Structure):
+    """hiprec_lightgcn_plan (include/hiprec.h)."""
+
+    _fields_ = [("a", Csr), ("at", Csr), ("n_users", c_int64), ("n_items", c_int64),
+                ("dim", c_int32), ("n_layers", c_int32), ("decay", c_float), ("_pad", c_int32)] + \
+               [(n, c_void_p) for n in ("e0", "g", "xa", "xb", "acc", "da", "db")]
+
+
 # name -> (restype, argtypes); every symbol of include/hiprec.h must be listed here
 _P = c_void_p
 _T = POINTER(MfTables)
@@ -114,6 +129,15 @@ SIGNATURES = {
         c_int,
         [POINTER(NcfPlan), _P, _P, _P, c_int64, c_float, _P, _P, c_size_t, _P],
     ),
+    "hiprec_lightgcn_plan_bytes": (c_size_t, []),
+    "hiprec_spmm_csr": (c_int, [POINTER(Csr), _P, c_float, _P, _P, _P, c_int32, _P]),
+    "hiprec_edge_dropout_mask": (c_int, [_P, c_int64, c_float, ctypes.c_uint64, ctypes.c_uint64, _P]),
+    "hiprec_lightgcn_propagate": (c_int, [POINTER(LightGcnPlan), _P, c_float, _P]),
+    "hiprec_lightgcn_predict": (c_int, [POINTER(LightGcnPlan), _P, _P, c_int64, _P, _P, _P]),
+    "hiprec_lightgcn_grad": (
+        c_int,
+        [POINTER(LightGcnPlan), _P, c_float, _P, _P, _P, c_int64, c_float, _P, _P, c_size_t, _P],
+    ),
     "hiprec_mf_bpr_epoch": (
         c_int,
         [_T, _T, _P, _P, _P, _P, c_int64, c_int64, c_float, c_int]
@@ -154,6 +178,8 @@ def load():
         fn.argtypes = argtypes
     if lib.hiprec_stats_bytes() != ctypes.sizeof(Stats):
         raise RuntimeError("hiprec_stats layout mismatch between _lib.py and libhiprec.so")
+    if lib.hiprec_lightgcn_plan_bytes() != ctypes.sizeof(LightGcnPlan):
+        raise RuntimeError("hiprec_lightgcn_plan layout mismatch between _lib.py and libhiprec.so")
     if lib.hiprec_ncf_plan_bytes() != ctypes.sizeof(NcfPlan):
         raise RuntimeError("hiprec_ncf_plan layout mismatch between _lib.py and libhiprec.so")
     _lib = lib

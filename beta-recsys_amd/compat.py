@@ -14,6 +14,7 @@ MIRRORS = {
     "beta_rec.models.ncf": "ncf",
     "beta_rec.models.gmf": "ncf",
     "beta_rec.models.mlp": "ncf",
+    "beta_rec.models.lightgcn": "lightgcn",
 }
 
 

@@ -1,0 +1,323 @@
+// LightGCN training step for gfx950.
+//
+// Replaces beta_rec/models/lightgcn.py:46-78 (LightGCN.forward: edge dropout + n_layers x
+// torch.sparse.mm + mean over layers), :119-152 / :171-191 (gather of the propagated rows, BPR
+// softplus loss, L2 on the layer-0 rows) and the autograd backward (n_layers x sparse.mm with the
+// transposed graph, dense gradients).
+//
+// SpMM: the graph is the reference's D^-1 (A + I) in CSR (int64 row pointers, int32 columns, fp32
+// values); item degrees follow a popularity law (a handful of rows own thousands of edges), so the
+// work is split by EDGES, not rows: every wavefront takes a contiguous slice of kEdgesPerWave edges,
+// finds its first row by binary search, keeps the running row sum in registers (one lane per
+// embedding column) and flushes at row boundaries with fp32 atomics.  64 (col, val) pairs are
+// fetched with ONE coalesced vector load and broadcast lane by lane with v_readlane.  The flush goes
+// to the layer output Y and, fused, to the running layer sum ACC (the mean over layers / the
+// accumulated gradient), so no separate add kernel exists.  Edge dropout is a per-edge keep byte
+// (drawn like the reference does, or by hiprec_edge_dropout_mask) applied on the fly; the
+// transposed graph looks its edges up through `eid` so both directions drop the same edges.
+#include "common.hpp"
+
+namespace hiprec {
+
+constexpr int kEdgesPerWave = 256;
+
+__device__ __forceinline__ int64_t find_row(const int64_t* __restrict__ rowptr, int64_t n_rows,
+                                            int64_t e) {
+  // largest r with rowptr[r] <= e
+  int64_t lo = 0, hi = n_rows;
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (rowptr[mid] <= e) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// NPL = columns per lane held in registers (dim <= 64 * NPL)
+template <int NPL>
+__global__ __launch_bounds__(kBlock) void spmm_csr_kernel(hiprec_csr a,
+                                                          const uint8_t* __restrict__ keep,
+                                                          float scale, const float* __restrict__ x,
+                                                          float* __restrict__ y,
+                                                          float* __restrict__ acc_out, int dim) {
+  const int lane = lane_id();
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
+  const int64_t e_begin = wave * kEdgesPerWave;
+  if (e_begin >= a.nnz) return;
+  const int64_t e_end = min(a.nnz, e_begin + kEdgesPerWave);
+  int64_t row = find_row(a.rowptr, a.n_rows, e_begin);
+  int64_t row_end = a.rowptr[row + 1];
+  float acc[NPL];
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) acc[k] = 0.f;
+
+  auto flush = [&](int64_t r) {
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+      const int c = lane + kWave * k;
+      if (c < dim && acc[k] != 0.f) {
+        atomic_add_f32(y + r * dim + c, acc[k]);
+        if (acc_out) atomic_add_f32(acc_out + r * dim + c, acc[k]);
+      }
+      acc[k] = 0.f;
+    }
+  };
+
+  for (int64_t e0 = e_begin; e0 < e_end; e0 += kWave) {
+    const int64_t e = e0 + lane;
+    int my_col = 0;
+    float my_val = 0.f;
+    if (e < e_end) {
+      my_col = a.col[e];
+      my_val = a.val[e];
+      if (keep) my_val = keep[a.eid ? a.eid[e] : e] ? my_val * scale : 0.f;
+    }
+    const int n_here = static_cast<int>(min<int64_t>(kWave, e_end - e0));
+    for (int j = 0; j < n_here; ++j) {
+      while (e0 + j >= row_end) {  // row boundary (empty rows are skipped)
+        flush(row);
+        ++row;
+        row_end = a.rowptr[row + 1];
+      }
+      const int c_src = __builtin_amdgcn_readlane(my_col, j);
+      const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), j));
+      if (v != 0.f) {
+        const float* xr = x + static_cast<int64_t>(c_src) * dim;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+          const int c = lane + kWave * k;
+          if (c < dim) acc[k] += v * xr[c];
+        }
+      }
+    }
+  }
+  flush(row);
+}
+
+// keep[e] = (uniform(seed, step, e) < keep_prob): counter-based (splitmix64 finaliser), no state
+__global__ __launch_bounds__(kBlock) void edge_dropout_kernel(uint8_t* __restrict__ keep,
+                                                              int64_t nnz, float keep_prob,
+                                                              uint64_t seed, uint64_t step) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < nnz; e += stride) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (static_cast<uint64_t>(e) + 1) +
+                 0xD1B54A32D192ED03ull * (step + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = static_cast<float>(z >> 40) * (1.0f / 16777216.0f);  // 24 bits -> [0, 1)
+    keep[e] = u < keep_prob ? 1 : 0;
+  }
+}
+
+// BPR softplus loss on the propagated rows + L2 on the layer-0 rows (lightgcn.py:171-191) and
+// the gradient w.r.t. the propagated embeddings.  One wave per triple.  `acc` holds the SUM over
+// layers (out = acc / (L+1)).  d_out contributions go to `d` (input of the backward propagation)
+// AND to `g` (its l = 0 term); the L2 gradient goes to `g` only.
+__global__ __launch_bounds__(kBlock) void lightgcn_loss_kernel(
+    hiprec_lightgcn_plan p, const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
+    const int64_t* __restrict__ neg, int64_t batch, float inv_batch, hiprec_stats* stats,
+    Scratch* scratch) {
+  const int lane = lane_id();
+  const int D = p.dim;
+  const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const float inv_l = 1.0f / static_cast<float>(p.n_layers + 1);
+  float loss_acc = 0.f, reg_acc = 0.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) advance_step(stats);
+  for (int64_t t = wave0; t < batch; t += n_waves) {
+    const int64_t u = users[t], i = pos[t], j = neg[t];
+    const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(p.n_users);
+    const bool i_ok = static_cast<uint64_t>(i) < static_cast<uint64_t>(p.n_items) &&
+                      static_cast<uint64_t>(j) < static_cast<uint64_t>(p.n_items);
+    if (!(u_ok && i_ok)) {
+      if (lane == 0)
+        atomicOr(&stats->status,
+                 (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
+      continue;
+    }
+    const int64_t ru = u * D, rp = (p.n_users + i) * D, rn = (p.n_users + j) * D;
+    float dp = 0.f, dn = 0.f;
+    for (int c = lane; c < D; c += kWave) {
+      const float ue = p.acc[ru + c] * inv_l, pe = p.acc[rp + c] * inv_l, ne = p.acc[rn + c] * inv_l;
+      dp += ue * pe;
+      dn += ue * ne;
+      const float u0 = p.e0[ru + c], p0 = p.e0[rp + c], n0 = p.e0[rn + c];
+      reg_acc += u0 * u0 + p0 * p0 + n0 * n0;
+    }
+    dp = wave_sum(dp);
+    dn = wave_sum(dn);
+    const float xx = dn - dp;  // softplus(neg - pos)
+    loss_acc += xx > 20.f ? xx : log1pf(expf(xx));
+    const float dx = sigmoid_f32(xx) * inv_batch * inv_l;  // d mf / d x, pre-scaled by 1/(L+1)
+    const float cr = p.decay * inv_batch;                   // d reg / d row = decay * row / B
+    for (int c = lane; c < D; c += kWave) {
+      const float ue = p.acc[ru + c] * inv_l, pe = p.acc[rp + c] * inv_l, ne = p.acc[rn + c] * inv_l;
+      const float gu = dx * (ne - pe), gp = -dx * ue, gn = dx * ue;
+      atomic_add_f32(p.da + ru + c, gu);
+      atomic_add_f32(p.da + rp + c, gp);
+      atomic_add_f32(p.da + rn + c, gn);
+      atomic_add_f32(p.g + ru + c, gu + cr * p.e0[ru + c]);
+      atomic_add_f32(p.g + rp + c, gp + cr * p.e0[rp + c]);
+      atomic_add_f32(p.g + rn + c, gn + cr * p.e0[rn + c]);
+    }
+  }
+  // loss = mean softplus + decay * 0.5 * sum(...) / B ; published as ONE number (loss slot)
+  const float reg_w = wave_sum(reg_acc);
+  publish_partials<kWavesPerBlock>(loss_acc + 0.5f * p.decay * reg_w, 0.f, 0.f, inv_batch, scratch);
+}
+
+// scores[k] = sigmoid(<out[u], out[U + i]>) with out = acc / (L+1)   (LightGCN.predict :98-100)
+__global__ __launch_bounds__(kBlock) void lightgcn_predict_kernel(hiprec_lightgcn_plan p,
+                                                                  const int64_t* __restrict__ users,
+                                                                  const int64_t* __restrict__ items,
+                                                                  int64_t n, float* __restrict__ scores,
+                                                                  hiprec_stats* stats) {
+  const int lane = lane_id();
+  const int D = p.dim;
+  const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const float inv_l = 1.0f / static_cast<float>(p.n_layers + 1);
+  for (int64_t t = wave0; t < n; t += n_waves) {
+    const int64_t u = users[t], i = items[t];
+    if (static_cast<uint64_t>(u) >= static_cast<uint64_t>(p.n_users) ||
+        static_cast<uint64_t>(i) >= static_cast<uint64_t>(p.n_items)) {
+      if (lane == 0) {
+        atomicOr(&stats->status, HIPREC_STATUS_ROW_OOB);
+        scores[t] = __builtin_nanf("");
+      }
+      continue;
+    }
+    float dot = 0.f;
+    for (int c = lane; c < D; c += kWave)
+      dot += (p.acc[u * D + c] * inv_l) * (p.acc[(p.n_users + i) * D + c] * inv_l);
+    dot = wave_sum(dot);
+    if (lane == 0) scores[t] = sigmoid_f32(dot);
+  }
+}
+
+static int launch_spmm(const hiprec_csr* a, const uint8_t* keep, float scale, const float* x,
+                       float* y, float* acc, int dim, hipStream_t st) {
+  HIPREC_TRY(hipMemsetAsync(y, 0, sizeof(float) * a->n_rows * dim, st));
+  if (a->nnz == 0) return 0;
+  const int64_t n_waves = (a->nnz + kEdgesPerWave - 1) / kEdgesPerWave;
+  const int64_t blocks = (n_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+  HIPREC_REQUIRE(blocks < (1ll << 31), "graph too large for one launch");
+  const int grid = static_cast<int>(blocks);
+  if (dim <= 64) spmm_csr_kernel<1><<<grid, kBlock, 0, st>>>(*a, keep, scale, x, y, acc, dim);
+  else if (dim <= 128) spmm_csr_kernel<2><<<grid, kBlock, 0, st>>>(*a, keep, scale, x, y, acc, dim);
+  else if (dim <= 256) spmm_csr_kernel<4><<<grid, kBlock, 0, st>>>(*a, keep, scale, x, y, acc, dim);
+  else {
+    set_error("LightGCN embedding dim %d > 256 is not supported", dim);
+    return HIPREC_E_UNSUPPORTED;
+  }
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+static int check_csr(const hiprec_csr* a, const char* name) {
+  HIPREC_REQUIRE(a && a->rowptr && a->n_rows > 0 && a->nnz >= 0, "bad CSR %s", name);
+  HIPREC_REQUIRE(a->nnz == 0 || (a->col && a->val), "CSR %s has NULL col/val", name);
+  return 0;
+}
+
+static int check_lg_plan(const hiprec_lightgcn_plan* p, bool train) {
+  HIPREC_REQUIRE(p != nullptr, "NULL plan");
+  if (int rc = check_csr(&p->a, "a")) return rc;
+  HIPREC_REQUIRE(p->n_users > 0 && p->n_items > 0 && p->dim > 0 && p->n_layers >= 0, "bad sizes");
+  HIPREC_REQUIRE(p->a.n_rows == p->n_users + p->n_items, "graph size != n_users + n_items");
+  HIPREC_REQUIRE(p->e0 && p->xa && p->xb && p->acc, "NULL forward buffers");
+  if (train) {
+    if (int rc = check_csr(&p->at, "at")) return rc;
+    HIPREC_REQUIRE(p->at.n_rows == p->a.n_rows && p->at.nnz == p->a.nnz, "a / at mismatch");
+    HIPREC_REQUIRE(p->g && p->da && p->db, "NULL backward buffers");
+  }
+  return 0;
+}
+
+// acc = sum_{l=0..L} A^l E0   (out = acc / (L+1))
+static int propagate(const hiprec_lightgcn_plan* p, const uint8_t* keep, float keep_prob,
+                     hipStream_t st) {
+  const size_t bytes = sizeof(float) * p->a.n_rows * p->dim;
+  HIPREC_TRY(hipMemcpyAsync(p->acc, p->e0, bytes, hipMemcpyDeviceToDevice, st));
+  const float scale = keep ? 1.0f / keep_prob : 1.0f;
+  const float* cur = p->e0;
+  for (int l = 0; l < p->n_layers; ++l) {
+    float* nxt = (l & 1) ? p->xb : p->xa;
+    if (int rc = launch_spmm(&p->a, keep, scale, cur, nxt, p->acc, p->dim, st)) return rc;
+    cur = nxt;
+  }
+  return 0;
+}
+
+}  // namespace hiprec
+
+using namespace hiprec;
+
+extern "C" size_t hiprec_lightgcn_plan_bytes(void) { return sizeof(hiprec_lightgcn_plan); }
+
+extern "C" int hiprec_spmm_csr(const hiprec_csr* a, const uint8_t* keep, float scale, const float* x,
+                               float* y, float* acc, int32_t dim, void* stream) {
+  if (int rc = check_csr(a, "a")) return rc;
+  HIPREC_REQUIRE(x && y && dim > 0, "NULL x / y or bad dim");
+  return launch_spmm(a, keep, keep ? scale : 1.0f, x, y, acc, dim, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int hiprec_edge_dropout_mask(uint8_t* keep, int64_t nnz, float keep_prob, uint64_t seed,
+                                        uint64_t step, void* stream) {
+  HIPREC_REQUIRE(nnz >= 0 && (nnz == 0 || keep), "bad mask buffer");
+  if (nnz == 0) return 0;
+  edge_dropout_kernel<<<grid_for_threads(nnz), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      keep, nnz, keep_prob, seed, step);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_lightgcn_propagate(const hiprec_lightgcn_plan* plan, const uint8_t* keep,
+                                         float keep_prob, void* stream) {
+  if (int rc = check_lg_plan(plan, false)) return rc;
+  return propagate(plan, keep, keep_prob, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int hiprec_lightgcn_predict(const hiprec_lightgcn_plan* plan, const int64_t* users,
+                                       const int64_t* items, int64_t n, float* scores,
+                                       hiprec_stats* stats, void* stream) {
+  if (int rc = check_lg_plan(plan, false)) return rc;
+  if (n == 0) return 0;
+  HIPREC_REQUIRE(n > 0 && users && items && scores && stats, "NULL pointer");
+  lightgcn_predict_kernel<<<grid_for_waves(n), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      *plan, users, items, n, scores, stats);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_lightgcn_grad(const hiprec_lightgcn_plan* plan, const uint8_t* keep,
+                                    float keep_prob, const int64_t* users, const int64_t* pos,
+                                    const int64_t* neg, int64_t batch, float inv_batch,
+                                    hiprec_stats* stats, void* scratch, size_t scratch_bytes,
+                                    void* stream) {
+  if (int rc = check_lg_plan(plan, true)) return rc;
+  HIPREC_REQUIRE(batch > 0 && users && pos && neg && stats && scratch, "NULL pointer / empty batch");
+  if (scratch_bytes < kScratchBytes) {
+    set_error("scratch too small: %zu < %zu", scratch_bytes, kScratchBytes);
+    return HIPREC_E_SCRATCH;
+  }
+  const hiprec_lightgcn_plan* p = plan;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (int rc = propagate(p, keep, keep_prob, st)) return rc;
+  const size_t bytes = sizeof(float) * p->a.n_rows * p->dim;
+  HIPREC_TRY(hipMemsetAsync(p->da, 0, bytes, st));
+  lightgcn_loss_kernel<<<grid_for_waves(batch), kBlock, 0, st>>>(
+      *p, users, pos, neg, batch, inv_batch, stats, static_cast<Scratch*>(scratch));
+  HIPREC_TRY(hipGetLastError());
+  // g = sum_{l=0..L} (A^T)^l d_out : the l = 0 term is already in g
+  const float scale = keep ? 1.0f / keep_prob : 1.0f;
+  float* cur = p->da;
+  float* nxt = p->db;
+  for (int l = 0; l < p->n_layers; ++l) {
+    if (int rc = launch_spmm(&p->at, keep, scale, cur, nxt, p->g, p->dim, st)) return rc;
+    float* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+  return 0;
+}

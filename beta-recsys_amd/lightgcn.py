@@ -1,0 +1,274 @@
+"""Drop-in ``LightGCN`` / ``LightGCNEngine`` for beta_rec/models/lightgcn.py on libhiprec.so.
+
+Interface parity (file:line = /root/reference/beta_rec/...): ``LightGCN(config, norm_adj)``
+models/lightgcn.py:7-101 (``forward(norm_adj) -> (user, item) embeddings``, ``predict``),
+``LightGCNEngine(config)`` :104-191 (``train_single_batch(batch) -> float``, ``train_an_epoch``).
+Same config keys (``n_users n_items emb_dim layer_size keep_pro regs norm_adj optimizer lr
+device_str``), same ``state_dict`` keys, same initial weights for the same torch seed.
+
+The sparse propagation, the loss and the whole backward are ``csrc/lightgcn.hip``.  The graph is
+converted ONCE from the torch sparse COO tensor the reference passes around to CSR + transposed CSR
+on the device.  Edge dropout (training only, ``keep_pro``): ``dropout_rng = "torch_cpu"`` (default)
+draws ``torch.rand(nnz)`` from the global CPU generator exactly like models/lightgcn.py:32, so the
+same seed drops the same edges as the reference; ``"device"`` draws the keep bytes on the GPU
+(no host work, no 2 MB upload per step) for production speed.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .mf import _new_stats, raise_on_status, read_stats
+from .ncf import _FlatModel, _ParamView
+from .torch_engine import ModelEngine
+
+
+def _csr_from_coo(rows, cols, vals, n, device):
+    """Sorted CSR (int64 rowptr, int32 col, fp32 val) + the sort permutation."""
+    order = torch.argsort(rows * n + cols, stable=True)
+    r, c, v = rows[order], cols[order], vals[order]
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=n), 0)
+    return (rowptr.to(device), c.to(torch.int32).to(device), v.to(torch.float32).to(device), order)
+
+
+class LightGCN(_FlatModel):
+    """models/lightgcn.py:7-101."""
+
+    def __init__(self, config, norm_adj):
+        super().__init__()
+        self.config = config
+        self.n_users, self.n_items = int(config["n_users"]), int(config["n_items"])
+        self.emb_dim = int(config["emb_dim"])
+        self.layer_size = config["layer_size"]
+        self.n_layers = len(self.layer_size)
+        self.norm_adj = norm_adj
+        self.layer_size = [self.emb_dim] + list(self.layer_size)
+        v = self._build([("user_embedding.weight", (self.n_users, self.emb_dim)),
+                         ("item_embedding.weight", (self.n_items, self.emb_dim))])
+        # RNG order of lightgcn.py:22-25,40-44: two nn.Embedding (N(0,1)) then xavier_uniform_ x2
+        v["user_embedding.weight"].normal_(0, 1)
+        v["item_embedding.weight"].normal_(0, 1)
+        nn.init.xavier_uniform_(v["user_embedding.weight"])
+        nn.init.xavier_uniform_(v["item_embedding.weight"])
+        self.user_embedding = _ParamView(v["user_embedding.weight"])
+        self.item_embedding = _ParamView(v["item_embedding.weight"])
+        self.f = nn.Sigmoid()
+        self.dropout_rng = config["dropout_rng"] if "dropout_rng" in config else "torch_cpu"
+        self.dropout_seed = int(config["dropout_seed"]) if "dropout_seed" in config else 0
+        self._graph = None
+        self._ws = None
+        self._stats = None
+        self._step = 0
+
+    # ---- graph + workspace ------------------------------------------------------------------
+    def graph(self):
+        """CSR and transposed CSR of norm_adj on the parameters' device (built once)."""
+        dev = self._flat.device
+        if self._graph is not None and self._graph["dev"] == dev:
+            return self._graph
+        co = self.norm_adj.coalesce().cpu()
+        N = self.n_users + self.n_items
+        if tuple(co.shape) != (N, N):
+            raise ValueError(f"norm_adj is {tuple(co.shape)}, expected ({N}, {N})")
+        rows, cols = co.indices()[0], co.indices()[1]
+        vals = co.values().to(torch.float32)
+        # coalesced COO is already sorted row-major: edge e of the CSR == value e of the COO, which
+        # is the order LightGCN.dropout draws its mask in (lightgcn.py:29-35)
+        rp, c, v, _ = _csr_from_coo(rows, cols, vals, N, dev)
+        rpt, ct, vt, order_t = _csr_from_coo(cols, rows, vals, N, dev)
+        self._graph = {"dev": dev, "nnz": int(vals.numel()), "rowptr": rp, "col": c, "val": v,
+                       "rowptr_t": rpt, "col_t": ct, "val_t": vt,
+                       "eid_t": order_t.to(torch.int32).to(dev)}
+        return self._graph
+
+    def workspace(self):
+        dev = self._flat.device
+        if self._ws is not None and self._ws["dev"] == dev:
+            return self._ws
+        N, D = self.n_users + self.n_items, self.emb_dim
+        g = self.graph()
+        self._ws = {"dev": dev, "keep": torch.ones(max(g["nnz"], 1), dtype=torch.uint8, device=dev)}
+        for name in ("xa", "xb", "acc", "da", "db"):
+            self._ws[name] = torch.zeros(N, D, dtype=torch.float32, device=dev)
+        return self._ws
+
+    def plan(self, g_flat=None, decay=0.0):
+        gr, ws = self.graph(), self.workspace()
+        N = self.n_users + self.n_items
+        p = _lib.LightGcnPlan()
+        p.a = _lib.Csr(gr["rowptr"].data_ptr(), gr["col"].data_ptr(), gr["val"].data_ptr(), None, N, gr["nnz"])
+        p.at = _lib.Csr(gr["rowptr_t"].data_ptr(), gr["col_t"].data_ptr(), gr["val_t"].data_ptr(),
+                        gr["eid_t"].data_ptr(), N, gr["nnz"])
+        p.n_users, p.n_items, p.dim, p.n_layers = self.n_users, self.n_items, self.emb_dim, self.n_layers
+        p.decay = float(decay)
+        p.e0 = self._flat.data_ptr()
+        p.g = None if g_flat is None else g_flat.data_ptr()
+        for name in ("xa", "xb", "acc", "da", "db"):
+            setattr(p, name, ws[name].data_ptr())
+        return p
+
+    def draw_keep_mask(self):
+        """Edge keep bytes of one training step (None in eval mode)."""
+        if not self.training:
+            return None
+        lib = self._require_hip()
+        ws, gr = self.workspace(), self.graph()
+        keep_prob = float(self.config["keep_pro"])
+        self._step += 1
+        if self.dropout_rng == "torch_cpu":
+            # lightgcn.py:32-33: (torch.rand(len(values)) + keep_prob).int().bool()
+            mask = (torch.rand(gr["nnz"]) + keep_prob).int().bool()
+            ws["keep"][: gr["nnz"]].copy_(mask.to(torch.uint8), non_blocking=False)
+        elif self.dropout_rng == "device":
+            _lib.check(lib.hiprec_edge_dropout_mask(
+                _lib.ptr(ws["keep"]), gr["nnz"], keep_prob, self.dropout_seed, self._step,
+                _lib.stream_ptr(self._flat.device)))
+        else:
+            raise ValueError(f"unknown dropout_rng {self.dropout_rng!r}: 'torch_cpu' or 'device'")
+        return ws["keep"]
+
+    # ---- reference API ---------------------------------------------------------------------
+    def forward(self, norm_adj=None):
+        """lightgcn.py:46-78 without autograd: ``(u_g_embeddings, i_g_embeddings)``.  The graph is
+        the one given at construction (the reference always passes that same tensor)."""
+        lib = self._require_hip()
+        keep = self.draw_keep_mask()
+        plan = self.plan()
+        _lib.check(lib.hiprec_lightgcn_propagate(
+            ctypes.byref(plan), _lib.ptr(keep), float(self.config["keep_pro"]) if keep is not None else 1.0,
+            _lib.stream_ptr(self._flat.device)))
+        out = self._ws["acc"] / float(self.n_layers + 1)
+        return torch.split(out, [self.n_users, self.n_items])
+
+    def predict(self, users, items):
+        """lightgcn.py:80-101: eval mode, full propagation, sigmoid of the dot product."""
+        self.eval()
+        lib = self._require_hip()
+        dev = self._flat.device
+        users_t = torch.as_tensor(np.asarray(users), dtype=torch.int64).to(dev).reshape(-1).contiguous()
+        items_t = torch.as_tensor(np.asarray(items), dtype=torch.int64).to(dev).reshape(-1).contiguous()
+        if self._stats is None or self._stats.device != dev:
+            self._stats = _new_stats(dev)
+        plan = self.plan()
+        st = _lib.stream_ptr(dev)
+        _lib.check(lib.hiprec_lightgcn_propagate(ctypes.byref(plan), None, 1.0, st))
+        scores = torch.empty(users_t.numel(), dtype=torch.float32, device=dev)
+        _lib.check(lib.hiprec_lightgcn_predict(ctypes.byref(plan), _lib.ptr(users_t), _lib.ptr(items_t),
+                                               users_t.numel(), _lib.ptr(scores), _lib.ptr(self._stats), st))
+        s = read_stats(self._stats)
+        if s.status:
+            self._stats = None
+            raise_on_status(s.status)
+        return scores
+
+
+class LightGCNEngine(ModelEngine):
+    """models/lightgcn.py:104-191."""
+
+    def __init__(self, config):
+        self.config = config
+        self.regs = config["model"]["regs"]
+        self.decay = self.regs[0]
+        self.norm_adj = config["model"]["norm_adj"]
+        self.model = LightGCN(config["model"], self.norm_adj)
+        super(LightGCNEngine, self).__init__(config)
+        self.model.to(self.device)
+        self._ready = False
+
+    def _setup(self):
+        lib = self.require_hip()
+        flat = self.model.flat
+        if self._ready and self._g_flat.device == flat.device:
+            return lib
+        self._g_flat = torch.zeros_like(flat)
+        self.optimizer.allocate_state(flat)
+        self._scratch = torch.zeros(lib.hiprec_scratch_bytes(0), dtype=torch.uint8, device=flat.device)
+        self._stats = _new_stats(flat.device, self.optimizer.beta1 or 0.9, self.optimizer.beta2 or 0.999)
+        self._ready = True
+        return lib
+
+    def _enqueue_grad(self, batch_data):
+        lib = self._setup()
+        m = self.model
+        dev = m.flat.device
+        users, pos, neg = (torch.as_tensor(x, device=dev).to(torch.int64).reshape(-1).contiguous()
+                           for x in batch_data)
+        B = users.numel()
+        if not (pos.numel() == B and neg.numel() == B):
+            raise ValueError("batch tensors differ in length")
+        if B == 0:
+            raise ValueError("empty batch")
+        keep = m.draw_keep_mask()
+        plan = m.plan(self._g_flat, self.decay)
+        _lib.check(lib.hiprec_lightgcn_grad(
+            ctypes.byref(plan), _lib.ptr(keep), float(m.config["keep_pro"]) if keep is not None else 1.0,
+            _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), B, 1.0 / B, _lib.ptr(self._stats),
+            _lib.ptr(self._scratch), self._scratch.numel(), _lib.stream_ptr(dev)))
+
+    def _enqueue_step(self, batch_data):
+        self._enqueue_grad(batch_data)
+        lib, m, opt = _lib.load(), self.model, self.optimizer
+        _lib.check(lib.hiprec_opt_dense_step(
+            opt.kind, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),
+            _lib.ptr(opt.exp_avg_sq), m.flat.numel(), opt.lr, opt.beta1, opt.beta2, opt.eps,
+            _lib.ptr(self._stats), _lib.ptr(self._scratch), -1, _lib.stream_ptr(m.flat.device)))
+
+    def _sync_stats(self):
+        st = read_stats(self._stats)
+        if st.status:
+            raw = self._stats.cpu()
+            off = _lib.Stats.status.offset
+            raw[off:off + 4] = 0
+            self._stats.copy_(raw)
+            raise_on_status(st.status)
+        return st
+
+    def backward_only(self, batch_data):
+        """zero_grad + forward + loss + backward without the optimizer step: ``(loss, grads)``."""
+        self._enqueue_grad(batch_data)
+        lib = _lib.load()
+        _lib.check(lib.hiprec_finalize_stats(_lib.ptr(self._stats), _lib.ptr(self._scratch), None,
+                                             _lib.stream_ptr(self.model.flat.device)))
+        st = self._sync_stats()
+        grads = {k: v.clone() for k, v in self.model.views(self._g_flat).items()}
+        self._g_flat.zero_()
+        return st.loss, grads
+
+    def load_optimizer_state(self, step, exp_avg=None, exp_avg_sq=None):
+        lib = self._setup()
+        opt, m = self.optimizer, self.model
+        dev = m.flat.device
+        _lib.check(lib.hiprec_stats_reset(_lib.ptr(self._stats), opt.beta1 or 0.9, opt.beta2 or 0.999,
+                                          _lib.stream_ptr(dev)))
+        for _ in range(int(step)):
+            _lib.check(lib.hiprec_stats_advance_step(_lib.ptr(self._stats), _lib.stream_ptr(dev)))
+        for buf, src in ((opt.exp_avg, exp_avg), (opt.exp_avg_sq, exp_avg_sq)):
+            if buf is None:
+                continue
+            if src is None:
+                buf.zero_()
+                continue
+            for name, view in m.views(buf).items():
+                view.copy_(torch.as_tensor(src[name], dtype=torch.float32).reshape(view.shape))
+
+    def train_single_batch(self, batch_data):
+        """lightgcn.py:119-152: one step, returns ``batch_mf_loss + batch_reg_loss`` as a float."""
+        assert hasattr(self, "model"), "Please specify the exact model !"
+        self._enqueue_step(batch_data)
+        return self._sync_stats().loss
+
+    def train_an_epoch(self, train_loader, epoch_id):
+        """lightgcn.py:154-169: prints the last batch's loss, logs the epoch sum."""
+        assert hasattr(self, "model"), "Please specify the exact model !"
+        self.model.train()
+        lib = self._setup()
+        _lib.check(lib.hiprec_stats_begin_epoch(_lib.ptr(self._stats),
+                                                _lib.stream_ptr(self.model.flat.device)))
+        for batch_data in train_loader:
+            self._enqueue_step(batch_data)
+        st = self._sync_stats()
+        print("[Training Epoch {}], Loss {}".format(epoch_id, st.loss))
+        self.writer.add_scalar("model/loss", st.loss_sum, epoch_id)

@@ -225,6 +225,63 @@ int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users, const int
                     const float* ratings, int64_t batch, float inv_batch, hiprec_stats* stats,
                     void* scratch, size_t scratch_bytes, void* stream);
 
+/* ======================= LightGCN (models/lightgcn.py) ============================================ */
+
+/* CSR graph: the reference's norm_adj = D^-1 (A + I) over (n_users + n_items) nodes
+ * (utils/common_util.py:24-41, data/deprecated_data_base.py:353), or its transpose.  `eid` (may be
+ * NULL = identity) maps an edge of THIS matrix to its index in the forward matrix, so that the
+ * transposed graph applies the same edge-dropout bytes. */
+typedef struct hiprec_csr {
+  const int64_t* rowptr; /* [n_rows + 1] */
+  const int32_t* col;    /* [nnz] */
+  const float* val;      /* [nnz] */
+  const int32_t* eid;    /* [nnz] or NULL */
+  int64_t n_rows;
+  int64_t nnz;
+} hiprec_csr;
+
+/* Everything one LightGCN step touches.  e0 / g are the flat parameter / gradient buffers
+ * [user_embedding | item_embedding] = [(n_users + n_items), dim]; the rest is caller-owned
+ * workspace of the same shape. */
+typedef struct hiprec_lightgcn_plan {
+  hiprec_csr a;  /* forward graph  */
+  hiprec_csr at; /* its transpose (backward) */
+  int64_t n_users, n_items;
+  int32_t dim, n_layers;
+  float decay; /* regs[0], lightgcn.py:112-113 */
+  int32_t _pad;
+  float *e0, *g, *xa, *xb, *acc, *da, *db;
+} hiprec_lightgcn_plan;
+
+size_t hiprec_lightgcn_plan_bytes(void);
+
+/* ---- y = (A with dropped edges) x ; acc += y.  keep (may be NULL) holds one byte per forward edge,
+ * kept edges are scaled by `scale` (= 1/keep_prob, lightgcn.py:27-38).  y is zeroed by the call. */
+int hiprec_spmm_csr(const hiprec_csr* a, const uint8_t* keep, float scale, const float* x, float* y,
+                    float* acc, int32_t dim, void* stream);
+
+/* ---- keep[e] = uniform(seed, step, e) < keep_prob on the device (counter-based, stateless): the
+ * fast alternative to drawing torch.rand(nnz) on the CPU every step as lightgcn.py:32 does. */
+int hiprec_edge_dropout_mask(uint8_t* keep, int64_t nnz, float keep_prob, uint64_t seed,
+                             uint64_t step, void* stream);
+
+/* ---- LightGCN.forward (lightgcn.py:46-78): plan->acc = sum_l A^l E0 (propagated = acc/(L+1)). */
+int hiprec_lightgcn_propagate(const hiprec_lightgcn_plan* plan, const uint8_t* keep, float keep_prob,
+                              void* stream);
+
+/* ---- scores = sigmoid(<out[u], out[item]>) on the rows left in plan->acc by the last propagate
+ * (LightGCN.predict, lightgcn.py:80-101). */
+int hiprec_lightgcn_predict(const hiprec_lightgcn_plan* plan, const int64_t* users,
+                            const int64_t* items, int64_t n, float* scores, hiprec_stats* stats,
+                            void* stream);
+
+/* ---- zero_grad + forward + loss_comput + backward of LightGCNEngine.train_single_batch
+ * (lightgcn.py:119-149, 171-191): dense gradient into plan->g, loss partials in scratch. */
+int hiprec_lightgcn_grad(const hiprec_lightgcn_plan* plan, const uint8_t* keep, float keep_prob,
+                         const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t batch,
+                         float inv_batch, hiprec_stats* stats, void* scratch, size_t scratch_bytes,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -245,7 +245,7 @@ def main():
     epoch_fixture(MFEngine, PairwiseNegativeDataset, "mf_epoch_sgd", "sgd", seed=22)
 
 
-if __name__ == "__main__" and "--ncf" not in sys.argv:
+if __name__ == "__main__" and "--ncf" not in sys.argv and "--lightgcn" not in sys.argv:
     main()
 
 
@@ -313,3 +313,81 @@ def main_ncf():
 
 if __name__ == "__main__" and "--ncf" in sys.argv:
     main_ncf()
+
+
+# ---- LightGCN (models/lightgcn.py) ------------------------------------------------------------------
+
+def lightgcn_fixture(name, U, I, D, L, B, n_edges, optimizer, lr, keep, n_steps, seed):
+    import scipy.sparse as sp
+
+    import_reference()
+    from beta_rec.models.lightgcn import LightGCNEngine
+    from beta_rec.utils.common_util import normalized_adj_single
+
+    rng = np.random.default_rng(seed)
+    eu = rng.integers(0, U, n_edges)
+    ei = zipf_items(rng, n_edges, I)
+    # the reference's adjacency (data/deprecated_data_base.py:331-353): R in a dok matrix, A = [[0,R],[R^T,0]],
+    # norm_adj = normalized_adj_single(A + I)
+    N = U + I
+    R = sp.dok_matrix((U, I), dtype=np.float32)
+    for a, b in zip(eu, ei):
+        R[a, b] = 1.0
+    adj = sp.dok_matrix((N, N), dtype=np.float32).tolil()
+    adj[:U, U:] = R.tolil()
+    adj[U:, :U] = R.tolil().T
+    adj = adj.todok()
+    norm = quiet(normalized_adj_single, adj + sp.eye(adj.shape[0])).tocoo().astype(np.float32)
+    idx = torch.from_numpy(np.vstack((norm.row, norm.col)).astype(np.int64))
+    norm_t = torch.sparse_coo_tensor(idx, torch.from_numpy(norm.data), torch.Size(norm.shape))
+    torch.manual_seed(seed)
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, layer_size=[D] * L, keep_pro=keep, regs=[1e-5],
+                         device_str="cpu", optimizer=optimizer, lr=lr, batch_size=B, norm_adj=norm_t),
+           "system": {"run_dir": "/tmp/hiprec_golden_runs"}}
+    eng = quiet(LightGCNEngine, cfg)
+    out = {"meta": np.array([U, I, D, L, B, n_steps, seed], dtype=np.int64), "optimizer": np.array(optimizer),
+           "lr": np.array(lr), "keep": np.array(keep), "decay": np.array(1e-5),
+           "edge_users": eu, "edge_items": ei}
+    co = norm_t.coalesce()
+    out["adj_row"], out["adj_col"] = co.indices()[0].numpy(), co.indices()[1].numpy()
+    out["adj_val"] = co.values().numpy()
+    out.update(state_np(eng.model, "w0"))
+    grads_seen = []
+    orig_step = eng.optimizer.step
+
+    def capturing_step(*a, **k):
+        grads_seen.append({n: p.grad.detach().numpy().copy() for n, p in eng.model.named_parameters()})
+        return orig_step(*a, **k)
+
+    eng.optimizer.step = capturing_step
+    users = rng.integers(0, U, size=(n_steps, B))
+    pos = np.stack([zipf_items(rng, B, I) for _ in range(n_steps)])
+    neg = rng.integers(0, I, size=(n_steps, B))
+    losses, masks = [], []
+    eng.model.train()
+    for s in range(n_steps):
+        torch.manual_seed(1000 + s)  # the state the dropout mask of this step is drawn from
+        losses.append(eng.train_single_batch((torch.from_numpy(users[s]), torch.from_numpy(pos[s]),
+                                              torch.from_numpy(neg[s]))))
+        torch.manual_seed(1000 + s)
+        masks.append((torch.rand(len(co.values())) + keep).int().bool().numpy())
+        out.update(state_np(eng.model, f"w{s + 1}"))
+        for k, v in grads_seen[-1].items():
+            out[f"g{s + 1}/{k}"] = v
+        for pname, p in eng.model.named_parameters():
+            pst = eng.optimizer.state.get(p, {})
+            for sk, tag in (("exp_avg", "m"), ("exp_avg_sq", "v")):
+                if sk in pst:
+                    out[f"{tag}{s + 1}/{pname}"] = pst[sk].detach().numpy().copy()
+    pu, pi = rng.integers(0, U, 50), rng.integers(0, I, 50)
+    out["probe_users"], out["probe_items"] = pu, pi
+    out["probe_scores"] = eng.model.predict(pu, pi).numpy()
+    out.update(users=users, pos=pos, neg=neg, losses=np.array(losses), masks=np.packbits(np.stack(masks), axis=1),
+               nnz=np.array(len(co.values())))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: nnz {len(co.values())} losses {losses}")
+
+
+if __name__ == "__main__" and "--lightgcn" in sys.argv:
+    lightgcn_fixture("lightgcn_adam", 61, 47, 16, 3, 40, 400, "adam", 0.05, 0.6, 3, seed=41)
+    lightgcn_fixture("lightgcn_sgd_d64", 37, 29, 64, 2, 24, 250, "sgd", 0.05, 0.6, 2, seed=42)

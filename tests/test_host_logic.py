@@ -257,3 +257,31 @@ def test_ncf_family_init_and_state_dict_match_reference(case, engine):
         eng.train_single_batch(torch.tensor([0, 1]), torch.tensor([0, 1]), torch.tensor([1.0, 0.0]))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.predict(np.array([0]), np.array([0]))
+
+
+def test_lightgcn_init_and_surface_on_cpu():
+    """Same seed -> the reference's xavier init; reference state_dict keys; no CPU compute path."""
+    import scipy.sparse as sp
+
+    import beta_recsys_amd as hp
+
+    g = load_golden("lightgcn_adam")
+    U, I, D, L, B, _, seed = (int(x) for x in g["meta"])
+    N = U + I
+    idx = torch.from_numpy(np.vstack((g["adj_row"], g["adj_col"])).astype(np.int64))
+    norm = torch.sparse_coo_tensor(idx, torch.from_numpy(g["adj_val"]), torch.Size((N, N)))
+    torch.manual_seed(seed)
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, layer_size=[D] * L, keep_pro=0.6, regs=[1e-5],
+                         device_str="cpu", optimizer="adam", lr=0.05, batch_size=B, norm_adj=norm),
+           "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = hp.LightGCNEngine(cfg)
+    sd = eng.model.state_dict()
+    assert list(sd.keys()) == ["user_embedding.weight", "item_embedding.weight"]
+    for k in sd:
+        assert np.array_equal(sd[k].numpy(), g[f"w0/{k}"]), k
+    assert eng.decay == 1e-5 and eng.model.n_layers == L
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        eng.train_single_batch((torch.tensor([0, 1]), torch.tensor([0, 1]), torch.tensor([1, 2])))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        eng.model.predict(np.array([0]), np.array([0]))
