@@ -172,6 +172,59 @@ def bench_ncf(args, device):
     print(json.dumps(out), flush=True)
 
 
+def bench_lightgcn(args, device):
+    """BASELINE configs[4]: LightGCN on an ML-1M-sized graph (~1M interactions, nnz ~2M), 3 layers,
+    dim 64, batch 1024 triples, keep_pro 0.6 (device-side edge dropout), Adam lr 0.05."""
+    import beta_recsys_amd as hp
+    from oracle.lightgcn_numpy import build_norm_adj  # graph construction only (one-off, host)
+
+    L, Bl = 3, 1024
+    rng = np.random.default_rng(0)
+    n_edges = 1_000_000
+    p = 1.0 / np.arange(1, I + 1) ** 0.9
+    eu = rng.integers(0, U, n_edges)
+    ei = rng.permutation(I)[rng.choice(I, n_edges, p=p / p.sum())]
+    adj = build_norm_adj(U, I, eu, ei).tocoo()
+    idx = torch.from_numpy(np.vstack((adj.row, adj.col)).astype(np.int64))
+    norm = torch.sparse_coo_tensor(idx, torch.from_numpy(adj.data), torch.Size(adj.shape))
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, layer_size=[D] * L, keep_pro=0.6, regs=[1e-5],
+                         device_str=str(device), optimizer="adam", lr=0.05, batch_size=Bl, norm_adj=norm,
+                         dropout_rng="device"),
+           "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
+    torch.manual_seed(2020)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = hp.LightGCNEngine(cfg)
+    n_total = (args.warmup + args.steps) * Bl
+    users, pos, neg = (t.to(device) for t in synth_triples(n_total, seed=100))
+
+    def run(lo, n):
+        for k in range(n):
+            sl = slice(lo + k * Bl, lo + (k + 1) * Bl)
+            eng._enqueue_step((users[sl], pos[sl], neg[sl]))
+
+    run(0, args.warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.warmup * Bl, args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = eng._sync_stats()
+    nnz, N = adj.nnz, U + I
+    # SURVEY §8(d): 2L SpMMs x [nnz*(4+4) + (N+1)*8 + 2*N*D*4] bytes (+ the keep byte per edge)
+    bytes_step = 2 * L * (nnz * 9 + (N + 1) * 8 + 2 * N * D * 4)
+    out = {"metric": "training interactions/sec (LightGCN triples)", "value": args.steps * Bl / dt,
+           "unit": "triples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"LightGCN (BASELINE configs[4]): 6040 x 3706 graph, nnz {nnz}, 3 layers, "
+                                  "dim 64, batch 1024, keep_pro 0.6 (device RNG), adam 0.05",
+                      "last_loss": st.loss},
+           "roofline": {"bound": "hbm", "algorithmic_bytes_per_step": bytes_step,
+                        "achieved": bytes_step / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": bytes_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,7 +232,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adam", "rmsprop"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="mf", choices=["mf", "ncf"],
+    ap.add_argument("--workload", default="mf", choices=["mf", "ncf", "lightgcn"],
                     help="mf = BASELINE configs[1] (the headline); ncf = configs[2] (NeuMF, emb_dim 32)")
     ap.add_argument("--multi-gpu", default="auto", choices=["auto", "replicated", "sharded"],
                     help="N>1: replicate small tables (gradient all-reduce) or row-shard them "
@@ -207,6 +260,8 @@ def main():
 
     if args.workload == "ncf":
         return bench_ncf(args, device)
+    if args.workload == "lightgcn":
+        return bench_lightgcn(args, device)
 
     n_total = (args.warmup + args.steps) * B
     users, pos, neg = (t.to(device) for t in synth_triples(n_total, seed=100 + rank))
