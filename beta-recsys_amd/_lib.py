@@ -109,7 +109,7 @@ SIGNATURES = {
         c_int,
         [_T, _T, _P, _P, _P, _P, c_int64, c_float, c_float, _P, _P, c_size_t, _P],
     ),
-    "hiprec_finalize_stats": (c_int, [_P, _P, _P, _P]),
+    "hiprec_finalize_stats": (c_int, [_P, _P, _P, _P, _P]),
     "hiprec_opt_dense_step": (
         c_int,
         [c_int, _P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, _P, _P, c_int64,

@@ -43,9 +43,15 @@ __global__ void stats_begin_epoch_kernel(hiprec_stats* s) {
 __global__ void stats_advance_kernel(hiprec_stats* s) { advance_step(s); }
 
 __global__ __launch_bounds__(kBlock) void finalize_kernel(hiprec_stats* s, const Scratch* sc,
-                                                          float* g_scalar) {
+                                                          float* g_scalar, float* loss_reg_out) {
   const float gb_part = finalize_partials(s, sc);
-  if (threadIdx.x == 0 && g_scalar) *g_scalar += gb_part;
+  if (threadIdx.x == 0) {
+    if (g_scalar) *g_scalar += gb_part;
+    if (loss_reg_out) {
+      loss_reg_out[0] = s->loss;
+      loss_reg_out[1] = s->reg;
+    }
+  }
 }
 
 // out[k, :] = table[idx[k], :] — a pure copy, hence bit-exact.  VEC floats per thread.
@@ -143,10 +149,10 @@ extern "C" int hiprec_stats_advance_step(hiprec_stats* stats, void* stream) {
 }
 
 extern "C" int hiprec_finalize_stats(hiprec_stats* stats, const void* scratch, float* g_scalar,
-                                     void* stream) {
+                                     float* loss_reg_out, void* stream) {
   HIPREC_REQUIRE(stats && scratch, "NULL stats/scratch");
   finalize_kernel<<<1, kBlock, 0, static_cast<hipStream_t>(stream)>>>(
-      stats, static_cast<const Scratch*>(scratch), g_scalar);
+      stats, static_cast<const Scratch*>(scratch), g_scalar, loss_reg_out);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }

@@ -230,7 +230,7 @@ class LightGCNEngine(ModelEngine):
         """zero_grad + forward + loss + backward without the optimizer step: ``(loss, grads)``."""
         self._enqueue_grad(batch_data)
         lib = _lib.load()
-        _lib.check(lib.hiprec_finalize_stats(_lib.ptr(self._stats), _lib.ptr(self._scratch), None,
+        _lib.check(lib.hiprec_finalize_stats(_lib.ptr(self._stats), _lib.ptr(self._scratch), None, None,
                                              _lib.stream_ptr(self.model.flat.device)))
         st = self._sync_stats()
         grads = {k: v.clone() for k, v in self.model.views(self._g_flat).items()}

@@ -462,7 +462,7 @@ class MFEngine(ModelEngine):
         self._enqueue_grad(lib, users, a_items, third)
         g_global = self.model._views(self._g_flat)[4]
         _lib.check(lib.hiprec_finalize_stats(
-            _lib.ptr(self._stats), _lib.ptr(self._scratch), _lib.ptr(g_global),
+            _lib.ptr(self._stats), _lib.ptr(self._scratch), _lib.ptr(g_global), None,
             _lib.stream_ptr(self.model.flat.device)))
         st = self._sync_stats()
         ue, ie, ub, ib, gb = (v.clone() for v in self.model._views(self._g_flat))

@@ -406,7 +406,7 @@ class _NcfEngine(ModelEngine):
             _lib.ptr(self._stats), _lib.ptr(self._scratch), self._scratch.numel(), st))
         g = m.views(self._g_flat)
         _lib.check(lib.hiprec_finalize_stats(_lib.ptr(self._stats), _lib.ptr(self._scratch),
-                                             _lib.ptr(g["affine_output.bias"]), st))
+                                             _lib.ptr(g["affine_output.bias"]), None, st))
         stt = self._sync_stats()
         grads = {k: v.clone() for k, v in g.items()}
         self._g_flat.zero_()

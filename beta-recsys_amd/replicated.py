@@ -50,16 +50,28 @@ class ReplicatedMFEngine(MFEngine):
             # one collective moves everything
             self._g_ext = torch.zeros(P + 2, dtype=torch.float32, device=self.model.flat.device)
             self._g_flat = self._g_ext[:P]
-            self._epoch_acc = torch.zeros(2, dtype=torch.float64, device=self.model.flat.device)
+            self._tail = self._g_ext[P:]
+            self._gb_ptr = self._g_ext.data_ptr() + 4 * (P - 1)
+            self._tail_ptr = self._g_ext.data_ptr() + 4 * P
+            self._epoch_acc = torch.zeros(2, dtype=torch.float32, device=self.model.flat.device)
             self._rows_sgd = False  # replicas always take the dense sweep
         return lib
 
     def _enqueue_step(self, batch_data):
         users, a_items, third = self._prepare_batch(batch_data)
+        self._enqueue_core(users, a_items, third)
+
+    def enqueue_presorted(self, users, a_items, third):
+        """Lean per-step entry for callers that already hold device-resident, contiguous int64
+        batches grouped by item (the staged-epoch layout): no conversions, no checks."""
+        self._enqueue_core(users, a_items, third)
+
+    def _enqueue_core(self, users, a_items, third):
+        """Five launches: grad, finalize (+ loss/reg into the tail of the gradient buffer), ONE
+        all-reduce of [gradient | loss | reg], epoch accumulation, dense optimizer sweep."""
         lib = self._setup()
         m, opt = self.model, self.optimizer
-        dev = m.flat.device
-        st = _lib.stream_ptr(dev)
+        st = _lib.stream_ptr(m.flat.device)
         P = m.flat.numel()
         w, g = m.tables(), m.tables(self._g_flat)
         B_global = users.numel() * self.world  # every rank feeds the same local batch size
@@ -69,16 +81,21 @@ class ReplicatedMFEngine(MFEngine):
             None, users.numel(), 1.0 / B_global, float(self.reg), _lib.ptr(self._stats),
             _lib.ptr(self._scratch), self._scratch.numel(), st))
         _lib.check(lib.hiprec_finalize_stats(
-            _lib.ptr(self._stats), _lib.ptr(self._scratch), _lib.ptr(self._g_ext[P - 1:]), st))
-        head = self._stats[:8].view(torch.float32)          # this rank's (loss, reg) share
-        self._g_ext[P:].copy_(head)
+            _lib.ptr(self._stats), _lib.ptr(self._scratch), ctypes.c_void_p(self._gb_ptr),
+            ctypes.c_void_p(self._tail_ptr), st))
         allreduce_sum_(self._g_ext, self.pg)
-        head.copy_(self._g_ext[P:])                          # stats now hold the global values
-        self._epoch_acc += self._g_ext[P:].double()
+        self._epoch_acc.add_(self._tail)
         _lib.check(lib.hiprec_opt_dense_step(
             opt.kind, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),
             _lib.ptr(opt.exp_avg_sq), P, opt.lr, opt.beta1, opt.beta2, opt.eps,
             _lib.ptr(self._stats), None, -1, st))
+
+    def _sync_stats(self):
+        """Global (all-reduced) loss / reg of the last step replace the local shares in stats."""
+        st = super()._sync_stats()
+        loss, reg = (float(x) for x in self._tail.cpu())
+        st.loss, st.reg = loss, reg
+        return st
 
     def prepare_epoch(self, train_loader):
         """Replicas iterate their loader batch by batch (one collective per step)."""

@@ -90,7 +90,7 @@ class HipKernels:
             users.numel(), inv_batch, reg_coef, _lib.ptr(self.stats), _lib.ptr(self.scratch),
             self.scratch.numel(), self._st()))
         _lib.check(self.lib.hiprec_finalize_stats(
-            _lib.ptr(self.stats), _lib.ptr(self.scratch), _lib.ptr(gb_part), self._st()))
+            _lib.ptr(self.stats), _lib.ptr(self.scratch), _lib.ptr(gb_part), None, self._st()))
         head = self.stats[:8].view(torch.float32)  # hiprec_stats.loss, .reg
         return torch.cat([head, gb_part])
 

@@ -131,9 +131,12 @@ int hiprec_mf_bce_grad(const hiprec_mf_tables* w, const hiprec_mf_tables* g, con
 
 /* Reduce the per-block partials left in scratch by the last *_grad call into stats
  * (loss, reg, loss_sum += loss, reg_sum += reg) and add the scalar-bias gradient they carry to
- * *g_scalar (the global_bias slot of `g`; may be NULL).  Only needed when no optimizer call
- * follows: hiprec_opt_dense_step / hiprec_mf_sgd_rows do the same reduction themselves. */
-int hiprec_finalize_stats(hiprec_stats* stats, const void* scratch, float* g_scalar, void* stream);
+ * *g_scalar (the global_bias slot of `g`; may be NULL); loss_reg_out (may be NULL) additionally
+ * receives {loss, reg} as two floats (the data-parallel engine appends them to the gradient buffer
+ * it all-reduces).  Only needed when no optimizer call follows: hiprec_opt_dense_step /
+ * hiprec_mf_sgd_rows do the same reduction themselves. */
+int hiprec_finalize_stats(hiprec_stats* stats, const void* scratch, float* g_scalar,
+                          float* loss_reg_out, void* stream);
 
 /* ---- dense optimizer step over one flat fp32 buffer (torch.optim.{SGD,Adam,RMSprop}.step with the
  * defaults torch_engine.py:23-39 leaves in place: Adam betas (0.9,0.999) eps 1e-8, RMSprop alpha
