@@ -89,6 +89,17 @@ __device__ __forceinline__ int wave_in_block() {
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & 63; }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a release/acquire fence for
+// GLOBAL memory too: hipcc emits s_waitcnt vmcnt(0) in front of it, i.e. every wave would sit out
+// the full latency of its fire-and-forget gradient atomics (1-2 us under load) at each barrier of
+// the LDS merge.  Nothing in the block ever reads those atomics' targets, so only LDS (and scalar)
+// operations have to be complete before the barrier.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ void lds_add_f32(float* p, float v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_f32
 }
@@ -123,7 +134,7 @@ __device__ __forceinline__ void publish_partials(float loss_w, float reg_lane, f
     s_reg[w] = reg_w;
     s_gb[w] = gb_w;
   }
-  __syncthreads();
+  lds_barrier();
   if (threadIdx.x == 0) {
     float l = 0.f, r = 0.f, b = 0.f;
 #pragma unroll
@@ -140,13 +151,16 @@ __device__ __forceinline__ void publish_partials(float loss_w, float reg_lane, f
 // Run by block 0 (all kBlock threads) of the kernel that FOLLOWS a *_grad kernel: deterministic
 // reduction of the per-block partials into the device stats.  Returns (valid in thread 0) the
 // gradient of the scalar bias, which the caller adds to that parameter's gradient.
+// NT = threads of the calling block.  A scratch block that holds no partials (n_partials == 0:
+// nothing was computed yet) leaves the stats untouched.
+template <int NT = kBlock>
 __device__ __forceinline__ float finalize_partials(hiprec_stats* stats, const Scratch* scratch) {
-  __shared__ double s_l[kBlock];
-  __shared__ double s_r[kBlock];
-  __shared__ double s_b[kBlock];
+  __shared__ double s_l[NT];
+  __shared__ double s_r[NT];
+  __shared__ double s_b[NT];
   const uint32_t n = scratch->n_partials;
   double l = 0.0, r = 0.0, b = 0.0;
-  for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+  for (uint32_t i = threadIdx.x; i < n; i += NT) {
     float4 p = scratch->partials[i];
     l += p.x;
     r += p.y;
@@ -156,7 +170,7 @@ __device__ __forceinline__ float finalize_partials(hiprec_stats* stats, const Sc
   s_r[threadIdx.x] = r;
   s_b[threadIdx.x] = b;
   __syncthreads();
-  for (int s = kBlock / 2; s > 0; s >>= 1) {
+  for (int s = NT / 2; s > 0; s >>= 1) {
     if (static_cast<int>(threadIdx.x) < s) {
       s_l[threadIdx.x] += s_l[threadIdx.x + s];
       s_r[threadIdx.x] += s_r[threadIdx.x + s];
@@ -164,7 +178,7 @@ __device__ __forceinline__ float finalize_partials(hiprec_stats* stats, const Sc
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && n > 0) {
     stats->loss = static_cast<float>(s_l[0]);
     stats->reg = static_cast<float>(s_r[0]);
     stats->loss_sum += static_cast<double>(static_cast<float>(s_l[0]));

@@ -72,11 +72,39 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(hiprec_csr a,
       if (keep) my_val = keep[a.eid ? a.eid[e] : e] ? my_val * scale : 0.f;
     }
     const int n_here = static_cast<int>(min<int64_t>(kWave, e_end - e0));
-    for (int j = 0; j < n_here; ++j) {
+    int j = 0;
+    while (j < n_here) {
       while (e0 + j >= row_end) {  // row boundary (empty rows are skipped)
         flush(row);
         ++row;
         row_end = a.rowptr[row + 1];
+      }
+      // fast path: four edges of the same row -> four independent row gathers in flight
+      if (j + 4 <= n_here && e0 + j + 4 <= row_end) {
+        int cs[4];
+        float vs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          cs[q] = __builtin_amdgcn_readlane(my_col, j + q);
+          vs[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), j + q));
+        }
+        float xv[4][NPL];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float* xr = x + static_cast<int64_t>(cs[q]) * dim;
+#pragma unroll
+          for (int k = 0; k < NPL; ++k) {
+            const int c = lane + kWave * k;
+            xv[q][k] = (c < dim) ? xr[c] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int k = 0; k < NPL; ++k) acc[k] += vs[q] * xv[q][k];
+        }
+        j += 4;
+        continue;
       }
       const int c_src = __builtin_amdgcn_readlane(my_col, j);
       const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), j));
@@ -88,6 +116,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(hiprec_csr a,
           if (c < dim) acc[k] += v * xr[c];
         }
       }
+      ++j;
     }
   }
   flush(row);

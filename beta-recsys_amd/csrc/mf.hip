@@ -9,6 +9,7 @@
 // ONE global_atomic_add_f32 wave instruction).  Index triples are wave-uniform -> scalar loads.
 // The two dot products are reduced on the VALU with DPP (no LDS round trip); loss / regularizer
 // partial sums stay in registers across the grid-stride loop and are published once per block.
+#include <algorithm>
 #include <type_traits>
 
 #include "common.hpp"
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
       }
     }
     if (lane == 0) s_item[wv] = valid ? static_cast<long long>(p) : -static_cast<long long>(wv + 1);
-    __syncthreads();
+    lds_barrier();
     const int head = valid ? run_head(s_item, wv, p) : wv;
     const bool is_head = head == wv;
 
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
       loss_acc += nls;
       gb_acc += dpos + dneg;
     }
-    __syncthreads();
+    lds_barrier();
     if (valid && !is_head) {  // merge into the run head's slot
       float* slot = s_acc + head * ld;
       if constexpr (NPL > 0) {
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
       }
       if (lane == 0) lds_add_f32(slot + D, dpos + ri * bp);
     }
-    __syncthreads();
+    lds_barrier();
     if (valid && is_head) {  // one global atomic per run
       const float* slot = s_acc + wv * ld;
       float* gpr = g.item_emb + p * D;
@@ -190,6 +191,213 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
   }
   // d(loss)/d(global_bias) goes out with the per-block partials (no same-address atomics)
   publish_partials<kAggWaves>(loss_acc, reg_acc, gb_acc, inv_batch, scratch);
+}
+
+// ---- fused SGD step: ONE launch per step -----------------------------------------------------------
+// Plain SGD (momentum 0) is linear, so the optimizer kernel of step k-1 can ride inside the gradient
+// kernel of step k without giving up the reference's semantics (all gradients of a batch come from
+// the pre-step weights):
+//   gather blocks   read  w_eff = W_a[row] - lr * G_prev[row]  on the fly  (= the weights after step
+//                   k-1; neither W_a nor G_prev is written by this launch) and accumulate the
+//                   gradients of step k into G_cur;
+//   sweep blocks    (the rest of the same grid) write W_b = W_a - lr * G_prev for the WHOLE buffer
+//                   and clear G_zero (the accumulator of step k+1), and reduce step k-1's loss
+//                   partials into the stats.
+// W ping-pongs between two buffers, G rotates through three; the arithmetic per element is the very
+// expression torch.optim.SGD evaluates, so results are bit-identical to the two-kernel path.
+struct FusedSgd {
+  hiprec_mf_tables gp;         // pending gradient G_prev, viewed as tables
+  const float* w_read;         // flat W_a
+  float* w_write;              // flat W_b
+  const float* g_prev;         // flat G_prev
+  float* g_zero;               // flat accumulator of the NEXT step, cleared here
+  int64_t n_flat;
+  float lr;
+  int n_gather_blocks;
+  const Scratch* scratch_prev; // partials of step k-1 (n_partials == 0 before the first step)
+};
+
+template <int NPL>
+__global__ __launch_bounds__(kAggBlock) void mf_bpr_sgd_fused_kernel(
+    hiprec_mf_tables w, hiprec_mf_tables g, FusedSgd f, const int64_t* __restrict__ users,
+    const int64_t* __restrict__ pos, const int64_t* __restrict__ neg, int64_t batch,
+    float inv_batch, float reg_coef, hiprec_stats* stats, Scratch* scratch) {
+  extern __shared__ __attribute__((aligned(16))) float s_acc[];
+  __shared__ long long s_item[kAggWaves];
+  const int lane = lane_id();
+  const int wv = wave_in_block();
+  const float lr = f.lr;
+
+  if (static_cast<int>(blockIdx.x) >= f.n_gather_blocks) {
+    // ------------------------------ sweep part ------------------------------
+    const int sb = static_cast<int>(blockIdx.x) - f.n_gather_blocks;
+    const int n_sb = static_cast<int>(gridDim.x) - f.n_gather_blocks;
+    const int64_t gb_index = f.n_flat - 1;  // global_bias is the last element of the flat layout
+    const int64_t n4 = f.n_flat >> 2;
+    const int64_t skip4 = (gb_index < (n4 << 2)) ? (gb_index >> 2) : -1;
+    const float4* wr4 = reinterpret_cast<const float4*>(f.w_read);
+    const float4* gp4 = reinterpret_cast<const float4*>(f.g_prev);
+    float4* ww4 = reinterpret_cast<float4*>(f.w_write);
+    float4* gz4 = reinterpret_cast<float4*>(f.g_zero);
+    const int64_t stride = static_cast<int64_t>(n_sb) * kAggBlock;
+    for (int64_t i = static_cast<int64_t>(sb) * kAggBlock + threadIdx.x; i < n4; i += stride) {
+      if (i == skip4) continue;
+      const float4 a = wr4[i], d = gp4[i];
+      ww4[i] = make_float4(a.x - lr * d.x, a.y - lr * d.y, a.z - lr * d.z, a.w - lr * d.w);
+      gz4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t i = (n4 << 2) + static_cast<int64_t>(sb) * kAggBlock + threadIdx.x; i < f.n_flat;
+         i += stride) {
+      if (i == gb_index) continue;
+      f.w_write[i] = f.w_read[i] - lr * f.g_prev[i];
+      f.g_zero[i] = 0.f;
+    }
+    if (sb == 0) {
+      const float gb_part = finalize_partials<kAggBlock>(stats, f.scratch_prev);
+      if (threadIdx.x == 0) {
+        const int64_t lo = skip4 >= 0 ? (skip4 << 2) : gb_index;
+        for (int64_t i = lo; i <= gb_index; ++i) {
+          const float gv = f.g_prev[i] + (i == gb_index ? gb_part : 0.f);
+          f.w_write[i] = f.w_read[i] - lr * gv;
+          f.g_zero[i] = 0.f;
+        }
+      }
+    }
+    return;
+  }
+
+  // ------------------------------ gather part ------------------------------
+  const int D = w.dim;
+  const int ld = D + 1;
+  const float ru = 4.f * reg_coef * inv_batch, ri = 2.f * reg_coef * inv_batch;
+  // global_bias after step k-1: its gradient lives in the previous step's partials
+  float gbp = 0.f;
+  {
+    const uint32_t np = f.scratch_prev->n_partials;
+    for (uint32_t i = lane; i < np; i += kWave) gbp += f.scratch_prev->partials[i].z;
+    gbp = wave_sum(gbp);
+  }
+  const float gb = *w.global_bias - lr * (*f.gp.global_bias + gbp);
+
+  float loss_acc = 0.f, reg_acc = 0.f, gb_acc = 0.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) advance_step(stats);
+
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * kAggWaves; base < batch;
+       base += static_cast<int64_t>(f.n_gather_blocks) * kAggWaves) {
+    const int64_t t = base + wv;
+    bool valid = t < batch;
+    int64_t u = 0, p = 0, n = 0;
+    if (valid) {
+      u = users[t];
+      p = pos[t];
+      n = neg[t];
+      const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(w.n_users);
+      const bool i_ok = static_cast<uint64_t>(p) < static_cast<uint64_t>(w.n_items) &&
+                        static_cast<uint64_t>(n) < static_cast<uint64_t>(w.n_items);
+      if (!(u_ok && i_ok)) {
+        if (lane == 0)
+          atomicOr(&stats->status,
+                   (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
+        valid = false;
+      }
+    }
+    if (lane == 0) s_item[wv] = valid ? static_cast<long long>(p) : -static_cast<long long>(wv + 1);
+    lds_barrier();
+    const int head = valid ? run_head(s_item, wv, p) : wv;
+    const bool is_head = head == wv;
+
+    float uu[NPL], pp[NPL];
+    float dpos = 0.f, bp = 0.f;
+    if (valid) {
+      const int64_t ou = u * D, op = p * D, on = n * D;
+      float nn[NPL];
+      float dp = 0.f, dn = 0.f;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        const int c = lane + kWave * k;
+        const bool in = c < D;
+        // weights after step k-1, evaluated on the fly (same expression as the sweep writes)
+        uu[k] = in ? w.user_emb[ou + c] - lr * f.gp.user_emb[ou + c] : 0.f;
+        pp[k] = in ? w.item_emb[op + c] - lr * f.gp.item_emb[op + c] : 0.f;
+        nn[k] = in ? w.item_emb[on + c] - lr * f.gp.item_emb[on + c] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        dp += uu[k] * pp[k];
+        dn += uu[k] * nn[k];
+        reg_acc += 2.f * uu[k] * uu[k] + pp[k] * pp[k] + nn[k] * nn[k];
+      }
+      dp = wave_sum(dp);
+      dn = wave_sum(dn);
+      const float bu = w.user_bias[u] - lr * f.gp.user_bias[u];
+      const float bn = w.item_bias[n] - lr * f.gp.item_bias[n];
+      bp = w.item_bias[p] - lr * f.gp.item_bias[p];
+      const float yp = sigmoid_f32(((dp + bu) + bp) + gb);
+      const float yn = sigmoid_f32(((dn + bu) + bn) + gb);
+      float sig_neg_x;
+      const float nls = neg_logsigmoid(yp - yn, &sig_neg_x);
+      const float delta = -sig_neg_x * inv_batch;
+      dpos = delta * ((1.f - yp) * yp);
+      const float dneg = -delta * ((1.f - yn) * yn);
+      float* gur = g.user_emb + ou;
+      float* gnr = g.item_emb + on;
+      float* slot = s_acc + wv * ld;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        const int c = lane + kWave * k;
+        if (c < D) {
+          atomic_add_f32(gur + c, (dpos * pp[k] + dneg * nn[k]) + ru * uu[k]);
+          atomic_add_f32(gnr + c, dneg * uu[k] + ri * nn[k]);
+          if (is_head) slot[c] = dpos * uu[k] + ri * pp[k];
+        }
+      }
+      if (lane == 0) {
+        atomic_add_f32(g.user_bias + u, (dpos + dneg) + ru * bu);
+        atomic_add_f32(g.item_bias + n, dneg + ri * bn);
+        if (is_head) slot[D] = dpos + ri * bp;
+        reg_acc += 2.f * bu * bu + bp * bp + bn * bn;
+      }
+      loss_acc += nls;
+      gb_acc += dpos + dneg;
+    }
+    lds_barrier();
+    if (valid && !is_head) {
+      float* slot = s_acc + head * ld;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        const int c = lane + kWave * k;
+        if (c < D) lds_add_f32(slot + c, dpos * uu[k] + ri * pp[k]);
+      }
+      if (lane == 0) lds_add_f32(slot + D, dpos + ri * bp);
+    }
+    lds_barrier();
+    if (valid && is_head) {
+      const float* slot = s_acc + wv * ld;
+      float* gpr = g.item_emb + p * D;
+      for (int c = lane; c < D; c += kWave) atomic_add_f32(gpr + c, slot[c]);
+      if (lane == 0) atomic_add_f32(g.item_bias + p, slot[D]);
+    }
+  }
+  // publish this step's partials; n_partials = number of GATHER blocks
+  __shared__ float s_loss[kAggWaves], s_reg[kAggWaves], s_gbv[kAggWaves];
+  const float reg_w = wave_sum(reg_acc);
+  if (lane == 0) {
+    s_loss[wv] = loss_acc;
+    s_reg[wv] = reg_w;
+    s_gbv[wv] = gb_acc;
+  }
+  lds_barrier();
+  if (threadIdx.x == 0) {
+    float l = 0.f, r = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < kAggWaves; ++i) {
+      l += s_loss[i];
+      r += s_reg[i];
+      b += s_gbv[i];
+    }
+    scratch->partials[blockIdx.x] = make_float4(l * inv_batch, r * inv_batch, b, 0.f);
+    if (blockIdx.x == 0) scratch->n_partials = static_cast<uint32_t>(f.n_gather_blocks);
+  }
 }
 
 template <int NPL>
@@ -231,7 +439,7 @@ __global__ __launch_bounds__(kAggBlock) void mf_bce_grad_kernel(
       }
     }
     if (lane == 0) s_item[wv] = valid ? static_cast<long long>(i) : -static_cast<long long>(wv + 1);
-    __syncthreads();
+    lds_barrier();
     const int head = valid ? run_head(s_item, wv, i) : wv;
     const bool is_head = head == wv;
 
@@ -296,7 +504,7 @@ __global__ __launch_bounds__(kAggBlock) void mf_bce_grad_kernel(
       loss_acc += loss_k;
       gb_acc += ds;
     }
-    __syncthreads();
+    lds_barrier();
     if (valid && !is_head) {
       float* slot = s_acc + head * ld;
       if constexpr (NPL > 0) {
@@ -310,7 +518,7 @@ __global__ __launch_bounds__(kAggBlock) void mf_bce_grad_kernel(
       }
       if (lane == 0) lds_add_f32(slot + D, ds + rr * bi);
     }
-    __syncthreads();
+    lds_barrier();
     if (valid && is_head) {
       const float* slot = s_acc + wv * ld;
       float* gir = g.item_emb + i * D;
@@ -527,5 +735,83 @@ extern "C" int hiprec_mf_sgd_rows(const hiprec_mf_tables* w, const hiprec_mf_tab
       *w, *g, users, items_a, items_b, perm, batch, static_cast<float>(lr), user_stamp, item_stamp, stamp, stats,
       static_cast<const Scratch*>(scratch));
   HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+// One epoch of BPR-MF with plain SGD, ONE kernel per step (see mf_bpr_sgd_fused_kernel).
+// w_flat[2] / g_flat[3] / scratch[2] are caller-owned; w_flat[0] holds the weights on entry, all g
+// buffers and both scratch blocks are zero.  On return the weights are in w_flat[*final_index] and
+// every g buffer is zero again.  users/pos/neg are the epoch laid out in visiting order.
+extern "C" int hiprec_mf_bpr_epoch_sgd_fused(float* const* w_flat, float* const* g_flat,
+                                             void* const* scratch2, int64_t n_users,
+                                             int64_t n_items, int32_t dim, const int64_t* users,
+                                             const int64_t* pos, const int64_t* neg,
+                                             int64_t n_triples, int64_t batch, float reg_coef,
+                                             double lr, hiprec_stats* stats, int32_t* final_index,
+                                             void* stream) {
+  HIPREC_REQUIRE(w_flat && g_flat && scratch2 && final_index && stats, "NULL pointer");
+  HIPREC_REQUIRE(w_flat[0] && w_flat[1] && g_flat[0] && g_flat[1] && g_flat[2] && scratch2[0] &&
+                     scratch2[1], "NULL buffer");
+  HIPREC_REQUIRE(n_users > 0 && n_items > 0 && dim > 0 && dim <= 256, "fused SGD needs dim <= 256");
+  HIPREC_REQUIRE(n_triples >= 0 && batch > 0, "bad n_triples/batch");
+  HIPREC_REQUIRE(n_triples == 0 || (users && pos && neg), "NULL index arrays");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t n_flat = (n_users + n_items) * (static_cast<int64_t>(dim) + 1) + 1;
+  auto tables = [&](float* flat) {
+    hiprec_mf_tables t;
+    t.user_emb = flat;
+    t.item_emb = flat + n_users * dim;
+    t.user_bias = t.item_emb + n_items * dim;
+    t.item_bias = t.user_bias + n_users;
+    t.global_bias = t.item_bias + n_items;
+    t.n_users = n_users;
+    t.n_items = n_items;
+    t.dim = dim;
+    t._pad = 0;
+    return t;
+  };
+  if (int rc = hiprec_stats_begin_epoch(stats, stream)) return rc;
+  const size_t lds = agg_lds_bytes(dim);
+  const int n_sweep = static_cast<int>(std::min<int64_t>(256, (n_flat / 4 + kAggBlock - 1) / kAggBlock));
+  const int64_t n_steps = (n_triples + batch - 1) / batch;
+  for (int64_t k = 0; k <= n_steps; ++k) {  // step n_steps is the sweep-only flush
+    const int64_t off = k * batch;
+    const int64_t b = k < n_steps ? std::min<int64_t>(batch, n_triples - off) : 0;
+    FusedSgd f;
+    float* w_read = w_flat[k & 1];
+    float* g_prev = g_flat[(k + 2) % 3];
+    float* g_cur = g_flat[k % 3];
+    f.gp = tables(g_prev);
+    f.w_read = w_read;
+    f.w_write = w_flat[(k + 1) & 1];
+    f.g_prev = g_prev;
+    f.g_zero = g_flat[(k + 1) % 3];
+    f.n_flat = n_flat;
+    f.lr = static_cast<float>(lr);
+    f.n_gather_blocks = b > 0 ? agg_grid(b) : 0;
+    f.scratch_prev = static_cast<const Scratch*>(scratch2[(k + 1) & 1]);
+    Scratch* sc = static_cast<Scratch*>(scratch2[k & 1]);
+    const hiprec_mf_tables w = tables(w_read), g = tables(g_cur);
+    const float inv_b = b > 0 ? 1.0f / static_cast<float>(b) : 0.f;
+    const int grid = f.n_gather_blocks + n_sweep;
+    const int64_t* uu = users ? users + off : nullptr;
+    const int64_t* pp = pos ? pos + off : nullptr;
+    const int64_t* nn = neg ? neg + off : nullptr;
+    if (dim <= 64)
+      mf_bpr_sgd_fused_kernel<1><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    else if (dim <= 128)
+      mf_bpr_sgd_fused_kernel<2><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    else
+      mf_bpr_sgd_fused_kernel<4><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    HIPREC_TRY(hipGetLastError());
+    if (b == 0) {
+      // the flush wrote no partials of its own: mark its scratch block empty for the next epoch
+      HIPREC_TRY(hipMemsetAsync(sc, 0, 16, st));
+    }
+  }
+  // the gradient applied by the flush is the only buffer that is still non-zero
+  HIPREC_TRY(hipMemsetAsync(g_flat[(n_steps + 2) % 3], 0, sizeof(float) * n_flat, st));
+  HIPREC_TRY(hipMemsetAsync(scratch2[(n_steps + 1) & 1], 0, 16, st));
+  *final_index = static_cast<int32_t>((n_steps + 1) & 1);
   return 0;
 }

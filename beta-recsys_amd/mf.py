@@ -337,6 +337,7 @@ class MFEngine(ModelEngine):
     ROWS_SGD_MIN_BYTES = 64 << 20
     SORT_MIN_BATCH = 256
     presorted = False  # set when the caller already grouped equal items (sort_within_batches)
+    fused_sgd = True   # plain SGD epochs: one kernel per step (hiprec_mf_bpr_epoch_sgd_fused)
 
     def __init__(self, config):
         self.config = config
@@ -567,13 +568,50 @@ class MFEngine(ModelEngine):
             return None
         return self._resident_triples(train_loader)
 
+    def _fused_sgd_ok(self, perm):
+        """Plain SGD on cache-sized tables takes the one-kernel-per-step epoch driver."""
+        return (self.fused_sgd and self.optimizer.name == "sgd" and not self._rows_sgd
+                and self.loss == "bpr" and perm is None and self.model.emb_dim <= 256)
+
+    def _run_fused_sgd_epoch(self, lib, users, pos, neg, n_run, bs):
+        m = self.model
+        dev = m.flat.device
+        if getattr(self, "_fused_bufs", None) is None or self._fused_bufs["dev"] != dev:
+            self._fused_bufs = {
+                "dev": dev, "w_alt": torch.empty_like(m.flat),
+                "g": [self._g_flat, torch.zeros_like(m.flat), torch.zeros_like(m.flat)],
+                "scratch": [torch.zeros_like(self._scratch), torch.zeros_like(self._scratch)],
+            }
+        fb = self._fused_bufs
+        fb["g"][0] = self._g_flat
+        w_arr = (ctypes.c_void_p * 2)(m.flat.data_ptr(), fb["w_alt"].data_ptr())
+        g_arr = (ctypes.c_void_p * 3)(*(t.data_ptr() for t in fb["g"]))
+        s_arr = (ctypes.c_void_p * 2)(*(t.data_ptr() for t in fb["scratch"]))
+        final = ctypes.c_int32(-1)
+        _lib.check(lib.hiprec_mf_bpr_epoch_sgd_fused(
+            w_arr, g_arr, s_arr, m.n_users, m.n_items, m.emb_dim, _lib.ptr(users), _lib.ptr(pos),
+            _lib.ptr(neg), n_run, bs, float(self.reg), self.optimizer.lr, _lib.ptr(self._stats),
+            ctypes.byref(final), _lib.stream_ptr(dev)))
+        if final.value == 1:  # the weights ended up in the alternate buffer
+            m.flat.copy_(fb["w_alt"])
+
     def run_prepared_epoch(self, prepared, sync=True):
-        """Enqueue every step of a prepared epoch (hiprec_mf_bpr_epoch).  With ``sync=False`` nothing
-        is read back; call :meth:`epoch_stats` later."""
+        """Enqueue every step of a prepared epoch (hiprec_mf_bpr_epoch, or the fused one-kernel-per-
+        step driver for plain SGD).  With ``sync=False`` nothing is read back; call
+        :meth:`epoch_stats` later."""
         lib = self._setup()
         users, pos, neg, perm, bs = prepared
         n = users.numel()
         n_run = n - 1 if n % bs == 1 else n  # Q4: a trailing batch of one raises (below)
+        if self._fused_sgd_ok(perm):
+            self._run_fused_sgd_epoch(lib, users, pos, neg, n_run, bs)
+            if not sync:
+                return None
+            st = self._sync_stats()
+            if n_run != n:
+                raise IndexError(
+                    "Dimension out of range (expected to be in range of [-1, 0], but got 1)")
+            return st
         m, opt = self.model, self.optimizer
         w, g = m.tables(), m.tables(self._g_flat)
         n_batches = (n_run + bs - 1) // bs

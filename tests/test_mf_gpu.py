@@ -410,3 +410,43 @@ def test_full_size_epoch_resident_equals_per_batch(hip_device):
         assert_tensor_close(wa[k], wb[k], 1e-6, f"{k}")
     assert_scalar_close(sa["model/loss"], sb["model/loss"], 1e-6, "epoch loss")
     assert len(batcher) == 4
+
+
+def test_fused_sgd_epoch_is_bit_identical_to_two_kernel_epoch(hip_device):
+    """The one-kernel-per-step SGD epoch (update of step k-1 applied on the fly inside the gradient
+    kernel of step k) evaluates the same expressions as grad kernel + dense SGD sweep: the weights
+    agree to fp32 summation order of the atomics, the untouched rows bit for bit, and two epochs in
+    a row leave every gradient buffer clean."""
+    import beta_recsys_amd as hp
+
+    rng = np.random.default_rng(2)
+    N = 5 * C2["B"] + 1234  # six steps, the last one short
+    users = torch.from_numpy(rng.integers(0, C2["U"], N)).cuda()
+    pos = torch.from_numpy(rng.integers(0, 400, N)).cuda()   # few hot items: long merge runs
+    neg = torch.from_numpy(rng.integers(0, C2["I"], N)).cuda()
+    w0 = onp.init_params(C2["U"], C2["I"], C2["D"], seed=11)
+    out = {}
+    for fused in (True, False):
+        eng = make_engine(C2["U"], C2["I"], C2["D"], "sgd", "bpr", 0.05, C2["B"])
+        eng.fused_sgd = fused
+        load_weights(eng, w0)
+        batcher = hp.DeviceTripleBatcher(users, pos, neg, C2["B"], generator=torch.Generator().manual_seed(5))
+        for epoch in range(2):
+            batcher.generator.manual_seed(5 + epoch)
+            with contextlib.redirect_stdout(io.StringIO()):
+                eng.train_an_epoch(batcher, epoch)
+        assert float(eng._g_flat.abs().max()) == 0.0
+        if fused:
+            for t in eng._fused_bufs["g"]:
+                assert float(t.abs().max()) == 0.0
+        st = eng.epoch_stats()
+        assert st.step == 12
+        out[fused] = (get_weights(eng), dict((t, v) for t, v, e in eng.writer.scalars if e == 1), st.loss)
+    (wa, sa, la), (wb, sb, lb) = out[True], out[False]
+    for k in KEYS:
+        assert_tensor_close(wa[k], wb[k], 1e-6, f"fused vs two-kernel {k}")
+    assert_scalar_close(sa["model/loss"], sb["model/loss"], 1e-6, "epoch loss sum")
+    assert_scalar_close(sa["model/regularizer"], sb["model/regularizer"], 1e-6, "epoch reg sum")
+    assert_scalar_close(la, lb, 1e-5, "last loss")
+    never = np.setdiff1d(np.arange(C2["U"]), users.cpu().numpy())
+    assert np.array_equal(wa["user_emb.weight"][never], w0["user_emb.weight"][never])
