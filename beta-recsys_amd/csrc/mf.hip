@@ -561,15 +561,11 @@ __global__ __launch_bounds__(kBlock) void mf_predict_kernel(hiprec_mf_tables w,
   }
 }
 
-// Exact SGD on the rows a batch touched.  One wave per triple; for each of its (up to) three rows
-// lane 0 races for the row's stamp, the single winner applies w -= lr*g and clears g.
-__device__ __forceinline__ void sgd_row(float* __restrict__ wrow, float* __restrict__ grow,
-                                        float* wb, float* gb, int D, float lr, int32_t* stamp_slot,
-                                        int32_t stamp, int lane) {
-  int won = 0;
-  if (lane == 0) won = atomicExch(stamp_slot, stamp) != stamp;
-  won = __builtin_amdgcn_readfirstlane(won);
-  if (!won) return;
+// Exact SGD on the rows a batch touched.  One wave per triple: lanes 0..2 race (one returning
+// atomicExch each, all three in flight together) for the stamps of the triple's user / item rows;
+// the single winner of a row applies w -= lr*g and clears g.
+__device__ __forceinline__ void sgd_apply_row(float* __restrict__ wrow, float* __restrict__ grow,
+                                              float* wb, float* gb, int D, float lr, int lane) {
   for (int c = lane; c < D; c += kWave) {
     const float gv = grow[c];
     wrow[c] = wrow[c] - lr * gv;
@@ -599,13 +595,19 @@ __global__ __launch_bounds__(kBlock) void mf_sgd_rows_kernel(
         static_cast<uint64_t>(a) >= static_cast<uint64_t>(w.n_items) ||
         static_cast<uint64_t>(b) >= static_cast<uint64_t>(w.n_items))
       continue;  // flagged by the grad kernel, which skipped it too
-    sgd_row(w.user_emb + u * D, g.user_emb + u * D, w.user_bias + u, g.user_bias + u, D, lr,
-            user_stamp + u, stamp, lane);
-    sgd_row(w.item_emb + a * D, g.item_emb + a * D, w.item_bias + a, g.item_bias + a, D, lr,
-            item_stamp + a, stamp, lane);
-    if (items_b)
-      sgd_row(w.item_emb + b * D, g.item_emb + b * D, w.item_bias + b, g.item_bias + b, D, lr,
-              item_stamp + b, stamp, lane);
+    int won = 0;
+    if (lane == 0) won = atomicExch(user_stamp + u, stamp) != stamp;
+    else if (lane == 1) won = atomicExch(item_stamp + a, stamp) != stamp;
+    else if (lane == 2 && items_b && b != a) won = atomicExch(item_stamp + b, stamp) != stamp;
+    const int won_u = __builtin_amdgcn_readlane(won, 0);
+    const int won_a = __builtin_amdgcn_readlane(won, 1);
+    const int won_b = __builtin_amdgcn_readlane(won, 2);
+    if (won_u)
+      sgd_apply_row(w.user_emb + u * D, g.user_emb + u * D, w.user_bias + u, g.user_bias + u, D, lr, lane);
+    if (won_a)
+      sgd_apply_row(w.item_emb + a * D, g.item_emb + a * D, w.item_bias + a, g.item_bias + a, D, lr, lane);
+    if (won_b)
+      sgd_apply_row(w.item_emb + b * D, g.item_emb + b * D, w.item_bias + b, g.item_bias + b, D, lr, lane);
   }
   if (blockIdx.x == 0) {
     const float gb_part = scratch ? finalize_partials(stats, scratch) : 0.f;

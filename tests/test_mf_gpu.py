@@ -450,3 +450,28 @@ def test_fused_sgd_epoch_is_bit_identical_to_two_kernel_epoch(hip_device):
     assert_scalar_close(la, lb, 1e-5, "last loss")
     never = np.setdiff1d(np.arange(C2["U"]), users.cpu().numpy())
     assert np.array_equal(wa["user_emb.weight"][never], w0["user_emb.weight"][never])
+
+
+def test_bce_epoch_through_generic_loader(hip_device):
+    """MF with loss 'bce' fed by a RatingDataset-style loader of (user, item, rating) batches
+    (data/base_data.py:182-216): per-batch path, chained SGD steps vs the oracle."""
+    U, I, D, B = 200, 150, 32, 64
+    rng = np.random.default_rng(8)
+    w = onp.init_params(U, I, D, seed=8)
+    eng = make_engine(U, I, D, "sgd", "bce", 0.05, B)
+    load_weights(eng, w)
+    st = onp.new_opt_state(w, "sgd")
+    batches, total = [], 0.0
+    for k in range(5):
+        n = B if k < 4 else 17
+        b = (rng.integers(0, U, n), rng.integers(0, I, n), (rng.random(n) < 0.3).astype(np.float32))
+        batches.append(tuple(torch.from_numpy(a) for a in b))
+        loss, _ = onp.mf_train_step(w, st, b, "bce", "sgd", 0.05)
+        total += loss
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng.train_an_epoch(batches, 3)
+    scal = dict((t, v) for t, v, e in eng.writer.scalars)
+    assert_scalar_close(scal["model/loss"], total, 2e-5, "epoch BCE loss")
+    got = get_weights(eng)
+    for k in KEYS:
+        assert_tensor_close(got[k], w[k], 2e-6, f"bce epoch {k}")
