@@ -53,30 +53,47 @@ __global__ __launch_bounds__(kBlock) void gemm_f32_kernel(int M, int N, int K,
   const int k_per = ((K + static_cast<int>(gridDim.z) - 1) / static_cast<int>(gridDim.z) + kTK - 1) / kTK * kTK;
   const int k_begin = static_cast<int>(blockIdx.z) * k_per;
   const int k_end = min(K, k_begin + k_per);
-  for (int k0 = k_begin; k0 < k_end; k0 += kTK) {
-    // stage A tile: As[m][k] = op(A)(m0+m, k0+k)
-    for (int e = tid; e < kTM * kTK; e += kBlock) {
-      int m, k;
-      if (MODE == kTNm) { m = e % kTM; k = e / kTM; } else { k = e % kTK; m = e / kTK; }
-      const int gm = m0 + m, gk = k0 + k;
-      float v = 0.f;
-      if (gm < M && gk < k_end)
-        v = (MODE == kTNm) ? A[static_cast<int64_t>(gk) * lda + gm]
-                           : A[static_cast<int64_t>(gm) * lda + gk];
-      As[m][k] = v;
+
+  // Each thread stages kPer = 8 elements of the A tile and 8 of the B tile per k-step.  Their
+  // (row, k) coordinates inside the tile and the global offsets are fixed across k-steps, so they
+  // are computed once; the loads of step t+1 are issued BEFORE the MFMAs of step t and land in
+  // registers while the matrix pipe works (software pipelining through registers).
+  constexpr int kPer = kTM * kTK / kBlock;  // 8
+  int a_m[kPer], a_k[kPer], b_n[kPer], b_k[kPer];
+  int64_t a_off[kPer], b_off[kPer];
+  bool a_ok[kPer], b_ok[kPer];
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) {
+    const int e = tid + i * kBlock;
+    if (MODE == kTNm) { a_m[i] = e % kTM; a_k[i] = e / kTM; } else { a_k[i] = e % kTK; a_m[i] = e / kTK; }
+    if (MODE == kNT) { b_k[i] = e % kTK; b_n[i] = e / kTK; } else { b_n[i] = e % kTN; b_k[i] = e / kTN; }
+    const int gm = m0 + a_m[i], gn = n0 + b_n[i];
+    a_ok[i] = gm < M;
+    b_ok[i] = gn < N;
+    a_off[i] = (MODE == kTNm) ? static_cast<int64_t>(a_k[i]) * lda + gm
+                              : static_cast<int64_t>(gm) * lda + a_k[i];
+    b_off[i] = (MODE == kNT) ? static_cast<int64_t>(gn) * ldb + b_k[i]
+                             : static_cast<int64_t>(b_k[i]) * ldb + gn;
+  }
+  const int64_t a_step = (MODE == kTNm) ? static_cast<int64_t>(lda) : 1;  // per unit of k
+  const int64_t b_step = (MODE == kNT) ? 1 : static_cast<int64_t>(ldb);
+  float ra[kPer], rb[kPer];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      ra[i] = (a_ok[i] && k0 + a_k[i] < k_end) ? A[a_off[i] + a_step * k0] : 0.f;
+      rb[i] = (b_ok[i] && k0 + b_k[i] < k_end) ? B[b_off[i] + b_step * k0] : 0.f;
     }
-    // stage B tile: Bs[k][n] = op(B)(k0+k, n0+n)
-    for (int e = tid; e < kTK * kTN; e += kBlock) {
-      int n, k;
-      if (MODE == kNT) { k = e % kTK; n = e / kTK; } else { n = e % kTN; k = e / kTN; }
-      const int gn = n0 + n, gk = k0 + k;
-      float v = 0.f;
-      if (gn < N && gk < k_end)
-        v = (MODE == kNT) ? B[static_cast<int64_t>(gn) * ldb + gk]
-                          : B[static_cast<int64_t>(gk) * ldb + gn];
-      Bs[k][n] = v;
+  };
+  if (k_begin < k_end) fetch(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += kTK) {
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      As[a_m[i]][a_k[i]] = ra[i];
+      Bs[b_k[i]][b_n[i]] = rb[i];
     }
     __syncthreads();
+    if (k0 + kTK < k_end) fetch(k0 + kTK);
     // lane l feeds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]
     const int i = lane & 31, kh = lane >> 5;
 #pragma unroll
