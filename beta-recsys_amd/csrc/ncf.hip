@@ -14,6 +14,8 @@
 // LDS-staged 64x64x32 MFMA tile with fused bias / ReLU / ReLU-mask epilogues — fp32 in, fp32
 // accumulate, bitwise an fmaf chain in k order (no TF32-like path exists on gfx950, and the parity
 // tolerance of 1e-5 rules out bf16).
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace hiprec {
@@ -272,16 +274,32 @@ __global__ __launch_bounds__(kBlock) void ncf_head_kernel(hiprec_ncf_plan p,
 }
 
 // ---- column sums: out[n] += sum_m X[m, n]   (bias gradients) ---------------------------------------
+// A block owns kColsumRows rows: 4 thread groups x 64 columns, each thread sums a quarter of the rows
+// of its column, the four partials meet in LDS and ONE atomic per (block, column) leaves.  Few,
+// fat blocks on purpose: every block adds into the same N addresses and same-address atomics
+// serialise at ~25 ns.
+constexpr int kColsumRows = 128;
+
 __global__ __launch_bounds__(kBlock) void colsum_kernel(const float* __restrict__ X, int M, int N,
                                                         float* __restrict__ out) {
-  const int rows_per_block = 16;
-  const int m0 = blockIdx.x * rows_per_block;
-  const int m1 = min(M, m0 + rows_per_block);
-  for (int n = threadIdx.x; n < N; n += kBlock) {
+  __shared__ float s_part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int m0 = blockIdx.x * kColsumRows;
+  const int m1 = min(M, m0 + kColsumRows);
+  for (int n0 = 0; n0 < N; n0 += 64) {
+    const int n = n0 + tx;
     float s = 0.f;
-#pragma unroll 4
-    for (int m = m0; m < m1; ++m) s += X[static_cast<int64_t>(m) * N + n];
-    if (s != 0.f) atomic_add_f32(out + n, s);
+    if (n < N) {
+#pragma unroll 8
+      for (int m = m0 + ty; m < m1; m += 4) s += X[static_cast<int64_t>(m) * N + n];
+    }
+    s_part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && n < N) {
+      const float t = (s_part[0][tx] + s_part[1][tx]) + (s_part[2][tx] + s_part[3][tx]);
+      if (t != 0.f) atomic_add_f32(out + n, t);
+    }
+    __syncthreads();
   }
 }
 
@@ -406,7 +424,8 @@ extern "C" int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int B = static_cast<int>(batch);
   if (int rc = forward(p, users, items, batch, stats, st)) return rc;
-  ncf_head_kernel<true><<<grid_for_waves(batch), kBlock, 0, st>>>(
+  // at most 128 blocks: each block ends with one atomic per column of affine_output.weight
+  ncf_head_kernel<true><<<std::min(grid_for_waves(batch), 128), kBlock, 0, st>>>(
       *p, ratings, batch, inv_batch, stats, static_cast<Scratch*>(scratch));
   HIPREC_TRY(hipGetLastError());
   if (p->dim_mlp > 0) {
@@ -416,7 +435,7 @@ extern "C" int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users
       if (int rc = launch_gemm(kTNm, nout, nin, B, p->dact[l + 1], nout, p->act[l], nin, p->g_fc_w[l],
                                nin, nullptr, 0, nullptr, 0, st, /*split_k=*/true))
         return rc;
-      colsum_kernel<<<(B + 15) / 16, kBlock, 0, st>>>(p->dact[l + 1], B, nout, p->g_fc_b[l]);
+      colsum_kernel<<<(B + kColsumRows - 1) / kColsumRows, kBlock, 0, st>>>(p->dact[l + 1], B, nout, p->g_fc_b[l]);
       HIPREC_TRY(hipGetLastError());
       // dZ_{l-1} = (dZ_l W_l) * [H_{l-1} > 0]; for l == 0 the mask is the ReLU NeuMF applies to the
       // raw embeddings (quirk Q7) and is absent for the stand-alone MLP
