@@ -95,7 +95,8 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(hiprec_csr a,
 #pragma unroll
           for (int k = 0; k < NPL; ++k) {
             const int c = lane + kWave * k;
-            xv[q][k] = (c < dim) ? xr[c] : 0.f;
+            // dropped edges (v == 0, wave-uniform) do not fetch their source row
+            xv[q][k] = (c < dim && vs[q] != 0.f) ? xr[c] : 0.f;
           }
         }
 #pragma unroll
