@@ -142,13 +142,13 @@ def cpu_baseline(budget_s=12.0):
                       f"{os.cpu_count()} logical cpus"}
 
 
-def measured_traffic_bytes():
+def measured_traffic_bytes(kernel="hiprec::mf_bpr_grad_kernel<1>"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r01_pmc_summary.json: FETCH_SIZE + WRITE_SIZE, KB per dispatch), or None."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
     try:
         with open(path) as f:
-            k = json.load(f)["hiprec::mf_bpr_grad_kernel<1>"]
+            k = json.load(f)[kernel]
         return (k["FETCH_SIZE_KB_mean"] + k["WRITE_SIZE_KB_mean"]) * 1024.0
     except Exception:
         return None
@@ -487,7 +487,8 @@ def main():
                 "algorithmic_bytes_per_launch": bpt * B,
                 "kernel_us": dom_s * 1e6,
                 "grad_only_kernel_us": k_mean * 1e6,
-                "traffic": measured_traffic_bytes(),
+                "traffic": measured_traffic_bytes("hiprec::mf_bpr_sgd_fused_kernel<1>" if fused
+                                                 else "hiprec::mf_bpr_grad_kernel<1>"),
                 "step_frac": (world * args.steps * B / dt) / world * bpt / (HBM_PEAK_GBS * 1e9),
             },
         }
