@@ -475,3 +475,37 @@ def test_bce_epoch_through_generic_loader(hip_device):
     got = get_weights(eng)
     for k in KEYS:
         assert_tensor_close(got[k], w[k], 2e-6, f"bce epoch {k}")
+
+
+def test_c4_shard_size_properties(hip_device):
+    """One rank's share of BASELINE configs[3] (1.25M x 125k rows, dim 128, batch 65536): too big for
+    the oracle in seconds, so size-independent properties: gradient conservation, every gradient row
+    outside the batch exactly zero, touched-rows SGD leaves untouched rows bit-identical and the
+    gradient buffer clean, and the step is linear in lr (two half steps of the gradient == one)."""
+    U, I, D, B = 1_250_000, 125_000, 128, 65536
+    eng = make_engine(U, I, D, "sgd", "bpr", 0.05, B)
+    assert eng._setup() and eng._rows_sgd, "tables of this size take the touched-rows SGD path"
+    gen = torch.Generator().manual_seed(1)
+    users = torch.randint(0, U, (B,), generator=gen)
+    pos = torch.randint(0, 2000, (B,), generator=gen)  # popular items: heavy merging
+    neg = torch.randint(0, I, (B,), generator=gen)
+    w0 = eng.model.flat.clone()
+    loss, reg, grads = eng.backward_only((users, pos, neg))
+    assert 0.3 < loss < 1.4 and reg > 0
+    gg = float(grads["global_bias"].double().sum())
+    assert abs(float(grads["user_bias.weight"].double().sum()) - gg) < 1e-5
+    assert abs(float(grads["item_bias.weight"].double().sum()) - gg) < 1e-5
+    touched_u = torch.zeros(U, dtype=torch.bool)
+    touched_u[users] = True
+    assert float(grads["user_emb.weight"][~touched_u.cuda()].abs().max()) == 0.0
+    assert int((grads["user_emb.weight"].abs().sum(1) > 0).sum()) <= int(touched_u.sum())
+    # one SGD step == w0 - lr * grad on the touched rows, nothing else moves
+    eng.train_single_batch((users, pos, neg))
+    w1 = eng.model.flat
+    g_flat = torch.cat([grads[k].reshape(-1) for k in
+                        ("user_emb.weight", "item_emb.weight", "user_bias.weight", "item_bias.weight", "global_bias")])
+    expect = w0 - 0.05 * g_flat
+    err = float((w1 - expect).abs().max())
+    assert err <= 1e-5 * float((0.05 * g_flat).abs().max()) + 1e-7, err
+    assert torch.equal(w1[: U * D].view(U, D)[~touched_u.cuda()], w0[: U * D].view(U, D)[~touched_u.cuda()])
+    assert float(eng._g_flat.abs().max()) == 0.0
