@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libhiprec.so")
 OPT_SGD, OPT_ADAM, OPT_RMSPROP = 0, 1, 2
 OPT_KINDS = {"sgd": OPT_SGD, "adam": OPT_ADAM, "rmsprop": OPT_RMSPROP}
 
-STATUS_USER_OOB, STATUS_ITEM_OOB, STATUS_ROW_OOB = 1, 2, 4
+STATUS_USER_OOB, STATUS_ITEM_OOB, STATUS_ROW_OOB, STATUS_ROUTE_OVERFLOW = 1, 2, 4, 8
 
 
 class MfTables(Structure):
@@ -99,6 +99,7 @@ SIGNATURES = {
     "hiprec_stats_advance_step": (c_int, [_P, _P]),
     "hiprec_stats_begin_epoch": (c_int, [_P, _P]),
     "hiprec_gather_rows": (c_int, [_P, c_int64, c_int32, _P, c_int64, _P, _P, _P]),
+    "hiprec_route_bucket": (c_int, [_P, c_int64, c_int32, c_int64, _P, _P, _P, _P]),
     "hiprec_scatter_add_rows": (c_int, [_P, c_int64, c_int32, _P, _P, c_int64, c_int64, _P, _P]),
     "hiprec_mf_predict": (c_int, [_T, _P, _P, c_int64, _P, _P, _P]),
     "hiprec_mf_bpr_grad": (

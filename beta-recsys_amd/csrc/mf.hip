@@ -77,7 +77,9 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
       const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(w.n_users);
       const bool i_ok = static_cast<uint64_t>(p) < static_cast<uint64_t>(w.n_items) &&
                         static_cast<uint64_t>(n) < static_cast<uint64_t>(w.n_items);
-      if (!(u_ok && i_ok)) {
+      if (u == -1) {
+        valid = false;  // padding slot of a fixed-capacity exchange
+      } else if (!(u_ok && i_ok)) {
         if (lane == 0)
           atomicOr(&stats->status,
                    (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));

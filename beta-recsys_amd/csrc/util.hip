@@ -69,6 +69,11 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __rest
     const int64_t k = e / per_row;
     const int c = static_cast<int>(e - k * per_row);
     const int64_t r = idx[k];
+    if (r == -1) {  // padding slot of a fixed-capacity exchange: a zero row, no error
+      if constexpr (VEC == 4) reinterpret_cast<float4*>(out)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      else out[e] = 0.f;
+      continue;
+    }
     if (static_cast<uint64_t>(r) >= static_cast<uint64_t>(n_rows)) {
       if (c == 0) atomicOr(&stats->status, HIPREC_STATUS_ROW_OOB);
       continue;
@@ -79,6 +84,39 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __rest
     } else {
       out[e] = table[r * dim + c];
     }
+  }
+}
+
+// Bucketing for the fixed-capacity all-to-all of the row-sharded engine: key k goes to destination
+// rank d = key mod n_dest and receives slot d*cap + (its arrival position in bucket d).  One wave
+// aggregates per destination with a ballot, so only one atomic per (wave, destination) reaches the
+// n_dest counters.  Negative keys are padding (slot -1); a full bucket raises ROUTE_OVERFLOW.
+__global__ __launch_bounds__(kBlock) void route_bucket_kernel(const int64_t* __restrict__ keys,
+                                                              int64_t n, int n_dest, int64_t cap,
+                                                              int32_t* __restrict__ counts,
+                                                              int64_t* __restrict__ slot_out,
+                                                              hiprec_stats* stats) {
+  const int lane = lane_id();
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * kBlock + (threadIdx.x & ~63); base < n;
+       base += stride) {
+    const int64_t i = base + lane;
+    const int64_t key = i < n ? keys[i] : -1;
+    const int d = key >= 0 ? static_cast<int>(key % n_dest) : -1;
+    int64_t slot = -1;
+    for (int q = 0; q < n_dest; ++q) {
+      const unsigned long long m = __ballot(d == q);
+      if (m == 0) continue;
+      int start = 0;
+      if (lane == 0) start = atomicAdd(counts + q, __popcll(m));
+      start = __builtin_amdgcn_readfirstlane(start);
+      if (d == q) {
+        const int pos = start + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < cap) slot = static_cast<int64_t>(q) * cap + pos;
+        else atomicOr(&stats->status, HIPREC_STATUS_ROUTE_OVERFLOW);
+      }
+    }
+    if (i < n) slot_out[i] = slot;
   }
 }
 
@@ -96,6 +134,7 @@ __global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(float* __restr
   const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
   for (int64_t k = wave0; k < n; k += n_waves) {
     const int64_t r = idx[k];
+    if (r == -1) continue;  // padding slot of a fixed-capacity exchange
     if (static_cast<uint64_t>(r) >= static_cast<uint64_t>(n_rows)) {
       if (lane == 0) atomicOr(&stats->status, HIPREC_STATUS_ROW_OOB);
       continue;
@@ -173,6 +212,20 @@ extern "C" int hiprec_gather_rows(const float* table, int64_t n_rows, int32_t di
     gather_rows_kernel<1><<<grid_for_threads(n * dim), kBlock, 0, st>>>(table, n_rows, dim, idx,
                                                                        n, out, stats);
   }
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_route_bucket(const int64_t* keys, int64_t n, int32_t n_dest, int64_t cap,
+                                   int32_t* counts, int64_t* slot_out, hiprec_stats* stats,
+                                   void* stream) {
+  HIPREC_REQUIRE(n >= 0 && n_dest > 0 && n_dest <= 64 && cap > 0, "bad routing sizes");
+  HIPREC_REQUIRE(counts && stats && (n == 0 || (keys && slot_out)), "NULL pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIPREC_TRY(hipMemsetAsync(counts, 0, sizeof(int32_t) * n_dest, st));
+  if (n == 0) return 0;
+  route_bucket_kernel<<<grid_for_threads(n), kBlock, 0, st>>>(keys, n, n_dest, cap, counts, slot_out,
+                                                              stats);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }

@@ -92,6 +92,10 @@ def raise_on_status(status):
             which.append("item")
         if status & _lib.STATUS_ROW_OOB:
             which.append("row")
+        if status & _lib.STATUS_ROUTE_OVERFLOW:
+            raise RuntimeError(
+                "a fixed-capacity all-to-all bucket overflowed: raise the sharded engine's "
+                "`route_slack` (config['model']['route_slack'])")
         raise IndexError("index out of range in self (" + "/".join(which) + " index)")
 
 

@@ -68,6 +68,15 @@ class HipKernels:
             _lib.ptr(out), _lib.ptr(self.stats), self._st()))
         return out
 
+    def route_bucket(self, keys, n_dest, cap):
+        """slot[k] = dest*cap + arrival position (dest = key mod n_dest), -1 for padding/overflow."""
+        slots = torch.empty_like(keys)
+        counts = torch.empty(n_dest, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.hiprec_route_bucket(
+            _lib.ptr(keys), keys.numel(), n_dest, cap, _lib.ptr(counts), _lib.ptr(slots),
+            _lib.ptr(self.stats), self._st()))
+        return slots
+
     def scatter_add_rows(self, table, idx, src):
         _lib.check(self.lib.hiprec_scatter_add_rows(
             _lib.ptr(table), table.shape[0], table.shape[1], _lib.ptr(idx), _lib.ptr(src),
@@ -151,6 +160,11 @@ class ShardedMFEngine:
         self.optimizer.allocate_state(self.model.flat)
         self.step_count = 0
         self.last = (float("nan"), float("nan"))
+        # "padded": fixed-capacity all-to-alls, bucketing on the device, no host sync per step (all
+        # ranks must feed the same local batch size); "variable": exact-size all-to-alls with
+        # host-side split sizes (any batch sizes, one host sync per exchange)
+        self.routing = mc["routing"] if "routing" in mc else "padded"
+        self.route_slack = float(mc["route_slack"]) if "route_slack" in mc else 1.25
 
     # ---- state ------------------------------------------------------------------------------
     def load_full_state_dict(self, full_state):
@@ -208,6 +222,87 @@ class ShardedMFEngine:
     def train_single_batch(self, batch_data, sync=True):
         """One optimisation step on the GLOBAL batch formed by every rank's ``batch_data``.
         Returns ``(loss, regularizer)`` of the global batch (identical on every rank)."""
+        if self.routing == "padded":
+            return self._step_padded(batch_data, sync)
+        return self._step_variable(batch_data, sync)
+
+    def _a2a_equal(self, send):
+        """All-to-all with equal splits (first dim = world * capacity): no sizes, no host sync."""
+        out = torch.empty_like(send)
+        dist.all_to_all_single(out, send.contiguous(), group=self.pg)
+        return out
+
+    def _pack(self, slots, values, n_slots, fill):
+        """Padded send buffer: values[k] goes to slot slots[k]; slot -1 is dropped (dummy row)."""
+        shape = (n_slots + 1,) + tuple(values.shape[1:])
+        buf = torch.full(shape, fill, dtype=values.dtype, device=values.device)
+        safe = torch.where(slots < 0, torch.full_like(slots, n_slots), slots)
+        buf[safe] = values
+        return buf[:n_slots]
+
+    def _step_padded(self, batch_data, sync=True):
+        """Fixed-capacity routing: every exchange moves world x cap slots (padding = -1), bucketing
+        runs on the device (hiprec_route_bucket) and nothing is read back by the host during the
+        step.  Every rank must pass the same local batch size."""
+        R, dev, m, D = self.world, self.device, self.model, self.emb_dim
+        users, pos, neg = (torch.as_tensor(x, device=dev).to(torch.int64).contiguous()
+                           for x in batch_data)
+        b = users.numel()
+        B = b * R
+        if B < 2:
+            raise IndexError("Dimension out of range (expected to be in range of [-1, 0], but got 1)")
+        cap1 = int(b / R * self.route_slack) + 64
+        cap2 = int(2 * b / R * self.route_slack + 0.15 * b) + 64
+        T1 = R * cap1
+
+        # A2A-1: triples to the owner of the user row
+        slot1 = self.k.route_bucket(users, R, cap1)
+        mine = self._a2a_equal(self._pack(slot1, torch.stack([users, pos, neg], dim=1), T1, -1))
+        u_g, p_g, n_g = mine[:, 0].contiguous(), mine[:, 1].contiguous(), mine[:, 2].contiguous()
+        pad = u_g < 0
+
+        # A2A-2: item ids to their owners, rows (+bias) back into the SAME slots
+        items = torch.cat([p_g, n_g])                       # -1 where the triple slot is padding
+        slot2 = self.k.route_bucket(items, R, cap2)
+        incoming = self._a2a_equal(self._pack(slot2, items, R * cap2, -1))
+        local_idx = torch.where(incoming < 0, incoming, torch.div(incoming, R, rounding_mode="floor"))
+        payload = torch.cat([self.k.gather_rows(m.item_emb.weight.data, local_idx),
+                             self.k.gather_rows(m.item_bias.weight.data, local_idx)], dim=1)
+        fetched = self._a2a_equal(payload)
+
+        # the single-GPU gradient kernel: the fetched buffer plays the item table, slot ids are the
+        # item indices, padded triples (user -1) are skipped by the kernel
+        w = {"user_emb.weight": m.user_emb.weight.data, "user_bias.weight": m.user_bias.weight.data,
+             "global_bias": m.global_bias.data,
+             "item_emb.weight": fetched[:, :D].contiguous(),
+             "item_bias.weight": fetched[:, D:].contiguous()}
+        gue, gie, gub, gib, ggb = m._views(self._g_flat)
+        g_rows = torch.zeros((R * cap2, D), dtype=torch.float32, device=dev)
+        g_bias = torch.zeros((R * cap2, 1), dtype=torch.float32, device=dev)
+        g = {"user_emb.weight": gue, "user_bias.weight": gub, "global_bias": ggb,
+             "item_emb.weight": g_rows, "item_bias.weight": g_bias}
+        u_loc = torch.where(pad, u_g, torch.div(u_g, R, rounding_mode="floor"))
+        part = self.k.bpr_grad(w, g, u_loc, slot2[:T1].contiguous(), slot2[T1:].contiguous(),
+                               1.0 / B, float(self.reg))
+
+        # A2A-3: item-row gradients back to the owners (same slots, reverse direction)
+        gincoming = self._a2a_equal(torch.cat([g_rows, g_bias], dim=1))
+        self.k.scatter_add_rows(gie, local_idx, gincoming[:, :D])
+        self.k.scatter_add_rows(gib, local_idx, gincoming[:, D:])
+
+        dist.all_reduce(part, group=self.pg)
+        ggb += part[2]
+        self.step_count += 1
+        self.k.opt_step(self.optimizer, m.flat, self._g_flat, self.step_count)
+        if not sync:
+            self._pending = part
+            return None
+        self.k.check_status()
+        self.last = (float(part[0]), float(part[1]))
+        return self.last
+
+    def _step_variable(self, batch_data, sync=True):
+        """Exact-size routing with host-side split sizes (any per-rank batch sizes)."""
         R = self.world
         dev = self.device
         users, pos, neg = (torch.as_tensor(x, device=dev).to(torch.int64).contiguous()

@@ -42,6 +42,7 @@ extern "C" {
 #define HIPREC_STATUS_USER_OOB 1u
 #define HIPREC_STATUS_ITEM_OOB 2u
 #define HIPREC_STATUS_ROW_OOB 4u
+#define HIPREC_STATUS_ROUTE_OVERFLOW 8u /* a fixed-capacity all-to-all bucket was too small */
 
 /* optimizer kinds, beta_rec/models/torch_engine.py:23-39 (only `lr` is ever set there) */
 #define HIPREC_OPT_SGD 0
@@ -92,9 +93,17 @@ int hiprec_stats_advance_step(hiprec_stats* stats, void* stream);
 int hiprec_stats_begin_epoch(hiprec_stats* stats, void* stream);
 
 /* ---- bit-exact row gather: out[k,:] = table[idx[k],:]  (nn.Embedding.forward, mf.py:39-42;
- *      ncf.py:54-57; lightgcn.py:134-136).  dim floats per row. */
+ *      ncf.py:54-57; lightgcn.py:134-136).  dim floats per row.  idx == -1 is a padding slot of a
+ *      fixed-capacity exchange: it yields a zero row (hiprec_scatter_add_rows skips it). */
 int hiprec_gather_rows(const float* table, int64_t n_rows, int32_t dim, const int64_t* idx,
                        int64_t n, float* out, hiprec_stats* stats, void* stream);
+
+/* ---- bucketing for the fixed-capacity all-to-all of the row-sharded engine:
+ *      slot_out[k] = d*cap + (arrival position of key k in bucket d), d = keys[k] mod n_dest;
+ *      negative keys are padding (slot -1); counts[d] receives the bucket sizes (zeroed by the
+ *      call); a full bucket sets HIPREC_STATUS_ROUTE_OVERFLOW and yields slot -1. */
+int hiprec_route_bucket(const int64_t* keys, int64_t n, int32_t n_dest, int64_t cap, int32_t* counts,
+                        int64_t* slot_out, hiprec_stats* stats, void* stream);
 
 /* ---- table[idx[k], :] += src[k, 0:dim]  (src rows are src_stride floats apart).  Owner-side
  *      accumulation of the gradient rows that come back through the all-to-all of the row-sharded
@@ -112,7 +121,8 @@ int hiprec_mf_predict(const hiprec_mf_tables* w, const int64_t* users, const int
 /* ---- MF BPR forward + backward (mf.py:101-107,116-117; torch_engine.py:104-105).
  * Accumulates the DENSE gradient of the batch-mean BPR loss into `g` (same layout as `w`; the
  * caller guarantees it is zero on entry, exactly like optimizer.zero_grad()+backward()).
- * Triple k of the batch is (users[j], pos[j], neg[j]) with j = perm ? perm[k] : k — the optional
+ * A triple whose user index is exactly -1 is padding (fixed-capacity all-to-all) and is skipped
+ * silently.  Triple k of the batch is (users[j], pos[j], neg[j]) with j = perm ? perm[k] : k — the optional
  * permutation is the device-side batcher replacing DataLoader(shuffle=True) (base_data.py:253).
  * Writes per-block partial (loss, reg) sums to scratch; the optimizer call that follows (or
  * hiprec_finalize_stats) reduces them into stats.  inv_batch is 1/B of the (global) batch;

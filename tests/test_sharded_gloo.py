@@ -27,14 +27,33 @@ class OracleKernels:
         self.clock = 0
 
     def gather_rows(self, table, idx):
-        return table[idx].clone()
+        out = table[idx.clamp(min=0)].clone()
+        out[idx < 0] = 0.0  # padding slots yield zero rows
+        return out
+
+    def route_bucket(self, keys, n_dest, cap):
+        slots = torch.full_like(keys, -1)
+        fill = [0] * n_dest
+        for k, key in enumerate(keys.tolist()):
+            if key < 0:
+                continue
+            d = key % n_dest
+            if fill[d] < cap:
+                slots[k] = d * cap + fill[d]
+                fill[d] += 1
+            else:
+                self.overflow = True
+        return slots
 
     def scatter_add_rows(self, table, idx, src):
-        table.index_add_(0, idx, src.contiguous())
+        keep = idx >= 0  # -1 = padding slot
+        table.index_add_(0, idx[keep], src.contiguous()[keep])
 
     def bpr_grad(self, w, g, users, pos, neg, inv_batch, reg_coef):
         wn = {k: v.numpy() for k, v in w.items()}
         B = int(round(1.0 / inv_batch))
+        live = users >= 0  # user -1 = padded triple slot
+        users, pos, neg = users[live], pos[live], neg[live]
         loss, reg, grads = onp.mf_bpr_grads(wn, users.numpy(), pos.numpy(), neg.numpy(), reg_coef,
                                             global_batch=B)
         for k in ("user_emb.weight", "item_emb.weight", "user_bias.weight", "item_bias.weight"):
@@ -62,13 +81,13 @@ def free_port():
         return s.getsockname()[1]
 
 
-def make_config(U, I, D, optimizer, lr):
+def make_config(U, I, D, optimizer, lr, routing="variable"):
     return {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cpu", optimizer=optimizer,
-                          lr=lr, batch_size=8, loss="bpr"),
+                          lr=lr, batch_size=8, loss="bpr", routing=routing),
             "system": {"run_dir": "/tmp/hiprec_test_runs"}}
 
 
-def worker(rank, world, port, optimizer, lr, splits, out_path):
+def worker(rank, world, port, optimizer, lr, splits, out_path, routing="variable"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -80,7 +99,7 @@ def worker(rank, world, port, optimizer, lr, splits, out_path):
         w0 = onp.init_params(U, I, D, seed=7)
         rng = np.random.default_rng(100)
         with contextlib.redirect_stdout(io.StringIO()):
-            eng = ShardedMFEngine(make_config(U, I, D, optimizer, lr), kernels=OracleKernels(),
+            eng = ShardedMFEngine(make_config(U, I, D, optimizer, lr, routing), kernels=OracleKernels(),
                                   full_state={k: torch.from_numpy(v) for k, v in w0.items()})
         losses = []
         batches = []
@@ -118,6 +137,24 @@ def test_two_rank_sharded_step_equals_single_process(tmp_path, optimizer, lr):
         frac_bad = np.mean(np.abs(res["full"][k] - w[k]) > tol)
         assert frac_bad < 0.01, f"{k}: {frac_bad:.2%} of elements differ from the single-process run"
         assert res["full"][k].shape == w[k].shape
+
+
+@pytest.mark.parametrize("optimizer,lr", [("sgd", 0.1), ("adam", 0.05)])
+def test_two_rank_padded_routing_equals_single_process(tmp_path, optimizer, lr):
+    """The fixed-capacity (no host sync) routing: same result as the single-process step."""
+    splits = [(12, 12), (30, 30), (2, 2)]  # equal local batches, as the padded mode requires
+    out_path = str(tmp_path / "out.pt")
+    mp.spawn(worker, args=(2, free_port(), optimizer, lr, splits, out_path, "padded"), nprocs=2, join=True)
+    res = torch.load(out_path, weights_only=False)
+    w = onp.copy_params(res["w0"])
+    st = onp.new_opt_state(w, optimizer)
+    for (users, pos, neg), (loss, reg) in zip(res["batches"], res["losses"]):
+        ref_loss, ref_reg = onp.mf_train_step(w, st, (users, pos, neg), "bpr", optimizer, lr)
+        assert_scalar_close(loss, ref_loss, 2e-5, "loss")
+        assert_scalar_close(reg, ref_reg, 2e-5, "reg")
+    tol = 1e-6 if optimizer == "sgd" else 2e-3
+    for k in KEYS:
+        assert np.mean(np.abs(res["full"][k] - w[k]) > tol) < 0.01, k
 
 
 def test_shard_bookkeeping():

@@ -29,14 +29,15 @@ def nccl_group(hip_device):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("routing", ["padded", "variable"])
 @pytest.mark.parametrize("optimizer,lr", [("sgd", 0.1), ("adam", 0.05)])
-def test_sharded_step_with_hip_kernels(nccl_group, optimizer, lr):
+def test_sharded_step_with_hip_kernels(nccl_group, optimizer, lr, routing):
     from beta_recsys_amd.sharded import ShardedMFEngine
 
     U, I, D, B = 300, 200, 64, 512
     w0 = onp.init_params(U, I, D, seed=3)
     cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer=optimizer,
-                         lr=lr, batch_size=B, loss="bpr"),
+                         lr=lr, batch_size=B, loss="bpr", routing=routing),
            "system": {"run_dir": "/tmp/hiprec_test_runs"}}
     with contextlib.redirect_stdout(io.StringIO()):
         eng = ShardedMFEngine(cfg, full_state={k: torch.from_numpy(v) for k, v in w0.items()})
@@ -88,3 +89,29 @@ def test_replicated_engine_with_hip_kernels(nccl_group, optimizer, lr):
     with contextlib.redirect_stdout(io.StringIO()):
         eng.train_an_epoch(batches, 1)
     assert len(eng.writer.scalars) == 2
+
+
+def test_route_bucket_kernel(hip_device):
+    """Device bucketing: every key lands in its destination's bucket exactly once, padding stays
+    -1, a too-small capacity raises the overflow bit."""
+    from beta_recsys_amd import _lib
+    from beta_recsys_amd.sharded import HipKernels
+    from beta_recsys_amd.mf import read_stats
+
+    k = HipKernels(hip_device)
+    rng = np.random.default_rng(0)
+    keys = rng.integers(0, 10_000, 5000)
+    keys[rng.random(5000) < 0.2] = -1
+    kt = torch.from_numpy(keys).cuda()
+    R, cap = 8, 700
+    slots = k.route_bucket(kt, R, cap).cpu().numpy()
+    live = keys >= 0
+    assert np.all(slots[~live] == -1) and np.all(slots[live] >= 0)
+    assert len(np.unique(slots[live])) == live.sum(), "slots must be unique"
+    assert np.array_equal(slots[live] // cap, keys[live] % R), "bucket = key mod R"
+    for d in range(R):
+        pos = np.sort(slots[live & (keys % R == d)] - d * cap)
+        assert np.array_equal(pos, np.arange(len(pos))), "buckets are filled densely from 0"
+    assert read_stats(k.stats).status == 0
+    k.route_bucket(kt, R, 100)
+    assert read_stats(k.stats).status & _lib.STATUS_ROUTE_OVERFLOW
