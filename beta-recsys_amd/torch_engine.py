@@ -84,6 +84,21 @@ class HipOptimizer:
     def zero_grad(self):
         """No-op: the HIP optimizer kernels clear the gradient buffer as they consume it."""
 
+    def state_dict(self):
+        """Flat moment buffers + hyper-parameters (the reference never persists optimizer state,
+        torch_engine.py:70-73; offered for resume)."""
+        return {"name": self.name, "lr": self.lr,
+                "exp_avg": None if self.exp_avg is None else self.exp_avg.clone(),
+                "exp_avg_sq": None if self.exp_avg_sq is None else self.exp_avg_sq.clone()}
+
+    def load_state_dict(self, sd):
+        if sd["name"] != self.name:
+            raise ValueError(f"optimizer state is for {sd['name']!r}, engine uses {self.name!r}")
+        self.lr = float(sd["lr"])
+        for attr in ("exp_avg", "exp_avg_sq"):
+            if sd[attr] is not None and getattr(self, attr) is not None:
+                getattr(self, attr).copy_(sd[attr])
+
     def __repr__(self):
         return f"HipOptimizer({self.name}, lr={self.lr})"
 
@@ -120,6 +135,14 @@ class ModelEngine(object):
                 "HIP path and there is deliberately no CPU fallback"
             )
         return _lib.load()
+
+    def train_single_batch(self, batch_data, ratings=None):
+        """torch_engine.py:47-56 is a generic template every reference engine overrides."""
+        raise NotImplementedError("engines implement train_single_batch")
+
+    def train_an_epoch(self, train_loader, epoch_id):
+        """torch_engine.py:58-68: likewise overridden by every engine."""
+        raise NotImplementedError("engines implement train_an_epoch")
 
     def save_checkpoint(self, model_dir):
         """torch_engine.py:70-73: torch.save(model.state_dict(), path)."""
