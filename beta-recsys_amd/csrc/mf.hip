@@ -42,6 +42,39 @@ __device__ __forceinline__ int run_head(const long long* s_item, int wv, long lo
   return head;
 }
 
+// Triple of one wave for one trip of the grid-stride loop (all fields wave-uniform).
+struct TripleIdx {
+  int64_t u, p, n;
+  bool valid;
+};
+
+__device__ __forceinline__ TripleIdx load_triple(const hiprec_mf_tables& w,
+                                                 const int64_t* __restrict__ users,
+                                                 const int64_t* __restrict__ pos,
+                                                 const int64_t* __restrict__ neg,
+                                                 const int64_t* __restrict__ perm, int64_t t,
+                                                 int64_t batch, hiprec_stats* stats, int lane) {
+  TripleIdx r{0, 0, 0, t < batch};
+  if (r.valid) {
+    const int64_t j = perm ? perm[t] : t;
+    r.u = users[j];
+    r.p = pos[j];
+    r.n = neg[j];
+    const bool u_ok = static_cast<uint64_t>(r.u) < static_cast<uint64_t>(w.n_users);
+    const bool i_ok = static_cast<uint64_t>(r.p) < static_cast<uint64_t>(w.n_items) &&
+                      static_cast<uint64_t>(r.n) < static_cast<uint64_t>(w.n_items);
+    if (r.u == -1) {
+      r.valid = false;  // padding slot of a fixed-capacity exchange
+    } else if (!(u_ok && i_ok)) {
+      if (lane == 0)
+        atomicOr(&stats->status,
+                 (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
+      r.valid = false;
+    }
+  }
+  return r;
+}
+
 template <int NPL>
 __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
     hiprec_mf_tables w, hiprec_mf_tables g, const int64_t* __restrict__ users,
@@ -57,6 +90,7 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
   const float gb = *w.global_bias;
   // mf.py:116 batch_loss = loss + reg*regularizer; user terms appear in both forward calls
   const float ru = 4.f * reg_coef * inv_batch, ri = 2.f * reg_coef * inv_batch;
+  constexpr int R = NPL > 0 ? NPL : 1;
 
   float loss_acc = 0.f;  // wave-uniform
   float reg_acc = 0.f;   // per lane
@@ -64,29 +98,44 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
 
   if (blockIdx.x == 0 && threadIdx.x == 0) advance_step(stats);
 
-  for (int64_t base = static_cast<int64_t>(blockIdx.x) * kAggWaves; base < batch;
-       base += static_cast<int64_t>(gridDim.x) * kAggWaves) {
-    const int64_t t = base + wv;
-    bool valid = t < batch;
-    int64_t u = 0, p = 0, n = 0;
-    if (valid) {
-      const int64_t j = perm ? perm[t] : t;
-      u = users[j];
-      p = pos[j];
-      n = neg[j];
-      const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(w.n_users);
-      const bool i_ok = static_cast<uint64_t>(p) < static_cast<uint64_t>(w.n_items) &&
-                        static_cast<uint64_t>(n) < static_cast<uint64_t>(w.n_items);
-      if (u == -1) {
-        valid = false;  // padding slot of a fixed-capacity exchange
-      } else if (!(u_ok && i_ok)) {
-        if (lane == 0)
-          atomicOr(&stats->status,
-                   (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
-        valid = false;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kAggWaves;
+  const int64_t first = static_cast<int64_t>(blockIdx.x) * kAggWaves;
+
+  // Software pipeline over the grid-stride loop (batches larger than the grid, i.e. the
+  // HBM-resident regime): the rows of trip i+1 are requested right after the dot products of trip
+  // i and land while trip i sits in its atomics and LDS-merge barriers.
+  float cu[R], cp[R], cn[R], cbu = 0.f, cbp = 0.f, cbn = 0.f;
+  auto fetch_rows = [&](const TripleIdx& tr, float (&ru_)[R], float (&rp_)[R], float (&rn_)[R],
+                        float& bu_, float& bp_, float& bn_) {
+    if constexpr (NPL > 0) {
+      const float* ur = w.user_emb + tr.u * D;
+      const float* pr = w.item_emb + tr.p * D;
+      const float* nr = w.item_emb + tr.n * D;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        const int c = lane + kWave * k;
+        const bool in = tr.valid && c < D;
+        ru_[k] = in ? ur[c] : 0.f;
+        rp_[k] = in ? pr[c] : 0.f;
+        rn_[k] = in ? nr[c] : 0.f;
       }
     }
+    bu_ = tr.valid ? w.user_bias[tr.u] : 0.f;
+    bp_ = tr.valid ? w.item_bias[tr.p] : 0.f;
+    bn_ = tr.valid ? w.item_bias[tr.n] : 0.f;
+  };
+
+  TripleIdx cur = load_triple(w, users, pos, neg, perm, first + wv, batch, stats, lane);
+  fetch_rows(cur, cu, cp, cn, cbu, cbp, cbn);
+
+  for (int64_t base = first; base < batch; base += stride) {
+    const bool valid = cur.valid;
+    const int64_t u = cur.u, p = cur.p, n = cur.n;
     if (lane == 0) s_item[wv] = valid ? static_cast<long long>(p) : -static_cast<long long>(wv + 1);
+    // indices of the next trip: scalar loads, issued before the barrier
+    const bool more = base + stride < batch;
+    TripleIdx nxt{0, 0, 0, false};
+    if (more) nxt = load_triple(w, users, pos, neg, perm, base + stride + wv, batch, stats, lane);
     lds_barrier();
     const int head = valid ? run_head(s_item, wv, p) : wv;
     const bool is_head = head == wv;
@@ -94,24 +143,17 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
     const float* ur = w.user_emb + u * D;
     const float* pr = w.item_emb + p * D;
     const float* nr = w.item_emb + n * D;
-    float uu[NPL > 0 ? NPL : 1], pp[NPL > 0 ? NPL : 1];
-    float dpos = 0.f, bp = 0.f;
+    float uu[R], pp[R];
+    float dpos = 0.f, dneg = 0.f, bp = cbp, bu = cbu, bn = cbn;
+    float dp = 0.f, dn = 0.f;
+    float nn[R];
     if (valid) {
-      float* gur = g.user_emb + u * D;
-      float* gnr = g.item_emb + n * D;
-      float dp = 0.f, dn = 0.f;
-      float nn[NPL > 0 ? NPL : 1];
       if constexpr (NPL > 0) {
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
-          const int c = lane + kWave * k;
-          const bool in = c < D;
-          uu[k] = in ? ur[c] : 0.f;
-          pp[k] = in ? pr[c] : 0.f;
-          nn[k] = in ? nr[c] : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) {
+          uu[k] = cu[k];
+          pp[k] = cp[k];
+          nn[k] = cn[k];
           dp += uu[k] * pp[k];
           dn += uu[k] * nn[k];
           reg_acc += 2.f * uu[k] * uu[k] + pp[k] * pp[k] + nn[k] * nn[k];
@@ -124,11 +166,14 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
           reg_acc += 2.f * a * a + b * b + d * d;
         }
       }
+    }
+    // request the next trip's rows now: they travel while this trip finishes
+    if (more) fetch_rows(nxt, cu, cp, cn, cbu, cbp, cbn);
+    if (valid) {
+      float* gur = g.user_emb + u * D;
+      float* gnr = g.item_emb + n * D;
       dp = wave_sum(dp);
       dn = wave_sum(dn);
-
-      const float bu = w.user_bias[u], bn = w.item_bias[n];
-      bp = w.item_bias[p];
       // mf.py:43-48: sigmoid(sum + u_bias + i_bias + global_bias)
       const float yp = sigmoid_f32(((dp + bu) + bp) + gb);
       const float yn = sigmoid_f32(((dn + bu) + bn) + gb);
@@ -137,7 +182,7 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
       const float nls = neg_logsigmoid(yp - yn, &sig_neg_x);
       const float delta = -sig_neg_x * inv_batch;    // dL/d(yp) ; dL/d(yn) = -delta
       dpos = delta * ((1.f - yp) * yp);              // through the sigmoid
-      const float dneg = -delta * ((1.f - yn) * yn);
+      dneg = -delta * ((1.f - yn) * yn);
 
       // user row, negative-item row: no popularity skew -> straight to the dense gradient;
       // positive-item row of a run head: parked in its LDS slot.
@@ -190,6 +235,7 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
       for (int c = lane; c < D; c += kWave) atomic_add_f32(gpr + c, slot[c]);
       if (lane == 0) atomic_add_f32(g.item_bias + p, slot[D]);
     }
+    cur = nxt;
   }
   // d(loss)/d(global_bias) goes out with the per-block partials (no same-address atomics)
   publish_partials<kAggWaves>(loss_acc, reg_acc, gb_acc, inv_batch, scratch);

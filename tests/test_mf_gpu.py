@@ -509,3 +509,54 @@ def test_c4_shard_size_properties(hip_device):
     assert err <= 1e-5 * float((0.05 * g_flat).abs().max()) + 1e-7, err
     assert torch.equal(w1[: U * D].view(U, D)[~touched_u.cuda()], w0[: U * D].view(U, D)[~touched_u.cuda()])
     assert float(eng._g_flat.abs().max()) == 0.0
+
+
+def test_c1_ml100k_shaped_epoch_vs_cpu_port(hip_device):
+    """BASELINE configs[0] (mf_default.json shape): 943 users x 1682 items, dim 64, batch 400, adam
+    lr 0.05, one epoch of ~98k triples through a real DataLoader(shuffle=True) — the HIP engine vs the
+    reference's PyTorch-CPU op sequence (oracle/torch_port.py) fed with the very same batches."""
+    from torch.utils.data import DataLoader, Dataset
+
+    from oracle.torch_port import TorchMFPort
+
+    class PairwiseNegativeDataset(Dataset):
+        def __init__(self, u, p, n):
+            self.user_tensor, self.pos_item_tensor, self.neg_item_tensor = u, p, n
+
+        def __getitem__(self, i):
+            return self.user_tensor[i], self.pos_item_tensor[i], self.neg_item_tensor[i]
+
+        def __len__(self):
+            return self.user_tensor.size(0)
+
+    U, I, D, B, N = 943, 1682, 64, 400, 98114
+    rng = np.random.default_rng(2020)
+    p = 1.0 / np.arange(1, I + 1)
+    users = torch.from_numpy(rng.integers(0, U, N))
+    pos = torch.from_numpy(rng.permutation(I)[rng.choice(I, N, p=p / p.sum())])
+    neg = torch.from_numpy(rng.integers(0, I, N))
+    loader = DataLoader(PairwiseNegativeDataset(users, pos, neg), batch_size=B, shuffle=True)
+    w0 = onp.init_params(U, I, D, seed=1)
+    eng = make_engine(U, I, D, "adam", "bpr", 0.05, B)
+    load_weights(eng, w0)
+    torch.manual_seed(99)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng.train_an_epoch(loader, 0)
+    scal = dict((t, v) for t, v, _ in eng.writer.scalars)
+    # the same batches for the CPU port: same seed -> same DataLoader order
+    port = TorchMFPort(w0, "adam", 0.05, "bpr")
+    torch.manual_seed(99)
+    tot_loss = tot_reg = 0.0
+    n_batches = 0
+    for batch in loader:
+        l, r = port.step(batch)
+        tot_loss += l
+        tot_reg += r
+        n_batches += 1
+    assert n_batches == 246 and N % B != 1
+    assert_scalar_close(scal["model/loss"], tot_loss, 2e-4, "epoch loss sum over 246 adam steps")
+    assert_scalar_close(scal["model/regularizer"], tot_reg, 2e-3, "epoch regularizer sum")
+    w, wr = get_weights(eng), port.numpy_weights()
+    for k in KEYS:
+        rel = np.abs(w[k] - wr[k]).mean() / (np.abs(wr[k]).mean() + 1e-12)
+        assert rel < 2e-3, f"{k}: mean relative deviation {rel:.2e} after one epoch"
