@@ -134,9 +134,30 @@ def cpu_baseline(budget_s=12.0):
         rate = steps * B / dt
         if best is None or rate > best[0]:
             best = (rate, nt, steps, dt)
-    torch.set_num_threads(all_threads)
     rate, nt, steps, dt = best
+    # (ii) end to end through DataLoader(PairwiseNegativeDataset, shuffle=True) as the reference
+    # feeds it (data/base_data.py:247-253): per-sample __getitem__ + default_collate dominate
+    from torch.utils.data import DataLoader, Dataset
+
+    class _Pairs(Dataset):
+        def __getitem__(self, i):
+            return users[i], pos[i], neg[i]
+
+        def __len__(self):
+            return users.size(0)
+
+    torch.set_num_threads(nt)
+    port = TorchMFPort(onp.init_params(U, I, D, seed=0), "sgd", LR, "bpr")
+    e2e_steps, t0 = 0, time.perf_counter()
+    for batch in DataLoader(_Pairs(), batch_size=B, shuffle=True):
+        port.step(batch)
+        e2e_steps += 1
+        if time.perf_counter() - t0 > 3.0:
+            break
+    e2e_rate = e2e_steps * B / (time.perf_counter() - t0)
+    torch.set_num_threads(all_threads)
     return {"value": rate, "unit": "triples/s", "cores": nt, "kind": "port",
+            "end_to_end_dataloader_value": e2e_rate,
             "sample": f"{steps} sgd steps of batch {B} (same C2 workload) in {dt:.1f} s with {nt} ATen "
                       f"threads (best of {candidates}); PyTorch-CPU op sequence of the reference; host has "
                       f"{os.cpu_count()} logical cpus"}

@@ -285,3 +285,35 @@ def test_lightgcn_init_and_surface_on_cpu():
         eng.train_single_batch((torch.tensor([0, 1]), torch.tensor([0, 1]), torch.tensor([1, 2])))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         eng.model.predict(np.array([0]), np.array([0]))
+
+
+def test_ncf_pre_merges_gmf_and_mlp_checkpoints(tmp_path):
+    """models/ncf.py:155-193: `ncf_pre` builds NeuMF from trained GMF + MLP checkpoints —
+    embeddings copied, tower copied, affine_output = 0.5 * cat(mlp, gmf), bias = 0.5 * (sum)."""
+    import beta_recsys_amd as hp
+
+    U, I, E, L = 13, 11, 4, 2
+    cfg = ncf_config(U, I, E, L)
+    cfg["system"]["model_save_dir"] = str(tmp_path)
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        gmf = hp.GMFEngine(cfg)
+        mlp = hp.MLPEngine(cfg)
+    gmf.save_checkpoint(str(tmp_path / "gmf.model"))
+    mlp.save_checkpoint(str(tmp_path / "mlp.model"))
+    pre = ncf_config(U, I, E, L, model="ncf_pre")
+    pre["system"]["model_save_dir"] = str(tmp_path)
+    with contextlib.redirect_stdout(io.StringIO()):
+        neu = hp.NeuMFEngine(pre)
+    n, g, m = neu.model.state_dict(), gmf.model.state_dict(), mlp.model.state_dict()
+    assert torch.equal(n["embedding_user_mf.weight"], g["embedding_user.weight"])
+    assert torch.equal(n["embedding_item_mf.weight"], g["embedding_item.weight"])
+    assert torch.equal(n["embedding_user_mlp.weight"], m["embedding_user.weight"])
+    assert torch.equal(n["embedding_item_mlp.weight"], m["embedding_item.weight"])
+    for k in ("fc_layers.1.weight", "fc_layers.1.bias", "fc_layers.4.weight", "fc_layers.4.bias"):
+        assert torch.equal(n[k], m[k])
+    assert torch.equal(n["affine_output.weight"],
+                       0.5 * torch.cat([m["affine_output.weight"], g["affine_output.weight"]], dim=-1))
+    assert torch.equal(n["affine_output.bias"], 0.5 * (m["affine_output.bias"] + g["affine_output.bias"]))
+    # the merged parameters are still views of NeuMF's single flat buffer
+    assert neu.model.embedding_user_mlp.weight.data_ptr() == neu.model.flat.data_ptr()
