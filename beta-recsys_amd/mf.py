@@ -62,8 +62,8 @@ class _Table(nn.Module):
         return self.weight.shape[1]
 
     def forward(self, idx):
-        """Row gather (bit-exact copy) through hiprec_gather_rows."""
-        return gather_rows(self.weight, idx)
+        """Row gather (bit-exact copy) through hiprec_gather_rows; IndexError like nn.Embedding."""
+        return gather_rows(self.weight, idx, check=True)
 
     def extra_repr(self):
         return f"{self.num_embeddings}, {self.embedding_dim}"
@@ -102,15 +102,17 @@ def raise_on_status(status):
 _gather_stats = {}
 
 
-def gather_rows(table, idx):
-    """out[k] = table[idx[k]] on the GPU, bit-exact (nn.Embedding.forward)."""
+def gather_rows(table, idx, check=False):
+    """out[k] = table[idx[k]] on the GPU, bit-exact (nn.Embedding.forward).  Rows of out-of-range
+    indices come back as zeros; with ``check=True`` the call synchronises and raises IndexError for
+    them, as nn.Embedding would."""
     if table.device.type != "cuda":
         raise RuntimeError("gather_rows: HIP path only (no CPU fallback)")
     lib = _lib.load()
     dev = table.device
     idx = torch.as_tensor(idx, dtype=torch.int64, device=dev).contiguous()
     flat_idx = idx.reshape(-1)
-    out = torch.empty((flat_idx.numel(), table.shape[1]), dtype=torch.float32, device=dev)
+    out = torch.zeros((flat_idx.numel(), table.shape[1]), dtype=torch.float32, device=dev)
     key = (dev.type, dev.index)
     if key not in _gather_stats:
         _gather_stats[key] = _new_stats(dev)
@@ -121,6 +123,11 @@ def gather_rows(table, idx):
             flat_idx.numel(), _lib.ptr(out), _lib.ptr(stats), _lib.stream_ptr(dev),
         )
     )
+    if check:
+        st = read_stats(stats)
+        if st.status:
+            _gather_stats.pop(key)
+            raise_on_status(st.status)
     return out.reshape(*idx.shape, table.shape[1])
 
 

@@ -53,7 +53,6 @@ class ReplicatedMFEngine(MFEngine):
             self._tail = self._g_ext[P:]
             self._gb_ptr = self._g_ext.data_ptr() + 4 * (P - 1)
             self._tail_ptr = self._g_ext.data_ptr() + 4 * P
-            self._epoch_acc = torch.zeros(2, dtype=torch.float32, device=self.model.flat.device)
             self._rows_sgd = False  # replicas always take the dense sweep
         return lib
 
@@ -67,8 +66,9 @@ class ReplicatedMFEngine(MFEngine):
         self._enqueue_core(users, a_items, third)
 
     def _enqueue_core(self, users, a_items, third):
-        """Five launches: grad, finalize (+ loss/reg into the tail of the gradient buffer), ONE
-        all-reduce of [gradient | loss | reg], epoch accumulation, dense optimizer sweep."""
+        """Four launches: grad, finalize (+ loss/reg into the tail of the gradient buffer), ONE
+        all-reduce of [gradient | loss | reg], dense optimizer sweep.  The epoch sums are kept as
+        per-rank shares in hiprec_stats (they are linear) and all-reduced once per epoch."""
         lib = self._setup()
         m, opt = self.model, self.optimizer
         st = _lib.stream_ptr(m.flat.device)
@@ -84,7 +84,6 @@ class ReplicatedMFEngine(MFEngine):
             _lib.ptr(self._stats), _lib.ptr(self._scratch), ctypes.c_void_p(self._gb_ptr),
             ctypes.c_void_p(self._tail_ptr), st))
         allreduce_sum_(self._g_ext, self.pg)
-        self._epoch_acc.add_(self._tail)
         _lib.check(lib.hiprec_opt_dense_step(
             opt.kind, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),
             _lib.ptr(opt.exp_avg_sq), P, opt.lr, opt.beta1, opt.beta2, opt.eps,
@@ -102,12 +101,15 @@ class ReplicatedMFEngine(MFEngine):
         return None
 
     def train_an_epoch(self, train_loader, epoch_id):
-        self._setup()
-        self._epoch_acc.zero_()
+        lib = self._setup()
+        dev = self.model.flat.device
+        _lib.check(lib.hiprec_stats_begin_epoch(_lib.ptr(self._stats), _lib.stream_ptr(dev)))
         for batch_data in train_loader:
             self._enqueue_step(batch_data)
         st = self._sync_stats()
-        total_loss, total_reg = (float(x) for x in self._epoch_acc.cpu())
+        sums = torch.tensor([st.loss_sum, st.reg_sum], dtype=torch.float64, device=dev)
+        allreduce_sum_(sums, self.pg)  # per-rank shares of every step's loss / reg
+        total_loss, total_reg = (float(x) for x in sums.cpu())
         if self.rank == 0:
             print(f"[Training Epoch {epoch_id}], Loss {st.loss}, Regularizer {total_reg}")
         self.writer.add_scalar("model/loss", total_loss, epoch_id)

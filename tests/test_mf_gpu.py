@@ -83,11 +83,15 @@ def test_gather_rows_2d_index_and_oob(hip_device):
     out = hp.gather_rows(table, idx)
     assert out.shape == (2, 2, 4)
     assert torch.equal(out.cpu(), table.cpu()[idx])
-    hp.gather_rows(table, torch.tensor([1, 10]))  # 10 is out of range
+    oob = hp.gather_rows(table, torch.tensor([1, 10]))  # 10 is out of range: zero row + status bit
+    assert torch.equal(oob.cpu(), torch.stack([table.cpu()[1], torch.zeros(4)]))
     key = (hip_device.type, hip_device.index)
     st = hmf.read_stats(hmf._gather_stats[key])
     assert st.status & hp._lib.STATUS_ROW_OOB
     hmf._gather_stats.pop(key)
+    with pytest.raises(IndexError):
+        hp.gather_rows(table, torch.tensor([1, 10]), check=True)
+    assert torch.equal(hp.gather_rows(table, torch.tensor([2]), check=True).cpu(), table.cpu()[[2]])
 
 
 # ---- golden vectors from the real reference -----------------------------------------------------
