@@ -265,3 +265,41 @@ extern "C" int hiprec_mf_bpr_epoch(const hiprec_mf_tables* w, const hiprec_mf_ta
   }
   return 0;
 }
+
+// MFEngine.train_an_epoch with loss == "bce" (mf.py:108-111,121-139) over resident
+// (user, item, rating) arrays — the RatingDataset loader of data/base_data.py:182-216 replaced by
+// perm[] slices / a staged layout, exactly like hiprec_mf_bpr_epoch.
+extern "C" int hiprec_mf_bce_epoch(const hiprec_mf_tables* w, const hiprec_mf_tables* g,
+                                   const int64_t* users, const int64_t* items, const float* ratings,
+                                   const int64_t* perm, int64_t n_samples, int64_t batch,
+                                   float reg_coef, int kind, double lr, double beta1, double beta2,
+                                   double eps, float* flat_w, float* flat_g, float* flat_m,
+                                   float* flat_v, int64_t n_flat, int32_t* user_stamp,
+                                   int32_t* item_stamp, int32_t first_stamp, hiprec_stats* stats,
+                                   void* scratch, size_t scratch_bytes, void* stream) {
+  HIPREC_REQUIRE(n_samples >= 0 && batch > 0, "bad n_samples/batch");
+  const bool rows_sgd = (kind == HIPREC_OPT_SGD) && user_stamp && item_stamp;
+  if (!rows_sgd) HIPREC_REQUIRE(flat_w && flat_g && n_flat > 0, "dense optimizer needs flat buffers");
+  if (int rc = hiprec_stats_begin_epoch(stats, stream)) return rc;
+  int32_t stamp = first_stamp;
+  for (int64_t off = 0; off < n_samples; off += batch, ++stamp) {
+    const int64_t b = (n_samples - off < batch) ? (n_samples - off) : batch;
+    const float inv_b = 1.0f / static_cast<float>(b);
+    const int64_t* pm = perm ? perm + off : nullptr;
+    const int64_t* uu = perm ? users : users + off;
+    const int64_t* ii = perm ? items : items + off;
+    const float* rr = perm ? ratings : ratings + off;
+    if (int rc = hiprec_mf_bce_grad(w, g, uu, ii, rr, pm, b, inv_b, reg_coef, stats, scratch,
+                                    scratch_bytes, stream))
+      return rc;
+    int rc;
+    if (rows_sgd)
+      rc = hiprec_mf_sgd_rows(w, g, uu, ii, nullptr, pm, b, lr, user_stamp, item_stamp, stamp, stats,
+                              scratch, stream);
+    else
+      rc = hiprec_opt_dense_step(kind, flat_w, flat_g, flat_m, flat_v, n_flat, lr, beta1, beta2,
+                                 eps, stats, scratch, w->global_bias - flat_w, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}

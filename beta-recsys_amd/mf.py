@@ -545,9 +545,9 @@ class MFEngine(ModelEngine):
             ds, perm = train_loader, train_loader.permutation()
         else:
             ds = getattr(train_loader, "dataset", None)
-            if ds is None or not all(
-                hasattr(ds, a) for a in ("user_tensor", "pos_item_tensor", "neg_item_tensor")
-            ):
+            names = (("user_tensor", "pos_item_tensor", "neg_item_tensor") if self.loss == "bpr"
+                     else ("user_tensor", "item_tensor", "target_tensor"))
+            if ds is None or not all(hasattr(ds, a) for a in names):
                 return None
             if getattr(train_loader, "drop_last", False) or train_loader.batch_sampler is None:
                 return None
@@ -559,8 +559,12 @@ class MFEngine(ModelEngine):
             perm = torch.as_tensor(order, dtype=torch.int64)
         dev = self.device
         users = ds.user_tensor.to(dev, torch.int64).contiguous()
-        pos = ds.pos_item_tensor.to(dev, torch.int64).contiguous()
-        neg = ds.neg_item_tensor.to(dev, torch.int64).contiguous()
+        if self.loss == "bpr":
+            pos = ds.pos_item_tensor.to(dev, torch.int64).contiguous()
+            neg = ds.neg_item_tensor.to(dev, torch.int64).contiguous()
+        else:  # RatingDataset (data/data_loaders.py:4-27): items + fp32 ratings
+            pos = ds.item_tensor.to(dev, torch.int64).contiguous()
+            neg = ds.target_tensor.to(dev, torch.float32).contiguous()
         perm = None if perm is None else perm.to(dev).contiguous()
         bs = int(train_loader.batch_size)
         if bs >= self.SORT_MIN_BATCH:
@@ -575,7 +579,9 @@ class MFEngine(ModelEngine):
         """Stage one epoch's inputs in HBM: resident triple arrays + this epoch's visiting order.
         Returns an opaque tuple for :meth:`run_prepared_epoch`, or None when the loader's data
         cannot be batched on the device (then train_an_epoch falls back to iterating it)."""
-        if self.loss != "bpr":
+        if self.loss not in ("bpr", "bce") or isinstance(train_loader, (list, tuple)):
+            return None
+        if self.loss == "bce" and isinstance(train_loader, DeviceTripleBatcher):
             return None
         return self._resident_triples(train_loader)
 
@@ -627,7 +633,8 @@ class MFEngine(ModelEngine):
         w, g = m.tables(), m.tables(self._g_flat)
         n_batches = (n_run + bs - 1) // bs
         first = self._take_stamps(n_batches) if self._rows_sgd else 0
-        _lib.check(lib.hiprec_mf_bpr_epoch(
+        epoch_fn = lib.hiprec_mf_bpr_epoch if self.loss == "bpr" else lib.hiprec_mf_bce_epoch
+        _lib.check(epoch_fn(
             ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg),
             _lib.ptr(perm), n_run, bs, float(self.reg), opt.kind, opt.lr, opt.beta1, opt.beta2,
             opt.eps, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),

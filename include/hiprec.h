@@ -188,6 +188,16 @@ int hiprec_mf_bpr_epoch(const hiprec_mf_tables* w, const hiprec_mf_tables* g, co
                         int32_t first_stamp, hiprec_stats* stats, void* scratch,
                         size_t scratch_bytes, void* stream);
 
+/* ---- the same for loss == "bce" (mf.py:108-111): resident (user, item, rating) arrays, the
+ * RatingDataset loader of data/base_data.py:182-216 replaced by perm[] slices / a staged layout. */
+int hiprec_mf_bce_epoch(const hiprec_mf_tables* w, const hiprec_mf_tables* g, const int64_t* users,
+                        const int64_t* items, const float* ratings, const int64_t* perm,
+                        int64_t n_samples, int64_t batch, float reg_coef, int kind, double lr,
+                        double beta1, double beta2, double eps, float* flat_w, float* flat_g,
+                        float* flat_m, float* flat_v, int64_t n_flat, int32_t* user_stamp,
+                        int32_t* item_stamp, int32_t first_stamp, hiprec_stats* stats,
+                        void* scratch, size_t scratch_bytes, void* stream);
+
 /* ---- one epoch of BPR-MF with PLAIN SGD, one kernel per step.  SGD (momentum 0,
  * torch_engine.py:26-29) is linear, so the update of step k-1 rides inside the gradient kernel of
  * step k: gather blocks read W_a - lr*G_prev on the fly (nothing they read is written by the

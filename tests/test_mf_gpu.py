@@ -564,3 +564,47 @@ def test_c1_ml100k_shaped_epoch_vs_cpu_port(hip_device):
     for k in KEYS:
         rel = np.abs(w[k] - wr[k]).mean() / (np.abs(wr[k]).mean() + 1e-12)
         assert rel < 2e-3, f"{k}: mean relative deviation {rel:.2e} after one epoch"
+
+
+def test_bce_resident_epoch_through_rating_dataloader(hip_device):
+    """loss 'bce' fed by DataLoader(RatingDataset) (data/base_data.py:182-216): the resident epoch
+    driver (hiprec_mf_bce_epoch) draws the loader's own order and matches the oracle fed with the
+    same batches."""
+    from torch.utils.data import DataLoader, Dataset
+
+    class RatingDataset(Dataset):  # same fields as data/data_loaders.py:4-27
+        def __init__(self, u, i, r):
+            self.user_tensor, self.item_tensor, self.target_tensor = u, i, r
+
+        def __getitem__(self, k):
+            return self.user_tensor[k], self.item_tensor[k], self.target_tensor[k]
+
+        def __len__(self):
+            return self.user_tensor.size(0)
+
+    U, I, D, B, N = 200, 150, 32, 300, 1000
+    rng = np.random.default_rng(9)
+    users = torch.from_numpy(rng.integers(0, U, N))
+    items = torch.from_numpy(rng.integers(0, 40, N))
+    ratings = torch.from_numpy((rng.random(N) < 0.3).astype(np.float32))
+    loader = DataLoader(RatingDataset(users, items, ratings), batch_size=B, shuffle=True)
+    for opt, lr in (("sgd", 0.05), ("adam", 0.01)):
+        w = onp.init_params(U, I, D, seed=9)
+        eng = make_engine(U, I, D, opt, "bce", lr, B)
+        load_weights(eng, w)
+        assert eng.prepare_epoch(loader) is not None
+        torch.manual_seed(4)
+        with contextlib.redirect_stdout(io.StringIO()):
+            eng.train_an_epoch(loader, 0)
+        st = onp.new_opt_state(w, opt)
+        torch.manual_seed(4)
+        total = 0.0
+        for bu, bi, br in loader:
+            loss, _ = onp.mf_train_step(w, st, (bu.numpy(), bi.numpy(), br.numpy()), "bce", opt, lr)
+            total += loss
+        scal = dict((t, v) for t, v, _ in eng.writer.scalars)
+        assert_scalar_close(scal["model/loss"], total, 5e-5, f"{opt} epoch BCE loss")
+        got = get_weights(eng)
+        tol = 2e-6 if opt == "sgd" else 2e-3
+        for k in KEYS:
+            assert np.mean(np.abs(got[k] - w[k]) > tol) < 0.01, f"{opt} {k}"
