@@ -386,7 +386,10 @@ def main():
         timed = hp.DeviceTripleBatcher(users[nw:], pos[nw:], neg[nw:], B)
         if args.warmup > 0:
             eng.run_prepared_epoch(stage(eng, warm))
-        prepared = stage(eng, timed)
+        torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        prepared = stage(eng, timed)  # per-epoch staging: permutation, per-batch sort by item, layout
+        staging_s = time.perf_counter() - ts0
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -497,6 +500,12 @@ def main():
                 "optimizer": args.optimizer, "lr": LR, "loss": "bpr", "batch_per_gpu": B,
                 "global_batch": B * world,
                 "parallelism": parallelism,
+            },
+            "epoch_staging": None if dist_on else {
+                "ms": staging_s * 1e3,
+                "what": "per-epoch device-side batcher work outside the timed region: randperm, sort of "
+                        "every batch by item, gather of the triples into visiting order",
+                "value_including_staging": args.steps * B / (dt + staging_s),
             },
             "roofline": {
                 "bound": "hbm",
