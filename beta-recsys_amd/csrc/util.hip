@@ -145,9 +145,98 @@ __global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(float* __restr
   }
 }
 
+// ---- device-side batcher: stage one epoch -----------------------------------------------------------
+// Replaces DataLoader(PairwiseNegativeDataset / RatingDataset, shuffle=True) + default_collate
+// (data/base_data.py:247-253, data/data_loaders.py): block b takes batch b of the epoch's visiting
+// order (perm[], or sequential), sorts it by item id in LDS (bitonic sort of (item, position)
+// pairs; a sum over the batch does not depend on order, and the gradient kernels merge adjacent equal
+// items) and writes the three arrays of the batch contiguously, so that the training kernels read
+// their batches as plain slices.
+template <int NPAD>
+__global__ __launch_bounds__(1024) void stage_epoch_kernel(const int64_t* __restrict__ users,
+                                                           const int64_t* __restrict__ items,
+                                                           const void* __restrict__ third,
+                                                           int third_bytes,
+                                                           const int64_t* __restrict__ perm,
+                                                           int64_t n, int64_t batch,
+                                                           int64_t* __restrict__ out_u,
+                                                           int64_t* __restrict__ out_i,
+                                                           void* __restrict__ out_third) {
+  __shared__ unsigned long long s_kv[NPAD];
+  const int64_t off = static_cast<int64_t>(blockIdx.x) * batch;
+  const int cnt = static_cast<int>(min<int64_t>(batch, n - off));
+  for (int i = threadIdx.x; i < NPAD; i += blockDim.x) {
+    unsigned long long kv = ~0ull;  // padding sorts to the end
+    if (i < cnt) {
+      const int64_t j = perm ? perm[off + i] : off + i;
+      kv = (static_cast<unsigned long long>(static_cast<uint32_t>(items[j])) << 32) |
+           static_cast<uint32_t>(i);
+    }
+    s_kv[i] = kv;
+  }
+  __syncthreads();
+  for (int k = 2; k <= NPAD; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < NPAD; i += blockDim.x) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long a = s_kv[i], b = s_kv[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            s_kv[i] = b;
+            s_kv[l] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+    const int src = static_cast<int>(s_kv[i] & 0xFFFFFFFFull);
+    const int64_t j = perm ? perm[off + src] : off + src;
+    out_u[off + i] = users[j];
+    out_i[off + i] = items[j];
+    if (third_bytes == 8)
+      static_cast<int64_t*>(out_third)[off + i] = static_cast<const int64_t*>(third)[j];
+    else
+      static_cast<float*>(out_third)[off + i] = static_cast<const float*>(third)[j];
+  }
+}
+
 }  // namespace hiprec
 
 using namespace hiprec;
+
+extern "C" int hiprec_stage_epoch(const int64_t* users, const int64_t* items, const void* third,
+                                  int32_t third_bytes, const int64_t* perm, int64_t n, int64_t batch,
+                                  int64_t* out_users, int64_t* out_items, void* out_third,
+                                  void* stream) {
+  HIPREC_REQUIRE(n >= 0 && batch > 0, "bad n / batch");
+  HIPREC_REQUIRE(third_bytes == 4 || third_bytes == 8, "third array must be fp32 or int64");
+  if (n == 0) return 0;
+  HIPREC_REQUIRE(users && items && third && out_users && out_items && out_third, "NULL pointer");
+  if (batch > 8192) {
+    set_error("hiprec_stage_epoch sorts a batch in LDS: batch %lld > 8192 is not supported",
+              (long long)batch);
+    return HIPREC_E_UNSUPPORTED;
+  }
+  const int64_t n_batches = (n + batch - 1) / batch;
+  HIPREC_REQUIRE(n_batches < (1ll << 31), "too many batches");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int grid = static_cast<int>(n_batches);
+#define HIPREC_STAGE(NP, T)                                                                          \
+  stage_epoch_kernel<NP><<<grid, T, 0, st>>>(users, items, third, third_bytes, perm, n, batch,       \
+                                             out_users, out_items, out_third)
+  if (batch <= 64) HIPREC_STAGE(64, 64);
+  else if (batch <= 256) HIPREC_STAGE(256, 256);
+  else if (batch <= 1024) HIPREC_STAGE(1024, 512);
+  else if (batch <= 2048) HIPREC_STAGE(2048, 1024);
+  else if (batch <= 4096) HIPREC_STAGE(4096, 1024);
+  else HIPREC_STAGE(8192, 1024);
+#undef HIPREC_STAGE
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
 
 extern "C" int hiprec_scatter_add_rows(float* table, int64_t n_rows, int32_t dim,
                                        const int64_t* idx, const float* src, int64_t src_stride,

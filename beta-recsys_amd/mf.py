@@ -567,6 +567,15 @@ class MFEngine(ModelEngine):
             neg = ds.target_tensor.to(dev, torch.float32).contiguous()
         perm = None if perm is None else perm.to(dev).contiguous()
         bs = int(train_loader.batch_size)
+        if bs <= 8192 and dev.type == "cuda":
+            # native batcher: one block per batch sorts it by item in LDS and writes the epoch in
+            # visiting order (hiprec_stage_epoch)
+            lib = _lib.load()
+            ou, op, on = torch.empty_like(users), torch.empty_like(pos), torch.empty_like(neg)
+            _lib.check(lib.hiprec_stage_epoch(
+                _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), neg.element_size(), _lib.ptr(perm),
+                users.numel(), bs, _lib.ptr(ou), _lib.ptr(op), _lib.ptr(on), _lib.stream_ptr(dev)))
+            return ou, op, on, None, bs
         if bs >= self.SORT_MIN_BATCH:
             perm = sort_within_batches(perm, pos, bs, self.model.n_items)
         if perm is not None:

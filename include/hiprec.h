@@ -173,6 +173,16 @@ int hiprec_mf_sgd_rows(const hiprec_mf_tables* w, const hiprec_mf_tables* g, con
                        int64_t batch, double lr, int32_t* user_stamp, int32_t* item_stamp,
                        int32_t stamp, hiprec_stats* stats, const void* scratch, void* stream);
 
+/* ---- device-side batcher: lay one epoch out in visiting order.  Batch b = triples
+ * perm[b*batch .. (b+1)*batch) (perm NULL = sequential; last batch short), sorted by item id
+ * inside the batch, written contiguously to out_*.  `third` is the negative-item array (int64,
+ * third_bytes 8) or the rating array (fp32, third_bytes 4).  Replaces
+ * DataLoader(PairwiseNegativeDataset|RatingDataset, shuffle=True) + default_collate
+ * (data/base_data.py:206-216,247-253; data/data_loaders.py:4-53).  batch <= 8192. */
+int hiprec_stage_epoch(const int64_t* users, const int64_t* items, const void* third,
+                       int32_t third_bytes, const int64_t* perm, int64_t n, int64_t batch,
+                       int64_t* out_users, int64_t* out_items, void* out_third, void* stream);
+
 /* ---- one whole epoch of MF-BPR training enqueued back to back (MFEngine.train_an_epoch,
  * mf.py:121-139, with the DataLoader replaced by perm[] slices of the resident triple arrays;
  * the last batch is short, drop_last=False as base_data.py:253).  `flat_*` are the flat buffers

@@ -608,3 +608,34 @@ def test_bce_resident_epoch_through_rating_dataloader(hip_device):
         tol = 2e-6 if opt == "sgd" else 2e-3
         for k in KEYS:
             assert np.mean(np.abs(got[k] - w[k]) > tol) < 0.01, f"{opt} {k}"
+
+
+@pytest.mark.parametrize("batch", [16, 400, 1000, 4096, 8192])
+@pytest.mark.parametrize("third_kind", ["int64", "float32"])
+def test_stage_epoch_kernel(hip_device, batch, third_kind):
+    """The native batcher: batch composition is exactly perm[b*bs:(b+1)*bs] (as a multiset of whole
+    triples), every batch comes out sorted by item, the last batch is short."""
+    from beta_recsys_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(batch)
+    n = 3 * batch + batch // 3 + 1
+    users = rng.integers(0, 10_000, n)
+    items = rng.integers(0, 500, n)
+    third = rng.integers(0, 10_000, n) if third_kind == "int64" else rng.random(n).astype(np.float32)
+    perm = rng.permutation(n)
+    tu, ti, tt, tp = (torch.from_numpy(a).cuda() for a in (users, items, third, perm))
+    for use_perm in (True, False):
+        ou, oi, ot = torch.zeros_like(tu), torch.zeros_like(ti), torch.zeros_like(tt)
+        _lib.check(lib.hiprec_stage_epoch(
+            _lib.ptr(tu), _lib.ptr(ti), _lib.ptr(tt), tt.element_size(), _lib.ptr(tp) if use_perm else None,
+            n, batch, _lib.ptr(ou), _lib.ptr(oi), _lib.ptr(ot), _lib.stream_ptr(hip_device)))
+        gu, gi, gt = ou.cpu().numpy(), oi.cpu().numpy(), ot.cpu().numpy()
+        order = perm if use_perm else np.arange(n)
+        for b0 in range(0, n, batch):
+            sl = slice(b0, min(n, b0 + batch))
+            src = order[sl]
+            assert np.all(np.diff(gi[sl]) >= 0), "batch must be sorted by item"
+            want = sorted(zip(items[src].tolist(), users[src].tolist(), third[src].tolist()))
+            got = sorted(zip(gi[sl].tolist(), gu[sl].tolist(), gt[sl].tolist()))
+            assert want == got, "batch must contain exactly its triples"
