@@ -318,7 +318,14 @@ class DeviceTripleBatcher:
         dev = self.user_tensor.device
         if self.generator is not None:
             return torch.randperm(n, generator=self.generator).to(dev)
-        return torch.randperm(n, device=dev)
+        if dev.type != "cuda":
+            return torch.randperm(n)
+        # native shuffle: a Feistel bijection keyed by a seed drawn from torch's global CPU generator
+        # (so torch.manual_seed controls it), no sort
+        seed = int(torch.randint(0, 2**62, (1,)).item())
+        perm = torch.empty(n, dtype=torch.int64, device=dev)
+        _lib.check(_lib.load().hiprec_random_permutation(_lib.ptr(perm), n, seed, _lib.stream_ptr(dev)))
+        return perm
 
     def __iter__(self):
         perm = self.permutation()

@@ -173,6 +173,11 @@ int hiprec_mf_sgd_rows(const hiprec_mf_tables* w, const hiprec_mf_tables* g, con
                        int64_t batch, double lr, int32_t* user_stamp, int32_t* item_stamp,
                        int32_t stamp, hiprec_stats* stats, const void* scratch, void* stream);
 
+/* ---- device-side shuffle: out[i] = P_seed(i), a pseudo-random bijection of [0, n) (Feistel network
+ * with cycle walking; stateless, no sort).  The epoch order of the device batcher, in place of
+ * RandomSampler's torch.randperm (torch/utils/data/sampler.py, used by base_data.py:253). */
+int hiprec_random_permutation(int64_t* out, int64_t n, uint64_t seed, void* stream);
+
 /* ---- device-side batcher: lay one epoch out in visiting order.  Batch b = triples
  * perm[b*batch .. (b+1)*batch) (perm NULL = sequential; last batch short), sorted by item id
  * inside the batch, written contiguously to out_*.  `third` is the negative-item array (int64,

@@ -639,3 +639,25 @@ def test_stage_epoch_kernel(hip_device, batch, third_kind):
             want = sorted(zip(items[src].tolist(), users[src].tolist(), third[src].tolist()))
             got = sorted(zip(gi[sl].tolist(), gu[sl].tolist(), gt[sl].tolist()))
             assert want == got, "batch must contain exactly its triples"
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 1000, 4097, 1_000_003])
+def test_random_permutation_kernel(hip_device, n):
+    """The device shuffle is a bijection of [0, n), depends on the seed, and mixes well."""
+    from beta_recsys_amd import _lib
+
+    lib = _lib.load()
+    outs = []
+    for seed in (1, 2):
+        out = torch.full((n,), -1, dtype=torch.int64, device=hip_device)
+        _lib.check(lib.hiprec_random_permutation(_lib.ptr(out), n, seed, _lib.stream_ptr(hip_device)))
+        p = out.cpu().numpy()
+        assert np.array_equal(np.sort(p), np.arange(n)), "must be a permutation"
+        outs.append(p)
+    if n >= 1000:
+        assert (outs[0] != outs[1]).mean() > 0.99
+        assert (outs[0] == np.arange(n)).mean() < 0.01
+        # neighbours are sent far apart and without a preferred direction
+        d = np.diff(outs[0].astype(np.float64))
+        assert abs(np.corrcoef(outs[0][:-1], outs[0][1:])[0, 1]) < 0.05
+        assert abs((d > 0).mean() - 0.5) < 0.05
