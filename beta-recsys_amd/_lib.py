@@ -140,6 +140,11 @@ SIGNATURES = {
         [POINTER(LightGcnPlan), _P, c_float, _P, _P, _P, c_int64, c_float, _P, _P, c_size_t, _P],
     ),
     "hiprec_random_permutation": (c_int, [_P, c_int64, ctypes.c_uint64, _P]),
+    "hiprec_rank_metrics_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "hiprec_rank_metrics": (
+        c_int,
+        [_P, c_int64, _P, _P, POINTER(c_int32), c_int32, _P, c_size_t, _P, _P],
+    ),
     "hiprec_stage_epoch": (c_int, [_P, _P, _P, c_int32, _P, c_int64, c_int64, _P, _P, _P, _P]),
     "hiprec_mf_bce_epoch": (
         c_int,

@@ -43,3 +43,34 @@ def uninstall():
         mod = sys.modules.get(ref_name)
         if mod is not None and mod.__name__.startswith(__name__.rsplit(".", 1)[0]):
             del sys.modules[ref_name]
+
+
+def install_eval():
+    """Route ``beta_rec.core.eval_engine.evaluate`` (eval_engine.py:49-87; called by
+    ``train_eval_worker`` :91-141 and ``test_eval_worker`` :145-170) through the HIP ranking-metric
+    kernel.  Calls that ask for a non-ranking metric (rmse, mae, rsquared) keep going to the
+    reference's own function — those are not part of this path."""
+    import importlib
+
+    from . import eval as hip_eval
+
+    ee = importlib.import_module("beta_rec.core.eval_engine")
+    if getattr(ee.evaluate, "_hiprec", False):
+        return ee.evaluate
+    reference_evaluate = ee.evaluate
+
+    def evaluate(data_df, predictions, metrics, k_li):
+        if all(m in hip_eval.RANK_METRICS for m in metrics):
+            return hip_eval.evaluate(data_df, predictions, metrics, k_li)
+        return reference_evaluate(data_df, predictions, metrics, k_li)
+
+    evaluate._hiprec = True
+    evaluate._reference = reference_evaluate
+    ee.evaluate = evaluate
+    return evaluate
+
+
+def uninstall_eval():
+    ee = sys.modules.get("beta_rec.core.eval_engine")
+    if ee is not None and getattr(ee.evaluate, "_hiprec", False):
+        ee.evaluate = ee.evaluate._reference

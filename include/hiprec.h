@@ -336,6 +336,25 @@ int hiprec_lightgcn_grad(const hiprec_lightgcn_plan* plan, const uint8_t* keep, 
                          float inv_batch, hiprec_stats* stats, void* scratch, size_t scratch_bytes,
                          void* stream);
 
+/* ================= Ranking evaluation ("next": the caller after the train step) ====
+ * core/eval_engine.py:49-87 evaluate() -> utils/evaluation.py:461-533 merge_ranking_true_pred
+ * (relevancy_method "top_k"), :535-583 precision_at_k, :586-629 recall_at_k, :632-689 ndcg_at_k,
+ * :692-752 map_at_k.  evaluate() scores the SAME rows it takes the truth from, so the input is one
+ * (score, rating) pair per candidate, grouped by user: segment s owns rows seg_ptr[s]..seg_ptr[s+1]
+ * (device int64, n_segments+1 entries) in the data frame's original row order (ties in score rank
+ * by that order, like nlargest(keep="first") + rank(method="first"), evaluation.py:778-784,516-518).
+ * A row is relevant when rating >= 1 (evaluation.py:492); users with no relevant row are not
+ * "common users" and are left out of the mean (evaluation.py:495-498).  (user,item) pairs must be
+ * unique per user, as in every frame the reference's splitters produce.
+ * k_list_host is a HOST array of n_k (<= HIPREC_RANK_MAX_K) cut-offs.  out (device, fp64):
+ *   out[0] = number of common users, out[1+4j .. 4+4j] = precision, recall, ndcg, map at k_list[j].
+ * workspace: hiprec_rank_metrics_workspace_bytes(n_segments, n_k) bytes of device memory. */
+#define HIPREC_RANK_MAX_K 8
+size_t hiprec_rank_metrics_workspace_bytes(int64_t n_segments, int32_t n_k);
+int hiprec_rank_metrics(const int64_t* seg_ptr, int64_t n_segments, const float* scores,
+                        const float* ratings, const int32_t* k_list_host, int32_t n_k,
+                        double* workspace, size_t workspace_bytes, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -245,7 +245,7 @@ def main():
     epoch_fixture(MFEngine, PairwiseNegativeDataset, "mf_epoch_sgd", "sgd", seed=22)
 
 
-if __name__ == "__main__" and "--ncf" not in sys.argv and "--lightgcn" not in sys.argv:
+if __name__ == "__main__" and not {"--ncf", "--lightgcn", "--eval"} & set(sys.argv):
     main()
 
 
@@ -391,3 +391,82 @@ def lightgcn_fixture(name, U, I, D, L, B, n_edges, optimizer, lr, keep, n_steps,
 if __name__ == "__main__" and "--lightgcn" in sys.argv:
     lightgcn_fixture("lightgcn_adam", 61, 47, 16, 3, 40, 400, "adam", 0.05, 0.6, 3, seed=41)
     lightgcn_fixture("lightgcn_sgd_d64", 37, 29, 64, 2, 24, 250, "sgd", 0.05, 0.6, 2, seed=42)
+
+
+# ---- ranking evaluation (core/eval_engine.py evaluate -> utils/evaluation.py) ------------------------
+
+RANK_METRICS = ("precision", "recall", "ndcg", "map")
+
+
+def eval_fixture(name, users, items, ratings, scores, k_list):
+    """Run the reference's own evaluate() on one frame and keep inputs + the metric table."""
+    import warnings
+
+    import pandas as pd
+
+    import_reference()
+    from beta_rec.core.eval_engine import evaluate
+
+    df = pd.DataFrame({"col_user": users, "col_item": items, "col_rating": ratings})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = evaluate(df, scores, list(RANK_METRICS), list(k_list))
+    table = np.array([[res[f"{m}@{k}"] for m in RANK_METRICS] for k in k_list], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), users=np.asarray(users, np.int64),
+                        items=np.asarray(items, np.int64), ratings=np.asarray(ratings, np.float32),
+                        scores=np.asarray(scores, np.float32), k_list=np.asarray(k_list, np.int32),
+                        metrics=table)
+    print(name, table.round(4).tolist())
+
+
+def main_eval():
+    rng = np.random.default_rng(7)
+    # (1) the reference's usual test frame: one held-out positive + 20 sampled negatives per user
+    U, C = 40, 21
+    users = np.repeat(np.arange(U), C)
+    items = np.concatenate([rng.permutation(500)[:C] for _ in range(U)])
+    ratings = np.tile(np.r_[1.0, np.zeros(C - 1)], U).astype(np.float32)
+    scores = rng.random(U * C).astype(np.float32)
+    eval_fixture("eval_leave_one_out", users, items, ratings, scores, [1, 5, 10, 20])
+    # (2) ragged, shuffled rows, several positives with rating values 1..5, users without positives,
+    #     segments shorter than k; continuous scores (no ties)
+    rows = []
+    for u in range(60):
+        n = int(rng.integers(1, 40))
+        its = rng.permutation(300)[:n]
+        n_pos = 0 if u % 7 == 0 else int(rng.integers(1, max(2, n // 3 + 1)))
+        for j, it in enumerate(its):
+            rows.append((u * 3 + 1, it, float(rng.integers(1, 6)) if j < n_pos else 0.0))
+    rows = [rows[i] for i in rng.permutation(len(rows))]
+    users, items, ratings = (np.array(c) for c in zip(*rows))
+    scores = rng.normal(size=len(rows)).astype(np.float32)
+    eval_fixture("eval_ragged", users, items, ratings.astype(np.float32), scores, [3, 10, 50])
+    # (2b) heavy score ties (quantised scores incl. negatives and +-0), every segment longer than
+    #      max(k): pandas' nlargest then takes its stable path (first occurrence wins a tie).  With
+    #      k >= len(group) it falls back to an UNSTABLE sort_values (pandas core/methods/selectn.py
+    #      "slow method"), whose tie order is a numpy-build detail — not pinned (DESIGN.md quirk Q12).
+    rows = []
+    for u in range(40):
+        n = int(rng.integers(55, 90))
+        its = rng.permutation(300)[:n]
+        n_pos = int(rng.integers(1, 12))
+        for j, it in enumerate(its):
+            rows.append((u, it, float(rng.integers(1, 6)) if j < n_pos else 0.0))
+    rows = [rows[i] for i in rng.permutation(len(rows))]
+    tu, ti, tr = (np.array(c) for c in zip(*rows))
+    tscores = (rng.integers(-3, 4, len(rows)) / 4.0).astype(np.float32)
+    tscores[rng.random(len(rows)) < 0.1] = -0.0
+    eval_fixture("eval_ties", tu, ti, tr.astype(np.float32), tscores, [3, 10, 50])
+    # (3) nothing relevant anywhere -> every metric is 0.0 (evaluation.py:581-582)
+    eval_fixture("eval_no_hits", users[:200], items[:200], np.zeros(200, np.float32), scores[:200], [5])
+    # (4) fractional ratings below the relevance threshold 1 (evaluation.py:492) and full-catalogue ranking
+    U, I = 12, 400
+    users = np.repeat(np.arange(U), I)
+    items = np.tile(np.arange(I), U)
+    ratings = np.where(rng.random(U * I) < 0.03, 1.0, np.where(rng.random(U * I) < 0.05, 0.5, 0.0))
+    scores = rng.normal(size=U * I).astype(np.float32)
+    eval_fixture("eval_full_catalogue", users, items, ratings.astype(np.float32), scores, [10, 20, 100])
+
+
+if __name__ == "__main__" and "--eval" in sys.argv:
+    main_eval()

@@ -317,3 +317,56 @@ def test_ncf_pre_merges_gmf_and_mlp_checkpoints(tmp_path):
     assert torch.equal(n["affine_output.bias"], 0.5 * (m["affine_output.bias"] + g["affine_output.bias"]))
     # the merged parameters are still views of NeuMF's single flat buffer
     assert neu.model.embedding_user_mlp.weight.data_ptr() == neu.model.flat.data_ptr()
+
+
+def test_compat_install_eval_patches_evaluate_and_keeps_rating_metrics(tmp_path, monkeypatch):
+    """install_eval swaps eval_engine.evaluate for the HIP one; non-ranking metrics stay with the reference."""
+    import importlib
+    import sys
+
+    from beta_recsys_amd import compat
+    from beta_recsys_amd import eval as hip_eval
+
+    root = tmp_path / "fake"
+    (root / "beta_rec" / "core").mkdir(parents=True)
+    (root / "beta_rec" / "__init__.py").write_text("")
+    (root / "beta_rec" / "core" / "__init__.py").write_text("")
+    (root / "beta_rec" / "core" / "eval_engine.py").write_text(
+        "def evaluate(data_df, predictions, metrics, k_li):\n    return {'from': 'reference'}\n"
+        "def train_eval_worker(df, pred, metrics, k):\n    return evaluate(df, pred, metrics, k)\n")
+    monkeypatch.syspath_prepend(str(root))
+    saved = {k: v for k, v in sys.modules.items() if k == "beta_rec" or k.startswith("beta_rec.")}
+    for k in saved:
+        del sys.modules[k]
+    seen = []
+    monkeypatch.setattr(hip_eval, "evaluate", lambda *a, **k: seen.append(a) or {"from": "hip"})
+    try:
+        compat.install_eval()
+        ee = importlib.import_module("beta_rec.core.eval_engine")
+        assert compat.install_eval() is ee.evaluate          # idempotent
+        assert ee.train_eval_worker(None, None, ["ndcg", "recall"], [10]) == {"from": "hip"}
+        assert ee.train_eval_worker(None, None, ["rmse"], [10]) == {"from": "reference"}
+        assert len(seen) == 1
+        compat.uninstall_eval()
+        assert ee.train_eval_worker(None, None, ["ndcg"], [10]) == {"from": "reference"}
+    finally:
+        for k in [k for k in sys.modules if k.startswith("beta_rec.") or k == "beta_rec"]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def test_eval_group_by_user_and_argument_checks():
+    from beta_recsys_amd import eval as hip_eval
+
+    order, seg = hip_eval.group_by_user(torch.tensor([4, 4, 7, 9, 9, 9]))
+    assert order is None and seg.tolist() == [0, 2, 3, 6]                   # already grouped: no sort
+    order, seg = hip_eval.group_by_user(torch.tensor([9, 4, 9, 7, 4, 9]))
+    assert order.tolist() == [1, 4, 3, 0, 2, 5] and seg.tolist() == [0, 2, 3, 6]   # stable within a user
+    order, seg = hip_eval.group_by_user(torch.tensor([], dtype=torch.int64))
+    assert order is None and seg.tolist() == [0]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        hip_eval.rank_metrics([0], [1.0], [0.5], [1], device="cpu")
+    with pytest.raises(ValueError):
+        hip_eval.rank_metrics([0], [1.0], [0.5], [], device="cpu")
+    with pytest.raises(KeyError):
+        hip_eval.evaluate({"col_user": [0], "col_rating": [1.0]}, [0.5], ["rmse"], 5)
