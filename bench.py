@@ -342,6 +342,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adam", "rmsprop"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-kernel", action="store_true",
+                    help="mf: gradient kernel + dense optimizer sweep per step instead of the fused one-kernel step")
     ap.add_argument("--workload", default="mf", choices=["mf", "ncf", "lightgcn", "mf-c4shard"],
                     help="mf = BASELINE configs[1] (the headline); ncf = configs[2] (NeuMF, emb_dim 32)")
     ap.add_argument("--multi-gpu", default="auto", choices=["auto", "replicated", "sharded"],
@@ -382,6 +384,7 @@ def main():
     prepared = None
     if not dist_on:
         eng = make_engine(device, args.optimizer)
+        eng.fused_step = not args.two_kernel
         warm = hp.DeviceTripleBatcher(users[:nw], pos[:nw], neg[:nw], B)
         timed = hp.DeviceTripleBatcher(users[nw:], pos[nw:], neg[nw:], B)
         if args.warmup > 0:
@@ -469,12 +472,14 @@ def main():
     if rank == 0:
         k_mean, k_med = kernel_timing(eng, prepared)
         bpt = algorithmic_bytes_per_triple(D)
-        fused = (not dist_on) and args.optimizer == "sgd" and eng.fused_sgd
+        fused = (not dist_on) and eng.fused_step
+        kind_id = {"sgd": 0, "adam": 1, "rmsprop": 2}[args.optimizer]
         if fused:
-            # plain SGD runs ONE kernel per step (gather + score + gradient scatter + the SGD update
-            # of the previous step): its launch period, from HIP events around the timed epoch, is
-            # what the algorithmic bytes of a step are divided by
-            dom_name = "mf_bpr_sgd_fused_kernel (gather + score + BPR grad + scatter + SGD update, 1 launch/step)"
+            # ONE kernel per step (gather + score + gradient scatter + the optimizer update of the
+            # previous step): its launch period, from HIP events around the timed epoch, is what
+            # the algorithmic bytes of a step are divided by
+            dom_name = (f"mf_bpr_fused_kernel<1,{kind_id}> (gather + score + BPR grad + scatter + "
+                        f"{args.optimizer} update, 1 launch/step)")
             dom_s = epoch_event_s / (args.steps + 1)
         else:
             dom_name = "mf_bpr_grad_kernel (gather + score + BPR grad + atomic scatter)"
@@ -517,7 +522,7 @@ def main():
                 "algorithmic_bytes_per_launch": bpt * B,
                 "kernel_us": dom_s * 1e6,
                 "grad_only_kernel_us": k_mean * 1e6,
-                "traffic": measured_traffic_bytes("hiprec::mf_bpr_sgd_fused_kernel<1>" if fused
+                "traffic": measured_traffic_bytes(f"hiprec::mf_bpr_fused_kernel<1, {kind_id}>" if fused
                                                  else "hiprec::mf_bpr_grad_kernel<1>"),
                 "step_frac": (world * args.steps * B / dt) / world * bpt / (HBM_PEAK_GBS * 1e9),
             },

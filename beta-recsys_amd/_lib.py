@@ -152,6 +152,11 @@ SIGNATURES = {
         + [c_double, c_double, c_double, c_double]
         + [_P, _P, _P, _P, c_int64, _P, _P, c_int32, _P, _P, c_size_t, _P],
     ),
+    "hiprec_mf_bpr_epoch_fused": (
+        c_int,
+        [c_int, _P, _P, _P, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P, c_int64, c_int64, c_float,
+         c_double, c_double, c_double, c_double, _P, POINTER(c_int32), _P],
+    ),
     "hiprec_mf_bpr_epoch_sgd_fused": (
         c_int,
         [_P, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P, c_int64, c_int64, c_float, c_double, _P,

@@ -195,6 +195,97 @@ __device__ __forceinline__ void advance_step(hiprec_stats* stats) {
   stats->beta2_pow *= stats->beta2;
 }
 
+// ---- optimizer arithmetic shared by the dense sweep (optim.hip) and the fused step (mf.hip) ----
+// Scalars exactly as the reference's python doubles become fp32 inside the ATen ops:
+// (float)lr, (float)beta2, (float)(1 - beta1), (float)(1 - beta2), (float)eps.
+struct OptScalars {
+  double lr_d;
+  float lr, beta2, omb1, omb2, eps;
+};
+
+// Division and square root of the Adam / RMSprop denominators.  The default uses the hardware
+// v_rcp_f32 / v_sqrt_f32 (1 ulp each): the update then differs from ATen's correctly rounded
+// sqrt/div by a few ulp of the UPDATE (<= 1e-6 * lr in absolute terms, two orders below the 1e-5
+// parity bar), and costs ~8 VALU issue slots instead of ~35 per element -- the IEEE sequences made
+// the fused Adam step VALU-bound (13.6 us per step, 2 us of it in these two functions).
+// Build with -DHIPREC_IEEE_DIV for the op-for-op ATen arithmetic.
+__device__ __forceinline__ float opt_div(float a, float b) {
+#ifdef HIPREC_IEEE_DIV
+  return a / b;
+#else
+  return a * __builtin_amdgcn_rcpf(b);
+#endif
+}
+
+__device__ __forceinline__ float opt_sqrt(float a) {
+#ifdef HIPREC_IEEE_DIV
+  return sqrtf(a);
+#else
+  return __builtin_amdgcn_sqrtf(a);
+#endif
+}
+
+template <int KIND>
+__device__ __forceinline__ void opt_update(float& w, float& g, float& m, float& v,
+                                           const OptScalars s, float step_size, float bc2_sqrt) {
+  if constexpr (KIND == HIPREC_OPT_SGD) {
+    w = w - s.lr * g;  // param.add_(grad, alpha=-lr)
+  } else if constexpr (KIND == HIPREC_OPT_ADAM) {
+    m = m + s.omb1 * (g - m);                                 // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * s.beta2 + (s.omb2 * g) * g;                         // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+    const float denom = opt_div(opt_sqrt(v), bc2_sqrt) + s.eps;  // (sqrt(v)/sqrt(bc2)).add_(eps)
+    w = w + opt_div(-step_size * m, denom);                     // param.addcdiv_(m, denom, value=-step_size)
+  } else {
+    v = v * s.beta2 + (s.omb2 * g) * g;                         // square_avg.mul_(alpha).addcmul_(g,g,1-alpha)
+    const float avg = opt_sqrt(v) + s.eps;                      // square_avg.sqrt().add_(eps)
+    w = w + opt_div(-s.lr * g, avg);                            // param.addcdiv_(grad, avg, value=-lr)
+  }
+  g = 0.f;
+}
+
+// Step-dependent scalars of the update that follows the step counted last in `stats`.
+template <int KIND>
+__device__ __forceinline__ void step_scalars(const OptScalars& s, const hiprec_stats* stats,
+                                             float* step_size, float* bc2_sqrt) {
+  *step_size = s.lr;
+  *bc2_sqrt = 1.f;
+  if constexpr (KIND == HIPREC_OPT_ADAM) {
+    // bias_correction1 = 1 - beta1**t ; step_size = lr / bc1 ; bc2_sqrt = sqrt(1 - beta2**t)
+    // (python doubles in torch, then rounded to fp32 when they enter the tensor ops)
+    const double bc1 = 1.0 - stats->beta1_pow;
+    const double bc2 = 1.0 - stats->beta2_pow;
+    *step_size = static_cast<float>(s.lr_d / bc1);
+    *bc2_sqrt = static_cast<float>(sqrt(bc2));
+  }
+}
+
+// The same update split in two so that its loads travel with the caller's own first loads and its
+// arithmetic + stores happen at the end of the kernel: called back to back (as advance_step does)
+// the one thread that runs it, and with it its whole block, starts a memory round trip late.
+struct StepState {
+  long long step;
+  double b1, b2, b1p, b2p;
+};
+
+__device__ __forceinline__ StepState step_load(const hiprec_stats* stats) {
+  return StepState{stats->step, stats->beta1, stats->beta2, stats->beta1_pow, stats->beta2_pow};
+}
+
+__device__ __forceinline__ void step_store_advanced(hiprec_stats* stats, const StepState& s) {
+  stats->step = s.step + 1;
+  stats->beta1_pow = s.b1p * s.b1;
+  stats->beta2_pow = s.b2p * s.b2;
+}
+
+// *p as a VECTOR load (the zero offset is opaque to the compiler).  A scalar load of a value the
+// previous launch wrote is a full miss, and because scalar loads share lgkmcnt the wave's index
+// loads would have to queue behind it.
+__device__ __forceinline__ float load_scalar_param(const float* p) {
+  int vzero = 0;
+  asm volatile("" : "+v"(vzero));
+  return p[vzero];
+}
+
 #endif  // __HIPCC__
 
 }  // namespace hiprec

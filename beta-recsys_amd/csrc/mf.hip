@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
   const int wv = wave_in_block();
   const int D = w.dim;
   const int ld = D + 1;
-  const float gb = *w.global_bias;
+  const float gb = load_scalar_param(w.global_bias);
   // mf.py:116 batch_loss = loss + reg*regularizer; user terms appear in both forward calls
   const float ru = 4.f * reg_coef * inv_batch, ri = 2.f * reg_coef * inv_batch;
   constexpr int R = NPL > 0 ? NPL : 1;
@@ -91,7 +91,9 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
   float reg_acc = 0.f;   // per lane
   float gb_acc = 0.f;    // wave-uniform: d(loss)/d(global_bias)
 
-  if (blockIdx.x == 0 && threadIdx.x == 0) advance_step(stats);
+  const bool stepper = blockIdx.x == 0 && threadIdx.x == 0;
+  StepState step_state{};
+  if (stepper) step_state = step_load(stats);
 
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kAggWaves;
   const int64_t first = static_cast<int64_t>(blockIdx.x) * kAggWaves;
@@ -122,6 +124,9 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
 
   TripleIdx cur = load_triple(w, users, pos, neg, perm, first + wv, batch, stats, lane);
   fetch_rows(cur, cu, cp, cn, cbu, cbp, cbn);
+  // the stepper's loads were requested before the index loads, so they are back by now: finish the
+  // update in the shadow of the row gather
+  if (stepper) step_store_advanced(stats, step_state);
 
   for (int64_t base = first; base < batch; base += stride) {
     const bool valid = cur.valid;
@@ -236,73 +241,130 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
   publish_partials<kAggWaves>(loss_acc, reg_acc, gb_acc, inv_batch, scratch);
 }
 
-// ---- fused SGD step: ONE launch per step -----------------------------------------------------------
-// Plain SGD (momentum 0) is linear, so the optimizer kernel of step k-1 can ride inside the gradient
-// kernel of step k without giving up the reference's semantics (all gradients of a batch come from
-// the pre-step weights):
-//   gather blocks   read  w_eff = W_a[row] - lr * G_prev[row]  on the fly  (= the weights after step
-//                   k-1; neither W_a nor G_prev is written by this launch) and accumulate the
+// ---- fused step: ONE launch per step ---------------------------------------------------------------
+// torch's SGD / Adam / RMSprop updates are elementwise functions of (w, g, m, v), so the optimizer
+// kernel of step k-1 can ride inside the gradient kernel of step k without giving up the reference's
+// semantics (all gradients of a batch come from the pre-step weights):
+//   gather blocks   evaluate  w_eff = update(W_a, G_prev, M_a, V_a)[row]  on the fly  (= the weights
+//                   after step k-1; none of the four is written by this launch) and accumulate the
 //                   gradients of step k into G_cur;
-//   sweep blocks    (the rest of the same grid) write W_b = W_a - lr * G_prev for the WHOLE buffer
-//                   and clear G_zero (the accumulator of step k+1), and reduce step k-1's loss
-//                   partials into the stats.
-// W ping-pongs between two buffers, G rotates through three; the arithmetic per element is the very
-// expression torch.optim.SGD evaluates, so results are bit-identical to the two-kernel path.
-struct FusedSgd {
-  hiprec_mf_tables gp;         // pending gradient G_prev, viewed as tables
-  const float* w_read;         // flat W_a
-  float* w_write;              // flat W_b
-  const float* g_prev;         // flat G_prev
-  float* g_zero;               // flat accumulator of the NEXT step, cleared here
+//   sweep blocks    (the rest of the same grid) write W_b, M_b, V_b = update(...) for the WHOLE buffer
+//                   and clear G_zero (the accumulator of step k+1); the first of them reduces step
+//                   k-1's loss partials into the stats, advances the step counter and leaves step
+//                   k's bias-correction scalars in this step's scratch header for launch k+1.
+// W, M, V ping-pong between two buffers each, G rotates through three; the arithmetic per element is
+// opt_update<KIND>, the very expression the dense sweep of the two-kernel path evaluates.
+constexpr int kFusedMaxGather = 256;  // gather blocks of one fused launch (bigger batches loop)
+constexpr int kFusedSlots = kFusedMaxGather / kWave;
+
+struct FusedOpt {
+  hiprec_mf_tables gp, mp, vp;  // G_prev, M_a, V_a viewed as tables (mp / vp unused for SGD)
+  const float* w_read;          // flat W_a
+  const float* g_prev;          // flat G_prev
+  const float* m_read;          // flat M_a (Adam)
+  const float* v_read;          // flat V_a (Adam, RMSprop)
+  float* w_write;               // flat W_b
+  float* m_write;
+  float* v_write;
+  float* g_zero;                // flat accumulator of the NEXT step, cleared here
   int64_t n_flat;
-  float lr;
+  OptScalars s;
   int n_gather_blocks;
-  const Scratch* scratch_prev; // partials of step k-1 (n_partials == 0 before the first step)
+  int n_prev_partials;          // gather blocks of step k-1, known to the host: spares the gather
+                                // blocks a dependent load of scratch_prev->n_partials (~1 us miss)
+  int apply_prev;               // 0 for the first launch of an epoch: nothing is pending
+  const Scratch* scratch_prev;  // partials + step scalars of step k-1
 };
 
-template <int NPL>
-__global__ __launch_bounds__(kAggBlock) void mf_bpr_sgd_fused_kernel(
-    hiprec_mf_tables w, hiprec_mf_tables g, FusedSgd f, const int64_t* __restrict__ users,
+template <int KIND>
+__device__ __forceinline__ float fused_eff(float w, float g, float m, float v, const OptScalars& s,
+                                           float step_size, float bc2_sqrt) {
+  opt_update<KIND>(w, g, m, v, s, step_size, bc2_sqrt);
+  return w;
+}
+
+// Two 16-wave blocks must fit on a CU (8 waves per SIMD, i.e. <= 64 VGPRs): the sweep blocks are the
+// second half of the grid and would otherwise wait for a gather block to retire (measured: Adam at 70
+// VGPRs ran 15.4 us per step instead of 10.7).  The dim > 64 variants keep their registers.
+template <int NPL, int KIND>
+__global__ __launch_bounds__(kAggBlock) __attribute__((amdgpu_waves_per_eu(NPL == 1 ? 8 : 4, 8)))
+void mf_bpr_fused_kernel(
+    hiprec_mf_tables w, hiprec_mf_tables g, FusedOpt f, const int64_t* __restrict__ users,
     const int64_t* __restrict__ pos, const int64_t* __restrict__ neg, int64_t batch,
     float inv_batch, float reg_coef, hiprec_stats* stats, Scratch* scratch) {
   extern __shared__ __attribute__((aligned(16))) float s_acc[];
   __shared__ long long s_item[kAggWaves];
   const int lane = lane_id();
   const int wv = wave_in_block();
-  const float lr = f.lr;
+  constexpr bool kHasM = KIND == HIPREC_OPT_ADAM;
+  constexpr bool kHasV = KIND != HIPREC_OPT_SGD;
+  const bool apply = f.apply_prev != 0;
 
   if (static_cast<int>(blockIdx.x) >= f.n_gather_blocks) {
     // ------------------------------ sweep part ------------------------------
     const int sb = static_cast<int>(blockIdx.x) - f.n_gather_blocks;
     const int n_sb = static_cast<int>(gridDim.x) - f.n_gather_blocks;
+    float step_size = f.s.lr, bc2_sqrt = 1.f;
+    if constexpr (KIND == HIPREC_OPT_ADAM) {
+      step_size = __uint_as_float(f.scratch_prev->_pad[0]);
+      bc2_sqrt = __uint_as_float(f.scratch_prev->_pad[1]);
+    }
     const int64_t gb_index = f.n_flat - 1;  // global_bias is the last element of the flat layout
     const int64_t n4 = f.n_flat >> 2;
     const int64_t skip4 = (gb_index < (n4 << 2)) ? (gb_index >> 2) : -1;
     const float4* wr4 = reinterpret_cast<const float4*>(f.w_read);
     const float4* gp4 = reinterpret_cast<const float4*>(f.g_prev);
+    const float4* mr4 = reinterpret_cast<const float4*>(f.m_read);
+    const float4* vr4 = reinterpret_cast<const float4*>(f.v_read);
     float4* ww4 = reinterpret_cast<float4*>(f.w_write);
+    float4* mw4 = reinterpret_cast<float4*>(f.m_write);
+    float4* vw4 = reinterpret_cast<float4*>(f.v_write);
     float4* gz4 = reinterpret_cast<float4*>(f.g_zero);
     const int64_t stride = static_cast<int64_t>(n_sb) * kAggBlock;
     for (int64_t i = static_cast<int64_t>(sb) * kAggBlock + threadIdx.x; i < n4; i += stride) {
       if (i == skip4) continue;
-      const float4 a = wr4[i], d = gp4[i];
-      ww4[i] = make_float4(a.x - lr * d.x, a.y - lr * d.y, a.z - lr * d.z, a.w - lr * d.w);
+      float4 a = wr4[i], d = gp4[i];
+      float4 mv = make_float4(0.f, 0.f, 0.f, 0.f), vv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (kHasM) mv = mr4[i];
+      if constexpr (kHasV) vv = vr4[i];
+      if (apply) {
+        opt_update<KIND>(a.x, d.x, mv.x, vv.x, f.s, step_size, bc2_sqrt);
+        opt_update<KIND>(a.y, d.y, mv.y, vv.y, f.s, step_size, bc2_sqrt);
+        opt_update<KIND>(a.z, d.z, mv.z, vv.z, f.s, step_size, bc2_sqrt);
+        opt_update<KIND>(a.w, d.w, mv.w, vv.w, f.s, step_size, bc2_sqrt);
+      }
+      ww4[i] = a;
+      if constexpr (kHasM) mw4[i] = mv;
+      if constexpr (kHasV) vw4[i] = vv;
       gz4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    auto scalar_update = [&](int64_t i, float extra_g) {
+      float a = f.w_read[i], d = f.g_prev[i] + extra_g, mv = 0.f, vv = 0.f;
+      if constexpr (kHasM) mv = f.m_read[i];
+      if constexpr (kHasV) vv = f.v_read[i];
+      if (apply) opt_update<KIND>(a, d, mv, vv, f.s, step_size, bc2_sqrt);
+      f.w_write[i] = a;
+      if constexpr (kHasM) f.m_write[i] = mv;
+      if constexpr (kHasV) f.v_write[i] = vv;
+      f.g_zero[i] = 0.f;
+    };
     for (int64_t i = (n4 << 2) + static_cast<int64_t>(sb) * kAggBlock + threadIdx.x; i < f.n_flat;
          i += stride) {
-      if (i == gb_index) continue;
-      f.w_write[i] = f.w_read[i] - lr * f.g_prev[i];
-      f.g_zero[i] = 0.f;
+      if (i != gb_index) scalar_update(i, 0.f);
     }
     if (sb == 0) {
       const float gb_part = finalize_partials<kAggBlock>(stats, f.scratch_prev);
       if (threadIdx.x == 0) {
         const int64_t lo = skip4 >= 0 ? (skip4 << 2) : gb_index;
-        for (int64_t i = lo; i <= gb_index; ++i) {
-          const float gv = f.g_prev[i] + (i == gb_index ? gb_part : 0.f);
-          f.w_write[i] = f.w_read[i] - lr * gv;
-          f.g_zero[i] = 0.f;
+        for (int64_t i = lo; i <= gb_index; ++i) scalar_update(i, i == gb_index ? gb_part : 0.f);
+        if (batch > 0) {
+          // count step k and leave its bias-correction scalars for launch k+1 (kept off the gather
+          // blocks' critical path; they read step k-1's pair from scratch_prev, never this one)
+          advance_step(stats);
+          float ss, bq;
+          step_scalars<KIND>(f.s, stats, &ss, &bq);
+          scratch->_pad[0] = __float_as_uint(ss);
+          scratch->_pad[1] = __float_as_uint(bq);
         }
       }
     }
@@ -313,17 +375,31 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_sgd_fused_kernel(
   const int D = w.dim;
   const int ld = D + 1;
   const float ru = 4.f * reg_coef * inv_batch, ri = 2.f * reg_coef * inv_batch;
-  // global_bias after step k-1: its gradient lives in the previous step's partials
-  float gbp = 0.f;
+  // global_bias after step k-1: its gradient lives in the previous step's partials.  The loads are
+  // only REQUESTED here; they travel together with the index and row loads below and are reduced
+  // at their first use (the sigmoid), so the launch pays one memory round trip for them instead
+  // of two in front of everything else.
+  float gbz[kFusedSlots];  // every slot of the scratch block is addressable: no branches
   {
-    const uint32_t np = f.scratch_prev->n_partials;
-    for (uint32_t i = lane; i < np; i += kWave) gbp += f.scratch_prev->partials[i].z;
-    gbp = wave_sum(gbp);
+    const float4* pv = f.scratch_prev->partials;
+#pragma unroll
+    for (int j = 0; j < kFusedSlots; ++j) gbz[j] = pv[lane + kWave * j].z;
   }
-  const float gb = *w.global_bias - lr * (*f.gp.global_bias + gbp);
+  // VECTOR loads on purpose: as scalar loads they would share lgkmcnt with the index loads below,
+  // and all of these were written by the previous launch (full misses).
+  const float gb_w = load_scalar_param(w.global_bias), gb_g = load_scalar_param(f.gp.global_bias);
+  float gb_m = 0.f, gb_v = 0.f, step_size = f.s.lr, bc2_sqrt = 1.f;
+  if constexpr (kHasM) gb_m = load_scalar_param(f.mp.global_bias);
+  if constexpr (kHasV) gb_v = load_scalar_param(f.vp.global_bias);
+  if constexpr (KIND == HIPREC_OPT_ADAM) {
+    const float* hdr = reinterpret_cast<const float*>(f.scratch_prev->_pad);
+    step_size = load_scalar_param(hdr);
+    bc2_sqrt = load_scalar_param(hdr + 1);
+  }
+  float gb = 0.f;
+  bool gb_ready = false;
 
   float loss_acc = 0.f, reg_acc = 0.f, gb_acc = 0.f;
-  if (blockIdx.x == 0 && threadIdx.x == 0) advance_step(stats);
 
   for (int64_t base = static_cast<int64_t>(blockIdx.x) * kAggWaves; base < batch;
        base += static_cast<int64_t>(f.n_gather_blocks) * kAggWaves) {
@@ -355,14 +431,58 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_sgd_fused_kernel(
       const int64_t ou = u * D, op = p * D, on = n * D;
       float nn[NPL];
       float dp = 0.f, dn = 0.f;
+      // everything this triple needs goes out in one burst (one round trip): biases ...
+      const float wbu = w.user_bias[u], gbu = f.gp.user_bias[u];
+      const float wbn = w.item_bias[n], gbn = f.gp.item_bias[n];
+      const float wbp = w.item_bias[p], gbp_ = f.gp.item_bias[p];
+      float mbu = 0.f, mbn = 0.f, mbp = 0.f, vbu = 0.f, vbn = 0.f, vbp = 0.f;
+      if constexpr (kHasM) {
+        mbu = f.mp.user_bias[u];
+        mbn = f.mp.item_bias[n];
+        mbp = f.mp.item_bias[p];
+      }
+      if constexpr (kHasV) {
+        vbu = f.vp.user_bias[u];
+        vbn = f.vp.item_bias[n];
+        vbp = f.vp.item_bias[p];
+      }
+      // ... and rows
+      float wu[NPL], gu[NPL], wp[NPL], gpv[NPL], wn[NPL], gn[NPL];
+      float mu[NPL], mpv[NPL], mn[NPL], vu[NPL], vpv[NPL], vn[NPL];
 #pragma unroll
       for (int k = 0; k < NPL; ++k) {
         const int c = lane + kWave * k;
-        const bool in = c < D;
+        const int cc = c < D ? c : D - 1;  // always a valid column: unconditional loads, one wait
+        wu[k] = w.user_emb[ou + cc];
+        gu[k] = f.gp.user_emb[ou + cc];
+        wp[k] = w.item_emb[op + cc];
+        gpv[k] = f.gp.item_emb[op + cc];
+        wn[k] = w.item_emb[on + cc];
+        gn[k] = f.gp.item_emb[on + cc];
+        mu[k] = mpv[k] = mn[k] = vu[k] = vpv[k] = vn[k] = 0.f;
+        if constexpr (kHasM) {
+          mu[k] = f.mp.user_emb[ou + cc];
+          mpv[k] = f.mp.item_emb[op + cc];
+          mn[k] = f.mp.item_emb[on + cc];
+        }
+        if constexpr (kHasV) {
+          vu[k] = f.vp.user_emb[ou + cc];
+          vpv[k] = f.vp.item_emb[op + cc];
+          vn[k] = f.vp.item_emb[on + cc];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        const bool in = lane + kWave * k < D;
         // weights after step k-1, evaluated on the fly (same expression as the sweep writes)
-        uu[k] = in ? w.user_emb[ou + c] - lr * f.gp.user_emb[ou + c] : 0.f;
-        pp[k] = in ? w.item_emb[op + c] - lr * f.gp.item_emb[op + c] : 0.f;
-        nn[k] = in ? w.item_emb[on + c] - lr * f.gp.item_emb[on + c] : 0.f;
+        if (apply) {
+          wu[k] = fused_eff<KIND>(wu[k], gu[k], mu[k], vu[k], f.s, step_size, bc2_sqrt);
+          wp[k] = fused_eff<KIND>(wp[k], gpv[k], mpv[k], vpv[k], f.s, step_size, bc2_sqrt);
+          wn[k] = fused_eff<KIND>(wn[k], gn[k], mn[k], vn[k], f.s, step_size, bc2_sqrt);
+        }
+        uu[k] = in ? wu[k] : 0.f;
+        pp[k] = in ? wp[k] : 0.f;
+        nn[k] = in ? wn[k] : 0.f;
       }
 #pragma unroll
       for (int k = 0; k < NPL; ++k) {
@@ -372,9 +492,24 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_sgd_fused_kernel(
       }
       dp = wave_sum(dp);
       dn = wave_sum(dn);
-      const float bu = w.user_bias[u] - lr * f.gp.user_bias[u];
-      const float bn = w.item_bias[n] - lr * f.gp.item_bias[n];
-      bp = w.item_bias[p] - lr * f.gp.item_bias[p];
+      if (!gb_ready) {
+        float gbp = 0.f;
+#pragma unroll
+        for (int j = 0; j < kFusedSlots; ++j) {
+          asm volatile("" : "+v"(gbz[j]));  // keep the reduction (and its vmcnt wait) down here
+          gbp += lane + kWave * j < f.n_prev_partials ? gbz[j] : 0.f;
+        }
+        gb = apply ? fused_eff<KIND>(gb_w, gb_g + wave_sum(gbp), gb_m, gb_v, f.s, step_size, bc2_sqrt)
+                   : gb_w;
+        gb_ready = true;
+      }
+      float bu = wbu, bn = wbn;
+      bp = wbp;
+      if (apply) {
+        bu = fused_eff<KIND>(wbu, gbu, mbu, vbu, f.s, step_size, bc2_sqrt);
+        bn = fused_eff<KIND>(wbn, gbn, mbn, vbn, f.s, step_size, bc2_sqrt);
+        bp = fused_eff<KIND>(wbp, gbp_, mbp, vbp, f.s, step_size, bc2_sqrt);
+      }
       const float yp = sigmoid_f32(((dp + bu) + bp) + gb);
       const float yn = sigmoid_f32(((dn + bu) + bn) + gb);
       float sig_neg_x;
@@ -455,11 +590,13 @@ __global__ __launch_bounds__(kAggBlock) void mf_bce_grad_kernel(
   const int wv = wave_in_block();
   const int D = w.dim;
   const int ld = D + 1;
-  const float gb = *w.global_bias;
+  const float gb = load_scalar_param(w.global_bias);
   const float rr = 2.f * reg_coef * inv_batch;
 
   float loss_acc = 0.f, reg_acc = 0.f, gb_acc = 0.f;
-  if (blockIdx.x == 0 && threadIdx.x == 0) advance_step(stats);
+  const bool stepper = blockIdx.x == 0 && threadIdx.x == 0;
+  StepState step_state{};
+  if (stepper) step_state = step_load(stats);
 
   for (int64_t base = static_cast<int64_t>(blockIdx.x) * kAggWaves; base < batch;
        base += static_cast<int64_t>(gridDim.x) * kAggWaves) {
@@ -570,6 +707,7 @@ __global__ __launch_bounds__(kAggBlock) void mf_bce_grad_kernel(
     }
   }
   publish_partials<kAggWaves>(loss_acc, reg_acc, gb_acc, inv_batch, scratch);
+  if (stepper) step_store_advanced(stats, step_state);
 }
 
 // scores[k] = sigmoid(<U[u], I[i]> + bu + bi + g)   (MF.predict, mf.py:57-70)
@@ -582,7 +720,7 @@ __global__ __launch_bounds__(kBlock) void mf_predict_kernel(hiprec_mf_tables w,
   const int D = w.dim;
   const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
   const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
-  const float gb = *w.global_bias;
+  const float gb = load_scalar_param(w.global_bias);
   for (int64_t t = wave0; t < n; t += n_waves) {
     const int64_t u = users[t], i = items[t];
     const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(w.n_users);
@@ -783,21 +921,43 @@ extern "C" int hiprec_mf_sgd_rows(const hiprec_mf_tables* w, const hiprec_mf_tab
   return 0;
 }
 
-// One epoch of BPR-MF with plain SGD, ONE kernel per step (see mf_bpr_sgd_fused_kernel).
-// w_flat[2] / g_flat[3] / scratch[2] are caller-owned; w_flat[0] holds the weights on entry, all g
-// buffers and both scratch blocks are zero.  On return the weights are in w_flat[*final_index] and
-// every g buffer is zero again.  users/pos/neg are the epoch laid out in visiting order.
-extern "C" int hiprec_mf_bpr_epoch_sgd_fused(float* const* w_flat, float* const* g_flat,
-                                             void* const* scratch2, int64_t n_users,
-                                             int64_t n_items, int32_t dim, const int64_t* users,
-                                             const int64_t* pos, const int64_t* neg,
-                                             int64_t n_triples, int64_t batch, float reg_coef,
-                                             double lr, hiprec_stats* stats, int32_t* final_index,
-                                             void* stream) {
+// One epoch of BPR-MF with ONE kernel per step (see mf_bpr_fused_kernel).
+// w_flat[2] / g_flat[3] / scratch[2] (and m_flat[2] for Adam, v_flat[2] for Adam and RMSprop) are
+// caller-owned; index 0 of w/m/v holds the state on entry, all g buffers and both scratch blocks are
+// zero.  On return the state is in w_flat/m_flat/v_flat[*final_index] and every g buffer is zero
+// again.  users/pos/neg are the epoch laid out in visiting order.
+template <int KIND>
+static int launch_fused(int dim, int grid, size_t lds, hipStream_t st, const hiprec_mf_tables& w,
+                        const hiprec_mf_tables& g, const FusedOpt& f, const int64_t* uu,
+                        const int64_t* pp, const int64_t* nn, int64_t b, float inv_b, float reg_coef,
+                        hiprec_stats* stats, Scratch* sc) {
+  if (dim <= 64)
+    mf_bpr_fused_kernel<1, KIND><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+  else if (dim <= 128)
+    mf_bpr_fused_kernel<2, KIND><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+  else
+    mf_bpr_fused_kernel<4, KIND><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_mf_bpr_epoch_fused(int kind, float* const* w_flat, float* const* g_flat,
+                                         float* const* m_flat, float* const* v_flat,
+                                         void* const* scratch2, int64_t n_users, int64_t n_items,
+                                         int32_t dim, const int64_t* users, const int64_t* pos,
+                                         const int64_t* neg, int64_t n_triples, int64_t batch,
+                                         float reg_coef, double lr, double beta1, double beta2,
+                                         double eps, hiprec_stats* stats, int32_t* final_index,
+                                         void* stream) {
+  HIPREC_REQUIRE(kind == HIPREC_OPT_SGD || kind == HIPREC_OPT_ADAM || kind == HIPREC_OPT_RMSPROP,
+                 "unknown optimizer kind %d", kind);
   HIPREC_REQUIRE(w_flat && g_flat && scratch2 && final_index && stats, "NULL pointer");
   HIPREC_REQUIRE(w_flat[0] && w_flat[1] && g_flat[0] && g_flat[1] && g_flat[2] && scratch2[0] &&
                      scratch2[1], "NULL buffer");
-  HIPREC_REQUIRE(n_users > 0 && n_items > 0 && dim > 0 && dim <= 256, "fused SGD needs dim <= 256");
+  const bool has_m = kind == HIPREC_OPT_ADAM, has_v = kind != HIPREC_OPT_SGD;
+  HIPREC_REQUIRE(!has_m || (m_flat && m_flat[0] && m_flat[1]), "Adam needs m_flat[2]");
+  HIPREC_REQUIRE(!has_v || (v_flat && v_flat[0] && v_flat[1]), "Adam/RMSprop need v_flat[2]");
+  HIPREC_REQUIRE(n_users > 0 && n_items > 0 && dim > 0 && dim <= 256, "fused step needs dim <= 256");
   HIPREC_REQUIRE(n_triples >= 0 && batch > 0, "bad n_triples/batch");
   HIPREC_REQUIRE(n_triples == 0 || (users && pos && neg), "NULL index arrays");
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -805,10 +965,10 @@ extern "C" int hiprec_mf_bpr_epoch_sgd_fused(float* const* w_flat, float* const*
   auto tables = [&](float* flat) {
     hiprec_mf_tables t;
     t.user_emb = flat;
-    t.item_emb = flat + n_users * dim;
-    t.user_bias = t.item_emb + n_items * dim;
-    t.item_bias = t.user_bias + n_users;
-    t.global_bias = t.item_bias + n_items;
+    t.item_emb = flat ? flat + n_users * dim : nullptr;
+    t.user_bias = flat ? t.item_emb + n_items * dim : nullptr;
+    t.item_bias = flat ? t.user_bias + n_users : nullptr;
+    t.global_bias = flat ? t.item_bias + n_items : nullptr;
     t.n_users = n_users;
     t.n_items = n_items;
     t.dim = dim;
@@ -819,21 +979,38 @@ extern "C" int hiprec_mf_bpr_epoch_sgd_fused(float* const* w_flat, float* const*
   const size_t lds = agg_lds_bytes(dim);
   const int n_sweep = static_cast<int>(std::min<int64_t>(256, (n_flat / 4 + kAggBlock - 1) / kAggBlock));
   const int64_t n_steps = (n_triples + batch - 1) / batch;
+  const OptScalars sc_opt{lr,
+                          static_cast<float>(lr),
+                          static_cast<float>(beta2),
+                          static_cast<float>(1.0 - beta1),
+                          static_cast<float>(1.0 - beta2),
+                          static_cast<float>(eps)};
   for (int64_t k = 0; k <= n_steps; ++k) {  // step n_steps is the sweep-only flush
     const int64_t off = k * batch;
     const int64_t b = k < n_steps ? std::min<int64_t>(batch, n_triples - off) : 0;
-    FusedSgd f;
+    FusedOpt f;
     float* w_read = w_flat[k & 1];
     float* g_prev = g_flat[(k + 2) % 3];
     float* g_cur = g_flat[k % 3];
+    float* m_read = has_m ? m_flat[k & 1] : nullptr;
+    float* v_read = has_v ? v_flat[k & 1] : nullptr;
     f.gp = tables(g_prev);
+    f.mp = tables(m_read);
+    f.vp = tables(v_read);
     f.w_read = w_read;
-    f.w_write = w_flat[(k + 1) & 1];
     f.g_prev = g_prev;
+    f.m_read = m_read;
+    f.v_read = v_read;
+    f.w_write = w_flat[(k + 1) & 1];
+    f.m_write = has_m ? m_flat[(k + 1) & 1] : nullptr;
+    f.v_write = has_v ? v_flat[(k + 1) & 1] : nullptr;
     f.g_zero = g_flat[(k + 1) % 3];
     f.n_flat = n_flat;
-    f.lr = static_cast<float>(lr);
-    f.n_gather_blocks = b > 0 ? agg_grid(b) : 0;
+    f.s = sc_opt;
+    f.n_gather_blocks = b > 0 ? std::min(agg_grid(b), kFusedMaxGather) : 0;
+    f.n_prev_partials =
+        k > 0 ? std::min(agg_grid(std::min<int64_t>(batch, n_triples - (k - 1) * batch)), kFusedMaxGather) : 0;
+    f.apply_prev = k > 0 ? 1 : 0;
     f.scratch_prev = static_cast<const Scratch*>(scratch2[(k + 1) & 1]);
     Scratch* sc = static_cast<Scratch*>(scratch2[k & 1]);
     const hiprec_mf_tables w = tables(w_read), g = tables(g_cur);
@@ -842,13 +1019,14 @@ extern "C" int hiprec_mf_bpr_epoch_sgd_fused(float* const* w_flat, float* const*
     const int64_t* uu = users ? users + off : nullptr;
     const int64_t* pp = pos ? pos + off : nullptr;
     const int64_t* nn = neg ? neg + off : nullptr;
-    if (dim <= 64)
-      mf_bpr_sgd_fused_kernel<1><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
-    else if (dim <= 128)
-      mf_bpr_sgd_fused_kernel<2><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    int rc;
+    if (kind == HIPREC_OPT_SGD)
+      rc = launch_fused<HIPREC_OPT_SGD>(dim, grid, lds, st, w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    else if (kind == HIPREC_OPT_ADAM)
+      rc = launch_fused<HIPREC_OPT_ADAM>(dim, grid, lds, st, w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
     else
-      mf_bpr_sgd_fused_kernel<4><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
-    HIPREC_TRY(hipGetLastError());
+      rc = launch_fused<HIPREC_OPT_RMSPROP>(dim, grid, lds, st, w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    if (rc) return rc;
     if (b == 0) {
       // the flush wrote no partials of its own: mark its scratch block empty for the next epoch
       HIPREC_TRY(hipMemsetAsync(sc, 0, 16, st));
@@ -859,4 +1037,17 @@ extern "C" int hiprec_mf_bpr_epoch_sgd_fused(float* const* w_flat, float* const*
   HIPREC_TRY(hipMemsetAsync(scratch2[(n_steps + 1) & 1], 0, 16, st));
   *final_index = static_cast<int32_t>((n_steps + 1) & 1);
   return 0;
+}
+
+// The plain-SGD spelling of the above, kept for callers of the first ABI revision.
+extern "C" int hiprec_mf_bpr_epoch_sgd_fused(float* const* w_flat, float* const* g_flat,
+                                             void* const* scratch2, int64_t n_users,
+                                             int64_t n_items, int32_t dim, const int64_t* users,
+                                             const int64_t* pos, const int64_t* neg,
+                                             int64_t n_triples, int64_t batch, float reg_coef,
+                                             double lr, hiprec_stats* stats, int32_t* final_index,
+                                             void* stream) {
+  return hiprec_mf_bpr_epoch_fused(HIPREC_OPT_SGD, w_flat, g_flat, nullptr, nullptr, scratch2, n_users,
+                                   n_items, dim, users, pos, neg, n_triples, batch, reg_coef, lr, 0.0,
+                                   0.0, 0.0, stats, final_index, stream);
 }

@@ -15,31 +15,6 @@
 
 namespace hiprec {
 
-// Scalars exactly as the reference's python doubles become fp32 inside the ATen ops:
-// (float)lr, (float)beta2, (float)(1 - beta1), (float)(1 - beta2), (float)eps.
-struct OptScalars {
-  double lr_d;
-  float lr, beta2, omb1, omb2, eps;
-};
-
-template <int KIND>
-__device__ __forceinline__ void opt_update(float& w, float& g, float& m, float& v,
-                                           const OptScalars s, float step_size, float bc2_sqrt) {
-  if constexpr (KIND == HIPREC_OPT_SGD) {
-    w = w - s.lr * g;  // param.add_(grad, alpha=-lr)
-  } else if constexpr (KIND == HIPREC_OPT_ADAM) {
-    m = m + s.omb1 * (g - m);                       // exp_avg.lerp_(grad, 1 - beta1)
-    v = v * s.beta2 + (s.omb2 * g) * g;               // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
-    const float denom = sqrtf(v) / bc2_sqrt + s.eps;  // (sqrt(v)/sqrt(bc2)).add_(eps)
-    w = w + (-step_size * m) / denom;                 // param.addcdiv_(m, denom, value=-step_size)
-  } else {
-    v = v * s.beta2 + (s.omb2 * g) * g;               // square_avg.mul_(alpha).addcmul_(g,g,1-alpha)
-    const float avg = sqrtf(v) + s.eps;               // square_avg.sqrt().add_(eps)
-    w = w + (-s.lr * g) / avg;                        // param.addcdiv_(grad, avg, value=-lr)
-  }
-  g = 0.f;
-}
-
 template <int KIND>
 __global__ __launch_bounds__(kBlock) void opt_dense_kernel(float* __restrict__ w,
                                                            float* __restrict__ g,
@@ -48,15 +23,8 @@ __global__ __launch_bounds__(kBlock) void opt_dense_kernel(float* __restrict__ w
                                                            OptScalars s, hiprec_stats* stats,
                                                            const Scratch* scratch,
                                                            int64_t scalar_index) {
-  float step_size = s.lr, bc2_sqrt = 1.f;
-  if constexpr (KIND == HIPREC_OPT_ADAM) {
-    // bias_correction1 = 1 - beta1**t ; step_size = lr / bc1 ; bc2_sqrt = sqrt(1 - beta2**t)
-    // (python doubles in torch, then rounded to fp32 when they enter the tensor ops)
-    const double bc1 = 1.0 - stats->beta1_pow;
-    const double bc2 = 1.0 - stats->beta2_pow;
-    step_size = static_cast<float>(s.lr_d / bc1);
-    bc2_sqrt = static_cast<float>(sqrt(bc2));
-  }
+  float step_size, bc2_sqrt;
+  step_scalars<KIND>(s, stats, &step_size, &bc2_sqrt);
   const int64_t tid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   const int64_t n4 = n >> 2;

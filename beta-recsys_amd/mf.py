@@ -355,7 +355,7 @@ class MFEngine(ModelEngine):
     ROWS_SGD_MIN_BYTES = 64 << 20
     SORT_MIN_BATCH = 256
     presorted = False  # set when the caller already grouped equal items (sort_within_batches)
-    fused_sgd = True   # plain SGD epochs: one kernel per step (hiprec_mf_bpr_epoch_sgd_fused)
+    fused_step = True  # resident BPR epochs: one kernel per step (hiprec_mf_bpr_epoch_fused)
 
     def __init__(self, config):
         self.config = config
@@ -601,32 +601,47 @@ class MFEngine(ModelEngine):
             return None
         return self._resident_triples(train_loader)
 
-    def _fused_sgd_ok(self, perm):
-        """Plain SGD on cache-sized tables takes the one-kernel-per-step epoch driver."""
-        return (self.fused_sgd and self.optimizer.name == "sgd" and not self._rows_sgd
-                and self.loss == "bpr" and perm is None and self.model.emb_dim <= 256)
+    def _fused_ok(self, perm):
+        """Cache-sized tables take the one-kernel-per-step epoch driver (any of the three optimizers)."""
+        return (self.fused_step and not self._rows_sgd and self.loss == "bpr" and perm is None
+                and self.model.emb_dim <= 256)
 
-    def _run_fused_sgd_epoch(self, lib, users, pos, neg, n_run, bs):
-        m = self.model
+    def _run_fused_epoch(self, lib, users, pos, neg, n_run, bs):
+        """hiprec_mf_bpr_epoch_fused: W (and Adam/RMSprop moments) ping-pong between the engine's
+        buffers and one alternate each; whatever ends up in the alternates is copied back."""
+        m, opt = self.model, self.optimizer
         dev = m.flat.device
         if getattr(self, "_fused_bufs", None) is None or self._fused_bufs["dev"] != dev:
             self._fused_bufs = {
                 "dev": dev, "w_alt": torch.empty_like(m.flat),
+                "m_alt": torch.empty_like(m.flat) if opt.exp_avg is not None else None,
+                "v_alt": torch.empty_like(m.flat) if opt.exp_avg_sq is not None else None,
                 "g": [self._g_flat, torch.zeros_like(m.flat), torch.zeros_like(m.flat)],
                 "scratch": [torch.zeros_like(self._scratch), torch.zeros_like(self._scratch)],
             }
         fb = self._fused_bufs
         fb["g"][0] = self._g_flat
-        w_arr = (ctypes.c_void_p * 2)(m.flat.data_ptr(), fb["w_alt"].data_ptr())
+
+        def pair(primary, alt):
+            return None if primary is None else (ctypes.c_void_p * 2)(primary.data_ptr(), alt.data_ptr())
+
+        w_arr = pair(m.flat, fb["w_alt"])
+        m_arr = pair(opt.exp_avg, fb["m_alt"])
+        v_arr = pair(opt.exp_avg_sq, fb["v_alt"])
         g_arr = (ctypes.c_void_p * 3)(*(t.data_ptr() for t in fb["g"]))
         s_arr = (ctypes.c_void_p * 2)(*(t.data_ptr() for t in fb["scratch"]))
         final = ctypes.c_int32(-1)
-        _lib.check(lib.hiprec_mf_bpr_epoch_sgd_fused(
-            w_arr, g_arr, s_arr, m.n_users, m.n_items, m.emb_dim, _lib.ptr(users), _lib.ptr(pos),
-            _lib.ptr(neg), n_run, bs, float(self.reg), self.optimizer.lr, _lib.ptr(self._stats),
-            ctypes.byref(final), _lib.stream_ptr(dev)))
-        if final.value == 1:  # the weights ended up in the alternate buffer
+        _lib.check(lib.hiprec_mf_bpr_epoch_fused(
+            opt.kind, w_arr, g_arr, m_arr, v_arr, s_arr, m.n_users, m.n_items, m.emb_dim,
+            _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), n_run, bs, float(self.reg), opt.lr,
+            opt.beta1, opt.beta2, opt.eps, _lib.ptr(self._stats), ctypes.byref(final),
+            _lib.stream_ptr(dev)))
+        if final.value == 1:  # the state ended up in the alternate buffers
             m.flat.copy_(fb["w_alt"])
+            if opt.exp_avg is not None:
+                opt.exp_avg.copy_(fb["m_alt"])
+            if opt.exp_avg_sq is not None:
+                opt.exp_avg_sq.copy_(fb["v_alt"])
 
     def run_prepared_epoch(self, prepared, sync=True):
         """Enqueue every step of a prepared epoch (hiprec_mf_bpr_epoch, or the fused one-kernel-per-
@@ -636,8 +651,8 @@ class MFEngine(ModelEngine):
         users, pos, neg, perm, bs = prepared
         n = users.numel()
         n_run = n - 1 if n % bs == 1 else n  # Q4: a trailing batch of one raises (below)
-        if self._fused_sgd_ok(perm):
-            self._run_fused_sgd_epoch(lib, users, pos, neg, n_run, bs)
+        if self._fused_ok(perm):
+            self._run_fused_epoch(lib, users, pos, neg, n_run, bs)
             if not sync:
                 return None
             st = self._sync_stats()

@@ -213,16 +213,28 @@ int hiprec_mf_bce_epoch(const hiprec_mf_tables* w, const hiprec_mf_tables* g, co
                         int32_t* item_stamp, int32_t first_stamp, hiprec_stats* stats,
                         void* scratch, size_t scratch_bytes, void* stream);
 
-/* ---- one epoch of BPR-MF with PLAIN SGD, one kernel per step.  SGD (momentum 0,
- * torch_engine.py:26-29) is linear, so the update of step k-1 rides inside the gradient kernel of
- * step k: gather blocks read W_a - lr*G_prev on the fly (nothing they read is written by the
- * launch, so every gradient of the batch still comes from the pre-step weights, as in mf.py:101-118)
- * while the other blocks of the same grid write W_b = W_a - lr*G_prev for the whole buffer.
- * w_flat[2], g_flat[3] (flat layout of hiprec_mf_tables: user_emb|item_emb|user_bias|item_bias|
- * global_bias) and scratch2[2] are caller-owned; on entry the weights are in w_flat[0] and all g /
- * scratch buffers are zero; on return the weights are in w_flat[*final_index] and every g / scratch
- * header is zero again.  users/pos/neg hold the epoch in visiting order (n_triples, last batch
- * short).  Results are bit-identical to hiprec_mf_bpr_epoch with the dense SGD step. */
+/* ---- one epoch of BPR-MF, ONE kernel per step (mf.py:121-139 around mf.py:92-119 with
+ * torch_engine.py:23-39's optimizer).  torch's SGD / Adam / RMSprop updates are elementwise
+ * functions of (w, g, m, v), so the update of step k-1 rides inside the gradient kernel of step k:
+ * gather blocks evaluate update(W_a, G_prev, M_a, V_a) on the fly for the rows they read (nothing
+ * they read is written by the launch, so every gradient of the batch still comes from the pre-step
+ * weights, as in mf.py:101-118) while the other blocks of the same grid write W_b, M_b, V_b for the
+ * whole buffer.  kind = HIPREC_OPT_*.  w_flat[2], g_flat[3], m_flat[2] (Adam), v_flat[2] (Adam,
+ * RMSprop; NULL otherwise) are flat buffers laid out like hiprec_mf_tables (user_emb|item_emb|
+ * user_bias|item_bias|global_bias), scratch2[2] two scratch blocks; all caller-owned.  On entry the
+ * state is in w/m/v_flat[0] and all g / scratch buffers are zero; on return it is in
+ * w/m/v_flat[*final_index] and every g buffer / scratch header is zero again.  users/pos/neg hold
+ * the epoch in visiting order (n_triples, last batch short).  The arithmetic per element is that
+ * of hiprec_opt_dense_step, so results equal hiprec_mf_bpr_epoch's up to the order of the atomic
+ * gradient sums. */
+int hiprec_mf_bpr_epoch_fused(int kind, float* const* w_flat, float* const* g_flat,
+                              float* const* m_flat, float* const* v_flat, void* const* scratch2,
+                              int64_t n_users, int64_t n_items, int32_t dim, const int64_t* users,
+                              const int64_t* pos, const int64_t* neg, int64_t n_triples,
+                              int64_t batch, float reg_coef, double lr, double beta1, double beta2,
+                              double eps, hiprec_stats* stats, int32_t* final_index, void* stream);
+
+/* The plain-SGD spelling of hiprec_mf_bpr_epoch_fused (first ABI revision). */
 int hiprec_mf_bpr_epoch_sgd_fused(float* const* w_flat, float* const* g_flat, void* const* scratch2,
                                   int64_t n_users, int64_t n_items, int32_t dim,
                                   const int64_t* users, const int64_t* pos, const int64_t* neg,

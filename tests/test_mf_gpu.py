@@ -416,11 +416,12 @@ def test_full_size_epoch_resident_equals_per_batch(hip_device):
     assert len(batcher) == 4
 
 
-def test_fused_sgd_epoch_is_bit_identical_to_two_kernel_epoch(hip_device):
-    """The one-kernel-per-step SGD epoch (update of step k-1 applied on the fly inside the gradient
-    kernel of step k) evaluates the same expressions as grad kernel + dense SGD sweep: the weights
-    agree to fp32 summation order of the atomics, the untouched rows bit for bit, and two epochs in
-    a row leave every gradient buffer clean."""
+@pytest.mark.parametrize("optimizer", ["sgd", "adam", "rmsprop"])
+def test_fused_epoch_matches_two_kernel_epoch(hip_device, optimizer):
+    """The one-kernel-per-step epoch (update of step k-1 applied on the fly inside the gradient
+    kernel of step k) evaluates the same expressions as grad kernel + dense optimizer sweep: the
+    weights and moments agree to fp32 summation order of the atomics, for SGD the untouched rows bit
+    for bit, and two epochs in a row leave every gradient buffer clean."""
     import beta_recsys_amd as hp
 
     rng = np.random.default_rng(2)
@@ -431,8 +432,8 @@ def test_fused_sgd_epoch_is_bit_identical_to_two_kernel_epoch(hip_device):
     w0 = onp.init_params(C2["U"], C2["I"], C2["D"], seed=11)
     out = {}
     for fused in (True, False):
-        eng = make_engine(C2["U"], C2["I"], C2["D"], "sgd", "bpr", 0.05, C2["B"])
-        eng.fused_sgd = fused
+        eng = make_engine(C2["U"], C2["I"], C2["D"], optimizer, "bpr", 0.05, C2["B"])
+        eng.fused_step = fused
         load_weights(eng, w0)
         batcher = hp.DeviceTripleBatcher(users, pos, neg, C2["B"], generator=torch.Generator().manual_seed(5))
         for epoch in range(2):
@@ -445,15 +446,28 @@ def test_fused_sgd_epoch_is_bit_identical_to_two_kernel_epoch(hip_device):
                 assert float(t.abs().max()) == 0.0
         st = eng.epoch_stats()
         assert st.step == 12
-        out[fused] = (get_weights(eng), dict((t, v) for t, v, e in eng.writer.scalars if e == 1), st.loss)
-    (wa, sa, la), (wb, sb, lb) = out[True], out[False]
+        out[fused] = (get_weights(eng), dict((t, v) for t, v, e in eng.writer.scalars if e == 1), st.loss,
+                      {n: (None if getattr(eng.optimizer, n) is None else getattr(eng.optimizer, n).cpu().numpy().copy())
+                       for n in ("exp_avg", "exp_avg_sq")})
+    (wa, sa, la, oa), (wb, sb, lb, ob) = out[True], out[False]
+    # The moments are linear / quadratic in the gradients: tight.  Adam / RMSprop weights divide by
+    # sqrt(v)+eps, so an element whose gradient is of the order of its own rounding noise moves by up
+    # to lr per step in either direction (see helpers.optimizer_band): 12 steps of lr 0.05 there.
+    for name in ("exp_avg", "exp_avg_sq"):
+        if oa[name] is not None:
+            assert_tensor_close(oa[name], ob[name], 1e-5, f"fused vs two-kernel {name}")
+    tol = 1e-6 if optimizer == "sgd" else 2e-3
     for k in KEYS:
-        assert_tensor_close(wa[k], wb[k], 1e-6, f"fused vs two-kernel {k}")
+        assert_tensor_close(wa[k], wb[k], tol, f"fused vs two-kernel {k}")
+        if optimizer != "sgd":   # ... and those ill-conditioned elements are rare
+            close = np.abs(wa[k] - wb[k]) <= 1e-5 * max(np.abs(wb[k]).max(), 1e-3)
+            assert close.mean() > 0.99, f"{k}: only {close.mean():.4f} of the elements agree to 1e-5"
     assert_scalar_close(sa["model/loss"], sb["model/loss"], 1e-6, "epoch loss sum")
     assert_scalar_close(sa["model/regularizer"], sb["model/regularizer"], 1e-6, "epoch reg sum")
     assert_scalar_close(la, lb, 1e-5, "last loss")
-    never = np.setdiff1d(np.arange(C2["U"]), users.cpu().numpy())
-    assert np.array_equal(wa["user_emb.weight"][never], w0["user_emb.weight"][never])
+    if optimizer == "sgd":
+        never = np.setdiff1d(np.arange(C2["U"]), users.cpu().numpy())
+        assert np.array_equal(wa["user_emb.weight"][never], w0["user_emb.weight"][never])
 
 
 def test_bce_epoch_through_generic_loader(hip_device):
