@@ -105,7 +105,7 @@ def kernel_timing(eng, prepared, n_launch=200):
     return back_to_back, float(per[len(per) // 2]) * 1e-3  # seconds
 
 
-def cpu_baseline(budget_s=12.0):
+def cpu_baseline(optimizer="adam", budget_s=12.0):
     """The reference's CPU path (PyTorch ops, dense autograd, torch.optim) on this box's host
     cores, timed on a bounded sample of the same workload: oracle/torch_port.py, kind "port".
     ATen's intra-op threading hurts these small ops on many-core hosts, so a few thread counts are
@@ -123,7 +123,7 @@ def cpu_baseline(budget_s=12.0):
     for nt in candidates:
         torch.set_num_threads(nt)
         torch.manual_seed(0)
-        port = TorchMFPort(onp.init_params(U, I, D, seed=0), "sgd", LR, "bpr")
+        port = TorchMFPort(onp.init_params(U, I, D, seed=0), optimizer, LR, "bpr")
         for i in range(3):
             port.step(batches[i])
         steps, t0 = 0, time.perf_counter()
@@ -147,7 +147,7 @@ def cpu_baseline(budget_s=12.0):
             return users.size(0)
 
     torch.set_num_threads(nt)
-    port = TorchMFPort(onp.init_params(U, I, D, seed=0), "sgd", LR, "bpr")
+    port = TorchMFPort(onp.init_params(U, I, D, seed=0), optimizer, LR, "bpr")
     e2e_steps, t0 = 0, time.perf_counter()
     for batch in DataLoader(_Pairs(), batch_size=B, shuffle=True):
         port.step(batch)
@@ -158,7 +158,7 @@ def cpu_baseline(budget_s=12.0):
     torch.set_num_threads(all_threads)
     return {"value": rate, "unit": "triples/s", "cores": nt, "kind": "port",
             "end_to_end_dataloader_value": e2e_rate,
-            "sample": f"{steps} sgd steps of batch {B} (same C2 workload) in {dt:.1f} s with {nt} ATen "
+            "sample": f"{steps} {optimizer} steps of batch {B} (same C2 workload) in {dt:.1f} s with {nt} ATen "
                       f"threads (best of {candidates}); PyTorch-CPU op sequence of the reference; host has "
                       f"{os.cpu_count()} logical cpus"}
 
@@ -340,7 +340,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adam", "rmsprop"])
+    ap.add_argument("--optimizer", default="adam", choices=["sgd", "adam", "rmsprop"],
+                    help="mf: adam is the reference's own default (configs/mf_default.json); sgd / rmsprop are the other two torch_engine.py:23-39 builds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--two-kernel", action="store_true",
                     help="mf: gradient kernel + dense optimizer sweep per step instead of the fused one-kernel step")
@@ -528,7 +529,7 @@ def main():
             },
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.optimizer)
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()
