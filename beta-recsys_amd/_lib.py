@@ -15,6 +15,7 @@ OPT_SGD, OPT_ADAM, OPT_RMSPROP = 0, 1, 2
 OPT_KINDS = {"sgd": OPT_SGD, "adam": OPT_ADAM, "rmsprop": OPT_RMSPROP}
 
 STATUS_USER_OOB, STATUS_ITEM_OOB, STATUS_ROW_OOB, STATUS_ROUTE_OVERFLOW = 1, 2, 4, 8
+STATUS_NEG_EXHAUSTED = 16
 
 
 class MfTables(Structure):
@@ -140,6 +141,10 @@ SIGNATURES = {
         [POINTER(LightGcnPlan), _P, c_float, _P, _P, _P, c_int64, c_float, _P, _P, c_size_t, _P],
     ),
     "hiprec_random_permutation": (c_int, [_P, c_int64, ctypes.c_uint64, _P]),
+    "hiprec_sample_negatives": (
+        c_int,
+        [_P, _P, c_int64, c_int64, _P, c_int64, c_int32, ctypes.c_uint64, _P, _P, _P],
+    ),
     "hiprec_rank_metrics_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hiprec_rank_metrics": (
         c_int,

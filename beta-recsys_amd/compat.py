@@ -74,3 +74,43 @@ def uninstall_eval():
     ee = sys.modules.get("beta_rec.core.eval_engine")
     if ee is not None and getattr(ee.evaluate, "_hiprec", False):
         ee.evaluate = ee.evaluate._reference
+
+
+_DATA_METHODS = ("instance_bpr_loader", "instance_bce_loader", "instance_mul_neg_loader")
+
+
+def install_data():
+    """Route ``BaseData.instance_{bpr,bce,mul_neg}_loader`` (data/base_data.py:182-288) through the
+    device-side sampler + batchers of :mod:`beta_recsys_amd.data`.  Same call signatures
+    (``data.instance_bpr_loader(batch_size, device)`` ...); the returned loaders are device batchers
+    that the engines of this package run resident."""
+    import importlib
+
+    from . import data as hip_data
+
+    base = importlib.import_module("beta_rec.data.base_data").BaseData
+    for name in _DATA_METHODS:
+        current = getattr(base, name)
+        if getattr(current, "_hiprec", False):
+            continue
+        hip_fn = getattr(hip_data, name)
+
+        def method(self, *args, _fn=hip_fn, **kwargs):
+            return _fn(self, *args, **kwargs)
+
+        method._hiprec = True
+        method._reference = current
+        method.__name__ = name
+        method.__doc__ = hip_fn.__doc__
+        setattr(base, name, method)
+    return base
+
+
+def uninstall_data():
+    mod = sys.modules.get("beta_rec.data.base_data")
+    if mod is None:
+        return
+    for name in _DATA_METHODS:
+        current = getattr(mod.BaseData, name, None)
+        if getattr(current, "_hiprec", False):
+            setattr(mod.BaseData, name, current._reference)

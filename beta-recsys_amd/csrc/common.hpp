@@ -60,7 +60,51 @@ inline int grid_for_threads(int64_t n_threads) {
   return static_cast<int>(blocks);
 }
 
+// Width of one Feistel half for a bijection of [0, n): the smallest even-width power of two >= n.
+__host__ __device__ inline int feistel_half_bits(uint64_t n) {
+  int bits = 2;
+  while (bits < 62 && (1ull << bits) < n) ++bits;
+  return (bits + 1) / 2;
+}
+
 #if defined(__HIPCC__)
+
+// ---- counter-based randomness (stateless, replayable, restated bit for bit in oracle/sampler_numpy.py)
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ uint32_t feistel_round(uint32_t x, uint32_t key) {
+  x = (x ^ key) * 0x9E3779B1u;
+  x ^= x >> 15;
+  x *= 0x85EBCA77u;
+  x ^= x >> 13;
+  return x;
+}
+
+// P_seed(i): a bijection of [0, n).  6-round Feistel network over 2^(2*half_bits) >= n with cycle
+// walking (values that land outside [0, n) are encrypted again).
+__device__ __forceinline__ uint64_t feistel_permute(uint64_t i, uint64_t n, int half_bits, uint64_t seed) {
+  const uint64_t mask = (1ull << half_bits) - 1ull;
+  uint64_t x = i;
+  do {
+    uint32_t l = static_cast<uint32_t>(x >> half_bits), r = static_cast<uint32_t>(x & mask);
+#pragma unroll
+    for (int round = 0; round < 6; ++round) {
+      const uint32_t k = static_cast<uint32_t>(seed >> (8 * (round & 3))) + 0x632BE5ABu * (round + 1) +
+                         static_cast<uint32_t>(seed >> 32);
+      const uint32_t f = feistel_round(r, k) & static_cast<uint32_t>(mask);
+      const uint32_t nl = r;
+      r = l ^ f;
+      l = nl;
+    }
+    x = (static_cast<uint64_t>(l) << half_bits) | r;
+  } while (x >= n);
+  return x;
+}
 
 // ---- wave64 all-reduce (sum) on the VALU: 4 DPP steps inside each 16-lane row, then the four row
 // totals are read back through SGPRs.  No LDS traffic, result uniform across the wave.

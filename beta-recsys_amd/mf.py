@@ -92,6 +92,8 @@ def raise_on_status(status):
             which.append("item")
         if status & _lib.STATUS_ROW_OOB:
             which.append("row")
+        if status & _lib.STATUS_NEG_EXHAUSTED:
+            raise ValueError("Sample larger than population or is negative")  # random.sample's message
         if status & _lib.STATUS_ROUTE_OVERFLOW:
             raise RuntimeError(
                 "a fixed-capacity all-to-all bucket overflowed: raise the sharded engine's "

@@ -43,6 +43,7 @@ extern "C" {
 #define HIPREC_STATUS_ITEM_OOB 2u
 #define HIPREC_STATUS_ROW_OOB 4u
 #define HIPREC_STATUS_ROUTE_OVERFLOW 8u /* a fixed-capacity all-to-all bucket was too small */
+#define HIPREC_STATUS_NEG_EXHAUSTED 16u /* a user has fewer untouched items than negatives were asked for */
 
 /* optimizer kinds, beta_rec/models/torch_engine.py:23-39 (only `lr` is ever set there) */
 #define HIPREC_OPT_SGD 0
@@ -347,6 +348,21 @@ int hiprec_lightgcn_grad(const hiprec_lightgcn_plan* plan, const uint8_t* keep, 
                          const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t batch,
                          float inv_batch, hiprec_stats* stats, void* scratch, size_t scratch_bytes,
                          void* stream);
+
+/* ================= Negative sampling ("next": the data step in front of the path) ====
+ * data/base_data.py:218-253 instance_bpr_loader (k = 1), :182-216 instance_bce_loader and :254-288
+ * instance_mul_neg_loader (k = num_negative): for every row of the training frame, k DISTINCT items
+ * drawn uniformly from the items of the pool (ids 0..n_items-1, base_data.py:48) the row's user never
+ * interacted with — random.sample(list(set(item_id_pool) - positive_items), k).
+ * user_ptr[n_users+1] / pos_sorted: CSR of each user's positive items, ascending and unique.
+ * users[n_rows]: the user of each training row.  out[n_rows * k], row-major.  The draw is a pure
+ * function of (seed, row, j): out[row*k + j] = the r-th item not in the user's list, r = element j of
+ * the Feistel permutation of [0, n_items - deg) keyed by splitmix64(seed ^ splitmix64(row))
+ * (oracle/sampler_numpy.py restates it bit for bit).  A user with fewer than k untouched items sets
+ * HIPREC_STATUS_NEG_EXHAUSTED (python raises ValueError there) and yields -1. */
+int hiprec_sample_negatives(const int64_t* user_ptr, const int64_t* pos_sorted, int64_t n_users,
+                            int64_t n_items, const int64_t* users, int64_t n_rows, int32_t k,
+                            uint64_t seed, int64_t* out, hiprec_stats* stats, void* stream);
 
 /* ================= Ranking evaluation ("next": the caller after the train step) ====
  * core/eval_engine.py:49-87 evaluate() -> utils/evaluation.py:461-533 merge_ranking_true_pred

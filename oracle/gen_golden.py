@@ -245,7 +245,7 @@ def main():
     epoch_fixture(MFEngine, PairwiseNegativeDataset, "mf_epoch_sgd", "sgd", seed=22)
 
 
-if __name__ == "__main__" and not {"--ncf", "--lightgcn", "--eval"} & set(sys.argv):
+if __name__ == "__main__" and not {"--ncf", "--lightgcn", "--eval", "--sampler"} & set(sys.argv):
     main()
 
 
@@ -470,3 +470,55 @@ def main_eval():
 
 if __name__ == "__main__" and "--eval" in sys.argv:
     main_eval()
+
+
+# ---- negative sampling / loader builders (data/base_data.py:182-288) ----------------------------------
+
+def main_sampler():
+    """Outputs of the reference's own loader builders on a small training frame: what rows and
+    tensors they produce (pinned exactly) and which negatives they draw (pinned distributionally)."""
+    import random
+    import types
+    import warnings
+
+    import pandas as pd
+
+    import_reference()
+    from beta_rec.data.base_data import BaseData
+
+    rng = np.random.default_rng(23)
+    U, I = 30, 40
+    rows = set()
+    for u in range(U):
+        deg = int(rng.integers(1, 30)) if u != 5 else 37   # user 5 has only 3 untouched items
+        for i in rng.permutation(I)[:deg]:
+            rows.add((u, int(i)))
+    rows = sorted(rows)
+    rows = [rows[i] for i in rng.permutation(len(rows))]
+    users, items = (np.array(c, dtype=np.int64) for c in zip(*rows))
+    ratings = rng.integers(1, 6, len(rows)).astype(np.float64)
+    train = pd.DataFrame({"col_user": users, "col_item": items, "col_rating": ratings})
+    fake = types.SimpleNamespace(train=train, item_id_pool=list(range(I)), n_users=U, n_items=I)
+    out = {"meta": np.array([U, I], dtype=np.int64), "train_users": users, "train_items": items,
+           "train_ratings": ratings.astype(np.float32)}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        random.seed(2020)
+        bpr = quiet(BaseData.instance_bpr_loader, fake, 16, "cpu").dataset
+        out["bpr_users"], out["bpr_pos"], out["bpr_neg"] = (t.numpy() for t in (bpr.user_tensor, bpr.pos_item_tensor, bpr.neg_item_tensor))
+        bce = quiet(BaseData.instance_bce_loader, fake, 16, "cpu", 3).dataset
+        out["bce_users"], out["bce_items"], out["bce_ratings"] = (t.numpy() for t in (bce.user_tensor, bce.item_tensor, bce.target_tensor))
+        mul = quiet(BaseData.instance_mul_neg_loader, fake, 16, "cpu", 3).dataset
+        out["mul_users"], out["mul_pos"], out["mul_neg"] = (t.numpy() for t in (mul.user_tensor, mul.pos_item_tensor, mul.neg_item_tensor))
+        # many independent draws for one row each of a few users: the reference's sampling distribution
+        reps = 400
+        draws = np.empty((reps, len(rows)), dtype=np.int64)
+        for r in range(reps):
+            draws[r] = quiet(BaseData.instance_bpr_loader, fake, 16, "cpu").dataset.neg_item_tensor.numpy()
+        out["bpr_neg_draws"] = draws.astype(np.int16)
+    np.savez_compressed(os.path.join(OUT, "sampler_loaders.npz"), **out)
+    print("sampler_loaders:", len(rows), "rows;", {k: v.shape for k, v in out.items() if k.startswith(("bpr", "bce", "mul"))})
+
+
+if __name__ == "__main__" and "--sampler" in sys.argv:
+    main_sampler()

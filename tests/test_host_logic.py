@@ -370,3 +370,59 @@ def test_eval_group_by_user_and_argument_checks():
         hip_eval.rank_metrics([0], [1.0], [0.5], [], device="cpu")
     with pytest.raises(KeyError):
         hip_eval.evaluate({"col_user": [0], "col_rating": [1.0]}, [0.5], ["rmse"], 5)
+
+
+def test_compat_install_data_patches_the_loader_builders(tmp_path, monkeypatch):
+    """install_data swaps BaseData.instance_*_loader for the device-side builders, same signatures."""
+    import importlib
+    import sys
+
+    from beta_recsys_amd import compat
+    from beta_recsys_amd import data as hip_data
+
+    root = tmp_path / "fake"
+    (root / "beta_rec" / "data").mkdir(parents=True)
+    (root / "beta_rec" / "__init__.py").write_text("")
+    (root / "beta_rec" / "data" / "__init__.py").write_text("")
+    (root / "beta_rec" / "data" / "base_data.py").write_text(
+        "class BaseData:\n"
+        "    def instance_bpr_loader(self, batch_size, device):\n        return 'ref-bpr'\n"
+        "    def instance_bce_loader(self, batch_size, device, num_negative):\n        return 'ref-bce'\n"
+        "    def instance_mul_neg_loader(self, batch_size, device, num_negative):\n        return 'ref-mul'\n")
+    monkeypatch.syspath_prepend(str(root))
+    saved = {k: v for k, v in sys.modules.items() if k == "beta_rec" or k.startswith("beta_rec.")}
+    for k in saved:
+        del sys.modules[k]
+    calls = []
+    for name in ("instance_bpr_loader", "instance_bce_loader", "instance_mul_neg_loader"):
+        monkeypatch.setattr(hip_data, name, lambda data, *a, _n=name, **k: calls.append((_n, data, a, k)) or _n)
+    try:
+        base = compat.install_data()
+        compat.install_data()                                    # idempotent
+        obj = importlib.import_module("beta_rec.data.base_data").BaseData()
+        assert obj.instance_bpr_loader(512, "cuda:0") == "instance_bpr_loader"
+        assert obj.instance_bce_loader(512, "cuda:0", 4) == "instance_bce_loader"
+        assert obj.instance_mul_neg_loader(512, "cuda:0", num_negative=4) == "instance_mul_neg_loader"
+        assert calls[0] == ("instance_bpr_loader", obj, (512, "cuda:0"), {})
+        assert calls[2][3] == {"num_negative": 4}
+        compat.uninstall_data()
+        assert base().instance_bpr_loader(1, "cpu") == "ref-bpr"
+    finally:
+        for k in [k for k in sys.modules if k.startswith("beta_rec.") or k == "beta_rec"]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def test_positive_csr_and_loader_argument_checks():
+    from beta_recsys_amd import data as hip_data
+
+    users = torch.tensor([2, 0, 2, 2, 0, 3])
+    items = torch.tensor([5, 1, 0, 5, 4, 2])                      # (2, 5) twice: a set per user
+    ptr, cols = hip_data.build_positive_csr(users, items, 5, 6)
+    assert ptr.tolist() == [0, 2, 2, 4, 5, 5] and cols.tolist() == [1, 4, 0, 5, 2]
+    with pytest.raises(IndexError):
+        hip_data.build_positive_csr(users, items, 3, 6)           # user 3 outside [0, 3)
+    with pytest.raises(ValueError):
+        hip_data.sample_negatives(users, items, 5, 6, k=0, device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        hip_data.sample_negatives(users, items, 5, 6, device="cpu")
