@@ -189,8 +189,16 @@ def bench_ncf(args, device):
     with contextlib.redirect_stdout(io.StringIO()):
         eng = hp.NeuMFEngine(cfg)
     n_total = (args.warmup + args.steps) * B
-    users, items, _ = (t.to(device) for t in synth_triples(n_total, seed=100))
-    ratings = (torch.rand(n_total, device=device) < 0.2).float()
+    # the sample stream instance_bce_loader builds (data/base_data.py:182-216, num_negative 4): every
+    # positive (Zipf item, rating 1) is followed by 4 negatives of the same user (uniform items, rating
+    # 0), then the DataLoader shuffles the samples
+    pu, ppos, pneg = synth_triples(n_total // 5 + 1, seed=100)
+    g = torch.Generator().manual_seed(101)
+    users = pu.repeat_interleave(5)[:n_total]
+    items = torch.cat([ppos[:, None], torch.randint(0, I, (ppos.numel(), 4), generator=g)], 1).reshape(-1)[:n_total]
+    ratings = torch.tensor([1.0, 0, 0, 0, 0]).repeat(ppos.numel())[:n_total]
+    shuffle = torch.randperm(n_total, generator=g)
+    users, items, ratings = (t[shuffle].contiguous().to(device) for t in (users, items, ratings))
 
     def run(lo, n):
         for k in range(n):

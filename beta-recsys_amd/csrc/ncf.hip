@@ -24,36 +24,62 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kTM = 64, kTN = 64, kTK = 32;
 
-enum GemmMode { kNT = 0, kNN = 1, kTNm = 2 };
 
-// C[M,N] = epilogue( op(A) * op(B) )
-//   MODE kNT : A is [M,K] (lda), B is [N,K] (ldb)          C = A B^T      (forward: H W^T)
-//   MODE kNN : A is [M,K] (lda), B is [K,N] (ldb)          C = A B        (dgrad:   dZ W)
-//   MODE kTNm: A is [K,M] (lda), B is [K,N] (ldb)          C = A^T B      (wgrad:   dZ^T H)
-// epilogue: + bias[n] (if bias) ; relu (if relu) ; * [mask[m,n] > 0] (if mask)
+// One problem of a grouped launch.  mode kNT / kNN / kTNm: C[M,N] = epilogue(op(A) op(B)) with
+//   kNT : A is [M,K] (lda), B is [N,K] (ldb)          C = A B^T      (forward: H W^T)
+//   kNN : A is [M,K] (lda), B is [K,N] (ldb)          C = A B        (dgrad:   dZ W)
+//   kTNm: A is [K,M] (lda), B is [K,N] (ldb)          C = A^T B      (wgrad:   dZ^T H)
+//   epilogue: + bias[n] (if bias) ; relu (if relu) ; * [mask[m,n] > 0] (if mask)
+// mode kColsum: C[n] += sum_m A[m, n] over the block's kColsumRows rows (bias gradients).
+enum GemmMode { kNT = 0, kNN = 1, kTNm = 2, kColsum = 3 };
+
+struct GemmProblem {
+  int mode, M, N, K;
+  const float* A;
+  int lda;
+  const float* B;
+  int ldb;
+  float* C;
+  int ldc;
+  const float* bias;
+  int relu;
+  const float* mask;
+  int ldm;
+  int tiles_n, tiles_m, split;  // block decomposition of this problem
+  int first_block;              // its first block in the grouped grid
+};
+
+constexpr int kMaxGroup = 4;
+struct GemmGroup {
+  int n;
+  GemmProblem p[kMaxGroup];
+};
+
+constexpr int kColsumRows = 128;
+
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void gemm_f32_kernel(int M, int N, int K,
-                                                          const float* __restrict__ A, int lda,
-                                                          const float* __restrict__ B, int ldb,
-                                                          float* __restrict__ C, int ldc,
-                                                          const float* __restrict__ bias, int relu,
-                                                          const float* __restrict__ mask, int ldm) {
-  __shared__ float As[kTM][kTK + 1];
-  __shared__ float Bs[kTK][kTN + 1];
+__device__ __forceinline__ void gemm_tile(float (*As)[kTK + 1], float (*Bs)[kTN + 1], const GemmProblem& q,
+                                          int tile_m, int tile_n, int z) {
+  const int M = q.M, N = q.N, K = q.K, lda = q.lda, ldb = q.ldb, ldc = q.ldc, ldm = q.ldm;
+  const float* __restrict__ A = q.A;
+  const float* __restrict__ B = q.B;
+  float* __restrict__ C = q.C;
+  const float* __restrict__ bias = q.bias;
+  const float* __restrict__ mask = q.mask;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * kTM, n0 = blockIdx.x * kTN;
+  const int m0 = tile_m * kTM, n0 = tile_n * kTN;
 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  // split-K: blockIdx.z owns a kTK-aligned slice of K and adds its partial product atomically
+  // split-K: slice z owns a kTK-aligned stretch of K and adds its partial product atomically
   // (wgrad has K = batch and only a handful of output tiles; C must then be zero on entry)
-  const int k_per = ((K + static_cast<int>(gridDim.z) - 1) / static_cast<int>(gridDim.z) + kTK - 1) / kTK * kTK;
-  const int k_begin = static_cast<int>(blockIdx.z) * k_per;
+  const int k_per = ((K + q.split - 1) / q.split + kTK - 1) / kTK * kTK;
+  const int k_begin = z * k_per;
   const int k_end = min(K, k_begin + k_per);
 
   // Each thread stages kPer = 8 elements of the A tile and 8 of the B tile per k-step.  Their
@@ -116,9 +142,9 @@ __global__ __launch_bounds__(kBlock) void gemm_f32_kernel(int M, int N, int K,
     if (gm < M && gn < N) {
       float v = acc[r];
       if (bias) v += bias[gn];
-      if (relu) v = fmaxf(v, 0.f);
+      if (q.relu) v = fmaxf(v, 0.f);
       if (mask) v = mask[static_cast<int64_t>(gm) * ldm + gn] > 0.f ? v : 0.f;
-      if (gridDim.z > 1) {
+      if (q.split > 1) {
         if (v != 0.f) atomic_add_f32(C + static_cast<int64_t>(gm) * ldc + gn, v);
       } else {
         C[static_cast<int64_t>(gm) * ldc + gn] = v;
@@ -127,36 +153,121 @@ __global__ __launch_bounds__(kBlock) void gemm_f32_kernel(int M, int N, int K,
   }
 }
 
+// ---- column sums: out[n] += sum_m X[m, n]   (bias gradients) ---------------------------------------
+// A block owns kColsumRows rows: 4 thread groups x 64 columns, each thread sums a quarter of the rows
+// of its column, the four partials meet in LDS and ONE atomic per (block, column) leaves.  Few,
+// fat blocks on purpose: every block adds into the same N addresses and same-address atomics
+// serialise at ~25 ns.
+__device__ __forceinline__ void colsum_tile(float* s_flat, const GemmProblem& q, int slab) {
+  float (*s_part)[64] = reinterpret_cast<float (*)[64]>(s_flat);
+  const float* __restrict__ X = q.A;
+  const int M = q.M, N = q.N;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int m0 = slab * kColsumRows;
+  const int m1 = min(M, m0 + kColsumRows);
+  for (int n0 = 0; n0 < N; n0 += 64) {
+    const int n = n0 + tx;
+    float s = 0.f;
+    if (n < N) {
+#pragma unroll 8
+      for (int m = m0 + ty; m < m1; m += 4) s += X[static_cast<int64_t>(m) * q.lda + n];
+    }
+    s_part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && n < N) {
+      const float t = (s_part[0][tx] + s_part[1][tx]) + (s_part[2][tx] + s_part[3][tx]);
+      if (t != 0.f) atomic_add_f32(q.C + n, t);
+    }
+    __syncthreads();
+  }
+}
+
+// Grouped launch: up to kMaxGroup independent problems share one grid (the backward pass of one
+// Linear layer is three of them reading the same dZ: weight gradient, bias gradient, input
+// gradient; each is a ~10 us latency-bound launch on its own at batch 4096).
+__global__ __launch_bounds__(kBlock) void gemm_group_kernel(GemmGroup g) {
+  __shared__ float As[kTM][kTK + 1];
+  __shared__ float Bs[kTK][kTN + 1];
+  int qi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (i < g.n && static_cast<int>(blockIdx.x) >= g.p[i].first_block) qi = i;
+  const GemmProblem& q = g.p[qi];
+  const int local = static_cast<int>(blockIdx.x) - q.first_block;
+  if (q.mode == kColsum) {
+    colsum_tile(&As[0][0], q, local);
+    return;
+  }
+  const int tile_n = local % q.tiles_n;
+  const int tile_m = (local / q.tiles_n) % q.tiles_m;
+  const int z = local / (q.tiles_n * q.tiles_m);
+  switch (q.mode) {
+    case kNT:
+      gemm_tile<kNT>(As, Bs, q, tile_m, tile_n, z);
+      break;
+    case kNN:
+      gemm_tile<kNN>(As, Bs, q, tile_m, tile_n, z);
+      break;
+    default:
+      gemm_tile<kTNm>(As, Bs, q, tile_m, tile_n, z);
+      break;
+  }
+}
+
+static GemmProblem make_gemm(int mode, int M, int N, int K, const float* A, int lda, const float* B,
+                             int ldb, float* C, int ldc, const float* bias, int relu,
+                             const float* mask, int ldm, bool split_k) {
+  GemmProblem q{};
+  q.mode = mode; q.M = M; q.N = N; q.K = K; q.A = A; q.lda = lda; q.B = B; q.ldb = ldb; q.C = C; q.ldc = ldc;
+  q.bias = bias; q.relu = relu; q.mask = mask; q.ldm = ldm;
+  q.tiles_n = (N + kTN - 1) / kTN;
+  q.tiles_m = (M + kTM - 1) / kTM;
+  q.split = 1;
+  // split K when the output has too few tiles to fill 256 CUs (only legal without an epilogue,
+  // into a zero-initialised C: the weight-gradient GEMMs)
+  if (split_k && !bias && !relu && !mask) {
+    const int tiles = q.tiles_n * q.tiles_m;
+    int z = (512 + tiles - 1) / tiles;
+    const int max_z = (K + 4 * kTK - 1) / (4 * kTK);  // at least 4 k-tiles per slice
+    if (z > max_z) z = max_z;
+    if (z > 1) q.split = z;
+  }
+  return q;
+}
+
+static GemmProblem make_colsum(const float* X, int M, int N, int ldx, float* out) {
+  GemmProblem q{};
+  q.mode = kColsum; q.M = M; q.N = N; q.A = X; q.lda = ldx; q.C = out;
+  q.tiles_n = 1;
+  q.tiles_m = (M + kColsumRows - 1) / kColsumRows;
+  q.split = 1;
+  return q;
+}
+
+static int launch_group(GemmGroup& g, hipStream_t st) {
+  int blocks = 0;
+  for (int i = 0; i < g.n; ++i) {
+    g.p[i].first_block = blocks;
+    blocks += g.p[i].tiles_n * g.p[i].tiles_m * g.p[i].split;
+  }
+  if (blocks == 0) return 0;
+  gemm_group_kernel<<<blocks, kBlock, 0, st>>>(g);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
 static int launch_gemm(int mode, int M, int N, int K, const float* A, int lda, const float* B,
                        int ldb, float* C, int ldc, const float* bias, int relu, const float* mask,
                        int ldm, hipStream_t st, bool split_k = false) {
   if (M <= 0 || N <= 0) return 0;
-  dim3 grid((N + kTN - 1) / kTN, (M + kTM - 1) / kTM);
-  // split K when the output has too few tiles to fill 256 CUs (only legal without an epilogue,
-  // into a zero-initialised C: the weight-gradient GEMMs)
-  if (split_k && !bias && !relu && !mask) {
-    const int tiles = grid.x * grid.y;
-    int z = (512 + tiles - 1) / tiles;
-    const int max_z = (K + 4 * kTK - 1) / (4 * kTK);  // at least 4 k-tiles per slice
-    if (z > max_z) z = max_z;
-    if (z > 1) grid.z = z;
+  if (mode != kNT && mode != kNN && mode != kTNm) {
+    set_error("bad gemm mode %d", mode);
+    return HIPREC_E_BADARG;
   }
-  switch (mode) {
-    case kNT:
-      gemm_f32_kernel<kNT><<<grid, kBlock, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldm);
-      break;
-    case kNN:
-      gemm_f32_kernel<kNN><<<grid, kBlock, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldm);
-      break;
-    case kTNm:
-      gemm_f32_kernel<kTNm><<<grid, kBlock, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldm);
-      break;
-    default:
-      set_error("bad gemm mode %d", mode);
-      return HIPREC_E_BADARG;
-  }
-  HIPREC_TRY(hipGetLastError());
-  return 0;
+  GemmGroup g{};
+  g.n = 1;
+  g.p[0] = make_gemm(mode, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldm, split_k);
+  return launch_group(g, st);
 }
 
 // ---- gather: H0[b] = [relu](cat(Um[u], Im[i])),  MF[b] = Ug[u] * Ig[i] ------------------------------
@@ -218,38 +329,57 @@ __global__ __launch_bounds__(kBlock) void ncf_head_kernel(hiprec_ncf_plan p,
 
   if (TRAIN && blockIdx.x == 0 && threadIdx.x == 0) advance_step(stats);
 
-  for (int64_t b = wave0; b < batch; b += n_waves) {
-    float part = 0.f;
-    float vec[5];
+  // kUnroll samples per trip: their input loads are requested together, so a wave pays one memory
+  // round trip per trip instead of one per sample (a wave owns batch / n_waves = 8 samples at B 4096).
+  constexpr int kUnroll = 4;
+  float wout[5];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int c = lane + kWave * k;
-      float v = 0.f;
-      if (c < nH) v = hL[b * nH + c];
-      else if (c < nV) v = p.mf[b * E + (c - nH)];
-      vec[k] = v;
-      if (c < nV) part += v * p.out_w[c];
+  for (int k = 0; k < 5; ++k) wout[k] = lane + kWave * k < nV ? p.out_w[lane + kWave * k] : 0.f;
+  for (int64_t b0 = wave0; b0 < batch; b0 += n_waves * kUnroll) {
+    float vec[kUnroll][5];
+    float rj[kUnroll];
+#pragma unroll
+    for (int j = 0; j < kUnroll; ++j) {
+      const int64_t b = b0 + j * n_waves;
+      const bool live = b < batch;
+      rj[j] = (TRAIN && live) ? ratings[b] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int c = lane + kWave * k;
+        float v = 0.f;
+        if (live && c < nH) v = hL[b * nH + c];
+        else if (live && c < nV) v = p.mf[b * E + (c - nH)];
+        vec[j][k] = v;
+      }
     }
-    const float logit = wave_sum(part) + bo;
-    const float y = sigmoid_f32(logit);
-    if (lane == 0) p.scores[b] = y;
-    if (!TRAIN) continue;
-    const float r = ratings[b];
-    const float ly = fmaxf(logf(y), -100.f);
-    const float l1y = fmaxf(log1pf(-y), -100.f);
-    loss_acc += -(r * ly + (1.f - r) * l1y);
-    const float gy = (y - r) / fmaxf((1.f - y) * y, 1e-12f) * inv_batch;
-    const float dl = gy * ((1.f - y) * y);
-    gb_acc += dl;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int c = lane + kWave * k;
-      if (c < nV) gw[k] += dl * vec[k];
-      if (c < nH) {
-        // d loss / d z_L = d h_L * [h_L > 0]  (ReLU of the last Linear, applied twice in NeuMF)
-        p.dact[L][b * nH + c] = vec[k] > 0.f ? dl * p.out_w[c] : 0.f;
-      } else if (c < nV) {
-        p.dmf[b * E + (c - nH)] = dl * p.out_w[c];
+    for (int j = 0; j < kUnroll; ++j) {
+      const int64_t b = b0 + j * n_waves;
+      if (b >= batch) break;
+      float part = 0.f;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) part += vec[j][k] * wout[k];
+      const float logit = wave_sum(part) + bo;
+      const float y = sigmoid_f32(logit);
+      if (lane == 0) p.scores[b] = y;
+      if (!TRAIN) continue;
+      const float r = rj[j];
+      const float ly = fmaxf(logf(y), -100.f);
+      const float l1y = fmaxf(log1pf(-y), -100.f);
+      loss_acc += -(r * ly + (1.f - r) * l1y);
+      const float gy = (y - r) / fmaxf((1.f - y) * y, 1e-12f) * inv_batch;
+      const float dl = gy * ((1.f - y) * y);
+      gb_acc += dl;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int c = lane + kWave * k;
+        if (c < nV) gw[k] += dl * vec[j][k];
+        if (c < nH) {
+          // d loss / d z_L = d h_L * [h_L > 0]  (ReLU of the last Linear, applied twice in NeuMF)
+          p.dact[L][b * nH + c] = vec[j][k] > 0.f ? dl * wout[k] : 0.f;
+        } else if (c < nV) {
+          p.dmf[b * E + (c - nH)] = dl * wout[k];
+        }
       }
     }
   }
@@ -270,36 +400,6 @@ __global__ __launch_bounds__(kBlock) void ncf_head_kernel(hiprec_ncf_plan p,
   if (nV > 256) {  // rare wide heads: straight per-wave atomics for the tail columns
     const int c = lane + 256;
     if (c < nV && gw[4] != 0.f) atomic_add_f32(p.g_out_w + c, gw[4]);
-  }
-}
-
-// ---- column sums: out[n] += sum_m X[m, n]   (bias gradients) ---------------------------------------
-// A block owns kColsumRows rows: 4 thread groups x 64 columns, each thread sums a quarter of the rows
-// of its column, the four partials meet in LDS and ONE atomic per (block, column) leaves.  Few,
-// fat blocks on purpose: every block adds into the same N addresses and same-address atomics
-// serialise at ~25 ns.
-constexpr int kColsumRows = 128;
-
-__global__ __launch_bounds__(kBlock) void colsum_kernel(const float* __restrict__ X, int M, int N,
-                                                        float* __restrict__ out) {
-  __shared__ float s_part[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int m0 = blockIdx.x * kColsumRows;
-  const int m1 = min(M, m0 + kColsumRows);
-  for (int n0 = 0; n0 < N; n0 += 64) {
-    const int n = n0 + tx;
-    float s = 0.f;
-    if (n < N) {
-#pragma unroll 8
-      for (int m = m0 + ty; m < m1; m += 4) s += X[static_cast<int64_t>(m) * N + n];
-    }
-    s_part[ty][tx] = s;
-    __syncthreads();
-    if (ty == 0 && n < N) {
-      const float t = (s_part[0][tx] + s_part[1][tx]) + (s_part[2][tx] + s_part[3][tx]);
-      if (t != 0.f) atomic_add_f32(out + n, t);
-    }
-    __syncthreads();
   }
 }
 
@@ -431,18 +531,20 @@ extern "C" int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users
   if (p->dim_mlp > 0) {
     for (int l = p->n_layers - 1; l >= 0; --l) {
       const int nin = p->layer_in[l], nout = p->layer_out[l];
-      // dW_l = dZ_l^T H_{l-1}      (the gradient buffer is all-zero between steps: plain store)
-      if (int rc = launch_gemm(kTNm, nout, nin, B, p->dact[l + 1], nout, p->act[l], nin, p->g_fc_w[l],
-                               nin, nullptr, 0, nullptr, 0, st, /*split_k=*/true))
-        return rc;
-      colsum_kernel<<<(B + kColsumRows - 1) / kColsumRows, kBlock, 0, st>>>(p->dact[l + 1], B, nout, p->g_fc_b[l]);
-      HIPREC_TRY(hipGetLastError());
-      // dZ_{l-1} = (dZ_l W_l) * [H_{l-1} > 0]; for l == 0 the mask is the ReLU NeuMF applies to the
-      // raw embeddings (quirk Q7) and is absent for the stand-alone MLP
+      // One grouped launch per layer, three problems that all read dZ_l:
+      //   dW_l = dZ_l^T H_{l-1}   (split-K into the all-zero gradient buffer)
+      //   db_l = column sums of dZ_l
+      //   dZ_{l-1} = (dZ_l W_l) * [H_{l-1} > 0]; for l == 0 the mask is the ReLU NeuMF applies to
+      //   the raw embeddings (quirk Q7) and is absent for the stand-alone MLP
       const float* mask = (l > 0 || p->relu_input) ? p->act[l] : nullptr;
-      if (int rc = launch_gemm(kNN, B, nin, nout, p->dact[l + 1], nout, p->fc_w[l], nin, p->dact[l],
-                               nin, nullptr, 0, mask, nin, st))
-        return rc;
+      GemmGroup g{};
+      g.n = 3;
+      g.p[0] = make_gemm(kNN, B, nin, nout, p->dact[l + 1], nout, p->fc_w[l], nin, p->dact[l], nin, nullptr,
+                         0, mask, nin, false);
+      g.p[1] = make_gemm(kTNm, nout, nin, B, p->dact[l + 1], nout, p->act[l], nin, p->g_fc_w[l], nin, nullptr,
+                         0, nullptr, 0, /*split_k=*/true);
+      g.p[2] = make_colsum(p->dact[l + 1], B, nout, nout, p->g_fc_b[l]);
+      if (int rc = launch_group(g, st)) return rc;
     }
   }
   ncf_scatter_kernel<<<grid_for_waves(batch), kBlock, 0, st>>>(*p, users, items, batch);
