@@ -24,6 +24,11 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kTM = 64, kTN = 64, kTK = 32;
 
+// Every block-level barrier in this file orders LDS traffic only (operands staged through LDS; global
+// results are consumed by LATER launches), so lds_barrier() is used throughout: __syncthreads() also
+// waits for vmcnt(0), i.e. for the register-prefetched operands of the next k-step, which serialised
+// every k-step on a full memory round trip.
+
 
 // One problem of a grouped launch.  mode kNT / kNN / kTNm: C[M,N] = epilogue(op(A) op(B)) with
 //   kNT : A is [M,K] (lda), B is [N,K] (ldb)          C = A B^T      (forward: H W^T)
@@ -49,7 +54,7 @@ struct GemmProblem {
   int first_block;              // its first block in the grouped grid
 };
 
-constexpr int kMaxGroup = 4;
+constexpr int kMaxGroup = 16;
 struct GemmGroup {
   int n;
   GemmProblem p[kMaxGroup];
@@ -105,23 +110,25 @@ __device__ __forceinline__ void gemm_tile(float (*As)[kTK + 1], float (*Bs)[kTN 
   }
   const int64_t a_step = (MODE == kTNm) ? static_cast<int64_t>(lda) : 1;  // per unit of k
   const int64_t b_step = (MODE == kNT) ? 1 : static_cast<int64_t>(ldb);
-  float ra[kPer], rb[kPer];
-  auto fetch = [&](int k0) {
+  // Two register stages: the loads of steps t+1 and t+2 are in flight while step t's MFMAs run.  One
+  // stage is not enough here: a k-step is 16 MFMAs (~0.45 us per wave) and an L2 hit under load takes
+  // longer than that, so with one stage every step waited for its operands.
+  float ra0[kPer], rb0[kPer], ra1[kPer], rb1[kPer];
+  auto fetch = [&](float (&ra)[kPer], float (&rb)[kPer], int k0) {
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
       ra[i] = (a_ok[i] && k0 + a_k[i] < k_end) ? A[a_off[i] + a_step * k0] : 0.f;
       rb[i] = (b_ok[i] && k0 + b_k[i] < k_end) ? B[b_off[i] + b_step * k0] : 0.f;
     }
   };
-  if (k_begin < k_end) fetch(k_begin);
-  for (int k0 = k_begin; k0 < k_end; k0 += kTK) {
+  auto step = [&](float (&ra)[kPer], float (&rb)[kPer], int k0) {
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
       As[a_m[i]][a_k[i]] = ra[i];
       Bs[b_k[i]][b_n[i]] = rb[i];
     }
-    __syncthreads();
-    if (k0 + kTK < k_end) fetch(k0 + kTK);
+    lds_barrier();
+    if (k0 + 2 * kTK < k_end) fetch(ra, rb, k0 + 2 * kTK);  // this stage's registers are free again
     // lane l feeds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]
     const int i = lane & 31, kh = lane >> 5;
 #pragma unroll
@@ -130,7 +137,13 @@ __device__ __forceinline__ void gemm_tile(float (*As)[kTK + 1], float (*Bs)[kTN 
       const float b = Bs[kk + kh][wn * 32 + i];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
-    __syncthreads();
+    lds_barrier();
+  };
+  if (k_begin < k_end) fetch(ra0, rb0, k_begin);
+  if (k_begin + kTK < k_end) fetch(ra1, rb1, k_begin + kTK);
+  for (int k0 = k_begin; k0 < k_end; k0 += 2 * kTK) {
+    step(ra0, rb0, k0);
+    if (k0 + kTK < k_end) step(ra1, rb1, k0 + kTK);
   }
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int col = lane & 31;
@@ -173,12 +186,12 @@ __device__ __forceinline__ void colsum_tile(float* s_flat, const GemmProblem& q,
       for (int m = m0 + ty; m < m1; m += 4) s += X[static_cast<int64_t>(m) * q.lda + n];
     }
     s_part[ty][tx] = s;
-    __syncthreads();
+    lds_barrier();
     if (ty == 0 && n < N) {
       const float t = (s_part[0][tx] + s_part[1][tx]) + (s_part[2][tx] + s_part[3][tx]);
       if (t != 0.f) atomic_add_f32(q.C + n, t);
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -308,16 +321,22 @@ __global__ __launch_bounds__(kBlock) void ncf_gather_kernel(hiprec_ncf_plan p,
 // ---- head: logit, sigmoid, BCE, d logit, dH_L (masked), dMF, d w_out, d b_out ------------------------
 // one wave per sample; d w_out is accumulated per lane over the wave's samples, then one atomic per
 // (block, column).  TRAIN = false: scores only.
+// 16-wave blocks: at batch 4096 the training launch is 64 blocks whose waves own 4 samples each (one
+// trip of the loop below), and every block ends with ONE atomic per column of affine_output.weight --
+// 64 same-address atomics (~25 ns each) instead of one per 4-wave block.
+constexpr int kHeadWaves = 16;
+constexpr int kHeadBlock = kHeadWaves * kWave;
+
 template <bool TRAIN>
-__global__ __launch_bounds__(kBlock) void ncf_head_kernel(hiprec_ncf_plan p,
+__global__ __launch_bounds__(kHeadBlock) void ncf_head_kernel(hiprec_ncf_plan p,
                                                           const float* __restrict__ ratings,
                                                           int64_t batch, float inv_batch,
                                                           hiprec_stats* stats, Scratch* scratch) {
-  __shared__ float s_gw[kWavesPerBlock][256 + 1];
+  __shared__ float s_gw[kHeadWaves][256 + 1];
   const int lane = lane_id();
   const int wv = wave_in_block();
-  const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wv;
-  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kHeadWaves + wv;
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kHeadWaves;
   const int L = p.n_layers;
   const int nH = (p.dim_mlp > 0) ? p.layer_out[L - 1] : 0;  // width of the tower output
   const int E = p.dim_mf;
@@ -327,7 +346,10 @@ __global__ __launch_bounds__(kBlock) void ncf_head_kernel(hiprec_ncf_plan p,
   float loss_acc = 0.f, gb_acc = 0.f;
   float gw[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // columns lane, lane+64, ... (nV <= 320)
 
-  if (TRAIN && blockIdx.x == 0 && threadIdx.x == 0) advance_step(stats);
+  // the stepper's loads travel with the first trip's input loads; its stores go out after them
+  const bool stepper = TRAIN && blockIdx.x == 0 && threadIdx.x == 0;
+  StepState step_state{};
+  if (stepper) step_state = step_load(stats);
 
   // kUnroll samples per trip: their input loads are requested together, so a wave pays one memory
   // round trip per trip instead of one per sample (a wave owns batch / n_waves = 8 samples at B 4096).
@@ -384,17 +406,18 @@ __global__ __launch_bounds__(kBlock) void ncf_head_kernel(hiprec_ncf_plan p,
     }
   }
   if (!TRAIN) return;
+  if (stepper) step_store_advanced(stats, step_state);
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const int c = lane + kWave * k;
     if (c < 256) s_gw[wv][c] = gw[k];
   }
   // loss partial (reg slot unused = 0); d b_out travels in the scalar-gradient slot
-  publish_partials<kWavesPerBlock>(loss_acc, 0.f, gb_acc, inv_batch, scratch);
-  for (int c = threadIdx.x; c < nV && c < 256; c += kBlock) {
+  publish_partials<kHeadWaves>(loss_acc, 0.f, gb_acc, inv_batch, scratch);
+  for (int c = threadIdx.x; c < nV && c < 256; c += kHeadBlock) {
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < kWavesPerBlock; ++w) s += s_gw[w][c];
+    for (int w = 0; w < kHeadWaves; ++w) s += s_gw[w][c];
     if (s != 0.f) atomic_add_f32(p.g_out_w + c, s);
   }
   if (nV > 256) {  // rare wide heads: straight per-wave atomics for the tail columns
@@ -435,6 +458,268 @@ __global__ __launch_bounds__(kBlock) void ncf_scatter_kernel(hiprec_ncf_plan p,
   }
 }
 
+// ======================= fused tower: one launch forward, one launch backward ========================
+// At batch 4096 every stand-alone launch of this path (gather, a 4096 x 128 x 256 GEMM, the head...)
+// costs 8-14 us although its arithmetic is worth 1-2 us: each one starts by missing on what the
+// previous launch wrote (rocprofv3: 11 launches, 106 us per step).  A block of 8 waves that owns 64
+// samples can carry them through the whole tower without leaving the CU: the activations of the 64
+// samples stay in LDS between layers (they are also written to HBM once, for the weight-gradient
+// GEMMs), only the weights stream through a 32-row LDS tile, and the head / the embedding-gradient
+// scatter run on the same rows at the two ends.  Layers are fp32 MFMA 32x32x2 as in gemm_tile.
+// Shapes outside the limits below take the unfused path.
+constexpr int kFR = 32;                    // samples per block (one 32-row MFMA tile: 128 blocks at B 4096)
+constexpr int kFWaves = 4;                 // one wave per 32 output columns of a 128-column pass
+constexpr int kFThreads = kFWaves * kWave; // 256
+constexpr int kFMaxIn = 256;               // widest tower input (2 * dim_mlp)
+constexpr int kFMaxN = 128;                // widest layer output / widest hidden activation
+constexpr int kFLdIn = kFMaxIn + 1;
+constexpr int kFLdN = kFMaxN + 1;
+constexpr int kFMaxE = 64;                 // GMF width kept in LDS
+constexpr int kFLdE = kFMaxE + 1;
+
+static bool fusable(const hiprec_ncf_plan* p) {
+  if (p->dim_mlp <= 0 || p->n_layers < 1) return false;
+  if (2 * p->dim_mlp > kFMaxIn || (2 * p->dim_mlp) % kTK) return false;
+  if (p->dim_mf > kFMaxE) return false;
+  for (int l = 0; l < p->n_layers; ++l) {
+    if (p->layer_out[l] > kFMaxN || p->layer_out[l] % 32) return false;
+    if (p->layer_in[l] % kTK) return false;
+  }
+  return true;
+}
+
+struct FusedLds {
+  float* wide;   // [kFR][kFLdIn]  tower input, later narrow activations
+  float* narrow; // [kFR][kFLdN]
+  float* bs;     // [2][kTK][kFLdN] weight tiles (double-buffered)
+  float* mf;     // [kFR][kFLdE]   GMF product (forward) / unused (backward)
+  __device__ int ld_of(const float* buf) const { return buf == wide ? kFLdIn : kFLdN; }
+};
+constexpr size_t kFusedLdsBytes =
+    sizeof(float) * (kFR * kFLdIn + kFR * kFLdN + 2 * kTK * kFLdN + kFR * kFLdE);
+
+__device__ __forceinline__ FusedLds fused_lds(float* base) {
+  FusedLds l;
+  l.wide = base;
+  l.narrow = l.wide + kFR * kFLdIn;
+  l.bs = l.narrow + kFR * kFLdN;
+  l.mf = l.bs + 2 * kTK * kFLdN;
+  return l;
+}
+
+// acc(32x32 per wave) = In[32 x K] * W^T: wave wn owns output columns wn*32.. of the N <= 128 columns
+// (W is nn.Linear.weight, [N][K] row-major; K is a multiple of kTK).  Waves beyond N idle in the MFMAs
+// but still help staging.  Software pipeline, measured per chunk of 32 k with in-kernel timestamps:
+// staged naively (16 scalar loads issued, then 16 LDS stores, then the 16 dependent MFMAs) a chunk
+// took 2760 cycles of which the MFMAs are 1150 -- with one wave per SIMD nothing else fills the
+// matrix pipe while that wave issues memory instructions.  Hence: 16-byte weight loads (4 per chunk
+// instead of 16), a double-buffered LDS tile written one chunk ahead, two register stages, and the
+// memory instructions spread between the MFMAs with sched_group_barrier so they issue in the shadow
+// of the 64-cycle dependent MFMA chain.
+constexpr int kFW4 = kFMaxN * kTK / 4 / kFThreads;  // float4 weight loads per thread and chunk (4)
+
+__device__ __forceinline__ void fused_mma(f32x16& acc, const float* in, int ld_in, int K,
+                                          const float* __restrict__ W, int N, float* bs) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 3;
+  const bool active = wn * 32 < N;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // staging coordinates of this thread inside a [kTK x 128] tile (fixed across chunks): float4 q
+  // covers W[n][k4 .. k4+3]
+  int s_n[kFW4], s_k4[kFW4];
+  const float4* s_src[kFW4];
+  bool s_ok[kFW4];
+#pragma unroll
+  for (int i = 0; i < kFW4; ++i) {
+    const int q = tid + i * kFThreads;
+    s_n[i] = q >> 3;
+    s_k4[i] = (q & 7) * 4;
+    s_ok[i] = s_n[i] < N;
+    s_src[i] = reinterpret_cast<const float4*>(W + static_cast<int64_t>(s_ok[i] ? s_n[i] : 0) * K + s_k4[i]);
+  }
+  float4 w0[kFW4], w1[kFW4];
+  auto fetch = [&](float4 (&w)[kFW4], int k0) {
+#pragma unroll
+    for (int i = 0; i < kFW4; ++i) w[i] = s_src[i][k0 >> 2];
+  };
+  auto stage = [&](const float4 (&w)[kFW4], float* tile) {
+#pragma unroll
+    for (int i = 0; i < kFW4; ++i) {
+      float* d = tile + s_k4[i] * kFLdN + s_n[i];
+      const float4 v = s_ok[i] ? w[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      d[0] = v.x;
+      d[kFLdN] = v.y;
+      d[2 * kFLdN] = v.z;
+      d[3 * kFLdN] = v.w;
+    }
+  };
+  const int n_chunks = K / kTK;
+  float* tile[2] = {bs, bs + kTK * kFLdN};
+  fetch(w0, 0);
+  if (n_chunks > 1) fetch(w1, kTK);
+  stage(w0, tile[0]);
+  if (n_chunks > 2) fetch(w0, 2 * kTK);
+  lds_barrier();
+  auto chunk = [&](float4 (&w_next)[kFW4], int t) {
+    // chunk t+1 goes to the other tile, chunk t+3 into the registers it frees, chunk t is multiplied
+    if (t + 1 < n_chunks) stage(w_next, tile[(t + 1) & 1]);
+    if (t + 3 < n_chunks) fetch(w_next, (t + 3) * kTK);
+    if (active) {
+      const float* cur = tile[t & 1];
+      const int i = lane & 31, kh = lane >> 5;
+      const int k0 = t * kTK;
+#pragma unroll
+      for (int kk = 0; kk < kTK; kk += 2) {
+        const float a = in[i * ld_in + k0 + kk + kh];
+        const float b = cur[(kk + kh) * kFLdN + wn * 32 + i];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
+    }
+    // issue order: one MFMA, then the LDS reads of the next one, one staging store, and every
+    // fourth slot one weight load
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+      if ((g & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+    }
+    lds_barrier();
+  };
+  for (int t = 0; t < n_chunks; t += 2) {
+    chunk(w1, t);
+    if (t + 1 < n_chunks) chunk(w0, t + 1);
+  }
+}
+
+// ---- forward: gather -> tower -> affine_output -> sigmoid; writes act[0..L], mf, scores -----------------
+__global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(hiprec_ncf_plan p,
+                                                                       const int64_t* __restrict__ users,
+                                                                       const int64_t* __restrict__ items,
+                                                                       int64_t batch, hiprec_stats* stats) {
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  const FusedLds L = fused_lds(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kFR;
+  const int Dm = p.dim_mlp, E = p.dim_mf, K0 = 2 * Dm;
+
+  // gather, element-parallel: 64 threads fetch the index pairs, then every thread owns
+  // kFR * K0 / 512 <= 32 elements of the tower input; all its loads are requested before anything
+  // is stored (one round trip for the whole tile instead of one per row)
+  __shared__ long long s_u[kFR], s_i[kFR];
+  if (tid < kFR) {
+    const int64_t b = m0 + tid;
+    long long u = -1, it = -1;
+    if (b < batch) {
+      u = users[b];
+      it = items[b];
+      const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(p.n_users);
+      const bool i_ok = static_cast<uint64_t>(it) < static_cast<uint64_t>(p.n_items);
+      if (!(u_ok && i_ok)) {
+        atomicOr(&stats->status,
+                 (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
+        u = it = -1;
+      }
+    }
+    s_u[tid] = u;
+    s_i[tid] = it;
+  }
+  lds_barrier();
+  {
+    // thread t owns column t of every row (K0 <= 256 = kFThreads) and (row j*4 + t/64, column t%64)
+    // of the GMF tile: no divisions, one load per row, all requested before anything is stored
+    static_assert(kFMaxIn <= kFThreads && kFMaxE == kWave, "gather mapping");
+    float v[kFR];
+    const int c = tid < K0 ? tid : 0;
+    const bool c_user = c < Dm;
+    const float* base = c_user ? p.user_mlp + c : p.item_mlp + (c - Dm);
+#pragma unroll
+    for (int r = 0; r < kFR; ++r) {
+      const long long idx = c_user ? s_u[r] : s_i[r];
+      v[r] = base[(idx >= 0 ? idx : 0) * Dm];  // flagged samples read row 0 and are zeroed below
+    }
+    constexpr int kPerE = kFR * kFMaxE / kFThreads;  // 8
+    float w[kPerE];
+    const int ce = (tid & 63) < E ? (tid & 63) : 0;
+#pragma unroll
+    for (int j = 0; j < kPerE; ++j) {
+      const int r = j * (kFThreads / kWave) + (tid >> 6);
+      const long long u = s_u[r], it = s_i[r];
+      w[j] = E > 0 ? p.user_mf[(u >= 0 ? u : 0) * E + ce] * p.item_mf[(it >= 0 ? it : 0) * E + ce] : 0.f;
+    }
+    if (tid < K0) {
+#pragma unroll
+      for (int r = 0; r < kFR; ++r) {
+        float x = s_u[r] >= 0 ? v[r] : 0.f;
+        if (p.relu_input) x = fmaxf(x, 0.f);
+        L.wide[r * kFLdIn + tid] = x;
+        if (m0 + r < batch) p.act[0][(m0 + r) * K0 + tid] = x;
+      }
+    }
+    if ((tid & 63) < E) {
+#pragma unroll
+      for (int j = 0; j < kPerE; ++j) {
+        const int r = j * (kFThreads / kWave) + (tid >> 6);
+        const float x = s_u[r] >= 0 ? w[j] : 0.f;
+        L.mf[r * kFLdE + (tid & 63)] = x;
+        if (m0 + r < batch) p.mf[(m0 + r) * E + (tid & 63)] = x;
+      }
+    }
+  }
+  lds_barrier();
+
+  const float* in = L.wide;
+  float* out = L.narrow;
+  for (int l = 0; l < p.n_layers; ++l) {
+    const int K = p.layer_in[l], N = p.layer_out[l];
+    f32x16 acc;
+    fused_mma(acc, in, L.ld_of(in), K, p.fc_w[l], N, L.bs);
+    if (wn * 32 < N) {
+      const int col = wn * 32 + (lane & 31);
+      const float bias = p.fc_b[l][col];
+      const int ld_out = L.ld_of(out);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float v = fmaxf(acc[r] + bias, 0.f);
+        out[row * ld_out + col] = v;
+        if (m0 + row < batch) p.act[l + 1][(m0 + row) * N + col] = v;
+      }
+    }
+    lds_barrier();
+    const float* t = in;
+    in = out;
+    out = const_cast<float*>(t);
+  }
+
+  // affine_output + sigmoid: wave w scores rows w, w + 8, ...
+  const int nH = p.layer_out[p.n_layers - 1], nV = nH + E;
+  const int ld_h = L.ld_of(in);
+  const float bo = load_scalar_param(p.out_b);
+  float wout[3];  // nV <= 192
+#pragma unroll
+  for (int k = 0; k < 3; ++k) wout[k] = lane + kWave * k < nV ? p.out_w[lane + kWave * k] : 0.f;
+  for (int r = wave; r < kFR; r += kFWaves) {
+    const int64_t b = m0 + r;
+    if (b >= batch) continue;
+    float part = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int c = lane + kWave * k;
+      if (c < nV) part += (c < nH ? in[r * ld_h + c] : L.mf[r * kFLdE + (c - nH)]) * wout[k];
+    }
+    const float logit = wave_sum(part) + bo;
+    if (lane == 0) p.scores[b] = sigmoid_f32(logit);
+  }
+}
+
+static int head_grid(int64_t batch, int samples_per_wave) {
+  const int64_t per_block = static_cast<int64_t>(kHeadWaves) * samples_per_wave;
+  return static_cast<int>(std::min<int64_t>(std::max<int64_t>((batch + per_block - 1) / per_block, 1), 256));
+}
+
 static int check_plan(const hiprec_ncf_plan* p, int64_t batch, bool train) {
   HIPREC_REQUIRE(p != nullptr, "NULL plan");
   HIPREC_REQUIRE(p->n_users > 0 && p->n_items > 0, "bad table sizes");
@@ -464,8 +749,28 @@ static int check_plan(const hiprec_ncf_plan* p, int64_t batch, bool train) {
   return 0;
 }
 
+static int fused_attrs() {
+  static int rc = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ncf_fused_forward_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(kFusedLdsBytes));
+    return e == hipSuccess ? 0 : hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  }();
+  return rc;
+}
+
+// Tower forward.  Returns (through *scored) whether plan->scores already holds the sigmoid outputs.
 static int forward(const hiprec_ncf_plan* p, const int64_t* users, const int64_t* items,
-                   int64_t batch, hiprec_stats* stats, hipStream_t st) {
+                   int64_t batch, hiprec_stats* stats, hipStream_t st, bool* scored) {
+  *scored = false;
+  if (fusable(p)) {
+    if (int rc = fused_attrs()) return rc;
+    const int grid = static_cast<int>((batch + kFR - 1) / kFR);
+    ncf_fused_forward_kernel<<<grid, kFThreads, kFusedLdsBytes, st>>>(*p, users, items, batch, stats);
+    HIPREC_TRY(hipGetLastError());
+    *scored = true;
+    return 0;
+  }
   ncf_gather_kernel<<<grid_for_waves(batch), kBlock, 0, st>>>(*p, users, items, batch, stats);
   HIPREC_TRY(hipGetLastError());
   if (p->dim_mlp > 0) {
@@ -502,10 +807,13 @@ extern "C" int hiprec_ncf_forward(const hiprec_ncf_plan* plan, const int64_t* us
   if (batch == 0) return 0;
   HIPREC_REQUIRE(users && items && stats, "NULL pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (int rc = forward(plan, users, items, batch, stats, st)) return rc;
-  ncf_head_kernel<false><<<grid_for_waves(batch), kBlock, 0, st>>>(*plan, nullptr, batch, 0.f, stats,
-                                                                   nullptr);
-  HIPREC_TRY(hipGetLastError());
+  bool scored = false;
+  if (int rc = forward(plan, users, items, batch, stats, st, &scored)) return rc;
+  if (!scored) {
+    ncf_head_kernel<false><<<head_grid(batch, 1), kHeadBlock, 0, st>>>(*plan, nullptr, batch, 0.f, stats,
+                                                                     nullptr);
+    HIPREC_TRY(hipGetLastError());
+  }
   return 0;
 }
 
@@ -523,9 +831,9 @@ extern "C" int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users
   const hiprec_ncf_plan* p = plan;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int B = static_cast<int>(batch);
-  if (int rc = forward(p, users, items, batch, stats, st)) return rc;
-  // at most 128 blocks: each block ends with one atomic per column of affine_output.weight
-  ncf_head_kernel<true><<<std::min(grid_for_waves(batch), 128), kBlock, 0, st>>>(
+  bool scored = false;
+  if (int rc = forward(p, users, items, batch, stats, st, &scored)) return rc;
+  ncf_head_kernel<true><<<head_grid(batch, 4), kHeadBlock, 0, st>>>(
       *p, ratings, batch, inv_batch, stats, static_cast<Scratch*>(scratch));
   HIPREC_TRY(hipGetLastError());
   if (p->dim_mlp > 0) {
@@ -551,3 +859,4 @@ extern "C" int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
+
