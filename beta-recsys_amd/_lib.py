@@ -85,7 +85,8 @@ class LightGcnPlan(Structure):
 
     _fields_ = [("a", Csr), ("at", Csr), ("n_users", c_int64), ("n_items", c_int64),
                 ("dim", c_int32), ("n_layers", c_int32), ("decay", c_float), ("_pad", c_int32)] + \
-               [(n, c_void_p) for n in ("e0", "g", "xa", "xb", "acc", "da", "db")]
+               [(n, c_void_p) for n in ("e0", "g", "xa", "xb", "acc", "da", "db", "zero_ws")] + \
+               [("zero_ws_floats", c_int64)]
 
 
 # name -> (restype, argtypes); every symbol of include/hiprec.h must be listed here

@@ -72,52 +72,42 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(hiprec_csr a,
       if (keep) my_val = keep[a.eid ? a.eid[e] : e] ? my_val * scale : 0.f;
     }
     const int n_here = static_cast<int>(min<int64_t>(kWave, e_end - e0));
-    int j = 0;
-    while (j < n_here) {
-      while (e0 + j >= row_end) {  // row boundary (empty rows are skipped)
-        flush(row);
-        ++row;
-        row_end = a.rowptr[row + 1];
+    // kGroup edges per trip: their source rows are requested together and unconditionally (lanes
+    // past the slice hold column 0 / value 0, dropped edges multiply by 0), so a wave keeps
+    // kGroup * NPL row gathers in flight; the row bookkeeping is scalar and runs after the loads
+    // are issued.  With 4 conditional gathers per trip the SpMM sat on one L2 round trip per 4 edges.
+    constexpr int kGroup = 16 / NPL;
+    for (int j = 0; j < n_here; j += kGroup) {
+      int cs[kGroup];
+      float vs[kGroup];
+#pragma unroll
+      for (int q = 0; q < kGroup; ++q) {
+        cs[q] = __builtin_amdgcn_readlane(my_col, j + q);
+        vs[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), j + q));
       }
-      // fast path: four edges of the same row -> four independent row gathers in flight
-      if (j + 4 <= n_here && e0 + j + 4 <= row_end) {
-        int cs[4];
-        float vs[4];
+      float xv[kGroup][NPL];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          cs[q] = __builtin_amdgcn_readlane(my_col, j + q);
-          vs[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), j + q));
-        }
-        float xv[4][NPL];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float* xr = x + static_cast<int64_t>(cs[q]) * dim;
-#pragma unroll
-          for (int k = 0; k < NPL; ++k) {
-            const int c = lane + kWave * k;
-            // dropped edges (v == 0, wave-uniform) do not fetch their source row
-            xv[q][k] = (c < dim && vs[q] != 0.f) ? xr[c] : 0.f;
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-          for (int k = 0; k < NPL; ++k) acc[k] += vs[q] * xv[q][k];
-        }
-        j += 4;
-        continue;
-      }
-      const int c_src = __builtin_amdgcn_readlane(my_col, j);
-      const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), j));
-      if (v != 0.f) {
-        const float* xr = x + static_cast<int64_t>(c_src) * dim;
+      for (int q = 0; q < kGroup; ++q) {
+        const float* xr = x + static_cast<int64_t>(cs[q]) * dim;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
           const int c = lane + kWave * k;
-          if (c < dim) acc[k] += v * xr[c];
+          xv[q][k] = xr[c < dim ? c : dim - 1];
         }
       }
-      ++j;
+#pragma unroll
+      for (int q = 0; q < kGroup; ++q) {
+        if (j + q < n_here) {
+          while (e0 + j + q >= row_end) {  // row boundary (empty rows are skipped)
+            flush(row);
+            ++row;
+            row_end = a.rowptr[row + 1];
+          }
+#pragma unroll
+          for (int k = 0; k < NPL; ++k)
+            if (lane + kWave * k < dim) acc[k] += vs[q] * xv[q][k];
+        }
+      }
     }
   }
   flush(row);
@@ -226,8 +216,8 @@ __global__ __launch_bounds__(kBlock) void lightgcn_predict_kernel(hiprec_lightgc
 }
 
 static int launch_spmm(const hiprec_csr* a, const uint8_t* keep, float scale, const float* x,
-                       float* y, float* acc, int dim, hipStream_t st) {
-  HIPREC_TRY(hipMemsetAsync(y, 0, sizeof(float) * a->n_rows * dim, st));
+                       float* y, float* acc, int dim, hipStream_t st, bool y_is_zero = false) {
+  if (!y_is_zero) HIPREC_TRY(hipMemsetAsync(y, 0, sizeof(float) * a->n_rows * dim, st));
   if (a->nnz == 0) return 0;
   const int64_t n_waves = (a->nnz + kEdgesPerWave - 1) / kEdgesPerWave;
   const int64_t blocks = (n_waves + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -255,25 +245,40 @@ static int check_lg_plan(const hiprec_lightgcn_plan* p, bool train) {
   if (int rc = check_csr(&p->a, "a")) return rc;
   HIPREC_REQUIRE(p->n_users > 0 && p->n_items > 0 && p->dim > 0 && p->n_layers >= 0, "bad sizes");
   HIPREC_REQUIRE(p->a.n_rows == p->n_users + p->n_items, "graph size != n_users + n_items");
-  HIPREC_REQUIRE(p->e0 && p->xa && p->xb && p->acc, "NULL forward buffers");
+  const bool ws = p->zero_ws != nullptr;
+  if (ws)
+    HIPREC_REQUIRE(p->zero_ws_floats >= (1 + 2 * static_cast<int64_t>(p->n_layers)) * p->a.n_rows * p->dim,
+                   "zero_ws holds %lld floats, (1 + 2*n_layers) * n_rows * dim are needed",
+                   (long long)p->zero_ws_floats);
+  HIPREC_REQUIRE(p->e0 && p->acc && (ws || (p->xa && p->xb)), "NULL forward buffers");
   if (train) {
     if (int rc = check_csr(&p->at, "at")) return rc;
     HIPREC_REQUIRE(p->at.n_rows == p->a.n_rows && p->at.nnz == p->a.nnz, "a / at mismatch");
-    HIPREC_REQUIRE(p->g && p->da && p->db, "NULL backward buffers");
+    HIPREC_REQUIRE(p->g && (ws || (p->da && p->db)), "NULL backward buffers");
   }
   return 0;
 }
 
+// slice k of the contiguous zero-once workspace: 0 = d_out, 1..L = forward layer outputs,
+// L+1..2L = backward layer outputs
+static float* ws_slice(const hiprec_lightgcn_plan* p, int k) {
+  return p->zero_ws + static_cast<int64_t>(k) * p->a.n_rows * p->dim;
+}
+
 // acc = sum_{l=0..L} A^l E0   (out = acc / (L+1))
+// `ws_zeroed`: the caller already cleared the whole zero_ws region (training step)
 static int propagate(const hiprec_lightgcn_plan* p, const uint8_t* keep, float keep_prob,
-                     hipStream_t st) {
+                     hipStream_t st, bool ws_zeroed = false) {
   const size_t bytes = sizeof(float) * p->a.n_rows * p->dim;
   HIPREC_TRY(hipMemcpyAsync(p->acc, p->e0, bytes, hipMemcpyDeviceToDevice, st));
+  const bool ws = p->zero_ws != nullptr;
+  if (ws && !ws_zeroed && p->n_layers > 0)
+    HIPREC_TRY(hipMemsetAsync(ws_slice(p, 1), 0, bytes * p->n_layers, st));
   const float scale = keep ? 1.0f / keep_prob : 1.0f;
   const float* cur = p->e0;
   for (int l = 0; l < p->n_layers; ++l) {
-    float* nxt = (l & 1) ? p->xb : p->xa;
-    if (int rc = launch_spmm(&p->a, keep, scale, cur, nxt, p->acc, p->dim, st)) return rc;
+    float* nxt = ws ? ws_slice(p, 1 + l) : ((l & 1) ? p->xb : p->xa);
+    if (int rc = launch_spmm(&p->a, keep, scale, cur, nxt, p->acc, p->dim, st, ws)) return rc;
     cur = nxt;
   }
   return 0;
@@ -333,18 +338,26 @@ extern "C" int hiprec_lightgcn_grad(const hiprec_lightgcn_plan* plan, const uint
   }
   const hiprec_lightgcn_plan* p = plan;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (int rc = propagate(p, keep, keep_prob, st)) return rc;
   const size_t bytes = sizeof(float) * p->a.n_rows * p->dim;
-  HIPREC_TRY(hipMemsetAsync(p->da, 0, bytes, st));
+  const bool ws = p->zero_ws != nullptr;
+  hiprec_lightgcn_plan q = *p;  // d_out may live in the workspace
+  if (ws) {
+    // ONE fill for d_out and every layer output of the step (it was 7 launches of ~5 us each)
+    HIPREC_TRY(hipMemsetAsync(p->zero_ws, 0, bytes * (1 + 2 * static_cast<size_t>(p->n_layers)), st));
+    q.da = ws_slice(p, 0);
+  }
+  if (int rc = propagate(p, keep, keep_prob, st, /*ws_zeroed=*/ws)) return rc;
+  if (!ws) HIPREC_TRY(hipMemsetAsync(q.da, 0, bytes, st));
   lightgcn_loss_kernel<<<grid_for_waves(batch), kBlock, 0, st>>>(
-      *p, users, pos, neg, batch, inv_batch, stats, static_cast<Scratch*>(scratch));
+      q, users, pos, neg, batch, inv_batch, stats, static_cast<Scratch*>(scratch));
   HIPREC_TRY(hipGetLastError());
   // g = sum_{l=0..L} (A^T)^l d_out : the l = 0 term is already in g
   const float scale = keep ? 1.0f / keep_prob : 1.0f;
-  float* cur = p->da;
+  float* cur = q.da;
   float* nxt = p->db;
   for (int l = 0; l < p->n_layers; ++l) {
-    if (int rc = launch_spmm(&p->at, keep, scale, cur, nxt, p->g, p->dim, st)) return rc;
+    if (ws) nxt = ws_slice(p, 1 + p->n_layers + l);
+    if (int rc = launch_spmm(&p->at, keep, scale, cur, nxt, p->g, p->dim, st, ws)) return rc;
     float* t = cur;
     cur = nxt;
     nxt = t;

@@ -91,8 +91,10 @@ class LightGCN(_FlatModel):
         N, D = self.n_users + self.n_items, self.emb_dim
         g = self.graph()
         self._ws = {"dev": dev, "keep": torch.ones(max(g["nnz"], 1), dtype=torch.uint8, device=dev)}
-        for name in ("xa", "xb", "acc", "da", "db"):
-            self._ws[name] = torch.zeros(N, D, dtype=torch.float32, device=dev)
+        self._ws["acc"] = torch.zeros(N, D, dtype=torch.float32, device=dev)
+        # d_out + one output buffer per SpMM of a step, contiguous: the library clears them with one
+        # fill per step (hiprec_lightgcn_plan.zero_ws) instead of one fill launch per SpMM
+        self._ws["zero_ws"] = torch.zeros((1 + 2 * self.n_layers) * N * D, dtype=torch.float32, device=dev)
         return self._ws
 
     def plan(self, g_flat=None, decay=0.0):
@@ -106,8 +108,9 @@ class LightGCN(_FlatModel):
         p.decay = float(decay)
         p.e0 = self._flat.data_ptr()
         p.g = None if g_flat is None else g_flat.data_ptr()
-        for name in ("xa", "xb", "acc", "da", "db"):
-            setattr(p, name, ws[name].data_ptr())
+        p.acc = ws["acc"].data_ptr()
+        p.zero_ws = ws["zero_ws"].data_ptr()
+        p.zero_ws_floats = ws["zero_ws"].numel()
         return p
 
     def draw_keep_mask(self):
