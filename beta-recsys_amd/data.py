@@ -83,13 +83,19 @@ class DeviceTensorBatcher:
         n = self.tensors[0].shape[0]
         return (n + self.batch_size - 1) // self.batch_size
 
+    def permutation(self):
+        """One epoch's visiting order (int64, on the tensors' device); None = sequential."""
+        n = self.tensors[0].shape[0]
+        if not (self.shuffle and n):
+            return None
+        dev = self.tensors[0].device
+        perm = torch.empty(n, dtype=torch.int64, device=dev)
+        _lib.check(_lib.load().hiprec_random_permutation(_lib.ptr(perm), n, _draw_seed(), _lib.stream_ptr(dev)))
+        return perm
+
     def __iter__(self):
         n = self.tensors[0].shape[0]
-        dev = self.tensors[0].device
-        perm = None
-        if self.shuffle and n:
-            perm = torch.empty(n, dtype=torch.int64, device=dev)
-            _lib.check(_lib.load().hiprec_random_permutation(_lib.ptr(perm), n, _draw_seed(), _lib.stream_ptr(dev)))
+        perm = self.permutation()
         for off in range(0, n, self.batch_size):
             if perm is None:
                 yield tuple(t[off:off + self.batch_size] for t in self.tensors)

@@ -552,6 +552,13 @@ class MFEngine(ModelEngine):
         """(users, pos, neg, perm) when the loader's data is resident and can be batched on device."""
         if isinstance(train_loader, DeviceTripleBatcher):
             ds, perm = train_loader, train_loader.permutation()
+        elif (self.loss == "bce" and len(getattr(train_loader, "tensors", ())) == 3
+              and train_loader.tensors[2].is_floating_point() and hasattr(train_loader, "permutation")):
+            # data.DeviceTensorBatcher of (user, item, rating): the device-side instance_bce_loader
+            class _Rating:
+                user_tensor, item_tensor, target_tensor = train_loader.tensors
+
+            ds, perm = _Rating, train_loader.permutation()
         else:
             ds = getattr(train_loader, "dataset", None)
             names = (("user_tensor", "pos_item_tensor", "neg_item_tensor") if self.loss == "bpr"

@@ -160,3 +160,25 @@ def test_full_size_support_distinctness_uniformity(hip_device):
     assert int(live.sum()) > 3000 and float(zscore.abs().max()) < 6.0 and abs(float(zscore.mean())) < 0.2
     again = hdata().sample_negatives(users.to(hip_device), items.to(hip_device), U, I, k, 11)
     assert torch.equal(again, neg)
+
+
+def test_bce_loader_runs_the_resident_bce_epoch(hip_device):
+    """MF with loss 'bce' fed by the device-side instance_bce_loader (1 positive : 4 negatives per
+    row, data/base_data.py:182-216): the engine stages the (user, item, rating) stream and runs the
+    resident epoch; the loss falls and the step counter equals the number of batches."""
+    import beta_recsys_amd as hp
+
+    g, U, I, positives = frame()
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=16, device_str="cuda:0", optimizer="adam", lr=0.01,
+                         batch_size=128, loss="bce"), "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = hp.MFEngine(cfg)
+        loader = hdata().instance_bce_loader(as_data(g, U, I), 128, "cuda:0", 2)
+        assert eng.prepare_epoch(loader) is not None          # resident path, not the per-batch loop
+        losses = []
+        for epoch in range(4):
+            eng.train_an_epoch(loader, epoch)
+            losses.append(eng.epoch_stats().loss_sum)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert eng.epoch_stats().step == 4 * len(loader)
