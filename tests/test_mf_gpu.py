@@ -675,3 +675,62 @@ def test_random_permutation_kernel(hip_device, n):
         d = np.diff(outs[0].astype(np.float64))
         assert abs(np.corrcoef(outs[0][:-1], outs[0][1:])[0, 1]) < 0.05
         assert abs((d > 0).mean() - 0.5) < 0.05
+
+
+@pytest.mark.parametrize("D,optimizer,reg", [(100, "adam", None), (200, "rmsprop", None), (256, "adam", 0.01),
+                                              (4, "sgd", None), (300, "adam", None)])
+def test_fused_epoch_other_widths_against_the_oracle(hip_device, D, optimizer, reg):
+    """The fused step kernel's other instantiations (2 and 4 columns per lane, non-multiples of 64, the
+    regularised loss) and the width (300 > 256) that must fall back to the two-kernel epoch: five
+    sequential batches vs the numpy oracle stepping the same batches."""
+    import beta_recsys_amd as hp
+
+    U, I, B = 500, 300, 96
+    rng = np.random.default_rng(D)
+    n = 4 * B + 17
+    triples = (rng.integers(0, U, n), rng.integers(0, 40, n), rng.integers(0, I, n))
+    w = onp.init_params(U, I, D, seed=D)
+    eng = make_engine(U, I, D, optimizer, "bpr", 0.02, B, reg=reg)
+    load_weights(eng, w)
+    loader = hp.DeviceTripleBatcher(*(torch.from_numpy(a).cuda() for a in triples), B, shuffle=False)
+    eng._setup()
+    assert eng._fused_ok(None) == (D <= 256)
+    st = onp.new_opt_state(w, optimizer)
+    total = 0.0
+    for k in range(0, n, B):
+        loss, _ = onp.mf_train_step(w, st, tuple(a[k:k + B] for a in triples), "bpr", optimizer, 0.02,
+                                    reg_coef=0.0 if reg is None else reg)
+        total += loss
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng.train_an_epoch(loader, 0)
+    stats = eng.epoch_stats()
+    assert stats.step == 5
+    assert_scalar_close(stats.loss_sum, total, 1e-5, "epoch loss sum")
+    got = get_weights(eng)
+    tol = 1e-5 if optimizer == "sgd" else 2e-3     # Adam / RMSprop: see helpers.optimizer_band
+    for k in KEYS:
+        assert_tensor_close(got[k], w[k], tol, f"fused epoch D={D} {k}")
+        if k == "global_bias":   # one element whose gradient is a cancelling sum: Adam's worst case
+            continue
+        close = np.abs(got[k] - w[k]) <= 1e-5 * max(np.abs(w[k]).max(), 1e-3)
+        assert close.mean() > 0.98, f"{k}: only {close.mean():.4f} of the elements agree to 1e-5"
+
+
+def test_fused_epoch_flags_out_of_range_ids_and_handles_empty_epochs(hip_device):
+    import beta_recsys_amd as hp
+
+    U, I, D, B = 50, 40, 64, 16
+    eng = make_engine(U, I, D, "adam", "bpr", 0.01, B)
+    w0 = get_weights(eng)
+    empty = hp.DeviceTripleBatcher(*(torch.zeros(0, dtype=torch.int64).cuda() for _ in range(3)), B, shuffle=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng.train_an_epoch(empty, 0)
+    assert eng.epoch_stats().step == 0
+    for k in KEYS:
+        assert np.array_equal(get_weights(eng)[k], w0[k])
+    users = torch.arange(2 * B) % U
+    users[5] = U + 3                                       # nn.Embedding would raise IndexError
+    bad = hp.DeviceTripleBatcher(users.cuda(), (torch.arange(2 * B) % I).cuda(), (torch.arange(2 * B) % I).cuda(),
+                                 B, shuffle=False)
+    with pytest.raises(IndexError), contextlib.redirect_stdout(io.StringIO()):
+        eng.train_an_epoch(bad, 1)
