@@ -594,10 +594,14 @@ __device__ __forceinline__ void fused_mma(f32x16& acc, const float* in, int ld_i
 }
 
 // ---- forward: gather -> tower -> affine_output -> sigmoid; writes act[0..L], mf, scores -----------------
-__global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(hiprec_ncf_plan p,
-                                                                       const int64_t* __restrict__ users,
-                                                                       const int64_t* __restrict__ items,
-                                                                       int64_t batch, hiprec_stats* stats) {
+// TRAIN: the head's backward half rides along (BCELoss term, d loss / d logit, dZ_L, dMF, d w_out,
+// the loss / d b_out partials) -- everything it needs is already in LDS, and a separate head launch
+// cost 12 us.
+template <bool TRAIN>
+__global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
+    hiprec_ncf_plan p, const int64_t* __restrict__ users, const int64_t* __restrict__ items,
+    const float* __restrict__ ratings, int64_t batch, float inv_batch, hiprec_stats* stats,
+    Scratch* scratch) {
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   const FusedLds L = fused_lds(lds_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -701,17 +705,71 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(hiprec_ncf
   float wout[3];  // nV <= 192
 #pragma unroll
   for (int k = 0; k < 3; ++k) wout[k] = lane + kWave * k < nV ? p.out_w[lane + kWave * k] : 0.f;
-  for (int r = wave; r < kFR; r += kFWaves) {
+  const bool stepper = TRAIN && blockIdx.x == 0 && tid == 0;
+  StepState step_state{};
+  if (stepper) step_state = step_load(stats);
+  float rt[kFR / kFWaves];
+  if (TRAIN) {
+#pragma unroll
+    for (int j = 0; j < kFR / kFWaves; ++j) {
+      const int64_t b = m0 + wave + j * kFWaves;
+      rt[j] = ratings[b < batch ? b : batch - 1];
+    }
+  }
+  float loss_acc = 0.f, gb_acc = 0.f;
+  float gw[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < kFR / kFWaves; ++j) {
+    const int r = wave + j * kFWaves;
     const int64_t b = m0 + r;
     if (b >= batch) continue;
+    float vec[3];
     float part = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int c = lane + kWave * k;
-      if (c < nV) part += (c < nH ? in[r * ld_h + c] : L.mf[r * kFLdE + (c - nH)]) * wout[k];
+      vec[k] = c < nH ? in[r * ld_h + c] : (c < nV ? L.mf[r * kFLdE + (c - nH)] : 0.f);
+      part += vec[k] * wout[k];
     }
     const float logit = wave_sum(part) + bo;
-    if (lane == 0) p.scores[b] = sigmoid_f32(logit);
+    const float y = sigmoid_f32(logit);
+    if (lane == 0) p.scores[b] = y;
+    if (!TRAIN) continue;
+    const float ly = fmaxf(logf(y), -100.f);
+    const float l1y = fmaxf(log1pf(-y), -100.f);
+    loss_acc += -(rt[j] * ly + (1.f - rt[j]) * l1y);
+    const float gy = (y - rt[j]) / fmaxf((1.f - y) * y, 1e-12f) * inv_batch;
+    const float dl = gy * ((1.f - y) * y);
+    gb_acc += dl;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int c = lane + kWave * k;
+      if (c < nV) gw[k] += dl * vec[k];
+      if (c < nH) {
+        // d loss / d z_L = d h_L * [h_L > 0]  (ReLU of the last Linear, applied twice in NeuMF)
+        p.dact[p.n_layers][b * nH + c] = vec[k] > 0.f ? dl * wout[k] : 0.f;
+      } else if (c < nV) {
+        p.dmf[b * E + (c - nH)] = dl * wout[k];
+      }
+    }
+  }
+  if (!TRAIN) return;
+  if (stepper) step_store_advanced(stats, step_state);
+  // d affine_output.weight: the waves' sums meet in LDS (the weight tile is free by now), one atomic
+  // per (block, column); loss partial (reg slot unused = 0), d b_out in the scalar-gradient slot
+  float* s_gw = L.bs;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int c = lane + kWave * k;
+    if (c < nV) s_gw[wave * (kFMaxN + kFMaxE) + c] = gw[k];
+  }
+  publish_partials<kFWaves>(loss_acc, 0.f, gb_acc, inv_batch, scratch);  // barriers inside
+  lds_barrier();
+  for (int c = tid; c < nV; c += kFThreads) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < kFWaves; ++w) t += s_gw[w * (kFMaxN + kFMaxE) + c];
+    if (t != 0.f) atomic_add_f32(p.g_out_w + c, t);
   }
 }
 
@@ -751,22 +809,34 @@ static int check_plan(const hiprec_ncf_plan* p, int64_t batch, bool train) {
 
 static int fused_attrs() {
   static int rc = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ncf_fused_forward_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ncf_fused_forward_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(kFusedLdsBytes));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(kFusedLdsBytes));
     return e == hipSuccess ? 0 : hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
   }();
   return rc;
 }
 
 // Tower forward.  Returns (through *scored) whether plan->scores already holds the sigmoid outputs.
+// With `ratings` (training) the fused launch also does the head's backward half; *scored then means
+// "plan->scores, dact[L], dmf, g_out_w and the loss partials are all in place".
 static int forward(const hiprec_ncf_plan* p, const int64_t* users, const int64_t* items,
-                   int64_t batch, hiprec_stats* stats, hipStream_t st, bool* scored) {
+                   int64_t batch, hiprec_stats* stats, hipStream_t st, bool* scored,
+                   const float* ratings = nullptr, float inv_batch = 0.f, Scratch* scratch = nullptr) {
   *scored = false;
   if (fusable(p)) {
     if (int rc = fused_attrs()) return rc;
     const int grid = static_cast<int>((batch + kFR - 1) / kFR);
-    ncf_fused_forward_kernel<<<grid, kFThreads, kFusedLdsBytes, st>>>(*p, users, items, batch, stats);
+    if (ratings)
+      ncf_fused_forward_kernel<true><<<grid, kFThreads, kFusedLdsBytes, st>>>(
+          *p, users, items, ratings, batch, inv_batch, stats, scratch);
+    else
+      ncf_fused_forward_kernel<false><<<grid, kFThreads, kFusedLdsBytes, st>>>(
+          *p, users, items, nullptr, batch, 0.f, stats, nullptr);
     HIPREC_TRY(hipGetLastError());
     *scored = true;
     return 0;
@@ -832,10 +902,14 @@ extern "C" int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int B = static_cast<int>(batch);
   bool scored = false;
-  if (int rc = forward(p, users, items, batch, stats, st, &scored)) return rc;
-  ncf_head_kernel<true><<<head_grid(batch, 4), kHeadBlock, 0, st>>>(
-      *p, ratings, batch, inv_batch, stats, static_cast<Scratch*>(scratch));
-  HIPREC_TRY(hipGetLastError());
+  if (int rc = forward(p, users, items, batch, stats, st, &scored, ratings, inv_batch,
+                       static_cast<Scratch*>(scratch)))
+    return rc;
+  if (!scored) {
+    ncf_head_kernel<true><<<head_grid(batch, 4), kHeadBlock, 0, st>>>(
+        *p, ratings, batch, inv_batch, stats, static_cast<Scratch*>(scratch));
+    HIPREC_TRY(hipGetLastError());
+  }
   if (p->dim_mlp > 0) {
     for (int l = p->n_layers - 1; l >= 0; --l) {
       const int nin = p->layer_in[l], nout = p->layer_out[l];

@@ -177,3 +177,25 @@ def test_ncf_full_size_c3_vs_oracle(hip_device):
         assert_tensor_close(grads[k].cpu().numpy(), g_ref[k], 2e-5, f"grad {k}", scale_floor=bias_floor(k))
     scores = eng.model.predict(users[:1000], items[:1000]).cpu().numpy()
     assert_tensor_close(scores, onc.ncf_predict(w, users[:1000], items[:1000], "neumf"), what="scores")
+
+
+@pytest.mark.parametrize("engine,kind,E,L,B", [("MLPEngine", "mlp", 32, 3, 1000), ("NeuMFEngine", "neumf", 16, 2, 77),
+                                                ("MLPEngine", "mlp", 64, 2, 333)])
+def test_fused_tower_shapes_vs_oracle(hip_device, engine, kind, E, L, B):
+    """Shapes that take the fused forward launch (2*dim_mlp <= 256, layer widths multiples of 32) in the
+    variants the goldens do not reach: the stand-alone MLP (no ReLU on the embeddings, no GMF half),
+    two-layer towers, ragged last blocks; gradients and scores vs the numpy oracle."""
+    U, I = 700, 500
+    torch.manual_seed(E + L)
+    eng = make_engine(engine, U, I, E, L, "adam", 1e-3, B)
+    w = get_weights(eng)
+    rng = np.random.default_rng(B)
+    users, items = rng.integers(0, U, B), rng.integers(0, I, B)
+    ratings = (rng.random(B) < 0.3).astype(np.float32)
+    loss_ref, g_ref, _ = onc.ncf_grads(w, users, items, ratings, kind)
+    loss, grads = eng.backward_only(torch.from_numpy(users), torch.from_numpy(items), torch.from_numpy(ratings))
+    assert_scalar_close(loss, loss_ref, what="loss")
+    for k in g_ref:
+        assert_tensor_close(grads[k].cpu().numpy(), g_ref[k], 2e-5, f"grad {k}", scale_floor=bias_floor(k))
+    scores = eng.model.predict(users[:200], items[:200]).cpu().numpy()
+    assert_tensor_close(scores, onc.ncf_predict(w, users[:200], items[:200], kind), what="scores")
