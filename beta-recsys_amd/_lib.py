@@ -89,6 +89,16 @@ class LightGcnPlan(Structure):
                [("zero_ws_floats", c_int64)]
 
 
+class DpStep(Structure):
+    """hiprec_dp_step (include/hiprec.h)."""
+
+    _fields_ = [("w", MfTables), ("g", MfTables), ("stats", c_void_p), ("scratch", c_void_p),
+                ("scratch_bytes", c_size_t), ("loss_reg_out", c_void_p), ("w_flat", c_void_p),
+                ("g_flat", c_void_p), ("m_flat", c_void_p), ("v_flat", c_void_p), ("n_flat", c_int64),
+                ("lr", c_double), ("beta1", c_double), ("beta2", c_double), ("eps", c_double),
+                ("reg_coef", c_float), ("loss_kind", c_int32), ("opt_kind", c_int32), ("_pad", c_int32)]
+
+
 # name -> (restype, argtypes); every symbol of include/hiprec.h must be listed here
 _P = c_void_p
 _T = POINTER(MfTables)
@@ -142,6 +152,9 @@ SIGNATURES = {
         [POINTER(LightGcnPlan), _P, c_float, _P, _P, _P, c_int64, c_float, _P, _P, c_size_t, _P],
     ),
     "hiprec_random_permutation": (c_int, [_P, c_int64, ctypes.c_uint64, _P]),
+    "hiprec_dp_step_bytes": (c_size_t, []),
+    "hiprec_mf_dp_step_begin": (c_int, [POINTER(DpStep), _P, _P, _P, c_int64, c_float, _P]),
+    "hiprec_mf_dp_step_end": (c_int, [POINTER(DpStep), _P]),
     "hiprec_sample_negatives": (
         c_int,
         [_P, _P, c_int64, c_int64, _P, c_int64, c_int32, ctypes.c_uint64, _P, _P, _P],
@@ -210,6 +223,8 @@ def load():
         raise RuntimeError("hiprec_stats layout mismatch between _lib.py and libhiprec.so")
     if lib.hiprec_lightgcn_plan_bytes() != ctypes.sizeof(LightGcnPlan):
         raise RuntimeError("hiprec_lightgcn_plan layout mismatch between _lib.py and libhiprec.so")
+    if lib.hiprec_dp_step_bytes() != ctypes.sizeof(DpStep):
+        raise RuntimeError("hiprec_dp_step layout mismatch between _lib.py and libhiprec.so")
     if lib.hiprec_ncf_plan_bytes() != ctypes.sizeof(NcfPlan):
         raise RuntimeError("hiprec_ncf_plan layout mismatch between _lib.py and libhiprec.so")
     _lib = lib

@@ -417,3 +417,26 @@ extern "C" int hiprec_mf_bce_epoch(const hiprec_mf_tables* w, const hiprec_mf_ta
   }
   return 0;
 }
+
+extern "C" size_t hiprec_dp_step_bytes(void) { return sizeof(hiprec_dp_step); }
+
+extern "C" int hiprec_mf_dp_step_begin(const hiprec_dp_step* c, const int64_t* users,
+                                       const int64_t* items_a, const void* third, int64_t batch,
+                                       float inv_batch_global, void* stream) {
+  HIPREC_REQUIRE(c != nullptr, "NULL step context");
+  int rc;
+  if (c->loss_kind == 0)
+    rc = hiprec_mf_bpr_grad(&c->w, &c->g, users, items_a, static_cast<const int64_t*>(third), nullptr, batch,
+                            inv_batch_global, c->reg_coef, c->stats, c->scratch, c->scratch_bytes, stream);
+  else
+    rc = hiprec_mf_bce_grad(&c->w, &c->g, users, items_a, static_cast<const float*>(third), nullptr, batch,
+                            inv_batch_global, c->reg_coef, c->stats, c->scratch, c->scratch_bytes, stream);
+  if (rc) return rc;
+  return hiprec_finalize_stats(c->stats, c->scratch, c->g.global_bias, c->loss_reg_out, stream);
+}
+
+extern "C" int hiprec_mf_dp_step_end(const hiprec_dp_step* c, void* stream) {
+  HIPREC_REQUIRE(c != nullptr, "NULL step context");
+  return hiprec_opt_dense_step(c->opt_kind, c->w_flat, c->g_flat, c->m_flat, c->v_flat, c->n_flat, c->lr,
+                               c->beta1, c->beta2, c->eps, c->stats, nullptr, -1, stream);
+}

@@ -54,7 +54,29 @@ class ReplicatedMFEngine(MFEngine):
             self._gb_ptr = self._g_ext.data_ptr() + 4 * (P - 1)
             self._tail_ptr = self._g_ext.data_ptr() + 4 * P
             self._rows_sgd = False  # replicas always take the dense sweep
+            self._dp_ctx = None
         return lib
+
+    def _step_context(self):
+        """hiprec_dp_step with every per-engine constant: the step is then two short C calls around
+        the collective (the replicated engine is host-bound whenever the all-reduce is short)."""
+        m, opt = self.model, self.optimizer
+        key = (m.flat.data_ptr(), self._g_ext.data_ptr(), opt.lr, float(self.reg), self.loss)
+        if self._dp_ctx is None or self._dp_ctx[0] != key:
+            c = _lib.DpStep()
+            c.w, c.g = m.tables(), m.tables(self._g_flat)
+            c.stats, c.scratch, c.scratch_bytes = self._stats.data_ptr(), self._scratch.data_ptr(), self._scratch.numel()
+            c.loss_reg_out = self._tail_ptr
+            c.w_flat, c.g_flat = m.flat.data_ptr(), self._g_flat.data_ptr()
+            c.m_flat = None if opt.exp_avg is None else opt.exp_avg.data_ptr()
+            c.v_flat = None if opt.exp_avg_sq is None else opt.exp_avg_sq.data_ptr()
+            c.n_flat = m.flat.numel()
+            c.lr, c.beta1, c.beta2, c.eps = opt.lr, opt.beta1, opt.beta2, opt.eps
+            c.reg_coef = float(self.reg)
+            c.loss_kind = 0 if self.loss == "bpr" else 1
+            c.opt_kind = opt.kind
+            self._dp_ctx = (key, c, ctypes.byref(c))
+        return self._dp_ctx[2]
 
     def _enqueue_step(self, batch_data):
         users, a_items, third = self._prepare_batch(batch_data)
@@ -66,28 +88,18 @@ class ReplicatedMFEngine(MFEngine):
         self._enqueue_core(users, a_items, third)
 
     def _enqueue_core(self, users, a_items, third):
-        """Four launches: grad, finalize (+ loss/reg into the tail of the gradient buffer), ONE
-        all-reduce of [gradient | loss | reg], dense optimizer sweep.  The epoch sums are kept as
-        per-rank shares in hiprec_stats (they are linear) and all-reduced once per epoch."""
+        """Two C calls around ONE all-reduce of [gradient | loss | reg]: hiprec_mf_dp_step_begin
+        (gradient kernel + reduction of the loss partials into the buffer's tail), the collective,
+        hiprec_mf_dp_step_end (dense optimizer sweep).  The epoch sums are kept as per-rank shares in
+        hiprec_stats (they are linear) and all-reduced once per epoch."""
         lib = self._setup()
-        m, opt = self.model, self.optimizer
-        st = _lib.stream_ptr(m.flat.device)
-        P = m.flat.numel()
-        w, g = m.tables(), m.tables(self._g_flat)
-        B_global = users.numel() * self.world  # every rank feeds the same local batch size
-        fn = lib.hiprec_mf_bpr_grad if self.loss == "bpr" else lib.hiprec_mf_bce_grad
-        _lib.check(fn(
-            ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(a_items), _lib.ptr(third),
-            None, users.numel(), 1.0 / B_global, float(self.reg), _lib.ptr(self._stats),
-            _lib.ptr(self._scratch), self._scratch.numel(), st))
-        _lib.check(lib.hiprec_finalize_stats(
-            _lib.ptr(self._stats), _lib.ptr(self._scratch), ctypes.c_void_p(self._gb_ptr),
-            ctypes.c_void_p(self._tail_ptr), st))
+        ctx = self._step_context()
+        st = _lib.stream_ptr(self.model.flat.device)
+        n = users.numel()
+        _lib.check(lib.hiprec_mf_dp_step_begin(
+            ctx, users.data_ptr(), a_items.data_ptr(), third.data_ptr(), n, 1.0 / (n * self.world), st))
         allreduce_sum_(self._g_ext, self.pg)
-        _lib.check(lib.hiprec_opt_dense_step(
-            opt.kind, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),
-            _lib.ptr(opt.exp_avg_sq), P, opt.lr, opt.beta1, opt.beta2, opt.eps,
-            _lib.ptr(self._stats), None, -1, st))
+        _lib.check(lib.hiprec_mf_dp_step_end(ctx, st))
 
     def _sync_stats(self):
         """Global (all-reduced) loss / reg of the last step replace the local shares in stats."""

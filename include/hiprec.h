@@ -242,6 +242,39 @@ int hiprec_mf_bpr_epoch_sgd_fused(float* const* w_flat, float* const* g_flat, vo
                                   int64_t n_triples, int64_t batch, float reg_coef, double lr,
                                   hiprec_stats* stats, int32_t* final_index, void* stream);
 
+/* ---- the data-parallel (replicated-table) step, split around its one collective:
+ *        begin = zero_grad + forward + loss + backward on the local share of the global batch, then
+ *                the reduction of the loss partials: the scalar-bias gradient lands in its slot of g,
+ *                {loss, reg} in the two floats that follow the gradient (loss_reg_out), so that ONE
+ *                all-reduce of [g | loss | reg] moves everything;
+ *        (the caller all-reduces that buffer over RCCL)
+ *        end   = the dense optimizer sweep over the summed gradient.
+ *      Semantically hiprec_mf_{bpr,bce}_grad + hiprec_finalize_stats, and hiprec_opt_dense_step; the
+ *      context carries every per-engine constant so that the host pays two short calls per step
+ *      (the replicated engine is host-bound at world sizes whose all-reduce is short). */
+typedef struct hiprec_dp_step {
+  hiprec_mf_tables w, g;
+  hiprec_stats* stats;
+  void* scratch;
+  size_t scratch_bytes;
+  float* loss_reg_out; /* the two floats after the gradient in the all-reduced buffer */
+  float* w_flat;       /* flat views of w / g / optimizer state (hiprec_opt_dense_step) */
+  float* g_flat;
+  float* m_flat;
+  float* v_flat;
+  int64_t n_flat;
+  double lr, beta1, beta2, eps;
+  float reg_coef;
+  int32_t loss_kind; /* 0 = BPR (third = negative items, int64), 1 = BCE (third = ratings, fp32) */
+  int32_t opt_kind;  /* HIPREC_OPT_* */
+  int32_t _pad;
+} hiprec_dp_step;
+
+size_t hiprec_dp_step_bytes(void);
+int hiprec_mf_dp_step_begin(const hiprec_dp_step* c, const int64_t* users, const int64_t* items_a,
+                            const void* third, int64_t batch, float inv_batch_global, void* stream);
+int hiprec_mf_dp_step_end(const hiprec_dp_step* c, void* stream);
+
 /* ======================= NCF family: NeuMF / GMF / MLP (models/ncf.py, gmf.py, mlp.py) ============ */
 
 #define HIPREC_NCF_MAX_LAYERS 8
