@@ -20,7 +20,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .mf import MFEngine, read_stats
+from .mf import MFEngine
 
 
 def allreduce_sum_(buf, group=None):

@@ -26,7 +26,6 @@ import contextlib
 import ctypes
 import io
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

@@ -9,7 +9,6 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_golden
 from oracle import sampler_numpy as osn
 from test_oracle_golden_sampler import check_support, frame, pooled_chi2
 

@@ -261,7 +261,6 @@ def test_ncf_family_init_and_state_dict_match_reference(case, engine):
 
 def test_lightgcn_init_and_surface_on_cpu():
     """Same seed -> the reference's xavier init; reference state_dict keys; no CPU compute path."""
-    import scipy.sparse as sp
 
     import beta_recsys_amd as hp
 

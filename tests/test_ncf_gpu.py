@@ -5,7 +5,6 @@ Tolerances: 1e-5 relative (to the tensor's scale) on loss and gradients — the 
 fmaf chain, only the summation order differs from MKL's; optimizer updates within 1e-5 of the update
 scale plus the Adam/RMSprop conditioning band (see tests/helpers.py::optimizer_band)."""
 import contextlib
-import ctypes
 import io
 
 import numpy as np
