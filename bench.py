@@ -294,7 +294,6 @@ def bench_lightgcn(args, device):
     """BASELINE configs[4]: LightGCN on an ML-1M-sized graph (~1M interactions, nnz ~2M), 3 layers,
     dim 64, batch 1024 triples, keep_pro 0.6 (device-side edge dropout), Adam lr 0.05."""
     import beta_recsys_amd as hp
-    from oracle.lightgcn_numpy import build_norm_adj  # graph construction only (one-off, host)
 
     L, Bl = 3, 1024
     rng = np.random.default_rng(0)
@@ -302,7 +301,16 @@ def bench_lightgcn(args, device):
     p = 1.0 / np.arange(1, I + 1) ** 0.9
     eu = rng.integers(0, U, n_edges)
     ei = rng.permutation(I)[rng.choice(I, n_edges, p=p / p.sum())]
-    adj = build_norm_adj(U, I, eu, ei).tocoo()
+    # the reference's norm_adj = D^-1 (A + I) over users + items (data/deprecated_data_base.py:331-353 +
+    # utils/common_util.py normalized_adj_single), built once on the host like the reference does
+    import scipy.sparse as sp
+
+    n_nodes = U + I
+    rows, cols = np.concatenate([eu, ei + U]), np.concatenate([ei + U, eu])
+    a = sp.coo_matrix((np.ones(len(rows), dtype=np.float32), (rows, cols)), shape=(n_nodes, n_nodes)).tocsr()
+    a.data[:] = 1.0  # duplicate interactions are one edge
+    a = a + sp.eye(n_nodes, dtype=np.float32, format="csr")
+    adj = sp.diags(1.0 / np.asarray(a.sum(1)).flatten()).dot(a).astype(np.float32).tocoo()
     idx = torch.from_numpy(np.vstack((adj.row, adj.col)).astype(np.int64))
     norm = torch.sparse_coo_tensor(idx, torch.from_numpy(adj.data), torch.Size(adj.shape))
     cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, layer_size=[D] * L, keep_pro=0.6, regs=[1e-5],

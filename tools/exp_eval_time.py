@@ -1,4 +1,4 @@
-"""Time hiprec_rank_metrics at ML-1M evaluation sizes; the numpy oracle on a bounded sample beside it."""
+"""Time hiprec_rank_metrics at ML-1M evaluation sizes."""
 import json
 import os
 import sys
@@ -10,7 +10,6 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from beta_recsys_amd import eval as hev  # noqa: E402
-from oracle import eval_numpy as oev  # noqa: E402
 
 dev = torch.device("cuda:0")
 gen = torch.Generator().manual_seed(0)
@@ -50,12 +49,6 @@ for name, U, C, pos in (("leave_one_out_6040x101", 6040, 101, None), ("full_cata
     e1.record()
     torch.cuda.synchronize()
     kern_ms = e0.elapsed_time(e1) / reps
-    sub = min(U, 600)
-    hu, hr, hs = (x[: sub * C].cpu().numpy() for x in (users, ratings, scores))
-    t0 = time.perf_counter()
-    oev.rank_metrics(hu, hr, hs, ks)
-    cpu_ms_full = (time.perf_counter() - t0) * 1e3 * U / sub
     out[name] = dict(rows=U * C, end_to_end_ms=round(gpu_ms, 3), kernels_ms=round(kern_ms, 3),
-                     rows_per_s=round(U * C / (kern_ms * 1e-3)), numpy_oracle_ms_extrapolated=round(cpu_ms_full, 1),
-                     ndcg_at_10=float(table[1, 2]))
+                     rows_per_s=round(U * C / (kern_ms * 1e-3)), ndcg_at_10=float(table[1, 2]))
 print(json.dumps(out))
