@@ -225,17 +225,19 @@ def bench_ncf(args, device):
     print(json.dumps(out), flush=True)
 
 
-def bench_mf_c4shard(args, device):
-    """One rank's share of BASELINE configs[3] (10M users x 1M items, dim 128, 8 GPUs): tables of
-    1.25M x 128 and 125k x 128 (HBM-resident, 0.7 GB + as much gradient), batch 65536, exact SGD on the
-    touched rows.  No exchange is timed here: this is the HBM-bound regime of the SAME gradient kernel
-    the headline runs in its cache-resident regime."""
+def bench_mf_c4shard(args, device, full=False):
+    """BASELINE configs[3] (10M users x 1M items, dim 128) in the HBM-resident regime of the SAME
+    gradient kernel the headline runs in its cache-resident regime, batch 65536, exact SGD on the
+    touched rows.  `full=False`: one rank's share of the 8-GPU layout (1.25M x 128 and 125k x 128
+    rows, 0.7 GB + as much gradient), no exchange timed.  `full=True`: the WHOLE configuration on
+    one MI355X -- 5.7 GB of tables + 5.7 GB of dense gradient buffer fit 288 GB of HBM many times
+    over, so a single GPU needs no sharding and no all-to-all at all for this size."""
     import ctypes
 
     import beta_recsys_amd as hp
     from beta_recsys_amd import _lib
 
-    Uc, Ic, Dc, Bc = 1_250_000, 125_000, 128, 65536
+    Uc, Ic, Dc, Bc = (10_000_000, 1_000_000, 128, 65536) if full else (1_250_000, 125_000, 128, 65536)
     cfg = {"model": dict(n_users=Uc, n_items=Ic, emb_dim=Dc, device_str=str(device), optimizer="sgd",
                          lr=LR, batch_size=Bc, loss="bpr", sgd_mode="rows"),
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
@@ -280,8 +282,10 @@ def bench_mf_c4shard(args, device):
     out = {"metric": "training interactions/sec (BPR triples)", "value": steps * Bc / dt, "unit": "triples/s",
            "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": dt / steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "BPR-MF, one rank's shard of BASELINE configs[3]: 1.25M x 125k rows, dim 128, "
-                                  "batch 65536, exact SGD on touched rows (no exchange timed)",
+           "config": {"workload": ("BPR-MF, BASELINE configs[3] whole on one GPU: 10M x 1M rows, dim 128, batch "
+                                   "65536, exact SGD on touched rows" if full else
+                                   "BPR-MF, one rank's shard of BASELINE configs[3]: 1.25M x 125k rows, dim 128, "
+                                   "batch 65536, exact SGD on touched rows (no exchange timed)"),
                       "last_loss": st.loss},
            "roofline": {"bound": "hbm", "kernel": "mf_bpr_grad_kernel<2>", "achieved": bpt * Bc / k_s / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bpt * Bc / k_s / 1e9 / HBM_PEAK_GBS,
@@ -361,7 +365,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--two-kernel", action="store_true",
                     help="mf: gradient kernel + dense optimizer sweep per step instead of the fused one-kernel step")
-    ap.add_argument("--workload", default="mf", choices=["mf", "ncf", "lightgcn", "mf-c4shard"],
+    ap.add_argument("--workload", default="mf", choices=["mf", "ncf", "lightgcn", "mf-c4shard", "mf-c4"],
                     help="mf = BASELINE configs[1] (the headline); ncf = configs[2] (NeuMF, emb_dim 32)")
     ap.add_argument("--multi-gpu", default="auto", choices=["auto", "replicated", "sharded"],
                     help="N>1: replicate small tables (gradient all-reduce) or row-shard them "
@@ -391,8 +395,8 @@ def main():
         return bench_ncf(args, device)
     if args.workload == "lightgcn":
         return bench_lightgcn(args, device)
-    if args.workload == "mf-c4shard":
-        return bench_mf_c4shard(args, device)
+    if args.workload in ("mf-c4shard", "mf-c4"):
+        return bench_mf_c4shard(args, device, full=args.workload == "mf-c4")
 
     n_total = (args.warmup + args.steps) * B
     users, pos, neg = (t.to(device) for t in synth_triples(n_total, seed=100 + rank))

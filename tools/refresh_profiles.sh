@@ -6,7 +6,7 @@ for o in adam sgd rmsprop; do
   timeout 200 python bench.py --optimizer $o > $OUT/r01_bench_$o.json 2> $OUT/r01_bench_$o.err
   tail -c 300 $OUT/r01_bench_$o.json | head -c 120; echo
 done
-for w in ncf lightgcn mf-c4shard; do
+for w in ncf lightgcn mf-c4shard mf-c4; do
   timeout 300 python bench.py --workload $w > $OUT/r01_bench_$w.json 2> $OUT/r01_bench_$w.err
   head -c 240 $OUT/r01_bench_$w.json; echo
 done
