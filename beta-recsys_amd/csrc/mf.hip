@@ -745,20 +745,20 @@ __global__ __launch_bounds__(kBlock) void mf_predict_kernel(hiprec_mf_tables w,
 // Exact SGD on the rows a batch touched.  One wave per triple: lanes 0..2 race (one returning
 // atomicExch each, all three in flight together) for the stamps of the triple's user / item rows;
 // the single winner of a row applies w -= lr*g and clears g.
-__device__ __forceinline__ void sgd_apply_row(float* __restrict__ wrow, float* __restrict__ grow,
-                                              float* wb, float* gb, int D, float lr, int lane) {
-  for (int c = lane; c < D; c += kWave) {
-    const float gv = grow[c];
-    wrow[c] = wrow[c] - lr * gv;
-    grow[c] = 0.f;
-  }
-  if (lane == 0) {
-    const float gv = *gb;
-    *wb = *wb - lr * gv;
-    *gb = 0.f;
-  }
-}
+// NPL = columns per lane (dim <= 64 * NPL; 0 = any dim, rows streamed).  A trip is one triple: the
+// stamps of its three rows are raced first, then the gradient and weight rows of EVERY row this wave
+// won are requested together and only then updated and stored, and the next trip's indices are
+// already on their way -- the first version took the rows one after the other (five dependent
+// memory round trips per trip, 135 us per 65 536-triple step at the configs[3] size; the gradient
+// kernel of the same step takes 100).
+struct RowPtrs {
+  float* w;
+  float* g;
+  float* wb;
+  float* gb;
+};
 
+template <int NPL>
 __global__ __launch_bounds__(kBlock) void mf_sgd_rows_kernel(
     hiprec_mf_tables w, hiprec_mf_tables g, const int64_t* __restrict__ users,
     const int64_t* __restrict__ items_a, const int64_t* __restrict__ items_b,
@@ -768,27 +768,89 @@ __global__ __launch_bounds__(kBlock) void mf_sgd_rows_kernel(
   const int D = w.dim;
   const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
   const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  constexpr int R = NPL > 0 ? NPL : 1;
+
+  auto load_idx = [&](int64_t t, int64_t& u, int64_t& a, int64_t& b) {
+    u = a = b = -1;
+    if (t < batch) {
+      const int64_t j = perm ? perm[t] : t;
+      u = users[j];
+      a = items_a[j];
+      b = items_b ? items_b[j] : a;
+    }
+  };
+  int64_t u, a, b;
+  load_idx(wave0, u, a, b);
   for (int64_t t = wave0; t < batch; t += n_waves) {
-    const int64_t j = perm ? perm[t] : t;
-    const int64_t u = users[j], a = items_a[j];
-    const int64_t b = items_b ? items_b[j] : a;
-    if (static_cast<uint64_t>(u) >= static_cast<uint64_t>(w.n_users) ||
-        static_cast<uint64_t>(a) >= static_cast<uint64_t>(w.n_items) ||
-        static_cast<uint64_t>(b) >= static_cast<uint64_t>(w.n_items))
-      continue;  // flagged by the grad kernel, which skipped it too
+    int64_t nu, na, nb;
+    load_idx(t + n_waves, nu, na, nb);  // next trip's indices travel during this trip
+    const bool ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(w.n_users) &&
+                    static_cast<uint64_t>(a) < static_cast<uint64_t>(w.n_items) &&
+                    static_cast<uint64_t>(b) < static_cast<uint64_t>(w.n_items);
+    // (a triple with an out-of-range id was flagged and skipped by the grad kernel too)
     int won = 0;
-    if (lane == 0) won = atomicExch(user_stamp + u, stamp) != stamp;
-    else if (lane == 1) won = atomicExch(item_stamp + a, stamp) != stamp;
-    else if (lane == 2 && items_b && b != a) won = atomicExch(item_stamp + b, stamp) != stamp;
-    const int won_u = __builtin_amdgcn_readlane(won, 0);
-    const int won_a = __builtin_amdgcn_readlane(won, 1);
-    const int won_b = __builtin_amdgcn_readlane(won, 2);
-    if (won_u)
-      sgd_apply_row(w.user_emb + u * D, g.user_emb + u * D, w.user_bias + u, g.user_bias + u, D, lr, lane);
-    if (won_a)
-      sgd_apply_row(w.item_emb + a * D, g.item_emb + a * D, w.item_bias + a, g.item_bias + a, D, lr, lane);
-    if (won_b)
-      sgd_apply_row(w.item_emb + b * D, g.item_emb + b * D, w.item_bias + b, g.item_bias + b, D, lr, lane);
+    if (ok) {
+      if (lane == 0) won = atomicExch(user_stamp + u, stamp) != stamp;
+      else if (lane == 1) won = atomicExch(item_stamp + a, stamp) != stamp;
+      else if (lane == 2 && items_b && b != a) won = atomicExch(item_stamp + b, stamp) != stamp;
+    }
+    const bool won_r[3] = {__builtin_amdgcn_readlane(won, 0) != 0, __builtin_amdgcn_readlane(won, 1) != 0,
+                           __builtin_amdgcn_readlane(won, 2) != 0};
+    // rows this wave does not own point at row 0 (valid memory): their loads stay unconditional
+    // and branch-free, only the stores are guarded
+    const int64_t ru = won_r[0] ? u : 0, ra = won_r[1] ? a : 0, rb = won_r[2] ? b : 0;
+    const RowPtrs rows[3] = {{w.user_emb + ru * D, g.user_emb + ru * D, w.user_bias + ru, g.user_bias + ru},
+                             {w.item_emb + ra * D, g.item_emb + ra * D, w.item_bias + ra, g.item_bias + ra},
+                             {w.item_emb + rb * D, g.item_emb + rb * D, w.item_bias + rb, g.item_bias + rb}};
+    if constexpr (NPL > 0) {
+      float wv[3][R], gv[3][R], wbv[3], gbv[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const int c = lane + kWave * k;
+          const int cc = c < D ? c : D - 1;
+          gv[q][k] = rows[q].g[cc];
+          wv[q][k] = rows[q].w[cc];
+        }
+        gbv[q] = *rows[q].gb;
+        wbv[q] = *rows[q].wb;
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if (!won_r[q]) continue;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const int c = lane + kWave * k;
+          if (c < D) {
+            rows[q].w[c] = wv[q][k] - lr * gv[q][k];
+            rows[q].g[c] = 0.f;
+          }
+        }
+        if (lane == 0) {
+          *rows[q].wb = wbv[q] - lr * gbv[q];
+          *rows[q].gb = 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if (!won_r[q]) continue;
+        for (int c = lane; c < D; c += kWave) {
+          const float gvv = rows[q].g[c];
+          rows[q].w[c] = rows[q].w[c] - lr * gvv;
+          rows[q].g[c] = 0.f;
+        }
+        if (lane == 0) {
+          const float gvv = *rows[q].gb;
+          *rows[q].wb = *rows[q].wb - lr * gvv;
+          *rows[q].gb = 0.f;
+        }
+      }
+    }
+    u = nu;
+    a = na;
+    b = nb;
   }
   if (blockIdx.x == 0) {
     const float gb_part = scratch ? finalize_partials(stats, scratch) : 0.f;
@@ -914,11 +976,13 @@ extern "C" int hiprec_mf_sgd_rows(const hiprec_mf_tables* w, const hiprec_mf_tab
   if (int rc = check_same_shape(w, g)) return rc;
   HIPREC_REQUIRE(users && items_a && user_stamp && item_stamp && stats, "NULL pointer");
   HIPREC_REQUIRE(batch >= 0, "negative batch");
-  mf_sgd_rows_kernel<<<grid_for_waves(batch), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
-      *w, *g, users, items_a, items_b, perm, batch, static_cast<float>(lr), user_stamp, item_stamp, stamp, stats,
-      static_cast<const Scratch*>(scratch));
-  HIPREC_TRY(hipGetLastError());
-  return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int grid = grid_for_waves(batch);
+  return dispatch_npl(w->dim, [&](auto npl) {
+    mf_sgd_rows_kernel<decltype(npl)::value><<<grid, kBlock, 0, st>>>(
+        *w, *g, users, items_a, items_b, perm, batch, static_cast<float>(lr), user_stamp, item_stamp, stamp,
+        stats, static_cast<const Scratch*>(scratch));
+  });
 }
 
 // One epoch of BPR-MF with ONE kernel per step (see mf_bpr_fused_kernel).
