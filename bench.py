@@ -455,14 +455,20 @@ def main():
             step_fn = lambda batch: seng.train_single_batch(batch, sync=False)  # noqa: E731
             check_fn = seng.k.check_status
         else:
-            step_fn = lambda batch: seng.enqueue_presorted(*batch)  # noqa: E731
+            # resident data-parallel epoch: one fused launch + one all-reduce per step; the sweep-only
+            # flush that applies the last update is part of the timed region
+            step_fn = lambda batch: seng.fused_step(*batch)  # noqa: E731
             check_fn = seng.epoch_stats
 
         def run(lo, n_steps):
             last = None
+            if mode != "sharded":
+                seng.fused_epoch_begin()
             for sidx in range(n_steps):
                 sl = slice(lo + sidx * B, lo + (sidx + 1) * B)
                 last = step_fn((users[sl], pos[sl], neg[sl]))
+            if mode != "sharded":
+                seng.fused_epoch_end()
             return last
 
         run(0, args.warmup)
@@ -475,7 +481,10 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        check_fn()
+        st = check_fn()
+        if mode != "sharded":   # the replicas' loss sums are global: same sanity window as the single-GPU path
+            assert st.step == args.warmup + args.steps, (st.step, args.warmup + args.steps)
+            assert np.isfinite(st.loss_sum) and 0.3 < st.loss_sum / args.steps < 1.4, st.loss_sum
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -488,8 +497,8 @@ def main():
         parallelism = (f"row-sharded tables over {world} GPUs (owner = row mod {world}), all-to-all "
                        "routing of triples / item rows / item gradients over RCCL"
                        if mode == "sharded" else
-                       f"dp{world}: replicated 2.5 MB tables, one RCCL all-reduce of the dense "
-                       "gradient per step, global batch = N x 4096")
+                       f"dp{world}: replicated 2.5 MB tables, one fused launch + one RCCL all-reduce of the "
+                       "dense gradient per step, global batch = N x 4096")
     if rank == 0:
         k_mean, k_med = kernel_timing(eng, prepared)
         bpt = algorithmic_bytes_per_triple(D)

@@ -89,6 +89,16 @@ class LightGcnPlan(Structure):
                [("zero_ws_floats", c_int64)]
 
 
+class FusedStep(Structure):
+    """hiprec_fused_step (include/hiprec.h)."""
+
+    _fields_ = [("kind", c_int32), ("dim", c_int32), ("n_users", c_int64), ("n_items", c_int64)] + \
+               [(n, c_void_p) for n in ("w_read", "g_prev", "m_read", "v_read", "w_write", "m_write", "v_write",
+                                        "g_cur", "g_zero", "scratch_prev", "scratch_cur")] + \
+               [("lr", c_double), ("beta1", c_double), ("beta2", c_double), ("eps", c_double),
+                ("reg_coef", c_float), ("_pad", c_int32)]
+
+
 class DpStep(Structure):
     """hiprec_dp_step (include/hiprec.h)."""
 
@@ -152,6 +162,8 @@ SIGNATURES = {
         [POINTER(LightGcnPlan), _P, c_float, _P, _P, _P, c_int64, c_float, _P, _P, c_size_t, _P],
     ),
     "hiprec_random_permutation": (c_int, [_P, c_int64, ctypes.c_uint64, _P]),
+    "hiprec_fused_step_bytes": (c_size_t, []),
+    "hiprec_mf_bpr_fused_step": (c_int, [POINTER(FusedStep), _P, _P, _P, c_int64, c_int64, c_float, _P, _P]),
     "hiprec_dp_step_bytes": (c_size_t, []),
     "hiprec_mf_dp_step_begin": (c_int, [POINTER(DpStep), _P, _P, _P, c_int64, c_float, _P]),
     "hiprec_mf_dp_step_end": (c_int, [POINTER(DpStep), _P]),
@@ -223,6 +235,8 @@ def load():
         raise RuntimeError("hiprec_stats layout mismatch between _lib.py and libhiprec.so")
     if lib.hiprec_lightgcn_plan_bytes() != ctypes.sizeof(LightGcnPlan):
         raise RuntimeError("hiprec_lightgcn_plan layout mismatch between _lib.py and libhiprec.so")
+    if lib.hiprec_fused_step_bytes() != ctypes.sizeof(FusedStep):
+        raise RuntimeError("hiprec_fused_step layout mismatch between _lib.py and libhiprec.so")
     if lib.hiprec_dp_step_bytes() != ctypes.sizeof(DpStep):
         raise RuntimeError("hiprec_dp_step layout mismatch between _lib.py and libhiprec.so")
     if lib.hiprec_ncf_plan_bytes() != ctypes.sizeof(NcfPlan):

@@ -1005,26 +1005,26 @@ static int launch_fused(int dim, int grid, size_t lds, hipStream_t st, const hip
   return 0;
 }
 
-extern "C" int hiprec_mf_bpr_epoch_fused(int kind, float* const* w_flat, float* const* g_flat,
-                                         float* const* m_flat, float* const* v_flat,
-                                         void* const* scratch2, int64_t n_users, int64_t n_items,
-                                         int32_t dim, const int64_t* users, const int64_t* pos,
-                                         const int64_t* neg, int64_t n_triples, int64_t batch,
-                                         float reg_coef, double lr, double beta1, double beta2,
-                                         double eps, hiprec_stats* stats, int32_t* final_index,
-                                         void* stream) {
+// One launch of the fused sequence with explicitly named buffers (see hiprec_fused_step in hiprec.h).
+extern "C" int hiprec_mf_bpr_fused_step(const hiprec_fused_step* c, const int64_t* users,
+                                        const int64_t* pos, const int64_t* neg, int64_t batch,
+                                        int64_t prev_batch, float inv_batch, hiprec_stats* stats,
+                                        void* stream) {
+  HIPREC_REQUIRE(c && stats, "NULL step / stats");
+  const int kind = c->kind;
   HIPREC_REQUIRE(kind == HIPREC_OPT_SGD || kind == HIPREC_OPT_ADAM || kind == HIPREC_OPT_RMSPROP,
                  "unknown optimizer kind %d", kind);
-  HIPREC_REQUIRE(w_flat && g_flat && scratch2 && final_index && stats, "NULL pointer");
-  HIPREC_REQUIRE(w_flat[0] && w_flat[1] && g_flat[0] && g_flat[1] && g_flat[2] && scratch2[0] &&
-                     scratch2[1], "NULL buffer");
   const bool has_m = kind == HIPREC_OPT_ADAM, has_v = kind != HIPREC_OPT_SGD;
-  HIPREC_REQUIRE(!has_m || (m_flat && m_flat[0] && m_flat[1]), "Adam needs m_flat[2]");
-  HIPREC_REQUIRE(!has_v || (v_flat && v_flat[0] && v_flat[1]), "Adam/RMSprop need v_flat[2]");
-  HIPREC_REQUIRE(n_users > 0 && n_items > 0 && dim > 0 && dim <= 256, "fused step needs dim <= 256");
-  HIPREC_REQUIRE(n_triples >= 0 && batch > 0, "bad n_triples/batch");
-  HIPREC_REQUIRE(n_triples == 0 || (users && pos && neg), "NULL index arrays");
+  HIPREC_REQUIRE(c->w_read && c->w_write && c->g_prev && c->g_cur && c->g_zero && c->scratch_prev &&
+                     c->scratch_cur, "NULL buffer");
+  HIPREC_REQUIRE(!has_m || (c->m_read && c->m_write), "Adam needs m_read / m_write");
+  HIPREC_REQUIRE(!has_v || (c->v_read && c->v_write), "Adam/RMSprop need v_read / v_write");
+  HIPREC_REQUIRE(c->n_users > 0 && c->n_items > 0 && c->dim > 0 && c->dim <= 256, "fused step needs dim <= 256");
+  HIPREC_REQUIRE(batch >= 0 && prev_batch >= 0, "negative batch");
+  HIPREC_REQUIRE(batch == 0 || (users && pos && neg), "NULL index arrays");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t n_users = c->n_users, n_items = c->n_items;
+  const int dim = c->dim;
   const int64_t n_flat = (n_users + n_items) * (static_cast<int64_t>(dim) + 1) + 1;
   auto tables = [&](float* flat) {
     hiprec_mf_tables t;
@@ -1039,62 +1039,100 @@ extern "C" int hiprec_mf_bpr_epoch_fused(int kind, float* const* w_flat, float* 
     t._pad = 0;
     return t;
   };
-  if (int rc = hiprec_stats_begin_epoch(stats, stream)) return rc;
+  FusedOpt f;
+  f.gp = tables(const_cast<float*>(c->g_prev));
+  f.mp = tables(has_m ? const_cast<float*>(c->m_read) : nullptr);
+  f.vp = tables(has_v ? const_cast<float*>(c->v_read) : nullptr);
+  f.w_read = c->w_read;
+  f.g_prev = c->g_prev;
+  f.m_read = has_m ? c->m_read : nullptr;
+  f.v_read = has_v ? c->v_read : nullptr;
+  f.w_write = c->w_write;
+  f.m_write = has_m ? c->m_write : nullptr;
+  f.v_write = has_v ? c->v_write : nullptr;
+  f.g_zero = c->g_zero;
+  f.n_flat = n_flat;
+  f.s = OptScalars{c->lr,
+                   static_cast<float>(c->lr),
+                   static_cast<float>(c->beta2),
+                   static_cast<float>(1.0 - c->beta1),
+                   static_cast<float>(1.0 - c->beta2),
+                   static_cast<float>(c->eps)};
+  f.n_gather_blocks = batch > 0 ? std::min(agg_grid(batch), kFusedMaxGather) : 0;
+  f.n_prev_partials = prev_batch > 0 ? std::min(agg_grid(prev_batch), kFusedMaxGather) : 0;
+  f.apply_prev = prev_batch > 0 ? 1 : 0;
+  f.scratch_prev = static_cast<const Scratch*>(c->scratch_prev);
+  Scratch* sc = static_cast<Scratch*>(c->scratch_cur);
+  const hiprec_mf_tables w = tables(const_cast<float*>(c->w_read)), g = tables(c->g_cur);
   const size_t lds = agg_lds_bytes(dim);
   const int n_sweep = static_cast<int>(std::min<int64_t>(256, (n_flat / 4 + kAggBlock - 1) / kAggBlock));
+  const int grid = f.n_gather_blocks + n_sweep;
+  int rc;
+  if (kind == HIPREC_OPT_SGD)
+    rc = launch_fused<HIPREC_OPT_SGD>(dim, grid, lds, st, w, g, f, users, pos, neg, batch, inv_batch, c->reg_coef, stats, sc);
+  else if (kind == HIPREC_OPT_ADAM)
+    rc = launch_fused<HIPREC_OPT_ADAM>(dim, grid, lds, st, w, g, f, users, pos, neg, batch, inv_batch, c->reg_coef, stats, sc);
+  else
+    rc = launch_fused<HIPREC_OPT_RMSPROP>(dim, grid, lds, st, w, g, f, users, pos, neg, batch, inv_batch, c->reg_coef, stats, sc);
+  if (rc) return rc;
+  if (batch == 0) {
+    // the flush wrote no partials of its own: mark its scratch block empty
+    HIPREC_TRY(hipMemsetAsync(sc, 0, 16, st));
+  }
+  return 0;
+}
+
+extern "C" size_t hiprec_fused_step_bytes(void) { return sizeof(hiprec_fused_step); }
+
+extern "C" int hiprec_mf_bpr_epoch_fused(int kind, float* const* w_flat, float* const* g_flat,
+                                         float* const* m_flat, float* const* v_flat,
+                                         void* const* scratch2, int64_t n_users, int64_t n_items,
+                                         int32_t dim, const int64_t* users, const int64_t* pos,
+                                         const int64_t* neg, int64_t n_triples, int64_t batch,
+                                         float reg_coef, double lr, double beta1, double beta2,
+                                         double eps, hiprec_stats* stats, int32_t* final_index,
+                                         void* stream) {
+  HIPREC_REQUIRE(w_flat && g_flat && scratch2 && final_index && stats, "NULL pointer");
+  HIPREC_REQUIRE(w_flat[0] && w_flat[1] && g_flat[0] && g_flat[1] && g_flat[2] && scratch2[0] &&
+                     scratch2[1], "NULL buffer");
+  const bool has_m = kind == HIPREC_OPT_ADAM, has_v = kind != HIPREC_OPT_SGD;
+  HIPREC_REQUIRE(!has_m || (m_flat && m_flat[0] && m_flat[1]), "Adam needs m_flat[2]");
+  HIPREC_REQUIRE(!has_v || (v_flat && v_flat[0] && v_flat[1]), "Adam/RMSprop need v_flat[2]");
+  HIPREC_REQUIRE(n_triples >= 0 && batch > 0, "bad n_triples/batch");
+  HIPREC_REQUIRE(n_triples == 0 || (users && pos && neg), "NULL index arrays");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t n_flat = (n_users + n_items) * (static_cast<int64_t>(dim) + 1) + 1;
+  if (int rc = hiprec_stats_begin_epoch(stats, stream)) return rc;
   const int64_t n_steps = (n_triples + batch - 1) / batch;
-  const OptScalars sc_opt{lr,
-                          static_cast<float>(lr),
-                          static_cast<float>(beta2),
-                          static_cast<float>(1.0 - beta1),
-                          static_cast<float>(1.0 - beta2),
-                          static_cast<float>(eps)};
+  hiprec_fused_step c{};
+  c.kind = kind;
+  c.dim = dim;
+  c.n_users = n_users;
+  c.n_items = n_items;
+  c.lr = lr;
+  c.beta1 = beta1;
+  c.beta2 = beta2;
+  c.eps = eps;
+  c.reg_coef = reg_coef;
   for (int64_t k = 0; k <= n_steps; ++k) {  // step n_steps is the sweep-only flush
     const int64_t off = k * batch;
     const int64_t b = k < n_steps ? std::min<int64_t>(batch, n_triples - off) : 0;
-    FusedOpt f;
-    float* w_read = w_flat[k & 1];
-    float* g_prev = g_flat[(k + 2) % 3];
-    float* g_cur = g_flat[k % 3];
-    float* m_read = has_m ? m_flat[k & 1] : nullptr;
-    float* v_read = has_v ? v_flat[k & 1] : nullptr;
-    f.gp = tables(g_prev);
-    f.mp = tables(m_read);
-    f.vp = tables(v_read);
-    f.w_read = w_read;
-    f.g_prev = g_prev;
-    f.m_read = m_read;
-    f.v_read = v_read;
-    f.w_write = w_flat[(k + 1) & 1];
-    f.m_write = has_m ? m_flat[(k + 1) & 1] : nullptr;
-    f.v_write = has_v ? v_flat[(k + 1) & 1] : nullptr;
-    f.g_zero = g_flat[(k + 1) % 3];
-    f.n_flat = n_flat;
-    f.s = sc_opt;
-    f.n_gather_blocks = b > 0 ? std::min(agg_grid(b), kFusedMaxGather) : 0;
-    f.n_prev_partials =
-        k > 0 ? std::min(agg_grid(std::min<int64_t>(batch, n_triples - (k - 1) * batch)), kFusedMaxGather) : 0;
-    f.apply_prev = k > 0 ? 1 : 0;
-    f.scratch_prev = static_cast<const Scratch*>(scratch2[(k + 1) & 1]);
-    Scratch* sc = static_cast<Scratch*>(scratch2[k & 1]);
-    const hiprec_mf_tables w = tables(w_read), g = tables(g_cur);
+    const int64_t prev_b = k > 0 ? std::min<int64_t>(batch, n_triples - (k - 1) * batch) : 0;
+    c.w_read = w_flat[k & 1];
+    c.w_write = w_flat[(k + 1) & 1];
+    c.m_read = has_m ? m_flat[k & 1] : nullptr;
+    c.m_write = has_m ? m_flat[(k + 1) & 1] : nullptr;
+    c.v_read = has_v ? v_flat[k & 1] : nullptr;
+    c.v_write = has_v ? v_flat[(k + 1) & 1] : nullptr;
+    c.g_prev = g_flat[(k + 2) % 3];
+    c.g_cur = g_flat[k % 3];
+    c.g_zero = g_flat[(k + 1) % 3];
+    c.scratch_prev = scratch2[(k + 1) & 1];
+    c.scratch_cur = scratch2[k & 1];
     const float inv_b = b > 0 ? 1.0f / static_cast<float>(b) : 0.f;
-    const int grid = f.n_gather_blocks + n_sweep;
-    const int64_t* uu = users ? users + off : nullptr;
-    const int64_t* pp = pos ? pos + off : nullptr;
-    const int64_t* nn = neg ? neg + off : nullptr;
-    int rc;
-    if (kind == HIPREC_OPT_SGD)
-      rc = launch_fused<HIPREC_OPT_SGD>(dim, grid, lds, st, w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
-    else if (kind == HIPREC_OPT_ADAM)
-      rc = launch_fused<HIPREC_OPT_ADAM>(dim, grid, lds, st, w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
-    else
-      rc = launch_fused<HIPREC_OPT_RMSPROP>(dim, grid, lds, st, w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
-    if (rc) return rc;
-    if (b == 0) {
-      // the flush wrote no partials of its own: mark its scratch block empty for the next epoch
-      HIPREC_TRY(hipMemsetAsync(sc, 0, 16, st));
-    }
+    if (int rc = hiprec_mf_bpr_fused_step(&c, users ? users + off : nullptr, pos ? pos + off : nullptr,
+                                          neg ? neg + off : nullptr, b, prev_b, inv_b, stats, stream))
+      return rc;
   }
   // the gradient applied by the flush is the only buffer that is still non-zero
   HIPREC_TRY(hipMemsetAsync(g_flat[(n_steps + 2) % 3], 0, sizeof(float) * n_flat, st));

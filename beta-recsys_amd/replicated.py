@@ -55,6 +55,8 @@ class ReplicatedMFEngine(MFEngine):
             self._tail_ptr = self._g_ext.data_ptr() + 4 * P
             self._rows_sgd = False  # replicas always take the dense sweep
             self._dp_ctx = None
+            self._fe = None
+        self._lib_cached = lib
         return lib
 
     def _step_context(self):
@@ -93,6 +95,7 @@ class ReplicatedMFEngine(MFEngine):
         hiprec_mf_dp_step_end (dense optimizer sweep).  The epoch sums are kept as per-rank shares in
         hiprec_stats (they are linear) and all-reduced once per epoch."""
         lib = self._setup()
+        self._stats_are_global = False
         ctx = self._step_context()
         st = _lib.stream_ptr(self.model.flat.device)
         n = users.numel()
@@ -101,11 +104,102 @@ class ReplicatedMFEngine(MFEngine):
         allreduce_sum_(self._g_ext, self.pg)
         _lib.check(lib.hiprec_mf_dp_step_end(ctx, st))
 
+    # ---- resident epochs: ONE launch + ONE all-reduce per step ------------------------------------------
+    # The single-GPU resident epoch runs one fused kernel per step (csrc/mf.hip mf_bpr_fused_kernel:
+    # the update of step k-1 rides inside the gradient kernel of step k).  Data-parallel replicas can
+    # do the same: the launch of step k needs the SUMMED gradient and loss partials of step k-1, so
+    # the all-reduce goes between two launches and covers [partials of step k | gradient of step k],
+    # which live back to back in one buffer (three of them rotate, like the gradient buffers of the
+    # single-GPU epoch).  Per step: one kernel launch and one collective instead of three launches
+    # and one collective, and the loss sums in hiprec_stats are global on every rank.
+
+    def fused_epoch_begin(self):
+        """Allocate / clear the rotating buffers and reset the step counter of a fused epoch."""
+        lib = self._setup()
+        m, opt = self.model, self.optimizer
+        if self.loss != "bpr" or m.emb_dim > 256:
+            raise RuntimeError("the fused data-parallel epoch covers BPR with emb_dim <= 256")
+        dev = m.flat.device
+        P = m.flat.numel()
+        sf = self._scratch.numel() // 4                    # floats of one scratch block (16-B header first)
+        fe = getattr(self, "_fe", None)
+        if fe is None or fe["dev"] != dev:
+            bufs = [torch.zeros(sf + P, dtype=torch.float32, device=dev) for _ in range(3)]
+            fe = {"dev": dev, "bufs": bufs, "w": [m.flat, torch.empty_like(m.flat)],
+                  "m": None if opt.exp_avg is None else [opt.exp_avg, torch.empty_like(m.flat)],
+                  "v": None if opt.exp_avg_sq is None else [opt.exp_avg_sq, torch.empty_like(m.flat)],
+                  # what the collective sums: everything behind the 4-float scratch header
+                  "reduce": [b[4:] for b in bufs], "steps": {}}
+            self._fe = fe
+        else:
+            for b in fe["bufs"]:
+                b.zero_()
+        fe["w"][0] = m.flat
+        fe["steps"] = {}                                   # lr / buffers may have changed since last epoch
+        fe["k"], fe["prev_batch"] = 0, 0
+        self._stats_are_global = True                      # the fused launches reduce SUMMED partials
+        _lib.check(lib.hiprec_stats_begin_epoch(_lib.ptr(self._stats), _lib.stream_ptr(dev)))
+        return fe
+
+    def _fused_step_struct(self, k):
+        """hiprec_fused_step for rotation state k mod 6 (w/m/v ping-pong x gradient buffers mod 3)."""
+        fe = self._fe
+        key = k % 6
+        cached = fe["steps"].get(key)
+        if cached is not None:
+            return cached[1]
+        m, opt = self.model, self.optimizer
+        sf = self._scratch.numel() // 4
+        c = _lib.FusedStep()
+        c.kind, c.dim, c.n_users, c.n_items = opt.kind, m.emb_dim, m.n_users, m.n_items
+        c.w_read, c.w_write = fe["w"][k & 1].data_ptr(), fe["w"][(k + 1) & 1].data_ptr()
+        if fe["m"] is not None:
+            c.m_read, c.m_write = fe["m"][k & 1].data_ptr(), fe["m"][(k + 1) & 1].data_ptr()
+        if fe["v"] is not None:
+            c.v_read, c.v_write = fe["v"][k & 1].data_ptr(), fe["v"][(k + 1) & 1].data_ptr()
+        prev, cur, nxt = fe["bufs"][(k + 2) % 3], fe["bufs"][k % 3], fe["bufs"][(k + 1) % 3]
+        c.scratch_prev, c.g_prev = prev.data_ptr(), prev.data_ptr() + 4 * sf
+        c.scratch_cur, c.g_cur = cur.data_ptr(), cur.data_ptr() + 4 * sf
+        c.g_zero = nxt.data_ptr() + 4 * sf
+        c.lr, c.beta1, c.beta2, c.eps = opt.lr, opt.beta1, opt.beta2, opt.eps
+        c.reg_coef = float(self.reg)
+        fe["steps"][key] = (c, ctypes.byref(c))
+        return fe["steps"][key][1]
+
+    def fused_step(self, users, pos, neg):
+        """One step of a fused epoch on device-resident, contiguous int64 index tensors."""
+        fe = self._fe
+        k, n = fe["k"], users.numel()
+        _lib.check(self._lib_cached.hiprec_mf_bpr_fused_step(
+            self._fused_step_struct(k), users.data_ptr(), pos.data_ptr(), neg.data_ptr(), n, fe["prev_batch"],
+            1.0 / (n * self.world), self._stats.data_ptr(), _lib.stream_ptr(fe["dev"])))
+        allreduce_sum_(fe["reduce"][k % 3], self.pg)
+        fe["k"], fe["prev_batch"] = k + 1, n
+
+    def fused_epoch_end(self):
+        """Apply the last pending update (sweep-only launch) and hand the state back to the engine's
+        own buffers; leaves every rotating buffer clean."""
+        fe = self._fe
+        k = fe["k"]
+        _lib.check(self._lib_cached.hiprec_mf_bpr_fused_step(
+            self._fused_step_struct(k), None, None, None, 0, fe["prev_batch"], 0.0, self._stats.data_ptr(),
+            _lib.stream_ptr(fe["dev"])))
+        fe["bufs"][(k + 2) % 3].zero_()       # the gradient the flush applied
+        fe["bufs"][k % 3][:4].zero_()          # header of the flush's own (empty) scratch block
+        if (k + 1) & 1:                        # the state ended up in the alternate buffers
+            self.model.flat.copy_(fe["w"][1])
+            if fe["m"] is not None:
+                self.optimizer.exp_avg.copy_(fe["m"][1])
+            if fe["v"] is not None:
+                self.optimizer.exp_avg_sq.copy_(fe["v"][1])
+        fe["k"], fe["prev_batch"] = 0, 0
+
     def _sync_stats(self):
         """Global (all-reduced) loss / reg of the last step replace the local shares in stats."""
         st = super()._sync_stats()
-        loss, reg = (float(x) for x in self._tail.cpu())
-        st.loss, st.reg = loss, reg
+        if not getattr(self, "_stats_are_global", False):
+            loss, reg = (float(x) for x in self._tail.cpu())
+            st.loss, st.reg = loss, reg
         return st
 
     def prepare_epoch(self, train_loader):

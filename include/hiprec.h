@@ -235,6 +235,34 @@ int hiprec_mf_bpr_epoch_fused(int kind, float* const* w_flat, float* const* g_fl
                               int64_t batch, float reg_coef, double lr, double beta1, double beta2,
                               double eps, hiprec_stats* stats, int32_t* final_index, void* stream);
 
+/* ---- ONE launch of that sequence, with the buffers of this step named explicitly: for callers that
+ *      have to do something between two steps -- the data-parallel engine all-reduces
+ *      [partials of scratch_cur | g_cur] over RCCL before the next launch consumes them as
+ *      scratch_prev / g_prev.  The launch of step k applies update(w_read, g_prev,
+ *      m_read, v_read) (the step whose batch had prev_batch triples; prev_batch = 0: nothing pending,
+ *      first step of an epoch), accumulates the gradient of its own batch into g_cur (zero on entry)
+ *      with the loss partials in scratch_cur, writes w_write / m_write / v_write and clears g_zero.
+ *      batch = 0 is the flush that only applies the pending update.  inv_batch is 1/B of the GLOBAL
+ *      batch.  hiprec_mf_bpr_epoch_fused is a loop over this call with w/m/v ping-ponging between two
+ *      buffers, g rotating through three and scratch between two. */
+typedef struct hiprec_fused_step {
+  int32_t kind; /* HIPREC_OPT_* */
+  int32_t dim;
+  int64_t n_users, n_items;
+  const float *w_read, *g_prev, *m_read, *v_read; /* flat buffers (layout of hiprec_mf_tables) */
+  float *w_write, *m_write, *v_write, *g_cur, *g_zero;
+  const void* scratch_prev;
+  void* scratch_cur;
+  double lr, beta1, beta2, eps;
+  float reg_coef;
+  int32_t _pad;
+} hiprec_fused_step;
+
+size_t hiprec_fused_step_bytes(void);
+int hiprec_mf_bpr_fused_step(const hiprec_fused_step* step, const int64_t* users, const int64_t* pos,
+                             const int64_t* neg, int64_t batch, int64_t prev_batch, float inv_batch,
+                             hiprec_stats* stats, void* stream);
+
 /* The plain-SGD spelling of hiprec_mf_bpr_epoch_fused (first ABI revision). */
 int hiprec_mf_bpr_epoch_sgd_fused(float* const* w_flat, float* const* g_flat, void* const* scratch2,
                                   int64_t n_users, int64_t n_items, int32_t dim,

@@ -115,3 +115,47 @@ def test_route_bucket_kernel(hip_device):
     assert read_stats(k.stats).status == 0
     k.route_bucket(kt, R, 100)
     assert read_stats(k.stats).status & _lib.STATUS_ROUTE_OVERFLOW
+
+
+@pytest.mark.parametrize("optimizer,lr", [("sgd", 0.1), ("adam", 0.05), ("rmsprop", 0.01)])
+def test_replicated_fused_epoch_with_hip_kernels(nccl_group, optimizer, lr):
+    """The data-parallel resident epoch (one fused launch + one all-reduce of [partials | gradient]
+    per step) at world size 1, two epochs in a row, against the oracle stepping the same batches; the
+    loss sums it leaves in hiprec_stats are the global ones."""
+    from beta_recsys_amd.replicated import ReplicatedMFEngine
+
+    U, I, D, B = 300, 200, 64, 512
+    w0 = onp.init_params(U, I, D, seed=9)
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer=optimizer,
+                         lr=lr, batch_size=B, loss="bpr"),
+           "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = ReplicatedMFEngine(cfg)
+    eng.model.load_state_dict({k: torch.from_numpy(v) for k, v in w0.items()})
+    w = onp.copy_params(w0)
+    st = onp.new_opt_state(w, optimizer)
+    rng = np.random.default_rng(3)
+    for epoch, n_steps in enumerate((3, 4)):            # odd and even: both final ping-pong positions
+        total = 0.0
+        eng.fused_epoch_begin()
+        for s in range(n_steps):
+            nb = B if s < n_steps - 1 else 77           # short last batch
+            batch = (rng.integers(0, U, nb), rng.integers(0, 30, nb), rng.integers(0, I, nb))
+            eng.fused_step(*(torch.from_numpy(a).cuda() for a in batch))
+            loss, _ = onp.mf_train_step(w, st, batch, "bpr", optimizer, lr)
+            total += loss
+        eng.fused_epoch_end()
+        stats = eng.epoch_stats()
+        assert_scalar_close(stats.loss_sum, total, 2e-5, f"epoch {epoch} loss sum")
+        # every rotating gradient buffer is clean again
+        assert all(float(b[eng._scratch.numel() // 4:].abs().max()) == 0.0 for b in eng._fe["bufs"])
+    assert eng.epoch_stats().step == 7
+    got = {k: v.cpu().numpy() for k, v in eng.model.state_dict().items()}
+    tol = 1e-5 if optimizer == "sgd" else 2e-3
+    for k in KEYS:
+        assert np.mean(np.abs(got[k] - w[k]) > tol * max(np.abs(w[k]).max(), 1e-3)) < 0.01, k
+    # the per-batch path still works afterwards and continues from the same state
+    batch = tuple(torch.from_numpy(rng.integers(0, n, B)) for n in (U, I, I))
+    loss, _ = eng.train_single_batch(batch)
+    ref_loss, _ = onp.mf_train_step(w, st, tuple(t.numpy() for t in batch), "bpr", optimizer, lr)
+    assert_scalar_close(loss, ref_loss, 1e-4, "loss after the fused epochs")
