@@ -135,6 +135,10 @@ class ReplicatedMFEngine(MFEngine):
             for b in fe["bufs"]:
                 b.zero_()
         fe["w"][0] = m.flat
+        if fe["m"] is not None:
+            fe["m"][0] = opt.exp_avg
+        if fe["v"] is not None:
+            fe["v"][0] = opt.exp_avg_sq
         fe["steps"] = {}                                   # lr / buffers may have changed since last epoch
         fe["k"], fe["prev_batch"] = 0, 0
         self._stats_are_global = True                      # the fused launches reduce SUMMED partials
