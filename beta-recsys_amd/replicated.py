@@ -213,13 +213,29 @@ class ReplicatedMFEngine(MFEngine):
     def train_an_epoch(self, train_loader, epoch_id):
         lib = self._setup()
         dev = self.model.flat.device
-        _lib.check(lib.hiprec_stats_begin_epoch(_lib.ptr(self._stats), _lib.stream_ptr(dev)))
-        for batch_data in train_loader:
-            self._enqueue_step(batch_data)
-        st = self._sync_stats()
-        sums = torch.tensor([st.loss_sum, st.reg_sum], dtype=torch.float64, device=dev)
-        allreduce_sum_(sums, self.pg)  # per-rank shares of every step's loss / reg
-        total_loss, total_reg = (float(x) for x in sums.cpu())
+        staged = None
+        if self.loss == "bpr" and self.model.emb_dim <= 256 and not isinstance(train_loader, (list, tuple)):
+            staged = self._resident_triples(train_loader)   # this rank's share, laid out in visiting order
+            if staged is not None and staged[3] is not None:
+                staged = None
+        if staged is not None:
+            # resident loader: one fused launch + one all-reduce per step; every rank must hold the same
+            # number of batches (one collective per step), as with any data-parallel loader
+            users, pos, neg, _, bs = staged
+            self.fused_epoch_begin()
+            for off in range(0, users.numel(), bs):
+                self.fused_step(users[off:off + bs], pos[off:off + bs], neg[off:off + bs])
+            self.fused_epoch_end()
+            st = self._sync_stats()
+            total_loss, total_reg = st.loss_sum, st.reg_sum  # already global
+        else:
+            _lib.check(lib.hiprec_stats_begin_epoch(_lib.ptr(self._stats), _lib.stream_ptr(dev)))
+            for batch_data in train_loader:
+                self._enqueue_step(batch_data)
+            st = self._sync_stats()
+            sums = torch.tensor([st.loss_sum, st.reg_sum], dtype=torch.float64, device=dev)
+            allreduce_sum_(sums, self.pg)  # per-rank shares of every step's loss / reg
+            total_loss, total_reg = (float(x) for x in sums.cpu())
         if self.rank == 0:
             print(f"[Training Epoch {epoch_id}], Loss {st.loss}, Regularizer {total_reg}")
         self.writer.add_scalar("model/loss", total_loss, epoch_id)

@@ -159,3 +159,25 @@ def test_replicated_fused_epoch_with_hip_kernels(nccl_group, optimizer, lr):
     loss, _ = eng.train_single_batch(batch)
     ref_loss, _ = onp.mf_train_step(w, st, tuple(t.numpy() for t in batch), "bpr", optimizer, lr)
     assert_scalar_close(loss, ref_loss, 1e-4, "loss after the fused epochs")
+
+
+def test_replicated_train_an_epoch_takes_the_fused_path_for_resident_loaders(nccl_group):
+    import beta_recsys_amd as hp
+    from beta_recsys_amd.replicated import ReplicatedMFEngine
+
+    U, I, D, B = 300, 200, 32, 128
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer="adam", lr=0.02,
+                         batch_size=B, loss="bpr"), "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = ReplicatedMFEngine(cfg)
+    rng = np.random.default_rng(2)
+    n = 5 * B + 40
+    loader = hp.DeviceTripleBatcher(*(torch.from_numpy(rng.integers(0, m, n)).cuda() for m in (U, I, I)), B)
+    sums = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for epoch in range(3):
+            eng.train_an_epoch(loader, epoch)
+            sums.append(eng.writer.scalars[-2][1])
+    assert eng._fe is not None and eng.epoch_stats().step == 18       # 6 fused steps per epoch
+    assert all(np.isfinite(sums)) and sums[2] < sums[0]
