@@ -172,10 +172,15 @@ class ReplicatedMFEngine(MFEngine):
 
     def fused_step(self, users, pos, neg):
         """One step of a fused epoch on device-resident, contiguous int64 index tensors."""
+        self.fused_step_ptr(users.data_ptr(), pos.data_ptr(), neg.data_ptr(), users.numel())
+
+    def fused_step_ptr(self, users_ptr, pos_ptr, neg_ptr, n):
+        """Same, on raw device addresses of n consecutive int64 indices each (a slice of a staged epoch
+        without creating tensor views: the step is host-bound)."""
         fe = self._fe
-        k, n = fe["k"], users.numel()
+        k = fe["k"]
         _lib.check(self._lib_cached.hiprec_mf_bpr_fused_step(
-            self._fused_step_struct(k), users.data_ptr(), pos.data_ptr(), neg.data_ptr(), n, fe["prev_batch"],
+            self._fused_step_struct(k), users_ptr, pos_ptr, neg_ptr, n, fe["prev_batch"],
             1.0 / (n * self.world), self._stats.data_ptr(), _lib.stream_ptr(fe["dev"])))
         allreduce_sum_(fe["reduce"][k % 3], self.pg)
         fe["k"], fe["prev_batch"] = k + 1, n
@@ -223,8 +228,9 @@ class ReplicatedMFEngine(MFEngine):
             # number of batches (one collective per step), as with any data-parallel loader
             users, pos, neg, _, bs = staged
             self.fused_epoch_begin()
-            for off in range(0, users.numel(), bs):
-                self.fused_step(users[off:off + bs], pos[off:off + bs], neg[off:off + bs])
+            n, pu, pp, pn = users.numel(), users.data_ptr(), pos.data_ptr(), neg.data_ptr()
+            for off in range(0, n, bs):
+                self.fused_step_ptr(pu + 8 * off, pp + 8 * off, pn + 8 * off, min(bs, n - off))
             self.fused_epoch_end()
             st = self._sync_stats()
             total_loss, total_reg = st.loss_sum, st.reg_sum  # already global
