@@ -495,6 +495,19 @@ def main():
         if rank == 0:  # roofline of the dominant kernel: measured on a single-GPU engine
             eng = make_engine(device, args.optimizer)
             prepared = stage(eng, hp.DeviceTripleBatcher(users[:4 * B], pos[:4 * B], neg[:4 * B], B))
+            if mode == "replicated":
+                # the replicas run the same fused step kernel as the single-GPU epoch: its launch period
+                # from HIP events around a short resident epoch on this rank's GPU
+                n_ev = min(args.steps, 200)
+                probe = stage(eng, hp.DeviceTripleBatcher(users[:n_ev * B], pos[:n_ev * B], neg[:n_ev * B], B))
+                eng.run_prepared_epoch(probe, sync=False)
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                ev0.record()
+                eng.run_prepared_epoch(probe, sync=False)
+                ev1.record()
+                torch.cuda.synchronize()
+                epoch_event_s, event_steps = ev0.elapsed_time(ev1) * 1e-3, n_ev
 
     parallelism = "single GPU"
     if dist_on:
@@ -506,7 +519,7 @@ def main():
     if rank == 0:
         k_mean, k_med = kernel_timing(eng, prepared)
         bpt = algorithmic_bytes_per_triple(D)
-        fused = (not dist_on) and eng.fused_step
+        fused = eng.fused_step and (not dist_on or mode == "replicated")
         kind_id = {"sgd": 0, "adam": 1, "rmsprop": 2}[args.optimizer]
         if fused:
             # ONE kernel per step (gather + score + gradient scatter + the optimizer update of the
@@ -514,7 +527,7 @@ def main():
             # the algorithmic bytes of a step are divided by
             dom_name = (f"mf_bpr_fused_kernel<1,{kind_id}> (gather + score + BPR grad + scatter + "
                         f"{args.optimizer} update, 1 launch/step)")
-            dom_s = epoch_event_s / (args.steps + 1)
+            dom_s = epoch_event_s / ((event_steps if dist_on else args.steps) + 1)
         else:
             dom_name = "mf_bpr_grad_kernel (gather + score + BPR grad + atomic scatter)"
             dom_s = k_mean
