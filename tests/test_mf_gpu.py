@@ -734,3 +734,29 @@ def test_fused_epoch_flags_out_of_range_ids_and_handles_empty_epochs(hip_device)
                                  B, shuffle=False)
     with pytest.raises(IndexError), contextlib.redirect_stdout(io.StringIO()):
         eng.train_an_epoch(bad, 1)
+
+
+def test_fused_epoch_with_batches_larger_than_the_gather_grid(hip_device):
+    """Batches beyond 256 blocks x 16 waves make every gather block loop (three trips here, the last one
+    ragged) and publish one partial per block for all of them: loss and weights vs the oracle."""
+    import beta_recsys_amd as hp
+
+    U, I, D, B = 3000, 2000, 64, 10000
+    rng = np.random.default_rng(17)
+    n = 2 * B + 777
+    triples = (rng.integers(0, U, n), rng.integers(0, 200, n), rng.integers(0, I, n))
+    w = onp.init_params(U, I, D, seed=17)
+    eng = make_engine(U, I, D, "sgd", "bpr", 0.05, B)
+    load_weights(eng, w)
+    loader = hp.DeviceTripleBatcher(*(torch.from_numpy(a).cuda() for a in triples), B, shuffle=False)
+    st = onp.new_opt_state(w, "sgd")
+    total = sum(onp.mf_train_step(w, st, tuple(a[k:k + B] for a in triples), "bpr", "sgd", 0.05)[0]
+                for k in range(0, n, B))
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng.train_an_epoch(loader, 0)
+    stats = eng.epoch_stats()
+    assert stats.step == 3
+    assert_scalar_close(stats.loss_sum, total, 1e-5, "epoch loss sum")
+    got = get_weights(eng)
+    for k in KEYS:
+        assert_tensor_close(got[k], w[k], 1e-5, f"large-batch fused epoch {k}", scale_floor=grad_scale_floor(k, B) * 0.05)
