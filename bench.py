@@ -175,6 +175,17 @@ def measured_traffic_bytes(kernel="hiprec::mf_bpr_grad_kernel<1>"):
         return None
 
 
+def other_workload_traffic(workload, kernel):
+    """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, KB per dispatch) of a kernel of another bench
+    workload from the committed rocprofv3 PMC passes (profiles/r01_pmc_other_workloads.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_other_workloads.json")) as f:
+            k = json.load(f)[workload][kernel]
+        return (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
+
+
 def bench_ncf(args, device):
     """BASELINE configs[2]: NeuMF (GMF + MLP [128, 64, 32] <=> emb_dim 32, quirk Q9) on the ML-1M
     shape, batch 4096 (user, item, rating) samples with 1 positive : 4 negatives, Adam lr 1e-3."""
@@ -289,7 +300,8 @@ def bench_mf_c4shard(args, device, full=False):
                       "last_loss": st.loss},
            "roofline": {"bound": "hbm", "kernel": "mf_bpr_grad_kernel<2>", "achieved": bpt * Bc / k_s / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bpt * Bc / k_s / 1e9 / HBM_PEAK_GBS,
-                        "algorithmic_bytes_per_launch": bpt * Bc, "kernel_us": k_s * 1e6, "traffic": None,
+                        "algorithmic_bytes_per_launch": bpt * Bc, "kernel_us": k_s * 1e6,
+                        "traffic": None if full else other_workload_traffic("mf-c4shard", "hiprec::mf_bpr_grad_kernel<2>"),
                         "step_frac": steps * Bc / dt * bpt / (HBM_PEAK_GBS * 1e9)}}
     print(json.dumps(out), flush=True)
 
