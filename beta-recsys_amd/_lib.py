@@ -122,6 +122,11 @@ SIGNATURES = {
     "hiprec_stats_begin_epoch": (c_int, [_P, _P]),
     "hiprec_gather_rows": (c_int, [_P, c_int64, c_int32, _P, c_int64, _P, _P, _P]),
     "hiprec_route_bucket": (c_int, [_P, c_int64, c_int32, c_int64, _P, _P, _P, _P]),
+    "hiprec_shard_route_triples": (c_int, [_P, _P, _P, c_int64, c_int32, c_int64, _P, _P, _P, _P]),
+    "hiprec_shard_route_items": (c_int, [_P, c_int64, c_int32, c_int64, _P, _P, _P, _P, _P, _P, _P]),
+    "hiprec_shard_gather_payload": (c_int, [_P, _P, c_int64, c_int32, _P, c_int64, c_int32, _P, _P, _P, _P]),
+    "hiprec_shard_split_rows": (c_int, [_P, c_int64, c_int32, _P, _P, _P]),
+    "hiprec_shard_join_rows": (c_int, [_P, _P, c_int64, c_int32, _P, _P]),
     "hiprec_scatter_add_rows": (c_int, [_P, c_int64, c_int32, _P, _P, c_int64, c_int64, _P, _P]),
     "hiprec_mf_predict": (c_int, [_T, _P, _P, c_int64, _P, _P, _P]),
     "hiprec_mf_bpr_grad": (

@@ -102,6 +102,57 @@ class HipKernels:
         head = self.stats[:8].view(torch.float32)  # hiprec_stats.loss, .reg
         return torch.cat([head, gb_part])
 
+    # ---- fused routing / packing of the padded step (csrc/shard.hip): one launch each -----------------
+    def _counts(self):
+        if getattr(self, "_cnt", None) is None:
+            self._cnt = torch.zeros(64, dtype=torch.int32, device=self.device)
+        return self._cnt
+
+    def route_triples(self, users, pos, neg, n_dest, cap, send):
+        """send[n_dest*cap, 3] = (user, pos, neg) bucketed by owner(user), -1 padding."""
+        _lib.check(self.lib.hiprec_shard_route_triples(
+            _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), users.numel(), n_dest, cap, _lib.ptr(self._counts()),
+            _lib.ptr(send), _lib.ptr(self.stats), self._st()))
+
+    def route_items(self, recv, n_dest, cap, req, slot_pos, slot_neg, u_loc):
+        """From received triples: item request buffer + the slots their rows come back in + local users."""
+        _lib.check(self.lib.hiprec_shard_route_items(
+            _lib.ptr(recv), recv.shape[0], n_dest, cap, _lib.ptr(self._counts()), _lib.ptr(req),
+            _lib.ptr(slot_pos), _lib.ptr(slot_neg), _lib.ptr(u_loc), _lib.ptr(self.stats), self._st()))
+
+    def gather_payload(self, item_emb, item_bias, incoming, n_dest, payload, local_idx):
+        """payload[k] = [item_emb row | item_bias] of incoming[k] // n_dest (zeros for padding)."""
+        _lib.check(self.lib.hiprec_shard_gather_payload(
+            _lib.ptr(item_emb), _lib.ptr(item_bias), item_emb.shape[0], item_emb.shape[1], _lib.ptr(incoming),
+            incoming.numel(), n_dest, _lib.ptr(payload), _lib.ptr(local_idx), _lib.ptr(self.stats), self._st()))
+
+    def split_rows(self, src, emb, bias):
+        _lib.check(self.lib.hiprec_shard_split_rows(_lib.ptr(src), src.shape[0], emb.shape[1], _lib.ptr(emb),
+                                                    _lib.ptr(bias), self._st()))
+
+    def join_rows(self, emb, bias, dst):
+        _lib.check(self.lib.hiprec_shard_join_rows(_lib.ptr(emb), _lib.ptr(bias), emb.shape[0], emb.shape[1],
+                                                   _lib.ptr(dst), self._st()))
+
+    def bpr_grad_into(self, w, g, users, pos, neg, inv_batch, reg_coef, part):
+        """bpr_grad writing [loss, reg, d global_bias] into the caller's 3-float tensor (no allocation)."""
+        def tables(t):
+            return _lib.MfTables(
+                t["user_emb.weight"].data_ptr(), t["item_emb.weight"].data_ptr(),
+                t["user_bias.weight"].data_ptr(), t["item_bias.weight"].data_ptr(),
+                t["global_bias"].data_ptr(), t["user_emb.weight"].shape[0],
+                t["item_emb.weight"].shape[0], t["user_emb.weight"].shape[1], 0)
+
+        wt, gt = tables(w), tables(g)
+        part.zero_()
+        _lib.check(self.lib.hiprec_mf_bpr_grad(
+            ctypes.byref(wt), ctypes.byref(gt), _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), None,
+            users.numel(), inv_batch, reg_coef, _lib.ptr(self.stats), _lib.ptr(self.scratch),
+            self.scratch.numel(), self._st()))
+        _lib.check(self.lib.hiprec_finalize_stats(
+            _lib.ptr(self.stats), _lib.ptr(self.scratch), ctypes.c_void_p(part.data_ptr() + 8),
+            _lib.ptr(part), self._st()))
+
     def advance_clock(self):
         """A rank that received no triple this step still has to tick the optimizer clock."""
         _lib.check(self.lib.hiprec_stats_advance_step(_lib.ptr(self.stats), self._st()))
@@ -225,24 +276,39 @@ class ShardedMFEngine:
             return self._step_padded(batch_data, sync)
         return self._step_variable(batch_data, sync)
 
-    def _a2a_equal(self, send):
-        """All-to-all with equal splits (first dim = world * capacity): no sizes, no host sync."""
-        out = torch.empty_like(send)
-        dist.all_to_all_single(out, send.contiguous(), group=self.pg)
-        return out
-
-    def _pack(self, slots, values, n_slots, fill):
-        """Padded send buffer: values[k] goes to slot slots[k]; slot -1 is dropped (dummy row)."""
-        shape = (n_slots + 1,) + tuple(values.shape[1:])
-        buf = torch.full(shape, fill, dtype=values.dtype, device=values.device)
-        safe = torch.where(slots < 0, torch.full_like(slots, n_slots), slots)
-        buf[safe] = values
-        return buf[:n_slots]
+    def _padded_buffers(self, b):
+        """Persistent device buffers of the padded step for local batch size b (allocated once)."""
+        key = (b, self.world)
+        pb = getattr(self, "_pb", None)
+        if pb is not None and pb["key"] == key:
+            return pb
+        R, dev, D = self.world, self.device, self.emb_dim
+        cap1 = int(b / R * self.route_slack) + 64
+        cap2 = int(2 * b / R * self.route_slack + 0.15 * b) + 64
+        T1, T2 = R * cap1, R * cap2
+        i64 = dict(dtype=torch.int64, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        pb = {"key": key, "cap1": cap1, "cap2": cap2, "T1": T1, "T2": T2,
+              "send": torch.empty((T1, 3), **i64), "recv": torch.empty((T1, 3), **i64),
+              "req": torch.empty(T2, **i64), "incoming": torch.empty(T2, **i64),
+              "slot_pos": torch.empty(T1, **i64), "slot_neg": torch.empty(T1, **i64),
+              "u_loc": torch.empty(T1, **i64), "local_idx": torch.empty(T2, **i64),
+              "payload": torch.empty((T2, D + 1), **f32), "fetched": torch.empty((T2, D + 1), **f32),
+              "rows": torch.empty((T2, D), **f32), "bias": torch.empty((T2, 1), **f32),
+              # gradient of the fetched rows: rows and biases back to back so that one fill clears both
+              "g_flat": torch.empty(T2 * (D + 1), **f32),
+              "g_send": torch.empty((T2, D + 1), **f32), "g_recv": torch.empty((T2, D + 1), **f32),
+              "part": torch.zeros(3, **f32)}
+        pb["g_rows"] = pb["g_flat"][: T2 * D].view(T2, D)
+        pb["g_bias"] = pb["g_flat"][T2 * D:].view(T2, 1)
+        self._pb = pb
+        return pb
 
     def _step_padded(self, batch_data, sync=True):
-        """Fixed-capacity routing: every exchange moves world x cap slots (padding = -1), bucketing
-        runs on the device (hiprec_route_bucket) and nothing is read back by the host during the
-        step.  Every rank must pass the same local batch size."""
+        """Fixed-capacity routing: every exchange moves world x cap slots (padding = -1), bucketing and
+        packing run on the device in one launch each (csrc/shard.hip), the buffers are persistent, and
+        nothing is read back by the host during the step.  Every rank must pass the same local batch
+        size."""
         R, dev, m, D = self.world, self.device, self.model, self.emb_dim
         users, pos, neg = (torch.as_tensor(x, device=dev).to(torch.int64).contiguous()
                            for x in batch_data)
@@ -250,53 +316,46 @@ class ShardedMFEngine:
         B = b * R
         if B < 2:
             raise IndexError("Dimension out of range (expected to be in range of [-1, 0], but got 1)")
-        cap1 = int(b / R * self.route_slack) + 64
-        cap2 = int(2 * b / R * self.route_slack + 0.15 * b) + 64
-        T1 = R * cap1
+        pb = self._padded_buffers(b)
+        k = self.k
 
         # A2A-1: triples to the owner of the user row
-        slot1 = self.k.route_bucket(users, R, cap1)
-        mine = self._a2a_equal(self._pack(slot1, torch.stack([users, pos, neg], dim=1), T1, -1))
-        u_g, p_g, n_g = mine[:, 0].contiguous(), mine[:, 1].contiguous(), mine[:, 2].contiguous()
-        pad = u_g < 0
+        k.route_triples(users, pos, neg, R, pb["cap1"], pb["send"])
+        dist.all_to_all_single(pb["recv"], pb["send"], group=self.pg)
 
         # A2A-2: item ids to their owners, rows (+bias) back into the SAME slots
-        items = torch.cat([p_g, n_g])                       # -1 where the triple slot is padding
-        slot2 = self.k.route_bucket(items, R, cap2)
-        incoming = self._a2a_equal(self._pack(slot2, items, R * cap2, -1))
-        local_idx = torch.where(incoming < 0, incoming, torch.div(incoming, R, rounding_mode="floor"))
-        payload = torch.cat([self.k.gather_rows(m.item_emb.weight.data, local_idx),
-                             self.k.gather_rows(m.item_bias.weight.data, local_idx)], dim=1)
-        fetched = self._a2a_equal(payload)
+        k.route_items(pb["recv"], R, pb["cap2"], pb["req"], pb["slot_pos"], pb["slot_neg"], pb["u_loc"])
+        dist.all_to_all_single(pb["incoming"], pb["req"], group=self.pg)
+        k.gather_payload(m.item_emb.weight.data, m.item_bias.weight.data, pb["incoming"], R, pb["payload"],
+                         pb["local_idx"])
+        dist.all_to_all_single(pb["fetched"], pb["payload"], group=self.pg)
+        k.split_rows(pb["fetched"], pb["rows"], pb["bias"])
 
         # the single-GPU gradient kernel: the fetched buffer plays the item table, slot ids are the
         # item indices, padded triples (user -1) are skipped by the kernel
-        w = {"user_emb.weight": m.user_emb.weight.data, "user_bias.weight": m.user_bias.weight.data,
-             "global_bias": m.global_bias.data,
-             "item_emb.weight": fetched[:, :D].contiguous(),
-             "item_bias.weight": fetched[:, D:].contiguous()}
         gue, gie, gub, gib, ggb = m._views(self._g_flat)
-        g_rows = torch.zeros((R * cap2, D), dtype=torch.float32, device=dev)
-        g_bias = torch.zeros((R * cap2, 1), dtype=torch.float32, device=dev)
+        w = {"user_emb.weight": m.user_emb.weight.data, "user_bias.weight": m.user_bias.weight.data,
+             "global_bias": m.global_bias.data, "item_emb.weight": pb["rows"], "item_bias.weight": pb["bias"]}
+        pb["g_flat"].zero_()
         g = {"user_emb.weight": gue, "user_bias.weight": gub, "global_bias": ggb,
-             "item_emb.weight": g_rows, "item_bias.weight": g_bias}
-        u_loc = torch.where(pad, u_g, torch.div(u_g, R, rounding_mode="floor"))
-        part = self.k.bpr_grad(w, g, u_loc, slot2[:T1].contiguous(), slot2[T1:].contiguous(),
-                               1.0 / B, float(self.reg))
+             "item_emb.weight": pb["g_rows"], "item_bias.weight": pb["g_bias"]}
+        part = pb["part"]
+        k.bpr_grad_into(w, g, pb["u_loc"], pb["slot_pos"], pb["slot_neg"], 1.0 / B, float(self.reg), part)
 
         # A2A-3: item-row gradients back to the owners (same slots, reverse direction)
-        gincoming = self._a2a_equal(torch.cat([g_rows, g_bias], dim=1))
-        self.k.scatter_add_rows(gie, local_idx, gincoming[:, :D])
-        self.k.scatter_add_rows(gib, local_idx, gincoming[:, D:])
+        k.join_rows(pb["g_rows"], pb["g_bias"], pb["g_send"])
+        dist.all_to_all_single(pb["g_recv"], pb["g_send"], group=self.pg)
+        k.scatter_add_rows(gie, pb["local_idx"], pb["g_recv"][:, :D])
+        k.scatter_add_rows(gib, pb["local_idx"], pb["g_recv"][:, D:])
 
         dist.all_reduce(part, group=self.pg)
         ggb += part[2]
         self.step_count += 1
-        self.k.opt_step(self.optimizer, m.flat, self._g_flat, self.step_count)
+        k.opt_step(self.optimizer, m.flat, self._g_flat, self.step_count)
         if not sync:
             self._pending = part
             return None
-        self.k.check_status()
+        k.check_status()
         self.last = (float(part[0]), float(part[1]))
         return self.last
 

@@ -106,6 +106,31 @@ int hiprec_gather_rows(const float* table, int64_t n_rows, int32_t dim, const in
 int hiprec_route_bucket(const int64_t* keys, int64_t n, int32_t n_dest, int64_t cap, int32_t* counts,
                         int64_t* slot_out, hiprec_stats* stats, void* stream);
 
+/* ---- fused routing / packing for the fixed-capacity all-to-alls of the row-sharded engine
+ *      (owner(row) = row mod n_dest, bucket d = slots [d*cap, (d+1)*cap), padding -1,
+ *      a full bucket sets HIPREC_STATUS_ROUTE_OVERFLOW and drops the entry):
+ *  route_triples   A2A-1 send buffer send[n_dest*cap][3] = (user, pos, neg) bucketed by owner(user);
+ *  route_items     from the received triples recv[n_slots][3]: A2A-2 request buffer req[n_dest*cap]
+ *                  = item ids bucketed by owner(item), slot_pos / slot_neg[n_slots] = the slots the
+ *                  rows of each triple come back in, u_loc[n_slots] = local user row (-1 = padding);
+ *  gather_payload  owner side: payload[n][dim+1] = [item_emb row | item_bias] of incoming[k] / n_dest
+ *                  (zeros for padding), local_idx[n] = that local row or -1;
+ *  split / join    [n][dim+1] <-> ([n][dim], [n]) around the gradient kernel.
+ *      counts[n_dest] is a caller-owned int32 workspace (bucket fill levels). */
+int hiprec_shard_route_triples(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
+                               int32_t n_dest, int64_t cap, int32_t* counts, int64_t* send,
+                               hiprec_stats* stats, void* stream);
+int hiprec_shard_route_items(const int64_t* recv, int64_t n_slots, int32_t n_dest, int64_t cap,
+                             int32_t* counts, int64_t* req, int64_t* slot_pos, int64_t* slot_neg,
+                             int64_t* u_loc, hiprec_stats* stats, void* stream);
+int hiprec_shard_gather_payload(const float* item_emb, const float* item_bias, int64_t n_rows,
+                                int32_t dim, const int64_t* incoming, int64_t n, int32_t n_dest,
+                                float* payload, int64_t* local_idx, hiprec_stats* stats, void* stream);
+int hiprec_shard_split_rows(const float* src, int64_t n, int32_t dim, float* emb, float* bias,
+                            void* stream);
+int hiprec_shard_join_rows(const float* emb, const float* bias, int64_t n, int32_t dim, float* dst,
+                           void* stream);
+
 /* ---- table[idx[k], :] += src[k, 0:dim]  (src rows are src_stride floats apart).  Owner-side
  *      accumulation of the gradient rows that come back through the all-to-all of the row-sharded
  *      engine; the single-process reference does this inside

@@ -45,6 +45,46 @@ class OracleKernels:
                 self.overflow = True
         return slots
 
+    # ---- the fused routing / packing ops of the padded step (csrc/shard.hip), restated with numpy ------
+    def route_triples(self, users, pos, neg, n_dest, cap, send):
+        send.fill_(-1)
+        slots = self.route_bucket(users, n_dest, cap)
+        for k, s in enumerate(slots.tolist()):
+            if s >= 0:
+                send[s, 0], send[s, 1], send[s, 2] = users[k], pos[k], neg[k]
+
+    def route_items(self, recv, n_dest, cap, req, slot_pos, slot_neg, u_loc):
+        req.fill_(-1)
+        u, p, n = recv[:, 0], recv[:, 1].clone(), recv[:, 2].clone()
+        p[u < 0] = -1
+        n[u < 0] = -1
+        # the kernel buckets each triple's pos then neg, wave by wave; any arrival order is legal
+        slots = self.route_bucket(torch.stack([p, n], 1).reshape(-1), n_dest, cap).reshape(-1, 2)
+        for k in range(recv.shape[0]):
+            sp, sn = int(slots[k, 0]), int(slots[k, 1])
+            if sp >= 0:
+                req[sp] = p[k]
+            if sn >= 0:
+                req[sn] = n[k]
+            live = u[k] >= 0 and sp >= 0 and sn >= 0
+            slot_pos[k], slot_neg[k] = (sp, sn) if live else (0, 0)
+            u_loc[k] = u[k] // n_dest if live else -1
+
+    def gather_payload(self, item_emb, item_bias, incoming, n_dest, payload, local_idx):
+        local = torch.where(incoming < 0, incoming, torch.div(incoming, n_dest, rounding_mode="floor"))
+        local_idx.copy_(local)
+        payload.copy_(torch.cat([self.gather_rows(item_emb, local), self.gather_rows(item_bias, local)], dim=1))
+
+    def split_rows(self, src, emb, bias):
+        emb.copy_(src[:, :-1])
+        bias.copy_(src[:, -1:])
+
+    def join_rows(self, emb, bias, dst):
+        dst.copy_(torch.cat([emb, bias], dim=1))
+
+    def bpr_grad_into(self, w, g, users, pos, neg, inv_batch, reg_coef, part):
+        part.copy_(self.bpr_grad(w, g, users, pos, neg, inv_batch, reg_coef))
+
     def scatter_add_rows(self, table, idx, src):
         keep = idx >= 0  # -1 = padding slot
         table.index_add_(0, idx[keep], src.contiguous()[keep])
