@@ -153,6 +153,14 @@ class HipKernels:
             _lib.ptr(self.stats), _lib.ptr(self.scratch), ctypes.c_void_p(part.data_ptr() + 8),
             _lib.ptr(part), self._st()))
 
+    def sgd_rows(self, model, g_flat, users, items, lr, user_stamp, item_stamp, stamp):
+        """Exact SGD on the rows named by `users` / `items` only (-1 = padding): w -= lr * g, g = 0, plus the
+        scalar bias.  Plain SGD leaves untouched rows bit-identical, so a shard need not sweep its slice."""
+        w, g = model.tables(), model.tables(g_flat)
+        _lib.check(self.lib.hiprec_mf_sgd_rows(
+            ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(items), None, None, users.numel(), lr,
+            _lib.ptr(user_stamp), _lib.ptr(item_stamp), stamp, _lib.ptr(self.stats), None, self._st()))
+
     def advance_clock(self):
         """A rank that received no triple this step still has to tick the optimizer clock."""
         _lib.check(self.lib.hiprec_stats_advance_step(_lib.ptr(self.stats), self._st()))
@@ -215,6 +223,15 @@ class ShardedMFEngine:
         # host-side split sizes (any batch sizes, one host sync per exchange)
         self.routing = mc["routing"] if "routing" in mc else "padded"
         self.route_slack = float(mc["route_slack"]) if "route_slack" in mc else 1.25
+        # plain SGD on big shards visits only the rows of the step (as MFEngine does above 64 MB):
+        # `sgd_mode` = "rows" | "dense" | "auto"
+        mode = mc["sgd_mode"] if "sgd_mode" in mc else "auto"
+        self._rows_sgd = self.optimizer.name == "sgd" and self.routing == "padded" and (
+            mode == "rows" or (mode == "auto" and self.model.flat.numel() * 4 >= (64 << 20)))
+        if self._rows_sgd:
+            self._user_stamp = torch.zeros(max(self.model.n_users, 1), dtype=torch.int32, device=self.device)
+            self._item_stamp = torch.zeros(max(self.model.n_items, 1), dtype=torch.int32, device=self.device)
+            self._stamp = 0
 
     # ---- state ------------------------------------------------------------------------------
     def load_full_state_dict(self, full_state):
@@ -298,7 +315,8 @@ class ShardedMFEngine:
               # gradient of the fetched rows: rows and biases back to back so that one fill clears both
               "g_flat": torch.empty(T2 * (D + 1), **f32),
               "g_send": torch.empty((T2, D + 1), **f32), "g_recv": torch.empty((T2, D + 1), **f32),
-              "part": torch.zeros(3, **f32)}
+              "part": torch.zeros(3, **f32),
+              "zeros1": torch.zeros(T1, **i64), "zeros2": torch.zeros(T2, **i64)}
         pb["g_rows"] = pb["g_flat"][: T2 * D].view(T2, D)
         pb["g_bias"] = pb["g_flat"][T2 * D:].view(T2, 1)
         self._pb = pb
@@ -351,7 +369,20 @@ class ShardedMFEngine:
         dist.all_reduce(part, group=self.pg)
         ggb += part[2]
         self.step_count += 1
-        k.opt_step(self.optimizer, m.flat, self._g_flat, self.step_count)
+        if self._rows_sgd:
+            # the step touched the user rows it received and the item rows its peers asked for; the
+            # dummy index 0 of the other table is a legal row whose pending gradient (if any) is due anyway
+            if self._stamp > 2**31 - 8:
+                self._user_stamp.zero_()
+                self._item_stamp.zero_()
+                self._stamp = 0
+            k.sgd_rows(m, self._g_flat, pb["u_loc"], pb["zeros1"], self.optimizer.lr, self._user_stamp,
+                       self._item_stamp, self._stamp + 1)
+            k.sgd_rows(m, self._g_flat, pb["zeros2"], pb["local_idx"], self.optimizer.lr, self._user_stamp,
+                       self._item_stamp, self._stamp + 2)
+            self._stamp += 2
+        else:
+            k.opt_step(self.optimizer, m.flat, self._g_flat, self.step_count)
         if not sync:
             self._pending = part
             return None

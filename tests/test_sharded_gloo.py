@@ -85,6 +85,20 @@ class OracleKernels:
     def bpr_grad_into(self, w, g, users, pos, neg, inv_batch, reg_coef, part):
         part.copy_(self.bpr_grad(w, g, users, pos, neg, inv_batch, reg_coef))
 
+    def sgd_rows(self, model, g_flat, users, items, lr, user_stamp, item_stamp, stamp):
+        ue, ie, ub, ib, gb = model._views(model.flat)
+        gue, gie, gub, gib, ggb = model._views(g_flat)
+        live = (users >= 0) & (items >= 0)
+        lr32 = torch.tensor(lr, dtype=torch.float32)
+        for rows, w_e, w_b, g_e, g_b in ((users[live].unique(), ue, ub, gue, gub),
+                                          (items[live].unique(), ie, ib, gie, gib)):
+            w_e[rows] = w_e[rows] - lr32 * g_e[rows]
+            w_b[rows] = w_b[rows] - lr32 * g_b[rows]
+            g_e[rows] = 0.0
+            g_b[rows] = 0.0
+        gb -= lr32 * ggb
+        ggb.zero_()
+
     def scatter_add_rows(self, table, idx, src):
         keep = idx >= 0  # -1 = padding slot
         table.index_add_(0, idx[keep], src.contiguous()[keep])
@@ -121,13 +135,13 @@ def free_port():
         return s.getsockname()[1]
 
 
-def make_config(U, I, D, optimizer, lr, routing="variable"):
+def make_config(U, I, D, optimizer, lr, routing="variable", sgd_mode="dense"):
     return {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cpu", optimizer=optimizer,
-                          lr=lr, batch_size=8, loss="bpr", routing=routing),
+                          lr=lr, batch_size=8, loss="bpr", routing=routing, sgd_mode=sgd_mode),
             "system": {"run_dir": "/tmp/hiprec_test_runs"}}
 
 
-def worker(rank, world, port, optimizer, lr, splits, out_path, routing="variable"):
+def worker(rank, world, port, optimizer, lr, splits, out_path, routing="variable", sgd_mode="dense"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -139,7 +153,7 @@ def worker(rank, world, port, optimizer, lr, splits, out_path, routing="variable
         w0 = onp.init_params(U, I, D, seed=7)
         rng = np.random.default_rng(100)
         with contextlib.redirect_stdout(io.StringIO()):
-            eng = ShardedMFEngine(make_config(U, I, D, optimizer, lr, routing), kernels=OracleKernels(),
+            eng = ShardedMFEngine(make_config(U, I, D, optimizer, lr, routing, sgd_mode), kernels=OracleKernels(),
                                   full_state={k: torch.from_numpy(v) for k, v in w0.items()})
         losses = []
         batches = []
@@ -195,6 +209,22 @@ def test_two_rank_padded_routing_equals_single_process(tmp_path, optimizer, lr):
     tol = 1e-6 if optimizer == "sgd" else 2e-3
     for k in KEYS:
         assert np.mean(np.abs(res["full"][k] - w[k]) > tol) < 0.01, k
+
+
+def test_two_rank_padded_routing_with_touched_rows_sgd(tmp_path):
+    """Plain SGD on shards visiting only the rows of the step (sgd_mode 'rows'): the same weights as the
+    single-process dense step (untouched rows are not moved by SGD)."""
+    splits = [(12, 12), (30, 30), (2, 2)]
+    out_path = str(tmp_path / "out.pt")
+    mp.spawn(worker, args=(2, free_port(), "sgd", 0.1, splits, out_path, "padded", "rows"), nprocs=2, join=True)
+    res = torch.load(out_path, weights_only=False)
+    w = onp.copy_params(res["w0"])
+    st = onp.new_opt_state(w, "sgd")
+    for (users, pos, neg), (loss, reg) in zip(res["batches"], res["losses"]):
+        ref_loss, ref_reg = onp.mf_train_step(w, st, (users, pos, neg), "bpr", "sgd", 0.1)
+        assert_scalar_close(loss, ref_loss, 2e-5, "loss")
+    for k in KEYS:
+        assert np.mean(np.abs(res["full"][k] - w[k]) > 1e-6) < 0.01, k
 
 
 def test_shard_bookkeeping():

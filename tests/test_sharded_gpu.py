@@ -29,18 +29,19 @@ def nccl_group(hip_device):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("routing", ["padded", "variable"])
+@pytest.mark.parametrize("routing,sgd_mode", [("padded", "dense"), ("variable", "dense"), ("padded", "rows")])
 @pytest.mark.parametrize("optimizer,lr", [("sgd", 0.1), ("adam", 0.05)])
-def test_sharded_step_with_hip_kernels(nccl_group, optimizer, lr, routing):
+def test_sharded_step_with_hip_kernels(nccl_group, optimizer, lr, routing, sgd_mode):
     from beta_recsys_amd.sharded import ShardedMFEngine
 
     U, I, D, B = 300, 200, 64, 512
     w0 = onp.init_params(U, I, D, seed=3)
     cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer=optimizer,
-                         lr=lr, batch_size=B, loss="bpr", routing=routing),
+                         lr=lr, batch_size=B, loss="bpr", routing=routing, sgd_mode=sgd_mode),
            "system": {"run_dir": "/tmp/hiprec_test_runs"}}
     with contextlib.redirect_stdout(io.StringIO()):
         eng = ShardedMFEngine(cfg, full_state={k: torch.from_numpy(v) for k, v in w0.items()})
+    assert eng._rows_sgd == (sgd_mode == "rows" and optimizer == "sgd")   # Adam needs the dense sweep
     w = onp.copy_params(w0)
     st = onp.new_opt_state(w, optimizer)
     rng = np.random.default_rng(0)
