@@ -770,12 +770,15 @@ __global__ __launch_bounds__(kBlock) void mf_sgd_rows_kernel(
   const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
   constexpr int R = NPL > 0 ? NPL : 1;
 
+  // users / items_a may be NULL, and any index may be -1: "no row of that table for this entry" (the
+  // row-sharded engine passes the user rows it received and the item rows its peers fetched as two
+  // separate lists).  Any OTHER out-of-range index marks a triple the grad kernel flagged and skipped.
   auto load_idx = [&](int64_t t, int64_t& u, int64_t& a, int64_t& b) {
     u = a = b = -1;
     if (t < batch) {
       const int64_t j = perm ? perm[t] : t;
-      u = users[j];
-      a = items_a[j];
+      u = users ? users[j] : -1;
+      a = items_a ? items_a[j] : -1;
       b = items_b ? items_b[j] : a;
     }
   };
@@ -784,15 +787,16 @@ __global__ __launch_bounds__(kBlock) void mf_sgd_rows_kernel(
   for (int64_t t = wave0; t < batch; t += n_waves) {
     int64_t nu, na, nb;
     load_idx(t + n_waves, nu, na, nb);  // next trip's indices travel during this trip
-    const bool ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(w.n_users) &&
-                    static_cast<uint64_t>(a) < static_cast<uint64_t>(w.n_items) &&
-                    static_cast<uint64_t>(b) < static_cast<uint64_t>(w.n_items);
+    const bool u_in = static_cast<uint64_t>(u) < static_cast<uint64_t>(w.n_users);
+    const bool a_in = static_cast<uint64_t>(a) < static_cast<uint64_t>(w.n_items);
+    const bool b_in = static_cast<uint64_t>(b) < static_cast<uint64_t>(w.n_items);
     // (a triple with an out-of-range id was flagged and skipped by the grad kernel too)
+    const bool ok = (u_in || u == -1) && (a_in || a == -1) && (b_in || b == -1);
     int won = 0;
     if (ok) {
-      if (lane == 0) won = atomicExch(user_stamp + u, stamp) != stamp;
-      else if (lane == 1) won = atomicExch(item_stamp + a, stamp) != stamp;
-      else if (lane == 2 && items_b && b != a) won = atomicExch(item_stamp + b, stamp) != stamp;
+      if (lane == 0 && u_in) won = atomicExch(user_stamp + u, stamp) != stamp;
+      else if (lane == 1 && a_in) won = atomicExch(item_stamp + a, stamp) != stamp;
+      else if (lane == 2 && items_b && b_in && b != a) won = atomicExch(item_stamp + b, stamp) != stamp;
     }
     const bool won_r[3] = {__builtin_amdgcn_readlane(won, 0) != 0, __builtin_amdgcn_readlane(won, 1) != 0,
                            __builtin_amdgcn_readlane(won, 2) != 0};
@@ -974,7 +978,7 @@ extern "C" int hiprec_mf_sgd_rows(const hiprec_mf_tables* w, const hiprec_mf_tab
   if (int rc = check_tables(w, "w")) return rc;
   if (int rc = check_tables(g, "g")) return rc;
   if (int rc = check_same_shape(w, g)) return rc;
-  HIPREC_REQUIRE(users && items_a && user_stamp && item_stamp && stats, "NULL pointer");
+  HIPREC_REQUIRE((users || items_a) && user_stamp && item_stamp && stats, "NULL pointer");
   HIPREC_REQUIRE(batch >= 0, "negative batch");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int grid = grid_for_waves(batch);

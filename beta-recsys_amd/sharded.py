@@ -157,8 +157,9 @@ class HipKernels:
         """Exact SGD on the rows named by `users` / `items` only (-1 = padding): w -= lr * g, g = 0, plus the
         scalar bias.  Plain SGD leaves untouched rows bit-identical, so a shard need not sweep its slice."""
         w, g = model.tables(), model.tables(g_flat)
+        n = users.numel() if users is not None else items.numel()
         _lib.check(self.lib.hiprec_mf_sgd_rows(
-            ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(items), None, None, users.numel(), lr,
+            ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(items), None, None, n, lr,
             _lib.ptr(user_stamp), _lib.ptr(item_stamp), stamp, _lib.ptr(self.stats), None, self._st()))
 
     def advance_clock(self):
@@ -315,8 +316,7 @@ class ShardedMFEngine:
               # gradient of the fetched rows: rows and biases back to back so that one fill clears both
               "g_flat": torch.empty(T2 * (D + 1), **f32),
               "g_send": torch.empty((T2, D + 1), **f32), "g_recv": torch.empty((T2, D + 1), **f32),
-              "part": torch.zeros(3, **f32),
-              "zeros1": torch.zeros(T1, **i64), "zeros2": torch.zeros(T2, **i64)}
+              "part": torch.zeros(3, **f32)}
         pb["g_rows"] = pb["g_flat"][: T2 * D].view(T2, D)
         pb["g_bias"] = pb["g_flat"][T2 * D:].view(T2, 1)
         self._pb = pb
@@ -370,15 +370,14 @@ class ShardedMFEngine:
         ggb += part[2]
         self.step_count += 1
         if self._rows_sgd:
-            # the step touched the user rows it received and the item rows its peers asked for; the
-            # dummy index 0 of the other table is a legal row whose pending gradient (if any) is due anyway
+            # the step touched the user rows it received and the item rows its peers asked for
             if self._stamp > 2**31 - 8:
                 self._user_stamp.zero_()
                 self._item_stamp.zero_()
                 self._stamp = 0
-            k.sgd_rows(m, self._g_flat, pb["u_loc"], pb["zeros1"], self.optimizer.lr, self._user_stamp,
+            k.sgd_rows(m, self._g_flat, pb["u_loc"], None, self.optimizer.lr, self._user_stamp,
                        self._item_stamp, self._stamp + 1)
-            k.sgd_rows(m, self._g_flat, pb["zeros2"], pb["local_idx"], self.optimizer.lr, self._user_stamp,
+            k.sgd_rows(m, self._g_flat, None, pb["local_idx"], self.optimizer.lr, self._user_stamp,
                        self._item_stamp, self._stamp + 2)
             self._stamp += 2
         else:

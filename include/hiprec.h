@@ -193,7 +193,10 @@ int hiprec_opt_dense_step(int kind, float* w, float* g, float* m, float* v, int6
  * row bit-identical: torch_engine.py:26-29).  For each distinct row of the batch:
  * w[row] -= lr*g[row]; g[row] = 0.  `user_stamp` [n_users] / `item_stamp` [n_items] are int32
  * arrays owned by the caller, zero-initialised once; `stamp` must be a value never used before
- * for these arrays (the host passes a running step counter starting at 1).  */
+ * for these arrays (the host passes a running step counter starting at 1).  `users` or `items_a`
+ * may be NULL and any entry may be -1 ("no row of that table for this entry": the row-sharded engine
+ * passes the user rows it received and the item rows its peers fetched as two separate lists); any
+ * other out-of-range index marks a triple the gradient kernel flagged and skipped.  */
 int hiprec_mf_sgd_rows(const hiprec_mf_tables* w, const hiprec_mf_tables* g, const int64_t* users,
                        const int64_t* items_a, const int64_t* items_b, const int64_t* perm,
                        int64_t batch, double lr, int32_t* user_stamp, int32_t* item_stamp,

@@ -88,10 +88,10 @@ class OracleKernels:
     def sgd_rows(self, model, g_flat, users, items, lr, user_stamp, item_stamp, stamp):
         ue, ie, ub, ib, gb = model._views(model.flat)
         gue, gie, gub, gib, ggb = model._views(g_flat)
-        live = (users >= 0) & (items >= 0)
+        none = torch.zeros(0, dtype=torch.int64)
         lr32 = torch.tensor(lr, dtype=torch.float32)
-        for rows, w_e, w_b, g_e, g_b in ((users[live].unique(), ue, ub, gue, gub),
-                                          (items[live].unique(), ie, ib, gie, gib)):
+        for rows, w_e, w_b, g_e, g_b in (((users[users >= 0] if users is not None else none).unique(), ue, ub, gue, gub),
+                                          ((items[items >= 0] if items is not None else none).unique(), ie, ib, gie, gib)):
             w_e[rows] = w_e[rows] - lr32 * g_e[rows]
             w_b[rows] = w_b[rows] - lr32 * g_b[rows]
             g_e[rows] = 0.0
