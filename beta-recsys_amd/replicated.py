@@ -246,3 +246,70 @@ class ReplicatedMFEngine(MFEngine):
             print(f"[Training Epoch {epoch_id}], Loss {st.loss}, Regularizer {total_reg}")
         self.writer.add_scalar("model/loss", total_loss, epoch_id)
         self.writer.add_scalar("model/regularizer", total_reg, epoch_id)
+
+
+# ---- the NCF family, data-parallel ---------------------------------------------------------------------
+# "tower weights replicated + gradient all-reduce — classic DP for the dense part".  The
+# NCF tables of the shipped configs (ML-1M shape, a few MB) are replicated as well: every rank runs
+# hiprec_ncf_grad on its share of the global batch with the GLOBAL 1/B, one all-reduce sums
+# [flat gradient | loss], an identical dense sweep runs on every replica.
+
+class _ReplicatedNcfMixin:
+    """Mix into a ``beta_recsys_amd.ncf`` engine class: ``class E(_ReplicatedNcfMixin, NeuMFEngine)``."""
+
+    def __init__(self, config, process_group=None):
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        super().__init__(config)
+        if self.model.flat.device.type == "cuda":
+            dist.broadcast(self.model.flat, src=0, group=self.pg)
+
+    def _setup(self):
+        fresh = not self._ready
+        lib = super()._setup()
+        if fresh:
+            P = self.model.flat.numel()
+            # gradient accumulator with two trailing slots for the (loss, -) partial sums: one collective
+            self._g_ext = torch.zeros(P + 2, dtype=torch.float32, device=self.model.flat.device)
+            self._g_flat = self._g_ext[:P]
+            self._tail = self._g_ext[P:]
+        return lib
+
+    def _enqueue_step(self, users, items, ratings):
+        lib = self._setup()
+        m, opt = self.model, self.optimizer
+        dev = m.flat.device
+        users = torch.as_tensor(users, device=dev).to(torch.int64).reshape(-1).contiguous()
+        items = torch.as_tensor(items, device=dev).to(torch.int64).reshape(-1).contiguous()
+        ratings = torch.as_tensor(ratings, device=dev).to(torch.float32).reshape(-1).contiguous()
+        B = users.numel()
+        if not (items.numel() == B and ratings.numel() == B) or B == 0:
+            raise ValueError("users, items and ratings must be non-empty and of equal length")
+        st = _lib.stream_ptr(dev)
+        plan = m.plan(B, self._g_flat)
+        _lib.check(lib.hiprec_ncf_grad(
+            ctypes.byref(plan), _lib.ptr(users), _lib.ptr(items), _lib.ptr(ratings), B, 1.0 / (B * self.world),
+            _lib.ptr(self._stats), _lib.ptr(self._scratch), self._scratch.numel(), st))
+        # d loss / d affine_output.bias travels in the scratch partials: put it into its gradient slot and
+        # the loss into the tail before the collective
+        bias_ptr = self._g_ext.data_ptr() + 4 * m.offset_of("affine_output.bias")
+        _lib.check(lib.hiprec_finalize_stats(
+            _lib.ptr(self._stats), _lib.ptr(self._scratch), ctypes.c_void_p(bias_ptr),
+            ctypes.c_void_p(self._tail.data_ptr()), st))
+        allreduce_sum_(self._g_ext, self.pg)
+        _lib.check(lib.hiprec_opt_dense_step(
+            opt.kind, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),
+            _lib.ptr(opt.exp_avg_sq), m.flat.numel(), opt.lr, opt.beta1, opt.beta2, opt.eps,
+            _lib.ptr(self._stats), None, -1, st))
+
+    def _sync_stats(self):
+        """The global (all-reduced) loss of the last step replaces this rank's share."""
+        st = super()._sync_stats()
+        st.loss = float(self._tail[0].item())
+        return st
+
+
+def replicated_ncf_engine(engine_cls):
+    """Data-parallel variant of NeuMFEngine / GMFEngine / MLPEngine: ``replicated_ncf_engine(NeuMFEngine)(config)``."""
+    return type("Replicated" + engine_cls.__name__, (_ReplicatedNcfMixin, engine_cls), {})

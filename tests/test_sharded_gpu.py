@@ -182,3 +182,32 @@ def test_replicated_train_an_epoch_takes_the_fused_path_for_resident_loaders(ncc
             sums.append(eng.writer.scalars[-2][1])
     assert eng._fe is not None and eng.epoch_stats().step == 18       # 6 fused steps per epoch
     assert all(np.isfinite(sums)) and sums[2] < sums[0]
+
+
+def test_replicated_ncf_engine_with_hip_kernels(nccl_group):
+    """Data-parallel NeuMF at world size 1: gradient kernel with the global 1/B, all-reduce of
+    [gradient | loss], dense Adam sweep; losses and weights follow the oracle."""
+    from oracle import ncf_numpy as onc
+
+    import beta_recsys_amd as hp
+    from beta_recsys_amd.replicated import replicated_ncf_engine
+
+    U, I, E, L, B = 120, 90, 32, 3, 200
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=E, dropout=0.0, device_str="cuda:0", optimizer="adam",
+                         lr=1e-3, batch_size=B, model="ncf_end", mlp_config={"n_layers": L}, gmf_config={}),
+           "system": {"run_dir": "/tmp/hiprec_test_runs", "model_save_dir": "/tmp/hiprec_test_runs"}}
+    torch.manual_seed(4)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = replicated_ncf_engine(hp.NeuMFEngine)(cfg)
+    w = {k: v.detach().cpu().numpy().copy() for k, v in eng.model.state_dict().items()}
+    st = onc.new_opt_state(w, "adam")
+    rng = np.random.default_rng(4)
+    for _ in range(3):
+        users, items = rng.integers(0, U, B), rng.integers(0, I, B)
+        ratings = (rng.random(B) < 0.3).astype(np.float32)
+        loss = eng.train_single_batch(torch.from_numpy(users), torch.from_numpy(items), torch.from_numpy(ratings))
+        ref = onc.ncf_train_step(w, st, (users, items, ratings), "neumf", "adam", 1e-3)
+        assert_scalar_close(loss, ref, 2e-5, "loss")
+    got = {k: v.cpu().numpy() for k, v in eng.model.state_dict().items()}
+    for k in w:
+        assert np.mean(np.abs(got[k] - w[k]) > 2e-3 * max(np.abs(w[k]).max(), 1e-3)) < 0.01, k
