@@ -245,7 +245,7 @@ def main():
     epoch_fixture(MFEngine, PairwiseNegativeDataset, "mf_epoch_sgd", "sgd", seed=22)
 
 
-if __name__ == "__main__" and not {"--ncf", "--lightgcn", "--eval", "--sampler"} & set(sys.argv):
+if __name__ == "__main__" and not {"--ncf", "--lightgcn", "--eval", "--sampler", "--c1"} & set(sys.argv):
     main()
 
 
@@ -522,3 +522,38 @@ def main_sampler():
 
 if __name__ == "__main__" and "--sampler" in sys.argv:
     main_sampler()
+
+
+# ---- BASELINE configs[0]: the reference's own CPU-runnable case (configs/mf_default.json on ML-100k) ----
+
+def main_c1():
+    """MF at the mf_default.json shape (943 x 1682, emb_dim 64, batch 400, adam lr 0.05, reg 0.001 -- inert,
+    quirk Q1): 6 steps of the REAL reference from its own seeded init.  The weights are too big to
+    store (1.4 MB per snapshot); the fixture keeps the inputs, the losses and per-tensor checksums."""
+    MFEngine, _, _ = import_reference()
+    U, I, D, B, n_steps, seed = 943, 1682, 64, 400, 6, 2020
+    torch.manual_seed(seed)
+    cfg = make_config(U, I, D, "adam", "bpr", 0.05, B, reg=0.001)
+    eng = quiet(MFEngine, cfg)
+    rng = np.random.default_rng(seed)
+    users = rng.integers(0, U, size=(n_steps, B))
+    pos = np.stack([zipf_items(rng, B, I) for _ in range(n_steps)])
+    neg = rng.integers(0, I, size=(n_steps, B))
+    losses, regs = [], []
+    for s in range(n_steps):
+        l, r = eng.train_single_batch(tuple(torch.from_numpy(a[s]) for a in (users, pos, neg)))
+        losses.append(l)
+        regs.append(r)
+    out = {"meta": np.array([U, I, D, B, n_steps, seed], dtype=np.int64), "users": users, "pos": pos, "neg": neg,
+           "losses": np.array(losses, dtype=np.float64), "regs": np.array(regs, dtype=np.float64)}
+    for k, v in eng.model.state_dict().items():
+        a = v.detach().numpy().astype(np.float64)
+        out[f"sum/{k}"] = np.array(a.sum())
+        out[f"sumsq/{k}"] = np.array((a * a).sum())
+        out[f"head/{k}"] = v.detach().numpy().reshape(-1)[:64].copy()
+    np.savez_compressed(os.path.join(OUT, "mf_c1_adam.npz"), **out)
+    print("mf_c1_adam: losses", losses)
+
+
+if __name__ == "__main__" and "--c1" in sys.argv:
+    main_c1()

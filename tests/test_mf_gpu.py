@@ -760,3 +760,24 @@ def test_fused_epoch_with_batches_larger_than_the_gather_grid(hip_device):
     got = get_weights(eng)
     for k in KEYS:
         assert_tensor_close(got[k], w[k], 1e-5, f"large-batch fused epoch {k}", scale_floor=grad_scale_floor(k, B) * 0.05)
+
+
+def test_c1_config_against_the_reference_run(hip_device):
+    """BASELINE configs[0] (mf_default.json shape, adam lr 0.05, batch 400): the engine, built with the
+    reference's seed, reproduces the losses of the real reference's own run step by step and ends with
+    the same weight checksums."""
+    g = load_golden("mf_c1_adam")
+    U, I, D, B, n_steps, seed = (int(x) for x in g["meta"])
+    torch.manual_seed(seed)
+    eng = make_engine(U, I, D, "adam", "bpr", 0.05, B)
+    for s in range(n_steps):
+        loss, reg = eng.train_single_batch(tuple(torch.from_numpy(g[k][s]) for k in ("users", "pos", "neg")))
+        assert_scalar_close(loss, g["losses"][s], 1e-5, f"loss of step {s}")
+        assert_scalar_close(reg, g["regs"][s], 1e-5, f"regularizer of step {s}")
+    got = get_weights(eng)
+    for k in KEYS:
+        a = got[k].astype(np.float64)
+        assert abs((a * a).sum() - float(g[f"sumsq/{k}"])) <= 2e-3 * float(g[f"sumsq/{k}"]) + 1e-9, k
+        head = got[k].reshape(-1)[:64]
+        close = np.abs(head - g[f"head/{k}"]) <= 2e-3 * max(np.abs(g[f"head/{k}"]).max(), 1e-3)
+        assert close.mean() >= 0.9, f"{k}: {close.mean():.2f} of the sampled weights agree"
