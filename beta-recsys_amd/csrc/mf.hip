@@ -267,6 +267,7 @@ struct FusedOpt {
   float* m_write;
   float* v_write;
   float* g_zero;                // flat accumulator of the NEXT step, cleared here
+  float* g_zero2;               // flush only: the gradient being applied, cleared as it is consumed (else NULL)
   int64_t n_flat;
   OptScalars s;
   int n_gather_blocks;
@@ -337,6 +338,7 @@ void mf_bpr_fused_kernel(
       if constexpr (kHasM) mw4[i] = mv;
       if constexpr (kHasV) vw4[i] = vv;
       gz4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f.g_zero2) reinterpret_cast<float4*>(f.g_zero2)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     auto scalar_update = [&](int64_t i, float extra_g) {
       float a = f.w_read[i], d = f.g_prev[i] + extra_g, mv = 0.f, vv = 0.f;
@@ -347,14 +349,23 @@ void mf_bpr_fused_kernel(
       if constexpr (kHasM) f.m_write[i] = mv;
       if constexpr (kHasV) f.v_write[i] = vv;
       f.g_zero[i] = 0.f;
+      if (f.g_zero2) f.g_zero2[i] = 0.f;
     };
     for (int64_t i = (n4 << 2) + static_cast<int64_t>(sb) * kAggBlock + threadIdx.x; i < f.n_flat;
          i += stride) {
       if (i != gb_index) scalar_update(i, 0.f);
     }
     if (sb == 0) {
+      if (!apply && threadIdx.x == 0) {  // first launch of an epoch: hiprec_stats_begin_epoch, folded in
+        stats->loss_sum = 0.0;
+        stats->reg_sum = 0.0;
+      }
       const float gb_part = finalize_partials<kAggBlock>(stats, f.scratch_prev);
       if (threadIdx.x == 0) {
+        if (batch == 0) {  // flush: both scratch blocks are spent, leave them marked empty
+          scratch->n_partials = 0;
+          const_cast<Scratch*>(f.scratch_prev)->n_partials = 0;
+        }
         const int64_t lo = skip4 >= 0 ? (skip4 << 2) : gb_index;
         for (int64_t i = lo; i <= gb_index; ++i) scalar_update(i, i == gb_index ? gb_part : 0.f);
         if (batch > 0) {
@@ -1055,6 +1066,7 @@ extern "C" int hiprec_mf_bpr_fused_step(const hiprec_fused_step* c, const int64_
   f.m_write = has_m ? c->m_write : nullptr;
   f.v_write = has_v ? c->v_write : nullptr;
   f.g_zero = c->g_zero;
+  f.g_zero2 = batch == 0 ? const_cast<float*>(c->g_prev) : nullptr;  // the flush clears what it applies
   f.n_flat = n_flat;
   f.s = OptScalars{c->lr,
                    static_cast<float>(c->lr),
@@ -1078,12 +1090,7 @@ extern "C" int hiprec_mf_bpr_fused_step(const hiprec_fused_step* c, const int64_
     rc = launch_fused<HIPREC_OPT_ADAM>(dim, grid, lds, st, w, g, f, users, pos, neg, batch, inv_batch, c->reg_coef, stats, sc);
   else
     rc = launch_fused<HIPREC_OPT_RMSPROP>(dim, grid, lds, st, w, g, f, users, pos, neg, batch, inv_batch, c->reg_coef, stats, sc);
-  if (rc) return rc;
-  if (batch == 0) {
-    // the flush wrote no partials of its own: mark its scratch block empty
-    HIPREC_TRY(hipMemsetAsync(sc, 0, 16, st));
-  }
-  return 0;
+  return rc;
 }
 
 extern "C" size_t hiprec_fused_step_bytes(void) { return sizeof(hiprec_fused_step); }
@@ -1104,9 +1111,6 @@ extern "C" int hiprec_mf_bpr_epoch_fused(int kind, float* const* w_flat, float* 
   HIPREC_REQUIRE(!has_v || (v_flat && v_flat[0] && v_flat[1]), "Adam/RMSprop need v_flat[2]");
   HIPREC_REQUIRE(n_triples >= 0 && batch > 0, "bad n_triples/batch");
   HIPREC_REQUIRE(n_triples == 0 || (users && pos && neg), "NULL index arrays");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int64_t n_flat = (n_users + n_items) * (static_cast<int64_t>(dim) + 1) + 1;
-  if (int rc = hiprec_stats_begin_epoch(stats, stream)) return rc;
   const int64_t n_steps = (n_triples + batch - 1) / batch;
   hiprec_fused_step c{};
   c.kind = kind;
@@ -1122,12 +1126,15 @@ extern "C" int hiprec_mf_bpr_epoch_fused(int kind, float* const* w_flat, float* 
     const int64_t off = k * batch;
     const int64_t b = k < n_steps ? std::min<int64_t>(batch, n_triples - off) : 0;
     const int64_t prev_b = k > 0 ? std::min<int64_t>(batch, n_triples - (k - 1) * batch) : 0;
+    // the flush (no gather blocks, one thread per element) may update in place: it always lands
+    // in buffer 0, so nothing has to be copied back whatever the parity of the epoch
+    const int out = k == n_steps ? 0 : static_cast<int>((k + 1) & 1);
     c.w_read = w_flat[k & 1];
-    c.w_write = w_flat[(k + 1) & 1];
+    c.w_write = w_flat[out];
     c.m_read = has_m ? m_flat[k & 1] : nullptr;
-    c.m_write = has_m ? m_flat[(k + 1) & 1] : nullptr;
+    c.m_write = has_m ? m_flat[out] : nullptr;
     c.v_read = has_v ? v_flat[k & 1] : nullptr;
-    c.v_write = has_v ? v_flat[(k + 1) & 1] : nullptr;
+    c.v_write = has_v ? v_flat[out] : nullptr;
     c.g_prev = g_flat[(k + 2) % 3];
     c.g_cur = g_flat[k % 3];
     c.g_zero = g_flat[(k + 1) % 3];
@@ -1138,10 +1145,8 @@ extern "C" int hiprec_mf_bpr_epoch_fused(int kind, float* const* w_flat, float* 
                                           neg ? neg + off : nullptr, b, prev_b, inv_b, stats, stream))
       return rc;
   }
-  // the gradient applied by the flush is the only buffer that is still non-zero
-  HIPREC_TRY(hipMemsetAsync(g_flat[(n_steps + 2) % 3], 0, sizeof(float) * n_flat, st));
-  HIPREC_TRY(hipMemsetAsync(scratch2[(n_steps + 1) & 1], 0, 16, st));
-  *final_index = static_cast<int32_t>((n_steps + 1) & 1);
+  // the flush cleared the gradient it applied and both scratch headers, and wrote into buffer 0
+  *final_index = 0;
   return 0;
 }
 

@@ -145,10 +145,12 @@ class ReplicatedMFEngine(MFEngine):
         _lib.check(lib.hiprec_stats_begin_epoch(_lib.ptr(self._stats), _lib.stream_ptr(dev)))
         return fe
 
-    def _fused_step_struct(self, k):
-        """hiprec_fused_step for rotation state k mod 6 (w/m/v ping-pong x gradient buffers mod 3)."""
+    def _fused_step_struct(self, k, flush=False):
+        """hiprec_fused_step for rotation state k mod 6 (w/m/v ping-pong x gradient buffers mod 3).
+        The flush (sweep-only, one thread per element) may update in place: it always writes into
+        the engine's own buffers, so nothing is copied back whatever the parity of the epoch."""
         fe = self._fe
-        key = k % 6
+        key = (k % 6, flush)
         cached = fe["steps"].get(key)
         if cached is not None:
             return cached[1]
@@ -156,11 +158,12 @@ class ReplicatedMFEngine(MFEngine):
         sf = self._scratch.numel() // 4
         c = _lib.FusedStep()
         c.kind, c.dim, c.n_users, c.n_items = opt.kind, m.emb_dim, m.n_users, m.n_items
-        c.w_read, c.w_write = fe["w"][k & 1].data_ptr(), fe["w"][(k + 1) & 1].data_ptr()
+        out = 0 if flush else (k + 1) & 1
+        c.w_read, c.w_write = fe["w"][k & 1].data_ptr(), fe["w"][out].data_ptr()
         if fe["m"] is not None:
-            c.m_read, c.m_write = fe["m"][k & 1].data_ptr(), fe["m"][(k + 1) & 1].data_ptr()
+            c.m_read, c.m_write = fe["m"][k & 1].data_ptr(), fe["m"][out].data_ptr()
         if fe["v"] is not None:
-            c.v_read, c.v_write = fe["v"][k & 1].data_ptr(), fe["v"][(k + 1) & 1].data_ptr()
+            c.v_read, c.v_write = fe["v"][k & 1].data_ptr(), fe["v"][out].data_ptr()
         prev, cur, nxt = fe["bufs"][(k + 2) % 3], fe["bufs"][k % 3], fe["bufs"][(k + 1) % 3]
         c.scratch_prev, c.g_prev = prev.data_ptr(), prev.data_ptr() + 4 * sf
         c.scratch_cur, c.g_cur = cur.data_ptr(), cur.data_ptr() + 4 * sf
@@ -190,17 +193,10 @@ class ReplicatedMFEngine(MFEngine):
         own buffers; leaves every rotating buffer clean."""
         fe = self._fe
         k = fe["k"]
+        # the flush clears the gradient it applies and marks both scratch blocks empty
         _lib.check(self._lib_cached.hiprec_mf_bpr_fused_step(
-            self._fused_step_struct(k), None, None, None, 0, fe["prev_batch"], 0.0, self._stats.data_ptr(),
-            _lib.stream_ptr(fe["dev"])))
-        fe["bufs"][(k + 2) % 3].zero_()       # the gradient the flush applied
-        fe["bufs"][k % 3][:4].zero_()          # header of the flush's own (empty) scratch block
-        if (k + 1) & 1:                        # the state ended up in the alternate buffers
-            self.model.flat.copy_(fe["w"][1])
-            if fe["m"] is not None:
-                self.optimizer.exp_avg.copy_(fe["m"][1])
-            if fe["v"] is not None:
-                self.optimizer.exp_avg_sq.copy_(fe["v"][1])
+            self._fused_step_struct(k, flush=True), None, None, None, 0, fe["prev_batch"], 0.0,
+            self._stats.data_ptr(), _lib.stream_ptr(fe["dev"])))
         fe["k"], fe["prev_batch"] = 0, 0
 
     def _sync_stats(self):
