@@ -252,7 +252,8 @@ int hiprec_mf_bce_epoch(const hiprec_mf_tables* w, const hiprec_mf_tables* g, co
  * RMSprop; NULL otherwise) are flat buffers laid out like hiprec_mf_tables (user_emb|item_emb|
  * user_bias|item_bias|global_bias), scratch2[2] two scratch blocks; all caller-owned.  On entry the
  * state is in w/m/v_flat[0] and all g / scratch buffers are zero; on return it is in
- * w/m/v_flat[*final_index] and every g buffer / scratch header is zero again.  users/pos/neg hold
+ * w/m/v_flat[*final_index] (always 0: the sweep-only flush that ends the epoch updates in place
+ * into buffer 0) and every g buffer / scratch header is zero again.  users/pos/neg hold
  * the epoch in visiting order (n_triples, last batch short).  The arithmetic per element is that
  * of hiprec_opt_dense_step, so results equal hiprec_mf_bpr_epoch's up to the order of the atomic
  * gradient sums. */
