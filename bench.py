@@ -581,7 +581,7 @@ def main():
                 "algorithmic_bytes_per_launch": bpt * B,
                 "kernel_us": dom_s * 1e6,
                 "grad_only_kernel_us": k_mean * 1e6,
-                "traffic": measured_traffic_bytes(f"hiprec::mf_bpr_fused_kernel<1, {kind_id}>" if fused
+                "traffic": measured_traffic_bytes(f"hiprec::mf_bpr_fused_kernel<1, {kind_id}, false>" if fused
                                                  else "hiprec::mf_bpr_grad_kernel<1>"),
                 "step_frac": (world * args.steps * B / dt) / world * bpt / (HBM_PEAK_GBS * 1e9),
             },

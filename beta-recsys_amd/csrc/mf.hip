@@ -287,7 +287,10 @@ __device__ __forceinline__ float fused_eff(float w, float g, float m, float v, c
 // Two 16-wave blocks must fit on a CU (8 waves per SIMD, i.e. <= 64 VGPRs): the sweep blocks are the
 // second half of the grid and would otherwise wait for a gather block to retire (measured: Adam at 70
 // VGPRs ran 15.4 us per step instead of 10.7).  The dim > 64 variants keep their registers.
-template <int NPL, int KIND>
+// FLUSH: the sweep-only launch that ends an epoch (no gather blocks): it also clears the gradient it
+// applies (g_zero2) and marks both scratch blocks empty, and may run in place (w_write == w_read).  A
+// separate instantiation so that the per-step kernel carries none of it.
+template <int NPL, int KIND, bool FLUSH>
 __global__ __launch_bounds__(kAggBlock) __attribute__((amdgpu_waves_per_eu(NPL == 1 ? 8 : 4, 8)))
 void mf_bpr_fused_kernel(
     hiprec_mf_tables w, hiprec_mf_tables g, FusedOpt f, const int64_t* __restrict__ users,
@@ -338,7 +341,7 @@ void mf_bpr_fused_kernel(
       if constexpr (kHasM) mw4[i] = mv;
       if constexpr (kHasV) vw4[i] = vv;
       gz4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f.g_zero2) reinterpret_cast<float4*>(f.g_zero2)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (FLUSH) reinterpret_cast<float4*>(f.g_zero2)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     auto scalar_update = [&](int64_t i, float extra_g) {
       float a = f.w_read[i], d = f.g_prev[i] + extra_g, mv = 0.f, vv = 0.f;
@@ -349,7 +352,7 @@ void mf_bpr_fused_kernel(
       if constexpr (kHasM) f.m_write[i] = mv;
       if constexpr (kHasV) f.v_write[i] = vv;
       f.g_zero[i] = 0.f;
-      if (f.g_zero2) f.g_zero2[i] = 0.f;
+      if constexpr (FLUSH) f.g_zero2[i] = 0.f;
     };
     for (int64_t i = (n4 << 2) + static_cast<int64_t>(sb) * kAggBlock + threadIdx.x; i < f.n_flat;
          i += stride) {
@@ -362,7 +365,7 @@ void mf_bpr_fused_kernel(
       }
       const float gb_part = finalize_partials<kAggBlock>(stats, f.scratch_prev);
       if (threadIdx.x == 0) {
-        if (batch == 0) {  // flush: both scratch blocks are spent, leave them marked empty
+        if constexpr (FLUSH) {  // both scratch blocks are spent, leave them marked empty
           scratch->n_partials = 0;
           const_cast<Scratch*>(f.scratch_prev)->n_partials = 0;
         }
@@ -383,6 +386,7 @@ void mf_bpr_fused_kernel(
   }
 
   // ------------------------------ gather part ------------------------------
+  if constexpr (FLUSH) return;  // a flush launch has no gather blocks
   const int D = w.dim;
   const int ld = D + 1;
   const float ru = 4.f * reg_coef * inv_batch, ri = 2.f * reg_coef * inv_batch;
@@ -1010,12 +1014,14 @@ static int launch_fused(int dim, int grid, size_t lds, hipStream_t st, const hip
                         const hiprec_mf_tables& g, const FusedOpt& f, const int64_t* uu,
                         const int64_t* pp, const int64_t* nn, int64_t b, float inv_b, float reg_coef,
                         hiprec_stats* stats, Scratch* sc) {
-  if (dim <= 64)
-    mf_bpr_fused_kernel<1, KIND><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+  if (b == 0)  // flush: sweep blocks only, any NPL
+    mf_bpr_fused_kernel<1, KIND, true><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+  else if (dim <= 64)
+    mf_bpr_fused_kernel<1, KIND, false><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
   else if (dim <= 128)
-    mf_bpr_fused_kernel<2, KIND><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    mf_bpr_fused_kernel<2, KIND, false><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
   else
-    mf_bpr_fused_kernel<4, KIND><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    mf_bpr_fused_kernel<4, KIND, false><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
