@@ -257,8 +257,13 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
 constexpr int kFusedMaxGather = 256;  // gather blocks of one fused launch (bigger batches loop)
 constexpr int kFusedSlots = kFusedMaxGather / kWave;
 
+// Everything is addressed through FLAT buffers + one shared set of offsets (all of W, G, M, V have the
+// layout of hiprec_mf_tables): five table structs as kernel arguments cost 80 SGPRs and the compiler
+// spilled as many (80 v_writelane + 110 v_readlane in the Adam instantiation).
 struct FusedOpt {
-  hiprec_mf_tables gp, mp, vp;  // G_prev, M_a, V_a viewed as tables (mp / vp unused for SGD)
+  int64_t n_users, n_items;
+  int32_t dim, _pad0;
+  float* g_cur;                 // flat accumulator of THIS step
   const float* w_read;          // flat W_a
   const float* g_prev;          // flat G_prev
   const float* m_read;          // flat M_a (Adam)
@@ -293,9 +298,9 @@ __device__ __forceinline__ float fused_eff(float w, float g, float m, float v, c
 template <int NPL, int KIND, bool FLUSH>
 __global__ __launch_bounds__(kAggBlock) __attribute__((amdgpu_waves_per_eu(NPL == 1 ? 8 : 4, 8)))
 void mf_bpr_fused_kernel(
-    hiprec_mf_tables w, hiprec_mf_tables g, FusedOpt f, const int64_t* __restrict__ users,
-    const int64_t* __restrict__ pos, const int64_t* __restrict__ neg, int64_t batch,
-    float inv_batch, float reg_coef, hiprec_stats* stats, Scratch* scratch) {
+    FusedOpt f, const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
+    const int64_t* __restrict__ neg, int64_t batch, float inv_batch, float reg_coef,
+    hiprec_stats* stats, Scratch* scratch) {
   extern __shared__ __attribute__((aligned(16))) float s_acc[];
   __shared__ long long s_item[kAggWaves];
   const int lane = lane_id();
@@ -387,7 +392,12 @@ void mf_bpr_fused_kernel(
 
   // ------------------------------ gather part ------------------------------
   if constexpr (FLUSH) return;  // a flush launch has no gather blocks
-  const int D = w.dim;
+  const int D = f.dim;
+  // offsets of the five tensors inside any of the flat buffers
+  const int64_t o_ie = f.n_users * D, o_ub = o_ie + f.n_items * D, o_ib = o_ub + f.n_users,
+                o_gb = o_ib + f.n_items;
+  const float* const wf = f.w_read;
+  float* const gf = f.g_cur;
   const int ld = D + 1;
   const float ru = 4.f * reg_coef * inv_batch, ri = 2.f * reg_coef * inv_batch;
   // global_bias after step k-1: its gradient lives in the previous step's partials.  The loads are
@@ -402,10 +412,10 @@ void mf_bpr_fused_kernel(
   }
   // VECTOR loads on purpose: as scalar loads they would share lgkmcnt with the index loads below,
   // and all of these were written by the previous launch (full misses).
-  const float gb_w = load_scalar_param(w.global_bias), gb_g = load_scalar_param(f.gp.global_bias);
+  const float gb_w = load_scalar_param(wf + o_gb), gb_g = load_scalar_param(f.g_prev + o_gb);
   float gb_m = 0.f, gb_v = 0.f, step_size = f.s.lr, bc2_sqrt = 1.f;
-  if constexpr (kHasM) gb_m = load_scalar_param(f.mp.global_bias);
-  if constexpr (kHasV) gb_v = load_scalar_param(f.vp.global_bias);
+  if constexpr (kHasM) gb_m = load_scalar_param(f.m_read + o_gb);
+  if constexpr (kHasV) gb_v = load_scalar_param(f.v_read + o_gb);
   if constexpr (KIND == HIPREC_OPT_ADAM) {
     const float* hdr = reinterpret_cast<const float*>(f.scratch_prev->_pad);
     step_size = load_scalar_param(hdr);
@@ -425,9 +435,9 @@ void mf_bpr_fused_kernel(
       u = users[t];
       p = pos[t];
       n = neg[t];
-      const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(w.n_users);
-      const bool i_ok = static_cast<uint64_t>(p) < static_cast<uint64_t>(w.n_items) &&
-                        static_cast<uint64_t>(n) < static_cast<uint64_t>(w.n_items);
+      const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(f.n_users);
+      const bool i_ok = static_cast<uint64_t>(p) < static_cast<uint64_t>(f.n_items) &&
+                        static_cast<uint64_t>(n) < static_cast<uint64_t>(f.n_items);
       if (!(u_ok && i_ok)) {
         if (lane == 0)
           atomicOr(&stats->status,
@@ -443,23 +453,23 @@ void mf_bpr_fused_kernel(
     float uu[NPL], pp[NPL];
     float dpos = 0.f, bp = 0.f;
     if (valid) {
-      const int64_t ou = u * D, op = p * D, on = n * D;
+      const int64_t ou = u * D, op = o_ie + p * D, on = o_ie + n * D;  // rows inside a flat buffer
       float nn[NPL];
       float dp = 0.f, dn = 0.f;
       // everything this triple needs goes out in one burst (one round trip): biases ...
-      const float wbu = w.user_bias[u], gbu = f.gp.user_bias[u];
-      const float wbn = w.item_bias[n], gbn = f.gp.item_bias[n];
-      const float wbp = w.item_bias[p], gbp_ = f.gp.item_bias[p];
+      const float wbu = wf[o_ub + u], gbu = f.g_prev[o_ub + u];
+      const float wbn = wf[o_ib + n], gbn = f.g_prev[o_ib + n];
+      const float wbp = wf[o_ib + p], gbp_ = f.g_prev[o_ib + p];
       float mbu = 0.f, mbn = 0.f, mbp = 0.f, vbu = 0.f, vbn = 0.f, vbp = 0.f;
       if constexpr (kHasM) {
-        mbu = f.mp.user_bias[u];
-        mbn = f.mp.item_bias[n];
-        mbp = f.mp.item_bias[p];
+        mbu = f.m_read[o_ub + u];
+        mbn = f.m_read[o_ib + n];
+        mbp = f.m_read[o_ib + p];
       }
       if constexpr (kHasV) {
-        vbu = f.vp.user_bias[u];
-        vbn = f.vp.item_bias[n];
-        vbp = f.vp.item_bias[p];
+        vbu = f.v_read[o_ub + u];
+        vbn = f.v_read[o_ib + n];
+        vbp = f.v_read[o_ib + p];
       }
       // ... and rows
       float wu[NPL], gu[NPL], wp[NPL], gpv[NPL], wn[NPL], gn[NPL];
@@ -468,22 +478,22 @@ void mf_bpr_fused_kernel(
       for (int k = 0; k < NPL; ++k) {
         const int c = lane + kWave * k;
         const int cc = c < D ? c : D - 1;  // always a valid column: unconditional loads, one wait
-        wu[k] = w.user_emb[ou + cc];
-        gu[k] = f.gp.user_emb[ou + cc];
-        wp[k] = w.item_emb[op + cc];
-        gpv[k] = f.gp.item_emb[op + cc];
-        wn[k] = w.item_emb[on + cc];
-        gn[k] = f.gp.item_emb[on + cc];
+        wu[k] = wf[ou + cc];
+        gu[k] = f.g_prev[ou + cc];
+        wp[k] = wf[op + cc];
+        gpv[k] = f.g_prev[op + cc];
+        wn[k] = wf[on + cc];
+        gn[k] = f.g_prev[on + cc];
         mu[k] = mpv[k] = mn[k] = vu[k] = vpv[k] = vn[k] = 0.f;
         if constexpr (kHasM) {
-          mu[k] = f.mp.user_emb[ou + cc];
-          mpv[k] = f.mp.item_emb[op + cc];
-          mn[k] = f.mp.item_emb[on + cc];
+          mu[k] = f.m_read[ou + cc];
+          mpv[k] = f.m_read[op + cc];
+          mn[k] = f.m_read[on + cc];
         }
         if constexpr (kHasV) {
-          vu[k] = f.vp.user_emb[ou + cc];
-          vpv[k] = f.vp.item_emb[op + cc];
-          vn[k] = f.vp.item_emb[on + cc];
+          vu[k] = f.v_read[ou + cc];
+          vpv[k] = f.v_read[op + cc];
+          vn[k] = f.v_read[on + cc];
         }
       }
 #pragma unroll
@@ -532,8 +542,8 @@ void mf_bpr_fused_kernel(
       const float delta = -sig_neg_x * inv_batch;
       dpos = delta * ((1.f - yp) * yp);
       const float dneg = -delta * ((1.f - yn) * yn);
-      float* gur = g.user_emb + ou;
-      float* gnr = g.item_emb + on;
+      float* gur = gf + ou;
+      float* gnr = gf + on;
       float* slot = s_acc + wv * ld;
 #pragma unroll
       for (int k = 0; k < NPL; ++k) {
@@ -545,8 +555,8 @@ void mf_bpr_fused_kernel(
         }
       }
       if (lane == 0) {
-        atomic_add_f32(g.user_bias + u, (dpos + dneg) + ru * bu);
-        atomic_add_f32(g.item_bias + n, dneg + ri * bn);
+        atomic_add_f32(gf + o_ub + u, (dpos + dneg) + ru * bu);
+        atomic_add_f32(gf + o_ib + n, dneg + ri * bn);
         if (is_head) slot[D] = dpos + ri * bp;
         reg_acc += 2.f * bu * bu + bp * bp + bn * bn;
       }
@@ -566,9 +576,9 @@ void mf_bpr_fused_kernel(
     lds_barrier();
     if (valid && is_head) {
       const float* slot = s_acc + wv * ld;
-      float* gpr = g.item_emb + p * D;
+      float* gpr = gf + o_ie + p * D;
       for (int c = lane; c < D; c += kWave) atomic_add_f32(gpr + c, slot[c]);
-      if (lane == 0) atomic_add_f32(g.item_bias + p, slot[D]);
+      if (lane == 0) atomic_add_f32(gf + o_ib + p, slot[D]);
     }
   }
   // publish this step's partials; n_partials = number of GATHER blocks
@@ -1010,18 +1020,17 @@ extern "C" int hiprec_mf_sgd_rows(const hiprec_mf_tables* w, const hiprec_mf_tab
 // zero.  On return the state is in w_flat/m_flat/v_flat[*final_index] and every g buffer is zero
 // again.  users/pos/neg are the epoch laid out in visiting order.
 template <int KIND>
-static int launch_fused(int dim, int grid, size_t lds, hipStream_t st, const hiprec_mf_tables& w,
-                        const hiprec_mf_tables& g, const FusedOpt& f, const int64_t* uu,
+static int launch_fused(int dim, int grid, size_t lds, hipStream_t st, const FusedOpt& f, const int64_t* uu,
                         const int64_t* pp, const int64_t* nn, int64_t b, float inv_b, float reg_coef,
                         hiprec_stats* stats, Scratch* sc) {
   if (b == 0)  // flush: sweep blocks only, any NPL
-    mf_bpr_fused_kernel<1, KIND, true><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    mf_bpr_fused_kernel<1, KIND, true><<<grid, kAggBlock, lds, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
   else if (dim <= 64)
-    mf_bpr_fused_kernel<1, KIND, false><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    mf_bpr_fused_kernel<1, KIND, false><<<grid, kAggBlock, lds, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
   else if (dim <= 128)
-    mf_bpr_fused_kernel<2, KIND, false><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    mf_bpr_fused_kernel<2, KIND, false><<<grid, kAggBlock, lds, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
   else
-    mf_bpr_fused_kernel<4, KIND, false><<<grid, kAggBlock, lds, st>>>(w, g, f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    mf_bpr_fused_kernel<4, KIND, false><<<grid, kAggBlock, lds, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
@@ -1047,23 +1056,12 @@ extern "C" int hiprec_mf_bpr_fused_step(const hiprec_fused_step* c, const int64_
   const int64_t n_users = c->n_users, n_items = c->n_items;
   const int dim = c->dim;
   const int64_t n_flat = (n_users + n_items) * (static_cast<int64_t>(dim) + 1) + 1;
-  auto tables = [&](float* flat) {
-    hiprec_mf_tables t;
-    t.user_emb = flat;
-    t.item_emb = flat ? flat + n_users * dim : nullptr;
-    t.user_bias = flat ? t.item_emb + n_items * dim : nullptr;
-    t.item_bias = flat ? t.user_bias + n_users : nullptr;
-    t.global_bias = flat ? t.item_bias + n_items : nullptr;
-    t.n_users = n_users;
-    t.n_items = n_items;
-    t.dim = dim;
-    t._pad = 0;
-    return t;
-  };
   FusedOpt f;
-  f.gp = tables(const_cast<float*>(c->g_prev));
-  f.mp = tables(has_m ? const_cast<float*>(c->m_read) : nullptr);
-  f.vp = tables(has_v ? const_cast<float*>(c->v_read) : nullptr);
+  f.n_users = n_users;
+  f.n_items = n_items;
+  f.dim = dim;
+  f._pad0 = 0;
+  f.g_cur = c->g_cur;
   f.w_read = c->w_read;
   f.g_prev = c->g_prev;
   f.m_read = has_m ? c->m_read : nullptr;
@@ -1085,17 +1083,16 @@ extern "C" int hiprec_mf_bpr_fused_step(const hiprec_fused_step* c, const int64_
   f.apply_prev = prev_batch > 0 ? 1 : 0;
   f.scratch_prev = static_cast<const Scratch*>(c->scratch_prev);
   Scratch* sc = static_cast<Scratch*>(c->scratch_cur);
-  const hiprec_mf_tables w = tables(const_cast<float*>(c->w_read)), g = tables(c->g_cur);
   const size_t lds = agg_lds_bytes(dim);
   const int n_sweep = static_cast<int>(std::min<int64_t>(256, (n_flat / 4 + kAggBlock - 1) / kAggBlock));
   const int grid = f.n_gather_blocks + n_sweep;
   int rc;
   if (kind == HIPREC_OPT_SGD)
-    rc = launch_fused<HIPREC_OPT_SGD>(dim, grid, lds, st, w, g, f, users, pos, neg, batch, inv_batch, c->reg_coef, stats, sc);
+    rc = launch_fused<HIPREC_OPT_SGD>(dim, grid, lds, st, f, users, pos, neg, batch, inv_batch, c->reg_coef, stats, sc);
   else if (kind == HIPREC_OPT_ADAM)
-    rc = launch_fused<HIPREC_OPT_ADAM>(dim, grid, lds, st, w, g, f, users, pos, neg, batch, inv_batch, c->reg_coef, stats, sc);
+    rc = launch_fused<HIPREC_OPT_ADAM>(dim, grid, lds, st, f, users, pos, neg, batch, inv_batch, c->reg_coef, stats, sc);
   else
-    rc = launch_fused<HIPREC_OPT_RMSPROP>(dim, grid, lds, st, w, g, f, users, pos, neg, batch, inv_batch, c->reg_coef, stats, sc);
+    rc = launch_fused<HIPREC_OPT_RMSPROP>(dim, grid, lds, st, f, users, pos, neg, batch, inv_batch, c->reg_coef, stats, sc);
   return rc;
 }
 
