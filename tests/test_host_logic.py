@@ -65,6 +65,48 @@ def test_bad_arguments_return_error_codes_without_a_gpu():
     assert rc == -1 and b"NULL tensor pointer" in lib.hiprec_last_error()
 
 
+def test_newer_entry_points_validate_before_touching_the_gpu():
+    """Same contract for the eval / sampler / fused-step / shard / dp entry points."""
+    from beta_recsys_amd import _lib
+
+    lib = _lib.load()
+    ks = (ctypes.c_int32 * 2)(5, 10)
+    rc = lib.hiprec_rank_metrics(None, 4, None, None, ks, 0, None, 0, None, None)
+    assert rc == -1 and b"n_k=0" in lib.hiprec_last_error()
+    rc = lib.hiprec_rank_metrics(None, 4, None, None, ks, 9, None, 0, None, None)
+    assert rc == -1 and b"outside" in lib.hiprec_last_error()
+    bad_k = (ctypes.c_int32 * 2)(5, 0)
+    out = (ctypes.c_double * 8)()
+    rc = lib.hiprec_rank_metrics(None, 4, None, None, bad_k, 2, None, 0, out, None)
+    assert rc == -1 and b"k[1]=0" in lib.hiprec_last_error()
+    assert lib.hiprec_rank_metrics_workspace_bytes(100, 2) >= 100 * 2 * 8
+
+    rc = lib.hiprec_sample_negatives(None, None, 0, 10, None, 5, 1, 1, None, None, None)
+    assert rc == -1 and b"bad sizes" in lib.hiprec_last_error()
+    rc = lib.hiprec_sample_negatives(None, None, 3, 10, None, 5, 0, 1, None, None, None)
+    assert rc == -1 and b"bad sizes" in lib.hiprec_last_error()
+    rc = lib.hiprec_sample_negatives(None, None, 3, 10, None, 5, 1, 1, None, None, None)
+    assert rc == -1 and b"NULL" in lib.hiprec_last_error()
+
+    rc = lib.hiprec_mf_bpr_fused_step(None, None, None, None, 4, 0, 0.25, None, None)
+    assert rc == -1 and b"NULL step" in lib.hiprec_last_error()
+    assert lib.hiprec_fused_step_bytes() == ctypes.sizeof(_lib.FusedStep)
+    assert lib.hiprec_dp_step_bytes() == ctypes.sizeof(_lib.DpStep)
+    rc = lib.hiprec_mf_dp_step_begin(None, None, None, None, 4, 0.25, None)
+    assert rc == -1 and b"NULL step context" in lib.hiprec_last_error()
+    rc = lib.hiprec_mf_dp_step_end(None, None)
+    assert rc == -1
+
+    rc = lib.hiprec_shard_route_triples(None, None, None, 8, 65, 16, None, None, None, None)
+    assert rc == -1 and b"bad routing sizes" in lib.hiprec_last_error()
+    rc = lib.hiprec_shard_route_triples(None, None, None, 8, 2, 16, None, None, None, None)
+    assert rc == -1 and b"NULL" in lib.hiprec_last_error()
+    rc = lib.hiprec_shard_split_rows(None, 8, 0, None, None, None)
+    assert rc == -1 and b"bad sizes" in lib.hiprec_last_error()
+    rc = lib.hiprec_random_permutation(None, -1, 3, None)
+    assert rc == -1 and b"bad permutation" in lib.hiprec_last_error()
+
+
 def test_mf_initial_weights_match_reference_for_same_seed():
     """MF.__init__ consumes the torch RNG like models/mf.py:21-30 -> bit-identical init."""
     g = load_golden("mf_init")
