@@ -89,6 +89,13 @@ class LightGcnPlan(Structure):
                [("zero_ws_floats", c_int64)]
 
 
+class PgmfTables(Structure):
+    """hiprec_pgmf_tables (include/hiprec.h)."""
+
+    _fields_ = [("user_memory", c_void_p), ("item_memory", c_void_p), ("v", c_void_p),
+                ("n_users", c_int64), ("n_items", c_int64), ("dim", c_int32), ("_pad", c_int32)]
+
+
 class FusedStep(Structure):
     """hiprec_fused_step (include/hiprec.h)."""
 
@@ -176,6 +183,14 @@ SIGNATURES = {
         c_int,
         [_P, _P, c_int64, c_int64, _P, c_int64, c_int32, ctypes.c_uint64, _P, _P, _P],
     ),
+    "hiprec_pgmf_workspace_bytes": (c_size_t, [c_int32]),
+    "hiprec_pgmf_bpr_grad": (
+        c_int,
+        [POINTER(PgmfTables), POINTER(PgmfTables), _P, _P, _P, c_int64, c_float, c_float, _P, _P, c_size_t,
+         _P, c_size_t, _P],
+    ),
+    "hiprec_clip_workspace_bytes": (c_size_t, []),
+    "hiprec_clip_grad_norm": (c_int, [_P, c_int64, c_float, _P, c_size_t, _P]),
     "hiprec_rank_metrics_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hiprec_rank_metrics": (
         c_int,

@@ -479,6 +479,43 @@ int hiprec_rank_metrics(const int64_t* seg_ptr, int64_t n_segments, const float*
                         const float* ratings, const int32_t* k_list_host, int32_t n_k,
                         double* workspace, size_t workspace_bytes, double* out, void* stream);
 
+/* ================= PairwiseGMF, the CMN pre-training model (sibling models) ====
+ * models/pairwise_gmf.py:28-46 parameters: user_memory [n_users, dim], item_memory [n_items, dim],
+ * v = nn.Linear(dim, 1, bias=False).weight [1, dim].  The host keeps them in ONE flat buffer in that
+ * order (and the dense gradient in another) so that hiprec_clip_grad_norm and hiprec_opt_dense_step
+ * sweep them in one pass each. */
+typedef struct hiprec_pgmf_tables {
+  float* user_memory; /* [n_users, dim] */
+  float* item_memory; /* [n_items, dim] */
+  float* v;           /* [dim] */
+  int64_t n_users;
+  int64_t n_items;
+  int32_t dim;        /* <= 256 */
+  int32_t _pad;
+} hiprec_pgmf_tables;
+
+/* bytes of device workspace hiprec_pgmf_bpr_grad needs (per-block partial sums of grad v) */
+size_t hiprec_pgmf_workspace_bytes(int32_t dim);
+/* ---- zero_grad + forward + loss + backward of PairwiseGMFEngine.train_single_batch
+ * (pairwise_gmf.py:82-112): s = relu(v . (U[u] * I[i])) (pairwise_gmf.py:48-62), loss =
+ * mean(-log(sigmoid(s+ - s-) + 1e-12)) (the engine's own bpr_loss, pairwise_gmf.py:144-158)
+ * + l2_lambda * ||v||_2 (pairwise_gmf.py:105-108).  Accumulates into the dense gradient g (which the
+ * previous hiprec_opt_dense_step left zeroed), leaves the loss partials in scratch for that sweep to
+ * fold into stats->loss, and advances the step counter.  Out-of-range ids set the status bits and
+ * the triple is skipped. */
+int hiprec_pgmf_bpr_grad(const hiprec_pgmf_tables* w, const hiprec_pgmf_tables* g,
+                         const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t batch,
+                         float inv_batch, float l2_lambda, hiprec_stats* stats, void* scratch,
+                         size_t scratch_bytes, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- torch.nn.utils.clip_grad_norm_(parameters, max_norm) (pairwise_gmf.py:111, cmn.py:197), L2,
+ * over one flat gradient of n floats: total = ||g||, g *= min(max_norm / (total + 1e-6), 1).
+ * workspace: hiprec_clip_workspace_bytes() of device memory; afterwards workspace[0] (fp64) holds
+ * the total norm (the function's return value in torch) and workspace[1] the coefficient. */
+size_t hiprec_clip_workspace_bytes(void);
+int hiprec_clip_grad_norm(float* g, int64_t n, float max_norm, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

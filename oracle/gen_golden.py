@@ -245,7 +245,7 @@ def main():
     epoch_fixture(MFEngine, PairwiseNegativeDataset, "mf_epoch_sgd", "sgd", seed=22)
 
 
-if __name__ == "__main__" and not {"--ncf", "--lightgcn", "--eval", "--sampler", "--c1"} & set(sys.argv):
+if __name__ == "__main__" and not {"--ncf", "--lightgcn", "--eval", "--sampler", "--c1", "--pgmf"} & set(sys.argv):
     main()
 
 
@@ -557,3 +557,80 @@ def main_c1():
 
 if __name__ == "__main__" and "--c1" in sys.argv:
     main_c1()
+
+
+def pgmf_config(U, I, D, B, optimizer, lr, l2_lambda, grad_clip):
+    """PairwiseGMFEngine reads flat keys (pairwise_gmf.py:31-33,76-78,107,111) AND, through
+    ModelEngine.__init__, config["model"]{device_str,optimizer,lr} + config["system"]["run_dir"]."""
+    return {"n_users": U, "n_items": I, "emb_dim": D, "regs": [1e-5], "batch_size": B, "lr": lr,
+            "pretrain_l2_lambda": l2_lambda, "grad_clip": grad_clip, "neg_count": 4,
+            "model": {"device_str": "cpu", "optimizer": optimizer, "lr": lr},
+            "system": {"run_dir": "/tmp/hiprec_golden_runs"}}
+
+
+def pgmf_fixture(Engine, name, U, I, D, B, optimizer, lr, l2_lambda, grad_clip, n_steps, seed, scale=1.0):
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    eng = quiet(Engine, pgmf_config(U, I, D, B, optimizer, lr, l2_lambda, grad_clip))
+    with torch.no_grad():
+        # the reference's init (std 0.01) keeps every score within 1e-4 of zero; scaled fixtures move
+        # the scores far enough from 0 for sigmoid and both relu branches to matter
+        eng.model.user_memory.weight.mul_(scale)
+        eng.model.item_memory.weight.mul_(scale)
+    out = {"meta": np.array([U, I, D, B, n_steps, seed], dtype=np.int64), "optimizer": np.array(optimizer),
+           "lr": np.array(lr), "l2_lambda": np.array(l2_lambda), "grad_clip": np.array(grad_clip)}
+    for k, v in eng.model.state_dict().items():
+        out[f"w0/{k}"] = v.detach().numpy().copy()
+    seen = []
+    orig_step = eng.optimizer.step
+
+    def capturing_step(*a, **k):  # runs after clip_grad_norm_: these are the clipped gradients
+        seen.append({n: p.grad.detach().numpy().copy() for n, p in eng.model.named_parameters()})
+        return orig_step(*a, **k)
+
+    eng.optimizer.step = capturing_step
+    users = rng.integers(0, U, size=(n_steps, B))
+    pos = np.stack([zipf_items(rng, B, I) for _ in range(n_steps)])
+    neg = rng.integers(0, I, size=(n_steps, B))
+    losses = []
+    for s in range(n_steps):
+        losses.append(eng.train_single_batch((users[s], pos[s], neg[s])))
+        for k, v in eng.model.state_dict().items():
+            out[f"w{s + 1}/{k}"] = v.detach().numpy().copy()
+        for k, v in seen[-1].items():
+            out[f"g{s + 1}/{k}"] = v
+        for pname, p in eng.model.named_parameters():
+            pst = eng.optimizer.state.get(p, {})
+            for sk, tag in (("exp_avg", "m"), ("exp_avg_sq", "v"), ("square_avg", "v")):
+                if sk in pst:
+                    out[f"{tag}{s + 1}/{pname}"] = pst[sk].detach().numpy().copy()
+    out["users"], out["pos"], out["neg"] = users, pos, neg
+    out["losses"] = np.array(losses, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: losses {losses}")
+
+
+def main_pgmf():
+    """PairwiseGMF (CMN pre-training) fixtures from the real reference engine."""
+    import_reference()
+    from beta_rec.models.pairwise_gmf import PairwiseGMFEngine
+
+    # cmn_default.json values: adam, l2 1e-4, clip 5.0 (never active at this scale)
+    pgmf_fixture(PairwiseGMFEngine, "pgmf_adam", 23, 17, 8, 16, "adam", 1e-3, 1e-4, 5.0, 3, 11, scale=60.0)
+    # clip active on every step, width that is not a multiple of 64, sgd
+    pgmf_fixture(PairwiseGMFEngine, "pgmf_sgd_clip", 31, 29, 100, 48, "sgd", 0.5, 1e-2, 1e-3, 3, 12, scale=40.0)
+    # the reference's own init scale (scores ~1e-4), rmsprop, D 64
+    pgmf_fixture(PairwiseGMFEngine, "pgmf_rmsprop_init", 40, 33, 64, 32, "rmsprop", 1e-3, 1e-4, 5.0, 2, 13)
+    # seeded initial weights (truncated normal + xavier) for the init-parity test
+    out = {}
+    for tag, (U, I, D, seed) in {"a": (7, 5, 4, 3), "b": (19, 33, 64, 2020)}.items():
+        torch.manual_seed(seed)
+        eng = quiet(PairwiseGMFEngine, pgmf_config(U, I, D, 8, "adam", 1e-4, 1e-4, 5.0))
+        out[f"{tag}/meta"] = np.array([U, I, D, seed], dtype=np.int64)
+        for k, v in eng.model.state_dict().items():
+            out[f"{tag}/w/{k}"] = v.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "pgmf_init.npz"), **out)
+
+
+if __name__ == "__main__" and "--pgmf" in sys.argv:
+    main_pgmf()

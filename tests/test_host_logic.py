@@ -467,3 +467,62 @@ def test_positive_csr_and_loader_argument_checks():
         hip_data.sample_negatives(users, items, 5, 6, k=0, device="cpu")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         hip_data.sample_negatives(users, items, 5, 6, device="cpu")
+
+
+def pgmf_config(U=9, I=7, D=4, **model):
+    m = {"device_str": "cpu", "optimizer": "adam", "lr": 1e-3}
+    m.update(model)
+    return {"n_users": U, "n_items": I, "emb_dim": D, "regs": [1e-5], "batch_size": 8, "lr": 1e-4,
+            "pretrain_l2_lambda": 1e-4, "grad_clip": 5.0, "neg_count": 4, "model": m,
+            "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+
+
+def test_pairwise_gmf_initial_weights_match_reference_for_same_seed():
+    """PairwiseGMF.__init__ consumes the torch RNG like models/pairwise_gmf.py:35-46."""
+    import beta_recsys_amd as hp
+
+    g = load_golden("pgmf_init")
+    for tag in ("a", "b"):
+        U, I, D, seed = (int(x) for x in g[f"{tag}/meta"])
+        torch.manual_seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            eng = hp.PairwiseGMFEngine(pgmf_config(U, I, D))
+        sd = eng.model.state_dict()
+        assert list(sd.keys()) == ["user_memory.weight", "item_memory.weight", "v.weight"]
+        for k in sd:
+            assert np.array_equal(sd[k].numpy(), g[f"{tag}/w/{k}"]), f"{tag} {k} differs"
+
+
+def test_pairwise_gmf_engine_surface():
+    import beta_recsys_amd as hp
+    from beta_recsys_amd import _lib, compat
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = hp.PairwiseGMFEngine(pgmf_config())
+        keeps_adam = hp.PairwiseGMFEngine(pgmf_config(optimizer="none-of-the-three"))
+        sgd = hp.PairwiseGMFEngine(pgmf_config(optimizer="sgd", lr=0.5))
+    # torch_engine.py:23-39 replaces the engine's Adam(lr=config["lr"]) only for a known name
+    assert (eng.optimizer.name, eng.optimizer.lr) == ("adam", 1e-3)
+    assert (keeps_adam.optimizer.name, keeps_adam.optimizer.lr) == ("adam", 1e-4)
+    assert (sgd.optimizer.name, sgd.optimizer.lr) == ("sgd", 0.5)
+    assert eng.batch_size == 8 and eng.regs == [1e-5]
+    m = eng.model
+    t = m.tables()
+    assert t.user_memory == m.flat.data_ptr() and t.v == m.flat.data_ptr() + 4 * (9 + 7) * 4
+    assert m.flat.numel() == (9 + 7 + 1) * 4 and m.v.weight.shape == (1, 4)
+    p, n = torch.tensor([[0.7], [0.2]]), torch.tensor([[0.1], [0.4]])
+    assert torch.allclose(eng.bpr_loss(p, n), (-torch.log(torch.sigmoid(p - n) + 1e-12)).mean())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        eng.train_single_batch(([0, 1], [1, 2], [3, 4]))
+    assert compat.MIRRORS["beta_rec.models.pairwise_gmf"] == "pairwise_gmf"
+    # C-ABI argument checks fire before any launch
+    lib = _lib.load()
+    assert lib.hiprec_pgmf_workspace_bytes(64) >= 64 * 4
+    rc = lib.hiprec_pgmf_bpr_grad(None, None, None, None, None, 4, 0.25, 0.0, None, None, 0, None, 0, None)
+    assert rc == -1 and b"NULL tables" in lib.hiprec_last_error()
+    big = _lib.PgmfTables(8, 8, 8, 3, 3, 300, 0)
+    rc = lib.hiprec_pgmf_bpr_grad(ctypes.byref(big), ctypes.byref(big), None, None, None, 0, 0.25, 0.0, None,
+                                  None, 0, None, 0, None)
+    assert rc == -1 and b"dim <= 256" in lib.hiprec_last_error()
+    rc = lib.hiprec_clip_grad_norm(None, 5, 1.0, None, 0, None)
+    assert rc == -1 and b"NULL" in lib.hiprec_last_error()
