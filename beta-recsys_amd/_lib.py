@@ -96,6 +96,14 @@ class PgmfTables(Structure):
                 ("n_users", c_int64), ("n_items", c_int64), ("dim", c_int32), ("_pad", c_int32)]
 
 
+class T2vTables(Structure):
+    """hiprec_t2v_tables (include/hiprec.h)."""
+
+    _fields_ = [("user_emb", c_void_p), ("item_emb1", c_void_p), ("item_emb2", c_void_p),
+                ("user_bias", c_void_p), ("item_bias", c_void_p),
+                ("n_users", c_int64), ("n_items", c_int64), ("dim", c_int32), ("_pad", c_int32)]
+
+
 class FusedStep(Structure):
     """hiprec_fused_step (include/hiprec.h)."""
 
@@ -191,6 +199,13 @@ SIGNATURES = {
     ),
     "hiprec_clip_workspace_bytes": (c_size_t, []),
     "hiprec_clip_grad_norm": (c_int, [_P, c_int64, c_float, _P, c_size_t, _P]),
+    "hiprec_t2v_grad": (
+        c_int,
+        [POINTER(T2vTables), POINTER(T2vTables), _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_float, _P, _P,
+         c_size_t, _P],
+    ),
+    "hiprec_t2v_predict": (c_int, [POINTER(T2vTables), _P, _P, c_int64, _P, _P, _P]),
+    "hiprec_alias_sample": (c_int, [_P, _P, _P, c_int64, ctypes.c_uint64, _P, c_int64, _P]),
     "hiprec_rank_metrics_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hiprec_rank_metrics": (
         c_int,

@@ -516,6 +516,47 @@ size_t hiprec_clip_workspace_bytes(void);
 int hiprec_clip_grad_norm(float* g, int64_t n, float max_norm, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* ================= Triple2vec (sibling models) ===============================
+ * models/triple2vec.py:11-34 parameters.  item_emb2 may be the SAME pointer as item_emb1 (in w and in
+ * g alike): triple2vec.py:19,38-39 aliases the two tables from the first forward on whenever
+ * n_neg != 0, and the kernels then load / update the shared row once. */
+typedef struct hiprec_t2v_tables {
+  float* user_emb;   /* [n_users, dim] */
+  float* item_emb1;  /* [n_items, dim] */
+  float* item_emb2;  /* [n_items, dim] or == item_emb1 */
+  float* user_bias;  /* [n_users] */
+  float* item_bias;  /* [n_items] */
+  int64_t n_users;
+  int64_t n_items;
+  int32_t dim;       /* <= 256 */
+  int32_t _pad;
+} hiprec_t2v_tables;
+
+/* ---- zero_grad + forward + backward of Triple2vecEngine.train_single_batch (triple2vec.py:36-92,
+ * 115-124).  pos_*[batch]; neg_*[batch * n_neg] row-major (the [B, n_neg] tensors of
+ * triple2vec.py:145-168).  Both negative item ROWS are gathered with neg_i2 and neg_i1 only selects an
+ * item_bias entry, exactly as triple2vec.py:46-47,69-71 do.  scale = 1 / (3 * config batch_size)
+ * (triple2vec.py:92 divides by the configured batch size, also for a short last batch).  Accumulates
+ * into the dense gradient g, leaves the loss partials in scratch and advances the step counter. */
+int hiprec_t2v_grad(const hiprec_t2v_tables* w, const hiprec_t2v_tables* g, const int64_t* pos_u,
+                    const int64_t* pos_i1, const int64_t* pos_i2, const int64_t* neg_u,
+                    const int64_t* neg_i1, const int64_t* neg_i2, int64_t batch, int32_t n_neg,
+                    float scale, hiprec_stats* stats, void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---- scores[k] = <U[u_k], (E1[i_k] + E2[i_k]) / 2>  (Triple2vec.predict, triple2vec.py:94-104) */
+int hiprec_t2v_predict(const hiprec_t2v_tables* w, const int64_t* users, const int64_t* items,
+                       int64_t n, float* scores, hiprec_stats* stats, void* stream);
+
+/* ---- AliasTable.sample (utils/alias_table.py:82-97; called three times per batch by
+ * Triple2vecEngine.train_an_epoch, triple2vec.py:145-168) on the device: n draws from the alias table
+ * (prob[vocab] fp64 = AliasTable.prob_arr, alias[vocab] = AliasTable.alias_arr, labels[vocab] =
+ * AliasTable.index2Label or NULL for the identity).  Draw e is a pure function of (seed, e):
+ * h1 = splitmix64(seed ^ splitmix64(e)), h2 = splitmix64(h1), column = mulhi64(h1, vocab),
+ * u = (h2 >> 11) * 2^-53, result = u < prob[column] ? column : alias[column]
+ * (oracle/triple2vec_numpy.py restates it bit for bit). */
+int hiprec_alias_sample(const double* prob, const int64_t* alias, const int64_t* labels, int64_t vocab,
+                        uint64_t seed, int64_t* out, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

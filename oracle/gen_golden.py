@@ -245,7 +245,7 @@ def main():
     epoch_fixture(MFEngine, PairwiseNegativeDataset, "mf_epoch_sgd", "sgd", seed=22)
 
 
-if __name__ == "__main__" and not {"--ncf", "--lightgcn", "--eval", "--sampler", "--c1", "--pgmf"} & set(sys.argv):
+if __name__ == "__main__" and not {"--ncf", "--lightgcn", "--eval", "--sampler", "--c1", "--pgmf", "--t2v"} & set(sys.argv):
     main()
 
 
@@ -634,3 +634,95 @@ def main_pgmf():
 
 if __name__ == "__main__" and "--pgmf" in sys.argv:
     main_pgmf()
+
+
+def t2v_config(U, I, D, B, n_neg, optimizer, lr):
+    model = dict(n_users=U, n_items=I, emb_dim=D, n_neg=n_neg, batch_size=B, device_str="cpu",
+                 optimizer=optimizer, lr=lr)
+    return {"model": model, "system": {"run_dir": "/tmp/hiprec_golden_runs"}}
+
+
+def t2v_fixture(Engine, name, U, I, D, B, n_neg, optimizer, lr, batch_lens, seed, scale=1.0):
+    """batch_lens: real length of each step's batch (a short one pins the / (3 * batch_size) quirk)."""
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    eng = quiet(Engine, t2v_config(U, I, D, B, n_neg, optimizer, lr))
+    m = eng.model
+    with torch.no_grad():
+        for emb in (m.user_emb, m.item_emb1, m.item_emb2):
+            emb.weight.mul_(scale)
+        m.user_bias.weight.copy_(torch.from_numpy(rng.normal(0, 0.3, (U, 1)).astype(np.float32)))
+        m.item_bias.weight.copy_(torch.from_numpy(rng.normal(0, 0.3, (I, 1)).astype(np.float32)))
+    n_steps = len(batch_lens)
+    out = {"meta": np.array([U, I, D, B, n_neg, n_steps, seed], dtype=np.int64), "optimizer": np.array(optimizer),
+           "lr": np.array(lr), "batch_lens": np.array(batch_lens, dtype=np.int64)}
+    for k, v in m.state_dict().items():
+        out[f"w0/{k}"] = v.detach().numpy().copy()
+    names = {id(p): n for n, p in m.named_parameters()}   # captured BEFORE item_emb2 is aliased away
+    params = list(m.parameters())
+    seen = []
+    orig_step = eng.optimizer.step
+
+    def capturing_step(*a, **k):
+        seen.append({names[id(p)]: (p.grad.detach().numpy().copy() if p.grad is not None
+                                    else np.zeros(tuple(p.shape), np.float32)) for p in params})
+        return orig_step(*a, **k)
+
+    eng.optimizer.step = capturing_step
+    losses = []
+    for s, n in enumerate(batch_lens):
+        batch = [rng.integers(0, U, n), zipf_items(rng, n, I), zipf_items(rng, n, I),
+                 rng.integers(0, U, (n, n_neg)), rng.integers(0, I, (n, n_neg)), rng.integers(0, I, (n, n_neg))]
+        for j, key in enumerate(("pos_u", "pos_i1", "pos_i2", "neg_u", "neg_i1", "neg_i2")):
+            out[f"b{s}/{key}"] = batch[j]
+        losses.append(eng.train_single_batch(tuple(torch.from_numpy(x) for x in batch)))
+        for k, v in m.state_dict().items():
+            out[f"w{s + 1}/{k}"] = v.detach().numpy().copy()
+        for k, v in seen[-1].items():
+            out[f"g{s + 1}/{k}"] = v
+        wanted = {"adam": (("exp_avg", "m"), ("exp_avg_sq", "v")), "rmsprop": (("square_avg", "v"),), "sgd": ()}
+        for p in params:
+            pst = eng.optimizer.state.get(p, {})   # empty for the orphaned item_emb2 (never gets a grad)
+            for sk, tag in wanted[optimizer]:
+                out[f"{tag}{s + 1}/{names[id(p)]}"] = (pst[sk].detach().numpy().copy() if sk in pst
+                                                       else np.zeros(tuple(p.shape), np.float32))
+    # predict on the trained model (item_emb2 is item_emb1 by now)
+    pu, pi = rng.integers(0, U, 40), rng.integers(0, I, 40)
+    out["predict/users"], out["predict/items"] = pu, pi
+    out["predict/scores"] = m.predict(pu, pi).numpy()
+    out["losses"] = np.array(losses, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: losses {losses}")
+
+
+def main_t2v():
+    """Triple2vec fixtures from the real reference engine + its AliasTable."""
+    import_reference()
+    from beta_rec.models.triple2vec import Triple2vecEngine
+    from beta_rec.utils.alias_table import AliasTable
+
+    t2v_fixture(Triple2vecEngine, "t2v_adam", 21, 17, 8, 12, 3, "adam", 1e-2, [12, 12, 5], 21, scale=60.0)
+    t2v_fixture(Triple2vecEngine, "t2v_sgd_d100", 30, 26, 100, 16, 1, "sgd", 0.5, [16, 16], 22, scale=30.0)
+    t2v_fixture(Triple2vecEngine, "t2v_rmsprop_init", 25, 31, 64, 8, 5, "rmsprop", 1e-3, [8, 8], 23)
+    out = {}
+    for tag, (U, I, D, seed) in {"a": (7, 5, 4, 3), "b": (19, 33, 64, 2020)}.items():
+        torch.manual_seed(seed)
+        eng = quiet(Triple2vecEngine, t2v_config(U, I, D, 8, 2, "adam", 1e-3))
+        out[f"{tag}/meta"] = np.array([U, I, D, seed], dtype=np.int64)
+        for k, v in eng.model.state_dict().items():
+            out[f"{tag}/w/{k}"] = v.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "t2v_init.npz"), **out)
+    # AliasTable construction: list and dict frequencies (alias_table.py:24-80)
+    rng = np.random.default_rng(5)
+    out = {}
+    for tag, freq in {"zipf": [int(1000 / (r + 1)) + 1 for r in range(37)],
+                      "flat": [3] * 8, "rand": rng.integers(1, 50, 101).tolist()}.items():
+        t = quiet(AliasTable, freq)
+        out[f"{tag}/freq"] = np.array(freq, dtype=np.int64)
+        out[f"{tag}/prob"] = np.asarray(t.prob_arr, dtype=np.float64)
+        out[f"{tag}/alias"] = np.asarray(t.alias_arr, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "alias_table.npz"), **out)
+
+
+if __name__ == "__main__" and "--t2v" in sys.argv:
+    main_t2v()
