@@ -367,6 +367,77 @@ def bench_lightgcn(args, device):
     print(json.dumps(out), flush=True)
 
 
+def bench_siblings(args, device):
+    """SURVEY.md §8f rank 4 siblings at the reference's own default shapes on ML-1M-sized tables:
+    pgmf = PairwiseGMF (configs/cmn_default.json: emb_dim 64, batch 1024, adam 1e-4, l2 1e-4, clip 5);
+    t2v  = Triple2vec  (configs/triple2vec_default.json: emb_dim 64, n_neg 5, batch 256, adam 5e-4)."""
+    import beta_recsys_amd as hp
+
+    run_dir = {"run_dir": "/tmp/hiprec_bench_runs"}
+    torch.manual_seed(2020)
+    g = torch.Generator().manual_seed(102)
+    if args.workload == "pgmf":
+        Bs = 1024
+        cfg = {"n_users": U, "n_items": I, "emb_dim": D, "regs": [1e-5], "batch_size": Bs, "lr": 1e-4,
+               "pretrain_l2_lambda": 1e-4, "grad_clip": 5.0, "neg_count": 4,
+               "model": {"device_str": str(device), "optimizer": "adam", "lr": 1e-4}, "system": run_dir}
+        with contextlib.redirect_stdout(io.StringIO()):
+            eng = hp.PairwiseGMFEngine(cfg)
+        n_total = (args.warmup + args.steps) * Bs
+        cols = [t.to(device) for t in synth_triples(n_total, seed=100)]
+        batch_of = lambda sl: tuple(c[sl] for c in cols)  # noqa: E731
+        P = eng.model.flat.numel()
+        # per triple: 3 ids + 3 rows read + 3 rows accumulated; per step: clip reads g once (4 P), the
+        # Adam sweep reads w, m, v, g and writes w, m, v (28 P)
+        bytes_step = Bs * (24 + 24 * D) + 32 * P
+        label = (f"PairwiseGMF (cmn_default.json): 6040 x 3706, emb_dim 64, batch {Bs}, adam 1e-4, "
+                 "l2 1e-4, grad_clip 5.0")
+        unit = "triples/s"
+    else:
+        Bs, n_neg = 256, 5
+        cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, n_neg=n_neg, batch_size=Bs, device_str=str(device),
+                             optimizer="adam", lr=5e-4), "system": run_dir}
+        with contextlib.redirect_stdout(io.StringIO()):
+            eng = hp.Triple2vecEngine(cfg)
+        n_total = (args.warmup + args.steps) * Bs
+        u, i1, _ = synth_triples(n_total, seed=100)
+        _, i2, _ = synth_triples(n_total, seed=101)
+        _, nb1, _ = synth_triples(n_total * n_neg, seed=103)   # popularity-weighted, like the alias sampler
+        _, nb2, _ = synth_triples(n_total * n_neg, seed=104)
+        nu = torch.randint(0, U, (n_total, n_neg), generator=g)
+        cols = [t.to(device) for t in (u, i1, i2, nu, nb1.reshape(n_total, n_neg), nb2.reshape(n_total, n_neg))]
+        batch_of = lambda sl: tuple(c[sl] for c in cols)  # noqa: E731
+        eng.model._alias()
+        P = eng.model.n_active()
+        # per triple (item_emb2 aliased): 3 + 3 n_neg ids, 3 + 2 n_neg rows read and as many
+        # accumulated, 3 + 3 n_neg bias reads + updates; per step the Adam sweep (28 P)
+        bytes_step = Bs * ((3 + 3 * n_neg) * 8 + 2 * (3 + 2 * n_neg) * D * 4 + 2 * (3 + 3 * n_neg) * 4) + 28 * P
+        label = (f"Triple2vec (triple2vec_default.json): 6040 x 3706, emb_dim 64, n_neg {n_neg}, "
+                 f"batch {Bs}, adam 5e-4")
+        unit = "triples/s"
+
+    def run(lo, n):  # n steps = one resident "epoch" of n * Bs triples, enqueued by the library's C driver
+        eng.enqueue_epoch(*batch_of(slice(lo, lo + n * Bs)))
+
+    run(0, args.warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.warmup * Bs, args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = eng._sync_stats()
+    out = {"metric": f"training interactions/sec ({args.workload} triples)", "value": args.steps * Bs / dt,
+           "unit": unit, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": label, "last_loss": st.loss},
+           "roofline": {"bound": "hbm", "algorithmic_bytes_per_step": bytes_step,
+                        "achieved": bytes_step / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": bytes_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                        "note": "whole step (all launches); at these batch sizes the step is launch-latency bound"}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -377,7 +448,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--two-kernel", action="store_true",
                     help="mf: gradient kernel + dense optimizer sweep per step instead of the fused one-kernel step")
-    ap.add_argument("--workload", default="mf", choices=["mf", "ncf", "lightgcn", "mf-c4shard", "mf-c4"],
+    ap.add_argument("--workload", default="mf", choices=["mf", "ncf", "lightgcn", "mf-c4shard", "mf-c4", "pgmf", "t2v"],
                     help="mf = BASELINE configs[1] (the headline); ncf = configs[2] (NeuMF, emb_dim 32)")
     ap.add_argument("--multi-gpu", default="auto", choices=["auto", "replicated", "sharded"],
                     help="N>1: replicate small tables (gradient all-reduce) or row-shard them "
@@ -407,6 +478,8 @@ def main():
         return bench_ncf(args, device)
     if args.workload == "lightgcn":
         return bench_lightgcn(args, device)
+    if args.workload in ("pgmf", "t2v"):
+        return bench_siblings(args, device)
     if args.workload in ("mf-c4shard", "mf-c4"):
         return bench_mf_c4shard(args, device, full=args.workload == "mf-c4")
 

@@ -197,6 +197,17 @@ SIGNATURES = {
         [POINTER(PgmfTables), POINTER(PgmfTables), _P, _P, _P, c_int64, c_float, c_float, _P, _P, c_size_t,
          _P, c_size_t, _P],
     ),
+    "hiprec_pgmf_epoch": (
+        c_int,
+        [POINTER(PgmfTables), POINTER(PgmfTables), _P, _P, _P, c_int64, c_int64, c_float, c_float, c_int,
+         c_double, c_double, c_double, c_double, _P, _P, _P, _P, c_int64, _P, _P, c_size_t, _P, c_size_t,
+         _P, c_size_t, _P],
+    ),
+    "hiprec_t2v_epoch": (
+        c_int,
+        [POINTER(T2vTables), POINTER(T2vTables), _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int32, c_float,
+         c_int, c_double, c_double, c_double, c_double, _P, _P, _P, _P, c_int64, _P, _P, c_size_t, _P],
+    ),
     "hiprec_clip_workspace_bytes": (c_size_t, []),
     "hiprec_clip_grad_norm": (c_int, [_P, c_int64, c_float, _P, c_size_t, _P]),
     "hiprec_t2v_grad": (

@@ -13,8 +13,8 @@
 //                         fp32 atomics, the gradient of v summed per wave in registers and per block
 //                         in LDS, one [D] partial per block written to the workspace (no atomics on
 //                         the D hot addresses)
-//   pgmf_finish_kernel    1 block: deterministic sum of the per-block partials of grad v, + the
-//                         gradient and the value of lambda * ||v||
+//   pgmf_finish_kernel    1 block of 1024 threads: deterministic sum of the per-block partials of
+//                         grad v, + the gradient and the value of lambda * ||v||
 //   clip_sumsq_kernel / clip_scale_kernel   torch.nn.utils.clip_grad_norm_ over the flat gradient
 //   hiprec_opt_dense_step                   the optimizer sweep, shared with MF / NCF / LightGCN
 // HBM-bound integer-indexed row traffic: 3 rows read + 3 rows accumulated per triple, like BPR-MF.
@@ -116,30 +116,52 @@ __global__ __launch_bounds__(kBlock) void pgmf_bpr_grad_kernel(
   if (stepper) step_store_advanced(stats, step_state);
 }
 
-// One block.  g.v[c] += sum_b vpart[b][c] + lambda * v[c] / ||v||; loss partial += lambda * ||v||.
-__global__ __launch_bounds__(kBlock) void pgmf_finish_kernel(hiprec_pgmf_tables w,
-                                                             hiprec_pgmf_tables g,
-                                                             const float* __restrict__ vpart,
-                                                             int n_blocks, float l2_lambda,
-                                                             Scratch* scratch) {
-  __shared__ float s_sq[kBlock];
+// One block of kFinishThreads.  g.v[c] += sum_b vpart[b][c] + lambda * v[c] / ||v||; loss partial +=
+// lambda * ||v||.  Thread (s, c) sums the partials of blocks b = s, s + n_slices, ... with four loads in
+// flight (one thread per column walking all blocks serially cost 57 us at 256 blocks: 256 dependent
+// L2 round trips); the slices are then added in a fixed order, so the result is deterministic.
+// (Folding this into the gradient kernel with a "last block done" counter was measured and lost:
+// the agent-scope fences it needs write the L2 of every XCD back, 24.6 us vs 4.4 + 4.7 us.)
+constexpr int kFinishThreads = 1024;
+
+__global__ __launch_bounds__(kFinishThreads) void pgmf_finish_kernel(hiprec_pgmf_tables w,
+                                                                     hiprec_pgmf_tables g,
+                                                                     const float* __restrict__ vpart,
+                                                                     int n_blocks, float l2_lambda,
+                                                                     Scratch* scratch) {
+  __shared__ float s_part[kFinishThreads];
+  __shared__ float s_sq[kPgmfMaxNpl * kWave];
   const int D = w.dim;
-  const int c = threadIdx.x;
-  float vc = 0.f, sum = 0.f;
-  if (c < D) {
-    vc = w.v[c];
-    for (int b = 0; b < n_blocks; ++b) sum += vpart[static_cast<int64_t>(b) * D + c];
+  const int n_slices = kFinishThreads / D;  // >= 4 (D <= 256)
+  const int c = threadIdx.x % D;
+  const int sl = threadIdx.x / D;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (sl < n_slices) {
+    int b = sl;
+    for (; b + 3 * n_slices < n_blocks; b += 4 * n_slices) {
+      a0 += vpart[static_cast<int64_t>(b) * D + c];
+      a1 += vpart[static_cast<int64_t>(b + n_slices) * D + c];
+      a2 += vpart[static_cast<int64_t>(b + 2 * n_slices) * D + c];
+      a3 += vpart[static_cast<int64_t>(b + 3 * n_slices) * D + c];
+    }
+    for (; b < n_blocks; b += n_slices) a0 += vpart[static_cast<int64_t>(b) * D + c];
   }
-  s_sq[c] = vc * vc;
+  s_part[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  const float vc = static_cast<int>(threadIdx.x) < D ? w.v[threadIdx.x] : 0.f;
+  if (threadIdx.x < kPgmfMaxNpl * kWave) s_sq[threadIdx.x] = vc * vc;
   __syncthreads();
-  for (int s = kBlock / 2; s > 0; s >>= 1) {
-    if (c < s) s_sq[c] += s_sq[c + s];
+  for (int s = kPgmfMaxNpl * kWave / 2; s > 0; s >>= 1) {
+    if (static_cast<int>(threadIdx.x) < s) s_sq[threadIdx.x] += s_sq[threadIdx.x + s];
     __syncthreads();
   }
   const float l2 = sqrtf(s_sq[0]);
-  // sqrt backward then pow backward: lambda / (2 l2) * 2 v  (0/0 -> NaN exactly as autograd gives)
-  if (c < D) g.v[c] += sum + (l2_lambda / (2.f * l2)) * (2.f * vc);
-  if (c == 0) {
+  if (static_cast<int>(threadIdx.x) < D) {
+    float sum = 0.f;
+    for (int i = 0; i < n_slices; ++i) sum += s_part[i * D + threadIdx.x];
+    // sqrt backward then pow backward: lambda / (2 l2) * 2 v  (0/0 -> NaN exactly as autograd gives)
+    g.v[threadIdx.x] += sum + (l2_lambda / (2.f * l2)) * (2.f * vc);
+  }
+  if (threadIdx.x == 0) {
     const uint32_t n = scratch->n_partials;
     scratch->partials[n] = make_float4(l2_lambda * l2, 0.f, 0.f, 0.f);
     scratch->n_partials = n + 1;
@@ -260,7 +282,7 @@ extern "C" int hiprec_pgmf_bpr_grad(const hiprec_pgmf_tables* w, const hiprec_pg
                                                static_cast<Scratch*>(scratch),
                                                static_cast<float*>(workspace));
   HIPREC_TRY(hipGetLastError());
-  pgmf_finish_kernel<<<1, kBlock, 0, s>>>(*w, *g, static_cast<const float*>(workspace), grid,
+  pgmf_finish_kernel<<<1, kFinishThreads, 0, s>>>(*w, *g, static_cast<const float*>(workspace), grid,
                                           l2_lambda, static_cast<Scratch*>(scratch));
   HIPREC_TRY(hipGetLastError());
   return 0;
@@ -279,5 +301,35 @@ extern "C" int hiprec_clip_grad_norm(float* g, int64_t n, float max_norm, void* 
   HIPREC_TRY(hipGetLastError());
   clip_scale_kernel<<<grid, kBlock, 0, s>>>(g, n, max_norm, grid, static_cast<double*>(workspace));
   HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+// PairwiseGMFEngine.train_an_epoch (pairwise_gmf.py:118-142) over resident (user, pos, neg) arrays in
+// visiting order: every batch is hiprec_pgmf_bpr_grad + hiprec_clip_grad_norm + hiprec_opt_dense_step,
+// enqueued back to back from C (the python loop costs ~50 us per step, three times the kernels).
+extern "C" int hiprec_pgmf_epoch(const hiprec_pgmf_tables* w, const hiprec_pgmf_tables* g,
+                                 const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                 int64_t n_triples, int64_t batch, float l2_lambda, float max_norm,
+                                 int kind, double lr, double beta1, double beta2, double eps,
+                                 float* flat_w, float* flat_g, float* flat_m, float* flat_v,
+                                 int64_t n_flat, hiprec_stats* stats, void* scratch,
+                                 size_t scratch_bytes, void* workspace, size_t workspace_bytes,
+                                 void* clip_workspace, size_t clip_workspace_bytes, void* stream) {
+  HIPREC_REQUIRE(n_triples >= 0 && batch > 0, "bad n_triples/batch");
+  HIPREC_REQUIRE(flat_w && flat_g && n_flat > 0, "the dense optimizer needs the flat buffers");
+  if (int rc = hiprec_stats_begin_epoch(stats, stream)) return rc;
+  for (int64_t off = 0; off < n_triples; off += batch) {
+    const int64_t b = (n_triples - off < batch) ? (n_triples - off) : batch;
+    if (int rc = hiprec_pgmf_bpr_grad(w, g, users + off, pos + off, neg + off, b,
+                                      1.0f / static_cast<float>(b), l2_lambda, stats, scratch,
+                                      scratch_bytes, workspace, workspace_bytes, stream))
+      return rc;
+    if (int rc = hiprec_clip_grad_norm(flat_g, n_flat, max_norm, clip_workspace, clip_workspace_bytes,
+                                       stream))
+      return rc;
+    if (int rc = hiprec_opt_dense_step(kind, flat_w, flat_g, flat_m, flat_v, n_flat, lr, beta1, beta2,
+                                       eps, stats, scratch, -1, stream))
+      return rc;
+  }
   return 0;
 }

@@ -216,21 +216,44 @@ class PairwiseGMFEngine(ModelEngine):
         self._enqueue_step(batch_data)
         return self._sync_stats().loss
 
+    def enqueue_epoch(self, users, pos, neg):
+        """One epoch over resident device arrays in visiting order (batches of ``batch_size``, the last
+        one short), enqueued by ``hiprec_pgmf_epoch`` with no host work between steps and no sync."""
+        lib = self._setup()
+        m, opt = self.model, self.optimizer
+        dev = m.flat.device
+        users, pos, neg = (x.to(dev).to(torch.int64).reshape(-1).contiguous() for x in (users, pos, neg))
+        if not (users.numel() == pos.numel() == neg.numel()):
+            raise ValueError("epoch arrays differ in length")
+        w, g = m.tables(), m.tables(self._g_flat)
+        _lib.check(lib.hiprec_pgmf_epoch(
+            ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), users.numel(),
+            int(self.batch_size), float(self.config["pretrain_l2_lambda"]), float(self.config["grad_clip"]),
+            opt.kind, opt.lr, opt.beta1, opt.beta2, opt.eps, _lib.ptr(m.flat), _lib.ptr(self._g_flat),
+            _lib.ptr(opt.exp_avg), _lib.ptr(opt.exp_avg_sq), m.flat.numel(), _lib.ptr(self._stats),
+            _lib.ptr(self._scratch), self._scratch.numel(), _lib.ptr(self._ws), self._ws.numel(),
+            _lib.ptr(self._clip_ws), self._clip_ws.numel() * 8, _lib.stream_ptr(dev)))
+
     def train_an_epoch(self, train_loader, epoch_id):
         """pairwise_gmf.py:118-142: batches come from ``train_loader.cmn_train_loader(batch_size, False,
         neg_count)`` as ``[B, 3]`` arrays (any iterable of such arrays is accepted too); prints the last
-        batch's loss and logs the epoch sum.  The whole epoch is enqueued with one host sync at the end."""
+        batch's loss and logs the epoch sum.  The batches are collected, moved to the device in one copy
+        and the whole epoch is enqueued from C with one host sync at the end."""
         assert hasattr(self, "model"), "Please specify the exact model !"
         self.model.train()
-        lib = self._setup()
-        _lib.check(lib.hiprec_stats_begin_epoch(_lib.ptr(self._stats),
-                                                _lib.stream_ptr(self.model.flat.device)))
+        self._setup()
+        dev = self.model.flat.device
         if hasattr(train_loader, "cmn_train_loader"):
             batches = train_loader.cmn_train_loader(self.batch_size, False, self.config["neg_count"])
         else:
             batches = train_loader
-        for batch in batches:
-            self._enqueue_step((batch[:, 0], batch[:, 1], batch[:, 2]))
+        blocks = [b if isinstance(b, torch.Tensor) else torch.from_numpy(np.array(b, dtype=np.int32)) for b in batches]
+        if not blocks:
+            raise ValueError("empty epoch")
+        if any(b.shape[0] != self.batch_size for b in blocks[:-1]) or blocks[-1].shape[0] > self.batch_size:
+            raise ValueError("every batch but the last must hold batch_size triples")
+        epoch = torch.cat([b.to(dev).to(torch.int64).reshape(-1, 3) for b in blocks])
+        self.enqueue_epoch(epoch[:, 0], epoch[:, 1], epoch[:, 2])
         st = self._sync_stats()
         print("[Training Epoch {}], Loss {}".format(epoch_id, st.loss))
         self.writer.add_scalar("model/loss", st.loss_sum, epoch_id)

@@ -290,20 +290,54 @@ class Triple2vecEngine(ModelEngine):
         base = (self.sampler_seed * 1_000_003 + int(epoch_id)) * 1_000_003 + batch_id
         return [us.sample(n_neg, n, 3 * base), its.sample(n_neg, n, 3 * base + 1), its.sample(n_neg, n, 3 * base + 2)]
 
+    def enqueue_epoch(self, pos_u, pos_i1, pos_i2, neg_u, neg_i1, neg_i2):
+        """One epoch over resident device arrays in visiting order (``pos_*[N]``, ``neg_*[N, n_neg]``;
+        batches of the configured ``batch_size``, the last one short), enqueued by ``hiprec_t2v_epoch``
+        with no host work between steps and no sync."""
+        lib = self._setup()
+        m, opt = self.model, self.optimizer
+        m._alias()
+        dev = m.flat.device
+        t = [x.to(dev).to(torch.int64).contiguous() for x in (pos_u, pos_i1, pos_i2, neg_u, neg_i1, neg_i2)]
+        N = t[0].numel()
+        if N == 0:
+            raise ValueError("empty epoch")
+        n_neg = t[3].numel() // N
+        if not (t[1].numel() == N and t[2].numel() == N and all(x.numel() == N * n_neg for x in t[3:])):
+            raise ValueError("epoch arrays must be pos_*[N] and neg_*[N, n_neg]")
+        w, g = m.tables(), m.tables(self._g_flat)
+        _lib.check(lib.hiprec_t2v_epoch(
+            ctypes.byref(w), ctypes.byref(g), *(_lib.ptr(x) for x in t), N, int(m.batch_size), n_neg,
+            1.0 / (3 * m.batch_size), opt.kind, opt.lr, opt.beta1, opt.beta2, opt.eps, _lib.ptr(m.flat),
+            _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg), _lib.ptr(opt.exp_avg_sq), m.n_active(),
+            _lib.ptr(self._stats), _lib.ptr(self._scratch), self._scratch.numel(), _lib.stream_ptr(dev)))
+
     def train_an_epoch(self, train_loader, epoch_id):
         """triple2vec.py:126-169: every ``sample`` of the loader is a ``[B, 3]`` block of (u, i1, i2)
-        triples; negatives are drawn per batch; prints the LAST batch's loss and logs the epoch sum.
-        The whole epoch is enqueued with one host sync at the end."""
+        triples; negatives are drawn per batch (host sampler, in the reference's order: users, items,
+        items) or for the whole epoch at once (device sampler); prints the LAST batch's loss and logs the
+        epoch sum.  The epoch is enqueued from C with one host sync at the end."""
         assert hasattr(self, "model"), "Please specify the exact model !"
         self.model.train()
-        lib = self._setup()
+        self._setup()
         dev = self.model.flat.device
-        _lib.check(lib.hiprec_stats_begin_epoch(_lib.ptr(self._stats), _lib.stream_ptr(dev)))
+        blocks, negs = [], []
         for batch_id, sample in enumerate(train_loader):
             sample = torch.as_tensor(sample, device=dev).to(torch.int64).reshape(-1, 3)
-            negs = self._negatives(sample.shape[0], epoch_id, batch_id)
-            cols = [sample[:, k].contiguous() for k in range(3)]
-            self._enqueue_step((cols[0], cols[1], cols[2], negs[0], negs[1], negs[2]))
+            blocks.append(sample)
+            if self.negative_sampler == "host":
+                negs.append(self._negatives(sample.shape[0], epoch_id, batch_id))
+        if not blocks:
+            raise ValueError("empty epoch")
+        B = self.model.batch_size
+        if any(b.shape[0] != B for b in blocks[:-1]) or blocks[-1].shape[0] > B:
+            raise ValueError("every batch but the last must hold batch_size triples")
+        epoch = torch.cat(blocks)
+        if self.negative_sampler == "host":
+            neg = [torch.cat([n[k] for n in negs]) for k in range(3)]
+        else:
+            neg = self._negatives(epoch.shape[0], epoch_id, 0)
+        self.enqueue_epoch(epoch[:, 0], epoch[:, 1], epoch[:, 2], *neg)
         st = self._sync_stats()
         print("[Training Epoch {}], Loss {}".format(epoch_id, st.loss))
         self.writer.add_scalar("model/loss", st.loss_sum, epoch_id)

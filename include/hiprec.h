@@ -508,6 +508,18 @@ int hiprec_pgmf_bpr_grad(const hiprec_pgmf_tables* w, const hiprec_pgmf_tables* 
                          float inv_batch, float l2_lambda, hiprec_stats* stats, void* scratch,
                          size_t scratch_bytes, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- PairwiseGMFEngine.train_an_epoch (pairwise_gmf.py:118-142) over resident (user, pos, neg) arrays
+ * in visiting order (n_triples, last batch short): per batch hiprec_pgmf_bpr_grad, hiprec_clip_grad_norm
+ * (max_norm) and hiprec_opt_dense_step over the flat buffers [user_memory | item_memory | v] that w / g
+ * point into, enqueued back to back with no host work in between. */
+int hiprec_pgmf_epoch(const hiprec_pgmf_tables* w, const hiprec_pgmf_tables* g, const int64_t* users,
+                      const int64_t* pos, const int64_t* neg, int64_t n_triples, int64_t batch,
+                      float l2_lambda, float max_norm, int kind, double lr, double beta1, double beta2,
+                      double eps, float* flat_w, float* flat_g, float* flat_m, float* flat_v,
+                      int64_t n_flat, hiprec_stats* stats, void* scratch, size_t scratch_bytes,
+                      void* workspace, size_t workspace_bytes, void* clip_workspace,
+                      size_t clip_workspace_bytes, void* stream);
+
 /* ---- torch.nn.utils.clip_grad_norm_(parameters, max_norm) (pairwise_gmf.py:111, cmn.py:197), L2,
  * over one flat gradient of n floats: total = ||g||, g *= min(max_norm / (total + 1e-6), 1).
  * workspace: hiprec_clip_workspace_bytes() of device memory; afterwards workspace[0] (fp64) holds
@@ -542,6 +554,18 @@ int hiprec_t2v_grad(const hiprec_t2v_tables* w, const hiprec_t2v_tables* g, cons
                     const int64_t* pos_i1, const int64_t* pos_i2, const int64_t* neg_u,
                     const int64_t* neg_i1, const int64_t* neg_i2, int64_t batch, int32_t n_neg,
                     float scale, hiprec_stats* stats, void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---- Triple2vecEngine.train_an_epoch (triple2vec.py:126-169) over resident arrays in visiting order
+ * (pos_*[n_triples], neg_*[n_triples * n_neg], last batch short): per batch hiprec_t2v_grad and
+ * hiprec_opt_dense_step over the first n_sweep floats of the flat buffers (the host lays the orphaned
+ * item_emb2 out last and leaves it out of the sweep), enqueued back to back. */
+int hiprec_t2v_epoch(const hiprec_t2v_tables* w, const hiprec_t2v_tables* g, const int64_t* pos_u,
+                     const int64_t* pos_i1, const int64_t* pos_i2, const int64_t* neg_u,
+                     const int64_t* neg_i1, const int64_t* neg_i2, int64_t n_triples, int64_t batch,
+                     int32_t n_neg, float scale, int kind, double lr, double beta1, double beta2,
+                     double eps, float* flat_w, float* flat_g, float* flat_m, float* flat_v,
+                     int64_t n_sweep, hiprec_stats* stats, void* scratch, size_t scratch_bytes,
+                     void* stream);
 
 /* ---- scores[k] = <U[u_k], (E1[i_k] + E2[i_k]) / 2>  (Triple2vec.predict, triple2vec.py:94-104) */
 int hiprec_t2v_predict(const hiprec_t2v_tables* w, const int64_t* users, const int64_t* items,

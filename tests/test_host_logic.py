@@ -526,6 +526,12 @@ def test_pairwise_gmf_engine_surface():
     assert rc == -1 and b"dim <= 256" in lib.hiprec_last_error()
     rc = lib.hiprec_clip_grad_norm(None, 5, 1.0, None, 0, None)
     assert rc == -1 and b"NULL" in lib.hiprec_last_error()
+    rc = lib.hiprec_pgmf_epoch(None, None, None, None, None, 10, 0, 0.0, 5.0, 1, 1e-3, 0.9, 0.999, 1e-8, None, None,
+                               None, None, 0, None, None, 0, None, 0, None, 0, None)
+    assert rc == -1 and b"bad n_triples/batch" in lib.hiprec_last_error()
+    rc = lib.hiprec_pgmf_epoch(None, None, None, None, None, 10, 4, 0.0, 5.0, 1, 1e-3, 0.9, 0.999, 1e-8, None, None,
+                               None, None, 0, None, None, 0, None, 0, None, 0, None)
+    assert rc == -1 and b"flat buffers" in lib.hiprec_last_error()
 
 
 def t2v_config(U=9, I=7, D=4, n_neg=2, **model):
@@ -594,6 +600,9 @@ def test_triple2vec_item_emb2_alias_and_layout():
     rc = lib.hiprec_t2v_grad(ctypes.byref(mixed_w), ctypes.byref(plain_g), None, None, None, None, None, None, 0, 2,
                              0.1, None, None, 0, None)
     assert rc == -1 and b"alias" in lib.hiprec_last_error()
+    rc = lib.hiprec_t2v_epoch(None, None, None, None, None, None, None, None, 10, 4, -1, 0.1, 1, 1e-3, 0.9, 0.999,
+                              1e-8, None, None, None, None, 0, None, None, 0, None)
+    assert rc == -1 and b"bad n_triples/batch/n_neg" in lib.hiprec_last_error()
     rc = lib.hiprec_alias_sample(None, None, None, 0, 1, None, 5, None)
     assert rc == -1 and b"bad sizes" in lib.hiprec_last_error()
     rc = lib.hiprec_t2v_predict(ctypes.byref(mixed_w), None, None, 3, None, None, None)
