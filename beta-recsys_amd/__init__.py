@@ -11,6 +11,7 @@ from .torch_engine import HipOptimizer, ModelEngine  # noqa: F401
 from .mf import MF, DeviceTripleBatcher, MFEngine, gather_rows  # noqa: F401
 from .ncf import GMF, MLP, GMFEngine, MLPEngine, NeuMF, NeuMFEngine  # noqa: F401
 from .lightgcn import LightGCN, LightGCNEngine  # noqa: F401
+from .ngcf import NGCF, NGCFEngine  # noqa: F401
 from .pairwise_gmf import PairwiseGMF, PairwiseGMFEngine  # noqa: F401
 from .triple2vec import Triple2vec, Triple2vecEngine  # noqa: F401
 from . import eval  # noqa: F401,A004  (evaluate / predict / rank_metrics)

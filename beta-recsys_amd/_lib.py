@@ -104,6 +104,22 @@ class T2vTables(Structure):
                 ("n_users", c_int64), ("n_items", c_int64), ("dim", c_int32), ("_pad", c_int32)]
 
 
+NGCF_MAX_LAYERS = 6
+
+
+class NgcfPlan(Structure):
+    """hiprec_ngcf_plan (include/hiprec.h)."""
+
+    _fields_ = ([("a", Csr), ("at", Csr), ("n_users", c_int64), ("n_items", c_int64), ("n_layers", c_int32),
+                 ("dim", c_int32 * (NGCF_MAX_LAYERS + 1)), ("decay", c_float), ("inv_reg_batch", c_float),
+                 ("e0", c_void_p), ("g_e0", c_void_p)]
+                + [(n, c_void_p * NGCF_MAX_LAYERS) for n in ("gc_w", "gc_b", "bi_w", "bi_b", "g_gc_w", "g_gc_b", "g_bi_w",
+                                                "g_bi_b", "side", "bi_in", "sum_pre", "bi_pre", "ego", "nrm")]
+                + [("all", c_void_p), ("keep", c_void_p * NGCF_MAX_LAYERS), ("keep_scale", c_float * NGCF_MAX_LAYERS),
+                   ("d_all", c_void_p), ("d_sum", c_void_p), ("d_bi", c_void_p), ("d_side", c_void_p),
+                   ("d_bi_in", c_void_p), ("d_ego", c_void_p * 2), ("spmm_tmp", c_void_p)])
+
+
 class FusedStep(Structure):
     """hiprec_fused_step (include/hiprec.h)."""
 
@@ -217,6 +233,10 @@ SIGNATURES = {
     ),
     "hiprec_t2v_predict": (c_int, [POINTER(T2vTables), _P, _P, c_int64, _P, _P, _P]),
     "hiprec_alias_sample": (c_int, [_P, _P, _P, c_int64, ctypes.c_uint64, _P, c_int64, _P]),
+    "hiprec_ngcf_plan_bytes": (c_size_t, []),
+    "hiprec_ngcf_forward": (c_int, [POINTER(NgcfPlan), c_int, _P]),
+    "hiprec_ngcf_predict": (c_int, [POINTER(NgcfPlan), _P, _P, c_int64, _P, _P, _P]),
+    "hiprec_ngcf_grad": (c_int, [POINTER(NgcfPlan), _P, _P, _P, c_int64, c_float, _P, _P, c_size_t, _P]),
     "hiprec_rank_metrics_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hiprec_rank_metrics": (
         c_int,
@@ -285,6 +305,8 @@ def load():
         raise RuntimeError("hiprec_fused_step layout mismatch between _lib.py and libhiprec.so")
     if lib.hiprec_dp_step_bytes() != ctypes.sizeof(DpStep):
         raise RuntimeError("hiprec_dp_step layout mismatch between _lib.py and libhiprec.so")
+    if lib.hiprec_ngcf_plan_bytes() != ctypes.sizeof(NgcfPlan):
+        raise RuntimeError("hiprec_ngcf_plan layout mismatch between _lib.py and libhiprec.so")
     if lib.hiprec_ncf_plan_bytes() != ctypes.sizeof(NcfPlan):
         raise RuntimeError("hiprec_ncf_plan layout mismatch between _lib.py and libhiprec.so")
     _lib = lib

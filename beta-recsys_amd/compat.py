@@ -15,6 +15,7 @@ MIRRORS = {
     "beta_rec.models.gmf": "ncf",
     "beta_rec.models.mlp": "ncf",
     "beta_rec.models.lightgcn": "lightgcn",
+    "beta_rec.models.ngcf": "ngcf",
     "beta_rec.models.pairwise_gmf": "pairwise_gmf",
     "beta_rec.models.triple2vec": "triple2vec",
 }

@@ -1,0 +1,49 @@
+// Grouped exact-fp32 MFMA GEMM (csrc/ncf.hip): the problem descriptors and the host-side launcher,
+// shared by the NCF tower (ncf.hip) and NGCF's per-hop Linear layers (ngcf.hip).  The kernel itself
+// lives in ncf.hip only.
+#pragma once
+#include "common.hpp"
+
+namespace hiprec {
+
+// One problem of a grouped launch.  mode kNT / kNN / kTNm: C[M,N] = epilogue(op(A) op(B)) with
+//   kNT : A is [M,K] (lda), B is [N,K] (ldb)          C = A B^T      (forward: H W^T)
+//   kNN : A is [M,K] (lda), B is [K,N] (ldb)          C = A B        (dgrad:   dZ W)
+//   kTNm: A is [K,M] (lda), B is [K,N] (ldb)          C = A^T B      (wgrad:   dZ^T H)
+//   epilogue: + bias[n] (if bias) ; relu (if relu) ; * [mask[m,n] > 0] (if mask)
+// mode kColsum: C[n] += sum_m A[m, n] over the block's kColsumRows rows (bias gradients).
+enum GemmMode { kNT = 0, kNN = 1, kTNm = 2, kColsum = 3 };
+
+struct GemmProblem {
+  int mode, M, N, K;
+  const float* A;
+  int lda;
+  const float* B;
+  int ldb;
+  float* C;
+  int ldc;
+  const float* bias;
+  int relu;
+  const float* mask;
+  int ldm;
+  int tiles_n, tiles_m, split;  // block decomposition of this problem
+  int first_block;              // its first block in the grouped grid
+};
+
+constexpr int kMaxGroup = 16;
+struct GemmGroup {
+  int n;
+  GemmProblem p[kMaxGroup];
+};
+
+// split_k: let the launcher split K over several blocks that accumulate with atomics into a
+// ZERO-INITIALISED C (only without an epilogue: the weight-gradient GEMMs).
+GemmProblem make_gemm(int mode, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                      float* C, int ldc, const float* bias, int relu, const float* mask, int ldm,
+                      bool split_k);
+// C[n] += sum_m X[m, n]
+GemmProblem make_colsum(const float* X, int M, int N, int ldx, float* out);
+// assigns the blocks of g.p[0..n) and launches them as ONE grid
+int launch_group(GemmGroup& g, hipStream_t st);
+
+}  // namespace hiprec

@@ -17,6 +17,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "gemm.hpp"
 
 namespace hiprec {
 
@@ -29,36 +30,6 @@ constexpr int kTM = 64, kTN = 64, kTK = 32;
 // waits for vmcnt(0), i.e. for the register-prefetched operands of the next k-step, which serialised
 // every k-step on a full memory round trip.
 
-
-// One problem of a grouped launch.  mode kNT / kNN / kTNm: C[M,N] = epilogue(op(A) op(B)) with
-//   kNT : A is [M,K] (lda), B is [N,K] (ldb)          C = A B^T      (forward: H W^T)
-//   kNN : A is [M,K] (lda), B is [K,N] (ldb)          C = A B        (dgrad:   dZ W)
-//   kTNm: A is [K,M] (lda), B is [K,N] (ldb)          C = A^T B      (wgrad:   dZ^T H)
-//   epilogue: + bias[n] (if bias) ; relu (if relu) ; * [mask[m,n] > 0] (if mask)
-// mode kColsum: C[n] += sum_m A[m, n] over the block's kColsumRows rows (bias gradients).
-enum GemmMode { kNT = 0, kNN = 1, kTNm = 2, kColsum = 3 };
-
-struct GemmProblem {
-  int mode, M, N, K;
-  const float* A;
-  int lda;
-  const float* B;
-  int ldb;
-  float* C;
-  int ldc;
-  const float* bias;
-  int relu;
-  const float* mask;
-  int ldm;
-  int tiles_n, tiles_m, split;  // block decomposition of this problem
-  int first_block;              // its first block in the grouped grid
-};
-
-constexpr int kMaxGroup = 16;
-struct GemmGroup {
-  int n;
-  GemmProblem p[kMaxGroup];
-};
 
 constexpr int kColsumRows = 128;
 
@@ -227,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void gemm_group_kernel(GemmGroup g) {
   }
 }
 
-static GemmProblem make_gemm(int mode, int M, int N, int K, const float* A, int lda, const float* B,
+GemmProblem make_gemm(int mode, int M, int N, int K, const float* A, int lda, const float* B,
                              int ldb, float* C, int ldc, const float* bias, int relu,
                              const float* mask, int ldm, bool split_k) {
   GemmProblem q{};
@@ -248,7 +219,7 @@ static GemmProblem make_gemm(int mode, int M, int N, int K, const float* A, int 
   return q;
 }
 
-static GemmProblem make_colsum(const float* X, int M, int N, int ldx, float* out) {
+GemmProblem make_colsum(const float* X, int M, int N, int ldx, float* out) {
   GemmProblem q{};
   q.mode = kColsum; q.M = M; q.N = N; q.A = X; q.lda = ldx; q.C = out;
   q.tiles_n = 1;
@@ -257,7 +228,7 @@ static GemmProblem make_colsum(const float* X, int M, int N, int ldx, float* out
   return q;
 }
 
-static int launch_group(GemmGroup& g, hipStream_t st) {
+int launch_group(GemmGroup& g, hipStream_t st) {
   int blocks = 0;
   for (int i = 0; i < g.n; ++i) {
     g.p[i].first_block = blocks;

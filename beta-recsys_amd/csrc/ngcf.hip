@@ -1,0 +1,395 @@
+// NGCF on the LightGCN SpMM and the NCF grouped GEMM — SURVEY.md §8f rank 4 (sibling models).
+//
+//   beta_rec/models/ngcf.py:48-80     forward, per hop l (ego_0 = cat(user_embedding, item_embedding)):
+//                                       side = A ego_l
+//                                       ego_{l+1} = dropout(lrelu(GC_l(side)) + lrelu(Bi_l(ego_l * side)))
+//                                     all = cat(ego_0, normalize(ego_1), ..., normalize(ego_L))  along dim 1
+//   beta_rec/models/ngcf.py:82-100    predict: <all[u], all[U + i]>
+//   beta_rec/models/ngcf.py:118-149   train_single_batch: gather rows of `all`, bpr_loss, backward
+//   beta_rec/models/ngcf.py:172-199   bpr_loss: -mean logsigmoid(s+ - s-) + decay * (|u|^2+|p|^2+|n|^2)/2 / batch_size
+//
+// Every hop is a short chain of HBM-bound passes over [N, d] activations (N = users + items, d <= 256):
+//   SpMM (lightgcn.hip)  ->  bi_mul  ->  ONE grouped launch of the two Linear layers (fp32 MFMA, ncf.hip)
+//   ->  act (lrelu + lrelu, dropout, row L2 norm, write the hop's slice of `all`)
+// and the backward walks it in reverse:
+//   act_bwd (normalize / dropout / lrelu backward -> d_sum, d_bi)  ->  ONE grouped launch of six problems
+//   (two dgrads, two wgrads, two bias column sums)  ->  bi_bwd  ->  SpMM with the transposed graph.
+// The loss gathers / scatters rows of the concatenated table directly (one wave per triple).
+// Nothing here is GEMM-bound: 2 x N x d x d flops per Linear (80 MFLOP at ML-1M size) against 2.5 MB
+// activations; the MFMA group is used because it is the exact-fp32 GEMM the NCF tower already has.
+#include "common.hpp"
+#include "gemm.hpp"
+
+namespace hiprec {
+
+constexpr int kNgcfMaxNpl = 4;  // hop widths <= 256: columns lane, lane + 64, ...
+constexpr float kSlope = 0.01f; // F.leaky_relu default negative_slope
+constexpr float kNormEps = 1e-12f;
+
+__device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : x * kSlope; }
+
+// bi_in = ego * side   (n floats, 16-B vectors + tail)
+__global__ __launch_bounds__(kBlock) void ngcf_bi_mul_kernel(const float* __restrict__ ego,
+                                                             const float* __restrict__ side,
+                                                             float* __restrict__ bi_in, int64_t n) {
+  const int64_t tid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = tid; i < n4; i += stride) {
+    const float4 a = reinterpret_cast<const float4*>(ego)[i];
+    const float4 b = reinterpret_cast<const float4*>(side)[i];
+    reinterpret_cast<float4*>(bi_in)[i] = make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+  }
+  for (int64_t i = (n4 << 2) + tid; i < n; i += stride) bi_in[i] = ego[i] * side[i];
+}
+
+// One wave per node row: ego' = keep * scale * (lrelu(sum_pre) + lrelu(bi_pre)); nrm = |ego'|_2;
+// all[row, off : off + d] = ego' / max(nrm, eps).
+__global__ __launch_bounds__(kBlock) void ngcf_act_kernel(const float* __restrict__ sum_pre,
+                                                          const float* __restrict__ bi_pre,
+                                                          const uint8_t* __restrict__ keep, float scale,
+                                                          float* __restrict__ ego_out,
+                                                          float* __restrict__ nrm_out,
+                                                          float* __restrict__ all, int ld_all, int off,
+                                                          int64_t n_rows, int d) {
+  const int lane = lane_id();
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block(); r < n_rows;
+       r += static_cast<int64_t>(gridDim.x) * kWavesPerBlock) {
+    float x[kNgcfMaxNpl];
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < kNgcfMaxNpl; ++k) {
+      const int c = lane + kWave * k;
+      x[k] = 0.f;
+      if (c < d) {
+        const int64_t i = r * d + c;
+        float v = lrelu(sum_pre[i]) + lrelu(bi_pre[i]);
+        if (keep) v = keep[i] ? v * scale : 0.f;
+        x[k] = v;
+        ego_out[i] = v;
+      }
+      sq += x[k] * x[k];
+    }
+    const float nrm = sqrtf(wave_sum(sq));
+    const float inv = 1.0f / fmaxf(nrm, kNormEps);
+    if (lane == 0) nrm_out[r] = nrm;
+#pragma unroll
+    for (int k = 0; k < kNgcfMaxNpl; ++k) {
+      const int c = lane + kWave * k;
+      if (c < d) all[r * ld_all + off + c] = x[k] * inv;
+    }
+  }
+}
+
+// all[row, 0 : d0] = ego_0 (the embedding tables themselves)
+__global__ __launch_bounds__(kBlock) void ngcf_copy_e0_kernel(const float* __restrict__ e0,
+                                                              float* __restrict__ all, int ld_all,
+                                                              int64_t n_rows, int d0) {
+  const int64_t n = n_rows * d0;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+    const int64_t r = i / d0;
+    all[r * ld_all + (i - r * d0)] = e0[i];
+  }
+}
+
+// One wave per triple on rows of `all` (width dt): BPR loss + L2 term, gradient rows into d_all.
+__global__ __launch_bounds__(kBlock) void ngcf_loss_kernel(const float* __restrict__ all,
+                                                           float* __restrict__ d_all, int dt,
+                                                           int64_t n_users, int64_t n_items,
+                                                           const int64_t* __restrict__ users,
+                                                           const int64_t* __restrict__ pos,
+                                                           const int64_t* __restrict__ neg, int64_t batch,
+                                                           float inv_batch, float reg_coef,
+                                                           hiprec_stats* stats, Scratch* scratch) {
+  const int lane = lane_id();
+  const bool stepper = blockIdx.x == 0 && threadIdx.x == 0;
+  StepState step_state{};
+  if (stepper) step_state = step_load(stats);
+  float loss_acc = 0.f, reg_acc = 0.f;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block(); t < batch;
+       t += static_cast<int64_t>(gridDim.x) * kWavesPerBlock) {
+    const int64_t u = users[t], p = pos[t], n = neg[t];
+    const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(n_users);
+    const bool i_ok = static_cast<uint64_t>(p) < static_cast<uint64_t>(n_items) &&
+                      static_cast<uint64_t>(n) < static_cast<uint64_t>(n_items);
+    if (!(u_ok && i_ok)) {
+      if (lane == 0)
+        atomicOr(&stats->status,
+                 (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
+      continue;
+    }
+    const float* ur = all + u * dt;
+    const float* pr = all + (n_users + p) * dt;
+    const float* nr = all + (n_users + n) * dt;
+    float dp = 0.f, dn = 0.f, sq = 0.f;
+    for (int c = lane; c < dt; c += kWave) {
+      const float a = ur[c], b = pr[c], e = nr[c];
+      dp += a * b;
+      dn += a * e;
+      sq += a * a + b * b + e * e;
+    }
+    float sig;
+    loss_acc += neg_logsigmoid(wave_sum(dp) - wave_sum(dn), &sig);
+    reg_acc += 0.5f * sq;
+    const float dx = -sig * inv_batch;
+    float* gu = d_all + u * dt;
+    float* gp = d_all + (n_users + p) * dt;
+    float* gn = d_all + (n_users + n) * dt;
+    for (int c = lane; c < dt; c += kWave) {  // second pass over rows that are in cache by now
+      const float a = ur[c], b = pr[c], e = nr[c];
+      atomic_add_f32(gu + c, dx * (b - e) + reg_coef * a);
+      atomic_add_f32(gp + c, dx * a + reg_coef * b);
+      atomic_add_f32(gn + c, -dx * a + reg_coef * e);
+    }
+  }
+  // stats->loss = mf_loss + emb_loss (what train_single_batch returns); partial.y keeps the L2 part
+  const float reg_w = wave_sum(reg_acc);
+  publish_partials<kWavesPerBlock>(loss_acc * inv_batch + reg_coef * reg_w, lane == 0 ? reg_coef * reg_w : 0.f,
+                                   0.f, 1.0f, scratch);
+  if (stepper) step_store_advanced(stats, step_state);
+}
+
+// One wave per node row: backward of normalize, (+ the gradient arriving from the next hop), dropout and
+// the two leaky-ReLUs:  d_sum = d_x * keep * scale * lrelu'(sum_pre), d_bi likewise with bi_pre.
+__global__ __launch_bounds__(kBlock) void ngcf_act_bwd_kernel(
+    const float* __restrict__ d_all, const float* __restrict__ all, int ld_all, int off,
+    const float* __restrict__ nrm, const float* __restrict__ d_next, const uint8_t* __restrict__ keep,
+    float scale, const float* __restrict__ sum_pre, const float* __restrict__ bi_pre,
+    float* __restrict__ d_sum, float* __restrict__ d_bi, int64_t n_rows, int d) {
+  const int lane = lane_id();
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block(); r < n_rows;
+       r += static_cast<int64_t>(gridDim.x) * kWavesPerBlock) {
+    float dy[kNgcfMaxNpl], y[kNgcfMaxNpl];
+    float proj = 0.f;
+#pragma unroll
+    for (int k = 0; k < kNgcfMaxNpl; ++k) {
+      const int c = lane + kWave * k;
+      dy[k] = c < d ? d_all[r * ld_all + off + c] : 0.f;
+      y[k] = c < d ? all[r * ld_all + off + c] : 0.f;
+      proj += y[k] * dy[k];
+    }
+    proj = wave_sum(proj);
+    const float n = nrm[r];
+    const bool big = n >= kNormEps;  // clamp_min passes the norm's gradient only where norm >= eps
+    const float inv = 1.0f / fmaxf(n, kNormEps);
+#pragma unroll
+    for (int k = 0; k < kNgcfMaxNpl; ++k) {
+      const int c = lane + kWave * k;
+      if (c < d) {
+        const int64_t i = r * d + c;
+        float dx = (big ? dy[k] - y[k] * proj : dy[k]) * inv;
+        if (d_next) dx += d_next[i];
+        if (keep) dx = keep[i] ? dx * scale : 0.f;
+        d_sum[i] = sum_pre[i] > 0.f ? dx : dx * kSlope;
+        d_bi[i] = bi_pre[i] > 0.f ? dx : dx * kSlope;
+      }
+    }
+  }
+}
+
+// d_ego = d_bi_in * side ;  d_side += d_bi_in * ego
+__global__ __launch_bounds__(kBlock) void ngcf_bi_bwd_kernel(const float* __restrict__ d_bi_in,
+                                                             const float* __restrict__ side,
+                                                             const float* __restrict__ ego,
+                                                             float* __restrict__ d_ego,
+                                                             float* __restrict__ d_side, int64_t n) {
+  const int64_t tid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = tid; i < n; i += stride) {
+    const float g = d_bi_in[i];
+    d_ego[i] = g * side[i];
+    d_side[i] += g * ego[i];
+  }
+}
+
+// g_e0[r, c] += d_all[r, c] + d_ego[r, c]   (the embedding tables' gradient: their own slice of `all`
+// plus what flows back through hop 0)
+__global__ __launch_bounds__(kBlock) void ngcf_e0_grad_kernel(const float* __restrict__ d_all, int ld_all,
+                                                              const float* __restrict__ d_ego,
+                                                              float* __restrict__ g_e0, int64_t n_rows,
+                                                              int d0) {
+  const int64_t n = n_rows * d0;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+    const int64_t r = i / d0;
+    g_e0[i] += d_all[r * ld_all + (i - r * d0)] + d_ego[i];
+  }
+}
+
+// scores[k] = <all[u], all[U + i]>
+__global__ __launch_bounds__(kBlock) void ngcf_predict_kernel(const float* __restrict__ all, int dt,
+                                                              int64_t n_users, int64_t n_items,
+                                                              const int64_t* __restrict__ users,
+                                                              const int64_t* __restrict__ items, int64_t n,
+                                                              float* __restrict__ scores,
+                                                              hiprec_stats* stats) {
+  const int lane = lane_id();
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block(); t < n;
+       t += static_cast<int64_t>(gridDim.x) * kWavesPerBlock) {
+    const int64_t u = users[t], i = items[t];
+    const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(n_users);
+    const bool i_ok = static_cast<uint64_t>(i) < static_cast<uint64_t>(n_items);
+    if (!(u_ok && i_ok)) {
+      if (lane == 0) {
+        atomicOr(&stats->status,
+                 (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
+        scores[t] = __builtin_nanf("");
+      }
+      continue;
+    }
+    float dot = 0.f;
+    for (int c = lane; c < dt; c += kWave) dot += all[u * dt + c] * all[(n_users + i) * dt + c];
+    dot = wave_sum(dot);
+    if (lane == 0) scores[t] = dot;
+  }
+}
+
+inline int total_width(const hiprec_ngcf_plan* p) {
+  int t = 0;
+  for (int l = 0; l <= p->n_layers; ++l) t += p->dim[l];
+  return t;
+}
+
+inline int check_ngcf_plan(const hiprec_ngcf_plan* p, bool train) {
+  HIPREC_REQUIRE(p != nullptr, "NULL plan");
+  HIPREC_REQUIRE(p->n_layers >= 1 && p->n_layers <= HIPREC_NGCF_MAX_LAYERS, "n_layers %d outside 1..%d",
+                 p->n_layers, HIPREC_NGCF_MAX_LAYERS);
+  HIPREC_REQUIRE(p->n_users > 0 && p->n_items > 0, "bad table sizes");
+  HIPREC_REQUIRE(p->a.n_rows == p->n_users + p->n_items, "graph has %lld rows, tables %lld",
+                 (long long)p->a.n_rows, (long long)(p->n_users + p->n_items));
+  for (int l = 0; l <= p->n_layers; ++l)
+    HIPREC_REQUIRE(p->dim[l] > 0 && p->dim[l] <= kNgcfMaxNpl * kWave, "hop width %d outside 1..%d",
+                   p->dim[l], kNgcfMaxNpl * kWave);
+  HIPREC_REQUIRE(p->e0 && p->all && p->spmm_tmp, "NULL e0 / all / spmm_tmp");
+  for (int l = 0; l < p->n_layers; ++l) {
+    HIPREC_REQUIRE(p->gc_w[l] && p->gc_b[l] && p->bi_w[l] && p->bi_b[l], "NULL layer %d weights", l);
+    HIPREC_REQUIRE(p->side[l] && p->bi_in[l] && p->sum_pre[l] && p->bi_pre[l] && p->ego[l] && p->nrm[l],
+                   "NULL layer %d workspace", l);
+  }
+  if (train) {
+    HIPREC_REQUIRE(p->at.n_rows == p->a.n_rows && p->at.nnz == p->a.nnz, "transposed graph differs in shape");
+    HIPREC_REQUIRE(p->g_e0 && p->d_all && p->d_sum && p->d_bi && p->d_side && p->d_bi_in && p->d_ego[0] &&
+                       p->d_ego[1],
+                   "NULL backward workspace");
+    for (int l = 0; l < p->n_layers; ++l)
+      HIPREC_REQUIRE(p->g_gc_w[l] && p->g_gc_b[l] && p->g_bi_w[l] && p->g_bi_b[l], "NULL layer %d gradients", l);
+  }
+  return 0;
+}
+
+// NGCF.forward: fills the per-hop workspaces and `all`.  keep bytes are used only when train.
+inline int ngcf_forward(const hiprec_ngcf_plan* p, bool train, hipStream_t st) {
+  const int64_t N = p->n_users + p->n_items;
+  const int dt = total_width(p);
+  ngcf_copy_e0_kernel<<<grid_for_threads(N * p->dim[0]), kBlock, 0, st>>>(p->e0, p->all, dt, N, p->dim[0]);
+  HIPREC_TRY(hipGetLastError());
+  const float* ego = p->e0;
+  int off = p->dim[0];
+  for (int l = 0; l < p->n_layers; ++l) {
+    const int di = p->dim[l], dout = p->dim[l + 1];
+    if (int rc = hiprec_spmm_csr(&p->a, nullptr, 1.0f, ego, p->side[l], nullptr, di, st)) return rc;
+    ngcf_bi_mul_kernel<<<grid_for_threads((N * di + 3) / 4), kBlock, 0, st>>>(ego, p->side[l], p->bi_in[l],
+                                                                             N * di);
+    HIPREC_TRY(hipGetLastError());
+    GemmGroup g{};
+    g.n = 2;
+    g.p[0] = make_gemm(kNT, static_cast<int>(N), dout, di, p->side[l], di, p->gc_w[l], di, p->sum_pre[l], dout,
+                       p->gc_b[l], 0, nullptr, 0, false);
+    g.p[1] = make_gemm(kNT, static_cast<int>(N), dout, di, p->bi_in[l], di, p->bi_w[l], di, p->bi_pre[l], dout,
+                       p->bi_b[l], 0, nullptr, 0, false);
+    if (int rc = launch_group(g, st)) return rc;
+    const uint8_t* keep = train ? p->keep[l] : nullptr;
+    ngcf_act_kernel<<<grid_for_waves(N), kBlock, 0, st>>>(p->sum_pre[l], p->bi_pre[l], keep, p->keep_scale[l],
+                                                         p->ego[l], p->nrm[l], p->all, dt, off, N, dout);
+    HIPREC_TRY(hipGetLastError());
+    ego = p->ego[l];
+    off += dout;
+  }
+  return 0;
+}
+
+}  // namespace hiprec
+
+using namespace hiprec;
+
+extern "C" size_t hiprec_ngcf_plan_bytes(void) { return sizeof(hiprec_ngcf_plan); }
+
+extern "C" int hiprec_ngcf_forward(const hiprec_ngcf_plan* plan, int train, void* stream) {
+  if (int rc = check_ngcf_plan(plan, false)) return rc;
+  HIPREC_REQUIRE(plan->n_users + plan->n_items < (1ll << 31), "too many nodes for the 32-bit GEMM extents");
+  return ngcf_forward(plan, train != 0, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int hiprec_ngcf_predict(const hiprec_ngcf_plan* plan, const int64_t* users, const int64_t* items,
+                                   int64_t n, float* scores, hiprec_stats* stats, void* stream) {
+  if (int rc = check_ngcf_plan(plan, false)) return rc;
+  HIPREC_REQUIRE(n >= 0, "negative n");
+  if (n == 0) return 0;
+  HIPREC_REQUIRE(users && items && scores && stats, "NULL pointer");
+  ngcf_predict_kernel<<<grid_for_waves(n), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      plan->all, total_width(plan), plan->n_users, plan->n_items, users, items, n, scores, stats);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_ngcf_grad(const hiprec_ngcf_plan* plan, const int64_t* users, const int64_t* pos,
+                                const int64_t* neg, int64_t batch, float inv_batch, hiprec_stats* stats,
+                                void* scratch, size_t scratch_bytes, void* stream) {
+  if (int rc = check_ngcf_plan(plan, true)) return rc;
+  const hiprec_ngcf_plan* p = plan;
+  HIPREC_REQUIRE(p->n_users + p->n_items < (1ll << 31), "too many nodes for the 32-bit GEMM extents");
+  HIPREC_REQUIRE(stats && scratch, "NULL stats/scratch");
+  HIPREC_REQUIRE(batch >= 0, "negative batch");
+  HIPREC_REQUIRE(batch == 0 || (users && pos && neg), "NULL index arrays");
+  if (scratch_bytes < kScratchBytes) {
+    set_error("scratch %zu B < %zu B", scratch_bytes, kScratchBytes);
+    return HIPREC_E_SCRATCH;
+  }
+  auto st = static_cast<hipStream_t>(stream);
+  const int64_t N = p->n_users + p->n_items;
+  const int dt = total_width(p);
+  if (int rc = ngcf_forward(p, true, st)) return rc;
+  HIPREC_TRY(hipMemsetAsync(p->d_all, 0, sizeof(float) * N * dt, st));
+  ngcf_loss_kernel<<<grid_for_waves(batch > 0 ? batch : 1), kBlock, 0, st>>>(
+      p->all, p->d_all, dt, p->n_users, p->n_items, users, pos, neg, batch, inv_batch,
+      p->decay * p->inv_reg_batch, stats, static_cast<Scratch*>(scratch));
+  HIPREC_TRY(hipGetLastError());
+
+  int off = dt;
+  const float* d_next = nullptr;
+  for (int l = p->n_layers - 1; l >= 0; --l) {
+    const int di = p->dim[l], dout = p->dim[l + 1];
+    off -= dout;
+    ngcf_act_bwd_kernel<<<grid_for_waves(N), kBlock, 0, st>>>(
+        p->d_all, p->all, dt, off, p->nrm[l], d_next, p->keep[l], p->keep_scale[l], p->sum_pre[l],
+        p->bi_pre[l], p->d_sum, p->d_bi, N, dout);
+    HIPREC_TRY(hipGetLastError());
+    const float* ego_in = l == 0 ? p->e0 : p->ego[l - 1];
+    GemmGroup g{};
+    g.n = 6;
+    const int n32 = static_cast<int>(N);
+    g.p[0] = make_gemm(kNN, n32, di, dout, p->d_sum, dout, p->gc_w[l], di, p->d_side, di, nullptr, 0, nullptr, 0,
+                       false);
+    g.p[1] = make_gemm(kNN, n32, di, dout, p->d_bi, dout, p->bi_w[l], di, p->d_bi_in, di, nullptr, 0, nullptr, 0,
+                       false);
+    g.p[2] = make_gemm(kTNm, dout, di, n32, p->d_sum, dout, p->side[l], di, p->g_gc_w[l], di, nullptr, 0, nullptr,
+                       0, true);
+    g.p[3] = make_gemm(kTNm, dout, di, n32, p->d_bi, dout, p->bi_in[l], di, p->g_bi_w[l], di, nullptr, 0, nullptr,
+                       0, true);
+    g.p[4] = make_colsum(p->d_sum, n32, dout, dout, p->g_gc_b[l]);
+    g.p[5] = make_colsum(p->d_bi, n32, dout, dout, p->g_bi_b[l]);
+    if (int rc = launch_group(g, st)) return rc;
+    float* d_ego = p->d_ego[l & 1];
+    ngcf_bi_bwd_kernel<<<grid_for_threads(N * di), kBlock, 0, st>>>(p->d_bi_in, p->side[l], ego_in, d_ego,
+                                                                   p->d_side, N * di);
+    HIPREC_TRY(hipGetLastError());
+    // d_ego += A^T d_side
+    if (int rc = hiprec_spmm_csr(&p->at, nullptr, 1.0f, p->d_side, p->spmm_tmp, d_ego, di, st)) return rc;
+    d_next = d_ego;
+  }
+  ngcf_e0_grad_kernel<<<grid_for_threads(N * p->dim[0]), kBlock, 0, st>>>(p->d_all, dt, d_next, p->g_e0, N,
+                                                                        p->dim[0]);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}

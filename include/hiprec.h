@@ -581,6 +581,70 @@ int hiprec_t2v_predict(const hiprec_t2v_tables* w, const int64_t* users, const i
 int hiprec_alias_sample(const double* prob, const int64_t* alias, const int64_t* labels, int64_t vocab,
                         uint64_t seed, int64_t* out, int64_t n, void* stream);
 
+/* ================= NGCF (sibling models) =====================================
+ * models/ngcf.py:12-46.  Everything one step touches; all buffers are caller-owned device memory.
+ * Hop l (0-based, l < n_layers) maps width dim[l] to dim[l+1]; N = n_users + n_items; the concatenated
+ * output `all` is [N, dim[0] + ... + dim[n_layers]] (ngcf.py:74-78).  a / at: norm_adj and its transpose
+ * as CSR (the same hiprec_csr LightGCN uses). */
+#define HIPREC_NGCF_MAX_LAYERS 6
+typedef struct hiprec_ngcf_plan {
+  hiprec_csr a, at;
+  int64_t n_users, n_items;
+  int32_t n_layers;
+  int32_t dim[HIPREC_NGCF_MAX_LAYERS + 1];   /* each <= 256 */
+  float decay;                               /* regs[0] (ngcf.py:108-109) */
+  float inv_reg_batch;                       /* 1 / config batch_size (ngcf.py:189) */
+  /* parameters and their gradients (zero on entry of hiprec_ngcf_grad, like optimizer.zero_grad) */
+  float* e0;                                 /* [N, dim[0]]: user_embedding rows, then item_embedding rows */
+  float* g_e0;
+  float* gc_w[HIPREC_NGCF_MAX_LAYERS];       /* GC_weights[l].weight [dim[l+1], dim[l]] */
+  float* gc_b[HIPREC_NGCF_MAX_LAYERS];       /* GC_weights[l].bias   [dim[l+1]] */
+  float* bi_w[HIPREC_NGCF_MAX_LAYERS];       /* Bi_weights[l].* likewise */
+  float* bi_b[HIPREC_NGCF_MAX_LAYERS];
+  float* g_gc_w[HIPREC_NGCF_MAX_LAYERS];
+  float* g_gc_b[HIPREC_NGCF_MAX_LAYERS];
+  float* g_bi_w[HIPREC_NGCF_MAX_LAYERS];
+  float* g_bi_b[HIPREC_NGCF_MAX_LAYERS];
+  /* forward workspace, kept for the backward */
+  float* side[HIPREC_NGCF_MAX_LAYERS];       /* [N, dim[l]]   A ego_l */
+  float* bi_in[HIPREC_NGCF_MAX_LAYERS];      /* [N, dim[l]]   ego_l * side */
+  float* sum_pre[HIPREC_NGCF_MAX_LAYERS];    /* [N, dim[l+1]] GC_l(side) */
+  float* bi_pre[HIPREC_NGCF_MAX_LAYERS];     /* [N, dim[l+1]] Bi_l(bi_in) */
+  float* ego[HIPREC_NGCF_MAX_LAYERS];        /* [N, dim[l+1]] ego_{l+1} (after dropout, before normalize) */
+  float* nrm[HIPREC_NGCF_MAX_LAYERS];        /* [N] row norms of ego_{l+1} */
+  float* all;                                /* [N, sum dim] */
+  /* message dropout (ngcf.py:70): one keep byte per element of ego_{l+1}, or NULL for none; kept
+   * entries are scaled by keep_scale[l] = 1 / (1 - p) */
+  const uint8_t* keep[HIPREC_NGCF_MAX_LAYERS];
+  float keep_scale[HIPREC_NGCF_MAX_LAYERS];
+  /* backward workspace, each [N, max dim] unless noted */
+  float* d_all;                              /* [N, sum dim] */
+  float* d_sum;
+  float* d_bi;
+  float* d_side;
+  float* d_bi_in;
+  float* d_ego[2];
+  float* spmm_tmp;                           /* also used by the forward */
+} hiprec_ngcf_plan;
+
+size_t hiprec_ngcf_plan_bytes(void);
+
+/* ---- NGCF.forward (ngcf.py:48-80): fills plan->all (and the per-hop workspaces).  train != 0 applies
+ * the keep bytes of the plan, 0 is eval mode. */
+int hiprec_ngcf_forward(const hiprec_ngcf_plan* plan, int train, void* stream);
+
+/* ---- scores[k] = <all[u_k], all[n_users + i_k]> on the rows left in plan->all by the last forward
+ * (NGCF.predict, ngcf.py:82-100). */
+int hiprec_ngcf_predict(const hiprec_ngcf_plan* plan, const int64_t* users, const int64_t* items,
+                        int64_t n, float* scores, hiprec_stats* stats, void* stream);
+
+/* ---- zero_grad + forward + bpr_loss + backward of NGCFEngine.train_single_batch (ngcf.py:118-149,
+ * 172-199): dense gradients into the plan's g_* buffers, loss partials in scratch (stats->loss =
+ * mf_loss + emb_loss, stats->reg = emb_loss), step counter advanced.  inv_batch = 1 / len(users). */
+int hiprec_ngcf_grad(const hiprec_ngcf_plan* plan, const int64_t* users, const int64_t* pos,
+                     const int64_t* neg, int64_t batch, float inv_batch, hiprec_stats* stats,
+                     void* scratch, size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

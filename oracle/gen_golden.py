@@ -245,7 +245,7 @@ def main():
     epoch_fixture(MFEngine, PairwiseNegativeDataset, "mf_epoch_sgd", "sgd", seed=22)
 
 
-if __name__ == "__main__" and not {"--ncf", "--lightgcn", "--eval", "--sampler", "--c1", "--pgmf", "--t2v"} & set(sys.argv):
+if __name__ == "__main__" and not {"--ncf", "--lightgcn", "--eval", "--sampler", "--c1", "--pgmf", "--t2v", "--ngcf"} & set(sys.argv):
     main()
 
 
@@ -726,3 +726,104 @@ def main_t2v():
 
 if __name__ == "__main__" and "--t2v" in sys.argv:
     main_t2v()
+
+
+def ngcf_fixture(name, U, I, D, layers, B, n_edges, optimizer, lr, mess_dropout, batch_lens, seed, scale=1.0):
+    """NGCFEngine on a small synthetic graph.  The message-dropout masks of every step are captured with
+    forward hooks AND re-drawn from the same torch seed the way the product does, to pin that recipe."""
+    import scipy.sparse as sp
+
+    import_reference()
+    from beta_rec.models.ngcf import NGCFEngine
+    from beta_rec.utils.common_util import normalized_adj_single
+
+    rng = np.random.default_rng(seed)
+    eu = rng.integers(0, U, n_edges)
+    ei = zipf_items(rng, n_edges, I)
+    N = U + I
+    R = sp.dok_matrix((U, I), dtype=np.float32)
+    for a, b in zip(eu, ei):
+        R[a, b] = 1.0
+    adj = sp.dok_matrix((N, N), dtype=np.float32).tolil()
+    adj[:U, U:] = R.tolil()
+    adj[U:, :U] = R.tolil().T
+    adj = adj.todok()
+    norm = quiet(normalized_adj_single, adj + sp.eye(adj.shape[0])).tocoo().astype(np.float32)
+    idx = torch.from_numpy(np.vstack((norm.row, norm.col)).astype(np.int64))
+    norm_t = torch.sparse_coo_tensor(idx, torch.from_numpy(norm.data), torch.Size(norm.shape))
+    torch.manual_seed(seed)
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, layer_size=list(layers), mess_dropout=list(mess_dropout),
+                         regs=[1e-5], device_str="cpu", optimizer=optimizer, lr=lr, batch_size=B, norm_adj=norm_t),
+           "system": {"run_dir": "/tmp/hiprec_golden_runs"}}
+    eng = quiet(NGCFEngine, cfg)
+    m = eng.model
+    n_steps = len(batch_lens)
+    out = {"meta": np.array([U, I, D, len(layers), B, n_steps, seed], dtype=np.int64), "layers": np.array(layers),
+           "optimizer": np.array(optimizer), "lr": np.array(lr), "decay": np.array(1e-5),
+           "mess_dropout": np.array(mess_dropout, dtype=np.float64), "batch_lens": np.array(batch_lens)}
+    co = norm_t.coalesce()
+    out["adj_row"], out["adj_col"] = co.indices()[0].numpy(), co.indices()[1].numpy()
+    out["adj_val"] = co.values().numpy()
+    for k, v in m.state_dict().items():
+        out[f"init/{k}"] = v.detach().numpy().copy()          # the seeded init, before any scaling
+    with torch.no_grad():
+        m.user_embedding.weight.mul_(scale)
+        m.item_embedding.weight.mul_(scale)
+    for k, v in m.state_dict().items():
+        out[f"w0/{k}"] = v.detach().numpy().copy()
+    seen, captured = [], []
+    orig_step = eng.optimizer.step
+
+    def capturing_step(*a, **k):
+        seen.append({n: p.grad.detach().numpy().copy() for n, p in m.named_parameters()})
+        return orig_step(*a, **k)
+
+    eng.optimizer.step = capturing_step
+    for l, mod in enumerate(m.dropout):
+        mod.register_forward_hook(lambda _m, inp, outp, l=l: captured.append((l, inp[0].detach().clone(),
+                                                                             outp.detach().clone())))
+    m.train()
+    losses = []
+    for s, n in enumerate(batch_lens):
+        users, pos, neg = rng.integers(0, U, n), zipf_items(rng, n, I), rng.integers(0, I, n)
+        out[f"b{s}/users"], out[f"b{s}/pos"], out[f"b{s}/neg"] = users, pos, neg
+        captured.clear()
+        torch.manual_seed(2000 + s)
+        loss, reg = eng.train_single_batch(tuple(torch.from_numpy(x) for x in (users, pos, neg)))
+        assert reg == 0.0
+        losses.append(loss)
+        # the product's recipe: same seed, one bernoulli_(1 - p) draw of [N, d] per hop with p > 0, in hop order
+        torch.manual_seed(2000 + s)
+        for l, x_in, x_out in captured:
+            p = mess_dropout[l]
+            if p == 0:
+                assert torch.equal(x_in, x_out)
+                keep = np.ones(tuple(x_in.shape), dtype=bool)
+            else:
+                keep = torch.empty_like(x_in).bernoulli_(1 - p).bool().numpy()
+                ref_keep = (x_out != 0) | (x_in == 0)
+                assert np.array_equal(keep | (x_in.numpy() == 0), ref_keep.numpy()), "mask recipe does not replay"
+            out[f"mask{s}/{l}"] = np.packbits(keep, axis=1)
+        for k, v in m.state_dict().items():
+            out[f"w{s + 1}/{k}"] = v.detach().numpy().copy()
+        for k, v in seen[-1].items():
+            out[f"g{s + 1}/{k}"] = v
+        for pname, p_ in m.named_parameters():
+            pst = eng.optimizer.state.get(p_, {})
+            for sk, tag in (("exp_avg", "m"), ("exp_avg_sq", "v"), ("square_avg", "v")):
+                if sk in pst:
+                    out[f"{tag}{s + 1}/{pname}"] = pst[sk].detach().numpy().copy()
+    m.eval()
+    pu, pi = rng.integers(0, U, 50), rng.integers(0, I, 50)
+    out["probe_users"], out["probe_items"] = pu, pi
+    out["probe_scores"] = m.predict(pu, pi).numpy()
+    out["losses"] = np.array(losses, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: nnz {len(co.values())} losses {losses}")
+
+
+if __name__ == "__main__" and "--ngcf" in sys.argv:
+    ngcf_fixture("ngcf_adam", 41, 37, 16, [16, 16, 16], 24, 300, "adam", 0.01, [0.1, 0.1, 0.1], [24, 24, 9], 51,
+                 scale=3.0)
+    ngcf_fixture("ngcf_sgd_widths", 33, 29, 24, [32, 8], 16, 250, "sgd", 0.5, [0.0, 0.3], [16, 16], 52, scale=3.0)
+    ngcf_fixture("ngcf_rmsprop_d64", 50, 45, 64, [64, 64, 64], 32, 400, "rmsprop", 0.001, [0.0, 0.0, 0.0], [32], 53)

@@ -607,3 +607,40 @@ def test_triple2vec_item_emb2_alias_and_layout():
     assert rc == -1 and b"bad sizes" in lib.hiprec_last_error()
     rc = lib.hiprec_t2v_predict(ctypes.byref(mixed_w), None, None, 3, None, None, None)
     assert rc == -1 and b"NULL pointer" in lib.hiprec_last_error()
+
+
+def test_ngcf_initial_weights_and_state_dict_order_match_reference():
+    """NGCF.__init__ consumes the torch RNG like models/ngcf.py:29-46; state_dict keeps its key order."""
+    import beta_recsys_amd as hp
+    from beta_recsys_amd import _lib, compat
+
+    for case in ("ngcf_adam", "ngcf_sgd_widths"):
+        g = load_golden(case)
+        U, I, D, L, B, _, seed = (int(x) for x in g["meta"])
+        idx = torch.from_numpy(np.vstack((g["adj_row"], g["adj_col"])).astype(np.int64))
+        adj = torch.sparse_coo_tensor(idx, torch.from_numpy(g["adj_val"]), torch.Size((U + I, U + I)))
+        model = dict(n_users=U, n_items=I, emb_dim=D, layer_size=[int(x) for x in g["layers"]],
+                     mess_dropout=[float(x) for x in g["mess_dropout"]], regs=[1e-5], device_str="cpu",
+                     optimizer=str(g["optimizer"]), lr=float(g["lr"]), batch_size=B, norm_adj=adj)
+        torch.manual_seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            eng = hp.NGCFEngine({"model": model, "system": {"run_dir": "/tmp/hiprec_test_runs"}})
+        sd = eng.model.state_dict()
+        assert list(sd.keys()) == [k[len("init/"):] for k in g if k.startswith("init/")]
+        for k in sd:
+            assert np.array_equal(sd[k].numpy(), g[f"init/{k}"]), f"{case} {k} differs"
+        m = eng.model
+        assert m.flat.data_ptr() == m.user_embedding.weight.data_ptr()
+        assert m.item_embedding.weight.data_ptr() == m.flat.data_ptr() + 4 * U * D
+        assert eng.decay == 1e-5 and eng.batch_size == B
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            eng.train_single_batch(([0], [1], [2]))
+    assert compat.MIRRORS["beta_rec.models.ngcf"] == "ngcf"
+    lib = _lib.load()
+    assert lib.hiprec_ngcf_plan_bytes() == ctypes.sizeof(_lib.NgcfPlan)
+    rc = lib.hiprec_ngcf_grad(None, None, None, None, 4, 0.25, None, None, 0, None)
+    assert rc == -1 and b"NULL plan" in lib.hiprec_last_error()
+    plan = _lib.NgcfPlan()
+    plan.n_layers = 9
+    rc = lib.hiprec_ngcf_forward(ctypes.byref(plan), 0, None)
+    assert rc == -1 and b"n_layers 9" in lib.hiprec_last_error()
