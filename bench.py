@@ -438,6 +438,76 @@ def bench_siblings(args, device):
     print(json.dumps(out), flush=True)
 
 
+def bench_ngcf(args, device):
+    """NGCF at configs/ngcf_default.json (emb 64, three hops of 64, mess_dropout 0.1,
+    batch 1024, Adam lr 0.05) on the same ML-1M-sized graph as the LightGCN workload."""
+    import beta_recsys_amd as hp
+    import scipy.sparse as sp
+
+    L, Bn = 3, 1024
+    rng = np.random.default_rng(0)
+    n_edges = 1_000_000
+    p = 1.0 / np.arange(1, I + 1) ** 0.9
+    eu = rng.integers(0, U, n_edges)
+    ei = rng.permutation(I)[rng.choice(I, n_edges, p=p / p.sum())]
+    n_nodes = U + I
+    rows, cols = np.concatenate([eu, ei + U]), np.concatenate([ei + U, eu])
+    a = sp.coo_matrix((np.ones(len(rows), dtype=np.float32), (rows, cols)), shape=(n_nodes, n_nodes)).tocsr()
+    a.data[:] = 1.0
+    a = a + sp.eye(n_nodes, dtype=np.float32, format="csr")
+    adj = sp.diags(1.0 / np.asarray(a.sum(1)).flatten()).dot(a).astype(np.float32).tocoo()
+    idx = torch.from_numpy(np.vstack((adj.row, adj.col)).astype(np.int64))
+    norm = torch.sparse_coo_tensor(idx, torch.from_numpy(adj.data), torch.Size(adj.shape))
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, layer_size=[D] * L, mess_dropout=[0.1] * L, regs=[1e-5],
+                         device_str=str(device), optimizer="adam", lr=0.05, batch_size=Bn, norm_adj=norm,
+                         dropout_rng="device"),
+           "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
+    torch.manual_seed(2020)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = hp.NGCFEngine(cfg)
+    eng.model.train()
+    n_total = (args.warmup + args.steps) * Bn
+    users, pos, neg = (t.to(device) for t in synth_triples(n_total, seed=100))
+
+    def run(lo, n):
+        for k in range(n):
+            sl = slice(lo + k * Bn, lo + (k + 1) * Bn)
+            eng._enqueue_step((users[sl], pos[sl], neg[sl]))
+
+    run(0, args.warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.warmup * Bn, args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = eng._sync_stats()
+    nnz, N = adj.nnz, U + I
+    act = N * D * 4                      # one [N, D] fp32 activation
+    spmm = nnz * 8 + (N + 1) * 8 + 2 * act
+    # per hop, forward: SpMM; bi_mul (2 in, 1 out); two Linear (2 in, 2 out); act (2 in + keep byte, ego + slice out)
+    fwd = spmm + 3 * act + 4 * act + (4 * act + N * D)
+    # per hop, backward: act_bwd (d_all + all slices, d_next, keep, 2 pre in; 2 out); six grouped problems
+    # (d_sum, d_bi read by dgrad + wgrad + colsum; side, bi_in in; d_side, d_bi_in out); bi_bwd (4 in, 2 out);
+    # transposed SpMM (+ accumulate into d_ego: 2 more)
+    bwd = (5 * act + N * D + 2 * act) + (6 * act + 2 * act + 2 * act) + 6 * act + (spmm + 2 * act)
+    P = eng.model.flat.numel()
+    bytes_step = L * (fwd + bwd) + 2 * N * 4 * D * 4 + Bn * (24 + 6 * 4 * D * 4) + 28 * P
+    flops = L * 6 * 2 * N * D * D        # two Linear per hop: forward + dgrad + wgrad
+    out = {"metric": "training interactions/sec (NGCF triples)", "value": args.steps * Bn / dt,
+           "unit": "triples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"NGCF (ngcf_default.json): 6040 x 3706 graph, nnz {nnz}, emb 64, hops "
+                                  "[64, 64, 64], mess_dropout 0.1 (device RNG), batch 1024, adam 0.05",
+                      "last_loss": st.loss},
+           "roofline": {"bound": "hbm", "algorithmic_bytes_per_step": bytes_step,
+                        "achieved": bytes_step / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": bytes_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                        "gemm_tflops": flops / (dt / args.steps) / 1e12,
+                        "note": "whole step (~35 launches); full-graph propagation per step like the reference"}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -448,7 +518,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--two-kernel", action="store_true",
                     help="mf: gradient kernel + dense optimizer sweep per step instead of the fused one-kernel step")
-    ap.add_argument("--workload", default="mf", choices=["mf", "ncf", "lightgcn", "mf-c4shard", "mf-c4", "pgmf", "t2v"],
+    ap.add_argument("--workload", default="mf", choices=["mf", "ncf", "lightgcn", "mf-c4shard", "mf-c4", "pgmf", "t2v", "ngcf"],
                     help="mf = BASELINE configs[1] (the headline); ncf = configs[2] (NeuMF, emb_dim 32)")
     ap.add_argument("--multi-gpu", default="auto", choices=["auto", "replicated", "sharded"],
                     help="N>1: replicate small tables (gradient all-reduce) or row-shard them "
@@ -480,6 +550,8 @@ def main():
         return bench_lightgcn(args, device)
     if args.workload in ("pgmf", "t2v"):
         return bench_siblings(args, device)
+    if args.workload == "ngcf":
+        return bench_ngcf(args, device)
     if args.workload in ("mf-c4shard", "mf-c4"):
         return bench_mf_c4shard(args, device, full=args.workload == "mf-c4")
 

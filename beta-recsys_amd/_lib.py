@@ -117,7 +117,8 @@ class NgcfPlan(Structure):
                                                 "g_bi_b", "side", "bi_in", "sum_pre", "bi_pre", "ego", "nrm")]
                 + [("all", c_void_p), ("keep", c_void_p * NGCF_MAX_LAYERS), ("keep_scale", c_float * NGCF_MAX_LAYERS),
                    ("d_all", c_void_p), ("d_sum", c_void_p), ("d_bi", c_void_p), ("d_side", c_void_p),
-                   ("d_bi_in", c_void_p), ("d_ego", c_void_p * 2), ("spmm_tmp", c_void_p)])
+                   ("d_bi_in", c_void_p), ("d_ego", c_void_p * 2), ("spmm_tmp", c_void_p * NGCF_MAX_LAYERS),
+                   ("zero_ws", c_void_p), ("zero_ws_floats", c_int64)])
 
 
 class FusedStep(Structure):

@@ -16,6 +16,7 @@
 // (drawn like the reference does, or by hiprec_edge_dropout_mask) applied on the fly; the
 // transposed graph looks its edges up through `eid` so both directions drop the same edges.
 #include "common.hpp"
+#include "spmm.hpp"
 
 namespace hiprec {
 
@@ -215,8 +216,8 @@ __global__ __launch_bounds__(kBlock) void lightgcn_predict_kernel(hiprec_lightgc
   }
 }
 
-static int launch_spmm(const hiprec_csr* a, const uint8_t* keep, float scale, const float* x,
-                       float* y, float* acc, int dim, hipStream_t st, bool y_is_zero = false) {
+int launch_spmm(const hiprec_csr* a, const uint8_t* keep, float scale, const float* x, float* y,
+                float* acc, int dim, hipStream_t st, bool y_is_zero) {
   if (!y_is_zero) HIPREC_TRY(hipMemsetAsync(y, 0, sizeof(float) * a->n_rows * dim, st));
   if (a->nnz == 0) return 0;
   const int64_t n_waves = (a->nnz + kEdgesPerWave - 1) / kEdgesPerWave;

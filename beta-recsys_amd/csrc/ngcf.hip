@@ -19,6 +19,7 @@
 // activations; the MFMA group is used because it is the exact-fp32 GEMM the NCF tower already has.
 #include "common.hpp"
 #include "gemm.hpp"
+#include "spmm.hpp"
 
 namespace hiprec {
 
@@ -256,22 +257,34 @@ inline int check_ngcf_plan(const hiprec_ngcf_plan* p, bool train) {
   HIPREC_REQUIRE(p->n_layers >= 1 && p->n_layers <= HIPREC_NGCF_MAX_LAYERS, "n_layers %d outside 1..%d",
                  p->n_layers, HIPREC_NGCF_MAX_LAYERS);
   HIPREC_REQUIRE(p->n_users > 0 && p->n_items > 0, "bad table sizes");
+  HIPREC_REQUIRE(p->a.rowptr && p->a.nnz >= 0 && (p->a.nnz == 0 || (p->a.col && p->a.val)), "bad CSR a");
   HIPREC_REQUIRE(p->a.n_rows == p->n_users + p->n_items, "graph has %lld rows, tables %lld",
                  (long long)p->a.n_rows, (long long)(p->n_users + p->n_items));
   for (int l = 0; l <= p->n_layers; ++l)
     HIPREC_REQUIRE(p->dim[l] > 0 && p->dim[l] <= kNgcfMaxNpl * kWave, "hop width %d outside 1..%d",
                    p->dim[l], kNgcfMaxNpl * kWave);
-  HIPREC_REQUIRE(p->e0 && p->all && p->spmm_tmp, "NULL e0 / all / spmm_tmp");
+  HIPREC_REQUIRE(p->e0 && p->all, "NULL e0 / all");
+  if (p->zero_ws) {  // every buffer the SpMMs / the loss scatter into must lie inside the zero-once region
+    const float* lo = p->zero_ws;
+    const float* hi = p->zero_ws + p->zero_ws_floats;
+    auto inside = [&](const float* q) { return q >= lo && q < hi; };
+    for (int l = 0; l < p->n_layers; ++l)
+      HIPREC_REQUIRE(inside(p->side[l]) && (!train || inside(p->spmm_tmp[l])),
+                     "layer %d: side / spmm_tmp outside zero_ws", l);
+    HIPREC_REQUIRE(!train || inside(p->d_all), "d_all outside zero_ws");
+  }
   for (int l = 0; l < p->n_layers; ++l) {
     HIPREC_REQUIRE(p->gc_w[l] && p->gc_b[l] && p->bi_w[l] && p->bi_b[l], "NULL layer %d weights", l);
     HIPREC_REQUIRE(p->side[l] && p->bi_in[l] && p->sum_pre[l] && p->bi_pre[l] && p->ego[l] && p->nrm[l],
                    "NULL layer %d workspace", l);
   }
   if (train) {
+    HIPREC_REQUIRE(p->at.rowptr && (p->at.nnz == 0 || (p->at.col && p->at.val)), "bad CSR at");
     HIPREC_REQUIRE(p->at.n_rows == p->a.n_rows && p->at.nnz == p->a.nnz, "transposed graph differs in shape");
     HIPREC_REQUIRE(p->g_e0 && p->d_all && p->d_sum && p->d_bi && p->d_side && p->d_bi_in && p->d_ego[0] &&
                        p->d_ego[1],
                    "NULL backward workspace");
+    for (int l = 0; l < p->n_layers; ++l) HIPREC_REQUIRE(p->spmm_tmp[l], "NULL spmm_tmp[%d]", l);
     for (int l = 0; l < p->n_layers; ++l)
       HIPREC_REQUIRE(p->g_gc_w[l] && p->g_gc_b[l] && p->g_bi_w[l] && p->g_bi_b[l], "NULL layer %d gradients", l);
   }
@@ -282,13 +295,15 @@ inline int check_ngcf_plan(const hiprec_ngcf_plan* p, bool train) {
 inline int ngcf_forward(const hiprec_ngcf_plan* p, bool train, hipStream_t st) {
   const int64_t N = p->n_users + p->n_items;
   const int dt = total_width(p);
+  const bool zeroed = p->zero_ws != nullptr;  // ONE fill for every SpMM output (+ d_all) of the step
+  if (zeroed) HIPREC_TRY(hipMemsetAsync(p->zero_ws, 0, sizeof(float) * p->zero_ws_floats, st));
   ngcf_copy_e0_kernel<<<grid_for_threads(N * p->dim[0]), kBlock, 0, st>>>(p->e0, p->all, dt, N, p->dim[0]);
   HIPREC_TRY(hipGetLastError());
   const float* ego = p->e0;
   int off = p->dim[0];
   for (int l = 0; l < p->n_layers; ++l) {
     const int di = p->dim[l], dout = p->dim[l + 1];
-    if (int rc = hiprec_spmm_csr(&p->a, nullptr, 1.0f, ego, p->side[l], nullptr, di, st)) return rc;
+    if (int rc = launch_spmm(&p->a, nullptr, 1.0f, ego, p->side[l], nullptr, di, st, zeroed)) return rc;
     ngcf_bi_mul_kernel<<<grid_for_threads((N * di + 3) / 4), kBlock, 0, st>>>(ego, p->side[l], p->bi_in[l],
                                                                              N * di);
     HIPREC_TRY(hipGetLastError());
@@ -350,7 +365,7 @@ extern "C" int hiprec_ngcf_grad(const hiprec_ngcf_plan* plan, const int64_t* use
   const int64_t N = p->n_users + p->n_items;
   const int dt = total_width(p);
   if (int rc = ngcf_forward(p, true, st)) return rc;
-  HIPREC_TRY(hipMemsetAsync(p->d_all, 0, sizeof(float) * N * dt, st));
+  if (!p->zero_ws) HIPREC_TRY(hipMemsetAsync(p->d_all, 0, sizeof(float) * N * dt, st));
   ngcf_loss_kernel<<<grid_for_waves(batch > 0 ? batch : 1), kBlock, 0, st>>>(
       p->all, p->d_all, dt, p->n_users, p->n_items, users, pos, neg, batch, inv_batch,
       p->decay * p->inv_reg_batch, stats, static_cast<Scratch*>(scratch));
@@ -385,7 +400,8 @@ extern "C" int hiprec_ngcf_grad(const hiprec_ngcf_plan* plan, const int64_t* use
                                                                    p->d_side, N * di);
     HIPREC_TRY(hipGetLastError());
     // d_ego += A^T d_side
-    if (int rc = hiprec_spmm_csr(&p->at, nullptr, 1.0f, p->d_side, p->spmm_tmp, d_ego, di, st)) return rc;
+    if (int rc = launch_spmm(&p->at, nullptr, 1.0f, p->d_side, p->spmm_tmp[l], d_ego, di, st, p->zero_ws != nullptr))
+      return rc;
     d_next = d_ego;
   }
   ngcf_e0_grad_kernel<<<grid_for_threads(N * p->dim[0]), kBlock, 0, st>>>(p->d_all, dt, d_next, p->g_e0, N,

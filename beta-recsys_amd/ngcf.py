@@ -99,14 +99,20 @@ class NGCF(_FlatModel):
         N, dims = self.n_users + self.n_items, self.layer_size
         dmax = max(dims)
         new = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)  # noqa: E731
-        ws = {"dev": dev, "all": new(N, sum(dims)), "d_all": new(N, sum(dims))}
-        for name in ("side", "bi_in"):
-            ws[name] = [new(N, dims[i]) for i in range(self.n_layers)]
+        # every buffer an SpMM (atomics on heavy rows) or the loss scatters into sits in ONE region that
+        # the library clears with one fill per step: side[l], spmm_tmp[l], d_all
+        sizes = [N * dims[i] for i in range(self.n_layers)] * 2 + [N * sum(dims)]
+        zero_ws = new(sum(sizes))
+        parts = torch.split(zero_ws, sizes)
+        ws = {"dev": dev, "zero_ws": zero_ws, "all": new(N, sum(dims)), "d_all": parts[-1].view(N, sum(dims))}
+        ws["side"] = [parts[i].view(N, dims[i]) for i in range(self.n_layers)]
+        ws["spmm_tmp"] = [parts[self.n_layers + i].view(N, dims[i]) for i in range(self.n_layers)]
+        ws["bi_in"] = [new(N, dims[i]) for i in range(self.n_layers)]
         for name in ("sum_pre", "bi_pre", "ego"):
             ws[name] = [new(N, dims[i + 1]) for i in range(self.n_layers)]
         ws["nrm"] = [new(N) for _ in range(self.n_layers)]
         ws["keep"] = [torch.ones(N, dims[i + 1], dtype=torch.uint8, device=dev) for i in range(self.n_layers)]
-        for name in ("d_sum", "d_bi", "d_side", "d_bi_in", "d_ego0", "d_ego1", "spmm_tmp"):
+        for name in ("d_sum", "d_bi", "d_side", "d_bi_in", "d_ego0", "d_ego1"):
             ws[name] = new(N, dmax)
         self._ws = ws
         return ws
@@ -133,14 +139,15 @@ class NGCF(_FlatModel):
                 getattr(p, field)[i] = at(self._flat, name)
                 if g_flat is not None:
                     getattr(p, "g_" + field)[i] = at(g_flat, name)
-            for field in ("side", "bi_in", "sum_pre", "bi_pre", "ego", "nrm"):
+            for field in ("side", "bi_in", "sum_pre", "bi_pre", "ego", "nrm", "spmm_tmp"):
                 getattr(p, field)[i] = ws[field][i].data_ptr()
             k = None if keep is None else keep[i]
             p.keep[i] = None if k is None else k.data_ptr()
             p.keep_scale[i] = 1.0 if k is None else 1.0 / (1.0 - float(self.dropout_list[i]))
         p.all, p.d_all = ws["all"].data_ptr(), ws["d_all"].data_ptr()
-        for field in ("d_sum", "d_bi", "d_side", "d_bi_in", "spmm_tmp"):
+        for field in ("d_sum", "d_bi", "d_side", "d_bi_in"):
             setattr(p, field, ws[field].data_ptr())
+        p.zero_ws, p.zero_ws_floats = ws["zero_ws"].data_ptr(), ws["zero_ws"].numel()
         p.d_ego[0], p.d_ego[1] = ws["d_ego0"].data_ptr(), ws["d_ego1"].data_ptr()
         return p
 

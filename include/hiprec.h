@@ -624,7 +624,12 @@ typedef struct hiprec_ngcf_plan {
   float* d_side;
   float* d_bi_in;
   float* d_ego[2];
-  float* spmm_tmp;                           /* also used by the forward */
+  float* spmm_tmp[HIPREC_NGCF_MAX_LAYERS];   /* output of the transposed SpMM of hop l */
+  /* Optional: one contiguous caller-owned region that contains every side[l], spmm_tmp[l] and d_all.
+   * When set, a step clears it with ONE fill instead of one ~5 us fill launch per SpMM (their outputs
+   * must be zero on entry: heavy rows are accumulated with atomics). */
+  float* zero_ws;
+  int64_t zero_ws_floats;
 } hiprec_ngcf_plan;
 
 size_t hiprec_ngcf_plan_bytes(void);
