@@ -367,6 +367,32 @@ def bench_lightgcn(args, device):
     print(json.dumps(out), flush=True)
 
 
+def port_baseline(make_port, batches, units_per_step, what, budget_s=9.0):
+    """cpu_baseline for the sibling workloads: the reference's ATen op sequence (oracle/torch_port.py,
+    pinned on goldens from the real reference) on this box's host cores, bounded sample, best of a few
+    intra-op thread counts (cores = the count that won)."""
+    all_threads = torch.get_num_threads()
+    candidates = sorted({all_threads, min(32, all_threads), min(8, all_threads)}, reverse=True)
+    best = None
+    for nt in candidates:
+        torch.set_num_threads(nt)
+        torch.manual_seed(0)
+        port = make_port()
+        port.step(batches[0])
+        steps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s / len(candidates):
+            port.step(batches[(steps + 1) % len(batches)])
+            steps += 1
+        dt = time.perf_counter() - t0
+        if best is None or steps / dt > best[0] / best[3]:
+            best = (steps, nt, units_per_step, dt)
+    torch.set_num_threads(all_threads)
+    steps, nt, units, dt = best
+    return {"value": steps * units / dt, "unit": "triples/s", "cores": nt, "kind": "port",
+            "sample": f"{steps} steps of {what} in {dt:.1f} s with {nt} ATen threads (best of {candidates}); "
+                      f"PyTorch-CPU op sequence of the reference; host has {os.cpu_count()} logical cpus"}
+
+
 def bench_siblings(args, device):
     """SURVEY.md §8f rank 4 siblings at the reference's own default shapes on ML-1M-sized tables:
     pgmf = PairwiseGMF (configs/cmn_default.json: emb_dim 64, batch 1024, adam 1e-4, l2 1e-4, clip 5);
@@ -435,6 +461,16 @@ def bench_siblings(args, device):
                         "achieved": bytes_step / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bytes_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                         "note": "whole step (all launches); at these batch sizes the step is launch-latency bound"}}
+    if not args.no_cpu_baseline:
+        from oracle import torch_port
+
+        w0 = {k: v.detach().cpu().numpy() for k, v in eng.model.state_dict().items()}
+        host = [tuple(c[k * Bs:(k + 1) * Bs].cpu() for c in cols) for k in range(8)]
+        if args.workload == "pgmf":
+            make = lambda: torch_port.TorchPGMFPort(w0, "adam", 1e-4, 1e-4, 5.0)  # noqa: E731
+        else:
+            make = lambda: torch_port.TorchT2VPort(w0, Bs, "adam", 5e-4)  # noqa: E731
+        out["cpu_baseline"] = port_baseline(make, host, Bs, f"batch {Bs} (same workload)")
     print(json.dumps(out), flush=True)
 
 
@@ -505,6 +541,14 @@ def bench_ngcf(args, device):
                         "frac": bytes_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                         "gemm_tflops": flops / (dt / args.steps) / 1e12,
                         "note": "whole step (~35 launches); full-graph propagation per step like the reference"}}
+    if not args.no_cpu_baseline:
+        from oracle import torch_port
+
+        w0 = {k: v.detach().cpu().numpy() for k, v in eng.model.state_dict().items()}
+        host = [(users[k * Bn:(k + 1) * Bn].cpu(), pos[k * Bn:(k + 1) * Bn].cpu(), neg[k * Bn:(k + 1) * Bn].cpu())
+                for k in range(8)]
+        make = lambda: torch_port.TorchNGCFPort(w0, norm.coalesce(), [0.1] * L, 1e-5, Bn, "adam", 0.05)  # noqa: E731
+        out["cpu_baseline"] = port_baseline(make, host, Bn, f"batch {Bn} on the same graph")
     print(json.dumps(out), flush=True)
 
 

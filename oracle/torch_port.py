@@ -88,3 +88,115 @@ class TorchMFPort:
     def predict(self, users, items):
         with torch.no_grad():
             return self.forward(users, items)[0]
+
+
+def _make_optimizer(params, optimizer, lr):
+    if optimizer == "sgd":
+        return torch.optim.SGD(params, lr=lr)
+    if optimizer == "adam":
+        return torch.optim.Adam(params, lr=lr)
+    if optimizer == "rmsprop":
+        return torch.optim.RMSprop(params, lr=lr)
+    raise ValueError(optimizer)
+
+
+class _Port:
+    """Leaf tensors keyed like the reference's state_dict + a stock torch optimizer over them."""
+
+    def __init__(self, weights, optimizer, lr):
+        self.w = {k: torch.as_tensor(v, dtype=torch.float32).clone().requires_grad_(True)
+                  for k, v in weights.items()}
+        self.opt = _make_optimizer(list(self.w.values()), optimizer, lr)
+
+    def numpy_weights(self):
+        return {k: v.detach().numpy().copy() for k, v in self.w.items()}
+
+
+class TorchPGMFPort(_Port):
+    """PairwiseGMFEngine.train_single_batch as ATen ops (models/pairwise_gmf.py:48-62, 82-116, 144-158):
+    relu(Linear(u * i)), -log(sigmoid(.) + 1e-12), + lambda * ||v||, clip_grad_norm_, optimizer step.
+    Pinned by tests/golden/pgmf_*.npz."""
+
+    def __init__(self, weights, optimizer="adam", lr=1e-4, l2_lambda=1e-4, grad_clip=5.0):
+        super().__init__(weights, optimizer, lr)
+        self.l2_lambda, self.grad_clip = l2_lambda, grad_clip
+
+    def step(self, batch):
+        users, pos, neg = (torch.as_tensor(x, dtype=torch.int64) for x in batch)
+        w = self.w
+        self.opt.zero_grad()
+        u = F.embedding(users, w["user_memory.weight"])
+        score = lambda items: F.relu(F.linear(u * F.embedding(items, w["item_memory.weight"]), w["v.weight"]))  # noqa: E731
+        loss = torch.mean(-1 * torch.log(torch.sigmoid(score(pos) - score(neg)) + 1e-12))
+        loss = loss + self.l2_lambda * torch.sqrt(w["v.weight"].pow(2).sum())
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(w.values()), self.grad_clip)
+        self.opt.step()
+        return loss.item()
+
+
+class TorchT2VPort(_Port):
+    """Triple2vecEngine.train_single_batch as ATen ops (models/triple2vec.py:36-92, 115-124) with
+    item_emb2 aliased to item_emb1 (use_bias = n_neg) and both negative item rows gathered by neg_i_2.
+    Weights: user_emb / item_emb1 / user_bias / item_bias.  Pinned by tests/golden/t2v_*.npz."""
+
+    def __init__(self, weights, batch_size, optimizer="adam", lr=5e-4):
+        super().__init__({k: v for k, v in weights.items() if k != "item_emb2.weight"}, optimizer, lr)
+        self.batch_size = batch_size
+
+    def step(self, batch):
+        pu, p1, p2, nu, n1, n2 = (torch.as_tensor(x, dtype=torch.int64) for x in batch)
+        w = self.w
+        E, bias_u, bias_i = w["item_emb1.weight"], w["user_bias.weight"], w["item_bias.weight"]
+        self.opt.zero_grad()
+        eu, e1, e2 = F.embedding(pu, w["user_emb.weight"]), F.embedding(p1, E), F.embedding(p2, E)
+        ru, r1, r2 = F.embedding(nu, w["user_emb.weight"]), F.embedding(n2, E), F.embedding(n2, E)
+
+        def part(center, context, bias_pos, neg_rows, bias_neg):
+            pos_s = F.logsigmoid(torch.sum(center * context, dim=1) + bias_pos.squeeze())
+            neg_s = F.logsigmoid(-1 * (torch.bmm(neg_rows, center.unsqueeze(2)).squeeze() + bias_neg.squeeze()))
+            return -1 * (torch.sum(pos_s) + torch.sum(neg_s))
+
+        total = (part(eu, e1 + e2, F.embedding(pu, bias_u), ru, F.embedding(nu, bias_u))
+                 + part(e1, eu + e2, F.embedding(p1, bias_i), r1, F.embedding(n1, bias_i))
+                 + part(e2, eu + e1, F.embedding(p2, bias_i), r2, F.embedding(n2, bias_i)))
+        loss = total / (3 * self.batch_size)
+        loss.backward()
+        self.opt.step()
+        return loss.item()
+
+
+class TorchNGCFPort(_Port):
+    """NGCFEngine.train_single_batch as ATen ops (models/ngcf.py:48-80, 118-149, 172-199) on a torch sparse
+    norm_adj; nn.Dropout draws from the global CPU generator as in the reference.  Pinned by
+    tests/golden/ngcf_*.npz."""
+
+    def __init__(self, weights, norm_adj, mess_dropout, decay, batch_size, optimizer="adam", lr=0.05):
+        super().__init__(weights, optimizer, lr)
+        self.adj, self.drop, self.decay, self.batch_size = norm_adj, list(mess_dropout), decay, batch_size
+        self.n_layers = sum(1 for k in weights if k.startswith("GC_weights.") and k.endswith(".weight"))
+        self.training = True
+
+    def forward(self):
+        w = self.w
+        ego = torch.cat((w["user_embedding.weight"], w["item_embedding.weight"]), dim=0)
+        outs = [ego]
+        for l in range(self.n_layers):
+            side = torch.sparse.mm(self.adj, ego)
+            s = F.leaky_relu(F.linear(side, w[f"GC_weights.{l}.weight"], w[f"GC_weights.{l}.bias"]))
+            b = F.leaky_relu(F.linear(ego * side, w[f"Bi_weights.{l}.weight"], w[f"Bi_weights.{l}.bias"]))
+            ego = F.dropout(s + b, self.drop[l], self.training)
+            outs.append(F.normalize(ego, p=2, dim=1))
+        return torch.cat(outs, dim=1)
+
+    def step(self, batch):
+        users, pos, neg = (torch.as_tensor(x, dtype=torch.int64) for x in batch)
+        n_users = self.w["user_embedding.weight"].shape[0]
+        self.opt.zero_grad()
+        allv = self.forward()
+        u, p, n = allv[users], allv[n_users + pos], allv[n_users + neg]
+        reg = (0.5 * (u ** 2).sum() + 0.5 * (p ** 2).sum() + 0.5 * (n ** 2).sum()) / self.batch_size
+        loss = -torch.mean(F.logsigmoid((u * p).sum(1) - (u * n).sum(1))) + self.decay * reg
+        loss.backward()
+        self.opt.step()
+        return loss.item()

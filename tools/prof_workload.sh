@@ -1,4 +1,4 @@
-# kernel-trace stats of one bench workload: bash tools/prof_workload.sh ncf|lightgcn|mf-c4shard [tag]
+# kernel-trace stats of one bench workload: bash tools/prof_workload.sh ncf|lightgcn|mf-c4shard|pgmf|t2v|ngcf [tag]
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 W=$1; TAG=${2:-$1}
