@@ -1,4 +1,4 @@
-# FETCH_SIZE / WRITE_SIZE passes for one bench workload: bash tools/pmc_workload.sh lightgcn|ncf|mf-c4shard
+# FETCH_SIZE / WRITE_SIZE passes for one bench workload: bash tools/pmc_workload.sh lightgcn|ncf|mf-c4shard|pgmf|t2v|ngcf
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 W=$1
