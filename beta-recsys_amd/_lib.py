@@ -77,7 +77,7 @@ class Csr(Structure):
     """hiprec_csr (include/hiprec.h)."""
 
     _fields_ = [("rowptr", c_void_p), ("col", c_void_p), ("val", c_void_p), ("eid", c_void_p),
-                ("n_rows", c_int64), ("nnz", c_int64)]
+                ("n_rows", c_int64), ("nnz", c_int64), ("slice_row", c_void_p)]
 
 
 class LightGcnPlan(Structure):
@@ -238,6 +238,8 @@ SIGNATURES = {
     "hiprec_ngcf_forward": (c_int, [POINTER(NgcfPlan), c_int, _P]),
     "hiprec_ngcf_predict": (c_int, [POINTER(NgcfPlan), _P, _P, c_int64, _P, _P, _P]),
     "hiprec_ngcf_grad": (c_int, [POINTER(NgcfPlan), _P, _P, _P, c_int64, c_float, _P, _P, c_size_t, _P]),
+    "hiprec_csr_n_slices": (c_int64, [c_int64]),
+    "hiprec_csr_slice_rows": (c_int, [POINTER(Csr), _P, c_int64, _P]),
     "hiprec_rank_metrics_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hiprec_rank_metrics": (
         c_int,

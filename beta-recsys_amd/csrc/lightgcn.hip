@@ -33,7 +33,26 @@ __device__ __forceinline__ int64_t find_row(const int64_t* __restrict__ rowptr, 
   return lo;
 }
 
-// NPL = columns per lane held in registers (dim <= 64 * NPL)
+// One thread per kEdgesPerWave-edge slice: the row its first edge belongs to (done once per graph, so
+// that a wave of the SpMM does not start with a 14-step dependent binary search through L2).
+__global__ __launch_bounds__(kBlock) void csr_slice_rows_kernel(const int64_t* __restrict__ rowptr,
+                                                                int64_t n_rows, int64_t nnz,
+                                                                int32_t* __restrict__ out,
+                                                                int64_t n_slices) {
+  const int64_t s = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (s < n_slices) out[s] = static_cast<int32_t>(find_row(rowptr, n_rows, min(s * kEdgesPerWave, nnz - 1)));
+}
+
+// NPL = columns per lane held in registers (dim <= 64 * NPL).
+// A wave owns one slice of kEdgesPerWave consecutive edges and ALL waves of the launch are resident
+// at once (~23 per CU at ML-1M size), so the launch lasts as long as ONE wave's chain of dependent
+// memory round trips (~1 us each through L2 under load): the chain is kept short --
+//   * the slice's first row comes from a.slice_row (one load) instead of a binary search (14 loads),
+//   * the (col, val, keep) lanes of the NEXT 64-edge chunk are requested before the current chunk's
+//     row gathers, so they never cost a round trip of their own,
+//   * kGroup = 32 / NPL source rows are requested together and unconditionally (lanes past the slice
+//     hold column 0 / value 0, dropped edges multiply by 0); row bookkeeping is scalar and runs after
+//     the loads are issued.
 template <int NPL>
 __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(hiprec_csr a,
                                                           const uint8_t* __restrict__ keep,
@@ -45,7 +64,21 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(hiprec_csr a,
   const int64_t e_begin = wave * kEdgesPerWave;
   if (e_begin >= a.nnz) return;
   const int64_t e_end = min(a.nnz, e_begin + kEdgesPerWave);
-  int64_t row = find_row(a.rowptr, a.n_rows, e_begin);
+
+  auto load_chunk = [&](int64_t e0, int& col, float& val) {
+    const int64_t e = e0 + lane;
+    col = 0;
+    val = 0.f;
+    if (e < e_end) {
+      col = a.col[e];
+      val = a.val[e];
+      if (keep) val = keep[a.eid ? a.eid[e] : e] ? val * scale : 0.f;
+    }
+  };
+  int my_col, nxt_col = 0;
+  float my_val, nxt_val = 0.f;
+  load_chunk(e_begin, my_col, my_val);
+  int64_t row = a.slice_row ? static_cast<int64_t>(a.slice_row[wave]) : find_row(a.rowptr, a.n_rows, e_begin);
   int64_t row_end = a.rowptr[row + 1];
   float acc[NPL];
 #pragma unroll
@@ -64,32 +97,14 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(hiprec_csr a,
   };
 
   for (int64_t e0 = e_begin; e0 < e_end; e0 += kWave) {
-    const int64_t e = e0 + lane;
-    int my_col = 0;
-    float my_val = 0.f;
-    if (e < e_end) {
-      my_col = a.col[e];
-      my_val = a.val[e];
-      if (keep) my_val = keep[a.eid ? a.eid[e] : e] ? my_val * scale : 0.f;
-    }
+    if (e0 + kWave < e_end) load_chunk(e0 + kWave, nxt_col, nxt_val);
     const int n_here = static_cast<int>(min<int64_t>(kWave, e_end - e0));
-    // kGroup edges per trip: their source rows are requested together and unconditionally (lanes
-    // past the slice hold column 0 / value 0, dropped edges multiply by 0), so a wave keeps
-    // kGroup * NPL row gathers in flight; the row bookkeeping is scalar and runs after the loads
-    // are issued.  With 4 conditional gathers per trip the SpMM sat on one L2 round trip per 4 edges.
-    constexpr int kGroup = 16 / NPL;
+    constexpr int kGroup = 32 / NPL;
     for (int j = 0; j < n_here; j += kGroup) {
-      int cs[kGroup];
-      float vs[kGroup];
-#pragma unroll
-      for (int q = 0; q < kGroup; ++q) {
-        cs[q] = __builtin_amdgcn_readlane(my_col, j + q);
-        vs[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), j + q));
-      }
       float xv[kGroup][NPL];
 #pragma unroll
       for (int q = 0; q < kGroup; ++q) {
-        const float* xr = x + static_cast<int64_t>(cs[q]) * dim;
+        const float* xr = x + static_cast<int64_t>(__builtin_amdgcn_readlane(my_col, j + q)) * dim;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
           const int c = lane + kWave * k;
@@ -104,12 +119,15 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(hiprec_csr a,
             ++row;
             row_end = a.rowptr[row + 1];
           }
+          const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), j + q));
 #pragma unroll
           for (int k = 0; k < NPL; ++k)
-            if (lane + kWave * k < dim) acc[k] += vs[q] * xv[q][k];
+            if (lane + kWave * k < dim) acc[k] += v * xv[q][k];
         }
       }
     }
+    my_col = nxt_col;
+    my_val = nxt_val;
   }
   flush(row);
 }
@@ -296,6 +314,21 @@ extern "C" int hiprec_spmm_csr(const hiprec_csr* a, const uint8_t* keep, float s
   if (int rc = check_csr(a, "a")) return rc;
   HIPREC_REQUIRE(x && y && dim > 0, "NULL x / y or bad dim");
   return launch_spmm(a, keep, keep ? scale : 1.0f, x, y, acc, dim, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int64_t hiprec_csr_n_slices(int64_t nnz) { return (nnz + kEdgesPerWave - 1) / kEdgesPerWave; }
+
+extern "C" int hiprec_csr_slice_rows(const hiprec_csr* a, int32_t* out, int64_t n_out, void* stream) {
+  if (int rc = check_csr(a, "a")) return rc;
+  const int64_t n = hiprec_csr_n_slices(a->nnz);
+  HIPREC_REQUIRE(a->n_rows < (1ll << 31), "too many rows for 32-bit slice rows");
+  HIPREC_REQUIRE(n_out >= n && (n == 0 || out), "slice_row buffer holds %lld entries, %lld needed",
+                 (long long)n_out, (long long)n);
+  if (n == 0) return 0;
+  csr_slice_rows_kernel<<<grid_for_threads(n), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      a->rowptr, a->n_rows, a->nnz, out, n);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
 }
 
 extern "C" int hiprec_edge_dropout_mask(uint8_t* keep, int64_t nnz, float keep_prob, uint64_t seed,

@@ -25,6 +25,15 @@ from .ncf import _FlatModel, _ParamView
 from .torch_engine import ModelEngine
 
 
+def _slice_rows(rowptr, col, val, n, nnz):
+    """hiprec_csr.slice_row of a CSR on the device (one launch, once per graph)."""
+    lib = _lib.load()
+    out = torch.empty(max(int(lib.hiprec_csr_n_slices(nnz)), 1), dtype=torch.int32, device=rowptr.device)
+    csr = _lib.Csr(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), None, n, nnz, None)
+    _lib.check(lib.hiprec_csr_slice_rows(ctypes.byref(csr), _lib.ptr(out), out.numel(), _lib.stream_ptr(rowptr.device)))
+    return out
+
+
 def _csr_from_coo(rows, cols, vals, n, device):
     """Sorted CSR (int64 rowptr, int32 col, fp32 val) + the sort permutation."""
     order = torch.argsort(rows * n + cols, stable=True)
@@ -79,9 +88,13 @@ class LightGCN(_FlatModel):
         # is the order LightGCN.dropout draws its mask in (lightgcn.py:29-35)
         rp, c, v, _ = _csr_from_coo(rows, cols, vals, N, dev)
         rpt, ct, vt, order_t = _csr_from_coo(cols, rows, vals, N, dev)
-        self._graph = {"dev": dev, "nnz": int(vals.numel()), "rowptr": rp, "col": c, "val": v,
+        nnz = int(vals.numel())
+        self._graph = {"dev": dev, "nnz": nnz, "rowptr": rp, "col": c, "val": v,
                        "rowptr_t": rpt, "col_t": ct, "val_t": vt,
                        "eid_t": order_t.to(torch.int32).to(dev)}
+        if dev.type == "cuda":
+            self._graph["slice_row"] = _slice_rows(rp, c, v, N, nnz)
+            self._graph["slice_row_t"] = _slice_rows(rpt, ct, vt, N, nnz)
         return self._graph
 
     def workspace(self):
@@ -101,9 +114,10 @@ class LightGCN(_FlatModel):
         gr, ws = self.graph(), self.workspace()
         N = self.n_users + self.n_items
         p = _lib.LightGcnPlan()
-        p.a = _lib.Csr(gr["rowptr"].data_ptr(), gr["col"].data_ptr(), gr["val"].data_ptr(), None, N, gr["nnz"])
+        p.a = _lib.Csr(gr["rowptr"].data_ptr(), gr["col"].data_ptr(), gr["val"].data_ptr(), None, N, gr["nnz"],
+                       _lib.ptr(gr.get("slice_row")))
         p.at = _lib.Csr(gr["rowptr_t"].data_ptr(), gr["col_t"].data_ptr(), gr["val_t"].data_ptr(),
-                        gr["eid_t"].data_ptr(), N, gr["nnz"])
+                        gr["eid_t"].data_ptr(), N, gr["nnz"], _lib.ptr(gr.get("slice_row_t")))
         p.n_users, p.n_items, p.dim, p.n_layers = self.n_users, self.n_items, self.emb_dim, self.n_layers
         p.decay = float(decay)
         p.e0 = self._flat.data_ptr()

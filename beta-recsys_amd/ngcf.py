@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .lightgcn import _csr_from_coo
+from .lightgcn import _csr_from_coo, _slice_rows
 from .mf import _new_stats, raise_on_status, read_stats
 from .ncf import _FlatModel, _init_linear_like_torch, _ParamView
 from .torch_engine import ModelEngine
@@ -88,8 +88,12 @@ class NGCF(_FlatModel):
         vals = co.values().to(torch.float32)
         rp, c, v, _ = _csr_from_coo(rows, cols, vals, N, dev)
         rpt, ct, vt, _ = _csr_from_coo(cols, rows, vals, N, dev)
-        self._graph = {"dev": dev, "nnz": int(vals.numel()), "rowptr": rp, "col": c, "val": v,
+        nnz = int(vals.numel())
+        self._graph = {"dev": dev, "nnz": nnz, "rowptr": rp, "col": c, "val": v,
                        "rowptr_t": rpt, "col_t": ct, "val_t": vt}
+        if dev.type == "cuda":
+            self._graph["slice_row"] = _slice_rows(rp, c, v, N, nnz)
+            self._graph["slice_row_t"] = _slice_rows(rpt, ct, vt, N, nnz)
         return self._graph
 
     def workspace(self):
@@ -123,9 +127,10 @@ class NGCF(_FlatModel):
         gr, ws = self.graph(), self.workspace()
         N = self.n_users + self.n_items
         p = _lib.NgcfPlan()
-        p.a = _lib.Csr(gr["rowptr"].data_ptr(), gr["col"].data_ptr(), gr["val"].data_ptr(), None, N, gr["nnz"])
+        p.a = _lib.Csr(gr["rowptr"].data_ptr(), gr["col"].data_ptr(), gr["val"].data_ptr(), None, N, gr["nnz"],
+                       _lib.ptr(gr.get("slice_row")))
         p.at = _lib.Csr(gr["rowptr_t"].data_ptr(), gr["col_t"].data_ptr(), gr["val_t"].data_ptr(), None, N,
-                        gr["nnz"])
+                        gr["nnz"], _lib.ptr(gr.get("slice_row_t")))
         p.n_users, p.n_items, p.n_layers = self.n_users, self.n_items, self.n_layers
         for i, d in enumerate(self.layer_size):
             p.dim[i] = d

@@ -395,7 +395,14 @@ typedef struct hiprec_csr {
   const int32_t* eid;    /* [nnz] or NULL */
   int64_t n_rows;
   int64_t nnz;
+  const int32_t* slice_row; /* [hiprec_csr_n_slices(nnz)] from hiprec_csr_slice_rows, or NULL: the row of
+                             * the first edge of every 256-edge slice (one SpMM wave per slice; NULL makes
+                             * every wave binary-search rowptr, 14 dependent loads) */
 } hiprec_csr;
+
+/* ---- per-graph preprocessing for hiprec_spmm_csr: out[s] = row that owns edge 256 * s. */
+int64_t hiprec_csr_n_slices(int64_t nnz);
+int hiprec_csr_slice_rows(const hiprec_csr* a, int32_t* out, int64_t n_out, void* stream);
 
 /* Everything one LightGCN step touches.  e0 / g are the flat parameter / gradient buffers
  * [user_embedding | item_embedding] = [(n_users + n_items), dim]; the rest is caller-owned

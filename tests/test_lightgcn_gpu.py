@@ -58,7 +58,13 @@ def test_spmm_csr_vs_scipy(hip_device, dim):
     co = a.tocoo()
     rp, c, v, _ = _csr_from_coo(torch.from_numpy(co.row.astype(np.int64)), torch.from_numpy(co.col.astype(np.int64)),
                                 torch.from_numpy(co.data), n, hip_device)
-    csr = _lib.Csr(rp.data_ptr(), c.data_ptr(), v.data_ptr(), None, n, a.nnz)
+    from beta_recsys_amd.lightgcn import _slice_rows
+
+    sr = _slice_rows(rp, c, v, n, a.nnz)
+    starts = np.arange(len(sr)) * 256
+    assert np.array_equal(sr.cpu().numpy(), np.searchsorted(a.indptr, starts, side="right") - 1)
+    # with the per-slice first rows (what the engines pass) and without (binary search per wave)
+    csr = _lib.Csr(rp.data_ptr(), c.data_ptr(), v.data_ptr(), None, n, a.nnz, _lib.ptr(sr if dim != 100 else None))
     x = rng.standard_normal((n, dim)).astype(np.float32)
     keep = (rng.random(a.nnz) < 0.6)
     xt = torch.from_numpy(x).cuda()
