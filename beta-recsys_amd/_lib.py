@@ -116,6 +116,8 @@ class NgcfPlan(Structure):
                 + [(n, c_void_p * NGCF_MAX_LAYERS) for n in ("gc_w", "gc_b", "bi_w", "bi_b", "g_gc_w", "g_gc_b", "g_bi_w",
                                                 "g_bi_b", "side", "bi_in", "sum_pre", "bi_pre", "ego", "nrm")]
                 + [("all", c_void_p), ("keep", c_void_p * NGCF_MAX_LAYERS), ("keep_scale", c_float * NGCF_MAX_LAYERS),
+                   ("keep_prob", c_float * NGCF_MAX_LAYERS), ("keep_seed", ctypes.c_uint64),
+                   ("keep_step", ctypes.c_uint64), ("keep_gen", c_int32), ("_pad", c_int32),
                    ("d_all", c_void_p), ("d_sum", c_void_p), ("d_bi", c_void_p), ("d_side", c_void_p),
                    ("d_bi_in", c_void_p), ("d_ego", c_void_p * 2), ("spmm_tmp", c_void_p * NGCF_MAX_LAYERS),
                    ("zero_ws", c_void_p), ("zero_ws_floats", c_int64)])

@@ -77,6 +77,16 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   return x ^ (x >> 31);
 }
 
+// keep/drop draw of element e at (seed, step): uniform 24-bit fraction < keep_prob.  Counter-based and
+// stateless: LightGCN's edge dropout and NGCF's message dropout use it.
+__device__ __forceinline__ bool keep_draw(uint64_t seed, uint64_t step, int64_t e, float keep_prob) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (static_cast<uint64_t>(e) + 1) + 0xD1B54A32D192ED03ull * (step + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return static_cast<float>(z >> 40) * (1.0f / 16777216.0f) < keep_prob;  // 24 bits -> [0, 1)
+}
+
 __device__ __forceinline__ uint32_t feistel_round(uint32_t x, uint32_t key) {
   x = (x ^ key) * 0x9E3779B1u;
   x ^= x >> 15;

@@ -138,13 +138,7 @@ __global__ __launch_bounds__(kBlock) void edge_dropout_kernel(uint8_t* __restric
                                                               uint64_t seed, uint64_t step) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < nnz; e += stride) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (static_cast<uint64_t>(e) + 1) +
-                 0xD1B54A32D192ED03ull * (step + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    const float u = static_cast<float>(z >> 40) * (1.0f / 16777216.0f);  // 24 bits -> [0, 1)
-    keep[e] = u < keep_prob ? 1 : 0;
+    keep[e] = keep_draw(seed, step, e, keep_prob) ? 1 : 0;
   }
 }
 

@@ -10,7 +10,7 @@
 //
 // Every hop is a short chain of HBM-bound passes over [N, d] activations (N = users + items, d <= 256):
 //   SpMM (lightgcn.hip)  ->  bi_mul  ->  ONE grouped launch of the two Linear layers (fp32 MFMA, ncf.hip)
-//   ->  act (lrelu + lrelu, dropout, row L2 norm, write the hop's slice of `all`)
+//   ->  act (lrelu + lrelu, dropout drawn or read, row L2 norm, write the hop's slice of `all`)
 // and the backward walks it in reverse:
 //   act_bwd (normalize / dropout / lrelu backward -> d_sum, d_bi)  ->  ONE grouped launch of six problems
 //   (two dgrads, two wgrads, two bias column sums)  ->  bi_bwd  ->  SpMM with the transposed graph.
@@ -45,10 +45,17 @@ __global__ __launch_bounds__(kBlock) void ngcf_bi_mul_kernel(const float* __rest
 }
 
 // One wave per node row: ego' = keep * scale * (lrelu(sum_pre) + lrelu(bi_pre)); nrm = |ego'|_2;
-// all[row, off : off + d] = ego' / max(nrm, eps).
+// all[row, off : off + d] = ego' / max(nrm, eps).  gen: draw the keep bytes here (and store them for the
+// backward) instead of reading them -- one launch less per hop than a separate mask kernel.
+struct KeepGen {
+  int on;
+  float keep_prob;
+  uint64_t seed, step;
+};
+
 __global__ __launch_bounds__(kBlock) void ngcf_act_kernel(const float* __restrict__ sum_pre,
                                                           const float* __restrict__ bi_pre,
-                                                          const uint8_t* __restrict__ keep, float scale,
+                                                          uint8_t* __restrict__ keep, float scale, KeepGen gen,
                                                           float* __restrict__ ego_out,
                                                           float* __restrict__ nrm_out,
                                                           float* __restrict__ all, int ld_all, int off,
@@ -65,7 +72,16 @@ __global__ __launch_bounds__(kBlock) void ngcf_act_kernel(const float* __restric
       if (c < d) {
         const int64_t i = r * d + c;
         float v = lrelu(sum_pre[i]) + lrelu(bi_pre[i]);
-        if (keep) v = keep[i] ? v * scale : 0.f;
+        if (keep) {
+          bool k;
+          if (gen.on) {
+            k = keep_draw(gen.seed, gen.step, i, gen.keep_prob);
+            keep[i] = k ? 1 : 0;
+          } else {
+            k = keep[i] != 0;
+          }
+          v = k ? v * scale : 0.f;
+        }
         x[k] = v;
         ego_out[i] = v;
       }
@@ -82,20 +98,13 @@ __global__ __launch_bounds__(kBlock) void ngcf_act_kernel(const float* __restric
   }
 }
 
-// all[row, 0 : d0] = ego_0 (the embedding tables themselves)
-__global__ __launch_bounds__(kBlock) void ngcf_copy_e0_kernel(const float* __restrict__ e0,
-                                                              float* __restrict__ all, int ld_all,
-                                                              int64_t n_rows, int d0) {
-  const int64_t n = n_rows * d0;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
-    const int64_t r = i / d0;
-    all[r * ld_all + (i - r * d0)] = e0[i];
-  }
-}
-
-// One wave per triple on rows of `all` (width dt): BPR loss + L2 term, gradient rows into d_all.
-__global__ __launch_bounds__(kBlock) void ngcf_loss_kernel(const float* __restrict__ all,
+// One wave per triple on rows of the concatenated table (width dt): BPR loss + L2 term, gradient rows
+// scattered with atomics.  Hop 0's slice (columns < d0) is not copied anywhere: it is read from the
+// embedding tables e0 themselves and its gradient goes straight into their gradient g_e0; columns
+// >= d0 live in `all` / `d_all` (row stride dt, their first d0 columns unused).
+__global__ __launch_bounds__(kBlock) void ngcf_loss_kernel(const float* __restrict__ e0,
+                                                           float* __restrict__ g_e0, int d0,
+                                                           const float* __restrict__ all,
                                                            float* __restrict__ d_all, int dt,
                                                            int64_t n_users, int64_t n_items,
                                                            const int64_t* __restrict__ users,
@@ -120,12 +129,12 @@ __global__ __launch_bounds__(kBlock) void ngcf_loss_kernel(const float* __restri
                  (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
       continue;
     }
-    const float* ur = all + u * dt;
-    const float* pr = all + (n_users + p) * dt;
-    const float* nr = all + (n_users + n) * dt;
+    const int64_t ru = u, rp = n_users + p, rn = n_users + n;
+    auto at = [&](int64_t r, int c) { return c < d0 ? e0[r * d0 + c] : all[r * dt + c]; };
+    auto grad_at = [&](int64_t r, int c) { return c < d0 ? g_e0 + r * d0 + c : d_all + r * dt + c; };
     float dp = 0.f, dn = 0.f, sq = 0.f;
     for (int c = lane; c < dt; c += kWave) {
-      const float a = ur[c], b = pr[c], e = nr[c];
+      const float a = at(ru, c), b = at(rp, c), e = at(rn, c);
       dp += a * b;
       dn += a * e;
       sq += a * a + b * b + e * e;
@@ -134,14 +143,11 @@ __global__ __launch_bounds__(kBlock) void ngcf_loss_kernel(const float* __restri
     loss_acc += neg_logsigmoid(wave_sum(dp) - wave_sum(dn), &sig);
     reg_acc += 0.5f * sq;
     const float dx = -sig * inv_batch;
-    float* gu = d_all + u * dt;
-    float* gp = d_all + (n_users + p) * dt;
-    float* gn = d_all + (n_users + n) * dt;
     for (int c = lane; c < dt; c += kWave) {  // second pass over rows that are in cache by now
-      const float a = ur[c], b = pr[c], e = nr[c];
-      atomic_add_f32(gu + c, dx * (b - e) + reg_coef * a);
-      atomic_add_f32(gp + c, dx * a + reg_coef * b);
-      atomic_add_f32(gn + c, -dx * a + reg_coef * e);
+      const float a = at(ru, c), b = at(rp, c), e = at(rn, c);
+      atomic_add_f32(grad_at(ru, c), dx * (b - e) + reg_coef * a);
+      atomic_add_f32(grad_at(rp, c), dx * a + reg_coef * b);
+      atomic_add_f32(grad_at(rn, c), -dx * a + reg_coef * e);
     }
   }
   // stats->loss = mf_loss + emb_loss (what train_single_batch returns); partial.y keeps the L2 part
@@ -189,7 +195,8 @@ __global__ __launch_bounds__(kBlock) void ngcf_act_bwd_kernel(
   }
 }
 
-// d_ego = d_bi_in * side ;  d_side += d_bi_in * ego
+// d_ego (=  or +=, hop 0 adds into the embedding gradient) d_bi_in * side ;  d_side += d_bi_in * ego
+template <bool ACCUMULATE>
 __global__ __launch_bounds__(kBlock) void ngcf_bi_bwd_kernel(const float* __restrict__ d_bi_in,
                                                              const float* __restrict__ side,
                                                              const float* __restrict__ ego,
@@ -199,27 +206,14 @@ __global__ __launch_bounds__(kBlock) void ngcf_bi_bwd_kernel(const float* __rest
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t i = tid; i < n; i += stride) {
     const float g = d_bi_in[i];
-    d_ego[i] = g * side[i];
+    if (ACCUMULATE) d_ego[i] += g * side[i]; else d_ego[i] = g * side[i];
     d_side[i] += g * ego[i];
   }
 }
 
-// g_e0[r, c] += d_all[r, c] + d_ego[r, c]   (the embedding tables' gradient: their own slice of `all`
-// plus what flows back through hop 0)
-__global__ __launch_bounds__(kBlock) void ngcf_e0_grad_kernel(const float* __restrict__ d_all, int ld_all,
-                                                              const float* __restrict__ d_ego,
-                                                              float* __restrict__ g_e0, int64_t n_rows,
-                                                              int d0) {
-  const int64_t n = n_rows * d0;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
-    const int64_t r = i / d0;
-    g_e0[i] += d_all[r * ld_all + (i - r * d0)] + d_ego[i];
-  }
-}
-
 // scores[k] = <all[u], all[U + i]>
-__global__ __launch_bounds__(kBlock) void ngcf_predict_kernel(const float* __restrict__ all, int dt,
+__global__ __launch_bounds__(kBlock) void ngcf_predict_kernel(const float* __restrict__ e0, int d0,
+                                                              const float* __restrict__ all, int dt,
                                                               int64_t n_users, int64_t n_items,
                                                               const int64_t* __restrict__ users,
                                                               const int64_t* __restrict__ items, int64_t n,
@@ -240,7 +234,9 @@ __global__ __launch_bounds__(kBlock) void ngcf_predict_kernel(const float* __res
       continue;
     }
     float dot = 0.f;
-    for (int c = lane; c < dt; c += kWave) dot += all[u * dt + c] * all[(n_users + i) * dt + c];
+    const int64_t ri = n_users + i;
+    for (int c = lane; c < dt; c += kWave)
+      dot += c < d0 ? e0[u * d0 + c] * e0[ri * d0 + c] : all[u * dt + c] * all[ri * dt + c];
     dot = wave_sum(dot);
     if (lane == 0) scores[t] = dot;
   }
@@ -297,8 +293,6 @@ inline int ngcf_forward(const hiprec_ngcf_plan* p, bool train, hipStream_t st) {
   const int dt = total_width(p);
   const bool zeroed = p->zero_ws != nullptr;  // ONE fill for every SpMM output (+ d_all) of the step
   if (zeroed) HIPREC_TRY(hipMemsetAsync(p->zero_ws, 0, sizeof(float) * p->zero_ws_floats, st));
-  ngcf_copy_e0_kernel<<<grid_for_threads(N * p->dim[0]), kBlock, 0, st>>>(p->e0, p->all, dt, N, p->dim[0]);
-  HIPREC_TRY(hipGetLastError());
   const float* ego = p->e0;
   int off = p->dim[0];
   for (int l = 0; l < p->n_layers; ++l) {
@@ -314,9 +308,10 @@ inline int ngcf_forward(const hiprec_ngcf_plan* p, bool train, hipStream_t st) {
     g.p[1] = make_gemm(kNT, static_cast<int>(N), dout, di, p->bi_in[l], di, p->bi_w[l], di, p->bi_pre[l], dout,
                        p->bi_b[l], 0, nullptr, 0, false);
     if (int rc = launch_group(g, st)) return rc;
-    const uint8_t* keep = train ? p->keep[l] : nullptr;
+    uint8_t* keep = train ? p->keep[l] : nullptr;
+    const KeepGen gen{p->keep_gen, p->keep_prob[l], p->keep_seed * 64 + static_cast<uint64_t>(l), p->keep_step};
     ngcf_act_kernel<<<grid_for_waves(N), kBlock, 0, st>>>(p->sum_pre[l], p->bi_pre[l], keep, p->keep_scale[l],
-                                                         p->ego[l], p->nrm[l], p->all, dt, off, N, dout);
+                                                         gen, p->ego[l], p->nrm[l], p->all, dt, off, N, dout);
     HIPREC_TRY(hipGetLastError());
     ego = p->ego[l];
     off += dout;
@@ -343,7 +338,8 @@ extern "C" int hiprec_ngcf_predict(const hiprec_ngcf_plan* plan, const int64_t* 
   if (n == 0) return 0;
   HIPREC_REQUIRE(users && items && scores && stats, "NULL pointer");
   ngcf_predict_kernel<<<grid_for_waves(n), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
-      plan->all, total_width(plan), plan->n_users, plan->n_items, users, items, n, scores, stats);
+      plan->e0, plan->dim[0], plan->all, total_width(plan), plan->n_users, plan->n_items, users, items, n, scores,
+      stats);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
@@ -367,7 +363,7 @@ extern "C" int hiprec_ngcf_grad(const hiprec_ngcf_plan* plan, const int64_t* use
   if (int rc = ngcf_forward(p, true, st)) return rc;
   if (!p->zero_ws) HIPREC_TRY(hipMemsetAsync(p->d_all, 0, sizeof(float) * N * dt, st));
   ngcf_loss_kernel<<<grid_for_waves(batch > 0 ? batch : 1), kBlock, 0, st>>>(
-      p->all, p->d_all, dt, p->n_users, p->n_items, users, pos, neg, batch, inv_batch,
+      p->e0, p->g_e0, p->dim[0], p->all, p->d_all, dt, p->n_users, p->n_items, users, pos, neg, batch, inv_batch,
       p->decay * p->inv_reg_batch, stats, static_cast<Scratch*>(scratch));
   HIPREC_TRY(hipGetLastError());
 
@@ -395,17 +391,19 @@ extern "C" int hiprec_ngcf_grad(const hiprec_ngcf_plan* plan, const int64_t* use
     g.p[4] = make_colsum(p->d_sum, n32, dout, dout, p->g_gc_b[l]);
     g.p[5] = make_colsum(p->d_bi, n32, dout, dout, p->g_bi_b[l]);
     if (int rc = launch_group(g, st)) return rc;
-    float* d_ego = p->d_ego[l & 1];
-    ngcf_bi_bwd_kernel<<<grid_for_threads(N * di), kBlock, 0, st>>>(p->d_bi_in, p->side[l], ego_in, d_ego,
-                                                                   p->d_side, N * di);
+    // hop 0 hands its result to the embedding gradient itself (which already holds the loss's share)
+    float* d_ego = l == 0 ? p->g_e0 : p->d_ego[l & 1];
+    if (l == 0)
+      ngcf_bi_bwd_kernel<true><<<grid_for_threads(N * di), kBlock, 0, st>>>(p->d_bi_in, p->side[l], ego_in, d_ego,
+                                                                           p->d_side, N * di);
+    else
+      ngcf_bi_bwd_kernel<false><<<grid_for_threads(N * di), kBlock, 0, st>>>(p->d_bi_in, p->side[l], ego_in, d_ego,
+                                                                            p->d_side, N * di);
     HIPREC_TRY(hipGetLastError());
     // d_ego += A^T d_side
     if (int rc = launch_spmm(&p->at, nullptr, 1.0f, p->d_side, p->spmm_tmp[l], d_ego, di, st, p->zero_ws != nullptr))
       return rc;
     d_next = d_ego;
   }
-  ngcf_e0_grad_kernel<<<grid_for_threads(N * p->dim[0]), kBlock, 0, st>>>(p->d_all, dt, d_next, p->g_e0, N,
-                                                                        p->dim[0]);
-  HIPREC_TRY(hipGetLastError());
   return 0;
 }

@@ -149,10 +149,13 @@ class NGCF(_FlatModel):
             k = None if keep is None else keep[i]
             p.keep[i] = None if k is None else k.data_ptr()
             p.keep_scale[i] = 1.0 if k is None else 1.0 / (1.0 - float(self.dropout_list[i]))
+            p.keep_prob[i] = 1.0 - float(self.dropout_list[i])
         p.all, p.d_all = ws["all"].data_ptr(), ws["d_all"].data_ptr()
         for field in ("d_sum", "d_bi", "d_side", "d_bi_in"):
             setattr(p, field, ws[field].data_ptr())
         p.zero_ws, p.zero_ws_floats = ws["zero_ws"].data_ptr(), ws["zero_ws"].numel()
+        p.keep_gen = 1 if (keep is not None and self.dropout_rng == "device") else 0
+        p.keep_seed, p.keep_step = self.dropout_seed, self._step
         p.d_ego[0], p.d_ego[1] = ws["d_ego0"].data_ptr(), ws["d_ego1"].data_ptr()
         return p
 
@@ -175,9 +178,7 @@ class NGCF(_FlatModel):
                 mask = torch.empty(N, self.layer_size[i + 1]).bernoulli_(1 - p)
                 buf.copy_(mask.to(torch.uint8), non_blocking=False)
             elif self.dropout_rng == "device":
-                _lib.check(lib.hiprec_edge_dropout_mask(
-                    _lib.ptr(buf), buf.numel(), 1.0 - p, self.dropout_seed * 64 + i, self._step,
-                    _lib.stream_ptr(self._flat.device)))
+                pass                          # drawn inside the forward (hiprec_ngcf_plan.keep_gen)
             else:
                 raise ValueError(f"unknown dropout_rng {self.dropout_rng!r}: 'torch_cpu' or 'device'")
             out.append(buf)
@@ -198,7 +199,9 @@ class NGCF(_FlatModel):
         plan = self.plan(keep=keep)
         _lib.check(lib.hiprec_ngcf_forward(ctypes.byref(plan), 1 if keep is not None else 0,
                                            _lib.stream_ptr(self._flat.device)))
-        return torch.split(self._ws["all"].clone(), [self.n_users, self.n_items], dim=0)
+        N, d0 = self.n_users + self.n_items, self.emb_dim
+        e0 = self._flat[: N * d0].view(N, d0)      # hop 0's slice of the concatenation is the tables themselves
+        return torch.split(torch.cat([e0, self._ws["all"][:, d0:]], dim=1), [self.n_users, self.n_items], dim=0)
 
     def predict(self, users, items):
         """ngcf.py:82-100: a full forward (dropout follows ``self.training`` exactly like the reference,

@@ -619,11 +619,17 @@ typedef struct hiprec_ngcf_plan {
   float* bi_pre[HIPREC_NGCF_MAX_LAYERS];     /* [N, dim[l+1]] Bi_l(bi_in) */
   float* ego[HIPREC_NGCF_MAX_LAYERS];        /* [N, dim[l+1]] ego_{l+1} (after dropout, before normalize) */
   float* nrm[HIPREC_NGCF_MAX_LAYERS];        /* [N] row norms of ego_{l+1} */
-  float* all;                                /* [N, sum dim] */
+  float* all;                                /* [N, sum dim]; columns < dim[0] are NOT filled: hop 0's slice is e0 */
   /* message dropout (ngcf.py:70): one keep byte per element of ego_{l+1}, or NULL for none; kept
    * entries are scaled by keep_scale[l] = 1 / (1 - p) */
-  const uint8_t* keep[HIPREC_NGCF_MAX_LAYERS];
+  uint8_t* keep[HIPREC_NGCF_MAX_LAYERS];
   float keep_scale[HIPREC_NGCF_MAX_LAYERS];
+  /* keep_gen != 0: the forward DRAWS the keep bytes of every hop with keep[l] != NULL itself (byte =
+   * uniform(keep_seed * 64 + l, keep_step, element) < keep_prob[l], the generator of
+   * hiprec_edge_dropout_mask) and stores them in keep[l] for the backward; 0: keep[l] is an input. */
+  float keep_prob[HIPREC_NGCF_MAX_LAYERS];
+  uint64_t keep_seed, keep_step;
+  int32_t keep_gen, _pad;
   /* backward workspace, each [N, max dim] unless noted */
   float* d_all;                              /* [N, sum dim] */
   float* d_sum;
@@ -641,7 +647,7 @@ typedef struct hiprec_ngcf_plan {
 
 size_t hiprec_ngcf_plan_bytes(void);
 
-/* ---- NGCF.forward (ngcf.py:48-80): fills plan->all (and the per-hop workspaces).  train != 0 applies
+/* ---- NGCF.forward (ngcf.py:48-80): fills columns >= dim[0] of plan->all (and the per-hop workspaces).  train != 0 applies
  * the keep bytes of the plan, 0 is eval mode. */
 int hiprec_ngcf_forward(const hiprec_ngcf_plan* plan, int train, void* stream);
 
