@@ -163,7 +163,7 @@ class NGCF(_FlatModel):
         """Per hop the keep bytes of one training forward (None for a hop without dropout / in eval)."""
         if not self.training:
             return None
-        lib = self._require_hip()
+        self._require_hip()
         ws = self.workspace()
         N = self.n_users + self.n_items
         self._step += 1

@@ -2,14 +2,13 @@
 backward, the gradient-norm clip and the full step vs golden vectors from the real reference's
 PairwiseGMFEngine, and vs the numpy oracle at the ML-1M shape."""
 import contextlib
-import ctypes
 import io
 
 import numpy as np
 import pytest
 import torch
 
-from helpers import REL, assert_scalar_close, assert_step_close, assert_tensor_close, load_golden
+from helpers import assert_scalar_close, assert_step_close, assert_tensor_close, load_golden
 from oracle import pgmf_numpy as onp
 from test_oracle_golden_pgmf import CASES, KEYS, pgmf_band, pgmf_opt_state, pgmf_params
 

@@ -1,5 +1,5 @@
 """Experiment: how much of the BPR grad kernel's time is atomic contention on popular items?"""
-import ctypes, sys, os, contextlib, io
+import ctypes, sys, os
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
