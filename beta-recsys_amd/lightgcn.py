@@ -165,8 +165,9 @@ class LightGCN(_FlatModel):
         self.eval()
         lib = self._require_hip()
         dev = self._flat.device
-        users_t = torch.as_tensor(np.asarray(users), dtype=torch.int64).to(dev).reshape(-1).contiguous()
-        items_t = torch.as_tensor(np.asarray(items), dtype=torch.int64).to(dev).reshape(-1).contiguous()
+        users_t, items_t = (x.to(dev, torch.int64).reshape(-1).contiguous() if torch.is_tensor(x) else
+                            torch.as_tensor(np.asarray(x), dtype=torch.int64).to(dev).reshape(-1).contiguous()
+                            for x in (users, items))
         if self._stats is None or self._stats.device != dev:
             self._stats = _new_stats(dev)
         plan = self.plan()

@@ -125,8 +125,9 @@ class Triple2vec(_FlatModel):
         """triple2vec.py:94-104."""
         lib = self._require_hip()
         dev = self._flat.device
-        users_t = torch.as_tensor(np.asarray(users), dtype=torch.int64).to(dev).reshape(-1).contiguous()
-        items_t = torch.as_tensor(np.asarray(items), dtype=torch.int64).to(dev).reshape(-1).contiguous()
+        users_t, items_t = (x.to(dev, torch.int64).reshape(-1).contiguous() if torch.is_tensor(x) else
+                            torch.as_tensor(np.asarray(x), dtype=torch.int64).to(dev).reshape(-1).contiguous()
+                            for x in (users, items))
         if users_t.numel() != items_t.numel():
             raise ValueError("users and items differ in length")
         stats = self._device_stats()
