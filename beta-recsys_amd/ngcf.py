@@ -25,7 +25,7 @@ from . import _lib
 from .lightgcn import _csr_from_coo, _slice_rows
 from .mf import _new_stats, raise_on_status, read_stats
 from .ncf import _FlatModel, _init_linear_like_torch, _ParamView
-from .torch_engine import ModelEngine
+from .flat_engine import FlatModelEngine
 
 
 class NGCF(_FlatModel):
@@ -228,7 +228,7 @@ class NGCF(_FlatModel):
         return scores
 
 
-class NGCFEngine(ModelEngine):
+class NGCFEngine(FlatModelEngine):
     """models/ngcf.py:103-199."""
 
     def __init__(self, config):
@@ -240,19 +240,6 @@ class NGCFEngine(ModelEngine):
         self.model = NGCF(config["model"], self.norm_adj)
         super(NGCFEngine, self).__init__(config)
         self.model.to(self.device)
-        self._ready = False
-
-    def _setup(self):
-        lib = self.require_hip()
-        flat = self.model.flat
-        if self._ready and self._g_flat.device == flat.device:
-            return lib
-        self._g_flat = torch.zeros_like(flat)
-        self.optimizer.allocate_state(flat)
-        self._scratch = torch.zeros(lib.hiprec_scratch_bytes(0), dtype=torch.uint8, device=flat.device)
-        self._stats = _new_stats(flat.device, self.optimizer.beta1 or 0.9, self.optimizer.beta2 or 0.999)
-        self._ready = True
-        return lib
 
     def _enqueue_grad(self, batch_data):
         lib = self._setup()
@@ -269,54 +256,6 @@ class NGCFEngine(ModelEngine):
         _lib.check(lib.hiprec_ngcf_grad(ctypes.byref(plan), _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), B,
                                         1.0 / B, _lib.ptr(self._stats), _lib.ptr(self._scratch),
                                         self._scratch.numel(), _lib.stream_ptr(dev)))
-
-    def _enqueue_step(self, batch_data):
-        self._enqueue_grad(batch_data)
-        lib, m, opt = _lib.load(), self.model, self.optimizer
-        _lib.check(lib.hiprec_opt_dense_step(
-            opt.kind, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),
-            _lib.ptr(opt.exp_avg_sq), m.flat.numel(), opt.lr, opt.beta1, opt.beta2, opt.eps,
-            _lib.ptr(self._stats), _lib.ptr(self._scratch), -1, _lib.stream_ptr(m.flat.device)))
-
-    def _sync_stats(self):
-        st = read_stats(self._stats)
-        if st.status:
-            raw = self._stats.cpu()
-            off = _lib.Stats.status.offset
-            raw[off:off + 4] = 0
-            self._stats.copy_(raw)
-            self._g_flat.zero_()
-            raise_on_status(st.status)
-        return st
-
-    def backward_only(self, batch_data):
-        """zero_grad + forward + loss + backward without the optimizer step: ``(loss, grads)``."""
-        self._enqueue_grad(batch_data)
-        lib = _lib.load()
-        _lib.check(lib.hiprec_finalize_stats(_lib.ptr(self._stats), _lib.ptr(self._scratch), None, None,
-                                             _lib.stream_ptr(self.model.flat.device)))
-        st = self._sync_stats()
-        grads = {k: v.clone() for k, v in self.model.views(self._g_flat).items()}
-        self._g_flat.zero_()
-        return st.loss, grads
-
-    def load_optimizer_state(self, step, exp_avg=None, exp_avg_sq=None):
-        """Resume from a reference optimizer state (per-parameter dicts keyed like state_dict)."""
-        lib = self._setup()
-        opt, m = self.optimizer, self.model
-        dev = m.flat.device
-        _lib.check(lib.hiprec_stats_reset(_lib.ptr(self._stats), opt.beta1 or 0.9, opt.beta2 or 0.999,
-                                          _lib.stream_ptr(dev)))
-        for _ in range(int(step)):
-            _lib.check(lib.hiprec_stats_advance_step(_lib.ptr(self._stats), _lib.stream_ptr(dev)))
-        for buf, src in ((opt.exp_avg, exp_avg), (opt.exp_avg_sq, exp_avg_sq)):
-            if buf is None:
-                continue
-            if src is None:
-                buf.zero_()
-                continue
-            for name, view in m.views(buf).items():
-                view.copy_(torch.as_tensor(src[name], dtype=torch.float32).reshape(view.shape))
 
     def train_single_batch(self, batch_data):
         """ngcf.py:118-149: one step, returns ``(batch_loss.item(), batch_reg_loss)`` — the second is the

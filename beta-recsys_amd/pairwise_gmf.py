@@ -22,7 +22,8 @@ import torch.nn as nn
 from . import _lib
 from .mf import _new_stats, raise_on_status, read_stats
 from .ncf import _FlatModel, _ParamView
-from .torch_engine import HipOptimizer, ModelEngine
+from .flat_engine import FlatModelEngine
+from .torch_engine import HipOptimizer
 
 
 def truncated_normal_(tensor, mean=0, std=1):
@@ -96,7 +97,7 @@ class PairwiseGMF(_FlatModel):
         """pairwise_gmf.py:64-66: a stub in the reference as well."""
 
 
-class PairwiseGMFEngine(ModelEngine):
+class PairwiseGMFEngine(FlatModelEngine):
     """models/pairwise_gmf.py:69-158."""
 
     def __init__(self, config):
@@ -108,27 +109,15 @@ class PairwiseGMFEngine(ModelEngine):
         # config["model"]["optimizer"] names one of sgd/adam/rmsprop (torch_engine.py:23-39)
         self.optimizer = HipOptimizer("adam", config["lr"])
         super(PairwiseGMFEngine, self).__init__(config)
-        self._ready = False
 
     def set_optimizer(self):
         name = self.config["model"]["optimizer"] if "optimizer" in self.config["model"] else None
         if name in _lib.OPT_KINDS:
             self.optimizer = HipOptimizer(name, self.config["model"]["lr"])
 
-    def _setup(self):
-        lib = self.require_hip()
-        flat = self.model.flat
-        if self._ready and self._g_flat.device == flat.device:
-            return lib
-        dev = flat.device
-        self._g_flat = torch.zeros_like(flat)
-        self.optimizer.allocate_state(flat)
-        self._scratch = torch.zeros(lib.hiprec_scratch_bytes(0), dtype=torch.uint8, device=dev)
+    def _alloc_extra(self, lib, dev):
         self._ws = torch.zeros(lib.hiprec_pgmf_workspace_bytes(self.model.emb_dim), dtype=torch.uint8, device=dev)
         self._clip_ws = torch.zeros(lib.hiprec_clip_workspace_bytes() // 8, dtype=torch.float64, device=dev)
-        self._stats = _new_stats(dev, self.optimizer.beta1 or 0.9, self.optimizer.beta2 or 0.999)
-        self._ready = True
-        return lib
 
     def _indices(self, batch_data):
         """pairwise_gmf.py:94-103: ``LongTensor(np.array(x, dtype=np.int32))``; tensors that are
@@ -162,53 +151,12 @@ class PairwiseGMFEngine(ModelEngine):
                 _lib.ptr(self._g_flat), self._g_flat.numel(), float(self.config["grad_clip"]),
                 _lib.ptr(self._clip_ws), self._clip_ws.numel() * 8, st))
 
-    def _enqueue_step(self, batch_data):
-        self._enqueue_grad(batch_data)
-        lib, m, opt = _lib.load(), self.model, self.optimizer
-        _lib.check(lib.hiprec_opt_dense_step(
-            opt.kind, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),
-            _lib.ptr(opt.exp_avg_sq), m.flat.numel(), opt.lr, opt.beta1, opt.beta2, opt.eps,
-            _lib.ptr(self._stats), _lib.ptr(self._scratch), -1, _lib.stream_ptr(m.flat.device)))
-
-    def _sync_stats(self):
-        st = read_stats(self._stats)
-        if st.status:
-            raw = self._stats.cpu()
-            off = _lib.Stats.status.offset
-            raw[off:off + 4] = 0
-            self._stats.copy_(raw)
-            raise_on_status(st.status)
-        return st
-
     def backward_only(self, batch_data, clip=True):
         """zero_grad + forward + loss + backward (+ clip) without the optimizer step:
         ``(loss, grads, total_norm)``; ``total_norm`` is None when ``clip`` is False."""
         self._enqueue_grad(batch_data, clip)
-        lib = _lib.load()
-        _lib.check(lib.hiprec_finalize_stats(_lib.ptr(self._stats), _lib.ptr(self._scratch), None, None,
-                                             _lib.stream_ptr(self.model.flat.device)))
-        st = self._sync_stats()
-        grads = {k: v.clone() for k, v in self.model.views(self._g_flat).items()}
-        self._g_flat.zero_()
+        st, grads = self._finish_backward_only()
         return st.loss, grads, (float(self._clip_ws[0]) if clip else None)
-
-    def load_optimizer_state(self, step, exp_avg=None, exp_avg_sq=None):
-        """Resume from a reference optimizer state (per-parameter dicts keyed like state_dict)."""
-        lib = self._setup()
-        opt, m = self.optimizer, self.model
-        dev = m.flat.device
-        _lib.check(lib.hiprec_stats_reset(_lib.ptr(self._stats), opt.beta1 or 0.9, opt.beta2 or 0.999,
-                                          _lib.stream_ptr(dev)))
-        for _ in range(int(step)):
-            _lib.check(lib.hiprec_stats_advance_step(_lib.ptr(self._stats), _lib.stream_ptr(dev)))
-        for buf, src in ((opt.exp_avg, exp_avg), (opt.exp_avg_sq, exp_avg_sq)):
-            if buf is None:
-                continue
-            if src is None:
-                buf.zero_()
-                continue
-            for name, view in m.views(buf).items():
-                view.copy_(torch.as_tensor(src[name], dtype=torch.float32).reshape(view.shape))
 
     def train_single_batch(self, batch_data):
         """pairwise_gmf.py:82-116: one step, returns ``batch_loss.item()``."""
