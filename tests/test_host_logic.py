@@ -248,6 +248,12 @@ def test_compat_install_routes_reference_imports(tmp_path, monkeypatch):
     (root / "beta_rec" / "recommenders" / "__init__.py").write_text("")
     (root / "beta_rec" / "recommenders" / "matrix_factorization.py").write_text(
         "from ..models.mf import MFEngine\nfrom beta_rec.models.torch_engine import ModelEngine\n")
+    # the other call sites the mirrors serve: recommenders/ngcf.py:11, recommenders/triple2vec.py:9,
+    # examples/train_cmn.py:13, models/cmn.py:7 (truncated_normal_)
+    (root / "beta_rec" / "recommenders" / "siblings.py").write_text(
+        "from ..models.ngcf import NGCFEngine\nfrom ..models.triple2vec import Triple2vecEngine\n"
+        "from beta_rec.models.pairwise_gmf import PairwiseGMFEngine, truncated_normal_\n"
+        "from ..models.lightgcn import LightGCNEngine\nfrom ..models.ncf import NeuMFEngine\n")
     monkeypatch.syspath_prepend(str(root))
     saved = {k: v for k, v in sys.modules.items() if k == "beta_rec" or k.startswith("beta_rec.")}
     for k in saved:
@@ -256,6 +262,10 @@ def test_compat_install_routes_reference_imports(tmp_path, monkeypatch):
         assert compat.install()[:2] == ["beta_rec.models.torch_engine", "beta_rec.models.mf"]
         m = importlib.import_module("beta_rec.recommenders.matrix_factorization")
         assert m.MFEngine is hp.MFEngine and m.ModelEngine is hp.ModelEngine
+        sib = importlib.import_module("beta_rec.recommenders.siblings")
+        assert sib.NGCFEngine is hp.NGCFEngine and sib.Triple2vecEngine is hp.Triple2vecEngine
+        assert sib.PairwiseGMFEngine is hp.PairwiseGMFEngine and callable(sib.truncated_normal_)
+        assert sib.LightGCNEngine is hp.LightGCNEngine and sib.NeuMFEngine is hp.NeuMFEngine
     finally:
         compat.uninstall()
         for k in [k for k in sys.modules if k.startswith("beta_rec.") or k == "beta_rec"]:
