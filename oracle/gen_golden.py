@@ -245,7 +245,7 @@ def main():
     epoch_fixture(MFEngine, PairwiseNegativeDataset, "mf_epoch_sgd", "sgd", seed=22)
 
 
-if __name__ == "__main__" and not {"--ncf", "--lightgcn", "--eval", "--sampler", "--c1", "--pgmf", "--t2v", "--ngcf"} & set(sys.argv):
+if __name__ == "__main__" and not {"--ncf", "--lightgcn", "--eval", "--sampler", "--c1", "--pgmf", "--t2v", "--ngcf", "--ncf-dropout"} & set(sys.argv):
     main()
 
 
@@ -827,3 +827,71 @@ if __name__ == "__main__" and "--ngcf" in sys.argv:
                  scale=3.0)
     ngcf_fixture("ngcf_sgd_widths", 33, 29, 24, [32, 8], 16, 250, "sgd", 0.5, [0.0, 0.3], [16, 16], 52, scale=3.0)
     ngcf_fixture("ngcf_rmsprop_d64", 50, 45, 64, [64, 64, 64], 32, 400, "rmsprop", 0.001, [0.0, 0.0, 0.0], [32], 53)
+
+
+def ncf_dropout_fixture(engine_cls, name, kind, U, I, E, L, B, optimizer, lr, dropout, n_steps, seed):
+    """NeuMF / MLP with dropout > 0 in the tower (ncf.py:42-45, mlp.py:30-33: Dropout in front of every
+    Linear).  The masks of every step are captured with forward hooks AND re-drawn from the same torch
+    seed — one bernoulli_(1 - p) of the layer input's shape per Dropout, in layer order — to pin that
+    replay recipe (nn.Dropout's own CPU draws)."""
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    cfg = ncf_config(U, I, E, L, optimizer, lr, B)
+    cfg["model"]["dropout"] = dropout
+    eng = quiet(engine_cls, cfg)
+    out = {"meta": np.array([U, I, E, L, B, n_steps, seed], dtype=np.int64), "kind": np.array(kind),
+           "optimizer": np.array(optimizer), "lr": np.array(lr), "dropout": np.array(dropout)}
+    out.update(state_np(eng.model, "w0"))
+    grads_seen, captured = [], []
+    orig_step = eng.optimizer.step
+
+    def capturing_step(*a, **k):
+        grads_seen.append({n: p.grad.detach().numpy().copy() for n, p in eng.model.named_parameters()})
+        return orig_step(*a, **k)
+
+    eng.optimizer.step = capturing_step
+    drops = [m for m in eng.model.fc_layers if isinstance(m, torch.nn.Dropout)]
+    for l, mod in enumerate(drops):
+        mod.register_forward_hook(lambda _m, inp, outp, l=l: captured.append((l, inp[0].detach().clone(),
+                                                                             outp.detach().clone())))
+    users = rng.integers(0, U, size=(n_steps, B))
+    items = np.stack([zipf_items(rng, B, I) for _ in range(n_steps)])
+    ratings = (rng.random((n_steps, B)) < 0.25).astype(np.float32)
+    losses = []
+    eng.model.train()
+    for s in range(n_steps):
+        captured.clear()
+        torch.manual_seed(3000 + s)
+        losses.append(eng.train_single_batch(torch.from_numpy(users[s]), torch.from_numpy(items[s]),
+                                             torch.from_numpy(ratings[s])))
+        assert [c[0] for c in captured] == list(range(len(drops)))
+        torch.manual_seed(3000 + s)
+        for l, x_in, x_out in captured:
+            keep = torch.empty_like(x_in).bernoulli_(1 - dropout).bool().numpy()
+            ref_keep = ((x_out != 0) | (x_in == 0)).numpy()
+            assert np.array_equal(keep | (x_in.numpy() == 0), ref_keep), "mask recipe does not replay"
+            out[f"mask{s}/{l}"] = np.packbits(keep, axis=1)
+        out.update(state_np(eng.model, f"w{s + 1}"))
+        for k, v in grads_seen[-1].items():
+            out[f"g{s + 1}/{k}"] = v
+        for pname, p in eng.model.named_parameters():
+            pst = eng.optimizer.state.get(p, {})
+            for sk, tag in (("exp_avg", "m"), ("exp_avg_sq", "v"), ("square_avg", "v")):
+                if sk in pst:
+                    out[f"{tag}{s + 1}/{pname}"] = pst[sk].detach().numpy().copy()
+    out.update(users=users, items=items, ratings=ratings, losses=np.array(losses, dtype=np.float64))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: losses {losses}")
+
+
+def main_ncf_dropout():
+    import_reference()
+    from beta_rec.models.mlp import MLPEngine
+    from beta_rec.models.ncf import NeuMFEngine
+
+    ncf_dropout_fixture(NeuMFEngine, "ncf_neumf_dropout", "neumf", 47, 39, 8, 3, 33, "adam", 1e-3, 0.3, 2, seed=36)
+    ncf_dropout_fixture(MLPEngine, "ncf_mlp_dropout", "mlp", 47, 39, 8, 2, 33, "sgd", 0.05, 0.5, 2, seed=37)
+
+
+if __name__ == "__main__" and "--ncf-dropout" in sys.argv:
+    main_ncf_dropout()

@@ -1,7 +1,8 @@
 """ORACLE (test infrastructure — never imported by the product path).
 
-numpy fp32 restatement of the beta-recsys NCF family training step (NeuMF, GMF, MLP) with
-dropout 0.  Each function cites the reference lines (relative to /root/reference/beta_rec/).
+numpy fp32 restatement of the beta-recsys NCF family training step (NeuMF, GMF, MLP); tower dropout
+through explicit keep masks (``masks``: one boolean [B, width] array per Linear's input, kept entries
+scaled by 1 / (1 - p); None = dropout 0 or eval mode).  Each function cites the reference lines (relative to /root/reference/beta_rec/).
 Pinned against golden vectors captured from the real reference (oracle/gen_golden.py ->
 tests/golden/ncf_*.npz, gmf_*.npz, mlp_*.npz; checked by tests/test_oracle_golden_ncf.py).
 
@@ -33,36 +34,44 @@ def bce(y, r):
     return loss, gy
 
 
-def tower_forward(w, x, relu_input):
+def tower_forward(w, x, relu_input, masks=None, dropout=0.0):
     """The fc_layers loop.  NeuMF (models/ncf.py:64-66) applies an extra ReLU after EVERY entry of
     fc_layers, the Dropout entries included (quirk Q7), so the raw concatenated embedding is
-    ReLU-ed before the first Linear (relu_input=True).  MLP (models/mlp.py:47-48) applies the
-    entries only.  Dropout has p = 0 and is the identity."""
+    ReLU-ed before the first Linear (relu_input=True; ReLU and the non-negative dropout scaling
+    commute).  MLP (models/mlp.py:47-48) applies the entries only.  Every Linear's input goes through
+    its Dropout entry first (ncf.py:42-45): ``acts`` holds what the Linear actually saw."""
     acts = []
     h = np.maximum(x, F32(0)) if relu_input else x
-    for li in layer_keys(w):
+    for l, li in enumerate(layer_keys(w)):
+        if masks is not None and masks[l] is not None:
+            h = (h * (masks[l].astype(F32) / F32(1.0 - dropout))).astype(F32)
         acts.append(h)
         z = (h @ w[f"fc_layers.{li}.weight"].T + w[f"fc_layers.{li}.bias"]).astype(F32)
         h = np.maximum(z, F32(0))
     return h, acts
 
 
-def tower_backward(w, g, acts, h_out, dh, x, relu_input):
+def tower_backward(w, g, acts, h_out, dh, x, relu_input, masks=None, dropout=0.0):
     """Backward through the tower; returns d loss / d x (the concatenated embedding)."""
     keys = layer_keys(w)
     out = h_out
-    for li, h_in in zip(reversed(keys), reversed(acts)):
+    for l in range(len(keys) - 1, -1, -1):
+        li, h_in = keys[l], acts[l]
         dz = (dh * (out > 0)).astype(F32)
         g[f"fc_layers.{li}.weight"] += (dz.T @ h_in).astype(F32)
         g[f"fc_layers.{li}.bias"] += dz.sum(axis=0, dtype=F32)
         dh = (dz @ w[f"fc_layers.{li}.weight"]).astype(F32)
+        if masks is not None and masks[l] is not None:
+            dh = (dh * (masks[l].astype(F32) / F32(1.0 - dropout))).astype(F32)
+        # the previous layer's ReLU output is h_in before its dropout; a dropped entry has dh = 0 already,
+        # a kept one is > 0 exactly when the undropped activation was
         out = h_in
     if relu_input:
         dh = (dh * (x > 0)).astype(F32)
     return dh
 
 
-def ncf_grads(w, users, items, ratings, kind="neumf"):
+def ncf_grads(w, users, items, ratings, kind="neumf", masks=None, dropout=0.0):
     """zero_grad + forward + BCELoss + backward of {NeuMF,GMF,MLP}Engine.train_single_batch
     (models/ncf.py:100-120, models/gmf.py:60-80, models/mlp.py:76-96).  Returns (loss, grads)."""
     users = np.asarray(users, dtype=np.int64)
@@ -73,7 +82,7 @@ def ncf_grads(w, users, items, ratings, kind="neumf"):
         um, im = w["embedding_user_mlp.weight"][users], w["embedding_item_mlp.weight"][items]
         ug, ig = w["embedding_user_mf.weight"][users], w["embedding_item_mf.weight"][items]
         x = np.concatenate([um, im], axis=1)                       # ncf.py:59-61
-        h, acts = tower_forward(w, x, relu_input=True)              # ncf.py:64-66
+        h, acts = tower_forward(w, x, True, masks, dropout)         # ncf.py:64-66
         mf = (ug * ig).astype(F32)                                  # ncf.py:62
         vec = np.concatenate([h, mf], axis=1)                       # ncf.py:68
     elif kind == "gmf":
@@ -82,7 +91,7 @@ def ncf_grads(w, users, items, ratings, kind="neumf"):
     elif kind == "mlp":
         um, im = w["embedding_user.weight"][users], w["embedding_item.weight"][items]
         x = np.concatenate([um, im], axis=1)                        # mlp.py:44-46
-        h, acts = tower_forward(w, x, relu_input=False)             # mlp.py:47-48
+        h, acts = tower_forward(w, x, False, masks, dropout)        # mlp.py:47-48
         vec = h
     else:
         raise ValueError(kind)
@@ -107,7 +116,7 @@ def ncf_grads(w, users, items, ratings, kind="neumf"):
         np.add.at(g[ku], users, dmf * ig)
         np.add.at(g[ki], items, dmf * ug)
     if dh is not None:
-        dx = tower_backward(w, g, acts, h, dh, x, relu_input=(kind == "neumf"))
+        dx = tower_backward(w, g, acts, h, dh, x, kind == "neumf", masks, dropout)
         Dm = um.shape[1]
         ku = "embedding_user_mlp.weight" if kind == "neumf" else "embedding_user.weight"
         ki = "embedding_item_mlp.weight" if kind == "neumf" else "embedding_item.weight"

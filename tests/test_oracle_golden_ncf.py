@@ -57,3 +57,39 @@ def test_neumf_init_quirk_q8_is_in_the_fixture():
     assert 0.8 < g["w0/embedding_item_mlp.weight"].std() < 1.2
     assert g["w0/embedding_user_mlp.weight"].std() < 0.02
     assert g["w0/embedding_item_mf.weight"].std() < 0.02
+
+
+def dropout_masks(g, s, w):
+    """Keep masks of step s: one [B, in_features] boolean array per Linear of the tower."""
+    B = int(g["meta"][4])
+    out = []
+    for l, li in enumerate(onc.layer_keys(w)):
+        width = w[f"fc_layers.{li}.weight"].shape[1]
+        out.append(np.unpackbits(g[f"mask{s}/{l}"], axis=1)[:, :width].astype(bool).reshape(B, width))
+    return out
+
+
+@pytest.mark.parametrize("case", ["ncf_neumf_dropout", "ncf_mlp_dropout"])
+def test_ncf_oracle_with_tower_dropout_matches_reference(case):
+    """Dropout > 0 in front of every Linear (ncf.py:42-45, mlp.py:30-33), masks captured from the
+    reference's nn.Dropout modules (and shown by the generator to replay from the torch seed)."""
+    g = load_golden(case)
+    n_steps, p = int(g["meta"][5]), float(g["dropout"])
+    kind, opt, lr = str(g["kind"]), str(g["optimizer"]), float(g["lr"])
+    for s in range(n_steps):
+        w = params(g, f"w{s}")
+        st = opt_state(g, s, opt, w)
+        masks = dropout_masks(g, s, w)
+        assert all(abs(m.mean() - (1 - p)) < 0.1 for m in masks)
+        loss, grads, _ = onc.ncf_grads(w, g["users"][s], g["items"][s], g["ratings"][s], kind, masks, p)
+        assert_scalar_close(loss, g["losses"][s], what=f"loss step {s}")
+        nodrop, _, _ = onc.ncf_grads(w, g["users"][s], g["items"][s], g["ratings"][s], kind)
+        assert abs(nodrop - loss) > 1e-4, "the fixture is meant to exercise the masks"
+        g_ref = params(g, f"g{s + 1}")
+        for k in g_ref:
+            floor = 0.05 if k.endswith("bias") else 0.0
+            assert_tensor_close(grads[k], g_ref[k], 2e-5, f"grad {k} step {s}", scale_floor=floor)
+        if opt == "sgd":
+            onc.opt_step(w, grads, st, opt, lr)
+            for k in w:
+                assert_tensor_close(w[k], g[f"w{s + 1}/{k}"], 1e-6, f"weights {k} step {s}")
