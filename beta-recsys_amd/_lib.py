@@ -69,7 +69,8 @@ class NcfPlan(Structure):
            ("out_w", c_void_p), ("out_b", c_void_p), ("g_out_w", c_void_p), ("g_out_b", c_void_p),
            ("max_batch", c_int64),
            ("act", c_void_p * (NCF_MAX_LAYERS + 1)), ("dact", c_void_p * (NCF_MAX_LAYERS + 1)),
-           ("mf", c_void_p), ("dmf", c_void_p), ("scores", c_void_p)]
+           ("mf", c_void_p), ("dmf", c_void_p), ("scores", c_void_p),
+           ("keep", c_void_p * NCF_MAX_LAYERS), ("keep_scale", c_float), ("_pad", c_int32)]
     )
 
 

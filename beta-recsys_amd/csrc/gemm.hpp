@@ -10,7 +10,8 @@ namespace hiprec {
 //   kNT : A is [M,K] (lda), B is [N,K] (ldb)          C = A B^T      (forward: H W^T)
 //   kNN : A is [M,K] (lda), B is [K,N] (ldb)          C = A B        (dgrad:   dZ W)
 //   kTNm: A is [K,M] (lda), B is [K,N] (ldb)          C = A^T B      (wgrad:   dZ^T H)
-//   epilogue: + bias[n] (if bias) ; relu (if relu) ; * [mask[m,n] > 0] (if mask)
+//   epilogue: + bias[n] (if bias) ; relu (if relu) ; * [mask[m,n] > 0] (if mask) ; dropout keep bytes (if
+//   keep; make_gemm leaves it NULL, callers set keep / ldk / keep_scale on the returned problem)
 // mode kColsum: C[n] += sum_m A[m, n] over the block's kColsumRows rows (bias gradients).
 enum GemmMode { kNT = 0, kNN = 1, kTNm = 2, kColsum = 3 };
 
@@ -26,6 +27,10 @@ struct GemmProblem {
   int relu;
   const float* mask;
   int ldm;
+  // dropout epilogue (after bias / relu / mask): C = keep[m, n] ? C * keep_scale : 0.  NULL = none.
+  const uint8_t* keep;
+  int ldk;
+  float keep_scale;
   int tiles_n, tiles_m, split;  // block decomposition of this problem
   int first_block;              // its first block in the grouped grid
 };

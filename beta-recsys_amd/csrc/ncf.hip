@@ -128,6 +128,7 @@ __device__ __forceinline__ void gemm_tile(float (*As)[kTK + 1], float (*Bs)[kTN 
       if (bias) v += bias[gn];
       if (q.relu) v = fmaxf(v, 0.f);
       if (mask) v = mask[static_cast<int64_t>(gm) * ldm + gn] > 0.f ? v : 0.f;
+      if (q.keep) v = q.keep[static_cast<int64_t>(gm) * q.ldk + gn] ? v * q.keep_scale : 0.f;
       if (q.split > 1) {
         if (v != 0.f) atomic_add_f32(C + static_cast<int64_t>(gm) * ldc + gn, v);
       } else {
@@ -277,6 +278,11 @@ __global__ __launch_bounds__(kBlock) void ncf_gather_kernel(hiprec_ncf_plan p,
         float a = ok ? p.user_mlp[u * Dm + c] : 0.f;
         float d = ok ? p.item_mlp[i * Dm + c] : 0.f;
         if (p.relu_input) { a = fmaxf(a, 0.f); d = fmaxf(d, 0.f); }
+        if (p.keep[0]) {  // the Dropout in front of the first Linear (ncf.py:42-45, mlp.py:30-33)
+          const uint8_t* k0 = p.keep[0] + b * (2 * Dm);
+          a = k0[c] ? a * p.keep_scale : 0.f;
+          d = k0[Dm + c] ? d * p.keep_scale : 0.f;
+        }
         h0[c] = a;
         h0[Dm + c] = d;
       }
@@ -455,6 +461,7 @@ static bool fusable(const hiprec_ncf_plan* p) {
   for (int l = 0; l < p->n_layers; ++l) {
     if (p->layer_out[l] > kFMaxN || p->layer_out[l] % 32) return false;
     if (p->layer_in[l] % kTK) return false;
+    if (p->keep[l]) return false;  // tower dropout runs through the launch-per-layer path
   }
   return true;
 }
@@ -816,10 +823,17 @@ static int forward(const hiprec_ncf_plan* p, const int64_t* users, const int64_t
   HIPREC_TRY(hipGetLastError());
   if (p->dim_mlp > 0) {
     for (int l = 0; l < p->n_layers; ++l) {
-      if (int rc = launch_gemm(kNT, static_cast<int>(batch), p->layer_out[l], p->layer_in[l],
-                               p->act[l], p->layer_in[l], p->fc_w[l], p->layer_in[l], p->act[l + 1],
-                               p->layer_out[l], p->fc_b[l], /*relu=*/1, nullptr, 0, st))
-        return rc;
+      GemmGroup g{};
+      g.n = 1;
+      g.p[0] = make_gemm(kNT, static_cast<int>(batch), p->layer_out[l], p->layer_in[l], p->act[l],
+                         p->layer_in[l], p->fc_w[l], p->layer_in[l], p->act[l + 1], p->layer_out[l], p->fc_b[l],
+                         /*relu=*/1, nullptr, 0, false);
+      if (l + 1 < p->n_layers && p->keep[l + 1]) {  // act[l+1] is stored AFTER the next Linear's Dropout
+        g.p[0].keep = p->keep[l + 1];
+        g.p[0].ldk = p->layer_out[l];
+        g.p[0].keep_scale = p->keep_scale;
+      }
+      if (int rc = launch_group(g, st)) return rc;
     }
   }
   return 0;
@@ -894,6 +908,11 @@ extern "C" int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users
       g.n = 3;
       g.p[0] = make_gemm(kNN, B, nin, nout, p->dact[l + 1], nout, p->fc_w[l], nin, p->dact[l], nin, nullptr,
                          0, mask, nin, false);
+      if (p->keep[l]) {  // backward of the Dropout in front of Linear l
+        g.p[0].keep = p->keep[l];
+        g.p[0].ldk = nin;
+        g.p[0].keep_scale = p->keep_scale;
+      }
       g.p[1] = make_gemm(kTNm, nout, nin, B, p->dact[l + 1], nout, p->act[l], nin, p->g_fc_w[l], nin, nullptr,
                          0, nullptr, 0, /*split_k=*/true);
       g.p[2] = make_colsum(p->dact[l + 1], B, nout, nout, p->g_fc_b[l]);

@@ -138,6 +138,8 @@ class _NcfBase(_FlatModel):
             widths = [2 * self.dim_mlp] + [o for _, o in dims]
             ws["act"] = [torch.empty(batch, w, device=dev) for w in widths]
             ws["dact"] = [torch.empty(batch, w, device=dev) for w in widths]
+            # dropout keep bytes of every Linear's input (only touched when dropout > 0 in training)
+            ws["keep"] = [torch.ones(batch, nin, dtype=torch.uint8, device=dev) for nin, _ in dims]
         ws["mf"] = torch.empty(batch, max(self.dim_mf, 1), device=dev)
         ws["dmf"] = torch.empty(batch, max(self.dim_mf, 1), device=dev)
         ws["scores"] = torch.empty(batch, device=dev)
@@ -180,8 +182,41 @@ class _NcfBase(_FlatModel):
             p.act[l] = t.data_ptr()
             p.dact[l] = ws["dact"][l].data_ptr()
         p.mf, p.dmf, p.scores = ws["mf"].data_ptr(), ws["dmf"].data_ptr(), ws["scores"].data_ptr()
+        p.keep_scale = 1.0
         self._plan_cache = (key, p)
         return p
+
+    def draw_keep_masks(self, plan, batch):
+        """Training step with dropout > 0: draw the keep bytes of every Linear's input (ncf.py:42-45,
+        mlp.py:30-33) and point ``plan`` at them; otherwise clear the plan's keep pointers.
+        ``dropout_rng = "torch_cpu"`` (default) replays nn.Dropout's own CPU draws — one
+        ``torch.empty(B, in_features).bernoulli_(1 - p)`` per layer, in layer order, so the same torch seed
+        drops the same activations as the reference (pinned by tests/golden/ncf_*_dropout.npz);
+        ``"device"`` draws them on the GPU."""
+        p = float(getattr(self, "dropout", 0.0) or 0.0)
+        n_layers = len(self.tower_dims) if self.dim_mlp > 0 else 0
+        active = self.training and p > 0.0 and n_layers > 0
+        for l in range(n_layers):
+            plan.keep[l] = None
+        plan.keep_scale = 1.0
+        if not active:
+            return
+        ws = self.workspace(batch)
+        rng = self.config["dropout_rng"] if "dropout_rng" in self.config else "torch_cpu"
+        self._dropout_step = getattr(self, "_dropout_step", 0) + 1
+        for l, (nin, _) in enumerate(self.tower_dims):
+            buf = ws["keep"][l]
+            if rng == "torch_cpu":
+                buf[:batch].copy_(torch.empty(batch, nin).bernoulli_(1 - p).to(torch.uint8))
+            elif rng == "device":
+                seed = int(self.config["dropout_seed"]) if "dropout_seed" in self.config else 0
+                _lib.check(_lib.load().hiprec_edge_dropout_mask(
+                    _lib.ptr(buf), batch * nin, 1.0 - p, seed * 64 + l, self._dropout_step,
+                    _lib.stream_ptr(self._flat.device)))
+            else:
+                raise ValueError(f"unknown dropout_rng {rng!r}: 'torch_cpu' or 'device'")
+            plan.keep[l] = buf.data_ptr()
+        plan.keep_scale = 1.0 / (1.0 - p)
 
     # -- reference API ------------------------------------------------------------------------
     def forward(self, user_indices, item_indices):
@@ -196,6 +231,8 @@ class _NcfBase(_FlatModel):
         if self._stats is None or self._stats.device != dev:
             self._stats = _new_stats(dev)
         plan = self.plan(max(n, 1))
+        if n:
+            self.draw_keep_masks(plan, n)   # like the reference, dropout follows self.training here too
         _lib.check(lib.hiprec_ncf_forward(ctypes.byref(plan), _lib.ptr(users), _lib.ptr(items), n,
                                           _lib.ptr(self._stats), _lib.stream_ptr(dev)))
         return self._ws["scores"][:n].clone().view(n, 1)
@@ -347,10 +384,6 @@ class _NcfEngine(ModelEngine):
         flat = self.model.flat
         if self._ready and self._g_flat.device == flat.device:
             return lib
-        if self.model.dropout if hasattr(self.model, "dropout") else 0:
-            raise NotImplementedError(
-                "dropout > 0 is not supported by the HIP engine (the reference draws its masks from "
-                "the CPU RNG stream); the shipped configs use dropout 0.0")
         self._g_flat = torch.zeros_like(flat)
         self.optimizer.allocate_state(flat)
         self._scratch = torch.zeros(lib.hiprec_scratch_bytes(0), dtype=torch.uint8, device=flat.device)
@@ -372,6 +405,7 @@ class _NcfEngine(ModelEngine):
             raise ValueError("empty batch")
         st = _lib.stream_ptr(dev)
         plan = m.plan(B, self._g_flat)
+        m.draw_keep_masks(plan, B)
         _lib.check(lib.hiprec_ncf_grad(
             ctypes.byref(plan), _lib.ptr(users), _lib.ptr(items), _lib.ptr(ratings), B, 1.0 / B,
             _lib.ptr(self._stats), _lib.ptr(self._scratch), self._scratch.numel(), st))
@@ -401,6 +435,7 @@ class _NcfEngine(ModelEngine):
         B = users.numel()
         st = _lib.stream_ptr(dev)
         plan = m.plan(B, self._g_flat)
+        m.draw_keep_masks(plan, B)
         _lib.check(lib.hiprec_ncf_grad(
             ctypes.byref(plan), _lib.ptr(users), _lib.ptr(items), _lib.ptr(ratings), B, 1.0 / B,
             _lib.ptr(self._stats), _lib.ptr(self._scratch), self._scratch.numel(), st))

@@ -284,6 +284,7 @@ class _ReplicatedNcfMixin:
             raise ValueError("users, items and ratings must be non-empty and of equal length")
         st = _lib.stream_ptr(dev)
         plan = m.plan(B, self._g_flat)
+        m.draw_keep_masks(plan, B)     # every rank draws its own share's masks (its own rows of the batch)
         _lib.check(lib.hiprec_ncf_grad(
             ctypes.byref(plan), _lib.ptr(users), _lib.ptr(items), _lib.ptr(ratings), B, 1.0 / (B * self.world),
             _lib.ptr(self._stats), _lib.ptr(self._scratch), self._scratch.numel(), st))

@@ -358,6 +358,13 @@ typedef struct hiprec_ncf_plan {
   float* dact[HIPREC_NCF_MAX_LAYERS + 1]; /* d loss / d (pre-activation), same shapes */
   float *mf, *dmf;                        /* [B, dim_mf] */
   float* scores;                          /* [B] sigmoid outputs */
+  /* tower dropout (ncf.py:42-45, mlp.py:30-33: nn.Dropout in front of every Linear), training only:
+   * keep[l] = one byte per element of Linear l's input [B, layer_in[l]], or NULL for none; kept entries
+   * are scaled by keep_scale = 1 / (1 - p).  With any keep[l] set the step runs one launch per layer
+   * (the fused tower kernel has no mask input); act[l] then holds the input AFTER its Dropout. */
+  const uint8_t* keep[HIPREC_NCF_MAX_LAYERS];
+  float keep_scale;
+  int32_t _pad;
 } hiprec_ncf_plan;
 
 size_t hiprec_ncf_plan_bytes(void); /* sizeof(hiprec_ncf_plan), for binding-layout checks */

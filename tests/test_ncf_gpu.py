@@ -198,3 +198,60 @@ def test_fused_tower_shapes_vs_oracle(hip_device, engine, kind, E, L, B):
         assert_tensor_close(grads[k].cpu().numpy(), g_ref[k], 2e-5, f"grad {k}", scale_floor=bias_floor(k))
     scores = eng.model.predict(users[:200], items[:200]).cpu().numpy()
     assert_tensor_close(scores, onc.ncf_predict(w, users[:200], items[:200], kind), what="scores")
+
+
+@pytest.mark.parametrize("case,engine", [("ncf_neumf_dropout", "NeuMFEngine"), ("ncf_mlp_dropout", "MLPEngine")])
+def test_tower_dropout_matches_reference(hip_device, case, engine):
+    """Dropout > 0 in front of every Linear of the tower (ncf.py:42-45, mlp.py:30-33): with the reference's
+    torch seed the engine draws the SAME masks (CPU replay of nn.Dropout), and loss, gradients and the SGD
+    step match the real reference."""
+    from test_oracle_golden_ncf import dropout_masks
+
+    g = load_golden(case)
+    U, I, E, L, B, n_steps, seed = (int(x) for x in g["meta"])
+    kind, opt, lr, p = str(g["kind"]), str(g["optimizer"]), float(g["lr"]), float(g["dropout"])
+    import beta_recsys_amd as hp
+
+    cfg = ncf_config(U, I, E, L, opt, lr, B, device="cuda:0")
+    cfg["model"]["dropout"] = p
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = getattr(hp, engine)(cfg)
+    eng.model.train()
+    for s in range(n_steps):
+        w0 = params(g, f"w{s}")
+        load_weights(eng, w0)
+        eng.load_optimizer_state(s)      # gradients / the SGD step do not depend on the moments
+        batch = (g["users"][s], g["items"][s], g["ratings"][s])
+        torch.manual_seed(3000 + s)
+        loss, grads = eng.backward_only(*batch)
+        ref_masks = dropout_masks(g, s, w0)
+        for l, ref in enumerate(ref_masks):
+            mine = eng.model._ws["keep"][l][:B].cpu().numpy().astype(bool)
+            assert np.array_equal(mine, ref), f"layer {l}: the same seed must drop the same activations"
+        assert_scalar_close(loss, g["losses"][s], what=f"loss step {s}")
+        g_ref = params(g, f"g{s + 1}")
+        for k in g_ref:
+            assert_tensor_close(grads[k].cpu().numpy(), g_ref[k], 2e-5, f"grad {k} step {s}", scale_floor=bias_floor(k))
+        if opt == "sgd":
+            torch.manual_seed(3000 + s)
+            loss2 = eng.train_single_batch(*(torch.from_numpy(x) for x in batch))
+            assert_scalar_close(loss2, g["losses"][s], what=f"loss (step) {s}")
+            w1 = get_weights(eng)
+            for k in w0:
+                assert_tensor_close(w1[k], g[f"w{s + 1}/{k}"], 1e-6, f"weights {k} step {s}")
+    # eval mode: no dropout, the fused path scores like the oracle without masks
+    eng.model.eval()
+    wf = params(g, f"w{n_steps}")
+    load_weights(eng, wf)
+    probe_u, probe_i = g["users"][0][:16], g["items"][0][:16]
+    scores = eng.model.predict(probe_u, probe_i).cpu().numpy()
+    assert_tensor_close(scores, onc.ncf_predict(wf, probe_u, probe_i, kind), 1e-5, "eval scores")
+    # device RNG: keep rate ~ 1 - p and a different mask every step
+    cfg["model"]["dropout_rng"] = "device"
+    with contextlib.redirect_stdout(io.StringIO()):
+        dev_eng = getattr(hp, engine)(cfg)
+    dev_eng.model.train()
+    dev_eng.train_single_batch(*(torch.from_numpy(x) for x in batch))
+    k1 = dev_eng.model._ws["keep"][0][:B].clone()
+    dev_eng.train_single_batch(*(torch.from_numpy(x) for x in batch))
+    assert abs(float(k1.float().mean()) - (1 - p)) < 0.12 and not torch.equal(k1, dev_eng.model._ws["keep"][0][:B])
