@@ -9,7 +9,9 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 from ctypes import c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhiprec.so")
+# HIPREC_LIB selects another build of the same sources, e.g. libhiprec_ieee.so (-DHIPREC_IEEE_DIV: ATen's
+# correctly rounded sqrt / division in the Adam / RMSprop denominators, op for op)
+LIB_PATH = os.path.join(_HERE, os.environ.get("HIPREC_LIB", "libhiprec.so"))
 
 OPT_SGD, OPT_ADAM, OPT_RMSPROP = 0, 1, 2
 OPT_KINDS = {"sgd": OPT_SGD, "adam": OPT_ADAM, "rmsprop": OPT_RMSPROP}
@@ -154,6 +156,7 @@ SIGNATURES = {
     "hiprec_scratch_bytes": (c_size_t, [c_int64]),
     "hiprec_stats_reset": (c_int, [_P, c_double, c_double, _P]),
     "hiprec_stats_advance_step": (c_int, [_P, _P]),
+    "hiprec_stats_set_step": (c_int, [_P, c_int64, c_double, c_double, _P]),
     "hiprec_stats_begin_epoch": (c_int, [_P, _P]),
     "hiprec_gather_rows": (c_int, [_P, c_int64, c_int32, _P, c_int64, _P, _P, _P]),
     "hiprec_route_bucket": (c_int, [_P, c_int64, c_int32, c_int64, _P, _P, _P, _P]),
@@ -315,14 +318,57 @@ def load():
         raise RuntimeError("hiprec_ngcf_plan layout mismatch between _lib.py and libhiprec.so")
     if lib.hiprec_ncf_plan_bytes() != ctypes.sizeof(NcfPlan):
         raise RuntimeError("hiprec_ncf_plan layout mismatch between _lib.py and libhiprec.so")
-    _lib = lib
-    return lib
+    _lib = _DeviceGuardedLib(lib)
+    return _lib
+
+
+class _Stream(c_void_p):
+    """A hipStream_t that remembers which HIP device it belongs to (see _DeviceGuardedLib)."""
+
+    device_index = None
+
+
+class _DeviceGuardedLib:
+    """libhiprec's entry points behind a HIP-device guard.
+
+    A kernel launch goes to the CURRENT HIP device, and torch's default stream has the handle 0 on
+    every device, so a call for tensors on ``cuda:1`` made while device 0 is current would run on
+    GPU 0's null stream against GPU 1's pointers.  The reference never calls ``set_device`` and
+    ``TrainEngine.get_device`` hands out ``cuda:N``, so every stream-taking entry point is wrapped:
+    the stream argument built by :func:`stream_ptr` carries its device index, and the wrapper makes
+    that device current for the duration of the call.
+    """
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(cdll, name)
+            setattr(self, name, self._guard(fn) if (restype is c_int and argtypes) else fn)
+
+    @staticmethod
+    def _guard(fn):
+        import torch
+
+        def call(*args):
+            want = None
+            for a in reversed(args):  # the stream is the last argument of almost every entry point
+                if type(a) is _Stream:
+                    want = a.device_index
+                    break
+            if want is None or want == torch.cuda.current_device():
+                return fn(*args)
+            with torch.cuda.device(want):
+                return fn(*args)
+
+        call.__name__ = fn.__name__
+        call.argtypes, call.restype = fn.argtypes, fn.restype
+        return call
 
 
 def check(rc):
     """Raise HiprecError for a non-zero return code of a libhiprec call."""
     if rc != 0:
-        msg = load().hiprec_last_error()
+        msg = load().hiprec_last_error()  # (thread-local buffer of the C library)
         raise HiprecError(f"libhiprec call failed (code {rc}): {msg.decode() if msg else ''}")
 
 
@@ -335,4 +381,7 @@ def stream_ptr(device):
     """Current torch stream of `device` as a hipStream_t (c_void_p)."""
     import torch
 
-    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    device = torch.device(device)
+    st = _Stream(torch.cuda.current_stream(device).cuda_stream)
+    st.device_index = device.index if device.index is not None else torch.cuda.current_device()
+    return st

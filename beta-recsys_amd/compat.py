@@ -2,14 +2,16 @@
 
 ``install()`` registers this package's mirrors under the reference's module names, so that
 ``from ..models.mf import MFEngine`` inside ``beta_rec/recommenders/matrix_factorization.py:8``
-(and ``from beta_rec.models.torch_engine import ModelEngine``) resolve to them.  Call it before
+resolves to them.  Call it before
 importing ``beta_rec.recommenders``.
 """
 import sys
 
-# reference module name -> mirror module in this package
+# reference module name -> mirror module in this package.  ``beta_rec.models.torch_engine`` is NOT in
+# this table: about fifteen reference engines this package does not mirror (vbcar, narm, sasrec, sgl,
+# ultragcn, vaecf, cmn ...) import ``ModelEngine`` from it and need the torch optimizer it builds
+# (``self.optimizer.step()``); the mirrors import their own base class relatively.
 MIRRORS = {
-    "beta_rec.models.torch_engine": "torch_engine",
     "beta_rec.models.mf": "mf",
     "beta_rec.models.ncf": "ncf",
     "beta_rec.models.gmf": "ncf",
@@ -20,9 +22,17 @@ MIRRORS = {
     "beta_rec.models.triple2vec": "triple2vec",
 }
 
+_MISSING = object()
+_saved = {}  # ref_name -> (previous sys.modules entry, previous parent attribute)
+
 
 def install(extra=None):
-    """Register the mirrors in ``sys.modules``; returns the list of module names replaced."""
+    """Register the mirrors in ``sys.modules``; returns the list of module names replaced.
+
+    ``extra`` adds entries, e.g. ``{"beta_rec.models.torch_engine": "torch_engine"}`` for a caller
+    that wants the HIP ``ModelEngine`` base under the reference's name as well (its
+    ``set_optimizer`` falls back to ``torch.optim`` for models without a flat parameter buffer, so
+    un-mirrored engines keep training)."""
     import importlib
 
     pkg = __name__.rsplit(".", 1)[0]
@@ -31,9 +41,12 @@ def install(extra=None):
     done = []
     for ref_name, local in table.items():
         mod = importlib.import_module(f"{pkg}.{local}")
-        sys.modules[ref_name] = mod
         parent_name, _, attr = ref_name.rpartition(".")
         parent = sys.modules.get(parent_name)
+        if ref_name not in _saved:
+            _saved[ref_name] = (sys.modules.get(ref_name, _MISSING),
+                                _MISSING if parent is None else parent.__dict__.get(attr, _MISSING))
+        sys.modules[ref_name] = mod
         if parent is not None:
             setattr(parent, attr, mod)
         done.append(ref_name)
@@ -41,11 +54,23 @@ def install(extra=None):
 
 
 def uninstall():
-    """Remove the registrations made by :func:`install` (the reference's own modules load again)."""
-    for ref_name in MIRRORS:
-        mod = sys.modules.get(ref_name)
-        if mod is not None and mod.__name__.startswith(__name__.rsplit(".", 1)[0]):
-            del sys.modules[ref_name]
+    """Undo :func:`install`: ``sys.modules`` entries and the parent packages' attributes go back to
+    what they were (the reference's own modules load again)."""
+    for ref_name, (prev_mod, prev_attr) in list(_saved.items()):
+        if prev_mod is _MISSING:
+            sys.modules.pop(ref_name, None)
+        else:
+            sys.modules[ref_name] = prev_mod
+        parent_name, _, attr = ref_name.rpartition(".")
+        parent = sys.modules.get(parent_name)
+        if parent is not None:
+            if prev_attr is not _MISSING:
+                setattr(parent, attr, prev_attr)
+            elif prev_mod is not _MISSING:
+                setattr(parent, attr, prev_mod)
+            elif attr in parent.__dict__:
+                delattr(parent, attr)
+        del _saved[ref_name]
 
 
 def install_eval():

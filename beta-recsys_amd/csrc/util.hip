@@ -3,6 +3,8 @@
 // without returning to the host between batches.
 #include <cstring>
 
+#include <cmath>
+
 #include "common.hpp"
 
 namespace hiprec {
@@ -33,6 +35,14 @@ __global__ void stats_reset_kernel(hiprec_stats* s, double b1, double b2) {
   s->beta2_pow = 1.0;
   s->status = 0u;
   s->_pad = 0u;
+}
+
+__global__ void stats_set_step_kernel(hiprec_stats* s, long long step, double b1, double b2, double b1p, double b2p) {
+  s->step = step;
+  s->beta1 = b1;
+  s->beta2 = b2;
+  s->beta1_pow = b1p;
+  s->beta2_pow = b2p;
 }
 
 __global__ void stats_begin_epoch_kernel(hiprec_stats* s) {
@@ -283,6 +293,16 @@ extern "C" size_t hiprec_scratch_bytes(int64_t) { return kScratchBytes; }
 extern "C" int hiprec_stats_reset(hiprec_stats* stats, double beta1, double beta2, void* stream) {
   HIPREC_REQUIRE(stats, "NULL stats");
   stats_reset_kernel<<<1, 1, 0, static_cast<hipStream_t>(stream)>>>(stats, beta1, beta2);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_stats_set_step(hiprec_stats* stats, int64_t step, double beta1, double beta2, void* stream) {
+  HIPREC_REQUIRE(stats && step >= 0, "NULL stats / negative step");
+  // torch.optim computes beta ** step with the host's pow() on python doubles: do exactly that
+  stats_set_step_kernel<<<1, 1, 0, static_cast<hipStream_t>(stream)>>>(
+      stats, static_cast<long long>(step), beta1, beta2, pow(beta1, static_cast<double>(step)),
+      pow(beta2, static_cast<double>(step)));
   HIPREC_TRY(hipGetLastError());
   return 0;
 }

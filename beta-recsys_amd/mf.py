@@ -501,8 +501,8 @@ class MFEngine(ModelEngine):
         dev = m.flat.device
         _lib.check(lib.hiprec_stats_reset(
             _lib.ptr(self._stats), opt.beta1 or 0.9, opt.beta2 or 0.999, _lib.stream_ptr(dev)))
-        for _ in range(int(step)):
-            _lib.check(lib.hiprec_stats_advance_step(_lib.ptr(self._stats), _lib.stream_ptr(dev)))
+        _lib.check(lib.hiprec_stats_set_step(_lib.ptr(self._stats), int(step), opt.beta1 or 0.9,
+                                             opt.beta2 or 0.999, _lib.stream_ptr(dev)))
         for buf, src in ((opt.exp_avg, exp_avg), (opt.exp_avg_sq, exp_avg_sq)):
             if buf is None:
                 continue

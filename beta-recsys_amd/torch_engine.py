@@ -116,10 +116,25 @@ class ModelEngine(object):
         self.writer = make_writer(config["system"]["run_dir"])
 
     def set_optimizer(self):
-        """torch_engine.py:23-39; unknown names raise ValueError early instead of AttributeError later."""
-        self.optimizer = HipOptimizer(
-            self.config["model"]["optimizer"], self.config["model"]["lr"]
-        )
+        """torch_engine.py:23-39; unknown names raise ValueError early instead of AttributeError later.
+
+        Flat-buffer models (everything this package mirrors) get the HIP optimizer descriptor.  A
+        model WITHOUT a flat buffer -- one of the reference's own engines subclassing this base
+        through ``compat.install(extra={"beta_rec.models.torch_engine": ...})`` -- gets exactly the
+        torch optimizer the reference builds, so its ``optimizer.step()`` keeps working."""
+        name, lr = self.config["model"]["optimizer"], self.config["model"]["lr"]
+        if hasattr(self.model, "flat"):
+            self.optimizer = HipOptimizer(name, lr)
+            return
+        params = self.model.parameters()
+        if name == "sgd":
+            self.optimizer = torch.optim.SGD(params, lr=lr)
+        elif name == "adam":
+            self.optimizer = torch.optim.Adam(params, lr=lr)
+        elif name == "rmsprop":
+            self.optimizer = torch.optim.RMSprop(params, lr=lr)
+        else:
+            raise ValueError(f"Unsupported optimizer {name!r} (beta_rec/models/torch_engine.py:23-39)")
 
     def set_device(self):
         """torch_engine.py:41-45."""

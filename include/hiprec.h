@@ -90,6 +90,9 @@ size_t hiprec_scratch_bytes(int64_t batch);
 int hiprec_stats_reset(hiprec_stats* stats, double beta1, double beta2, void* stream);
 /* t <- t+1 without a *_grad call (stand-alone use of hiprec_opt_dense_step) */
 int hiprec_stats_advance_step(hiprec_stats* stats, void* stream);
+/* resume: t <- step and the Adam bias-correction powers beta**step (host pow(), as torch.optim computes
+ * them) in ONE launch; loss / sums / status are left alone */
+int hiprec_stats_set_step(hiprec_stats* stats, int64_t step, double beta1, double beta2, void* stream);
 /* zero only the epoch accumulators loss_sum/reg_sum (start of train_an_epoch, mf.py:131-132) */
 int hiprec_stats_begin_epoch(hiprec_stats* stats, void* stream);
 

@@ -245,6 +245,9 @@ def test_compat_install_routes_reference_imports(tmp_path, monkeypatch):
     (root / "beta_rec" / "__init__.py").write_text("")
     (root / "beta_rec" / "models" / "__init__.py").write_text("")
     (root / "beta_rec" / "models" / "mf.py").write_text("raise ImportError('the reference module must not load')\n")
+    # the reference's own base module stays the reference's (~15 un-mirrored engines -- vbcar,
+    # narm, sasrec, cmn ... -- subclass it and call self.optimizer.step())
+    (root / "beta_rec" / "models" / "torch_engine.py").write_text("class ModelEngine:\n    reference = True\n")
     (root / "beta_rec" / "recommenders" / "__init__.py").write_text("")
     (root / "beta_rec" / "recommenders" / "matrix_factorization.py").write_text(
         "from ..models.mf import MFEngine\nfrom beta_rec.models.torch_engine import ModelEngine\n")
@@ -259,18 +262,58 @@ def test_compat_install_routes_reference_imports(tmp_path, monkeypatch):
     for k in saved:
         del sys.modules[k]
     try:
-        assert compat.install()[:2] == ["beta_rec.models.torch_engine", "beta_rec.models.mf"]
+        installed = compat.install()
+        assert installed[0] == "beta_rec.models.mf" and "beta_rec.models.torch_engine" not in installed
         m = importlib.import_module("beta_rec.recommenders.matrix_factorization")
-        assert m.MFEngine is hp.MFEngine and m.ModelEngine is hp.ModelEngine
+        assert m.MFEngine is hp.MFEngine
+        assert m.ModelEngine is not hp.ModelEngine and m.ModelEngine.reference
         sib = importlib.import_module("beta_rec.recommenders.siblings")
         assert sib.NGCFEngine is hp.NGCFEngine and sib.Triple2vecEngine is hp.Triple2vecEngine
         assert sib.PairwiseGMFEngine is hp.PairwiseGMFEngine and callable(sib.truncated_normal_)
         assert sib.LightGCNEngine is hp.LightGCNEngine and sib.NeuMFEngine is hp.NeuMFEngine
+        models_pkg = sys.modules["beta_rec.models"]
+        compat.install()  # idempotent; now that the parent package is loaded it also gets the attributes
+        assert models_pkg.mf is sys.modules["beta_rec.models.mf"]
+        # opt-in: the HIP base under the reference's name
+        compat.install(extra={"beta_rec.models.torch_engine": "torch_engine"})
+        assert sys.modules["beta_rec.models.torch_engine"].ModelEngine is hp.ModelEngine
+        compat.uninstall()
+        # uninstall puts back what was there: the reference's torch_engine module, and no mirror
+        # left behind either in sys.modules or as an attribute of the parent package
+        assert sys.modules["beta_rec.models.torch_engine"].ModelEngine.reference
+        assert models_pkg.torch_engine.ModelEngine.reference
+        assert "beta_rec.models.mf" not in sys.modules and not hasattr(models_pkg, "mf")
     finally:
         compat.uninstall()
         for k in [k for k in sys.modules if k.startswith("beta_rec.") or k == "beta_rec"]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_model_engine_builds_torch_optimizer_for_foreign_models():
+    """A reference engine that is NOT mirrored but subclasses the HIP ``ModelEngine`` (compat.install with the
+    torch_engine extra) keeps the torch optimizer torch_engine.py:23-39 builds: optimizer.step() works."""
+    import beta_recsys_amd as hp
+
+    class Foreign(hp.ModelEngine):
+        def __init__(self, config):
+            self.model = torch.nn.Linear(3, 1)
+            super().__init__(config)
+
+    for name, cls in (("sgd", torch.optim.SGD), ("adam", torch.optim.Adam), ("rmsprop", torch.optim.RMSprop)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            eng = Foreign({"model": {"optimizer": name, "lr": 0.1, "device_str": "cpu"},
+                           "system": {"run_dir": "/tmp/hiprec_test_runs"}})
+        assert isinstance(eng.optimizer, cls)
+        before = eng.model.weight.detach().clone()
+        eng.optimizer.zero_grad()
+        eng.model(torch.ones(2, 3)).sum().backward()
+        eng.optimizer.step()
+        assert not torch.equal(before, eng.model.weight)
+    with pytest.raises(ValueError):
+        with contextlib.redirect_stdout(io.StringIO()):
+            Foreign({"model": {"optimizer": "lbfgs", "lr": 0.1, "device_str": "cpu"},
+                     "system": {"run_dir": "/tmp/hiprec_test_runs"}})
 
 
 def ncf_config(U, I, E, L, optimizer="adam", lr=1e-3, B=8, device="cpu", model="ncf_end"):
