@@ -1,19 +1,34 @@
 """bench.py — BPR-MF training throughput on MI355X (BASELINE.json configs[1]).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--optimizer sgd|adam|rmsprop]
+                    [--workload mf|mf-c4|mf-c4shard|ncf|lightgcn|...] [--scaling weak|strong]
 
 A "step" is one pass of the hot path over one batch of B = 4096 synthetic (user, pos, neg) triples:
 gather -> score -> BPR gradient -> scatter into the dense gradient -> optimizer update (exactly
-the work of MFEngine.train_single_batch in the reference, beta_rec/models/mf.py:92-119).  Inputs
-(triples + permutation) are resident in HBM when the timed region starts; the K timed steps are
-enqueued by the library's epoch driver and bracketed by barrier + synchronize on both sides.
-Rank 0 prints ONE JSON line.
+the work of MFEngine.train_single_batch in the reference, beta_rec/models/mf.py:92-119).  The triples
+are resident in HBM when the clock starts; everything an epoch of K steps does on top of them is INSIDE
+the timed region: the per-epoch shuffle, the staging of the epoch (per-batch sort by item + layout), the
+K fused steps and the flush that applies the last update.
+
+Timing (>= 200 timed steps, median of >= 5 repeats): the K-step epoch is repeated
+R = max(5, ceil(200 / K)) times; `ms_per_step` is the MEDIAN over the repeats of (epoch time / K), `value`
+follows from it, `steps` stays K and `repeats` says R; `wall_ms_per_step` is the plain wall clock of
+the whole R x K region (first staging and launch latency included) for cross-checking.  N = 1: the R
+epochs are enqueued back to back and delimited by HIP events on the stream they run on (a host
+synchronize per 0.2 ms epoch would measure the synchronize).  N > 1: every repeat is bracketed by
+barrier + torch.cuda.synchronize() on both sides and the MAX over ranks is taken per repeat.
+
+`python bench.py --gpus N` without a torch.distributed environment starts its own N ranks (re-exec
+through torch.distributed.run on 127.0.0.1); under torchrun it uses RANK / LOCAL_RANK / WORLD_SIZE as
+given.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import contextlib
 import io
 import json
 import os
+import socket
+import statistics
 import sys
 import time
 
@@ -28,11 +43,87 @@ if ROOT not in sys.path:
 U, I, D, B = 6040, 3706, 64, 4096
 LR = 0.05
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec peak)
+MIN_TIMED_STEPS, MIN_REPEATS = 200, 5
+ROUND = "r02"
 
 
 def algorithmic_bytes_per_triple(dim):
     """indices 3*8 B + 3 row reads + 3 row writes of (dim+1) fp32."""
     return 24 + 24 * (dim + 1)
+
+
+def optimizer_sweep_bytes(optimizer, n_params):
+    """what the dense optimizer adds per STEP on top of the per-triple row traffic --
+    Adam reads w, m, v, g and writes w, m, v (28 P), RMSprop reads w, v, g and writes w, v (20 P); SGD's
+    row updates are already the "3 row writes" of the per-triple figure."""
+    return {"sgd": 0, "adam": 28, "rmsprop": 20}[optimizer] * n_params
+
+
+def n_repeats(steps):
+    return max(MIN_REPEATS, -(-MIN_TIMED_STEPS // max(steps, 1)))
+
+
+def timed_repeats(run_epoch, steps, device, dist_on=False):
+    """Run `run_epoch(r)` (which enqueues exactly `steps` steps incl. their per-epoch staging) R times.
+    Returns (per-repeat seconds, wall seconds of the whole region).  See the module docstring."""
+    R = n_repeats(steps)
+    if not dist_on:
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(R + 1)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        evs[0].record()
+        for r in range(R):
+            run_epoch(r)
+            evs[r + 1].record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        return [evs[r].elapsed_time(evs[r + 1]) * 1e-3 for r in range(R)], wall
+    import torch.distributed as dist
+
+    per = []
+    w0 = time.perf_counter()
+    for r in range(R):
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_epoch(r)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        per.append(time.perf_counter() - t0)
+    wall = time.perf_counter() - w0
+    t = torch.tensor(per + [wall], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank defines every repeat
+    t = t.cpu().tolist()
+    return t[:-1], t[-1]
+
+
+def timing_fields(per, wall, steps, units_per_step, world=1):
+    """The contract's fields from the per-repeat times: median epoch time / K."""
+    med = statistics.median(per)
+    return {"value": world * units_per_step * steps / med, "ms_per_step": med / steps * 1e3,
+            "repeats": len(per), "timed_steps_total": len(per) * steps,
+            "ms_per_step_min": min(per) / steps * 1e3, "ms_per_step_max": max(per) / steps * 1e3,
+            "wall_ms_per_step": wall / (len(per) * steps) * 1e3}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without RANK / WORLD_SIZE: become `torch.distributed.run` with N ranks on
+    this node (one process per GPU over RCCL), same arguments."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: needs {n} visible MI355X GPUs, this node shows {have} "
+                         "(torch.cuda.device_count()); nothing was launched")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def synth_triples(n, seed):
@@ -163,48 +254,32 @@ def cpu_baseline(optimizer="adam", budget_s=12.0):
                       f"{os.cpu_count()} logical cpus"}
 
 
-def measured_traffic_bytes(kernel="hiprec::mf_bpr_grad_kernel<1>"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_summary.json: FETCH_SIZE + WRITE_SIZE, KB per dispatch), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    try:
-        with open(path) as f:
-            k = json.load(f)[kernel]
-        return (k["FETCH_SIZE_KB_mean"] + k["WRITE_SIZE_KB_mean"]) * 1024.0
-    except Exception:
-        return None
-
-
-def other_workload_traffic(workload, kernel):
-    """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, KB per dispatch) of a kernel of another bench
-    workload from the committed rocprofv3 PMC passes (profiles/r01_pmc_other_workloads.json), or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_other_workloads.json")) as f:
-            k = json.load(f)[workload][kernel]
-        return (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
-    except Exception:
-        return None
-
-
-def bench_ncf(args, device):
-    """BASELINE configs[2]: NeuMF (GMF + MLP [128, 64, 32] <=> emb_dim 32, quirk Q9) on the ML-1M
-    shape, batch 4096 (user, item, rating) samples with 1 positive : 4 negatives, Adam lr 1e-3."""
+def bench_ncf(args, device, world=1, rank=0, dist_on=False):
+    """BASELINE configs[2]: NeuMF (GMF + MLP) on the ML-1M shape, batch 4096 (user, item, rating) samples with
+    1 positive : 4 negatives, Adam lr 1e-3.  `--emb-dim 32` (default): tower 256->128->64->32 (MLP [128, 64, 32],
+    quirk Q9); `--emb-dim 64`: tables 256/256/64/64, tower 512->256->128->64.  N > 1: replicated tables and tower,
+    one all-reduce of [flat gradient | loss] per step (replicated.replicated_ncf_engine)."""
     import beta_recsys_amd as hp
 
-    E, L = 32, 3
+    E, L, K, W = args.emb_dim, 3, args.steps, args.warmup
     cfg = {"model": dict(n_users=U, n_items=I, emb_dim=E, dropout=0.0, device_str=str(device),
                          optimizer="adam", lr=1e-3, batch_size=B, model="ncf_end",
                          mlp_config={"n_layers": L}, gmf_config={}),
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
-        eng = hp.NeuMFEngine(cfg)
-    n_total = (args.warmup + args.steps) * B
+        if dist_on:
+            from beta_recsys_amd.replicated import replicated_ncf_engine
+
+            eng = replicated_ncf_engine(hp.NeuMFEngine)(cfg)
+        else:
+            eng = hp.NeuMFEngine(cfg)
+    n_total = (W + K) * B
     # the sample stream instance_bce_loader builds (data/base_data.py:182-216, num_negative 4): every
     # positive (Zipf item, rating 1) is followed by 4 negatives of the same user (uniform items, rating
     # 0), then the DataLoader shuffles the samples
-    pu, ppos, pneg = synth_triples(n_total // 5 + 1, seed=100)
-    g = torch.Generator().manual_seed(101)
+    pu, ppos, pneg = synth_triples(n_total // 5 + 1, seed=100 + rank)
+    g = torch.Generator().manual_seed(101 + rank)
     users = pu.repeat_interleave(5)[:n_total]
     items = torch.cat([ppos[:, None], torch.randint(0, I, (ppos.numel(), 4), generator=g)], 1).reshape(-1)[:n_total]
     ratings = torch.tensor([1.0, 0, 0, 0, 0]).repeat(ppos.numel())[:n_total]
@@ -216,24 +291,30 @@ def bench_ncf(args, device):
             sl = slice(lo + k * B, lo + (k + 1) * B)
             eng._enqueue_step(users[sl], items[sl], ratings[sl])
 
-    run(0, args.warmup)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.warmup * B, args.steps)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    run(0, W)
+    per, wall = timed_repeats(lambda r: run(W * B, K), K, device, dist_on)
     st = eng._sync_stats()
-    flops = 3 * 2 * (256 * 128 + 128 * 64 + 64 * 32 + 64)  # fwd + dgrad + wgrad per sample
-    out = {"metric": "training interactions/sec (NCF samples)", "value": args.steps * B / dt,
-           "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "NeuMF (BASELINE configs[2]): 6040 x 3706, emb_dim 32 => tables "
-                                  "128/128/32/32, tower 256->128->64->32, head 64->1, batch 4096, adam 1e-3",
-                      "last_loss": st.loss},
-           "mfma": {"flops_per_sample": flops, "achieved_tflops": args.steps * B * flops / dt / 1e12,
-                    "peak_fp32_mfma_tflops": 157.3}}
-    print(json.dumps(out), flush=True)
+    if rank != 0:
+        return None
+    dims = [2 * E * 2 ** (L - 1)] + [E * 2 ** (L - 1 - i) for i in range(L)]      # 256,128,64,32 at E 32
+    macs = sum(a * b for a, b in zip(dims[:-1], dims[1:])) + 2 * E                # tower + head (E mlp + E mf)
+    flops = 3 * 2 * macs                                                          # fwd + dgrad + wgrad per sample
+    out = {"metric": "training interactions/sec (NCF samples)", "unit": "samples/s"}
+    out.update(timing_fields(per, wall, K, B, world))
+    step_s = out["ms_per_step"] * 1e-3
+    out.update({"n_gpus": world, "steps": K, "warmup": W, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"NeuMF (BASELINE configs[2]): 6040 x 3706, emb_dim {E} => tables "
+                                       f"{dims[0] // 2}/{dims[0] // 2}/{E}/{E}, tower {'->'.join(map(str, dims))}, head "
+                                       f"{2 * E}->1, batch 4096/GPU, adam 1e-3",
+                           "parallelism": f"dp{world}: replicated tables + tower, one RCCL all-reduce per step" if dist_on
+                           else "single GPU", "rccl_world_size": world if dist_on else None,
+                           "last_loss": st.loss},
+                "roofline": {"bound": "mfma", "achieved": B * flops / step_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                             "frac": B * flops / step_s / 1e12 / 157.3, "flops_per_sample": flops,
+                             "note": "whole step (all launches) against the dense fp32 MFMA peak; traffic not collected",
+                             "traffic": None}})
+    return out
 
 
 def bench_mf_c4shard(args, device, full=False):
@@ -255,7 +336,7 @@ def bench_mf_c4shard(args, device, full=False):
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
         eng = hp.MFEngine(cfg)
-    steps, warm = min(args.steps, 200), min(args.warmup, 20)
+    steps, warm = min(args.steps, 100), min(args.warmup, 10)
     n_total = (steps + warm) * Bc
     g = torch.Generator().manual_seed(5)
     users = torch.randint(0, Uc, (n_total,), generator=g).to(device)
@@ -263,13 +344,10 @@ def bench_mf_c4shard(args, device, full=False):
     pos = torch.randperm(Ic, generator=g)[torch.multinomial(pz / pz.sum(), n_total, True, generator=g)].to(device)
     neg = torch.randint(0, Ic, (n_total,), generator=g).to(device)
     nw = warm * Bc
-    eng.run_prepared_epoch(stage(eng, hp.DeviceTripleBatcher(users[:nw], pos[:nw], neg[:nw], Bc)))
+    if warm:
+        eng.run_prepared_epoch(stage(eng, hp.DeviceTripleBatcher(users[:nw], pos[:nw], neg[:nw], Bc)))
     prepared = stage(eng, hp.DeviceTripleBatcher(users[nw:], pos[nw:], neg[nw:], Bc))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.run_prepared_epoch(prepared, sync=False)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    per, wall = timed_repeats(lambda r: eng.run_prepared_epoch(prepared, sync=False), steps, device)
     st = eng.epoch_stats()
     # dominant kernel alone, back to back
     lib = eng._setup()
@@ -290,23 +368,77 @@ def bench_mf_c4shard(args, device, full=False):
     torch.cuda.synchronize()
     k_s = a.elapsed_time(b) / 50 * 1e-3
     bpt = algorithmic_bytes_per_triple(Dc)
-    out = {"metric": "training interactions/sec (BPR triples)", "value": steps * Bc / dt, "unit": "triples/s",
-           "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": dt / steps * 1e3,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": ("BPR-MF, BASELINE configs[3] whole on one GPU: 10M x 1M rows, dim 128, batch "
-                                   "65536, exact SGD on touched rows" if full else
-                                   "BPR-MF, one rank's shard of BASELINE configs[3]: 1.25M x 125k rows, dim 128, "
-                                   "batch 65536, exact SGD on touched rows (no exchange timed)"),
-                      "last_loss": st.loss},
-           "roofline": {"bound": "hbm", "kernel": "mf_bpr_grad_kernel<2>", "achieved": bpt * Bc / k_s / 1e9,
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bpt * Bc / k_s / 1e9 / HBM_PEAK_GBS,
-                        "algorithmic_bytes_per_launch": bpt * Bc, "kernel_us": k_s * 1e6,
-                        "traffic": None if full else other_workload_traffic("mf-c4shard", "hiprec::mf_bpr_grad_kernel<2>"),
-                        "step_frac": steps * Bc / dt * bpt / (HBM_PEAK_GBS * 1e9)}}
-    print(json.dumps(out), flush=True)
+    traffic, traffic_src = (None, None) if full else traffic_from_profiles("hiprec::mf_bpr_grad_kernel<2>", "mf-c4shard")
+    out = {"metric": "training interactions/sec (BPR triples)", "unit": "triples/s"}
+    out.update(timing_fields(per, wall, steps, Bc))
+    out.update({"n_gpus": 1, "steps": steps, "warmup": warm,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": ("BPR-MF, BASELINE configs[3] whole on one GPU: 10M x 1M rows, dim 128, batch "
+                                        "65536, exact SGD on touched rows" if full else
+                                        "BPR-MF, one rank's shard of BASELINE configs[3]: 1.25M x 125k rows, dim 128, "
+                                        "batch 65536, exact SGD on touched rows (no exchange timed)"),
+                           "timed_region": "K steps of a pre-staged epoch (the staging of 65536-triple batches is a "
+                                           "device sort outside the clock)",
+                           "last_loss": st.loss},
+                "roofline": {"bound": "hbm", "kernel": "mf_bpr_grad_kernel<2>", "achieved": bpt * Bc / k_s / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bpt * Bc / k_s / 1e9 / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": bpt * Bc, "kernel_us": k_s * 1e6,
+                             "traffic": traffic, "traffic_source": traffic_src,
+                             "step_frac": out["value"] * bpt / (HBM_PEAK_GBS * 1e9)}})
+    return out
 
 
-def bench_lightgcn(args, device):
+def bench_mf_c4_sharded(args, device, world, rank):
+    """BASELINE configs[3] as specified: 10M users x 1M items, dim 128, tables ROW-SHARDED over the ranks
+    (owner = row mod N), every rank feeds 65536 triples per step (global batch N x 65536), triples / item rows /
+    item-row gradients routed with RCCL all-to-alls, exact SGD on the rows each shard's step touched."""
+    from beta_recsys_amd.sharded import ShardedMFEngine
+
+    Uc, Ic, Dc, Bc = 10_000_000, 1_000_000, 128, 65536
+    cfg = {"model": dict(n_users=Uc, n_items=Ic, emb_dim=Dc, device_str=str(device), optimizer="sgd", lr=LR,
+                         batch_size=Bc, loss="bpr", sgd_mode="rows", shard_init="local"),
+           "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
+    torch.manual_seed(2020)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = ShardedMFEngine(cfg)
+    steps, warm = min(args.steps, 50), min(args.warmup, 5)
+    n_total = (steps + warm) * Bc
+    g = torch.Generator().manual_seed(5 + rank)
+    users = torch.randint(0, Uc, (n_total,), generator=g).to(device)
+    pz = 1.0 / torch.arange(1, Ic + 1, dtype=torch.float64)
+    item_perm = torch.randperm(Ic, generator=torch.Generator().manual_seed(5))   # the same popular items on every rank
+    pos = item_perm[torch.multinomial(pz / pz.sum(), n_total, True, generator=g)].to(device)
+    neg = torch.randint(0, Ic, (n_total,), generator=g).to(device)
+
+    def run(lo, n):
+        for k in range(n):
+            sl = slice(lo + k * Bc, lo + (k + 1) * Bc)
+            eng.train_single_batch((users[sl], pos[sl], neg[sl]), sync=False)
+
+    run(0, warm)
+    per, wall = timed_repeats(lambda r: run(warm * Bc, steps), steps, device, dist_on=True)
+    eng.k.check_status()
+    if rank != 0:
+        return None
+    bpt = algorithmic_bytes_per_triple(Dc)
+    out = {"metric": "training interactions/sec (BPR triples)", "unit": "triples/s"}
+    out.update(timing_fields(per, wall, steps, Bc, world))
+    out.update({"n_gpus": world, "steps": steps, "warmup": warm, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "BPR-MF, BASELINE configs[3]: 10M x 1M rows, dim 128, batch 65536 triples/GPU, "
+                                       "uniform users, Zipf(1.0) positives, exact SGD on touched rows",
+                           "parallelism": f"tables row-sharded over {world} GPUs (owner = row mod {world}); per step "
+                                          "A2A-1 triples -> owner(user), A2A-2 item ids / rows, A2A-3 item-row gradients, "
+                                          "3-float all-reduce",
+                           "global_batch": world * Bc, "rccl_world_size": world},
+                "roofline": {"bound": "hbm", "kernel": "whole sharded step (per GPU)",
+                             "achieved": out["value"] / world * bpt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": out["value"] / world * bpt / (HBM_PEAK_GBS * 1e9),
+                             "algorithmic_bytes_per_launch": bpt * Bc, "traffic": None}})
+    return out
+
+
+def bench_lightgcn(args, device, world=1, rank=0, dist_on=False):
     """BASELINE configs[4]: LightGCN on an ML-1M-sized graph (~1M interactions, nnz ~2M), 3 layers,
     dim 64, batch 1024 triples, keep_pro 0.6 (device-side edge dropout), Adam lr 0.05."""
     import beta_recsys_amd as hp
@@ -336,35 +468,37 @@ def bench_lightgcn(args, device):
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
         eng = hp.LightGCNEngine(cfg)
-    n_total = (args.warmup + args.steps) * Bl
-    users, pos, neg = (t.to(device) for t in synth_triples(n_total, seed=100))
+    K, W = args.steps, args.warmup
+    n_total = (W + K) * Bl
+    users, pos, neg = (t.to(device) for t in synth_triples(n_total, seed=100 + rank))
 
     def run(lo, n):
         for k in range(n):
             sl = slice(lo + k * Bl, lo + (k + 1) * Bl)
             eng._enqueue_step((users[sl], pos[sl], neg[sl]))
 
-    run(0, args.warmup)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.warmup * Bl, args.steps)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    run(0, W)
+    per, wall = timed_repeats(lambda r: run(W * Bl, K), K, device, dist_on)
     st = eng._sync_stats()
+    if rank != 0:
+        return None
     nnz, N = adj.nnz, U + I
     # 2L SpMMs x [nnz*(4+4) + (N+1)*8 + 2*N*D*4] bytes (+ the keep byte per edge)
     bytes_step = 2 * L * (nnz * 9 + (N + 1) * 8 + 2 * N * D * 4)
-    out = {"metric": "training interactions/sec (LightGCN triples)", "value": args.steps * Bl / dt,
-           "unit": "triples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"LightGCN (BASELINE configs[4]): 6040 x 3706 graph, nnz {nnz}, 3 layers, "
-                                  "dim 64, batch 1024, keep_pro 0.6 (device RNG), adam 0.05",
-                      "last_loss": st.loss},
-           "roofline": {"bound": "hbm", "algorithmic_bytes_per_step": bytes_step,
-                        "achieved": bytes_step / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": bytes_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}}
-    print(json.dumps(out), flush=True)
+    out = {"metric": "training interactions/sec (LightGCN triples)", "unit": "triples/s"}
+    out.update(timing_fields(per, wall, K, Bl, world))
+    step_s = out["ms_per_step"] * 1e-3
+    out.update({"n_gpus": world, "steps": K, "warmup": W, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"LightGCN (BASELINE configs[4]): 6040 x 3706 graph, nnz {nnz}, 3 layers, "
+                                       "dim 64, batch 1024, keep_pro 0.6 (device RNG), adam 0.05",
+                           # full-graph propagation per step => replicas only, no data-path collective
+                           "parallelism": f"{world} independent replicas (replicas only, SURVEY 8e)" if dist_on else "single GPU",
+                           "last_loss": st.loss},
+                "roofline": {"bound": "hbm", "algorithmic_bytes_per_step": bytes_step,
+                             "achieved": bytes_step / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": bytes_step / step_s / 1e9 / HBM_PEAK_GBS, "traffic": None}})
+    return out
 
 
 def port_baseline(make_port, batches, units_per_step, what, budget_s=9.0):
@@ -446,11 +580,8 @@ def bench_siblings(args, device):
         eng.enqueue_epoch(*batch_of(slice(lo, lo + n * Bs)))
 
     run(0, args.warmup)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.warmup * Bs, args.steps)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    per, wall = timed_repeats(lambda r: run(args.warmup * Bs, args.steps), args.steps, device)
+    dt = statistics.median(per)   # median over the repeats of one {args.steps}-step pass
     st = eng._sync_stats()
     out = {"metric": f"training interactions/sec ({args.workload} triples)", "value": args.steps * Bs / dt,
            "unit": unit, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -471,7 +602,9 @@ def bench_siblings(args, device):
         else:
             make = lambda: torch_port.TorchT2VPort(w0, Bs, "adam", 5e-4)  # noqa: E731
         out["cpu_baseline"] = port_baseline(make, host, Bs, f"batch {Bs} (same workload)")
-    print(json.dumps(out), flush=True)
+    out.update(repeats=len(per), timed_steps_total=len(per) * args.steps,
+               wall_ms_per_step=wall / (len(per) * args.steps) * 1e3)
+    return out
 
 
 def bench_ngcf(args, device):
@@ -511,11 +644,8 @@ def bench_ngcf(args, device):
             eng._enqueue_step((users[sl], pos[sl], neg[sl]))
 
     run(0, args.warmup)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.warmup * Bn, args.steps)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    per, wall = timed_repeats(lambda r: run(args.warmup * Bn, args.steps), args.steps, device)
+    dt = statistics.median(per)   # median over the repeats of one {args.steps}-step pass
     st = eng._sync_stats()
     nnz, N = adj.nnz, U + I
     act = N * D * 4                      # one [N, D] fp32 activation
@@ -549,7 +679,172 @@ def bench_ngcf(args, device):
                 for k in range(8)]
         make = lambda: torch_port.TorchNGCFPort(w0, norm.coalesce(), [0.1] * L, 1e-5, Bn, "adam", 0.05)  # noqa: E731
         out["cpu_baseline"] = port_baseline(make, host, Bn, f"batch {Bn} on the same graph")
-    print(json.dumps(out), flush=True)
+    out.update(repeats=len(per), timed_steps_total=len(per) * args.steps,
+               wall_ms_per_step=wall / (len(per) * args.steps) * 1e3)
+    return out
+
+
+def traffic_from_profiles(kernel, workload=None):
+    """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) of a kernel from the COMMITTED rocprofv3 PMC passes
+    -- this round's summary if it exists, else round 1's -- as (bytes | None, source file | None).  It is
+    not measured in this run: counters need their own rocprofv3 passes (tools/pmc_workload.sh)."""
+    for rnd in (ROUND, "r01"):
+        try:
+            if workload is None:
+                name = f"{rnd}_pmc_summary.json"
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    k = json.load(f)[kernel]
+                return (k["FETCH_SIZE_KB_mean"] + k["WRITE_SIZE_KB_mean"]) * 1024.0, "profiles/" + name
+            name = f"{rnd}_pmc_other_workloads.json"
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                k = json.load(f)[workload][kernel]
+            return (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0, "profiles/" + name
+        except Exception:
+            continue
+    return None, None
+
+
+def bench_mf(args, device, world, rank, dist_on):
+    """BASELINE configs[1] (the headline).  N = 1: MFEngine's resident epoch (one fused launch per step).
+    N > 1: replicated tables + one all-reduce per step (auto below 64 MB of parameters) or row-sharded
+    tables with all-to-all routing (`--multi-gpu sharded`)."""
+    import beta_recsys_amd as hp
+
+    K, W = args.steps, args.warmup
+    strong = args.scaling == "strong" and world > 1
+    if strong and B % world:
+        raise SystemExit(f"--scaling strong splits the batch of {B} over the ranks: {world} does not divide it")
+    b_local = B // world if strong else B
+    # this rank's triples: one epoch of K steps (re-shuffled and re-staged by every repeat) + W warm-up steps
+    users, pos, neg = (t.to(device) for t in synth_triples((W + K) * b_local, seed=100 + rank))
+    torch.manual_seed(7 + rank)  # keys of the device-side shuffles
+    nw = W * b_local
+    mode = "single"
+    if dist_on:
+        import torch.distributed as dist
+
+        from beta_recsys_amd.replicated import ReplicatedMFEngine
+        from beta_recsys_amd.sharded import ShardedMFEngine
+
+        mode = args.multi_gpu
+        if mode == "auto":
+            mode = "replicated" if 4 * ((U + I) * (D + 1) + 1) < (64 << 20) else "sharded"
+        cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str=str(device), optimizer=args.optimizer,
+                             lr=LR, batch_size=b_local, loss="bpr"),
+               "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
+        torch.manual_seed(2020)
+        with contextlib.redirect_stdout(io.StringIO()):
+            eng = ShardedMFEngine(cfg) if mode == "sharded" else ReplicatedMFEngine(cfg)
+    else:
+        eng = make_engine(device, args.optimizer)
+        eng.fused_step = not args.two_kernel
+    warm = hp.DeviceTripleBatcher(users[:nw], pos[:nw], neg[:nw], b_local) if W > 0 else None
+    timed = hp.DeviceTripleBatcher(users[nw:], pos[nw:], neg[nw:], b_local)
+    assert len(timed) == K
+
+    if mode == "single":
+        def run_epoch(r, loader=timed):
+            # shuffle + staging (taken from the side stream if the previous epoch prefetched it), K fused
+            # steps + the flush, then the NEXT epoch's staging starts on the side stream
+            eng.run_prepared_epoch(eng.prepare_epoch(loader), sync=False, prefetch=loader)
+    elif mode == "replicated":
+        def run_epoch(r, loader=timed):
+            assert eng.run_resident_epoch(loader)
+    else:
+        def run_epoch(r, loader=timed):
+            for batch in loader:  # device-side shuffle, batch views of the resident arrays
+                eng.train_single_batch(batch, sync=False)
+
+    if warm is not None:
+        run_epoch(-1, warm)
+    if mode == "single":
+        eng._drop_prefetch()  # the warm-up's prefetch belongs to another loader
+    torch.cuda.synchronize()
+    per, wall = timed_repeats(run_epoch, K, device, dist_on)
+    R = len(per)
+    if mode == "sharded":
+        eng.k.check_status()
+    else:
+        st = eng.epoch_stats()
+        assert st.step == W + R * K, (st.step, W + R * K)
+        assert np.isfinite(st.loss_sum) and 0.2 < st.loss_sum / K < 1.4, st.loss_sum
+
+    # ---- dominant kernel: its launch period from HIP events on the stream it runs on ------------------
+    probe_s = probe_steps = None
+    if rank == 0:
+        peng = eng if mode == "single" else make_engine(device, args.optimizer)
+        fused = peng.fused_step and mode != "sharded"
+        P = min(max(K, MIN_TIMED_STEPS), 2000)
+        pu, pp, pn = (t.to(device) for t in synth_triples(P * B, seed=99))
+        probe = stage(peng, hp.DeviceTripleBatcher(pu, pp, pn, B))
+        peng.run_prepared_epoch(probe, sync=False)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        peng.run_prepared_epoch(probe, sync=False)
+        e1.record()
+        torch.cuda.synchronize()
+        probe_s, probe_steps = e0.elapsed_time(e1) * 1e-3, P
+        k_mean, _ = kernel_timing(peng, probe)
+
+    parallelism = "single GPU"
+    if dist_on:
+        parallelism = (f"row-sharded tables over {world} GPUs (owner = row mod {world}), all-to-all routing of "
+                       "triples / item rows / item gradients over RCCL"
+                       if mode == "sharded" else
+                       f"dp{world}: replicated 2.5 MB tables, one fused launch + one RCCL all-reduce of the dense "
+                       f"gradient per step, global batch = {world} x {b_local}")
+    if rank != 0:
+        return None
+    n_params = (U + I) * (D + 1) + 1
+    gs_bytes = algorithmic_bytes_per_triple(D) * B                     # gather / scatter rows of one batch
+    step_bytes = gs_bytes + optimizer_sweep_bytes(args.optimizer, n_params)   # SURVEY §8(d) for THIS optimizer
+    kind_id = {"sgd": 0, "adam": 1, "rmsprop": 2}[args.optimizer]
+    if fused:
+        dom_name = (f"mf_bpr_fused_kernel<1,{kind_id}> (gather + score + BPR grad + scatter + "
+                    f"{args.optimizer} update, 1 launch/step)")
+        dom_s = probe_s / (probe_steps + 1)      # P step launches + the sweep-only flush
+        dom_bytes = step_bytes
+        pmc_name = f"hiprec::mf_bpr_fused_kernel<1, {kind_id}, false>"
+    else:
+        dom_name = "mf_bpr_grad_kernel (gather + score + BPR grad + atomic scatter)"
+        dom_s, dom_bytes, pmc_name = k_mean, gs_bytes, "hiprec::mf_bpr_grad_kernel<1>"
+    traffic, traffic_src = traffic_from_profiles(pmc_name)
+    out = {"metric": "training interactions/sec (BPR triples)", "unit": "triples/s"}
+    out.update(timing_fields(per, wall, K, b_local, world))
+    out.update({
+        "n_gpus": world, "steps": K, "warmup": W, "higher_is_better": True,
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "BPR-MF, MovieLens-1M-shaped synthetic (BASELINE configs[1]): 6040 users x 3706 items, "
+                        f"dim 64, batch {b_local} triples/GPU, uniform users, Zipf(1.0) positives, uniform negatives",
+            "optimizer": args.optimizer, "lr": LR, "loss": "bpr", "batch_per_gpu": b_local,
+            "global_batch": b_local * world, "parallelism": parallelism,
+            "rccl_world_size": world if dist_on else None,
+            "timed_region": "per repeat: device shuffle + staging of the epoch (sort of every batch by item, "
+                            "layout; prefetched on a side stream during the previous epoch) + K steps + flush",
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": dom_name,
+            "achieved": dom_bytes / dom_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": dom_bytes / dom_s / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": dom_bytes,
+            "algorithmic_bytes_note": f"SURVEY 8(d): {algorithmic_bytes_per_triple(D)} B/triple x {B} triples"
+                                      + (f" + dense {args.optimizer} sweep {optimizer_sweep_bytes(args.optimizer, n_params)} B"
+                                         if fused and args.optimizer != "sgd" else ""),
+            "kernel_us": dom_s * 1e6, "kernel_us_source": f"HIP events around a {probe_steps}-step resident epoch",
+            "gather_scatter_only": {"algorithmic_bytes_per_launch": gs_bytes, "achieved": gs_bytes / dom_s / 1e9,
+                                    "frac": gs_bytes / dom_s / 1e9 / HBM_PEAK_GBS},
+            "grad_only_kernel_us": k_mean * 1e6,
+            "traffic": traffic, "traffic_source": traffic_src,
+            # whole step, per GPU: (triples/s) x (row bytes per triple + this optimizer's sweep bytes per triple)
+            "step_frac": out["value"] / world * (algorithmic_bytes_per_triple(D) + (step_bytes - gs_bytes) / b_local)
+                         / (HBM_PEAK_GBS * 1e9),
+        },
+    })
+    if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 at N = 1 only
+        out["cpu_baseline"] = cpu_baseline(args.optimizer)
+    return out
 
 
 def main():
@@ -563,20 +858,28 @@ def main():
     ap.add_argument("--two-kernel", action="store_true",
                     help="mf: gradient kernel + dense optimizer sweep per step instead of the fused one-kernel step")
     ap.add_argument("--workload", default="mf", choices=["mf", "ncf", "lightgcn", "mf-c4shard", "mf-c4", "pgmf", "t2v", "ngcf"],
-                    help="mf = BASELINE configs[1] (the headline); ncf = configs[2] (NeuMF, emb_dim 32)")
+                    help="mf = BASELINE configs[1] (the headline); ncf = configs[2]; mf-c4 = configs[3] "
+                         "(whole on one GPU at --gpus 1, row-sharded over the ranks at --gpus N); lightgcn = configs[4]")
+    ap.add_argument("--emb-dim", type=int, default=32, help="ncf: 32 (tower 256-128-64-32, primary) or 64")
     ap.add_argument("--multi-gpu", default="auto", choices=["auto", "replicated", "sharded"],
-                    help="N>1: replicate small tables (gradient all-reduce) or row-shard them "
+                    help="mf, N>1: replicate small tables (gradient all-reduce) or row-shard them "
                          "(all-to-all routing); auto = replicated below 64 MB of parameters")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = every rank feeds a full batch (global batch N x B); strong = the reference's "
+                         "batch split over the ranks (global batch = B, identical semantics to one GPU)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPUs are visible")
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     # HIPREC_BENCH_FORCE_SHARDED=1 exercises the N>1 code path on a single GPU (world size 1)
@@ -584,199 +887,29 @@ def main():
     if dist_on:
         import torch.distributed as dist
 
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
-
-    import beta_recsys_amd as hp
+        assert dist.get_world_size() == world
 
     if args.workload == "ncf":
-        return bench_ncf(args, device)
-    if args.workload == "lightgcn":
-        return bench_lightgcn(args, device)
-    if args.workload in ("pgmf", "t2v"):
-        return bench_siblings(args, device)
-    if args.workload == "ngcf":
-        return bench_ngcf(args, device)
-    if args.workload in ("mf-c4shard", "mf-c4"):
-        return bench_mf_c4shard(args, device, full=args.workload == "mf-c4")
-
-    n_total = (args.warmup + args.steps) * B
-    users, pos, neg = (t.to(device) for t in synth_triples(n_total, seed=100 + rank))
-    torch.manual_seed(7 + rank)  # device-side randperm per epoch
-    nw = args.warmup * B
-    prepared = None
-    if not dist_on:
-        eng = make_engine(device, args.optimizer)
-        eng.fused_step = not args.two_kernel
-        warm = hp.DeviceTripleBatcher(users[:nw], pos[:nw], neg[:nw], B)
-        timed = hp.DeviceTripleBatcher(users[nw:], pos[nw:], neg[nw:], B)
-        if args.warmup > 0:
-            eng.run_prepared_epoch(stage(eng, warm))
-        torch.cuda.synchronize()
-        ts0 = time.perf_counter()
-        prepared = stage(eng, timed)  # per-epoch staging: permutation, per-batch sort by item, layout
-        staging_s = time.perf_counter() - ts0
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ev0.record()
-        eng.run_prepared_epoch(prepared, sync=False)  # enqueues exactly args.steps steps
-        ev1.record()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        epoch_event_s = ev0.elapsed_time(ev1) * 1e-3
-        assert len(timed) == args.steps
-        st = eng.epoch_stats()
-        assert st.step == args.warmup + args.steps, (st.step, args.warmup + args.steps)
-        assert np.isfinite(st.loss_sum) and 0.3 < st.loss_sum / args.steps < 1.4, st.loss_sum
+        out = bench_ncf(args, device, world, rank, dist_on)
+    elif args.workload == "lightgcn":
+        out = bench_lightgcn(args, device, world, rank, dist_on)
+    elif args.workload in ("pgmf", "t2v"):
+        out = bench_siblings(args, device) if not dist_on else None
+    elif args.workload == "ngcf":
+        out = bench_ngcf(args, device) if not dist_on else None
+    elif args.workload in ("mf-c4shard", "mf-c4"):
+        out = (bench_mf_c4_sharded(args, device, world, rank) if dist_on and args.workload == "mf-c4"
+               else bench_mf_c4shard(args, device, full=args.workload == "mf-c4"))
     else:
-        # N > 1: tables row-sharded over the ranks (owner = row mod N), every rank feeds B triples
-        # per step (weak scaling, global batch N*B), triples / item rows / item gradients are
-        # routed with all-to-all over RCCL (beta-recsys_amd/sharded.py).
-        from beta_recsys_amd.replicated import ReplicatedMFEngine
-        from beta_recsys_amd.sharded import ShardedMFEngine
-
-        cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str=str(device),
-                             optimizer=args.optimizer, lr=LR, batch_size=B, loss="bpr"),
-               "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
-        param_bytes = 4 * ((U + I) * (D + 1) + 1)
-        mode = args.multi_gpu
-        if mode == "auto":
-            mode = "replicated" if param_bytes < (64 << 20) else "sharded"
-        torch.manual_seed(2020)
-        with contextlib.redirect_stdout(io.StringIO()):
-            seng = ShardedMFEngine(cfg) if mode == "sharded" else ReplicatedMFEngine(cfg)
-        perm = torch.randperm(n_total, device=device)
-        if mode == "replicated":  # stage the epoch like the single-GPU path: batches sorted by item
-            from beta_recsys_amd.mf import sort_within_batches
-
-            perm = sort_within_batches(perm, pos, B, I)
-            seng.presorted = True
-        users, pos, neg = users[perm], pos[perm], neg[perm]
-        if mode == "sharded":
-            step_fn = lambda batch: seng.train_single_batch(batch, sync=False)  # noqa: E731
-            check_fn = seng.k.check_status
-        else:
-            # resident data-parallel epoch: one fused launch + one all-reduce per step; the sweep-only
-            # flush that applies the last update is part of the timed region
-            step_fn = None
-            check_fn = seng.epoch_stats
-
-        def run(lo, n_steps):
-            last = None
-            if mode != "sharded":
-                pu, pp, pn = users.data_ptr(), pos.data_ptr(), neg.data_ptr()
-                seng.fused_epoch_begin()
-                for sidx in range(n_steps):
-                    off = 8 * (lo + sidx * B)
-                    seng.fused_step_ptr(pu + off, pp + off, pn + off, B)
-                seng.fused_epoch_end()
-                return last
-            for sidx in range(n_steps):
-                sl = slice(lo + sidx * B, lo + (sidx + 1) * B)
-                last = step_fn((users[sl], pos[sl], neg[sl]))
-            return last
-
-        run(0, args.warmup)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run(nw, args.steps)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        st = check_fn()
-        if mode != "sharded":   # the replicas' loss sums are global: same sanity window as the single-GPU path
-            assert st.step == args.warmup + args.steps, (st.step, args.warmup + args.steps)
-            assert np.isfinite(st.loss_sum) and 0.3 < st.loss_sum / args.steps < 1.4, st.loss_sum
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        if rank == 0:  # roofline of the dominant kernel: measured on a single-GPU engine
-            eng = make_engine(device, args.optimizer)
-            prepared = stage(eng, hp.DeviceTripleBatcher(users[:4 * B], pos[:4 * B], neg[:4 * B], B))
-            if mode == "replicated":
-                # the replicas run the same fused step kernel as the single-GPU epoch: its launch period
-                # from HIP events around a short resident epoch on this rank's GPU
-                n_ev = min(args.steps, 200)
-                probe = stage(eng, hp.DeviceTripleBatcher(users[:n_ev * B], pos[:n_ev * B], neg[:n_ev * B], B))
-                eng.run_prepared_epoch(probe, sync=False)
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda.synchronize()
-                ev0.record()
-                eng.run_prepared_epoch(probe, sync=False)
-                ev1.record()
-                torch.cuda.synchronize()
-                epoch_event_s, event_steps = ev0.elapsed_time(ev1) * 1e-3, n_ev
-
-    parallelism = "single GPU"
-    if dist_on:
-        parallelism = (f"row-sharded tables over {world} GPUs (owner = row mod {world}), all-to-all "
-                       "routing of triples / item rows / item gradients over RCCL"
-                       if mode == "sharded" else
-                       f"dp{world}: replicated 2.5 MB tables, one fused launch + one RCCL all-reduce of the "
-                       "dense gradient per step, global batch = N x 4096")
-    if rank == 0:
-        k_mean, k_med = kernel_timing(eng, prepared)
-        bpt = algorithmic_bytes_per_triple(D)
-        fused = eng.fused_step and (not dist_on or mode == "replicated")
-        kind_id = {"sgd": 0, "adam": 1, "rmsprop": 2}[args.optimizer]
-        if fused:
-            # ONE kernel per step (gather + score + gradient scatter + the optimizer update of the
-            # previous step): its launch period, from HIP events around the timed epoch, is what
-            # the algorithmic bytes of a step are divided by
-            dom_name = (f"mf_bpr_fused_kernel<1,{kind_id}> (gather + score + BPR grad + scatter + "
-                        f"{args.optimizer} update, 1 launch/step)")
-            dom_s = epoch_event_s / ((event_steps if dist_on else args.steps) + 1)
-        else:
-            dom_name = "mf_bpr_grad_kernel (gather + score + BPR grad + atomic scatter)"
-            dom_s = k_mean
-        achieved = bpt * B / dom_s / 1e9
-        out = {
-            "metric": "training interactions/sec (BPR triples)",
-            "value": world * args.steps * B / dt,
-            "unit": "triples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": "BPR-MF, MovieLens-1M-shaped synthetic (BASELINE configs[1]): 6040 users x "
-                            "3706 items, dim 64, batch 4096 triples/GPU, uniform users, Zipf(1.0) "
-                            "positives, uniform negatives",
-                "optimizer": args.optimizer, "lr": LR, "loss": "bpr", "batch_per_gpu": B,
-                "global_batch": B * world,
-                "parallelism": parallelism,
-            },
-            "epoch_staging": None if dist_on else {
-                "ms": staging_s * 1e3,
-                "what": "per-epoch device-side batcher work outside the timed region: randperm, sort of "
-                        "every batch by item, gather of the triples into visiting order",
-                "value_including_staging": args.steps * B / (dt + staging_s),
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": dom_name,
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": bpt * B,
-                "kernel_us": dom_s * 1e6,
-                "grad_only_kernel_us": k_mean * 1e6,
-                "traffic": measured_traffic_bytes(f"hiprec::mf_bpr_fused_kernel<1, {kind_id}, false>" if fused
-                                                 else "hiprec::mf_bpr_grad_kernel<1>"),
-                "step_frac": (world * args.steps * B / dt) / world * bpt / (HBM_PEAK_GBS * 1e9),
-            },
-        }
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args.optimizer)
+        out = bench_mf(args, device, world, rank, dist_on)
+    if dist_on and args.workload in ("pgmf", "t2v", "ngcf"):
+        raise SystemExit(f"--workload {args.workload} is single-GPU (no data-parallel wrapper)")
+    if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()

@@ -252,6 +252,7 @@ SIGNATURES = {
         [_P, c_int64, _P, _P, POINTER(c_int32), c_int32, _P, c_size_t, _P, _P],
     ),
     "hiprec_stage_epoch": (c_int, [_P, _P, _P, c_int32, _P, c_int64, c_int64, _P, _P, _P, _P]),
+    "hiprec_stage_epoch_shuffled": (c_int, [_P, _P, _P, c_int32, ctypes.c_uint64, c_int64, c_int64, _P, _P, _P, _P]),
     "hiprec_mf_bce_epoch": (
         c_int,
         [_T, _T, _P, _P, _P, _P, c_int64, c_int64, c_float, c_int]

@@ -312,6 +312,14 @@ class DeviceTripleBatcher:
         n = len(self.user_tensor)
         return (n + self.batch_size - 1) // self.batch_size
 
+    def draw_seed(self):
+        """Key of one epoch's Feistel shuffle, drawn from torch's global CPU generator."""
+        return int(torch.randint(0, 2**62, (1,)).item())
+
+    def native_shuffle(self):
+        """True when an epoch's order is P_seed of the device shuffle (no materialised permutation needed)."""
+        return self.shuffle and self.generator is None and self.user_tensor.device.type == "cuda"
+
     def permutation(self):
         """One epoch's visiting order (int64, on the triples' device); None = sequential."""
         if not self.shuffle:
@@ -324,7 +332,7 @@ class DeviceTripleBatcher:
             return torch.randperm(n)
         # native shuffle: a Feistel bijection keyed by a seed drawn from torch's global CPU generator
         # (so torch.manual_seed controls it), no sort
-        seed = int(torch.randint(0, 2**62, (1,)).item())
+        seed = self.draw_seed()
         perm = torch.empty(n, dtype=torch.int64, device=dev)
         _lib.check(_lib.load().hiprec_random_permutation(_lib.ptr(perm), n, seed, _lib.stream_ptr(dev)))
         return perm
@@ -550,8 +558,13 @@ class MFEngine(ModelEngine):
     # ---- one epoch --------------------------------------------------------------------------
     def _resident_triples(self, train_loader):
         """(users, pos, neg, perm) when the loader's data is resident and can be batched on device."""
+        seed = None
         if isinstance(train_loader, DeviceTripleBatcher):
-            ds, perm = train_loader, train_loader.permutation()
+            if (train_loader.native_shuffle() and train_loader.batch_size <= 8192
+                    and train_loader.user_tensor.device == self.model.flat.device):
+                ds, perm, seed = train_loader, None, train_loader.draw_seed()  # shuffle folded into the staging kernel
+            else:
+                ds, perm = train_loader, train_loader.permutation()
         elif (self.loss == "bce" and len(getattr(train_loader, "tensors", ())) == 3
               and train_loader.tensors[2].is_floating_point() and hasattr(train_loader, "permutation")):
             # data.DeviceTensorBatcher of (user, item, rating): the device-side instance_bce_loader
@@ -586,11 +599,8 @@ class MFEngine(ModelEngine):
         if bs <= 8192 and dev.type == "cuda":
             # native batcher: one block per batch sorts it by item in LDS and writes the epoch in
             # visiting order (hiprec_stage_epoch)
-            lib = _lib.load()
             ou, op, on = torch.empty_like(users), torch.empty_like(pos), torch.empty_like(neg)
-            _lib.check(lib.hiprec_stage_epoch(
-                _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), neg.element_size(), _lib.ptr(perm),
-                users.numel(), bs, _lib.ptr(ou), _lib.ptr(op), _lib.ptr(on), _lib.stream_ptr(dev)))
+            self._stage_into(users, pos, neg, perm, seed, bs, ou, op, on)
             return ou, op, on, None, bs
         if bs >= self.SORT_MIN_BATCH:
             perm = sort_within_batches(perm, pos, bs, self.model.n_items)
@@ -600,10 +610,83 @@ class MFEngine(ModelEngine):
             users, pos, neg, perm = users[perm], pos[perm], neg[perm], None
         return users, pos, neg, perm, bs
 
+    def _stage_into(self, users, pos, neg, perm, seed, bs, ou, op, on):
+        """hiprec_stage_epoch[_shuffled] on the current stream: one block per batch gathers it in visiting
+        order (perm[], P_seed on the fly, or sequential), sorts it by item in LDS and writes it out."""
+        lib, dev = _lib.load(), users.device
+        if seed is not None:
+            _lib.check(lib.hiprec_stage_epoch_shuffled(
+                _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), neg.element_size(), seed, users.numel(), bs,
+                _lib.ptr(ou), _lib.ptr(op), _lib.ptr(on), _lib.stream_ptr(dev)))
+        else:
+            _lib.check(lib.hiprec_stage_epoch(
+                _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), neg.element_size(), _lib.ptr(perm),
+                users.numel(), bs, _lib.ptr(ou), _lib.ptr(op), _lib.ptr(on), _lib.stream_ptr(dev)))
+
+    # ---- next-epoch prefetch ---------------------------------------------------------------------
+    # TrainEngine._train (core/train_engine.py:225-240) calls train_an_epoch with the SAME loader every
+    # epoch and evaluates in between.  The staging of epoch r+1 (shuffle + per-batch sort + layout) does
+    # not depend on the weights, so it runs on a side stream while epoch r trains (it occupies one CU per
+    # batch for a few tens of microseconds) into one of two persistent buffer sets.
+    def _can_prefetch(self, train_loader):
+        return (isinstance(train_loader, DeviceTripleBatcher) and self.loss == "bpr"
+                and train_loader.native_shuffle() and train_loader.batch_size <= 8192
+                and train_loader.user_tensor.device == self.model.flat.device
+                and len(train_loader.user_tensor) > 0)
+
+    def prefetch_epoch(self, train_loader):
+        """Stage the NEXT epoch of ``train_loader`` on a side stream.  The following
+        :meth:`prepare_epoch` with the same loader object takes it (after making the current stream
+        wait for it).  A prepared epoch obtained this way stays valid until the second prefetch after
+        it.  Returns False when the loader cannot be staged ahead."""
+        if not self._can_prefetch(train_loader):
+            return False
+        self._drop_prefetch()
+        dev = self.model.flat.device
+        main = torch.cuda.current_stream(dev)
+        pf = getattr(self, "_pf", None)
+        if pf is None or pf["dev"] != dev:
+            pf = self._pf = {"dev": dev, "side": torch.cuda.Stream(dev), "slots": [None, None], "next": 0}
+        users, pos, neg = train_loader.user_tensor, train_loader.pos_item_tensor, train_loader.neg_item_tensor
+        k = pf["next"]
+        pf["next"] = 1 - k
+        slot = pf["slots"][k]
+        if slot is None or slot[0].numel() != users.numel():
+            # allocated with the SIDE stream current: the caching allocator keeps one pool per stream, so
+            # these can never be blocks that kernels still in flight on the main stream were just reading
+            with torch.cuda.stream(pf["side"]):
+                slot = pf["slots"][k] = tuple(torch.empty_like(t) for t in (users, pos, neg))
+        seed = train_loader.draw_seed()
+        begin = getattr(self, "_ev_epoch_begin", None)
+        if begin is not None:
+            # everything enqueued before the epoch that is running now (in particular the epoch that last
+            # read this slot) is complete when the side stream starts; the running epoch is NOT waited for
+            pf["side"].wait_event(begin)
+        else:
+            pf["side"].wait_stream(main)
+        with torch.cuda.stream(pf["side"]):
+            self._stage_into(users, pos, neg, None, seed, train_loader.batch_size, *slot)
+            done = torch.cuda.Event()
+            done.record(pf["side"])
+        self._prefetched = (train_loader, done, slot + (None, train_loader.batch_size))
+        return True
+
+    def _drop_prefetch(self):
+        pending = getattr(self, "_prefetched", None)
+        if pending is not None:
+            torch.cuda.current_stream(self.model.flat.device).wait_event(pending[1])
+            self._prefetched = None
+
     def prepare_epoch(self, train_loader):
         """Stage one epoch's inputs in HBM: resident triple arrays + this epoch's visiting order.
         Returns an opaque tuple for :meth:`run_prepared_epoch`, or None when the loader's data
         cannot be batched on the device (then train_an_epoch falls back to iterating it)."""
+        pending = getattr(self, "_prefetched", None)
+        if pending is not None:
+            self._prefetched = None
+            torch.cuda.current_stream(self.model.flat.device).wait_event(pending[1])
+            if pending[0] is train_loader:
+                return pending[2]
         if self.loss not in ("bpr", "bce") or isinstance(train_loader, (list, tuple)):
             return None
         if self.loss == "bce" and isinstance(train_loader, DeviceTripleBatcher):
@@ -652,14 +735,24 @@ class MFEngine(ModelEngine):
             if opt.exp_avg_sq is not None:
                 opt.exp_avg_sq.copy_(fb["v_alt"])
 
-    def run_prepared_epoch(self, prepared, sync=True):
+    def run_prepared_epoch(self, prepared, sync=True, prefetch=None):
         """Enqueue every step of a prepared epoch (hiprec_mf_bpr_epoch, or the fused one-kernel-per-
-        step driver for plain SGD).  With ``sync=False`` nothing is read back; call
-        :meth:`epoch_stats` later."""
+        step driver).  With ``sync=False`` nothing is read back; call :meth:`epoch_stats` later.
+        ``prefetch`` = the loader whose NEXT epoch is to be staged on the side stream meanwhile
+        (:meth:`prefetch_epoch`; issued before this epoch's launches so that the host does not hand it
+        to the GPU only when the epoch is nearly over)."""
         lib = self._setup()
         users, pos, neg, perm, bs = prepared
         n = users.numel()
         n_run = n - 1 if n % bs == 1 else n  # Q4: a trailing batch of one raises (below)
+        self._ev_epoch_begin = torch.cuda.Event()
+        self._ev_epoch_begin.record(torch.cuda.current_stream(self.model.flat.device))
+        # the staged arrays must outlive the kernels that read them: a caller's temporary would be freed as soon
+        # as this call returns, with the epoch still in flight (fine for later work on THIS stream, not for the
+        # side-stream staging of the next epoch).  Held until the next epoch replaces them.
+        self._epoch_inputs = prepared
+        if prefetch is not None:
+            self.prefetch_epoch(prefetch)
         if self._fused_ok(perm):
             self._run_fused_epoch(lib, users, pos, neg, n_run, bs)
             if not sync:
@@ -701,7 +794,13 @@ class MFEngine(ModelEngine):
         lib = self._setup()
         prepared = self.prepare_epoch(train_loader)
         if prepared is not None:
-            st = self.run_prepared_epoch(prepared)
+            # the next epoch's shuffle + staging overlaps this one (side stream)
+            ahead = train_loader if self.config["model"].get("prefetch_epoch", True) else None
+            self.run_prepared_epoch(prepared, sync=False, prefetch=ahead)
+            n, bs = prepared[0].numel(), prepared[4]
+            st = self._sync_stats()
+            if n % bs == 1:  # Q4: a trailing batch of one raises in the reference
+                raise IndexError("Dimension out of range (expected to be in range of [-1, 0], but got 1)")
         else:
             _lib.check(lib.hiprec_stats_begin_epoch(
                 _lib.ptr(self._stats), _lib.stream_ptr(self.model.flat.device)))

@@ -211,23 +211,53 @@ class ReplicatedMFEngine(MFEngine):
         """Replicas iterate their loader batch by batch (one collective per step)."""
         return None
 
+    def _check_equal_batches(self, n, bs):
+        """Every step is one collective and scales by 1/(n * world) with the LOCAL n: all ranks must hold the
+        same number of triples and use the same batch size (checked once per loader shape, one host sync)."""
+        key = (n, bs)
+        if getattr(self, "_checked_shape", None) == key:
+            return
+        t = torch.tensor([n, -n, bs, -bs], dtype=torch.int64, device=self.model.flat.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+        hi_n, lo_n, hi_b, lo_b = (int(x) for x in t.cpu())
+        if hi_n != -lo_n or hi_b != -lo_b:
+            raise ValueError(
+                f"data-parallel replicas need the same local epoch on every rank: this rank has {n} triples in "
+                f"batches of {bs}, the group spans {-lo_n}..{hi_n} triples / batches of {-lo_b}..{hi_b}")
+        self._checked_shape = key
+
+    def run_resident_epoch(self, train_loader):
+        """Enqueue one whole epoch of a device-resident loader without reading anything back: the staging of
+        this rank's share (MFEngine's device batcher, taken from the side stream when the previous epoch
+        prefetched it), one fused launch + one all-reduce per step, the flush, and the prefetch of the next
+        epoch's staging.  Returns False when the loader cannot run resident (caller iterates it instead)."""
+        self._setup()
+        if self.loss != "bpr" or self.model.emb_dim > 256 or isinstance(train_loader, (list, tuple)):
+            return False
+        staged = MFEngine.prepare_epoch(self, train_loader)   # this rank's share, laid out in visiting order
+        if staged is None or staged[3] is not None:
+            return False
+        users, pos, neg, _, bs = staged
+        n = users.numel()
+        self._check_equal_batches(n, bs)
+        self._ev_epoch_begin = torch.cuda.Event()
+        self._ev_epoch_begin.record(torch.cuda.current_stream(self.model.flat.device))
+        self._last_staged = staged   # keeps the arrays alive until the next epoch replaces them
+        if self.config["model"].get("prefetch_epoch", True):
+            self.prefetch_epoch(train_loader)   # next epoch's staging, on the side stream, while this one runs
+        self.fused_epoch_begin()
+        pu, pp, pn = users.data_ptr(), pos.data_ptr(), neg.data_ptr()
+        for off in range(0, n, bs):
+            self.fused_step_ptr(pu + 8 * off, pp + 8 * off, pn + 8 * off, min(bs, n - off))
+        self.fused_epoch_end()
+        return True
+
     def train_an_epoch(self, train_loader, epoch_id):
         lib = self._setup()
         dev = self.model.flat.device
-        staged = None
-        if self.loss == "bpr" and self.model.emb_dim <= 256 and not isinstance(train_loader, (list, tuple)):
-            staged = self._resident_triples(train_loader)   # this rank's share, laid out in visiting order
-            if staged is not None and staged[3] is not None:
-                staged = None
-        if staged is not None:
-            # resident loader: one fused launch + one all-reduce per step; every rank must hold the same
-            # number of batches (one collective per step), as with any data-parallel loader
-            users, pos, neg, _, bs = staged
-            self.fused_epoch_begin()
-            n, pu, pp, pn = users.numel(), users.data_ptr(), pos.data_ptr(), neg.data_ptr()
-            for off in range(0, n, bs):
-                self.fused_step_ptr(pu + 8 * off, pp + 8 * off, pn + 8 * off, min(bs, n - off))
-            self.fused_epoch_end()
+        if self.run_resident_epoch(train_loader):
+            # resident loader: every rank must hold the same number of batches (one collective per step), as
+            # with any data-parallel loader
             st = self._sync_stats()
             total_loss, total_reg = st.loss_sum, st.reg_sum  # already global
         else:

@@ -203,15 +203,22 @@ class ShardedMFEngine:
         local_cfg = dict(mc)
         local_cfg["n_users"] = shard_rows(self.n_users, r, R)
         local_cfg["n_items"] = shard_rows(self.n_items, r, R)
-        if full_state is None:
+        local_init = full_state is None and mc.get("shard_init", "full") == "local"
+        if full_state is None and not local_init:
             # Same initial model on every world size: draw the full tables like the single-process
             # model does (same torch seed -> same weights), keep this rank's rows.
             with contextlib.redirect_stdout(io.StringIO()):
                 full = MF(dict(mc, device_str="cpu"))
             full_state = full.state_dict()
         with torch.random.fork_rng(devices=[]):
-            self.model = MF(local_cfg)
-        self.load_full_state_dict(full_state)
+            if local_init:
+                # `shard_init: "local"`: every rank draws only its own rows (tables too large to draw whole on
+                # every rank: configs[3] is 5.7 GB); same distribution, not the single-process stream
+                torch.manual_seed(torch.initial_seed() + 7919 * (r + 1))
+            with contextlib.redirect_stdout(io.StringIO()):
+                self.model = MF(local_cfg)
+        if not local_init:
+            self.load_full_state_dict(full_state)
         self.model.to(self.device)
         self.k = kernels if kernels is not None else HipKernels(self.device)
         self.k.reset_clock(self.optimizer.beta1 or 0.9, self.optimizer.beta2 or 0.999)

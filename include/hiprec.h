@@ -219,6 +219,12 @@ int hiprec_random_permutation(int64_t* out, int64_t n, uint64_t seed, void* stre
 int hiprec_stage_epoch(const int64_t* users, const int64_t* items, const void* third,
                        int32_t third_bytes, const int64_t* perm, int64_t n, int64_t batch,
                        int64_t* out_users, int64_t* out_items, void* out_third, void* stream);
+/* The same with the shuffle folded in: the visiting order is P_seed of hiprec_random_permutation, evaluated on
+ * the fly (no perm[] array, one launch per epoch).  Bit-identical to hiprec_random_permutation(seed) followed
+ * by hiprec_stage_epoch(perm). */
+int hiprec_stage_epoch_shuffled(const int64_t* users, const int64_t* items, const void* third,
+                                int32_t third_bytes, uint64_t seed, int64_t n, int64_t batch,
+                                int64_t* out_users, int64_t* out_items, void* out_third, void* stream);
 
 /* ---- one whole epoch of MF-BPR training enqueued back to back (MFEngine.train_an_epoch,
  * mf.py:121-139, with the DataLoader replaced by perm[] slices of the resident triple arrays;

@@ -635,7 +635,8 @@ def test_stage_epoch_kernel(hip_device, batch, third_kind):
     rng = np.random.default_rng(batch)
     n = 3 * batch + batch // 3 + 1
     users = rng.integers(0, 10_000, n)
-    items = rng.integers(0, 500, n)
+    # float32 case: a small catalogue (32-bit (item, position) keys); int64 case: ids beyond 2^19 (64-bit keys)
+    items = rng.integers(0, 500, n) if third_kind == "float32" else rng.integers(0, 2**31 - 1, n) // rng.choice([1, 4096], n)
     third = rng.integers(0, 10_000, n) if third_kind == "int64" else rng.random(n).astype(np.float32)
     perm = rng.permutation(n)
     tu, ti, tt, tp = (torch.from_numpy(a).cuda() for a in (users, items, third, perm))
@@ -781,3 +782,83 @@ def test_c1_config_against_the_reference_run(hip_device):
         head = got[k].reshape(-1)[:64]
         close = np.abs(head - g[f"head/{k}"]) <= 2e-3 * max(np.abs(g[f"head/{k}"]).max(), 1e-3)
         assert close.mean() >= 0.9, f"{k}: {close.mean():.2f} of the sampled weights agree"
+
+
+@pytest.mark.parametrize("batch", [64, 1000, 4096])
+def test_stage_epoch_shuffled_equals_permutation_then_stage(hip_device, batch):
+    """The shuffle folded into the staging kernel (P_seed evaluated on the fly) lays the epoch out exactly as
+    hiprec_random_permutation(seed) followed by hiprec_stage_epoch(perm) does -- bit for bit."""
+    from beta_recsys_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(batch)
+    n = 5 * batch + 17
+    tu, ti, tt = (torch.from_numpy(rng.integers(0, 3000, n)).cuda() for _ in range(3))
+    st = _lib.stream_ptr(hip_device)
+    for seed in (1, 0x1234_5678_9ABC_DEF0):
+        perm = torch.empty(n, dtype=torch.int64, device=hip_device)
+        _lib.check(lib.hiprec_random_permutation(_lib.ptr(perm), n, seed, st))
+        a = [torch.zeros_like(tu) for _ in range(3)]
+        b = [torch.zeros_like(tu) for _ in range(3)]
+        _lib.check(lib.hiprec_stage_epoch(_lib.ptr(tu), _lib.ptr(ti), _lib.ptr(tt), 8, _lib.ptr(perm), n, batch,
+                                          *(_lib.ptr(x) for x in a), st))
+        _lib.check(lib.hiprec_stage_epoch_shuffled(_lib.ptr(tu), _lib.ptr(ti), _lib.ptr(tt), 8, seed, n, batch,
+                                                   *(_lib.ptr(x) for x in b), st))
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        # and it IS a shuffle of whole triples: same multiset, not the identity order
+        got = sorted(zip(*(x.cpu().tolist() for x in b)))
+        want = sorted(zip(tu.cpu().tolist(), ti.cpu().tolist(), tt.cpu().tolist()))
+        assert got == want
+
+
+def test_next_epoch_prefetch_is_the_same_training_run(hip_device):
+    """train_an_epoch stages the NEXT epoch on a side stream while the current one trains (TrainEngine._train,
+    core/train_engine.py:225-240, passes the same loader every epoch).  With the same torch seed the shuffle
+    keys are drawn in the same order, so three epochs with and without the prefetch visit the same batches:
+    same per-epoch loss sums, same weights (up to the order of the fp32 atomics)."""
+    import beta_recsys_amd as hp
+
+    U, I, D, B, N = 500, 300, 64, 256, 256 * 9 + 40
+    rng = np.random.default_rng(3)
+    triples = [torch.from_numpy(rng.integers(0, hi, N)).cuda() for hi in (U, I, I)]
+    w0 = onp.init_params(U, I, D, seed=3)
+    runs = []
+    for prefetch in (True, False):
+        eng = make_engine(U, I, D, "adam", "bpr", 0.01, B, prefetch_epoch=prefetch)
+        load_weights(eng, w0)
+        loader = hp.DeviceTripleBatcher(*triples, B)
+        torch.manual_seed(11)
+        sums = []
+        for epoch in range(3):
+            with contextlib.redirect_stdout(io.StringIO()):
+                eng.train_an_epoch(loader, epoch)
+            sums.append(eng.epoch_stats().loss_sum)
+            if prefetch:
+                assert getattr(eng, "_prefetched", None) is not None and eng._prefetched[0] is loader
+        # a different loader object must not be served the pending prefetch
+        other = hp.DeviceTripleBatcher(*triples, B, shuffle=False)
+        prepared = eng.prepare_epoch(other)
+        assert torch.equal(prepared[1][:B].sort().values, triples[1][:B].sort().values)
+        assert getattr(eng, "_prefetched", None) is None
+        runs.append((sums, get_weights(eng)))
+    (sa, wa), (sb, wb) = runs
+    for a, b in zip(sa, sb):
+        assert_scalar_close(a, b, 1e-5, "epoch loss sum with / without prefetch")
+    for k in KEYS:
+        assert_tensor_close(wa[k], wb[k], 2e-4, f"{k} after 3 epochs with / without prefetch")
+
+
+def test_engine_on_a_device_that_is_not_current(hip_device):
+    """the reference never calls set_device and TrainEngine.get_device hands out 'cuda:N'; every
+    libhiprec launch must go to the device its tensors live on even while another device is current."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    g = load_golden("mf_bpr_adam")
+    assert torch.cuda.current_device() == 0
+    eng = engine_for_case(g, device_str="cuda:1")
+    w0 = params(g, "w0")
+    load_weights(eng, w0)
+    loss, reg = eng.train_single_batch(batch_of(g, 0))
+    assert torch.cuda.current_device() == 0
+    assert_scalar_close(loss, g["losses"][0], what="loss on cuda:1 while cuda:0 is current")
