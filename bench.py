@@ -5,18 +5,21 @@
 
 A "step" is one pass of the hot path over one batch of B = 4096 synthetic (user, pos, neg) triples:
 gather -> score -> BPR gradient -> scatter into the dense gradient -> optimizer update (exactly
-the work of MFEngine.train_single_batch in the reference, beta_rec/models/mf.py:92-119).  The triples
-are resident in HBM when the clock starts; everything an epoch of K steps does on top of them is INSIDE
-the timed region: the per-epoch shuffle, the staging of the epoch (per-batch sort by item + layout), the
-K fused steps and the flush that applies the last update.
+the work of MFEngine.train_single_batch in the reference, beta_rec/models/mf.py:92-119).  The workload is
+continuous training on the C2 data set of SURVEY.md §8(d): ~1 M triples per epoch (245 batches), resident in
+HBM when the clock starts; the engine trains epoch after epoch of it exactly as TrainEngine._train drives
+train_an_epoch.  Everything an epoch does on top of the resident triples is INSIDE the timed region: the
+per-epoch device shuffle, the staging of the epoch (per-batch sort by item + layout; it runs on a side
+stream while the previous epoch trains), the 245 fused steps and the flush launch that applies the last update.
 
-Timing (>= 200 timed steps, median of >= 5 repeats): the K-step epoch is repeated
-R = max(5, ceil(200 / K)) times; `ms_per_step` is the MEDIAN over the repeats of (epoch time / K), `value`
-follows from it, `steps` stays K and `repeats` says R; `wall_ms_per_step` is the plain wall clock of
-the whole R x K region (first staging and launch latency included) for cross-checking.  N = 1: the R
-epochs are enqueued back to back and delimited by HIP events on the stream they run on (a host
-synchronize per 0.2 ms epoch would measure the synchronize).  N > 1: every repeat is bracketed by
-barrier + torch.cuda.synchronize() on both sides and the MAX over ranks is taken per repeat.
+Timing (>= 200 timed steps, median of >= 5 repeats): after W warm-up steps the next K steps
+are timed, R = max(5, ceil(200 / K)) times in a row (each repeat continues where the last one stopped, across
+epoch boundaries); `ms_per_step` is the MEDIAN over the repeats of (time of the K steps / K), `value` follows
+from it, `steps` stays K and `repeats` says R; `wall_ms_per_step` is the plain wall clock of the whole R x K
+region (launch latency of the first step included) for cross-checking.  N = 1: the repeats are enqueued back
+to back and delimited by HIP events on the stream they run on (a host synchronize per 0.2 ms window would
+measure the synchronize).  N > 1: every repeat is bracketed by barrier + torch.cuda.synchronize() on both
+sides and the MAX over ranks is taken per repeat.
 
 `python bench.py --gpus N` without a torch.distributed environment starts its own N ranks (re-exec
 through torch.distributed.run on 127.0.0.1); under torchrun it uses RANK / LOCAL_RANK / WORLD_SIZE as
@@ -44,6 +47,7 @@ U, I, D, B = 6040, 3706, 64, 4096
 LR = 0.05
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec peak)
 MIN_TIMED_STEPS, MIN_REPEATS = 200, 5
+EPOCH_STEPS = 245  # N = 1 000 000 triples per epoch -> 245 batches of 4096 (1 003 520 triples)
 ROUND = "r02"
 
 
@@ -715,14 +719,11 @@ def bench_mf(args, device, world, rank, dist_on):
     if strong and B % world:
         raise SystemExit(f"--scaling strong splits the batch of {B} over the ranks: {world} does not divide it")
     b_local = B // world if strong else B
-    # this rank's triples: one epoch of K steps (re-shuffled and re-staged by every repeat) + W warm-up steps
-    users, pos, neg = (t.to(device) for t in synth_triples((W + K) * b_local, seed=100 + rank))
+    # ~1 000 000 triples per epoch = EPOCH_STEPS full batches; this rank's share is resident
+    users, pos, neg = (t.to(device) for t in synth_triples(EPOCH_STEPS * b_local, seed=100 + rank))
     torch.manual_seed(7 + rank)  # keys of the device-side shuffles
-    nw = W * b_local
     mode = "single"
     if dist_on:
-        import torch.distributed as dist
-
         from beta_recsys_amd.replicated import ReplicatedMFEngine
         from beta_recsys_amd.sharded import ShardedMFEngine
 
@@ -738,36 +739,45 @@ def bench_mf(args, device, world, rank, dist_on):
     else:
         eng = make_engine(device, args.optimizer)
         eng.fused_step = not args.two_kernel
-    warm = hp.DeviceTripleBatcher(users[:nw], pos[:nw], neg[:nw], b_local) if W > 0 else None
-    timed = hp.DeviceTripleBatcher(users[nw:], pos[nw:], neg[nw:], b_local)
-    assert len(timed) == K
+    loader = hp.DeviceTripleBatcher(users, pos, neg, b_local)
+    assert len(loader) == EPOCH_STEPS
 
-    if mode == "single":
-        def run_epoch(r, loader=timed):
-            # shuffle + staging (taken from the side stream if the previous epoch prefetched it), K fused
-            # steps + the flush, then the NEXT epoch's staging starts on the side stream
-            eng.run_prepared_epoch(eng.prepare_epoch(loader), sync=False, prefetch=loader)
-    elif mode == "replicated":
-        def run_epoch(r, loader=timed):
-            assert eng.run_resident_epoch(loader)
-    else:
-        def run_epoch(r, loader=timed):
-            for batch in loader:  # device-side shuffle, batch views of the resident arrays
-                eng.train_single_batch(batch, sync=False)
+    # Continuous training: epoch after epoch of the same loader (as TrainEngine._train drives it), enqueued in
+    # pieces so that a timestamp can sit between two K-step windows.  A piece that starts an epoch takes its
+    # staged arrays (shuffle + per-batch sort + layout, prefetched on the side stream during the previous
+    # epoch) and starts the next epoch's staging; the piece that ends it enqueues the flush.
+    state = {"pos": 0, "prepared": None, "it": None}
 
-    if warm is not None:
-        run_epoch(-1, warm)
-    if mode == "single":
-        eng._drop_prefetch()  # the warm-up's prefetch belongs to another loader
+    def advance(n):
+        while n > 0:
+            take = min(n, EPOCH_STEPS - state["pos"])
+            piece = (state["pos"], state["pos"] + take)
+            if mode == "single":
+                if piece[0] == 0:
+                    state["prepared"] = eng.prepare_epoch(loader)
+                eng.run_prepared_epoch(state["prepared"], sync=False, prefetch=loader, steps=piece)
+            elif mode == "replicated":
+                assert eng.run_resident_epoch(loader, steps=piece)
+            else:
+                if piece[0] == 0:
+                    state["it"] = iter(loader)  # device-side shuffle, batch views of the resident arrays
+                for _ in range(take):
+                    eng.train_single_batch(next(state["it"]), sync=False)
+            state["pos"] = piece[1] % EPOCH_STEPS
+            n -= take
+
+    advance(W)
     torch.cuda.synchronize()
-    per, wall = timed_repeats(run_epoch, K, device, dist_on)
+    per, wall = timed_repeats(lambda r: advance(K), K, device, dist_on)
     R = len(per)
+    advance((EPOCH_STEPS - state["pos"]) % EPOCH_STEPS)   # finish the epoch in flight (flush) before reading back
     if mode == "sharded":
         eng.k.check_status()
     else:
         st = eng.epoch_stats()
-        assert st.step == W + R * K, (st.step, W + R * K)
-        assert np.isfinite(st.loss_sum) and 0.2 < st.loss_sum / K < 1.4, st.loss_sum
+        done = W + R * K
+        assert st.step == done + (-done) % EPOCH_STEPS, (st.step, done)
+        assert np.isfinite(st.loss) and 0.05 < st.loss < 1.4, st.loss
 
     # ---- dominant kernel: its launch period from HIP events on the stream it runs on ------------------
     probe_s = probe_steps = None
@@ -821,8 +831,10 @@ def bench_mf(args, device, world, rank, dist_on):
             "optimizer": args.optimizer, "lr": LR, "loss": "bpr", "batch_per_gpu": b_local,
             "global_batch": b_local * world, "parallelism": parallelism,
             "rccl_world_size": world if dist_on else None,
-            "timed_region": "per repeat: device shuffle + staging of the epoch (sort of every batch by item, "
-                            "layout; prefetched on a side stream during the previous epoch) + K steps + flush",
+            "epoch": f"{EPOCH_STEPS} steps = {EPOCH_STEPS * b_local * world} triples (SURVEY 8d C2: ~1M triples / epoch)",
+            "timed_region": "continuous training, epoch after epoch; a repeat = the next K steps, with everything "
+                            "that falls into them: per epoch one device shuffle + staging (sort of every batch by "
+                            "item, layout; runs on a side stream during the previous epoch) and one flush launch",
         },
         "roofline": {
             "bound": "hbm", "kernel": dom_name,

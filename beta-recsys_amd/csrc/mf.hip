@@ -1098,14 +1098,15 @@ extern "C" int hiprec_mf_bpr_fused_step(const hiprec_fused_step* c, const int64_
 
 extern "C" size_t hiprec_fused_step_bytes(void) { return sizeof(hiprec_fused_step); }
 
-extern "C" int hiprec_mf_bpr_epoch_fused(int kind, float* const* w_flat, float* const* g_flat,
-                                         float* const* m_flat, float* const* v_flat,
-                                         void* const* scratch2, int64_t n_users, int64_t n_items,
-                                         int32_t dim, const int64_t* users, const int64_t* pos,
-                                         const int64_t* neg, int64_t n_triples, int64_t batch,
-                                         float reg_coef, double lr, double beta1, double beta2,
-                                         double eps, hiprec_stats* stats, int32_t* final_index,
-                                         void* stream) {
+extern "C" int hiprec_mf_bpr_epoch_fused_range(int kind, float* const* w_flat, float* const* g_flat,
+                                               float* const* m_flat, float* const* v_flat,
+                                               void* const* scratch2, int64_t n_users, int64_t n_items,
+                                               int32_t dim, const int64_t* users, const int64_t* pos,
+                                               const int64_t* neg, int64_t n_triples, int64_t batch,
+                                               int64_t step_begin, int64_t step_end,
+                                               float reg_coef, double lr, double beta1, double beta2,
+                                               double eps, hiprec_stats* stats, int32_t* final_index,
+                                               void* stream) {
   HIPREC_REQUIRE(w_flat && g_flat && scratch2 && final_index && stats, "NULL pointer");
   HIPREC_REQUIRE(w_flat[0] && w_flat[1] && g_flat[0] && g_flat[1] && g_flat[2] && scratch2[0] &&
                      scratch2[1], "NULL buffer");
@@ -1115,6 +1116,12 @@ extern "C" int hiprec_mf_bpr_epoch_fused(int kind, float* const* w_flat, float* 
   HIPREC_REQUIRE(n_triples >= 0 && batch > 0, "bad n_triples/batch");
   HIPREC_REQUIRE(n_triples == 0 || (users && pos && neg), "NULL index arrays");
   const int64_t n_steps = (n_triples + batch - 1) / batch;
+  HIPREC_REQUIRE(0 <= step_begin && step_begin <= step_end && step_end <= n_steps,
+                 "bad step range [%lld, %lld) of %lld", (long long)step_begin, (long long)step_end, (long long)n_steps);
+  // steps [step_begin, step_end) of the epoch; the call that reaches the epoch's last step also enqueues
+  // the sweep-only flush (launch index n_steps).  Until then the state is mid-rotation: W / M / V of step k
+  // live in buffer (k & 1) with the update of step k-1 still pending in g_flat[(k + 2) % 3].
+  const int64_t k_end = step_end == n_steps ? n_steps + 1 : step_end;
   hiprec_fused_step c{};
   c.kind = kind;
   c.dim = dim;
@@ -1125,7 +1132,7 @@ extern "C" int hiprec_mf_bpr_epoch_fused(int kind, float* const* w_flat, float* 
   c.beta2 = beta2;
   c.eps = eps;
   c.reg_coef = reg_coef;
-  for (int64_t k = 0; k <= n_steps; ++k) {  // step n_steps is the sweep-only flush
+  for (int64_t k = step_begin; k < k_end; ++k) {  // launch n_steps is the sweep-only flush
     const int64_t off = k * batch;
     const int64_t b = k < n_steps ? std::min<int64_t>(batch, n_triples - off) : 0;
     const int64_t prev_b = k > 0 ? std::min<int64_t>(batch, n_triples - (k - 1) * batch) : 0;
@@ -1148,9 +1155,24 @@ extern "C" int hiprec_mf_bpr_epoch_fused(int kind, float* const* w_flat, float* 
                                           neg ? neg + off : nullptr, b, prev_b, inv_b, stats, stream))
       return rc;
   }
-  // the flush cleared the gradient it applied and both scratch headers, and wrote into buffer 0
-  *final_index = 0;
+  // the flush cleared the gradient it applied and both scratch headers, and wrote into buffer 0;
+  // a range that stops short of the epoch's end leaves the state in rotation (-1)
+  *final_index = step_end == n_steps ? 0 : -1;
   return 0;
+}
+
+extern "C" int hiprec_mf_bpr_epoch_fused(int kind, float* const* w_flat, float* const* g_flat,
+                                         float* const* m_flat, float* const* v_flat,
+                                         void* const* scratch2, int64_t n_users, int64_t n_items,
+                                         int32_t dim, const int64_t* users, const int64_t* pos,
+                                         const int64_t* neg, int64_t n_triples, int64_t batch,
+                                         float reg_coef, double lr, double beta1, double beta2,
+                                         double eps, hiprec_stats* stats, int32_t* final_index,
+                                         void* stream) {
+  const int64_t n_steps = batch > 0 && n_triples >= 0 ? (n_triples + batch - 1) / batch : 0;
+  return hiprec_mf_bpr_epoch_fused_range(kind, w_flat, g_flat, m_flat, v_flat, scratch2, n_users, n_items, dim,
+                                         users, pos, neg, n_triples, batch, 0, n_steps, reg_coef, lr, beta1,
+                                         beta2, eps, stats, final_index, stream);
 }
 
 // The plain-SGD spelling of the above, kept for callers of the first ABI revision.

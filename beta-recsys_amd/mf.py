@@ -698,7 +698,7 @@ class MFEngine(ModelEngine):
         return (self.fused_step and not self._rows_sgd and self.loss == "bpr" and perm is None
                 and self.model.emb_dim <= 256)
 
-    def _run_fused_epoch(self, lib, users, pos, neg, n_run, bs):
+    def _run_fused_epoch(self, lib, users, pos, neg, n_run, bs, steps=None):
         """hiprec_mf_bpr_epoch_fused: W (and Adam/RMSprop moments) ping-pong between the engine's
         buffers and one alternate each; whatever ends up in the alternates is copied back."""
         m, opt = self.model, self.optimizer
@@ -723,9 +723,11 @@ class MFEngine(ModelEngine):
         g_arr = (ctypes.c_void_p * 3)(*(t.data_ptr() for t in fb["g"]))
         s_arr = (ctypes.c_void_p * 2)(*(t.data_ptr() for t in fb["scratch"]))
         final = ctypes.c_int32(-1)
-        _lib.check(lib.hiprec_mf_bpr_epoch_fused(
+        n_steps = (n_run + bs - 1) // bs
+        a, b = (0, n_steps) if steps is None else steps
+        _lib.check(lib.hiprec_mf_bpr_epoch_fused_range(
             opt.kind, w_arr, g_arr, m_arr, v_arr, s_arr, m.n_users, m.n_items, m.emb_dim,
-            _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), n_run, bs, float(self.reg), opt.lr,
+            _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), n_run, bs, a, b, float(self.reg), opt.lr,
             opt.beta1, opt.beta2, opt.eps, _lib.ptr(self._stats), ctypes.byref(final),
             _lib.stream_ptr(dev)))
         if final.value == 1:  # the state ended up in the alternate buffers
@@ -735,16 +737,43 @@ class MFEngine(ModelEngine):
             if opt.exp_avg_sq is not None:
                 opt.exp_avg_sq.copy_(fb["v_alt"])
 
-    def run_prepared_epoch(self, prepared, sync=True, prefetch=None):
+    def run_prepared_epoch(self, prepared, sync=True, prefetch=None, steps=None):
         """Enqueue every step of a prepared epoch (hiprec_mf_bpr_epoch, or the fused one-kernel-per-
         step driver).  With ``sync=False`` nothing is read back; call :meth:`epoch_stats` later.
         ``prefetch`` = the loader whose NEXT epoch is to be staged on the side stream meanwhile
         (:meth:`prefetch_epoch`; issued before this epoch's launches so that the host does not hand it
-        to the GPU only when the epoch is nearly over)."""
+        to the GPU only when the epoch is nearly over).  ``steps=(a, b)`` enqueues only steps [a, b) of
+        the epoch (consecutive calls with the same ``prepared`` cover it piece by piece, e.g. to put a
+        timestamp in between; the weights are valid again once a piece reaches the last step)."""
         lib = self._setup()
         users, pos, neg, perm, bs = prepared
         n = users.numel()
         n_run = n - 1 if n % bs == 1 else n  # Q4: a trailing batch of one raises (below)
+        if steps is not None:
+            n_steps = (n_run + bs - 1) // bs
+            if not (0 <= steps[0] <= steps[1] <= n_steps):
+                raise ValueError(f"steps {steps} outside the epoch's {n_steps} steps")
+            if sync:
+                raise ValueError("a partial epoch cannot be read back: pass sync=False")
+        if steps is None or steps[0] == 0:
+            self._begin_epoch_marker(prepared, prefetch)
+        if self._fused_ok(perm):
+            self._run_fused_epoch(lib, users, pos, neg, n_run, bs, steps)
+            if not sync:
+                return None
+            st = self._sync_stats()
+            if n_run != n:
+                raise IndexError(
+                    "Dimension out of range (expected to be in range of [-1, 0], but got 1)")
+            return st
+        if steps is not None:
+            # the launch-per-kernel drivers keep no state between steps: a piece is a slice of the arrays
+            a, b = steps[0] * bs, min(steps[1] * bs, n_run)
+            users, pos, neg, n_run = users[a:b], pos[a:b], neg[a:b], b - a
+            perm = None if perm is None else perm[a:b]
+        return self._run_unfused_epoch(lib, users, pos, neg, perm, bs, n, n_run, sync)
+
+    def _begin_epoch_marker(self, prepared, prefetch):
         self._ev_epoch_begin = torch.cuda.Event()
         self._ev_epoch_begin.record(torch.cuda.current_stream(self.model.flat.device))
         # the staged arrays must outlive the kernels that read them: a caller's temporary would be freed as soon
@@ -753,15 +782,8 @@ class MFEngine(ModelEngine):
         self._epoch_inputs = prepared
         if prefetch is not None:
             self.prefetch_epoch(prefetch)
-        if self._fused_ok(perm):
-            self._run_fused_epoch(lib, users, pos, neg, n_run, bs)
-            if not sync:
-                return None
-            st = self._sync_stats()
-            if n_run != n:
-                raise IndexError(
-                    "Dimension out of range (expected to be in range of [-1, 0], but got 1)")
-            return st
+
+    def _run_unfused_epoch(self, lib, users, pos, neg, perm, bs, n, n_run, sync):
         m, opt = self.model, self.optimizer
         w, g = m.tables(), m.tables(self._g_flat)
         n_batches = (n_run + bs - 1) // bs

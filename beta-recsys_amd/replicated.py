@@ -226,30 +226,39 @@ class ReplicatedMFEngine(MFEngine):
                 f"batches of {bs}, the group spans {-lo_n}..{hi_n} triples / batches of {-lo_b}..{hi_b}")
         self._checked_shape = key
 
-    def run_resident_epoch(self, train_loader):
+    def run_resident_epoch(self, train_loader, steps=None):
         """Enqueue one whole epoch of a device-resident loader without reading anything back: the staging of
         this rank's share (MFEngine's device batcher, taken from the side stream when the previous epoch
-        prefetched it), one fused launch + one all-reduce per step, the flush, and the prefetch of the next
-        epoch's staging.  Returns False when the loader cannot run resident (caller iterates it instead)."""
+        prefetched it), the prefetch of the next epoch's staging, one fused launch + one all-reduce per
+        step, and the flush.  ``steps=(a, b)``: only steps [a, b) of the epoch (a = 0 stages it, the piece
+        that reaches the last step flushes; pieces must be consecutive).  Returns False when the loader
+        cannot run resident (caller iterates it instead)."""
         self._setup()
         if self.loss != "bpr" or self.model.emb_dim > 256 or isinstance(train_loader, (list, tuple)):
             return False
-        staged = MFEngine.prepare_epoch(self, train_loader)   # this rank's share, laid out in visiting order
-        if staged is None or staged[3] is not None:
-            return False
-        users, pos, neg, _, bs = staged
+        if steps is None or steps[0] == 0:
+            staged = MFEngine.prepare_epoch(self, train_loader)   # this rank's share, laid out in visiting order
+            if staged is None or staged[3] is not None:
+                return False
+            self._check_equal_batches(staged[0].numel(), staged[4])
+            self._ev_epoch_begin = torch.cuda.Event()
+            self._ev_epoch_begin.record(torch.cuda.current_stream(self.model.flat.device))
+            self._last_staged = staged   # keeps the arrays alive until the next epoch replaces them
+            if self.config["model"].get("prefetch_epoch", True):
+                self.prefetch_epoch(train_loader)   # next epoch's staging, on the side stream, while this one runs
+            self.fused_epoch_begin()
+        users, pos, neg, _, bs = self._last_staged
         n = users.numel()
-        self._check_equal_batches(n, bs)
-        self._ev_epoch_begin = torch.cuda.Event()
-        self._ev_epoch_begin.record(torch.cuda.current_stream(self.model.flat.device))
-        self._last_staged = staged   # keeps the arrays alive until the next epoch replaces them
-        if self.config["model"].get("prefetch_epoch", True):
-            self.prefetch_epoch(train_loader)   # next epoch's staging, on the side stream, while this one runs
-        self.fused_epoch_begin()
+        n_steps = (n + bs - 1) // bs
+        a, b = (0, n_steps) if steps is None else steps
+        if not (0 <= a <= b <= n_steps) or a != self._fe["k"]:
+            raise ValueError(f"steps {steps}: pieces of an epoch must be consecutive (next step {self._fe['k']} of {n_steps})")
         pu, pp, pn = users.data_ptr(), pos.data_ptr(), neg.data_ptr()
-        for off in range(0, n, bs):
+        for k in range(a, b):
+            off = k * bs
             self.fused_step_ptr(pu + 8 * off, pp + 8 * off, pn + 8 * off, min(bs, n - off))
-        self.fused_epoch_end()
+        if b == n_steps:
+            self.fused_epoch_end()
         return True
 
     def train_an_epoch(self, train_loader, epoch_id):

@@ -272,6 +272,17 @@ int hiprec_mf_bpr_epoch_fused(int kind, float* const* w_flat, float* const* g_fl
                               const int64_t* pos, const int64_t* neg, int64_t n_triples,
                               int64_t batch, float reg_coef, double lr, double beta1, double beta2,
                               double eps, hiprec_stats* stats, int32_t* final_index, void* stream);
+/* Steps [step_begin, step_end) of that epoch (same arguments, same buffers from call to call): an epoch
+ * enqueued in pieces, e.g. to put a timestamp between them.  The call whose step_end is the epoch's step
+ * count also enqueues the flush (*final_index = 0); before that the state is mid-rotation (*final_index =
+ * -1) and must not be read.  step_begin = 0 starts the epoch (epoch sums reset). */
+int hiprec_mf_bpr_epoch_fused_range(int kind, float* const* w_flat, float* const* g_flat,
+                                    float* const* m_flat, float* const* v_flat, void* const* scratch2,
+                                    int64_t n_users, int64_t n_items, int32_t dim, const int64_t* users,
+                                    const int64_t* pos, const int64_t* neg, int64_t n_triples,
+                                    int64_t batch, int64_t step_begin, int64_t step_end, float reg_coef,
+                                    double lr, double beta1, double beta2, double eps, hiprec_stats* stats,
+                                    int32_t* final_index, void* stream);
 
 /* ---- ONE launch of that sequence, with the buffers of this step named explicitly: for callers that
  *      have to do something between two steps -- the data-parallel engine all-reduces

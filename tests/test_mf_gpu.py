@@ -862,3 +862,36 @@ def test_engine_on_a_device_that_is_not_current(hip_device):
     loss, reg = eng.train_single_batch(batch_of(g, 0))
     assert torch.cuda.current_device() == 0
     assert_scalar_close(loss, g["losses"][0], what="loss on cuda:1 while cuda:0 is current")
+
+
+@pytest.mark.parametrize("optimizer,fused", [("adam", True), ("sgd", True), ("adam", False)])
+def test_epoch_enqueued_in_pieces_equals_the_whole_epoch(hip_device, optimizer, fused):
+    """run_prepared_epoch(steps=(a, b)): an epoch enqueued piece by piece (bench.py puts timestamps between the
+    pieces) is the same training run as the epoch enqueued at once -- the fused driver carries the pending
+    update and the buffer rotation from piece to piece, the last piece flushes."""
+    import beta_recsys_amd as hp
+
+    U, I, D, B, N = 400, 250, 64, 128, 128 * 11 + 50   # 12 steps, last batch short
+    rng = np.random.default_rng(5)
+    triples = [torch.from_numpy(rng.integers(0, hi, N)).cuda() for hi in (U, I, I)]
+    w0 = onp.init_params(U, I, D, seed=5)
+    out = []
+    for pieces in (None, [(0, 1), (1, 5), (5, 5), (5, 11), (11, 12)]):
+        eng = make_engine(U, I, D, optimizer, "bpr", 0.02, B)
+        eng.fused_step = fused
+        load_weights(eng, w0)
+        prepared = eng.prepare_epoch(hp.DeviceTripleBatcher(*triples, B, shuffle=False))
+        if pieces is None:
+            eng.run_prepared_epoch(prepared, sync=False)
+        else:
+            for piece in pieces:
+                eng.run_prepared_epoch(prepared, sync=False, steps=piece)
+        st = eng.epoch_stats()
+        assert st.step == 12
+        out.append((st.loss, get_weights(eng)))
+    with pytest.raises(ValueError):
+        eng.run_prepared_epoch(prepared, sync=False, steps=(3, 13))
+    (la, wa), (lb, wb) = out
+    assert_scalar_close(la, lb, 1e-6, "last-step loss, whole epoch vs pieces")
+    for k in KEYS:
+        assert_tensor_close(wa[k], wb[k], 1e-5, f"{k}: whole epoch vs pieces")
