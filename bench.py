@@ -334,57 +334,93 @@ def bench_mf_c4shard(args, device, full=False):
     from beta_recsys_amd import _lib
 
     Uc, Ic, Dc, Bc = (10_000_000, 1_000_000, 128, 65536) if full else (1_250_000, 125_000, 128, 65536)
+    owned = args.sgd_mode == "owned"
     cfg = {"model": dict(n_users=Uc, n_items=Ic, emb_dim=Dc, device_str=str(device), optimizer="sgd",
-                         lr=LR, batch_size=Bc, loss="bpr", sgd_mode="rows"),
+                         lr=LR, batch_size=Bc, loss="bpr", sgd_mode=args.sgd_mode),
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
         eng = hp.MFEngine(cfg)
     steps, warm = min(args.steps, 100), min(args.warmup, 10)
-    n_total = (steps + warm) * Bc
+    epoch_steps = 50                                     # 3.3 M triples per epoch
     g = torch.Generator().manual_seed(5)
+    n_total = epoch_steps * Bc
     users = torch.randint(0, Uc, (n_total,), generator=g).to(device)
     pz = 1.0 / torch.arange(1, Ic + 1, dtype=torch.float64)
     pos = torch.randperm(Ic, generator=g)[torch.multinomial(pz / pz.sum(), n_total, True, generator=g)].to(device)
     neg = torch.randint(0, Ic, (n_total,), generator=g).to(device)
-    nw = warm * Bc
-    if warm:
-        eng.run_prepared_epoch(stage(eng, hp.DeviceTripleBatcher(users[:nw], pos[:nw], neg[:nw], Bc)))
-    prepared = stage(eng, hp.DeviceTripleBatcher(users[nw:], pos[nw:], neg[nw:], Bc))
-    per, wall = timed_repeats(lambda r: eng.run_prepared_epoch(prepared, sync=False), steps, device)
+    loader = hp.DeviceTripleBatcher(users, pos, neg, Bc)
+    torch.manual_seed(7)
+    # continuous training, epoch after epoch, K-step windows (see bench_mf): the staging of an epoch -- device
+    # shuffle, per-batch sort by item, layout and (owned-rows step) the row-ownership arrays, all torch sorts at
+    # this batch size -- runs on the side stream while the previous epoch trains
+    state = {"pos": 0, "prepared": None}
+
+    def advance(n):
+        while n > 0:
+            take = min(n, epoch_steps - state["pos"])
+            if state["pos"] == 0:
+                state["prepared"] = eng.prepare_epoch(loader)
+            eng.run_prepared_epoch(state["prepared"], sync=False, prefetch=loader,
+                                   steps=(state["pos"], state["pos"] + take))
+            state["pos"] = (state["pos"] + take) % epoch_steps
+            n -= take
+
+    advance(warm)
+    per, wall = timed_repeats(lambda r: advance(steps), steps, device)
+    advance((epoch_steps - state["pos"]) % epoch_steps)
     st = eng.epoch_stats()
-    # dominant kernel alone, back to back
-    lib = eng._setup()
-    m = eng.model
-    pu, pp, pn, _, _ = prepared
-    w, gt = m.tables(), m.tables(eng._g_flat)
-    sp = _lib.stream_ptr(device)
-    kargs = (ctypes.byref(w), ctypes.byref(gt), _lib.ptr(pu), _lib.ptr(pp), _lib.ptr(pn), None, Bc,
-             1.0 / Bc, 0.0, _lib.ptr(eng._stats), _lib.ptr(eng._scratch), eng._scratch.numel(), sp)
-    for _ in range(5):
-        _lib.check(lib.hiprec_mf_bpr_grad(*kargs))
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # the same steps with the epoch staged beforehand (nothing else on the GPU): the step kernels alone
+    prepared = eng.prepare_epoch(loader)
+    eng._drop_prefetch()
     torch.cuda.synchronize()
-    a.record()
-    for _ in range(50):
-        _lib.check(lib.hiprec_mf_bpr_grad(*kargs))
-    b.record()
+    eng.run_prepared_epoch(prepared, sync=False)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    eng.run_prepared_epoch(prepared, sync=False)
+    e1.record()
     torch.cuda.synchronize()
-    k_s = a.elapsed_time(b) / 50 * 1e-3
+    alone_s = e0.elapsed_time(e1) * 1e-3 / epoch_steps
+    eng.epoch_stats()
     bpt = algorithmic_bytes_per_triple(Dc)
-    traffic, traffic_src = (None, None) if full else traffic_from_profiles("hiprec::mf_bpr_grad_kernel<2>", "mf-c4shard")
+    if owned:
+        kname, k_s = "mf_bpr_owned_kernel<2> (gather + score + BPR grad + in-place SGD rows, 1 launch/step)", alone_s
+        traffic, traffic_src = (None, None) if full else traffic_from_profiles("hiprec::mf_bpr_owned_kernel<2>", "mf-c4shard")
+    else:
+        # dominant kernel alone, back to back
+        lib = eng._setup()
+        m = eng.model
+        pu, pp, pn, _, _ = prepared
+        w, gt = m.tables(), m.tables(eng._g_flat)
+        sp = _lib.stream_ptr(device)
+        kargs = (ctypes.byref(w), ctypes.byref(gt), _lib.ptr(pu), _lib.ptr(pp), _lib.ptr(pn), None, Bc,
+                 1.0 / Bc, 0.0, _lib.ptr(eng._stats), _lib.ptr(eng._scratch), eng._scratch.numel(), sp)
+        for _ in range(5):
+            _lib.check(lib.hiprec_mf_bpr_grad(*kargs))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(50):
+            _lib.check(lib.hiprec_mf_bpr_grad(*kargs))
+        b.record()
+        torch.cuda.synchronize()
+        kname, k_s = "mf_bpr_grad_kernel<2>", a.elapsed_time(b) / 50 * 1e-3
+        traffic, traffic_src = (None, None) if full else traffic_from_profiles("hiprec::mf_bpr_grad_kernel<2>", "mf-c4shard")
     out = {"metric": "training interactions/sec (BPR triples)", "unit": "triples/s"}
     out.update(timing_fields(per, wall, steps, Bc))
     out.update({"n_gpus": 1, "steps": steps, "warmup": warm,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": ("BPR-MF, BASELINE configs[3] whole on one GPU: 10M x 1M rows, dim 128, batch "
-                                        "65536, exact SGD on touched rows" if full else
+                                        "65536, plain SGD" if full else
                                         "BPR-MF, one rank's shard of BASELINE configs[3]: 1.25M x 125k rows, dim 128, "
-                                        "batch 65536, exact SGD on touched rows (no exchange timed)"),
-                           "timed_region": "K steps of a pre-staged epoch (the staging of 65536-triple batches is a "
-                                           "device sort outside the clock)",
+                                        "batch 65536, plain SGD (no exchange timed)"),
+                           "sgd_mode": args.sgd_mode,
+                           "epoch": f"{epoch_steps} steps = {n_total} triples",
+                           "timed_region": "continuous training; per epoch one staging pass (device shuffle, per-batch "
+                                           "sort, layout, row ownership) on a side stream during the previous epoch",
+                           "ms_per_step_kernels_alone": alone_s * 1e3,
                            "last_loss": st.loss},
-                "roofline": {"bound": "hbm", "kernel": "mf_bpr_grad_kernel<2>", "achieved": bpt * Bc / k_s / 1e9,
+                "roofline": {"bound": "hbm", "kernel": kname, "achieved": bpt * Bc / k_s / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bpt * Bc / k_s / 1e9 / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_launch": bpt * Bc, "kernel_us": k_s * 1e6,
                              "traffic": traffic, "traffic_source": traffic_src,
@@ -872,6 +908,9 @@ def main():
     ap.add_argument("--workload", default="mf", choices=["mf", "ncf", "lightgcn", "mf-c4shard", "mf-c4", "pgmf", "t2v", "ngcf"],
                     help="mf = BASELINE configs[1] (the headline); ncf = configs[2]; mf-c4 = configs[3] "
                          "(whole on one GPU at --gpus 1, row-sharded over the ranks at --gpus N); lightgcn = configs[4]")
+    ap.add_argument("--sgd-mode", default="owned", choices=["owned", "rows", "dense"],
+                    help="mf-c4 / mf-c4shard: owned = one launch per step, rows updated in place (csrc/mf_owned.hip); "
+                         "rows = gradient kernel into a dense buffer + touched-rows pass (round 1)")
     ap.add_argument("--emb-dim", type=int, default=32, help="ncf: 32 (tower 256-128-64-32, primary) or 64")
     ap.add_argument("--multi-gpu", default="auto", choices=["auto", "replicated", "sharded"],
                     help="mf, N>1: replicate small tables (gradient all-reduce) or row-shard them "

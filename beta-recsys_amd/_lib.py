@@ -269,6 +269,14 @@ SIGNATURES = {
         [c_int, _P, _P, _P, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P, c_int64, c_int64, c_int64, c_int64,
          c_float, c_double, c_double, c_double, c_double, _P, POINTER(c_int32), _P],
     ),
+    "hiprec_mf_bpr_epoch_owned": (
+        c_int,
+        [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64,
+         c_int64, c_int64, c_int64, c_float, c_double, _P, _P],
+    ),
+    "hiprec_ownership_table_bits": (c_int32, [c_int64]),
+    "hiprec_batch_row_ownership": (
+        c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P]),
     "hiprec_mf_bpr_epoch_sgd_fused": (
         c_int,
         [_P, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P, c_int64, c_int64, c_float, c_double, _P,

@@ -163,6 +163,13 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Find the first wave of the run of equal items that `wv` belongs to (s_item: one item id per wave of the block).
+__device__ __forceinline__ int run_head(const long long* s_item, int wv, long long item) {
+  int head = wv;
+  while (head > 0 && s_item[head - 1] == item) --head;
+  return head;
+}
+
 __device__ __forceinline__ float sigmoid_f32(float s) { return 1.0f / (1.0f + expf(-s)); }
 
 // -logsigmoid(x) and sigmoid(-x) the way ATen computes them (min(x,0) - log1p(exp(-|x|)))

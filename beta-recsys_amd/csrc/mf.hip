@@ -30,12 +30,6 @@ namespace hiprec {
 // NPL = embedding columns held per lane (dim <= 64*NPL).  NPL == 0: any dim, rows are re-read
 // (from L1/L2) when needed instead of being held in registers.
 
-// Find the first wave of the run of equal items that `wv` belongs to.
-__device__ __forceinline__ int run_head(const long long* s_item, int wv, long long item) {
-  int head = wv;
-  while (head > 0 && s_item[head - 1] == item) --head;
-  return head;
-}
 
 // Triple of one wave for one trip of the grid-stride loop (all fields wave-uniform).
 struct TripleIdx {

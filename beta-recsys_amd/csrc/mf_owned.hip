@@ -1,0 +1,467 @@
+// BPR-MF step with plain SGD for tables that do NOT fit the caches (BASELINE configs[3]: 10 M x 1 M x 128,
+// or one rank's shard of it): ONE launch per step, no dense gradient buffer, every touched row written once.
+//
+// Reference semantics (beta_rec/models/mf.py:92-119 + torch.optim.SGD, torch_engine.py:26-29): all gradients of
+// a batch come from the pre-step weights, then every touched row r becomes w_r - lr * g_r with g_r the SUM of
+// the batch's contributions to r; untouched rows stay bit-identical.  The two-kernel path (mf_bpr_grad_kernel +
+// mf_sgd_rows_kernel) keeps a dense gradient buffer: atomics read-modify-write it, a second pass reads it, reads
+// and writes the weights and clears it -- 347 MB of HBM traffic per 65 536-triple step for 204 MB algorithmic.
+//
+// Here a row is updated IN PLACE by whichever wave holds its complete gradient:
+//  * the device batcher (beta-recsys_amd/mf.py, torch ops on the side stream) tells every triple, for each of
+//    its three rows, whether the row occurs ONCE in the batch (own = -1) or several times (own = a slot id, with
+//    total[slot] = its number of occurrences).
+//  * a row that occurs once: the wave that read it for the dot products writes w - lr * g straight back -- a
+//    plain store, no atomic, no gradient memory at all.  Nobody else in the batch reads that row.
+//  * a row that occurs several times: every occurrence READS the row (pre-step) and CONTRIBUTES its part of the
+//    gradient, so "all readers have read" == "all contributions have arrived".  Contributions are added with
+//    device-scope atomics into a compact accumulator row acc[slot] (a few tens of MB for the whole batch: it
+//    lives in the Infinity Cache, not in HBM), then the contributor adds its weight to arrived[slot]; the one
+//    that completes the count swaps the accumulated gradient out (atomic exchange with 0: read and clear in one
+//    operation, the accumulators are clean for the next step) and applies it to ITS register copy of the
+//    pre-step row.  No fence is needed: accumulator and counter are only ever touched by device-scope atomics,
+//    and a contributor waits for its adds to be acknowledged before it bumps the counter.
+//  * positive items follow a Zipf law; as in mf_bpr_grad_kernel adjacent equal items of a block (the batcher
+//    sorts every batch by positive item) are first merged in LDS and only the run head contributes, with the
+//    run length as its weight; a run that holds ALL occurrences of its item is applied directly.
+// The scalar bias is handled like the fused cache-resident step does it: its gradient travels in the per-block
+// partials, every wave evaluates bias - lr * (sum of the previous step's partials) on the fly, and one extra
+// block of the grid folds the partials into hiprec_stats and writes the updated scalar to a ping-pong slot.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.hpp"
+
+namespace hiprec {
+
+constexpr int kOwnedBlock = 256;          // 4 independent waves per block (no LDS merge across waves)
+constexpr int kOwnedWaves = kOwnedBlock / kWave;
+constexpr int kOwnedMaxGather = kMaxBlocks;                 // 2048 blocks x 4 waves x 8 triples = 65 536 per sweep
+constexpr int kOwnedPartialLoads = kMaxBlocks / kOwnedBlock;  // per-thread loads of the previous step's partials
+constexpr int kOwnedGroup = 4;            // completed rows swapped out together in the chunk's epilogue
+// consecutive triples of the batch handled by ONE wave, all of their rows in flight at once (registers)
+constexpr int owned_chunk(int npl) { return npl <= 2 ? 8 : 4; }
+
+struct OwnedStep {
+  float* w;                    // flat parameters [user_emb | item_emb | user_bias | item_bias | global_bias]
+  int64_t n_users, n_items;
+  int32_t dim, apply_prev;
+  const int32_t* own_u;        // per triple: -1 = this row occurs once in the batch, else its slot
+  const int32_t* own_p;
+  const int32_t* own_n;
+  const int32_t* total;        // per slot: occurrences of the row in this batch
+  int32_t* arrived;            // per slot: occurrences that have contributed (zero between steps)
+  float* acc;                  // per slot: [dim + 1] accumulated gradient row + bias (zero between steps)
+  const float* gb_read;        // scalar bias before the previous step's gradient
+  float* gb_write;             // ... and where the extra block leaves it with that gradient applied
+  const Scratch* scratch_prev;
+  int32_t n_prev_partials, n_gather_blocks;
+  float lr;
+  int32_t dbg;                 // timing experiments only (HIPREC_OWNED_DBG): 1 = every row direct, 2 = no writes
+};
+
+__device__ __forceinline__ float atomic_swap_f32(float* p, float v) {
+  return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
+  const uint32_t lo = __builtin_amdgcn_readlane(static_cast<int>(static_cast<uint64_t>(v) & 0xFFFFFFFFu), l);
+  const uint32_t hi = __builtin_amdgcn_readlane(static_cast<int>(static_cast<uint64_t>(v) >> 32), l);
+  return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+// One wave = CH CONSECUTIVE triples of the batch.  Per chunk: (1) lane j < CH loads triple j's ids and ownership
+// slots (the next chunk's are requested a chunk ahead), (2) ALL rows of the chunk -- 3 x CH rows, 12 KB at dim
+// 128 -- are requested at once into registers: one memory round trip per chunk with 24 rows in flight per wave
+// is what lifts the gather off the latency floor (one triple at a time with the next one prefetched ran 47 us
+// per 65 536 triples for the reads alone), (3) the triples are scored in order; a row whose complete gradient is
+// in hand (it occurs once in the batch, or all of its occurrences form one run of equal positive items inside
+// this chunk: the batcher sorts every batch by positive item) is written straight back, fire and forget; other
+// rows get their contribution added into the slot's accumulator and a note in lane k of the pending table,
+// (4) ONE wait for the chunk's adds, ONE vector of counter updates (lane k = pending contribution k), and the
+// rows this wave completed are swapped out kOwnedGroup at a time, re-read (a row still holds its pre-step value:
+// only its owner ever writes it) and written back as w - lr * g.
+// Waves never wait for each other inside the loop.
+template <int NPL>
+__global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
+    OwnedStep f, const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
+    const int64_t* __restrict__ neg, int64_t batch, float inv_batch, float reg_coef, hiprec_stats* stats,
+    Scratch* scratch) {
+  constexpr int CH = owned_chunk(NPL);
+  __shared__ float s_red[3 * kOwnedWaves];
+  const int lane = lane_id();
+  const int wv = wave_in_block();
+  const bool apply = f.apply_prev != 0;
+  const int D = f.dim;
+  const int64_t o_ie = f.n_users * D, o_ub = o_ie + f.n_items * D, o_ib = o_ub + f.n_users;
+
+  if (static_cast<int>(blockIdx.x) >= f.n_gather_blocks) {
+    // ---- the extra block: previous step's partials -> stats and the scalar bias; count this step ----
+    if (!apply && threadIdx.x == 0) {  // first launch of an epoch: hiprec_stats_begin_epoch, folded in
+      stats->loss_sum = 0.0;
+      stats->reg_sum = 0.0;
+    }
+    const float gb_part = finalize_partials<kOwnedBlock>(stats, f.scratch_prev);
+    if (threadIdx.x == 0) {
+      float gb = *f.gb_read;
+      if (apply) gb = gb - f.lr * gb_part;
+      *f.gb_write = gb;
+      if (batch > 0) advance_step(stats);
+      else {  // flush: both scratch blocks are spent
+        scratch->n_partials = 0;
+        const_cast<Scratch*>(f.scratch_prev)->n_partials = 0;
+      }
+    }
+    return;
+  }
+
+  float* const wf = f.w;
+  const int ld = D + 1;
+  const float ru = 4.f * reg_coef * inv_batch, ri = 2.f * reg_coef * inv_batch;
+  const int64_t n_chunks = (batch + CH - 1) / CH;
+  const int64_t ch_stride = static_cast<int64_t>(f.n_gather_blocks) * kOwnedWaves;
+
+  // lane j < CH holds triple j of a chunk: ids and ownership slots
+  struct Ids {
+    int64_t u, p, n;
+    int su, sp, sn;
+  };
+  auto load_ids = [&](int64_t ch, Ids& d) {
+    const int64_t t = ch * CH + lane;
+    d.u = d.p = d.n = 0;
+    d.su = d.sp = d.sn = -1;
+    if (ch < n_chunks && lane < CH && t < batch) {
+      d.u = users[t];
+      d.p = pos[t];
+      d.n = neg[t];
+      d.su = f.own_u[t];
+      d.sp = f.own_p[t];
+      d.sn = f.own_n[t];
+    }
+  };
+  int64_t ch = static_cast<int64_t>(blockIdx.x) * kOwnedWaves + wv;
+  Ids ids;
+  load_ids(ch, ids);
+
+  // scalar bias after the previous step: the block sums that step's partials once (up to 2048 of them)
+  float gb = load_scalar_param(f.gb_read);
+  {
+    const float4* pv = f.scratch_prev->partials;
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < kOwnedPartialLoads; ++j) {
+      const int i = static_cast<int>(threadIdx.x) + kOwnedBlock * j;  // every slot is addressable: no branches
+      const float z = pv[i].z;
+      part += i < f.n_prev_partials ? z : 0.f;
+    }
+    part = wave_sum(part);
+    if (lane == 0) s_red[wv] = part;
+    __syncthreads();
+    if (apply) gb = gb - f.lr * (((s_red[0] + s_red[1]) + s_red[2]) + s_red[3]);
+  }
+  float loss_acc = 0.f, reg_acc = 0.f, gb_acc = 0.f;
+
+  for (; ch < n_chunks; ch += ch_stride) {
+    const int cnt = static_cast<int>(min<int64_t>(CH, batch - ch * CH));
+    int64_t lu = ids.u, lp = ids.p, ln = ids.n;
+    const int lsu = ids.su, lsp = ids.sp, lsn = ids.sn;
+    load_ids(ch + ch_stride, ids);  // the next chunk's ids travel while this one is worked on
+    bool lok = lane < cnt;
+    if (lok) {
+      const bool u_ok = static_cast<uint64_t>(lu) < static_cast<uint64_t>(f.n_users);
+      const bool i_ok = static_cast<uint64_t>(lp) < static_cast<uint64_t>(f.n_items) &&
+                        static_cast<uint64_t>(ln) < static_cast<uint64_t>(f.n_items);
+      lok = u_ok && i_ok;
+      if (!lok && lu != -1)  // -1 = padding slot of a fixed-capacity exchange
+        atomicOr(&stats->status, (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
+    }
+    if (!lok) lu = lp = ln = 0;  // row 0 is always addressable; the triple is skipped below
+    // occurrence counts of the shared rows and the three biases: one gather per lane
+    int ltu = 1, ltp = 1, ltn = 1;
+    float lbu = 0.f, lbp = 0.f, lbn = 0.f;
+    if (lok) {
+      if (lsu >= 0) ltu = f.total[lsu];
+      if (lsp >= 0) ltp = f.total[lsp];
+      if (lsn >= 0) ltn = f.total[lsn];
+      lbu = wf[o_ub + lu];
+      lbp = wf[o_ib + lp];
+      lbn = wf[o_ib + ln];
+    }
+    const uint64_t ok_mask = __ballot(lok);
+
+    // ---- every row of the chunk, requested in one burst ----
+    float ru_[CH][NPL], rp_[CH][NPL], rn_[CH][NPL];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int64_t u = readlane64(lu, i), p = readlane64(lp, i), n = readlane64(ln, i);  // row 0 beyond cnt
+      const int64_t ou = u * D, op = o_ie + p * D, on = o_ie + n * D;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        const int c = lane + kWave * k;
+        const int cc = c < D ? c : D - 1;  // always a valid column: unconditional loads
+        ru_[i][k] = wf[ou + cc];
+        rp_[i][k] = wf[op + cc];
+        rn_[i][k] = wf[on + cc];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        const bool in = lane + kWave * k < D;
+        ru_[i][k] = in ? ru_[i][k] : 0.f;
+        rp_[i][k] = in ? rp_[i][k] : 0.f;
+        rn_[i][k] = in ? rn_[i][k] : 0.f;
+      }
+
+    // pending contributions to shared rows (lane k = the k-th of this chunk): slot, weight, total, row, bias
+    int p_slot = 0, p_wt = 0, p_tot = 0, n_pend = 0;
+    int64_t p_row = 0, p_bias = 0;
+
+    // direct rows: w - lr * g straight back; shared rows: contribution into the slot's accumulator + a note
+    auto settle = [&](int slot, int wt, int tot, int64_t row, int64_t bias, const float (&g)[NPL], float gb_,
+                      const float (&v)[NPL], float vb) {
+      if (f.dbg & 2) return;
+      if (slot < 0 || wt == tot || (f.dbg & 1)) {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+          const int c = lane + kWave * k;
+          if (c < D) wf[row + c] = v[k] - f.lr * g[k];
+        }
+        if (lane == 0) wf[bias] = vb - f.lr * gb_;
+      } else {
+        float* a = f.acc + static_cast<int64_t>(slot) * ld;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+          const int c = lane + kWave * k;
+          if (c < D) atomic_add_f32(a + c, g[k]);
+        }
+        if (lane == 0) atomic_add_f32(a + D, gb_);
+        if (lane == n_pend) {
+          p_slot = slot;
+          p_wt = wt;
+          p_tot = tot;
+          p_row = row;
+          p_bias = bias;
+        }
+        ++n_pend;
+      }
+    };
+
+    // the run of equal positive items in progress
+    int64_t run_p = -1;
+    int run_len = 0, run_slot = -1, run_tot = 1;
+    float run_g[NPL], run_v[NPL], run_gb = 0.f, run_vb = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) run_g[k] = run_v[k] = 0.f;
+    auto flush_run = [&]() {
+      if (run_len > 0)
+        settle(run_slot, run_len, run_tot, o_ie + run_p * D, o_ib + run_p, run_g, run_gb, run_v, run_vb);
+      run_len = 0;
+    };
+
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      if (!((ok_mask >> i) & 1ull)) continue;  // beyond the chunk, padding, or out-of-range ids
+      const int64_t u = readlane64(lu, i), p = readlane64(lp, i), n = readlane64(ln, i);
+      const float bu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lbu), i));
+      const float bp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lbp), i));
+      const float bn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lbn), i));
+      float dp = 0.f, dn = 0.f;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        dp += ru_[i][k] * rp_[i][k];
+        dn += ru_[i][k] * rn_[i][k];
+        reg_acc += 2.f * ru_[i][k] * ru_[i][k] + rp_[i][k] * rp_[i][k] + rn_[i][k] * rn_[i][k];
+      }
+      dp = wave_sum(dp);
+      dn = wave_sum(dn);
+      const float yp = sigmoid_f32(((dp + bu) + bp) + gb);
+      const float yn = sigmoid_f32(((dn + bu) + bn) + gb);
+      float sig_neg_x;
+      const float nls = neg_logsigmoid(yp - yn, &sig_neg_x);
+      const float delta = -sig_neg_x * inv_batch;
+      const float dpos = delta * ((1.f - yp) * yp);
+      const float dneg = -delta * ((1.f - yn) * yn);
+      float gu[NPL], gn[NPL];
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        gu[k] = (dpos * rp_[i][k] + dneg * rn_[i][k]) + ru * ru_[i][k];
+        gn[k] = dneg * ru_[i][k] + ri * rn_[i][k];
+      }
+      if (lane == 0) reg_acc += 2.f * bu * bu + bp * bp + bn * bn;
+      loss_acc += nls;
+      gb_acc += dpos + dneg;
+      settle(__builtin_amdgcn_readlane(lsu, i), 1, __builtin_amdgcn_readlane(ltu, i), u * D, o_ub + u, gu,
+             (dpos + dneg) + ru * bu, ru_[i], bu);
+      settle(__builtin_amdgcn_readlane(lsn, i), 1, __builtin_amdgcn_readlane(ltn, i), o_ie + n * D, o_ib + n, gn,
+             dneg + ri * bn, rn_[i], bn);
+      if (run_len > 0 && p == run_p) {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) run_g[k] += dpos * ru_[i][k] + ri * rp_[i][k];
+        run_gb += dpos + ri * bp;
+        ++run_len;
+      } else {
+        flush_run();
+        run_p = p;
+        run_len = 1;
+        run_slot = __builtin_amdgcn_readlane(lsp, i);
+        run_tot = __builtin_amdgcn_readlane(ltp, i);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+          run_g[k] = dpos * ru_[i][k] + ri * rp_[i][k];
+          run_v[k] = rp_[i][k];
+        }
+        run_gb = dpos + ri * bp;
+        run_vb = bp;
+      }
+    }
+    flush_run();
+
+    // ---- settle the shared rows of this chunk ----
+    if (n_pend > 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the adds are performed before this wave reports in
+      const bool mine = lane < n_pend;
+      int old = 0;
+      if (mine) old = __hip_atomic_fetch_add(f.arrived + p_slot, p_wt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool is_last = mine && old + p_wt == p_tot;
+      if (is_last) __hip_atomic_store(f.arrived + p_slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint64_t last = __ballot(is_last);
+      // whoever completes a row's count owns it: swap the gradient out (read + clear), kOwnedGroup rows per round
+      // trip, together with the row itself (it still holds its pre-step value: only the owner ever writes it)
+      while (last) {
+        float g[kOwnedGroup][NPL], gbv[kOwnedGroup], w0[kOwnedGroup][NPL], wb0[kOwnedGroup];
+        int64_t row[kOwnedGroup], bias[kOwnedGroup];
+        bool on[kOwnedGroup];
+#pragma unroll
+        for (int q = 0; q < kOwnedGroup; ++q) {
+          on[q] = last != 0;
+          const int k = on[q] ? __builtin_ctzll(last) : 0;
+          last &= last - (on[q] ? 1 : 0);
+          row[q] = readlane64(p_row, k);
+          bias[q] = readlane64(p_bias, k);
+          float* a = f.acc + static_cast<int64_t>(__builtin_amdgcn_readlane(p_slot, k)) * ld;
+          gbv[q] = wb0[q] = 0.f;
+#pragma unroll
+          for (int j = 0; j < NPL; ++j) {
+            const int c = lane + kWave * j;
+            g[q][j] = w0[q][j] = 0.f;
+            if (on[q] && c < D) {
+              g[q][j] = atomic_swap_f32(a + c, 0.f);
+              w0[q][j] = wf[row[q] + c];  // a plain load next to the swap: fp32 atomics are the scarce resource
+            }
+          }
+          if (on[q] && lane == 0) {
+            gbv[q] = atomic_swap_f32(a + D, 0.f);
+            wb0[q] = wf[bias[q]];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < kOwnedGroup; ++q) {
+          if (!on[q]) continue;
+#pragma unroll
+          for (int j = 0; j < NPL; ++j) {
+            const int c = lane + kWave * j;
+            if (c < D) wf[row[q] + c] = w0[q][j] - f.lr * g[q][j];
+          }
+          if (lane == 0) wf[bias[q]] = wb0[q] - f.lr * gbv[q];
+        }
+      }
+    }
+  }
+  // publish this step's partials; n_partials = number of GATHER blocks
+  const float reg_w = wave_sum(reg_acc);
+  __syncthreads();  // s_red is reused
+  if (lane == 0) {
+    s_red[wv] = loss_acc;
+    s_red[kOwnedWaves + wv] = reg_w;
+    s_red[2 * kOwnedWaves + wv] = gb_acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float l = 0.f, r = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < kOwnedWaves; ++i) {
+      l += s_red[i];
+      r += s_red[kOwnedWaves + i];
+      b += s_red[2 * kOwnedWaves + i];
+    }
+    scratch->partials[blockIdx.x] = make_float4(l * inv_batch, r * inv_batch, b, 0.f);
+    if (blockIdx.x == 0) scratch->n_partials = static_cast<uint32_t>(f.n_gather_blocks);
+  }
+}
+
+static int launch_owned(const OwnedStep& f, int grid, hipStream_t st, const int64_t* uu, const int64_t* pp,
+                        const int64_t* nn, int64_t b, float inv_b, float reg_coef, hiprec_stats* stats, Scratch* sc) {
+  if (f.dim <= 64)
+    mf_bpr_owned_kernel<1><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+  else if (f.dim <= 128)
+    mf_bpr_owned_kernel<2><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+  else
+    mf_bpr_owned_kernel<4><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // namespace hiprec
+
+using namespace hiprec;
+
+extern "C" int hiprec_mf_bpr_epoch_owned(float* w_flat, int64_t n_users, int64_t n_items, int32_t dim,
+                                         const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                         const int32_t* own_u, const int32_t* own_p, const int32_t* own_n,
+                                         const int32_t* total, int64_t total_stride,
+                                         int32_t* arrived, float* acc, int64_t n_slots, float* gb_pingpong,
+                                         void* const* scratch2, int64_t n_triples, int64_t batch,
+                                         int64_t step_begin, int64_t step_end, float reg_coef, double lr,
+                                         hiprec_stats* stats, void* stream) {
+  HIPREC_REQUIRE(w_flat && gb_pingpong && scratch2 && scratch2[0] && scratch2[1] && stats, "NULL pointer");
+  HIPREC_REQUIRE(n_users > 0 && n_items > 0 && dim > 0 && dim <= 256, "owned-rows step needs 0 < dim <= 256");
+  HIPREC_REQUIRE(n_triples >= 0 && batch > 0, "bad n_triples/batch");
+  HIPREC_REQUIRE(n_triples == 0 || (users && pos && neg && own_u && own_p && own_n), "NULL index / ownership arrays");
+  HIPREC_REQUIRE(n_slots == 0 || (total && arrived && acc), "NULL slot arrays");
+  HIPREC_REQUIRE(total_stride >= 0 && total_stride <= n_slots, "total_stride %lld exceeds the %lld accumulator slots",
+                 (long long)total_stride, (long long)n_slots);
+  const int64_t n_steps = (n_triples + batch - 1) / batch;
+  HIPREC_REQUIRE(0 <= step_begin && step_begin <= step_end && step_end <= n_steps,
+                 "bad step range [%lld, %lld) of %lld", (long long)step_begin, (long long)step_end, (long long)n_steps);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t o_gb = (n_users + n_items) * (static_cast<int64_t>(dim) + 1);
+  const int64_t k_end = step_end == n_steps ? n_steps + 1 : step_end;  // launch n_steps is the flush
+  for (int64_t k = step_begin; k < k_end; ++k) {
+    const int64_t off = k * batch;
+    const int64_t b = k < n_steps ? std::min<int64_t>(batch, n_triples - off) : 0;
+    const int64_t prev_b = k > 0 ? std::min<int64_t>(batch, n_triples - (k - 1) * batch) : 0;
+    auto blocks = [dim](int64_t bb) {
+      const int64_t per_block = static_cast<int64_t>(owned_chunk(dim <= 64 ? 1 : dim <= 128 ? 2 : 4)) * kOwnedWaves;
+      return static_cast<int>(std::min<int64_t>((bb + per_block - 1) / per_block, kOwnedMaxGather));
+    };
+    OwnedStep f;
+    f.w = w_flat;
+    f.n_users = n_users;
+    f.n_items = n_items;
+    f.dim = dim;
+    f.apply_prev = prev_b > 0 ? 1 : 0;
+    f.own_u = own_u ? own_u + off : nullptr;
+    f.own_p = own_p ? own_p + off : nullptr;
+    f.own_n = own_n ? own_n + off : nullptr;
+    f.total = total ? total + k * total_stride : nullptr;
+    f.arrived = arrived;
+    f.acc = acc;
+    // the scalar bias ping-pongs between two slots; the epoch starts from and ends in the model's own element
+    f.gb_read = k == 0 ? w_flat + o_gb : gb_pingpong + (k & 1);
+    f.gb_write = k == n_steps ? w_flat + o_gb : gb_pingpong + ((k + 1) & 1);
+    f.scratch_prev = static_cast<const Scratch*>(scratch2[(k + 1) & 1]);
+    f.n_prev_partials = prev_b > 0 ? blocks(prev_b) : 0;
+    f.n_gather_blocks = b > 0 ? blocks(b) : 0;
+    f.lr = static_cast<float>(lr);
+    static const int dbg = getenv("HIPREC_OWNED_DBG") ? atoi(getenv("HIPREC_OWNED_DBG")) : 0;
+    f.dbg = dbg;
+    const float inv_b = b > 0 ? 1.0f / static_cast<float>(b) : 0.f;
+    if (int rc = launch_owned(f, f.n_gather_blocks + 1, st, users ? users + off : nullptr, pos ? pos + off : nullptr,
+                              neg ? neg + off : nullptr, b, inv_b, reg_coef, stats,
+                              static_cast<Scratch*>(scratch2[k & 1])))
+      return rc;
+  }
+  return 0;
+}

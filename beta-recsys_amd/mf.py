@@ -285,7 +285,86 @@ def sort_within_batches(perm, items, batch_size, n_items):
     idx = torch.arange(n, device=items.device) if perm is None else perm
     key = torch.div(torch.arange(n, device=items.device), batch_size, rounding_mode="floor")
     key = key * int(n_items) + items[idx]
+    if (n + batch_size - 1) // batch_size * int(n_items) < 2**31:
+        key = key.to(torch.int32)  # half the radix passes of the device sort
     return idx[torch.argsort(key)].contiguous()
+
+
+class PreparedEpoch(tuple):
+    """(users, pos, neg, perm, batch_size) of one staged epoch; ``own`` carries the row-ownership arrays of the
+    owned-rows SGD step (csrc/mf_owned.hip) when the engine runs that path."""
+
+    own = None
+
+
+def batch_row_ownership(users, pos, neg, batch_size, n_users, n_items):
+    """For an epoch laid out in visiting order: which rows occur ONCE in their batch and which several times
+    (``own`` int32 [3, n]: -1 or the row's slot inside its batch; ``total`` int32 [n_batches, stride]:
+    occurrences per slot).  On the device this is ``hiprec_batch_row_ownership`` (one hash table per batch, the
+    table position is the slot); :func:`batch_row_ownership_torch` states the same contract with sorts."""
+    if users.device.type != "cuda" or n_users + n_items >= 2**31:
+        return batch_row_ownership_torch(users, pos, neg, batch_size, n_users, n_items)
+    lib = _lib.load()
+    n, dev = users.numel(), users.device
+    n_batches = max((n + batch_size - 1) // batch_size, 1)
+    bits = lib.hiprec_ownership_table_bits(batch_size)
+    stride = 1 << bits
+    keys = torch.empty(n_batches * stride, dtype=torch.int32, device=dev)
+    total = torch.empty((n_batches, stride), dtype=torch.int32, device=dev)
+    own = torch.empty((3, n), dtype=torch.int32, device=dev)
+    _lib.check(lib.hiprec_batch_row_ownership(
+        _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), n, batch_size, n_users, n_items, bits, _lib.ptr(keys),
+        _lib.ptr(total), _lib.ptr(own[0]), _lib.ptr(own[1]), _lib.ptr(own[2]), _lib.stream_ptr(dev)))
+    return own, total, stride
+
+
+def batch_row_ownership_torch(users, pos, neg, batch_size, n_users, n_items):
+    """For an epoch laid out in visiting order: which rows occur ONCE in their batch and which several times.
+
+    Returns ``(own, total, stride)`` for ``hiprec_mf_bpr_epoch_owned``: ``own`` int32 [3, n] (user / pos / neg
+    row of every triple: -1 = the row occurs once in its batch, else its slot id inside the batch), ``total``
+    int32 [n_batches, stride] (occurrences per slot; a positive and a negative occurrence of one item both count;
+    user rows take the first slots of a batch, item rows follow), ``stride`` = batch_size + batch_size // 2, the
+    most slots a batch can need (every slot stands for >= 2 of its 3 * batch_size row occurrences).  Triples with
+    an out-of-range id get keys of their own (the kernel skips and flags them).  Integer work on the device (two
+    sorts, fixed-size outputs, nothing read back by the host), independent of the weights: it belongs to the
+    epoch's staging."""
+    n, dev = users.numel(), users.device
+    n_batches = (n + batch_size - 1) // batch_size
+    stride = batch_size + batch_size // 2
+    total = torch.zeros(n_batches * stride + 1, dtype=torch.int32, device=dev)   # last element: dump for non-slots
+    if n == 0:
+        return torch.zeros((3, 0), dtype=torch.int32, device=dev), total[:-1].view(n_batches, stride), stride
+    idx = torch.arange(n, device=dev)
+    bid = torch.div(idx, batch_size, rounding_mode="floor")
+    ok = ((users >= 0) & (users < n_users) & (pos >= 0) & (pos < n_items) & (neg >= 0) & (neg < n_items))
+
+    def slots(keys, n_rows, first_slot):
+        """keys: (batch * n_rows + row) per occurrence, negative = not a real row.  -> slot per occurrence
+        (-1 = single) and the number of shared rows per batch; fills `total`."""
+        skeys, order = torch.sort(keys)
+        new_run = torch.ones_like(skeys, dtype=torch.bool)
+        new_run[1:] = skeys[1:] != skeys[:-1]
+        run = torch.cumsum(new_run, 0) - 1                                         # run id per sorted position
+        cnt = torch.zeros_like(skeys).index_add_(0, run, torch.ones_like(skeys))[run]   # occurrences of its row
+        shared = (cnt > 1) & (skeys >= 0)
+        head = (shared & new_run).to(torch.int64)                                  # first occurrence of a shared row
+        sb = torch.div(skeys, n_rows, rounding_mode="floor").clamp_(min=0)         # batch per sorted position
+        n_shared = torch.zeros(n_batches, dtype=torch.int64, device=dev).index_add_(0, sb, head)
+        batch_start = torch.cumsum(n_shared, 0) - n_shared                         # shared rows of earlier batches
+        slot = torch.cumsum(head, 0) - 1 - batch_start[sb] + first_slot[sb]
+        dump = torch.full_like(slot, n_batches * stride)
+        total.index_put_((torch.where(head.bool(), sb * stride + slot, dump),), cnt.to(torch.int32))
+        out = torch.empty_like(slot)
+        out[order] = torch.where(shared, slot, torch.full_like(slot, -1))
+        return out, n_shared
+
+    ku = torch.where(ok, bid * n_users + users, -1 - idx)
+    su, n_su = slots(ku, n_users, torch.zeros(n_batches, dtype=torch.int64, device=dev))
+    ki = torch.cat([torch.where(ok, bid * n_items + pos, -1 - idx), torch.where(ok, bid * n_items + neg, -1 - n - idx)])
+    si, _ = slots(ki, n_items, n_su)
+    own = torch.stack([su, si[:n], si[n:]]).to(torch.int32).contiguous()
+    return own, total[:-1].view(n_batches, stride), stride
 
 
 class DeviceTripleBatcher:
@@ -393,10 +472,11 @@ class MFEngine(ModelEngine):
         self.optimizer.allocate_state(flat)
         self._scratch = torch.zeros(lib.hiprec_scratch_bytes(0), dtype=torch.uint8, device=dev)
         self._stats = _new_stats(dev, self.optimizer.beta1 or 0.9, self.optimizer.beta2 or 0.999)
-        mode = self.config["model"].get("sgd_mode", "auto")
-        rows = self.optimizer.name == "sgd" and (
-            mode == "rows" or (mode == "auto" and flat.numel() * 4 >= self.ROWS_SGD_MIN_BYTES)
-        )
+        # plain SGD on tables beyond the caches visits only the rows of the step.  sgd_mode: "dense" (sweep),
+        # "rows" (dense gradient buffer + touched-rows pass, two kernels), "owned" (resident BPR epochs run the
+        # one-launch in-place step of csrc/mf_owned.hip, everything else as "rows"), "auto" = dense below 64 MB
+        # of parameters, owned above
+        rows, self._owned_sgd = self._sgd_modes()
         self._rows_sgd = rows
         if rows:
             self._user_stamp = torch.zeros(self.model.n_users, dtype=torch.int32, device=dev)
@@ -545,6 +625,10 @@ class MFEngine(ModelEngine):
             off = _lib.Stats.status.offset
             raw[off:off + 4] = 0
             self._stats.copy_(raw)
+            ob = getattr(self, "_owned_bufs", None)
+            if ob is not None:   # a skipped (out-of-range) triple leaves its rows' counts incomplete
+                ob["arrived"].zero_()
+                ob["acc"].zero_()
             raise_on_status(st.status)
         return st
 
@@ -630,7 +714,7 @@ class MFEngine(ModelEngine):
     # batch for a few tens of microseconds) into one of two persistent buffer sets.
     def _can_prefetch(self, train_loader):
         return (isinstance(train_loader, DeviceTripleBatcher) and self.loss == "bpr"
-                and train_loader.native_shuffle() and train_loader.batch_size <= 8192
+                and train_loader.native_shuffle()
                 and train_loader.user_tensor.device == self.model.flat.device
                 and len(train_loader.user_tensor) > 0)
 
@@ -647,28 +731,43 @@ class MFEngine(ModelEngine):
         pf = getattr(self, "_pf", None)
         if pf is None or pf["dev"] != dev:
             pf = self._pf = {"dev": dev, "side": torch.cuda.Stream(dev), "slots": [None, None], "next": 0}
-        users, pos, neg = train_loader.user_tensor, train_loader.pos_item_tensor, train_loader.neg_item_tensor
-        k = pf["next"]
-        pf["next"] = 1 - k
-        slot = pf["slots"][k]
-        if slot is None or slot[0].numel() != users.numel():
-            # allocated with the SIDE stream current: the caching allocator keeps one pool per stream, so
-            # these can never be blocks that kernels still in flight on the main stream were just reading
-            with torch.cuda.stream(pf["side"]):
-                slot = pf["slots"][k] = tuple(torch.empty_like(t) for t in (users, pos, neg))
-        seed = train_loader.draw_seed()
         begin = getattr(self, "_ev_epoch_begin", None)
         if begin is not None:
             # everything enqueued before the epoch that is running now (in particular the epoch that last
-            # read this slot) is complete when the side stream starts; the running epoch is NOT waited for
+            # read the slot reused below) is complete when the side stream starts; the running epoch is NOT
+            # waited for
             pf["side"].wait_event(begin)
         else:
             pf["side"].wait_stream(main)
+        bs = train_loader.batch_size
+        if bs <= 8192:
+            users, pos, neg = train_loader.user_tensor, train_loader.pos_item_tensor, train_loader.neg_item_tensor
+            k = pf["next"]
+            pf["next"] = 1 - k
+            slot = pf["slots"][k]
+            if slot is None or slot[0].numel() != users.numel():
+                # allocated with the SIDE stream current: the caching allocator keeps one pool per stream, so
+                # these can never be blocks that kernels still in flight on the main stream were just reading
+                with torch.cuda.stream(pf["side"]):
+                    slot = pf["slots"][k] = tuple(torch.empty_like(t) for t in (users, pos, neg))
+            seed = train_loader.draw_seed()
+            with torch.cuda.stream(pf["side"]):
+                self._stage_into(users, pos, neg, None, seed, bs, *slot)
+                prepared = self._finish_staging(slot + (None, bs))
+        else:
+            # batches beyond the LDS sort: shuffle, per-batch sort and layout are torch ops, enqueued on the
+            # side stream like everything else of the staging
+            with torch.cuda.stream(pf["side"]):
+                prepared = self._finish_staging(self._resident_triples(train_loader))
+            for t in prepared[:3]:
+                t.record_stream(main)
         with torch.cuda.stream(pf["side"]):
-            self._stage_into(users, pos, neg, None, seed, train_loader.batch_size, *slot)
             done = torch.cuda.Event()
             done.record(pf["side"])
-        self._prefetched = (train_loader, done, slot + (None, train_loader.batch_size))
+        if prepared.own is not None:  # allocated on the side stream, read (and eventually freed) under the main one
+            for t in prepared.own[:2]:
+                t.record_stream(main)
+        self._prefetched = (train_loader, done, prepared)
         return True
 
     def _drop_prefetch(self):
@@ -691,7 +790,24 @@ class MFEngine(ModelEngine):
             return None
         if self.loss == "bce" and isinstance(train_loader, DeviceTripleBatcher):
             return None
-        return self._resident_triples(train_loader)
+        return self._finish_staging(self._resident_triples(train_loader))
+
+    def _sgd_modes(self):
+        """(touched-rows SGD?, owned-rows resident step?) -- see _setup."""
+        mode = self.config["model"].get("sgd_mode", "auto")
+        big = self.model.flat.numel() * 4 >= self.ROWS_SGD_MIN_BYTES
+        rows = self.optimizer.name == "sgd" and (mode in ("rows", "owned") or (mode == "auto" and big))
+        return rows, rows and mode in ("owned", "auto") and self.model.emb_dim <= 256
+
+    def _finish_staging(self, staged):
+        """Wrap a staged epoch; the owned-rows SGD step also needs to know which rows its batches share."""
+        if staged is None:
+            return None
+        prepared = PreparedEpoch(staged)
+        users, pos, neg, perm, bs = prepared
+        if self._sgd_modes()[1] and self.loss == "bpr" and perm is None and users.device.type == "cuda":
+            prepared.own = batch_row_ownership(users, pos, neg, bs, self.model.n_users, self.model.n_items)
+        return prepared
 
     def _fused_ok(self, perm):
         """Cache-sized tables take the one-kernel-per-step epoch driver (any of the three optimizers)."""
@@ -757,6 +873,15 @@ class MFEngine(ModelEngine):
                 raise ValueError("a partial epoch cannot be read back: pass sync=False")
         if steps is None or steps[0] == 0:
             self._begin_epoch_marker(prepared, prefetch)
+        if self._owned_sgd and self.loss == "bpr" and getattr(prepared, "own", None) is not None:
+            self._run_owned_epoch(lib, prepared, n_run, steps)
+            if not sync:
+                return None
+            st = self._sync_stats()
+            if n_run != n:
+                raise IndexError(
+                    "Dimension out of range (expected to be in range of [-1, 0], but got 1)")
+            return st
         if self._fused_ok(perm):
             self._run_fused_epoch(lib, users, pos, neg, n_run, bs, steps)
             if not sync:
@@ -772,6 +897,31 @@ class MFEngine(ModelEngine):
             users, pos, neg, n_run = users[a:b], pos[a:b], neg[a:b], b - a
             perm = None if perm is None else perm[a:b]
         return self._run_unfused_epoch(lib, users, pos, neg, perm, bs, n, n_run, sync)
+
+    def _run_owned_epoch(self, lib, prepared, n_run, steps):
+        """hiprec_mf_bpr_epoch_owned (csrc/mf_owned.hip): plain SGD on tables beyond the caches, one launch per
+        step, rows updated in place by the wave that holds their complete gradient.  Work space: one compact
+        accumulator row + arrival counter per shared row of a batch (zero between steps), nothing table-sized."""
+        users, pos, neg, _, bs = prepared
+        own, total, stride = prepared.own
+        m = self.model
+        dev = m.flat.device
+        ob = getattr(self, "_owned_bufs", None)
+        if ob is None or ob["dev"] != dev or ob["stride"] < stride:
+            ob = self._owned_bufs = {
+                "dev": dev, "stride": stride,
+                "arrived": torch.zeros(stride, dtype=torch.int32, device=dev),
+                "acc": torch.zeros(stride * (m.emb_dim + 1), dtype=torch.float32, device=dev),
+                "gb": torch.zeros(2, dtype=torch.float32, device=dev),
+                "scratch": [torch.zeros_like(self._scratch), torch.zeros_like(self._scratch)]}
+        s_arr = (ctypes.c_void_p * 2)(*(t.data_ptr() for t in ob["scratch"]))
+        n_steps = (n_run + bs - 1) // bs
+        a, b = (0, n_steps) if steps is None else steps
+        _lib.check(lib.hiprec_mf_bpr_epoch_owned(
+            _lib.ptr(m.flat), m.n_users, m.n_items, m.emb_dim, _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg),
+            _lib.ptr(own[0]), _lib.ptr(own[1]), _lib.ptr(own[2]), _lib.ptr(total), stride,
+            _lib.ptr(ob["arrived"]), _lib.ptr(ob["acc"]), ob["stride"], _lib.ptr(ob["gb"]), s_arr, n_run, bs,
+            a, b, float(self.reg), self.optimizer.lr, _lib.ptr(self._stats), _lib.stream_ptr(dev)))
 
     def _begin_epoch_marker(self, prepared, prefetch):
         self._ev_epoch_begin = torch.cuda.Event()

@@ -59,6 +59,9 @@ class ReplicatedMFEngine(MFEngine):
         self._lib_cached = lib
         return lib
 
+    def _sgd_modes(self):
+        return False, False   # replicas always take the dense sweep
+
     def _step_context(self):
         """hiprec_dp_step with every per-engine constant: the step is then two short C calls around
         the collective (the replicated engine is host-bound whenever the all-reduce is short)."""

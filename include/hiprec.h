@@ -284,6 +284,37 @@ int hiprec_mf_bpr_epoch_fused_range(int kind, float* const* w_flat, float* const
                                     double lr, double beta1, double beta2, double eps, hiprec_stats* stats,
                                     int32_t* final_index, void* stream);
 
+/* ---- plain SGD on tables that do not fit the caches (configs[3]): ONE launch per step, no dense gradient
+ * buffer, every touched row written once, in place (csrc/mf_owned.hip).  The caller's batcher supplies, for
+ * every triple of the epoch (laid out in visiting order, every batch sorted by positive item) and each of
+ * its three rows, own_u / own_p / own_n[n_triples] (int32): -1 when the row occurs ONCE in its batch, else a slot
+ * id in [0, total_stride) with total[step * total_stride + slot] = the row's number of occurrences in that
+ * batch (a pos and a neg occurrence of one item both count; user rows and item rows use distinct slots).
+ * arrived[n_slots] (int32) and acc[n_slots * (dim + 1)] (fp32) are zero on entry and zero again on return;
+ * gb_pingpong[2], scratch2[2] are caller-owned work space.  Steps [step_begin, step_end) of the epoch are
+ * enqueued; the call that reaches the last step also enqueues the flush (scalar bias + stats of the last
+ * step), before that the scalar bias element of w_flat is stale.  Semantics: mf.py:92-119 with
+ * torch.optim.SGD(lr) -- gradients from the pre-step weights, untouched rows bit-identical. */
+int hiprec_mf_bpr_epoch_owned(float* w_flat, int64_t n_users, int64_t n_items, int32_t dim,
+                              const int64_t* users, const int64_t* pos, const int64_t* neg,
+                              const int32_t* own_u, const int32_t* own_p, const int32_t* own_n,
+                              const int32_t* total, int64_t total_stride,
+                              int32_t* arrived, float* acc, int64_t n_slots, float* gb_pingpong,
+                              void* const* scratch2, int64_t n_triples, int64_t batch,
+                              int64_t step_begin, int64_t step_end, float reg_coef, double lr,
+                              hiprec_stats* stats, void* stream);
+
+/* Row ownership of a staged epoch for hiprec_mf_bpr_epoch_owned (csrc/ownership.hip): one hash table of
+ * 2^table_bits entries per batch (hiprec_ownership_table_bits(batch): >= 4 x batch), the table position of a row
+ * IS its slot, so total_stride = n_slots = 2^table_bits.  keys[n_batches << table_bits] is work space,
+ * total[n_batches << table_bits] and own_u / own_p / own_n[n] are the outputs.  Triples with an out-of-range
+ * id get -1 everywhere.  Integer work, no sort, nothing read back by the host. */
+int32_t hiprec_ownership_table_bits(int64_t batch);
+int hiprec_batch_row_ownership(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
+                               int64_t batch, int64_t n_users, int64_t n_items, int32_t table_bits,
+                               int32_t* keys, int32_t* total, int32_t* own_u, int32_t* own_p, int32_t* own_n,
+                               void* stream);
+
 /* ---- ONE launch of that sequence, with the buffers of this step named explicitly: for callers that
  *      have to do something between two steps -- the data-parallel engine all-reduces
  *      [partials of scratch_cur | g_cur] over RCCL before the next launch consumes them as

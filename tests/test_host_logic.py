@@ -733,3 +733,46 @@ def test_sibling_engines_checkpoint_round_trip(tmp_path):
             want = sd["item_emb2.weight"] if (name == "t2v" and k.startswith("item_emb")) else sd[k]
             assert torch.equal(v, want), (name, k)          # shared parameter: the last key loaded wins
         assert b.model.flat.data_ptr() == next(iter(b.model.parameters())).data_ptr() or name != "pgmf"
+
+
+def _brute_force_ownership_check(users, pos, neg, bs, U, I, own, total):
+    """own / total against a per-batch count of row occurrences (python loops: small inputs only)."""
+    from collections import Counter
+
+    n = len(users)
+    for b in range((n + bs - 1) // bs):
+        ts = range(b * bs, min(n, (b + 1) * bs))
+        ok = {t: 0 <= users[t] < U and 0 <= pos[t] < I and 0 <= neg[t] < I for t in ts}
+        cu = Counter(int(users[t]) for t in ts if ok[t])
+        ci = Counter([int(pos[t]) for t in ts if ok[t]] + [int(neg[t]) for t in ts if ok[t]])
+        seen = {}
+        for t in ts:
+            if not ok[t]:
+                assert own[:, t].tolist() == [-1, -1, -1]
+                continue
+            for role, (cnt, key) in enumerate(((cu, ("u", int(users[t]))), (ci, ("i", int(pos[t]))),
+                                               (ci, ("i", int(neg[t]))))):
+                c, s = cnt[key[1]], int(own[role, t])
+                if c == 1:
+                    assert s == -1, "a row that occurs once must be owned by its triple"
+                else:
+                    assert s >= 0 and int(total[b, s]) == c, (b, t, role, c, s)
+                    assert seen.setdefault(s, key) == key, "two different rows share a slot"
+        assert len(seen) == sum(v > 1 for v in cu.values()) + sum(v > 1 for v in ci.values())
+
+
+def test_batch_row_ownership_contract():
+    """The staging data of the owned-rows SGD step (csrc/mf_owned.hip), sort-based statement: a row that occurs
+    once in its batch gets -1, every other row a slot of its own inside the batch with total = its occurrences
+    (a positive and a negative occurrence of one item both count); triples with out-of-range ids get -1."""
+    from beta_recsys_amd.mf import batch_row_ownership_torch
+
+    rng = np.random.default_rng(0)
+    n, bs, U, I = 1000, 128, 50, 30
+    users, pos, neg = (torch.from_numpy(rng.integers(0, hi, n)) for hi in (U, I, I))
+    users[5], pos[77], neg[500] = U + 3, -2, I
+    own, total, stride = batch_row_ownership_torch(users, pos, neg, bs, U, I)
+    assert stride == bs + bs // 2 and tuple(total.shape) == (8, stride) and own.dtype == torch.int32
+    _brute_force_ownership_check(users.numpy(), pos.numpy(), neg.numpy(), bs, U, I, own.numpy(), total.numpy())
+    own0, total0, _ = batch_row_ownership_torch(users[:0], pos[:0], neg[:0], bs, U, I)
+    assert own0.shape == (3, 0)

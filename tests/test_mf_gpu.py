@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import KEYS, assert_scalar_close, assert_step_close, assert_tensor_close
+from helpers import KEYS, assert_scalar_close, assert_step_close, assert_tensor_close, assert_update_close
 from helpers import golden_opt_state, grad_scale_floor, load_golden, optimizer_band, params
 from oracle import mf_numpy as onp
 
@@ -895,3 +895,130 @@ def test_epoch_enqueued_in_pieces_equals_the_whole_epoch(hip_device, optimizer, 
     assert_scalar_close(la, lb, 1e-6, "last-step loss, whole epoch vs pieces")
     for k in KEYS:
         assert_tensor_close(wa[k], wb[k], 1e-5, f"{k}: whole epoch vs pieces")
+
+
+# ---- owned-rows SGD step (csrc/mf_owned.hip): the HBM-resident regime of BASELINE configs[3] ----------
+
+def _zipf_triples(rng, n, U, I, hot=None):
+    users = rng.integers(0, U, n)
+    p = 1.0 / np.arange(1, I + 1)
+    pos = rng.permutation(I)[rng.choice(I, n, p=p / p.sum())]
+    if hot is not None:
+        pos[rng.random(n) < hot] = 7
+    neg = rng.integers(0, I, n)
+    return users, pos, neg
+
+
+@pytest.mark.parametrize("U,I,D,B,steps,hot,reg", [
+    (300, 200, 64, 256, 5, None, None),     # everything shared: tiny tables, every row occurs many times
+    (50_000, 3_000, 128, 2048, 4, 0.5, None),  # mostly single users, one item holding half of the positives
+    (5_000, 4_000, 100, 1000, 3, None, 0.01),  # dim not a multiple of 64, short last batch, reg != 0
+    (2_000, 1_500, 256, 512, 3, 0.1, None),
+])
+def test_owned_rows_epoch_matches_the_oracle(hip_device, U, I, D, B, steps, hot, reg):
+    """sgd_mode 'owned': one launch per step, rows updated in place by whoever holds their complete gradient.
+    Against oracle/mf_numpy.py step by step (mf.py:92-119 + torch.optim.SGD): per-epoch loss sum, every weight
+    within 1e-5 of the update scale, rows the epoch never touched bit-identical, accumulators left clean; and
+    the same epoch enqueued in pieces."""
+    import beta_recsys_amd as hp
+
+    rng = np.random.default_rng(U + B)
+    n = steps * B - (B // 3 if D == 100 else 0)
+    users, pos, neg = _zipf_triples(rng, n, U, I, hot)
+    lr = 0.05
+    w0 = onp.init_params(U, I, D, seed=3)
+    triples = [torch.from_numpy(a).cuda() for a in (users, pos, neg)]
+    # the oracle on the same batches (the batcher only reorders INSIDE a batch)
+    w = onp.copy_params(w0)
+    st = onp.new_opt_state(w, "sgd")
+    total = 0.0
+    for k in range(0, n, B):
+        loss, _ = onp.mf_train_step(w, st, (users[k:k + B], pos[k:k + B], neg[k:k + B]), "bpr", "sgd", lr,
+                                    reg_coef=reg or 0.0)
+        total += loss
+    for pieces in (None, [(0, 1), (1, 2), (2, steps)]):
+        eng = make_engine(U, I, D, "sgd", "bpr", lr, B, reg=reg, sgd_mode="owned")
+        load_weights(eng, w0)
+        prepared = eng.prepare_epoch(hp.DeviceTripleBatcher(*triples, B, shuffle=False))
+        assert prepared.own is not None and eng._setup() and eng._owned_sgd
+        if pieces is None:
+            eng.run_prepared_epoch(prepared, sync=False)
+        else:
+            for piece in pieces:
+                eng.run_prepared_epoch(prepared, sync=False, steps=piece)
+        stt = eng.epoch_stats()
+        assert stt.step == steps
+        assert_scalar_close(stt.loss_sum, total, 2e-5, "epoch loss sum")
+        got = get_weights(eng)
+        for k in KEYS:
+            assert_update_close(w0[k], got[k], w[k], what=f"{k} after {steps} owned-rows steps")
+        for k, rows in (("user_emb.weight", users), ("item_emb.weight", np.concatenate([pos, neg]))):
+            untouched = np.ones(w0[k].shape[0], dtype=bool)
+            untouched[rows] = False
+            assert np.array_equal(got[k][untouched], w0[k][untouched]), f"{k}: untouched rows moved"
+        assert float(eng._owned_bufs["acc"].abs().max()) == 0.0 and int(eng._owned_bufs["arrived"].abs().max()) == 0
+
+
+def test_owned_rows_step_at_c4_shard_size(hip_device):
+    """One rank's share of BASELINE configs[3] (1.25M x 125k rows, dim 128, batch 65536, Zipf positives): the
+    owned-rows step and the two-kernel touched-rows path (dense gradient buffer) are the same SGD step -- equal
+    weights on every touched row to 1e-5 of the update, every other row bit-identical -- over three steps, and
+    the accumulators come back clean."""
+    import beta_recsys_amd as hp
+
+    U, I, D, B, steps = 1_250_000, 125_000, 128, 65536, 3
+    rng = np.random.default_rng(11)
+    users, pos, neg = _zipf_triples(rng, steps * B, U, I)
+    triples = [torch.from_numpy(a).cuda() for a in (users, pos, neg)]
+    out = {}
+    for mode in ("rows", "owned"):
+        torch.manual_seed(5)
+        eng = make_engine(U, I, D, "sgd", "bpr", 0.05, B, sgd_mode=mode)
+        w0 = eng.model.flat.clone()
+        prepared = eng.prepare_epoch(hp.DeviceTripleBatcher(*triples, B, shuffle=False))
+        assert (prepared.own is not None) == (mode == "owned")
+        st = eng.run_prepared_epoch(prepared)
+        assert st.step == steps and 0.3 < st.loss < 1.4
+        out[mode] = (eng.model.flat.clone(), st.loss_sum)
+        if mode == "owned":
+            assert float(eng._owned_bufs["acc"].abs().max()) == 0.0
+            assert int(eng._owned_bufs["arrived"].abs().max()) == 0
+        del eng
+    (wa, la), (wb, lb) = out["rows"], out["owned"]
+    assert_scalar_close(lb, la, 1e-5, "loss sum, owned vs touched-rows path")
+    upd = float((wa - w0).abs().max())
+    assert float((wa - wb).abs().max()) <= 1e-5 * upd + 4 * 1.2e-7 * float(w0.abs().max())
+    moved = (wb != w0)
+    touched = torch.zeros_like(moved)
+    tu = torch.from_numpy(np.unique(users)).cuda()
+    ti = torch.from_numpy(np.unique(np.concatenate([pos, neg]))).cuda()
+    touched[: U * D].view(U, D)[tu] = True
+    touched[U * D:(U + I) * D].view(I, D)[ti] = True
+    touched[(U + I) * D:(U + I) * D + U][tu] = True
+    touched[(U + I) * D + U:(U + I) * D + U + I][ti] = True
+    touched[-1] = True
+    assert not bool((moved & ~touched).any()), "a row outside the batches moved"
+
+
+@pytest.mark.parametrize("n,bs,U,I", [(1000, 128, 50, 30), (3 * 4096 + 77, 4096, 100_000, 2_000), (65536, 65536, 1_250_000, 125_000)])
+def test_batch_row_ownership_kernel(hip_device, n, bs, U, I):
+    """hiprec_batch_row_ownership (one hash table per batch, the table position is the slot) states the same
+    contract as the sort-based batch_row_ownership_torch: same single / shared classification, same occurrence
+    counts, one slot per shared row."""
+    from beta_recsys_amd.mf import batch_row_ownership, batch_row_ownership_torch
+    from test_host_logic import _brute_force_ownership_check
+
+    rng = np.random.default_rng(n)
+    users, pos, neg = _zipf_triples(rng, n, U, I)
+    users[3], pos[min(77, n - 1)] = U, -1
+    tu, tp, tn = (torch.from_numpy(a).cuda() for a in (users, pos, neg))
+    own, total, stride = batch_row_ownership(tu, tp, tn, bs, U, I)
+    own_t, total_t, _ = batch_row_ownership_torch(tu, tp, tn, bs, U, I)
+    assert stride >= 4 * min(bs, n) and stride & (stride - 1) == 0 and tuple(total.shape) == ((n + bs - 1) // bs, stride)
+    assert torch.equal(own >= 0, own_t >= 0)
+    bid = (torch.arange(n, device=hip_device) // bs).repeat(3).view(3, n)
+    sh = own >= 0
+    assert torch.equal(total[bid[sh], own[sh].long()], total_t[bid[sh], own_t[sh].long()])
+    assert int(total.sum()) == int(total_t.sum()) + int((total == 1).sum())   # singles are counted, never referenced
+    if n <= 20_000:
+        _brute_force_ownership_check(users, pos, neg, bs, U, I, own.cpu().numpy(), total.cpu().numpy())
