@@ -276,7 +276,7 @@ SIGNATURES = {
     ),
     "hiprec_ownership_table_bits": (c_int32, [c_int64]),
     "hiprec_batch_row_ownership": (
-        c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P]),
+        c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
     "hiprec_mf_bpr_epoch_sgd_fused": (
         c_int,
         [_P, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P, c_int64, c_int64, c_float, c_double, _P,

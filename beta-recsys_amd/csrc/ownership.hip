@@ -3,12 +3,22 @@
 // contributions meet in a slot).  Part of the device batcher's staging: integer work, independent of the weights.
 //
 // One open-addressing hash table per batch, 2^table_bits entries (>= 4 x batch: at most 3 x batch distinct rows
-// go in).  Pass 1 inserts every row occurrence (key = user row, or n_users + item row) with atomicCAS + linear
-// probing and counts it in total[]; the table position IS the row's slot id -- no compaction, no sort.  Pass 2
-// turns the positions of rows that were counted once into -1.
+// go in); the table position of a row IS its slot id -- no compaction, no sort.  The table is cut into
+// partitions of 2^14 entries by the top bits of the hash, and one workgroup builds one (batch, partition) in
+// LDS: it scans the 32-bit keys of the batch's 3 x batch row occurrences (key = user row, or n_users + item row,
+// made once by a streaming pre-pass), inserts the ones that hash into its partition with LDS compare-and-swap +
+// linear probing (inside the partition), counts them and hands every occurrence its slot; the partition's counts
+// go to total[] in one coalesced write.  A row that occurs once has total[slot] == 1: the step kernel treats it
+// exactly like own = -1.  A first version kept the tables in global memory: 20 M device atomics per 50-batch
+// epoch, 1.5 ms; LDS atomics make it one pass over L2-resident keys per partition.
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace hiprec {
+
+constexpr int kOwnPartBits = 14;              // 16 384 entries x (key + count) = 128 KB of LDS
+constexpr int kOwnThreads = 1024;
 
 __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
   x ^= x >> 16;
@@ -19,51 +29,67 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
   return x;
 }
 
-__global__ __launch_bounds__(kBlock) void ownership_insert_kernel(
-    const int64_t* __restrict__ users, const int64_t* __restrict__ pos, const int64_t* __restrict__ neg, int64_t n,
-    int64_t batch, int64_t n_users, int64_t n_items, int table_bits, int32_t* __restrict__ keys,
-    int32_t* __restrict__ total, int32_t* __restrict__ own_u, int32_t* __restrict__ own_p,
-    int32_t* __restrict__ own_n) {
-  const uint32_t mask = (1u << table_bits) - 1u;
+// key of every row occurrence, role-major ([0,n) user rows, [n,2n) positive, [2n,3n) negative item rows):
+// user row, or n_users + item row; -1 when the triple has an out-of-range id (the step kernel skips it whole)
+__global__ __launch_bounds__(kBlock) void ownership_keys_kernel(const int64_t* __restrict__ users,
+                                                                const int64_t* __restrict__ pos,
+                                                                const int64_t* __restrict__ neg, int64_t n,
+                                                                int64_t n_users, int64_t n_items,
+                                                                int32_t* __restrict__ keys) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < 3 * n; i += stride) {
-    const int role = static_cast<int>(i / n);
-    const int64_t t = i - role * n;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < n; t += stride) {
     const int64_t u = users[t], p = pos[t], q = neg[t];
-    int32_t* out = role == 0 ? own_u : role == 1 ? own_p : own_n;
     const bool ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(n_users) &&
                     static_cast<uint64_t>(p) < static_cast<uint64_t>(n_items) &&
                     static_cast<uint64_t>(q) < static_cast<uint64_t>(n_items);
-    if (!ok) {  // the step kernel skips (and flags) the whole triple
-      out[t] = -1;
-      continue;
-    }
-    const int32_t key = static_cast<int32_t>(role == 0 ? u : n_users + (role == 1 ? p : q));
-    const int64_t base = (t / batch) << table_bits;
-    uint32_t h = hash_u32(static_cast<uint32_t>(key)) & mask;
-    for (;;) {
-      const int32_t prev = atomicCAS(keys + base + h, -1, key);
-      if (prev == -1 || prev == key) break;
-      h = (h + 1u) & mask;
-    }
-    atomicAdd(total + base + h, 1);
-    out[t] = static_cast<int32_t>(h);
+    keys[t] = ok ? static_cast<int32_t>(u) : -1;
+    keys[n + t] = ok ? static_cast<int32_t>(n_users + p) : -1;
+    keys[2 * n + t] = ok ? static_cast<int32_t>(n_users + q) : -1;
   }
 }
 
-__global__ __launch_bounds__(kBlock) void ownership_resolve_kernel(int64_t n, int64_t batch, int table_bits,
-                                                                   const int32_t* __restrict__ total,
-                                                                   int32_t* __restrict__ own_u,
-                                                                   int32_t* __restrict__ own_p,
-                                                                   int32_t* __restrict__ own_n) {
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < 3 * n; i += stride) {
-    const int role = static_cast<int>(i / n);
-    const int64_t t = i - role * n;
-    int32_t* out = role == 0 ? own_u : role == 1 ? own_p : own_n;
-    const int32_t h = out[t];
-    if (h >= 0 && total[((t / batch) << table_bits) + h] < 2) out[t] = -1;
+__global__ __launch_bounds__(kOwnThreads) void ownership_kernel(const int32_t* __restrict__ keys, int64_t n,
+                                                                int64_t batch, int table_bits,
+                                                                int32_t* __restrict__ total,
+                                                                int32_t* __restrict__ own) {
+  extern __shared__ int32_t s_tab[];          // [part_size] keys, then [part_size] counts
+  const int part_bits = table_bits < kOwnPartBits ? table_bits : kOwnPartBits;
+  const uint32_t part_size = 1u << part_bits, part_mask = part_size - 1u;
+  const int n_parts = 1 << (table_bits - part_bits);
+  const int64_t b = blockIdx.x / n_parts;
+  const uint32_t part = static_cast<uint32_t>(blockIdx.x % n_parts);
+  int32_t* s_key = s_tab;
+  int32_t* s_cnt = s_tab + part_size;
+  for (uint32_t i = threadIdx.x; i < part_size; i += kOwnThreads) {
+    s_key[i] = -1;
+    s_cnt[i] = 0;
   }
+  __syncthreads();
+  const int64_t t0 = b * batch;
+  const int64_t cnt = min<int64_t>(batch, n - t0);
+  for (int64_t i = threadIdx.x; i < 3 * cnt; i += kOwnThreads) {
+    const int role = static_cast<int>(i / cnt);
+    const int64_t at = role * n + t0 + (i - role * cnt);
+    const int32_t key = keys[at];
+    if (key < 0) {
+      if (part == 0) own[at] = -1;
+      continue;
+    }
+    // the partition is chosen by the hash's top bits, the position inside it by its low bits
+    const uint32_t x = hash_u32(static_cast<uint32_t>(key));
+    if (n_parts > 1 && (x >> (32 - (table_bits - part_bits))) != part) continue;
+    uint32_t h = x & part_mask;
+    for (;;) {
+      const int32_t prev = atomicCAS(s_key + h, -1, key);
+      if (prev == -1 || prev == key) break;
+      h = (h + 1u) & part_mask;
+    }
+    atomicAdd(s_cnt + h, 1);
+    own[at] = static_cast<int32_t>((part << part_bits) | h);
+  }
+  __syncthreads();
+  int32_t* out = total + (b << table_bits) + (static_cast<int64_t>(part) << part_bits);
+  for (uint32_t i = threadIdx.x; i < part_size; i += kOwnThreads) out[i] = s_cnt[i];
 }
 
 }  // namespace hiprec
@@ -78,23 +104,27 @@ extern "C" int32_t hiprec_ownership_table_bits(int64_t batch) {
 
 extern "C" int hiprec_batch_row_ownership(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
                                           int64_t batch, int64_t n_users, int64_t n_items, int32_t table_bits,
-                                          int32_t* keys, int32_t* total, int32_t* own_u, int32_t* own_p,
-                                          int32_t* own_n, void* stream) {
+                                          int32_t* keys, int32_t* total, int32_t* own, void* stream) {
   HIPREC_REQUIRE(n >= 0 && batch > 0 && n_users > 0 && n_items > 0, "bad sizes");
   HIPREC_REQUIRE(n_users + n_items < (1ll << 31), "row keys need n_users + n_items < 2^31");
   HIPREC_REQUIRE(table_bits >= 2 && table_bits <= 30 && (1ll << table_bits) >= 4 * std::min<int64_t>(batch, n > 0 ? n : 1),
                  "table of 2^%d entries is too small for batches of %lld", table_bits, (long long)batch);
   if (n == 0) return 0;
-  HIPREC_REQUIRE(users && pos && neg && keys && total && own_u && own_p && own_n, "NULL pointer");
+  HIPREC_REQUIRE(users && pos && neg && keys && total && own, "NULL pointer");
   const int64_t n_batches = (n + batch - 1) / batch;
-  const size_t bytes = static_cast<size_t>(n_batches) << table_bits << 2;
+  const int part_bits = std::min<int>(table_bits, kOwnPartBits);
+  const int64_t grid = n_batches << (table_bits - part_bits);
+  HIPREC_REQUIRE(grid < (1ll << 31), "too many (batch, partition) pairs");
+  const size_t lds = sizeof(int32_t) * 2 * (static_cast<size_t>(1) << part_bits);
+  static bool attr_set = false;
+  if (!attr_set) {  // 128 KB of dynamic LDS (gfx950 has 160 KB per workgroup)
+    HIPREC_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ownership_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sizeof(int32_t) << kOwnPartBits));
+    attr_set = true;
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  HIPREC_TRY(hipMemsetAsync(keys, 0xFF, bytes, st));
-  HIPREC_TRY(hipMemsetAsync(total, 0, bytes, st));
-  const int grid = grid_for_threads(3 * n);
-  ownership_insert_kernel<<<grid, kBlock, 0, st>>>(users, pos, neg, n, batch, n_users, n_items, table_bits, keys,
-                                                   total, own_u, own_p, own_n);
-  ownership_resolve_kernel<<<grid, kBlock, 0, st>>>(n, batch, table_bits, total, own_u, own_p, own_n);
+  ownership_keys_kernel<<<grid_for_threads(n), kBlock, 0, st>>>(users, pos, neg, n, n_users, n_items, keys);
+  ownership_kernel<<<static_cast<int>(grid), kOwnThreads, lds, st>>>(keys, n, batch, table_bits, total, own);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }

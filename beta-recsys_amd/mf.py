@@ -299,8 +299,8 @@ class PreparedEpoch(tuple):
 
 def batch_row_ownership(users, pos, neg, batch_size, n_users, n_items):
     """For an epoch laid out in visiting order: which rows occur ONCE in their batch and which several times
-    (``own`` int32 [3, n]: -1 or the row's slot inside its batch; ``total`` int32 [n_batches, stride]:
-    occurrences per slot).  On the device this is ``hiprec_batch_row_ownership`` (one hash table per batch, the
+    (``own`` int32 [3, n]: the row's slot inside its batch, or -1; ``total`` int32 [n_batches, stride]:
+    occurrences per slot; a row that occurs once has own = -1 or total = 1).  On the device this is ``hiprec_batch_row_ownership`` (one hash table per batch, the
     table position is the slot); :func:`batch_row_ownership_torch` states the same contract with sorts."""
     if users.device.type != "cuda" or n_users + n_items >= 2**31:
         return batch_row_ownership_torch(users, pos, neg, batch_size, n_users, n_items)
@@ -309,12 +309,12 @@ def batch_row_ownership(users, pos, neg, batch_size, n_users, n_items):
     n_batches = max((n + batch_size - 1) // batch_size, 1)
     bits = lib.hiprec_ownership_table_bits(batch_size)
     stride = 1 << bits
-    keys = torch.empty(n_batches * stride, dtype=torch.int32, device=dev)
+    keys = torch.empty(3 * n, dtype=torch.int32, device=dev)
     total = torch.empty((n_batches, stride), dtype=torch.int32, device=dev)
     own = torch.empty((3, n), dtype=torch.int32, device=dev)
     _lib.check(lib.hiprec_batch_row_ownership(
         _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), n, batch_size, n_users, n_items, bits, _lib.ptr(keys),
-        _lib.ptr(total), _lib.ptr(own[0]), _lib.ptr(own[1]), _lib.ptr(own[2]), _lib.stream_ptr(dev)))
+        _lib.ptr(total), _lib.ptr(own), _lib.stream_ptr(dev)))
     return own, total, stride
 
 

@@ -287,7 +287,7 @@ int hiprec_mf_bpr_epoch_fused_range(int kind, float* const* w_flat, float* const
 /* ---- plain SGD on tables that do not fit the caches (configs[3]): ONE launch per step, no dense gradient
  * buffer, every touched row written once, in place (csrc/mf_owned.hip).  The caller's batcher supplies, for
  * every triple of the epoch (laid out in visiting order, every batch sorted by positive item) and each of
- * its three rows, own_u / own_p / own_n[n_triples] (int32): -1 when the row occurs ONCE in its batch, else a slot
+ * its three rows, own_u / own_p / own_n[n_triples] (int32): -1 (or a slot whose total is 1) when the row occurs ONCE in its batch, else a slot
  * id in [0, total_stride) with total[step * total_stride + slot] = the row's number of occurrences in that
  * batch (a pos and a neg occurrence of one item both count; user rows and item rows use distinct slots).
  * arrived[n_slots] (int32) and acc[n_slots * (dim + 1)] (fp32) are zero on entry and zero again on return;
@@ -305,15 +305,16 @@ int hiprec_mf_bpr_epoch_owned(float* w_flat, int64_t n_users, int64_t n_items, i
                               hiprec_stats* stats, void* stream);
 
 /* Row ownership of a staged epoch for hiprec_mf_bpr_epoch_owned (csrc/ownership.hip): one hash table of
- * 2^table_bits entries per batch (hiprec_ownership_table_bits(batch): >= 4 x batch), the table position of a row
- * IS its slot, so total_stride = n_slots = 2^table_bits.  keys[n_batches << table_bits] is work space,
- * total[n_batches << table_bits] and own_u / own_p / own_n[n] are the outputs.  Triples with an out-of-range
- * id get -1 everywhere.  Integer work, no sort, nothing read back by the host. */
+ * 2^table_bits entries per batch (hiprec_ownership_table_bits(batch): >= 4 x batch) built in LDS, the table
+ * position of a row IS its slot, so total_stride = n_slots = 2^table_bits.  keys[3 * n] is work space; outputs:
+ * own[3 * n] (role-major: user, positive, negative row of every triple; its three thirds are the own_u / own_p /
+ * own_n of the step) = the row's slot, and total[(batch index << table_bits) + slot] = its occurrences in that
+ * batch (1 for a row that occurs once: the step treats it like own = -1; 0 for unused entries).  Triples with
+ * an out-of-range id get -1.  Integer work, no sort, nothing read back by the host. */
 int32_t hiprec_ownership_table_bits(int64_t batch);
 int hiprec_batch_row_ownership(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
                                int64_t batch, int64_t n_users, int64_t n_items, int32_t table_bits,
-                               int32_t* keys, int32_t* total, int32_t* own_u, int32_t* own_p, int32_t* own_n,
-                               void* stream);
+                               int32_t* keys, int32_t* total, int32_t* own, void* stream);
 
 /* ---- ONE launch of that sequence, with the buffers of this step named explicitly: for callers that
  *      have to do something between two steps -- the data-parallel engine all-reduces
