@@ -78,7 +78,7 @@ def perturb_biases(model, rng):
         model.global_bias.fill_(0.05)
 
 
-def steps_fixture(MFEngine, name, U, I, D, B, optimizer, loss, lr, n_steps, seed, top_reg=None):
+def steps_fixture(MFEngine, name, U, I, D, B, optimizer, loss, lr, n_steps, seed, top_reg=None, hot=None):
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
     cfg = make_config(U, I, D, optimizer, loss, lr, B)
@@ -106,6 +106,10 @@ def steps_fixture(MFEngine, name, U, I, D, B, optimizer, loss, lr, n_steps, seed
     eng.optimizer.step = capturing_step
     users = rng.integers(0, U, size=(n_steps, B))
     a_items = np.stack([zipf_items(rng, B, I) for _ in range(n_steps)])
+    if hot is not None:
+        # a heavy-duplicate batch: ONE item holds the fraction `hot` of the positives (the LDS run-merge path of the
+        # gradient kernels)
+        a_items[rng.random((n_steps, B)) < hot] = 3
     if loss == "bpr":
         third = rng.integers(0, I, size=(n_steps, B))
     else:
@@ -245,7 +249,16 @@ def main():
     epoch_fixture(MFEngine, PairwiseNegativeDataset, "mf_epoch_sgd", "sgd", seed=22)
 
 
-if __name__ == "__main__" and not {"--ncf", "--lightgcn", "--eval", "--sampler", "--c1", "--pgmf", "--t2v", "--ngcf", "--ncf-dropout"} & set(sys.argv):
+def main_hot():
+    MFEngine, _, _ = import_reference()
+    steps_fixture(MFEngine, "mf_bpr_adam_hot", 300, 120, 64, 320, "adam", "bpr", 0.05, 2, seed=31, hot=0.6)
+    steps_fixture(MFEngine, "mf_bpr_sgd_hot", 300, 120, 64, 320, "sgd", "bpr", 0.05, 2, seed=32, hot=0.6)
+
+
+if __name__ == "__main__" and "--hot" in sys.argv:
+    main_hot()
+
+if __name__ == "__main__" and not {"--hot", "--ncf", "--lightgcn", "--eval", "--sampler", "--c1", "--pgmf", "--t2v", "--ngcf", "--ncf-dropout"} & set(sys.argv):
     main()
 
 

@@ -123,3 +123,31 @@ def assert_step_close(w_prev, got, ref, band, rel=REL, what=""):
     bad = err > tol
     assert not bad.any(), (f"{what}: {int(bad.sum())} elements out of tolerance, worst err "
                            f"{err[bad].max():.3e} vs tol {tol[bad][np.argmax(err[bad])]:.3e}")
+
+
+def legal_trajectory_envelope(gold, n_steps, opt, lr, batch, loss="bpr", reg_coef=0.0, trials=8, rel=REL, seed=0):
+    """Elementwise envelope of where a CORRECT implementation may end up after `n_steps` chained steps.
+
+    north_star allows every gradient to be off by rel = 1e-5 of its tensor's scale.  Adam / RMSprop turn such an error
+    into anything up to ~lr for elements whose gradient is ~eps, and the moments carry it into the next steps, so a
+    per-step tolerance cannot be summed into a multi-step one.  Instead the oracle itself is run `trials` times with
+    every gradient element moved by +-rel * scale (random signs): each run is a legal trajectory.  Returns, per
+    parameter tensor, max over the runs of |w_run - w_reference|."""
+    from oracle import mf_numpy as onp
+
+    rng = np.random.default_rng(seed)
+    env = {k: np.zeros(gold[f"w0/{k}"].shape, dtype=np.float64) for k in KEYS}
+    for _ in range(trials):
+        w = params(gold, "w0")
+        st = onp.new_opt_state(w, opt)
+        for s in range(n_steps):
+            batch_s = tuple(gold[k][s] for k in ("users", "items_a", "third"))
+            fn = onp.mf_bpr_grads if loss == "bpr" else onp.mf_bce_grads
+            _, _, g = fn(w, batch_s[0], batch_s[1], batch_s[2], reg_coef)
+            for k in KEYS:
+                scale = max(float(np.abs(g[k]).max()), grad_scale_floor(k, batch))
+                g[k] = (g[k] + (rng.choice([-1.0, 1.0], size=g[k].shape) * rel * scale).astype(np.float32)).astype(np.float32)
+            onp.opt_step(w, g, st, opt, lr)
+        for k in KEYS:
+            env[k] = np.maximum(env[k], np.abs(w[k].astype(np.float64) - gold[f"w{n_steps}/{k}"]))
+    return env

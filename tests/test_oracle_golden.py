@@ -12,7 +12,9 @@ from oracle.torch_port import TorchMFPort
 
 STEP_CASES = ["mf_bpr_sgd", "mf_bpr_adam", "mf_bpr_rmsprop", "mf_bce_sgd", "mf_bce_adam",
               "mf_bpr_sgd_d4", "mf_bpr_sgd_d100", "mf_bpr_adam_d200", "mf_bpr_sgd_d300",
-              "mf_bpr_sgd_reg", "mf_bce_sgd_reg"]
+              "mf_bpr_sgd_reg", "mf_bce_sgd_reg",
+              # one item holding 60 % of a 320-triple batch's positives, captured from the real engine
+              "mf_bpr_adam_hot", "mf_bpr_sgd_hot"]
 
 
 def test_known_answer_vector():
