@@ -272,7 +272,13 @@ def bench_ncf(args, device, world=1, rank=0, dist_on=False):
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
-        if dist_on:
+        if dist_on and args.multi_gpu == "sharded":
+            from beta_recsys_amd.sharded_ncf import ShardedNeuMFEngine
+
+            eng = ShardedNeuMFEngine(cfg)   # the four tables row-sharded (owner = row mod N), tower replicated
+            eng._enqueue_step = lambda u, i, r: eng.train_single_batch(u, i, r, sync=False)
+            eng._sync_stats = lambda: type("S", (), {"loss": float(eng._g_ext[-2])})()
+        elif dist_on:
             from beta_recsys_amd.replicated import replicated_ncf_engine
 
             eng = replicated_ncf_engine(hp.NeuMFEngine)(cfg)
@@ -311,8 +317,11 @@ def bench_ncf(args, device, world=1, rank=0, dist_on=False):
                 "config": {"workload": f"NeuMF (BASELINE configs[2]): 6040 x 3706, emb_dim {E} => tables "
                                        f"{dims[0] // 2}/{dims[0] // 2}/{E}/{E}, tower {'->'.join(map(str, dims))}, head "
                                        f"{2 * E}->1, batch 4096/GPU, adam 1e-3",
-                           "parallelism": f"dp{world}: replicated tables + tower, one RCCL all-reduce per step" if dist_on
-                           else "single GPU", "rccl_world_size": world if dist_on else None,
+                           "parallelism": (f"tables row-sharded over {world} GPUs (owner = row mod {world}), ids / rows / row "
+                                           "gradients routed with RCCL all-to-alls, tower replicated + all-reduced"
+                                           if dist_on and args.multi_gpu == "sharded" else
+                                           f"dp{world}: replicated tables + tower, one RCCL all-reduce per step" if dist_on
+                                           else "single GPU"), "rccl_world_size": world if dist_on else None,
                            "last_loss": st.loss},
                 "roofline": {"bound": "mfma", "achieved": B * flops / step_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                              "frac": B * flops / step_s / 1e12 / 157.3, "flops_per_sample": flops,

@@ -11,9 +11,9 @@ Same config keys, same ``state_dict`` keys / shapes (``embedding_*``, ``fc_layer
 ``affine_output.*``), same initial weights for the same torch seed, ``train_single_batch(users,
 items, ratings) -> float``, ``train_an_epoch`` with the reference's prints and ``add_scalar`` tag,
 ``model.predict -> [n, 1]`` tensor.  The arithmetic — gather, fp32-MFMA tower forward / backward,
-BCE, scatter, dense optimizer — is ``csrc/ncf.hip`` + ``csrc/optim.hip``.  Dropout must be 0 (the
-shipped configs' value): the reference draws its masks from the CPU RNG stream, which no GPU kernel
-can reproduce.
+BCE, scatter, dense optimizer — is ``csrc/ncf.hip`` + ``csrc/optim.hip``.  Tower dropout (``dropout`` > 0,
+models/ncf.py:42-45; the shipped configs use 0) is supported: the keep masks are either ``nn.Dropout``'s own
+CPU draws replayed (same torch seed -> the reference's masks) or drawn on the device (``dropout_rng``).
 """
 import ctypes
 import os
@@ -151,8 +151,10 @@ class _NcfBase(_FlatModel):
         """hiprec_ncf_plan over the parameters (and the gradient buffer ``g_flat`` if given)."""
         ws = self.workspace(batch)
         key = (self._flat.data_ptr(), None if g_flat is None else g_flat.data_ptr(), ws["max_batch"])
-        if self._plan_cache is not None and self._plan_cache[0] == key:
-            return self._plan_cache[1]
+        if self._plan_cache is None:
+            self._plan_cache = {}
+        if key in self._plan_cache:   # the forward (eval) plan and the gradient plan coexist
+            return self._plan_cache[key]
         w = self.views()
         g = self.views(g_flat) if g_flat is not None else None
         p = _lib.NcfPlan()
@@ -183,7 +185,9 @@ class _NcfBase(_FlatModel):
             p.dact[l] = ws["dact"][l].data_ptr()
         p.mf, p.dmf, p.scores = ws["mf"].data_ptr(), ws["dmf"].data_ptr(), ws["scores"].data_ptr()
         p.keep_scale = 1.0
-        self._plan_cache = (key, p)
+        if len(self._plan_cache) > 4:
+            self._plan_cache.clear()
+        self._plan_cache[key] = p
         return p
 
     def draw_keep_masks(self, plan, batch):
@@ -207,7 +211,7 @@ class _NcfBase(_FlatModel):
         for l, (nin, _) in enumerate(self.tower_dims):
             buf = ws["keep"][l]
             if rng == "torch_cpu":
-                buf[:batch].copy_(torch.empty(batch, nin).bernoulli_(1 - p).to(torch.uint8))
+                buf[:batch].copy_(torch.empty(batch, nin).bernoulli_(max(1 - p, 0.0)).to(torch.uint8))
             elif rng == "device":
                 seed = int(self.config["dropout_seed"]) if "dropout_seed" in self.config else 0
                 _lib.check(_lib.load().hiprec_edge_dropout_mask(
@@ -216,7 +220,7 @@ class _NcfBase(_FlatModel):
             else:
                 raise ValueError(f"unknown dropout_rng {rng!r}: 'torch_cpu' or 'device'")
             plan.keep[l] = buf.data_ptr()
-        plan.keep_scale = 1.0 / (1.0 - p)
+        plan.keep_scale = 1.0 / (1.0 - p) if p < 1.0 else 0.0   # nn.Dropout(p=1) outputs zeros
 
     # -- reference API ------------------------------------------------------------------------
     def forward(self, user_indices, item_indices):

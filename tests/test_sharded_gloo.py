@@ -276,3 +276,115 @@ def test_replicated_gradient_sum_equals_global_batch_gradient(tmp_path):
     loss, reg, g = onp.mf_bpr_grads(res["w"], *res["batch"])
     ref = np.concatenate([g[k].ravel() for k in KEYS] + [[loss, reg]])
     assert_tensor_close(res["buf"], ref, 1e-5, "all-reduced [grad | loss | reg]")
+
+
+# ---- row-sharded NCF (sharded_ncf.py): host logic on 2 gloo ranks, the numpy oracle as the kernel backend ------
+
+class OracleNcfKernels:
+    """oracle/ncf_numpy.py behind the sharded NCF engine's kernel seam (CPU tensors)."""
+
+    def __init__(self, kind):
+        self.kind, self.st = kind, None
+
+    def reset_clock(self, beta1, beta2):
+        pass
+
+    def gather_rows(self, table, idx):
+        return table[idx].clone()
+
+    def scatter_add_rows(self, table, idx, src):
+        table.index_add_(0, idx, src.contiguous())
+
+    def grad_on_fetched(self, model, g_flat, fetched, g_fetched, ratings, inv_batch, loss_out):
+        from oracle import ncf_numpy as onc
+
+        b = ratings.numel()
+        names = dict(zip(("user_mlp", "item_mlp", "user_mf", "item_mf"), model._names()))
+        w = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+        for field, t in fetched.items():          # the fetched rows play the tables: sample k reads row k
+            w[names[field]] = t.numpy()
+        loss, g, _ = onc.ncf_grads(w, np.arange(b), np.arange(b), ratings.numpy(), self.kind)
+        scale = np.float32(b * inv_batch)         # the oracle averages over the LOCAL batch
+        gv = model.views(g_flat)
+        for k, v in g.items():
+            field = next((f for f, n in names.items() if n == k), None)
+            if field is not None:
+                g_fetched[field] += torch.from_numpy(v * scale)
+            else:
+                gv[k] += torch.from_numpy(v * scale).reshape(gv[k].shape)
+        loss_out[0] = float(loss) * float(scale)
+        loss_out[1] = 0.0
+
+    def advance_clock(self):
+        pass
+
+    def opt_step(self, opt, flat_w, flat_g):
+        if self.st is None:
+            self.st = onp.new_opt_state({"flat": flat_w.numpy()}, opt.name)
+        onp.opt_step({"flat": flat_w.numpy()}, {"flat": flat_g.numpy()}, self.st, opt.name, opt.lr)
+        flat_g.zero_()
+
+    def check_status(self):
+        pass
+
+
+def ncf_worker(rank, world, port, kind, optimizer, lr, splits, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import beta_recsys_amd as hp
+        from beta_recsys_amd import sharded_ncf
+
+        U, I, E, L = 23, 19, 4, 2
+        cfg = {"model": dict(n_users=U, n_items=I, emb_dim=E, dropout=0.0, device_str="cpu", optimizer=optimizer, lr=lr,
+                             batch_size=8, model="ncf_end", mlp_config={"n_layers": L}, gmf_config={}),
+               "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+        torch.manual_seed(3)   # the same seed on every rank: the same full model, every rank keeps its rows
+        with contextlib.redirect_stdout(io.StringIO()):
+            full = getattr(hp, {"neumf": "NeuMF", "gmf": "GMF", "mlp": "MLP"}[kind])(cfg["model"]).state_dict()
+        engine_cls = {"neumf": sharded_ncf.ShardedNeuMFEngine, "gmf": sharded_ncf.ShardedGMFEngine,
+                      "mlp": sharded_ncf.ShardedMLPEngine}[kind]
+        eng = engine_cls(cfg, kernels=OracleNcfKernels(kind), full_state=full)
+        rng = np.random.default_rng(100)
+        losses, batches = [], []
+        for split in splits:
+            B = sum(split)
+            users, items = rng.integers(0, U, B), rng.integers(0, I, B)
+            items[: B // 3] = items[0]   # a popular item: many rows fetched from one owner
+            ratings = (rng.random(B) < 0.3).astype(np.float32)
+            batches.append((users, items, ratings))
+            lo = sum(split[:rank])
+            sl = slice(lo, lo + split[rank])
+            losses.append(eng.train_single_batch(users[sl], items[sl], ratings[sl]))
+        out = eng.gather_full_state_dict()
+        if rank == 0:
+            torch.save({"losses": losses, "full": {k: v.numpy() for k, v in out.items()}, "batches": batches,
+                        "w0": {k: v.numpy() for k, v in full.items()}}, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,optimizer,lr", [("neumf", "adam", 0.01), ("neumf", "sgd", 0.1), ("gmf", "adam", 0.01),
+                                               ("mlp", "rmsprop", 0.01)])
+def test_two_rank_sharded_ncf_equals_single_process(tmp_path, kind, optimizer, lr):
+    """Tables row-sharded over 2 ranks (owner = row mod 2), tower replicated: the same losses and the same full
+    state_dict as oracle/ncf_numpy.py's single-process step on the concatenated batches -- even / uneven splits,
+    an empty rank, a popular item."""
+    from oracle import ncf_numpy as onc
+
+    splits = [(10, 10), (13, 7), (20, 0), (2, 3)]
+    out_path = str(tmp_path / "out.pt")
+    mp.spawn(ncf_worker, args=(2, free_port(), kind, optimizer, lr, splits, out_path), nprocs=2, join=True)
+    res = torch.load(out_path, weights_only=False)
+    w = {k: v.copy() for k, v in res["w0"].items()}
+    st = onc.new_opt_state(w, optimizer)
+    for batch, loss in zip(res["batches"], res["losses"]):
+        ref = onc.ncf_train_step(w, st, batch, kind, optimizer, lr)
+        assert_scalar_close(loss, ref, 2e-5, "loss")
+    tol = 1e-6 if optimizer == "sgd" else 2e-3
+    assert set(res["full"]) == set(w)
+    for k in w:
+        assert res["full"][k].shape == w[k].shape, k
+        assert np.mean(np.abs(res["full"][k] - w[k]) > tol) < 0.01, f"{k} differs from the single-process run"

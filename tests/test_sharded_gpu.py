@@ -211,3 +211,41 @@ def test_replicated_ncf_engine_with_hip_kernels(nccl_group):
     got = {k: v.cpu().numpy() for k, v in eng.model.state_dict().items()}
     for k in w:
         assert np.mean(np.abs(got[k] - w[k]) > 2e-3 * max(np.abs(w[k]).max(), 1e-3)) < 0.01, k
+
+
+@pytest.mark.parametrize("kind,emb", [("neumf", 32), ("neumf", 8), ("gmf", 16), ("mlp", 16)])
+def test_sharded_ncf_engine_with_hip_kernels(nccl_group, kind, emb):
+    """sharded_ncf.py with the real kernels at world size 1 (RCCL all-to-all / all-reduce with itself): ids routed
+    to the owner, rows fetched, hiprec_ncf_grad on the fetched buffers, row gradients returned and scattered, dense
+    Adam over [table shards | tower | head] -- equal to oracle/ncf_numpy.py's single-process steps."""
+    import beta_recsys_amd as hp
+    from beta_recsys_amd import sharded_ncf
+    from oracle import ncf_numpy as onc
+
+    U, I, L, B = 300, 200, 3, 512
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=emb, dropout=0.0, device_str="cuda:0", optimizer="adam",
+                         lr=0.01, batch_size=B, model="ncf_end", mlp_config={"n_layers": L}, gmf_config={}),
+           "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+    torch.manual_seed(5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        full = getattr(hp, {"neumf": "NeuMF", "gmf": "GMF", "mlp": "MLP"}[kind])(dict(cfg["model"], device_str="cpu")).state_dict()
+    cls = {"neumf": sharded_ncf.ShardedNeuMFEngine, "gmf": sharded_ncf.ShardedGMFEngine,
+           "mlp": sharded_ncf.ShardedMLPEngine}[kind]
+    eng = cls(cfg, full_state=full)
+    w = {k: v.numpy().copy() for k, v in full.items()}
+    st = onc.new_opt_state(w, "adam")
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        users, items = rng.integers(0, U, B), rng.integers(0, I, B)
+        items[: B // 4] = items[0]
+        ratings = (rng.random(B) < 0.2).astype(np.float32)
+        loss = eng.train_single_batch(users, items, ratings)
+        ref = onc.ncf_train_step(w, st, (users, items, ratings), kind, "adam", 0.01)
+        assert_scalar_close(loss, ref, 2e-5, "loss")
+    out = eng.gather_full_state_dict()
+    for k in w:
+        got = out[k].cpu().numpy()
+        assert got.shape == w[k].shape
+        assert np.mean(np.abs(got - w[k]) > 2e-3) < 0.01, f"{k}: differs from the single-process run"
+    with pytest.raises(IndexError):
+        eng.train_single_batch(np.array([U]), np.array([0]), np.array([1.0], dtype=np.float32))
