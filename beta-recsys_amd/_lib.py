@@ -277,6 +277,14 @@ SIGNATURES = {
     "hiprec_ownership_table_bits": (c_int32, [c_int64]),
     "hiprec_batch_row_ownership": (
         c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
+    "hiprec_mf_bpr_owned_remote_step": (
+        c_int,
+        [_P, c_int64, c_int64, c_int32, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_float,
+         c_float, c_double, _P, _P, _P],
+    ),
+    "hiprec_shard_publish_partials": (c_int, [_P, _P, c_int32, _P, c_int32, _P]),
+    "hiprec_shard_apply_rows": (c_int, [_P, _P, c_int64, c_int32, _P, _P, c_int64, c_double, _P, _P]),
+    "hiprec_shard_finish_step": (c_int, [_P, c_int32, _P, c_int32, _P, c_double, c_int32, _P, _P]),
     "hiprec_mf_bpr_epoch_sgd_fused": (
         c_int,
         [_P, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P, c_int64, c_int64, c_float, c_double, _P,

@@ -58,6 +58,12 @@ struct OwnedStep {
   int32_t n_prev_partials, n_gather_blocks;
   float lr;
   int32_t dbg;                 // timing experiments only (HIPREC_OWNED_DBG): 1 = every row direct, 2 = no writes
+  // where rows live, in floats relative to w: user row u at u * dim, user bias at o_ub + u, item row i at
+  // o_ie + i * item_stride, item bias at o_ib + i * bias_stride.  Local tables: the flat layout.  Row-sharded
+  // engine (REMOTE): the items are slots of the fetched [n_slots, dim + 1] exchange buffer (o_ie = fetched - w,
+  // strides dim + 1, bias behind the row) and their gradients go to item_out (same layout) instead of the table.
+  int64_t o_ub, o_ie, o_ib, item_stride, bias_stride;
+  float* item_out;
 };
 
 __device__ __forceinline__ float atomic_swap_f32(float* p, float v) {
@@ -82,7 +88,7 @@ __device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
 // rows this wave completed are swapped out kOwnedGroup at a time, re-read (a row still holds its pre-step value:
 // only its owner ever writes it) and written back as w - lr * g.
 // Waves never wait for each other inside the loop.
-template <int NPL>
+template <int NPL, bool REMOTE>
 __global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
     OwnedStep f, const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
     const int64_t* __restrict__ neg, int64_t batch, float inv_batch, float reg_coef, hiprec_stats* stats,
@@ -93,9 +99,10 @@ __global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
   const int wv = wave_in_block();
   const bool apply = f.apply_prev != 0;
   const int D = f.dim;
-  const int64_t o_ie = f.n_users * D, o_ub = o_ie + f.n_items * D, o_ib = o_ub + f.n_users;
+  const int64_t o_ie = f.o_ie, o_ub = f.o_ub, o_ib = f.o_ib, i_st = f.item_stride, b_st = f.bias_stride;
 
   if (static_cast<int>(blockIdx.x) >= f.n_gather_blocks) {
+    if constexpr (REMOTE) return;  // the sharded step settles stats and the scalar bias after its exchange
     // ---- the extra block: previous step's partials -> stats and the scalar bias; count this step ----
     if (!apply && threadIdx.x == 0) {  // first launch of an epoch: hiprec_stats_begin_epoch, folded in
       stats->loss_sum = 0.0;
@@ -184,8 +191,8 @@ __global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
       if (lsp >= 0) ltp = f.total[lsp];
       if (lsn >= 0) ltn = f.total[lsn];
       lbu = wf[o_ub + lu];
-      lbp = wf[o_ib + lp];
-      lbn = wf[o_ib + ln];
+      lbp = wf[o_ib + lp * b_st];
+      lbn = wf[o_ib + ln * b_st];
     }
     const uint64_t ok_mask = __ballot(lok);
 
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int64_t u = readlane64(lu, i), p = readlane64(lp, i), n = readlane64(ln, i);  // row 0 beyond cnt
-      const int64_t ou = u * D, op = o_ie + p * D, on = o_ie + n * D;
+      const int64_t ou = u * D, op = o_ie + p * i_st, on = o_ie + n * i_st;
 #pragma unroll
       for (int k = 0; k < NPL; ++k) {
         const int c = lane + kWave * k;
@@ -248,6 +255,26 @@ __global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
       }
     };
 
+    // REMOTE items: the gradient of slot `item` goes into the exchange buffer -- a plain store when this wave holds
+    // every reference to the slot, an atomic add otherwise; the owner applies it after the exchange
+    auto send_item = [&](int slot, int wt, int tot, int64_t item, const float (&g)[NPL], float gb_) {
+      if (f.dbg & 2) return;
+      float* o = f.item_out + item * i_st;
+      const bool all_mine = slot < 0 || wt == tot;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        const int c = lane + kWave * k;
+        if (c < D) {
+          if (all_mine) o[c] = g[k];
+          else atomic_add_f32(o + c, g[k]);
+        }
+      }
+      if (lane == 0) {
+        if (all_mine) o[D] = gb_;
+        else atomic_add_f32(o + D, gb_);
+      }
+    };
+
     // the run of equal positive items in progress
     int64_t run_p = -1;
     int run_len = 0, run_slot = -1, run_tot = 1;
@@ -255,8 +282,10 @@ __global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
 #pragma unroll
     for (int k = 0; k < NPL; ++k) run_g[k] = run_v[k] = 0.f;
     auto flush_run = [&]() {
-      if (run_len > 0)
-        settle(run_slot, run_len, run_tot, o_ie + run_p * D, o_ib + run_p, run_g, run_gb, run_v, run_vb);
+      if (run_len > 0) {
+        if constexpr (REMOTE) send_item(run_slot, run_len, run_tot, run_p, run_g, run_gb);
+        else settle(run_slot, run_len, run_tot, o_ie + run_p * i_st, o_ib + run_p * b_st, run_g, run_gb, run_v, run_vb);
+      }
       run_len = 0;
     };
 
@@ -294,8 +323,11 @@ __global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
       gb_acc += dpos + dneg;
       settle(__builtin_amdgcn_readlane(lsu, i), 1, __builtin_amdgcn_readlane(ltu, i), u * D, o_ub + u, gu,
              (dpos + dneg) + ru * bu, ru_[i], bu);
-      settle(__builtin_amdgcn_readlane(lsn, i), 1, __builtin_amdgcn_readlane(ltn, i), o_ie + n * D, o_ib + n, gn,
-             dneg + ri * bn, rn_[i], bn);
+      if constexpr (REMOTE)
+        send_item(__builtin_amdgcn_readlane(lsn, i), 1, __builtin_amdgcn_readlane(ltn, i), n, gn, dneg + ri * bn);
+      else
+        settle(__builtin_amdgcn_readlane(lsn, i), 1, __builtin_amdgcn_readlane(ltn, i), o_ie + n * i_st,
+               o_ib + n * b_st, gn, dneg + ri * bn, rn_[i], bn);
       if (run_len > 0 && p == run_p) {
 #pragma unroll
         for (int k = 0; k < NPL; ++k) run_g[k] += dpos * ru_[i][k] + ri * rp_[i][k];
@@ -391,16 +423,22 @@ __global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
   }
 }
 
+template <bool REMOTE>
 static int launch_owned(const OwnedStep& f, int grid, hipStream_t st, const int64_t* uu, const int64_t* pp,
                         const int64_t* nn, int64_t b, float inv_b, float reg_coef, hiprec_stats* stats, Scratch* sc) {
   if (f.dim <= 64)
-    mf_bpr_owned_kernel<1><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    mf_bpr_owned_kernel<1, REMOTE><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
   else if (f.dim <= 128)
-    mf_bpr_owned_kernel<2><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    mf_bpr_owned_kernel<2, REMOTE><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
   else
-    mf_bpr_owned_kernel<4><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    mf_bpr_owned_kernel<4, REMOTE><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
   HIPREC_TRY(hipGetLastError());
   return 0;
+}
+
+static int owned_blocks(int dim, int64_t bb) {
+  const int64_t per_block = static_cast<int64_t>(owned_chunk(dim <= 64 ? 1 : dim <= 128 ? 2 : 4)) * kOwnedWaves;
+  return static_cast<int>(std::min<int64_t>((bb + per_block - 1) / per_block, kOwnedMaxGather));
 }
 
 }  // namespace hiprec
@@ -432,10 +470,7 @@ extern "C" int hiprec_mf_bpr_epoch_owned(float* w_flat, int64_t n_users, int64_t
     const int64_t off = k * batch;
     const int64_t b = k < n_steps ? std::min<int64_t>(batch, n_triples - off) : 0;
     const int64_t prev_b = k > 0 ? std::min<int64_t>(batch, n_triples - (k - 1) * batch) : 0;
-    auto blocks = [dim](int64_t bb) {
-      const int64_t per_block = static_cast<int64_t>(owned_chunk(dim <= 64 ? 1 : dim <= 128 ? 2 : 4)) * kOwnedWaves;
-      return static_cast<int>(std::min<int64_t>((bb + per_block - 1) / per_block, kOwnedMaxGather));
-    };
+    auto blocks = [dim](int64_t bb) { return owned_blocks(dim, bb); };
     OwnedStep f;
     f.w = w_flat;
     f.n_users = n_users;
@@ -455,13 +490,68 @@ extern "C" int hiprec_mf_bpr_epoch_owned(float* w_flat, int64_t n_users, int64_t
     f.n_prev_partials = prev_b > 0 ? blocks(prev_b) : 0;
     f.n_gather_blocks = b > 0 ? blocks(b) : 0;
     f.lr = static_cast<float>(lr);
+    f.o_ie = n_users * dim;
+    f.o_ub = (n_users + n_items) * static_cast<int64_t>(dim);
+    f.o_ib = f.o_ub + n_users;
+    f.item_stride = dim;
+    f.bias_stride = 1;
+    f.item_out = nullptr;
     static const int dbg = getenv("HIPREC_OWNED_DBG") ? atoi(getenv("HIPREC_OWNED_DBG")) : 0;
     f.dbg = dbg;
     const float inv_b = b > 0 ? 1.0f / static_cast<float>(b) : 0.f;
-    if (int rc = launch_owned(f, f.n_gather_blocks + 1, st, users ? users + off : nullptr, pos ? pos + off : nullptr,
+    if (int rc = launch_owned<false>(f, f.n_gather_blocks + 1, st, users ? users + off : nullptr, pos ? pos + off : nullptr,
                               neg ? neg + off : nullptr, b, inv_b, reg_coef, stats,
                               static_cast<Scratch*>(scratch2[k & 1])))
       return rc;
   }
   return 0;
+}
+
+// ---- the row-sharded engine's step (beta-recsys_amd/sharded.py): the same kernel on (local user shard, FETCHED item
+// rows).  users[] are local user rows (-1 = padding), pos[] / neg[] are SLOTS of the fetched [n_slots, dim + 1]
+// exchange buffer (row | bias); user rows are updated in place (own_u / total as in hiprec_mf_bpr_epoch_owned, over
+// the triples this rank received), item-slot gradients are written into g_send (same layout, zero on entry for the
+// slots several triples reference: own_p / own_n >= 0 with total > 1) for the exchange back to their owners.  The
+// loss partials stay in `scratch` (hiprec_shard_publish_partials moves them into the exchange); the scalar bias is
+// read as it is (the previous step's hiprec_shard_finish_step updated it); the optimizer clock is not touched.
+extern "C" int hiprec_mf_bpr_owned_remote_step(float* w_flat, int64_t n_users, int64_t n_items_local, int32_t dim,
+                                               const float* fetched, float* g_send, int64_t n_slots,
+                                               const int64_t* users, const int64_t* pos_slot, const int64_t* neg_slot,
+                                               const int32_t* own_u, const int32_t* own_p, const int32_t* own_n,
+                                               const int32_t* total, int32_t* arrived, float* acc, int64_t batch,
+                                               float inv_batch, float reg_coef, double lr, hiprec_stats* stats,
+                                               void* scratch, void* stream) {
+  HIPREC_REQUIRE(w_flat && stats && scratch, "NULL pointer");
+  HIPREC_REQUIRE(n_users > 0 && n_items_local >= 0 && dim > 0 && dim <= 256, "bad shape");
+  HIPREC_REQUIRE(batch >= 0 && n_slots >= 0, "negative batch / n_slots");
+  if (batch == 0) return 0;
+  HIPREC_REQUIRE(fetched && g_send && users && pos_slot && neg_slot && own_u && own_p && own_n && total && arrived && acc,
+                 "NULL pointer");
+  OwnedStep f;
+  f.w = w_flat;
+  f.n_users = n_users;
+  f.n_items = n_slots;   // bound of the item ids the kernel sees
+  f.dim = dim;
+  f.apply_prev = 0;
+  f.own_u = own_u;
+  f.own_p = own_p;
+  f.own_n = own_n;
+  f.total = total;
+  f.arrived = arrived;
+  f.acc = acc;
+  const int64_t o_gb = (n_users + n_items_local) * (static_cast<int64_t>(dim) + 1);
+  f.gb_read = w_flat + o_gb;
+  f.gb_write = nullptr;
+  f.scratch_prev = static_cast<const Scratch*>(scratch);
+  f.n_prev_partials = 0;
+  f.n_gather_blocks = owned_blocks(dim, batch);
+  f.lr = static_cast<float>(lr);
+  f.dbg = 0;
+  f.o_ub = (n_users + n_items_local) * static_cast<int64_t>(dim);
+  f.o_ie = fetched - w_flat;   // the exchange buffer, addressed relative to the parameters (one flat address space)
+  f.o_ib = f.o_ie + dim;
+  f.item_stride = f.bias_stride = dim + 1;
+  f.item_out = g_send;
+  return launch_owned<true>(f, f.n_gather_blocks, static_cast<hipStream_t>(stream), users, pos_slot, neg_slot, batch,
+                            inv_batch, reg_coef, stats, static_cast<Scratch*>(scratch));
 }

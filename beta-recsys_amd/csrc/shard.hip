@@ -144,10 +144,128 @@ __global__ __launch_bounds__(kBlock) void shard_join_kernel(const float* __restr
   }
 }
 
+// ---- the epoch-planned sharded step (sharded.py::ShardedMFEngine.train_an_epoch, plain SGD) --------------------
+// Each destination's chunk of the gradient exchange ends with ONE extra row that carries this rank's
+// [loss, reg, d loss / d scalar bias] of the step: the 3-float all-reduce rides in the all-to-all.
+__global__ __launch_bounds__(kBlock) void shard_publish_partials_kernel(const Scratch* __restrict__ scratch,
+                                                                        float* __restrict__ g_send, int ld,
+                                                                        const int64_t* __restrict__ extra_rows,
+                                                                        int n_dest) {
+  __shared__ double s_l[kBlock], s_r[kBlock], s_b[kBlock];
+  const uint32_t n = scratch->n_partials;
+  double l = 0.0, r = 0.0, b = 0.0;
+  for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+    const float4 p = scratch->partials[i];
+    l += p.x;
+    r += p.y;
+    b += p.z;
+  }
+  s_l[threadIdx.x] = l;
+  s_r[threadIdx.x] = r;
+  s_b[threadIdx.x] = b;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (static_cast<int>(threadIdx.x) < s) {
+      s_l[threadIdx.x] += s_l[threadIdx.x + s];
+      s_r[threadIdx.x] += s_r[threadIdx.x + s];
+      s_b[threadIdx.x] += s_b[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (static_cast<int>(threadIdx.x) < n_dest) {
+    float* row = g_send + extra_rows[threadIdx.x] * ld;
+    row[0] = static_cast<float>(s_l[0]);
+    row[1] = static_cast<float>(s_r[0]);
+    row[2] = static_cast<float>(s_b[0]);
+  }
+}
+
+// Owner side of the gradient exchange: item row idx[k] (and its bias) -= lr * g_recv[k]; rows with idx -1 (the
+// extra rows, padding) are skipped.  Several peers may return gradients of one item: fp32 atomics.  Plain SGD on
+// the received rows IS the whole item-side optimizer step: no dense gradient buffer, no second pass.
+__global__ __launch_bounds__(kBlock) void shard_apply_rows_kernel(float* __restrict__ item_emb,
+                                                                  float* __restrict__ item_bias, int64_t n_rows,
+                                                                  int dim, const int64_t* __restrict__ idx,
+                                                                  const float* __restrict__ g_recv, int64_t n,
+                                                                  float lr, hiprec_stats* stats) {
+  const int lane = lane_id();
+  const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int ld = dim + 1;
+  for (int64_t k = wave0; k < n; k += n_waves) {
+    const int64_t r = idx[k];
+    if (r < 0) continue;
+    if (r >= n_rows) {
+      if (lane == 0) atomicOr(&stats->status, HIPREC_STATUS_ROW_OOB);
+      continue;
+    }
+    const float* g = g_recv + k * ld;
+    for (int c = lane; c < dim; c += kWave) atomic_add_f32(item_emb + r * dim + c, -lr * g[c]);
+    if (lane == 0) atomic_add_f32(item_bias + r, -lr * g[dim]);
+  }
+}
+
+// After the gradient exchange: sum the extra rows of every peer (the global loss, regularizer and scalar-bias
+// gradient of the step), book them in hiprec_stats, apply the scalar bias update, count the step.
+__global__ void shard_finish_step_kernel(const float* __restrict__ g_recv, int ld,
+                                         const int64_t* __restrict__ extra_rows, int n_src, float* global_bias,
+                                         float lr, int first_of_epoch, hiprec_stats* stats) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float l = 0.f, r = 0.f, b = 0.f;
+  for (int q = 0; q < n_src; ++q) {
+    const float* row = g_recv + extra_rows[q] * ld;
+    l += row[0];
+    r += row[1];
+    b += row[2];
+  }
+  if (first_of_epoch) {
+    stats->loss_sum = 0.0;
+    stats->reg_sum = 0.0;
+  }
+  stats->loss = l;
+  stats->reg = r;
+  stats->loss_sum += static_cast<double>(l);
+  stats->reg_sum += static_cast<double>(r);
+  *global_bias = *global_bias - lr * b;
+  advance_step(stats);
+}
+
 }  // namespace
 }  // namespace hiprec
 
 using namespace hiprec;
+
+extern "C" int hiprec_shard_publish_partials(const void* scratch, float* g_send, int32_t dim,
+                                             const int64_t* extra_rows, int32_t n_dest, void* stream) {
+  HIPREC_REQUIRE(scratch && g_send && extra_rows && dim > 0 && n_dest > 0 && n_dest <= kBlock, "bad arguments");
+  shard_publish_partials_kernel<<<1, kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const Scratch*>(scratch), g_send, dim + 1, extra_rows, n_dest);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_shard_apply_rows(float* item_emb, float* item_bias, int64_t n_rows, int32_t dim,
+                                       const int64_t* idx, const float* g_recv, int64_t n, double lr,
+                                       hiprec_stats* stats, void* stream) {
+  HIPREC_REQUIRE(n >= 0 && n_rows >= 0 && dim > 0, "bad sizes");
+  if (n == 0) return 0;
+  HIPREC_REQUIRE(item_emb && item_bias && idx && g_recv && stats, "NULL pointer");
+  shard_apply_rows_kernel<<<grid_for_waves(n), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      item_emb, item_bias, n_rows, dim, idx, g_recv, n, static_cast<float>(lr), stats);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_shard_finish_step(const float* g_recv, int32_t dim, const int64_t* extra_rows, int32_t n_src,
+                                        float* global_bias, double lr, int32_t first_of_epoch, hiprec_stats* stats,
+                                        void* stream) {
+  HIPREC_REQUIRE(g_recv && extra_rows && global_bias && stats && dim > 0 && n_src > 0, "bad arguments");
+  shard_finish_step_kernel<<<1, 1, 0, static_cast<hipStream_t>(stream)>>>(g_recv, dim + 1, extra_rows, n_src,
+                                                                       global_bias, static_cast<float>(lr),
+                                                                       first_of_epoch, stats);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
 
 extern "C" int hiprec_shard_route_triples(const int64_t* users, const int64_t* pos, const int64_t* neg,
                                           int64_t n, int32_t n_dest, int64_t cap, int32_t* counts,

@@ -162,6 +162,41 @@ class HipKernels:
             ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(items), None, None, n, lr,
             _lib.ptr(user_stamp), _lib.ptr(item_stamp), stamp, _lib.ptr(self.stats), None, self._st()))
 
+    # ---- the epoch-planned SGD step (csrc/mf_owned.hip REMOTE variant + csrc/shard.hip) ---------------------------
+    def payload_rows(self, item_emb, item_bias, local_idx, payload):
+        """payload[k] = [item_emb row | item_bias] of LOCAL row local_idx[k] (zeros for -1)."""
+        if getattr(self, "_idx_scratch", None) is None or self._idx_scratch.numel() < local_idx.numel():
+            self._idx_scratch = torch.empty(max(local_idx.numel(), 1), dtype=torch.int64, device=self.device)
+        self.gather_payload(item_emb, item_bias, local_idx, 1, payload, self._idx_scratch)
+
+    def owned_remote_step(self, model, fetched, g_send, n_slots, users, slot_pos, slot_neg, own, total, arrived, acc,
+                          inv_batch, reg_coef, lr):
+        _lib.check(self.lib.hiprec_mf_bpr_owned_remote_step(
+            _lib.ptr(model.flat), model.n_users, model.n_items, model.emb_dim, _lib.ptr(fetched), _lib.ptr(g_send),
+            n_slots, _lib.ptr(users), _lib.ptr(slot_pos), _lib.ptr(slot_neg), _lib.ptr(own[0]), _lib.ptr(own[1]),
+            _lib.ptr(own[2]), _lib.ptr(total), _lib.ptr(arrived), _lib.ptr(acc), users.numel(), inv_batch, reg_coef,
+            lr, _lib.ptr(self.stats), _lib.ptr(self.scratch), self._st()))
+
+    def publish_partials(self, g_send, dim, extra_rows):
+        _lib.check(self.lib.hiprec_shard_publish_partials(_lib.ptr(self.scratch), _lib.ptr(g_send), dim,
+                                                          _lib.ptr(extra_rows), extra_rows.numel(), self._st()))
+
+    def apply_rows(self, item_emb, item_bias, local_idx, g_recv, lr):
+        _lib.check(self.lib.hiprec_shard_apply_rows(
+            _lib.ptr(item_emb), _lib.ptr(item_bias), item_emb.shape[0], item_emb.shape[1], _lib.ptr(local_idx),
+            _lib.ptr(g_recv), local_idx.numel(), lr, _lib.ptr(self.stats), self._st()))
+
+    def finish_step(self, g_recv, dim, extra_rows, global_bias, lr, first_of_epoch):
+        _lib.check(self.lib.hiprec_shard_finish_step(
+            _lib.ptr(g_recv), dim, _lib.ptr(extra_rows), extra_rows.numel(), _lib.ptr(global_bias), lr,
+            1 if first_of_epoch else 0, _lib.ptr(self.stats), self._st()))
+
+    def epoch_stats(self):
+        """(last loss, last reg, loss sum, reg sum) of the epoch (synchronises)."""
+        self.check_status()
+        st = read_stats(self.stats)
+        return st.loss, st.reg, st.loss_sum, st.reg_sum
+
     def advance_clock(self):
         """A rank that received no triple this step still has to tick the optimizer clock."""
         _lib.check(self.lib.hiprec_stats_advance_step(_lib.ptr(self.stats), self._st()))
@@ -472,9 +507,174 @@ class ShardedMFEngine:
         self.last = (loss, reg)
         return loss, reg
 
+    # ---- epoch-planned steps (plain SGD): routing is a property of the DATA, so it is done once per epoch -------------
+    # Which rank owns a triple's user row and which item rows each rank must fetch for each step depend on the ids
+    # only, not on the weights.  For a device-resident loader the whole epoch is therefore routed in the staging:
+    # ONE all-to-all moves every triple to owner(user); the item references of every step are de-duplicated per
+    # (step, owner) (Zipf items: high duplication) and ONE all-to-all tells every owner which rows it will
+    # be asked for, step by step.  What is left per step is exact-size (the split sizes are host integers: no
+    # padding, nothing read back) and weight-dependent only:
+    #     gather rows -> all-to-all -> owned-rows kernel on (local users, fetched rows) -> all-to-all -> apply
+    # i.e. 2 collectives and 5 launches instead of 5 and 14.  User rows are updated in place by the gradient kernel
+    # (csrc/mf_owned.hip), item gradients are summed per fetched slot and applied by the owner with -lr straight
+    # into the table: no dense gradient buffer, no touched-rows pass; loss / reg / scalar-bias partials ride in one
+    # extra row per peer of the gradient exchange instead of a separate all-reduce.
+    def plan_epoch(self, train_loader):
+        """Collective.  Route one epoch of a DeviceTripleBatcher-like loader (this rank's share; the same number of
+        triples and batch size on every rank).  Returns the plan :meth:`run_planned_epoch` consumes."""
+        from .mf import batch_row_ownership
+
+        R, dev, D = self.world, self.device, self.emb_dim
+        users = train_loader.user_tensor.to(dev)
+        pos = train_loader.pos_item_tensor.to(dev)
+        neg = train_loader.neg_item_tensor.to(dev)
+        n, bs = users.numel(), int(train_loader.batch_size)
+        sizes = torch.tensor([n, -n, bs, -bs], dtype=torch.int64, device=dev)
+        dist.all_reduce(sizes, op=dist.ReduceOp.MAX, group=self.pg)
+        if sizes[0] != -sizes[1] or sizes[2] != -sizes[3]:
+            raise ValueError("the planned sharded epoch needs the same number of triples and batch size on every rank")
+        S = (n + bs - 1) // bs
+        perm = train_loader.permutation()
+        if perm is not None:
+            perm = perm.to(dev)
+            users, pos, neg = users[perm], pos[perm], neg[perm]
+        ar = lambda m: torch.arange(m, dtype=torch.int64, device=dev)  # noqa: E731
+        step = torch.div(ar(n), bs, rounding_mode="floor")
+
+        # (1) triples -> owner(user), the whole epoch in one exchange, (dest, step)-ordered
+        key = (users % R) * S + step
+        o1 = torch.argsort(key, stable=True)
+        cnt_ds = torch.bincount(key, minlength=R * S).view(R, S)
+        recv_cnt = torch.empty_like(cnt_ds)
+        dist.all_to_all_single(recv_cnt, cnt_ds, group=self.pg)            # [source, step]
+        n_k = recv_cnt.sum(0)
+        host = torch.cat([cnt_ds.sum(1), recv_cnt.sum(1), n_k.max().reshape(1)]).tolist()   # host sync 1 of 2
+        send1, recv1, cap = host[:R], host[R:2 * R], max(int(host[2 * R]), 1)
+        trip = self._a2a(torch.stack([users, pos, neg], 1)[o1], send1, recv1)   # (source, step)-ordered
+        step_r = torch.repeat_interleave(ar(S).repeat(R), recv_cnt.reshape(-1))
+        o2 = torch.argsort(step_r, stable=True)                            # -> (step, source)
+        trip, step_r = trip[o2], step_r[o2]
+        at = step_r * cap + (ar(trip.shape[0]) - (torch.cumsum(n_k, 0) - n_k)[step_r])
+        U = torch.full((S * cap,), -1, dtype=torch.int64, device=dev)      # fixed-size blocks, -1 = padding
+        P, N = torch.zeros_like(U), torch.zeros_like(U)
+        U[at] = torch.div(trip[:, 0], R, rounding_mode="floor")
+        P[at], N[at] = trip[:, 1], trip[:, 2]
+
+        # (2) item references de-duplicated per (step, owner); slot = position in the step's fetched buffer, whose
+        # layout is, per owner q: [rows asked of q ..., 1 extra row]
+        valid = U >= 0
+        v2 = torch.cat([valid, valid])
+        items = torch.cat([P, N])[v2]
+        st2 = torch.div(ar(2 * S * cap) % (S * cap), cap, rounding_mode="floor")[v2]
+        uniq, inv = torch.unique((st2 * R + items % R) * self.n_items + items, return_inverse=True)
+        u_item = uniq % self.n_items
+        u_sd = torch.div(uniq, self.n_items, rounding_mode="floor")       # step * R + dest
+        u_step, u_dest = torch.div(u_sd, R, rounding_mode="floor"), u_sd % R
+        req_cnt = torch.bincount(u_sd, minlength=S * R).view(S, R)
+        per_step = req_cnt.sum(1)
+        slot_u = ar(uniq.numel()) - (torch.cumsum(per_step, 0) - per_step)[u_step] + u_dest
+        slots = torch.zeros(2 * S * cap, dtype=torch.int64, device=dev)
+        slots[v2] = slot_u[inv]
+        SP, SN = slots[:S * cap], slots[S * cap:]
+
+        # (3) tell every owner which rows it will be asked for, step by step: one exchange, (dest, step)-ordered
+        req_ds = req_cnt.t().contiguous()
+        in_qs = torch.empty_like(req_ds)
+        dist.all_to_all_single(in_qs, req_ds, group=self.pg)               # [source, step]
+        in_cnt = in_qs.t().contiguous()                                   # [step, source]
+        host = torch.cat([req_ds.sum(1), in_qs.sum(1), req_cnt.reshape(-1), in_cnt.reshape(-1)]).tolist()  # sync 2 of 2
+        send2, recv2 = host[:R], host[R:2 * R]
+        req_l = [host[2 * R + k * R: 2 * R + (k + 1) * R] for k in range(S)]
+        in_l = [host[2 * R + S * R + k * R: 2 * R + S * R + (k + 1) * R] for k in range(S)]
+        o3 = torch.argsort(u_dest * S + u_step, stable=True)
+        incoming = self._a2a(u_item[o3], send2, recv2)                     # (source, step)-ordered
+        flat_cnt = in_qs.reshape(-1)
+        step_i = torch.repeat_interleave(ar(S).repeat(R), flat_cnt)
+        src_i = torch.repeat_interleave(ar(R).repeat_interleave(S), flat_cnt)
+        o4 = torch.argsort(step_i, stable=True)                            # -> (step, source)
+        incoming, step_i, src_i = incoming[o4], step_i[o4], src_i[o4]
+        in_idx = torch.full((incoming.numel() + S * R,), -1, dtype=torch.int64, device=dev)   # extras stay -1
+        in_idx[ar(incoming.numel()) + step_i * R + src_i] = torch.div(incoming, R, rounding_mode="floor")
+        in_len = [sum(c) + R for c in in_l]
+        n_slots = [sum(c) + R for c in req_l]
+        in_off = [0]
+        for length in in_len[:-1]:
+            in_off.append(in_off[-1] + length)
+
+        def extras(counts):  # position of each peer's extra row inside a step's block
+            out, run = [], 0
+            for q, c in enumerate(counts):
+                run += c
+                out.append(run + q)
+            return out
+
+        ex_req = torch.tensor([extras(c) for c in req_l], dtype=torch.int64, device=dev)
+        ex_in = torch.tensor([extras(c) for c in in_l], dtype=torch.int64, device=dev)
+
+        # (4) inside every step: triples sorted by positive slot (adjacent equal items merge in registers), and the
+        # ownership of the local user rows / the reference counts of the slots (csrc/ownership.hip)
+        big = max(n_slots) + 1
+        o5 = torch.argsort(torch.div(ar(S * cap), cap, rounding_mode="floor") * big + torch.where(valid, SP, big - 1))
+        U, SP, SN = U[o5].contiguous(), SP[o5].contiguous(), SN[o5].contiguous()
+        own, total, stride = batch_row_ownership(U, SP, SN, cap, self.model.n_users, max(n_slots))
+        return {"S": S, "cap": cap, "bs": bs, "n": n, "U": U, "SP": SP, "SN": SN, "own": own, "total": total,
+                "stride": stride, "in_idx": in_idx, "in_off": in_off, "in_len": in_len, "n_slots": n_slots,
+                "req_split": [[c + 1 for c in row] for row in req_l], "in_split": [[c + 1 for c in row] for row in in_l],
+                "ex_req": ex_req, "ex_in": ex_in}
+
+    def run_planned_epoch(self, plan, steps=None, sync=True):
+        """Collective.  Enqueue every step of a planned epoch (plain SGD), or steps [a, b) of it; nothing is read
+        back until the end.  Returns (last loss, last reg, loss sum, reg sum) of the global batches (None with
+        ``sync=False``)."""
+        if self.optimizer.name != "sgd":
+            raise RuntimeError("the planned sharded epoch applies plain SGD; Adam / RMSprop need the dense sweep "
+                               "(train_single_batch)")
+        R, dev, m, D, k = self.world, self.device, self.model, self.emb_dim, self.k
+        ld, cap, S = D + 1, plan["cap"], plan["S"]
+        max_in, max_slots = max(plan["in_len"]), max(plan["n_slots"])
+        pb = getattr(self, "_planned_bufs", None)
+        if pb is None or pb["max_in"] < max_in or pb["max_slots"] < max_slots or pb["stride"] < plan["stride"]:
+            f32 = dict(dtype=torch.float32, device=dev)
+            pb = self._planned_bufs = {
+                "max_in": max_in, "max_slots": max_slots, "stride": plan["stride"],
+                "payload": torch.empty((max_in, ld), **f32), "g_recv": torch.empty((max_in, ld), **f32),
+                "fetched": torch.empty((max_slots, ld), **f32), "g_send": torch.empty((max_slots, ld), **f32),
+                "arrived": torch.zeros(plan["stride"], dtype=torch.int32, device=dev),
+                "acc": torch.zeros(plan["stride"] * ld, **f32)}
+        item_emb, item_bias = m.item_emb.weight.data, m.item_bias.weight.data
+        lr, reg = self.optimizer.lr, float(self.reg)
+        for s in range(*(steps or (0, S))):
+            il, sl = plan["in_len"][s], plan["n_slots"][s]
+            idx = plan["in_idx"][plan["in_off"][s]: plan["in_off"][s] + il]
+            payload, fetched = pb["payload"][:il], pb["fetched"][:sl]
+            g_send, g_recv = pb["g_send"][:sl], pb["g_recv"][:il]
+            k.payload_rows(item_emb, item_bias, idx, payload)
+            dist.all_to_all_single(fetched, payload, output_split_sizes=plan["req_split"][s],
+                                   input_split_sizes=plan["in_split"][s], group=self.pg)
+            g_send.zero_()
+            blk = slice(s * cap, (s + 1) * cap)
+            B = R * min(plan["bs"], plan["n"] - s * plan["bs"])
+            k.owned_remote_step(m, fetched, g_send, sl, plan["U"][blk], plan["SP"][blk], plan["SN"][blk],
+                                plan["own"][:, blk], plan["total"][s], pb["arrived"], pb["acc"], 1.0 / B, reg, lr)
+            k.publish_partials(g_send, D, plan["ex_req"][s])
+            dist.all_to_all_single(g_recv, g_send, output_split_sizes=plan["in_split"][s],
+                                   input_split_sizes=plan["req_split"][s], group=self.pg)
+            k.apply_rows(item_emb, item_bias, idx, g_recv, lr)
+            k.finish_step(g_recv, D, plan["ex_in"][s], m.global_bias.data, lr, s == 0)
+            self.step_count += 1
+        return k.epoch_stats() if sync else None
+
     def train_an_epoch(self, train_loader, epoch_id):
         """Every rank iterates its own shard of the interaction stream; all loaders must yield the
-        same number of batches (one collective step per batch)."""
+        same number of batches (one collective step per batch).  A device-resident loader trained with plain SGD
+        takes the epoch-planned path (plan_epoch + run_planned_epoch)."""
+        if (self.optimizer.name == "sgd" and all(hasattr(train_loader, a) for a in
+                                                 ("user_tensor", "pos_item_tensor", "neg_item_tensor", "permutation"))
+                and self.config["model"].get("epoch_plan", True)):
+            loss, _, total_loss, total_reg = self.run_planned_epoch(self.plan_epoch(train_loader))
+            if self.rank == 0:
+                print(f"[Training Epoch {epoch_id}], Loss {loss}, Regularizer {total_reg}")
+            return total_loss, total_reg
         total_loss, total_reg, loss = 0.0, 0.0, float("nan")
         for batch in train_loader:
             loss, reg = self.train_single_batch(batch)

@@ -316,6 +316,32 @@ int hiprec_batch_row_ownership(const int64_t* users, const int64_t* pos, const i
                                int64_t batch, int64_t n_users, int64_t n_items, int32_t table_bits,
                                int32_t* keys, int32_t* total, int32_t* own, void* stream);
 
+/* ---- the row-sharded engine's epoch-planned SGD step (beta-recsys_amd/sharded.py).  Per step and
+ * rank: hiprec_shard_gather_payload (rows of the items peers asked for) -> all-to-all -> this call ->
+ * hiprec_shard_publish_partials -> all-to-all back -> hiprec_shard_apply_rows + hiprec_shard_finish_step.
+ * hiprec_mf_bpr_owned_remote_step is the owned-rows kernel on (local user shard, FETCHED item rows): users[] are
+ * local user rows (-1 = padding), pos_slot / neg_slot index the fetched [n_slots, dim + 1] exchange buffer
+ * (row | bias), user rows are updated in place (own_u / total / arrived / acc as in hiprec_mf_bpr_epoch_owned, over
+ * the triples this rank received), the gradients of the item slots go into g_send (same layout; zero on entry)
+ * for the way back.  The loss partials stay in `scratch`; the optimizer clock is not touched. */
+int hiprec_mf_bpr_owned_remote_step(float* w_flat, int64_t n_users, int64_t n_items_local, int32_t dim,
+                                    const float* fetched, float* g_send, int64_t n_slots, const int64_t* users,
+                                    const int64_t* pos_slot, const int64_t* neg_slot, const int32_t* own_u,
+                                    const int32_t* own_p, const int32_t* own_n, const int32_t* total,
+                                    int32_t* arrived, float* acc, int64_t batch, float inv_batch, float reg_coef,
+                                    double lr, hiprec_stats* stats, void* scratch, void* stream);
+/* rows extra_rows[0..n_dest) of g_send ([.., dim + 1]) <- this rank's [loss, reg, d loss / d scalar bias] of the
+ * step (from the gradient kernel's partials in scratch): the 3-float all-reduce rides in the all-to-all */
+int hiprec_shard_publish_partials(const void* scratch, float* g_send, int32_t dim, const int64_t* extra_rows,
+                                  int32_t n_dest, void* stream);
+/* owner side: item row idx[k] (+ bias) -= lr * g_recv[k] (fp32 atomics; idx -1 = extra row / padding: skipped) */
+int hiprec_shard_apply_rows(float* item_emb, float* item_bias, int64_t n_rows, int32_t dim, const int64_t* idx,
+                            const float* g_recv, int64_t n, double lr, hiprec_stats* stats, void* stream);
+/* sum the peers' extra rows of g_recv -> stats (loss, reg, epoch sums), scalar bias -= lr * its gradient, t <- t+1 */
+int hiprec_shard_finish_step(const float* g_recv, int32_t dim, const int64_t* extra_rows, int32_t n_src,
+                             float* global_bias, double lr, int32_t first_of_epoch, hiprec_stats* stats,
+                             void* stream);
+
 /* ---- ONE launch of that sequence, with the buffers of this step named explicitly: for callers that
  *      have to do something between two steps -- the data-parallel engine all-reduces
  *      [partials of scratch_cur | g_cur] over RCCL before the next launch consumes them as

@@ -388,3 +388,127 @@ def test_two_rank_sharded_ncf_equals_single_process(tmp_path, kind, optimizer, l
     for k in w:
         assert res["full"][k].shape == w[k].shape, k
         assert np.mean(np.abs(res["full"][k] - w[k]) > tol) < 0.01, f"{k} differs from the single-process run"
+
+
+# ---- epoch-planned sharded SGD (ShardedMFEngine.plan_epoch / run_planned_epoch) on gloo ------------------------------
+
+class OraclePlannedKernels(OracleKernels):
+    """numpy statements of the planned step's kernels (csrc/mf_owned.hip REMOTE variant, csrc/shard.hip)."""
+
+    def payload_rows(self, item_emb, item_bias, local_idx, payload):
+        payload.copy_(torch.cat([self.gather_rows(item_emb, local_idx), self.gather_rows(item_bias, local_idx)], dim=1))
+
+    def owned_remote_step(self, model, fetched, g_send, n_slots, users, slot_pos, slot_neg, own, total, arrived, acc,
+                          inv_batch, reg_coef, lr):
+        D = model.emb_dim
+        live = users >= 0
+        # the ownership arrays must describe the batch: -1 / total 1 exactly for rows referenced once
+        for role, ids in ((0, users), (1, slot_pos), (2, slot_neg)):
+            pool = users[live] if role == 0 else torch.cat([slot_pos[live], slot_neg[live]])
+            for t in torch.nonzero(live).flatten().tolist():
+                cnt = int((pool == ids[t]).sum())
+                s = int(own[role][t])
+                assert (cnt == 1) == (s < 0 or int(total[s]) == 1), "ownership does not match the batch"
+                assert s < 0 or int(total[s]) == cnt
+        if not bool(live.any()):   # this rank owns none of the step's users
+            self.partial = torch.zeros(3)
+            return
+        ue, ie, ub, ib, gb = model._views(model.flat)
+        w = {"user_emb.weight": ue.numpy(), "user_bias.weight": ub.numpy(), "global_bias": gb.numpy(),
+             "item_emb.weight": fetched[:, :D].numpy(), "item_bias.weight": fetched[:, D:].numpy()}
+        loss, reg, g = onp.mf_bpr_grads(w, users[live].numpy(), slot_pos[live].numpy(), slot_neg[live].numpy(),
+                                        reg_coef, global_batch=int(round(1.0 / inv_batch)))
+        lr32 = np.float32(lr)
+        ue -= torch.from_numpy(lr32 * g["user_emb.weight"])      # untouched rows have zero gradient
+        ub -= torch.from_numpy(lr32 * g["user_bias.weight"])
+        g_send[:, :D] += torch.from_numpy(g["item_emb.weight"])
+        g_send[:, D:] += torch.from_numpy(g["item_bias.weight"])
+        self.partial = torch.tensor([loss, reg, float(g["global_bias"][0])], dtype=torch.float32)
+
+    def publish_partials(self, g_send, dim, extra_rows):
+        g_send[extra_rows, :3] = self.partial
+
+    def apply_rows(self, item_emb, item_bias, local_idx, g_recv, lr):
+        keep = local_idx >= 0
+        item_emb.index_add_(0, local_idx[keep], -np.float32(lr) * g_recv[keep][:, :-1])
+        item_bias.index_add_(0, local_idx[keep], -np.float32(lr) * g_recv[keep][:, -1:])
+
+    def finish_step(self, g_recv, dim, extra_rows, global_bias, lr, first_of_epoch):
+        tot = g_recv[extra_rows, :3].sum(0)
+        if first_of_epoch:
+            self.sums = [0.0, 0.0]
+        self.loss, self.reg = float(tot[0]), float(tot[1])
+        self.sums[0] += self.loss
+        self.sums[1] += self.reg
+        global_bias -= np.float32(lr) * tot[2]
+
+    def epoch_stats(self):
+        return self.loss, self.reg, self.sums[0], self.sums[1]
+
+
+def planned_worker(rank, world, port, n_local, bs, shuffle, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import beta_recsys_amd as hp
+        from beta_recsys_amd.sharded import ShardedMFEngine
+
+        U, I, D = 37, 23, 8    # 37 % 4 != 0, 23 % 4 != 0: uneven shards
+        w0 = onp.init_params(U, I, D, seed=7)
+        rng = np.random.default_rng(50 + rank)
+        users, neg = rng.integers(0, U, n_local), rng.integers(0, I, n_local)
+        p = 1.0 / np.arange(1, I + 1)
+        pos = rng.choice(I, n_local, p=p / p.sum())            # Zipf items: duplicates inside a step's requests
+        with contextlib.redirect_stdout(io.StringIO()):
+            eng = ShardedMFEngine(make_config(U, I, D, "sgd", 0.1, "padded", "rows"), kernels=OraclePlannedKernels(),
+                                  full_state={k: torch.from_numpy(v) for k, v in w0.items()})
+        loader = hp.DeviceTripleBatcher(torch.from_numpy(users), torch.from_numpy(pos), torch.from_numpy(neg), bs,
+                                        shuffle=shuffle, generator=torch.Generator().manual_seed(9 + rank) if shuffle else None)
+        plan = eng.plan_epoch(loader)
+        # what the plan says this rank's local batches were (the order inside a batch is irrelevant)
+        order = np.arange(n_local)
+        if shuffle:
+            order = torch.randperm(n_local, generator=torch.Generator().manual_seed(9 + rank)).numpy()
+        # requests are de-duplicated: never more slots than distinct (item, owner) pairs, at most 2 per triple
+        for s in range(plan["S"]):
+            blk = slice(s * plan["cap"], (s + 1) * plan["cap"])
+            live = plan["U"][blk] >= 0
+            refs = torch.cat([plan["SP"][blk][live], plan["SN"][blk][live]])
+            assert plan["n_slots"][s] - world == refs.unique().numel() <= 2 * int(live.sum())
+        stats = eng.run_planned_epoch(plan)
+        full = eng.gather_full_state_dict()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (users[order], pos[order], neg[order]))
+        if rank == 0:
+            torch.save({"stats": stats, "full": {k: v.numpy() for k, v in full.items()}, "w0": w0,
+                        "local": gathered, "bs": bs}, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_local,bs,shuffle", [(2, 50, 16, False), (4, 41, 8, True), (3, 20, 32, False)])
+def test_planned_sharded_epoch_equals_single_process(tmp_path, world, n_local, bs, shuffle):
+    """plan_epoch + run_planned_epoch on 2, 3 and 4 gloo ranks with uneven shards (n_rows % R != 0), Zipf items and a
+    short last batch: the epoch-level routing (triples to owner(user), de-duplicated item requests to owner(item)),
+    the per-step exact-size exchanges and the partials riding in the extra rows reproduce the single-process SGD
+    steps on the concatenated global batches -- loss sums and the gathered full state_dict."""
+    out_path = str(tmp_path / "out.pt")
+    mp.spawn(planned_worker, args=(world, free_port(), n_local, bs, shuffle, out_path), nprocs=world, join=True)
+    res = torch.load(out_path, weights_only=False)
+    w = onp.copy_params(res["w0"])
+    st = onp.new_opt_state(w, "sgd")
+    tot_loss = tot_reg = 0.0
+    for k in range(0, n_local, bs):
+        batch = tuple(np.concatenate([loc[j][k:k + bs] for loc in res["local"]]) for j in range(3))
+        loss, reg = onp.mf_train_step(w, st, batch, "bpr", "sgd", 0.1)
+        tot_loss += loss
+        tot_reg += reg
+    last_loss, last_reg, loss_sum, reg_sum = res["stats"]
+    assert_scalar_close(last_loss, loss, 2e-5, "last step's global loss")
+    assert_scalar_close(loss_sum, tot_loss, 2e-5, "epoch loss sum")
+    assert_scalar_close(reg_sum, tot_reg, 2e-5, "epoch regularizer sum")
+    for k in KEYS:
+        assert res["full"][k].shape == w[k].shape
+        assert_tensor_close(res["full"][k], w[k], 2e-5, f"{k} after the planned epoch")

@@ -249,3 +249,77 @@ def test_sharded_ncf_engine_with_hip_kernels(nccl_group, kind, emb):
         assert np.mean(np.abs(got - w[k]) > 2e-3) < 0.01, f"{k}: differs from the single-process run"
     with pytest.raises(IndexError):
         eng.train_single_batch(np.array([U]), np.array([0]), np.array([1.0], dtype=np.float32))
+
+
+@pytest.mark.parametrize("D,B,shuffle", [(64, 512, False), (128, 1000, True), (100, 300, False)])
+def test_planned_sharded_epoch_with_hip_kernels(nccl_group, D, B, shuffle):
+    """ShardedMFEngine.train_an_epoch on a device-resident loader (plain SGD): epoch-level routing, then per step
+    gather -> all-to-all -> owned-rows kernel on (local users, fetched item slots) -> partials into the extra rows
+    -> all-to-all -> apply, all with the real kernels at world size 1; equal to the oracle's single-process steps."""
+    import beta_recsys_amd as hp
+    from beta_recsys_amd.sharded import ShardedMFEngine
+
+    U, I, n = 3000, 400, 4 * B + B // 3
+    w0 = onp.init_params(U, I, D, seed=3)
+    rng = np.random.default_rng(D)
+    p = 1.0 / np.arange(1, I + 1)
+    users, pos, neg = rng.integers(0, U, n), rng.choice(I, n, p=p / p.sum()), rng.integers(0, I, n)
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer="sgd", lr=0.05, batch_size=B,
+                         loss="bpr", sgd_mode="rows"), "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = ShardedMFEngine(cfg, full_state={k: torch.from_numpy(v) for k, v in w0.items()})
+    gen = torch.Generator().manual_seed(4) if shuffle else None
+    loader = hp.DeviceTripleBatcher(*(torch.from_numpy(a).cuda() for a in (users, pos, neg)), B, shuffle=shuffle,
+                                    generator=gen)
+    with contextlib.redirect_stdout(io.StringIO()):
+        total_loss, total_reg = eng.train_an_epoch(loader, 0)
+    order = torch.randperm(n, generator=torch.Generator().manual_seed(4)).numpy() if shuffle else np.arange(n)
+    w = onp.copy_params(w0)
+    st = onp.new_opt_state(w, "sgd")
+    ref_loss = ref_reg = 0.0
+    for k in range(0, n, B):
+        sl = order[k:k + B]
+        loss, reg = onp.mf_train_step(w, st, (users[sl], pos[sl], neg[sl]), "bpr", "sgd", 0.05)
+        ref_loss += loss
+        ref_reg += reg
+    assert_scalar_close(total_loss, ref_loss, 2e-5, "epoch loss sum")
+    assert_scalar_close(total_reg, ref_reg, 2e-5, "epoch regularizer sum")
+    full = eng.gather_full_state_dict()
+    for k in KEYS:
+        got = full[k].cpu().numpy()
+        upd = np.abs(w[k] - w0[k]).max()
+        assert np.abs(got - w[k]).max() <= 1e-5 * upd + 4 * 1.2e-7 * np.abs(w[k]).max(), k
+    assert float(eng._planned_bufs["acc"].abs().max()) == 0.0 and int(eng._planned_bufs["arrived"].abs().max()) == 0
+
+
+def test_planned_sharded_epoch_at_c4_shard_size(nccl_group):
+    """The sharded engine's step at one rank's share of BASELINE configs[3] (1.25M x 125k rows, dim 128, 65536
+    triples per step) in -m gpu: at world size 1 the row-sharded engine and the single-GPU engine run
+    the same SGD steps -- equal loss sums and weights (1e-5 of the update), rows outside the batches bit-identical."""
+    import beta_recsys_amd as hp
+    from beta_recsys_amd.sharded import ShardedMFEngine
+
+    U, I, D, B, steps = 1_250_000, 125_000, 128, 65536, 3
+    rng = np.random.default_rng(11)
+    pz = 1.0 / np.arange(1, I + 1)
+    users, pos, neg = rng.integers(0, U, steps * B), rng.permutation(I)[rng.choice(I, steps * B, p=pz / pz.sum())], rng.integers(0, I, steps * B)
+    triples = [torch.from_numpy(a).cuda() for a in (users, pos, neg)]
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer="sgd", lr=0.05, batch_size=B,
+                         loss="bpr", sgd_mode="owned"), "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+    torch.manual_seed(5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        single = hp.MFEngine(cfg)
+    w0 = single.model.flat.clone()
+    torch.manual_seed(5)   # the same seed -> the same initial model (drawn in full, every rank keeps its rows)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = ShardedMFEngine(cfg)
+    assert torch.equal(eng.model.flat, w0)
+    loader = hp.DeviceTripleBatcher(*triples, B, shuffle=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        total_loss, _ = eng.train_an_epoch(loader, 0)
+        single.train_an_epoch(loader, 0)
+    ref = single.model.flat
+    assert_scalar_close(total_loss, single.epoch_stats().loss_sum, 1e-5, "epoch loss sum, sharded vs single GPU")
+    upd = float((ref - w0).abs().max())
+    assert float((eng.model.flat - ref).abs().max()) <= 1e-5 * upd + 4 * 1.2e-7 * float(w0.abs().max())
+    assert torch.equal(eng.model.flat == w0, ref == w0), "the two engines moved different sets of elements"

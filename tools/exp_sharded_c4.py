@@ -30,4 +30,23 @@ for sgd_mode in ("rows", "dense"):
     print(f"sharded step, one rank's configs[3] share, sgd_mode={sgd_mode}: {dt * 1e6:.0f} us/step = {B / dt / 1e6:.0f} M triples/s")
     del eng
     torch.cuda.empty_cache()
+# the epoch-planned path (plan_epoch once per epoch, then 2 collectives + 5 launches per step)
+import beta_recsys_amd as hp
+cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer="sgd", lr=0.05, batch_size=B,
+                     loss="bpr", sgd_mode="rows"), "system": {"run_dir": "/tmp/x"}}
+torch.manual_seed(0)
+with contextlib.redirect_stdout(io.StringIO()):
+    eng = ShardedMFEngine(cfg)
+loader = hp.DeviceTripleBatcher(users, pos, neg, B)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+plan = eng.plan_epoch(loader)
+torch.cuda.synchronize(); t_plan = time.perf_counter() - t0
+t0 = time.perf_counter(); plan = eng.plan_epoch(loader); torch.cuda.synchronize(); t_plan2 = time.perf_counter() - t0
+eng.run_planned_epoch(plan)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+eng.run_planned_epoch(plan, sync=False)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / plan["S"]
+print(f"planned sharded epoch: plan {t_plan * 1e3:.1f} ms first / {t_plan2 * 1e3:.1f} ms warm for {plan['S']} steps "
+      f"({t_plan2 / plan['S'] * 1e6:.0f} us/step), step {dt * 1e6:.0f} us = {B / dt / 1e6:.0f} M triples/s; "
+      f"slots/step {sum(plan['n_slots']) / plan['S']:.0f} of {2 * B} references")
 dist.destroy_process_group()
