@@ -450,22 +450,32 @@ def bench_mf_c4_sharded(args, device, world, rank):
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
         eng = ShardedMFEngine(cfg)
-    steps, warm = min(args.steps, 50), min(args.warmup, 5)
-    n_total = (steps + warm) * Bc
+    import beta_recsys_amd as hp
+
+    steps, warm = min(args.steps, 100), min(args.warmup, 10)
+    epoch_steps = 50
+    n_total = epoch_steps * Bc
     g = torch.Generator().manual_seed(5 + rank)
     users = torch.randint(0, Uc, (n_total,), generator=g).to(device)
     pz = 1.0 / torch.arange(1, Ic + 1, dtype=torch.float64)
     item_perm = torch.randperm(Ic, generator=torch.Generator().manual_seed(5))   # the same popular items on every rank
     pos = item_perm[torch.multinomial(pz / pz.sum(), n_total, True, generator=g)].to(device)
     neg = torch.randint(0, Ic, (n_total,), generator=g).to(device)
+    loader = hp.DeviceTripleBatcher(users, pos, neg, Bc)
+    torch.manual_seed(7 + rank)
+    state = {"pos": 0, "plan": None}
 
-    def run(lo, n):
-        for k in range(n):
-            sl = slice(lo + k * Bc, lo + (k + 1) * Bc)
-            eng.train_single_batch((users[sl], pos[sl], neg[sl]), sync=False)
+    def advance(n):   # continuous training; an epoch is routed once (plan_epoch), then run step by step
+        while n > 0:
+            take = min(n, epoch_steps - state["pos"])
+            if state["pos"] == 0:
+                state["plan"] = eng.plan_epoch(loader)
+            eng.run_planned_epoch(state["plan"], steps=(state["pos"], state["pos"] + take), sync=False)
+            state["pos"] = (state["pos"] + take) % epoch_steps
+            n -= take
 
-    run(0, warm)
-    per, wall = timed_repeats(lambda r: run(warm * Bc, steps), steps, device, dist_on=True)
+    advance(warm)
+    per, wall = timed_repeats(lambda r: advance(steps), steps, device, dist_on=True)
     eng.k.check_status()
     if rank != 0:
         return None
@@ -804,10 +814,9 @@ def bench_mf(args, device, world, rank, dist_on):
             elif mode == "replicated":
                 assert eng.run_resident_epoch(loader, steps=piece)
             else:
-                if piece[0] == 0:
-                    state["it"] = iter(loader)  # device-side shuffle, batch views of the resident arrays
-                for _ in range(take):
-                    eng.train_single_batch(next(state["it"]), sync=False)
+                if piece[0] == 0:   # route the whole epoch once (ids only), then exact-size exchanges per step
+                    state["prepared"] = eng.plan_epoch(loader)
+                eng.run_planned_epoch(state["prepared"], steps=piece, sync=False)
             state["pos"] = piece[1] % EPOCH_STEPS
             n -= take
 

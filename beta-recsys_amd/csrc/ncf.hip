@@ -461,7 +461,6 @@ static bool fusable(const hiprec_ncf_plan* p) {
   for (int l = 0; l < p->n_layers; ++l) {
     if (p->layer_out[l] > kFMaxN || p->layer_out[l] % 32) return false;
     if (p->layer_in[l] % kTK) return false;
-    if (p->keep[l]) return false;  // tower dropout runs through the launch-per-layer path
   }
   return true;
 }
@@ -575,7 +574,7 @@ __device__ __forceinline__ void fused_mma(f32x16& acc, const float* in, int ld_i
 // TRAIN: the head's backward half rides along (BCELoss term, d loss / d logit, dZ_L, dMF, d w_out,
 // the loss / d b_out partials) -- everything it needs is already in LDS, and a separate head launch
 // cost 12 us.
-template <bool TRAIN>
+template <bool TRAIN, bool DROP>
 __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
     hiprec_ncf_plan p, const int64_t* __restrict__ users, const int64_t* __restrict__ items,
     const float* __restrict__ ratings, int64_t batch, float inv_batch, hiprec_stats* stats,
@@ -636,6 +635,9 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
       for (int r = 0; r < kFR; ++r) {
         float x = s_u[r] >= 0 ? v[r] : 0.f;
         if (p.relu_input) x = fmaxf(x, 0.f);
+        // the Dropout in front of the first Linear (ncf.py:42-45, mlp.py:30-33): one keep byte per element
+        if constexpr (DROP)
+          if (p.keep[0] && m0 + r < batch) x = p.keep[0][(m0 + r) * K0 + tid] ? x * p.keep_scale : 0.f;
         L.wide[r * kFLdIn + tid] = x;
         if (m0 + r < batch) p.act[0][(m0 + r) * K0 + tid] = x;
       }
@@ -665,7 +667,12 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const float v = fmaxf(acc[r] + bias, 0.f);
+        float v = fmaxf(acc[r] + bias, 0.f);
+        // act[l + 1] is what the NEXT Linear sees: its Dropout is applied here (the backward's dgrad epilogue
+        // applies the same keep bytes)
+        if constexpr (DROP)
+          if (l + 1 < p.n_layers && p.keep[l + 1] && m0 + row < batch)
+            v = p.keep[l + 1][(m0 + row) * N + col] ? v * p.keep_scale : 0.f;
         out[row * ld_out + col] = v;
         if (m0 + row < batch) p.act[l + 1][(m0 + row) * N + col] = v;
       }
@@ -787,14 +794,16 @@ static int check_plan(const hiprec_ncf_plan* p, int64_t batch, bool train) {
 
 static int fused_attrs() {
   static int rc = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ncf_fused_forward_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(kFusedLdsBytes));
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              static_cast<int>(kFusedLdsBytes));
-    return e == hipSuccess ? 0 : hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    const void* kernels[] = {reinterpret_cast<const void*>(&ncf_fused_forward_kernel<false, false>),
+                             reinterpret_cast<const void*>(&ncf_fused_forward_kernel<false, true>),
+                             reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, false>),
+                             reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, true>)};
+    for (const void* k : kernels) {
+      const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               static_cast<int>(kFusedLdsBytes));
+      if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    return 0;
   }();
   return rc;
 }
@@ -809,11 +818,19 @@ static int forward(const hiprec_ncf_plan* p, const int64_t* users, const int64_t
   if (fusable(p)) {
     if (int rc = fused_attrs()) return rc;
     const int grid = static_cast<int>((batch + kFR - 1) / kFR);
-    if (ratings)
-      ncf_fused_forward_kernel<true><<<grid, kFThreads, kFusedLdsBytes, st>>>(
+    bool drop = false;
+    for (int l = 0; l < p->n_layers; ++l) drop = drop || p->keep[l] != nullptr;
+    if (ratings && drop)
+      ncf_fused_forward_kernel<true, true><<<grid, kFThreads, kFusedLdsBytes, st>>>(
           *p, users, items, ratings, batch, inv_batch, stats, scratch);
+    else if (ratings)
+      ncf_fused_forward_kernel<true, false><<<grid, kFThreads, kFusedLdsBytes, st>>>(
+          *p, users, items, ratings, batch, inv_batch, stats, scratch);
+    else if (drop)   // model.train() + forward(): the reference applies dropout there too
+      ncf_fused_forward_kernel<false, true><<<grid, kFThreads, kFusedLdsBytes, st>>>(
+          *p, users, items, nullptr, batch, 0.f, stats, nullptr);
     else
-      ncf_fused_forward_kernel<false><<<grid, kFThreads, kFusedLdsBytes, st>>>(
+      ncf_fused_forward_kernel<false, false><<<grid, kFThreads, kFusedLdsBytes, st>>>(
           *p, users, items, nullptr, batch, 0.f, stats, nullptr);
     HIPREC_TRY(hipGetLastError());
     *scored = true;

@@ -159,9 +159,12 @@ def test_ncf_errors(hip_device):
     assert np.isfinite(one)  # unlike MF, a batch of one is legal for the NCF family
 
 
-def test_ncf_full_size_c3_vs_oracle(hip_device):
-    """BASELINE configs[2]: ML-1M shape, emb_dim 32 (tower 256->128->64->32), batch 4096."""
-    U, I, E, L, B = 6040, 3706, 32, 3, 4096
+@pytest.mark.parametrize("E", [32, 64])
+def test_ncf_full_size_c3_vs_oracle(hip_device, E):
+    """BASELINE configs[2]: ML-1M shape, batch 4096; emb_dim 32 (tower 256->128->64->32, the fused tower kernel) and
+    emb_dim 64 -- "dim=64" as BASELINE.json spells it: tables 256/256/64/64, tower 512->256->128->64, beyond the
+    fused kernel's LDS tiles, so it runs gather + one MFMA GEMM launch per layer + head."""
+    U, I, L, B = 6040, 3706, 3, 4096
     torch.manual_seed(5)
     eng = make_engine("NeuMFEngine", U, I, E, L, "adam", 1e-3, B)
     w = get_weights(eng)
@@ -255,3 +258,34 @@ def test_tower_dropout_matches_reference(hip_device, case, engine):
     k1 = dev_eng.model._ws["keep"][0][:B].clone()
     dev_eng.train_single_batch(*(torch.from_numpy(x) for x in batch))
     assert abs(float(k1.float().mean()) - (1 - p)) < 0.12 and not torch.equal(k1, dev_eng.model._ws["keep"][0][:B])
+
+
+@pytest.mark.parametrize("kind,engine,E,p", [("neumf", "NeuMFEngine", 32, 0.3), ("mlp", "MLPEngine", 32, 0.5)])
+def test_tower_dropout_inside_the_fused_forward(hip_device, kind, engine, E, p):
+    """Tower dropout at a shape the FUSED tower kernel takes (emb_dim 32: 256 -> 128 -> 64 -> 32, batch 4096 + a
+    ragged tail): the keep bytes of every Linear's input are applied inside the fused launch (gather for layer 0,
+    layer epilogues after that).  Loss, every gradient and the scores' keep rate against oracle/ncf_numpy.py fed
+    with the very masks the engine drew (read back from its workspace)."""
+    import beta_recsys_amd as hp
+
+    U, I, L, B = 6040, 3706, 3, 4096 + 37
+    cfg = ncf_config(U, I, E, L, "sgd", 0.05, B, device="cuda:0")
+    cfg["model"]["dropout"] = p
+    cfg["model"]["dropout_rng"] = "device"
+    torch.manual_seed(11)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = getattr(hp, engine)(cfg)
+    eng.model.train()
+    rng = np.random.default_rng(2)
+    users, items = rng.integers(0, U, B), rng.integers(0, I, B)
+    ratings = (rng.random(B) < 0.2).astype(np.float32)
+    w0 = get_weights(eng)
+    loss, grads = eng.backward_only(users, items, ratings)
+    n_layers = len(eng.model.tower_dims)
+    masks = [eng.model._ws["keep"][l][:B].cpu().numpy().astype(bool) for l in range(n_layers)]
+    for m in masks:
+        assert abs(m.mean() - (1 - p)) < 0.02
+    ref_loss, g_ref, _ = onc.ncf_grads(w0, users, items, ratings, kind, masks=masks, dropout=p)
+    assert_scalar_close(loss, ref_loss, what="loss with tower dropout (fused forward)")
+    for k in g_ref:
+        assert_tensor_close(grads[k].cpu().numpy(), g_ref[k], 2e-5, f"grad {k}", scale_floor=bias_floor(k))
