@@ -1,21 +1,44 @@
-# Refresh the judged evidence on a GPU box: bash tools/refresh_profiles.sh   (outputs under gpurun_out/)
-OUT=$GRAFT_REPO_ROOT/gpurun_out
+# Refresh the judged evidence on a GPU box: bash tools/refresh_profiles.sh [round tag, default r02]
+# bench JSON lines, rocprofv3 kernel-trace stats and FETCH_SIZE / WRITE_SIZE passes, all under gpurun_out/<tag>/;
+# tools/collect_profiles.py copies the summaries into profiles/.
+TAG=${1:-r02}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
+python bench.py --steps 20 --warmup 5 > $OUT/bench_adam_20.json 2> $OUT/bench_adam_20.err
 for o in adam sgd rmsprop; do
-  timeout 200 python bench.py --optimizer $o > $OUT/r01_bench_$o.json 2> $OUT/r01_bench_$o.err
-  tail -c 300 $OUT/r01_bench_$o.json | head -c 120; echo
+  timeout 200 python bench.py --optimizer $o --no-cpu-baseline > $OUT/bench_$o.json 2> $OUT/bench_$o.err
 done
-for w in ncf lightgcn mf-c4shard mf-c4; do
-  timeout 300 python bench.py --workload $w > $OUT/r01_bench_$w.json 2> $OUT/r01_bench_$w.err
-  head -c 240 $OUT/r01_bench_$w.json; echo
+timeout 300 python bench.py --workload ncf > $OUT/bench_ncf.json 2> $OUT/bench_ncf.err
+timeout 300 python bench.py --workload ncf --emb-dim 64 --no-cpu-baseline > $OUT/bench_ncf64.json 2> $OUT/bench_ncf64.err
+for w in lightgcn mf-c4shard mf-c4 pgmf t2v ngcf; do
+  timeout 300 python bench.py --workload $w --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err
 done
-bash tools/prof_fused.sh adam sgd
-bash tools/prof_workload.sh ncf > /dev/null 2>&1
-bash tools/prof_workload.sh lightgcn > /dev/null 2>&1
+timeout 300 python bench.py --workload mf-c4shard --sgd-mode rows --no-cpu-baseline > $OUT/bench_mf-c4shard_rows.json 2> /dev/null
+HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --no-cpu-baseline --steps 200 2> /dev/null | grep metric > $OUT/bench_replicated_w1.json
+HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload mf-c4 --no-cpu-baseline --steps 50 2> /dev/null | grep metric > $OUT/bench_mf-c4_sharded_w1.json
+python tools/exp_sharded_c4.py 2>&1 | grep sharded > $OUT/exp_sharded_c4.txt
 cd /tmp && export TMPDIR=/tmp
-for o in adam sgd; do for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${o}_$c -o mf -- \
-    python $GRAFT_REPO_ROOT/bench.py --optimizer $o --no-cpu-baseline --steps 200 --warmup 20 > $OUT/pmc_${o}_$c.log 2>&1
-  ls $OUT/pmc_${o}_$c | head -1
-done; done
+prof() {  # name, bench args...
+  local name=$1; shift
+  timeout 250 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o mf -- \
+    python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline "$@" > $OUT/prof_$name.log 2>&1
+}
+prof adam --steps 500 --warmup 50
+prof adam_20 --steps 20 --warmup 5
+prof sgd --optimizer sgd --steps 500 --warmup 50
+prof mf-c4shard --workload mf-c4shard --steps 50 --warmup 5
+prof ncf --workload ncf --steps 100 --warmup 10
+prof ncf64 --workload ncf --emb-dim 64 --steps 100 --warmup 10
+prof lightgcn --workload lightgcn --steps 100 --warmup 10
+pmc() {  # name, bench args...
+  local name=$1; shift
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 250 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${name}_$c -o mf -- \
+      python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline "$@" > $OUT/pmc_${name}_$c.log 2>&1
+  done
+}
+pmc adam --steps 200 --warmup 20
+pmc sgd --optimizer sgd --steps 200 --warmup 20
+pmc mf-c4shard --workload mf-c4shard --steps 50 --warmup 5
+ls $OUT | head -80
