@@ -17,9 +17,9 @@
 //    gradient, so "all readers have read" == "all contributions have arrived".  Contributions are added with
 //    device-scope atomics into a compact accumulator row acc[slot] (a few tens of MB for the whole batch: it
 //    lives in the Infinity Cache, not in HBM), then the contributor adds its weight to arrived[slot]; the one
-//    that completes the count swaps the accumulated gradient out (atomic exchange with 0: read and clear in one
-//    operation, the accumulators are clean for the next step) and applies it to ITS register copy of the
-//    pre-step row.  No fence is needed: accumulator and counter are only ever touched by device-scope atomics,
+//    that completes the count takes the accumulated gradient out (atomic exchange with 0: read and clear in one
+//    operation, the accumulators are clean for the next step) and applies it to the row, which still holds its
+//    pre-step value.  No fence is needed: accumulator and counter are only ever touched by device-scope atomics,
 //    and a contributor waits for its adds to be acknowledged before it bumps the counter.
 //  * positive items follow a Zipf law; as in mf_bpr_grad_kernel adjacent equal items of a block (the batcher
 //    sorts every batch by positive item) are first merged in LDS and only the run head contributes, with the
@@ -66,8 +66,11 @@ struct OwnedStep {
   float* item_out;
 };
 
-__device__ __forceinline__ float atomic_swap_f32(float* p, float v) {
-  return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Read a finished accumulator element and leave it zero for the next step: ONE device-scope exchange.  (A device-scope
+// load followed by a store of 0 would spare the atomic units, but sc1 loads / stores go past the L2: measured 162 us
+// per step instead of 92.)
+__device__ __forceinline__ float take_and_clear_f32(float* p) {
+  return __hip_atomic_exchange(p, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
@@ -289,6 +292,43 @@ __global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
       run_len = 0;
     };
 
+    // ---- scores: the two dot products of every triple are reduced across the wave and parked in lane i; the scalar
+    // part (two sigmoids, logsigmoid, the gradient coefficients) is then evaluated ONCE with lane i working on
+    // triple i.  Done per triple it is wave-uniform arithmetic that still occupies all 64 lanes: ~1600 VALU cycles
+    // per triple made the first version of this kernel VALU-bound (44 us for the reads of 65 536 triples that the
+    // memory system delivers in 17).
+    float dpv = 0.f, dnv = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      float dp = 0.f, dn = 0.f;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        dp += ru_[i][k] * rp_[i][k];
+        dn += ru_[i][k] * rn_[i][k];
+        if ((ok_mask >> i) & 1ull)
+          reg_acc += 2.f * ru_[i][k] * ru_[i][k] + rp_[i][k] * rp_[i][k] + rn_[i][k] * rn_[i][k];
+      }
+      dp = wave_sum(dp);
+      dn = wave_sum(dn);
+      dpv = lane == i ? dp : dpv;
+      dnv = lane == i ? dn : dnv;
+    }
+    float dposv = 0.f, dnegv = 0.f;
+    {
+      const float yp = sigmoid_f32(((dpv + lbu) + lbp) + gb);
+      const float yn = sigmoid_f32(((dnv + lbu) + lbn) + gb);
+      float sig_neg_x;
+      const float nls = neg_logsigmoid(yp - yn, &sig_neg_x);
+      const float delta = -sig_neg_x * inv_batch;
+      dposv = delta * ((1.f - yp) * yp);
+      dnegv = -delta * ((1.f - yn) * yn);
+      if (lok) {  // lane i = triple i: per-lane partial sums, reduced once per kernel
+        loss_acc += nls;
+        gb_acc += dposv + dnegv;
+        reg_acc += 2.f * lbu * lbu + lbp * lbp + lbn * lbn;
+      }
+    }
+
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       if (!((ok_mask >> i) & 1ull)) continue;  // beyond the chunk, padding, or out-of-range ids
@@ -296,31 +336,14 @@ __global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
       const float bu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lbu), i));
       const float bp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lbp), i));
       const float bn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lbn), i));
-      float dp = 0.f, dn = 0.f;
-#pragma unroll
-      for (int k = 0; k < NPL; ++k) {
-        dp += ru_[i][k] * rp_[i][k];
-        dn += ru_[i][k] * rn_[i][k];
-        reg_acc += 2.f * ru_[i][k] * ru_[i][k] + rp_[i][k] * rp_[i][k] + rn_[i][k] * rn_[i][k];
-      }
-      dp = wave_sum(dp);
-      dn = wave_sum(dn);
-      const float yp = sigmoid_f32(((dp + bu) + bp) + gb);
-      const float yn = sigmoid_f32(((dn + bu) + bn) + gb);
-      float sig_neg_x;
-      const float nls = neg_logsigmoid(yp - yn, &sig_neg_x);
-      const float delta = -sig_neg_x * inv_batch;
-      const float dpos = delta * ((1.f - yp) * yp);
-      const float dneg = -delta * ((1.f - yn) * yn);
+      const float dpos = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dposv), i));
+      const float dneg = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dnegv), i));
       float gu[NPL], gn[NPL];
 #pragma unroll
       for (int k = 0; k < NPL; ++k) {
         gu[k] = (dpos * rp_[i][k] + dneg * rn_[i][k]) + ru * ru_[i][k];
         gn[k] = dneg * ru_[i][k] + ri * rn_[i][k];
       }
-      if (lane == 0) reg_acc += 2.f * bu * bu + bp * bp + bn * bn;
-      loss_acc += nls;
-      gb_acc += dpos + dneg;
       settle(__builtin_amdgcn_readlane(lsu, i), 1, __builtin_amdgcn_readlane(ltu, i), u * D, o_ub + u, gu,
              (dpos + dneg) + ru * bu, ru_[i], bu);
       if constexpr (REMOTE)
@@ -379,12 +402,12 @@ __global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
             const int c = lane + kWave * j;
             g[q][j] = w0[q][j] = 0.f;
             if (on[q] && c < D) {
-              g[q][j] = atomic_swap_f32(a + c, 0.f);
+              g[q][j] = take_and_clear_f32(a + c);
               w0[q][j] = wf[row[q] + c];  // a plain load next to the swap: fp32 atomics are the scarce resource
             }
           }
           if (on[q] && lane == 0) {
-            gbv[q] = atomic_swap_f32(a + D, 0.f);
+            gbv[q] = take_and_clear_f32(a + D);
             wb0[q] = wf[bias[q]];
           }
         }
@@ -402,12 +425,12 @@ __global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
     }
   }
   // publish this step's partials; n_partials = number of GATHER blocks
-  const float reg_w = wave_sum(reg_acc);
+  const float reg_w = wave_sum(reg_acc), loss_w = wave_sum(loss_acc), gb_sum_w = wave_sum(gb_acc);
   __syncthreads();  // s_red is reused
   if (lane == 0) {
-    s_red[wv] = loss_acc;
+    s_red[wv] = loss_w;
     s_red[kOwnedWaves + wv] = reg_w;
-    s_red[2 * kOwnedWaves + wv] = gb_acc;
+    s_red[2 * kOwnedWaves + wv] = gb_sum_w;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
