@@ -912,8 +912,11 @@ def test_epoch_enqueued_in_pieces_equals_the_whole_epoch(hip_device, optimizer, 
         eng.run_prepared_epoch(prepared, sync=False, steps=(3, 13))
     (la, wa), (lb, wb) = out
     assert_scalar_close(la, lb, 1e-6, "last-step loss, whole epoch vs pieces")
-    for k in KEYS:   # the two runs differ in the order of their fp32 atomics only
-        assert_tensor_close(wa[k], wb[k], 1e-5, f"{k}: whole epoch vs pieces", scale_floor=0.1)
+    # the two runs differ in the order of their fp32 atomics only; Adam turns a last-bit difference of a gradient
+    # that is ~eps into a visible fraction of lr (lr = 0.02 here)
+    rel = 1e-5 if optimizer == "sgd" else 2e-3
+    for k in KEYS:
+        assert_tensor_close(wa[k], wb[k], rel, f"{k}: whole epoch vs pieces", scale_floor=0.1)
 
 
 # ---- owned-rows SGD step (csrc/mf_owned.hip): the HBM-resident regime of BASELINE configs[3] ----------
