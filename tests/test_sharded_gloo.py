@@ -126,7 +126,9 @@ class OracleKernels:
         flat_g.zero_()
 
     def check_status(self):
-        pass
+        if getattr(self, "overflow", False):   # the kernels raise HIPREC_STATUS_ROUTE_OVERFLOW for this
+            self.overflow = False
+            raise RuntimeError("a fixed-capacity all-to-all bucket overflowed: raise the sharded engine's `route_slack`")
 
 
 def free_port():
@@ -135,9 +137,9 @@ def free_port():
         return s.getsockname()[1]
 
 
-def make_config(U, I, D, optimizer, lr, routing="variable", sgd_mode="dense"):
+def make_config(U, I, D, optimizer, lr, routing="variable", sgd_mode="dense", **extra):
     return {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cpu", optimizer=optimizer,
-                          lr=lr, batch_size=8, loss="bpr", routing=routing, sgd_mode=sgd_mode),
+                          lr=lr, batch_size=8, loss="bpr", routing=routing, sgd_mode=sgd_mode, **extra),
             "system": {"run_dir": "/tmp/hiprec_test_runs"}}
 
 
@@ -193,12 +195,14 @@ def test_two_rank_sharded_step_equals_single_process(tmp_path, optimizer, lr):
         assert res["full"][k].shape == w[k].shape
 
 
+@pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("optimizer,lr", [("sgd", 0.1), ("adam", 0.05)])
-def test_two_rank_padded_routing_equals_single_process(tmp_path, optimizer, lr):
-    """The fixed-capacity (no host sync) routing: same result as the single-process step."""
-    splits = [(12, 12), (30, 30), (2, 2)]  # equal local batches, as the padded mode requires
+def test_two_rank_padded_routing_equals_single_process(tmp_path, optimizer, lr, world):
+    """The fixed-capacity (no host sync) routing: same result as the single-process step -- on 2 ranks and on 4
+    (23 users and 19 items: n_rows % 4 != 0, uneven shards)."""
+    splits = [(12,) * world, (30,) * world, (2,) * world]  # equal local batches, as the padded mode requires
     out_path = str(tmp_path / "out.pt")
-    mp.spawn(worker, args=(2, free_port(), optimizer, lr, splits, out_path, "padded"), nprocs=2, join=True)
+    mp.spawn(worker, args=(world, free_port(), optimizer, lr, splits, out_path, "padded"), nprocs=world, join=True)
     res = torch.load(out_path, weights_only=False)
     w = onp.copy_params(res["w0"])
     st = onp.new_opt_state(w, optimizer)
@@ -225,6 +229,32 @@ def test_two_rank_padded_routing_with_touched_rows_sgd(tmp_path):
         assert_scalar_close(loss, ref_loss, 2e-5, "loss")
     for k in KEYS:
         assert np.mean(np.abs(res["full"][k] - w[k]) > 1e-6) < 0.01, k
+
+
+def overflow_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from beta_recsys_amd.sharded import ShardedMFEngine
+
+        U, I, D, b = 64, 40, 4, 600
+        with contextlib.redirect_stdout(io.StringIO()):
+            eng = ShardedMFEngine(make_config(U, I, D, "sgd", 0.1, "padded"), kernels=OracleKernels())
+        # every triple of every rank goes to the owner of user 0 and asks for item 0: no capacity built around the
+        # mean (b / R * route_slack + headroom) holds that
+        users, pos, neg = np.zeros(b, dtype=np.int64), np.zeros(b, dtype=np.int64), np.zeros(b, dtype=np.int64)
+        with pytest.raises(RuntimeError, match="route_slack"):
+            eng.train_single_batch((users, pos, neg))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_padded_routing_reports_a_full_bucket():
+    """A bucket of the fixed-capacity exchange that overflows is an error (status bit -> RuntimeError naming
+    `route_slack`), never a silent drop."""
+    mp.spawn(overflow_worker, args=(2, free_port()), nprocs=2, join=True)
 
 
 def test_shard_bookkeeping():
