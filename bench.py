@@ -813,10 +813,15 @@ def bench_mf(args, device, world, rank, dist_on):
                 eng.run_prepared_epoch(state["prepared"], sync=False, prefetch=loader, steps=piece)
             elif mode == "replicated":
                 assert eng.run_resident_epoch(loader, steps=piece)
-            else:
+            elif args.optimizer == "sgd":
                 if piece[0] == 0:   # route the whole epoch once (ids only), then exact-size exchanges per step
                     state["prepared"] = eng.plan_epoch(loader)
                 eng.run_planned_epoch(state["prepared"], steps=piece, sync=False)
+            else:   # Adam / RMSprop need the dense sweep of the shard: the per-step (padded routing) path
+                if piece[0] == 0:
+                    state["it"] = iter(loader)
+                for _ in range(take):
+                    eng.train_single_batch(next(state["it"]), sync=False)
             state["pos"] = piece[1] % EPOCH_STEPS
             n -= take
 
