@@ -22,6 +22,7 @@
 namespace hiprec {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kTM = 64, kTN = 64, kTK = 32;
 
@@ -444,7 +445,8 @@ __global__ __launch_bounds__(kBlock) void ncf_scatter_kernel(hiprec_ncf_plan p,
 // GEMMs), only the weights stream through a 32-row LDS tile, and the head / the embedding-gradient
 // scatter run on the same rows at the two ends.  Layers are fp32 MFMA 32x32x2 as in gemm_tile.
 // Shapes outside the limits below take the unfused path.
-constexpr int kFR = 32;                    // samples per block (one 32-row MFMA tile: 128 blocks at B 4096)
+constexpr int kFR = 16;                    // samples per block: 16-row MFMA tiles (v_mfma_f32_16x16x4_f32), 256 blocks at
+                                           // B 4096 = one per CU (32-row tiles: 128 blocks, half the chip idle)
 constexpr int kFWaves = 4;                 // one wave per 32 output columns of a 128-column pass
 constexpr int kFThreads = kFWaves * kWave; // 256
 constexpr int kFMaxIn = 256;               // widest tower input (2 * dim_mlp)
@@ -495,13 +497,15 @@ __device__ __forceinline__ FusedLds fused_lds(float* base) {
 // of the 64-cycle dependent MFMA chain.
 constexpr int kFW4 = kFMaxN * kTK / 4 / kFThreads;  // float4 weight loads per thread and chunk (4)
 
-__device__ __forceinline__ void fused_mma(f32x16& acc, const float* in, int ld_in, int K,
+__device__ __forceinline__ void fused_mma(f32x4 (&acc)[2], const float* in, int ld_in, int K,
                                           const float* __restrict__ W, int N, float* bs) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave & 3;
   const bool active = wn * 32 < N;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
   // staging coordinates of this thread inside a [kTK x 128] tile (fixed across chunks): float4 q
   // covers W[n][k4 .. k4+3]
   int s_n[kFW4], s_k4[kFW4];
@@ -543,14 +547,18 @@ __device__ __forceinline__ void fused_mma(f32x16& acc, const float* in, int ld_i
     if (t + 1 < n_chunks) stage(w_next, tile[(t + 1) & 1]);
     if (t + 3 < n_chunks) fetch(w_next, (t + 3) * kTK);
     if (active) {
+      // 16x16x4 fp32 MFMA: lane l feeds A[row l & 15][k + (l >> 4)] and B[k + (l >> 4)][col l & 15]; the wave's 32
+      // output columns are two 16-column tiles that share the A operand
       const float* cur = tile[t & 1];
-      const int i = lane & 31, kh = lane >> 5;
+      const int i = lane & 15, kq = lane >> 4;
       const int k0 = t * kTK;
 #pragma unroll
-      for (int kk = 0; kk < kTK; kk += 2) {
-        const float a = in[i * ld_in + k0 + kk + kh];
-        const float b = cur[(kk + kh) * kFLdN + wn * 32 + i];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      for (int kk = 0; kk < kTK; kk += 4) {
+        const float a = in[i * ld_in + k0 + kk + kq];
+        const float b0 = cur[(kk + kq) * kFLdN + wn * 32 + i];
+        const float b1 = cur[(kk + kq) * kFLdN + wn * 32 + 16 + i];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[1], 0, 0, 0);
       }
     }
     // issue order: one MFMA, then the LDS reads of the next one, one staging store, and every
@@ -558,7 +566,7 @@ __device__ __forceinline__ void fused_mma(f32x16& acc, const float* in, int ld_i
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read (3 per MFMA pair: a, b0, b1)
       __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
       if ((g & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
     }
@@ -582,12 +590,12 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   const FusedLds L = fused_lds(lds_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wn = wave & 3;
   const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kFR;
   const int Dm = p.dim_mlp, E = p.dim_mf, K0 = 2 * Dm;
 
   // gather, element-parallel: 64 threads fetch the index pairs, then every thread owns
-  // kFR * K0 / 512 <= 32 elements of the tower input; all its loads are requested before anything
+  // kFR * K0 / 256 <= 16 elements of the tower input; all its loads are requested before anything
   // is stored (one round trip for the whole tile instead of one per row)
   __shared__ long long s_u[kFR], s_i[kFR];
   if (tid < kFR) {
@@ -658,16 +666,16 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
   float* out = L.narrow;
   for (int l = 0; l < p.n_layers; ++l) {
     const int K = p.layer_in[l], N = p.layer_out[l];
-    f32x16 acc;
+    f32x4 acc[2];
     fused_mma(acc, in, L.ld_of(in), K, p.fc_w[l], N, L.bs);
     if (wn * 32 < N) {
-      const int col = wn * 32 + (lane & 31);
-      const float bias = p.fc_b[l][col];
       const int ld_out = L.ld_of(out);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float v = fmaxf(acc[r] + bias, 0.f);
+      for (int q = 0; q < 8; ++q) {   // C[row 4 * (lane >> 4) + r][col lane & 15] of tile q >> 2
+        const int r = q & 3, col = wn * 32 + (q >> 2) * 16 + (lane & 15);
+        const int row = 4 * (lane >> 4) + r;
+        const float bias = p.fc_b[l][col];
+        float v = fmaxf(acc[q >> 2][r] + bias, 0.f);
         // act[l + 1] is what the NEXT Linear sees: its Dropout is applied here (the backward's dgrad epilogue
         // applies the same keep bytes)
         if constexpr (DROP)
@@ -815,7 +823,9 @@ static int forward(const hiprec_ncf_plan* p, const int64_t* users, const int64_t
                    int64_t batch, hiprec_stats* stats, hipStream_t st, bool* scored,
                    const float* ratings = nullptr, float inv_batch = 0.f, Scratch* scratch = nullptr) {
   *scored = false;
-  if (fusable(p)) {
+  // the training launch publishes one loss partial per block: batches beyond kMaxBlocks * kFR samples (32 768) take
+  // the launch-per-layer path
+  if (fusable(p) && (!ratings || (batch + kFR - 1) / kFR <= kMaxBlocks)) {
     if (int rc = fused_attrs()) return rc;
     const int grid = static_cast<int>((batch + kFR - 1) / kFR);
     bool drop = false;

@@ -539,11 +539,13 @@ class ShardedMFEngine:
             perm = perm.to(dev)
             users, pos, neg = users[perm], pos[perm], neg[perm]
         ar = lambda m: torch.arange(m, dtype=torch.int64, device=dev)  # noqa: E731
+        # sort keys travel as int32 whenever their range allows: half the radix passes of the device sorts
+        small = lambda key, bound: key.to(torch.int32) if bound < 2**31 else key  # noqa: E731
         step = torch.div(ar(n), bs, rounding_mode="floor")
 
         # (1) triples -> owner(user), the whole epoch in one exchange, (dest, step)-ordered
         key = (users % R) * S + step
-        o1 = torch.argsort(key, stable=True)
+        o1 = torch.argsort(small(key, R * S), stable=True)
         cnt_ds = torch.bincount(key, minlength=R * S).view(R, S)
         recv_cnt = torch.empty_like(cnt_ds)
         dist.all_to_all_single(recv_cnt, cnt_ds, group=self.pg)            # [source, step]
@@ -552,7 +554,7 @@ class ShardedMFEngine:
         send1, recv1, cap = host[:R], host[R:2 * R], max(int(host[2 * R]), 1)
         trip = self._a2a(torch.stack([users, pos, neg], 1)[o1], send1, recv1)   # (source, step)-ordered
         step_r = torch.repeat_interleave(ar(S).repeat(R), recv_cnt.reshape(-1))
-        o2 = torch.argsort(step_r, stable=True)                            # -> (step, source)
+        o2 = torch.argsort(small(step_r, S), stable=True)                  # -> (step, source)
         trip, step_r = trip[o2], step_r[o2]
         at = step_r * cap + (ar(trip.shape[0]) - (torch.cumsum(n_k, 0) - n_k)[step_r])
         U = torch.full((S * cap,), -1, dtype=torch.int64, device=dev)      # fixed-size blocks, -1 = padding
@@ -566,7 +568,9 @@ class ShardedMFEngine:
         v2 = torch.cat([valid, valid])
         items = torch.cat([P, N])[v2]
         st2 = torch.div(ar(2 * S * cap) % (S * cap), cap, rounding_mode="floor")[v2]
-        uniq, inv = torch.unique((st2 * R + items % R) * self.n_items + items, return_inverse=True)
+        uniq, inv = torch.unique(small((st2 * R + items % R) * self.n_items + items, S * R * self.n_items),
+                                 return_inverse=True)
+        uniq = uniq.to(torch.int64)
         u_item = uniq % self.n_items
         u_sd = torch.div(uniq, self.n_items, rounding_mode="floor")       # step * R + dest
         u_step, u_dest = torch.div(u_sd, R, rounding_mode="floor"), u_sd % R
@@ -586,12 +590,12 @@ class ShardedMFEngine:
         send2, recv2 = host[:R], host[R:2 * R]
         req_l = [host[2 * R + k * R: 2 * R + (k + 1) * R] for k in range(S)]
         in_l = [host[2 * R + S * R + k * R: 2 * R + S * R + (k + 1) * R] for k in range(S)]
-        o3 = torch.argsort(u_dest * S + u_step, stable=True)
+        o3 = torch.argsort(small(u_dest * S + u_step, R * S), stable=True)
         incoming = self._a2a(u_item[o3], send2, recv2)                     # (source, step)-ordered
         flat_cnt = in_qs.reshape(-1)
         step_i = torch.repeat_interleave(ar(S).repeat(R), flat_cnt)
         src_i = torch.repeat_interleave(ar(R).repeat_interleave(S), flat_cnt)
-        o4 = torch.argsort(step_i, stable=True)                            # -> (step, source)
+        o4 = torch.argsort(small(step_i, S), stable=True)                  # -> (step, source)
         incoming, step_i, src_i = incoming[o4], step_i[o4], src_i[o4]
         in_idx = torch.full((incoming.numel() + S * R,), -1, dtype=torch.int64, device=dev)   # extras stay -1
         in_idx[ar(incoming.numel()) + step_i * R + src_i] = torch.div(incoming, R, rounding_mode="floor")
@@ -614,7 +618,8 @@ class ShardedMFEngine:
         # (4) inside every step: triples sorted by positive slot (adjacent equal items merge in registers), and the
         # ownership of the local user rows / the reference counts of the slots (csrc/ownership.hip)
         big = max(n_slots) + 1
-        o5 = torch.argsort(torch.div(ar(S * cap), cap, rounding_mode="floor") * big + torch.where(valid, SP, big - 1))
+        o5 = torch.argsort(small(torch.div(ar(S * cap), cap, rounding_mode="floor") * big
+                                 + torch.where(valid, SP, big - 1), S * big))
         U, SP, SN = U[o5].contiguous(), SP[o5].contiguous(), SN[o5].contiguous()
         own, total, stride = batch_row_ownership(U, SP, SN, cap, self.model.n_users, max(n_slots))
         return {"S": S, "cap": cap, "bs": bs, "n": n, "U": U, "SP": SP, "SN": SN, "own": own, "total": total,
