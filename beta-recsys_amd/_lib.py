@@ -83,13 +83,22 @@ class Csr(Structure):
                 ("n_rows", c_int64), ("nnz", c_int64), ("slice_row", c_void_p)]
 
 
+class SlicedCsr(Structure):
+    """hiprec_sliced_csr (include/hiprec.h)."""
+
+    _fields_ = [("chunks", c_void_p), ("col16", c_void_p), ("val", c_void_p), ("eid", c_void_p),
+                ("sub_row", c_void_p), ("sub_chunk", c_void_p), ("n_rows", c_int64), ("n_slots", c_int64),
+                ("n_groups", c_int32), ("subs_per_group", c_int32), ("n_chunks", c_int32), ("row_cap", c_int32)]
+
+
 class LightGcnPlan(Structure):
     """hiprec_lightgcn_plan (include/hiprec.h)."""
 
     _fields_ = [("a", Csr), ("at", Csr), ("n_users", c_int64), ("n_items", c_int64),
                 ("dim", c_int32), ("n_layers", c_int32), ("decay", c_float), ("_pad", c_int32)] + \
                [(n, c_void_p) for n in ("e0", "g", "xa", "xb", "acc", "da", "db", "zero_ws")] + \
-               [("zero_ws_floats", c_int64)]
+               [("zero_ws_floats", c_int64), ("sa", SlicedCsr), ("sat", SlicedCsr), ("slice_w", c_int32),
+                ("_pad2", c_int32), ("sliced_ws", c_void_p), ("sliced_ws_floats", c_int64)]
 
 
 class PgmfTables(Structure):
@@ -197,6 +206,12 @@ SIGNATURES = {
     ),
     "hiprec_lightgcn_plan_bytes": (c_size_t, []),
     "hiprec_spmm_csr": (c_int, [POINTER(Csr), _P, c_float, _P, _P, _P, c_int32, _P]),
+    "hiprec_sliced_width": (c_int32, [c_int64, c_int32]),
+    "hiprec_sliced_row_cap": (c_int32, [c_int64, c_int32]),
+    "hiprec_to_sliced": (c_int, [_P, c_int64, c_int32, c_int32, _P, _P]),
+    "hiprec_from_sliced": (c_int, [_P, c_int64, c_int32, c_int32, _P, c_int32, _P]),
+    "hiprec_sliced_drop_values": (c_int, [POINTER(SlicedCsr), _P, _P, _P]),
+    "hiprec_spmm_sliced": (c_int, [POINTER(SlicedCsr), _P, c_float, _P, _P, _P, c_int32, c_int32, c_int32, _P]),
     "hiprec_edge_dropout_mask": (c_int, [_P, c_int64, c_float, ctypes.c_uint64, ctypes.c_uint64, _P]),
     "hiprec_lightgcn_propagate": (c_int, [POINTER(LightGcnPlan), _P, c_float, _P]),
     "hiprec_lightgcn_predict": (c_int, [POINTER(LightGcnPlan), _P, _P, c_int64, _P, _P, _P]),

@@ -264,6 +264,17 @@ static int check_lg_plan(const hiprec_lightgcn_plan* p, bool train) {
                    "zero_ws holds %lld floats, (1 + 2*n_layers) * n_rows * dim are needed",
                    (long long)p->zero_ws_floats);
   HIPREC_REQUIRE(p->e0 && p->acc && (ws || (p->xa && p->xb)), "NULL forward buffers");
+  if (p->sliced_ws) {
+    HIPREC_REQUIRE(p->slice_w == sliced_width(p->a.n_rows, p->dim) && p->slice_w > 0,
+                   "slice_w %d is not the sliced SpMM's width for %lld rows x dim %d", p->slice_w,
+                   (long long)p->a.n_rows, p->dim);
+    HIPREC_REQUIRE(p->sliced_ws_floats >= 4 * p->a.n_rows * p->dim + p->sa.n_slots + p->sat.n_slots,
+                   "sliced_ws holds %lld floats, 4 * n_rows * dim + sa.n_slots + sat.n_slots needed",
+                   (long long)p->sliced_ws_floats);
+    HIPREC_REQUIRE(p->sa.n_rows == p->a.n_rows && p->sa.n_slots >= p->a.nnz && p->sa.eid &&
+                       (!train || (p->sat.n_rows == p->a.n_rows && p->sat.n_slots >= p->a.nnz && p->sat.eid)),
+                   "sliced graphs do not match the CSRs");
+  }
   if (train) {
     if (int rc = check_csr(&p->at, "at")) return rc;
     HIPREC_REQUIRE(p->at.n_rows == p->a.n_rows && p->at.nnz == p->a.nnz, "a / at mismatch");
@@ -278,10 +289,47 @@ static float* ws_slice(const hiprec_lightgcn_plan* p, int k) {
   return p->zero_ws + static_cast<int64_t>(k) * p->a.n_rows * p->dim;
 }
 
+// The sliced path (csrc/spmm_sliced.hip): four buffers of n_rows * dim floats in plan->sliced_ws --
+// [0] the transposed input, [1] the running layer sum, [2], [3] ping-pong layer outputs -- then the dropped edge
+// values of the step: sa.n_slots floats for the forward graph, sat.n_slots for its transpose.
+static bool use_sliced(const hiprec_lightgcn_plan* p) { return p->sliced_ws != nullptr && p->slice_w > 0; }
+
+static float* sliced_buf(const hiprec_lightgcn_plan* p, int k) {
+  return p->sliced_ws + static_cast<int64_t>(k) * p->a.n_rows * p->dim;
+}
+
+// out (row-major) = [add] sum_{l = first .. L} G^l in, G = `graph`; the l = 0 term only when `with_input`
+static int propagate_sliced(const hiprec_lightgcn_plan* p, const hiprec_sliced_csr* graph, const uint8_t* keep,
+                            float keep_prob, const float* in, float* out, bool with_input, bool add,
+                            hipStream_t st) {
+  const int64_t N = p->a.n_rows;
+  const int D = p->dim, W = p->slice_w;
+  const float scale = keep ? 1.0f / keep_prob : 1.0f;
+  float* xs0 = sliced_buf(p, 0);
+  float* accs = sliced_buf(p, 1);
+  if (int rc = launch_to_sliced(in, N, D, W, xs0, with_input ? accs : nullptr, st)) return rc;
+  const float* val = nullptr;
+  if (keep && p->n_layers > 0) {  // once per step and graph, not per pass
+    float* dropped = sliced_buf(p, 4) + (graph == &p->sat ? p->sa.n_slots : 0);
+    if (int rc = launch_drop_values(graph, keep, dropped, st)) return rc;
+    val = dropped;
+  }
+  const float* cur = xs0;
+  for (int l = 0; l < p->n_layers; ++l) {
+    float* nxt = sliced_buf(p, 2 + (l & 1));
+    const int mode = (l == 0 && !with_input) ? 2 : 1;
+    if (int rc = launch_spmm_sliced(graph, val, scale, cur, nxt, accs, mode, D, W, st)) return rc;
+    cur = nxt;
+  }
+  if (p->n_layers == 0 && !with_input) return 0;
+  return launch_from_sliced(accs, N, D, W, out, add, st);
+}
+
 // acc = sum_{l=0..L} A^l E0   (out = acc / (L+1))
 // `ws_zeroed`: the caller already cleared the whole zero_ws region (training step)
 static int propagate(const hiprec_lightgcn_plan* p, const uint8_t* keep, float keep_prob,
                      hipStream_t st, bool ws_zeroed = false) {
+  if (use_sliced(p)) return propagate_sliced(p, &p->sa, keep, keep_prob, p->e0, p->acc, true, false, st);
   const size_t bytes = sizeof(float) * p->a.n_rows * p->dim;
   HIPREC_TRY(hipMemcpyAsync(p->acc, p->e0, bytes, hipMemcpyDeviceToDevice, st));
   const bool ws = p->zero_ws != nullptr;
@@ -369,9 +417,11 @@ extern "C" int hiprec_lightgcn_grad(const hiprec_lightgcn_plan* plan, const uint
   const size_t bytes = sizeof(float) * p->a.n_rows * p->dim;
   const bool ws = p->zero_ws != nullptr;
   hiprec_lightgcn_plan q = *p;  // d_out may live in the workspace
+  const bool sliced = use_sliced(p);
   if (ws) {
-    // ONE fill for d_out and every layer output of the step (it was 7 launches of ~5 us each)
-    HIPREC_TRY(hipMemsetAsync(p->zero_ws, 0, bytes * (1 + 2 * static_cast<size_t>(p->n_layers)), st));
+    // ONE fill for d_out and every layer output of the step (it was 7 launches of ~5 us each); the sliced SpMM
+    // writes every output row itself: only d_out (the loss kernel scatters into it) has to be clear
+    HIPREC_TRY(hipMemsetAsync(p->zero_ws, 0, sliced ? bytes : bytes * (1 + 2 * static_cast<size_t>(p->n_layers)), st));
     q.da = ws_slice(p, 0);
   }
   if (int rc = propagate(p, keep, keep_prob, st, /*ws_zeroed=*/ws)) return rc;
@@ -380,6 +430,7 @@ extern "C" int hiprec_lightgcn_grad(const hiprec_lightgcn_plan* plan, const uint
       q, users, pos, neg, batch, inv_batch, stats, static_cast<Scratch*>(scratch));
   HIPREC_TRY(hipGetLastError());
   // g = sum_{l=0..L} (A^T)^l d_out : the l = 0 term is already in g
+  if (sliced) return propagate_sliced(p, &p->sat, keep, keep_prob, q.da, p->g, false, true, st);
   const float scale = keep ? 1.0f / keep_prob : 1.0f;
   float* cur = q.da;
   float* nxt = p->db;

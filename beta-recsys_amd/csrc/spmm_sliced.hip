@@ -1,0 +1,270 @@
+// Column-sliced SpMM for graphs whose node count fits the LDS: Y = (A with dropped edges) X, ACC += Y.
+//
+// The edge-parallel SpMM of lightgcn.hip gathers one 256-B source row per edge out of L2: nnz x D x 4 B = 381 MB
+// per pass at the ML-1M graph (1.49 M edges, D 64), delivered at ~9.3 TB/s whatever the node order
+// (profiles/r02_experiments.md §28) -- the kernel is bound by the L2 -> CU row-gather rate, 41 us per pass.
+// The source matrix itself is tiny (9746 x 64 fp32 = 2.5 MB).  Cut into column slices of W = 4 floats it becomes
+// 16 slices of N x 16 B = 156 KB: ONE slice fits a CU's 160 KB of LDS.  So the feature dimension is split over the
+// workgroups instead of the lanes: block (slice s, row group g) loads slice s of X into LDS once (contiguous: the
+// propagation buffers live in a SLICED layout [D/W][N][W]), then walks the edges of its rows reading sources from
+// LDS.  What still comes out of L2 per edge is its (col, val) -- 6 B with 16-bit columns -- once per slice, and
+// the 16 blocks that share a row group sit on the same XCD (blockIdx = s * n_groups + g, n_groups a multiple of
+// 8), so the edge arrays leave HBM / MALL once.
+//
+// The graph is stored for this kernel (hiprec_sliced_csr): every row's edge list padded to a multiple of 16 slots
+// (col 0, value 0), and cut into CHUNKS of at most 64 slots of one row.  A chunk is the work item of FOUR lanes,
+// 16 consecutive slots each: three 16-byte loads per lane for the values, two for the columns, 16 LDS reads, 64
+// FMAs, then two DPP steps over the quad and one ds_add_f32 per component into the row's accumulator in LDS (the
+// rows of a block are cut into subgroups whose accumulators fit next to the slice).  Chunks are uniform, so their
+// assignment is static (no row-length imbalance), descriptors are fetched two chunks ahead and edge data one chunk
+// ahead of the arithmetic.  Edge dropout is applied to the value array once per step (drop_values_kernel), not
+// per pass.  A subgroup's finished rows are written once, coalesced, with plain stores: no global atomics, no
+// zero fill, and the fused layer sum is a plain read-modify-write.
+//
+// Earlier versions (MI355X, ML-1M graph, per pass): 16 lanes per ROW with a dynamic row counter 200 us (every row
+// switch is a chain of dependent loads and the four groups of a wave serialise theirs); 16 lanes per 64-edge chunk,
+// strided scalar loads, 16 DPP adds per chunk 47 us (VALU: ~180 instructions per 512 edges).
+#include <algorithm>
+
+#include "common.hpp"
+#include "spmm.hpp"
+
+namespace hiprec {
+
+constexpr int kSlicedThreads = 1024;
+constexpr int kSlicedQuads = kSlicedThreads / 4;
+constexpr int64_t kSlicedLds = 160 * 1024 - 64;  // one workgroup's LDS, less the kernel's own few words
+constexpr int kSlicedMinRowCap = 128;            // accumulator rows a subgroup must at least be able to hold
+
+struct SlicedEdges {  // the 16 slots of one lane
+  uint4 c[2];
+  float4 v[4];
+};
+
+__device__ __forceinline__ SlicedEdges load_sliced_edges(const uint16_t* __restrict__ col16,
+                                                         const float* __restrict__ val, int2 d, int q) {
+  SlicedEdges e;
+  if (q * 16 < (d.y >> 16)) {
+    const int64_t base = static_cast<int64_t>(d.x) + q * 16;  // a multiple of 16: 32-B / 64-B aligned
+    const uint4* pc = reinterpret_cast<const uint4*>(col16 + base);
+    const float4* pv = reinterpret_cast<const float4*>(val + base);
+    e.c[0] = pc[0];
+    e.c[1] = pc[1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e.v[k] = pv[k];
+  } else {
+    e.c[0] = e.c[1] = uint4{0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e.v[k] = float4{0.f, 0.f, 0.f, 0.f};
+  }
+  return e;
+}
+
+// acc_mode: 0 = none, 1 = accs += y, 2 = accs = y
+template <int W>
+__global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_sliced_csr a,
+                                                                     const float* __restrict__ val, float scale,
+                                                                     const float* __restrict__ xs,
+                                                                     float* __restrict__ ys, float* __restrict__ accs,
+                                                                     int acc_mode) {
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  const int64_t n_rows = a.n_rows;
+  float* s_x = s_mem;               // [n_rows][W]: slice s of the source
+  float* s_y = s_mem + n_rows * W;  // [rows of the subgroup][W]
+  const int s = static_cast<int>(blockIdx.x) / a.n_groups, g = static_cast<int>(blockIdx.x) % a.n_groups;
+  const int64_t slice_off = static_cast<int64_t>(s) * n_rows * W;
+  {
+    const float* x = xs + slice_off;
+    const int64_t n_f = n_rows * W, n4 = n_f >> 2;
+    for (int64_t i = threadIdx.x; i < n4; i += kSlicedThreads)
+      reinterpret_cast<float4*>(s_x)[i] = reinterpret_cast<const float4*>(x)[i];
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n_f; i += kSlicedThreads) s_x[i] = x[i];
+  }
+  const int quad = static_cast<int>(threadIdx.x) >> 2, q = static_cast<int>(threadIdx.x) & 3;
+  const int2* __restrict__ chunks = reinterpret_cast<const int2*>(a.chunks);
+  auto desc = [&](int c, int c1) { return c < c1 ? chunks[c] : int2{0, 0}; };  // {first slot, row | n_slots << 16}
+  for (int sg = g * a.subs_per_group; sg < (g + 1) * a.subs_per_group; ++sg) {
+    const int r0 = a.sub_row[sg], r1 = a.sub_row[sg + 1], c0 = a.sub_chunk[sg], c1 = a.sub_chunk[sg + 1];
+    const int n_out = (r1 - r0) * W;
+    for (int i = threadIdx.x; i < n_out; i += kSlicedThreads) s_y[i] = 0.f;
+    __syncthreads();  // (the first one also publishes the slice)
+    int c = c0 + quad;
+    int2 d = desc(c, c1), d_next = desc(c + kSlicedQuads, c1);
+    SlicedEdges e = load_sliced_edges(a.col16, val, d, q);
+    while (c < c1) {
+      const int2 d_after = desc(c + 2 * kSlicedQuads, c1);
+      const SlicedEdges e_next = load_sliced_edges(a.col16, val, d_next, q);
+      float acc[W];
+#pragma unroll
+      for (int w = 0; w < W; ++w) acc[w] = 0.f;
+      const uint32_t cw[8] = {e.c[0].x, e.c[0].y, e.c[0].z, e.c[0].w, e.c[1].x, e.c[1].y, e.c[1].z, e.c[1].w};
+      const float vv[16] = {e.v[0].x, e.v[0].y, e.v[0].z, e.v[0].w, e.v[1].x, e.v[1].y, e.v[1].z, e.v[1].w,
+                            e.v[2].x, e.v[2].y, e.v[2].z, e.v[2].w, e.v[3].x, e.v[3].y, e.v[3].z, e.v[3].w};
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const uint32_t col = (j & 1) ? (cw[j >> 1] >> 16) : (cw[j >> 1] & 0xFFFFu);
+        const float* src = s_x + col * W;
+#pragma unroll
+        for (int w = 0; w < W; ++w) acc[w] += vv[j] * src[w];
+      }
+      float mine = 0.f;  // lane q < W of the quad adds component q
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        float t = dpp_add<0xB1>(acc[w]);  // quad_perm [1,0,3,2]
+        t = dpp_add<0x4E>(t);             // quad_perm [2,3,0,1]
+        mine = q == w ? t : mine;
+      }
+      if (q < W && (d.y >> 16) > 0) lds_add_f32(&s_y[((d.y & 0xFFFF) - r0) * W + q], mine);
+      c += kSlicedQuads;
+      d = d_next;
+      d_next = d_after;
+      e = e_next;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_out; i += kSlicedThreads) {
+      const float y = s_y[i] * scale;
+      const int64_t o = slice_off + static_cast<int64_t>(r0) * W + i;
+      ys[o] = y;
+      if (acc_mode == 1) accs[o] += y;
+      else if (acc_mode == 2) accs[o] = y;
+    }
+    __syncthreads();
+  }
+}
+
+// out[slot] = keep[eid[slot]] ? val[slot] : 0 (padding slots: eid < 0, value 0) -- the dropped edge values of a
+// step in the sliced graph's slot order, so that no pass looks at keep bytes
+__global__ __launch_bounds__(kBlock) void drop_values_kernel(const float* __restrict__ val,
+                                                             const int32_t* __restrict__ eid,
+                                                             const uint8_t* __restrict__ keep, int64_t n_slots,
+                                                             float* __restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < n_slots; e += stride) {
+    const int32_t k = eid[e];
+    out[e] = (k >= 0 && keep[k]) ? val[e] : 0.f;
+  }
+}
+
+// row-major [n_rows][dim]  <->  sliced [dim / W][n_rows][W]
+__global__ __launch_bounds__(kBlock) void to_sliced_kernel(const float* __restrict__ x, int64_t n_rows, int dim,
+                                                           int W, float* __restrict__ xs,
+                                                           float* __restrict__ xs_copy) {
+  const int64_t total = n_rows * dim;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / dim;
+    const int c = static_cast<int>(i - r * dim);
+    const int64_t o = (static_cast<int64_t>(c / W) * n_rows + r) * W + c % W;
+    const float v = x[i];
+    xs[o] = v;
+    if (xs_copy) xs_copy[o] = v;
+  }
+}
+
+// y (row-major) = or += xs (sliced)
+__global__ __launch_bounds__(kBlock) void from_sliced_kernel(const float* __restrict__ xs, int64_t n_rows, int dim,
+                                                             int W, float* __restrict__ y, int add) {
+  const int64_t total = n_rows * dim;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / dim;
+    const int c = static_cast<int>(i - r * dim);
+    const float v = xs[(static_cast<int64_t>(c / W) * n_rows + r) * W + c % W];
+    y[i] = add ? y[i] + v : v;
+  }
+}
+
+int sliced_width(int64_t n_rows, int dim) {
+  if (n_rows <= 0 || n_rows >= 65536 || dim <= 0) return 0;  // 16-bit column and row ids
+  // a width below 4 floats re-reads the edge arrays more often than the gather SpMM reads source rows: W = 4 or
+  // (a narrower slice for graphs of up to ~20 k nodes) 2
+  for (int w : {4, 2})
+    if (dim % w == 0 && (n_rows + kSlicedMinRowCap) * w * static_cast<int64_t>(sizeof(float)) <= kSlicedLds) return w;
+  return 0;
+}
+
+int sliced_row_cap(int64_t n_rows, int dim) {
+  const int w = sliced_width(n_rows, dim);
+  if (w == 0) return 0;
+  return static_cast<int>(std::min<int64_t>(kSlicedLds / (w * sizeof(float)) - n_rows, n_rows));
+}
+
+int launch_spmm_sliced(const hiprec_sliced_csr* a, const float* val, float scale, const float* xs, float* ys,
+                       float* accs, int acc_mode, int dim, int W, hipStream_t st) {
+  HIPREC_REQUIRE(a && a->sub_row && a->sub_chunk && a->n_rows > 0 && a->n_groups > 0 && a->subs_per_group > 0,
+                 "bad sliced graph");
+  HIPREC_REQUIRE(a->n_slots == 0 || (a->col16 && a->val && a->chunks), "sliced graph has NULL chunks / col16 / val");
+  HIPREC_REQUIRE(a->n_slots % 16 == 0, "n_slots %lld is not a multiple of 16", (long long)a->n_slots);
+  HIPREC_REQUIRE(W > 0 && W == sliced_width(a->n_rows, dim), "slice width %d does not fit %lld rows x dim %d", W,
+                 (long long)a->n_rows, dim);
+  HIPREC_REQUIRE(a->row_cap > 0 && a->row_cap <= sliced_row_cap(a->n_rows, dim),
+                 "subgroups of up to %d rows do not fit the LDS next to the slice (at most %d)", a->row_cap,
+                 sliced_row_cap(a->n_rows, dim));
+  HIPREC_REQUIRE(xs && ys && (acc_mode == 0 || accs), "NULL sliced buffers");
+  const size_t lds = static_cast<size_t>(a->n_rows + a->row_cap) * W * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    for (const void* k : {reinterpret_cast<const void*>(&spmm_sliced_kernel<4>),
+                          reinterpret_cast<const void*>(&spmm_sliced_kernel<2>)})
+      HIPREC_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSlicedLds)));
+    attr_set = true;
+  }
+  if (val == nullptr) val = a->val;
+  const int grid = (dim / W) * a->n_groups;
+  if (W == 4)
+    spmm_sliced_kernel<4><<<grid, kSlicedThreads, lds, st>>>(*a, val, scale, xs, ys, accs, acc_mode);
+  else
+    spmm_sliced_kernel<2><<<grid, kSlicedThreads, lds, st>>>(*a, val, scale, xs, ys, accs, acc_mode);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_drop_values(const hiprec_sliced_csr* a, const uint8_t* keep, float* out, hipStream_t st) {
+  HIPREC_REQUIRE(a && keep && out && (a->n_slots == 0 || (a->val && a->eid)), "bad arguments");
+  if (a->n_slots == 0) return 0;
+  drop_values_kernel<<<grid_for_threads(a->n_slots), kBlock, 0, st>>>(a->val, a->eid, keep, a->n_slots, out);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_to_sliced(const float* x, int64_t n_rows, int dim, int W, float* xs, float* xs_copy, hipStream_t st) {
+  to_sliced_kernel<<<grid_for_threads(n_rows * dim), kBlock, 0, st>>>(x, n_rows, dim, W, xs, xs_copy);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_from_sliced(const float* xs, int64_t n_rows, int dim, int W, float* y, bool add, hipStream_t st) {
+  from_sliced_kernel<<<grid_for_threads(n_rows * dim), kBlock, 0, st>>>(xs, n_rows, dim, W, y, add ? 1 : 0);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // namespace hiprec
+
+using namespace hiprec;
+
+extern "C" int32_t hiprec_sliced_width(int64_t n_rows, int32_t dim) { return sliced_width(n_rows, dim); }
+
+extern "C" int32_t hiprec_sliced_row_cap(int64_t n_rows, int32_t dim) { return sliced_row_cap(n_rows, dim); }
+
+extern "C" int hiprec_to_sliced(const float* x, int64_t n_rows, int32_t dim, int32_t slice_w, float* xs,
+                                void* stream) {
+  HIPREC_REQUIRE(x && xs && n_rows > 0 && dim > 0 && slice_w > 0 && dim % slice_w == 0, "bad arguments");
+  return launch_to_sliced(x, n_rows, dim, slice_w, xs, nullptr, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int hiprec_from_sliced(const float* xs, int64_t n_rows, int32_t dim, int32_t slice_w, float* y,
+                                  int32_t add, void* stream) {
+  HIPREC_REQUIRE(y && xs && n_rows > 0 && dim > 0 && slice_w > 0 && dim % slice_w == 0, "bad arguments");
+  return launch_from_sliced(xs, n_rows, dim, slice_w, y, add != 0, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int hiprec_sliced_drop_values(const hiprec_sliced_csr* a, const uint8_t* keep, float* out, void* stream) {
+  return launch_drop_values(a, keep, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int hiprec_spmm_sliced(const hiprec_sliced_csr* a, const float* val, float scale, const float* xs,
+                                  float* ys, float* accs, int32_t acc_mode, int32_t dim, int32_t slice_w,
+                                  void* stream) {
+  return launch_spmm_sliced(a, val, scale, xs, ys, accs, acc_mode, dim, slice_w, static_cast<hipStream_t>(stream));
+}

@@ -43,6 +43,60 @@ def _csr_from_coo(rows, cols, vals, n, device):
     return (rowptr.to(device), c.to(torch.int32).to(device), v.to(torch.float32).to(device), order)
 
 
+SLICED_CHUNK, SLICED_PAD = 64, 16  # slots per work item / row padding of the column-sliced SpMM (csrc/spmm_sliced.hip)
+
+
+def sliced_graph_host(rowptr, col, val, eid, n_groups, row_cap, max_subs=64):
+    """hiprec_sliced_csr (include/hiprec.h) of a CSR given as numpy arrays; eid = keep-byte index of every edge
+    (None = the edge number itself).
+
+    Returns dict(col16 uint16, val float32, eid int32 [n_slots]; chunks int32 [n_chunks, 2]; sub_row, sub_chunk
+    int32 [n_groups * k + 1]; subs_per_group k; n_chunks; n_slots) or None when no k <= max_subs keeps every subgroup
+    within row_cap rows."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    n, nnz = rowptr.size - 1, int(rowptr[-1])
+    lens = np.diff(rowptr)
+    padded = (lens + SLICED_PAD - 1) // SLICED_PAD * SLICED_PAD
+    slotptr = np.concatenate([[0], np.cumsum(padded)])
+    n_slots = int(slotptr[-1])
+    edge_row = np.repeat(np.arange(n, dtype=np.int64), lens)
+    slot = np.arange(nnz, dtype=np.int64) + (slotptr[:-1] - rowptr[:-1])[edge_row]
+    col16, valp, eidp = np.zeros(n_slots, np.uint16), np.zeros(n_slots, np.float32), np.full(n_slots, -1, np.int32)
+    col16[slot] = np.asarray(col)[:nnz]
+    valp[slot] = np.asarray(val)[:nnz]
+    eidp[slot] = np.arange(nnz) if eid is None else np.asarray(eid)[:nnz]
+    per_row = (padded + SLICED_CHUNK - 1) // SLICED_CHUNK
+    first = np.cumsum(per_row) - per_row  # first chunk of every row
+    n_chunks = int(per_row.sum())
+    chunk_row = np.repeat(np.arange(n, dtype=np.int64), per_row)
+    within = np.arange(n_chunks, dtype=np.int64) - first[chunk_row]
+    start = slotptr[chunk_row] + SLICED_CHUNK * within
+    clen = np.minimum(SLICED_CHUNK, padded[chunk_row] - SLICED_CHUNK * within)
+    chunks = np.stack([start, chunk_row | (clen << 16)], axis=1).astype(np.int32)
+    for k in range(1, max_subs + 1):
+        n_sub = n_groups * k
+        target = np.minimum((np.arange(n_sub + 1) * n_chunks) // n_sub, max(n_chunks - 1, 0))
+        sub_row = chunk_row[target] if n_chunks else np.zeros(n_sub + 1, dtype=np.int64)
+        sub_row[0], sub_row[-1] = 0, n
+        sub_row = np.maximum.accumulate(sub_row)
+        sub_chunk = np.append(first, n_chunks)[sub_row]  # a subgroup starts at the first chunk of its first row
+        if np.diff(sub_row).max() <= row_cap:
+            return {"col16": col16, "val": valp, "eid": eidp, "chunks": chunks, "sub_row": sub_row.astype(np.int32),
+                    "sub_chunk": sub_chunk.astype(np.int32), "subs_per_group": k, "n_chunks": n_chunks,
+                    "n_slots": n_slots}
+    return None
+
+
+def sliced_graph_device(host, n_rows, n_groups, row_cap, device):
+    """(_lib.SlicedCsr, the device tensors it points to) of sliced_graph_host's arrays."""
+    hold = {k: torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else v).to(device)
+            for k, v in host.items() if isinstance(v, np.ndarray)}
+    sc = _lib.SlicedCsr(hold["chunks"].data_ptr(), hold["col16"].data_ptr(), hold["val"].data_ptr(),
+                        hold["eid"].data_ptr(), hold["sub_row"].data_ptr(), hold["sub_chunk"].data_ptr(), n_rows,
+                        host["n_slots"], n_groups, host["subs_per_group"], host["n_chunks"], row_cap)
+    return sc, hold
+
+
 class LightGCN(_FlatModel):
     """models/lightgcn.py:7-101."""
 
@@ -95,6 +149,23 @@ class LightGCN(_FlatModel):
         if dev.type == "cuda":
             self._graph["slice_row"] = _slice_rows(rp, c, v, N, nnz)
             self._graph["slice_row_t"] = _slice_rows(rpt, ct, vt, N, nnz)
+            # graphs whose node count fits the LDS take the column-sliced SpMM (csrc/spmm_sliced.hip): 16-bit column
+            # ids and row groups of equal edge count, one (slice, row group) per compute unit
+            lib = _lib.load()
+            w = int(lib.hiprec_sliced_width(N, self.emb_dim)) if self.config.get("spmm", "auto") != "gather" else 0
+            if w > 0:
+                n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+                n_groups = max(8, n_cu // (self.emb_dim // w) // 8 * 8)  # same row group -> same XCD
+                cap = int(lib.hiprec_sliced_row_cap(N, self.emb_dim))
+                for tag, rowptr, col, val, eid in (("", rp, c, v, None), ("_t", rpt, ct, vt, order_t)):
+                    host = sliced_graph_host(rowptr.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy(),
+                                             None if eid is None else eid.cpu().numpy(), n_groups, cap)
+                    if host is None:
+                        w = 0
+                        break
+                    self._graph["sliced" + tag] = sliced_graph_device(host, N, n_groups, cap, dev)
+                self._graph["n_groups"], self._graph["row_cap"] = n_groups, cap
+            self._graph["slice_w"] = w
         return self._graph
 
     def workspace(self):
@@ -108,6 +179,9 @@ class LightGCN(_FlatModel):
         # d_out + one output buffer per SpMM of a step, contiguous: the library clears them with one
         # fill per step (hiprec_lightgcn_plan.zero_ws) instead of one fill launch per SpMM
         self._ws["zero_ws"] = torch.zeros((1 + 2 * self.n_layers) * N * D, dtype=torch.float32, device=dev)
+        if g.get("slice_w", 0) > 0:
+            slots = g["sliced"][0].n_slots + g["sliced_t"][0].n_slots
+            self._ws["sliced_ws"] = torch.empty(4 * N * D + slots, dtype=torch.float32, device=dev)
         return self._ws
 
     def plan(self, g_flat=None, decay=0.0):
@@ -125,6 +199,11 @@ class LightGCN(_FlatModel):
         p.acc = ws["acc"].data_ptr()
         p.zero_ws = ws["zero_ws"].data_ptr()
         p.zero_ws_floats = ws["zero_ws"].numel()
+        if gr.get("slice_w", 0) > 0:
+            p.sa, p.sat = gr["sliced"][0], gr["sliced_t"][0]
+            p.slice_w = gr["slice_w"]
+            p.sliced_ws = ws["sliced_ws"].data_ptr()
+            p.sliced_ws_floats = ws["sliced_ws"].numel()
         return p
 
     def draw_keep_mask(self):

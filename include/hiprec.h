@@ -492,6 +492,43 @@ int hiprec_csr_slice_rows(const hiprec_csr* a, int32_t* out, int64_t n_out, void
 /* Everything one LightGCN step touches.  e0 / g are the flat parameter / gradient buffers
  * [user_embedding | item_embedding] = [(n_users + n_items), dim]; the rest is caller-owned
  * workspace of the same shape. */
+/* A graph stored for the column-sliced SpMM (n_rows < 65536).  Every row's edge list is padded to a multiple of 16
+ * SLOTS: col16 / val / eid hold n_slots entries (padding: col 0, val 0, eid -1; eid = the edge's index into the keep
+ * bytes of a step, i.e. its number in the FORWARD graph's CSR order).  Work items are chunks: at most 64 consecutive
+ * slots of one row, chunks[2 * c] = first slot (a multiple of 16), chunks[2 * c + 1] = row | n_slots_of_chunk << 16,
+ * sorted by row.  The rows are cut into n_groups * subs_per_group subgroups of consecutive rows and about equal
+ * chunk count: subgroup k covers rows sub_row[k] .. sub_row[k + 1] (sub_row[0] = 0, the last = n_rows; at most
+ * row_cap rows, so that their accumulators fit the LDS next to the slice: hiprec_sliced_row_cap) and chunks
+ * sub_chunk[k] .. sub_chunk[k + 1].  n_groups should be a multiple of 8 with (dim / slice width) * n_groups = the
+ * CU count.  beta-recsys_amd/lightgcn.py: sliced_graph_host builds it. */
+typedef struct hiprec_sliced_csr {
+  const int32_t* chunks;
+  const uint16_t* col16;
+  const float* val;
+  const int32_t* eid;
+  const int32_t* sub_row;
+  const int32_t* sub_chunk;
+  int64_t n_rows, n_slots;
+  int32_t n_groups, subs_per_group, n_chunks, row_cap;
+} hiprec_sliced_csr;
+
+/* slice width (floats) the sliced SpMM uses for n_rows x dim: 4 or 2, the largest that divides dim and lets one
+ * slice of the source matrix (n_rows x width x 4 B) fit the LDS; 0 = not applicable (use hiprec_spmm_csr) */
+int32_t hiprec_sliced_width(int64_t n_rows, int32_t dim);
+/* most rows a subgroup of hiprec_sliced_csr may hold at that width */
+int32_t hiprec_sliced_row_cap(int64_t n_rows, int32_t dim);
+/* row-major [n_rows][dim] <-> sliced [dim / slice_w][n_rows][slice_w] (add != 0: y += instead of y =) */
+int hiprec_to_sliced(const float* x, int64_t n_rows, int32_t dim, int32_t slice_w, float* xs, void* stream);
+int hiprec_from_sliced(const float* xs, int64_t n_rows, int32_t dim, int32_t slice_w, float* y, int32_t add,
+                       void* stream);
+/* out[slot] = keep[eid[slot]] ? val[slot] : 0 -- the dropped values of one step (n_slots floats), to be passed as
+ * `val` below; the 1 / keep_prob factor goes into `scale` */
+int hiprec_sliced_drop_values(const hiprec_sliced_csr* a, const uint8_t* keep, float* out, void* stream);
+/* ys = scale * A xs on SLICED buffers, val NULL = a->val; acc_mode 0: nothing else, 1: accs += ys, 2: accs = ys.
+ * Every row of ys is written (no zero fill needed). */
+int hiprec_spmm_sliced(const hiprec_sliced_csr* a, const float* val, float scale, const float* xs, float* ys,
+                       float* accs, int32_t acc_mode, int32_t dim, int32_t slice_w, void* stream);
+
 typedef struct hiprec_lightgcn_plan {
   hiprec_csr a;  /* forward graph  */
   hiprec_csr at; /* its transpose (backward) */
@@ -506,6 +543,13 @@ typedef struct hiprec_lightgcn_plan {
    * da / db are then unused. */
   float* zero_ws;
   int64_t zero_ws_floats;
+  /* Optional (graphs whose node count fits the LDS, hiprec_sliced_width(n_rows, dim) > 0): the same two graphs
+   * stored for the column-sliced SpMM and 4 * n_rows * dim + sa.n_slots + sat.n_slots floats of workspace; propagation then runs on
+   * sliced buffers (one transpose in, one out) and needs neither global atomics nor zero fills. */
+  hiprec_sliced_csr sa, sat;
+  int32_t slice_w, _pad2;
+  float* sliced_ws;
+  int64_t sliced_ws_floats;
 } hiprec_lightgcn_plan;
 
 size_t hiprec_lightgcn_plan_bytes(void);

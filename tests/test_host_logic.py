@@ -776,3 +776,59 @@ def test_batch_row_ownership_contract():
     _brute_force_ownership_check(users.numpy(), pos.numpy(), neg.numpy(), bs, U, I, own.numpy(), total.numpy())
     own0, total0, _ = batch_row_ownership_torch(users[:0], pos[:0], neg[:0], bs, U, I)
     assert own0.shape == (3, 0)
+
+
+@pytest.mark.parametrize("n,n_groups,cap,heavy", [(700, 16, 60, True), (9746, 16, 490, True), (50, 8, 128, False),
+                                                 (3000, 8, 100, False)])
+def test_sliced_graph_host_covers_every_edge_once(n, n_groups, cap, heavy):
+    """hiprec_sliced_csr as lightgcn.sliced_graph_host builds it: rows padded to 16 slots, every edge in exactly one
+    slot of one chunk of its row with its column / value / keep index, padding slots inert, chunks sorted by row,
+    subgroups = consecutive rows within the cap holding exactly their rows' chunks, empty rows (leading, interior,
+    trailing) inside some subgroup."""
+    from beta_recsys_amd.lightgcn import SLICED_CHUNK, SLICED_PAD, sliced_graph_host
+
+    rng = np.random.default_rng(n)
+    lens = rng.integers(0, 200, n)
+    lens[rng.random(n) < 0.2] = 0
+    lens[:3] = 0
+    lens[-5:] = 0
+    if heavy:
+        lens[7] = 5000
+    rowptr = np.concatenate([[0], np.cumsum(lens)])
+    nnz = int(rowptr[-1])
+    col = rng.integers(0, n, nnz)
+    val = rng.standard_normal(nnz).astype(np.float32)
+    eid = rng.permutation(nnz).astype(np.int64)
+    h = sliced_graph_host(rowptr, col, val, eid, n_groups, cap)
+    assert h is not None
+    chunks, k = h["chunks"], h["subs_per_group"]
+    start, row, clen = chunks[:, 0], chunks[:, 1] & 0xFFFF, chunks[:, 1] >> 16
+    assert np.all(clen >= SLICED_PAD) and np.all(clen <= SLICED_CHUNK) and np.all(np.diff(row) >= 0)
+    assert np.all(start % SLICED_PAD == 0) and np.all(clen % SLICED_PAD == 0) and h["n_slots"] % SLICED_PAD == 0
+    covered = np.zeros(h["n_slots"], dtype=np.int32)
+    slot_row = np.full(h["n_slots"], -1)
+    for s, r, c in zip(start, row, clen):
+        covered[s:s + c] += 1
+        slot_row[s:s + c] = r
+    assert np.all(covered == 1)
+    live = h["eid"] >= 0
+    assert live.sum() == nnz and np.all(h["val"][~live] == 0) and np.all(h["col16"][~live] == 0)
+    back = np.argsort(eid)  # edge whose keep index is j
+    edge_of_slot = back[h["eid"][live]]
+    assert np.array_equal(np.sort(edge_of_slot), np.arange(nnz))
+    assert np.array_equal(h["col16"][live], col[edge_of_slot].astype(np.uint16))
+    assert np.array_equal(h["val"][live], val[edge_of_slot])
+    assert np.array_equal(slot_row[live], np.repeat(np.arange(n), lens)[edge_of_slot])
+    plain = sliced_graph_host(rowptr, col, val, None, n_groups, cap)
+    assert np.array_equal(plain["eid"][live], np.arange(nnz))
+    sub_row, sub_chunk = h["sub_row"], h["sub_chunk"]
+    assert sub_row.size == n_groups * k + 1 and sub_row[0] == 0 and sub_row[-1] == n
+    assert sub_chunk[0] == 0 and sub_chunk[-1] == h["n_chunks"] == chunks.shape[0]
+    assert np.all(np.diff(sub_row) >= 0) and np.diff(sub_row).max() <= cap
+    for i in range(n_groups * k):
+        rows_of = row[sub_chunk[i]:sub_chunk[i + 1]]
+        assert np.all((rows_of >= sub_row[i]) & (rows_of < sub_row[i + 1]))
+    assert sliced_graph_host(rowptr, col, val, None, 1, 1, max_subs=4) is None
+    empty = sliced_graph_host(np.zeros(11, dtype=np.int64), col[:0], val[:0], None, 8, 16)
+    assert empty["n_chunks"] == 0 and empty["n_slots"] == 0 and empty["sub_row"][-1] == 10
+    assert np.all(empty["sub_chunk"] == 0)
