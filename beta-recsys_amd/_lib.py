@@ -98,7 +98,7 @@ class LightGcnPlan(Structure):
                 ("dim", c_int32), ("n_layers", c_int32), ("decay", c_float), ("_pad", c_int32)] + \
                [(n, c_void_p) for n in ("e0", "g", "xa", "xb", "acc", "da", "db", "zero_ws")] + \
                [("zero_ws_floats", c_int64), ("sa", SlicedCsr), ("sat", SlicedCsr), ("slice_w", c_int32),
-                ("_pad2", c_int32), ("sliced_ws", c_void_p), ("sliced_ws_floats", c_int64)]
+                ("dropped_ready", c_int32), ("sliced_ws", c_void_p), ("sliced_ws_floats", c_int64)]
 
 
 class PgmfTables(Structure):
@@ -213,6 +213,8 @@ SIGNATURES = {
     "hiprec_sliced_drop_values": (c_int, [POINTER(SlicedCsr), _P, _P, _P]),
     "hiprec_spmm_sliced": (c_int, [POINTER(SlicedCsr), _P, c_float, _P, _P, _P, c_int32, c_int32, c_int32, _P]),
     "hiprec_edge_dropout_mask": (c_int, [_P, c_int64, c_float, ctypes.c_uint64, ctypes.c_uint64, _P]),
+    "hiprec_lightgcn_step_values": (c_int, [POINTER(LightGcnPlan), _P, c_float, c_int32, ctypes.c_uint64,
+                                            ctypes.c_uint64, _P]),
     "hiprec_lightgcn_propagate": (c_int, [POINTER(LightGcnPlan), _P, c_float, _P]),
     "hiprec_lightgcn_predict": (c_int, [POINTER(LightGcnPlan), _P, _P, c_int64, _P, _P, _P]),
     "hiprec_lightgcn_grad": (

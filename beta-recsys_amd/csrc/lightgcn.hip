@@ -146,12 +146,22 @@ __global__ __launch_bounds__(kBlock) void edge_dropout_kernel(uint8_t* __restric
 // the gradient w.r.t. the propagated embeddings.  One wave per triple.  `acc` holds the SUM over
 // layers (out = acc / (L+1)).  d_out contributions go to `d` (input of the backward propagation)
 // AND to `g` (its l = 0 term); the L2 gradient goes to `g` only.
+// SLICED: the propagated sums are read from, and d_out is scattered into, the sliced layout [D / W][N][W] of the
+// column-sliced SpMM (p.acc / p.da then point at sliced buffers): no transposes around the loss.
+template <bool SLICED>
 __global__ __launch_bounds__(kBlock) void lightgcn_loss_kernel(
     hiprec_lightgcn_plan p, const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
     const int64_t* __restrict__ neg, int64_t batch, float inv_batch, hiprec_stats* stats,
     Scratch* scratch) {
   const int lane = lane_id();
   const int D = p.dim;
+  const int w_shift = p.slice_w == 4 ? 2 : 1;
+  const int64_t n_rows = p.a.n_rows;
+  // offset of (row-major offset r = row * D, column c) in the layout of acc / da
+  auto at = [&](int64_t r, int c) -> int64_t {
+    if (!SLICED) return r + c;
+    return ((static_cast<int64_t>(c >> w_shift) * n_rows + r / D) << w_shift) + (c & ((1 << w_shift) - 1));
+  };
   const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
   const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
   const float inv_l = 1.0f / static_cast<float>(p.n_layers + 1);
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void lightgcn_loss_kernel(
     const int64_t ru = u * D, rp = (p.n_users + i) * D, rn = (p.n_users + j) * D;
     float dp = 0.f, dn = 0.f;
     for (int c = lane; c < D; c += kWave) {
-      const float ue = p.acc[ru + c] * inv_l, pe = p.acc[rp + c] * inv_l, ne = p.acc[rn + c] * inv_l;
+      const float ue = p.acc[at(ru, c)] * inv_l, pe = p.acc[at(rp, c)] * inv_l, ne = p.acc[at(rn, c)] * inv_l;
       dp += ue * pe;
       dn += ue * ne;
       const float u0 = p.e0[ru + c], p0 = p.e0[rp + c], n0 = p.e0[rn + c];
@@ -184,11 +194,11 @@ __global__ __launch_bounds__(kBlock) void lightgcn_loss_kernel(
     const float dx = sigmoid_f32(xx) * inv_batch * inv_l;  // d mf / d x, pre-scaled by 1/(L+1)
     const float cr = p.decay * inv_batch;                   // d reg / d row = decay * row / B
     for (int c = lane; c < D; c += kWave) {
-      const float ue = p.acc[ru + c] * inv_l, pe = p.acc[rp + c] * inv_l, ne = p.acc[rn + c] * inv_l;
+      const float ue = p.acc[at(ru, c)] * inv_l, pe = p.acc[at(rp, c)] * inv_l, ne = p.acc[at(rn, c)] * inv_l;
       const float gu = dx * (ne - pe), gp = -dx * ue, gn = dx * ue;
-      atomic_add_f32(p.da + ru + c, gu);
-      atomic_add_f32(p.da + rp + c, gp);
-      atomic_add_f32(p.da + rn + c, gn);
+      atomic_add_f32(p.da + at(ru, c), gu);
+      atomic_add_f32(p.da + at(rp, c), gp);
+      atomic_add_f32(p.da + at(rn, c), gn);
       atomic_add_f32(p.g + ru + c, gu + cr * p.e0[ru + c]);
       atomic_add_f32(p.g + rp + c, gp + cr * p.e0[rp + c]);
       atomic_add_f32(p.g + rn + c, gn + cr * p.e0[rn + c]);
@@ -298,7 +308,8 @@ static float* sliced_buf(const hiprec_lightgcn_plan* p, int k) {
   return p->sliced_ws + static_cast<int64_t>(k) * p->a.n_rows * p->dim;
 }
 
-// out (row-major) = [add] sum_{l = first .. L} G^l in, G = `graph`; the l = 0 term only when `with_input`
+// out (row-major) = [add] sum_{l = first .. L} G^l in, G = `graph`; the l = 0 term only when `with_input`.
+// in NULL: the input is already in sliced buffer 0; out NULL: the result stays in sliced buffer 1.
 static int propagate_sliced(const hiprec_lightgcn_plan* p, const hiprec_sliced_csr* graph, const uint8_t* keep,
                             float keep_prob, const float* in, float* out, bool with_input, bool add,
                             hipStream_t st) {
@@ -307,11 +318,17 @@ static int propagate_sliced(const hiprec_lightgcn_plan* p, const hiprec_sliced_c
   const float scale = keep ? 1.0f / keep_prob : 1.0f;
   float* xs0 = sliced_buf(p, 0);
   float* accs = sliced_buf(p, 1);
-  if (int rc = launch_to_sliced(in, N, D, W, xs0, with_input ? accs : nullptr, st)) return rc;
+  if (in != nullptr) {
+    if (int rc = launch_to_sliced(in, N, D, W, xs0, with_input ? accs : nullptr, st)) return rc;
+  }
   const float* val = nullptr;
   if (keep && p->n_layers > 0) {  // once per step and graph, not per pass
     float* dropped = sliced_buf(p, 4) + (graph == &p->sat ? p->sa.n_slots : 0);
-    if (int rc = launch_drop_values(graph, keep, dropped, st)) return rc;
+    if (!p->dropped_ready) {
+      if (int rc = launch_step_values(graph, nullptr, const_cast<uint8_t*>(keep), false, keep_prob, 0, 0, dropped,
+                                      nullptr, st))
+        return rc;
+    }
     val = dropped;
   }
   const float* cur = xs0;
@@ -321,7 +338,7 @@ static int propagate_sliced(const hiprec_lightgcn_plan* p, const hiprec_sliced_c
     if (int rc = launch_spmm_sliced(graph, val, scale, cur, nxt, accs, mode, D, W, st)) return rc;
     cur = nxt;
   }
-  if (p->n_layers == 0 && !with_input) return 0;
+  if (out == nullptr || (p->n_layers == 0 && !with_input)) return 0;
   return launch_from_sliced(accs, N, D, W, out, add, st);
 }
 
@@ -383,6 +400,15 @@ extern "C" int hiprec_edge_dropout_mask(uint8_t* keep, int64_t nnz, float keep_p
   return 0;
 }
 
+extern "C" int hiprec_lightgcn_step_values(const hiprec_lightgcn_plan* plan, uint8_t* keep, float keep_prob,
+                                           int32_t draw, uint64_t seed, uint64_t step, void* stream) {
+  if (int rc = check_lg_plan(plan, false)) return rc;
+  HIPREC_REQUIRE(use_sliced(plan), "the plan has no sliced graphs");
+  HIPREC_REQUIRE(plan->sat.n_rows == plan->a.n_rows && plan->sat.eid, "the plan has no transposed sliced graph");
+  return launch_step_values(&plan->sa, &plan->sat, keep, draw != 0, keep_prob, seed, step, sliced_buf(plan, 4),
+                            sliced_buf(plan, 4) + plan->sa.n_slots, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int hiprec_lightgcn_propagate(const hiprec_lightgcn_plan* plan, const uint8_t* keep,
                                          float keep_prob, void* stream) {
   if (int rc = check_lg_plan(plan, false)) return rc;
@@ -417,20 +443,30 @@ extern "C" int hiprec_lightgcn_grad(const hiprec_lightgcn_plan* plan, const uint
   const size_t bytes = sizeof(float) * p->a.n_rows * p->dim;
   const bool ws = p->zero_ws != nullptr;
   hiprec_lightgcn_plan q = *p;  // d_out may live in the workspace
-  const bool sliced = use_sliced(p);
+  if (use_sliced(p)) {
+    // everything between E0 and g stays in the sliced layout: E0 -> sliced, L passes, the loss kernel reads the
+    // sliced layer sum and scatters d_out into sliced buffer 0 (free again after the first pass), L passes of the
+    // transposed graph, and one transpose adds the result to g.  No output fills: the SpMM writes every row.
+    if (int rc = propagate_sliced(p, &p->sa, keep, keep_prob, p->e0, nullptr, true, false, st)) return rc;
+    HIPREC_TRY(hipMemsetAsync(sliced_buf(p, 0), 0, bytes, st));
+    q.acc = sliced_buf(p, 1);
+    q.da = sliced_buf(p, 0);
+    lightgcn_loss_kernel<true><<<grid_for_waves(batch), kBlock, 0, st>>>(q, users, pos, neg, batch, inv_batch, stats,
+                                                                        static_cast<Scratch*>(scratch));
+    HIPREC_TRY(hipGetLastError());
+    return propagate_sliced(p, &p->sat, keep, keep_prob, nullptr, p->g, false, true, st);
+  }
   if (ws) {
-    // ONE fill for d_out and every layer output of the step (it was 7 launches of ~5 us each); the sliced SpMM
-    // writes every output row itself: only d_out (the loss kernel scatters into it) has to be clear
-    HIPREC_TRY(hipMemsetAsync(p->zero_ws, 0, sliced ? bytes : bytes * (1 + 2 * static_cast<size_t>(p->n_layers)), st));
+    // ONE fill for d_out and every layer output of the step (it was 7 launches of ~5 us each)
+    HIPREC_TRY(hipMemsetAsync(p->zero_ws, 0, bytes * (1 + 2 * static_cast<size_t>(p->n_layers)), st));
     q.da = ws_slice(p, 0);
   }
   if (int rc = propagate(p, keep, keep_prob, st, /*ws_zeroed=*/ws)) return rc;
   if (!ws) HIPREC_TRY(hipMemsetAsync(q.da, 0, bytes, st));
-  lightgcn_loss_kernel<<<grid_for_waves(batch), kBlock, 0, st>>>(
+  lightgcn_loss_kernel<false><<<grid_for_waves(batch), kBlock, 0, st>>>(
       q, users, pos, neg, batch, inv_batch, stats, static_cast<Scratch*>(scratch));
   HIPREC_TRY(hipGetLastError());
   // g = sum_{l=0..L} (A^T)^l d_out : the l = 0 term is already in g
-  if (sliced) return propagate_sliced(p, &p->sat, keep, keep_prob, q.da, p->g, false, true, st);
   const float scale = keep ? 1.0f / keep_prob : 1.0f;
   float* cur = q.da;
   float* nxt = p->db;

@@ -25,6 +25,7 @@
 // switch is a chain of dependent loads and the four groups of a wave serialise theirs); 16 lanes per 64-edge chunk,
 // strided scalar loads, 16 DPP adds per chunk 47 us (VALU: ~180 instructions per 512 edges).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.hpp"
 #include "spmm.hpp"
@@ -35,6 +36,15 @@ constexpr int kSlicedThreads = 1024;
 constexpr int kSlicedQuads = kSlicedThreads / 4;
 constexpr int64_t kSlicedLds = 160 * 1024 - 64;  // one workgroup's LDS, less the kernel's own few words
 constexpr int kSlicedMinRowCap = 128;            // accumulator rows a subgroup must at least be able to hold
+constexpr int kSlicedFill = (kSlicedLds / 16 + kSlicedThreads - 1) / kSlicedThreads;  // float4 per thread of a slice
+constexpr int kSlicedMaxRowCap = 512;            // ... and at most: 2 output floats per thread at W = 4
+
+template <int W>
+struct SlicedVec;
+template <>
+struct SlicedVec<4> { using type = float4; };
+template <>
+struct SlicedVec<2> { using type = float2; };
 
 struct SlicedEdges {  // the 16 slots of one lane
   uint4 c[2];
@@ -66,46 +76,97 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
                                                                      const float* __restrict__ val, float scale,
                                                                      const float* __restrict__ xs,
                                                                      float* __restrict__ ys, float* __restrict__ accs,
-                                                                     int acc_mode) {
+                                                                     int acc_mode, int dbg) {
+  using Vec = typename SlicedVec<W>::type;
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
   const int64_t n_rows = a.n_rows;
   float* s_x = s_mem;               // [n_rows][W]: slice s of the source
-  float* s_y = s_mem + n_rows * W;  // [rows of the subgroup][W]
+  float* s_y = s_mem + n_rows * W;  // [row_cap][W]: accumulators of the current subgroup's rows
   const int s = static_cast<int>(blockIdx.x) / a.n_groups, g = static_cast<int>(blockIdx.x) % a.n_groups;
   const int64_t slice_off = static_cast<int64_t>(s) * n_rows * W;
-  {
-    const float* x = xs + slice_off;
-    const int64_t n_f = n_rows * W, n4 = n_f >> 2;
-    for (int64_t i = threadIdx.x; i < n4; i += kSlicedThreads)
-      reinterpret_cast<float4*>(s_x)[i] = reinterpret_cast<const float4*>(x)[i];
-    for (int64_t i = (n4 << 2) + threadIdx.x; i < n_f; i += kSlicedThreads) s_x[i] = x[i];
-  }
   const int quad = static_cast<int>(threadIdx.x) >> 2, q = static_cast<int>(threadIdx.x) & 3;
   const int2* __restrict__ chunks = reinterpret_cast<const int2*>(a.chunks);
-  auto desc = [&](int c, int c1) { return c < c1 ? chunks[c] : int2{0, 0}; };  // {first slot, row | n_slots << 16}
-  for (int sg = g * a.subs_per_group; sg < (g + 1) * a.subs_per_group; ++sg) {
-    const int r0 = a.sub_row[sg], r1 = a.sub_row[sg + 1], c0 = a.sub_chunk[sg], c1 = a.sub_chunk[sg + 1];
+  long long ts[12];
+  int n_ts = 0;
+  auto stamp = [&]() {
+    if (dbg == 9 && n_ts < 12) ts[n_ts++] = wall_clock64();
+  };
+  stamp();
+  const int sg_begin = g * a.subs_per_group, sg_end = sg_begin + a.subs_per_group;
+  const int c_end = a.sub_chunk[sg_end];  // the block's chunks: sub_chunk[sg_begin] .. c_end
+  auto desc = [&](int c) { return c < c_end ? chunks[c] : int2{0, 0}; };  // {first slot, row | n_slots << 16}
+  // The chunk pipeline runs through the block's subgroups without draining: quad k takes chunks k, k + 256, ...
+  // of the block; descriptors are two chunks ahead of the arithmetic, edge data one.
+  // the slice: every thread's (at most kSlicedFill) 16-byte loads are issued together -- a load-store loop would pay
+  // the memory latency once per trip
+  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xs + slice_off);
+  const int n4 = static_cast<int>((n_rows * W) >> 2), n_tail = static_cast<int>((n_rows * W) & 3);  // (W = 2, odd n)
+  float4 fill[kSlicedFill];
+#pragma unroll
+  for (int k = 0; k < kSlicedFill; ++k) {
+    const int i = static_cast<int>(threadIdx.x) + k * kSlicedThreads;
+    fill[k] = i < n4 ? x4[i] : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  int c = a.sub_chunk[sg_begin] + quad;
+  int2 d0 = desc(c), d1 = desc(c + kSlicedQuads);
+#pragma unroll
+  for (int k = 0; k < kSlicedFill; ++k) {
+    const int i = static_cast<int>(threadIdx.x) + k * kSlicedThreads;
+    if (i < n4) reinterpret_cast<float4*>(s_x)[i] = fill[k];
+  }
+  if (static_cast<int>(threadIdx.x) < n_tail) s_x[4 * n4 + threadIdx.x] = xs[slice_off + 4 * n4 + threadIdx.x];
+  stamp();
+  SlicedEdges e0 = load_sliced_edges(a.col16, val, d0, q);
+  const int n_acc = a.row_cap * W;  // <= kSlicedMaxRowCap * 4 = 2 per thread
+  for (int i = threadIdx.x; i < n_acc; i += kSlicedThreads) s_y[i] = 0.f;
+  __syncthreads();
+  stamp();
+  for (int sg = sg_begin; sg < sg_end; ++sg) {
+    const int r0 = a.sub_row[sg], r1 = a.sub_row[sg + 1], c1 = a.sub_chunk[sg + 1];
     const int n_out = (r1 - r0) * W;
-    for (int i = threadIdx.x; i < n_out; i += kSlicedThreads) s_y[i] = 0.f;
-    __syncthreads();  // (the first one also publishes the slice)
-    int c = c0 + quad;
-    int2 d = desc(c, c1), d_next = desc(c + kSlicedQuads, c1);
-    SlicedEdges e = load_sliced_edges(a.col16, val, d, q);
+    const int64_t out0 = slice_off + static_cast<int64_t>(r0) * W;
+    float old[2] = {0.f, 0.f};  // the layer sum's current values, fetched while the chunks are processed
+    if (acc_mode == 1) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = static_cast<int>(threadIdx.x) + k * kSlicedThreads;
+        if (i < n_out) old[k] = accs[out0 + i];
+      }
+    }
     while (c < c1) {
-      const int2 d_after = desc(c + 2 * kSlicedQuads, c1);
-      const SlicedEdges e_next = load_sliced_edges(a.col16, val, d_next, q);
+      const int2 d2 = desc(c + 2 * kSlicedQuads);
+      const SlicedEdges e1 = load_sliced_edges(a.col16, val, d1, q);
+      // 16 random source rows out of the LDS (~3-way bank conflicts: the kernel's floor): addresses first, then
+      // reads four at a time with eight in flight while the previous four are multiplied -- left alone the compiler
+      // keeps two reads in flight and waits for each
+      const uint32_t cw[8] = {e0.c[0].x, e0.c[0].y, e0.c[0].z, e0.c[0].w, e0.c[1].x, e0.c[1].y, e0.c[1].z, e0.c[1].w};
+      const float vv[16] = {e0.v[0].x, e0.v[0].y, e0.v[0].z, e0.v[0].w, e0.v[1].x, e0.v[1].y, e0.v[1].z, e0.v[1].w,
+                            e0.v[2].x, e0.v[2].y, e0.v[2].z, e0.v[2].w, e0.v[3].x, e0.v[3].y, e0.v[3].z, e0.v[3].w};
+      const Vec* __restrict__ s_rows = reinterpret_cast<const Vec*>(s_x);
+      uint32_t col[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) col[j] = (j & 1) ? (cw[j >> 1] >> 16) : (cw[j >> 1] & 0xFFFFu);
+      Vec src[2][4];
       float acc[W];
 #pragma unroll
       for (int w = 0; w < W; ++w) acc[w] = 0.f;
-      const uint32_t cw[8] = {e.c[0].x, e.c[0].y, e.c[0].z, e.c[0].w, e.c[1].x, e.c[1].y, e.c[1].z, e.c[1].w};
-      const float vv[16] = {e.v[0].x, e.v[0].y, e.v[0].z, e.v[0].w, e.v[1].x, e.v[1].y, e.v[1].z, e.v[1].w,
-                            e.v[2].x, e.v[2].y, e.v[2].z, e.v[2].w, e.v[3].x, e.v[3].y, e.v[3].z, e.v[3].w};
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const uint32_t col = (j & 1) ? (cw[j >> 1] >> 16) : (cw[j >> 1] & 0xFFFFu);
-        const float* src = s_x + col * W;
+      for (int j = 0; j < 4; ++j) src[0][j] = s_rows[col[j]];
 #pragma unroll
-        for (int w = 0; w < W; ++w) acc[w] += vv[j] * src[w];
+      for (int b = 0; b < 4; ++b) {
+        if (b < 3) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) src[(b + 1) & 1][j] = s_rows[col[4 * (b + 1) + j]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float* f = reinterpret_cast<const float*>(&src[b & 1][j]);
+#pragma unroll
+          for (int w = 0; w < W; ++w) acc[w] += vv[4 * b + j] * f[w];
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       float mine = 0.f;  // lane q < W of the quad adds component q
 #pragma unroll
@@ -114,34 +175,60 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
         t = dpp_add<0x4E>(t);             // quad_perm [2,3,0,1]
         mine = q == w ? t : mine;
       }
-      if (q < W && (d.y >> 16) > 0) lds_add_f32(&s_y[((d.y & 0xFFFF) - r0) * W + q], mine);
+      if (q < W && (d0.y >> 16) > 0) lds_add_f32(&s_y[((d0.y & 0xFFFF) - r0) * W + q], mine);
       c += kSlicedQuads;
-      d = d_next;
-      d_next = d_after;
-      e = e_next;
+      d0 = d1;
+      d1 = d2;
+      e0 = e1;
+    }
+    stamp();
+    __syncthreads();
+    stamp();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = static_cast<int>(threadIdx.x) + k * kSlicedThreads;
+      if (i < n_out) {
+        const float y = s_y[i] * scale;
+        s_y[i] = 0.f;
+        ys[out0 + i] = y;
+        if (acc_mode == 1) accs[out0 + i] = old[k] + y;
+        else if (acc_mode == 2) accs[out0 + i] = y;
+      }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n_out; i += kSlicedThreads) {
-      const float y = s_y[i] * scale;
-      const int64_t o = slice_off + static_cast<int64_t>(r0) * W + i;
-      ys[o] = y;
-      if (acc_mode == 1) accs[o] += y;
-      else if (acc_mode == 2) accs[o] = y;
-    }
-    __syncthreads();
+    stamp();
+  }
+  if (dbg == 9 && (threadIdx.x == 0 || threadIdx.x == 1023) && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 255)) {
+    float* out = ys + (blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 32 : 64) + (threadIdx.x ? 16 : 0);
+    for (int k = 0; k < n_ts; ++k) out[k] = static_cast<float>(ts[k] - ts[0]) * 0.01f;  // us at 100 MHz
+    out[n_ts] = -1.f;
   }
 }
 
 // out[slot] = keep[eid[slot]] ? val[slot] : 0 (padding slots: eid < 0, value 0) -- the dropped edge values of a
-// step in the sliced graph's slot order, so that no pass looks at keep bytes
-__global__ __launch_bounds__(kBlock) void drop_values_kernel(const float* __restrict__ val,
-                                                             const int32_t* __restrict__ eid,
-                                                             const uint8_t* __restrict__ keep, int64_t n_slots,
-                                                             float* __restrict__ out) {
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
-  for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < n_slots; e += stride) {
-    const int32_t k = eid[e];
-    out[e] = (k >= 0 && keep[k]) ? val[e] : 0.f;
+// step in the sliced graph's slot order, so that no pass looks at keep bytes.  One launch serves both graphs of a
+// plan (slots of `a`, then slots of `b`); with `draw` the keep decision is the counter-based device draw itself
+// (the same function of (seed, step, edge) in both graphs) and `a`'s slots publish it to keep[] when that is given.
+__global__ __launch_bounds__(kBlock) void step_values_kernel(hiprec_sliced_csr a, hiprec_sliced_csr b,
+                                                             uint8_t* __restrict__ keep, int draw, float keep_prob,
+                                                             uint64_t seed, uint64_t step, float* __restrict__ out_a,
+                                                             float* __restrict__ out_b) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock, total = a.n_slots + b.n_slots;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += stride) {
+    const bool first = i < a.n_slots;
+    const int64_t e = first ? i : i - a.n_slots;
+    const int32_t k = first ? a.eid[e] : b.eid[e];
+    const float v = first ? a.val[e] : b.val[e];
+    bool kept = false;
+    if (k >= 0) {
+      if (draw) {
+        kept = keep_draw(seed, step, k, keep_prob);
+        if (first && keep != nullptr) keep[k] = kept ? 1 : 0;
+      } else {
+        kept = keep[k] != 0;
+      }
+    }
+    (first ? out_a : out_b)[e] = kept ? v : 0.f;
   }
 }
 
@@ -186,7 +273,7 @@ int sliced_width(int64_t n_rows, int dim) {
 int sliced_row_cap(int64_t n_rows, int dim) {
   const int w = sliced_width(n_rows, dim);
   if (w == 0) return 0;
-  return static_cast<int>(std::min<int64_t>(kSlicedLds / (w * sizeof(float)) - n_rows, n_rows));
+  return static_cast<int>(std::min<int64_t>(kSlicedLds / (w * sizeof(float)) - n_rows, kSlicedMaxRowCap));
 }
 
 int launch_spmm_sliced(const hiprec_sliced_csr* a, const float* val, float scale, const float* xs, float* ys,
@@ -210,19 +297,26 @@ int launch_spmm_sliced(const hiprec_sliced_csr* a, const float* val, float scale
     attr_set = true;
   }
   if (val == nullptr) val = a->val;
+  static const int dbg = getenv("HIPREC_SLICED_DBG") ? atoi(getenv("HIPREC_SLICED_DBG")) : 0;  // timing experiments
   const int grid = (dim / W) * a->n_groups;
   if (W == 4)
-    spmm_sliced_kernel<4><<<grid, kSlicedThreads, lds, st>>>(*a, val, scale, xs, ys, accs, acc_mode);
+    spmm_sliced_kernel<4><<<grid, kSlicedThreads, lds, st>>>(*a, val, scale, xs, ys, accs, acc_mode, dbg);
   else
-    spmm_sliced_kernel<2><<<grid, kSlicedThreads, lds, st>>>(*a, val, scale, xs, ys, accs, acc_mode);
+    spmm_sliced_kernel<2><<<grid, kSlicedThreads, lds, st>>>(*a, val, scale, xs, ys, accs, acc_mode, dbg);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
 
-int launch_drop_values(const hiprec_sliced_csr* a, const uint8_t* keep, float* out, hipStream_t st) {
-  HIPREC_REQUIRE(a && keep && out && (a->n_slots == 0 || (a->val && a->eid)), "bad arguments");
-  if (a->n_slots == 0) return 0;
-  drop_values_kernel<<<grid_for_threads(a->n_slots), kBlock, 0, st>>>(a->val, a->eid, keep, a->n_slots, out);
+int launch_step_values(const hiprec_sliced_csr* a, const hiprec_sliced_csr* b, uint8_t* keep, bool draw,
+                       float keep_prob, uint64_t seed, uint64_t step, float* out_a, float* out_b, hipStream_t st) {
+  hiprec_sliced_csr none = {};
+  if (b == nullptr) b = &none;
+  HIPREC_REQUIRE(a && out_a && (a->n_slots == 0 || (a->val && a->eid)), "bad sliced graph");
+  HIPREC_REQUIRE(b->n_slots == 0 || (b->val && b->eid && out_b), "bad second sliced graph");
+  HIPREC_REQUIRE(draw || keep, "keep bytes needed");
+  if (a->n_slots + b->n_slots == 0) return 0;
+  step_values_kernel<<<grid_for_threads(a->n_slots + b->n_slots), kBlock, 0, st>>>(*a, *b, keep, draw ? 1 : 0, keep_prob,
+                                                                                   seed, step, out_a, out_b);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
@@ -260,7 +354,8 @@ extern "C" int hiprec_from_sliced(const float* xs, int64_t n_rows, int32_t dim, 
 }
 
 extern "C" int hiprec_sliced_drop_values(const hiprec_sliced_csr* a, const uint8_t* keep, float* out, void* stream) {
-  return launch_drop_values(a, keep, out, static_cast<hipStream_t>(stream));
+  return launch_step_values(a, nullptr, const_cast<uint8_t*>(keep), false, 1.f, 0, 0, out, nullptr,
+                            static_cast<hipStream_t>(stream));
 }
 
 extern "C" int hiprec_spmm_sliced(const hiprec_sliced_csr* a, const float* val, float scale, const float* xs,

@@ -202,28 +202,38 @@ class LightGCN(_FlatModel):
         if gr.get("slice_w", 0) > 0:
             p.sa, p.sat = gr["sliced"][0], gr["sliced_t"][0]
             p.slice_w = gr["slice_w"]
+            p.dropped_ready = 1 if getattr(self, "_dropped_ready", False) else 0
             p.sliced_ws = ws["sliced_ws"].data_ptr()
             p.sliced_ws_floats = ws["sliced_ws"].numel()
         return p
 
     def draw_keep_mask(self):
         """Edge keep bytes of one training step (None in eval mode)."""
+        self._dropped_ready = False
         if not self.training:
             return None
         lib = self._require_hip()
         ws, gr = self.workspace(), self.graph()
         keep_prob = float(self.config["keep_pro"])
         self._step += 1
+        st = _lib.stream_ptr(self._flat.device)
+        sliced = gr.get("slice_w", 0) > 0  # then the step's dropped edge values are prepared here, in one launch
         if self.dropout_rng == "torch_cpu":
             # lightgcn.py:32-33: (torch.rand(len(values)) + keep_prob).int().bool()
             mask = (torch.rand(gr["nnz"]) + keep_prob).int().bool()
             ws["keep"][: gr["nnz"]].copy_(mask.to(torch.uint8), non_blocking=False)
         elif self.dropout_rng == "device":
-            _lib.check(lib.hiprec_edge_dropout_mask(
-                _lib.ptr(ws["keep"]), gr["nnz"], keep_prob, self.dropout_seed, self._step,
-                _lib.stream_ptr(self._flat.device)))
+            if not sliced:
+                _lib.check(lib.hiprec_edge_dropout_mask(_lib.ptr(ws["keep"]), gr["nnz"], keep_prob, self.dropout_seed,
+                                                        self._step, st))
         else:
             raise ValueError(f"unknown dropout_rng {self.dropout_rng!r}: 'torch_cpu' or 'device'")
+        if sliced:
+            plan = self.plan()
+            _lib.check(lib.hiprec_lightgcn_step_values(ctypes.byref(plan), _lib.ptr(ws["keep"]), keep_prob,
+                                                       1 if self.dropout_rng == "device" else 0, self.dropout_seed,
+                                                       self._step, st))
+            self._dropped_ready = True
         return ws["keep"]
 
     # ---- reference API ---------------------------------------------------------------------

@@ -547,7 +547,8 @@ typedef struct hiprec_lightgcn_plan {
    * stored for the column-sliced SpMM and 4 * n_rows * dim + sa.n_slots + sat.n_slots floats of workspace; propagation then runs on
    * sliced buffers (one transpose in, one out) and needs neither global atomics nor zero fills. */
   hiprec_sliced_csr sa, sat;
-  int32_t slice_w, _pad2;
+  int32_t slice_w;
+  int32_t dropped_ready; /* != 0: sliced_ws already holds this step's dropped values (hiprec_lightgcn_step_values) */
   float* sliced_ws;
   int64_t sliced_ws_floats;
 } hiprec_lightgcn_plan;
@@ -563,6 +564,13 @@ int hiprec_spmm_csr(const hiprec_csr* a, const uint8_t* keep, float scale, const
  * fast alternative to drawing torch.rand(nnz) on the CPU every step as lightgcn.py:32 does. */
 int hiprec_edge_dropout_mask(uint8_t* keep, int64_t nnz, float keep_prob, uint64_t seed,
                              uint64_t step, void* stream);
+
+/* ---- (sliced plans) the dropped edge values of one training step for both graphs, into plan->sliced_ws, in ONE
+ * launch: draw != 0 draws the mask on the device (the draw of hiprec_edge_dropout_mask for the same seed / step;
+ * written to keep[nnz] as well when keep is not NULL), draw == 0 reads keep[].  Set plan->dropped_ready for the
+ * propagate / grad calls of that step; without it they prepare the values themselves, one launch per graph. */
+int hiprec_lightgcn_step_values(const hiprec_lightgcn_plan* plan, uint8_t* keep, float keep_prob, int32_t draw,
+                                uint64_t seed, uint64_t step, void* stream);
 
 /* ---- LightGCN.forward (lightgcn.py:46-78): plan->acc = sum_l A^l E0 (propagated = acc/(L+1)). */
 int hiprec_lightgcn_propagate(const hiprec_lightgcn_plan* plan, const uint8_t* keep, float keep_prob,

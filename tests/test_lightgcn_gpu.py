@@ -98,7 +98,7 @@ def sliced_graph(rp, col, val, eid, n, nnz, dim, n_groups):
 
 
 @pytest.mark.parametrize("n,dim,width,n_groups", [(700, 64, 4, 16), (9746, 64, 4, 16), (10100, 100, 4, 3),
-                                                  (15000, 32, 2, 7), (19000, 8, 2, 1), (500, 6, 2, 40)])
+                                                  (15001, 32, 2, 7), (19000, 8, 2, 1), (500, 6, 2, 40)])
 def test_spmm_sliced_vs_scipy(hip_device, n, dim, width, n_groups):
     """The column-sliced SpMM (source slice in LDS, rows owned by one workgroup): forward graph and transposed graph
     with the forward keep bytes, heavy and empty rows, every accumulate mode, the layout transposes."""

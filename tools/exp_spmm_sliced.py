@@ -1,0 +1,57 @@
+"""column-sliced SpMM against the L2 row-gather SpMM on the BASELINE configs[4] graph (forward and transposed),
+with the kernel's debug variants (HIPREC_SLICED_DBG: 1 = no LDS source reads, 2 = no edge loads)"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, scipy.sparse as sp, torch
+from beta_recsys_amd import _lib
+from beta_recsys_amd.lightgcn import _csr_from_coo, _slice_rows, sliced_graph_device, sliced_graph_host
+from oracle import lightgcn_numpy as olg
+
+U, I, D = 6040, 3706, 64
+rng = np.random.default_rng(0)
+n_edges = 1_000_000
+p = 1.0 / np.arange(1, I + 1) ** 0.9
+eu = rng.integers(0, U, n_edges)
+ei = rng.permutation(I)[rng.choice(I, n_edges, p=p / p.sum())]
+N = U + I
+adj = olg.build_norm_adj(U, I, eu, ei).tocoo()
+lib = _lib.load()
+dev = torch.device("cuda:0")
+st = _lib.stream_ptr(dev)
+r, c, v = (torch.from_numpy(x) for x in (adj.row.astype(np.int64), adj.col.astype(np.int64), adj.data.astype(np.float32)))
+rp, cc, vv, _ = _csr_from_coo(r, c, v, N, dev)
+nnz = adj.nnz
+x = torch.randn(N, D, device=dev)
+y = torch.zeros(N, D, device=dev)
+acc = torch.zeros(N, D, device=dev)
+
+
+def timed(fn, n=100):
+    for _ in range(5):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+sl = _slice_rows(rp, cc, vv, N, nnz)
+csr = _lib.Csr(rp.data_ptr(), cc.data_ptr(), vv.data_ptr(), None, N, nnz, sl.data_ptr())
+print(f"gather SpMM   nnz {nnz}: {timed(lambda: _lib.check(lib.hiprec_spmm_csr(ctypes.byref(csr), None, 1.0, _lib.ptr(x), _lib.ptr(y), _lib.ptr(acc), D, st))):6.1f} us")
+W = lib.hiprec_sliced_width(N, D)
+cap = lib.hiprec_sliced_row_cap(N, D)
+for n_groups in (16, 32):
+    host = sliced_graph_host(rp.cpu().numpy(), cc.cpu().numpy(), vv.cpu().numpy(), None, n_groups, cap)
+    sc, hold = sliced_graph_device(host, N, n_groups, cap, dev)
+    xs, ys, accs = (torch.zeros(N * D, device=dev) for _ in range(3))
+    _lib.check(lib.hiprec_to_sliced(_lib.ptr(x), N, D, W, _lib.ptr(xs), st))
+    t = timed(lambda: _lib.check(lib.hiprec_spmm_sliced(ctypes.byref(sc), None, 1.0, _lib.ptr(xs), _lib.ptr(ys), _lib.ptr(accs), 1, D, W, st)))
+    print(f"sliced SpMM W {W} groups {n_groups} subs/group {host['subs_per_group']} chunks {host['n_chunks']} slots {host['n_slots']}: {t:6.1f} us"
+          f"  (dbg {os.environ.get('HIPREC_SLICED_DBG', '0')})", flush=True)
+    if os.environ.get("HIPREC_SLICED_DBG") == "9":
+        torch.cuda.synchronize()
+        t = ys[:96].cpu().numpy().reshape(6, 16)
+        for name, row in zip(("blk0 t0", "blk0 t1023", "blk100 t0", "blk100 t1023", "blk255 t0", "blk255 t1023"), t):
+            print(name, " ".join(f"{v:6.2f}" for v in row[:np.argmax(row < 0)]))
