@@ -87,7 +87,8 @@ class SlicedCsr(Structure):
     """hiprec_sliced_csr (include/hiprec.h)."""
 
     _fields_ = [("chunks", c_void_p), ("col16", c_void_p), ("val", c_void_p), ("eid", c_void_p),
-                ("sub_row", c_void_p), ("sub_chunk", c_void_p), ("n_rows", c_int64), ("n_slots", c_int64),
+                ("sub_row", c_void_p), ("sub_chunk", c_void_p), ("row_scale", c_void_p), ("col_scale", c_void_p),
+                ("n_rows", c_int64), ("n_slots", c_int64),
                 ("n_groups", c_int32), ("subs_per_group", c_int32), ("n_chunks", c_int32), ("row_cap", c_int32)]
 
 
@@ -208,7 +209,7 @@ SIGNATURES = {
     "hiprec_spmm_csr": (c_int, [POINTER(Csr), _P, c_float, _P, _P, _P, c_int32, _P]),
     "hiprec_sliced_width": (c_int32, [c_int64, c_int32]),
     "hiprec_sliced_row_cap": (c_int32, [c_int64, c_int32]),
-    "hiprec_to_sliced": (c_int, [_P, c_int64, c_int32, c_int32, _P, _P]),
+    "hiprec_to_sliced": (c_int, [_P, c_int64, c_int32, c_int32, _P, _P, _P]),
     "hiprec_from_sliced": (c_int, [_P, c_int64, c_int32, c_int32, _P, c_int32, _P]),
     "hiprec_sliced_drop_values": (c_int, [POINTER(SlicedCsr), _P, _P, _P]),
     "hiprec_spmm_sliced": (c_int, [POINTER(SlicedCsr), _P, c_float, _P, _P, _P, c_int32, c_int32, c_int32, _P]),

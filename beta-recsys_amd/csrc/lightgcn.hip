@@ -192,13 +192,16 @@ __global__ __launch_bounds__(kBlock) void lightgcn_loss_kernel(
     const float xx = dn - dp;  // softplus(neg - pos)
     loss_acc += xx > 20.f ? xx : log1pf(expf(xx));
     const float dx = sigmoid_f32(xx) * inv_batch * inv_l;  // d mf / d x, pre-scaled by 1/(L+1)
+    // (sliced, factored transposed graph: its passes take their source scaled by the column factor)
+    const float* cs = SLICED ? p.sat.col_scale : nullptr;
+    const float su = cs ? cs[u] : 1.f, sp = cs ? cs[p.n_users + i] : 1.f, sn = cs ? cs[p.n_users + j] : 1.f;
     const float cr = p.decay * inv_batch;                   // d reg / d row = decay * row / B
     for (int c = lane; c < D; c += kWave) {
       const float ue = p.acc[at(ru, c)] * inv_l, pe = p.acc[at(rp, c)] * inv_l, ne = p.acc[at(rn, c)] * inv_l;
       const float gu = dx * (ne - pe), gp = -dx * ue, gn = dx * ue;
-      atomic_add_f32(p.da + at(ru, c), gu);
-      atomic_add_f32(p.da + at(rp, c), gp);
-      atomic_add_f32(p.da + at(rn, c), gn);
+      atomic_add_f32(p.da + at(ru, c), gu * su);
+      atomic_add_f32(p.da + at(rp, c), gp * sp);
+      atomic_add_f32(p.da + at(rn, c), gn * sn);
       atomic_add_f32(p.g + ru + c, gu + cr * p.e0[ru + c]);
       atomic_add_f32(p.g + rp + c, gp + cr * p.e0[rp + c]);
       atomic_add_f32(p.g + rn + c, gn + cr * p.e0[rn + c]);
@@ -309,7 +312,8 @@ static float* sliced_buf(const hiprec_lightgcn_plan* p, int k) {
 }
 
 // out (row-major) = [add] sum_{l = first .. L} G^l in, G = `graph`; the l = 0 term only when `with_input`.
-// in NULL: the input is already in sliced buffer 0; out NULL: the result stays in sliced buffer 1.
+// in NULL: the input is already in sliced buffer 0 (scaled by graph->col_scale if the graph is factored);
+// out NULL: the result stays in sliced buffer 1.
 static int propagate_sliced(const hiprec_lightgcn_plan* p, const hiprec_sliced_csr* graph, const uint8_t* keep,
                             float keep_prob, const float* in, float* out, bool with_input, bool add,
                             hipStream_t st) {
@@ -319,9 +323,9 @@ static int propagate_sliced(const hiprec_lightgcn_plan* p, const hiprec_sliced_c
   float* xs0 = sliced_buf(p, 0);
   float* accs = sliced_buf(p, 1);
   if (in != nullptr) {
-    if (int rc = launch_to_sliced(in, N, D, W, xs0, with_input ? accs : nullptr, st)) return rc;
+    if (int rc = launch_to_sliced(in, N, D, W, graph->col_scale, xs0, with_input ? accs : nullptr, st)) return rc;
   }
-  const float* val = nullptr;
+  const void* val = nullptr;
   if (keep && p->n_layers > 0) {  // once per step and graph, not per pass
     float* dropped = sliced_buf(p, 4) + (graph == &p->sat ? p->sa.n_slots : 0);
     if (!p->dropped_ready) {

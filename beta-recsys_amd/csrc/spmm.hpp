@@ -11,16 +11,18 @@ int launch_spmm(const hiprec_csr* a, const uint8_t* keep, float scale, const flo
                 int dim, hipStream_t st, bool y_is_zero = false);
 
 // Column-sliced SpMM (csrc/spmm_sliced.hip) on sliced buffers [dim / W][n_rows][W]; acc_mode 0 / 1 (+=) / 2 (=).
-// `val` NULL = the graph's own values (otherwise a step's dropped values from launch_step_values).
+// `edges` NULL = the graph's own values / columns (otherwise a step's stream from launch_step_values: float
+// values, or uint16 columns for a factored graph, whose source and result are scaled by col_scale).
 int sliced_width(int64_t n_rows, int dim);
 int sliced_row_cap(int64_t n_rows, int dim);
-int launch_spmm_sliced(const hiprec_sliced_csr* a, const float* val, float scale, const float* xs, float* ys,
+int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scale, const float* xs, float* ys,
                        float* accs, int acc_mode, int dim, int W, hipStream_t st);
 // dropped values of one step for one or two graphs in one launch; draw: the device draw keep_draw(seed, step, edge)
 // instead of reading keep[] (which `a`'s slots then fill in, when given)
 int launch_step_values(const hiprec_sliced_csr* a, const hiprec_sliced_csr* b, uint8_t* keep, bool draw,
                        float keep_prob, uint64_t seed, uint64_t step, float* out_a, float* out_b, hipStream_t st);
-int launch_to_sliced(const float* x, int64_t n_rows, int dim, int W, float* xs, float* xs_copy, hipStream_t st);
+int launch_to_sliced(const float* x, int64_t n_rows, int dim, int W, const float* row_scale, float* xs,
+                     float* xs_copy, hipStream_t st);
 int launch_from_sliced(const float* xs, int64_t n_rows, int dim, int W, float* y, bool add, hipStream_t st);
 
 }  // namespace hiprec

@@ -21,11 +21,18 @@
 // per pass.  A subgroup's finished rows are written once, coalesced, with plain stores: no global atomics, no
 // zero fill, and the fused layer sum is a plain read-modify-write.
 //
+// FACTORED graphs.  At 27 us per pass the kernel moves 16 x 9.4 MB of edge stream + 40 MB of slice fills out of L2,
+// ~9.5 TB/s -- the rate the gather SpMM reached too: the L2 -> CU path is the bound, and only fewer bytes help.  A
+// degree-normalised adjacency has rank-one values on its pattern, val[i][j] = row_scale[i] * col_scale[j]
+// (lightgcn.py: factor_edge_values): the kernel then takes col_scale (.) X as its source, adds source rows without
+// multiplying, applies row_scale[i] when a row is written, and hands col_scale (.) Y to the next pass -- the edge
+// stream is the 2-byte column alone, and a dropped edge (or a padding slot) is a column that points at an all-zero
+// row n of the slice.
+//
 // Earlier versions (MI355X, ML-1M graph, per pass): 16 lanes per ROW with a dynamic row counter 200 us (every row
 // switch is a chain of dependent loads and the four groups of a wave serialise theirs); 16 lanes per 64-edge chunk,
 // strided scalar loads, 16 DPP adds per chunk 47 us (VALU: ~180 instructions per 512 edges).
 #include <algorithm>
-#include <cstdlib>
 
 #include "common.hpp"
 #include "spmm.hpp"
@@ -42,61 +49,79 @@ constexpr int kSlicedMaxRowCap = 512;            // ... and at most: 2 output fl
 template <int W>
 struct SlicedVec;
 template <>
-struct SlicedVec<4> { using type = float4; };
+struct SlicedVec<4> { using type = float __attribute__((ext_vector_type(4))); };
 template <>
-struct SlicedVec<2> { using type = float2; };
+struct SlicedVec<2> { using type = float __attribute__((ext_vector_type(2))); };
 
+template <bool FACTORED>
 struct SlicedEdges {  // the 16 slots of one lane
   uint4 c[2];
   float4 v[4];
 };
+template <>
+struct SlicedEdges<true> {
+  uint4 c[2];
+};
 
-__device__ __forceinline__ SlicedEdges load_sliced_edges(const uint16_t* __restrict__ col16,
-                                                         const float* __restrict__ val, int2 d, int q) {
-  SlicedEdges e;
-  if (q * 16 < (d.y >> 16)) {
-    const int64_t base = static_cast<int64_t>(d.x) + q * 16;  // a multiple of 16: 32-B / 64-B aligned
-    const uint4* pc = reinterpret_cast<const uint4*>(col16 + base);
-    const float4* pv = reinterpret_cast<const float4*>(val + base);
-    e.c[0] = pc[0];
-    e.c[1] = pc[1];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) e.v[k] = pv[k];
+// `edges`: float values [n_slots] (general graph) or uint16 columns [n_slots] (factored graph)
+template <bool FACTORED>
+__device__ __forceinline__ SlicedEdges<FACTORED> load_sliced_edges(const uint16_t* __restrict__ col16,
+                                                                   const void* __restrict__ edges, int2 d, int q,
+                                                                   uint32_t zero_row) {
+  SlicedEdges<FACTORED> e;
+  const bool live = q * 16 < (d.y >> 16);
+  const int64_t base = static_cast<int64_t>(d.x) + q * 16;  // a multiple of 16: 32-B / 64-B aligned
+  if constexpr (FACTORED) {
+    const uint32_t z = zero_row | (zero_row << 16);
+    e.c[0] = e.c[1] = uint4{z, z, z, z};
+    if (live) {
+      const uint4* pc = reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(edges) + base);
+      e.c[0] = pc[0];
+      e.c[1] = pc[1];
+    }
   } else {
     e.c[0] = e.c[1] = uint4{0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 4; ++k) e.v[k] = float4{0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      const uint4* pc = reinterpret_cast<const uint4*>(col16 + base);
+      const float4* pv = reinterpret_cast<const float4*>(static_cast<const float*>(edges) + base);
+      e.c[0] = pc[0];
+      e.c[1] = pc[1];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e.v[k] = pv[k];
+    }
   }
   return e;
 }
 
 // acc_mode: 0 = none, 1 = accs += y, 2 = accs = y
-template <int W>
+template <int W, bool FACTORED>
 __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_sliced_csr a,
-                                                                     const float* __restrict__ val, float scale,
+                                                                     const void* __restrict__ edges, float scale,
                                                                      const float* __restrict__ xs,
                                                                      float* __restrict__ ys, float* __restrict__ accs,
-                                                                     int acc_mode, int dbg) {
+                                                                     int acc_mode) {
   using Vec = typename SlicedVec<W>::type;
+  using LdsVec = const __attribute__((address_space(3))) Vec;
+  using Pair = float __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
   const int64_t n_rows = a.n_rows;
-  float* s_x = s_mem;               // [n_rows][W]: slice s of the source
-  float* s_y = s_mem + n_rows * W;  // [row_cap][W]: accumulators of the current subgroup's rows
+  float* s_x = s_mem;                     // [n_rows + 1][W]: slice s of the source, then an all-zero row
+  float* s_y = s_mem + (n_rows + 1) * W;  // [row_cap][W]: accumulators of the current subgroup's rows
+  const uint32_t zero_row = static_cast<uint32_t>(n_rows);
+  const uint32_t row_bytes = W * sizeof(float);
+  const uint32_t lds_base =
+      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)s_x));
   const int s = static_cast<int>(blockIdx.x) / a.n_groups, g = static_cast<int>(blockIdx.x) % a.n_groups;
   const int64_t slice_off = static_cast<int64_t>(s) * n_rows * W;
   const int quad = static_cast<int>(threadIdx.x) >> 2, q = static_cast<int>(threadIdx.x) & 3;
   const int2* __restrict__ chunks = reinterpret_cast<const int2*>(a.chunks);
-  long long ts[12];
-  int n_ts = 0;
-  auto stamp = [&]() {
-    if (dbg == 9 && n_ts < 12) ts[n_ts++] = wall_clock64();
-  };
-  stamp();
   const int sg_begin = g * a.subs_per_group, sg_end = sg_begin + a.subs_per_group;
   const int c_end = a.sub_chunk[sg_end];  // the block's chunks: sub_chunk[sg_begin] .. c_end
   auto desc = [&](int c) { return c < c_end ? chunks[c] : int2{0, 0}; };  // {first slot, row | n_slots << 16}
   // The chunk pipeline runs through the block's subgroups without draining: quad k takes chunks k, k + 256, ...
-  // of the block; descriptors are two chunks ahead of the arithmetic, edge data one.
+  // of the block, with its next chunks' descriptors and edge data in flight ahead of the arithmetic.
   // the slice: every thread's (at most kSlicedFill) 16-byte loads are issued together -- a load-store loop would pay
   // the memory latency once per trip
   const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xs + slice_off);
@@ -108,19 +133,25 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
     fill[k] = i < n4 ? x4[i] : float4{0.f, 0.f, 0.f, 0.f};
   }
   int c = a.sub_chunk[sg_begin] + quad;
-  int2 d0 = desc(c), d1 = desc(c + kSlicedQuads);
+  // P: edge data of P chunks in flight ahead of the arithmetic (descriptors one more).  Three instead of one
+  // (a factored graph's 8 registers per chunk allow it) changed nothing: 27.2 against 26.9 us.
+  constexpr int P = 1;
+  int2 dq[P + 1];
+#pragma unroll
+  for (int k = 0; k <= P; ++k) dq[k] = desc(c + k * kSlicedQuads);
 #pragma unroll
   for (int k = 0; k < kSlicedFill; ++k) {
     const int i = static_cast<int>(threadIdx.x) + k * kSlicedThreads;
     if (i < n4) reinterpret_cast<float4*>(s_x)[i] = fill[k];
   }
   if (static_cast<int>(threadIdx.x) < n_tail) s_x[4 * n4 + threadIdx.x] = xs[slice_off + 4 * n4 + threadIdx.x];
-  stamp();
-  SlicedEdges e0 = load_sliced_edges(a.col16, val, d0, q);
+  if (static_cast<int>(threadIdx.x) < W) s_x[n_rows * W + threadIdx.x] = 0.f;
+  SlicedEdges<FACTORED> eq[P];
+#pragma unroll
+  for (int k = 0; k < P; ++k) eq[k] = load_sliced_edges<FACTORED>(a.col16, edges, dq[k], q, zero_row);
   const int n_acc = a.row_cap * W;  // <= kSlicedMaxRowCap * 4 = 2 per thread
   for (int i = threadIdx.x; i < n_acc; i += kSlicedThreads) s_y[i] = 0.f;
   __syncthreads();
-  stamp();
   for (int sg = sg_begin; sg < sg_end; ++sg) {
     const int r0 = a.sub_row[sg], r1 = a.sub_row[sg + 1], c1 = a.sub_chunk[sg + 1];
     const int n_out = (r1 - r0) * W;
@@ -134,79 +165,99 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
       }
     }
     while (c < c1) {
-      const int2 d2 = desc(c + 2 * kSlicedQuads);
-      const SlicedEdges e1 = load_sliced_edges(a.col16, val, d1, q);
+      const int2 d0 = dq[0], d_new = desc(c + (P + 1) * kSlicedQuads);
+      const SlicedEdges<FACTORED> e0 = eq[0], e_new = load_sliced_edges<FACTORED>(a.col16, edges, dq[P], q, zero_row);
       // 16 random source rows out of the LDS (~3-way bank conflicts: the kernel's floor): addresses first, then
       // reads four at a time with eight in flight while the previous four are multiplied -- left alone the compiler
       // keeps two reads in flight and waits for each
       const uint32_t cw[8] = {e0.c[0].x, e0.c[0].y, e0.c[0].z, e0.c[0].w, e0.c[1].x, e0.c[1].y, e0.c[1].z, e0.c[1].w};
-      const float vv[16] = {e0.v[0].x, e0.v[0].y, e0.v[0].z, e0.v[0].w, e0.v[1].x, e0.v[1].y, e0.v[1].z, e0.v[1].w,
-                            e0.v[2].x, e0.v[2].y, e0.v[2].z, e0.v[2].w, e0.v[3].x, e0.v[3].y, e0.v[3].z, e0.v[3].w};
-      const Vec* __restrict__ s_rows = reinterpret_cast<const Vec*>(s_x);
-      uint32_t col[16];
+      float vv[16];
+      if constexpr (!FACTORED) {
+        const float4* pv = e0.v;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) col[j] = (j & 1) ? (cw[j >> 1] >> 16) : (cw[j >> 1] & 0xFFFFu);
+        for (int k = 0; k < 4; ++k) {
+          vv[4 * k] = pv[k].x;
+          vv[4 * k + 1] = pv[k].y;
+          vv[4 * k + 2] = pv[k].z;
+          vv[4 * k + 3] = pv[k].w;
+        }
+      }
+      // LDS byte address of slot j's source row: column (low / high half of a word) * row bytes + base, one
+      // v_mad_u32_u16 each (the compiler's and / bfe + shift-add pairs were a quarter of the loop's VALU work)
+      uint32_t addr[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j & 1)
+          asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(addr[j]) : "v"(cw[j >> 1]), "v"(row_bytes), "v"(lds_base));
+        else
+          asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(addr[j]) : "v"(cw[j >> 1]), "v"(row_bytes), "v"(lds_base));
+      }
+      auto source = [&](int j) { return *reinterpret_cast<LdsVec*>(addr[j]); };
       Vec src[2][4];
-      float acc[W];
+      Pair acc[W / 2];  // two floats per register pair: v_pk_add_f32 / v_pk_fma_f32
 #pragma unroll
-      for (int w = 0; w < W; ++w) acc[w] = 0.f;
+      for (int h = 0; h < W / 2; ++h) acc[h] = Pair{0.f, 0.f};
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) src[0][j] = s_rows[col[j]];
+      for (int j = 0; j < 4; ++j) src[0][j] = source(j);
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         if (b < 3) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) src[(b + 1) & 1][j] = s_rows[col[4 * (b + 1) + j]];
+          for (int j = 0; j < 4; ++j) src[(b + 1) & 1][j] = source(4 * (b + 1) + j);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float* f = reinterpret_cast<const float*>(&src[b & 1][j]);
+          const Pair* f = reinterpret_cast<const Pair*>(&src[b & 1][j]);
 #pragma unroll
-          for (int w = 0; w < W; ++w) acc[w] += vv[4 * b + j] * f[w];
+          for (int h = 0; h < W / 2; ++h) {
+            if constexpr (FACTORED) acc[h] += f[h];
+            else acc[h] += Pair{vv[4 * b + j], vv[4 * b + j]} * f[h];
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       float mine = 0.f;  // lane q < W of the quad adds component q
 #pragma unroll
       for (int w = 0; w < W; ++w) {
-        float t = dpp_add<0xB1>(acc[w]);  // quad_perm [1,0,3,2]
+        float t = dpp_add<0xB1>(acc[w >> 1][w & 1]);  // quad_perm [1,0,3,2]
         t = dpp_add<0x4E>(t);             // quad_perm [2,3,0,1]
         mine = q == w ? t : mine;
       }
       if (q < W && (d0.y >> 16) > 0) lds_add_f32(&s_y[((d0.y & 0xFFFF) - r0) * W + q], mine);
       c += kSlicedQuads;
-      d0 = d1;
-      d1 = d2;
-      e0 = e1;
+#pragma unroll
+      for (int k = 0; k < P; ++k) dq[k] = dq[k + 1];
+      dq[P] = d_new;
+#pragma unroll
+      for (int k = 0; k + 1 < P; ++k) eq[k] = eq[k + 1];
+      eq[P - 1] = e_new;
     }
-    stamp();
     __syncthreads();
-    stamp();
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int i = static_cast<int>(threadIdx.x) + k * kSlicedThreads;
       if (i < n_out) {
-        const float y = s_y[i] * scale;
+        float y = s_y[i] * scale, y_next = y;
+        if constexpr (FACTORED) {  // row factor now; the next pass wants its source scaled by the column factor
+          const int r = r0 + (W == 4 ? i >> 2 : i >> 1);
+          y *= a.row_scale[r];
+          y_next = y * a.col_scale[r];
+        }
         s_y[i] = 0.f;
-        ys[out0 + i] = y;
+        ys[out0 + i] = y_next;
         if (acc_mode == 1) accs[out0 + i] = old[k] + y;
         else if (acc_mode == 2) accs[out0 + i] = y;
       }
     }
     __syncthreads();
-    stamp();
-  }
-  if (dbg == 9 && (threadIdx.x == 0 || threadIdx.x == 1023) && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 255)) {
-    float* out = ys + (blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 32 : 64) + (threadIdx.x ? 16 : 0);
-    for (int k = 0; k < n_ts; ++k) out[k] = static_cast<float>(ts[k] - ts[0]) * 0.01f;  // us at 100 MHz
-    out[n_ts] = -1.f;
   }
 }
 
 // out[slot] = keep[eid[slot]] ? val[slot] : 0 (padding slots: eid < 0, value 0) -- the dropped edge values of a
-// step in the sliced graph's slot order, so that no pass looks at keep bytes.  One launch serves both graphs of a
+// step in the sliced graph's slot order, so that no pass looks at keep bytes; for a factored graph the step's
+// stream is uint16 columns instead, col16[slot] or n_rows (the zero row).  One launch serves both graphs of a
 // plan (slots of `a`, then slots of `b`); with `draw` the keep decision is the counter-based device draw itself
 // (the same function of (seed, step, edge) in both graphs) and `a`'s slots publish it to keep[] when that is given.
 __global__ __launch_bounds__(kBlock) void step_values_kernel(hiprec_sliced_csr a, hiprec_sliced_csr b,
@@ -218,7 +269,7 @@ __global__ __launch_bounds__(kBlock) void step_values_kernel(hiprec_sliced_csr a
     const bool first = i < a.n_slots;
     const int64_t e = first ? i : i - a.n_slots;
     const int32_t k = first ? a.eid[e] : b.eid[e];
-    const float v = first ? a.val[e] : b.val[e];
+    const hiprec_sliced_csr& gph = first ? a : b;
     bool kept = false;
     if (k >= 0) {
       if (draw) {
@@ -228,14 +279,19 @@ __global__ __launch_bounds__(kBlock) void step_values_kernel(hiprec_sliced_csr a
         kept = keep[k] != 0;
       }
     }
-    (first ? out_a : out_b)[e] = kept ? v : 0.f;
+    float* out = first ? out_a : out_b;
+    if (gph.col_scale != nullptr)  // factored: a dropped edge points at the zero row
+      reinterpret_cast<uint16_t*>(out)[e] = kept ? gph.col16[e] : static_cast<uint16_t>(gph.n_rows);
+    else
+      out[e] = kept ? gph.val[e] : 0.f;
   }
 }
 
 // row-major [n_rows][dim]  <->  sliced [dim / W][n_rows][W]
+// (xs = row_scale (.) x when row_scale is given: the source of a factored graph's pass; xs_copy = x)
 __global__ __launch_bounds__(kBlock) void to_sliced_kernel(const float* __restrict__ x, int64_t n_rows, int dim,
-                                                           int W, float* __restrict__ xs,
-                                                           float* __restrict__ xs_copy) {
+                                                           int W, const float* __restrict__ row_scale,
+                                                           float* __restrict__ xs, float* __restrict__ xs_copy) {
   const int64_t total = n_rows * dim;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += stride) {
@@ -243,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void to_sliced_kernel(const float* __restri
     const int c = static_cast<int>(i - r * dim);
     const int64_t o = (static_cast<int64_t>(c / W) * n_rows + r) * W + c % W;
     const float v = x[i];
-    xs[o] = v;
+    xs[o] = row_scale ? v * row_scale[r] : v;
     if (xs_copy) xs_copy[o] = v;
   }
 }
@@ -266,43 +322,51 @@ int sliced_width(int64_t n_rows, int dim) {
   // a width below 4 floats re-reads the edge arrays more often than the gather SpMM reads source rows: W = 4 or
   // (a narrower slice for graphs of up to ~20 k nodes) 2
   for (int w : {4, 2})
-    if (dim % w == 0 && (n_rows + kSlicedMinRowCap) * w * static_cast<int64_t>(sizeof(float)) <= kSlicedLds) return w;
+    if (dim % w == 0 && (n_rows + 1 + kSlicedMinRowCap) * w * static_cast<int64_t>(sizeof(float)) <= kSlicedLds)
+      return w;
   return 0;
 }
 
 int sliced_row_cap(int64_t n_rows, int dim) {
   const int w = sliced_width(n_rows, dim);
   if (w == 0) return 0;
-  return static_cast<int>(std::min<int64_t>(kSlicedLds / (w * sizeof(float)) - n_rows, kSlicedMaxRowCap));
+  return static_cast<int>(std::min<int64_t>(kSlicedLds / (w * sizeof(float)) - n_rows - 1, kSlicedMaxRowCap));
 }
 
-int launch_spmm_sliced(const hiprec_sliced_csr* a, const float* val, float scale, const float* xs, float* ys,
+int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scale, const float* xs, float* ys,
                        float* accs, int acc_mode, int dim, int W, hipStream_t st) {
   HIPREC_REQUIRE(a && a->sub_row && a->sub_chunk && a->n_rows > 0 && a->n_groups > 0 && a->subs_per_group > 0,
                  "bad sliced graph");
   HIPREC_REQUIRE(a->n_slots == 0 || (a->col16 && a->val && a->chunks), "sliced graph has NULL chunks / col16 / val");
   HIPREC_REQUIRE(a->n_slots % 16 == 0, "n_slots %lld is not a multiple of 16", (long long)a->n_slots);
+  HIPREC_REQUIRE((a->row_scale == nullptr) == (a->col_scale == nullptr), "row_scale and col_scale go together");
   HIPREC_REQUIRE(W > 0 && W == sliced_width(a->n_rows, dim), "slice width %d does not fit %lld rows x dim %d", W,
                  (long long)a->n_rows, dim);
   HIPREC_REQUIRE(a->row_cap > 0 && a->row_cap <= sliced_row_cap(a->n_rows, dim),
                  "subgroups of up to %d rows do not fit the LDS next to the slice (at most %d)", a->row_cap,
                  sliced_row_cap(a->n_rows, dim));
   HIPREC_REQUIRE(xs && ys && (acc_mode == 0 || accs), "NULL sliced buffers");
-  const size_t lds = static_cast<size_t>(a->n_rows + a->row_cap) * W * sizeof(float);
+  const size_t lds = static_cast<size_t>(a->n_rows + 1 + a->row_cap) * W * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    for (const void* k : {reinterpret_cast<const void*>(&spmm_sliced_kernel<4>),
-                          reinterpret_cast<const void*>(&spmm_sliced_kernel<2>)})
+    for (const void* k : {reinterpret_cast<const void*>(&spmm_sliced_kernel<4, false>),
+                          reinterpret_cast<const void*>(&spmm_sliced_kernel<2, false>),
+                          reinterpret_cast<const void*>(&spmm_sliced_kernel<4, true>),
+                          reinterpret_cast<const void*>(&spmm_sliced_kernel<2, true>)})
       HIPREC_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSlicedLds)));
     attr_set = true;
   }
-  if (val == nullptr) val = a->val;
-  static const int dbg = getenv("HIPREC_SLICED_DBG") ? atoi(getenv("HIPREC_SLICED_DBG")) : 0;  // timing experiments
+  const bool factored = a->col_scale != nullptr;
+  if (edges == nullptr) edges = factored ? static_cast<const void*>(a->col16) : static_cast<const void*>(a->val);
   const int grid = (dim / W) * a->n_groups;
-  if (W == 4)
-    spmm_sliced_kernel<4><<<grid, kSlicedThreads, lds, st>>>(*a, val, scale, xs, ys, accs, acc_mode, dbg);
+  if (W == 4 && factored)
+    spmm_sliced_kernel<4, true><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode);
+  else if (W == 4)
+    spmm_sliced_kernel<4, false><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode);
+  else if (factored)
+    spmm_sliced_kernel<2, true><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode);
   else
-    spmm_sliced_kernel<2><<<grid, kSlicedThreads, lds, st>>>(*a, val, scale, xs, ys, accs, acc_mode, dbg);
+    spmm_sliced_kernel<2, false><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
@@ -321,8 +385,9 @@ int launch_step_values(const hiprec_sliced_csr* a, const hiprec_sliced_csr* b, u
   return 0;
 }
 
-int launch_to_sliced(const float* x, int64_t n_rows, int dim, int W, float* xs, float* xs_copy, hipStream_t st) {
-  to_sliced_kernel<<<grid_for_threads(n_rows * dim), kBlock, 0, st>>>(x, n_rows, dim, W, xs, xs_copy);
+int launch_to_sliced(const float* x, int64_t n_rows, int dim, int W, const float* row_scale, float* xs,
+                     float* xs_copy, hipStream_t st) {
+  to_sliced_kernel<<<grid_for_threads(n_rows * dim), kBlock, 0, st>>>(x, n_rows, dim, W, row_scale, xs, xs_copy);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
@@ -341,10 +406,10 @@ extern "C" int32_t hiprec_sliced_width(int64_t n_rows, int32_t dim) { return sli
 
 extern "C" int32_t hiprec_sliced_row_cap(int64_t n_rows, int32_t dim) { return sliced_row_cap(n_rows, dim); }
 
-extern "C" int hiprec_to_sliced(const float* x, int64_t n_rows, int32_t dim, int32_t slice_w, float* xs,
-                                void* stream) {
+extern "C" int hiprec_to_sliced(const float* x, int64_t n_rows, int32_t dim, int32_t slice_w, const float* row_scale,
+                                float* xs, void* stream) {
   HIPREC_REQUIRE(x && xs && n_rows > 0 && dim > 0 && slice_w > 0 && dim % slice_w == 0, "bad arguments");
-  return launch_to_sliced(x, n_rows, dim, slice_w, xs, nullptr, static_cast<hipStream_t>(stream));
+  return launch_to_sliced(x, n_rows, dim, slice_w, row_scale, xs, nullptr, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int hiprec_from_sliced(const float* xs, int64_t n_rows, int32_t dim, int32_t slice_w, float* y,
@@ -358,8 +423,9 @@ extern "C" int hiprec_sliced_drop_values(const hiprec_sliced_csr* a, const uint8
                             static_cast<hipStream_t>(stream));
 }
 
-extern "C" int hiprec_spmm_sliced(const hiprec_sliced_csr* a, const float* val, float scale, const float* xs,
+extern "C" int hiprec_spmm_sliced(const hiprec_sliced_csr* a, const void* step_edges, float scale, const float* xs,
                                   float* ys, float* accs, int32_t acc_mode, int32_t dim, int32_t slice_w,
                                   void* stream) {
-  return launch_spmm_sliced(a, val, scale, xs, ys, accs, acc_mode, dim, slice_w, static_cast<hipStream_t>(stream));
+  return launch_spmm_sliced(a, step_edges, scale, xs, ys, accs, acc_mode, dim, slice_w,
+                            static_cast<hipStream_t>(stream));
 }

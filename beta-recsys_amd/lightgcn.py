@@ -46,22 +46,78 @@ def _csr_from_coo(rows, cols, vals, n, device):
 SLICED_CHUNK, SLICED_PAD = 64, 16  # slots per work item / row padding of the column-sliced SpMM (csrc/spmm_sliced.hip)
 
 
-def sliced_graph_host(rowptr, col, val, eid, n_groups, row_cap, max_subs=64):
-    """hiprec_sliced_csr (include/hiprec.h) of a CSR given as numpy arrays; eid = keep-byte index of every edge
-    (None = the edge number itself).
+def factor_edge_values(rowptr, col, val, rel_tol=2e-6, max_rounds=256):
+    """(row_scale, col_scale) float32 [n] with val[e] == row_scale[row(e)] * col_scale[col(e)] to rel_tol on every
+    edge of a square CSR -- what every degree-normalised adjacency is (D^-1 (A + I) of the reference: row_scale =
+    1 / degree, col_scale = 1; the symmetric D^-1/2 A D^-1/2 as well) -- or None.
 
-    Returns dict(col16 uint16, val float32, eid int32 [n_slots]; chunks int32 [n_chunks, 2]; sub_row, sub_chunk
-    int32 [n_groups * k + 1]; subs_per_group k; n_chunks; n_slots) or None when no k <= max_subs keeps every subgroup
-    within row_cap rows."""
+    Solved by propagation over the bipartite row / column graph: one seed row per connected component gets scale
+    1, known row scales fix the scales of their columns and the other way round, then every edge is verified."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import connected_components
+
     rowptr = np.asarray(rowptr, dtype=np.int64)
     n, nnz = rowptr.size - 1, int(rowptr[-1])
+    col = np.asarray(col, dtype=np.int64)[:nnz]
+    v = np.asarray(val, dtype=np.float64)[:nnz]
+    r, c = np.ones(n), np.ones(n)
+    if nnz == 0:
+        return r.astype(np.float32), c.astype(np.float32)
+    if not np.all(np.isfinite(v)) or np.any(v == 0):
+        return None
+    row = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr))
+    both = sp.coo_matrix((np.ones(nnz, np.int8), (row, col + n)), shape=(2 * n, 2 * n))
+    _, label = connected_components(both, directed=False)
+    known_r, known_c = np.zeros(n, bool), np.zeros(n, bool)
+    has_edges = np.diff(rowptr) > 0
+    rows_with = np.nonzero(has_edges)[0]
+    _, first = np.unique(label[rows_with], return_index=True)  # one seed row per component that has edges
+    known_r[rows_with[first]] = True
+    for _ in range(max_rounds):
+        m = known_r[row] & ~known_c[col]  # rows fix columns (first such edge per column)
+        if m.any():
+            cj, idx = np.unique(col[m], return_index=True)
+            e = np.nonzero(m)[0][idx]
+            c[cj] = v[e] / r[row[e]]
+            known_c[cj] = True
+        m2 = known_c[col] & ~known_r[row]
+        if m2.any():
+            ri, idx = np.unique(row[m2], return_index=True)
+            e = np.nonzero(m2)[0][idx]
+            r[ri] = v[e] / c[col[e]]
+            known_r[ri] = True
+        if not m.any() and not m2.any():
+            break
+    else:
+        return None
+    r32, c32 = r.astype(np.float32), c.astype(np.float32)
+    if not (np.all(np.isfinite(r32)) and np.all(np.isfinite(c32))):
+        return None
+    prod = r32[row].astype(np.float64) * c32[col].astype(np.float64)
+    if np.any(np.abs(prod - v) > rel_tol * np.abs(v)):
+        return None
+    return r32, c32
+
+
+def sliced_graph_host(rowptr, col, val, eid, n_groups, row_cap, max_subs=64, factor=True):
+    """hiprec_sliced_csr (include/hiprec.h) of a CSR given as numpy arrays; eid = keep-byte index of every edge
+    (None = the edge number itself).  factor: look for the rank-one form of the values (factor_edge_values); the
+    graph is then stored with row_scale / col_scale and its padding slots point at the zero row n.
+
+    Returns dict(col16 uint16, val float32, eid int32 [n_slots]; chunks int32 [n_chunks, 2]; sub_row, sub_chunk
+    int32 [n_groups * k + 1]; subs_per_group k; n_chunks; n_slots; optionally row_scale, col_scale float32 [n]) or
+    None when no k <= max_subs keeps every subgroup within row_cap rows."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    n, nnz = rowptr.size - 1, int(rowptr[-1])
+    scales = factor_edge_values(rowptr, col, val) if factor else None
     lens = np.diff(rowptr)
     padded = (lens + SLICED_PAD - 1) // SLICED_PAD * SLICED_PAD
     slotptr = np.concatenate([[0], np.cumsum(padded)])
     n_slots = int(slotptr[-1])
     edge_row = np.repeat(np.arange(n, dtype=np.int64), lens)
     slot = np.arange(nnz, dtype=np.int64) + (slotptr[:-1] - rowptr[:-1])[edge_row]
-    col16, valp, eidp = np.zeros(n_slots, np.uint16), np.zeros(n_slots, np.float32), np.full(n_slots, -1, np.int32)
+    col16 = np.full(n_slots, n if scales is not None else 0, np.uint16)
+    valp, eidp = np.zeros(n_slots, np.float32), np.full(n_slots, -1, np.int32)
     col16[slot] = np.asarray(col)[:nnz]
     valp[slot] = np.asarray(val)[:nnz]
     eidp[slot] = np.arange(nnz) if eid is None else np.asarray(eid)[:nnz]
@@ -81,9 +137,12 @@ def sliced_graph_host(rowptr, col, val, eid, n_groups, row_cap, max_subs=64):
         sub_row = np.maximum.accumulate(sub_row)
         sub_chunk = np.append(first, n_chunks)[sub_row]  # a subgroup starts at the first chunk of its first row
         if np.diff(sub_row).max() <= row_cap:
-            return {"col16": col16, "val": valp, "eid": eidp, "chunks": chunks, "sub_row": sub_row.astype(np.int32),
-                    "sub_chunk": sub_chunk.astype(np.int32), "subs_per_group": k, "n_chunks": n_chunks,
-                    "n_slots": n_slots}
+            out = {"col16": col16, "val": valp, "eid": eidp, "chunks": chunks, "sub_row": sub_row.astype(np.int32),
+                   "sub_chunk": sub_chunk.astype(np.int32), "subs_per_group": k, "n_chunks": n_chunks,
+                   "n_slots": n_slots}
+            if scales is not None:
+                out["row_scale"], out["col_scale"] = scales
+            return out
     return None
 
 
@@ -92,7 +151,8 @@ def sliced_graph_device(host, n_rows, n_groups, row_cap, device):
     hold = {k: torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else v).to(device)
             for k, v in host.items() if isinstance(v, np.ndarray)}
     sc = _lib.SlicedCsr(hold["chunks"].data_ptr(), hold["col16"].data_ptr(), hold["val"].data_ptr(),
-                        hold["eid"].data_ptr(), hold["sub_row"].data_ptr(), hold["sub_chunk"].data_ptr(), n_rows,
+                        hold["eid"].data_ptr(), hold["sub_row"].data_ptr(), hold["sub_chunk"].data_ptr(),
+                        _lib.ptr(hold.get("row_scale")), _lib.ptr(hold.get("col_scale")), n_rows,
                         host["n_slots"], n_groups, host["subs_per_group"], host["n_chunks"], row_cap)
     return sc, hold
 
@@ -152,14 +212,18 @@ class LightGCN(_FlatModel):
             # graphs whose node count fits the LDS take the column-sliced SpMM (csrc/spmm_sliced.hip): 16-bit column
             # ids and row groups of equal edge count, one (slice, row group) per compute unit
             lib = _lib.load()
-            w = int(lib.hiprec_sliced_width(N, self.emb_dim)) if self.config.get("spmm", "auto") != "gather" else 0
+            mode = self.config.get("spmm", "auto")  # "gather": the edge-parallel SpMM; "sliced_values": no factoring
+            if mode not in ("auto", "gather", "sliced_values"):
+                raise ValueError(f"unknown spmm mode {mode!r}")
+            w = int(lib.hiprec_sliced_width(N, self.emb_dim)) if mode != "gather" else 0
             if w > 0:
                 n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
                 n_groups = max(8, n_cu // (self.emb_dim // w) // 8 * 8)  # same row group -> same XCD
                 cap = int(lib.hiprec_sliced_row_cap(N, self.emb_dim))
                 for tag, rowptr, col, val, eid in (("", rp, c, v, None), ("_t", rpt, ct, vt, order_t)):
                     host = sliced_graph_host(rowptr.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy(),
-                                             None if eid is None else eid.cpu().numpy(), n_groups, cap)
+                                             None if eid is None else eid.cpu().numpy(), n_groups, cap,
+                                             factor=mode == "auto")
                     if host is None:
                         w = 0
                         break

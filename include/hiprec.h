@@ -500,7 +500,9 @@ int hiprec_csr_slice_rows(const hiprec_csr* a, int32_t* out, int64_t n_out, void
  * chunk count: subgroup k covers rows sub_row[k] .. sub_row[k + 1] (sub_row[0] = 0, the last = n_rows; at most
  * row_cap rows, so that their accumulators fit the LDS next to the slice: hiprec_sliced_row_cap) and chunks
  * sub_chunk[k] .. sub_chunk[k + 1].  n_groups should be a multiple of 8 with (dim / slice width) * n_groups = the
- * CU count.  beta-recsys_amd/lightgcn.py: sliced_graph_host builds it. */
+ * CU count.  A graph whose values have the rank-one form of a degree-normalised adjacency carries row_scale /
+ * col_scale: the SpMM then streams 2-byte columns only (see hiprec_spmm_sliced).
+ * beta-recsys_amd/lightgcn.py: sliced_graph_host builds it. */
 typedef struct hiprec_sliced_csr {
   const int32_t* chunks;
   const uint16_t* col16;
@@ -508,6 +510,8 @@ typedef struct hiprec_sliced_csr {
   const int32_t* eid;
   const int32_t* sub_row;
   const int32_t* sub_chunk;
+  const float* row_scale; /* both NULL, or the FACTORED form: val of edge (i, j) == row_scale[i] * col_scale[j]; */
+  const float* col_scale; /* padding slots then hold column n_rows (an all-zero source row), not 0           */
   int64_t n_rows, n_slots;
   int32_t n_groups, subs_per_group, n_chunks, row_cap;
 } hiprec_sliced_csr;
@@ -517,16 +521,21 @@ typedef struct hiprec_sliced_csr {
 int32_t hiprec_sliced_width(int64_t n_rows, int32_t dim);
 /* most rows a subgroup of hiprec_sliced_csr may hold at that width */
 int32_t hiprec_sliced_row_cap(int64_t n_rows, int32_t dim);
-/* row-major [n_rows][dim] <-> sliced [dim / slice_w][n_rows][slice_w] (add != 0: y += instead of y =) */
-int hiprec_to_sliced(const float* x, int64_t n_rows, int32_t dim, int32_t slice_w, float* xs, void* stream);
+/* row-major [n_rows][dim] <-> sliced [dim / slice_w][n_rows][slice_w] (add != 0: y += instead of y =);
+ * row_scale (may be NULL): xs = row_scale (.) x, the source a factored graph's pass expects (its col_scale) */
+int hiprec_to_sliced(const float* x, int64_t n_rows, int32_t dim, int32_t slice_w, const float* row_scale, float* xs,
+                     void* stream);
 int hiprec_from_sliced(const float* xs, int64_t n_rows, int32_t dim, int32_t slice_w, float* y, int32_t add,
                        void* stream);
-/* out[slot] = keep[eid[slot]] ? val[slot] : 0 -- the dropped values of one step (n_slots floats), to be passed as
- * `val` below; the 1 / keep_prob factor goes into `scale` */
+/* The edge stream of one step, n_slots entries in `out` (sized for n_slots floats): a general graph's dropped values
+ * out[slot] = keep[eid[slot]] ? val[slot] : 0 (float); a factored graph's dropped columns keep[..] ? col16[slot] :
+ * n_rows (uint16).  To be passed as step_edges below; the 1 / keep_prob factor goes into `scale`. */
 int hiprec_sliced_drop_values(const hiprec_sliced_csr* a, const uint8_t* keep, float* out, void* stream);
-/* ys = scale * A xs on SLICED buffers, val NULL = a->val; acc_mode 0: nothing else, 1: accs += ys, 2: accs = ys.
- * Every row of ys is written (no zero fill needed). */
-int hiprec_spmm_sliced(const hiprec_sliced_csr* a, const float* val, float scale, const float* xs, float* ys,
+/* ys = scale * A xs on SLICED buffers, step_edges NULL = no dropout; acc_mode 0: nothing else, 1: accs += Y,
+ * 2: accs = Y.  Every row of ys is written (no zero fill needed).  General graph: xs = X, ys = Y.  Factored graph:
+ * xs must hold col_scale (.) X (hiprec_to_sliced with row_scale = a->col_scale) and ys receives col_scale (.) Y,
+ * ready to be the next pass's source, while accs gets Y itself. */
+int hiprec_spmm_sliced(const hiprec_sliced_csr* a, const void* step_edges, float scale, const float* xs, float* ys,
                        float* accs, int32_t acc_mode, int32_t dim, int32_t slice_w, void* stream);
 
 typedef struct hiprec_lightgcn_plan {

@@ -832,3 +832,54 @@ def test_sliced_graph_host_covers_every_edge_once(n, n_groups, cap, heavy):
     empty = sliced_graph_host(np.zeros(11, dtype=np.int64), col[:0], val[:0], None, 8, 16)
     assert empty["n_chunks"] == 0 and empty["n_slots"] == 0 and empty["sub_row"][-1] == 10
     assert np.all(empty["sub_chunk"] == 0)
+
+
+def test_factor_edge_values():
+    """Rank-one form of a degree-normalised adjacency's values (column-only edge stream of the sliced SpMM)."""
+    import scipy.sparse as sp
+
+    from beta_recsys_amd.lightgcn import factor_edge_values, sliced_graph_host
+    from oracle import lightgcn_numpy as olg
+
+    rng = np.random.default_rng(5)
+    U, I = 300, 170
+    adj = olg.build_norm_adj(U, I, rng.integers(0, U, 4000), rng.integers(0, I, 4000))  # D^-1 (A + I)
+    r, c = factor_edge_values(adj.indptr, adj.indices, adj.data)
+    row = np.repeat(np.arange(U + I), np.diff(adj.indptr))
+    assert np.allclose(r[row] * c[adj.indices], adj.data, rtol=3e-6, atol=0)
+    assert np.allclose(c, c[0]) and r.dtype == np.float32  # row-normalised: the column factor is constant
+    at = adj.T.tocsr()
+    at.sort_indices()
+    rt, ct = factor_edge_values(at.indptr, at.indices, at.data)
+    rowt = np.repeat(np.arange(U + I), np.diff(at.indptr))
+    assert np.allclose(rt[rowt] * ct[at.indices], at.data, rtol=3e-6, atol=0)
+    # symmetric normalisation, several components, empty rows
+    n = 400
+    a = sp.random(n, n, density=0.01, random_state=3, format="csr")
+    a.data[:] = 1.0
+    a = ((a + a.T) > 0).astype(np.float64).tolil()
+    a[50:60, :] = 0
+    a[:, 50:60] = 0
+    a = a.tocsr()
+    a.eliminate_zeros()
+    d = np.asarray(a.sum(1)).ravel()
+    dinv = np.where(d > 0, 1 / np.sqrt(np.maximum(d, 1)), 0)
+    sym = (sp.diags(dinv) @ a @ sp.diags(dinv)).tocsr().astype(np.float32)
+    sym.sort_indices()
+    rs, cs = factor_edge_values(sym.indptr, sym.indices, sym.data)
+    rows = np.repeat(np.arange(n), np.diff(sym.indptr))
+    assert np.allclose(rs[rows] * cs[sym.indices], sym.data, rtol=3e-6, atol=0)
+    # arbitrary values do not factor; neither does a graph with an explicit zero
+    rnd = sym.copy()
+    rnd.data = rng.random(rnd.nnz).astype(np.float32) + 0.5
+    assert factor_edge_values(rnd.indptr, rnd.indices, rnd.data) is None
+    z = sym.copy()
+    z.data[3] = 0
+    assert factor_edge_values(z.indptr, z.indices, z.data) is None
+    assert factor_edge_values(np.zeros(5, np.int64), np.zeros(0), np.zeros(0))[0].shape == (4,)
+    # the host builder carries the factors and points padding slots at the zero row n
+    h = sliced_graph_host(adj.indptr, adj.indices, adj.data, None, 8, 128)
+    assert "row_scale" in h and np.all(h["col16"][h["eid"] < 0] == U + I)
+    g = sliced_graph_host(adj.indptr, adj.indices, adj.data, None, 8, 128, factor=False)
+    assert "row_scale" not in g and np.all(g["col16"][g["eid"] < 0] == 0)
+    assert "row_scale" not in sliced_graph_host(rnd.indptr, rnd.indices, rnd.data, None, 8, 128)

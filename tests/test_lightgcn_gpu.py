@@ -84,24 +84,26 @@ def test_spmm_csr_vs_scipy(hip_device, dim):
     assert np.all(np.abs(y.cpu().numpy() - ref2) <= 64 * EPS32 * (abs(a).astype(np.float64) @ np.abs(x)) + 1e-6)
 
 
-def sliced_graph(rp, col, val, eid, n, nnz, dim, n_groups):
+def sliced_graph(rp, col, val, eid, n, nnz, dim, n_groups, factor=True):
     """hiprec_sliced_csr of a CSR already on the device, as LightGCN.graph() builds it (+ the arrays it points to)."""
     from beta_recsys_amd import _lib
     from beta_recsys_amd.lightgcn import sliced_graph_device, sliced_graph_host
 
     cap = _lib.load().hiprec_sliced_row_cap(n, dim)
     host = sliced_graph_host(rp.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy(),
-                             None if eid is None else eid.cpu().numpy(), n_groups, cap)
+                             None if eid is None else eid.cpu().numpy(), n_groups, cap, factor=factor)
     assert host is not None
     sc, hold = sliced_graph_device(host, n, n_groups, cap, "cuda")
     return sc, hold, host
 
 
+@pytest.mark.parametrize("factored", [False, True])
 @pytest.mark.parametrize("n,dim,width,n_groups", [(700, 64, 4, 16), (9746, 64, 4, 16), (10100, 100, 4, 3),
                                                   (15001, 32, 2, 7), (19000, 8, 2, 1), (500, 6, 2, 40)])
-def test_spmm_sliced_vs_scipy(hip_device, n, dim, width, n_groups):
+def test_spmm_sliced_vs_scipy(hip_device, n, dim, width, n_groups, factored):
     """The column-sliced SpMM (source slice in LDS, rows owned by one workgroup): forward graph and transposed graph
-    with the forward keep bytes, heavy and empty rows, every accumulate mode, the layout transposes."""
+    with the forward keep bytes, heavy and empty rows, every accumulate mode, the layout transposes; general values
+    (the step's stream = dropped values) and rank-one values (stream = dropped columns, scaled source / result)."""
     from beta_recsys_amd import _lib
     from beta_recsys_amd.lightgcn import _csr_from_coo
 
@@ -117,6 +119,11 @@ def test_spmm_sliced_vs_scipy(hip_device, n, dim, width, n_groups):
     a = sp.coo_matrix((rng.standard_normal(nnz).astype(np.float32), (rows, cols)), shape=(n, n)).tocsr()
     a.sum_duplicates()
     a.sort_indices()
+    if factored:  # val[i][j] = r[i] * c[j], as a degree-normalised adjacency has them
+        fr, fc = (rng.random(n).astype(np.float32) + 0.5 for _ in range(2))
+        co = a.tocoo()
+        a = sp.csr_matrix((fr[co.row] * fc[co.col], (co.row, co.col)), shape=(n, n))
+        a.sort_indices()
     co = a.tocoo()
     r64, c64 = torch.from_numpy(co.row.astype(np.int64)), torch.from_numpy(co.col.astype(np.int64))
     rp, c, v, _ = _csr_from_coo(r64, c64, torch.from_numpy(co.data), n, hip_device)
@@ -128,7 +135,7 @@ def test_spmm_sliced_vs_scipy(hip_device, n, dim, width, n_groups):
     xt = torch.from_numpy(x).cuda()
     st = _lib.stream_ptr(hip_device)
     xs = torch.full((n * dim,), 3.0, device="cuda")
-    _lib.check(lib.hiprec_to_sliced(_lib.ptr(xt), n, dim, width, _lib.ptr(xs), st))
+    _lib.check(lib.hiprec_to_sliced(_lib.ptr(xt), n, dim, width, None, _lib.ptr(xs), st))
     assert np.array_equal(xs.cpu().numpy().reshape(dim // width, n, width),
                           x.reshape(n, dim // width, width).transpose(1, 0, 2))
     back = torch.ones((n, dim), device="cuda")
@@ -137,39 +144,48 @@ def test_spmm_sliced_vs_scipy(hip_device, n, dim, width, n_groups):
     dropped = olg.apply_edge_dropout(a, keep, 0.6)
     for graph, (rowptr, col, val, eid) in (("a", (rp, c, v, None)), ("at", (rpt, ct, vt, eid_t))):
         sc, hold, host = sliced_graph(rowptr, col, val, eid, n, a.nnz, dim, n_groups)
+        assert ("col_scale" in host) == factored
         assert np.diff(host["sub_row"]).max() <= lib.hiprec_sliced_row_cap(n, dim)
         lens = np.diff(rowptr.cpu().numpy())
         assert host["n_chunks"] == int(((lens + 63) // 64).sum()) and host["n_slots"] == int(((lens + 15) // 16 * 16).sum())
-        dropped_vals = torch.full((host["n_slots"],), 9.0, device="cuda")
-        _lib.check(lib.hiprec_sliced_drop_values(ctypes.byref(sc), _lib.ptr(kt), _lib.ptr(dropped_vals), st))
+        step_edges = torch.full((host["n_slots"],), 9.0, device="cuda")
+        _lib.check(lib.hiprec_sliced_drop_values(ctypes.byref(sc), _lib.ptr(kt), _lib.ptr(step_edges), st))
+        cs = hold.get("col_scale")  # a factored graph takes col_scale (.) X and returns col_scale (.) Y
+        src = torch.empty_like(xs)
+        _lib.check(lib.hiprec_to_sliced(_lib.ptr(xt), n, dim, width, _lib.ptr(cs), _lib.ptr(src), st))
+        unscale = 1.0 if cs is None else 1.0 / cs.cpu().numpy().astype(np.float64)[:, None]
         m = dropped if graph == "a" else dropped.T.tocsr()
         ref = m.astype(np.float64) @ x.astype(np.float64)
         tol = 64 * EPS32 * (abs(m).astype(np.float64) @ np.abs(x).astype(np.float64)) + 1e-6
         ys = torch.full((n * dim,), 7.0, device="cuda")  # stale contents: every row is written by the kernel
         accs = xs.clone()
-        _lib.check(lib.hiprec_spmm_sliced(ctypes.byref(sc), _lib.ptr(dropped_vals), 1 / 0.6, _lib.ptr(xs),
+        _lib.check(lib.hiprec_spmm_sliced(ctypes.byref(sc), _lib.ptr(step_edges), 1 / 0.6, _lib.ptr(src),
                                           _lib.ptr(ys), _lib.ptr(accs), 1, dim, width, st))
         y = torch.empty((n, dim), device="cuda")
         _lib.check(lib.hiprec_from_sliced(_lib.ptr(ys), n, dim, width, _lib.ptr(y), 0, st))
-        assert np.all(np.abs(y.cpu().numpy() - ref) <= tol), graph
+        assert np.all(np.abs(y.cpu().numpy() * unscale - ref) <= tol), graph
         if graph == "a":
             assert np.all(y.cpu().numpy()[n - 39:] == 0), "empty rows are written as zeros"
         _lib.check(lib.hiprec_from_sliced(_lib.ptr(accs), n, dim, width, _lib.ptr(y), 0, st))
         assert np.all(np.abs(y.cpu().numpy() - x - ref) <= tol + 1e-6), graph
-        # no dropout, accs = ys
+        # no dropout, accs = Y
         m2 = a if graph == "a" else a.T.tocsr()
-        _lib.check(lib.hiprec_spmm_sliced(ctypes.byref(sc), None, 1.0, _lib.ptr(xs), _lib.ptr(ys), _lib.ptr(accs),
+        _lib.check(lib.hiprec_spmm_sliced(ctypes.byref(sc), None, 1.0, _lib.ptr(src), _lib.ptr(ys), _lib.ptr(accs),
                                           2, dim, width, st))
-        assert torch.equal(ys, accs)
-        _lib.check(lib.hiprec_from_sliced(_lib.ptr(ys), n, dim, width, _lib.ptr(y), 0, st))
+        if not factored:
+            assert torch.equal(ys, accs)
+        _lib.check(lib.hiprec_from_sliced(_lib.ptr(accs), n, dim, width, _lib.ptr(y), 0, st))
         ref2 = m2.astype(np.float64) @ x.astype(np.float64)
-        assert np.all(np.abs(y.cpu().numpy() - ref2) <= 64 * EPS32 * (abs(m2).astype(np.float64) @ np.abs(x)) + 1e-6)
+        tol2 = 64 * EPS32 * (abs(m2).astype(np.float64) @ np.abs(x)) + 1e-6
+        assert np.all(np.abs(y.cpu().numpy() - ref2) <= tol2)
+        _lib.check(lib.hiprec_from_sliced(_lib.ptr(ys), n, dim, width, _lib.ptr(y), 0, st))
+        assert np.all(np.abs(y.cpu().numpy() * unscale - ref2) <= tol2)
     with pytest.raises(RuntimeError, match="slice width"):
         _lib.check(lib.hiprec_spmm_sliced(ctypes.byref(sc), None, 1.0, _lib.ptr(xs), _lib.ptr(ys), None, 0, dim,
                                           width * 2 if width < 4 else 2, st))
 
 
-@pytest.mark.parametrize("spmm", ["auto", "gather"])
+@pytest.mark.parametrize("spmm", ["auto", "sliced_values", "gather"])
 @pytest.mark.parametrize("case", ["lightgcn_adam", "lightgcn_sgd_d64"])
 def test_lightgcn_step_matches_reference(hip_device, case, spmm):
     g = load_golden(case)
@@ -178,7 +194,9 @@ def test_lightgcn_step_matches_reference(hip_device, case, spmm):
     adj = golden_adj(g)
     torch.manual_seed(seed)
     eng = make_engine(U, I, D, L, opt, lr, B, adj, keep, decay, spmm=spmm)
-    assert (eng.model.graph()["slice_w"] > 0) == (spmm == "auto")
+    assert (eng.model.graph()["slice_w"] > 0) == (spmm != "gather")
+    if spmm != "gather":  # the reference's D^-1 (A + I) has rank-one values: 2-byte edge stream
+        assert ("col_scale" in eng.model.graph()["sliced"][1]) == (spmm == "auto")
     w_init = get_weights(eng)
     for k in w_init:  # same seed -> the reference's xavier init, bit for bit
         assert np.array_equal(w_init[k], g[f"w0/{k}"]), k
@@ -230,7 +248,7 @@ def ml1m_like_graph(seed=0, U=6040, I=3706, n_edges=1_000_000):
     return olg.build_norm_adj(U, I, eu, ei)
 
 
-@pytest.mark.parametrize("spmm", ["auto", "gather"])
+@pytest.mark.parametrize("spmm", ["auto", "sliced_values", "gather"])
 def test_lightgcn_full_size_c5_vs_oracle(hip_device, spmm):
     """BASELINE configs[4] shape: ~1M interactions (nnz ~2M), 3 layers, dim 64, batch 1024,
     device-side edge dropout (the mask is read back and given to the oracle); on the column-sliced SpMM (the graph's
@@ -239,7 +257,7 @@ def test_lightgcn_full_size_c5_vs_oracle(hip_device, spmm):
     adj = ml1m_like_graph()
     torch.manual_seed(3)
     eng = make_engine(U, I, D, L, "adam", 0.05, B, adj, dropout_rng="device", dropout_seed=11, spmm=spmm)
-    assert (eng.model.graph()["slice_w"] == 4) == (spmm == "auto")
+    assert (eng.model.graph()["slice_w"] == 4) == (spmm != "gather")
     w = get_weights(eng)
     rng = np.random.default_rng(1)
     batch = (rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B))

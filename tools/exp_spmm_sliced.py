@@ -1,5 +1,4 @@
-"""column-sliced SpMM against the L2 row-gather SpMM on the BASELINE configs[4] graph (forward and transposed),
-with the kernel's debug variants (HIPREC_SLICED_DBG: 1 = no LDS source reads, 2 = no edge loads)"""
+"""column-sliced SpMM against the L2 row-gather SpMM on the BASELINE configs[4] graph (forward and transposed)"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp, torch
@@ -42,16 +41,18 @@ csr = _lib.Csr(rp.data_ptr(), cc.data_ptr(), vv.data_ptr(), None, N, nnz, sl.dat
 print(f"gather SpMM   nnz {nnz}: {timed(lambda: _lib.check(lib.hiprec_spmm_csr(ctypes.byref(csr), None, 1.0, _lib.ptr(x), _lib.ptr(y), _lib.ptr(acc), D, st))):6.1f} us")
 W = lib.hiprec_sliced_width(N, D)
 cap = lib.hiprec_sliced_row_cap(N, D)
-for n_groups in (16, 32):
-    host = sliced_graph_host(rp.cpu().numpy(), cc.cpu().numpy(), vv.cpu().numpy(), None, n_groups, cap)
+for n_groups, factor in ((16, False), (16, True)):
+    host = sliced_graph_host(rp.cpu().numpy(), cc.cpu().numpy(), vv.cpu().numpy(), None, n_groups, cap, factor=factor)
     sc, hold = sliced_graph_device(host, N, n_groups, cap, dev)
     xs, ys, accs = (torch.zeros(N * D, device=dev) for _ in range(3))
-    _lib.check(lib.hiprec_to_sliced(_lib.ptr(x), N, D, W, _lib.ptr(xs), st))
+    _lib.check(lib.hiprec_to_sliced(_lib.ptr(x), N, D, W, None, _lib.ptr(xs), st))
     t = timed(lambda: _lib.check(lib.hiprec_spmm_sliced(ctypes.byref(sc), None, 1.0, _lib.ptr(xs), _lib.ptr(ys), _lib.ptr(accs), 1, D, W, st)))
-    print(f"sliced SpMM W {W} groups {n_groups} subs/group {host['subs_per_group']} chunks {host['n_chunks']} slots {host['n_slots']}: {t:6.1f} us"
-          f"  (dbg {os.environ.get('HIPREC_SLICED_DBG', '0')})", flush=True)
-    if os.environ.get("HIPREC_SLICED_DBG") == "9":
-        torch.cuda.synchronize()
-        t = ys[:96].cpu().numpy().reshape(6, 16)
-        for name, row in zip(("blk0 t0", "blk0 t1023", "blk100 t0", "blk100 t1023", "blk255 t0", "blk255 t1023"), t):
-            print(name, " ".join(f"{v:6.2f}" for v in row[:np.argmax(row < 0)]))
+    print(f"sliced SpMM W {W} factored {'col_scale' in host} groups {n_groups} subs/group {host['subs_per_group']} chunks {host['n_chunks']} slots {host['n_slots']}: {t:6.1f} us"
+          "", flush=True)
+    if "col_scale" in host:  # LDS conflict share: every slot reads the zero row (one address: broadcast) / a conflict-free pattern
+        z = torch.full((host["n_slots"],), N, dtype=torch.int16, device=dev)
+        t = timed(lambda: _lib.check(lib.hiprec_spmm_sliced(ctypes.byref(sc), _lib.ptr(z), 1.0, _lib.ptr(xs), _lib.ptr(ys), _lib.ptr(accs), 1, D, W, st)))
+        print(f"   all slots -> zero row (broadcast reads): {t:6.1f} us")
+        seq = (torch.arange(host["n_slots"], device=dev) // 16 % 9000).to(torch.int16)  # lane-constant columns, quads differ
+        t = timed(lambda: _lib.check(lib.hiprec_spmm_sliced(ctypes.byref(sc), _lib.ptr(seq), 1.0, _lib.ptr(xs), _lib.ptr(ys), _lib.ptr(accs), 1, D, W, st)))
+        print(f"   lane-constant consecutive rows (conflict-free): {t:6.1f} us")
