@@ -313,12 +313,14 @@ static float* sliced_buf(const hiprec_lightgcn_plan* p, int k) {
 
 // out (row-major) = [add] sum_{l = first .. L} G^l in, G = `graph`; the l = 0 term only when `with_input`.
 // in NULL: the input is already in sliced buffer 0 (scaled by graph->col_scale if the graph is factored);
-// out NULL: the result stays in sliced buffer 1.
+// out NULL: the result stays in sliced buffer 1.  clear_buf0: sliced buffer 0 is all zeros afterwards (the last pass
+// clears it on the way when it is not that pass's own source).
 static int propagate_sliced(const hiprec_lightgcn_plan* p, const hiprec_sliced_csr* graph, const uint8_t* keep,
                             float keep_prob, const float* in, float* out, bool with_input, bool add,
-                            hipStream_t st) {
+                            hipStream_t st, bool clear_buf0 = false) {
   const int64_t N = p->a.n_rows;
   const int D = p->dim, W = p->slice_w;
+  const int L = p->n_layers;
   const float scale = keep ? 1.0f / keep_prob : 1.0f;
   float* xs0 = sliced_buf(p, 0);
   float* accs = sliced_buf(p, 1);
@@ -326,7 +328,7 @@ static int propagate_sliced(const hiprec_lightgcn_plan* p, const hiprec_sliced_c
     if (int rc = launch_to_sliced(in, N, D, W, graph->col_scale, xs0, with_input ? accs : nullptr, st)) return rc;
   }
   const void* val = nullptr;
-  if (keep && p->n_layers > 0) {  // once per step and graph, not per pass
+  if (keep && L > 0) {  // once per step and graph, not per pass
     float* dropped = sliced_buf(p, 4) + (graph == &p->sat ? p->sa.n_slots : 0);
     if (!p->dropped_ready) {
       if (int rc = launch_step_values(graph, nullptr, const_cast<uint8_t*>(keep), false, keep_prob, 0, 0, dropped,
@@ -335,14 +337,20 @@ static int propagate_sliced(const hiprec_lightgcn_plan* p, const hiprec_sliced_c
     }
     val = dropped;
   }
+  // the last pass adds the finished layer sum to a row-major `out` itself (no transpose launch) when `out` is added to
+  const bool direct_out = out != nullptr && add && L > 0;
   const float* cur = xs0;
-  for (int l = 0; l < p->n_layers; ++l) {
+  for (int l = 0; l < L; ++l) {
     float* nxt = sliced_buf(p, 2 + (l & 1));
     const int mode = (l == 0 && !with_input) ? 2 : 1;
-    if (int rc = launch_spmm_sliced(graph, val, scale, cur, nxt, accs, mode, D, W, st)) return rc;
+    const bool last = l == L - 1;
+    if (int rc = launch_spmm_sliced(graph, val, scale, cur, nxt, accs, mode, D, W, st,
+                                    last && clear_buf0 && l > 0 ? xs0 : nullptr, last && direct_out ? out : nullptr))
+      return rc;
     cur = nxt;
   }
-  if (out == nullptr || (p->n_layers == 0 && !with_input)) return 0;
+  if (clear_buf0 && L < 2) HIPREC_TRY(hipMemsetAsync(xs0, 0, sizeof(float) * N * D, st));
+  if (out == nullptr || direct_out || (L == 0 && !with_input)) return 0;
   return launch_from_sliced(accs, N, D, W, out, add, st);
 }
 
@@ -451,8 +459,8 @@ extern "C" int hiprec_lightgcn_grad(const hiprec_lightgcn_plan* plan, const uint
     // everything between E0 and g stays in the sliced layout: E0 -> sliced, L passes, the loss kernel reads the
     // sliced layer sum and scatters d_out into sliced buffer 0 (free again after the first pass), L passes of the
     // transposed graph, and one transpose adds the result to g.  No output fills: the SpMM writes every row.
-    if (int rc = propagate_sliced(p, &p->sa, keep, keep_prob, p->e0, nullptr, true, false, st)) return rc;
-    HIPREC_TRY(hipMemsetAsync(sliced_buf(p, 0), 0, bytes, st));
+    if (int rc = propagate_sliced(p, &p->sa, keep, keep_prob, p->e0, nullptr, true, false, st, /*clear_buf0=*/true))
+      return rc;
     q.acc = sliced_buf(p, 1);
     q.da = sliced_buf(p, 0);
     lightgcn_loss_kernel<true><<<grid_for_waves(batch), kBlock, 0, st>>>(q, users, pos, neg, batch, inv_batch, stats,

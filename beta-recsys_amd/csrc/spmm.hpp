@@ -15,8 +15,11 @@ int launch_spmm(const hiprec_csr* a, const uint8_t* keep, float scale, const flo
 // values, or uint16 columns for a factored graph, whose source and result are scaled by col_scale).
 int sliced_width(int64_t n_rows, int dim);
 int sliced_row_cap(int64_t n_rows, int dim);
+// zero_out (sliced, may be NULL): cleared row by row as a by-product; final_out (row-major, may be NULL): instead
+// of writing ys / accs the pass adds the layer sum (accs + Y for acc_mode 1, Y otherwise) to it.
 int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scale, const float* xs, float* ys,
-                       float* accs, int acc_mode, int dim, int W, hipStream_t st);
+                       float* accs, int acc_mode, int dim, int W, hipStream_t st, float* zero_out = nullptr,
+                       float* final_out = nullptr);
 // dropped values of one step for one or two graphs in one launch; draw: the device draw keep_draw(seed, step, edge)
 // instead of reading keep[] (which `a`'s slots then fill in, when given)
 int launch_step_values(const hiprec_sliced_csr* a, const hiprec_sliced_csr* b, uint8_t* keep, bool draw,

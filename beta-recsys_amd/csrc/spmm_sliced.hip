@@ -101,7 +101,8 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
                                                                      const void* __restrict__ edges, float scale,
                                                                      const float* __restrict__ xs,
                                                                      float* __restrict__ ys, float* __restrict__ accs,
-                                                                     int acc_mode) {
+                                                                     int acc_mode, float* __restrict__ zero_out,
+                                                                     float* __restrict__ final_out, int dim) {
   using Vec = typename SlicedVec<W>::type;
   using LdsVec = const __attribute__((address_space(3))) Vec;
   using Pair = float __attribute__((ext_vector_type(2)));
@@ -246,9 +247,16 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
           y_next = y * a.col_scale[r];
         }
         s_y[i] = 0.f;
-        ys[out0 + i] = y_next;
-        if (acc_mode == 1) accs[out0 + i] = old[k] + y;
-        else if (acc_mode == 2) accs[out0 + i] = y;
+        if (final_out != nullptr) {  // last pass: the layer sum goes straight to the row-major result, added
+          const int r = r0 + (W == 4 ? i >> 2 : i >> 1);
+          float* dst = final_out + static_cast<int64_t>(r) * dim + s * W + (i & (W - 1));
+          *dst += old[k] + y;
+        } else {
+          ys[out0 + i] = y_next;
+          if (acc_mode == 1) accs[out0 + i] = old[k] + y;
+          else if (acc_mode == 2) accs[out0 + i] = y;
+        }
+        if (zero_out != nullptr) zero_out[out0 + i] = 0.f;
       }
     }
     __syncthreads();
@@ -264,26 +272,43 @@ __global__ __launch_bounds__(kBlock) void step_values_kernel(hiprec_sliced_csr a
                                                              uint8_t* __restrict__ keep, int draw, float keep_prob,
                                                              uint64_t seed, uint64_t step, float* __restrict__ out_a,
                                                              float* __restrict__ out_b) {
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock, total = a.n_slots + b.n_slots;
+  // eight consecutive slots per thread (n_slots is a multiple of 16): 16-byte loads and stores
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock, total = (a.n_slots + b.n_slots) >> 3;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += stride) {
-    const bool first = i < a.n_slots;
-    const int64_t e = first ? i : i - a.n_slots;
-    const int32_t k = first ? a.eid[e] : b.eid[e];
+    const bool first = (i << 3) < a.n_slots;
+    const int64_t e = first ? i << 3 : (i << 3) - a.n_slots;
     const hiprec_sliced_csr& gph = first ? a : b;
-    bool kept = false;
-    if (k >= 0) {
-      if (draw) {
-        kept = keep_draw(seed, step, k, keep_prob);
-        if (first && keep != nullptr) keep[k] = kept ? 1 : 0;
-      } else {
-        kept = keep[k] != 0;
+    const int4 k0 = *reinterpret_cast<const int4*>(gph.eid + e), k1 = *reinterpret_cast<const int4*>(gph.eid + e + 4);
+    const int32_t k[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+    bool kept[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      kept[j] = false;
+      if (k[j] >= 0) {
+        if (draw) {
+          kept[j] = keep_draw(seed, step, k[j], keep_prob);
+          if (first && keep != nullptr) keep[k[j]] = kept[j] ? 1 : 0;
+        } else {
+          kept[j] = keep[k[j]] != 0;
+        }
       }
     }
     float* out = first ? out_a : out_b;
-    if (gph.col_scale != nullptr)  // factored: a dropped edge points at the zero row
-      reinterpret_cast<uint16_t*>(out)[e] = kept ? gph.col16[e] : static_cast<uint16_t>(gph.n_rows);
-    else
-      out[e] = kept ? gph.val[e] : 0.f;
+    if (gph.col_scale != nullptr) {  // factored: a dropped edge points at the zero row
+      const uint4 c = *reinterpret_cast<const uint4*>(gph.col16 + e);
+      const uint32_t cw[4] = {c.x, c.y, c.z, c.w}, z = static_cast<uint32_t>(gph.n_rows);
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = (kept[2 * j] ? cw[j] & 0xFFFFu : z) | (kept[2 * j + 1] ? cw[j] & 0xFFFF0000u : z << 16);
+      *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(out) + e) = uint4{o[0], o[1], o[2], o[3]};
+    } else {
+      const float4 v0 = *reinterpret_cast<const float4*>(gph.val + e), v1 = *reinterpret_cast<const float4*>(gph.val + e + 4);
+      *reinterpret_cast<float4*>(out + e) =
+          float4{kept[0] ? v0.x : 0.f, kept[1] ? v0.y : 0.f, kept[2] ? v0.z : 0.f, kept[3] ? v0.w : 0.f};
+      *reinterpret_cast<float4*>(out + e + 4) =
+          float4{kept[4] ? v1.x : 0.f, kept[5] ? v1.y : 0.f, kept[6] ? v1.z : 0.f, kept[7] ? v1.w : 0.f};
+    }
   }
 }
 
@@ -334,7 +359,8 @@ int sliced_row_cap(int64_t n_rows, int dim) {
 }
 
 int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scale, const float* xs, float* ys,
-                       float* accs, int acc_mode, int dim, int W, hipStream_t st) {
+                       float* accs, int acc_mode, int dim, int W, hipStream_t st, float* zero_out,
+                       float* final_out) {
   HIPREC_REQUIRE(a && a->sub_row && a->sub_chunk && a->n_rows > 0 && a->n_groups > 0 && a->subs_per_group > 0,
                  "bad sliced graph");
   HIPREC_REQUIRE(a->n_slots == 0 || (a->col16 && a->val && a->chunks), "sliced graph has NULL chunks / col16 / val");
@@ -360,13 +386,17 @@ int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scal
   if (edges == nullptr) edges = factored ? static_cast<const void*>(a->col16) : static_cast<const void*>(a->val);
   const int grid = (dim / W) * a->n_groups;
   if (W == 4 && factored)
-    spmm_sliced_kernel<4, true><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode);
+    spmm_sliced_kernel<4, true><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, zero_out,
+                                                                   final_out, dim);
   else if (W == 4)
-    spmm_sliced_kernel<4, false><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode);
+    spmm_sliced_kernel<4, false><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, zero_out,
+                                                                   final_out, dim);
   else if (factored)
-    spmm_sliced_kernel<2, true><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode);
+    spmm_sliced_kernel<2, true><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, zero_out,
+                                                                   final_out, dim);
   else
-    spmm_sliced_kernel<2, false><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode);
+    spmm_sliced_kernel<2, false><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, zero_out,
+                                                                   final_out, dim);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
@@ -379,8 +409,9 @@ int launch_step_values(const hiprec_sliced_csr* a, const hiprec_sliced_csr* b, u
   HIPREC_REQUIRE(b->n_slots == 0 || (b->val && b->eid && out_b), "bad second sliced graph");
   HIPREC_REQUIRE(draw || keep, "keep bytes needed");
   if (a->n_slots + b->n_slots == 0) return 0;
-  step_values_kernel<<<grid_for_threads(a->n_slots + b->n_slots), kBlock, 0, st>>>(*a, *b, keep, draw ? 1 : 0, keep_prob,
-                                                                                   seed, step, out_a, out_b);
+  HIPREC_REQUIRE(a->n_slots % 16 == 0 && b->n_slots % 16 == 0, "n_slots is not a multiple of 16");
+  step_values_kernel<<<grid_for_threads((a->n_slots + b->n_slots) / 8), kBlock, 0, st>>>(
+      *a, *b, keep, draw ? 1 : 0, keep_prob, seed, step, out_a, out_b);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
@@ -427,5 +458,5 @@ extern "C" int hiprec_spmm_sliced(const hiprec_sliced_csr* a, const void* step_e
                                   float* ys, float* accs, int32_t acc_mode, int32_t dim, int32_t slice_w,
                                   void* stream) {
   return launch_spmm_sliced(a, step_edges, scale, xs, ys, accs, acc_mode, dim, slice_w,
-                            static_cast<hipStream_t>(stream));
+                            static_cast<hipStream_t>(stream), nullptr, nullptr);
 }

@@ -294,11 +294,22 @@ class LightGCN(_FlatModel):
             raise ValueError(f"unknown dropout_rng {self.dropout_rng!r}: 'torch_cpu' or 'device'")
         if sliced:
             plan = self.plan()
-            _lib.check(lib.hiprec_lightgcn_step_values(ctypes.byref(plan), _lib.ptr(ws["keep"]), keep_prob,
-                                                       1 if self.dropout_rng == "device" else 0, self.dropout_seed,
+            device_draw = self.dropout_rng == "device"  # the draw is folded into the launch; no keep bytes written
+            _lib.check(lib.hiprec_lightgcn_step_values(ctypes.byref(plan), None if device_draw else _lib.ptr(ws["keep"]),
+                                                       keep_prob, 1 if device_draw else 0, self.dropout_seed,
                                                        self._step, st))
             self._dropped_ready = True
         return ws["keep"]
+
+    def last_keep_mask(self):
+        """Keep bytes (uint8 [nnz], forward CSR order) of the last training step's edge dropout.  With the device
+        draw on the sliced path nothing materialises them during the step: the stateless draw is repeated here."""
+        ws, gr = self.workspace(), self.graph()
+        if self.dropout_rng == "device" and gr.get("slice_w", 0) > 0:
+            _lib.check(self._require_hip().hiprec_edge_dropout_mask(
+                _lib.ptr(ws["keep"]), gr["nnz"], float(self.config["keep_pro"]), self.dropout_seed, self._step,
+                _lib.stream_ptr(self._flat.device)))
+        return ws["keep"][: gr["nnz"]]
 
     # ---- reference API ---------------------------------------------------------------------
     def forward(self, norm_adj=None):

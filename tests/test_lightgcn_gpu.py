@@ -206,7 +206,7 @@ def test_lightgcn_step_matches_reference(hip_device, case, spmm):
         load_weights(eng, params(g, f"w{s}"))
         torch.manual_seed(1000 + s)
         loss, grads = eng.backward_only(batch)
-        kept = eng.model._ws["keep"][: int(g["nnz"])].cpu().numpy().astype(bool)
+        kept = eng.model.last_keep_mask().cpu().numpy().astype(bool)
         assert np.array_equal(kept, golden_mask(g, s)), "same seed must drop the same edges"
         assert_scalar_close(loss, g["losses"][s], what=f"loss step {s}")
         for k in olg.KEYS:
@@ -262,7 +262,7 @@ def test_lightgcn_full_size_c5_vs_oracle(hip_device, spmm):
     rng = np.random.default_rng(1)
     batch = (rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B))
     loss, grads = eng.backward_only(tuple(torch.from_numpy(a) for a in batch))
-    keep = eng.model._ws["keep"][: adj.nnz].cpu().numpy().astype(bool)
+    keep = eng.model.last_keep_mask().cpu().numpy().astype(bool)
     assert abs(keep.mean() - 0.6) < 0.005, keep.mean()
     dropped = olg.apply_edge_dropout(adj, keep, 0.6)
     loss_ref, g_ref = olg.lightgcn_grads(w, dropped, L, *batch, 1e-5)
@@ -271,7 +271,7 @@ def test_lightgcn_full_size_c5_vs_oracle(hip_device, spmm):
         assert_tensor_close(grads[k].cpu().numpy(), g_ref[k], 2e-5, f"grad {k}")
     eng2_mask_a = keep.copy()
     eng.backward_only(tuple(torch.from_numpy(a) for a in batch))
-    keep_b = eng.model._ws["keep"][: adj.nnz].cpu().numpy().astype(bool)
+    keep_b = eng.model.last_keep_mask().cpu().numpy().astype(bool)
     assert (eng2_mask_a != keep_b).mean() > 0.3, "a fresh mask every step"
     scores = eng.model.predict(batch[0][:500], batch[1][:500]).cpu().numpy()
     assert_tensor_close(scores, olg.lightgcn_predict(w, adj, L, batch[0][:500], batch[1][:500]), 1e-5, "scores")
