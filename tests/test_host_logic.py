@@ -883,3 +883,30 @@ def test_factor_edge_values():
     g = sliced_graph_host(adj.indptr, adj.indices, adj.data, None, 8, 128, factor=False)
     assert "row_scale" not in g and np.all(g["col16"][g["eid"] < 0] == 0)
     assert "row_scale" not in sliced_graph_host(rnd.indptr, rnd.indices, rnd.data, None, 8, 128)
+
+
+def test_spread_bank_conflicts_only_reorders_inside_lane_segments():
+    """The LDS bank-conflict permutation of a sliced graph: every 16-slot lane segment keeps its multiset of
+    (column, value, keep index) -- sums are unchanged -- and the simulated conflict ways go down."""
+    from beta_recsys_amd.lightgcn import sliced_graph_host, spread_bank_conflicts
+    from oracle import lightgcn_numpy as olg
+
+    rng = np.random.default_rng(9)
+    U, I = 1500, 900
+    adj = olg.build_norm_adj(U, I, rng.integers(0, U, 120_000), rng.integers(0, I, 120_000))
+    for factor in (True, False):
+        h = sliced_graph_host(adj.indptr, adj.indices, adj.data, None, 16, 256, factor=factor)
+        ref = {k: h[k].copy() for k in ("col16", "val", "eid")}
+        before, after = spread_bank_conflicts(h, 16)
+        assert after < 0.8 * before and after >= 1.0, (before, after)
+        key_new = np.stack([h["col16"].astype(np.int64), h["eid"].astype(np.int64)], 1).reshape(-1, 16, 2)
+        key_old = np.stack([ref["col16"].astype(np.int64), ref["eid"].astype(np.int64)], 1).reshape(-1, 16, 2)
+        order_new = np.lexsort((key_new[:, :, 1], key_new[:, :, 0]), axis=1)
+        order_old = np.lexsort((key_old[:, :, 1], key_old[:, :, 0]), axis=1)
+        assert np.array_equal(np.take_along_axis(key_new, order_new[:, :, None], 1),
+                              np.take_along_axis(key_old, order_old[:, :, None], 1))
+        # values travel with their slots
+        by_eid_new = dict(zip(h["eid"][h["eid"] >= 0].tolist(), h["val"][h["eid"] >= 0].tolist()))
+        by_eid_old = dict(zip(ref["eid"][ref["eid"] >= 0].tolist(), ref["val"][ref["eid"] >= 0].tolist()))
+        assert by_eid_new == by_eid_old
+        assert not np.array_equal(h["col16"], ref["col16"])

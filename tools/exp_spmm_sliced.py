@@ -3,7 +3,8 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp, torch
 from beta_recsys_amd import _lib
-from beta_recsys_amd.lightgcn import _csr_from_coo, _slice_rows, sliced_graph_device, sliced_graph_host
+from beta_recsys_amd.lightgcn import (_csr_from_coo, _slice_rows, sliced_graph_device, sliced_graph_host,
+                                      spread_bank_conflicts)
 from oracle import lightgcn_numpy as olg
 
 U, I, D = 6040, 3706, 64
@@ -41,8 +42,10 @@ csr = _lib.Csr(rp.data_ptr(), cc.data_ptr(), vv.data_ptr(), None, N, nnz, sl.dat
 print(f"gather SpMM   nnz {nnz}: {timed(lambda: _lib.check(lib.hiprec_spmm_csr(ctypes.byref(csr), None, 1.0, _lib.ptr(x), _lib.ptr(y), _lib.ptr(acc), D, st))):6.1f} us")
 W = lib.hiprec_sliced_width(N, D)
 cap = lib.hiprec_sliced_row_cap(N, D)
-for n_groups, factor in ((16, False), (16, True)):
+for n_groups, factor, spread in ((16, False, False), (16, True, False), (16, True, True)):
     host = sliced_graph_host(rp.cpu().numpy(), cc.cpu().numpy(), vv.cpu().numpy(), None, n_groups, cap, factor=factor)
+    if spread:
+        print("bank-conflict ways before / after the slot permutation: %.2f / %.2f" % spread_bank_conflicts(host, n_groups))
     sc, hold = sliced_graph_device(host, N, n_groups, cap, dev)
     xs, ys, accs = (torch.zeros(N * D, device=dev) for _ in range(3))
     _lib.check(lib.hiprec_to_sliced(_lib.ptr(x), N, D, W, None, _lib.ptr(xs), st))
