@@ -133,7 +133,9 @@ class NgcfPlan(Structure):
                    ("keep_step", ctypes.c_uint64), ("keep_gen", c_int32), ("_pad", c_int32),
                    ("d_all", c_void_p), ("d_sum", c_void_p), ("d_bi", c_void_p), ("d_side", c_void_p),
                    ("d_bi_in", c_void_p), ("d_ego", c_void_p * 2), ("spmm_tmp", c_void_p * NGCF_MAX_LAYERS),
-                   ("zero_ws", c_void_p), ("zero_ws_floats", c_int64)])
+                   ("zero_ws", c_void_p), ("zero_ws_floats", c_int64), ("sa", SlicedCsr), ("sat", SlicedCsr),
+                   ("slice_w", c_int32), ("_pad2", c_int32), ("sliced_src", c_void_p),
+                   ("sliced_src_floats", c_int64)])
 
 
 class FusedStep(Structure):

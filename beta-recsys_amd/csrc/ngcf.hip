@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kBlock) void ngcf_act_kernel(const float* __restric
                                                           float* __restrict__ ego_out,
                                                           float* __restrict__ nrm_out,
                                                           float* __restrict__ all, int ld_all, int off,
-                                                          int64_t n_rows, int d) {
+                                                          int64_t n_rows, int d, SlicedOut next_src) {
   const int lane = lane_id();
   for (int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block(); r < n_rows;
        r += static_cast<int64_t>(gridDim.x) * kWavesPerBlock) {
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(kBlock) void ngcf_act_kernel(const float* __restric
         }
         x[k] = v;
         ego_out[i] = v;
+        next_src.put(r, c, v);  // the next hop's sliced SpMM source
       }
       sq += x[k] * x[k];
     }
@@ -201,13 +202,16 @@ __global__ __launch_bounds__(kBlock) void ngcf_bi_bwd_kernel(const float* __rest
                                                              const float* __restrict__ side,
                                                              const float* __restrict__ ego,
                                                              float* __restrict__ d_ego,
-                                                             float* __restrict__ d_side, int64_t n) {
+                                                             float* __restrict__ d_side, int64_t n, int d,
+                                                             SlicedOut spmm_src) {
   const int64_t tid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t i = tid; i < n; i += stride) {
     const float g = d_bi_in[i];
     if (ACCUMULATE) d_ego[i] += g * side[i]; else d_ego[i] = g * side[i];
-    d_side[i] += g * ego[i];
+    const float ds = d_side[i] + g * ego[i];
+    d_side[i] = ds;
+    if (spmm_src.xs != nullptr) spmm_src.put(i / d, static_cast<int>(i % d), ds);  // source of the transposed SpMM
   }
 }
 
@@ -287,17 +291,49 @@ inline int check_ngcf_plan(const hiprec_ngcf_plan* p, bool train) {
   return 0;
 }
 
+// The column-sliced SpMM (spmm_sliced.hip) serves a hop when the plan carries the sliced graphs and every hop's input
+// width takes the plan's slice width.  Its source is written in the sliced layout by whoever produces it (the
+// activation kernel of the previous hop, the bilinear backward kernel; one transpose launch for e0) and its result
+// goes straight to the row-major buffer the GEMMs read: no atomics, no zero fills of SpMM outputs.
+inline bool ngcf_sliced(const hiprec_ngcf_plan* p) {
+  if (p->sliced_src == nullptr || p->slice_w <= 0) return false;
+  for (int l = 0; l < p->n_layers; ++l)
+    if (sliced_width(p->n_users + p->n_items, p->dim[l]) != p->slice_w) return false;
+  return true;
+}
+
+inline SlicedOut ngcf_sliced_out(const hiprec_ngcf_plan* p, const hiprec_sliced_csr* graph) {
+  SlicedOut o;
+  o.xs = p->sliced_src;
+  o.col_scale = graph->col_scale;
+  o.n_rows = p->n_users + p->n_items;
+  o.w_shift = p->slice_w == 4 ? 2 : 1;
+  return o;
+}
+
 // NGCF.forward: fills the per-hop workspaces and `all`.  keep bytes are used only when train.
 inline int ngcf_forward(const hiprec_ngcf_plan* p, bool train, hipStream_t st) {
   const int64_t N = p->n_users + p->n_items;
   const int dt = total_width(p);
+  const bool sliced = ngcf_sliced(p);
   const bool zeroed = p->zero_ws != nullptr;  // ONE fill for every SpMM output (+ d_all) of the step
-  if (zeroed) HIPREC_TRY(hipMemsetAsync(p->zero_ws, 0, sizeof(float) * p->zero_ws_floats, st));
+  if (zeroed && sliced) HIPREC_TRY(hipMemsetAsync(p->d_all, 0, sizeof(float) * N * dt, st));  // (only the loss scatters)
+  else if (zeroed) HIPREC_TRY(hipMemsetAsync(p->zero_ws, 0, sizeof(float) * p->zero_ws_floats, st));
   const float* ego = p->e0;
   int off = p->dim[0];
+  if (sliced) {
+    if (int rc = launch_to_sliced(p->e0, N, p->dim[0], p->slice_w, p->sa.col_scale, p->sliced_src, nullptr, st))
+      return rc;
+  }
   for (int l = 0; l < p->n_layers; ++l) {
     const int di = p->dim[l], dout = p->dim[l + 1];
-    if (int rc = launch_spmm(&p->a, nullptr, 1.0f, ego, p->side[l], nullptr, di, st, zeroed)) return rc;
+    if (sliced) {
+      if (int rc = launch_spmm_sliced(&p->sa, nullptr, 1.0f, p->sliced_src, nullptr, nullptr, 0, di, p->slice_w, st,
+                                      nullptr, p->side[l], /*final_set=*/true))
+        return rc;
+    } else if (int rc = launch_spmm(&p->a, nullptr, 1.0f, ego, p->side[l], nullptr, di, st, zeroed)) {
+      return rc;
+    }
     ngcf_bi_mul_kernel<<<grid_for_threads((N * di + 3) / 4), kBlock, 0, st>>>(ego, p->side[l], p->bi_in[l],
                                                                              N * di);
     HIPREC_TRY(hipGetLastError());
@@ -311,7 +347,9 @@ inline int ngcf_forward(const hiprec_ngcf_plan* p, bool train, hipStream_t st) {
     uint8_t* keep = train ? p->keep[l] : nullptr;
     const KeepGen gen{p->keep_gen, p->keep_prob[l], p->keep_seed * 64 + static_cast<uint64_t>(l), p->keep_step};
     ngcf_act_kernel<<<grid_for_waves(N), kBlock, 0, st>>>(p->sum_pre[l], p->bi_pre[l], keep, p->keep_scale[l],
-                                                         gen, p->ego[l], p->nrm[l], p->all, dt, off, N, dout);
+                                                         gen, p->ego[l], p->nrm[l], p->all, dt, off, N, dout,
+                                                         sliced && l + 1 < p->n_layers ? ngcf_sliced_out(p, &p->sa)
+                                                                                       : SlicedOut{});
     HIPREC_TRY(hipGetLastError());
     ego = p->ego[l];
     off += dout;
@@ -361,6 +399,7 @@ extern "C" int hiprec_ngcf_grad(const hiprec_ngcf_plan* plan, const int64_t* use
   const int64_t N = p->n_users + p->n_items;
   const int dt = total_width(p);
   if (int rc = ngcf_forward(p, true, st)) return rc;
+  const bool sliced = ngcf_sliced(p);
   if (!p->zero_ws) HIPREC_TRY(hipMemsetAsync(p->d_all, 0, sizeof(float) * N * dt, st));
   ngcf_loss_kernel<<<grid_for_waves(batch > 0 ? batch : 1), kBlock, 0, st>>>(
       p->e0, p->g_e0, p->dim[0], p->all, p->d_all, dt, p->n_users, p->n_items, users, pos, neg, batch, inv_batch,
@@ -393,16 +432,23 @@ extern "C" int hiprec_ngcf_grad(const hiprec_ngcf_plan* plan, const int64_t* use
     if (int rc = launch_group(g, st)) return rc;
     // hop 0 hands its result to the embedding gradient itself (which already holds the loss's share)
     float* d_ego = l == 0 ? p->g_e0 : p->d_ego[l & 1];
+    const SlicedOut src = sliced ? ngcf_sliced_out(p, &p->sat) : SlicedOut{};
     if (l == 0)
       ngcf_bi_bwd_kernel<true><<<grid_for_threads(N * di), kBlock, 0, st>>>(p->d_bi_in, p->side[l], ego_in, d_ego,
-                                                                           p->d_side, N * di);
+                                                                           p->d_side, N * di, di, src);
     else
       ngcf_bi_bwd_kernel<false><<<grid_for_threads(N * di), kBlock, 0, st>>>(p->d_bi_in, p->side[l], ego_in, d_ego,
-                                                                            p->d_side, N * di);
+                                                                            p->d_side, N * di, di, src);
     HIPREC_TRY(hipGetLastError());
     // d_ego += A^T d_side
-    if (int rc = launch_spmm(&p->at, nullptr, 1.0f, p->d_side, p->spmm_tmp[l], d_ego, di, st, p->zero_ws != nullptr))
+    if (sliced) {
+      if (int rc = launch_spmm_sliced(&p->sat, nullptr, 1.0f, p->sliced_src, nullptr, nullptr, 0, di, p->slice_w, st,
+                                      nullptr, d_ego, /*final_set=*/false))
+        return rc;
+    } else if (int rc = launch_spmm(&p->at, nullptr, 1.0f, p->d_side, p->spmm_tmp[l], d_ego, di, st,
+                                    p->zero_ws != nullptr)) {
       return rc;
+    }
     d_next = d_ego;
   }
   return 0;

@@ -16,10 +16,23 @@ int launch_spmm(const hiprec_csr* a, const uint8_t* keep, float scale, const flo
 int sliced_width(int64_t n_rows, int dim);
 int sliced_row_cap(int64_t n_rows, int dim);
 // zero_out (sliced, may be NULL): cleared row by row as a by-product; final_out (row-major, may be NULL): instead
-// of writing ys / accs the pass adds the layer sum (accs + Y for acc_mode 1, Y otherwise) to it.
+// of writing ys / accs the pass adds (final_set: stores) the layer sum (accs + Y for acc_mode 1, Y otherwise) there.
 int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scale, const float* xs, float* ys,
                        float* accs, int acc_mode, int dim, int W, hipStream_t st, float* zero_out = nullptr,
-                       float* final_out = nullptr);
+                       float* final_out = nullptr, bool final_set = false);
+
+// optional second output of an elementwise producer: the same rows in the sliced layout, times col_scale[row]
+struct SlicedOut {
+  float* xs = nullptr;
+  const float* col_scale = nullptr;
+  int64_t n_rows = 0;
+  int w_shift = 0;
+  __device__ __forceinline__ void put(int64_t r, int c, float v) const {
+    if (xs == nullptr) return;
+    const int64_t o = ((static_cast<int64_t>(c >> w_shift) * n_rows + r) << w_shift) + (c & ((1 << w_shift) - 1));
+    xs[o] = col_scale ? v * col_scale[r] : v;
+  }
+};
 // dropped values of one step for one or two graphs in one launch; draw: the device draw keep_draw(seed, step, edge)
 // instead of reading keep[] (which `a`'s slots then fill in, when given)
 int launch_step_values(const hiprec_sliced_csr* a, const hiprec_sliced_csr* b, uint8_t* keep, bool draw,

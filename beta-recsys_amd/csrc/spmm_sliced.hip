@@ -102,7 +102,8 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
                                                                      const float* __restrict__ xs,
                                                                      float* __restrict__ ys, float* __restrict__ accs,
                                                                      int acc_mode, float* __restrict__ zero_out,
-                                                                     float* __restrict__ final_out, int dim) {
+                                                                     float* __restrict__ final_out, int final_set,
+                                                                     int dim) {
   using Vec = typename SlicedVec<W>::type;
   using LdsVec = const __attribute__((address_space(3))) Vec;
   using Pair = float __attribute__((ext_vector_type(2)));
@@ -247,10 +248,11 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
           y_next = y * a.col_scale[r];
         }
         s_y[i] = 0.f;
-        if (final_out != nullptr) {  // last pass: the layer sum goes straight to the row-major result, added
+        if (final_out != nullptr) {  // the result (plus the layer sum so far, acc_mode 1) goes straight to row-major
           const int r = r0 + (W == 4 ? i >> 2 : i >> 1);
           float* dst = final_out + static_cast<int64_t>(r) * dim + s * W + (i & (W - 1));
-          *dst += old[k] + y;
+          if (final_set) *dst = old[k] + y;
+          else *dst += old[k] + y;
         } else {
           ys[out0 + i] = y_next;
           if (acc_mode == 1) accs[out0 + i] = old[k] + y;
@@ -360,7 +362,7 @@ int sliced_row_cap(int64_t n_rows, int dim) {
 
 int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scale, const float* xs, float* ys,
                        float* accs, int acc_mode, int dim, int W, hipStream_t st, float* zero_out,
-                       float* final_out) {
+                       float* final_out, bool final_set) {
   HIPREC_REQUIRE(a && a->sub_row && a->sub_chunk && a->n_rows > 0 && a->n_groups > 0 && a->subs_per_group > 0,
                  "bad sliced graph");
   HIPREC_REQUIRE(a->n_slots == 0 || (a->col16 && a->val && a->chunks), "sliced graph has NULL chunks / col16 / val");
@@ -371,7 +373,7 @@ int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scal
   HIPREC_REQUIRE(a->row_cap > 0 && a->row_cap <= sliced_row_cap(a->n_rows, dim),
                  "subgroups of up to %d rows do not fit the LDS next to the slice (at most %d)", a->row_cap,
                  sliced_row_cap(a->n_rows, dim));
-  HIPREC_REQUIRE(xs && ys && (acc_mode == 0 || accs), "NULL sliced buffers");
+  HIPREC_REQUIRE(xs && (ys || final_out) && (acc_mode == 0 || accs), "NULL sliced buffers");
   const size_t lds = static_cast<size_t>(a->n_rows + 1 + a->row_cap) * W * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -387,16 +389,16 @@ int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scal
   const int grid = (dim / W) * a->n_groups;
   if (W == 4 && factored)
     spmm_sliced_kernel<4, true><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, zero_out,
-                                                                   final_out, dim);
+                                                                   final_out, final_set ? 1 : 0, dim);
   else if (W == 4)
     spmm_sliced_kernel<4, false><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, zero_out,
-                                                                   final_out, dim);
+                                                                   final_out, final_set ? 1 : 0, dim);
   else if (factored)
     spmm_sliced_kernel<2, true><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, zero_out,
-                                                                   final_out, dim);
+                                                                   final_out, final_set ? 1 : 0, dim);
   else
     spmm_sliced_kernel<2, false><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, zero_out,
-                                                                   final_out, dim);
+                                                                   final_out, final_set ? 1 : 0, dim);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
@@ -458,5 +460,5 @@ extern "C" int hiprec_spmm_sliced(const hiprec_sliced_csr* a, const void* step_e
                                   float* ys, float* accs, int32_t acc_mode, int32_t dim, int32_t slice_w,
                                   void* stream) {
   return launch_spmm_sliced(a, step_edges, scale, xs, ys, accs, acc_mode, dim, slice_w,
-                            static_cast<hipStream_t>(stream), nullptr, nullptr);
+                            static_cast<hipStream_t>(stream), nullptr, nullptr, false);
 }

@@ -239,6 +239,32 @@ def sliced_graph_device(host, n_rows, n_groups, row_cap, device):
     return sc, hold
 
 
+def build_sliced_graphs(csr, csr_t, order_t, n, dim, dev, mode="auto"):
+    """{"slice_w": W, "sliced": (SlicedCsr, tensors), "sliced_t": ..., "n_groups", "row_cap"} for a graph and its
+    transpose (device CSR triples; order_t: forward edge number of every transposed edge), or {"slice_w": 0} when the
+    column-sliced SpMM (csrc/spmm_sliced.hip) does not apply: 65 536 nodes or more, a slice that does not fit the
+    LDS, mode "gather".  mode "sliced_values" keeps the edge values in the stream (no rank-one factoring)."""
+    if mode not in ("auto", "gather", "sliced_values"):
+        raise ValueError(f"unknown spmm mode {mode!r}")
+    lib = _lib.load()
+    w = int(lib.hiprec_sliced_width(n, dim)) if mode != "gather" else 0
+    out = {"slice_w": 0}
+    if w == 0:
+        return out
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    n_groups = max(8, n_cu // (dim // w) // 8 * 8)  # one (slice, row group) per CU; same row group -> same XCD
+    cap = int(lib.hiprec_sliced_row_cap(n, dim))
+    for tag, (rowptr, col, val), eid in (("", csr, None), ("_t", csr_t, order_t)):
+        host = sliced_graph_host(rowptr.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy(),
+                                 None if eid is None else eid.cpu().numpy(), n_groups, cap, factor=mode == "auto")
+        if host is None:
+            return {"slice_w": 0}
+        spread_bank_conflicts(host, n_groups)
+        out["sliced" + tag] = sliced_graph_device(host, n, n_groups, cap, dev)
+    out.update(slice_w=w, n_groups=n_groups, row_cap=cap)
+    return out
+
+
 class LightGCN(_FlatModel):
     """models/lightgcn.py:7-101."""
 
@@ -291,28 +317,8 @@ class LightGCN(_FlatModel):
         if dev.type == "cuda":
             self._graph["slice_row"] = _slice_rows(rp, c, v, N, nnz)
             self._graph["slice_row_t"] = _slice_rows(rpt, ct, vt, N, nnz)
-            # graphs whose node count fits the LDS take the column-sliced SpMM (csrc/spmm_sliced.hip): 16-bit column
-            # ids and row groups of equal edge count, one (slice, row group) per compute unit
-            lib = _lib.load()
-            mode = self.config.get("spmm", "auto")  # "gather": the edge-parallel SpMM; "sliced_values": no factoring
-            if mode not in ("auto", "gather", "sliced_values"):
-                raise ValueError(f"unknown spmm mode {mode!r}")
-            w = int(lib.hiprec_sliced_width(N, self.emb_dim)) if mode != "gather" else 0
-            if w > 0:
-                n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-                n_groups = max(8, n_cu // (self.emb_dim // w) // 8 * 8)  # same row group -> same XCD
-                cap = int(lib.hiprec_sliced_row_cap(N, self.emb_dim))
-                for tag, rowptr, col, val, eid in (("", rp, c, v, None), ("_t", rpt, ct, vt, order_t)):
-                    host = sliced_graph_host(rowptr.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy(),
-                                             None if eid is None else eid.cpu().numpy(), n_groups, cap,
-                                             factor=mode == "auto")
-                    if host is None:
-                        w = 0
-                        break
-                    spread_bank_conflicts(host, n_groups)
-                    self._graph["sliced" + tag] = sliced_graph_device(host, N, n_groups, cap, dev)
-                self._graph["n_groups"], self._graph["row_cap"] = n_groups, cap
-            self._graph["slice_w"] = w
+            self._graph.update(build_sliced_graphs((rp, c, v), (rpt, ct, vt), order_t, N, self.emb_dim, dev,
+                                                   self.config.get("spmm", "auto")))
         return self._graph
 
     def workspace(self):

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .lightgcn import _csr_from_coo, _slice_rows
+from .lightgcn import _csr_from_coo, _slice_rows, build_sliced_graphs
 from .mf import _new_stats, raise_on_status, read_stats
 from .ncf import _FlatModel, _init_linear_like_torch, _ParamView
 from .flat_engine import FlatModelEngine
@@ -87,13 +87,20 @@ class NGCF(_FlatModel):
         rows, cols = co.indices()[0], co.indices()[1]
         vals = co.values().to(torch.float32)
         rp, c, v, _ = _csr_from_coo(rows, cols, vals, N, dev)
-        rpt, ct, vt, _ = _csr_from_coo(cols, rows, vals, N, dev)
+        rpt, ct, vt, order_t = _csr_from_coo(cols, rows, vals, N, dev)
         nnz = int(vals.numel())
         self._graph = {"dev": dev, "nnz": nnz, "rowptr": rp, "col": c, "val": v,
                        "rowptr_t": rpt, "col_t": ct, "val_t": vt}
         if dev.type == "cuda":
             self._graph["slice_row"] = _slice_rows(rp, c, v, N, nnz)
             self._graph["slice_row_t"] = _slice_rows(rpt, ct, vt, N, nnz)
+            # the column-sliced SpMM serves the hops when every hop's input width takes one slice width
+            dims = self.layer_size[: self.n_layers]
+            lib = _lib.load()
+            widths = {int(lib.hiprec_sliced_width(N, d)) for d in dims}
+            mode = self.config["spmm"] if "spmm" in self.config else "auto"
+            if len(widths) == 1 and 0 not in widths:
+                self._graph.update(build_sliced_graphs((rp, c, v), (rpt, ct, vt), order_t, N, max(dims), dev, mode))
         return self._graph
 
     def workspace(self):
@@ -116,7 +123,7 @@ class NGCF(_FlatModel):
             ws[name] = [new(N, dims[i + 1]) for i in range(self.n_layers)]
         ws["nrm"] = [new(N) for _ in range(self.n_layers)]
         ws["keep"] = [torch.ones(N, dims[i + 1], dtype=torch.uint8, device=dev) for i in range(self.n_layers)]
-        for name in ("d_sum", "d_bi", "d_side", "d_bi_in", "d_ego0", "d_ego1"):
+        for name in ("d_sum", "d_bi", "d_side", "d_bi_in", "d_ego0", "d_ego1", "sliced_src"):
             ws[name] = new(N, dmax)
         self._ws = ws
         return ws
@@ -157,6 +164,9 @@ class NGCF(_FlatModel):
         p.keep_gen = 1 if (keep is not None and self.dropout_rng == "device") else 0
         p.keep_seed, p.keep_step = self.dropout_seed, self._step
         p.d_ego[0], p.d_ego[1] = ws["d_ego0"].data_ptr(), ws["d_ego1"].data_ptr()
+        if gr.get("slice_w", 0) > 0:
+            p.sa, p.sat, p.slice_w = gr["sliced"][0], gr["sliced_t"][0], gr["slice_w"]
+            p.sliced_src, p.sliced_src_floats = ws["sliced_src"].data_ptr(), ws["sliced_src"].numel()
         return p
 
     def draw_keep_masks(self):

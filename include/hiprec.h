@@ -789,6 +789,15 @@ typedef struct hiprec_ngcf_plan {
    * must be zero on entry: heavy rows are accumulated with atomics). */
   float* zero_ws;
   int64_t zero_ws_floats;
+  /* Optional (graphs whose node count fits the LDS and hops whose input widths all take the same slice width,
+   * hiprec_sliced_width(N, dim[l]) == slice_w): the two graphs stored for the column-sliced SpMM and one buffer of
+   * N * max(dim[l]) floats for its sliced source.  The SpMMs of a step then run on hiprec_spmm_sliced's kernel: the
+   * source is written in the sliced layout by the kernel that produces it, the result goes straight to side[l] /
+   * d_ego; spmm_tmp is unused and only d_all is cleared. */
+  hiprec_sliced_csr sa, sat;
+  int32_t slice_w, _pad2;
+  float* sliced_src;
+  int64_t sliced_src_floats;
 } hiprec_ngcf_plan;
 
 size_t hiprec_ngcf_plan_bytes(void);

@@ -53,15 +53,17 @@ def kept_masks(eng, drop):
     return [None if p == 0 else eng.model._ws["keep"][l].cpu().numpy().astype(bool) for l, p in enumerate(drop)]
 
 
+@pytest.mark.parametrize("spmm", ["auto", "gather"])
 @pytest.mark.parametrize("case", CASES)
-def test_step_matches_reference(hip_device, case):
+def test_step_matches_reference(hip_device, case, spmm):
     g = load_golden(case)
     U, I, D, L, B, n_steps, seed = (int(x) for x in g["meta"])
     layers, drop = [int(x) for x in g["layers"]], [float(x) for x in g["mess_dropout"]]
     opt, lr, decay = str(g["optimizer"]), float(g["lr"]), float(g["decay"])
     adj = ngcf_adj(g)
     torch.manual_seed(seed)
-    eng = make_engine(U, I, D, layers, drop, opt, lr, B, adj, decay)
+    eng = make_engine(U, I, D, layers, drop, opt, lr, B, adj, decay, spmm=spmm)
+    assert (eng.model.graph().get("slice_w", 0) > 0) == (spmm == "auto")  # column-sliced or edge-parallel SpMM
     w_init = get_weights(eng)
     for k in w_init:  # same seed -> the reference's initial weights, bit for bit
         assert np.array_equal(w_init[k], g[f"init/{k}"]), k
@@ -139,9 +141,10 @@ def ml1m_graph(U, I, n_edges, seed):
     return olg.build_norm_adj(U, I, eu, ei)
 
 
+@pytest.mark.parametrize("spmm", ["auto", "gather"])
 @pytest.mark.parametrize("D,layers,drop,optimizer", [(64, [64, 64, 64], [0.1, 0.1, 0.1], "adam"),
                                                      (32, [128, 48], [0.0, 0.2], "sgd")])
-def test_ml1m_sized_graph_vs_oracle(hip_device, D, layers, drop, optimizer):
+def test_ml1m_sized_graph_vs_oracle(hip_device, D, layers, drop, optimizer, spmm):
     """ngcf_default.json shape (emb 64, three hops of 64, mess_dropout 0.1, batch 1024) on a 6040 x 3706
     graph with 200 k interactions: loss, gradients (vs the exact fp64 evaluation; the fp32 oracle stands in
     for the reference) and one full step, with the engine's own dropout masks."""
@@ -150,7 +153,8 @@ def test_ml1m_sized_graph_vs_oracle(hip_device, D, layers, drop, optimizer):
     rng = np.random.default_rng(D)
     torch.manual_seed(D)
     lr = 0.05 if optimizer == "sgd" else 1e-3
-    eng = make_engine(U, I, D, layers, drop, optimizer, lr, B, adj)
+    eng = make_engine(U, I, D, layers, drop, optimizer, lr, B, adj, spmm=spmm)
+    assert (eng.model.graph().get("slice_w", 0) == 4) == (spmm == "auto")
     eng.model.train()
     w = get_weights(eng)
     batch = (rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B))
