@@ -344,9 +344,10 @@ static int propagate_sliced(const hiprec_lightgcn_plan* p, const hiprec_sliced_c
     float* nxt = sliced_buf(p, 2 + (l & 1));
     const int mode = (l == 0 && !with_input) ? 2 : 1;
     const bool last = l == L - 1;
-    if (int rc = launch_spmm_sliced(graph, val, scale, cur, nxt, accs, mode, D, W, st,
-                                    last && clear_buf0 && l > 0 ? xs0 : nullptr, last && direct_out ? out : nullptr))
-      return rc;
+    SlicedFlush fl;
+    fl.zero_out = last && clear_buf0 && l > 0 ? xs0 : nullptr;
+    fl.final_out = last && direct_out ? out : nullptr;
+    if (int rc = launch_spmm_sliced(graph, val, scale, cur, nxt, accs, mode, D, W, st, fl)) return rc;
     cur = nxt;
   }
   if (clear_buf0 && L < 2) HIPREC_TRY(hipMemsetAsync(xs0, 0, sizeof(float) * N * D, st));

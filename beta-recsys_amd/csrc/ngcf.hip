@@ -328,12 +328,16 @@ inline int ngcf_forward(const hiprec_ngcf_plan* p, bool train, hipStream_t st) {
   for (int l = 0; l < p->n_layers; ++l) {
     const int di = p->dim[l], dout = p->dim[l + 1];
     if (sliced) {
-      if (int rc = launch_spmm_sliced(&p->sa, nullptr, 1.0f, p->sliced_src, nullptr, nullptr, 0, di, p->slice_w, st,
-                                      nullptr, p->side[l], /*final_set=*/true))
+      SlicedFlush fl;
+      fl.final_out = p->side[l];
+      fl.final_set = true;
+      if (int rc = launch_spmm_sliced(&p->sa, nullptr, 1.0f, p->sliced_src, nullptr, nullptr, 0, di, p->slice_w, st, fl))
         return rc;
     } else if (int rc = launch_spmm(&p->a, nullptr, 1.0f, ego, p->side[l], nullptr, di, st, zeroed)) {
       return rc;
     }
+    // (ego * side written by the sliced pass's flush instead: same step time -- its scattered 16-byte reads of ego
+    // cost the pass what the launch costs here)
     ngcf_bi_mul_kernel<<<grid_for_threads((N * di + 3) / 4), kBlock, 0, st>>>(ego, p->side[l], p->bi_in[l],
                                                                              N * di);
     HIPREC_TRY(hipGetLastError());
@@ -442,8 +446,9 @@ extern "C" int hiprec_ngcf_grad(const hiprec_ngcf_plan* plan, const int64_t* use
     HIPREC_TRY(hipGetLastError());
     // d_ego += A^T d_side
     if (sliced) {
-      if (int rc = launch_spmm_sliced(&p->sat, nullptr, 1.0f, p->sliced_src, nullptr, nullptr, 0, di, p->slice_w, st,
-                                      nullptr, d_ego, /*final_set=*/false))
+      SlicedFlush fl;
+      fl.final_out = d_ego;
+      if (int rc = launch_spmm_sliced(&p->sat, nullptr, 1.0f, p->sliced_src, nullptr, nullptr, 0, di, p->slice_w, st, fl))
         return rc;
     } else if (int rc = launch_spmm(&p->at, nullptr, 1.0f, p->d_side, p->spmm_tmp[l], d_ego, di, st,
                                     p->zero_ws != nullptr)) {

@@ -15,11 +15,14 @@ int launch_spmm(const hiprec_csr* a, const uint8_t* keep, float scale, const flo
 // values, or uint16 columns for a factored graph, whose source and result are scaled by col_scale).
 int sliced_width(int64_t n_rows, int dim);
 int sliced_row_cap(int64_t n_rows, int dim);
-// zero_out (sliced, may be NULL): cleared row by row as a by-product; final_out (row-major, may be NULL): instead
-// of writing ys / accs the pass adds (final_set: stores) the layer sum (accs + Y for acc_mode 1, Y otherwise) there.
+// What a pass does with its finished rows besides (or instead of) writing ys / accs:
+struct SlicedFlush {
+  float* zero_out = nullptr;     // sliced buffer cleared row by row as a by-product
+  float* final_out = nullptr;    // row-major: instead of ys / accs, the layer sum (accs + Y for acc_mode 1, Y otherwise)
+  bool final_set = false;        //   is stored here (true) or added (false)
+};
 int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scale, const float* xs, float* ys,
-                       float* accs, int acc_mode, int dim, int W, hipStream_t st, float* zero_out = nullptr,
-                       float* final_out = nullptr, bool final_set = false);
+                       float* accs, int acc_mode, int dim, int W, hipStream_t st, SlicedFlush fl = SlicedFlush{});
 
 // optional second output of an elementwise producer: the same rows in the sliced layout, times col_scale[row]
 struct SlicedOut {

@@ -101,9 +101,10 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
                                                                      const void* __restrict__ edges, float scale,
                                                                      const float* __restrict__ xs,
                                                                      float* __restrict__ ys, float* __restrict__ accs,
-                                                                     int acc_mode, float* __restrict__ zero_out,
-                                                                     float* __restrict__ final_out, int final_set,
-                                                                     int dim) {
+                                                                     int acc_mode, SlicedFlush fl, int dim) {
+  float* __restrict__ zero_out = fl.zero_out;
+  float* __restrict__ final_out = fl.final_out;
+  const int final_set = fl.final_set ? 1 : 0;
   using Vec = typename SlicedVec<W>::type;
   using LdsVec = const __attribute__((address_space(3))) Vec;
   using Pair = float __attribute__((ext_vector_type(2)));
@@ -361,8 +362,7 @@ int sliced_row_cap(int64_t n_rows, int dim) {
 }
 
 int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scale, const float* xs, float* ys,
-                       float* accs, int acc_mode, int dim, int W, hipStream_t st, float* zero_out,
-                       float* final_out, bool final_set) {
+                       float* accs, int acc_mode, int dim, int W, hipStream_t st, SlicedFlush fl) {
   HIPREC_REQUIRE(a && a->sub_row && a->sub_chunk && a->n_rows > 0 && a->n_groups > 0 && a->subs_per_group > 0,
                  "bad sliced graph");
   HIPREC_REQUIRE(a->n_slots == 0 || (a->col16 && a->val && a->chunks), "sliced graph has NULL chunks / col16 / val");
@@ -373,7 +373,7 @@ int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scal
   HIPREC_REQUIRE(a->row_cap > 0 && a->row_cap <= sliced_row_cap(a->n_rows, dim),
                  "subgroups of up to %d rows do not fit the LDS next to the slice (at most %d)", a->row_cap,
                  sliced_row_cap(a->n_rows, dim));
-  HIPREC_REQUIRE(xs && (ys || final_out) && (acc_mode == 0 || accs), "NULL sliced buffers");
+  HIPREC_REQUIRE(xs && (ys || fl.final_out) && (acc_mode == 0 || accs), "NULL sliced buffers");
   const size_t lds = static_cast<size_t>(a->n_rows + 1 + a->row_cap) * W * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -388,17 +388,13 @@ int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scal
   if (edges == nullptr) edges = factored ? static_cast<const void*>(a->col16) : static_cast<const void*>(a->val);
   const int grid = (dim / W) * a->n_groups;
   if (W == 4 && factored)
-    spmm_sliced_kernel<4, true><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, zero_out,
-                                                                   final_out, final_set ? 1 : 0, dim);
+    spmm_sliced_kernel<4, true><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, fl, dim);
   else if (W == 4)
-    spmm_sliced_kernel<4, false><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, zero_out,
-                                                                   final_out, final_set ? 1 : 0, dim);
+    spmm_sliced_kernel<4, false><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, fl, dim);
   else if (factored)
-    spmm_sliced_kernel<2, true><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, zero_out,
-                                                                   final_out, final_set ? 1 : 0, dim);
+    spmm_sliced_kernel<2, true><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, fl, dim);
   else
-    spmm_sliced_kernel<2, false><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, zero_out,
-                                                                   final_out, final_set ? 1 : 0, dim);
+    spmm_sliced_kernel<2, false><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, fl, dim);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
@@ -460,5 +456,5 @@ extern "C" int hiprec_spmm_sliced(const hiprec_sliced_csr* a, const void* step_e
                                   float* ys, float* accs, int32_t acc_mode, int32_t dim, int32_t slice_w,
                                   void* stream) {
   return launch_spmm_sliced(a, step_edges, scale, xs, ys, accs, acc_mode, dim, slice_w,
-                            static_cast<hipStream_t>(stream), nullptr, nullptr, false);
+                            static_cast<hipStream_t>(stream), SlicedFlush{});
 }
