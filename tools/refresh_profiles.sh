@@ -31,6 +31,7 @@ prof mf-c4shard --workload mf-c4shard --steps 50 --warmup 5
 prof ncf --workload ncf --steps 100 --warmup 10
 prof ncf64 --workload ncf --emb-dim 64 --steps 100 --warmup 10
 prof lightgcn --workload lightgcn --steps 100 --warmup 10
+prof ngcf --workload ngcf --steps 100 --warmup 10
 pmc() {  # name, bench args...
   local name=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -41,4 +42,6 @@ pmc() {  # name, bench args...
 pmc adam --steps 200 --warmup 20
 pmc sgd --optimizer sgd --steps 200 --warmup 20
 pmc mf-c4shard --workload mf-c4shard --steps 50 --warmup 5
+pmc lightgcn --workload lightgcn --steps 50 --warmup 5
+cd $GRAFT_REPO_ROOT && timeout 200 python tools/exp_spmm_sliced.py 2>&1 | grep -v amdgpu.ids > $OUT/exp_spmm_sliced.txt
 ls $OUT | head -80
