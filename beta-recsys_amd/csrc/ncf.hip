@@ -447,8 +447,11 @@ __global__ __launch_bounds__(kBlock) void ncf_scatter_kernel(hiprec_ncf_plan p,
 // Shapes outside the limits below take the unfused path.
 constexpr int kFR = 16;                    // samples per block: 16-row MFMA tiles (v_mfma_f32_16x16x4_f32), 256 blocks at
                                            // B 4096 = one per CU (32-row tiles: 128 blocks, half the chip idle)
-constexpr int kFWaves = 4;                 // one wave per 32 output columns of a 128-column pass
-constexpr int kFThreads = kFWaves * kWave; // 256
+constexpr int kFWaves = 8;                 // one wave per 16 output columns of a 128-column pass: two waves per SIMD, so
+                                           // one's MFMA chain runs under the other's LDS / memory waits (with 4 waves
+                                           // of 32 columns a 32-k chunk took ~1800 cycles for 512 cycles of MFMA)
+constexpr int kFThreads = kFWaves * kWave; // 512
+constexpr int kFK = 32;                    // k-chunk of the weight tiles (64: same step time)
 constexpr int kFMaxIn = 256;               // widest tower input (2 * dim_mlp)
 constexpr int kFMaxN = 128;                // widest layer output / widest hidden activation
 constexpr int kFLdIn = kFMaxIn + 1;
@@ -458,11 +461,11 @@ constexpr int kFLdE = kFMaxE + 1;
 
 static bool fusable(const hiprec_ncf_plan* p) {
   if (p->dim_mlp <= 0 || p->n_layers < 1) return false;
-  if (2 * p->dim_mlp > kFMaxIn || (2 * p->dim_mlp) % kTK) return false;
+  if (2 * p->dim_mlp > kFMaxIn || (2 * p->dim_mlp) % kFK) return false;
   if (p->dim_mf > kFMaxE) return false;
   for (int l = 0; l < p->n_layers; ++l) {
     if (p->layer_out[l] > kFMaxN || p->layer_out[l] % 32) return false;
-    if (p->layer_in[l] % kTK) return false;
+    if (p->layer_in[l] % kFK) return false;
   }
   return true;
 }
@@ -470,24 +473,24 @@ static bool fusable(const hiprec_ncf_plan* p) {
 struct FusedLds {
   float* wide;   // [kFR][kFLdIn]  tower input, later narrow activations
   float* narrow; // [kFR][kFLdN]
-  float* bs;     // [2][kTK][kFLdN] weight tiles (double-buffered)
+  float* bs;     // [2][kFK][kFLdN] weight tiles (double-buffered)
   float* mf;     // [kFR][kFLdE]   GMF product (forward) / unused (backward)
   __device__ int ld_of(const float* buf) const { return buf == wide ? kFLdIn : kFLdN; }
 };
 constexpr size_t kFusedLdsBytes =
-    sizeof(float) * (kFR * kFLdIn + kFR * kFLdN + 2 * kTK * kFLdN + kFR * kFLdE);
+    sizeof(float) * (kFR * kFLdIn + kFR * kFLdN + 2 * kFK * kFLdN + kFR * kFLdE);
 
 __device__ __forceinline__ FusedLds fused_lds(float* base) {
   FusedLds l;
   l.wide = base;
   l.narrow = l.wide + kFR * kFLdIn;
   l.bs = l.narrow + kFR * kFLdN;
-  l.mf = l.bs + 2 * kTK * kFLdN;
+  l.mf = l.bs + 2 * kFK * kFLdN;
   return l;
 }
 
 // acc(32x32 per wave) = In[32 x K] * W^T: wave wn owns output columns wn*32.. of the N <= 128 columns
-// (W is nn.Linear.weight, [N][K] row-major; K is a multiple of kTK).  Waves beyond N idle in the MFMAs
+// (W is nn.Linear.weight, [N][K] row-major; K is a multiple of kFK).  Waves beyond N idle in the MFMAs
 // but still help staging.  Software pipeline, measured per chunk of 32 k with in-kernel timestamps:
 // staged naively (16 scalar loads issued, then 16 LDS stores, then the 16 dependent MFMAs) a chunk
 // took 2760 cycles of which the MFMAs are 1150 -- with one wave per SIMD nothing else fills the
@@ -495,36 +498,25 @@ __device__ __forceinline__ FusedLds fused_lds(float* base) {
 // instead of 16), a double-buffered LDS tile written one chunk ahead, two register stages, and the
 // memory instructions spread between the MFMAs with sched_group_barrier so they issue in the shadow
 // of the 64-cycle dependent MFMA chain.
-constexpr int kFW4 = kFMaxN * kTK / 4 / kFThreads;  // float4 weight loads per thread and chunk (4)
+constexpr int kFW4 = kFMaxN * kFK / 4 / kFThreads;  // float4 weight loads per thread and chunk (2)
 
-__device__ __forceinline__ void fused_mma(f32x4 (&acc)[2], const float* in, int ld_in, int K,
-                                          const float* __restrict__ W, int N, float* bs) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave & 3;
-  const bool active = wn * 32 < N;
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
-  // staging coordinates of this thread inside a [kTK x 128] tile (fixed across chunks): float4 q
-  // covers W[n][k4 .. k4+3]
+// begin(): staging coordinates and the loads of the first two weight chunks -- they depend on nothing the block
+// computes, so the caller issues them BEFORE whatever produces `in` (layer 0: before the embedding gather; layer
+// l + 1: before layer l's epilogue) and their latency is off the block's serial chain.  run(): the rest.
+// (All of a layer's weights requested up front into registers -- 16 float4 per thread for 256 x 128 -- instead of
+// this two-to-three-chunks-ahead stream: no faster, 85.5 against 84 us per step.)
+struct FusedGemm {
   int s_n[kFW4], s_k4[kFW4];
   const float4* s_src[kFW4];
   bool s_ok[kFW4];
-#pragma unroll
-  for (int i = 0; i < kFW4; ++i) {
-    const int q = tid + i * kFThreads;
-    s_n[i] = q >> 3;
-    s_k4[i] = (q & 7) * 4;
-    s_ok[i] = s_n[i] < N;
-    s_src[i] = reinterpret_cast<const float4*>(W + static_cast<int64_t>(s_ok[i] ? s_n[i] : 0) * K + s_k4[i]);
-  }
   float4 w0[kFW4], w1[kFW4];
-  auto fetch = [&](float4 (&w)[kFW4], int k0) {
+  int K, N;
+
+  __device__ __forceinline__ void fetch(float4 (&w)[kFW4], int k0) {
 #pragma unroll
     for (int i = 0; i < kFW4; ++i) w[i] = s_src[i][k0 >> 2];
-  };
-  auto stage = [&](const float4 (&w)[kFW4], float* tile) {
+  }
+  __device__ __forceinline__ void stage(const float4 (&w)[kFW4], float* tile) {
 #pragma unroll
     for (int i = 0; i < kFW4; ++i) {
       float* d = tile + s_k4[i] * kFLdN + s_n[i];
@@ -534,49 +526,63 @@ __device__ __forceinline__ void fused_mma(f32x4 (&acc)[2], const float* in, int 
       d[2 * kFLdN] = v.z;
       d[3 * kFLdN] = v.w;
     }
-  };
-  const int n_chunks = K / kTK;
-  float* tile[2] = {bs, bs + kTK * kFLdN};
-  fetch(w0, 0);
-  if (n_chunks > 1) fetch(w1, kTK);
-  stage(w0, tile[0]);
-  if (n_chunks > 2) fetch(w0, 2 * kTK);
-  lds_barrier();
-  auto chunk = [&](float4 (&w_next)[kFW4], int t) {
-    // chunk t+1 goes to the other tile, chunk t+3 into the registers it frees, chunk t is multiplied
-    if (t + 1 < n_chunks) stage(w_next, tile[(t + 1) & 1]);
-    if (t + 3 < n_chunks) fetch(w_next, (t + 3) * kTK);
-    if (active) {
-      // 16x16x4 fp32 MFMA: lane l feeds A[row l & 15][k + (l >> 4)] and B[k + (l >> 4)][col l & 15]; the wave's 32
-      // output columns are two 16-column tiles that share the A operand
-      const float* cur = tile[t & 1];
-      const int i = lane & 15, kq = lane >> 4;
-      const int k0 = t * kTK;
-#pragma unroll
-      for (int kk = 0; kk < kTK; kk += 4) {
-        const float a = in[i * ld_in + k0 + kk + kq];
-        const float b0 = cur[(kk + kq) * kFLdN + wn * 32 + i];
-        const float b1 = cur[(kk + kq) * kFLdN + wn * 32 + 16 + i];
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[1], 0, 0, 0);
-      }
-    }
-    // issue order: one MFMA, then the LDS reads of the next one, one staging store, and every
-    // fourth slot one weight load
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read (3 per MFMA pair: a, b0, b1)
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
-      if ((g & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
-    }
-    lds_barrier();
-  };
-  for (int t = 0; t < n_chunks; t += 2) {
-    chunk(w1, t);
-    if (t + 1 < n_chunks) chunk(w0, t + 1);
   }
-}
+  __device__ __forceinline__ void begin(const float* __restrict__ W, int K_, int N_) {
+    K = K_;
+    N = N_;
+    const int tid = threadIdx.x;
+    // staging coordinates of this thread inside a [kFK x 128] tile (fixed across chunks): float4 q
+    // covers W[n][k4 .. k4+3]
+#pragma unroll
+    for (int i = 0; i < kFW4; ++i) {
+      const int q = tid + i * kFThreads;
+      s_n[i] = q / (kFK / 4);
+      s_k4[i] = (q % (kFK / 4)) * 4;
+      s_ok[i] = s_n[i] < N;
+      s_src[i] = reinterpret_cast<const float4*>(W + static_cast<int64_t>(s_ok[i] ? s_n[i] : 0) * K + s_k4[i]);
+    }
+    fetch(w0, 0);
+    if (K > kFK) fetch(w1, kFK);
+  }
+  __device__ __forceinline__ void run(f32x4& acc, const float* in, int ld_in, float* bs) {
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const bool active = wn * 16 < N;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = 0.f;
+    const int n_chunks = K / kFK;
+    float* tile[2] = {bs, bs + kFK * kFLdN};
+    stage(w0, tile[0]);
+    if (n_chunks > 2) fetch(w0, 2 * kFK);
+    lds_barrier();
+    auto chunk = [&](float4 (&w_next)[kFW4], int t) {
+      // chunk t+1 goes to the other tile, chunk t+3 into the registers it frees, chunk t is multiplied
+      if (t + 1 < n_chunks) stage(w_next, tile[(t + 1) & 1]);
+      if (t + 3 < n_chunks) fetch(w_next, (t + 3) * kFK);
+      if (active) {
+        // 16x16x4 fp32 MFMA: lane l feeds A[row l & 15][k + (l >> 4)] and B[k + (l >> 4)][col l & 15].  All
+        // operands of the chunk are requested first, then the MFMA chain runs back to back (left alone the
+        // compiler sinks each pair of reads next to its MFMAs: four LDS round trips per chunk)
+        const float* cur = tile[t & 1];
+        const int i = lane & 15, kq = lane >> 4;
+        const int k0 = t * kFK;
+        float a[kFK / 4], b[kFK / 4];
+#pragma unroll
+        for (int j = 0; j < kFK / 4; ++j) {
+          a[j] = in[i * ld_in + k0 + 4 * j + kq];
+          b[j] = cur[(4 * j + kq) * kFLdN + wn * 16 + i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < kFK / 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+      }
+      lds_barrier();
+    };
+    for (int t = 0; t < n_chunks; t += 2) {
+      chunk(w1, t);
+      if (t + 1 < n_chunks) chunk(w0, t + 1);
+    }
+  }
+};
 
 // ---- forward: gather -> tower -> affine_output -> sigmoid; writes act[0..L], mf, scores -----------------
 // TRAIN: the head's backward half rides along (BCELoss term, d loss / d logit, dZ_L, dMF, d w_out,
@@ -590,9 +596,33 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   const FusedLds L = fused_lds(lds_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave & 3;
+  const int wn = wave;
   const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kFR;
   const int Dm = p.dim_mlp, E = p.dim_mf, K0 = 2 * Dm;
+
+  // Loads that depend on nothing the block computes go first, off its serial chain: layer 0's first weight chunks,
+  // every layer's two bias elements of this lane, the head's weights and targets.
+  FusedGemm gemm;
+  if (p.n_layers > 0) gemm.begin(p.fc_w[0], p.layer_in[0], p.layer_out[0]);
+  float bias_now, bias_next;  // this lane's bias element of the current / the next layer
+  auto load_bias = [&](int l) {
+    const int col = wn * 16 + (lane & 15);
+    return l < p.n_layers && col < p.layer_out[l] ? p.fc_b[l][col] : 0.f;
+  };
+  bias_now = load_bias(0);
+  const int nH = p.n_layers > 0 ? p.layer_out[p.n_layers - 1] : 0, nV = nH + p.dim_mf;
+  const float bo = load_scalar_param(p.out_b);
+  float wout[3];  // nV <= 192
+#pragma unroll
+  for (int k = 0; k < 3; ++k) wout[k] = lane + kWave * k < nV ? p.out_w[lane + kWave * k] : 0.f;
+  float rt[kFR / kFWaves];
+  if (TRAIN) {
+#pragma unroll
+    for (int j = 0; j < kFR / kFWaves; ++j) {
+      const int64_t b = m0 + wave + j * kFWaves;
+      rt[j] = ratings[b < batch ? b : batch - 1];
+    }
+  }
 
   // gather, element-parallel: 64 threads fetch the index pairs, then every thread owns
   // kFR * K0 / 256 <= 16 elements of the tower input; all its loads are requested before anything
@@ -617,16 +647,18 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
   }
   lds_barrier();
   {
-    // thread t owns column t of every row (K0 <= 256 = kFThreads) and (row j*4 + t/64, column t%64)
-    // of the GMF tile: no divisions, one load per row, all requested before anything is stored
-    static_assert(kFMaxIn <= kFThreads && kFMaxE == kWave, "gather mapping");
-    float v[kFR];
-    const int c = tid < K0 ? tid : 0;
+    // thread t owns column t % 256 of the rows of its half (t / 256) of the tile and (row j * 8 + t / 64, column
+    // t % 64) of the GMF tile: no divisions, one load per row, all requested before anything is stored
+    static_assert(kFThreads % kFMaxIn == 0 && kFMaxE == kWave, "gather mapping");
+    constexpr int kHalves = kFThreads / kFMaxIn, kRowsPer = kFR / kHalves;  // 2 halves of 8 rows
+    float v[kRowsPer];
+    const int col_t = tid & (kFMaxIn - 1), row0 = (tid / kFMaxIn) * kRowsPer;
+    const int c = col_t < K0 ? col_t : 0;
     const bool c_user = c < Dm;
     const float* base = c_user ? p.user_mlp + c : p.item_mlp + (c - Dm);
 #pragma unroll
-    for (int r = 0; r < kFR; ++r) {
-      const long long idx = c_user ? s_u[r] : s_i[r];
+    for (int r = 0; r < kRowsPer; ++r) {
+      const long long idx = c_user ? s_u[row0 + r] : s_i[row0 + r];
       v[r] = base[(idx >= 0 ? idx : 0) * Dm];  // flagged samples read row 0 and are zeroed below
     }
     constexpr int kPerE = kFR * kFMaxE / kFThreads;  // 8
@@ -638,16 +670,17 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
       const long long u = s_u[r], it = s_i[r];
       w[j] = E > 0 ? p.user_mf[(u >= 0 ? u : 0) * E + ce] * p.item_mf[(it >= 0 ? it : 0) * E + ce] : 0.f;
     }
-    if (tid < K0) {
+    if (col_t < K0) {
 #pragma unroll
-      for (int r = 0; r < kFR; ++r) {
-        float x = s_u[r] >= 0 ? v[r] : 0.f;
+      for (int j = 0; j < kRowsPer; ++j) {
+        const int r = row0 + j;
+        float x = s_u[r] >= 0 ? v[j] : 0.f;
         if (p.relu_input) x = fmaxf(x, 0.f);
         // the Dropout in front of the first Linear (ncf.py:42-45, mlp.py:30-33): one keep byte per element
         if constexpr (DROP)
-          if (p.keep[0] && m0 + r < batch) x = p.keep[0][(m0 + r) * K0 + tid] ? x * p.keep_scale : 0.f;
-        L.wide[r * kFLdIn + tid] = x;
-        if (m0 + r < batch) p.act[0][(m0 + r) * K0 + tid] = x;
+          if (p.keep[0] && m0 + r < batch) x = p.keep[0][(m0 + r) * K0 + col_t] ? x * p.keep_scale : 0.f;
+        L.wide[r * kFLdIn + col_t] = x;
+        if (m0 + r < batch) p.act[0][(m0 + r) * K0 + col_t] = x;
       }
     }
     if ((tid & 63) < E) {
@@ -665,17 +698,18 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
   const float* in = L.wide;
   float* out = L.narrow;
   for (int l = 0; l < p.n_layers; ++l) {
-    const int K = p.layer_in[l], N = p.layer_out[l];
-    f32x4 acc[2];
-    fused_mma(acc, in, L.ld_of(in), K, p.fc_w[l], N, L.bs);
-    if (wn * 32 < N) {
+    const int N = p.layer_out[l];
+    f32x4 acc;
+    gemm.run(acc, in, L.ld_of(in), L.bs);
+    if (l + 1 < p.n_layers) gemm.begin(p.fc_w[l + 1], p.layer_in[l + 1], p.layer_out[l + 1]);  // under the epilogue
+    bias_next = load_bias(l + 1);
+    if (wn * 16 < N) {
       const int ld_out = L.ld_of(out);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {   // C[row 4 * (lane >> 4) + r][col lane & 15] of tile q >> 2
-        const int r = q & 3, col = wn * 32 + (q >> 2) * 16 + (lane & 15);
+      for (int r = 0; r < 4; ++r) {   // C[row 4 * (lane >> 4) + r][col lane & 15]
+        const int col = wn * 16 + (lane & 15);
         const int row = 4 * (lane >> 4) + r;
-        const float bias = p.fc_b[l][col];
-        float v = fmaxf(acc[q >> 2][r] + bias, 0.f);
+        float v = fmaxf(acc[r] + bias_now, 0.f);
         // act[l + 1] is what the NEXT Linear sees: its Dropout is applied here (the backward's dgrad epilogue
         // applies the same keep bytes)
         if constexpr (DROP)
@@ -689,26 +723,14 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
     const float* t = in;
     in = out;
     out = const_cast<float*>(t);
+    bias_now = bias_next;
   }
 
   // affine_output + sigmoid: wave w scores rows w, w + 8, ...
-  const int nH = p.layer_out[p.n_layers - 1], nV = nH + E;
   const int ld_h = L.ld_of(in);
-  const float bo = load_scalar_param(p.out_b);
-  float wout[3];  // nV <= 192
-#pragma unroll
-  for (int k = 0; k < 3; ++k) wout[k] = lane + kWave * k < nV ? p.out_w[lane + kWave * k] : 0.f;
   const bool stepper = TRAIN && blockIdx.x == 0 && tid == 0;
   StepState step_state{};
   if (stepper) step_state = step_load(stats);
-  float rt[kFR / kFWaves];
-  if (TRAIN) {
-#pragma unroll
-    for (int j = 0; j < kFR / kFWaves; ++j) {
-      const int64_t b = m0 + wave + j * kFWaves;
-      rt[j] = ratings[b < batch ? b : batch - 1];
-    }
-  }
   float loss_acc = 0.f, gb_acc = 0.f;
   float gw[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -765,6 +787,7 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
     if (t != 0.f) atomic_add_f32(p.g_out_w + c, t);
   }
 }
+
 
 static int head_grid(int64_t batch, int samples_per_wave) {
   const int64_t per_block = static_cast<int64_t>(kHeadWaves) * samples_per_wave;
