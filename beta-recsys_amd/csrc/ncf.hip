@@ -16,6 +16,8 @@
 // tolerance of 1e-5 rules out bf16).
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "common.hpp"
 #include "gemm.hpp"
 
@@ -789,6 +791,195 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
 }
 
 
+// ---- backward: dZ_L -> dZ_{L-1} -> ... -> d(tower input), embedding-row gradients scattered on the way out ------
+// The input-gradient chain of the tower for 16 samples, in LDS like the forward: dZ_{l-1} = (dZ_l W_l) * [H_{l-1} > 0]
+// (and the Dropout in front of Linear l).  The three grouped launches it replaces each paid 11-18 us for a dgrad that
+// the next launch had to wait for; the weight / bias gradients, which only READ the dZ_l this kernel writes, follow in
+// one grouped launch.  W_l ([nout][nin] row-major) is the B operand as it lies in memory: k = its rows, 16-byte
+// staging loads along n.  A pass produces 128 columns (8 waves x 16); the 2 * dim_mlp columns of layer 0 take two.
+// The layer-0 pass never writes d(tower input): each lane adds its four elements straight into the user / item
+// embedding gradients (what ncf_scatter_kernel did in a launch of its own), and the GMF rows' gradients leave at
+// the start, they depend on the head only.
+constexpr int kFLdB = kFMaxN + 8;  // 136: 16-byte aligned tile rows, two-way bank conflicts on the B reads
+constexpr size_t kFusedBwdLdsBytes = sizeof(float) * (kFR * kFLdIn + kFR * kFLdN + 2 * kFK * kFLdB);
+
+struct FusedGemmNN {
+  int s_k[kFW4], s_n4[kFW4];
+  const float* s_src[kFW4];
+  bool s_ok[kFW4];
+  float4 w0[kFW4], w1[kFW4];
+  int K, N, ldw;
+
+  __device__ __forceinline__ void fetch(float4 (&w)[kFW4], int k0) {
+#pragma unroll
+    for (int i = 0; i < kFW4; ++i)
+      w[i] = s_ok[i] ? *reinterpret_cast<const float4*>(s_src[i] + static_cast<int64_t>(k0) * ldw)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __device__ __forceinline__ void stage(const float4 (&w)[kFW4], float* tile) {
+#pragma unroll
+    for (int i = 0; i < kFW4; ++i) *reinterpret_cast<float4*>(tile + s_k[i] * kFLdB + s_n4[i]) = w[i];
+  }
+  // columns n_off .. n_off + N (N <= 128, a multiple of 16) of W[K][ldw]
+  __device__ __forceinline__ void begin(const float* __restrict__ W, int ldw_, int K_, int N_, int n_off) {
+    K = K_;
+    N = N_;
+    ldw = ldw_;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < kFW4; ++i) {
+      const int q = tid + i * kFThreads;  // float4 q of a [kFK x 128] tile
+      s_k[i] = q / (kFMaxN / 4);
+      s_n4[i] = (q % (kFMaxN / 4)) * 4;
+      s_ok[i] = s_n4[i] < N;
+      s_src[i] = W + static_cast<int64_t>(s_k[i]) * ldw + n_off + (s_ok[i] ? s_n4[i] : 0);
+    }
+    fetch(w0, 0);
+    if (K > kFK) fetch(w1, kFK);
+  }
+  __device__ __forceinline__ void run(f32x4& acc, const float* in, int ld_in, float* bs) {
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const bool active = wn * 16 < N;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = 0.f;
+    const int n_chunks = K / kFK;
+    float* tile[2] = {bs, bs + kFK * kFLdB};
+    stage(w0, tile[0]);
+    if (n_chunks > 2) fetch(w0, 2 * kFK);
+    lds_barrier();
+    auto chunk = [&](float4 (&w_next)[kFW4], int t) {
+      if (t + 1 < n_chunks) stage(w_next, tile[(t + 1) & 1]);
+      if (t + 3 < n_chunks) fetch(w_next, (t + 3) * kFK);
+      if (active) {
+        const float* cur = tile[t & 1];
+        const int i = lane & 15, kq = lane >> 4;
+        const int k0 = t * kFK;
+        float a[kFK / 4], b[kFK / 4];
+#pragma unroll
+        for (int j = 0; j < kFK / 4; ++j) {
+          a[j] = in[i * ld_in + k0 + 4 * j + kq];
+          b[j] = cur[(4 * j + kq) * kFLdB + wn * 16 + i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < kFK / 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+      }
+      lds_barrier();
+    };
+    for (int t = 0; t < n_chunks; t += 2) {
+      chunk(w1, t);
+      if (t + 1 < n_chunks) chunk(w0, t + 1);
+    }
+  }
+};
+
+template <bool DROP>
+__global__ __launch_bounds__(kFThreads) void ncf_fused_dgrad_kernel(hiprec_ncf_plan p,
+                                                                    const int64_t* __restrict__ users,
+                                                                    const int64_t* __restrict__ items,
+                                                                    int64_t batch) {
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  float* wide = lds_raw;                     // [kFR][kFLdIn]
+  float* narrow = wide + kFR * kFLdIn;       // [kFR][kFLdN]
+  float* bs = narrow + kFR * kFLdN;          // [2][kFK][kFLdB]
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kFR;
+  const int L = p.n_layers, Dm = p.dim_mlp, E = p.dim_mf;
+  __shared__ long long s_u[kFR], s_i[kFR];
+
+  // first weight chunks of the last layer's dgrad, the sample ids, dZ_L: nothing here waits for anything else
+  FusedGemmNN gemm;
+  gemm.begin(p.fc_w[L - 1], p.layer_in[L - 1], p.layer_out[L - 1], min(p.layer_in[L - 1], kFMaxN), 0);
+  if (tid < kFR) {
+    const int64_t b = m0 + tid;
+    long long u = -1, it = -1;
+    if (b < batch) {
+      u = users[b];
+      it = items[b];
+      if (static_cast<uint64_t>(u) >= static_cast<uint64_t>(p.n_users) ||
+          static_cast<uint64_t>(it) >= static_cast<uint64_t>(p.n_items))
+        u = it = -1;  // flagged by the forward
+    }
+    s_u[tid] = u;
+    s_i[tid] = it;
+  }
+  // chain buffers alternate; the widest result (layer 0's, if anything of it were kept) belongs in `wide`
+  float* in = (L & 1) ? narrow : wide;
+  float* out = (L & 1) ? wide : narrow;
+  int ld_in = (L & 1) ? kFLdN : kFLdIn, ld_out = (L & 1) ? kFLdIn : kFLdN;
+  {
+    const int nH = p.layer_out[L - 1];
+    for (int e = tid; e < kFR * nH; e += kFThreads) {
+      const int r = e / nH, c = e - r * nH;
+      in[r * ld_in + c] = m0 + r < batch ? p.dact[L][(m0 + r) * nH + c] : 0.f;
+    }
+  }
+  lds_barrier();
+  // GMF rows: d user_mf = dmf * item_mf and the other way round (the head left dmf); E <= 64 columns, 4 rows per trip
+  if (E > 0) {
+    for (int e = tid; e < kFR * kFMaxE; e += kFThreads) {
+      const int r = e / kFMaxE, c = e % kFMaxE;
+      const long long u = s_u[r], it = s_i[r];
+      if (c < E && u >= 0) {
+        const float d = p.dmf[(m0 + r) * E + c];
+        atomic_add_f32(p.g_user_mf + u * E + c, d * p.item_mf[it * E + c]);
+        atomic_add_f32(p.g_item_mf + it * E + c, d * p.user_mf[u * E + c]);
+      }
+    }
+  }
+  for (int l = L - 1; l >= 0; --l) {
+    const int nin = p.layer_in[l], nout = p.layer_out[l];
+    const bool masked = l > 0 || p.relu_input;  // [H_{l-1} > 0]; layer 0: NeuMF's ReLU on the raw embeddings (Q7)
+    for (int n_off = 0; n_off < nin; n_off += kFMaxN) {
+      const int n_pass = min(kFMaxN, nin - n_off);
+      // this lane's four (row, column) outputs of the pass: their masks / keep bytes are requested before the GEMM
+      const int col = n_off + wn * 16 + (lane & 15);
+      const bool live_col = wn * 16 < n_pass;
+      float h[4];
+      uint8_t kb[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + 4 * (lane >> 4) + r;
+        const bool ok = live_col && row < batch;
+        h[r] = masked && ok ? p.act[l][row * nin + col] : 1.f;
+        kb[r] = 1;
+        if constexpr (DROP)
+          if (p.keep[l] && ok) kb[r] = p.keep[l][row * nin + col];
+      }
+      f32x4 acc;
+      gemm.run(acc, in, ld_in, bs);
+      // the next pass's first weight chunks travel under this epilogue
+      if (n_off + kFMaxN < nin)
+        gemm.begin(p.fc_w[l], nin, nout, min(kFMaxN, nin - n_off - kFMaxN), n_off + kFMaxN);
+      else if (l > 0)
+        gemm.begin(p.fc_w[l - 1], p.layer_in[l - 1], p.layer_out[l - 1], min(p.layer_in[l - 1], kFMaxN), 0);
+      if (live_col) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int lrow = 4 * (lane >> 4) + r;
+          float v = h[r] > 0.f ? acc[r] : 0.f;
+          if constexpr (DROP)
+            if (p.keep[l]) v = kb[r] ? v * p.keep_scale : 0.f;
+          if (l > 0) {
+            out[lrow * ld_out + col] = v;
+            if (m0 + lrow < batch) p.dact[l][(m0 + lrow) * nin + col] = v;
+          } else if (s_u[lrow] >= 0 && v != 0.f) {  // tower input = [user_mlp row | item_mlp row]
+            if (col < Dm) atomic_add_f32(p.g_user_mlp + s_u[lrow] * Dm + col, v);
+            else atomic_add_f32(p.g_item_mlp + s_i[lrow] * Dm + (col - Dm), v);
+          }
+        }
+      }
+      lds_barrier();
+    }
+    float* t = in;
+    in = out;
+    out = t;
+    const int tl = ld_in;
+    ld_in = ld_out;
+    ld_out = tl;
+  }
+}
+
 static int head_grid(int64_t batch, int samples_per_wave) {
   const int64_t per_block = static_cast<int64_t>(kHeadWaves) * samples_per_wave;
   return static_cast<int>(std::min<int64_t>(std::max<int64_t>((batch + per_block - 1) / per_block, 1), 256));
@@ -832,6 +1023,13 @@ static int fused_attrs() {
     for (const void* k : kernels) {
       const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                static_cast<int>(kFusedLdsBytes));
+      if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    const void* bwd[] = {reinterpret_cast<const void*>(&ncf_fused_dgrad_kernel<false>),
+                         reinterpret_cast<const void*>(&ncf_fused_dgrad_kernel<true>)};
+    for (const void* k : bwd) {
+      const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               static_cast<int>(kFusedBwdLdsBytes));
       if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     }
     return 0;
@@ -944,6 +1142,29 @@ extern "C" int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users
     ncf_head_kernel<true><<<head_grid(batch, 4), kHeadBlock, 0, st>>>(
         *p, ratings, batch, inv_batch, stats, static_cast<Scratch*>(scratch));
     HIPREC_TRY(hipGetLastError());
+  }
+  static const bool no_fused_bwd = getenv("HIPREC_NCF_UNFUSED_BACKWARD") != nullptr;  // A/B switch, tests
+  if (fusable(p) && !no_fused_bwd && 2 * p->n_layers <= kMaxGroup) {
+    // the input-gradient chain + the embedding scatter in ONE launch, then every layer's weight and bias gradients
+    // (which only read the dZ_l the chain wrote) in one grouped launch: 2 launches for 4
+    if (int rc = fused_attrs()) return rc;
+    bool drop = false;
+    for (int l = 0; l < p->n_layers; ++l) drop = drop || p->keep[l] != nullptr;
+    const int grid = static_cast<int>((batch + kFR - 1) / kFR);
+    if (drop)
+      ncf_fused_dgrad_kernel<true><<<grid, kFThreads, kFusedBwdLdsBytes, st>>>(*p, users, items, batch);
+    else
+      ncf_fused_dgrad_kernel<false><<<grid, kFThreads, kFusedBwdLdsBytes, st>>>(*p, users, items, batch);
+    HIPREC_TRY(hipGetLastError());
+    GemmGroup g{};
+    g.n = 0;
+    for (int l = 0; l < p->n_layers; ++l) {
+      const int nin = p->layer_in[l], nout = p->layer_out[l];
+      g.p[g.n++] = make_gemm(kTNm, nout, nin, B, p->dact[l + 1], nout, p->act[l], nin, p->g_fc_w[l], nin, nullptr, 0,
+                             nullptr, 0, /*split_k=*/true);
+      g.p[g.n++] = make_colsum(p->dact[l + 1], B, nout, nout, p->g_fc_b[l]);
+    }
+    return launch_group(g, st);
   }
   if (p->dim_mlp > 0) {
     for (int l = p->n_layers - 1; l >= 0; --l) {
