@@ -17,6 +17,7 @@
 #include <algorithm>
 
 #include <cstdlib>
+#include <cstring>
 
 #include "common.hpp"
 #include "gemm.hpp"
@@ -586,220 +587,6 @@ struct FusedGemm {
   }
 };
 
-// ---- forward: gather -> tower -> affine_output -> sigmoid; writes act[0..L], mf, scores -----------------
-// TRAIN: the head's backward half rides along (BCELoss term, d loss / d logit, dZ_L, dMF, d w_out,
-// the loss / d b_out partials) -- everything it needs is already in LDS, and a separate head launch
-// cost 12 us.
-template <bool TRAIN, bool DROP>
-__global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
-    hiprec_ncf_plan p, const int64_t* __restrict__ users, const int64_t* __restrict__ items,
-    const float* __restrict__ ratings, int64_t batch, float inv_batch, hiprec_stats* stats,
-    Scratch* scratch) {
-  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-  const FusedLds L = fused_lds(lds_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave;
-  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kFR;
-  const int Dm = p.dim_mlp, E = p.dim_mf, K0 = 2 * Dm;
-
-  // Loads that depend on nothing the block computes go first, off its serial chain: layer 0's first weight chunks,
-  // every layer's two bias elements of this lane, the head's weights and targets.
-  FusedGemm gemm;
-  if (p.n_layers > 0) gemm.begin(p.fc_w[0], p.layer_in[0], p.layer_out[0]);
-  float bias_now, bias_next;  // this lane's bias element of the current / the next layer
-  auto load_bias = [&](int l) {
-    const int col = wn * 16 + (lane & 15);
-    return l < p.n_layers && col < p.layer_out[l] ? p.fc_b[l][col] : 0.f;
-  };
-  bias_now = load_bias(0);
-  const int nH = p.n_layers > 0 ? p.layer_out[p.n_layers - 1] : 0, nV = nH + p.dim_mf;
-  const float bo = load_scalar_param(p.out_b);
-  float wout[3];  // nV <= 192
-#pragma unroll
-  for (int k = 0; k < 3; ++k) wout[k] = lane + kWave * k < nV ? p.out_w[lane + kWave * k] : 0.f;
-  float rt[kFR / kFWaves];
-  if (TRAIN) {
-#pragma unroll
-    for (int j = 0; j < kFR / kFWaves; ++j) {
-      const int64_t b = m0 + wave + j * kFWaves;
-      rt[j] = ratings[b < batch ? b : batch - 1];
-    }
-  }
-
-  // gather, element-parallel: 64 threads fetch the index pairs, then every thread owns
-  // kFR * K0 / 256 <= 16 elements of the tower input; all its loads are requested before anything
-  // is stored (one round trip for the whole tile instead of one per row)
-  __shared__ long long s_u[kFR], s_i[kFR];
-  if (tid < kFR) {
-    const int64_t b = m0 + tid;
-    long long u = -1, it = -1;
-    if (b < batch) {
-      u = users[b];
-      it = items[b];
-      const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(p.n_users);
-      const bool i_ok = static_cast<uint64_t>(it) < static_cast<uint64_t>(p.n_items);
-      if (!(u_ok && i_ok)) {
-        atomicOr(&stats->status,
-                 (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
-        u = it = -1;
-      }
-    }
-    s_u[tid] = u;
-    s_i[tid] = it;
-  }
-  lds_barrier();
-  {
-    // thread t owns column t % 256 of the rows of its half (t / 256) of the tile and (row j * 8 + t / 64, column
-    // t % 64) of the GMF tile: no divisions, one load per row, all requested before anything is stored
-    static_assert(kFThreads % kFMaxIn == 0 && kFMaxE == kWave, "gather mapping");
-    constexpr int kHalves = kFThreads / kFMaxIn, kRowsPer = kFR / kHalves;  // 2 halves of 8 rows
-    float v[kRowsPer];
-    const int col_t = tid & (kFMaxIn - 1), row0 = (tid / kFMaxIn) * kRowsPer;
-    const int c = col_t < K0 ? col_t : 0;
-    const bool c_user = c < Dm;
-    const float* base = c_user ? p.user_mlp + c : p.item_mlp + (c - Dm);
-#pragma unroll
-    for (int r = 0; r < kRowsPer; ++r) {
-      const long long idx = c_user ? s_u[row0 + r] : s_i[row0 + r];
-      v[r] = base[(idx >= 0 ? idx : 0) * Dm];  // flagged samples read row 0 and are zeroed below
-    }
-    constexpr int kPerE = kFR * kFMaxE / kFThreads;  // 8
-    float w[kPerE];
-    const int ce = (tid & 63) < E ? (tid & 63) : 0;
-#pragma unroll
-    for (int j = 0; j < kPerE; ++j) {
-      const int r = j * (kFThreads / kWave) + (tid >> 6);
-      const long long u = s_u[r], it = s_i[r];
-      w[j] = E > 0 ? p.user_mf[(u >= 0 ? u : 0) * E + ce] * p.item_mf[(it >= 0 ? it : 0) * E + ce] : 0.f;
-    }
-    if (col_t < K0) {
-#pragma unroll
-      for (int j = 0; j < kRowsPer; ++j) {
-        const int r = row0 + j;
-        float x = s_u[r] >= 0 ? v[j] : 0.f;
-        if (p.relu_input) x = fmaxf(x, 0.f);
-        // the Dropout in front of the first Linear (ncf.py:42-45, mlp.py:30-33): one keep byte per element
-        if constexpr (DROP)
-          if (p.keep[0] && m0 + r < batch) x = p.keep[0][(m0 + r) * K0 + col_t] ? x * p.keep_scale : 0.f;
-        L.wide[r * kFLdIn + col_t] = x;
-        if (m0 + r < batch) p.act[0][(m0 + r) * K0 + col_t] = x;
-      }
-    }
-    if ((tid & 63) < E) {
-#pragma unroll
-      for (int j = 0; j < kPerE; ++j) {
-        const int r = j * (kFThreads / kWave) + (tid >> 6);
-        const float x = s_u[r] >= 0 ? w[j] : 0.f;
-        L.mf[r * kFLdE + (tid & 63)] = x;
-        if (m0 + r < batch) p.mf[(m0 + r) * E + (tid & 63)] = x;
-      }
-    }
-  }
-  lds_barrier();
-
-  const float* in = L.wide;
-  float* out = L.narrow;
-  for (int l = 0; l < p.n_layers; ++l) {
-    const int N = p.layer_out[l];
-    f32x4 acc;
-    gemm.run(acc, in, L.ld_of(in), L.bs);
-    if (l + 1 < p.n_layers) gemm.begin(p.fc_w[l + 1], p.layer_in[l + 1], p.layer_out[l + 1]);  // under the epilogue
-    bias_next = load_bias(l + 1);
-    if (wn * 16 < N) {
-      const int ld_out = L.ld_of(out);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {   // C[row 4 * (lane >> 4) + r][col lane & 15]
-        const int col = wn * 16 + (lane & 15);
-        const int row = 4 * (lane >> 4) + r;
-        float v = fmaxf(acc[r] + bias_now, 0.f);
-        // act[l + 1] is what the NEXT Linear sees: its Dropout is applied here (the backward's dgrad epilogue
-        // applies the same keep bytes)
-        if constexpr (DROP)
-          if (l + 1 < p.n_layers && p.keep[l + 1] && m0 + row < batch)
-            v = p.keep[l + 1][(m0 + row) * N + col] ? v * p.keep_scale : 0.f;
-        out[row * ld_out + col] = v;
-        if (m0 + row < batch) p.act[l + 1][(m0 + row) * N + col] = v;
-      }
-    }
-    lds_barrier();
-    const float* t = in;
-    in = out;
-    out = const_cast<float*>(t);
-    bias_now = bias_next;
-  }
-
-  // affine_output + sigmoid: wave w scores rows w, w + 8, ...
-  const int ld_h = L.ld_of(in);
-  const bool stepper = TRAIN && blockIdx.x == 0 && tid == 0;
-  StepState step_state{};
-  if (stepper) step_state = step_load(stats);
-  float loss_acc = 0.f, gb_acc = 0.f;
-  float gw[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < kFR / kFWaves; ++j) {
-    const int r = wave + j * kFWaves;
-    const int64_t b = m0 + r;
-    if (b >= batch) continue;
-    float vec[3];
-    float part = 0.f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int c = lane + kWave * k;
-      vec[k] = c < nH ? in[r * ld_h + c] : (c < nV ? L.mf[r * kFLdE + (c - nH)] : 0.f);
-      part += vec[k] * wout[k];
-    }
-    const float logit = wave_sum(part) + bo;
-    const float y = sigmoid_f32(logit);
-    if (lane == 0) p.scores[b] = y;
-    if (!TRAIN) continue;
-    const float ly = fmaxf(logf(y), -100.f);
-    const float l1y = fmaxf(log1pf(-y), -100.f);
-    loss_acc += -(rt[j] * ly + (1.f - rt[j]) * l1y);
-    const float gy = (y - rt[j]) / fmaxf((1.f - y) * y, 1e-12f) * inv_batch;
-    const float dl = gy * ((1.f - y) * y);
-    gb_acc += dl;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int c = lane + kWave * k;
-      if (c < nV) gw[k] += dl * vec[k];
-      if (c < nH) {
-        // d loss / d z_L = d h_L * [h_L > 0]  (ReLU of the last Linear, applied twice in NeuMF)
-        p.dact[p.n_layers][b * nH + c] = vec[k] > 0.f ? dl * wout[k] : 0.f;
-      } else if (c < nV) {
-        p.dmf[b * E + (c - nH)] = dl * wout[k];
-      }
-    }
-  }
-  if (!TRAIN) return;
-  if (stepper) step_store_advanced(stats, step_state);
-  // d affine_output.weight: the waves' sums meet in LDS (the weight tile is free by now), one atomic
-  // per (block, column); loss partial (reg slot unused = 0), d b_out in the scalar-gradient slot
-  float* s_gw = L.bs;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int c = lane + kWave * k;
-    if (c < nV) s_gw[wave * (kFMaxN + kFMaxE) + c] = gw[k];
-  }
-  publish_partials<kFWaves>(loss_acc, 0.f, gb_acc, inv_batch, scratch);  // barriers inside
-  lds_barrier();
-  for (int c = tid; c < nV; c += kFThreads) {
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < kFWaves; ++w) t += s_gw[w * (kFMaxN + kFMaxE) + c];
-    if (t != 0.f) atomic_add_f32(p.g_out_w + c, t);
-  }
-}
-
-
-// ---- backward: dZ_L -> dZ_{L-1} -> ... -> d(tower input), embedding-row gradients scattered on the way out ------
-// The input-gradient chain of the tower for 16 samples, in LDS like the forward: dZ_{l-1} = (dZ_l W_l) * [H_{l-1} > 0]
-// (and the Dropout in front of Linear l).  The three grouped launches it replaces each paid 11-18 us for a dgrad that
-// the next launch had to wait for; the weight / bias gradients, which only READ the dZ_l this kernel writes, follow in
-// one grouped launch.  W_l ([nout][nin] row-major) is the B operand as it lies in memory: k = its rows, 16-byte
-// staging loads along n.  A pass produces 128 columns (8 waves x 16); the 2 * dim_mlp columns of layer 0 take two.
-// The layer-0 pass never writes d(tower input): each lane adds its four elements straight into the user / item
-// embedding gradients (what ncf_scatter_kernel did in a launch of its own), and the GMF rows' gradients leave at
-// the start, they depend on the head only.
 constexpr int kFLdB = kFMaxN + 8;  // 136: 16-byte aligned tile rows, two-way bank conflicts on the B reads
 constexpr size_t kFusedBwdLdsBytes = sizeof(float) * (kFR * kFLdIn + kFR * kFLdN + 2 * kFK * kFLdB);
 
@@ -873,6 +660,326 @@ struct FusedGemmNN {
   }
 };
 
+// LDS of the forward + backward launch (BWD): every layer's activations stay (the backward masks with them), two
+// buffers carry the input-gradient chain, the weight tiles of both directions share one region.
+constexpr size_t kFusedTrainLdsBytes =
+    sizeof(float) * (kFR * kFLdIn + (HIPREC_NCF_MAX_LAYERS + 2) * kFR * kFLdN + 2 * kFK * kFLdB + kFR * kFLdE);
+
+// ---- forward: gather -> tower -> affine_output -> sigmoid; writes act[0..L], mf, scores -----------------
+// TRAIN: the head's backward half rides along (BCELoss term, d loss / d logit, dZ_L, dMF, d w_out,
+// the loss / d b_out partials) -- everything it needs is already in LDS, and a separate head launch
+// cost 12 us.
+template <bool TRAIN, bool DROP, bool BWD = false>
+__global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
+    hiprec_ncf_plan p, const int64_t* __restrict__ users, const int64_t* __restrict__ items,
+    const float* __restrict__ ratings, int64_t batch, float inv_batch, hiprec_stats* stats,
+    Scratch* scratch) {
+  static_assert(!BWD || TRAIN, "the backward rides on the training forward");
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  FusedLds L = fused_lds(lds_raw);
+  float* acts = nullptr;   // BWD: [n_layers][kFR][kFLdN] activations of layers 1..L, then two chain buffers
+  if constexpr (BWD) {     // layout: wide | acts + chain | tiles (kFLdB wide) | mf
+    acts = L.wide + kFR * kFLdIn;
+    L.narrow = acts;  // (unused as such)
+    L.bs = acts + (HIPREC_NCF_MAX_LAYERS + 2) * kFR * kFLdN;
+    L.mf = L.bs + 2 * kFK * kFLdB;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kFR;
+  const int Dm = p.dim_mlp, E = p.dim_mf, K0 = 2 * Dm;
+  // where layer l's input (= act[l]) lives: l = 0 the gathered rows; without BWD the two buffers alternate
+  auto act_buf = [&](int l) -> float* {
+    if (l == 0) return L.wide;
+    if constexpr (BWD) return acts + (l - 1) * kFR * kFLdN;
+    return (l & 1) ? L.narrow : L.wide;
+  };
+  auto act_ld = [&](int l) { return (l == 0 || (!BWD && !(l & 1))) ? kFLdIn : kFLdN; };
+
+  // Loads that depend on nothing the block computes go first, off its serial chain: layer 0's first weight chunks,
+  // every layer's two bias elements of this lane, the head's weights and targets.
+  FusedGemm gemm;
+  if (p.n_layers > 0) gemm.begin(p.fc_w[0], p.layer_in[0], p.layer_out[0]);
+  float bias_now, bias_next;  // this lane's bias element of the current / the next layer
+  auto load_bias = [&](int l) {
+    const int col = wn * 16 + (lane & 15);
+    return l < p.n_layers && col < p.layer_out[l] ? p.fc_b[l][col] : 0.f;
+  };
+  bias_now = load_bias(0);
+  const int nH = p.n_layers > 0 ? p.layer_out[p.n_layers - 1] : 0, nV = nH + p.dim_mf;
+  const float bo = load_scalar_param(p.out_b);
+  float wout[3];  // nV <= 192
+#pragma unroll
+  for (int k = 0; k < 3; ++k) wout[k] = lane + kWave * k < nV ? p.out_w[lane + kWave * k] : 0.f;
+  float rt[kFR / kFWaves];
+  if (TRAIN) {
+#pragma unroll
+    for (int j = 0; j < kFR / kFWaves; ++j) {
+      const int64_t b = m0 + wave + j * kFWaves;
+      rt[j] = ratings[b < batch ? b : batch - 1];
+    }
+  }
+
+  // gather, element-parallel: 64 threads fetch the index pairs, then every thread owns
+  // kFR * K0 / 256 <= 16 elements of the tower input; all its loads are requested before anything
+  // is stored (one round trip for the whole tile instead of one per row)
+  __shared__ long long s_u[kFR], s_i[kFR];
+  if (tid < kFR) {
+    const int64_t b = m0 + tid;
+    long long u = -1, it = -1;
+    if (b < batch) {
+      u = users[b];
+      it = items[b];
+      const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(p.n_users);
+      const bool i_ok = static_cast<uint64_t>(it) < static_cast<uint64_t>(p.n_items);
+      if (!(u_ok && i_ok)) {
+        atomicOr(&stats->status,
+                 (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
+        u = it = -1;
+      }
+    }
+    s_u[tid] = u;
+    s_i[tid] = it;
+  }
+  lds_barrier();
+  constexpr int kPerE = kFR * kFMaxE / kFThreads;  // GMF elements per thread (2)
+  float gmf_um[kPerE], gmf_im[kPerE];              // BWD: the two factors, for the GMF rows' gradients
+  {
+    // thread t owns column t % 256 of the rows of its half (t / 256) of the tile and (row j * 8 + t / 64, column
+    // t % 64) of the GMF tile: no divisions, one load per row, all requested before anything is stored
+    static_assert(kFThreads % kFMaxIn == 0 && kFMaxE == kWave, "gather mapping");
+    constexpr int kHalves = kFThreads / kFMaxIn, kRowsPer = kFR / kHalves;  // 2 halves of 8 rows
+    float v[kRowsPer];
+    const int col_t = tid & (kFMaxIn - 1), row0 = (tid / kFMaxIn) * kRowsPer;
+    const int c = col_t < K0 ? col_t : 0;
+    const bool c_user = c < Dm;
+    const float* base = c_user ? p.user_mlp + c : p.item_mlp + (c - Dm);
+#pragma unroll
+    for (int r = 0; r < kRowsPer; ++r) {
+      const long long idx = c_user ? s_u[row0 + r] : s_i[row0 + r];
+      v[r] = base[(idx >= 0 ? idx : 0) * Dm];  // flagged samples read row 0 and are zeroed below
+    }
+    float w[kPerE];
+    const int ce = (tid & 63) < E ? (tid & 63) : 0;
+#pragma unroll
+    for (int j = 0; j < kPerE; ++j) {
+      const int r = j * (kFThreads / kWave) + (tid >> 6);
+      const long long u = s_u[r], it = s_i[r];
+      const float um = E > 0 ? p.user_mf[(u >= 0 ? u : 0) * E + ce] : 0.f;
+      const float im = E > 0 ? p.item_mf[(it >= 0 ? it : 0) * E + ce] : 0.f;
+      w[j] = um * im;
+      if constexpr (BWD) {
+        gmf_um[j] = um;
+        gmf_im[j] = im;
+      }
+    }
+    if (col_t < K0) {
+#pragma unroll
+      for (int j = 0; j < kRowsPer; ++j) {
+        const int r = row0 + j;
+        float x = s_u[r] >= 0 ? v[j] : 0.f;
+        if (p.relu_input) x = fmaxf(x, 0.f);
+        // the Dropout in front of the first Linear (ncf.py:42-45, mlp.py:30-33): one keep byte per element
+        if constexpr (DROP)
+          if (p.keep[0] && m0 + r < batch) x = p.keep[0][(m0 + r) * K0 + col_t] ? x * p.keep_scale : 0.f;
+        L.wide[r * kFLdIn + col_t] = x;
+        if (m0 + r < batch) p.act[0][(m0 + r) * K0 + col_t] = x;
+      }
+    }
+    if ((tid & 63) < E) {
+#pragma unroll
+      for (int j = 0; j < kPerE; ++j) {
+        const int r = j * (kFThreads / kWave) + (tid >> 6);
+        const float x = s_u[r] >= 0 ? w[j] : 0.f;
+        L.mf[r * kFLdE + (tid & 63)] = x;
+        if (m0 + r < batch) p.mf[(m0 + r) * E + (tid & 63)] = x;
+      }
+    }
+  }
+  lds_barrier();
+
+  for (int l = 0; l < p.n_layers; ++l) {
+    const int N = p.layer_out[l];
+    const float* in = act_buf(l);
+    float* out = act_buf(l + 1);
+    f32x4 acc;
+    gemm.run(acc, in, act_ld(l), L.bs);
+    if (l + 1 < p.n_layers) gemm.begin(p.fc_w[l + 1], p.layer_in[l + 1], p.layer_out[l + 1]);  // under the epilogue
+    bias_next = load_bias(l + 1);
+    if (wn * 16 < N) {
+      const int ld_out = act_ld(l + 1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {   // C[row 4 * (lane >> 4) + r][col lane & 15]
+        const int col = wn * 16 + (lane & 15);
+        const int row = 4 * (lane >> 4) + r;
+        float v = fmaxf(acc[r] + bias_now, 0.f);
+        // act[l + 1] is what the NEXT Linear sees: its Dropout is applied here (the backward's dgrad epilogue
+        // applies the same keep bytes)
+        if constexpr (DROP)
+          if (l + 1 < p.n_layers && p.keep[l + 1] && m0 + row < batch)
+            v = p.keep[l + 1][(m0 + row) * N + col] ? v * p.keep_scale : 0.f;
+        out[row * ld_out + col] = v;
+        if (m0 + row < batch) p.act[l + 1][(m0 + row) * N + col] = v;
+      }
+    }
+    lds_barrier();
+    bias_now = bias_next;
+  }
+
+  FusedGemmNN gnn;  // BWD: the first weight chunks of the input-gradient chain travel under the head
+  if constexpr (BWD)
+    gnn.begin(p.fc_w[p.n_layers - 1], p.layer_in[p.n_layers - 1], p.layer_out[p.n_layers - 1],
+              min(p.layer_in[p.n_layers - 1], kFMaxN), 0);
+  // affine_output + sigmoid: wave w scores rows w, w + 8, ...
+  const float* in = act_buf(p.n_layers);
+  const int ld_h = act_ld(p.n_layers);
+  float* chain_a = nullptr;  // BWD: dZ_L of the tile, the input of the backward chain
+  if constexpr (BWD) chain_a = acts + HIPREC_NCF_MAX_LAYERS * kFR * kFLdN;
+  const bool stepper = TRAIN && blockIdx.x == 0 && tid == 0;
+  StepState step_state{};
+  if (stepper) step_state = step_load(stats);
+  float loss_acc = 0.f, gb_acc = 0.f;
+  float gw[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < kFR / kFWaves; ++j) {
+    const int r = wave + j * kFWaves;
+    const int64_t b = m0 + r;
+    if (b >= batch) {
+      if constexpr (BWD) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (lane + kWave * k < nH) chain_a[r * kFLdN + lane + kWave * k] = 0.f;
+      }
+      continue;
+    }
+    float vec[3];
+    float part = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int c = lane + kWave * k;
+      vec[k] = c < nH ? in[r * ld_h + c] : (c < nV ? L.mf[r * kFLdE + (c - nH)] : 0.f);
+      part += vec[k] * wout[k];
+    }
+    const float logit = wave_sum(part) + bo;
+    const float y = sigmoid_f32(logit);
+    if (lane == 0) p.scores[b] = y;
+    if (!TRAIN) continue;
+    const float ly = fmaxf(logf(y), -100.f);
+    const float l1y = fmaxf(log1pf(-y), -100.f);
+    loss_acc += -(rt[j] * ly + (1.f - rt[j]) * l1y);
+    const float gy = (y - rt[j]) / fmaxf((1.f - y) * y, 1e-12f) * inv_batch;
+    const float dl = gy * ((1.f - y) * y);
+    gb_acc += dl;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int c = lane + kWave * k;
+      if (c < nV) gw[k] += dl * vec[k];
+      if (c < nH) {
+        // d loss / d z_L = d h_L * [h_L > 0]  (ReLU of the last Linear, applied twice in NeuMF)
+        const float dz = vec[k] > 0.f ? dl * wout[k] : 0.f;
+        p.dact[p.n_layers][b * nH + c] = dz;
+        if constexpr (BWD) chain_a[r * kFLdN + c] = dz;
+      } else if (c < nV) {
+        p.dmf[b * E + (c - nH)] = dl * wout[k];
+        if constexpr (BWD) L.mf[r * kFLdE + (c - nH)] = dl * wout[k];  // (this lane just read the product there)
+      }
+    }
+  }
+  if (!TRAIN) return;
+  if (stepper) step_store_advanced(stats, step_state);
+  // d affine_output.weight: the waves' sums meet in LDS (the weight tile is free by now), one atomic
+  // per (block, column); loss partial (reg slot unused = 0), d b_out in the scalar-gradient slot
+  float* s_gw = L.bs;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int c = lane + kWave * k;
+    if (c < nV) s_gw[wave * (kFMaxN + kFMaxE) + c] = gw[k];
+  }
+  publish_partials<kFWaves>(loss_acc, 0.f, gb_acc, inv_batch, scratch);  // barriers inside
+  lds_barrier();
+  for (int c = tid; c < nV; c += kFThreads) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < kFWaves; ++w) t += s_gw[w * (kFMaxN + kFMaxE) + c];
+    if (t != 0.f) atomic_add_f32(p.g_out_w + c, t);
+  }
+  if constexpr (BWD) {
+    // ---- the input-gradient chain on the same 16 samples (ncf_fused_dgrad_kernel, with everything it loads from
+    // HBM already here: ids, activations for the ReLU masks, dZ_L, the GMF factors) ----
+    lds_barrier();  // s_gw lived in the weight tiles
+    float* cin = chain_a;
+    float* cout = chain_a + kFR * kFLdN;
+    for (int l = p.n_layers - 1; l >= 0; --l) {
+      const int nin = p.layer_in[l], nout = p.layer_out[l];
+      const bool masked = l > 0 || p.relu_input;
+      const float* h_l = act_buf(l);
+      const int ld_h_l = act_ld(l);
+      for (int n_off = 0; n_off < nin; n_off += kFMaxN) {
+        const int n_pass = min(kFMaxN, nin - n_off);
+        const int col = n_off + wn * 16 + (lane & 15);
+        const bool live_col = wn * 16 < n_pass;
+        uint8_t kb[4] = {1, 1, 1, 1};
+        if constexpr (DROP) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t row = m0 + 4 * (lane >> 4) + r;
+            if (p.keep[l] && live_col && row < batch) kb[r] = p.keep[l][row * nin + col];
+          }
+        }
+        f32x4 acc;
+        gnn.run(acc, cin, kFLdN, L.bs);
+        if (n_off + kFMaxN < nin)
+          gnn.begin(p.fc_w[l], nin, nout, min(kFMaxN, nin - n_off - kFMaxN), n_off + kFMaxN);
+        else if (l > 0)
+          gnn.begin(p.fc_w[l - 1], p.layer_in[l - 1], p.layer_out[l - 1], min(p.layer_in[l - 1], kFMaxN), 0);
+        if (live_col) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int lrow = 4 * (lane >> 4) + r;
+            float v = (!masked || h_l[lrow * ld_h_l + col] > 0.f) ? acc[r] : 0.f;
+            if constexpr (DROP)
+              if (p.keep[l]) v = kb[r] ? v * p.keep_scale : 0.f;
+            if (l > 0) {
+              cout[lrow * kFLdN + col] = v;
+              if (m0 + lrow < batch) p.dact[l][(m0 + lrow) * nin + col] = v;
+            } else if (s_u[lrow] >= 0 && v != 0.f) {  // tower input = [user_mlp row | item_mlp row]
+              if (col < Dm) atomic_add_f32(p.g_user_mlp + s_u[lrow] * Dm + col, v);
+              else atomic_add_f32(p.g_item_mlp + s_i[lrow] * Dm + (col - Dm), v);
+            }
+          }
+        }
+        lds_barrier();
+      }
+      float* t = cin;
+      cin = cout;
+      cout = t;
+    }
+    // GMF rows: d user_mf = dmf * item_mf and the other way round (dmf sits where the product was)
+    if ((tid & 63) < E) {
+#pragma unroll
+      for (int j = 0; j < kPerE; ++j) {
+        const int r = j * (kFThreads / kWave) + (tid >> 6);
+        const long long u = s_u[r], it = s_i[r];
+        const float d = L.mf[r * kFLdE + (tid & 63)];
+        if (u >= 0 && m0 + r < batch && d != 0.f) {
+          atomic_add_f32(p.g_user_mf + u * E + (tid & 63), d * gmf_im[j]);
+          atomic_add_f32(p.g_item_mf + it * E + (tid & 63), d * gmf_um[j]);
+        }
+      }
+    }
+  }
+}
+
+
+// ---- backward: dZ_L -> dZ_{L-1} -> ... -> d(tower input), embedding-row gradients scattered on the way out ------
+// The input-gradient chain of the tower for 16 samples, in LDS like the forward: dZ_{l-1} = (dZ_l W_l) * [H_{l-1} > 0]
+// (and the Dropout in front of Linear l).  The three grouped launches it replaces each paid 11-18 us for a dgrad that
+// the next launch had to wait for; the weight / bias gradients, which only READ the dZ_l this kernel writes, follow in
+// one grouped launch.  W_l ([nout][nin] row-major) is the B operand as it lies in memory: k = its rows, 16-byte
+// staging loads along n.  A pass produces 128 columns (8 waves x 16); the 2 * dim_mlp columns of layer 0 take two.
+// The layer-0 pass never writes d(tower input): each lane adds its four elements straight into the user / item
+// embedding gradients (what ncf_scatter_kernel did in a launch of its own), and the GMF rows' gradients leave at
+// the start, they depend on the head only.
 template <bool DROP>
 __global__ __launch_bounds__(kFThreads) void ncf_fused_dgrad_kernel(hiprec_ncf_plan p,
                                                                     const int64_t* __restrict__ users,
@@ -915,17 +1022,18 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_dgrad_kernel(hiprec_ncf_p
     }
   }
   lds_barrier();
-  // GMF rows: d user_mf = dmf * item_mf and the other way round (the head left dmf); E <= 64 columns, 4 rows per trip
-  if (E > 0) {
-    for (int e = tid; e < kFR * kFMaxE; e += kFThreads) {
-      const int r = e / kFMaxE, c = e % kFMaxE;
-      const long long u = s_u[r], it = s_i[r];
-      if (c < E && u >= 0) {
-        const float d = p.dmf[(m0 + r) * E + c];
-        atomic_add_f32(p.g_user_mf + u * E + c, d * p.item_mf[it * E + c]);
-        atomic_add_f32(p.g_item_mf + it * E + c, d * p.user_mf[u * E + c]);
-      }
-    }
+  // GMF rows: d user_mf = dmf * item_mf and the other way round (the head left dmf).  Operands are requested here,
+  // the atomics leave after the chain: ahead of it they were on every block's critical path.
+  constexpr int kGmfPer = kFR * kFMaxE / kFThreads;  // 2 elements per thread
+  float g_d[kGmfPer], g_im[kGmfPer], g_um[kGmfPer];
+#pragma unroll
+  for (int j = 0; j < kGmfPer; ++j) {
+    const int e = tid + j * kFThreads, r = e / kFMaxE, c = e % kFMaxE;
+    const long long u = s_u[r], it = s_i[r];
+    const bool ok = c < E && u >= 0;
+    g_d[j] = ok ? p.dmf[(m0 + r) * E + c] : 0.f;
+    g_im[j] = ok ? p.item_mf[it * E + c] : 0.f;
+    g_um[j] = ok ? p.user_mf[u * E + c] : 0.f;
   }
   for (int l = L - 1; l >= 0; --l) {
     const int nin = p.layer_in[l], nout = p.layer_out[l];
@@ -978,6 +1086,15 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_dgrad_kernel(hiprec_ncf_p
     ld_in = ld_out;
     ld_out = tl;
   }
+#pragma unroll
+  for (int j = 0; j < kGmfPer; ++j) {
+    const int e = tid + j * kFThreads, r = e / kFMaxE, c = e % kFMaxE;
+    const long long u = s_u[r], it = s_i[r];
+    if (c < E && u >= 0 && g_d[j] != 0.f) {
+      atomic_add_f32(p.g_user_mf + u * E + c, g_d[j] * g_im[j]);
+      atomic_add_f32(p.g_item_mf + it * E + c, g_d[j] * g_um[j]);
+    }
+  }
 }
 
 static int head_grid(int64_t batch, int samples_per_wave) {
@@ -1025,6 +1142,13 @@ static int fused_attrs() {
                                                static_cast<int>(kFusedLdsBytes));
       if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     }
+    const void* train[] = {reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, false, true>),
+                           reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, true, true>)};
+    for (const void* k : train) {
+      const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               static_cast<int>(kFusedTrainLdsBytes));
+      if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
     const void* bwd[] = {reinterpret_cast<const void*>(&ncf_fused_dgrad_kernel<false>),
                          reinterpret_cast<const void*>(&ncf_fused_dgrad_kernel<true>)};
     for (const void* k : bwd) {
@@ -1042,7 +1166,10 @@ static int fused_attrs() {
 // "plan->scores, dact[L], dmf, g_out_w and the loss partials are all in place".
 static int forward(const hiprec_ncf_plan* p, const int64_t* users, const int64_t* items,
                    int64_t batch, hiprec_stats* stats, hipStream_t st, bool* scored,
-                   const float* ratings = nullptr, float inv_batch = 0.f, Scratch* scratch = nullptr) {
+                   const float* ratings = nullptr, float inv_batch = 0.f, Scratch* scratch = nullptr,
+                   bool* chained = nullptr) {
+  // chained (training only): if given and the fused launch is taken, it also runs the tower's input-gradient chain
+  // and the embedding scatter (*chained = true); the caller then only owes the weight / bias gradients
   *scored = false;
   // the training launch publishes one loss partial per block: batches beyond kMaxBlocks * kFR samples (32 768) take
   // the launch-per-layer path
@@ -1051,7 +1178,15 @@ static int forward(const hiprec_ncf_plan* p, const int64_t* users, const int64_t
     const int grid = static_cast<int>((batch + kFR - 1) / kFR);
     bool drop = false;
     for (int l = 0; l < p->n_layers; ++l) drop = drop || p->keep[l] != nullptr;
-    if (ratings && drop)
+    if (ratings && chained) {
+      if (drop)
+        ncf_fused_forward_kernel<true, true, true><<<grid, kFThreads, kFusedTrainLdsBytes, st>>>(
+            *p, users, items, ratings, batch, inv_batch, stats, scratch);
+      else
+        ncf_fused_forward_kernel<true, false, true><<<grid, kFThreads, kFusedTrainLdsBytes, st>>>(
+            *p, users, items, ratings, batch, inv_batch, stats, scratch);
+      *chained = true;
+    } else if (ratings && drop)
       ncf_fused_forward_kernel<true, true><<<grid, kFThreads, kFusedLdsBytes, st>>>(
           *p, users, items, ratings, batch, inv_batch, stats, scratch);
     else if (ratings)
@@ -1134,28 +1269,36 @@ extern "C" int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users
   const hiprec_ncf_plan* p = plan;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int B = static_cast<int>(batch);
-  bool scored = false;
+  // HIPREC_NCF_BACKWARD (A/B switch, tests): "unfused" = one grouped launch per layer + scatter, "split" = the
+  // chain in its own launch after the forward; default: forward + chain in one launch
+  static const char* bwd_env = getenv("HIPREC_NCF_BACKWARD");
+  static const bool no_fused_bwd = bwd_env && strcmp(bwd_env, "unfused") == 0;
+  static const bool split_bwd = bwd_env && strcmp(bwd_env, "split") == 0;
+  const bool fuse_bwd = fusable(p) && !no_fused_bwd && 2 * p->n_layers <= kMaxGroup;
+  bool scored = false, chained = false;
   if (int rc = forward(p, users, items, batch, stats, st, &scored, ratings, inv_batch,
-                       static_cast<Scratch*>(scratch)))
+                       static_cast<Scratch*>(scratch), fuse_bwd && !split_bwd ? &chained : nullptr))
     return rc;
   if (!scored) {
     ncf_head_kernel<true><<<head_grid(batch, 4), kHeadBlock, 0, st>>>(
         *p, ratings, batch, inv_batch, stats, static_cast<Scratch*>(scratch));
     HIPREC_TRY(hipGetLastError());
   }
-  static const bool no_fused_bwd = getenv("HIPREC_NCF_UNFUSED_BACKWARD") != nullptr;  // A/B switch, tests
-  if (fusable(p) && !no_fused_bwd && 2 * p->n_layers <= kMaxGroup) {
-    // the input-gradient chain + the embedding scatter in ONE launch, then every layer's weight and bias gradients
-    // (which only read the dZ_l the chain wrote) in one grouped launch: 2 launches for 4
-    if (int rc = fused_attrs()) return rc;
-    bool drop = false;
-    for (int l = 0; l < p->n_layers; ++l) drop = drop || p->keep[l] != nullptr;
-    const int grid = static_cast<int>((batch + kFR - 1) / kFR);
-    if (drop)
-      ncf_fused_dgrad_kernel<true><<<grid, kFThreads, kFusedBwdLdsBytes, st>>>(*p, users, items, batch);
-    else
-      ncf_fused_dgrad_kernel<false><<<grid, kFThreads, kFusedBwdLdsBytes, st>>>(*p, users, items, batch);
-    HIPREC_TRY(hipGetLastError());
+  if (fuse_bwd) {
+    // the input-gradient chain + the embedding scatter ride on the forward launch (or, when that took the
+    // launch-per-layer path, run in ONE launch of their own), then every layer's weight and bias gradients -- which
+    // only read the dZ_l the chain wrote -- in one grouped launch: 2 launches for the 5 of round 1
+    if (!chained) {
+      if (int rc = fused_attrs()) return rc;
+      bool drop = false;
+      for (int l = 0; l < p->n_layers; ++l) drop = drop || p->keep[l] != nullptr;
+      const int grid = static_cast<int>((batch + kFR - 1) / kFR);
+      if (drop)
+        ncf_fused_dgrad_kernel<true><<<grid, kFThreads, kFusedBwdLdsBytes, st>>>(*p, users, items, batch);
+      else
+        ncf_fused_dgrad_kernel<false><<<grid, kFThreads, kFusedBwdLdsBytes, st>>>(*p, users, items, batch);
+      HIPREC_TRY(hipGetLastError());
+    }
     GemmGroup g{};
     g.n = 0;
     for (int l = 0; l < p->n_layers; ++l) {
