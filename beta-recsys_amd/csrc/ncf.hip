@@ -439,14 +439,14 @@ __global__ __launch_bounds__(kBlock) void ncf_scatter_kernel(hiprec_ncf_plan p,
   }
 }
 
-// ======================= fused tower: one launch forward, one launch backward ========================
+// ======================= fused tower: the per-sample chain of a training step in one launch ===========
 // At batch 4096 every stand-alone launch of this path (gather, a 4096 x 128 x 256 GEMM, the head...)
 // costs 8-14 us although its arithmetic is worth 1-2 us: each one starts by missing on what the
-// previous launch wrote (rocprofv3: 11 launches, 106 us per step).  A block of 8 waves that owns 64
-// samples can carry them through the whole tower without leaving the CU: the activations of the 64
-// samples stay in LDS between layers (they are also written to HBM once, for the weight-gradient
-// GEMMs), only the weights stream through a 32-row LDS tile, and the head / the embedding-gradient
-// scatter run on the same rows at the two ends.  Layers are fp32 MFMA 32x32x2 as in gemm_tile.
+// previous launch wrote (rocprofv3, round 1: 11 launches, 106 us per step).  A block of 8 waves that owns 16
+// samples carries them through the whole tower, the head, the tower's input-gradient chain and the embedding
+// scatter without leaving the CU: the activations stay in LDS between layers and for the backward's ReLU masks
+// (they are also written to HBM once, with the dZ_l, for the weight-gradient GEMMs), only the weights stream
+// through a 32-k LDS tile.  Layers are fp32 MFMA 16x16x4 (one 16 x 16 output tile per wave and pass).
 // Shapes outside the limits below take the unfused path.
 constexpr int kFR = 16;                    // samples per block: 16-row MFMA tiles (v_mfma_f32_16x16x4_f32), 256 blocks at
                                            // B 4096 = one per CU (32-row tiles: 128 blocks, half the chip idle)
@@ -455,44 +455,52 @@ constexpr int kFWaves = 8;                 // one wave per 16 output columns of 
                                            // of 32 columns a 32-k chunk took ~1800 cycles for 512 cycles of MFMA)
 constexpr int kFThreads = kFWaves * kWave; // 512
 constexpr int kFK = 32;                    // k-chunk of the weight tiles (64: same step time)
-constexpr int kFMaxIn = 256;               // widest tower input (2 * dim_mlp)
-constexpr int kFMaxN = 128;                // widest layer output / widest hidden activation
-constexpr int kFLdIn = kFMaxIn + 1;
-constexpr int kFLdN = kFMaxN + 1;
+constexpr int kFMaxIn = 512;               // widest tower input (2 * dim_mlp): emb_dim 64's 512-256-128-64 tower fits
+constexpr int kFMaxN = 128;                // output columns of one pass (8 waves x 16)
+constexpr int kFMaxW = 256;                // widest layer output (two passes)
 constexpr int kFMaxE = 64;                 // GMF width kept in LDS
 constexpr int kFLdE = kFMaxE + 1;
+constexpr int kFLdN = kFMaxN + 1;          // weight tile rows of the forward ([k][n], written transposed)
+constexpr int kFLdB = kFMaxN + 8;          // ... of the input-gradient chain: 16-byte aligned rows
+constexpr int kFNarrowIn = 256;            // limits of the stand-alone chain launch (ncf_fused_dgrad_kernel)
+constexpr int kFLdIn = kFNarrowIn + 1;
+constexpr size_t kFusedMaxLds = 160 * 1024 - 2048;  // (the kernels also hold a few hundred bytes of static LDS)
 
-static bool fusable(const hiprec_ncf_plan* p) {
+// LDS of the fused launch, in floats: every layer's input stays ([16][width + 1] each: the tower input, then each
+// layer's output) -- the next layer reads it, the backward masks with it --, with BWD two buffers for the
+// input-gradient chain, then the weight tiles (both directions share them) and the GMF tile.
+static size_t fused_lds_floats(const hiprec_ncf_plan* p, bool bwd) {
+  size_t n = static_cast<size_t>(kFR) * (2 * p->dim_mlp + 1);
+  int maxw = 0;
+  for (int l = 0; l < p->n_layers; ++l) {
+    n += static_cast<size_t>(kFR) * (p->layer_out[l] + 1);
+    maxw = std::max(maxw, p->layer_out[l]);
+  }
+  if (bwd) n += 2 * static_cast<size_t>(kFR) * (maxw + 1);
+  n = (n + 3) / 4 * 4;  // 16-byte aligned tiles
+  return n + 2 * kFK * kFLdB + kFR * kFLdE;
+}
+
+static bool fusable(const hiprec_ncf_plan* p, bool bwd = false) {
   if (p->dim_mlp <= 0 || p->n_layers < 1) return false;
   if (2 * p->dim_mlp > kFMaxIn || (2 * p->dim_mlp) % kFK) return false;
   if (p->dim_mf > kFMaxE) return false;
   for (int l = 0; l < p->n_layers; ++l) {
-    if (p->layer_out[l] > kFMaxN || p->layer_out[l] % 32) return false;
+    if (p->layer_out[l] > kFMaxW || p->layer_out[l] % 32) return false;
     if (p->layer_in[l] % kFK) return false;
   }
+  if (p->layer_out[p->n_layers - 1] + p->dim_mf > 3 * kWave) return false;  // the head keeps 3 values per lane
+  return fused_lds_floats(p, bwd) * sizeof(float) <= kFusedMaxLds;
+}
+
+// the stand-alone chain launch keeps round 2's first limits (tower input <= 256, layers <= 128 wide)
+static bool fusable_narrow(const hiprec_ncf_plan* p) {
+  if (!fusable(p) || 2 * p->dim_mlp > kFNarrowIn) return false;
+  for (int l = 0; l < p->n_layers; ++l)
+    if (p->layer_out[l] > kFMaxN) return false;
   return true;
 }
 
-struct FusedLds {
-  float* wide;   // [kFR][kFLdIn]  tower input, later narrow activations
-  float* narrow; // [kFR][kFLdN]
-  float* bs;     // [2][kFK][kFLdN] weight tiles (double-buffered)
-  float* mf;     // [kFR][kFLdE]   GMF product (forward) / unused (backward)
-  __device__ int ld_of(const float* buf) const { return buf == wide ? kFLdIn : kFLdN; }
-};
-constexpr size_t kFusedLdsBytes =
-    sizeof(float) * (kFR * kFLdIn + kFR * kFLdN + 2 * kFK * kFLdN + kFR * kFLdE);
-
-__device__ __forceinline__ FusedLds fused_lds(float* base) {
-  FusedLds l;
-  l.wide = base;
-  l.narrow = l.wide + kFR * kFLdIn;
-  l.bs = l.narrow + kFR * kFLdN;
-  l.mf = l.bs + 2 * kFK * kFLdN;
-  return l;
-}
-
-// acc(32x32 per wave) = In[32 x K] * W^T: wave wn owns output columns wn*32.. of the N <= 128 columns
 // (W is nn.Linear.weight, [N][K] row-major; K is a multiple of kFK).  Waves beyond N idle in the MFMAs
 // but still help staging.  Software pipeline, measured per chunk of 32 k with in-kernel timestamps:
 // staged naively (16 scalar loads issued, then 16 LDS stores, then the 16 dependent MFMAs) a chunk
@@ -587,7 +595,7 @@ struct FusedGemm {
   }
 };
 
-constexpr int kFLdB = kFMaxN + 8;  // 136: 16-byte aligned tile rows, two-way bank conflicts on the B reads
+// (weight tile rows of kFLdB = 136 floats: 16-byte aligned, two-way bank conflicts on the B reads)
 constexpr size_t kFusedBwdLdsBytes = sizeof(float) * (kFR * kFLdIn + kFR * kFLdN + 2 * kFK * kFLdB);
 
 struct FusedGemmNN {
@@ -660,15 +668,11 @@ struct FusedGemmNN {
   }
 };
 
-// LDS of the forward + backward launch (BWD): every layer's activations stay (the backward masks with them), two
-// buffers carry the input-gradient chain, the weight tiles of both directions share one region.
-constexpr size_t kFusedTrainLdsBytes =
-    sizeof(float) * (kFR * kFLdIn + (HIPREC_NCF_MAX_LAYERS + 2) * kFR * kFLdN + 2 * kFK * kFLdB + kFR * kFLdE);
-
 // ---- forward: gather -> tower -> affine_output -> sigmoid; writes act[0..L], mf, scores -----------------
 // TRAIN: the head's backward half rides along (BCELoss term, d loss / d logit, dZ_L, dMF, d w_out,
 // the loss / d b_out partials) -- everything it needs is already in LDS, and a separate head launch
-// cost 12 us.
+// cost 12 us.  BWD: so does the tower's input-gradient chain and the embedding scatter (see the header).
+// A layer wider than 128 columns takes passes of 128 (8 waves x 16); LDS layout: fused_lds_floats.
 template <bool TRAIN, bool DROP, bool BWD = false>
 __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
     hiprec_ncf_plan p, const int64_t* __restrict__ users, const int64_t* __restrict__ items,
@@ -676,37 +680,31 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
     Scratch* scratch) {
   static_assert(!BWD || TRAIN, "the backward rides on the training forward");
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-  FusedLds L = fused_lds(lds_raw);
-  float* acts = nullptr;   // BWD: [n_layers][kFR][kFLdN] activations of layers 1..L, then two chain buffers
-  if constexpr (BWD) {     // layout: wide | acts + chain | tiles (kFLdB wide) | mf
-    acts = L.wide + kFR * kFLdIn;
-    L.narrow = acts;  // (unused as such)
-    L.bs = acts + (HIPREC_NCF_MAX_LAYERS + 2) * kFR * kFLdN;
-    L.mf = L.bs + 2 * kFK * kFLdB;
-  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave;
   const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kFR;
-  const int Dm = p.dim_mlp, E = p.dim_mf, K0 = 2 * Dm;
-  // where layer l's input (= act[l]) lives: l = 0 the gathered rows; without BWD the two buffers alternate
-  auto act_buf = [&](int l) -> float* {
-    if (l == 0) return L.wide;
-    if constexpr (BWD) return acts + (l - 1) * kFR * kFLdN;
-    return (l & 1) ? L.narrow : L.wide;
-  };
-  auto act_ld = [&](int l) { return (l == 0 || (!BWD && !(l & 1))) ? kFLdIn : kFLdN; };
+  const int Dm = p.dim_mlp, E = p.dim_mf, K0 = 2 * Dm, n_layers = p.n_layers;
+  // LDS: act_0 (the gathered rows) | act_1 | ... | act_L | [chain A | chain B] | weight tiles | GMF tile
+  int act_floats = kFR * (K0 + 1), maxw = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    act_floats += kFR * (p.layer_out[l] + 1);
+    maxw = max(maxw, p.layer_out[l]);
+  }
+  const int ld_c = maxw + 1;
+  float* chain_a = lds_raw + act_floats;  // BWD: dZ_L of the tile, then the chain's ping-pong partner
+  float* tiles = lds_raw + (act_floats + (BWD ? 2 * kFR * ld_c : 0) + 3) / 4 * 4;
+  float* s_mf = tiles + 2 * kFK * kFLdB;
 
   // Loads that depend on nothing the block computes go first, off its serial chain: layer 0's first weight chunks,
-  // every layer's two bias elements of this lane, the head's weights and targets.
+  // this lane's bias element of the first pass, the head's weights and targets.
   FusedGemm gemm;
-  if (p.n_layers > 0) gemm.begin(p.fc_w[0], p.layer_in[0], p.layer_out[0]);
-  float bias_now, bias_next;  // this lane's bias element of the current / the next layer
-  auto load_bias = [&](int l) {
-    const int col = wn * 16 + (lane & 15);
-    return l < p.n_layers && col < p.layer_out[l] ? p.fc_b[l][col] : 0.f;
+  gemm.begin(p.fc_w[0], p.layer_in[0], min(p.layer_out[0], kFMaxN));
+  auto load_bias = [&](int l, int n_off) {  // this lane's bias element of pass (l, n_off)
+    const int col = n_off + wn * 16 + (lane & 15);
+    return l < n_layers && col < p.layer_out[l] ? p.fc_b[l][col] : 0.f;
   };
-  bias_now = load_bias(0);
-  const int nH = p.n_layers > 0 ? p.layer_out[p.n_layers - 1] : 0, nV = nH + p.dim_mf;
+  float bias_now = load_bias(0, 0), bias_next = 0.f;
+  const int nH = p.layer_out[n_layers - 1], nV = nH + E;
   const float bo = load_scalar_param(p.out_b);
   float wout[3];  // nV <= 192
 #pragma unroll
@@ -720,9 +718,9 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
     }
   }
 
-  // gather, element-parallel: 64 threads fetch the index pairs, then every thread owns
-  // kFR * K0 / 256 <= 16 elements of the tower input; all its loads are requested before anything
-  // is stored (one round trip for the whole tile instead of one per row)
+  // gather, element-parallel: 16 threads fetch the index pairs, then every thread owns one column of 8 (tower input
+  // up to 256 wide: the two halves of the block take 8 rows each) or 16 rows; all its loads are requested before
+  // anything is stored (one round trip for the whole tile instead of one per row)
   __shared__ long long s_u[kFR], s_i[kFR];
   if (tid < kFR) {
     const int64_t b = m0 + tid;
@@ -744,20 +742,23 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
   lds_barrier();
   constexpr int kPerE = kFR * kFMaxE / kFThreads;  // GMF elements per thread (2)
   float gmf_um[kPerE], gmf_im[kPerE];              // BWD: the two factors, for the GMF rows' gradients
+  const int ld0 = K0 + 1;
   {
-    // thread t owns column t % 256 of the rows of its half (t / 256) of the tile and (row j * 8 + t / 64, column
-    // t % 64) of the GMF tile: no divisions, one load per row, all requested before anything is stored
-    static_assert(kFThreads % kFMaxIn == 0 && kFMaxE == kWave, "gather mapping");
-    constexpr int kHalves = kFThreads / kFMaxIn, kRowsPer = kFR / kHalves;  // 2 halves of 8 rows
-    float v[kRowsPer];
-    const int col_t = tid & (kFMaxIn - 1), row0 = (tid / kFMaxIn) * kRowsPer;
+    static_assert(kFMaxIn == kFThreads && kFMaxE == kWave, "gather mapping");
+    const bool halves = K0 <= kFThreads / 2;  // block-uniform
+    const int col_t = halves ? tid & (kFThreads / 2 - 1) : tid;
+    const int row0 = halves ? (tid / (kFThreads / 2)) * (kFR / 2) : 0, n_rows_t = halves ? kFR / 2 : kFR;
+    float v[kFR];
     const int c = col_t < K0 ? col_t : 0;
     const bool c_user = c < Dm;
     const float* base = c_user ? p.user_mlp + c : p.item_mlp + (c - Dm);
 #pragma unroll
-    for (int r = 0; r < kRowsPer; ++r) {
-      const long long idx = c_user ? s_u[row0 + r] : s_i[row0 + r];
-      v[r] = base[(idx >= 0 ? idx : 0) * Dm];  // flagged samples read row 0 and are zeroed below
+    for (int r = 0; r < kFR; ++r) {
+      v[r] = 0.f;
+      if (r < n_rows_t) {
+        const long long idx = c_user ? s_u[row0 + r] : s_i[row0 + r];
+        v[r] = base[(idx >= 0 ? idx : 0) * Dm];  // flagged samples read row 0 and are zeroed below
+      }
     }
     float w[kPerE];
     const int ce = (tid & 63) < E ? (tid & 63) : 0;
@@ -775,14 +776,15 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
     }
     if (col_t < K0) {
 #pragma unroll
-      for (int j = 0; j < kRowsPer; ++j) {
+      for (int j = 0; j < kFR; ++j) {
+        if (j >= n_rows_t) break;
         const int r = row0 + j;
         float x = s_u[r] >= 0 ? v[j] : 0.f;
         if (p.relu_input) x = fmaxf(x, 0.f);
         // the Dropout in front of the first Linear (ncf.py:42-45, mlp.py:30-33): one keep byte per element
         if constexpr (DROP)
           if (p.keep[0] && m0 + r < batch) x = p.keep[0][(m0 + r) * K0 + col_t] ? x * p.keep_scale : 0.f;
-        L.wide[r * kFLdIn + col_t] = x;
+        lds_raw[r * ld0 + col_t] = x;
         if (m0 + r < batch) p.act[0][(m0 + r) * K0 + col_t] = x;
       }
     }
@@ -791,50 +793,58 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
       for (int j = 0; j < kPerE; ++j) {
         const int r = j * (kFThreads / kWave) + (tid >> 6);
         const float x = s_u[r] >= 0 ? w[j] : 0.f;
-        L.mf[r * kFLdE + (tid & 63)] = x;
+        s_mf[r * kFLdE + (tid & 63)] = x;
         if (m0 + r < batch) p.mf[(m0 + r) * E + (tid & 63)] = x;
       }
     }
   }
   lds_barrier();
 
-  for (int l = 0; l < p.n_layers; ++l) {
-    const int N = p.layer_out[l];
-    const float* in = act_buf(l);
-    float* out = act_buf(l + 1);
-    f32x4 acc;
-    gemm.run(acc, in, act_ld(l), L.bs);
-    if (l + 1 < p.n_layers) gemm.begin(p.fc_w[l + 1], p.layer_in[l + 1], p.layer_out[l + 1]);  // under the epilogue
-    bias_next = load_bias(l + 1);
-    if (wn * 16 < N) {
-      const int ld_out = act_ld(l + 1);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {   // C[row 4 * (lane >> 4) + r][col lane & 15]
-        const int col = wn * 16 + (lane & 15);
-        const int row = 4 * (lane >> 4) + r;
-        float v = fmaxf(acc[r] + bias_now, 0.f);
-        // act[l + 1] is what the NEXT Linear sees: its Dropout is applied here (the backward's dgrad epilogue
-        // applies the same keep bytes)
-        if constexpr (DROP)
-          if (l + 1 < p.n_layers && p.keep[l + 1] && m0 + row < batch)
-            v = p.keep[l + 1][(m0 + row) * N + col] ? v * p.keep_scale : 0.f;
-        out[row * ld_out + col] = v;
-        if (m0 + row < batch) p.act[l + 1][(m0 + row) * N + col] = v;
+  int in_off = 0, ld_in = ld0;  // act_l: lds_raw + in_off, [kFR][ld_in]
+  for (int l = 0; l < n_layers; ++l) {
+    const int K = p.layer_in[l], N = p.layer_out[l];
+    const int out_off = in_off + kFR * ld_in, ld_out = N + 1;
+    float* out = lds_raw + out_off;
+    for (int n_off = 0; n_off < N; n_off += kFMaxN) {
+      f32x4 acc;
+      gemm.run(acc, lds_raw + in_off, ld_in, tiles);
+      // the next pass's (or layer's) first weight chunks and bias travel under this epilogue
+      if (n_off + kFMaxN < N) {
+        gemm.begin(p.fc_w[l] + static_cast<int64_t>(n_off + kFMaxN) * K, K, min(kFMaxN, N - n_off - kFMaxN));
+        bias_next = load_bias(l, n_off + kFMaxN);
+      } else if (l + 1 < n_layers) {
+        gemm.begin(p.fc_w[l + 1], p.layer_in[l + 1], min(p.layer_out[l + 1], kFMaxN));
+        bias_next = load_bias(l + 1, 0);
       }
+      if (wn * 16 < N - n_off) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {   // C[row 4 * (lane >> 4) + r][col lane & 15]
+          const int col = n_off + wn * 16 + (lane & 15);
+          const int row = 4 * (lane >> 4) + r;
+          float v = fmaxf(acc[r] + bias_now, 0.f);
+          // act[l + 1] is what the NEXT Linear sees: its Dropout is applied here (the backward's dgrad epilogue
+          // applies the same keep bytes)
+          if constexpr (DROP)
+            if (l + 1 < n_layers && p.keep[l + 1] && m0 + row < batch)
+              v = p.keep[l + 1][(m0 + row) * N + col] ? v * p.keep_scale : 0.f;
+          out[row * ld_out + col] = v;
+          if (m0 + row < batch) p.act[l + 1][(m0 + row) * N + col] = v;
+        }
+      }
+      lds_barrier();
+      bias_now = bias_next;
     }
-    lds_barrier();
-    bias_now = bias_next;
+    in_off = out_off;
+    ld_in = ld_out;
   }
 
   FusedGemmNN gnn;  // BWD: the first weight chunks of the input-gradient chain travel under the head
   if constexpr (BWD)
-    gnn.begin(p.fc_w[p.n_layers - 1], p.layer_in[p.n_layers - 1], p.layer_out[p.n_layers - 1],
-              min(p.layer_in[p.n_layers - 1], kFMaxN), 0);
+    gnn.begin(p.fc_w[n_layers - 1], p.layer_in[n_layers - 1], p.layer_out[n_layers - 1],
+              min(p.layer_in[n_layers - 1], kFMaxN), 0);
   // affine_output + sigmoid: wave w scores rows w, w + 8, ...
-  const float* in = act_buf(p.n_layers);
-  const int ld_h = act_ld(p.n_layers);
-  float* chain_a = nullptr;  // BWD: dZ_L of the tile, the input of the backward chain
-  if constexpr (BWD) chain_a = acts + HIPREC_NCF_MAX_LAYERS * kFR * kFLdN;
+  const float* in = lds_raw + in_off;  // act_L
+  const int ld_h = ld_in;
   const bool stepper = TRAIN && blockIdx.x == 0 && tid == 0;
   StepState step_state{};
   if (stepper) step_state = step_load(stats);
@@ -848,7 +858,7 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
       if constexpr (BWD) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-          if (lane + kWave * k < nH) chain_a[r * kFLdN + lane + kWave * k] = 0.f;
+          if (lane + kWave * k < nH) chain_a[r * ld_c + lane + kWave * k] = 0.f;
       }
       continue;
     }
@@ -857,7 +867,7 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int c = lane + kWave * k;
-      vec[k] = c < nH ? in[r * ld_h + c] : (c < nV ? L.mf[r * kFLdE + (c - nH)] : 0.f);
+      vec[k] = c < nH ? in[r * ld_h + c] : (c < nV ? s_mf[r * kFLdE + (c - nH)] : 0.f);
       part += vec[k] * wout[k];
     }
     const float logit = wave_sum(part) + bo;
@@ -877,11 +887,11 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
       if (c < nH) {
         // d loss / d z_L = d h_L * [h_L > 0]  (ReLU of the last Linear, applied twice in NeuMF)
         const float dz = vec[k] > 0.f ? dl * wout[k] : 0.f;
-        p.dact[p.n_layers][b * nH + c] = dz;
-        if constexpr (BWD) chain_a[r * kFLdN + c] = dz;
+        p.dact[n_layers][b * nH + c] = dz;
+        if constexpr (BWD) chain_a[r * ld_c + c] = dz;
       } else if (c < nV) {
         p.dmf[b * E + (c - nH)] = dl * wout[k];
-        if constexpr (BWD) L.mf[r * kFLdE + (c - nH)] = dl * wout[k];  // (this lane just read the product there)
+        if constexpr (BWD) s_mf[r * kFLdE + (c - nH)] = dl * wout[k];  // (this lane just read the product there)
       }
     }
   }
@@ -889,18 +899,18 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
   if (stepper) step_store_advanced(stats, step_state);
   // d affine_output.weight: the waves' sums meet in LDS (the weight tile is free by now), one atomic
   // per (block, column); loss partial (reg slot unused = 0), d b_out in the scalar-gradient slot
-  float* s_gw = L.bs;
+  float* s_gw = tiles;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int c = lane + kWave * k;
-    if (c < nV) s_gw[wave * (kFMaxN + kFMaxE) + c] = gw[k];
+    if (c < nV) s_gw[wave * (3 * kWave) + c] = gw[k];
   }
   publish_partials<kFWaves>(loss_acc, 0.f, gb_acc, inv_batch, scratch);  // barriers inside
   lds_barrier();
   for (int c = tid; c < nV; c += kFThreads) {
     float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < kFWaves; ++w) t += s_gw[w * (kFMaxN + kFMaxE) + c];
+    for (int w = 0; w < kFWaves; ++w) t += s_gw[w * (3 * kWave) + c];
     if (t != 0.f) atomic_add_f32(p.g_out_w + c, t);
   }
   if constexpr (BWD) {
@@ -908,12 +918,14 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
     // HBM already here: ids, activations for the ReLU masks, dZ_L, the GMF factors) ----
     lds_barrier();  // s_gw lived in the weight tiles
     float* cin = chain_a;
-    float* cout = chain_a + kFR * kFLdN;
-    for (int l = p.n_layers - 1; l >= 0; --l) {
+    float* cout = chain_a + kFR * ld_c;
+    int h_off = in_off;  // act_{l+1}; act_l sits right before it
+    for (int l = n_layers - 1; l >= 0; --l) {
       const int nin = p.layer_in[l], nout = p.layer_out[l];
       const bool masked = l > 0 || p.relu_input;
-      const float* h_l = act_buf(l);
-      const int ld_h_l = act_ld(l);
+      const int ld_h_l = nin + 1;
+      h_off -= kFR * ld_h_l;
+      const float* h_l = lds_raw + h_off;
       for (int n_off = 0; n_off < nin; n_off += kFMaxN) {
         const int n_pass = min(kFMaxN, nin - n_off);
         const int col = n_off + wn * 16 + (lane & 15);
@@ -927,7 +939,7 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
           }
         }
         f32x4 acc;
-        gnn.run(acc, cin, kFLdN, L.bs);
+        gnn.run(acc, cin, ld_c, tiles);
         if (n_off + kFMaxN < nin)
           gnn.begin(p.fc_w[l], nin, nout, min(kFMaxN, nin - n_off - kFMaxN), n_off + kFMaxN);
         else if (l > 0)
@@ -940,7 +952,7 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
             if constexpr (DROP)
               if (p.keep[l]) v = kb[r] ? v * p.keep_scale : 0.f;
             if (l > 0) {
-              cout[lrow * kFLdN + col] = v;
+              cout[lrow * ld_c + col] = v;
               if (m0 + lrow < batch) p.dact[l][(m0 + lrow) * nin + col] = v;
             } else if (s_u[lrow] >= 0 && v != 0.f) {  // tower input = [user_mlp row | item_mlp row]
               if (col < Dm) atomic_add_f32(p.g_user_mlp + s_u[lrow] * Dm + col, v);
@@ -960,7 +972,7 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
       for (int j = 0; j < kPerE; ++j) {
         const int r = j * (kFThreads / kWave) + (tid >> 6);
         const long long u = s_u[r], it = s_i[r];
-        const float d = L.mf[r * kFLdE + (tid & 63)];
+        const float d = s_mf[r * kFLdE + (tid & 63)];
         if (u >= 0 && m0 + r < batch && d != 0.f) {
           atomic_add_f32(p.g_user_mf + u * E + (tid & 63), d * gmf_im[j]);
           atomic_add_f32(p.g_item_mf + it * E + (tid & 63), d * gmf_um[j]);
@@ -969,7 +981,6 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
     }
   }
 }
-
 
 // ---- backward: dZ_L -> dZ_{L-1} -> ... -> d(tower input), embedding-row gradients scattered on the way out ------
 // The input-gradient chain of the tower for 16 samples, in LDS like the forward: dZ_{l-1} = (dZ_l W_l) * [H_{l-1} > 0]
@@ -1133,20 +1144,15 @@ static int check_plan(const hiprec_ncf_plan* p, int64_t batch, bool train) {
 
 static int fused_attrs() {
   static int rc = [] {
-    const void* kernels[] = {reinterpret_cast<const void*>(&ncf_fused_forward_kernel<false, false>),
-                             reinterpret_cast<const void*>(&ncf_fused_forward_kernel<false, true>),
-                             reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, false>),
-                             reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, true>)};
-    for (const void* k : kernels) {
+    const void* fwd[] = {reinterpret_cast<const void*>(&ncf_fused_forward_kernel<false, false>),
+                         reinterpret_cast<const void*>(&ncf_fused_forward_kernel<false, true>),
+                         reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, false>),
+                         reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, true>),
+                         reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, false, true>),
+                         reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, true, true>)};
+    for (const void* k : fwd) {
       const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               static_cast<int>(kFusedLdsBytes));
-      if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-    }
-    const void* train[] = {reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, false, true>),
-                           reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, true, true>)};
-    for (const void* k : train) {
-      const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               static_cast<int>(kFusedTrainLdsBytes));
+                                               static_cast<int>(kFusedMaxLds));
       if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     }
     const void* bwd[] = {reinterpret_cast<const void*>(&ncf_fused_dgrad_kernel<false>),
@@ -1173,30 +1179,32 @@ static int forward(const hiprec_ncf_plan* p, const int64_t* users, const int64_t
   *scored = false;
   // the training launch publishes one loss partial per block: batches beyond kMaxBlocks * kFR samples (32 768) take
   // the launch-per-layer path
+  const bool chain = ratings && chained && fusable(p, true);
   if (fusable(p) && (!ratings || (batch + kFR - 1) / kFR <= kMaxBlocks)) {
     if (int rc = fused_attrs()) return rc;
     const int grid = static_cast<int>((batch + kFR - 1) / kFR);
+    const size_t lds = sizeof(float) * fused_lds_floats(p, chain);
     bool drop = false;
     for (int l = 0; l < p->n_layers; ++l) drop = drop || p->keep[l] != nullptr;
-    if (ratings && chained) {
+    if (chain) {
       if (drop)
-        ncf_fused_forward_kernel<true, true, true><<<grid, kFThreads, kFusedTrainLdsBytes, st>>>(
+        ncf_fused_forward_kernel<true, true, true><<<grid, kFThreads, lds, st>>>(
             *p, users, items, ratings, batch, inv_batch, stats, scratch);
       else
-        ncf_fused_forward_kernel<true, false, true><<<grid, kFThreads, kFusedTrainLdsBytes, st>>>(
+        ncf_fused_forward_kernel<true, false, true><<<grid, kFThreads, lds, st>>>(
             *p, users, items, ratings, batch, inv_batch, stats, scratch);
       *chained = true;
     } else if (ratings && drop)
-      ncf_fused_forward_kernel<true, true><<<grid, kFThreads, kFusedLdsBytes, st>>>(
+      ncf_fused_forward_kernel<true, true><<<grid, kFThreads, lds, st>>>(
           *p, users, items, ratings, batch, inv_batch, stats, scratch);
     else if (ratings)
-      ncf_fused_forward_kernel<true, false><<<grid, kFThreads, kFusedLdsBytes, st>>>(
+      ncf_fused_forward_kernel<true, false><<<grid, kFThreads, lds, st>>>(
           *p, users, items, ratings, batch, inv_batch, stats, scratch);
     else if (drop)   // model.train() + forward(): the reference applies dropout there too
-      ncf_fused_forward_kernel<false, true><<<grid, kFThreads, kFusedLdsBytes, st>>>(
+      ncf_fused_forward_kernel<false, true><<<grid, kFThreads, lds, st>>>(
           *p, users, items, nullptr, batch, 0.f, stats, nullptr);
     else
-      ncf_fused_forward_kernel<false, false><<<grid, kFThreads, kFusedLdsBytes, st>>>(
+      ncf_fused_forward_kernel<false, false><<<grid, kFThreads, lds, st>>>(
           *p, users, items, nullptr, batch, 0.f, stats, nullptr);
     HIPREC_TRY(hipGetLastError());
     *scored = true;
@@ -1274,17 +1282,20 @@ extern "C" int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users
   static const char* bwd_env = getenv("HIPREC_NCF_BACKWARD");
   static const bool no_fused_bwd = bwd_env && strcmp(bwd_env, "unfused") == 0;
   static const bool split_bwd = bwd_env && strcmp(bwd_env, "split") == 0;
-  const bool fuse_bwd = fusable(p) && !no_fused_bwd && 2 * p->n_layers <= kMaxGroup;
+  const bool group_ok = !no_fused_bwd && 2 * p->n_layers <= kMaxGroup;  // one grouped launch for all weight gradients
+  const bool fuse_bwd = group_ok && (fusable(p, true) || fusable_narrow(p));
   bool scored = false, chained = false;
   if (int rc = forward(p, users, items, batch, stats, st, &scored, ratings, inv_batch,
                        static_cast<Scratch*>(scratch), fuse_bwd && !split_bwd ? &chained : nullptr))
     return rc;
+  // not chained onto the forward (batch beyond its limit, "split"): the chain's own launch has narrower limits
+  const bool bwd_two_launches = fuse_bwd && (chained || fusable_narrow(p));
   if (!scored) {
     ncf_head_kernel<true><<<head_grid(batch, 4), kHeadBlock, 0, st>>>(
         *p, ratings, batch, inv_batch, stats, static_cast<Scratch*>(scratch));
     HIPREC_TRY(hipGetLastError());
   }
-  if (fuse_bwd) {
+  if (bwd_two_launches) {
     // the input-gradient chain + the embedding scatter ride on the forward launch (or, when that took the
     // launch-per-layer path, run in ONE launch of their own), then every layer's weight and bias gradients -- which
     // only read the dZ_l the chain wrote -- in one grouped launch: 2 launches for the 5 of round 1
