@@ -289,3 +289,24 @@ def test_tower_dropout_inside_the_fused_forward(hip_device, kind, engine, E, p):
     assert_scalar_close(loss, ref_loss, what="loss with tower dropout (fused forward)")
     for k in g_ref:
         assert_tensor_close(grads[k].cpu().numpy(), g_ref[k], 2e-5, f"grad {k}", scale_floor=bias_floor(k))
+
+
+@pytest.mark.parametrize("mode", ["split", "unfused"])
+def test_older_backward_forms_stay_correct(hip_device, mode):
+    """hiprec_ncf_grad's default is ONE launch for forward + head + input-gradient chain + scatter.  The two older
+    forms it falls back to -- the chain in a launch of its own (forward on the launch-per-layer path: batch beyond
+    32 768), one grouped launch per layer + scatter (shapes outside the fused limits) -- are selected here through
+    HIPREC_NCF_BACKWARD (read once per process: a fresh interpreter) and run the step / dropout / full-size tests."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("HIPREC_NCF_BACKWARD"):
+        pytest.skip("already running an older form")
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run(
+        [sys.executable, "-m", "pytest", os.path.join(here, "test_ncf_gpu.py"), "-m", "gpu", "-x", "-q", "-k",
+         "not older_backward_forms"],
+        env=dict(os.environ, HIPREC_NCF_BACKWARD=mode), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
