@@ -17,6 +17,8 @@
 // The loss gathers / scatters rows of the concatenated table directly (one wave per triple).
 // Nothing here is GEMM-bound: 2 x N x d x d flops per Linear (80 MFLOP at ML-1M size) against 2.5 MB
 // activations; the MFMA group is used because it is the exact-fp32 GEMM the NCF tower already has.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "gemm.hpp"
 #include "spmm.hpp"
@@ -96,6 +98,138 @@ __global__ __launch_bounds__(kBlock) void ngcf_act_kernel(const float* __restric
       const int c = lane + kWave * k;
       if (c < d) all[r * ld_all + off + c] = x[k] * inv;
     }
+  }
+}
+
+// ---- one hop's per-node chain in ONE launch: bi = ego * side, the two Linear layers, leaky-ReLUs, dropout, row norm ----
+// What ngcf_bi_mul_kernel + the grouped GEMM launch + ngcf_act_kernel do in three launches (4.9 + 12.3 + 7.3 us at
+// the ML-1M graph: each a pass over [N, d] activations that starts by missing on what the previous one wrote).  A
+// workgroup of 8 waves owns 16 node rows (the NCF recipe, ncf.hip): both weight matrices (d x d: 16 KB each) go to LDS
+// whole, waves 0-3 multiply side by GC^T and waves 4-7 ego * side by Bi^T on 16x16x4 fp32 MFMAs (one 16-column tile
+// each), the two results meet in LDS, and two rows per wave get activation, dropout, norm and all their outputs.
+// Limits: input width <= 128 (a multiple of 4), output width <= 64 (a multiple of 16).
+using hop_f32x4 = float __attribute__((ext_vector_type(4)));
+constexpr int kHopRows = 16, kHopThreads = 512, kHopMaxIn = 128, kHopMaxOut = 64;
+constexpr int kHopW4 = kHopMaxOut * kHopMaxIn / 4 / (kHopThreads / 2);  // float4 of one matrix per thread (8)
+
+static size_t hop_lds_floats(int di, int dout) {
+  return 2 * static_cast<size_t>(kHopRows) * (di + 1) + 2 * static_cast<size_t>(di) * (dout + 1) +
+         2 * static_cast<size_t>(kHopRows) * (dout + 1);
+}
+
+__global__ __launch_bounds__(kHopThreads) void ngcf_hop_forward_kernel(
+    const float* __restrict__ side, const float* __restrict__ ego_in, const float* __restrict__ gc_w,
+    const float* __restrict__ gc_b, const float* __restrict__ bi_w, const float* __restrict__ bi_b, int di, int dout,
+    int64_t n_rows, float* __restrict__ bi_in, float* __restrict__ sum_pre, float* __restrict__ bi_pre,
+    uint8_t* __restrict__ keep, float scale, KeepGen gen, float* __restrict__ ego_out, float* __restrict__ nrm_out,
+    float* __restrict__ all, int ld_all, int off, SlicedOut next_src) {
+  extern __shared__ __attribute__((aligned(16))) float hop_lds[];
+  const int lda = di + 1, ldw = dout + 1, ldx = dout + 1;
+  float* a_side = hop_lds;                       // [16][di + 1]
+  float* a_bi = a_side + kHopRows * lda;         // [16][di + 1]
+  float* wt = a_bi + kHopRows * lda;             // [2][di][dout + 1]: GC^T, Bi^T
+  float* xs = wt + 2 * di * ldw;                 // [2][16][dout + 1]: lrelu(GC(side)), lrelu(Bi(ego * side))
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, wn = wave & 3;      // which Linear, which 16-column tile
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kHopRows;
+
+  // every load first: this thread's share of one weight matrix (float4 along k), its bias, its tile elements
+  const float* __restrict__ W = grp ? bi_w : gc_w;
+  const int half_tid = tid & (kHopThreads / 2 - 1), k4s = di >> 2, n_w4 = dout * k4s;
+  float4 wreg[kHopW4];
+#pragma unroll
+  for (int j = 0; j < kHopW4; ++j) {
+    const int q = half_tid + j * (kHopThreads / 2);
+    wreg[j] = q < n_w4 ? reinterpret_cast<const float4*>(W)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int col_e = wn * 16 + (lane & 15);
+  const float bias = col_e < dout ? (grp ? bi_b : gc_b)[col_e] : 0.f;
+  constexpr int kPerT = kHopRows * kHopMaxIn / kHopThreads;  // 4 tile elements per thread
+  float sv[kPerT], ev[kPerT];
+#pragma unroll
+  for (int j = 0; j < kPerT; ++j) {
+    const int e = tid + j * kHopThreads, r = e / di, c = e - r * di;
+    const bool ok = e < kHopRows * di && m0 + r < n_rows;
+    sv[j] = ok ? side[(m0 + r) * di + c] : 0.f;
+    ev[j] = ok ? ego_in[(m0 + r) * di + c] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < kHopW4; ++j) {
+    const int q = half_tid + j * (kHopThreads / 2);
+    if (q < n_w4) {  // W[n][k4 .. k4 + 3] -> transposed tile [k][n]
+      const int n = q / k4s, k4 = (q - n * k4s) * 4;
+      float* d = wt + grp * di * ldw + k4 * ldw + n;
+      d[0] = wreg[j].x;
+      d[ldw] = wreg[j].y;
+      d[2 * ldw] = wreg[j].z;
+      d[3 * ldw] = wreg[j].w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kPerT; ++j) {
+    const int e = tid + j * kHopThreads, r = e / di, c = e - r * di;
+    if (e < kHopRows * di) {
+      const float b = sv[j] * ev[j];
+      a_side[r * lda + c] = sv[j];
+      a_bi[r * lda + c] = b;
+      if (m0 + r < n_rows) bi_in[(m0 + r) * di + c] = b;
+    }
+  }
+  lds_barrier();
+  // the wave's 16 x 16 tile of its Linear; operands of eight k-steps are read before their MFMAs
+  hop_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (wn * 16 < dout) {
+    const float* A = grp ? a_bi : a_side;
+    const float* B = wt + grp * di * ldw;
+    const int i = lane & 15, kq = lane >> 4;
+    for (int k0 = 0; k0 < di; k0 += 32) {
+      float a[8], b[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + 4 * j + kq;
+        a[j] = k < di ? A[i * lda + k] : 0.f;
+        b[j] = k < di ? B[k * ldw + wn * 16 + i] : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // C[row 4 * (lane >> 4) + r][col lane & 15]
+      const int row = 4 * (lane >> 4) + r;
+      const float pre = acc[r] + bias;
+      if (m0 + row < n_rows) (grp ? bi_pre : sum_pre)[(m0 + row) * dout + col_e] = pre;
+      xs[(grp * kHopRows + row) * ldx + col_e] = lrelu(pre);
+    }
+  }
+  lds_barrier();
+  // rows wave, wave + 8: lane = column
+#pragma unroll
+  for (int j = 0; j < kHopRows / (kHopThreads / kWave); ++j) {
+    const int r = wave + j * (kHopThreads / kWave);
+    const int64_t row = m0 + r;
+    if (row >= n_rows) continue;
+    float v = 0.f;
+    if (lane < dout) {
+      v = xs[r * ldx + lane] + xs[(kHopRows + r) * ldx + lane];
+      const int64_t i = row * dout + lane;
+      if (keep) {
+        bool k;
+        if (gen.on) {
+          k = keep_draw(gen.seed, gen.step, i, gen.keep_prob);
+          keep[i] = k ? 1 : 0;
+        } else {
+          k = keep[i] != 0;
+        }
+        v = k ? v * scale : 0.f;
+      }
+      ego_out[i] = v;
+      next_src.put(row, lane, v);  // the next hop's sliced SpMM source
+    }
+    const float nrm = sqrtf(wave_sum(v * v));
+    const float inv = 1.0f / fmaxf(nrm, kNormEps);
+    if (lane == 0) nrm_out[row] = nrm;
+    if (lane < dout) all[row * ld_all + off + lane] = v * inv;
   }
 }
 
@@ -336,25 +470,40 @@ inline int ngcf_forward(const hiprec_ngcf_plan* p, bool train, hipStream_t st) {
     } else if (int rc = launch_spmm(&p->a, nullptr, 1.0f, ego, p->side[l], nullptr, di, st, zeroed)) {
       return rc;
     }
-    // (ego * side written by the sliced pass's flush instead: same step time -- its scattered 16-byte reads of ego
-    // cost the pass what the launch costs here)
-    ngcf_bi_mul_kernel<<<grid_for_threads((N * di + 3) / 4), kBlock, 0, st>>>(ego, p->side[l], p->bi_in[l],
-                                                                             N * di);
-    HIPREC_TRY(hipGetLastError());
-    GemmGroup g{};
-    g.n = 2;
-    g.p[0] = make_gemm(kNT, static_cast<int>(N), dout, di, p->side[l], di, p->gc_w[l], di, p->sum_pre[l], dout,
-                       p->gc_b[l], 0, nullptr, 0, false);
-    g.p[1] = make_gemm(kNT, static_cast<int>(N), dout, di, p->bi_in[l], di, p->bi_w[l], di, p->bi_pre[l], dout,
-                       p->bi_b[l], 0, nullptr, 0, false);
-    if (int rc = launch_group(g, st)) return rc;
     uint8_t* keep = train ? p->keep[l] : nullptr;
     const KeepGen gen{p->keep_gen, p->keep_prob[l], p->keep_seed * 64 + static_cast<uint64_t>(l), p->keep_step};
-    ngcf_act_kernel<<<grid_for_waves(N), kBlock, 0, st>>>(p->sum_pre[l], p->bi_pre[l], keep, p->keep_scale[l],
-                                                         gen, p->ego[l], p->nrm[l], p->all, dt, off, N, dout,
-                                                         sliced && l + 1 < p->n_layers ? ngcf_sliced_out(p, &p->sa)
-                                                                                       : SlicedOut{});
-    HIPREC_TRY(hipGetLastError());
+    const SlicedOut next_src = sliced && l + 1 < p->n_layers ? ngcf_sliced_out(p, &p->sa) : SlicedOut{};
+    static const bool unfused_hop = getenv("HIPREC_NGCF_UNFUSED_HOP") != nullptr;  // A/B switch, tests
+    if (!unfused_hop && di <= kHopMaxIn && di % 4 == 0 && dout <= kHopMaxOut && dout % 16 == 0) {
+      // bi = ego * side, both Linear layers, activation, dropout, norm: one launch, 16 node rows per workgroup
+      const size_t lds = sizeof(float) * hop_lds_floats(di, dout);
+      static bool attr_set = false;
+      if (!attr_set) {
+        HIPREC_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ngcf_hop_forward_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(sizeof(float) * hop_lds_floats(kHopMaxIn, kHopMaxOut))));
+        attr_set = true;
+      }
+      ngcf_hop_forward_kernel<<<static_cast<int>((N + kHopRows - 1) / kHopRows), kHopThreads, lds, st>>>(
+          p->side[l], ego, p->gc_w[l], p->gc_b[l], p->bi_w[l], p->bi_b[l], di, dout, N, p->bi_in[l], p->sum_pre[l],
+          p->bi_pre[l], keep, p->keep_scale[l], gen, p->ego[l], p->nrm[l], p->all, dt, off, next_src);
+      HIPREC_TRY(hipGetLastError());
+    } else {
+      ngcf_bi_mul_kernel<<<grid_for_threads((N * di + 3) / 4), kBlock, 0, st>>>(ego, p->side[l], p->bi_in[l],
+                                                                               N * di);
+      HIPREC_TRY(hipGetLastError());
+      GemmGroup g{};
+      g.n = 2;
+      g.p[0] = make_gemm(kNT, static_cast<int>(N), dout, di, p->side[l], di, p->gc_w[l], di, p->sum_pre[l], dout,
+                         p->gc_b[l], 0, nullptr, 0, false);
+      g.p[1] = make_gemm(kNT, static_cast<int>(N), dout, di, p->bi_in[l], di, p->bi_w[l], di, p->bi_pre[l], dout,
+                         p->bi_b[l], 0, nullptr, 0, false);
+      if (int rc = launch_group(g, st)) return rc;
+      ngcf_act_kernel<<<grid_for_waves(N), kBlock, 0, st>>>(p->sum_pre[l], p->bi_pre[l], keep, p->keep_scale[l],
+                                                           gen, p->ego[l], p->nrm[l], p->all, dt, off, N, dout,
+                                                           next_src);
+      HIPREC_TRY(hipGetLastError());
+    }
     ego = p->ego[l];
     off += dout;
   }
