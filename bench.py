@@ -786,7 +786,7 @@ def bench_mf(args, device, world, rank, dist_on):
         if mode == "auto":
             mode = "replicated" if 4 * ((U + I) * (D + 1) + 1) < (64 << 20) else "sharded"
         cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str=str(device), optimizer=args.optimizer,
-                             lr=LR, batch_size=b_local, loss="bpr"),
+                             lr=LR, batch_size=b_local, loss="bpr", dp_collective=args.dp_collective),
                "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
         torch.manual_seed(2020)
         with contextlib.redirect_stdout(io.StringIO()):
@@ -862,7 +862,9 @@ def bench_mf(args, device, world, rank, dist_on):
                        "triples / item rows / item gradients over RCCL"
                        if mode == "sharded" else
                        f"dp{world}: replicated 2.5 MB tables, one fused launch + one RCCL all-reduce of the dense "
-                       f"gradient per step, global batch = {world} x {b_local}")
+                       f"gradient per step, global batch = {world} x {b_local}; collective enqueued by "
+                       + ("the C epoch driver (ncclAllReduce on the engine's own communicator)"
+                          if getattr(eng, "_direct_comm", None) is not None else "torch.distributed"))
     if rank != 0:
         return None
     n_params = (U + I) * (D + 1) + 1
@@ -938,6 +940,10 @@ def main():
     ap.add_argument("--multi-gpu", default="auto", choices=["auto", "replicated", "sharded"],
                     help="mf, N>1: replicate small tables (gradient all-reduce) or row-shard them "
                          "(all-to-all routing); auto = replicated below 64 MB of parameters")
+    ap.add_argument("--dp-collective", default=os.environ.get("HIPREC_DP_COLLECTIVE", "rccl"), choices=["rccl", "torch"],
+                    help="replicated mode: 'rccl' = the C epoch driver calls ncclAllReduce itself on the engine's own "
+                         "communicator (falls back to torch.distributed if any rank cannot create one), 'torch' = "
+                         "torch.distributed.all_reduce from the python step loop")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = every rank feeds a full batch (global batch N x B); strong = the reference's "
                          "batch split over the ranks (global batch = B, identical semantics to one GPU)")
@@ -958,8 +964,16 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     # HIPREC_BENCH_FORCE_SHARDED=1 exercises the N>1 code path on a single GPU (world size 1)
     dist_on = world > 1 or os.environ.get("HIPREC_BENCH_FORCE_SHARDED") == "1"
+    json_fd = None
     if dist_on:
         import torch.distributed as dist
+
+        # RCCL prints a version banner through C stdio on STDOUT when a communicator is created (buffered: it lands
+        # after anything python printed).  The contract is ONE JSON line on rank 0's stdout: for the whole run fd 1
+        # points at stderr, and the line goes to a saved copy of the real stdout at the very end.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
 
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
@@ -983,11 +997,15 @@ def main():
         out = bench_mf(args, device, world, rank, dist_on)
     if dist_on and args.workload in ("pgmf", "t2v", "ngcf"):
         raise SystemExit(f"--workload {args.workload} is single-GPU (no data-parallel wrapper)")
-    if rank == 0 and out is not None:
-        print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and out is not None:
+        if json_fd is not None:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -289,6 +289,11 @@ SIGNATURES = {
         [c_int, _P, _P, _P, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P, c_int64, c_int64, c_int64, c_int64,
          c_float, c_double, c_double, c_double, c_double, _P, POINTER(c_int32), _P],
     ),
+    "hiprec_mf_bpr_dp_epoch_fused_range": (
+        c_int,
+        [c_int, _P, _P, c_int64, _P, _P, c_int64, c_int64, c_int64, c_int32, _P, _P, _P, c_int64, c_int64, c_int64,
+         c_int64, c_int32, c_float, c_double, c_double, c_double, c_double, _P, _P, _P, POINTER(c_int32), _P],
+    ),
     "hiprec_mf_bpr_epoch_owned": (
         c_int,
         [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64,

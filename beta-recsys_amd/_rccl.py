@@ -1,0 +1,99 @@
+"""The two things the data-parallel epoch driver needs from RCCL, bound with ctypes to the librccl that PyTorch
+already loaded: a communicator of its own over a torch.distributed process group (the unique id travels through one
+broadcast of that group) and the ADDRESS of ncclAllReduce, which ``hiprec_mf_bpr_dp_epoch_fused_range`` calls from C
+between the step launches (libhiprec itself does not link RCCL).
+
+Plumbing, like torch.distributed: nothing here computes.  Every failure (library not found, a symbol missing, an
+init that does not return ncclSuccess) makes :func:`create_communicator` return None on that rank; the caller then
+agrees with its peers -- over the torch process group -- whether everybody got one."""
+import ctypes
+import glob
+import os
+
+import torch
+import torch.distributed as dist
+
+NCCL_UNIQUE_ID_BYTES = 128
+
+
+class _UniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_byte * NCCL_UNIQUE_ID_BYTES)]
+
+
+_lib = None
+
+
+def _load():
+    """librccl.so as torch ships it (falls back to the ROCm one); None if neither loads."""
+    global _lib
+    if _lib is not None:
+        return _lib or None
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*"))
+    cands += ["/opt/rocm/lib/librccl.so", "librccl.so"]
+    for path in cands:
+        try:
+            lib = ctypes.CDLL(path)
+            lib.ncclGetUniqueId.restype = ctypes.c_int
+            lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(_UniqueId)]
+            lib.ncclCommInitRank.restype = ctypes.c_int
+            lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _UniqueId, ctypes.c_int]
+            lib.ncclCommDestroy.restype = ctypes.c_int
+            lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            lib.ncclAllReduce  # noqa: B018  (must exist)
+            _lib = lib
+            return lib
+        except (OSError, AttributeError):
+            continue
+    _lib = False
+    return None
+
+
+class Communicator:
+    """An RCCL communicator + the address of ncclAllReduce."""
+
+    def __init__(self, lib, comm, world, rank):
+        self._lib, self.comm, self.world, self.rank = lib, comm, world, rank
+        self.all_reduce_fn = ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p).value
+
+    def destroy(self):
+        if self.comm:
+            self._lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
+def create_communicator(group, device):
+    """Collective over ``group`` (every rank calls it, with its own cuda ``device`` current): a Communicator, or
+    None where it could not be made.  Use :func:`all_ranks_agree` before relying on it."""
+    lib = _load()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    uid = _UniqueId()
+    ok = lib is not None
+    if ok and rank == 0:
+        ok = lib.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    # the id (and rank 0's verdict) travel through one broadcast of the group; every rank takes part whatever its state
+    payload = torch.zeros(NCCL_UNIQUE_ID_BYTES + 1, dtype=torch.uint8)
+    if rank == 0:
+        payload[:NCCL_UNIQUE_ID_BYTES] = torch.frombuffer(bytearray(bytes(uid.internal)), dtype=torch.uint8)
+        payload[NCCL_UNIQUE_ID_BYTES] = 1 if ok else 0
+    backend = dist.get_backend(group)
+    wire = payload.to(device) if backend == "nccl" else payload
+    dist.broadcast(wire, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    payload = wire.cpu()
+    if not ok or int(payload[NCCL_UNIQUE_ID_BYTES]) != 1:
+        return None
+    ctypes.memmove(uid.internal, bytes(payload[:NCCL_UNIQUE_ID_BYTES].tolist()), NCCL_UNIQUE_ID_BYTES)
+    comm = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = lib.ncclCommInitRank(ctypes.byref(comm), world, uid, rank)
+    if rc != 0 or not comm.value:
+        return None
+    return Communicator(lib, comm, world, rank)
+
+
+def all_ranks_agree(flag, group, device):
+    """True iff ``flag`` is true on every rank of the group (one small all-reduce of the torch group)."""
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+    if dist.get_backend(group) == "nccl":
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.cpu()[0]) == 1)

@@ -1169,6 +1169,83 @@ extern "C" int hiprec_mf_bpr_epoch_fused(int kind, float* const* w_flat, float* 
                                          beta2, eps, stats, final_index, stream);
 }
 
+// Steps [step_begin, step_end) of a DATA-PARALLEL fused epoch (beta-recsys_amd/replicated.py): every step is the
+// fused launch on this rank's batch followed by ONE in-place sum all-reduce of [loss partials | gradient], both
+// enqueued from here -- no host code between them (through torch.distributed the step was host-bound: 20-26 us
+// at world size 1 for an 11.5 us kernel).  The collective is the caller's: the address of ncclAllReduce (RCCL) and
+// a communicator; this library does not link RCCL.
+using nccl_all_reduce_fn = int (*)(const void*, void*, size_t, int, int, void*, hipStream_t);
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;  // ncclDataType_t / ncclRedOp_t values (nccl.h, rccl.h)
+
+extern "C" int hiprec_mf_bpr_dp_epoch_fused_range(int kind, float* const* w_flat, float* const* bufs,
+                                                  int64_t scratch_floats, float* const* m_flat,
+                                                  float* const* v_flat, int64_t n_flat, int64_t n_users,
+                                                  int64_t n_items, int32_t dim, const int64_t* users,
+                                                  const int64_t* pos, const int64_t* neg, int64_t n_triples,
+                                                  int64_t batch, int64_t step_begin, int64_t step_end,
+                                                  int32_t world, float reg_coef, double lr, double beta1,
+                                                  double beta2, double eps, hiprec_stats* stats,
+                                                  void* all_reduce_fn, void* comm, int32_t* final_index,
+                                                  void* stream) {
+  HIPREC_REQUIRE(w_flat && bufs && final_index && stats && all_reduce_fn && comm, "NULL pointer");
+  HIPREC_REQUIRE(w_flat[0] && w_flat[1] && bufs[0] && bufs[1] && bufs[2], "NULL buffer");
+  const bool has_m = kind == HIPREC_OPT_ADAM, has_v = kind != HIPREC_OPT_SGD;
+  HIPREC_REQUIRE(!has_m || (m_flat && m_flat[0] && m_flat[1]), "Adam needs m_flat[2]");
+  HIPREC_REQUIRE(!has_v || (v_flat && v_flat[0] && v_flat[1]), "Adam/RMSprop need v_flat[2]");
+  HIPREC_REQUIRE(n_triples >= 0 && batch > 0 && world >= 1 && scratch_floats >= 4 && n_flat > 0, "bad sizes");
+  HIPREC_REQUIRE(n_triples == 0 || (users && pos && neg), "NULL index arrays");
+  const int64_t n_steps = (n_triples + batch - 1) / batch;
+  HIPREC_REQUIRE(0 <= step_begin && step_begin <= step_end && step_end <= n_steps,
+                 "bad step range [%lld, %lld) of %lld", (long long)step_begin, (long long)step_end, (long long)n_steps);
+  const auto all_reduce = reinterpret_cast<nccl_all_reduce_fn>(all_reduce_fn);
+  const int64_t k_end = step_end == n_steps ? n_steps + 1 : step_end;  // launch n_steps is the sweep-only flush
+  hiprec_fused_step c{};
+  c.kind = kind;
+  c.dim = dim;
+  c.n_users = n_users;
+  c.n_items = n_items;
+  c.lr = lr;
+  c.beta1 = beta1;
+  c.beta2 = beta2;
+  c.eps = eps;
+  c.reg_coef = reg_coef;
+  for (int64_t k = step_begin; k < k_end; ++k) {
+    const int64_t off = k * batch;
+    const int64_t b = k < n_steps ? std::min<int64_t>(batch, n_triples - off) : 0;
+    const int64_t prev_b = k > 0 ? std::min<int64_t>(batch, n_triples - (k - 1) * batch) : 0;
+    const int out = k == n_steps ? 0 : static_cast<int>((k + 1) & 1);
+    float* prev = bufs[(k + 2) % 3];  // each buffer: [scratch block | gradient]
+    float* cur = bufs[k % 3];
+    float* nxt = bufs[(k + 1) % 3];
+    c.w_read = w_flat[k & 1];
+    c.w_write = w_flat[out];
+    c.m_read = has_m ? m_flat[k & 1] : nullptr;
+    c.m_write = has_m ? m_flat[out] : nullptr;
+    c.v_read = has_v ? v_flat[k & 1] : nullptr;
+    c.v_write = has_v ? v_flat[out] : nullptr;
+    c.scratch_prev = prev;
+    c.g_prev = prev + scratch_floats;
+    c.scratch_cur = cur;
+    c.g_cur = cur + scratch_floats;
+    c.g_zero = nxt + scratch_floats;
+    // the gradient is the GLOBAL batch's mean: every rank scales by 1 / (its batch * world)
+    const float inv_b = b > 0 ? 1.0f / (static_cast<float>(b) * static_cast<float>(world)) : 0.f;
+    if (int rc = hiprec_mf_bpr_fused_step(&c, b ? users + off : nullptr, b ? pos + off : nullptr,
+                                          b ? neg + off : nullptr, b, prev_b, inv_b, stats, stream))
+      return rc;
+    if (k < n_steps) {  // everything behind the 4-float scratch header: the loss partials and the gradient
+      const int rc = all_reduce(cur + 4, cur + 4, static_cast<size_t>(scratch_floats - 4 + n_flat), kNcclFloat32,
+                                kNcclSum, comm, static_cast<hipStream_t>(stream));
+      if (rc != 0) {
+        set_error("the caller's all-reduce returned %d at step %lld", rc, (long long)k);
+        return HIPREC_E_UNSUPPORTED;
+      }
+    }
+  }
+  *final_index = step_end == n_steps ? 0 : -1;
+  return 0;
+}
+
 // The plain-SGD spelling of the above, kept for callers of the first ABI revision.
 extern "C" int hiprec_mf_bpr_epoch_sgd_fused(float* const* w_flat, float* const* g_flat,
                                              void* const* scratch2, int64_t n_users,

@@ -283,6 +283,19 @@ int hiprec_mf_bpr_epoch_fused_range(int kind, float* const* w_flat, float* const
                                     int64_t batch, int64_t step_begin, int64_t step_end, float reg_coef,
                                     double lr, double beta1, double beta2, double eps, hiprec_stats* stats,
                                     int32_t* final_index, void* stream);
+/* The data-parallel spelling (replicated.py: ReplicatedMFEngine): after every step's fused launch, ONE in-place
+ * sum all-reduce of that step's [loss partials | gradient] is enqueued on the same stream through the caller's
+ * collective -- all_reduce_fn is the address of ncclAllReduce (RCCL; this library does not link it), comm a
+ * communicator of `world` ranks that all make this call with equal n_triples / batch.  bufs[3]: the rotating
+ * buffers, each [scratch_floats of scratch block | n_flat of gradient], zero on entry of step 0; gradients are
+ * scaled by 1 / (batch * world).  Everything else as hiprec_mf_bpr_epoch_fused_range. */
+int hiprec_mf_bpr_dp_epoch_fused_range(int kind, float* const* w_flat, float* const* bufs, int64_t scratch_floats,
+                                       float* const* m_flat, float* const* v_flat, int64_t n_flat, int64_t n_users,
+                                       int64_t n_items, int32_t dim, const int64_t* users, const int64_t* pos,
+                                       const int64_t* neg, int64_t n_triples, int64_t batch, int64_t step_begin,
+                                       int64_t step_end, int32_t world, float reg_coef, double lr, double beta1,
+                                       double beta2, double eps, hiprec_stats* stats, void* all_reduce_fn,
+                                       void* comm, int32_t* final_index, void* stream);
 
 /* ---- plain SGD on tables that do not fit the caches (configs[3]): ONE launch per step, no dense gradient
  * buffer, every touched row written once, in place (csrc/mf_owned.hip).  The caller's batcher supplies, for

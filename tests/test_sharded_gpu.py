@@ -184,6 +184,45 @@ def test_replicated_train_an_epoch_takes_the_fused_path_for_resident_loaders(ncc
     assert all(np.isfinite(sums)) and sums[2] < sums[0]
 
 
+@pytest.mark.parametrize("optimizer", ["adam", "sgd"])
+def test_replicated_epoch_driver_calls_rccl_itself(nccl_group, optimizer):
+    """The resident data-parallel epoch is ONE C call per piece (hiprec_mf_bpr_dp_epoch_fused_range) that enqueues the
+    fused launch and ncclAllReduce of every step itself, on a communicator the engine creates with _rccl; it must
+    leave the state the torch.distributed loop leaves (``dp_collective: "torch"``), whole epochs and in pieces."""
+    import beta_recsys_amd as hp
+    from beta_recsys_amd.replicated import ReplicatedMFEngine
+
+    U, I, D, B = 300, 200, 32, 128
+    rng = np.random.default_rng(2)
+    n = 5 * B + 40
+    data = [torch.from_numpy(rng.integers(0, m, n)).cuda() for m in (U, I, I)]
+    out = {}
+    for mode in ("rccl", "torch"):
+        cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer=optimizer, lr=0.02,
+                             batch_size=B, loss="bpr", dp_collective=mode, shuffle_seed=7),
+               "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+        torch.manual_seed(1)
+        with contextlib.redirect_stdout(io.StringIO()):
+            eng = ReplicatedMFEngine(cfg)
+        loader = hp.DeviceTripleBatcher(*data, B)
+        sums = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for epoch in range(2):
+                eng.train_an_epoch(loader, epoch)
+                sums.append(eng.writer.scalars[-2][1])
+            # a third epoch enqueued in two pieces
+            assert eng.run_resident_epoch(loader, steps=(0, 2)) and eng.run_resident_epoch(loader, steps=(2, 6))
+            sums.append(eng._sync_stats().loss_sum)
+        assert (eng._direct_comm is not None) == (mode == "rccl")
+        assert eng.epoch_stats().step == 18
+        out[mode] = (sums, {k: v.cpu().numpy() for k, v in eng.model.state_dict().items()})
+    for a, b in zip(out["rccl"][0], out["torch"][0]):
+        assert_scalar_close(a, b, 2e-5, "epoch loss sums of the two drivers")
+    for k in KEYS:
+        scale = max(np.abs(out["torch"][1][k]).max(), 1e-3)
+        assert np.mean(np.abs(out["rccl"][1][k] - out["torch"][1][k]) > 2e-3 * scale) < 0.01, k
+
+
 def test_replicated_ncf_engine_with_hip_kernels(nccl_group):
     """Data-parallel NeuMF at world size 1: gradient kernel with the global 1/B, all-reduce of
     [gradient | loss], dense Adam sweep; losses and weights follow the oracle."""
