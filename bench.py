@@ -469,9 +469,11 @@ def bench_mf_c4_sharded(args, device, world, rank):
         while n > 0:
             take = min(n, epoch_steps - state["pos"])
             if state["pos"] == 0:
-                state["plan"] = eng.plan_epoch(loader)
+                state["plan"] = eng.take_plan(loader)   # prefetched during the previous epoch, if there was one
             eng.run_planned_epoch(state["plan"], steps=(state["pos"], state["pos"] + take), sync=False)
             state["pos"] = (state["pos"] + take) % epoch_steps
+            if state["pos"] == 0 and not args.no_plan_prefetch:
+                eng.prefetch_plan(loader)   # the whole epoch is enqueued: route the next one on the side stream
             n -= take
 
     advance(warm)
@@ -940,6 +942,8 @@ def main():
     ap.add_argument("--multi-gpu", default="auto", choices=["auto", "replicated", "sharded"],
                     help="mf, N>1: replicate small tables (gradient all-reduce) or row-shard them "
                          "(all-to-all routing); auto = replicated below 64 MB of parameters")
+    ap.add_argument("--no-plan-prefetch", action="store_true",
+                    help="mf-c4 on N > 1 GPUs: plan every epoch synchronously instead of during the previous one")
     ap.add_argument("--dp-collective", default=os.environ.get("HIPREC_DP_COLLECTIVE", "rccl"), choices=["rccl", "torch"],
                     help="replicated mode: 'rccl' = the C epoch driver calls ncclAllReduce itself on the engine's own "
                          "communicator (falls back to torch.distributed if any rank cannot create one), 'torch' = "

@@ -314,12 +314,12 @@ class ShardedMFEngine:
         dist.all_to_all_single(recv, counts, group=self.pg)
         return recv
 
-    def _a2a(self, send, send_counts, recv_counts):
+    def _a2a(self, send, send_counts, recv_counts, group=None):
         """Variable-size all-to-all of rows (first dim split by the per-rank counts)."""
         out = torch.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype,
                           device=send.device)
         dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(recv_counts),
-                               input_split_sizes=list(send_counts), group=self.pg)
+                               input_split_sizes=list(send_counts), group=group or self.pg)
         return out
 
     def _bucket(self, owner):
@@ -519,9 +519,11 @@ class ShardedMFEngine:
     # (csrc/mf_owned.hip), item gradients are summed per fetched slot and applied by the owner with -lr straight
     # into the table: no dense gradient buffer, no touched-rows pass; loss / reg / scalar-bias partials ride in one
     # extra row per peer of the gradient exchange instead of a separate all-reduce.
-    def plan_epoch(self, train_loader):
+    def plan_epoch(self, train_loader, group=None):
         """Collective.  Route one epoch of a DeviceTripleBatcher-like loader (this rank's share; the same number of
-        triples and batch size on every rank).  Returns the plan :meth:`run_planned_epoch` consumes."""
+        triples and batch size on every rank).  Returns the plan :meth:`run_planned_epoch` consumes.  group: the
+        process group its exchanges use (default: the engine's; :meth:`prefetch_plan` passes one of its own)."""
+        pg = group or self.pg
         from .mf import batch_row_ownership
 
         R, dev, D = self.world, self.device, self.emb_dim
@@ -530,7 +532,7 @@ class ShardedMFEngine:
         neg = train_loader.neg_item_tensor.to(dev)
         n, bs = users.numel(), int(train_loader.batch_size)
         sizes = torch.tensor([n, -n, bs, -bs], dtype=torch.int64, device=dev)
-        dist.all_reduce(sizes, op=dist.ReduceOp.MAX, group=self.pg)
+        dist.all_reduce(sizes, op=dist.ReduceOp.MAX, group=pg)
         if sizes[0] != -sizes[1] or sizes[2] != -sizes[3]:
             raise ValueError("the planned sharded epoch needs the same number of triples and batch size on every rank")
         S = (n + bs - 1) // bs
@@ -548,11 +550,11 @@ class ShardedMFEngine:
         o1 = torch.argsort(small(key, R * S), stable=True)
         cnt_ds = torch.bincount(key, minlength=R * S).view(R, S)
         recv_cnt = torch.empty_like(cnt_ds)
-        dist.all_to_all_single(recv_cnt, cnt_ds, group=self.pg)            # [source, step]
+        dist.all_to_all_single(recv_cnt, cnt_ds, group=pg)            # [source, step]
         n_k = recv_cnt.sum(0)
         host = torch.cat([cnt_ds.sum(1), recv_cnt.sum(1), n_k.max().reshape(1)]).tolist()   # host sync 1 of 2
         send1, recv1, cap = host[:R], host[R:2 * R], max(int(host[2 * R]), 1)
-        trip = self._a2a(torch.stack([users, pos, neg], 1)[o1], send1, recv1)   # (source, step)-ordered
+        trip = self._a2a(torch.stack([users, pos, neg], 1)[o1], send1, recv1, pg)   # (source, step)-ordered
         step_r = torch.repeat_interleave(ar(S).repeat(R), recv_cnt.reshape(-1))
         o2 = torch.argsort(small(step_r, S), stable=True)                  # -> (step, source)
         trip, step_r = trip[o2], step_r[o2]
@@ -584,14 +586,14 @@ class ShardedMFEngine:
         # (3) tell every owner which rows it will be asked for, step by step: one exchange, (dest, step)-ordered
         req_ds = req_cnt.t().contiguous()
         in_qs = torch.empty_like(req_ds)
-        dist.all_to_all_single(in_qs, req_ds, group=self.pg)               # [source, step]
+        dist.all_to_all_single(in_qs, req_ds, group=pg)               # [source, step]
         in_cnt = in_qs.t().contiguous()                                   # [step, source]
         host = torch.cat([req_ds.sum(1), in_qs.sum(1), req_cnt.reshape(-1), in_cnt.reshape(-1)]).tolist()  # sync 2 of 2
         send2, recv2 = host[:R], host[R:2 * R]
         req_l = [host[2 * R + k * R: 2 * R + (k + 1) * R] for k in range(S)]
         in_l = [host[2 * R + S * R + k * R: 2 * R + S * R + (k + 1) * R] for k in range(S)]
         o3 = torch.argsort(small(u_dest * S + u_step, R * S), stable=True)
-        incoming = self._a2a(u_item[o3], send2, recv2)                     # (source, step)-ordered
+        incoming = self._a2a(u_item[o3], send2, recv2, pg)                     # (source, step)-ordered
         flat_cnt = in_qs.reshape(-1)
         step_i = torch.repeat_interleave(ar(S).repeat(R), flat_cnt)
         src_i = torch.repeat_interleave(ar(R).repeat_interleave(S), flat_cnt)
@@ -626,6 +628,37 @@ class ShardedMFEngine:
                 "stride": stride, "in_idx": in_idx, "in_off": in_off, "in_len": in_len, "n_slots": n_slots,
                 "req_split": [[c + 1 for c in row] for row in req_l], "in_split": [[c + 1 for c in row] for row in in_l],
                 "ex_req": ex_req, "ex_in": ex_in}
+
+    def prefetch_plan(self, train_loader):
+        """Collective.  Plan the NEXT epoch now, on a side stream and over a process group of its own, while the
+        steps of the current one (already enqueued) run: the plan depends on the data only -- its sorts, its four
+        exchanges and its two host round trips (4.9 ms per 30 steps of 65 536 triples) then cost the training
+        stream nothing.  :meth:`take_plan` hands it to the next epoch."""
+        dev = self.device
+        if getattr(self, "_plan_stream", None) is None:
+            self._plan_stream = torch.cuda.Stream(device=dev)
+            ranks = None if self.pg is None else dist.get_process_group_ranks(self.pg)
+            self._plan_pg = dist.new_group(ranks=ranks)   # its own communicator: no ordering against the steps' exchanges
+            self._plans_alive = []
+        with torch.cuda.stream(self._plan_stream):
+            plan = self.plan_epoch(train_loader, group=self._plan_pg)
+            plan["ready"] = torch.cuda.Event()
+            plan["ready"].record(self._plan_stream)
+        # the plan's tensors come from the side stream's allocator pool: they must outlive the epoch that reads them
+        # on the training stream, or the next prefetch would overwrite them in flight (r02 experiments §24)
+        self._plans_alive = (self._plans_alive + [plan])[-3:]
+        self._prefetched_plan = plan
+        return plan
+
+    def take_plan(self, train_loader):
+        """The plan of the epoch about to run: the prefetched one (the training stream waits for its event) or a
+        fresh synchronous one."""
+        plan = getattr(self, "_prefetched_plan", None)
+        self._prefetched_plan = None
+        if plan is None:
+            return self.plan_epoch(train_loader)
+        torch.cuda.current_stream(self.device).wait_event(plan["ready"])
+        return plan
 
     def run_planned_epoch(self, plan, steps=None, sync=True):
         """Collective.  Enqueue every step of a planned epoch (plain SGD), or steps [a, b) of it; nothing is read

@@ -331,6 +331,42 @@ def test_planned_sharded_epoch_with_hip_kernels(nccl_group, D, B, shuffle):
     assert float(eng._planned_bufs["acc"].abs().max()) == 0.0 and int(eng._planned_bufs["arrived"].abs().max()) == 0
 
 
+def test_planned_epochs_with_the_plan_prefetched_on_a_side_stream(nccl_group):
+    """prefetch_plan routes the NEXT epoch on a side stream / its own process group while the current one runs;
+    take_plan hands it over behind an event.  Four shuffled epochs that way equal four planned synchronously."""
+    import beta_recsys_amd as hp
+    from beta_recsys_amd.sharded import ShardedMFEngine
+
+    U, I, D, B = 3000, 400, 64, 512
+    n = 6 * B + 100
+    w0 = onp.init_params(U, I, D, seed=3)
+    rng = np.random.default_rng(1)
+    p = 1.0 / np.arange(1, I + 1)
+    data = [torch.from_numpy(a).cuda() for a in (rng.integers(0, U, n), rng.choice(I, n, p=p / p.sum()),
+                                                  rng.integers(0, I, n))]
+    results = {}
+    for mode in ("prefetch", "sync"):
+        cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer="sgd", lr=0.05,
+                             batch_size=B, loss="bpr"), "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+        with contextlib.redirect_stdout(io.StringIO()):
+            eng = ShardedMFEngine(cfg, full_state={k: torch.from_numpy(v) for k, v in w0.items()})
+        loader = hp.DeviceTripleBatcher(*data, B, shuffle=True, generator=torch.Generator().manual_seed(4))
+        sums = []
+        for epoch in range(4):
+            plan = eng.take_plan(loader) if mode == "prefetch" else eng.plan_epoch(loader)
+            assert ("ready" in plan) == (mode == "prefetch" and epoch > 0)
+            eng.run_planned_epoch(plan, sync=False)
+            if mode == "prefetch" and epoch < 3:
+                eng.prefetch_plan(loader)          # while the epoch just enqueued runs
+            sums.append(eng.k.epoch_stats()[2])
+        results[mode] = (sums, {k: v.cpu().numpy() for k, v in eng.gather_full_state_dict().items()})
+    for a, b in zip(*[results[m][0] for m in ("prefetch", "sync")]):
+        assert_scalar_close(a, b, 2e-5, "epoch loss sums")
+    for k in KEYS:
+        a, b = results["prefetch"][1][k], results["sync"][1][k]
+        assert np.abs(a - b).max() <= 1e-5 * max(np.abs(b - w0[k]).max(), 1e-6) + 4 * 1.2e-7 * np.abs(b).max(), k
+
+
 def test_planned_sharded_epoch_at_c4_shard_size(nccl_group):
     """The sharded engine's step at one rank's share of BASELINE configs[3] (1.25M x 125k rows, dim 128, 65536
     triples per step) in -m gpu: at world size 1 the row-sharded engine and the single-GPU engine run
