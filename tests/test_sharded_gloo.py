@@ -495,7 +495,8 @@ def planned_worker(rank, world, port, n_local, bs, shuffle, out_path):
                                   full_state={k: torch.from_numpy(v) for k, v in w0.items()})
         loader = hp.DeviceTripleBatcher(torch.from_numpy(users), torch.from_numpy(pos), torch.from_numpy(neg), bs,
                                         shuffle=shuffle, generator=torch.Generator().manual_seed(9 + rank) if shuffle else None)
-        plan = eng.plan_epoch(loader)
+        # world 3: the plan's exchanges run over a process group of their own, as prefetch_plan does on GPUs
+        plan = eng.plan_epoch(loader, group=dist.new_group() if world == 3 else None)
         # what the plan says this rank's local batches were (the order inside a batch is irrelevant)
         order = np.arange(n_local)
         if shuffle:
