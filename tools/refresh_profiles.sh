@@ -16,6 +16,7 @@ for w in lightgcn mf-c4shard mf-c4 pgmf t2v ngcf; do
 done
 timeout 300 python bench.py --workload mf-c4shard --sgd-mode rows --no-cpu-baseline > $OUT/bench_mf-c4shard_rows.json 2> /dev/null
 HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --no-cpu-baseline --steps 200 2> /dev/null | grep metric > $OUT/bench_replicated_w1.json
+HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --no-cpu-baseline --steps 200 --dp-collective torch 2> /dev/null | grep metric > $OUT/bench_replicated_w1_torch.json
 HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload mf-c4 --no-cpu-baseline --steps 50 2> /dev/null | grep metric > $OUT/bench_mf-c4_sharded_w1.json
 python tools/exp_sharded_c4.py 2>&1 | grep sharded > $OUT/exp_sharded_c4.txt
 cd /tmp && export TMPDIR=/tmp
