@@ -39,7 +39,9 @@ def _load():
             lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _UniqueId, ctypes.c_int]
             lib.ncclCommDestroy.restype = ctypes.c_int
             lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
-            lib.ncclAllReduce  # noqa: B018  (must exist)
+            lib.ncclAllReduce.restype = ctypes.c_int
+            lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_void_p]
             _lib = lib
             return lib
         except (OSError, AttributeError):
@@ -83,9 +85,21 @@ def create_communicator(group, device):
         return None
     ctypes.memmove(uid.internal, bytes(payload[:NCCL_UNIQUE_ID_BYTES].tolist()), NCCL_UNIQUE_ID_BYTES)
     comm = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        rc = lib.ncclCommInitRank(ctypes.byref(comm), world, uid, rank)
-    if rc != 0 or not comm.value:
+    try:
+        with torch.cuda.device(device):
+            rc = lib.ncclCommInitRank(ctypes.byref(comm), world, uid, rank)
+            if rc != 0 or not comm.value:
+                return None
+            # one small sum through the new communicator, the way the C driver will call it (float32 = 7, sum = 0,
+            # in place, on the current stream): every rank contributes rank + 1
+            probe = torch.full((8,), float(rank + 1), dtype=torch.float32, device=device)
+            rc = lib.ncclAllReduce(probe.data_ptr(), probe.data_ptr(), probe.numel(), 7, 0, comm,
+                                   torch.cuda.current_stream(device).cuda_stream)
+            torch.cuda.current_stream(device).synchronize()
+            if rc != 0 or not bool((probe == world * (world + 1) / 2).all()):
+                lib.ncclCommDestroy(comm)
+                return None
+    except Exception:  # noqa: BLE001  (a binding that does not fit this librccl: keep the torch.distributed loop)
         return None
     return Communicator(lib, comm, world, rank)
 
