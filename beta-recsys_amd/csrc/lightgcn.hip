@@ -324,7 +324,9 @@ static int propagate_sliced(const hiprec_lightgcn_plan* p, const hiprec_sliced_c
   const float scale = keep ? 1.0f / keep_prob : 1.0f;
   float* xs0 = sliced_buf(p, 0);
   float* accs = sliced_buf(p, 1);
-  if (in != nullptr) {
+  // (a prepared step -- hiprec_lightgcn_step_values -- already laid E0 out for the forward graph's first pass)
+  const bool prepared = p->dropped_ready && keep && in == p->e0 && graph == &p->sa && with_input;
+  if (in != nullptr && !prepared) {
     if (int rc = launch_to_sliced(in, N, D, W, graph->col_scale, xs0, with_input ? accs : nullptr, st)) return rc;
   }
   const void* val = nullptr;
@@ -418,8 +420,18 @@ extern "C" int hiprec_lightgcn_step_values(const hiprec_lightgcn_plan* plan, uin
   if (int rc = check_lg_plan(plan, false)) return rc;
   HIPREC_REQUIRE(use_sliced(plan), "the plan has no sliced graphs");
   HIPREC_REQUIRE(plan->sat.n_rows == plan->a.n_rows && plan->sat.eid, "the plan has no transposed sliced graph");
+  // the same launch lays E0 out for the first pass (sliced buffer 0, times the graph's column factor) and seeds the
+  // layer sum (buffer 1): a step that sets dropped_ready starts with its passes
+  SlicedInput in;
+  in.x = plan->e0;
+  in.n_rows = plan->a.n_rows;
+  in.dim = plan->dim;
+  in.W = plan->slice_w;
+  in.row_scale = plan->sa.col_scale;
+  in.xs = sliced_buf(plan, 0);
+  in.xs_copy = sliced_buf(plan, 1);
   return launch_step_values(&plan->sa, &plan->sat, keep, draw != 0, keep_prob, seed, step, sliced_buf(plan, 4),
-                            sliced_buf(plan, 4) + plan->sa.n_slots, static_cast<hipStream_t>(stream));
+                            sliced_buf(plan, 4) + plan->sa.n_slots, static_cast<hipStream_t>(stream), in);
 }
 
 extern "C" int hiprec_lightgcn_propagate(const hiprec_lightgcn_plan* plan, const uint8_t* keep,

@@ -38,8 +38,19 @@ struct SlicedOut {
 };
 // dropped values of one step for one or two graphs in one launch; draw: the device draw keep_draw(seed, step, edge)
 // instead of reading keep[] (which `a`'s slots then fill in, when given)
+// optional extra work of that launch: x (row-major [n_rows][dim]) into the sliced layout, xs = row_scale (.) x,
+// xs_copy = x -- what launch_to_sliced does
+struct SlicedInput {
+  const float* x = nullptr;
+  int64_t n_rows = 0;
+  int dim = 0, W = 0;
+  const float* row_scale = nullptr;
+  float* xs = nullptr;
+  float* xs_copy = nullptr;
+};
 int launch_step_values(const hiprec_sliced_csr* a, const hiprec_sliced_csr* b, uint8_t* keep, bool draw,
-                       float keep_prob, uint64_t seed, uint64_t step, float* out_a, float* out_b, hipStream_t st);
+                       float keep_prob, uint64_t seed, uint64_t step, float* out_a, float* out_b, hipStream_t st,
+                       SlicedInput in = SlicedInput{});
 int launch_to_sliced(const float* x, int64_t n_rows, int dim, int W, const float* row_scale, float* xs,
                      float* xs_copy, hipStream_t st);
 int launch_from_sliced(const float* xs, int64_t n_rows, int dim, int W, float* y, bool add, hipStream_t st);

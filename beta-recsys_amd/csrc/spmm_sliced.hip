@@ -274,10 +274,21 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
 __global__ __launch_bounds__(kBlock) void step_values_kernel(hiprec_sliced_csr a, hiprec_sliced_csr b,
                                                              uint8_t* __restrict__ keep, int draw, float keep_prob,
                                                              uint64_t seed, uint64_t step, float* __restrict__ out_a,
-                                                             float* __restrict__ out_b) {
+                                                             float* __restrict__ out_b, SlicedInput in) {
   // eight consecutive slots per thread (n_slots is a multiple of 16): 16-byte loads and stores
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock, total = (a.n_slots + b.n_slots) >> 3;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += stride) {
+  // ... and, riding on the same launch, the step's input matrix into the sliced layout (to_sliced_kernel's work)
+  const int64_t n_in = in.x != nullptr ? in.n_rows * in.dim : 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total + n_in; i += stride) {
+    if (i >= total) {
+      const int64_t j = i - total, r = j / in.dim;
+      const int c = static_cast<int>(j - r * in.dim);
+      const int64_t o = (static_cast<int64_t>(c / in.W) * in.n_rows + r) * in.W + c % in.W;
+      const float v = in.x[j];
+      in.xs[o] = in.row_scale ? v * in.row_scale[r] : v;
+      if (in.xs_copy) in.xs_copy[o] = v;
+      continue;
+    }
     const bool first = (i << 3) < a.n_slots;
     const int64_t e = first ? i << 3 : (i << 3) - a.n_slots;
     const hiprec_sliced_csr& gph = first ? a : b;
@@ -400,16 +411,18 @@ int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scal
 }
 
 int launch_step_values(const hiprec_sliced_csr* a, const hiprec_sliced_csr* b, uint8_t* keep, bool draw,
-                       float keep_prob, uint64_t seed, uint64_t step, float* out_a, float* out_b, hipStream_t st) {
+                       float keep_prob, uint64_t seed, uint64_t step, float* out_a, float* out_b, hipStream_t st,
+                       SlicedInput in) {
   hiprec_sliced_csr none = {};
   if (b == nullptr) b = &none;
   HIPREC_REQUIRE(a && out_a && (a->n_slots == 0 || (a->val && a->eid)), "bad sliced graph");
   HIPREC_REQUIRE(b->n_slots == 0 || (b->val && b->eid && out_b), "bad second sliced graph");
   HIPREC_REQUIRE(draw || keep, "keep bytes needed");
-  if (a->n_slots + b->n_slots == 0) return 0;
+  const int64_t n_in = in.x != nullptr ? in.n_rows * in.dim : 0;
+  if (a->n_slots + b->n_slots + n_in == 0) return 0;
   HIPREC_REQUIRE(a->n_slots % 16 == 0 && b->n_slots % 16 == 0, "n_slots is not a multiple of 16");
-  step_values_kernel<<<grid_for_threads((a->n_slots + b->n_slots) / 8), kBlock, 0, st>>>(
-      *a, *b, keep, draw ? 1 : 0, keep_prob, seed, step, out_a, out_b);
+  step_values_kernel<<<grid_for_threads((a->n_slots + b->n_slots) / 8 + n_in), kBlock, 0, st>>>(
+      *a, *b, keep, draw ? 1 : 0, keep_prob, seed, step, out_a, out_b, in);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }

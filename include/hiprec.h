@@ -589,8 +589,9 @@ int hiprec_edge_dropout_mask(uint8_t* keep, int64_t nnz, float keep_prob, uint64
 
 /* ---- (sliced plans) the dropped edge values of one training step for both graphs, into plan->sliced_ws, in ONE
  * launch: draw != 0 draws the mask on the device (the draw of hiprec_edge_dropout_mask for the same seed / step;
- * written to keep[nnz] as well when keep is not NULL), draw == 0 reads keep[].  Set plan->dropped_ready for the
- * propagate / grad calls of that step; without it they prepare the values themselves, one launch per graph. */
+ * written to keep[nnz] as well when keep is not NULL), draw == 0 reads keep[].  The same launch lays plan->e0 out in
+ * the sliced layout for the first pass.  Set plan->dropped_ready for the propagate / grad calls of that step (same
+ * e0, nothing in between); without it they prepare values and layout themselves, one launch each. */
 int hiprec_lightgcn_step_values(const hiprec_lightgcn_plan* plan, uint8_t* keep, float keep_prob, int32_t draw,
                                 uint64_t seed, uint64_t step, void* stream);
 
