@@ -182,11 +182,14 @@ def test_ncf_full_size_c3_vs_oracle(hip_device, E):
 
 
 @pytest.mark.parametrize("engine,kind,E,L,B", [("MLPEngine", "mlp", 32, 3, 1000), ("NeuMFEngine", "neumf", 16, 2, 77),
-                                                ("MLPEngine", "mlp", 64, 2, 333)])
+                                                ("MLPEngine", "mlp", 64, 2, 333), ("NeuMFEngine", "neumf", 64, 3, 100),
+                                                ("NeuMFEngine", "neumf", 16, 2, 40000)])
 def test_fused_tower_shapes_vs_oracle(hip_device, engine, kind, E, L, B):
-    """Shapes that take the fused forward launch (2*dim_mlp <= 256, layer widths multiples of 32) in the
+    """Shapes that take the fused launch (2*dim_mlp <= 512, layer widths <= 256, multiples of 32) in the
     variants the goldens do not reach: the stand-alone MLP (no ReLU on the embeddings, no GMF half),
-    two-layer towers, ragged last blocks; gradients and scores vs the numpy oracle."""
+    two-layer towers, ragged last blocks, the 512-wide input with a 256-wide first layer (two output passes) on a
+    ragged batch, and a batch beyond the fused forward's 32 768 samples (launch-per-layer forward, then the
+    input-gradient chain in its own launch); gradients and scores vs the numpy oracle."""
     U, I = 700, 500
     torch.manual_seed(E + L)
     eng = make_engine(engine, U, I, E, L, "adam", 1e-3, B)
