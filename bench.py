@@ -793,6 +793,8 @@ def bench_mf(args, device, world, rank, dist_on):
         torch.manual_seed(2020)
         with contextlib.redirect_stdout(io.StringIO()):
             eng = ShardedMFEngine(cfg) if mode == "sharded" else ReplicatedMFEngine(cfg)
+        if mode != "sharded":
+            eng._direct_communicator()   # (collective) created here, not inside a timed window when --warmup is 0
     else:
         eng = make_engine(device, args.optimizer)
         eng.fused_step = not args.two_kernel
