@@ -44,5 +44,6 @@ pmc adam --steps 200 --warmup 20
 pmc sgd --optimizer sgd --steps 200 --warmup 20
 pmc mf-c4shard --workload mf-c4shard --steps 50 --warmup 5
 pmc lightgcn --workload lightgcn --steps 50 --warmup 5
+pmc ncf --workload ncf --steps 50 --warmup 5
 cd $GRAFT_REPO_ROOT && timeout 200 python tools/exp_spmm_sliced.py 2>&1 | grep -v amdgpu.ids > $OUT/exp_spmm_sliced.txt
 ls $OUT | head -80
