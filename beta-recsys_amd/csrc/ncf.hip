@@ -217,7 +217,7 @@ GemmProblem make_gemm(int mode, int M, int N, int K, const float* A, int lda, co
   if (split_k && !bias && !relu && !mask) {
     const int tiles = q.tiles_n * q.tiles_m;
     int z = (512 + tiles - 1) / tiles;
-    const int max_z = (K + 4 * kTK - 1) / (4 * kTK);  // at least 4 k-tiles per slice
+    const int max_z = (K + 4 * kTK - 1) / (4 * kTK);  // at least 4 k-tiles per slice (2: NCF 58.8 -> 65.1 us; 8: 60.2, emb 64 127.6 -> 120.0)
     if (z > max_z) z = max_z;
     if (z > 1) q.split = z;
   }
