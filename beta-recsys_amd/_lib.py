@@ -135,7 +135,8 @@ class NgcfPlan(Structure):
                    ("d_bi_in", c_void_p), ("d_ego", c_void_p * 2), ("spmm_tmp", c_void_p * NGCF_MAX_LAYERS),
                    ("zero_ws", c_void_p), ("zero_ws_floats", c_int64), ("sa", SlicedCsr), ("sat", SlicedCsr),
                    ("slice_w", c_int32), ("_pad2", c_int32), ("sliced_src", c_void_p),
-                   ("sliced_src_floats", c_int64)])
+                   ("sliced_src_floats", c_int64), ("d_sum_l", c_void_p * NGCF_MAX_LAYERS),
+                   ("d_bi_l", c_void_p * NGCF_MAX_LAYERS)])
 
 
 class FusedStep(Structure):

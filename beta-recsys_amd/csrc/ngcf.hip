@@ -233,6 +233,138 @@ __global__ __launch_bounds__(kHopThreads) void ngcf_hop_forward_kernel(
   }
 }
 
+// ---- ... and the hop's backward chain in ONE launch: normalize / dropout / leaky-ReLU backward, both input gradients,
+// the bilinear backward.  What ngcf_act_bwd_kernel + the two dgrad problems of the grouped launch + ngcf_bi_bwd_kernel
+// do (5.6 + ~7 + 5.7 us), on the same 16 node rows: two rows per wave produce d_sum / d_bi (kept per hop for the
+// weight gradients, which then all go into ONE grouped launch after the last hop), waves 0-3 multiply d_sum by GC and
+// waves 4-7 d_bi by Bi (the weights as they lie in memory are the B operands), the bilinear term joins them in LDS and
+// d_ego / d_side (+ the transposed SpMM's sliced source) leave from registers.
+// Limits: both widths <= 64, input width a multiple of 16, output width a multiple of 4.
+constexpr int kHopBwdMax = 64;
+
+static size_t hop_bwd_lds_floats(int di, int dout) {
+  return 2 * static_cast<size_t>(kHopRows) * (dout + 1) + 2 * static_cast<size_t>(dout) * (di + 4) +
+         static_cast<size_t>(kHopRows) * (di + 1);
+}
+
+template <bool ACCUMULATE>
+__global__ __launch_bounds__(kHopThreads) void ngcf_hop_backward_kernel(
+    const float* __restrict__ d_all, const float* __restrict__ all, int ld_all, int off, const float* __restrict__ nrm,
+    const float* __restrict__ d_next, const uint8_t* __restrict__ keep, float scale,
+    const float* __restrict__ sum_pre, const float* __restrict__ bi_pre, const float* __restrict__ gc_w,
+    const float* __restrict__ bi_w, const float* __restrict__ side, const float* __restrict__ ego_in, int di, int dout,
+    int64_t n_rows, float* __restrict__ d_sum, float* __restrict__ d_bi, float* __restrict__ d_ego,
+    float* __restrict__ d_side, SlicedOut spmm_src) {
+  extern __shared__ __attribute__((aligned(16))) float hop_lds[];
+  const int ldd = dout + 1, ldw = di + 4, ldg = di + 1;
+  float* wt = hop_lds;                           // [2][dout][di + 4]: GC, Bi as stored ([k = out][n = in]); 16-B rows
+  float* ds = wt + 2 * dout * ldw;               // [2][16][dout + 1]: d_sum, d_bi of the tile
+  float* gt = ds + 2 * kHopRows * ldd;           // [16][di + 1]: d_bi_in = d_bi Bi
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, wn = wave & 3;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kHopRows;
+
+  // loads that wait for nothing: this thread's share of one weight matrix, and (waves 0-3) side / ego of its outputs
+  const float* __restrict__ W = grp ? bi_w : gc_w;
+  const int half_tid = tid & (kHopThreads / 2 - 1), n4s = di >> 2, n_w4 = dout * n4s;
+  constexpr int kW4 = kHopBwdMax * kHopBwdMax / 4 / (kHopThreads / 2);  // 4
+  float4 wreg[kW4];
+#pragma unroll
+  for (int j = 0; j < kW4; ++j) {
+    const int q = half_tid + j * (kHopThreads / 2);
+    wreg[j] = q < n_w4 ? reinterpret_cast<const float4*>(W)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int col_e = wn * 16 + (lane & 15);
+  float sv[4] = {0.f, 0.f, 0.f, 0.f}, ev[4] = {0.f, 0.f, 0.f, 0.f};
+  if (grp == 0 && col_e < di) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = m0 + 4 * (lane >> 4) + r;
+      if (row < n_rows) {
+        sv[r] = side[row * di + col_e];
+        ev[r] = ego_in[row * di + col_e];
+      }
+    }
+  }
+  // rows wave, wave + 8: normalize / dropout / leaky-ReLU backward (lane = column)
+#pragma unroll
+  for (int j = 0; j < kHopRows / (kHopThreads / kWave); ++j) {
+    const int r = wave + j * (kHopThreads / kWave);
+    const int64_t row = m0 + r;
+    float a = 0.f, b = 0.f;
+    if (row < n_rows) {
+      const bool live = lane < dout;
+      const float dy = live ? d_all[row * ld_all + off + lane] : 0.f;
+      const float y = live ? all[row * ld_all + off + lane] : 0.f;
+      const float proj = wave_sum(y * dy);
+      const float n = nrm[row];
+      const bool big = n >= kNormEps;  // clamp_min passes the norm's gradient only where norm >= eps
+      const float inv = 1.0f / fmaxf(n, kNormEps);
+      if (live) {
+        const int64_t i = row * dout + lane;
+        float dx = (big ? dy - y * proj : dy) * inv;
+        if (d_next) dx += d_next[i];
+        if (keep) dx = keep[i] ? dx * scale : 0.f;
+        a = sum_pre[i] > 0.f ? dx : dx * kSlope;
+        b = bi_pre[i] > 0.f ? dx : dx * kSlope;
+        d_sum[i] = a;
+        d_bi[i] = b;
+      }
+    }
+    if (lane < dout) {
+      ds[r * ldd + lane] = a;
+      ds[(kHopRows + r) * ldd + lane] = b;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kW4; ++j) {
+    const int q = half_tid + j * (kHopThreads / 2);
+    if (q < n_w4) {
+      const int k = q / n4s, n4 = (q - k * n4s) * 4;
+      *reinterpret_cast<float4*>(wt + (grp * dout + k) * ldw + n4) = wreg[j];
+    }
+  }
+  lds_barrier();
+  hop_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (wn * 16 < di) {
+    const float* A = ds + grp * kHopRows * ldd;
+    const float* B = wt + grp * dout * ldw;
+    const int i = lane & 15, kq = lane >> 4;
+    for (int k0 = 0; k0 < dout; k0 += 32) {
+      float a[8], b[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + 4 * j + kq;
+        a[j] = k < dout ? A[i * ldd + k] : 0.f;
+        b[j] = k < dout ? B[k * ldw + wn * 16 + i] : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+    }
+    if (grp == 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gt[(4 * (lane >> 4) + r) * ldg + col_e] = acc[r];
+    }
+  }
+  lds_barrier();
+  if (grp == 0 && col_e < di) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // d_ego (= or +=) d_bi_in * side ;  d_side = d_sum GC + d_bi_in * ego
+      const int lrow = 4 * (lane >> 4) + r;
+      const int64_t row = m0 + lrow;
+      if (row >= n_rows) continue;
+      const float g = gt[lrow * ldg + col_e];
+      const int64_t i = row * di + col_e;
+      if (ACCUMULATE) d_ego[i] += g * sv[r];
+      else d_ego[i] = g * sv[r];
+      const float dsv = acc[r] + g * ev[r];
+      d_side[i] = dsv;
+      spmm_src.put(row, col_e, dsv);
+    }
+  }
+}
+
 // One wave per triple on rows of the concatenated table (width dt): BPR loss + L2 term, gradient rows
 // scattered with atomics.  Hop 0's slice (columns < d0) is not copied anywhere: it is read from the
 // embedding tables e0 themselves and its gradient goes straight into their gradient g_e0; columns
@@ -561,38 +693,68 @@ extern "C" int hiprec_ngcf_grad(const hiprec_ngcf_plan* plan, const int64_t* use
 
   int off = dt;
   const float* d_next = nullptr;
+  // per-hop d_sum / d_bi (optional workspaces) let the hop's backward chain ride one launch and ALL weight / bias
+  // gradients one grouped launch at the end
+  static const bool unfused_bwd = getenv("HIPREC_NGCF_UNFUSED_HOP") != nullptr;
+  bool hop_bwd = !unfused_bwd && 4 * p->n_layers <= kMaxGroup;
+  for (int l = 0; l < p->n_layers; ++l)
+    hop_bwd = hop_bwd && p->d_sum_l[l] && p->d_bi_l[l] && p->dim[l] <= kHopBwdMax && p->dim[l] % 16 == 0 &&
+              p->dim[l + 1] <= kHopBwdMax && p->dim[l + 1] % 4 == 0;
+  const int n32 = static_cast<int>(N);
   for (int l = p->n_layers - 1; l >= 0; --l) {
     const int di = p->dim[l], dout = p->dim[l + 1];
     off -= dout;
-    ngcf_act_bwd_kernel<<<grid_for_waves(N), kBlock, 0, st>>>(
-        p->d_all, p->all, dt, off, p->nrm[l], d_next, p->keep[l], p->keep_scale[l], p->sum_pre[l],
-        p->bi_pre[l], p->d_sum, p->d_bi, N, dout);
-    HIPREC_TRY(hipGetLastError());
     const float* ego_in = l == 0 ? p->e0 : p->ego[l - 1];
-    GemmGroup g{};
-    g.n = 6;
-    const int n32 = static_cast<int>(N);
-    g.p[0] = make_gemm(kNN, n32, di, dout, p->d_sum, dout, p->gc_w[l], di, p->d_side, di, nullptr, 0, nullptr, 0,
-                       false);
-    g.p[1] = make_gemm(kNN, n32, di, dout, p->d_bi, dout, p->bi_w[l], di, p->d_bi_in, di, nullptr, 0, nullptr, 0,
-                       false);
-    g.p[2] = make_gemm(kTNm, dout, di, n32, p->d_sum, dout, p->side[l], di, p->g_gc_w[l], di, nullptr, 0, nullptr,
-                       0, true);
-    g.p[3] = make_gemm(kTNm, dout, di, n32, p->d_bi, dout, p->bi_in[l], di, p->g_bi_w[l], di, nullptr, 0, nullptr,
-                       0, true);
-    g.p[4] = make_colsum(p->d_sum, n32, dout, dout, p->g_gc_b[l]);
-    g.p[5] = make_colsum(p->d_bi, n32, dout, dout, p->g_bi_b[l]);
-    if (int rc = launch_group(g, st)) return rc;
     // hop 0 hands its result to the embedding gradient itself (which already holds the loss's share)
     float* d_ego = l == 0 ? p->g_e0 : p->d_ego[l & 1];
     const SlicedOut src = sliced ? ngcf_sliced_out(p, &p->sat) : SlicedOut{};
-    if (l == 0)
-      ngcf_bi_bwd_kernel<true><<<grid_for_threads(N * di), kBlock, 0, st>>>(p->d_bi_in, p->side[l], ego_in, d_ego,
-                                                                           p->d_side, N * di, di, src);
-    else
-      ngcf_bi_bwd_kernel<false><<<grid_for_threads(N * di), kBlock, 0, st>>>(p->d_bi_in, p->side[l], ego_in, d_ego,
-                                                                            p->d_side, N * di, di, src);
-    HIPREC_TRY(hipGetLastError());
+    if (hop_bwd) {
+      const size_t lds = sizeof(float) * hop_bwd_lds_floats(di, dout);
+      static bool attr_set = false;
+      if (!attr_set) {
+        const int cap = static_cast<int>(sizeof(float) * hop_bwd_lds_floats(kHopBwdMax, kHopBwdMax));
+        HIPREC_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ngcf_hop_backward_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIPREC_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ngcf_hop_backward_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        attr_set = true;
+      }
+      const int grid = static_cast<int>((N + kHopRows - 1) / kHopRows);
+      if (l == 0)
+        ngcf_hop_backward_kernel<true><<<grid, kHopThreads, lds, st>>>(
+            p->d_all, p->all, dt, off, p->nrm[l], d_next, p->keep[l], p->keep_scale[l], p->sum_pre[l], p->bi_pre[l],
+            p->gc_w[l], p->bi_w[l], p->side[l], ego_in, di, dout, N, p->d_sum_l[l], p->d_bi_l[l], d_ego, p->d_side, src);
+      else
+        ngcf_hop_backward_kernel<false><<<grid, kHopThreads, lds, st>>>(
+            p->d_all, p->all, dt, off, p->nrm[l], d_next, p->keep[l], p->keep_scale[l], p->sum_pre[l], p->bi_pre[l],
+            p->gc_w[l], p->bi_w[l], p->side[l], ego_in, di, dout, N, p->d_sum_l[l], p->d_bi_l[l], d_ego, p->d_side, src);
+      HIPREC_TRY(hipGetLastError());
+    } else {
+      ngcf_act_bwd_kernel<<<grid_for_waves(N), kBlock, 0, st>>>(
+          p->d_all, p->all, dt, off, p->nrm[l], d_next, p->keep[l], p->keep_scale[l], p->sum_pre[l],
+          p->bi_pre[l], p->d_sum, p->d_bi, N, dout);
+      HIPREC_TRY(hipGetLastError());
+      GemmGroup g{};
+      g.n = 6;
+      g.p[0] = make_gemm(kNN, n32, di, dout, p->d_sum, dout, p->gc_w[l], di, p->d_side, di, nullptr, 0, nullptr, 0,
+                         false);
+      g.p[1] = make_gemm(kNN, n32, di, dout, p->d_bi, dout, p->bi_w[l], di, p->d_bi_in, di, nullptr, 0, nullptr, 0,
+                         false);
+      g.p[2] = make_gemm(kTNm, dout, di, n32, p->d_sum, dout, p->side[l], di, p->g_gc_w[l], di, nullptr, 0, nullptr,
+                         0, true);
+      g.p[3] = make_gemm(kTNm, dout, di, n32, p->d_bi, dout, p->bi_in[l], di, p->g_bi_w[l], di, nullptr, 0, nullptr,
+                         0, true);
+      g.p[4] = make_colsum(p->d_sum, n32, dout, dout, p->g_gc_b[l]);
+      g.p[5] = make_colsum(p->d_bi, n32, dout, dout, p->g_bi_b[l]);
+      if (int rc = launch_group(g, st)) return rc;
+      if (l == 0)
+        ngcf_bi_bwd_kernel<true><<<grid_for_threads(N * di), kBlock, 0, st>>>(p->d_bi_in, p->side[l], ego_in, d_ego,
+                                                                             p->d_side, N * di, di, src);
+      else
+        ngcf_bi_bwd_kernel<false><<<grid_for_threads(N * di), kBlock, 0, st>>>(p->d_bi_in, p->side[l], ego_in, d_ego,
+                                                                              p->d_side, N * di, di, src);
+      HIPREC_TRY(hipGetLastError());
+    }
     // d_ego += A^T d_side
     if (sliced) {
       SlicedFlush fl;
@@ -604,6 +766,20 @@ extern "C" int hiprec_ngcf_grad(const hiprec_ngcf_plan* plan, const int64_t* use
       return rc;
     }
     d_next = d_ego;
+  }
+  if (hop_bwd) {  // every hop's weight and bias gradients: they only read what the hop launches wrote
+    GemmGroup g{};
+    g.n = 0;
+    for (int l = 0; l < p->n_layers; ++l) {
+      const int di = p->dim[l], dout = p->dim[l + 1];
+      g.p[g.n++] = make_gemm(kTNm, dout, di, n32, p->d_sum_l[l], dout, p->side[l], di, p->g_gc_w[l], di, nullptr, 0,
+                             nullptr, 0, true);
+      g.p[g.n++] = make_gemm(kTNm, dout, di, n32, p->d_bi_l[l], dout, p->bi_in[l], di, p->g_bi_w[l], di, nullptr, 0,
+                             nullptr, 0, true);
+      g.p[g.n++] = make_colsum(p->d_sum_l[l], n32, dout, dout, p->g_gc_b[l]);
+      g.p[g.n++] = make_colsum(p->d_bi_l[l], n32, dout, dout, p->g_bi_b[l]);
+    }
+    if (int rc = launch_group(g, st)) return rc;
   }
   return 0;
 }

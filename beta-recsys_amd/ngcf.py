@@ -122,6 +122,8 @@ class NGCF(_FlatModel):
         for name in ("sum_pre", "bi_pre", "ego"):
             ws[name] = [new(N, dims[i + 1]) for i in range(self.n_layers)]
         ws["nrm"] = [new(N) for _ in range(self.n_layers)]
+        for name in ("d_sum_l", "d_bi_l"):   # per hop: the backward chain of a hop is one launch, all wgrads one group
+            ws[name] = [new(N, dims[i + 1]) for i in range(self.n_layers)]
         ws["keep"] = [torch.ones(N, dims[i + 1], dtype=torch.uint8, device=dev) for i in range(self.n_layers)]
         for name in ("d_sum", "d_bi", "d_side", "d_bi_in", "d_ego0", "d_ego1", "sliced_src"):
             ws[name] = new(N, dmax)
@@ -151,7 +153,7 @@ class NGCF(_FlatModel):
                 getattr(p, field)[i] = at(self._flat, name)
                 if g_flat is not None:
                     getattr(p, "g_" + field)[i] = at(g_flat, name)
-            for field in ("side", "bi_in", "sum_pre", "bi_pre", "ego", "nrm", "spmm_tmp"):
+            for field in ("side", "bi_in", "sum_pre", "bi_pre", "ego", "nrm", "spmm_tmp", "d_sum_l", "d_bi_l"):
                 getattr(p, field)[i] = ws[field][i].data_ptr()
             k = None if keep is None else keep[i]
             p.keep[i] = None if k is None else k.data_ptr()

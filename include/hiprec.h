@@ -812,6 +812,10 @@ typedef struct hiprec_ngcf_plan {
   int32_t slice_w, _pad2;
   float* sliced_src;
   int64_t sliced_src_floats;
+  /* Optional: one [N, dim[l+1]] buffer per hop for d_sum / d_bi (instead of the shared d_sum / d_bi).  With them (hop
+   * widths <= 64) a hop's backward chain is one launch and all weight / bias gradients one grouped launch at the end. */
+  float* d_sum_l[HIPREC_NGCF_MAX_LAYERS];
+  float* d_bi_l[HIPREC_NGCF_MAX_LAYERS];
 } hiprec_ngcf_plan;
 
 size_t hiprec_ngcf_plan_bytes(void);
