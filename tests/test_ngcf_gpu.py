@@ -83,7 +83,8 @@ def test_step_matches_reference(hip_device, case, spmm):
         g_ref = ngcf_params(g, f"g{s + 1}")
         _, exact = onp.ngcf_grads(w0, adj, *batch, decay, B, ngcf_masks(g, s), drop, dt=np.float64)
         for k in w0:
-            assert_as_accurate_as_reference(grads[k].cpu().numpy(), g_ref[k], exact[k], what=f"grad {k} step {s}")
+            assert_as_accurate_as_reference(grads[k].cpu().numpy(), g_ref[k], exact[k], what=f"grad {k} step {s}",
+                                            ref_factor=3.0 if k.endswith(".bias") else 2.0)
         load_opt_state(eng, st0)
         torch.manual_seed(2000 + s)
         loss2, reg2 = eng.train_single_batch(batch)
@@ -167,7 +168,8 @@ def test_ml1m_sized_graph_vs_oracle(hip_device, D, layers, drop, optimizer, spmm
     _, exact = onp.ngcf_grads(w, adj, *batch, 1e-5, B, masks, drop, dt=np.float64)
     assert_scalar_close(loss, loss_o, what="loss")
     for k in w:
-        assert_as_accurate_as_reference(grads[k].cpu().numpy(), g_o[k], exact[k], what=f"grad {k}")
+        assert_as_accurate_as_reference(grads[k].cpu().numpy(), g_o[k], exact[k], what=f"grad {k}",
+                                        ref_factor=3.0 if k.endswith(".bias") else 2.0)
     # rows of nodes no triple touched still receive gradient through the graph, but a user with no
     # edge at all and no triple keeps a zero row
     deg = np.asarray((adj != 0).sum(1)).ravel()
