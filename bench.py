@@ -18,8 +18,8 @@ epoch boundaries); `ms_per_step` is the MEDIAN over the repeats of (time of the 
 from it, `steps` stays K and `repeats` says R; `wall_ms_per_step` is the plain wall clock of the whole R x K
 region (launch latency of the first step included) for cross-checking.  N = 1: the repeats are enqueued back
 to back and delimited by HIP events on the stream they run on (a host synchronize per 0.2 ms window would
-measure the synchronize).  N > 1: every repeat is bracketed by barrier + torch.cuda.synchronize() on both
-sides and the MAX over ranks is taken per repeat.
+measure the synchronize).  N > 1: the same events per rank, the whole R x K region bracketed by barrier +
+torch.cuda.synchronize() on both sides, and the MAX over ranks taken per repeat afterwards.
 
 `python bench.py --gpus N` without a torch.distributed environment starts its own N ranks (re-exec
 through torch.distributed.run on 127.0.0.1); under torchrun it uses RANK / LOCAL_RANK / WORLD_SIZE as
@@ -48,7 +48,7 @@ LR = 0.05
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec peak)
 MIN_TIMED_STEPS, MIN_REPEATS = 200, 5
 EPOCH_STEPS = 245  # N = 1 000 000 triples per epoch -> 245 batches of 4096 (1 003 520 triples)
-ROUND = "r02"
+ROUND = "r03"
 
 
 def algorithmic_bytes_per_triple(dim):
@@ -84,19 +84,25 @@ def timed_repeats(run_epoch, steps, device, dist_on=False):
         return [evs[r].elapsed_time(evs[r + 1]) * 1e-3 for r in range(R)], wall
     import torch.distributed as dist
 
-    per = []
-    w0 = time.perf_counter()
+    # N > 1: the WHOLE region (R x K steps) is bracketed by barrier + synchronize on both sides; inside it every
+    # rank delimits its K-step windows with HIP events on the stream the steps run on -- exactly like N = 1 -- and
+    # the per-window times are MAX-reduced over the ranks afterwards.  (Bracketing every 20-step window with
+    # synchronize + barrier + synchronize measured the brackets: 14.9 us/step at --steps 20 against 12.5 at 2000 for
+    # the same world-1 replicated step)  The steps' own collectives keep the ranks in lock step.
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(R + 1)]
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    evs[0].record()
     for r in range(R):
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
         run_epoch(r)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        per.append(time.perf_counter() - t0)
-    wall = time.perf_counter() - w0
+        evs[r + 1].record()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    per = [evs[r].elapsed_time(evs[r + 1]) * 1e-3 for r in range(R)]
     t = torch.tensor(per + [wall], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank defines every repeat
     t = t.cpu().tolist()
@@ -749,7 +755,7 @@ def traffic_from_profiles(kernel, workload=None):
     """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) of a kernel from the COMMITTED rocprofv3 PMC passes
     -- this round's summary if it exists, else round 1's -- as (bytes | None, source file | None).  It is
     not measured in this run: counters need their own rocprofv3 passes (tools/pmc_workload.sh)."""
-    for rnd in (ROUND, "r01"):
+    for rnd in (ROUND, "r02", "r01"):
         try:
             if workload is None:
                 name = f"{rnd}_pmc_summary.json"
