@@ -114,6 +114,7 @@ def timing_fields(per, wall, steps, units_per_step, world=1):
     med = statistics.median(per)
     return {"value": world * units_per_step * steps / med, "ms_per_step": med / steps * 1e3,
             "repeats": len(per), "timed_steps_total": len(per) * steps,
+            "ms_per_step_by_repeat": [round(t / steps * 1e3, 5) for t in per],
             "ms_per_step_min": min(per) / steps * 1e3, "ms_per_step_max": max(per) / steps * 1e3,
             "wall_ms_per_step": wall / (len(per) * steps) * 1e3}
 
@@ -450,12 +451,15 @@ def bench_mf_c4_sharded(args, device, world, rank):
     from beta_recsys_amd.sharded import ShardedMFEngine
 
     Uc, Ic, Dc, Bc = 10_000_000, 1_000_000, 128, 65536
-    cfg = {"model": dict(n_users=Uc, n_items=Ic, emb_dim=Dc, device_str=str(device), optimizer="sgd", lr=LR,
-                         batch_size=Bc, loss="bpr", sgd_mode="rows", shard_init="local"),
+    cfg = {"model": dict(n_users=Uc, n_items=Ic, emb_dim=Dc, device_str=str(device), optimizer=args.c4_optimizer, lr=LR,
+                         batch_size=Bc, loss="bpr", sgd_mode="rows", shard_init="local", step_driver=args.step_driver),
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
         eng = ShardedMFEngine(cfg)
+    eng._step_comm()   # (collective) the step driver's communicator is created here, not inside a timed window
+    if not args.no_plan_prefetch:
+        eng.prefetch_setup()   # likewise the side stream / process group of the prefetched plans
     import beta_recsys_amd as hp
 
     steps, warm = min(args.steps, 100), min(args.warmup, 10)
@@ -493,10 +497,16 @@ def bench_mf_c4_sharded(args, device, world, rank):
     out.update({"n_gpus": world, "steps": steps, "warmup": warm, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "BPR-MF, BASELINE configs[3]: 10M x 1M rows, dim 128, batch 65536 triples/GPU, "
-                                       "uniform users, Zipf(1.0) positives, exact SGD on touched rows",
-                           "parallelism": f"tables row-sharded over {world} GPUs (owner = row mod {world}); per step "
-                                          "A2A-1 triples -> owner(user), A2A-2 item ids / rows, A2A-3 item-row gradients, "
-                                          "3-float all-reduce",
+                                       "uniform users, Zipf(1.0) positives, " +
+                                       ("exact SGD on touched rows" if args.c4_optimizer == "sgd" else
+                                        f"dense {args.c4_optimizer} sweep of every shard per step"),
+                           "parallelism": f"tables row-sharded over {world} GPUs (owner = row mod {world}); the epoch is "
+                                          "routed once by the planner kernels (triples -> owner(user), de-duplicated item "
+                                          "requests -> owner(item)); per step 2 exact-size exchanges (rows out, gradients + "
+                                          "loss partials back) around 4 launches, " +
+                                          ("enqueued from C with grouped ncclSend/ncclRecv" if eng._step_mode == "c"
+                                           else "through torch.distributed.all_to_all_single"),
+                           "step_driver": eng._step_mode, "optimizer": args.c4_optimizer,
                            "global_batch": world * Bc, "rccl_world_size": world},
                 "roofline": {"bound": "hbm", "kernel": "whole sharded step (per GPU)",
                              "achieved": out["value"] / world * bpt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -823,15 +833,10 @@ def bench_mf(args, device, world, rank, dist_on):
                 eng.run_prepared_epoch(state["prepared"], sync=False, prefetch=loader, steps=piece)
             elif mode == "replicated":
                 assert eng.run_resident_epoch(loader, steps=piece)
-            elif args.optimizer == "sgd":
-                if piece[0] == 0:   # route the whole epoch once (ids only), then exact-size exchanges per step
+            else:   # row-sharded: route the whole epoch once (ids only), then exact-size exchanges per step
+                if piece[0] == 0:
                     state["prepared"] = eng.plan_epoch(loader)
                 eng.run_planned_epoch(state["prepared"], steps=piece, sync=False)
-            else:   # Adam / RMSprop need the dense sweep of the shard: the per-step (padded routing) path
-                if piece[0] == 0:
-                    state["it"] = iter(loader)
-                for _ in range(take):
-                    eng.train_single_batch(next(state["it"]), sync=False)
             state["pos"] = piece[1] % EPOCH_STEPS
             n -= take
 
@@ -950,6 +955,11 @@ def main():
     ap.add_argument("--multi-gpu", default="auto", choices=["auto", "replicated", "sharded"],
                     help="mf, N>1: replicate small tables (gradient all-reduce) or row-shard them "
                          "(all-to-all routing); auto = replicated below 64 MB of parameters")
+    ap.add_argument("--c4-optimizer", default="sgd", choices=["sgd", "adam", "rmsprop"],
+                    help="mf-c4 row-sharded: sgd (SURVEY 8d primary: exact scatter) or the dense optimizers (secondary)")
+    ap.add_argument("--step-driver", default="c", choices=["c", "torch"],
+                    help="row-sharded planned steps: c = kernels and grouped ncclSend/ncclRecv enqueued by one C call "
+                         "per range of steps; torch = torch.distributed.all_to_all_single between the launches")
     ap.add_argument("--no-plan-prefetch", action="store_true",
                     help="mf-c4 on N > 1 GPUs: plan every epoch synchronously instead of during the previous one")
     ap.add_argument("--dp-collective", default=os.environ.get("HIPREC_DP_COLLECTIVE", "rccl"), choices=["rccl", "torch"],

@@ -117,6 +117,31 @@ class T2vTables(Structure):
                 ("n_users", c_int64), ("n_items", c_int64), ("dim", c_int32), ("_pad", c_int32)]
 
 
+class ShardPlan(Structure):
+    """hiprec_shard_plan (include/hiprec.h)."""
+
+    _fields_ = [("world", c_int32), ("rank", c_int32), ("n_steps", c_int64), ("cap", c_int64),
+                ("local_batch", c_int64), ("n_local", c_int64), ("users", c_void_p), ("pos_slot", c_void_p),
+                ("neg_slot", c_void_p), ("own", c_void_p), ("total", c_void_p), ("total_stride", c_int64),
+                ("in_idx", c_void_p), ("ex_req", c_void_p), ("ex_in", c_void_p), ("in_off_host", c_void_p),
+                ("n_slots_host", c_void_p), ("req_cnt_host", c_void_p), ("in_cnt_host", c_void_p)]
+
+
+class ShardBufs(Structure):
+    """hiprec_shard_bufs (include/hiprec.h)."""
+
+    _fields_ = [("w_flat", c_void_p), ("n_users_local", c_int64), ("n_items_local", c_int64), ("dim", c_int32),
+                ("_pad", c_int32), ("payload", c_void_p), ("g_recv", c_void_p), ("fetched", c_void_p),
+                ("g_send", c_void_p), ("arrived", c_void_p), ("acc", c_void_p), ("scratch", c_void_p),
+                ("g_flat", c_void_p), ("m_flat", c_void_p), ("v_flat", c_void_p)]
+
+
+class NcclFns(Structure):
+    """hiprec_nccl_fns (include/hiprec.h)."""
+
+    _fields_ = [("send", c_void_p), ("recv", c_void_p), ("group_start", c_void_p), ("group_end", c_void_p)]
+
+
 NGCF_MAX_LAYERS = 6
 
 
@@ -308,6 +333,31 @@ SIGNATURES = {
         [_P, c_int64, c_int64, c_int32, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_float,
          c_float, c_double, _P, _P, _P],
     ),
+    "hiprec_batch_row_ownership_tables": (
+        c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "hiprec_plan_route_tiles": (c_int64, [c_int64, c_int64]),
+    "hiprec_plan_route_triples": (
+        c_int, [_P, _P, _P, _P, c_int64, c_int64, c_int32, c_int64, c_int64, _P, _P, _P, _P, _P]),
+    "hiprec_plan_place_triples": (c_int, [_P, c_int64, _P, c_int32, c_int64, c_int64, _P, _P, _P, _P, _P]),
+    "hiprec_plan_slot_ws_ints": (c_int64, [c_int64, c_int32, c_int32]),
+    "hiprec_plan_item_slots": (
+        c_int, [_P, c_int64, c_int64, c_int32, c_int64, c_int32] + [_P] * 16 + [_P]),
+    "hiprec_plan_place_requests": (c_int, [_P, c_int64, _P, c_int32, c_int64, _P, _P, _P, _P, _P]),
+    "hiprec_shard_payload_zero": (
+        c_int, [_P, _P, c_int64, c_int32, _P, c_int64, c_int64, c_int64, _P, _P, _P, c_int64, _P, _P]),
+    "hiprec_mf_bpr_grad_remote_step": (
+        c_int,
+        [_P, _P, c_int64, c_int64, c_int32, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int64, c_float, c_float,
+         _P, _P, _P],
+    ),
+    "hiprec_shard_apply_finish": (
+        c_int, [_P, _P, c_int64, c_int32, _P, _P, c_int64, c_int64, c_int64, _P, c_double, _P, c_int32, _P, c_double,
+                c_int32, _P, _P]),
+    "hiprec_shard_planned_steps": (
+        c_int, [POINTER(ShardPlan), POINTER(ShardBufs), c_int64, c_int64, c_int32, c_float, c_double, c_double,
+                c_double, c_double, POINTER(NcclFns), _P, _P, _P]),
+    "hiprec_shard_plan_bytes": (c_size_t, []),
+    "hiprec_shard_bufs_bytes": (c_size_t, []),
     "hiprec_shard_publish_partials": (c_int, [_P, _P, c_int32, _P, c_int32, _P]),
     "hiprec_shard_apply_rows": (c_int, [_P, _P, c_int64, c_int32, _P, _P, c_int64, c_double, _P, _P]),
     "hiprec_shard_finish_step": (c_int, [_P, c_int32, _P, c_int32, _P, c_double, c_int32, _P, _P]),

@@ -1,7 +1,8 @@
-"""The two things the data-parallel epoch driver needs from RCCL, bound with ctypes to the librccl that PyTorch
-already loaded: a communicator of its own over a torch.distributed process group (the unique id travels through one
-broadcast of that group) and the ADDRESS of ncclAllReduce, which ``hiprec_mf_bpr_dp_epoch_fused_range`` calls from C
-between the step launches (libhiprec itself does not link RCCL).
+"""What the C step drivers need from RCCL, bound with ctypes to the librccl that PyTorch already loaded: a
+communicator of their own over a torch.distributed process group (the unique id travels through one broadcast of
+that group) and the ADDRESSES of ncclAllReduce -- which ``hiprec_mf_bpr_dp_epoch_fused_range`` calls from C between
+the step launches -- and of ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd, with which
+``hiprec_shard_planned_steps`` posts the row-sharded step's two exchanges (libhiprec itself does not link RCCL).
 
 Plumbing, like torch.distributed: nothing here computes.  Every failure (library not found, a symbol missing, an
 init that does not return ncclSuccess) makes :func:`create_communicator` return None on that rank; the caller then
@@ -42,6 +43,10 @@ def _load():
             lib.ncclAllReduce.restype = ctypes.c_int
             lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_void_p, ctypes.c_void_p]
+            # point-to-point entry points of the row-sharded planned step (optional: older builds may lack them)
+            for name in ("ncclSend", "ncclRecv", "ncclGroupStart", "ncclGroupEnd"):
+                if hasattr(lib, name):
+                    getattr(lib, name).restype = ctypes.c_int
             _lib = lib
             return lib
         except (OSError, AttributeError):
@@ -51,11 +56,18 @@ def _load():
 
 
 class Communicator:
-    """An RCCL communicator + the address of ncclAllReduce."""
+    """An RCCL communicator + the addresses of the collectives the C step drivers call."""
 
     def __init__(self, lib, comm, world, rank):
         self._lib, self.comm, self.world, self.rank = lib, comm, world, rank
         self.all_reduce_fn = ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p).value
+        addr = lambda name: ctypes.cast(getattr(lib, name), ctypes.c_void_p).value if hasattr(lib, name) else None  # noqa: E731
+        self.send_fn, self.recv_fn = addr("ncclSend"), addr("ncclRecv")
+        self.group_start_fn, self.group_end_fn = addr("ncclGroupStart"), addr("ncclGroupEnd")
+
+    def has_send_recv(self):
+        """True when the grouped send / recv the row-sharded step driver calls from C are all there."""
+        return all((self.send_fn, self.recv_fn, self.group_start_fn, self.group_end_fn))
 
     def destroy(self):
         if self.comm:

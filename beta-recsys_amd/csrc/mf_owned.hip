@@ -42,6 +42,15 @@ constexpr int kOwnedGroup = 4;            // completed rows swapped out together
 // consecutive triples of the batch handled by ONE wave, all of their rows in flight at once (registers)
 constexpr int owned_chunk(int npl) { return npl <= 2 ? 8 : 4; }
 
+// OwnedStep.dbg switches parts of the step off for TIMING experiments (1 = every row written directly, racy; 2 = no
+// weight writes at all).  It only exists in builds made with -DHIPREC_OWNED_DEBUG; the product library has no such
+// switch.
+#ifdef HIPREC_OWNED_DEBUG
+#define HIPREC_OWNED_DBG_BIT(b) (f.dbg & (b))
+#else
+#define HIPREC_OWNED_DBG_BIT(b) false
+#endif
+
 struct OwnedStep {
   float* w;                    // flat parameters [user_emb | item_emb | user_bias | item_bias | global_bias]
   int64_t n_users, n_items;
@@ -64,6 +73,9 @@ struct OwnedStep {
   // strides dim + 1, bias behind the row) and their gradients go to item_out (same layout) instead of the table.
   int64_t o_ub, o_ie, o_ib, item_stride, bias_stride;
   float* item_out;
+  // GRAD variant (Adam / RMSprop on the row-sharded planned path): the user rows are not updated; their gradient goes
+  // into grad_out, a dense buffer laid out like w (zero on entry: a row that occurs once is a plain store)
+  float* grad_out;
 };
 
 // Read a finished accumulator element and leave it zero for the next step: ONE device-scope exchange.  (A device-scope
@@ -91,7 +103,7 @@ __device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
 // rows this wave completed are swapped out kOwnedGroup at a time, re-read (a row still holds its pre-step value:
 // only its owner ever writes it) and written back as w - lr * g.
 // Waves never wait for each other inside the loop.
-template <int NPL, bool REMOTE>
+template <int NPL, bool REMOTE, bool GRAD>
 __global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
     OwnedStep f, const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
     const int64_t* __restrict__ neg, int64_t batch, float inv_batch, float reg_coef, hiprec_stats* stats,
@@ -231,8 +243,25 @@ __global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
     // direct rows: w - lr * g straight back; shared rows: contribution into the slot's accumulator + a note
     auto settle = [&](int slot, int wt, int tot, int64_t row, int64_t bias, const float (&g)[NPL], float gb_,
                       const float (&v)[NPL], float vb) {
-      if (f.dbg & 2) return;
-      if (slot < 0 || wt == tot || (f.dbg & 1)) {
+      if constexpr (GRAD) {
+        float* o = f.grad_out;
+        const bool all_mine = slot < 0 || wt == tot;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+          const int c = lane + kWave * k;
+          if (c < D) {
+            if (all_mine) o[row + c] = g[k];
+            else atomic_add_f32(o + row + c, g[k]);
+          }
+        }
+        if (lane == 0) {
+          if (all_mine) o[bias] = gb_;
+          else atomic_add_f32(o + bias, gb_);
+        }
+        return;
+      }
+      if (HIPREC_OWNED_DBG_BIT(2)) return;
+      if (slot < 0 || wt == tot || HIPREC_OWNED_DBG_BIT(1)) {
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
           const int c = lane + kWave * k;
@@ -261,7 +290,7 @@ __global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
     // REMOTE items: the gradient of slot `item` goes into the exchange buffer -- a plain store when this wave holds
     // every reference to the slot, an atomic add otherwise; the owner applies it after the exchange
     auto send_item = [&](int slot, int wt, int tot, int64_t item, const float (&g)[NPL], float gb_) {
-      if (f.dbg & 2) return;
+      if (HIPREC_OWNED_DBG_BIT(2)) return;
       float* o = f.item_out + item * i_st;
       const bool all_mine = slot < 0 || wt == tot;
 #pragma unroll
@@ -446,15 +475,15 @@ __global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
   }
 }
 
-template <bool REMOTE>
+template <bool REMOTE, bool GRAD = false>
 static int launch_owned(const OwnedStep& f, int grid, hipStream_t st, const int64_t* uu, const int64_t* pp,
                         const int64_t* nn, int64_t b, float inv_b, float reg_coef, hiprec_stats* stats, Scratch* sc) {
   if (f.dim <= 64)
-    mf_bpr_owned_kernel<1, REMOTE><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    mf_bpr_owned_kernel<1, REMOTE, GRAD><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
   else if (f.dim <= 128)
-    mf_bpr_owned_kernel<2, REMOTE><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    mf_bpr_owned_kernel<2, REMOTE, GRAD><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
   else
-    mf_bpr_owned_kernel<4, REMOTE><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    mf_bpr_owned_kernel<4, REMOTE, GRAD><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
@@ -488,6 +517,7 @@ extern "C" int hiprec_mf_bpr_epoch_owned(float* w_flat, int64_t n_users, int64_t
                  "bad step range [%lld, %lld) of %lld", (long long)step_begin, (long long)step_end, (long long)n_steps);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t o_gb = (n_users + n_items) * (static_cast<int64_t>(dim) + 1);
+  if (step_begin == step_end && step_begin > 0) return 0;  // an empty range after the epoch's flush: nothing to do
   const int64_t k_end = step_end == n_steps ? n_steps + 1 : step_end;  // launch n_steps is the flush
   for (int64_t k = step_begin; k < k_end; ++k) {
     const int64_t off = k * batch;
@@ -519,8 +549,13 @@ extern "C" int hiprec_mf_bpr_epoch_owned(float* w_flat, int64_t n_users, int64_t
     f.item_stride = dim;
     f.bias_stride = 1;
     f.item_out = nullptr;
+    f.grad_out = nullptr;
+#ifdef HIPREC_OWNED_DEBUG
     static const int dbg = getenv("HIPREC_OWNED_DBG") ? atoi(getenv("HIPREC_OWNED_DBG")) : 0;
     f.dbg = dbg;
+#else
+    f.dbg = 0;
+#endif
     const float inv_b = b > 0 ? 1.0f / static_cast<float>(b) : 0.f;
     if (int rc = launch_owned<false>(f, f.n_gather_blocks + 1, st, users ? users + off : nullptr, pos ? pos + off : nullptr,
                               neg ? neg + off : nullptr, b, inv_b, reg_coef, stats,
@@ -537,19 +572,18 @@ extern "C" int hiprec_mf_bpr_epoch_owned(float* w_flat, int64_t n_users, int64_t
 // slots several triples reference: own_p / own_n >= 0 with total > 1) for the exchange back to their owners.  The
 // loss partials stay in `scratch` (hiprec_shard_publish_partials moves them into the exchange); the scalar bias is
 // read as it is (the previous step's hiprec_shard_finish_step updated it); the optimizer clock is not touched.
-extern "C" int hiprec_mf_bpr_owned_remote_step(float* w_flat, int64_t n_users, int64_t n_items_local, int32_t dim,
-                                               const float* fetched, float* g_send, int64_t n_slots,
-                                               const int64_t* users, const int64_t* pos_slot, const int64_t* neg_slot,
-                                               const int32_t* own_u, const int32_t* own_p, const int32_t* own_n,
-                                               const int32_t* total, int32_t* arrived, float* acc, int64_t batch,
-                                               float inv_batch, float reg_coef, double lr, hiprec_stats* stats,
-                                               void* scratch, void* stream) {
+static int owned_remote_impl(float* w_flat, float* g_flat, int64_t n_users, int64_t n_items_local, int32_t dim,
+                             const float* fetched, float* g_send, int64_t n_slots, const int64_t* users,
+                             const int64_t* pos_slot, const int64_t* neg_slot, const int32_t* own_u,
+                             const int32_t* own_p, const int32_t* own_n, const int32_t* total, int32_t* arrived,
+                             float* acc, int64_t batch, float inv_batch, float reg_coef, double lr, hiprec_stats* stats,
+                             void* scratch, void* stream) {
   HIPREC_REQUIRE(w_flat && stats && scratch, "NULL pointer");
   HIPREC_REQUIRE(n_users > 0 && n_items_local >= 0 && dim > 0 && dim <= 256, "bad shape");
   HIPREC_REQUIRE(batch >= 0 && n_slots >= 0, "negative batch / n_slots");
   if (batch == 0) return 0;
-  HIPREC_REQUIRE(fetched && g_send && users && pos_slot && neg_slot && own_u && own_p && own_n && total && arrived && acc,
-                 "NULL pointer");
+  HIPREC_REQUIRE(fetched && g_send && users && pos_slot && neg_slot && own_u && own_p && own_n && total, "NULL pointer");
+  HIPREC_REQUIRE(g_flat || (arrived && acc), "NULL pointer");
   OwnedStep f;
   f.w = w_flat;
   f.n_users = n_users;
@@ -575,6 +609,39 @@ extern "C" int hiprec_mf_bpr_owned_remote_step(float* w_flat, int64_t n_users, i
   f.o_ib = f.o_ie + dim;
   f.item_stride = f.bias_stride = dim + 1;
   f.item_out = g_send;
-  return launch_owned<true>(f, f.n_gather_blocks, static_cast<hipStream_t>(stream), users, pos_slot, neg_slot, batch,
-                            inv_batch, reg_coef, stats, static_cast<Scratch*>(scratch));
+  f.grad_out = g_flat;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (g_flat)
+    return launch_owned<true, true>(f, f.n_gather_blocks, st, users, pos_slot, neg_slot, batch, inv_batch, reg_coef,
+                                    stats, static_cast<Scratch*>(scratch));
+  return launch_owned<true>(f, f.n_gather_blocks, st, users, pos_slot, neg_slot, batch, inv_batch, reg_coef, stats,
+                            static_cast<Scratch*>(scratch));
+}
+
+extern "C" int hiprec_mf_bpr_owned_remote_step(float* w_flat, int64_t n_users, int64_t n_items_local, int32_t dim,
+                                               const float* fetched, float* g_send, int64_t n_slots,
+                                               const int64_t* users, const int64_t* pos_slot, const int64_t* neg_slot,
+                                               const int32_t* own_u, const int32_t* own_p, const int32_t* own_n,
+                                               const int32_t* total, int32_t* arrived, float* acc, int64_t batch,
+                                               float inv_batch, float reg_coef, double lr, hiprec_stats* stats,
+                                               void* scratch, void* stream) {
+  HIPREC_REQUIRE(batch == 0 || (arrived && acc), "NULL pointer");
+  return owned_remote_impl(w_flat, nullptr, n_users, n_items_local, dim, fetched, g_send, n_slots, users, pos_slot,
+                           neg_slot, own_u, own_p, own_n, total, arrived, acc, batch, inv_batch, reg_coef, lr, stats,
+                           scratch, stream);
+}
+
+// The same launch for the dense optimizers (Adam / RMSprop) of the row-sharded planned path: nothing is updated;
+// the gradients of the local user rows go into g_flat (dense, laid out like w_flat, zero on entry), those of the
+// fetched item slots into g_send as above.  own_* / total only say which rows have a single writer (plain stores).
+extern "C" int hiprec_mf_bpr_grad_remote_step(const float* w_flat, float* g_flat, int64_t n_users,
+                                              int64_t n_items_local, int32_t dim, const float* fetched, float* g_send,
+                                              int64_t n_slots, const int64_t* users, const int64_t* pos_slot,
+                                              const int64_t* neg_slot, const int32_t* own_u, const int32_t* own_p,
+                                              const int32_t* own_n, const int32_t* total, int64_t batch, float inv_batch,
+                                              float reg_coef, hiprec_stats* stats, void* scratch, void* stream) {
+  HIPREC_REQUIRE(g_flat, "NULL pointer");
+  return owned_remote_impl(const_cast<float*>(w_flat), g_flat, n_users, n_items_local, dim, fetched, g_send, n_slots,
+                           users, pos_slot, neg_slot, own_u, own_p, own_n, total, nullptr, nullptr, batch, inv_batch,
+                           reg_coef, 0.0, stats, scratch, stream);
 }

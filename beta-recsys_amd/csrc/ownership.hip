@@ -19,6 +19,7 @@ namespace hiprec {
 
 constexpr int kOwnPartBits = 14;              // 16 384 entries x (key + count) = 128 KB of LDS
 constexpr int kOwnThreads = 1024;
+constexpr int kOwnUnroll = 8;                // keys in flight per thread
 
 __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
   x ^= x >> 16;
@@ -48,10 +49,19 @@ __global__ __launch_bounds__(kBlock) void ownership_keys_kernel(const int64_t* _
   }
 }
 
+// tab_keys / pos_cnt / occ (all optional) serve the row-sharded engine's epoch planner (csrc/plan.hip): tab_keys =
+// the table itself (the row key that sits in every entry, -1 = empty); the user and positive-item occurrences are
+// inserted BEFORE the negative ones, so that an entry's count at that point -- pos_cnt -- is the number of POSITIVE
+// occurrences of an item row, and occ[at] (the entry's count when occurrence `at` arrived) is, for a positive
+// occurrence, its rank among them: the planner lays every batch out grouped by positive item from these two,
+// without a sort and without a second pass of atomics.
 __global__ __launch_bounds__(kOwnThreads) void ownership_kernel(const int32_t* __restrict__ keys, int64_t n,
                                                                 int64_t batch, int table_bits,
                                                                 int32_t* __restrict__ total,
-                                                                int32_t* __restrict__ own) {
+                                                                int32_t* __restrict__ own,
+                                                                int32_t* __restrict__ tab_keys,
+                                                                int32_t* __restrict__ pos_cnt,
+                                                                int32_t* __restrict__ occ) {
   extern __shared__ int32_t s_tab[];          // [part_size] keys, then [part_size] counts
   const int part_bits = table_bits < kOwnPartBits ? table_bits : kOwnPartBits;
   const uint32_t part_size = 1u << part_bits, part_mask = part_size - 1u;
@@ -67,29 +77,60 @@ __global__ __launch_bounds__(kOwnThreads) void ownership_kernel(const int32_t* _
   __syncthreads();
   const int64_t t0 = b * batch;
   const int64_t cnt = min<int64_t>(batch, n - t0);
-  for (int64_t i = threadIdx.x; i < 3 * cnt; i += kOwnThreads) {
-    const int role = static_cast<int>(i / cnt);
-    const int64_t at = role * n + t0 + (i - role * cnt);
-    const int32_t key = keys[at];
-    if (key < 0) {
-      if (part == 0) own[at] = -1;
-      continue;
+  const int64_t tab0 = (b << table_bits) + (static_cast<int64_t>(part) << part_bits);
+  // phase 0: user and positive rows ([0, 2 cnt)), phase 1: negative rows
+  for (int phase = 0; phase < 2; ++phase) {
+    const int64_t lo = phase == 0 ? 0 : 2 * cnt, hi = phase == 0 ? 2 * cnt : 3 * cnt;
+    // kOwnUnroll keys are requested together: with one 16-wave workgroup per CU (the LDS holds one table) a loop of
+    // single dependent loads is latency-bound (760 us per 50 x 65 536-triple epoch; the inserts themselves are few:
+    // one key in n_parts belongs to this partition)
+    for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += static_cast<int64_t>(kOwnThreads) * kOwnUnroll) {
+      int32_t key[kOwnUnroll];
+      int64_t at[kOwnUnroll];
+#pragma unroll
+      for (int j = 0; j < kOwnUnroll; ++j) {
+        const int64_t i = i0 + static_cast<int64_t>(j) * kOwnThreads;
+        const int role = i < cnt ? 0 : i < 2 * cnt ? 1 : 2;   // (no 64-bit division: it was most of this kernel's time)
+        at[j] = role * n + t0 + (i - role * cnt);
+        key[j] = i < hi ? keys[at[j]] : -2;
+      }
+#pragma unroll
+      for (int j = 0; j < kOwnUnroll; ++j) {
+        if (key[j] == -2) continue;
+        if (key[j] < 0) {
+          if (part == 0) own[at[j]] = -1;
+          continue;
+        }
+        // the partition is chosen by the hash's top bits, the position inside it by its low bits
+        const uint32_t x = hash_u32(static_cast<uint32_t>(key[j]));
+        if (n_parts > 1 && (x >> (32 - (table_bits - part_bits))) != part) continue;
+        uint32_t h = x & part_mask;
+        for (uint32_t probes = 0;; ++probes) {
+          const int32_t prev = atomicCAS(s_key + h, -1, key[j]);
+          if (prev == -1 || prev == key[j]) break;
+          h = (h + 1u) & part_mask;
+          if (probes > part_size) {  // a full partition (cannot happen at >= 4 x batch entries): give up, never spin
+            h = part_size;
+            break;
+          }
+        }
+        if (h == part_size) {
+          own[at[j]] = -1;
+          continue;
+        }
+        const int32_t before = atomicAdd(s_cnt + h, 1);
+        own[at[j]] = static_cast<int32_t>((part << part_bits) | h);
+        if (occ) occ[at[j]] = before;
+      }
     }
-    // the partition is chosen by the hash's top bits, the position inside it by its low bits
-    const uint32_t x = hash_u32(static_cast<uint32_t>(key));
-    if (n_parts > 1 && (x >> (32 - (table_bits - part_bits))) != part) continue;
-    uint32_t h = x & part_mask;
-    for (;;) {
-      const int32_t prev = atomicCAS(s_key + h, -1, key);
-      if (prev == -1 || prev == key) break;
-      h = (h + 1u) & part_mask;
-    }
-    atomicAdd(s_cnt + h, 1);
-    own[at] = static_cast<int32_t>((part << part_bits) | h);
+    __syncthreads();
+    if (phase == 0 && pos_cnt)
+      for (uint32_t i = threadIdx.x; i < part_size; i += kOwnThreads) pos_cnt[tab0 + i] = s_cnt[i];
   }
-  __syncthreads();
-  int32_t* out = total + (b << table_bits) + (static_cast<int64_t>(part) << part_bits);
-  for (uint32_t i = threadIdx.x; i < part_size; i += kOwnThreads) out[i] = s_cnt[i];
+  for (uint32_t i = threadIdx.x; i < part_size; i += kOwnThreads) {
+    total[tab0 + i] = s_cnt[i];
+    if (tab_keys) tab_keys[tab0 + i] = s_key[i];
+  }
 }
 
 }  // namespace hiprec
@@ -102,9 +143,9 @@ extern "C" int32_t hiprec_ownership_table_bits(int64_t batch) {
   return bits;
 }
 
-extern "C" int hiprec_batch_row_ownership(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
-                                          int64_t batch, int64_t n_users, int64_t n_items, int32_t table_bits,
-                                          int32_t* keys, int32_t* total, int32_t* own, void* stream) {
+static int ownership_impl(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n, int64_t batch,
+                          int64_t n_users, int64_t n_items, int32_t table_bits, int32_t* keys, int32_t* total,
+                          int32_t* own, int32_t* tab_keys, int32_t* pos_cnt, int32_t* occ, void* stream) {
   HIPREC_REQUIRE(n >= 0 && batch > 0 && n_users > 0 && n_items > 0, "bad sizes");
   HIPREC_REQUIRE(n_users + n_items < (1ll << 31), "row keys need n_users + n_items < 2^31");
   HIPREC_REQUIRE(table_bits >= 2 && table_bits <= 30 && (1ll << table_bits) >= 4 * std::min<int64_t>(batch, n > 0 ? n : 1),
@@ -118,13 +159,38 @@ extern "C" int hiprec_batch_row_ownership(const int64_t* users, const int64_t* p
   const size_t lds = sizeof(int32_t) * 2 * (static_cast<size_t>(1) << part_bits);
   static bool attr_set = false;
   if (!attr_set) {  // 128 KB of dynamic LDS (gfx950 has 160 KB per workgroup)
+    int dev = 0, lds_max = 0;
+    HIPREC_TRY(hipGetDevice(&dev));
+    HIPREC_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+    if (static_cast<size_t>(lds_max) < (2 * sizeof(int32_t) << kOwnPartBits)) {
+      set_error("the ownership tables need %zu bytes of LDS per workgroup, this device offers %d (gfx950: 160 KB)",
+                2 * sizeof(int32_t) << kOwnPartBits, lds_max);
+      return HIPREC_E_UNSUPPORTED;
+    }
     HIPREC_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ownership_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sizeof(int32_t) << kOwnPartBits));
     attr_set = true;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   ownership_keys_kernel<<<grid_for_threads(n), kBlock, 0, st>>>(users, pos, neg, n, n_users, n_items, keys);
-  ownership_kernel<<<static_cast<int>(grid), kOwnThreads, lds, st>>>(keys, n, batch, table_bits, total, own);
+  ownership_kernel<<<static_cast<int>(grid), kOwnThreads, lds, st>>>(keys, n, batch, table_bits, total, own, tab_keys,
+                                                                     pos_cnt, occ);
   HIPREC_TRY(hipGetLastError());
   return 0;
+}
+
+extern "C" int hiprec_batch_row_ownership(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
+                                          int64_t batch, int64_t n_users, int64_t n_items, int32_t table_bits,
+                                          int32_t* keys, int32_t* total, int32_t* own, void* stream) {
+  return ownership_impl(users, pos, neg, n, batch, n_users, n_items, table_bits, keys, total, own, nullptr, nullptr,
+                        nullptr, stream);
+}
+
+extern "C" int hiprec_batch_row_ownership_tables(const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                                 int64_t n, int64_t batch, int64_t n_users, int64_t n_items,
+                                                 int32_t table_bits, int32_t* keys, int32_t* total, int32_t* own,
+                                                 int32_t* tab_keys, int32_t* pos_cnt, int32_t* occ, void* stream) {
+  HIPREC_REQUIRE(tab_keys && pos_cnt && occ, "NULL pointer");
+  return ownership_impl(users, pos, neg, n, batch, n_users, n_items, table_bits, keys, total, own, tab_keys, pos_cnt,
+                        occ, stream);
 }

@@ -10,6 +10,8 @@
 //
 // Bucketing is the ballot scheme of route_bucket_kernel (util.hip): one atomic per (wave,
 // destination).  A full bucket sets HIPREC_STATUS_ROUTE_OVERFLOW and drops the entry (slot -1).
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace hiprec {
@@ -150,6 +152,7 @@ __global__ __launch_bounds__(kBlock) void shard_join_kernel(const float* __restr
 __global__ __launch_bounds__(kBlock) void shard_publish_partials_kernel(const Scratch* __restrict__ scratch,
                                                                         float* __restrict__ g_send, int ld,
                                                                         const int64_t* __restrict__ extra_rows,
+                                                                        const int32_t* __restrict__ extra_rows32,
                                                                         int n_dest) {
   __shared__ double s_l[kBlock], s_r[kBlock], s_b[kBlock];
   const uint32_t n = scratch->n_partials;
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void shard_publish_partials_kernel(const Sc
     __syncthreads();
   }
   if (static_cast<int>(threadIdx.x) < n_dest) {
-    float* row = g_send + extra_rows[threadIdx.x] * ld;
+    float* row = g_send + (extra_rows ? extra_rows[threadIdx.x] : extra_rows32[threadIdx.x]) * ld;
     row[0] = static_cast<float>(s_l[0]);
     row[1] = static_cast<float>(s_r[0]);
     row[2] = static_cast<float>(s_b[0]);
@@ -230,6 +233,99 @@ __global__ void shard_finish_step_kernel(const float* __restrict__ g_recv, int l
   advance_step(stats);
 }
 
+
+// ---- the planned step, fused (round 3): two launches around the gradient kernel instead of five --------------------
+// Row k of a step's incoming block: rows [self_lo, self_hi) are the ones this rank asked of ITSELF -- they never
+// travel: the payload goes straight into the fetched buffer, the gradient is read straight from the send buffer.
+__device__ __forceinline__ float* seg_row(float* other, float* self_base, int64_t k, int64_t self_lo, int64_t self_hi,
+                                          int ld) {
+  return (k >= self_lo && k < self_hi) ? self_base + (k - self_lo) * ld : other + k * ld;
+}
+
+// payload[k] = [item_emb[idx[k]] | item_bias[idx[k]]] (zeros for idx -1: the extra rows) for the rows peers asked
+// for, AND -- in the blocks behind the row blocks -- the clear of the gradient exchange buffer g_send.
+__global__ __launch_bounds__(kBlock) void shard_payload_zero_kernel(
+    const float* __restrict__ item_emb, const float* __restrict__ item_bias, int64_t n_rows, int dim,
+    const int32_t* __restrict__ idx, int64_t n, int64_t self_lo, int64_t self_hi, float* __restrict__ payload,
+    float* __restrict__ self_dst, float* __restrict__ zero, int64_t zero_floats, int n_row_blocks,
+    hiprec_stats* stats) {
+  if (static_cast<int>(blockIdx.x) >= n_row_blocks) {
+    const int64_t nb = gridDim.x - n_row_blocks;
+    const int64_t tid = static_cast<int64_t>(blockIdx.x - n_row_blocks) * kBlock + threadIdx.x;
+    float4* z4 = reinterpret_cast<float4*>(zero);
+    const int64_t n4 = zero_floats >> 2;
+    for (int64_t i = tid; i < n4; i += nb * kBlock) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (n4 << 2) + tid; i < zero_floats; i += nb * kBlock) zero[i] = 0.f;
+    return;
+  }
+  const int lane = lane_id();
+  const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
+  const int64_t n_waves = static_cast<int64_t>(n_row_blocks) * kWavesPerBlock;
+  const int ld = dim + 1;
+  for (int64_t k = wave0; k < n; k += n_waves) {
+    int64_t r = idx[k];
+    if (r >= n_rows) {
+      if (lane == 0) atomicOr(&stats->status, HIPREC_STATUS_ROW_OOB);
+      r = -1;
+    }
+    float* out = seg_row(payload, self_dst, k, self_lo, self_hi, ld);
+    for (int c = lane; c < ld; c += kWave) {
+      float v = 0.f;
+      if (r >= 0) v = c < dim ? item_emb[r * dim + c] : item_bias[r];
+      out[c] = v;
+    }
+  }
+}
+
+// After the gradient exchange, ONE launch: target row idx[k] (+ its bias) += coef * g_recv[k] with fp32 atomics
+// (several peers may return gradients of one item) -- plain SGD: target = the item table, coef = -lr, which IS the
+// item-side optimizer step; Adam / RMSprop: target = the dense gradient, coef = 1 -- and, in the last block, the
+// step's bookkeeping: the peers' extra rows (loss, reg, d loss / d scalar bias) summed in rank order ->
+// hiprec_stats, *scalar_target += scalar_coef * (its gradient), t <- t + 1.
+__global__ __launch_bounds__(kBlock) void shard_apply_finish_kernel(
+    float* __restrict__ t_emb, float* __restrict__ t_bias, int64_t n_rows, int dim, const int32_t* __restrict__ idx,
+    const float* __restrict__ g_recv, int64_t n, int64_t self_lo, int64_t self_hi, const float* __restrict__ g_self,
+    float coef, const int32_t* __restrict__ extra_pos, int n_src, float* scalar_target, float scalar_coef,
+    int first_of_epoch, int n_row_blocks, hiprec_stats* stats) {
+  const int ld = dim + 1;
+  if (static_cast<int>(blockIdx.x) >= n_row_blocks) {
+    if (threadIdx.x != 0) return;
+    float l = 0.f, r = 0.f, b = 0.f;
+    for (int q = 0; q < n_src; ++q) {
+      const float* row = seg_row(const_cast<float*>(g_recv), const_cast<float*>(g_self), extra_pos[q], self_lo,
+                                 self_hi, ld);
+      l += row[0];
+      r += row[1];
+      b += row[2];
+    }
+    if (first_of_epoch) {
+      stats->loss_sum = 0.0;
+      stats->reg_sum = 0.0;
+    }
+    stats->loss = l;
+    stats->reg = r;
+    stats->loss_sum += static_cast<double>(l);
+    stats->reg_sum += static_cast<double>(r);
+    *scalar_target = *scalar_target + scalar_coef * b;
+    advance_step(stats);
+    return;
+  }
+  const int lane = lane_id();
+  const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
+  const int64_t n_waves = static_cast<int64_t>(n_row_blocks) * kWavesPerBlock;
+  for (int64_t k = wave0; k < n; k += n_waves) {
+    const int64_t r = idx[k];
+    if (r < 0) continue;
+    if (r >= n_rows) {
+      if (lane == 0) atomicOr(&stats->status, HIPREC_STATUS_ROW_OOB);
+      continue;
+    }
+    const float* g = seg_row(const_cast<float*>(g_recv), const_cast<float*>(g_self), k, self_lo, self_hi, ld);
+    for (int c = lane; c < dim; c += kWave) atomic_add_f32(t_emb + r * dim + c, coef * g[c]);
+    if (lane == 0) atomic_add_f32(t_bias + r, coef * g[dim]);
+  }
+}
+
 }  // namespace
 }  // namespace hiprec
 
@@ -237,9 +333,10 @@ using namespace hiprec;
 
 extern "C" int hiprec_shard_publish_partials(const void* scratch, float* g_send, int32_t dim,
                                              const int64_t* extra_rows, int32_t n_dest, void* stream) {
-  HIPREC_REQUIRE(scratch && g_send && extra_rows && dim > 0 && n_dest > 0 && n_dest <= kBlock, "bad arguments");
+  HIPREC_REQUIRE(scratch && g_send && extra_rows && n_dest > 0 && n_dest <= kBlock, "bad arguments");
+  HIPREC_REQUIRE(dim >= 2, "an extra row carries 3 floats: the planned sharded step needs emb_dim >= 2");
   shard_publish_partials_kernel<<<1, kBlock, 0, static_cast<hipStream_t>(stream)>>>(
-      static_cast<const Scratch*>(scratch), g_send, dim + 1, extra_rows, n_dest);
+      static_cast<const Scratch*>(scratch), g_send, dim + 1, extra_rows, nullptr, n_dest);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
@@ -259,7 +356,8 @@ extern "C" int hiprec_shard_apply_rows(float* item_emb, float* item_bias, int64_
 extern "C" int hiprec_shard_finish_step(const float* g_recv, int32_t dim, const int64_t* extra_rows, int32_t n_src,
                                         float* global_bias, double lr, int32_t first_of_epoch, hiprec_stats* stats,
                                         void* stream) {
-  HIPREC_REQUIRE(g_recv && extra_rows && global_bias && stats && dim > 0 && n_src > 0, "bad arguments");
+  HIPREC_REQUIRE(g_recv && extra_rows && global_bias && stats && n_src > 0, "bad arguments");
+  HIPREC_REQUIRE(dim >= 2, "an extra row carries 3 floats: the planned sharded step needs emb_dim >= 2");
   shard_finish_step_kernel<<<1, 1, 0, static_cast<hipStream_t>(stream)>>>(g_recv, dim + 1, extra_rows, n_src,
                                                                        global_bias, static_cast<float>(lr),
                                                                        first_of_epoch, stats);
@@ -329,6 +427,179 @@ extern "C" int hiprec_shard_join_rows(const float* emb, const float* bias, int64
   HIPREC_REQUIRE(emb && bias && dst, "NULL pointer");
   shard_join_kernel<<<grid_for_threads(n * (dim + 1)), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
       emb, bias, n, dim, dst);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---- the planned step through the fused launches, and a whole range of steps enqueued from C -----------------------
+extern "C" int hiprec_shard_payload_zero(const float* item_emb, const float* item_bias, int64_t n_rows, int32_t dim,
+                                         const int32_t* idx, int64_t n, int64_t self_lo, int64_t self_hi,
+                                         float* payload, float* self_dst, float* zero, int64_t zero_floats,
+                                         hiprec_stats* stats, void* stream) {
+  HIPREC_REQUIRE(n >= 0 && n_rows >= 0 && dim > 0 && zero_floats >= 0 && self_lo >= 0 && self_lo <= self_hi, "bad sizes");
+  HIPREC_REQUIRE(stats && (n == 0 || (idx && payload)) && (zero_floats == 0 || zero) && (self_lo == self_hi || self_dst),
+                 "NULL pointer");
+  HIPREC_REQUIRE(n == 0 || n_rows == 0 || (item_emb && item_bias), "NULL pointer");
+  if (n == 0 && zero_floats == 0) return 0;
+  const int rb = n > 0 ? grid_for_waves(n) : 0;
+  const int zb = zero_floats > 0 ? grid_for_threads((zero_floats + 15) / 16) : 0;   // 4 x float4 per thread
+  shard_payload_zero_kernel<<<rb + zb, kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      item_emb, item_bias, n_rows, dim, idx, n, self_lo, self_hi, payload, self_dst, zero, zero_floats, rb, stats);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_shard_apply_finish(float* t_emb, float* t_bias, int64_t n_rows, int32_t dim, const int32_t* idx,
+                                         const float* g_recv, int64_t n, int64_t self_lo, int64_t self_hi,
+                                         const float* g_self, double coef, const int32_t* extra_pos, int32_t n_src,
+                                         float* scalar_target, double scalar_coef, int32_t first_of_epoch,
+                                         hiprec_stats* stats, void* stream) {
+  HIPREC_REQUIRE(n >= 0 && n_rows >= 0 && n_src > 0 && self_lo >= 0 && self_lo <= self_hi, "bad sizes");
+  HIPREC_REQUIRE(dim >= 2, "an extra row carries 3 floats: the planned sharded step needs emb_dim >= 2");
+  HIPREC_REQUIRE(stats && extra_pos && scalar_target && idx && g_recv && (self_lo == self_hi || g_self), "NULL pointer");
+  HIPREC_REQUIRE(n_rows == 0 || (t_emb && t_bias), "NULL pointer");
+  const int rb = n > 0 ? grid_for_waves(n) : 0;
+  shard_apply_finish_kernel<<<rb + 1, kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      t_emb, t_bias, n_rows, dim, idx, g_recv, n, self_lo, self_hi, g_self, static_cast<float>(coef), extra_pos, n_src,
+      scalar_target, static_cast<float>(scalar_coef), first_of_epoch, rb, stats);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+// RCCL entry points as the caller hands them over (beta-recsys_amd/_rccl.py binds the librccl PyTorch loaded; this
+// library does not link it): ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd.
+using nccl_send_fn = int (*)(const void*, size_t, int, int, void*, hipStream_t);
+using nccl_recv_fn = int (*)(void*, size_t, int, int, void*, hipStream_t);
+using nccl_group_fn = int (*)();
+constexpr int kNcclFloat32 = 7;  // ncclDataType_t (nccl.h / rccl.h)
+
+extern "C" int hiprec_mf_bpr_owned_remote_step(float*, int64_t, int64_t, int32_t, const float*, float*, int64_t,
+                                               const int64_t*, const int64_t*, const int64_t*, const int32_t*,
+                                               const int32_t*, const int32_t*, const int32_t*, int32_t*, float*,
+                                               int64_t, float, float, double, hiprec_stats*, void*, void*);
+extern "C" int hiprec_mf_bpr_grad_remote_step(const float*, float*, int64_t, int64_t, int32_t, const float*, float*,
+                                              int64_t, const int64_t*, const int64_t*, const int64_t*, const int32_t*,
+                                              const int32_t*, const int32_t*, const int32_t*, int64_t, float, float,
+                                              hiprec_stats*, void*, void*);
+
+extern "C" size_t hiprec_shard_plan_bytes(void) { return sizeof(hiprec_shard_plan); }
+extern "C" size_t hiprec_shard_bufs_bytes(void) { return sizeof(hiprec_shard_bufs); }
+
+extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const hiprec_shard_bufs* bufs,
+                                          int64_t step_begin, int64_t step_end, int32_t kind, float reg_coef,
+                                          double lr, double beta1, double beta2, double eps,
+                                          const hiprec_nccl_fns* nccl, void* comm, hiprec_stats* stats, void* stream) {
+  HIPREC_REQUIRE(plan && bufs && stats, "NULL pointer");
+  const int R = plan->world, me = plan->rank;
+  HIPREC_REQUIRE(R >= 1 && R <= 64 && me >= 0 && me < R, "bad world / rank");
+  HIPREC_REQUIRE(R == 1 || (nccl && comm && nccl->send && nccl->recv && nccl->group_start && nccl->group_end),
+                 "a world of %d ranks needs the RCCL entry points and a communicator", R);
+  HIPREC_REQUIRE(0 <= step_begin && step_begin <= step_end && step_end <= plan->n_steps, "bad step range");
+  HIPREC_REQUIRE(plan->users && plan->pos_slot && plan->neg_slot && plan->own && plan->total && plan->in_idx &&
+                     plan->ex_req && plan->ex_in && plan->in_off_host && plan->n_slots_host && plan->req_cnt_host &&
+                     plan->in_cnt_host,
+                 "incomplete plan");
+  HIPREC_REQUIRE(bufs->w_flat && bufs->payload && bufs->g_recv && bufs->fetched && bufs->g_send && bufs->scratch,
+                 "incomplete step buffers");
+  const bool dense = kind != HIPREC_OPT_SGD;
+  HIPREC_REQUIRE(kind == HIPREC_OPT_SGD || kind == HIPREC_OPT_ADAM || kind == HIPREC_OPT_RMSPROP, "unknown optimizer");
+  HIPREC_REQUIRE(dense ? (bufs->g_flat != nullptr) : (bufs->arrived && bufs->acc), "incomplete step buffers");
+  const int D = bufs->dim, ld = D + 1;
+  HIPREC_REQUIRE(D >= 2 && D <= 256, "the planned sharded step needs 2 <= emb_dim <= 256");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t nu = bufs->n_users_local, ni = bufs->n_items_local, cap = plan->cap, tot = plan->n_steps * cap;
+  float* w = bufs->w_flat;
+  float* item_emb = w + nu * D;
+  float* item_bias = w + (nu + ni) * D + nu;
+  float* gbias = w + (nu + ni) * static_cast<int64_t>(ld);
+  float* g = bufs->g_flat;
+  const int64_t n_flat = (nu + ni) * static_cast<int64_t>(ld) + 1;
+  const auto send = nccl ? reinterpret_cast<nccl_send_fn>(nccl->send) : nullptr;
+  const auto recv = nccl ? reinterpret_cast<nccl_recv_fn>(nccl->recv) : nullptr;
+  const auto g_start = nccl ? reinterpret_cast<nccl_group_fn>(nccl->group_start) : nullptr;
+  const auto g_end = nccl ? reinterpret_cast<nccl_group_fn>(nccl->group_end) : nullptr;
+  for (int64_t s = step_begin; s < step_end; ++s) {
+    const int64_t* req = plan->req_cnt_host + s * R;
+    const int64_t* inc = plan->in_cnt_host + s * R;
+    const int64_t il = plan->in_off_host[s + 1] - plan->in_off_host[s], sl = plan->n_slots_host[s];
+    const int32_t* idx = plan->in_idx + plan->in_off_host[s];
+    int64_t in_lo = 0, req_lo = 0;   // this rank's own segment in the incoming / the fetched block
+    for (int q = 0; q < me; ++q) {
+      in_lo += inc[q] + 1;
+      req_lo += req[q] + 1;
+    }
+    HIPREC_REQUIRE(inc[me] == req[me], "inconsistent plan: a rank asks itself for %lld rows and expects %lld",
+                   (long long)req[me], (long long)inc[me]);
+    const int64_t in_hi = in_lo + inc[me] + 1;
+    float* self_fetched = bufs->fetched + req_lo * ld;
+    float* self_g = bufs->g_send + req_lo * ld;
+    if (int rc = hiprec_shard_payload_zero(item_emb, item_bias, ni, D, idx, il, in_lo, in_hi, bufs->payload,
+                                           self_fetched, bufs->g_send, sl * ld, stats, stream))
+      return rc;
+    if (R > 1) {
+      if (g_start()) return HIPREC_E_UNSUPPORTED;
+      int64_t io = 0, ro = 0;
+      for (int q = 0; q < R; ++q) {
+        if (q != me) {
+          if (send(bufs->payload + io * ld, static_cast<size_t>((inc[q] + 1) * ld), kNcclFloat32, q, comm, st) ||
+              recv(bufs->fetched + ro * ld, static_cast<size_t>((req[q] + 1) * ld), kNcclFloat32, q, comm, st)) {
+            g_end();
+            set_error("ncclSend / ncclRecv failed in the row exchange of step %lld", (long long)s);
+            return HIPREC_E_UNSUPPORTED;
+          }
+        }
+        io += inc[q] + 1;
+        ro += req[q] + 1;
+      }
+      if (g_end()) return HIPREC_E_UNSUPPORTED;
+    }
+    const int64_t off = s * cap;
+    const int64_t b_local = std::min<int64_t>(plan->local_batch, plan->n_local - s * plan->local_batch);
+    const float inv_b = 1.0f / static_cast<float>(static_cast<int64_t>(R) * b_local);
+    int rc;
+    if (dense)
+      rc = hiprec_mf_bpr_grad_remote_step(w, g, nu, ni, D, bufs->fetched, bufs->g_send, sl, plan->users + off,
+                                          plan->pos_slot + off, plan->neg_slot + off, plan->own + off,
+                                          plan->own + tot + off, plan->own + 2 * tot + off,
+                                          plan->total + s * plan->total_stride, cap, inv_b, reg_coef, stats,
+                                          bufs->scratch, stream);
+    else
+      rc = hiprec_mf_bpr_owned_remote_step(w, nu, ni, D, bufs->fetched, bufs->g_send, sl, plan->users + off,
+                                           plan->pos_slot + off, plan->neg_slot + off, plan->own + off,
+                                           plan->own + tot + off, plan->own + 2 * tot + off,
+                                           plan->total + s * plan->total_stride, bufs->arrived, bufs->acc, cap, inv_b,
+                                           reg_coef, lr, stats, bufs->scratch, stream);
+    if (rc) return rc;
+    shard_publish_partials_kernel<<<1, kBlock, 0, st>>>(static_cast<const Scratch*>(bufs->scratch), bufs->g_send, ld,
+                                                        nullptr, plan->ex_req + s * R, R);
+    if (R > 1) {
+      if (g_start()) return HIPREC_E_UNSUPPORTED;
+      int64_t io = 0, ro = 0;
+      for (int q = 0; q < R; ++q) {
+        if (q != me) {
+          if (send(bufs->g_send + ro * ld, static_cast<size_t>((req[q] + 1) * ld), kNcclFloat32, q, comm, st) ||
+              recv(bufs->g_recv + io * ld, static_cast<size_t>((inc[q] + 1) * ld), kNcclFloat32, q, comm, st)) {
+            g_end();
+            set_error("ncclSend / ncclRecv failed in the gradient exchange of step %lld", (long long)s);
+            return HIPREC_E_UNSUPPORTED;
+          }
+        }
+        io += inc[q] + 1;
+        ro += req[q] + 1;
+      }
+      if (g_end()) return HIPREC_E_UNSUPPORTED;
+    }
+    float* t_emb = dense ? g + nu * D : item_emb;
+    float* t_bias = dense ? g + (nu + ni) * D + nu : item_bias;
+    float* scalar = dense ? g + (nu + ni) * static_cast<int64_t>(ld) : gbias;
+    if ((rc = hiprec_shard_apply_finish(t_emb, t_bias, ni, D, idx, bufs->g_recv, il, in_lo, in_hi, self_g,
+                                        dense ? 1.0 : -lr, plan->ex_in + s * R, R, scalar, dense ? 1.0 : -lr,
+                                        s == 0 ? 1 : 0, stats, stream)))
+      return rc;
+    if (dense && (rc = hiprec_opt_dense_step(kind, w, g, bufs->m_flat, bufs->v_flat, n_flat, lr, beta1, beta2, eps,
+                                             stats, nullptr, -1, stream)))
+      return rc;
+  }
   HIPREC_TRY(hipGetLastError());
   return 0;
 }

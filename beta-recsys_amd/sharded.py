@@ -162,12 +162,74 @@ class HipKernels:
             ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(items), None, None, n, lr,
             _lib.ptr(user_stamp), _lib.ptr(item_stamp), stamp, _lib.ptr(self.stats), None, self._st()))
 
-    # ---- the epoch-planned SGD step (csrc/mf_owned.hip REMOTE variant + csrc/shard.hip) ---------------------------
-    def payload_rows(self, item_emb, item_bias, local_idx, payload):
-        """payload[k] = [item_emb row | item_bias] of LOCAL row local_idx[k] (zeros for -1)."""
-        if getattr(self, "_idx_scratch", None) is None or self._idx_scratch.numel() < local_idx.numel():
-            self._idx_scratch = torch.empty(max(local_idx.numel(), 1), dtype=torch.int64, device=self.device)
-        self.gather_payload(item_emb, item_bias, local_idx, 1, payload, self._idx_scratch)
+    # ---- the epoch planner (csrc/plan.hip) and the planned step (csrc/mf_owned.hip REMOTE variants, csrc/shard.hip) ----
+    def _i32(self, *shape):
+        return torch.empty(shape, dtype=torch.int32, device=self.device)
+
+    def plan_route(self, users, pos, neg, perm, bs, world, n_users, n_items):
+        """-> (send int32 [n, 3]: (user // world, pos, neg), (destination, step)-ordered; cnt_ds int32 [world, S])."""
+        n = users.numel()
+        S = max((n + bs - 1) // bs, 1)
+        tiles = self.lib.hiprec_plan_route_tiles(n, bs)
+        ws, cnt_ds, send = self._i32(max(world * tiles, 1)), self._i32(world, S), self._i32(max(n, 1), 3)
+        _lib.check(self.lib.hiprec_plan_route_triples(
+            _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), _lib.ptr(perm) if perm is not None else None, n, bs, world,
+            n_users, n_items, _lib.ptr(ws), _lib.ptr(cnt_ds), _lib.ptr(send), _lib.ptr(self.stats), self._st()))
+        return send[:n], cnt_ds
+
+    def plan_status(self):
+        """The status word of the device stats as a 1-element int64 tensor (rides in the plan's host read)."""
+        off = _lib.Stats.status.offset
+        return self.stats[off:off + 4].view(torch.int32).to(torch.int64)
+
+    def plan_place_triples(self, recv, recv_cnt, S, cap):
+        R = recv_cnt.shape[0]
+        U, P, N = (torch.empty(S * cap, dtype=torch.int64, device=self.device) for _ in range(3))
+        ws = self._i32(2 * R * S + 1)
+        _lib.check(self.lib.hiprec_plan_place_triples(
+            _lib.ptr(recv), recv.shape[0], _lib.ptr(recv_cnt), R, S, cap, _lib.ptr(ws), _lib.ptr(U), _lib.ptr(P),
+            _lib.ptr(N), self._st()))
+        return U, P, N
+
+    def plan_item_slots(self, U, P, N, S, cap, world, n_users_local, n_items):
+        """Ownership tables of the step blocks + slots of the exchange buffers + the blocks grouped by positive item."""
+        lib, tot = self.lib, S * cap
+        bits = lib.hiprec_ownership_table_bits(cap)
+        T = 1 << bits
+        keys, own, occ = self._i32(3 * tot), self._i32(3, tot), self._i32(3 * tot)
+        total, tab_keys, pos_cnt, slot_of = (self._i32(S, T) for _ in range(4))
+        _lib.check(lib.hiprec_batch_row_ownership_tables(
+            _lib.ptr(U), _lib.ptr(P), _lib.ptr(N), tot, cap, max(n_users_local, 1), n_items, bits, _lib.ptr(keys),
+            _lib.ptr(total), _lib.ptr(own), _lib.ptr(tab_keys), _lib.ptr(pos_cnt), _lib.ptr(occ), self._st()))
+        ws = self._i32(lib.hiprec_plan_slot_ws_ints(S, bits, world))
+        req_cnt, req_ds, ex_req = self._i32(S, world), self._i32(world, S), self._i32(S, world)
+        n_slots, send_base = self._i32(S), self._i32(world * S + 1)
+        # at most 2 distinct items per live triple
+        req_send = self._i32(2 * tot)
+        U2, SP, SN = (torch.empty(tot, dtype=torch.int64, device=self.device) for _ in range(3))
+        own2 = self._i32(3, tot)
+        _lib.check(lib.hiprec_plan_item_slots(
+            _lib.ptr(U), S, cap, world, max(n_users_local, 1), bits, _lib.ptr(own), _lib.ptr(occ), _lib.ptr(tab_keys),
+            _lib.ptr(pos_cnt), _lib.ptr(ws), _lib.ptr(slot_of), _lib.ptr(req_cnt), _lib.ptr(req_ds), _lib.ptr(ex_req),
+            _lib.ptr(n_slots), _lib.ptr(send_base), _lib.ptr(req_send), _lib.ptr(U2), _lib.ptr(SP), _lib.ptr(SN),
+            _lib.ptr(own2), self._st()))
+        return {"U": U2, "SP": SP, "SN": SN, "own": own2, "total": total, "stride": T, "req_cnt": req_cnt,
+                "req_ds": req_ds, "ex_req": ex_req, "req_send": req_send}
+
+    def plan_place_requests(self, incoming, in_qs, S):
+        R, n_in = in_qs.shape[0], incoming.numel()
+        ws, in_idx = self._i32(2 * R * S + 1), self._i32(n_in + R * S)
+        step_off, ex_in = self._i32(S + 1), self._i32(S, R)
+        _lib.check(self.lib.hiprec_plan_place_requests(
+            _lib.ptr(incoming), n_in, _lib.ptr(in_qs), R, S, _lib.ptr(ws), _lib.ptr(in_idx), _lib.ptr(step_off),
+            _lib.ptr(ex_in), self._st()))
+        return in_idx, ex_in
+
+    def payload_zero(self, item_emb, item_bias, idx, payload, g_send):
+        """payload[k] = [item_emb row | item_bias] of LOCAL row idx[k] (zeros for -1); g_send = 0."""
+        _lib.check(self.lib.hiprec_shard_payload_zero(
+            _lib.ptr(item_emb), _lib.ptr(item_bias), item_emb.shape[0], item_emb.shape[1], _lib.ptr(idx), idx.numel(),
+            0, 0, _lib.ptr(payload), None, _lib.ptr(g_send), g_send.numel(), _lib.ptr(self.stats), self._st()))
 
     def owned_remote_step(self, model, fetched, g_send, n_slots, users, slot_pos, slot_neg, own, total, arrived, acc,
                           inv_batch, reg_coef, lr):
@@ -177,19 +239,58 @@ class HipKernels:
             _lib.ptr(own[2]), _lib.ptr(total), _lib.ptr(arrived), _lib.ptr(acc), users.numel(), inv_batch, reg_coef,
             lr, _lib.ptr(self.stats), _lib.ptr(self.scratch), self._st()))
 
+    def grad_remote_step(self, model, g_flat, fetched, g_send, n_slots, users, slot_pos, slot_neg, own, total,
+                         inv_batch, reg_coef):
+        """The dense optimizers' form: user-row gradients into g_flat, item-slot gradients into g_send."""
+        _lib.check(self.lib.hiprec_mf_bpr_grad_remote_step(
+            _lib.ptr(model.flat), _lib.ptr(g_flat), model.n_users, model.n_items, model.emb_dim, _lib.ptr(fetched),
+            _lib.ptr(g_send), n_slots, _lib.ptr(users), _lib.ptr(slot_pos), _lib.ptr(slot_neg), _lib.ptr(own[0]),
+            _lib.ptr(own[1]), _lib.ptr(own[2]), _lib.ptr(total), users.numel(), inv_batch, reg_coef,
+            _lib.ptr(self.stats), _lib.ptr(self.scratch), self._st()))
+
     def publish_partials(self, g_send, dim, extra_rows):
         _lib.check(self.lib.hiprec_shard_publish_partials(_lib.ptr(self.scratch), _lib.ptr(g_send), dim,
-                                                          _lib.ptr(extra_rows), extra_rows.numel(), self._st()))
+                                                          _lib.ptr(extra_rows.to(torch.int64)), extra_rows.numel(),
+                                                          self._st()))
 
-    def apply_rows(self, item_emb, item_bias, local_idx, g_recv, lr):
-        _lib.check(self.lib.hiprec_shard_apply_rows(
-            _lib.ptr(item_emb), _lib.ptr(item_bias), item_emb.shape[0], item_emb.shape[1], _lib.ptr(local_idx),
-            _lib.ptr(g_recv), local_idx.numel(), lr, _lib.ptr(self.stats), self._st()))
-
-    def finish_step(self, g_recv, dim, extra_rows, global_bias, lr, first_of_epoch):
-        _lib.check(self.lib.hiprec_shard_finish_step(
-            _lib.ptr(g_recv), dim, _lib.ptr(extra_rows), extra_rows.numel(), _lib.ptr(global_bias), lr,
+    def apply_finish(self, t_emb, t_bias, idx, g_recv, coef, extra_pos, scalar_target, scalar_coef, first_of_epoch):
+        """target row idx[k] += coef * g_recv[k]; the peers' extra rows -> stats, scalar += scalar_coef * its gradient."""
+        _lib.check(self.lib.hiprec_shard_apply_finish(
+            _lib.ptr(t_emb), _lib.ptr(t_bias), t_emb.shape[0], t_emb.shape[1], _lib.ptr(idx), _lib.ptr(g_recv),
+            idx.numel(), 0, 0, None, coef, _lib.ptr(extra_pos), extra_pos.numel(), _lib.ptr(scalar_target), scalar_coef,
             1 if first_of_epoch else 0, _lib.ptr(self.stats), self._st()))
+
+    def planned_steps(self, plan, bufs, model, g_flat, opt, a, b, reg, comm):
+        """Steps [a, b) of a planned epoch -- kernels AND exchanges -- enqueued by ONE C call
+        (hiprec_shard_planned_steps); comm: an _rccl.Communicator (None at world size 1)."""
+        c = plan.get("_c")
+        if c is None:   # the structs and the host arrays they point at live as long as the plan
+            import numpy as np
+
+            host = {k: np.ascontiguousarray(plan[k], dtype=np.int64) for k in ("in_off_h", "n_slots_h", "req_cnt_h",
+                                                                                "in_cnt_h")}
+            sp = _lib.ShardPlan(
+                plan["world"], plan["rank"], plan["S"], plan["cap"], plan["bs"], plan["n"], plan["U"].data_ptr(),
+                plan["SP"].data_ptr(), plan["SN"].data_ptr(), plan["own"].data_ptr(), plan["total"].data_ptr(),
+                plan["stride"], plan["in_idx"].data_ptr(), plan["ex_req"].data_ptr(), plan["ex_in"].data_ptr(),
+                host["in_off_h"].ctypes.data, host["n_slots_h"].ctypes.data, host["req_cnt_h"].ctypes.data,
+                host["in_cnt_h"].ctypes.data)
+            c = plan["_c"] = (sp, host)
+        dense = opt.name != "sgd"
+        sb = _lib.ShardBufs(
+            model.flat.data_ptr(), model.n_users, model.n_items, model.emb_dim, 0, bufs["payload"].data_ptr(),
+            bufs["g_recv"].data_ptr(), bufs["fetched"].data_ptr(), bufs["g_send"].data_ptr(),
+            bufs["arrived"].data_ptr(), bufs["acc"].data_ptr(), self.scratch.data_ptr(),
+            g_flat.data_ptr() if dense else None,
+            opt.exp_avg.data_ptr() if opt.exp_avg is not None else None,
+            opt.exp_avg_sq.data_ptr() if opt.exp_avg_sq is not None else None)
+        fns = None
+        if comm is not None:
+            fns = ctypes.byref(_lib.NcclFns(comm.send_fn, comm.recv_fn, comm.group_start_fn, comm.group_end_fn))
+        _lib.check(self.lib.hiprec_shard_planned_steps(
+            ctypes.byref(c[0]), ctypes.byref(sb), a, b, opt.kind, reg, opt.lr, opt.beta1, opt.beta2, opt.eps, fns,
+            ctypes.c_void_p(comm.comm.value if comm is not None else None), _lib.ptr(self.stats),
+            self._st()))
 
     def epoch_stats(self):
         """(last loss, last reg, loss sum, reg sum) of the epoch (synchronises)."""
@@ -507,146 +608,113 @@ class ShardedMFEngine:
         self.last = (loss, reg)
         return loss, reg
 
-    # ---- epoch-planned steps (plain SGD): routing is a property of the DATA, so it is done once per epoch -------------
+    # ---- epoch-planned steps: routing is a property of the DATA, so it is done once per epoch ---------------------------
     # Which rank owns a triple's user row and which item rows each rank must fetch for each step depend on the ids
     # only, not on the weights.  For a device-resident loader the whole epoch is therefore routed in the staging:
     # ONE all-to-all moves every triple to owner(user); the item references of every step are de-duplicated per
     # (step, owner) (Zipf items: high duplication) and ONE all-to-all tells every owner which rows it will
     # be asked for, step by step.  What is left per step is exact-size (the split sizes are host integers: no
     # padding, nothing read back) and weight-dependent only:
-    #     gather rows -> all-to-all -> owned-rows kernel on (local users, fetched rows) -> all-to-all -> apply
-    # i.e. 2 collectives and 5 launches instead of 5 and 14.  User rows are updated in place by the gradient kernel
+    #     payload rows (+ clear) -> exchange -> gradient kernel on (local users, fetched rows) -> exchange -> apply
+    # i.e. 2 exchanges and 4 launches.  Plain SGD: user rows are updated in place by the gradient kernel
     # (csrc/mf_owned.hip), item gradients are summed per fetched slot and applied by the owner with -lr straight
-    # into the table: no dense gradient buffer, no touched-rows pass; loss / reg / scalar-bias partials ride in one
-    # extra row per peer of the gradient exchange instead of a separate all-reduce.
+    # into the table: no dense gradient buffer, no touched-rows pass.  Adam / RMSprop: the same launches accumulate
+    # into the shard's dense gradient and one local sweep follows (their moments move every element every step,
+    # torch_engine.py:30-39).  Loss / reg / scalar-bias partials ride in one extra row per peer of the gradient
+    # exchange instead of a separate all-reduce.  The planner itself is csrc/plan.hip (round 2: torch sorts).
     def plan_epoch(self, train_loader, group=None):
         """Collective.  Route one epoch of a DeviceTripleBatcher-like loader (this rank's share; the same number of
         triples and batch size on every rank).  Returns the plan :meth:`run_planned_epoch` consumes.  group: the
         process group its exchanges use (default: the engine's; :meth:`prefetch_plan` passes one of its own)."""
         pg = group or self.pg
-        from .mf import batch_row_ownership
-
-        R, dev, D = self.world, self.device, self.emb_dim
-        users = train_loader.user_tensor.to(dev)
-        pos = train_loader.pos_item_tensor.to(dev)
-        neg = train_loader.neg_item_tensor.to(dev)
+        R, dev, k = self.world, self.device, self.k
+        if self.emb_dim < 2:
+            raise ValueError("the planned sharded epoch needs emb_dim >= 2 (an exchange row carries three partial sums)")
+        if max(self.n_users, self.n_items) >= 2**31:
+            raise ValueError("the epoch planner works on 32-bit ids: n_users, n_items < 2^31")
+        users, pos, neg = (getattr(train_loader, a).to(dev, torch.int64).contiguous()
+                           for a in ("user_tensor", "pos_item_tensor", "neg_item_tensor"))
         n, bs = users.numel(), int(train_loader.batch_size)
         sizes = torch.tensor([n, -n, bs, -bs], dtype=torch.int64, device=dev)
         dist.all_reduce(sizes, op=dist.ReduceOp.MAX, group=pg)
         if sizes[0] != -sizes[1] or sizes[2] != -sizes[3]:
             raise ValueError("the planned sharded epoch needs the same number of triples and batch size on every rank")
+        if n == 0:
+            raise ValueError("the planned sharded epoch needs a non-empty loader")
         S = (n + bs - 1) // bs
         perm = train_loader.permutation()
         if perm is not None:
-            perm = perm.to(dev)
-            users, pos, neg = users[perm], pos[perm], neg[perm]
-        ar = lambda m: torch.arange(m, dtype=torch.int64, device=dev)  # noqa: E731
-        # sort keys travel as int32 whenever their range allows: half the radix passes of the device sorts
-        small = lambda key, bound: key.to(torch.int32) if bound < 2**31 else key  # noqa: E731
-        step = torch.div(ar(n), bs, rounding_mode="floor")
+            perm = perm.to(dev, torch.int64).contiguous()
 
-        # (1) triples -> owner(user), the whole epoch in one exchange, (dest, step)-ordered
-        key = (users % R) * S + step
-        o1 = torch.argsort(small(key, R * S), stable=True)
-        cnt_ds = torch.bincount(key, minlength=R * S).view(R, S)
+        # (1) triples -> owner(user), the whole epoch in one exchange, (destination, step)-ordered
+        send, cnt_ds = k.plan_route(users, pos, neg, perm, bs, R, self.n_users, self.n_items)
         recv_cnt = torch.empty_like(cnt_ds)
-        dist.all_to_all_single(recv_cnt, cnt_ds, group=pg)            # [source, step]
-        n_k = recv_cnt.sum(0)
-        host = torch.cat([cnt_ds.sum(1), recv_cnt.sum(1), n_k.max().reshape(1)]).tolist()   # host sync 1 of 2
+        dist.all_to_all_single(recv_cnt, cnt_ds, group=pg)                 # [source, step]
+        host = torch.cat([cnt_ds.sum(1), recv_cnt.sum(1), recv_cnt.sum(0).max().reshape(1),
+                          k.plan_status().to(cnt_ds.device)]).tolist()     # host sync 1 of 2
+        status = int(host[2 * R + 1])
+        if status:
+            k.check_status()   # out-of-range ids: IndexError, as nn.Embedding raises (and the status word is cleared)
         send1, recv1, cap = host[:R], host[R:2 * R], max(int(host[2 * R]), 1)
-        trip = self._a2a(torch.stack([users, pos, neg], 1)[o1], send1, recv1, pg)   # (source, step)-ordered
-        step_r = torch.repeat_interleave(ar(S).repeat(R), recv_cnt.reshape(-1))
-        o2 = torch.argsort(small(step_r, S), stable=True)                  # -> (step, source)
-        trip, step_r = trip[o2], step_r[o2]
-        at = step_r * cap + (ar(trip.shape[0]) - (torch.cumsum(n_k, 0) - n_k)[step_r])
-        U = torch.full((S * cap,), -1, dtype=torch.int64, device=dev)      # fixed-size blocks, -1 = padding
-        P, N = torch.zeros_like(U), torch.zeros_like(U)
-        U[at] = torch.div(trip[:, 0], R, rounding_mode="floor")
-        P[at], N[at] = trip[:, 1], trip[:, 2]
+        recv = self._a2a(send[:sum(send1)], send1, recv1, pg)               # (source, step)-ordered
+        U, P, N = k.plan_place_triples(recv, recv_cnt, S, cap)              # fixed-size blocks per step, user -1 = padding
 
-        # (2) item references de-duplicated per (step, owner); slot = position in the step's fetched buffer, whose
-        # layout is, per owner q: [rows asked of q ..., 1 extra row]
-        valid = U >= 0
-        v2 = torch.cat([valid, valid])
-        items = torch.cat([P, N])[v2]
-        st2 = torch.div(ar(2 * S * cap) % (S * cap), cap, rounding_mode="floor")[v2]
-        uniq, inv = torch.unique(small((st2 * R + items % R) * self.n_items + items, S * R * self.n_items),
-                                 return_inverse=True)
-        uniq = uniq.to(torch.int64)
-        u_item = uniq % self.n_items
-        u_sd = torch.div(uniq, self.n_items, rounding_mode="floor")       # step * R + dest
-        u_step, u_dest = torch.div(u_sd, R, rounding_mode="floor"), u_sd % R
-        req_cnt = torch.bincount(u_sd, minlength=S * R).view(S, R)
-        per_step = req_cnt.sum(1)
-        slot_u = ar(uniq.numel()) - (torch.cumsum(per_step, 0) - per_step)[u_step] + u_dest
-        slots = torch.zeros(2 * S * cap, dtype=torch.int64, device=dev)
-        slots[v2] = slot_u[inv]
-        SP, SN = slots[:S * cap], slots[S * cap:]
+        # (2) the step's distinct items become slots of its exchange buffer ([rows asked of q ..., 1 extra row] per
+        # owner q), the blocks are re-laid grouped by positive item with their row-ownership arrays
+        sl = k.plan_item_slots(U, P, N, S, cap, R, self.model.n_users, self.n_items)
 
-        # (3) tell every owner which rows it will be asked for, step by step: one exchange, (dest, step)-ordered
-        req_ds = req_cnt.t().contiguous()
+        # (3) tell every owner which rows it will be asked for, step by step: one exchange
+        req_ds = sl["req_ds"]
         in_qs = torch.empty_like(req_ds)
-        dist.all_to_all_single(in_qs, req_ds, group=pg)               # [source, step]
-        in_cnt = in_qs.t().contiguous()                                   # [step, source]
-        host = torch.cat([req_ds.sum(1), in_qs.sum(1), req_cnt.reshape(-1), in_cnt.reshape(-1)]).tolist()  # sync 2 of 2
+        dist.all_to_all_single(in_qs, req_ds, group=pg)                     # [source, step]
+        host = torch.cat([req_ds.sum(1), in_qs.sum(1), sl["req_cnt"].reshape(-1),
+                          in_qs.t().reshape(-1)]).tolist()                 # host sync 2 of 2
         send2, recv2 = host[:R], host[R:2 * R]
-        req_l = [host[2 * R + k * R: 2 * R + (k + 1) * R] for k in range(S)]
-        in_l = [host[2 * R + S * R + k * R: 2 * R + S * R + (k + 1) * R] for k in range(S)]
-        o3 = torch.argsort(small(u_dest * S + u_step, R * S), stable=True)
-        incoming = self._a2a(u_item[o3], send2, recv2, pg)                     # (source, step)-ordered
-        flat_cnt = in_qs.reshape(-1)
-        step_i = torch.repeat_interleave(ar(S).repeat(R), flat_cnt)
-        src_i = torch.repeat_interleave(ar(R).repeat_interleave(S), flat_cnt)
-        o4 = torch.argsort(small(step_i, S), stable=True)                  # -> (step, source)
-        incoming, step_i, src_i = incoming[o4], step_i[o4], src_i[o4]
-        in_idx = torch.full((incoming.numel() + S * R,), -1, dtype=torch.int64, device=dev)   # extras stay -1
-        in_idx[ar(incoming.numel()) + step_i * R + src_i] = torch.div(incoming, R, rounding_mode="floor")
+        req_l = [host[2 * R + j * R: 2 * R + (j + 1) * R] for j in range(S)]
+        in_l = [host[2 * R + S * R + j * R: 2 * R + S * R + (j + 1) * R] for j in range(S)]
+        incoming = self._a2a(sl["req_send"][:sum(send2)], send2, recv2, pg)  # (source, step)-ordered
+        in_idx, ex_in = k.plan_place_requests(incoming, in_qs, S)
         in_len = [sum(c) + R for c in in_l]
         n_slots = [sum(c) + R for c in req_l]
         in_off = [0]
-        for length in in_len[:-1]:
+        for length in in_len:
             in_off.append(in_off[-1] + length)
-
-        def extras(counts):  # position of each peer's extra row inside a step's block
-            out, run = [], 0
-            for q, c in enumerate(counts):
-                run += c
-                out.append(run + q)
-            return out
-
-        ex_req = torch.tensor([extras(c) for c in req_l], dtype=torch.int64, device=dev)
-        ex_in = torch.tensor([extras(c) for c in in_l], dtype=torch.int64, device=dev)
-
-        # (4) inside every step: triples sorted by positive slot (adjacent equal items merge in registers), and the
-        # ownership of the local user rows / the reference counts of the slots (csrc/ownership.hip)
-        big = max(n_slots) + 1
-        o5 = torch.argsort(small(torch.div(ar(S * cap), cap, rounding_mode="floor") * big
-                                 + torch.where(valid, SP, big - 1), S * big))
-        U, SP, SN = U[o5].contiguous(), SP[o5].contiguous(), SN[o5].contiguous()
-        own, total, stride = batch_row_ownership(U, SP, SN, cap, self.model.n_users, max(n_slots))
-        return {"S": S, "cap": cap, "bs": bs, "n": n, "U": U, "SP": SP, "SN": SN, "own": own, "total": total,
-                "stride": stride, "in_idx": in_idx, "in_off": in_off, "in_len": in_len, "n_slots": n_slots,
+        return {"S": S, "cap": cap, "bs": bs, "n": n, "world": R, "rank": self.rank, "U": sl["U"], "SP": sl["SP"],
+                "SN": sl["SN"], "own": sl["own"], "total": sl["total"], "stride": sl["stride"], "in_idx": in_idx,
+                "in_off": in_off[:-1], "in_len": in_len, "n_slots": n_slots,
                 "req_split": [[c + 1 for c in row] for row in req_l], "in_split": [[c + 1 for c in row] for row in in_l],
-                "ex_req": ex_req, "ex_in": ex_in}
+                "ex_req": sl["ex_req"], "ex_in": ex_in,
+                "in_off_h": in_off, "n_slots_h": n_slots, "req_cnt_h": req_l, "in_cnt_h": in_l}
+
+    def prefetch_setup(self):
+        """Collective, one-off: the side stream and the process group (a communicator of its own: no ordering against
+        the steps' exchanges) the prefetched plans use.  :meth:`prefetch_plan` calls it; callers that time epochs
+        call it beforehand (creating a communicator takes tens of milliseconds)."""
+        if getattr(self, "_plan_stream", None) is None:
+            self._plan_stream = torch.cuda.Stream(device=self.device)
+            ranks = None if self.pg is None else dist.get_process_group_ranks(self.pg)
+            self._plan_pg = dist.new_group(ranks=ranks)
+            if dist.get_backend(self._plan_pg) == "nccl":   # RCCL creates the communicator lazily: do it now
+                with torch.cuda.stream(self._plan_stream):
+                    t = torch.zeros(self.world, dtype=torch.int32, device=self.device)
+                    dist.all_to_all_single(torch.empty_like(t), t, group=self._plan_pg)
+                self._plan_stream.synchronize()
 
     def prefetch_plan(self, train_loader):
         """Collective.  Plan the NEXT epoch now, on a side stream and over a process group of its own, while the
         steps of the current one (already enqueued) run: the plan depends on the data only -- its sorts, its four
         exchanges and its two host round trips (4.9 ms per 30 steps of 65 536 triples) then cost the training
         stream nothing.  :meth:`take_plan` hands it to the next epoch."""
-        dev = self.device
-        if getattr(self, "_plan_stream", None) is None:
-            self._plan_stream = torch.cuda.Stream(device=dev)
-            ranks = None if self.pg is None else dist.get_process_group_ranks(self.pg)
-            self._plan_pg = dist.new_group(ranks=ranks)   # its own communicator: no ordering against the steps' exchanges
-            self._plans_alive = []
+        self.prefetch_setup()
+        begin = getattr(self, "_ev_epoch_begin", None)
+        if begin is not None:
+            # the plan of epoch k + 2 is made while epoch k + 1 runs, not earlier: the host cannot run epochs ahead
+            # of the GPU (the plan's host reads wait here), and at most two plans are in flight
+            self._plan_stream.wait_event(begin)
         with torch.cuda.stream(self._plan_stream):
             plan = self.plan_epoch(train_loader, group=self._plan_pg)
             plan["ready"] = torch.cuda.Event()
             plan["ready"].record(self._plan_stream)
-        # the plan's tensors come from the side stream's allocator pool: they must outlive the epoch that reads them
-        # on the training stream, or the next prefetch would overwrite them in flight (r02 experiments §24)
-        self._plans_alive = (self._plans_alive + [plan])[-3:]
         self._prefetched_plan = plan
         return plan
 
@@ -655,20 +723,52 @@ class ShardedMFEngine:
         fresh synchronous one."""
         plan = getattr(self, "_prefetched_plan", None)
         self._prefetched_plan = None
+        main = torch.cuda.current_stream(self.device)
         if plan is None:
-            return self.plan_epoch(train_loader)
-        torch.cuda.current_stream(self.device).wait_event(plan["ready"])
+            plan = self.plan_epoch(train_loader)
+        else:
+            main.wait_event(plan["ready"])
+            # the plan's tensors come from the side stream's allocator pool and are read by the training stream:
+            # the allocator must not hand their memory to a later plan before the steps that read them are done
+            # (r02 experiments 24; with the C step driver the host is far ahead of the GPU)
+            for v in plan.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(main)
+        self._ev_epoch_begin = torch.cuda.Event()
+        self._ev_epoch_begin.record(main)
         return plan
 
+    def _step_comm(self):
+        """How the planned steps are enqueued: "c" -- one C call per range of steps that launches the kernels AND
+        posts the exchanges (grouped ncclSend / ncclRecv on a communicator of the engine's own, _rccl.py; no
+        communicator at all at world size 1) -- or "torch" (torch.distributed.all_to_all_single between the launches:
+        the gloo tests' path, and the fallback when the RCCL binding is not available on every rank).
+        `step_driver: "torch"` in the model config forces the latter."""
+        mode = getattr(self, "_step_mode", None)
+        if mode is not None:
+            return mode
+        self._comm = None
+        want_c = isinstance(self.k, HipKernels) and self.config["model"].get("step_driver", "c") == "c"
+        if want_c and self.world > 1:
+            from . import _rccl
+
+            comm = _rccl.create_communicator(self.pg, self.device)
+            ok = comm is not None and comm.has_send_recv()
+            if _rccl.all_ranks_agree(ok, self.pg, self.device):
+                self._comm = comm
+            else:
+                want_c = False
+                if comm is not None:
+                    comm.destroy()
+        self._step_mode = "c" if want_c else "torch"
+        return self._step_mode
+
     def run_planned_epoch(self, plan, steps=None, sync=True):
-        """Collective.  Enqueue every step of a planned epoch (plain SGD), or steps [a, b) of it; nothing is read
-        back until the end.  Returns (last loss, last reg, loss sum, reg sum) of the global batches (None with
-        ``sync=False``)."""
-        if self.optimizer.name != "sgd":
-            raise RuntimeError("the planned sharded epoch applies plain SGD; Adam / RMSprop need the dense sweep "
-                               "(train_single_batch)")
+        """Collective.  Enqueue every step of a planned epoch, or steps [a, b) of it; nothing is read back until the
+        end.  Returns (last loss, last reg, loss sum, reg sum) of the global batches (None with ``sync=False``)."""
         R, dev, m, D, k = self.world, self.device, self.model, self.emb_dim, self.k
         ld, cap, S = D + 1, plan["cap"], plan["S"]
+        dense = self.optimizer.name != "sgd"
         max_in, max_slots = max(plan["in_len"]), max(plan["n_slots"])
         pb = getattr(self, "_planned_bufs", None)
         if pb is None or pb["max_in"] < max_in or pb["max_slots"] < max_slots or pb["stride"] < plan["stride"]:
@@ -679,36 +779,55 @@ class ShardedMFEngine:
                 "fetched": torch.empty((max_slots, ld), **f32), "g_send": torch.empty((max_slots, ld), **f32),
                 "arrived": torch.zeros(plan["stride"], dtype=torch.int32, device=dev),
                 "acc": torch.zeros(plan["stride"] * ld, **f32)}
-        item_emb, item_bias = m.item_emb.weight.data, m.item_bias.weight.data
         lr, reg = self.optimizer.lr, float(self.reg)
-        for s in range(*(steps or (0, S))):
+        a, b = steps or (0, S)
+        if self._step_comm() == "c":
+            k.planned_steps(plan, pb, m, self._g_flat, self.optimizer, a, b, reg, self._comm)
+            self.step_count += b - a
+            return k.epoch_stats() if sync else None
+        item_emb, item_bias = m.item_emb.weight.data, m.item_bias.weight.data
+        gue, gie, gub, gib, ggb = m._views(self._g_flat)
+        for s in range(a, b):
             il, sl = plan["in_len"][s], plan["n_slots"][s]
             idx = plan["in_idx"][plan["in_off"][s]: plan["in_off"][s] + il]
             payload, fetched = pb["payload"][:il], pb["fetched"][:sl]
             g_send, g_recv = pb["g_send"][:sl], pb["g_recv"][:il]
-            k.payload_rows(item_emb, item_bias, idx, payload)
+            k.payload_zero(item_emb, item_bias, idx, payload, g_send)
             dist.all_to_all_single(fetched, payload, output_split_sizes=plan["req_split"][s],
                                    input_split_sizes=plan["in_split"][s], group=self.pg)
-            g_send.zero_()
             blk = slice(s * cap, (s + 1) * cap)
             B = R * min(plan["bs"], plan["n"] - s * plan["bs"])
-            k.owned_remote_step(m, fetched, g_send, sl, plan["U"][blk], plan["SP"][blk], plan["SN"][blk],
-                                plan["own"][:, blk], plan["total"][s], pb["arrived"], pb["acc"], 1.0 / B, reg, lr)
+            if dense:
+                k.grad_remote_step(m, self._g_flat, fetched, g_send, sl, plan["U"][blk], plan["SP"][blk],
+                                   plan["SN"][blk], plan["own"][:, blk], plan["total"][s], 1.0 / B, reg)
+            else:
+                k.owned_remote_step(m, fetched, g_send, sl, plan["U"][blk], plan["SP"][blk], plan["SN"][blk],
+                                    plan["own"][:, blk], plan["total"][s], pb["arrived"], pb["acc"], 1.0 / B, reg, lr)
             k.publish_partials(g_send, D, plan["ex_req"][s])
             dist.all_to_all_single(g_recv, g_send, output_split_sizes=plan["in_split"][s],
                                    input_split_sizes=plan["req_split"][s], group=self.pg)
-            k.apply_rows(item_emb, item_bias, idx, g_recv, lr)
-            k.finish_step(g_recv, D, plan["ex_in"][s], m.global_bias.data, lr, s == 0)
             self.step_count += 1
+            if dense:
+                k.apply_finish(gie, gib, idx, g_recv, 1.0, plan["ex_in"][s], ggb, 1.0, s == 0)
+                k.opt_step(self.optimizer, m.flat, self._g_flat, self.step_count)
+            else:
+                k.apply_finish(item_emb, item_bias, idx, g_recv, -lr, plan["ex_in"][s], m.global_bias.data, -lr, s == 0)
         return k.epoch_stats() if sync else None
+
+    def _equal_loaders(self, train_loader):
+        """Collective.  The planned epoch needs the same number of triples and batch size on every rank; loaders that
+        differ take the per-batch loop (fall back instead of raising)."""
+        n, bs = len(train_loader.user_tensor), int(train_loader.batch_size)
+        t = torch.tensor([n, -n, bs, -bs], dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+        return n > 0 and self.emb_dim >= 2 and int(t[0]) == -int(t[1]) and int(t[2]) == -int(t[3])
 
     def train_an_epoch(self, train_loader, epoch_id):
         """Every rank iterates its own shard of the interaction stream; all loaders must yield the
-        same number of batches (one collective step per batch).  A device-resident loader trained with plain SGD
-        takes the epoch-planned path (plan_epoch + run_planned_epoch)."""
-        if (self.optimizer.name == "sgd" and all(hasattr(train_loader, a) for a in
-                                                 ("user_tensor", "pos_item_tensor", "neg_item_tensor", "permutation"))
-                and self.config["model"].get("epoch_plan", True)):
+        same number of batches (one collective step per batch).  A device-resident loader takes the epoch-planned
+        path (plan_epoch + run_planned_epoch), whatever the optimizer."""
+        if (all(hasattr(train_loader, a) for a in ("user_tensor", "pos_item_tensor", "neg_item_tensor", "permutation"))
+                and self.config["model"].get("epoch_plan", True) and self._equal_loaders(train_loader)):
             loss, _, total_loss, total_reg = self.run_planned_epoch(self.plan_epoch(train_loader))
             if self.rank == 0:
                 print(f"[Training Epoch {epoch_id}], Loss {loss}, Regularizer {total_reg}")

@@ -355,6 +355,134 @@ int hiprec_shard_finish_step(const float* g_recv, int32_t dim, const int64_t* ex
                              float* global_bias, double lr, int32_t first_of_epoch, hiprec_stats* stats,
                              void* stream);
 
+/* ---- round 3: the epoch planner as kernels (csrc/plan.hip), the planned step in three launches, the dense
+ * optimizers on it, and a range of steps -- kernels AND exchanges -- enqueued by one call.  The reference has no
+ * counterpart (single device, beta_rec/models/mf.py:92-119 is the step that is distributed here); SURVEY.md 8e.
+ *
+ * Planner.  All ids and positions are 32-bit inside a plan (n_users, n_items, n, n_steps * cap < 2^31); world <= 64.
+ *  hiprec_batch_row_ownership_tables  hiprec_batch_row_ownership that also returns the tables: tab_keys[n_batches <<
+ *      table_bits] (the row key in every entry: user row, or n_users + item; -1 = empty), pos_cnt (same shape: an ITEM
+ *      entry's number of positive occurrences) and occ[3 * n] (role-major like own: the entry's count when the
+ *      occurrence arrived; for a positive occurrence its rank among the item's positive occurrences).
+ *  hiprec_plan_route_triples  owner(user) = user mod world.  Triple j of the epoch's visiting order (perm[j], or j when
+ *      perm is NULL) belongs to step j / batch.  cnt_ds[world * n_steps] (d-major) = triples per destination and
+ *      step; send[3 * n] (int32) = (user / world, pos, neg), (destination, step)-ordered, visiting order inside a
+ *      group.  tile_ws: world * hiprec_plan_route_tiles(n, batch) ints.  Out-of-range ids raise USER_OOB / ITEM_OOB
+ *      in stats->status and the triple is dropped (the host turns the bits into IndexError, like nn.Embedding).
+ *  hiprec_plan_place_triples  recv[3 * n_recv]: what the triple exchange delivered, (source, step)-ordered with
+ *      recv_cnt[world * n_steps] (source-major) elements per group -> users / pos / neg[n_steps * cap] (int64), step
+ *      s in block [s * cap, (s + 1) * cap), sources in rank order, padding user = -1.  group_ws: 2 * world * n_steps + 1.
+ *  hiprec_plan_item_slots  from the blocks above (users[] = local user rows) and their ownership tables (batch = cap,
+ *      n_users = n_users_local, n_items = the GLOBAL item count; own / occ [3][n_steps * cap], tab_keys / pos_cnt
+ *      [n_steps << table_bits]; pos_cnt is overwritten): every distinct item of a step gets one slot of the step's
+ *      exchange buffer, whose layout is, owner by owner (owner(item) = item mod world), [rows asked of d ..., 1 extra
+ *      row]: req_cnt[n_steps][world], its transpose req_ds[world][n_steps], ex_req[n_steps][world] (the extra rows),
+ *      n_slots[n_steps], slot_of[n_steps << table_bits] (slot per table entry, -1 for non-items), req_send (the
+ *      rows to ask for, item / world, (destination, step)-ordered; send_base[world * n_steps + 1] = group starts) and
+ *      the step blocks re-laid GROUPED BY POSITIVE ITEM with slots for items: users_out / pos_slot / neg_slot (int64,
+ *      padding -1 / 0 / 0) and own_out[3][n_steps * cap].  ws: hiprec_plan_slot_ws_ints(...) ints.
+ *  hiprec_plan_place_requests  incoming[n_in]: the rows peers will ask for, (source, step)-ordered with
+ *      in_cnt[world * n_steps] (source-major) -> in_idx[n_in + world * n_steps] packed step by step, sources in rank
+ *      order, each followed by one extra row (-1); step_off[n_steps + 1]; extra_pos[n_steps][world]. */
+int hiprec_batch_row_ownership_tables(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
+                                      int64_t batch, int64_t n_users, int64_t n_items, int32_t table_bits,
+                                      int32_t* keys, int32_t* total, int32_t* own, int32_t* tab_keys, int32_t* pos_cnt,
+                                      int32_t* occ, void* stream);
+int64_t hiprec_plan_route_tiles(int64_t n, int64_t batch);
+int hiprec_plan_route_triples(const int64_t* users, const int64_t* pos, const int64_t* neg, const int64_t* perm,
+                              int64_t n, int64_t batch, int32_t world, int64_t n_users, int64_t n_items,
+                              int32_t* tile_ws, int32_t* cnt_ds, int32_t* send, hiprec_stats* stats, void* stream);
+int hiprec_plan_place_triples(const int32_t* recv, int64_t n_recv, const int32_t* recv_cnt, int32_t world,
+                              int64_t n_steps, int64_t cap, int32_t* group_ws, int64_t* users, int64_t* pos,
+                              int64_t* neg, void* stream);
+int64_t hiprec_plan_slot_ws_ints(int64_t n_steps, int32_t table_bits, int32_t world);
+int hiprec_plan_item_slots(const int64_t* users, int64_t n_steps, int64_t cap, int32_t world, int64_t n_users_local,
+                           int32_t table_bits, const int32_t* own, const int32_t* occ, const int32_t* tab_keys,
+                           int32_t* pos_cnt, int32_t* ws, int32_t* slot_of, int32_t* req_cnt, int32_t* req_ds,
+                           int32_t* ex_req, int32_t* n_slots, int32_t* send_base, int32_t* req_send,
+                           int64_t* users_out, int64_t* pos_slot, int64_t* neg_slot, int32_t* own_out, void* stream);
+int hiprec_plan_place_requests(const int32_t* incoming, int64_t n_in, const int32_t* in_cnt, int32_t world,
+                               int64_t n_steps, int32_t* group_ws, int32_t* in_idx, int32_t* step_off,
+                               int32_t* extra_pos, void* stream);
+
+/* The planned step in three launches.  Rows [self_lo, self_hi) of a step's incoming block are the ones this rank
+ * asked of itself: they never travel (self_dst / g_self point into the fetched / the send buffer).
+ *  hiprec_shard_payload_zero  payload[k] = [item_emb[idx[k]] | item_bias[idx[k]]] (zeros for idx -1) AND
+ *      zero[0, zero_floats) = 0 (the gradient exchange buffer) in ONE launch;
+ *  hiprec_mf_bpr_grad_remote_step  hiprec_mf_bpr_owned_remote_step for Adam / RMSprop: nothing is updated, the local
+ *      user rows' gradients go into g_flat (dense, laid out like w_flat, zero on entry);
+ *  hiprec_shard_apply_finish  target row idx[k] += coef * g_recv[k] (SGD: the item table, coef = -lr; dense
+ *      optimizers: the dense gradient, coef = 1) AND the step's bookkeeping (the peers' extra rows -> stats,
+ *      *scalar_target += scalar_coef * d loss / d scalar bias, t <- t + 1) in ONE launch. */
+int hiprec_shard_payload_zero(const float* item_emb, const float* item_bias, int64_t n_rows, int32_t dim,
+                              const int32_t* idx, int64_t n, int64_t self_lo, int64_t self_hi, float* payload,
+                              float* self_dst, float* zero, int64_t zero_floats, hiprec_stats* stats, void* stream);
+int hiprec_mf_bpr_grad_remote_step(const float* w_flat, float* g_flat, int64_t n_users, int64_t n_items_local,
+                                   int32_t dim, const float* fetched, float* g_send, int64_t n_slots,
+                                   const int64_t* users, const int64_t* pos_slot, const int64_t* neg_slot,
+                                   const int32_t* own_u, const int32_t* own_p, const int32_t* own_n,
+                                   const int32_t* total, int64_t batch, float inv_batch, float reg_coef,
+                                   hiprec_stats* stats, void* scratch, void* stream);
+int hiprec_shard_apply_finish(float* t_emb, float* t_bias, int64_t n_rows, int32_t dim, const int32_t* idx,
+                              const float* g_recv, int64_t n, int64_t self_lo, int64_t self_hi, const float* g_self,
+                              double coef, const int32_t* extra_pos, int32_t n_src, float* scalar_target,
+                              double scalar_coef, int32_t first_of_epoch, hiprec_stats* stats, void* stream);
+
+/* One epoch plan as the step driver reads it (device arrays as the planner wrote them; the *_host arrays are the
+ * exact sizes of the exchanges, host integers: nothing is read back while the steps are enqueued). */
+typedef struct hiprec_shard_plan {
+  int32_t world, rank;
+  int64_t n_steps, cap;          /* steps of the epoch; triples per step block (incl. padding) */
+  int64_t local_batch, n_local;  /* the loader's batch size and triples per rank (equal on every rank) */
+  const int64_t* users;          /* [n_steps * cap] local user rows, -1 = padding */
+  const int64_t* pos_slot;       /* [n_steps * cap] slots of the step's fetched buffer */
+  const int64_t* neg_slot;
+  const int32_t* own;            /* [3][n_steps * cap] */
+  const int32_t* total;          /* [n_steps][total_stride] */
+  int64_t total_stride;
+  const int32_t* in_idx;         /* packed: local item rows peers ask for, -1 = extra row */
+  const int32_t* ex_req;         /* [n_steps][world] extra rows of the fetched / send buffer */
+  const int32_t* ex_in;          /* [n_steps][world] extra rows of the incoming block */
+  const int64_t* in_off_host;    /* [n_steps + 1] */
+  const int64_t* n_slots_host;   /* [n_steps] */
+  const int64_t* req_cnt_host;   /* [n_steps][world] rows asked of each owner (extra row not counted) */
+  const int64_t* in_cnt_host;    /* [n_steps][world] rows each peer asks for */
+} hiprec_shard_plan;
+
+typedef struct hiprec_shard_bufs {
+  float* w_flat;                 /* this rank's [user_emb | item_emb | user_bias | item_bias | global_bias] */
+  int64_t n_users_local, n_items_local;
+  int32_t dim, _pad;
+  float* payload;                /* [max incoming rows][dim + 1] */
+  float* g_recv;
+  float* fetched;                /* [max slots][dim + 1] */
+  float* g_send;
+  int32_t* arrived;              /* plain SGD: the owned-rows step's slot counters / accumulators */
+  float* acc;
+  void* scratch;
+  float* g_flat;                 /* Adam / RMSprop: dense gradient (zero between steps) and moments, like w_flat */
+  float* m_flat;
+  float* v_flat;
+} hiprec_shard_bufs;
+
+/* ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd of the RCCL the caller loaded (this library links none) */
+typedef struct hiprec_nccl_fns {
+  void* send;
+  void* recv;
+  void* group_start;
+  void* group_end;
+} hiprec_nccl_fns;
+
+size_t hiprec_shard_plan_bytes(void); /* sizeof the two structs above, for the host layer's layout check */
+size_t hiprec_shard_bufs_bytes(void);
+
+/* Steps [step_begin, step_end) of a planned epoch, kernels and exchanges, enqueued on `stream`: per step payload +
+ * clear -> grouped send / recv of rows -> gradient kernel -> partials into the extra rows -> grouped send / recv of
+ * gradients -> apply + bookkeeping (-> dense sweep for kind != HIPREC_OPT_SGD).  world == 1 needs no communicator. */
+int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const hiprec_shard_bufs* bufs, int64_t step_begin,
+                               int64_t step_end, int32_t kind, float reg_coef, double lr, double beta1, double beta2,
+                               double eps, const hiprec_nccl_fns* nccl, void* comm, hiprec_stats* stats, void* stream);
+
 /* ---- ONE launch of that sequence, with the buffers of this step named explicitly: for callers that
  *      have to do something between two steps -- the data-parallel engine all-reduces
  *      [partials of scratch_cur | g_cur] over RCCL before the next launch consumes them as

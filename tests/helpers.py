@@ -154,3 +154,73 @@ def legal_trajectory_envelope(gold, n_steps, opt, lr, batch, loss="bpr", reg_coe
         for k in KEYS:
             env[k] = np.maximum(env[k], np.abs(w[k].astype(np.float64) - gold[f"w{n_steps}/{k}"]))
     return env
+
+
+def oracle_trajectory(w0, batches, grad_fn, step_fn, new_state, floor_fn=None, trials=8, rel=REL, seed=0):
+    """The generalisation of :func:`legal_trajectory_envelope` over an oracle-step callback (any model, any data):
+    ``grad_fn(w, batch) -> {name: gradient}``, ``step_fn(w, g, state)`` updates ``w`` / ``state`` in place,
+    ``new_state(w)`` makes the optimizer state, ``floor_fn(name, batch)`` the scale floor of a gradient tensor.
+
+    Returns ``(w_ref, env, upd)``: the oracle's own end point, the elementwise envelope max |w_run - w_ref| over
+    `trials` runs in which every gradient element is moved by +-rel of its tensor's scale (what north_star allows an
+    implementation to differ by), and per tensor the largest single-step update of the reference run."""
+    rng = np.random.default_rng(seed)
+
+    def run(perturb):
+        w = {k: np.array(v, dtype=np.float32) for k, v in w0.items()}
+        st = new_state(w)
+        upd = {k: 0.0 for k in w}
+        for b in batches:
+            g = grad_fn(w, b)
+            if perturb:
+                for k in g:
+                    scale = max(float(np.abs(g[k]).max()) if g[k].size else 0.0, floor_fn(k, b) if floor_fn else 0.0)
+                    g[k] = (g[k] + (rng.choice([-1.0, 1.0], size=g[k].shape) * rel * scale).astype(np.float32)
+                            ).astype(np.float32)
+            before = {k: v.copy() for k, v in w.items()}
+            step_fn(w, g, st)
+            for k in w:
+                upd[k] = max(upd[k], float(np.abs(w[k].astype(np.float64) - before[k]).max()) if w[k].size else 0.0)
+        return w, upd
+
+    w_ref, upd = run(False)
+    env = {k: np.zeros(v.shape, dtype=np.float64) for k, v in w_ref.items()}
+    for _ in range(trials):
+        w, _ = run(True)
+        for k in env:
+            env[k] = np.maximum(env[k], np.abs(w[k].astype(np.float64) - w_ref[k]))
+    return w_ref, env, upd
+
+
+def assert_on_trajectory(got, w_ref, env, upd, what="", rel=REL, env_factor=2.0):
+    """EVERY element within env_factor x the legal envelope + rel of the largest update + 4 ulp of the weights: no
+    allowance for a fraction of outliers."""
+    for k in w_ref:
+        ref = w_ref[k].astype(np.float64)
+        g = np.asarray(got[k], dtype=np.float64).reshape(ref.shape)
+        bound = env_factor * env[k] + rel * upd[k] + 4 * EPS32 * (np.abs(ref).max() if ref.size else 0.0)
+        bad = np.abs(g - ref) > bound
+        assert not bad.any(), (f"{what} {k}: {int(bad.sum())} of {bad.size} elements off the reference trajectory, "
+                               f"worst {np.abs(g - ref)[bad].max():.3e} vs bound {bound[bad].min():.3e}")
+
+
+def assert_sgd_exact(got, w_ref, w0, what="", rel=REL):
+    """Plain SGD has no conditioning problem: every element within rel of the largest update + 4 ulp, zero outliers."""
+    for k in w_ref:
+        ref = np.asarray(w_ref[k], dtype=np.float64)
+        g = np.asarray(got[k], dtype=np.float64).reshape(ref.shape)
+        upd = np.abs(ref - np.asarray(w0[k], dtype=np.float64).reshape(ref.shape)).max() if ref.size else 0.0
+        tol = rel * upd + 4 * EPS32 * (np.abs(ref).max() if ref.size else 0.0)
+        err = np.abs(g - ref).max() if ref.size else 0.0
+        assert err <= tol, f"{what} {k}: max err {err:.3e} > {tol:.3e} (update scale {upd:.3e})"
+
+
+def mf_trajectory(w0, batches, opt, lr, reg_coef=0.0, loss="bpr", **kw):
+    """oracle_trajectory for BPR / BCE MF on a list of (users, items, third) batches."""
+    from oracle import mf_numpy as onp
+
+    fn = onp.mf_bpr_grads if loss == "bpr" else onp.mf_bce_grads
+    return oracle_trajectory(
+        w0, batches, lambda w, b: fn(w, b[0], b[1], b[2], reg_coef)[2],
+        lambda w, g, st: onp.opt_step(w, g, st, opt, lr), lambda w: onp.new_opt_state(w, opt),
+        lambda k, b: grad_scale_floor(k, len(b[0])), **kw)

@@ -15,6 +15,7 @@ import torch.multiprocessing as mp
 
 from helpers import KEYS, assert_scalar_close, assert_tensor_close
 from oracle import mf_numpy as onp
+import plan_statements as ps
 
 
 class OracleKernels:
@@ -423,13 +424,43 @@ def test_two_rank_sharded_ncf_equals_single_process(tmp_path, kind, optimizer, l
 # ---- epoch-planned sharded SGD (ShardedMFEngine.plan_epoch / run_planned_epoch) on gloo ------------------------------
 
 class OraclePlannedKernels(OracleKernels):
-    """numpy statements of the planned step's kernels (csrc/mf_owned.hip REMOTE variant, csrc/shard.hip)."""
+    """numpy statements of the epoch planner (csrc/plan.hip: tests/plan_statements.py) and of the planned step's
+    kernels (csrc/mf_owned.hip REMOTE variants, csrc/shard.hip)."""
 
-    def payload_rows(self, item_emb, item_bias, local_idx, payload):
-        payload.copy_(torch.cat([self.gather_rows(item_emb, local_idx), self.gather_rows(item_bias, local_idx)], dim=1))
+    status = 0
 
-    def owned_remote_step(self, model, fetched, g_send, n_slots, users, slot_pos, slot_neg, own, total, arrived, acc,
-                          inv_batch, reg_coef, lr):
+    def plan_route(self, users, pos, neg, perm, bs, world, n_users, n_items):
+        send, cnt_ds, status = ps.plan_route(users.numpy(), pos.numpy(), neg.numpy(),
+                                             None if perm is None else perm.numpy(), bs, world, n_users, n_items)
+        self.status |= status
+        return torch.from_numpy(send), torch.from_numpy(cnt_ds)
+
+    def plan_status(self):
+        return torch.tensor([self.status], dtype=torch.int64)
+
+    def check_status(self):
+        if self.status:
+            self.status = 0
+            raise IndexError("index out of range in self")
+        super().check_status()
+
+    def plan_place_triples(self, recv, recv_cnt, S, cap):
+        return tuple(torch.from_numpy(a) for a in ps.plan_place_triples(recv.numpy(), recv_cnt.numpy(), S, cap))
+
+    def plan_item_slots(self, U, P, N, S, cap, world, n_users_local, n_items):
+        out = ps.plan_item_slots(U.numpy(), P.numpy(), N.numpy(), S, cap, world, n_users_local)
+        ps.check_item_slots(out, U.numpy(), P.numpy(), N.numpy(), S, cap, world, n_users_local)
+        return {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in out.items()}
+
+    def plan_place_requests(self, incoming, in_qs, S):
+        return tuple(torch.from_numpy(a) for a in ps.plan_place_requests(incoming.numpy(), in_qs.numpy(), S))
+
+    def payload_zero(self, item_emb, item_bias, idx, payload, g_send):
+        idx = idx.long()
+        payload.copy_(torch.cat([self.gather_rows(item_emb, idx), self.gather_rows(item_bias, idx)], dim=1))
+        g_send.zero_()
+
+    def _remote_grads(self, model, fetched, users, slot_pos, slot_neg, own, total, inv_batch, reg_coef):
         D = model.emb_dim
         live = users >= 0
         # the ownership arrays must describe the batch: -1 / total 1 exactly for rows referenced once
@@ -442,41 +473,61 @@ class OraclePlannedKernels(OracleKernels):
                 assert s < 0 or int(total[s]) == cnt
         if not bool(live.any()):   # this rank owns none of the step's users
             self.partial = torch.zeros(3)
-            return
+            return None
         ue, ie, ub, ib, gb = model._views(model.flat)
         w = {"user_emb.weight": ue.numpy(), "user_bias.weight": ub.numpy(), "global_bias": gb.numpy(),
              "item_emb.weight": fetched[:, :D].numpy(), "item_bias.weight": fetched[:, D:].numpy()}
         loss, reg, g = onp.mf_bpr_grads(w, users[live].numpy(), slot_pos[live].numpy(), slot_neg[live].numpy(),
                                         reg_coef, global_batch=int(round(1.0 / inv_batch)))
+        self.partial = torch.tensor([loss, reg, float(g["global_bias"][0])], dtype=torch.float32)
+        return g
+
+    def owned_remote_step(self, model, fetched, g_send, n_slots, users, slot_pos, slot_neg, own, total, arrived, acc,
+                          inv_batch, reg_coef, lr):
+        g = self._remote_grads(model, fetched, users, slot_pos, slot_neg, own, total, inv_batch, reg_coef)
+        if g is None:
+            return
+        D = model.emb_dim
+        ue, ie, ub, ib, gb = model._views(model.flat)
         lr32 = np.float32(lr)
         ue -= torch.from_numpy(lr32 * g["user_emb.weight"])      # untouched rows have zero gradient
         ub -= torch.from_numpy(lr32 * g["user_bias.weight"])
         g_send[:, :D] += torch.from_numpy(g["item_emb.weight"])
         g_send[:, D:] += torch.from_numpy(g["item_bias.weight"])
-        self.partial = torch.tensor([loss, reg, float(g["global_bias"][0])], dtype=torch.float32)
+
+    def grad_remote_step(self, model, g_flat, fetched, g_send, n_slots, users, slot_pos, slot_neg, own, total,
+                         inv_batch, reg_coef):
+        g = self._remote_grads(model, fetched, users, slot_pos, slot_neg, own, total, inv_batch, reg_coef)
+        if g is None:
+            return
+        D = model.emb_dim
+        gue, gie, gub, gib, ggb = model._views(g_flat)
+        gue += torch.from_numpy(g["user_emb.weight"])
+        gub += torch.from_numpy(g["user_bias.weight"])
+        g_send[:, :D] += torch.from_numpy(g["item_emb.weight"])
+        g_send[:, D:] += torch.from_numpy(g["item_bias.weight"])
 
     def publish_partials(self, g_send, dim, extra_rows):
-        g_send[extra_rows, :3] = self.partial
+        g_send[extra_rows.long(), :3] = self.partial
 
-    def apply_rows(self, item_emb, item_bias, local_idx, g_recv, lr):
-        keep = local_idx >= 0
-        item_emb.index_add_(0, local_idx[keep], -np.float32(lr) * g_recv[keep][:, :-1])
-        item_bias.index_add_(0, local_idx[keep], -np.float32(lr) * g_recv[keep][:, -1:])
-
-    def finish_step(self, g_recv, dim, extra_rows, global_bias, lr, first_of_epoch):
-        tot = g_recv[extra_rows, :3].sum(0)
+    def apply_finish(self, t_emb, t_bias, idx, g_recv, coef, extra_pos, scalar_target, scalar_coef, first_of_epoch):
+        idx = idx.long()
+        keep = idx >= 0
+        t_emb.index_add_(0, idx[keep], np.float32(coef) * g_recv[keep][:, :-1])
+        t_bias.index_add_(0, idx[keep], np.float32(coef) * g_recv[keep][:, -1:])
+        tot = g_recv[extra_pos.long(), :3].sum(0)
         if first_of_epoch:
             self.sums = [0.0, 0.0]
         self.loss, self.reg = float(tot[0]), float(tot[1])
         self.sums[0] += self.loss
         self.sums[1] += self.reg
-        global_bias -= np.float32(lr) * tot[2]
+        scalar_target += np.float32(scalar_coef) * tot[2]
 
     def epoch_stats(self):
         return self.loss, self.reg, self.sums[0], self.sums[1]
 
 
-def planned_worker(rank, world, port, n_local, bs, shuffle, out_path):
+def planned_worker(rank, world, port, n_local, bs, shuffle, out_path, optimizer="sgd", lr=0.1, U=37, I=23):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -484,14 +535,14 @@ def planned_worker(rank, world, port, n_local, bs, shuffle, out_path):
         import beta_recsys_amd as hp
         from beta_recsys_amd.sharded import ShardedMFEngine
 
-        U, I, D = 37, 23, 8    # 37 % 4 != 0, 23 % 4 != 0: uneven shards
+        D = 8    # 37 % 4 != 0, 23 % 4 != 0 (and % 8): uneven shards
         w0 = onp.init_params(U, I, D, seed=7)
         rng = np.random.default_rng(50 + rank)
         users, neg = rng.integers(0, U, n_local), rng.integers(0, I, n_local)
         p = 1.0 / np.arange(1, I + 1)
         pos = rng.choice(I, n_local, p=p / p.sum())            # Zipf items: duplicates inside a step's requests
         with contextlib.redirect_stdout(io.StringIO()):
-            eng = ShardedMFEngine(make_config(U, I, D, "sgd", 0.1, "padded", "rows"), kernels=OraclePlannedKernels(),
+            eng = ShardedMFEngine(make_config(U, I, D, optimizer, lr, "padded", "rows"), kernels=OraclePlannedKernels(),
                                   full_state={k: torch.from_numpy(v) for k, v in w0.items()})
         loader = hp.DeviceTripleBatcher(torch.from_numpy(users), torch.from_numpy(pos), torch.from_numpy(neg), bs,
                                         shuffle=shuffle, generator=torch.Generator().manual_seed(9 + rank) if shuffle else None)
@@ -519,21 +570,16 @@ def planned_worker(rank, world, port, n_local, bs, shuffle, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_local,bs,shuffle", [(2, 50, 16, False), (4, 41, 8, True), (3, 20, 32, False)])
-def test_planned_sharded_epoch_equals_single_process(tmp_path, world, n_local, bs, shuffle):
-    """plan_epoch + run_planned_epoch on 2, 3 and 4 gloo ranks with uneven shards (n_rows % R != 0), Zipf items and a
-    short last batch: the epoch-level routing (triples to owner(user), de-duplicated item requests to owner(item)),
-    the per-step exact-size exchanges and the partials riding in the extra rows reproduce the single-process SGD
-    steps on the concatenated global batches -- loss sums and the gathered full state_dict."""
-    out_path = str(tmp_path / "out.pt")
-    mp.spawn(planned_worker, args=(world, free_port(), n_local, bs, shuffle, out_path), nprocs=world, join=True)
-    res = torch.load(out_path, weights_only=False)
+def check_planned(res, n_local, bs, optimizer, lr):
+    from helpers import assert_on_trajectory, assert_sgd_exact, mf_trajectory
+
+    batches = [tuple(np.concatenate([loc[j][k:k + bs] for loc in res["local"]]) for j in range(3))
+               for k in range(0, n_local, bs)]
     w = onp.copy_params(res["w0"])
-    st = onp.new_opt_state(w, "sgd")
+    st = onp.new_opt_state(w, optimizer)
     tot_loss = tot_reg = 0.0
-    for k in range(0, n_local, bs):
-        batch = tuple(np.concatenate([loc[j][k:k + bs] for loc in res["local"]]) for j in range(3))
-        loss, reg = onp.mf_train_step(w, st, batch, "bpr", "sgd", 0.1)
+    for batch in batches:
+        loss, reg = onp.mf_train_step(w, st, batch, "bpr", optimizer, lr)
         tot_loss += loss
         tot_reg += reg
     last_loss, last_reg, loss_sum, reg_sum = res["stats"]
@@ -542,4 +588,42 @@ def test_planned_sharded_epoch_equals_single_process(tmp_path, world, n_local, b
     assert_scalar_close(reg_sum, tot_reg, 2e-5, "epoch regularizer sum")
     for k in KEYS:
         assert res["full"][k].shape == w[k].shape
-        assert_tensor_close(res["full"][k], w[k], 2e-5, f"{k} after the planned epoch")
+    if optimizer == "sgd":
+        assert_sgd_exact(res["full"], w, res["w0"], "after the planned epoch")
+    else:
+        w_ref, env, upd = mf_trajectory(res["w0"], batches, optimizer, lr)
+        assert_on_trajectory(res["full"], w_ref, env, upd, "after the planned epoch")
+
+
+@pytest.mark.parametrize("world,n_local,bs,shuffle", [(2, 50, 16, False), (4, 41, 8, True), (3, 20, 32, False)])
+def test_planned_sharded_epoch_equals_single_process(tmp_path, world, n_local, bs, shuffle):
+    """plan_epoch + run_planned_epoch on 2, 3 and 4 gloo ranks with uneven shards (n_rows % R != 0), Zipf items and a
+    short last batch: the epoch-level routing (triples to owner(user), de-duplicated item requests to owner(item)),
+    the per-step exact-size exchanges and the partials riding in the extra rows reproduce the single-process SGD
+    steps on the concatenated global batches -- loss sums and the gathered full state_dict, every element within
+    1e-5 of the update."""
+    out_path = str(tmp_path / "out.pt")
+    mp.spawn(planned_worker, args=(world, free_port(), n_local, bs, shuffle, out_path), nprocs=world, join=True)
+    check_planned(torch.load(out_path, weights_only=False), n_local, bs, "sgd", 0.1)
+
+
+@pytest.mark.parametrize("world,optimizer,lr", [(2, "adam", 0.05), (4, "adam", 0.05), (2, "rmsprop", 0.01)])
+def test_planned_sharded_epoch_with_the_dense_optimizers(tmp_path, world, optimizer, lr):
+    """Adam / RMSprop on the planned path (torch_engine.py:30-39): the same routing and exchanges, the
+    gradient kernel's dense form (user rows -> the shard's dense gradient, item slots -> the exchange), the owners
+    accumulate what comes back into their dense gradient, one local sweep per step.  Against the single-process
+    oracle on the concatenated batches, every element inside the legal-trajectory envelope."""
+    n_local, bs = 41, 8
+    out_path = str(tmp_path / "out.pt")
+    mp.spawn(planned_worker, args=(world, free_port(), n_local, bs, True, out_path, optimizer, lr), nprocs=world,
+             join=True)
+    check_planned(torch.load(out_path, weights_only=False), n_local, bs, optimizer, lr)
+
+
+def test_planned_sharded_epoch_on_eight_ranks(tmp_path):
+    """World size 8 (the node BASELINE configs[3] names) with Zipf items, 37 users and 23 items (n_rows % 8 != 0:
+    shards of 5 and 4 / 3 and 2 rows), a short last batch and steps in which some ranks receive nothing."""
+    n_local, bs = 21, 8
+    out_path = str(tmp_path / "out.pt")
+    mp.spawn(planned_worker, args=(8, free_port(), n_local, bs, True, out_path), nprocs=8, join=True)
+    check_planned(torch.load(out_path, weights_only=False), n_local, bs, "sgd", 0.1)

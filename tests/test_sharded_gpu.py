@@ -290,21 +290,28 @@ def test_sharded_ncf_engine_with_hip_kernels(nccl_group, kind, emb):
         eng.train_single_batch(np.array([U]), np.array([0]), np.array([1.0], dtype=np.float32))
 
 
-@pytest.mark.parametrize("D,B,shuffle", [(64, 512, False), (128, 1000, True), (100, 300, False)])
-def test_planned_sharded_epoch_with_hip_kernels(nccl_group, D, B, shuffle):
-    """ShardedMFEngine.train_an_epoch on a device-resident loader (plain SGD): epoch-level routing, then per step
-    gather -> all-to-all -> owned-rows kernel on (local users, fetched item slots) -> partials into the extra rows
-    -> all-to-all -> apply, all with the real kernels at world size 1; equal to the oracle's single-process steps."""
+@pytest.mark.parametrize("D,B,shuffle,optimizer,lr", [(64, 512, False, "sgd", 0.05), (128, 1000, True, "sgd", 0.05),
+                                                      (100, 300, False, "sgd", 0.05), (64, 512, True, "adam", 0.05),
+                                                      (128, 300, False, "rmsprop", 0.01), (2, 200, False, "sgd", 0.05)])
+@pytest.mark.parametrize("driver", ["c", "torch"])
+def test_planned_sharded_epoch_with_hip_kernels(nccl_group, D, B, shuffle, optimizer, lr, driver):
+    """ShardedMFEngine.train_an_epoch on a device-resident loader: epoch-level routing by the planner kernels, then
+    per step payload -> exchange -> gradient kernel on (local users, fetched item slots) -> partials into the extra
+    rows -> exchange -> apply (-> dense sweep for Adam / RMSprop), all with the real kernels at world size 1 -- through
+    the C step driver (one call per epoch, no exchange at world 1) and through the torch.distributed loop; equal to
+    the oracle's single-process steps: SGD every element within 1e-5 of the update, the dense optimizers every
+    element inside the legal-trajectory envelope."""
     import beta_recsys_amd as hp
     from beta_recsys_amd.sharded import ShardedMFEngine
+    from helpers import assert_on_trajectory, assert_sgd_exact, mf_trajectory
 
     U, I, n = 3000, 400, 4 * B + B // 3
     w0 = onp.init_params(U, I, D, seed=3)
     rng = np.random.default_rng(D)
     p = 1.0 / np.arange(1, I + 1)
     users, pos, neg = rng.integers(0, U, n), rng.choice(I, n, p=p / p.sum()), rng.integers(0, I, n)
-    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer="sgd", lr=0.05, batch_size=B,
-                         loss="bpr", sgd_mode="rows"), "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer=optimizer, lr=lr, batch_size=B,
+                         loss="bpr", sgd_mode="rows", step_driver=driver), "system": {"run_dir": "/tmp/hiprec_test_runs"}}
     with contextlib.redirect_stdout(io.StringIO()):
         eng = ShardedMFEngine(cfg, full_state={k: torch.from_numpy(v) for k, v in w0.items()})
     gen = torch.Generator().manual_seed(4) if shuffle else None
@@ -312,23 +319,48 @@ def test_planned_sharded_epoch_with_hip_kernels(nccl_group, D, B, shuffle):
                                     generator=gen)
     with contextlib.redirect_stdout(io.StringIO()):
         total_loss, total_reg = eng.train_an_epoch(loader, 0)
+    assert eng._step_mode == driver
     order = torch.randperm(n, generator=torch.Generator().manual_seed(4)).numpy() if shuffle else np.arange(n)
+    batches = [(users[order[k:k + B]], pos[order[k:k + B]], neg[order[k:k + B]]) for k in range(0, n, B)]
     w = onp.copy_params(w0)
-    st = onp.new_opt_state(w, "sgd")
+    st = onp.new_opt_state(w, optimizer)
     ref_loss = ref_reg = 0.0
-    for k in range(0, n, B):
-        sl = order[k:k + B]
-        loss, reg = onp.mf_train_step(w, st, (users[sl], pos[sl], neg[sl]), "bpr", "sgd", 0.05)
+    for batch in batches:
+        loss, reg = onp.mf_train_step(w, st, batch, "bpr", optimizer, lr)
         ref_loss += loss
         ref_reg += reg
     assert_scalar_close(total_loss, ref_loss, 2e-5, "epoch loss sum")
     assert_scalar_close(total_reg, ref_reg, 2e-5, "epoch regularizer sum")
-    full = eng.gather_full_state_dict()
-    for k in KEYS:
-        got = full[k].cpu().numpy()
-        upd = np.abs(w[k] - w0[k]).max()
-        assert np.abs(got - w[k]).max() <= 1e-5 * upd + 4 * 1.2e-7 * np.abs(w[k]).max(), k
-    assert float(eng._planned_bufs["acc"].abs().max()) == 0.0 and int(eng._planned_bufs["arrived"].abs().max()) == 0
+    full = {k: v.cpu().numpy() for k, v in eng.gather_full_state_dict().items()}
+    if optimizer == "sgd":
+        assert_sgd_exact(full, w, w0, "planned epoch")
+        assert float(eng._planned_bufs["acc"].abs().max()) == 0.0 and int(eng._planned_bufs["arrived"].abs().max()) == 0
+    else:
+        w_ref, env, upd = mf_trajectory(w0, batches, optimizer, lr)
+        assert_on_trajectory(full, w_ref, env, upd, "planned epoch")
+        assert float(eng._g_flat.abs().max()) == 0.0, "the sweep leaves the dense gradient zeroed"
+
+
+def test_planned_epoch_raises_index_error_for_out_of_range_ids(nccl_group):
+    """the epoch plan validates user / item ids (IndexError, like nn.Embedding), it never aliases them."""
+    import beta_recsys_amd as hp
+    from beta_recsys_amd.sharded import ShardedMFEngine
+
+    U, I, D, B = 300, 40, 8, 64
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer="sgd", lr=0.05, batch_size=B,
+                         loss="bpr"), "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = ShardedMFEngine(cfg)
+    rng = np.random.default_rng(0)
+    users, pos, neg = rng.integers(0, U, 200), rng.integers(0, I, 200), rng.integers(0, I, 200)
+    pos[77] = I
+    loader = hp.DeviceTripleBatcher(*(torch.from_numpy(a).cuda() for a in (users, pos, neg)), B, shuffle=False)
+    with pytest.raises(IndexError):
+        eng.train_an_epoch(loader, 0)
+    pos[77] = 0
+    loader = hp.DeviceTripleBatcher(*(torch.from_numpy(a).cuda() for a in (users, pos, neg)), B, shuffle=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng.train_an_epoch(loader, 0)    # the engine is usable afterwards
 
 
 def test_planned_epochs_with_the_plan_prefetched_on_a_side_stream(nccl_group):
@@ -397,4 +429,18 @@ def test_planned_sharded_epoch_at_c4_shard_size(nccl_group):
     assert_scalar_close(total_loss, single.epoch_stats().loss_sum, 1e-5, "epoch loss sum, sharded vs single GPU")
     upd = float((ref - w0).abs().max())
     assert float((eng.model.flat - ref).abs().max()) <= 1e-5 * upd + 4 * 1.2e-7 * float(w0.abs().max())
-    assert torch.equal(eng.model.flat == w0, ref == w0), "the two engines moved different sets of elements"
+    # rows no triple of the epoch names are bit-identical to the initial model in BOTH engines (plain SGD moves
+    # touched rows only); inside touched rows the two engines sum in different orders, so "moved / not moved" of a
+    # single element may differ by an ulp-sized update and is not compared
+    m = eng.model
+    for name, ids, n_rows in (("user", users, U), ("item", np.concatenate([pos, neg]), I)):
+        idle = torch.ones(n_rows, dtype=torch.bool, device="cuda")
+        idle[torch.from_numpy(np.unique(ids)).cuda()] = False
+        ue, ie, ub, ib, _ = m._views(m.flat)
+        ue0, ie0, ub0, ib0, _ = m._views(w0)
+        re_, rie, rub, rib, _ = m._views(ref)
+        emb, emb0, remb = (ue, ue0, re_) if name == "user" else (ie, ie0, rie)
+        bias, bias0, rbias = (ub, ub0, rub) if name == "user" else (ib, ib0, rib)
+        assert idle.any()
+        assert torch.equal(emb[idle], emb0[idle]) and torch.equal(bias[idle], bias0[idle]), f"idle {name} rows moved"
+        assert torch.equal(remb[idle], emb0[idle]) and torch.equal(rbias[idle], bias0[idle])
