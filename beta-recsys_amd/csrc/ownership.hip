@@ -70,6 +70,11 @@ __global__ __launch_bounds__(kOwnThreads) void ownership_kernel(const int32_t* _
   const uint32_t part = static_cast<uint32_t>(blockIdx.x % n_parts);
   int32_t* s_key = s_tab;
   int32_t* s_cnt = s_tab + part_size;
+  __shared__ int32_t s_qkey[kOwnThreads / kWave][2 * kWave];   // per wave: ring of filtered keys ...
+  __shared__ uint32_t s_qidx[kOwnThreads / kWave][2 * kWave];  // ... and their occurrence index inside the batch
+  const int lane = lane_id();
+  int32_t* q_key = s_qkey[wave_in_block()];
+  uint32_t* q_idx = s_qidx[wave_in_block()];
   for (uint32_t i = threadIdx.x; i < part_size; i += kOwnThreads) {
     s_key[i] = -1;
     s_cnt[i] = 0;
@@ -81,48 +86,68 @@ __global__ __launch_bounds__(kOwnThreads) void ownership_kernel(const int32_t* _
   // phase 0: user and positive rows ([0, 2 cnt)), phase 1: negative rows
   for (int phase = 0; phase < 2; ++phase) {
     const int64_t lo = phase == 0 ? 0 : 2 * cnt, hi = phase == 0 ? 2 * cnt : 3 * cnt;
-    // kOwnUnroll keys are requested together: with one 16-wave workgroup per CU (the LDS holds one table) a loop of
-    // single dependent loads is latency-bound (760 us per 50 x 65 536-triple epoch; the inserts themselves are few:
-    // one key in n_parts belongs to this partition)
-    for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += static_cast<int64_t>(kOwnThreads) * kOwnUnroll) {
+    // Two stages per wave.  (1) Filter: kOwnUnroll keys per lane are requested together and the ones that hash into
+    // this partition (one in n_parts) are appended to the wave's queue in LDS (ballot + prefix: order of arrival).
+    // (2) Insert: as soon as 64 are queued, every lane takes one -- the probe loop is a chain of LDS compare-and-swap
+    // round trips whose length is the longest chain among the ACTIVE lanes; run straight on the filtered stream it
+    // had ~4 active lanes per wave instruction (560-760 us per 50 x 65 536-triple epoch).
+    uint32_t q_head = 0, q_tail = 0;  // wave-uniform; the ring holds q_tail - q_head <= 2 * kWave entries
+    auto drain = [&](uint32_t n_take) {
+      const bool on = static_cast<uint32_t>(lane) < n_take;
+      const uint32_t slot = (q_head + lane) & (2 * kWave - 1);
+      const int32_t key = on ? q_key[slot] : -1;
+      const uint32_t i = on ? q_idx[slot] : 0u;
+      q_head += n_take;
+      if (!on) return;
+      const int role = i < cnt ? 0 : i < 2 * cnt ? 1 : 2;
+      const int64_t at = role * n + t0 + (static_cast<int64_t>(i) - role * cnt);
+      uint32_t h = hash_u32(static_cast<uint32_t>(key)) & part_mask;
+      for (uint32_t probes = 0;; ++probes) {
+        const int32_t prev = atomicCAS(s_key + h, -1, key);
+        if (prev == -1 || prev == key) break;
+        h = (h + 1u) & part_mask;
+        if (probes > part_size) {  // a full partition (cannot happen at >= 4 x batch entries): give up, never spin
+          h = part_size;
+          break;
+        }
+      }
+      if (h == part_size) {
+        own[at] = -1;
+        return;
+      }
+      const int32_t before = atomicAdd(s_cnt + h, 1);
+      own[at] = static_cast<int32_t>((part << part_bits) | h);
+      if (occ) occ[at] = before;
+    };
+    for (int64_t i0 = lo + (threadIdx.x & ~(kWave - 1)); i0 < hi; i0 += static_cast<int64_t>(kOwnThreads) * kOwnUnroll) {
       int32_t key[kOwnUnroll];
-      int64_t at[kOwnUnroll];
 #pragma unroll
       for (int j = 0; j < kOwnUnroll; ++j) {
-        const int64_t i = i0 + static_cast<int64_t>(j) * kOwnThreads;
-        const int role = i < cnt ? 0 : i < 2 * cnt ? 1 : 2;   // (no 64-bit division: it was most of this kernel's time)
-        at[j] = role * n + t0 + (i - role * cnt);
-        key[j] = i < hi ? keys[at[j]] : -2;
+        const int64_t i = i0 + lane + static_cast<int64_t>(j) * kOwnThreads;
+        const int role = i < cnt ? 0 : i < 2 * cnt ? 1 : 2;   // (no 64-bit division here)
+        key[j] = i < hi ? keys[role * n + t0 + (i - role * cnt)] : -2;
       }
 #pragma unroll
       for (int j = 0; j < kOwnUnroll; ++j) {
-        if (key[j] == -2) continue;
-        if (key[j] < 0) {
-          if (part == 0) own[at[j]] = -1;
-          continue;
+        const int64_t i = i0 + lane + static_cast<int64_t>(j) * kOwnThreads;
+        if (key[j] == -1 && part == 0) {  // a triple with an out-of-range id: no slot
+          const int role = i < cnt ? 0 : i < 2 * cnt ? 1 : 2;
+          own[role * n + t0 + (i - role * cnt)] = -1;
         }
-        // the partition is chosen by the hash's top bits, the position inside it by its low bits
-        const uint32_t x = hash_u32(static_cast<uint32_t>(key[j]));
-        if (n_parts > 1 && (x >> (32 - (table_bits - part_bits))) != part) continue;
-        uint32_t h = x & part_mask;
-        for (uint32_t probes = 0;; ++probes) {
-          const int32_t prev = atomicCAS(s_key + h, -1, key[j]);
-          if (prev == -1 || prev == key[j]) break;
-          h = (h + 1u) & part_mask;
-          if (probes > part_size) {  // a full partition (cannot happen at >= 4 x batch entries): give up, never spin
-            h = part_size;
-            break;
-          }
+        const bool pass = key[j] >= 0 && (n_parts == 1 || (hash_u32(static_cast<uint32_t>(key[j])) >>
+                                                            (32 - (table_bits - part_bits))) == part);
+        const unsigned long long m = __ballot(pass);
+        if (m == 0) continue;
+        if (pass) {
+          const uint32_t slot = (q_tail + __popcll(m & ((1ull << lane) - 1ull))) & (2 * kWave - 1);
+          q_key[slot] = key[j];
+          q_idx[slot] = static_cast<uint32_t>(i);
         }
-        if (h == part_size) {
-          own[at[j]] = -1;
-          continue;
-        }
-        const int32_t before = atomicAdd(s_cnt + h, 1);
-        own[at[j]] = static_cast<int32_t>((part << part_bits) | h);
-        if (occ) occ[at[j]] = before;
+        q_tail += __popcll(m);
+        if (q_tail - q_head >= kWave) drain(kWave);
       }
     }
+    if (q_tail != q_head) drain(q_tail - q_head);
     __syncthreads();
     if (phase == 0 && pos_cnt)
       for (uint32_t i = threadIdx.x; i < part_size; i += kOwnThreads) pos_cnt[tab0 + i] = s_cnt[i];
