@@ -204,12 +204,16 @@ def assert_on_trajectory(got, w_ref, env, upd, what="", rel=REL, env_factor=2.0)
                                f"worst {np.abs(g - ref)[bad].max():.3e} vs bound {bound[bad].min():.3e}")
 
 
-def assert_sgd_exact(got, w_ref, w0, what="", rel=REL):
-    """Plain SGD has no conditioning problem: every element within rel of the largest update + 4 ulp, zero outliers."""
+def assert_sgd_exact(got, w_ref, w0, what="", rel=REL, lr=None, batch=None):
+    """Plain SGD has no conditioning problem: every element within rel of the largest update + 4 ulp, zero outliers.
+    With lr / batch given, the update scale of a bias tensor is at least lr x the scale of the TERMS its gradient
+    sums (grad_scale_floor: they cancel, the rounding error does not)."""
     for k in w_ref:
         ref = np.asarray(w_ref[k], dtype=np.float64)
         g = np.asarray(got[k], dtype=np.float64).reshape(ref.shape)
         upd = np.abs(ref - np.asarray(w0[k], dtype=np.float64).reshape(ref.shape)).max() if ref.size else 0.0
+        if lr is not None:
+            upd = max(upd, lr * grad_scale_floor(k, batch))
         tol = rel * upd + 4 * EPS32 * (np.abs(ref).max() if ref.size else 0.0)
         err = np.abs(g - ref).max() if ref.size else 0.0
         assert err <= tol, f"{what} {k}: max err {err:.3e} > {tol:.3e} (update scale {upd:.3e})"
