@@ -12,7 +12,9 @@ namespace hiprec {
 //   kTNm: A is [K,M] (lda), B is [K,N] (ldb)          C = A^T B      (wgrad:   dZ^T H)
 //   epilogue: + bias[n] (if bias) ; relu (if relu) ; * [mask[m,n] > 0] (if mask) ; dropout keep bytes (if
 //   keep; make_gemm leaves it NULL, callers set keep / ldk / keep_scale on the returned problem)
-// mode kColsum: C[n] += sum_m A[m, n] over the block's kColsumRows rows (bias gradients).
+// mode kColsum: C[n] += sum_m A[m, n] over the block's kColsumRows rows (bias gradients): one fp32 atomic per block
+// and column (the order of the blocks' partial sums changes from run to run), or, with a workspace, in two levels
+// with a fixed order (make_colsum's ws + launch_colsum_reduce).
 enum GemmMode { kNT = 0, kNN = 1, kTNm = 2, kColsum = 3 };
 
 struct GemmProblem {
@@ -33,6 +35,9 @@ struct GemmProblem {
   float keep_scale;
   int tiles_n, tiles_m, split;  // block decomposition of this problem
   int first_block;              // its first block in the grouped grid
+  // kColsum only: when set, the blocks leave their partial sums in ws[slab * N + n] (no atomics) and
+  // launch_colsum_reduce adds them up in slab order afterwards -- a column sum that is the same from run to run
+  float* ws;
 };
 
 constexpr int kMaxGroup = 16;
@@ -46,8 +51,11 @@ struct GemmGroup {
 GemmProblem make_gemm(int mode, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                       float* C, int ldc, const float* bias, int relu, const float* mask, int ldm,
                       bool split_k);
-// C[n] += sum_m X[m, n]
-GemmProblem make_colsum(const float* X, int M, int N, int ldx, float* out);
+// C[n] += sum_m X[m, n].  ws (optional): colsum_ws_floats(M, N) floats of scratch for the two-level, fixed-order form.
+GemmProblem make_colsum(const float* X, int M, int N, int ldx, float* out, float* ws = nullptr);
+int64_t colsum_ws_floats(int M, int N);
+// second level of every kColsum problem of g that has a workspace: out[n] += its partial sums in slab order
+int launch_colsum_reduce(const GemmGroup& g, hipStream_t st);
 // assigns the blocks of g.p[0..n) and launches them as ONE grid
 int launch_group(GemmGroup& g, hipStream_t st);
 

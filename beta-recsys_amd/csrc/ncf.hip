@@ -165,7 +165,8 @@ __device__ __forceinline__ void colsum_tile(float* s_flat, const GemmProblem& q,
     lds_barrier();
     if (ty == 0 && n < N) {
       const float t = (s_part[0][tx] + s_part[1][tx]) + (s_part[2][tx] + s_part[3][tx]);
-      if (t != 0.f) atomic_add_f32(q.C + n, t);
+      if (q.ws) q.ws[static_cast<int64_t>(slab) * N + n] = t;   // second level: colsum_reduce_kernel, fixed order
+      else if (t != 0.f) atomic_add_f32(q.C + n, t);
     }
     lds_barrier();
   }
@@ -224,13 +225,51 @@ GemmProblem make_gemm(int mode, int M, int N, int K, const float* A, int lda, co
   return q;
 }
 
-GemmProblem make_colsum(const float* X, int M, int N, int ldx, float* out) {
+GemmProblem make_colsum(const float* X, int M, int N, int ldx, float* out, float* ws) {
   GemmProblem q{};
   q.mode = kColsum; q.M = M; q.N = N; q.A = X; q.lda = ldx; q.C = out;
   q.tiles_n = 1;
   q.tiles_m = (M + kColsumRows - 1) / kColsumRows;
   q.split = 1;
+  q.ws = q.tiles_m > 1 ? ws : nullptr;   // a single block's one add into a zeroed gradient is already deterministic
   return q;
+}
+
+int64_t colsum_ws_floats(int M, int N) { return static_cast<int64_t>((M + kColsumRows - 1) / kColsumRows) * N; }
+
+struct ColsumReduce {
+  int n;
+  const float* ws[kMaxGroup];
+  float* out[kMaxGroup];
+  int N[kMaxGroup], slabs[kMaxGroup];
+};
+
+// out[n] += ws[0][n] + ws[1][n] + ... in slab order (one block per problem; a few thousand floats each)
+__global__ __launch_bounds__(kBlock) void colsum_reduce_kernel(ColsumReduce r) {
+  const int i = blockIdx.x;
+  const float* __restrict__ ws = r.ws[i];
+  for (int n = threadIdx.x; n < r.N[i]; n += kBlock) {
+    float t = 0.f;
+    for (int s = 0; s < r.slabs[i]; ++s) t += ws[static_cast<int64_t>(s) * r.N[i] + n];
+    r.out[i][n] += t;
+  }
+}
+
+int launch_colsum_reduce(const GemmGroup& g, hipStream_t st) {
+  ColsumReduce r{};
+  for (int i = 0; i < g.n; ++i) {
+    const GemmProblem& q = g.p[i];
+    if (q.mode != kColsum || !q.ws) continue;
+    r.ws[r.n] = q.ws;
+    r.out[r.n] = q.C;
+    r.N[r.n] = q.N;
+    r.slabs[r.n] = q.tiles_m;
+    ++r.n;
+  }
+  if (r.n == 0) return 0;
+  colsum_reduce_kernel<<<r.n, kBlock, 0, st>>>(r);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
 }
 
 int launch_group(GemmGroup& g, hipStream_t st) {

@@ -17,6 +17,7 @@
 // The loss gathers / scatters rows of the concatenated table directly (one wave per triple).
 // Nothing here is GEMM-bound: 2 x N x d x d flops per Linear (80 MFLOP at ML-1M size) against 2.5 MB
 // activations; the MFMA group is used because it is the exact-fp32 GEMM the NCF tower already has.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -744,9 +745,15 @@ extern "C" int hiprec_ngcf_grad(const hiprec_ngcf_plan* plan, const int64_t* use
                          0, true);
       g.p[3] = make_gemm(kTNm, dout, di, n32, p->d_bi, dout, p->bi_in[l], di, p->g_bi_w[l], di, nullptr, 0, nullptr,
                          0, true);
-      g.p[4] = make_colsum(p->d_sum, n32, dout, dout, p->g_gc_b[l]);
-      g.p[5] = make_colsum(p->d_bi, n32, dout, dout, p->g_bi_b[l]);
+      // bias gradients: cancelling column sums over all N nodes -- two levels in a fixed order (run-order atomics made
+      // them differ from run to run by more than the reference's own fp32 error).  Workspace: the other d_ego
+      // buffer, which the activation backward above has just consumed (d_next) and nobody writes before the SpMM
+      float* ws = p->d_ego[(l + 1) & 1];
+      const bool ws_fits = 2 * colsum_ws_floats(n32, dout) <= N * static_cast<int64_t>(di > dout ? di : dout);
+      g.p[4] = make_colsum(p->d_sum, n32, dout, dout, p->g_gc_b[l], ws_fits ? ws : nullptr);
+      g.p[5] = make_colsum(p->d_bi, n32, dout, dout, p->g_bi_b[l], ws_fits ? ws + colsum_ws_floats(n32, dout) : nullptr);
       if (int rc = launch_group(g, st)) return rc;
+      if (int rc = launch_colsum_reduce(g, st)) return rc;
       if (l == 0)
         ngcf_bi_bwd_kernel<true><<<grid_for_threads(N * di), kBlock, 0, st>>>(p->d_bi_in, p->side[l], ego_in, d_ego,
                                                                              p->d_side, N * di, di, src);
@@ -768,18 +775,29 @@ extern "C" int hiprec_ngcf_grad(const hiprec_ngcf_plan* plan, const int64_t* use
     d_next = d_ego;
   }
   if (hop_bwd) {  // every hop's weight and bias gradients: they only read what the hop launches wrote
+    // bias gradients in two levels with a fixed order (see the per-hop form above); workspace: d_bi_in, which only
+    // the per-hop form uses
     GemmGroup g{};
     g.n = 0;
+    int64_t ws_need = 0, ws_have = 0;
+    for (int l = 0; l < p->n_layers; ++l) {
+      ws_need += 2 * colsum_ws_floats(n32, p->dim[l + 1]);
+      ws_have = std::max<int64_t>(ws_have, N * static_cast<int64_t>(std::max(p->dim[l], p->dim[l + 1])));
+    }
+    float* ws = p->d_bi_in && ws_need <= ws_have ? p->d_bi_in : nullptr;
     for (int l = 0; l < p->n_layers; ++l) {
       const int di = p->dim[l], dout = p->dim[l + 1];
       g.p[g.n++] = make_gemm(kTNm, dout, di, n32, p->d_sum_l[l], dout, p->side[l], di, p->g_gc_w[l], di, nullptr, 0,
                              nullptr, 0, true);
       g.p[g.n++] = make_gemm(kTNm, dout, di, n32, p->d_bi_l[l], dout, p->bi_in[l], di, p->g_bi_w[l], di, nullptr, 0,
                              nullptr, 0, true);
-      g.p[g.n++] = make_colsum(p->d_sum_l[l], n32, dout, dout, p->g_gc_b[l]);
-      g.p[g.n++] = make_colsum(p->d_bi_l[l], n32, dout, dout, p->g_bi_b[l]);
+      g.p[g.n++] = make_colsum(p->d_sum_l[l], n32, dout, dout, p->g_gc_b[l], ws);
+      if (ws) ws += colsum_ws_floats(n32, dout);
+      g.p[g.n++] = make_colsum(p->d_bi_l[l], n32, dout, dout, p->g_bi_b[l], ws);
+      if (ws) ws += colsum_ws_floats(n32, dout);
     }
     if (int rc = launch_group(g, st)) return rc;
+    if (int rc = launch_colsum_reduce(g, st)) return rc;
   }
   return 0;
 }

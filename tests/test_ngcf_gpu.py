@@ -15,7 +15,7 @@ from helpers import load_golden
 from oracle import lightgcn_numpy as olg
 from oracle import ngcf_numpy as onp
 from test_oracle_golden_ngcf import CASES, ngcf_adj, ngcf_band, ngcf_batch, ngcf_grad_rel, ngcf_masks
-from test_oracle_golden_ngcf import ngcf_opt_state, ngcf_params
+from test_oracle_golden_ngcf import ngcf_opt_state, ngcf_params  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -83,8 +83,7 @@ def test_step_matches_reference(hip_device, case, spmm):
         g_ref = ngcf_params(g, f"g{s + 1}")
         _, exact = onp.ngcf_grads(w0, adj, *batch, decay, B, ngcf_masks(g, s), drop, dt=np.float64)
         for k in w0:
-            assert_as_accurate_as_reference(grads[k].cpu().numpy(), g_ref[k], exact[k], what=f"grad {k} step {s}",
-                                            ref_factor=3.0 if k.endswith(".bias") else 2.0)
+            assert_as_accurate_as_reference(grads[k].cpu().numpy(), g_ref[k], exact[k], what=f"grad {k} step {s}")
         load_opt_state(eng, st0)
         torch.manual_seed(2000 + s)
         loss2, reg2 = eng.train_single_batch(batch)
@@ -128,10 +127,25 @@ def test_trajectory_matches_reference(hip_device):
         torch.manual_seed(2000 + s)
         loss, _ = eng.train_single_batch(ngcf_batch(g, s))
         assert_scalar_close(loss, g["losses"][s], 5e-5, what=f"loss step {s}")
-    w = get_weights(eng)
-    for k in w:
-        frac_bad = np.mean(np.abs(w[k] - g[f"w{n_steps}/{k}"]) > 1e-3 * float(g["lr"]) + 1e-6)
-        assert frac_bad < 0.02, f"{k}: {frac_bad:.2%} off trajectory"
+    # every element on the reference's trajectory.  The legal envelope comes from oracle runs (the reference's own
+    # dropout masks) whose gradients are moved by what a gradient may differ by: 1e-5 of its scale + what the
+    # reference's fp32 gradient itself is away from the exact (fp64) one (ngcf_grad_rel; the last hop's row
+    # normalisation cancels) -- helpers.oracle_trajectory
+    from helpers import assert_on_trajectory, oracle_trajectory
+
+    adj, decay, lr = ngcf_adj(g), float(g["decay"]), float(g["lr"])
+    rel = {}
+    for s in range(n_steps):
+        w_s = ngcf_params(g, f"w{s}")
+        _, exact = onp.ngcf_grads(w_s, adj, *ngcf_batch(g, s), decay, B, ngcf_masks(g, s), drop, dt=np.float64)
+        for k, v in ngcf_grad_rel(ngcf_params(g, f"g{s + 1}"), exact).items():
+            rel[k] = max(rel.get(k, 0.0), v)
+    steps_np = [(ngcf_batch(g, s), ngcf_masks(g, s)) for s in range(n_steps)]
+    _, env, upd = oracle_trajectory(
+        ngcf_params(g, "w0"), steps_np,
+        lambda w, b: onp.ngcf_grads(w, adj, b[0][0], b[0][1], b[0][2], decay, B, b[1], drop)[1],
+        lambda w, gr, st: onp.opt_step(w, gr, st, "adam", lr), lambda w: onp.new_opt_state(w, "adam"), rel=rel)
+    assert_on_trajectory(get_weights(eng), ngcf_params(g, f"w{n_steps}"), env, upd, "NGCF trajectory", rel=rel)
 
 
 def ml1m_graph(U, I, n_edges, seed):
@@ -168,8 +182,7 @@ def test_ml1m_sized_graph_vs_oracle(hip_device, D, layers, drop, optimizer, spmm
     _, exact = onp.ngcf_grads(w, adj, *batch, 1e-5, B, masks, drop, dt=np.float64)
     assert_scalar_close(loss, loss_o, what="loss")
     for k in w:
-        assert_as_accurate_as_reference(grads[k].cpu().numpy(), g_o[k], exact[k], what=f"grad {k}",
-                                        ref_factor=3.0 if k.endswith(".bias") else 2.0)
+        assert_as_accurate_as_reference(grads[k].cpu().numpy(), g_o[k], exact[k], what=f"grad {k}")
     # rows of nodes no triple touched still receive gradient through the graph, but a user with no
     # edge at all and no triple keeps a zero row
     deg = np.asarray((adj != 0).sum(1)).ravel()

@@ -52,7 +52,7 @@ def ngcf_opt_state(g, step, opt):
 
 def ngcf_grad_rel(g_ref, exact, rel=REL):
     """Per tensor: the relative gradient error assert_as_accurate_as_reference admits."""
-    return {k: rel + 3.0 * float(np.abs(g_ref[k] - exact[k]).max()) / float(np.abs(exact[k]).max()) for k in g_ref}
+    return {k: rel + 2.0 * float(np.abs(g_ref[k] - exact[k]).max()) / float(np.abs(exact[k]).max()) for k in g_ref}
 
 
 def ngcf_band(w_prev, st_prev, g_ref, opt, lr, rel=REL):

@@ -424,11 +424,10 @@ def test_two_rank_sharded_ncf_equals_single_process(tmp_path, kind, optimizer, l
     for batch, loss in zip(res["batches"], res["losses"]):
         ref = onc.ncf_train_step(w, st, batch, kind, optimizer, lr)
         assert_scalar_close(loss, ref, 2e-5, "loss")
-    tol = 1e-6 if optimizer == "sgd" else 2e-3
-    assert set(res["full"]) == set(w)
-    for k in w:
-        assert res["full"][k].shape == w[k].shape, k
-        assert np.mean(np.abs(res["full"][k] - w[k]) > tol) < 0.01, f"{k} differs from the single-process run"
+    from helpers import assert_ncf_end_state
+
+    assert set(res["full"]) == set(w) and all(res["full"][k].shape == w[k].shape for k in w)
+    assert_ncf_end_state(res["full"], res["w0"], res["batches"], kind, optimizer, lr, f"sharded {kind}")
 
 
 # ---- epoch-planned sharded SGD (ShardedMFEngine.plan_epoch / run_planned_epoch) on gloo ------------------------------

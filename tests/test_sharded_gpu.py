@@ -11,7 +11,7 @@ import pytest
 import torch
 import torch.distributed as dist
 
-from helpers import KEYS, assert_scalar_close
+from helpers import KEYS, assert_mf_end_state, assert_ncf_end_state, assert_scalar_close
 from oracle import mf_numpy as onp
 
 pytestmark = pytest.mark.gpu
@@ -45,18 +45,17 @@ def test_sharded_step_with_hip_kernels(nccl_group, optimizer, lr, routing, sgd_m
     w = onp.copy_params(w0)
     st = onp.new_opt_state(w, optimizer)
     rng = np.random.default_rng(0)
+    batches = []
     for _ in range(3):
         batch = (rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B))
         batch[1][: B // 4] = batch[1][0]
+        batches.append(batch)
         loss, reg = eng.train_single_batch(tuple(torch.from_numpy(a) for a in batch))
         ref_loss, ref_reg = onp.mf_train_step(w, st, batch, "bpr", optimizer, lr)
         assert_scalar_close(loss, ref_loss, 2e-5, "loss")
         assert_scalar_close(reg, ref_reg, 2e-5, "reg")
-    full = eng.gather_full_state_dict()
-    tol = 1e-6 if optimizer == "sgd" else 2e-3
-    for k in KEYS:
-        frac_bad = np.mean(np.abs(full[k].cpu().numpy() - w[k]) > tol)
-        assert frac_bad < 0.01, f"{k}: {frac_bad:.2%} differ"
+    full = {k: v.cpu().numpy() for k, v in eng.gather_full_state_dict().items()}
+    assert_mf_end_state(full, w0, batches, optimizer, lr, f"{routing} routing")
 
 
 @pytest.mark.parametrize("optimizer,lr", [("sgd", 0.1), ("adam", 0.05)])
@@ -75,18 +74,17 @@ def test_replicated_engine_with_hip_kernels(nccl_group, optimizer, lr):
     w = onp.copy_params(w0)
     st = onp.new_opt_state(w, optimizer)
     rng = np.random.default_rng(1)
-    batches = []
+    batches, np_batches = [], []
     for _ in range(3):
         batch = (rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B))
+        np_batches.append(batch)
         batches.append(tuple(torch.from_numpy(a) for a in batch))
         loss, reg = eng.train_single_batch(batches[-1])
         ref_loss, ref_reg = onp.mf_train_step(w, st, batch, "bpr", optimizer, lr)
         assert_scalar_close(loss, ref_loss, 2e-5, "loss")
         assert_scalar_close(reg, ref_reg, 2e-5, "reg")
     got = {k: v.cpu().numpy() for k, v in eng.model.state_dict().items()}
-    tol = 1e-6 if optimizer == "sgd" else 2e-3
-    for k in KEYS:
-        assert np.mean(np.abs(got[k] - w[k]) > tol) < 0.01, k
+    assert_mf_end_state(got, w0, np_batches, optimizer, lr, "replicated steps")
     with contextlib.redirect_stdout(io.StringIO()):
         eng.train_an_epoch(batches, 1)
     assert len(eng.writer.scalars) == 2
@@ -136,12 +134,14 @@ def test_replicated_fused_epoch_with_hip_kernels(nccl_group, optimizer, lr):
     w = onp.copy_params(w0)
     st = onp.new_opt_state(w, optimizer)
     rng = np.random.default_rng(3)
+    np_batches = []
     for epoch, n_steps in enumerate((3, 4)):            # odd and even: both final ping-pong positions
         total = 0.0
         eng.fused_epoch_begin()
         for s in range(n_steps):
             nb = B if s < n_steps - 1 else 77           # short last batch
             batch = (rng.integers(0, U, nb), rng.integers(0, 30, nb), rng.integers(0, I, nb))
+            np_batches.append(batch)
             eng.fused_step(*(torch.from_numpy(a).cuda() for a in batch))
             loss, _ = onp.mf_train_step(w, st, batch, "bpr", optimizer, lr)
             total += loss
@@ -152,9 +152,7 @@ def test_replicated_fused_epoch_with_hip_kernels(nccl_group, optimizer, lr):
         assert all(float(b[eng._scratch.numel() // 4:].abs().max()) == 0.0 for b in eng._fe["bufs"])
     assert eng.epoch_stats().step == 7
     got = {k: v.cpu().numpy() for k, v in eng.model.state_dict().items()}
-    tol = 1e-5 if optimizer == "sgd" else 2e-3
-    for k in KEYS:
-        assert np.mean(np.abs(got[k] - w[k]) > tol * max(np.abs(w[k]).max(), 1e-3)) < 0.01, k
+    assert_mf_end_state(got, w0, np_batches, optimizer, lr, "replicated fused epochs")
     # the per-batch path still works afterwards and continues from the same state
     batch = tuple(torch.from_numpy(rng.integers(0, n, B)) for n in (U, I, I))
     loss, _ = eng.train_single_batch(batch)
@@ -205,6 +203,15 @@ def test_replicated_epoch_driver_calls_rccl_itself(nccl_group, optimizer):
         with contextlib.redirect_stdout(io.StringIO()):
             eng = ReplicatedMFEngine(cfg)
         loader = hp.DeviceTripleBatcher(*data, B)
+        w_start = {k: v.cpu().numpy().copy() for k, v in eng.model.state_dict().items()}
+        # the batches the three epochs will visit: the engine shuffles with seeds drawn from torch's CPU generator
+        # (DeviceTripleBatcher.draw_seed) -- replay the draws, then rewind the generator
+        rng_state = torch.get_rng_state()
+        visited = []
+        for _ in range(3):
+            perm = loader.permutation().cpu().numpy()
+            visited += [tuple(d.cpu().numpy()[perm[k:k + B]] for d in data) for k in range(0, n, B)]
+        torch.set_rng_state(rng_state)
         sums = []
         with contextlib.redirect_stdout(io.StringIO()):
             for epoch in range(2):
@@ -215,12 +222,12 @@ def test_replicated_epoch_driver_calls_rccl_itself(nccl_group, optimizer):
             sums.append(eng._sync_stats().loss_sum)
         assert (eng._direct_comm is not None) == (mode == "rccl")
         assert eng.epoch_stats().step == 18
-        out[mode] = (sums, {k: v.cpu().numpy() for k, v in eng.model.state_dict().items()})
+        out[mode] = (sums, {k: v.cpu().numpy() for k, v in eng.model.state_dict().items()}, w_start, visited)
     for a, b in zip(out["rccl"][0], out["torch"][0]):
         assert_scalar_close(a, b, 2e-5, "epoch loss sums of the two drivers")
-    for k in KEYS:
-        scale = max(np.abs(out["torch"][1][k]).max(), 1e-3)
-        assert np.mean(np.abs(out["rccl"][1][k] - out["torch"][1][k]) > 2e-3 * scale) < 0.01, k
+    # both drivers ran the same three epochs (same shuffle seeds): both end states lie on the oracle's trajectory
+    for mode in ("rccl", "torch"):
+        assert_mf_end_state(out[mode][1], out[mode][2], out[mode][3], optimizer, 0.02, f"{mode} driver")
 
 
 def test_replicated_ncf_engine_with_hip_kernels(nccl_group):
@@ -239,17 +246,19 @@ def test_replicated_ncf_engine_with_hip_kernels(nccl_group):
     with contextlib.redirect_stdout(io.StringIO()):
         eng = replicated_ncf_engine(hp.NeuMFEngine)(cfg)
     w = {k: v.detach().cpu().numpy().copy() for k, v in eng.model.state_dict().items()}
+    w_start = {k: v.copy() for k, v in w.items()}
     st = onc.new_opt_state(w, "adam")
     rng = np.random.default_rng(4)
+    batches = []
     for _ in range(3):
         users, items = rng.integers(0, U, B), rng.integers(0, I, B)
         ratings = (rng.random(B) < 0.3).astype(np.float32)
+        batches.append((users, items, ratings))
         loss = eng.train_single_batch(torch.from_numpy(users), torch.from_numpy(items), torch.from_numpy(ratings))
         ref = onc.ncf_train_step(w, st, (users, items, ratings), "neumf", "adam", 1e-3)
         assert_scalar_close(loss, ref, 2e-5, "loss")
     got = {k: v.cpu().numpy() for k, v in eng.model.state_dict().items()}
-    for k in w:
-        assert np.mean(np.abs(got[k] - w[k]) > 2e-3 * max(np.abs(w[k]).max(), 1e-3)) < 0.01, k
+    assert_ncf_end_state(got, w_start, batches, "neumf", "adam", 1e-3, "replicated NeuMF")
 
 
 @pytest.mark.parametrize("kind,emb", [("neumf", 32), ("neumf", 8), ("gmf", 16), ("mlp", 16)])
@@ -272,20 +281,21 @@ def test_sharded_ncf_engine_with_hip_kernels(nccl_group, kind, emb):
            "mlp": sharded_ncf.ShardedMLPEngine}[kind]
     eng = cls(cfg, full_state=full)
     w = {k: v.numpy().copy() for k, v in full.items()}
+    w_start = {k: v.copy() for k, v in w.items()}
     st = onc.new_opt_state(w, "adam")
     rng = np.random.default_rng(1)
+    batches = []
     for _ in range(3):
         users, items = rng.integers(0, U, B), rng.integers(0, I, B)
         items[: B // 4] = items[0]
         ratings = (rng.random(B) < 0.2).astype(np.float32)
+        batches.append((users, items, ratings))
         loss = eng.train_single_batch(users, items, ratings)
         ref = onc.ncf_train_step(w, st, (users, items, ratings), kind, "adam", 0.01)
         assert_scalar_close(loss, ref, 2e-5, "loss")
-    out = eng.gather_full_state_dict()
-    for k in w:
-        got = out[k].cpu().numpy()
-        assert got.shape == w[k].shape
-        assert np.mean(np.abs(got - w[k]) > 2e-3) < 0.01, f"{k}: differs from the single-process run"
+    out = {k: v.cpu().numpy() for k, v in eng.gather_full_state_dict().items()}
+    assert set(out) == set(w) and all(out[k].shape == w[k].shape for k in w)
+    assert_ncf_end_state(out, w_start, batches, kind, "adam", 0.01, f"sharded {kind}")
     with pytest.raises(IndexError):
         eng.train_single_batch(np.array([U]), np.array([0]), np.array([1.0], dtype=np.float32))
 
