@@ -313,6 +313,7 @@ def bench_ncf(args, device, world=1, rank=0, dist_on=False):
     st = eng._sync_stats()
     if rank != 0:
         return None
+    traffic, traffic_src = traffic_step_from_profiles("ncf" if E == 32 else "ncf64")
     dims = [2 * E * 2 ** (L - 1)] + [E * 2 ** (L - 1 - i) for i in range(L)]      # 256,128,64,32 at E 32
     macs = sum(a * b for a, b in zip(dims[:-1], dims[1:])) + 2 * E                # tower + head (E mlp + E mf)
     flops = 3 * 2 * macs                                                          # fwd + dgrad + wgrad per sample
@@ -332,8 +333,17 @@ def bench_ncf(args, device, world=1, rank=0, dist_on=False):
                            "last_loss": st.loss},
                 "roofline": {"bound": "mfma", "achieved": B * flops / step_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                              "frac": B * flops / step_s / 1e12 / 157.3, "flops_per_sample": flops,
-                             "note": "whole step (all launches) against the dense fp32 MFMA peak; traffic not collected",
-                             "traffic": None}})
+                             "note": "whole step (all launches) against the dense fp32 MFMA peak; traffic = HBM bytes of "
+                                     "the step's launches from the committed PMC passes",
+                             "traffic": traffic, "traffic_source": traffic_src}})
+    if not args.no_cpu_baseline and world == 1:
+        from oracle.torch_port import TorchNeuMFPort   # the reference's ATen op sequence (ncf.py:52-71, 100-120)
+
+        w0 = {k: v.detach().cpu().numpy() for k, v in eng.model.state_dict().items()}
+        cu, ci, cr = (t[: 16 * B].cpu() for t in (users, items, ratings))
+        batches = [(cu[k * B:(k + 1) * B], ci[k * B:(k + 1) * B], cr[k * B:(k + 1) * B]) for k in range(16)]
+        out["cpu_baseline"] = port_baseline(lambda: TorchNeuMFPort(w0, "adam", 1e-3), batches, B,
+                                            f"NeuMF emb_dim {E}, batch {B}", unit="samples/s")
     return out
 
 
@@ -441,6 +451,24 @@ def bench_mf_c4shard(args, device, full=False):
                              "algorithmic_bytes_per_launch": bpt * Bc, "kernel_us": k_s * 1e6,
                              "traffic": traffic, "traffic_source": traffic_src,
                              "step_frac": out["value"] * bpt / (HBM_PEAK_GBS * 1e9)}})
+    if not args.no_cpu_baseline:
+        # the reference's CPU path at this size: nn.Embedding is non-sparse, so every step materialises DENSE gradients
+        # of both tables (mf.py:117) and torch.optim.SGD sweeps them -- a bounded sample of a few steps
+        from oracle.torch_port import TorchMFPort
+
+        del eng, prepared
+        torch.cuda.empty_cache()
+        gcpu = torch.Generator().manual_seed(3)
+        w0 = {"user_emb.weight": torch.empty(Uc, Dc).normal_(0, 0.1, generator=gcpu),
+              "item_emb.weight": torch.empty(Ic, Dc).normal_(0, 0.1, generator=gcpu),
+              "user_bias.weight": torch.zeros(Uc, 1), "item_bias.weight": torch.zeros(Ic, 1),
+              "global_bias": torch.zeros(1)}
+        cu, cp, cn = (t[: 4 * Bc].cpu() for t in (users, pos, neg))
+        batches = [(cu[k * Bc:(k + 1) * Bc], cp[k * Bc:(k + 1) * Bc], cn[k * Bc:(k + 1) * Bc]) for k in range(4)]
+        nt = min(32, torch.get_num_threads())
+        out["cpu_baseline"] = port_baseline(lambda: TorchMFPort(w0, "sgd", LR, "bpr"), batches, Bc,
+                                            f"BPR-MF {Uc} x {Ic} x {Dc}, batch {Bc}, torch.optim.SGD over dense gradients",
+                                            budget_s=10.0, thread_counts=[nt])
     return out
 
 
@@ -521,11 +549,19 @@ def bench_lightgcn(args, device, world=1, rank=0, dist_on=False):
     import beta_recsys_amd as hp
 
     L, Bl = 3, 1024
+    # ML-1M degree profile, 988 k UNIQUE train edges => nnz(D^-1 (A + I)) = 2 x 988 000 + 9 746 = 1.99 M
+    # (rounds 1-2 drew 1 M edges with duplicates: 745 k unique, nnz 1.49 M).  Zipf items, duplicates redrawn.
     rng = np.random.default_rng(0)
-    n_edges = 1_000_000
+    n_edges = 988_000
     p = 1.0 / np.arange(1, I + 1) ** 0.9
-    eu = rng.integers(0, U, n_edges)
-    ei = rng.permutation(I)[rng.choice(I, n_edges, p=p / p.sum())]
+    p /= p.sum()
+    item_of = rng.permutation(I)
+    pairs = np.zeros(0, dtype=np.int64)
+    while pairs.size < n_edges:
+        m = int((n_edges - pairs.size) * 1.3) + 1000
+        pairs = np.unique(np.concatenate([pairs, rng.integers(0, U, m) * I + item_of[rng.choice(I, m, p=p)]]))
+    pairs = rng.permutation(pairs)[:n_edges]
+    eu, ei = pairs // I, pairs % I
     # the reference's norm_adj = D^-1 (A + I) over users + items (data/deprecated_data_base.py:331-353 +
     # utils/common_util.py normalized_adj_single), built once on the host like the reference does
     import scipy.sparse as sp
@@ -533,9 +569,9 @@ def bench_lightgcn(args, device, world=1, rank=0, dist_on=False):
     n_nodes = U + I
     rows, cols = np.concatenate([eu, ei + U]), np.concatenate([ei + U, eu])
     a = sp.coo_matrix((np.ones(len(rows), dtype=np.float32), (rows, cols)), shape=(n_nodes, n_nodes)).tocsr()
-    a.data[:] = 1.0  # duplicate interactions are one edge
     a = a + sp.eye(n_nodes, dtype=np.float32, format="csr")
     adj = sp.diags(1.0 / np.asarray(a.sum(1)).flatten()).dot(a).astype(np.float32).tocoo()
+    assert adj.nnz == 2 * n_edges + n_nodes
     idx = torch.from_numpy(np.vstack((adj.row, adj.col)).astype(np.int64))
     norm = torch.sparse_coo_tensor(idx, torch.from_numpy(adj.data), torch.Size(adj.shape))
     cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, layer_size=[D] * L, keep_pro=0.6, regs=[1e-5],
@@ -560,6 +596,7 @@ def bench_lightgcn(args, device, world=1, rank=0, dist_on=False):
     if rank != 0:
         return None
     nnz, N = adj.nnz, U + I
+    traffic, traffic_src = traffic_step_from_profiles("lightgcn")
     # 2L SpMMs x [nnz*(4+4) + (N+1)*8 + 2*N*D*4] bytes (+ the keep byte per edge)
     bytes_step = 2 * L * (nnz * 9 + (N + 1) * 8 + 2 * N * D * 4)
     out = {"metric": "training interactions/sec (LightGCN triples)", "unit": "triples/s"}
@@ -574,16 +611,25 @@ def bench_lightgcn(args, device, world=1, rank=0, dist_on=False):
                            "last_loss": st.loss},
                 "roofline": {"bound": "hbm", "algorithmic_bytes_per_step": bytes_step,
                              "achieved": bytes_step / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": bytes_step / step_s / 1e9 / HBM_PEAK_GBS, "traffic": None}})
+                             "frac": bytes_step / step_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                             "traffic_source": traffic_src}})
+    if not args.no_cpu_baseline and world == 1:
+        from oracle.torch_port import TorchLightGCNPort   # torch.sparse.mm, lightgcn.py:46-78, 119-152
+
+        w0 = {k: v.detach().cpu().numpy() for k, v in eng.model.state_dict().items()}
+        cu, cp, cn = (t[: 8 * Bl].cpu() for t in (users, pos, neg))
+        batches = [(cu[k * Bl:(k + 1) * Bl], cp[k * Bl:(k + 1) * Bl], cn[k * Bl:(k + 1) * Bl]) for k in range(8)]
+        out["cpu_baseline"] = port_baseline(lambda: TorchLightGCNPort(w0, norm, L, 0.6, 1e-5, "adam", 0.05), batches, Bl,
+                                            f"LightGCN on the same graph (nnz {nnz}), batch {Bl}")
     return out
 
 
-def port_baseline(make_port, batches, units_per_step, what, budget_s=9.0):
+def port_baseline(make_port, batches, units_per_step, what, budget_s=9.0, unit="triples/s", thread_counts=None):
     """cpu_baseline for the sibling workloads: the reference's ATen op sequence (oracle/torch_port.py,
     pinned on goldens from the real reference) on this box's host cores, bounded sample, best of a few
     intra-op thread counts (cores = the count that won)."""
     all_threads = torch.get_num_threads()
-    candidates = sorted({all_threads, min(32, all_threads), min(8, all_threads)}, reverse=True)
+    candidates = thread_counts or sorted({all_threads, min(32, all_threads), min(8, all_threads)}, reverse=True)
     best = None
     for nt in candidates:
         torch.set_num_threads(nt)
@@ -599,7 +645,7 @@ def port_baseline(make_port, batches, units_per_step, what, budget_s=9.0):
             best = (steps, nt, units_per_step, dt)
     torch.set_num_threads(all_threads)
     steps, nt, units, dt = best
-    return {"value": steps * units / dt, "unit": "triples/s", "cores": nt, "kind": "port",
+    return {"value": steps * units / dt, "unit": unit, "cores": nt, "kind": "port",
             "sample": f"{steps} steps of {what} in {dt:.1f} s with {nt} ATen threads (best of {candidates}); "
                       f"PyTorch-CPU op sequence of the reference; host has {os.cpu_count()} logical cpus"}
 
@@ -776,6 +822,24 @@ def traffic_from_profiles(kernel, workload=None):
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 k = json.load(f)[workload][kernel]
             return (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0, "profiles/" + name
+        except Exception:
+            continue
+    return None, None
+
+
+def traffic_step_from_profiles(workload):
+    """HBM bytes per STEP of a workload: (FETCH_SIZE + WRITE_SIZE) x launches per step summed over its kernels, from
+    the committed per-workload PMC passes (profiles/rNN_pmc_other_workloads.json: KB per dispatch and the number
+    of dispatches of every kernel).  (bytes | None, source | None)."""
+    for rnd in (ROUND, "r02"):
+        try:
+            name = f"{rnd}_pmc_other_workloads.json"
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                ks = json.load(f)[workload]
+            # every workload ends its step with ONE dense optimizer sweep: its dispatch count is the number of steps
+            steps = max(k["n"] for name_, k in ks.items() if "opt_dense_kernel" in name_)
+            tot = sum((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 * k["n"] / steps for k in ks.values())
+            return tot, "profiles/" + name
         except Exception:
             continue
     return None, None

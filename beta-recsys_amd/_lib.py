@@ -233,6 +233,11 @@ SIGNATURES = {
         c_int,
         [POINTER(NcfPlan), _P, _P, _P, c_int64, c_float, _P, _P, c_size_t, _P],
     ),
+    "hiprec_ncf_step": (
+        c_int,
+        [POINTER(NcfPlan), _P, _P, _P, c_int64, c_float, c_int, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_double,
+         c_double, c_double, c_double, _P, _P, c_size_t, _P],
+    ),
     "hiprec_lightgcn_plan_bytes": (c_size_t, []),
     "hiprec_spmm_csr": (c_int, [POINTER(Csr), _P, c_float, _P, _P, _P, c_int32, _P]),
     "hiprec_sliced_width": (c_int32, [c_int64, c_int32]),

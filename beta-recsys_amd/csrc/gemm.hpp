@@ -40,10 +40,22 @@ struct GemmProblem {
   float* ws;
 };
 
+// A dense optimizer sweep that rides in the grouped launch as its first n_blocks blocks: elements [0, 4 * n4) of the
+// flat buffers (parameters whose gradient is already complete when the grouped launch starts -- the embedding tables
+// of an NCF step -- while the GEMM problems of the same grid still produce the other gradients).  n_blocks = 0: none.
+struct SweepArgs {
+  float *w, *g, *m, *v;
+  int64_t n4;
+  int kind, n_blocks, first_block;
+  OptScalars s;
+  const hiprec_stats* stats;
+};
+
 constexpr int kMaxGroup = 16;
 struct GemmGroup {
   int n;
   GemmProblem p[kMaxGroup];
+  SweepArgs sweep;
 };
 
 // split_k: let the launcher split K over several blocks that accumulate with atomics into a

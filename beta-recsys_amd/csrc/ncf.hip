@@ -175,9 +175,41 @@ __device__ __forceinline__ void colsum_tile(float* s_flat, const GemmProblem& q,
 // Grouped launch: up to kMaxGroup independent problems share one grid (the backward pass of one
 // Linear layer is three of them reading the same dZ: weight gradient, bias gradient, input
 // gradient; each is a ~10 us latency-bound launch on its own at batch 4096).
+template <int KIND>
+__device__ __forceinline__ void sweep_blocks(const SweepArgs& a) {
+  float step_size, bc2_sqrt;
+  step_scalars<KIND>(a.s, a.stats, &step_size, &bc2_sqrt);
+  float4* w4 = reinterpret_cast<float4*>(a.w);
+  float4* g4 = reinterpret_cast<float4*>(a.g);
+  float4* m4 = reinterpret_cast<float4*>(a.m);
+  float4* v4 = reinterpret_cast<float4*>(a.v);
+  const int64_t stride = static_cast<int64_t>(a.n_blocks) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x - a.first_block) * kBlock + threadIdx.x; i < a.n4; i += stride) {
+    float4 wv = w4[i], gv = g4[i];
+    float4 mv = make_float4(0, 0, 0, 0), vv = make_float4(0, 0, 0, 0);
+    if constexpr (KIND == HIPREC_OPT_ADAM) mv = m4[i];
+    if constexpr (KIND != HIPREC_OPT_SGD) vv = v4[i];
+    opt_update<KIND>(wv.x, gv.x, mv.x, vv.x, a.s, step_size, bc2_sqrt);
+    opt_update<KIND>(wv.y, gv.y, mv.y, vv.y, a.s, step_size, bc2_sqrt);
+    opt_update<KIND>(wv.z, gv.z, mv.z, vv.z, a.s, step_size, bc2_sqrt);
+    opt_update<KIND>(wv.w, gv.w, mv.w, vv.w, a.s, step_size, bc2_sqrt);
+    w4[i] = wv;
+    g4[i] = gv;
+    if constexpr (KIND == HIPREC_OPT_ADAM) m4[i] = mv;
+    if constexpr (KIND != HIPREC_OPT_SGD) v4[i] = vv;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void gemm_group_kernel(GemmGroup g) {
   __shared__ float As[kTM][kTK + 1];
   __shared__ float Bs[kTK][kTN + 1];
+  const int sweep_lo = g.sweep.first_block;
+  if (static_cast<int>(blockIdx.x) >= sweep_lo && static_cast<int>(blockIdx.x) < sweep_lo + g.sweep.n_blocks) {
+    if (g.sweep.kind == HIPREC_OPT_ADAM) sweep_blocks<HIPREC_OPT_ADAM>(g.sweep);
+    else if (g.sweep.kind == HIPREC_OPT_RMSPROP) sweep_blocks<HIPREC_OPT_RMSPROP>(g.sweep);
+    else sweep_blocks<HIPREC_OPT_SGD>(g.sweep);
+    return;
+  }
   int qi = 0;
 #pragma unroll
   for (int i = 1; i < kMaxGroup; ++i)
@@ -273,11 +305,16 @@ int launch_colsum_reduce(const GemmGroup& g, hipStream_t st) {
 }
 
 int launch_group(GemmGroup& g, hipStream_t st) {
+  // the sweep's blocks come LAST: the GEMM tiles (chains of dependent cold misses on what the previous launch wrote)
+  // are dispatched first and the bandwidth-bound sweep fills in behind them.  Measured on the NCF step (r03 exp. 3):
+  // sweep first 64.1 us per step, last 58.1-58.9, no sweep in this launch (a 37 MB sweep of its own) 59.4
   int blocks = 0;
   for (int i = 0; i < g.n; ++i) {
     g.p[i].first_block = blocks;
     blocks += g.p[i].tiles_n * g.p[i].tiles_m * g.p[i].split;
   }
+  g.sweep.first_block = blocks;
+  blocks += g.sweep.n_blocks;
   if (blocks == 0) return 0;
   gemm_group_kernel<<<blocks, kBlock, 0, st>>>(g);
   HIPREC_TRY(hipGetLastError());
@@ -1302,10 +1339,13 @@ extern "C" int hiprec_ncf_forward(const hiprec_ncf_plan* plan, const int64_t* us
   return 0;
 }
 
-extern "C" int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users,
-                               const int64_t* items, const float* ratings, int64_t batch,
-                               float inv_batch, hiprec_stats* stats, void* scratch,
-                               size_t scratch_bytes, void* stream) {
+// sweep (optional): an optimizer sweep of the tables' part of the flat buffers that rides in the grouped weight-
+// gradient launch (the embedding gradients are complete when that launch starts); *swept tells the caller whether
+// that launch existed (the fused forms) or the whole sweep is still owed.
+static int ncf_grad_impl(const hiprec_ncf_plan* plan, const int64_t* users, const int64_t* items,
+                         const float* ratings, int64_t batch, float inv_batch, hiprec_stats* stats, void* scratch,
+                         size_t scratch_bytes, void* stream, const SweepArgs* sweep, bool* swept) {
+  if (swept) *swept = false;
   if (int rc = check_plan(plan, batch, true)) return rc;
   HIPREC_REQUIRE(batch > 0, "empty batch");
   HIPREC_REQUIRE(users && items && ratings && stats && scratch, "NULL pointer");
@@ -1357,6 +1397,10 @@ extern "C" int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users
                              nullptr, 0, /*split_k=*/true);
       g.p[g.n++] = make_colsum(p->dact[l + 1], B, nout, nout, p->g_fc_b[l]);
     }
+    if (sweep && sweep->n_blocks > 0) {
+      g.sweep = *sweep;
+      *swept = true;
+    }
     return launch_group(g, st);
   }
   if (p->dim_mlp > 0) {
@@ -1388,3 +1432,53 @@ extern "C" int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users
   return 0;
 }
 
+
+extern "C" int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users,
+                               const int64_t* items, const float* ratings, int64_t batch,
+                               float inv_batch, hiprec_stats* stats, void* scratch,
+                               size_t scratch_bytes, void* stream) {
+  return ncf_grad_impl(plan, users, items, ratings, batch, inv_batch, stats, scratch, scratch_bytes, stream, nullptr,
+                       nullptr);
+}
+
+// hiprec_ncf_grad + optimizer.step() (ncf.py:100-120) as ONE call.  The flat buffers hold [tables | tower | head];
+// the first table_floats elements (a multiple of 4) are the embedding tables, whose gradients are complete after
+// the forward + chain launch: their share of the dense sweep -- 97 % of the parameters at ncf_default.json's shape --
+// runs as extra blocks of the grouped weight-gradient launch, and only the tower / head tail (tens of thousands of
+// parameters) keeps a launch of its own behind it.  Round 2: 3 launches, the last one a 37 MB sweep (9.7 us of 59).
+extern "C" int hiprec_ncf_step(const hiprec_ncf_plan* plan, const int64_t* users, const int64_t* items,
+                               const float* ratings, int64_t batch, float inv_batch, int kind, float* w_flat,
+                               float* g_flat, float* m_flat, float* v_flat, int64_t n_flat, int64_t table_floats,
+                               int64_t scalar_index, double lr, double beta1, double beta2, double eps,
+                               hiprec_stats* stats, void* scratch, size_t scratch_bytes, void* stream) {
+  HIPREC_REQUIRE(w_flat && g_flat && stats && scratch, "NULL pointer");
+  HIPREC_REQUIRE(n_flat > 0 && table_floats >= 0 && table_floats <= n_flat, "bad flat sizes");
+  HIPREC_REQUIRE(kind == HIPREC_OPT_SGD || (kind == HIPREC_OPT_ADAM && m_flat && v_flat) ||
+                     (kind == HIPREC_OPT_RMSPROP && v_flat),
+                 "optimizer state missing / unknown optimizer");
+  HIPREC_REQUIRE(scalar_index < 0 || scalar_index >= table_floats, "the deferred scalar lies behind the tables");
+  SweepArgs sw{};
+  const bool aligned = (table_floats & 3) == 0 && (reinterpret_cast<uintptr_t>(w_flat) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(g_flat) & 15) == 0 && (reinterpret_cast<uintptr_t>(m_flat) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(v_flat) & 15) == 0;
+  if (aligned && table_floats >= (1 << 16)) {
+    sw.w = w_flat;
+    sw.g = g_flat;
+    sw.m = m_flat;
+    sw.v = v_flat;
+    sw.n4 = table_floats >> 2;
+    sw.kind = kind;
+    sw.n_blocks = static_cast<int>(std::min<int64_t>((sw.n4 + kBlock - 1) / kBlock, 2048));  // one 16-byte vector per thread
+    sw.s = OptScalars{lr, static_cast<float>(lr), static_cast<float>(beta2), static_cast<float>(1.0 - beta1),
+                      static_cast<float>(1.0 - beta2), static_cast<float>(eps)};
+    sw.stats = stats;
+  }
+  bool swept = false;
+  if (int rc = ncf_grad_impl(plan, users, items, ratings, batch, inv_batch, stats, scratch, scratch_bytes, stream, &sw,
+                             &swept))
+    return rc;
+  const int64_t done = swept ? table_floats : 0;
+  return hiprec_opt_dense_step(kind, w_flat + done, g_flat + done, m_flat ? m_flat + done : nullptr,
+                               v_flat ? v_flat + done : nullptr, n_flat - done, lr, beta1, beta2, eps, stats, scratch,
+                               scalar_index >= 0 ? scalar_index - done : -1, stream);
+}

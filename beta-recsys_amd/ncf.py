@@ -127,6 +127,17 @@ class _NcfBase(_FlatModel):
             return (None, None, "embedding_user.weight", "embedding_item.weight")
         return ("embedding_user.weight", "embedding_item.weight", None, None)
 
+    def table_floats(self):
+        """How many leading floats of the flat buffers are embedding tables (they come first in the layout)."""
+        tables = {n for n in self._names() if n is not None}
+        end = 0
+        for k, (name, _) in enumerate(self._spec):
+            if name in tables:
+                end = max(end, int(self._offsets[k + 1]))
+        first_dense = min((int(self._offsets[k]) for k, (name, _) in enumerate(self._spec) if name not in tables),
+                          default=end)
+        return end if end <= first_dense else 0
+
     def workspace(self, batch):
         """Activation buffers for up to ``batch`` samples (grown on demand)."""
         dev = self._flat.device
@@ -410,13 +421,13 @@ class _NcfEngine(ModelEngine):
         st = _lib.stream_ptr(dev)
         plan = m.plan(B, self._g_flat)
         m.draw_keep_masks(plan, B)
-        _lib.check(lib.hiprec_ncf_grad(
-            ctypes.byref(plan), _lib.ptr(users), _lib.ptr(items), _lib.ptr(ratings), B, 1.0 / B,
+        # forward + backward + optimizer.step() in one call: the tables' share of the dense sweep rides in the grouped
+        # weight-gradient launch (csrc/ncf.hip hiprec_ncf_step)
+        _lib.check(lib.hiprec_ncf_step(
+            ctypes.byref(plan), _lib.ptr(users), _lib.ptr(items), _lib.ptr(ratings), B, 1.0 / B, opt.kind,
+            _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg), _lib.ptr(opt.exp_avg_sq), m.flat.numel(),
+            m.table_floats(), m.offset_of("affine_output.bias"), opt.lr, opt.beta1, opt.beta2, opt.eps,
             _lib.ptr(self._stats), _lib.ptr(self._scratch), self._scratch.numel(), st))
-        _lib.check(lib.hiprec_opt_dense_step(
-            opt.kind, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),
-            _lib.ptr(opt.exp_avg_sq), m.flat.numel(), opt.lr, opt.beta1, opt.beta2, opt.eps,
-            _lib.ptr(self._stats), _lib.ptr(self._scratch), m.offset_of("affine_output.bias"), st))
 
     def _sync_stats(self):
         st = read_stats(self._stats)

@@ -607,6 +607,17 @@ int hiprec_ncf_forward(const hiprec_ncf_plan* plan, const int64_t* users, const 
 int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users, const int64_t* items,
                     const float* ratings, int64_t batch, float inv_batch, hiprec_stats* stats,
                     void* scratch, size_t scratch_bytes, void* stream);
+/* hiprec_ncf_grad + optimizer.step() (ncf.py:100-120, torch_engine.py:23-39) in ONE call.  The flat buffers hold
+ * [tables | tower | head] (w / g / m / v laid out alike, 16-byte aligned); the first table_floats elements are the
+ * embedding tables: their gradients are complete after the forward + chain launch, so their share of the dense sweep
+ * rides as extra blocks of the grouped weight-gradient launch and only the tower / head tail keeps a launch of its
+ * own.  scalar_index: the element (>= table_floats) whose gradient arrives through the loss partials
+ * (affine_output.bias), or -1.  Shapes outside the fused launches take hiprec_ncf_grad + hiprec_opt_dense_step. */
+int hiprec_ncf_step(const hiprec_ncf_plan* plan, const int64_t* users, const int64_t* items, const float* ratings,
+                    int64_t batch, float inv_batch, int kind, float* w_flat, float* g_flat, float* m_flat,
+                    float* v_flat, int64_t n_flat, int64_t table_floats, int64_t scalar_index, double lr, double beta1,
+                    double beta2, double eps, hiprec_stats* stats, void* scratch, size_t scratch_bytes, void* stream);
+
 
 /* ======================= LightGCN (models/lightgcn.py) ============================================ */
 

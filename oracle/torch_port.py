@@ -200,3 +200,78 @@ class TorchNGCFPort(_Port):
         loss.backward()
         self.opt.step()
         return loss.item()
+
+
+class TorchNeuMFPort(_Port):
+    """NeuMFEngine.train_single_batch as ATen ops (models/ncf.py:52-71, 100-120): four embedding gathers, the tower
+    walked module by module with a ReLU after EVERY module of ``fc_layers`` (Dropout, Linear and ReLU alike -- so the
+    concatenated embeddings are rectified before the first Linear, quirk Q7), GMF product, ``affine_output``,
+    sigmoid, BCELoss(mean), backward, optimizer step.  Weights keyed like the reference's state_dict
+    (``fc_layers.{1,4,7,..}``).  Pinned by tests/golden/ncf_neumf_*.npz (tests/test_torch_ports.py)."""
+
+    def __init__(self, weights, optimizer="adam", lr=1e-3, dropout=0.0):
+        super().__init__(weights, optimizer, lr)
+        self.layers = sorted(int(k.split(".")[1]) for k in weights if k.startswith("fc_layers.") and k.endswith(".weight"))
+        self.dropout, self.training = dropout, True
+
+    def forward(self, users, items):
+        w = self.w
+        mlp = torch.cat([F.embedding(users, w["embedding_user_mlp.weight"]),
+                         F.embedding(items, w["embedding_item_mlp.weight"])], dim=-1)
+        mf = torch.mul(F.embedding(users, w["embedding_user_mf.weight"]), F.embedding(items, w["embedding_item_mf.weight"]))
+        for idx in self.layers:     # module idx - 1 is the Dropout in front of Linear idx, idx + 1 the ReLU behind it
+            mlp = torch.relu(F.dropout(mlp, self.dropout, self.training))
+            mlp = torch.relu(F.linear(mlp, w[f"fc_layers.{idx}.weight"], w[f"fc_layers.{idx}.bias"]))
+            mlp = torch.relu(torch.relu(mlp))
+        logits = F.linear(torch.cat([mlp, mf], dim=-1), w["affine_output.weight"], w["affine_output.bias"])
+        return torch.sigmoid(logits)
+
+    def step(self, batch):
+        users, items = (torch.as_tensor(x, dtype=torch.int64) for x in batch[:2])
+        ratings = torch.as_tensor(batch[2], dtype=torch.float32)
+        self.opt.zero_grad()
+        loss = torch.nn.BCELoss()(self.forward(users, items).view(-1), ratings)
+        loss.backward()
+        self.opt.step()
+        return loss.item()
+
+
+class TorchLightGCNPort(_Port):
+    """LightGCNEngine.train_single_batch as ATen ops (models/lightgcn.py:27-38, 46-78, 119-152, 171-191) on a torch
+    sparse norm_adj: edge dropout drawn with ``torch.rand(nnz)`` from the global CPU generator like the reference
+    (keep where int(rand + keep_prob) != 0, scale 1 / keep_prob), L x ``torch.sparse.mm``, mean over the layer
+    stack, softplus BPR + decay * L2 of the layer-0 rows, backward through the sparse products, optimizer step.
+    Pinned by tests/golden/lightgcn_*.npz (tests/test_torch_ports.py)."""
+
+    def __init__(self, weights, norm_adj, n_layers, keep_prob, decay, optimizer="adam", lr=0.05):
+        super().__init__(weights, optimizer, lr)
+        self.adj, self.n_layers, self.keep, self.decay = norm_adj.coalesce(), n_layers, keep_prob, decay
+        self.training = True
+
+    def propagate(self):
+        w, adj = self.w, self.adj
+        if self.training:
+            keep = (torch.rand(adj.values().numel()) + self.keep).int().bool()
+            adj = torch.sparse_coo_tensor(adj.indices()[:, keep], adj.values()[keep] / self.keep, adj.size())
+        e = torch.cat((w["user_embedding.weight"], w["item_embedding.weight"]), dim=0)
+        embs = [e]
+        for _ in range(self.n_layers):
+            e = torch.sparse.mm(adj, e)
+            embs.append(e)
+        out = torch.mean(torch.stack(embs, dim=1), dim=1)
+        n_users = w["user_embedding.weight"].shape[0]
+        return out[:n_users], out[n_users:]
+
+    def step(self, batch):
+        users, pos, neg = (torch.as_tensor(x, dtype=torch.int64) for x in batch)
+        w = self.w
+        self.opt.zero_grad()
+        ua, ia = self.propagate()
+        u, p, n = ua[users], ia[pos], ia[neg]
+        u0 = F.embedding(users, w["user_embedding.weight"])
+        p0, n0 = F.embedding(pos, w["item_embedding.weight"]), F.embedding(neg, w["item_embedding.weight"])
+        reg = 0.5 * (u0.norm(2).pow(2) + p0.norm(2).pow(2) + n0.norm(2).pow(2)) / float(len(users)) * self.decay
+        loss = torch.mean(F.softplus(torch.sum(u * n, dim=1) - torch.sum(u * p, dim=1))) + reg
+        loss.backward()
+        self.opt.step()
+        return loss.item()

@@ -51,3 +51,45 @@ def test_ngcf_port_follows_the_reference_trajectory(case):
     w = port.numpy_weights()
     for k in w:
         assert_tensor_close(w[k], g[f"w{n_steps}/{k}"], 2e-5, f"final {k}")
+
+
+@pytest.mark.parametrize("case", ["ncf_neumf_adam"])
+def test_neumf_port_follows_the_reference_trajectory(case):
+    """oracle/torch_port.py::TorchNeuMFPort (the cpu_baseline of bench.py --workload ncf) on the golden captured from
+    the real NeuMFEngine: per-step losses and the final weights."""
+    from oracle.torch_port import TorchNeuMFPort
+    from test_oracle_golden_ncf import params
+
+    g = load_golden(case)
+    n_steps = int(g["meta"][5])
+    port = TorchNeuMFPort(params(g, "w0"), str(g["optimizer"]), float(g["lr"]))
+    for s in range(n_steps):
+        assert_scalar_close(port.step((g["users"][s], g["items"][s], g["ratings"][s])), g["losses"][s], 2e-6, f"loss {s}")
+    w = port.numpy_weights()
+    for k in w:
+        assert_tensor_close(w[k], g[f"w{n_steps}/{k}"], 1e-5, f"final {k}")
+
+
+@pytest.mark.parametrize("case", ["lightgcn_adam", "lightgcn_sgd_d64"])
+def test_lightgcn_port_follows_the_reference_trajectory(case):
+    """oracle/torch_port.py::TorchLightGCNPort (the cpu_baseline of bench.py --workload lightgcn): with the reference's
+    torch seeds it drops the same edges (asserted against the golden's masks) and reproduces losses and weights."""
+    from oracle.torch_port import TorchLightGCNPort
+    from test_oracle_golden_lightgcn import golden_adj, golden_mask, params
+
+    g = load_golden(case)
+    U, I, D, L, B, n_steps, seed = (int(x) for x in g["meta"])
+    co = golden_adj(g).tocoo()
+    adj = torch.sparse_coo_tensor(torch.from_numpy(np.vstack((co.row, co.col)).astype(np.int64)),
+                                  torch.from_numpy(co.data.astype(np.float32)), torch.Size(co.shape))
+    port = TorchLightGCNPort(params(g, "w0"), adj, L, float(g["keep"]), float(g["decay"]), str(g["optimizer"]),
+                             float(g["lr"]))
+    for s in range(n_steps):
+        torch.manual_seed(1000 + s)
+        drawn = (torch.rand(int(g["nnz"])) + float(g["keep"])).int().bool().numpy()
+        assert np.array_equal(drawn, golden_mask(g, s)), "the port's draw is the reference's"
+        torch.manual_seed(1000 + s)
+        assert_scalar_close(port.step(tuple(g[k][s] for k in ("users", "pos", "neg"))), g["losses"][s], 5e-6, f"loss {s}")
+    w = port.numpy_weights()
+    for k in w:
+        assert_tensor_close(w[k], g[f"w{n_steps}/{k}"], 2e-5, f"final {k}")
