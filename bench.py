@@ -154,6 +154,8 @@ def make_engine(device, optimizer):
     cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str=str(device), optimizer=optimizer,
                          lr=LR, batch_size=B, loss="bpr"),
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
+    if os.environ.get("HIPREC_BENCH_SGD_MODE"):   # experiments: force MFEngine's sgd_mode (auto | rows | owned | dense)
+        cfg["model"]["sgd_mode"] = os.environ["HIPREC_BENCH_SGD_MODE"]
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
         return hp.MFEngine(cfg)
