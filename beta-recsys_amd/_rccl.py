@@ -69,6 +69,14 @@ class Communicator:
         """True when the grouped send / recv the row-sharded step driver calls from C are all there."""
         return all((self.send_fn, self.recv_fn, self.group_start_fn, self.group_end_fn))
 
+    def all_reduce_sum_(self, tensor):
+        """In-place fp32 sum of a contiguous device tensor over the communicator, enqueued on the current stream by a
+        direct ncclAllReduce call (no torch.distributed host path: ~2 us instead of 10-14 per call)."""
+        rc = self._lib.ncclAllReduce(tensor.data_ptr(), tensor.data_ptr(), tensor.numel(), 7, 0, self.comm,
+                                     torch.cuda.current_stream(tensor.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"ncclAllReduce failed with code {rc}")
+
     def destroy(self):
         if self.comm:
             self._lib.ncclCommDestroy(self.comm)

@@ -17,6 +17,14 @@ class FlatModelEngine(ModelEngine):
     ``self._g_flat``, loss partials into ``self._scratch``)."""
 
     _ready = False
+    # data-parallel replicas (replicated.replicated_flat_engine) set these: every rank works on its share of the
+    # global batch, and a batch MEAN becomes 1 / (local batch x world) so that the sum over ranks is the reference's
+    # gradient on the whole batch
+    _dp_world = 1
+    _dp_rank = 0
+
+    def _batch_share(self):
+        return 1.0 / self._dp_world
 
     def _alloc_extra(self, lib, device):
         """Hook: model-specific workspaces (called once per device, after the common buffers exist)."""
@@ -39,14 +47,15 @@ class FlatModelEngine(ModelEngine):
         """How many leading floats of the flat buffers the optimizer moves (all of them by default)."""
         return self.model.flat.numel()
 
-    def _enqueue_opt(self):
-        """optimizer.step(): the dense sweep, which also folds the loss partials into the stats and leaves
-        the gradient cleared."""
+    def _enqueue_opt(self, fold_partials=True):
+        """optimizer.step(): the dense sweep, which also folds the loss partials into the stats (unless the caller
+        has done that already) and leaves the gradient cleared."""
         lib, m, opt = _lib.load(), self.model, self.optimizer
         _lib.check(lib.hiprec_opt_dense_step(
             opt.kind, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),
             _lib.ptr(opt.exp_avg_sq), self._sweep_floats(), opt.lr, opt.beta1, opt.beta2, opt.eps,
-            _lib.ptr(self._stats), _lib.ptr(self._scratch), -1, _lib.stream_ptr(m.flat.device)))
+            _lib.ptr(self._stats), _lib.ptr(self._scratch) if fold_partials else None, -1,
+            _lib.stream_ptr(m.flat.device)))
 
     def _enqueue_step(self, batch_data):
         self._enqueue_grad(batch_data)

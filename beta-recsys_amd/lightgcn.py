@@ -463,7 +463,7 @@ class LightGCNEngine(FlatModelEngine):
         plan = m.plan(self._g_flat, self.decay)
         _lib.check(lib.hiprec_lightgcn_grad(
             ctypes.byref(plan), _lib.ptr(keep), float(m.config["keep_pro"]) if keep is not None else 1.0,
-            _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), B, 1.0 / B, _lib.ptr(self._stats),
+            _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), B, self._batch_share() / B, _lib.ptr(self._stats),
             _lib.ptr(self._scratch), self._scratch.numel(), _lib.stream_ptr(dev)))
 
     def train_single_batch(self, batch_data):

@@ -266,7 +266,7 @@ class NGCFEngine(FlatModelEngine):
             raise ValueError("empty batch")
         plan = m.plan(self._g_flat, self.decay, self.batch_size, m.draw_keep_masks())
         _lib.check(lib.hiprec_ngcf_grad(ctypes.byref(plan), _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), B,
-                                        1.0 / B, _lib.ptr(self._stats), _lib.ptr(self._scratch),
+                                        self._batch_share() / B, _lib.ptr(self._stats), _lib.ptr(self._scratch),
                                         self._scratch.numel(), _lib.stream_ptr(dev)))
 
     def train_single_batch(self, batch_data):

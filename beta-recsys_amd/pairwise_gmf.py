@@ -143,8 +143,10 @@ class PairwiseGMFEngine(FlatModelEngine):
         w, g = m.tables(), m.tables(self._g_flat)
         st = _lib.stream_ptr(dev)
         _lib.check(lib.hiprec_pgmf_bpr_grad(
-            ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), B, 1.0 / B,
-            float(self.config["pretrain_l2_lambda"]), _lib.ptr(self._stats), _lib.ptr(self._scratch),
+            ctypes.byref(w), ctypes.byref(g), _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), B, self._batch_share() / B,
+            # data-parallel replicas: the lambda ||v|| term (loss and gradient) is added once, on rank 0
+            float(self.config["pretrain_l2_lambda"]) if self._dp_rank == 0 else 0.0, _lib.ptr(self._stats),
+            _lib.ptr(self._scratch),
             self._scratch.numel(), _lib.ptr(self._ws), self._ws.numel(), st))
         if clip:
             _lib.check(lib.hiprec_clip_grad_norm(

@@ -29,6 +29,31 @@ def allreduce_sum_(buf, group=None):
     return buf
 
 
+class DirectAllReduce:
+    """``sum_(buf)``: in-place sum of a flat fp32 buffer over the group.  On GPUs through a communicator of the
+    engine's own and a direct ncclAllReduce call from ctypes (:mod:`_rccl`; torch.distributed's host path costs
+    10-14 us per call, a fifth of a 59 us NCF step) when every rank could make one -- the ranks agree over the torch
+    group -- else (gloo, ``dp_collective: "torch"``) through torch.distributed.  Collective on first use."""
+
+    def __init__(self, group, device, mode="rccl"):
+        self.pg, self.comm = group, None
+        if device.type == "cuda" and mode != "torch" and dist.get_backend(group) == "nccl":
+            from . import _rccl
+
+            comm = _rccl.create_communicator(group, device)
+            if _rccl.all_ranks_agree(comm is not None, group, device):
+                self.comm = comm
+            elif comm is not None:
+                comm.destroy()
+
+    def sum_(self, buf):
+        if self.comm is not None and buf.dtype == torch.float32 and buf.is_contiguous():
+            self.comm.all_reduce_sum_(buf)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+        return buf
+
+
 class ReplicatedMFEngine(MFEngine):
     """``MFEngine`` whose step sums gradients over a process group before the optimizer sweep."""
 
@@ -376,11 +401,16 @@ class _ReplicatedNcfMixin:
         _lib.check(lib.hiprec_finalize_stats(
             _lib.ptr(self._stats), _lib.ptr(self._scratch), ctypes.c_void_p(bias_ptr),
             ctypes.c_void_p(self._tail.data_ptr()), st))
-        allreduce_sum_(self._g_ext, self.pg)
+        self._collective().sum_(self._g_ext)
         _lib.check(lib.hiprec_opt_dense_step(
             opt.kind, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),
             _lib.ptr(opt.exp_avg_sq), m.flat.numel(), opt.lr, opt.beta1, opt.beta2, opt.eps,
             _lib.ptr(self._stats), None, -1, st))
+
+    def _collective(self):
+        if getattr(self, "_dar", None) is None:
+            self._dar = DirectAllReduce(self.pg, self.model.flat.device, self.config["model"].get("dp_collective", "rccl"))
+        return self._dar
 
     def _sync_stats(self):
         """The global (all-reduced) loss of the last step replaces this rank's share."""
@@ -392,3 +422,80 @@ class _ReplicatedNcfMixin:
 def replicated_ncf_engine(engine_cls):
     """Data-parallel variant of NeuMFEngine / GMFEngine / MLPEngine: ``replicated_ncf_engine(NeuMFEngine)(config)``."""
     return type("Replicated" + engine_cls.__name__, (_ReplicatedNcfMixin, engine_cls), {})
+
+
+# ---- every other engine that trains: LightGCN, NGCF, PairwiseGMF, Triple2vec, data-parallel -----------------------
+# The reference trains all of them on one device (models/lightgcn.py:119-152, ngcf.py:118-149, pairwise_gmf.py:82-116,
+# triple2vec.py:94-104); SURVEY 8e: full-graph propagation per step => replicas, no graph partitioning.  A replica
+# works on its share of the GLOBAL batch (the reference's batch: `batch_size` in the config stays the global one, which
+# is also what NGCF's regulariser and Triple2vec's loss divide by): batch means are scaled by 1 / (local batch x world)
+# (FlatModelEngine._batch_share), ONE all-reduce sums [flat gradient | loss share], an identical sweep runs on every
+# replica.  Every replica must drop the same edges / messages in a step: the same dropout seed on every rank (the
+# counter-based device generator is a function of (seed, step, element); the CPU-replay generators are seeded alike).
+# PairwiseGMF: lambda ||v|| is added on rank 0 only and clip_grad_norm_ runs AFTER the reduction, on the global
+# gradient, as the reference clips the gradient of the whole batch.
+
+class _ReplicatedFlatMixin:
+    """Mix into a FlatModelEngine subclass: ``class E(_ReplicatedFlatMixin, LightGCNEngine)``."""
+
+    def __init__(self, config, process_group=None):
+        self.pg = process_group
+        self.world = self._dp_world = dist.get_world_size(process_group)
+        self.rank = self._dp_rank = dist.get_rank(process_group)
+        super().__init__(config)
+        if self.model.flat.device.type == "cuda":
+            src = dist.get_global_rank(self.pg, 0) if self.pg is not None else 0
+            dist.broadcast(self.model.flat, src=src, group=self.pg)
+
+    def _setup(self):
+        fresh = not self._ready
+        lib = super()._setup()
+        if fresh:
+            P = self.model.flat.numel()
+            self._g_ext = torch.zeros(P + 2, dtype=torch.float32, device=self.model.flat.device)
+            self._g_flat = self._g_ext[:P]       # [gradient | loss share | -]: one collective moves both
+            self._tail = self._g_ext[P:]
+            self._dar = DirectAllReduce(self.pg, self.model.flat.device, self.config["model"].get("dp_collective", "rccl"))
+        return lib
+
+    def _enqueue_step(self, batch_data):
+        lib = self._setup()
+        clips = hasattr(self, "_clip_ws")          # PairwiseGMF: clip the GLOBAL gradient, after the reduction
+        if clips:
+            self._enqueue_grad(batch_data, clip=False)
+        else:
+            self._enqueue_grad(batch_data)
+        st = _lib.stream_ptr(self.model.flat.device)
+        _lib.check(lib.hiprec_finalize_stats(_lib.ptr(self._stats), _lib.ptr(self._scratch), None,
+                                             ctypes.c_void_p(self._tail.data_ptr()), st))
+        self._dar.sum_(self._g_ext)
+        if clips:
+            _lib.check(lib.hiprec_clip_grad_norm(
+                _lib.ptr(self._g_flat), self._g_flat.numel(), float(self.config["grad_clip"]),
+                _lib.ptr(self._clip_ws), self._clip_ws.numel() * 8, st))
+        self._enqueue_opt(fold_partials=False)
+
+    def enqueue_epoch(self, *cols):
+        """The C epoch drivers of PairwiseGMF / Triple2vec have no collective inside: a data-parallel epoch is the
+        loop over this rank's batches (``cols``: the epoch's index columns, first dimension = triples)."""
+        lib = self._setup()
+        _lib.check(lib.hiprec_stats_begin_epoch(_lib.ptr(self._stats), _lib.stream_ptr(self.model.flat.device)))
+        B, n = int(getattr(self, "batch_size", None) or self.model.batch_size), cols[0].shape[0]
+        b_local = max(B // self.world, 1)      # the configured batch size is the GLOBAL one
+        for k in range(0, n, b_local):
+            self._enqueue_step(tuple(c[k:k + b_local] for c in cols))
+
+    def _sync_stats(self):
+        """Loss of the last step and the epoch sum as GLOBAL values (this rank's stats hold its shares)."""
+        st = super()._sync_stats()
+        st.loss = float(self._tail[0].item())
+        sums = torch.tensor([st.loss_sum], dtype=torch.float64, device=self.model.flat.device)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
+        st.loss_sum = float(sums[0].item())
+        return st
+
+
+def replicated_flat_engine(engine_cls):
+    """Data-parallel variant of LightGCNEngine / NGCFEngine / PairwiseGMFEngine / Triple2vecEngine:
+    ``replicated_flat_engine(LightGCNEngine)(config, process_group)``."""
+    return type("Replicated" + engine_cls.__name__, (_ReplicatedFlatMixin, engine_cls), {})

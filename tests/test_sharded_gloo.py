@@ -636,3 +636,92 @@ def test_planned_sharded_epoch_on_eight_ranks(tmp_path):
     out_path = str(tmp_path / "out.pt")
     mp.spawn(planned_worker, args=(8, free_port(), n_local, bs, True, out_path), nprocs=8, join=True)
     check_planned(torch.load(out_path, weights_only=False), n_local, bs, "sgd", 0.1)
+
+
+# ---- data-parallel replicas of the graph / sibling engines: the identity they rest on, on 2 gloo ranks ---------------
+
+def flat_dp_worker(rank, world, port, model, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from beta_recsys_amd.replicated import DirectAllReduce
+
+        share = np.float32(1.0 / world)     # FlatModelEngine._batch_share() of a replica
+        rng = np.random.default_rng(3)
+        U, I, D, B = 40, 30, 8, 24
+        users, pos, neg = rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)
+        sl = slice(rank * B // world, (rank + 1) * B // world)
+        if model == "lightgcn":
+            from oracle import lightgcn_numpy as olg
+
+            adj = olg.build_norm_adj(U, I, rng.integers(0, U, 200), rng.integers(0, I, 200))
+            w = {"user_embedding.weight": rng.standard_normal((U, D)).astype(np.float32) * 0.3,
+                 "item_embedding.weight": rng.standard_normal((I, D)).astype(np.float32) * 0.3}
+            full = olg.lightgcn_grads(w, adj, 2, users, pos, neg, 1e-3)
+            loss, g = olg.lightgcn_grads(w, adj, 2, users[sl], pos[sl], neg[sl], 1e-3)   # mean over the LOCAL batch
+            part = [loss * share] + [g[k] * share for k in olg.KEYS]
+            ref = [full[0]] + [full[1][k] for k in olg.KEYS]
+        elif model == "ngcf":
+            from oracle import ngcf_numpy as ong
+            from oracle import lightgcn_numpy as olg
+
+            adj = olg.build_norm_adj(U, I, rng.integers(0, U, 200), rng.integers(0, I, 200))
+            w = {"user_embedding.weight": rng.standard_normal((U, D)).astype(np.float32) * 0.3,
+                 "item_embedding.weight": rng.standard_normal((I, D)).astype(np.float32) * 0.3}
+            for l in range(2):
+                for kind in ("GC", "Bi"):
+                    w[f"{kind}_weights.{l}.weight"] = rng.standard_normal((D, D)).astype(np.float32) * 0.3
+                    w[f"{kind}_weights.{l}.bias"] = rng.standard_normal(D).astype(np.float32) * 0.1
+            w = {k: w[k] for k in ong.keys(2)}
+            masks = [rng.random((U + I, D)) < 0.9 for _ in range(2)]     # the SAME message dropout on every replica
+            full = ong.ngcf_grads(w, adj, users, pos, neg, 1e-3, B, masks, [0.1, 0.1])
+            # the regulariser divides by the CONFIGURED (global) batch size on every replica (ngcf.py:189); only the
+            # BPR mean is over the local batch and takes the 1 / world share
+            l_loc, g_loc = ong.ngcf_grads(w, adj, users[sl], pos[sl], neg[sl], 0.0, B, masks, [0.1, 0.1])
+            l_reg, g_reg = ong.ngcf_grads(w, adj, users[sl], pos[sl], neg[sl], 1e-3, B, masks, [0.1, 0.1])
+            part = [l_loc * share + (l_reg - l_loc)] + [g_loc[k] * share + (g_reg[k] - g_loc[k]) for k in ong.keys(2)]
+            ref = [full[0]] + [full[1][k] for k in ong.keys(2)]
+        else:   # pgmf: lambda ||v|| once (rank 0), clip AFTER the reduction
+            from oracle import pgmf_numpy as opg
+
+            w = {"user_memory.weight": rng.standard_normal((U, D)).astype(np.float32),
+                 "item_memory.weight": rng.standard_normal((I, D)).astype(np.float32),
+                 "v.weight": rng.standard_normal((1, D)).astype(np.float32)}
+            keys = list(w)
+            l_full, g_full = opg.pgmf_grads(w, users, pos, neg, 1e-2)
+            opg.clip_grad_norm(g_full, 0.05)
+            loss, g = opg.pgmf_grads(w, users[sl], pos[sl], neg[sl], 1e-2 if rank == 0 else 0.0)
+            # the lambda term is not a batch mean: take it out before scaling, add it back on rank 0
+            l0, g0 = opg.pgmf_grads(w, users[sl], pos[sl], neg[sl], 0.0)
+            part = [l0 * share + (loss - l0)] + [g0[k] * share + (g[k] - g0[k]) for k in keys]
+            ref = [l_full] + [g_full[k] for k in keys]
+        buf = torch.from_numpy(np.concatenate([np.ravel(np.float32(x)) for x in part]))
+        DirectAllReduce(None, torch.device("cpu")).sum_(buf)
+        got = buf.numpy()
+        if model == "pgmf":     # clip the reduced gradient, as the replicas do
+            gdict, off = {}, 1
+            for k in keys:
+                gdict[k] = got[off:off + w[k].size].reshape(w[k].shape).copy()
+                off += w[k].size
+            opg.clip_grad_norm(gdict, 0.05)
+            got = np.concatenate([got[:1]] + [gdict[k].ravel() for k in keys])
+        if rank == 0:
+            torch.save({"got": got, "ref": np.concatenate([np.ravel(np.float32(x)) for x in ref])}, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model", ["lightgcn", "ngcf", "pgmf"])
+def test_flat_replicas_sum_to_the_global_batch_gradient(tmp_path, model):
+    """What replicated_flat_engine rests on, with the oracles as the kernels: per-rank gradients of the rank's share,
+    batch means scaled by 1 / (local batch x world), the terms that are NOT batch means handled as the engines
+    handle them (NGCF's regulariser over the configured batch on every replica, PairwiseGMF's lambda ||v|| on rank 0,
+    its clip after the reduction), summed by the product's collective helper == the reference's single-process
+    [loss | gradient] on the whole batch."""
+    out_path = str(tmp_path / "dp.pt")
+    mp.spawn(flat_dp_worker, args=(2, free_port(), model, out_path), nprocs=2, join=True)
+    res = torch.load(out_path, weights_only=False)
+    assert_tensor_close(res["got"][:1], res["ref"][:1], 2e-5, "loss")
+    assert_tensor_close(res["got"][1:], res["ref"][1:], 2e-5, "all-reduced gradient")

@@ -513,3 +513,86 @@ def test_planned_sharded_epoch_on_the_whole_configs3_table(nccl_group):
         assert int(idle.sum()) > n_rows // 2
         assert torch.equal(emb[idle], emb0[idle]) and torch.equal(bias[idle], bias0[idle]), "an idle row moved"
     assert float(eng._planned_bufs["acc"].abs().max()) == 0.0 and int(eng._planned_bufs["arrived"].abs().max()) == 0
+
+
+@pytest.mark.parametrize("model", ["lightgcn", "ngcf", "pgmf", "t2v"])
+@pytest.mark.parametrize("collective", ["rccl", "torch"])
+def test_replicated_flat_engines_with_hip_kernels(nccl_group, model, collective):
+    """replicated.replicated_flat_engine (data-parallel LightGCN / NGCF / PairwiseGMF / Triple2vec) with the real
+    kernels at world size 1: gradient kernel with the share-scaled batch mean, loss share into the tail, ONE
+    all-reduce of [gradient | loss] (direct ncclAllReduce on the engine's own communicator, or torch.distributed),
+    PairwiseGMF's clip AFTER the reduction, dense sweep -- three Adam steps must follow the oracle's trajectory."""
+    import beta_recsys_amd as hp
+    from beta_recsys_amd.replicated import replicated_flat_engine
+    from helpers import assert_on_trajectory, oracle_trajectory
+    from oracle import lightgcn_numpy as olg
+
+    rng = np.random.default_rng(8)
+    U, I, D, B, lr = 300, 200, 32, 128, 0.01
+    sysd = {"run_dir": "/tmp/hiprec_test_runs"}
+    adj = olg.build_norm_adj(U, I, rng.integers(0, U, 3000), rng.integers(0, I, 3000))
+    co = adj.tocoo()
+    tadj = torch.sparse_coo_tensor(torch.from_numpy(np.vstack((co.row, co.col)).astype(np.int64)),
+                                   torch.from_numpy(co.data.astype(np.float32)), torch.Size(co.shape))
+    triples = [(rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)) for _ in range(3)]
+    torch.manual_seed(3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        if model == "lightgcn":
+            cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, layer_size=[D] * 2, keep_pro=1.0, regs=[1e-4],
+                                 device_str="cuda:0", optimizer="adam", lr=lr, batch_size=B, norm_adj=tadj,
+                                 dp_collective=collective), "system": sysd}
+            eng = replicated_flat_engine(hp.LightGCNEngine)(cfg)
+            eng.model.eval()     # no edge dropout: the oracle below propagates over the full graph
+            grads = lambda w, b: olg.lightgcn_grads(w, adj, 2, b[0], b[1], b[2], 1e-4)[1]  # noqa: E731
+            batches = triples
+        elif model == "ngcf":
+            from oracle import ngcf_numpy as ong
+
+            cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, layer_size=[D, D], mess_dropout=[0.0, 0.0], regs=[1e-4],
+                                 device_str="cuda:0", optimizer="adam", lr=lr, batch_size=B, norm_adj=tadj,
+                                 dp_collective=collective), "system": sysd}
+            eng = replicated_flat_engine(hp.NGCFEngine)(cfg)
+            grads = lambda w, b: ong.ngcf_grads(w, adj, b[0], b[1], b[2], 1e-4, B)[1]  # noqa: E731
+            batches = triples
+        elif model == "pgmf":
+            from oracle import pgmf_numpy as opg
+
+            cfg = {"n_users": U, "n_items": I, "emb_dim": D, "regs": [1e-5], "batch_size": B, "lr": lr,
+                   "pretrain_l2_lambda": 1e-2, "grad_clip": 0.05, "neg_count": 4,
+                   "model": {"device_str": "cuda:0", "optimizer": "adam", "lr": lr, "dp_collective": collective},
+                   "system": sysd}
+            eng = replicated_flat_engine(hp.PairwiseGMFEngine)(cfg)
+            grads = lambda w, b: opg.pgmf_grads(w, b[0], b[1], b[2], 1e-2)[1]  # noqa: E731
+            batches = triples
+        else:
+            from oracle import triple2vec_numpy as ot2
+
+            n_neg = 3
+            cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, n_neg=n_neg, batch_size=B, device_str="cuda:0",
+                                 optimizer="adam", lr=lr, dp_collective=collective), "system": sysd}
+            eng = replicated_flat_engine(hp.Triple2vecEngine)(cfg)
+            batches = [(u, p, q, rng.integers(0, U, (B, n_neg)), rng.integers(0, I, (B, n_neg)),
+                        rng.integers(0, I, (B, n_neg))) for u, p, q in triples]
+            grads = lambda w, b: ot2.t2v_grads(w, b, B)[1]  # noqa: E731
+    w0 = {k: v.detach().cpu().numpy().copy() for k, v in eng.model.state_dict().items()}
+    if model == "pgmf":        # the reference's 0.01-sized init keeps every ReLU closed: scale the memories up
+        for k in ("user_memory.weight", "item_memory.weight"):
+            w0[k] = w0[k] * 50.0
+        eng.model.load_state_dict({k: torch.from_numpy(v) for k, v in w0.items()})
+    for b in batches:
+        loss = eng.train_single_batch(tuple(torch.from_numpy(np.asarray(x)) for x in b))
+        assert np.isfinite(loss if not isinstance(loss, tuple) else loss[0])
+    assert (eng._dar.comm is not None) == (collective == "rccl")
+    from oracle import mf_numpy as omf
+
+    def step(w, g, st):
+        if model == "pgmf":
+            from oracle import pgmf_numpy as opg
+            opg.clip_grad_norm(g, 0.05)
+        omf.opt_step(w, g, st, "adam", lr)
+        if model == "t2v":
+            w["item_emb2.weight"][...] = w["item_emb1.weight"]
+
+    w_ref, env, upd = oracle_trajectory(w0, batches, grads, step, lambda w: omf.new_opt_state(w, "adam"))
+    got = {k: v.detach().cpu().numpy() for k, v in eng.model.state_dict().items()}
+    assert_on_trajectory(got, w_ref, env, upd, f"replicated {model}")
