@@ -356,8 +356,25 @@ __global__ __launch_bounds__(kBlock) void from_sliced_kernel(const float* __rest
   }
 }
 
+// LDS one workgroup may use on the current device (gfx950: 160 KB); a part with less (gfx942: 64 KB) gets width 0
+// from sliced_width for graphs whose slice does not fit, i.e. the edge-parallel gather SpMM
+static int64_t device_lds_bytes() {
+  static int64_t cached = -1;
+  if (cached < 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0)
+      cached = v;
+    else
+      cached = 0;   // no device (the CPU-side symbol tests): keep the gfx950 figure below
+  }
+  return cached;
+}
+
 int sliced_width(int64_t n_rows, int dim) {
   if (n_rows <= 0 || n_rows >= 65536 || dim <= 0) return 0;  // 16-bit column and row ids
+  const int64_t have = device_lds_bytes();
+  if (have > 0 && have < kSlicedLds) return 0;
   // a width below 4 floats re-reads the edge arrays more often than the gather SpMM reads source rows: W = 4 or
   // (a narrower slice for graphs of up to ~20 k nodes) 2
   for (int w : {4, 2})

@@ -720,8 +720,11 @@ class MFEngine(ModelEngine):
 
     def prefetch_epoch(self, train_loader):
         """Stage the NEXT epoch of ``train_loader`` on a side stream.  The following
-        :meth:`prepare_epoch` with the same loader object takes it (after making the current stream
-        wait for it).  A prepared epoch obtained this way stays valid until the second prefetch after
+        :meth:`prepare_epoch` with the same loader object -- and the same, unmodified tensors behind it, see
+        :meth:`_loader_fingerprint` -- takes it (after making the current stream wait for it).  Note on the CPU
+        generator: the epoch's shuffle seed (``DeviceTripleBatcher.draw_seed``) is drawn when the epoch is STAGED,
+        i.e. one epoch earlier than without prefetching, and one extra seed is drawn for the epoch that never runs;
+        the sequence of seeds -- and with it the batches of every epoch -- is the same either way.  A prepared epoch obtained this way stays valid until the second prefetch after
         it.  Returns False when the loader cannot be staged ahead."""
         if not self._can_prefetch(train_loader):
             return False
@@ -767,8 +770,16 @@ class MFEngine(ModelEngine):
         if prepared.own is not None:  # allocated on the side stream, read (and eventually freed) under the main one
             for t in prepared.own[:2]:
                 t.record_stream(main)
-        self._prefetched = (train_loader, done, prepared)
+        self._prefetched = (train_loader, done, prepared, self._loader_fingerprint(train_loader))
         return True
+
+    @staticmethod
+    def _loader_fingerprint(train_loader):
+        """What the staged arrays were made from: address, length and in-place version counter of the loader's
+        three tensors and its batch size.  A caller that resamples negatives in place or swaps a tensor between two
+        epochs changes it, and the prefetched epoch is dropped instead of training on stale triples."""
+        ts = (train_loader.user_tensor, train_loader.pos_item_tensor, train_loader.neg_item_tensor)
+        return tuple((t.data_ptr(), t.numel(), t._version) for t in ts) + (int(train_loader.batch_size),)
 
     def _drop_prefetch(self):
         pending = getattr(self, "_prefetched", None)
@@ -784,7 +795,7 @@ class MFEngine(ModelEngine):
         if pending is not None:
             self._prefetched = None
             torch.cuda.current_stream(self.model.flat.device).wait_event(pending[1])
-            if pending[0] is train_loader:
+            if pending[0] is train_loader and pending[3] == self._loader_fingerprint(train_loader):
                 return pending[2]
         if self.loss not in ("bpr", "bce") or isinstance(train_loader, (list, tuple)):
             return None

@@ -867,6 +867,30 @@ def test_next_epoch_prefetch_is_the_same_training_run(hip_device):
         assert_tensor_close(wa[k], wb[k], 2e-4, f"{k} after 3 epochs with / without prefetch")
 
 
+def test_prefetched_epoch_is_dropped_when_the_loader_data_changed(hip_device):
+    """the prefetched staging is keyed on the loader's tensors (address, length, in-place version), not
+    only on the loader object: a caller that resamples the negatives in place between two epochs trains the next
+    epoch on the NEW negatives."""
+    import beta_recsys_amd as hp
+
+    U, I, D, B, N = 400, 50, 16, 128, 128 * 4
+    rng = np.random.default_rng(5)
+    users, pos = (torch.from_numpy(rng.integers(0, hi, N)).cuda() for hi in (U, I))
+    neg = torch.zeros(N, dtype=torch.int64, device="cuda")          # epoch 0: every negative is item 0
+    eng = make_engine(U, I, D, "sgd", "bpr", 0.05, B)
+    loader = hp.DeviceTripleBatcher(users, pos, neg, B)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng.train_an_epoch(loader, 0)
+    assert eng._prefetched is not None                               # epoch 1 is staged (with negatives = 0)
+    neg.fill_(I - 1)                                                  # resampled IN PLACE
+    w_before = get_weights(eng)["item_emb.weight"].copy()
+    staged = eng.prepare_epoch(loader)
+    assert bool((staged[2] == I - 1).all()), "the stale staging was served"
+    eng.run_prepared_epoch(staged)
+    w_after = get_weights(eng)["item_emb.weight"]
+    assert not np.array_equal(w_after[I - 1], w_before[I - 1]), "the new negative item's row was never touched"
+
+
 def test_engine_on_a_device_that_is_not_current(hip_device):
     """the reference never calls set_device and TrainEngine.get_device hands out 'cuda:N'; every
     libhiprec launch must go to the device its tensors live on even while another device is current."""
