@@ -164,9 +164,9 @@ def test_ncf_errors(hip_device):
 
 @pytest.mark.parametrize("E", [32, 64])
 def test_ncf_full_size_c3_vs_oracle(hip_device, E):
-    """BASELINE configs[2]: ML-1M shape, batch 4096; emb_dim 32 (tower 256->128->64->32, the fused tower kernel) and
-    emb_dim 64 -- "dim=64" as BASELINE.json spells it: tables 256/256/64/64, tower 512->256->128->64, beyond the
-    fused kernel's LDS tiles, so it runs gather + one MFMA GEMM launch per layer + head."""
+    """BASELINE configs[2]: ML-1M shape, batch 4096; emb_dim 32 (tower 256->128->64->32) and emb_dim 64 -- "dim=64" as
+    BASELINE.json spells it: tables 256/256/64/64, tower 512->256->128->64 -- both on the fused forward + chain launch
+    (the wide tower's first layer in two 128-column passes, 134 KB of LDS)."""
     U, I, L, B = 6040, 3706, 3, 4096
     torch.manual_seed(5)
     eng = make_engine("NeuMFEngine", U, I, E, L, "adam", 1e-3, B)
