@@ -545,14 +545,13 @@ def bench_mf_c4_sharded(args, device, world, rank):
     return out
 
 
-def bench_lightgcn(args, device, world=1, rank=0, dist_on=False):
-    """BASELINE configs[4]: LightGCN on an ML-1M-sized graph (~1M interactions, nnz ~2M), 3 layers,
-    dim 64, batch 1024 triples, keep_pro 0.6 (device-side edge dropout), Adam lr 0.05."""
-    import beta_recsys_amd as hp
+def c5_graph():
+    """ML-1M degree profile, 988 k UNIQUE train edges => nnz(D^-1 (A + I)) = 2 x 988 000 + 9 746 =
+    1.99 M (rounds 1-2 drew 1 M edges with duplicates: 745 k unique, nnz 1.49 M).  Zipf items, duplicates redrawn.
+    The reference's norm_adj = D^-1 (A + I) over users + items (data/deprecated_data_base.py:331-353 +
+    utils/common_util.py normalized_adj_single), built once on the host like the reference does; scipy COO."""
+    import scipy.sparse as sp
 
-    L, Bl = 3, 1024
-    # SURVEY 8d C5: ML-1M degree profile, 988 k UNIQUE train edges => nnz(D^-1 (A + I)) = 2 x 988 000 + 9 746 = 1.99 M
-    # (rounds 1-2 drew 1 M edges with duplicates: 745 k unique, nnz 1.49 M).  Zipf items, duplicates redrawn.
     rng = np.random.default_rng(0)
     n_edges = 988_000
     p = 1.0 / np.arange(1, I + 1) ** 0.9
@@ -564,16 +563,22 @@ def bench_lightgcn(args, device, world=1, rank=0, dist_on=False):
         pairs = np.unique(np.concatenate([pairs, rng.integers(0, U, m) * I + item_of[rng.choice(I, m, p=p)]]))
     pairs = rng.permutation(pairs)[:n_edges]
     eu, ei = pairs // I, pairs % I
-    # the reference's norm_adj = D^-1 (A + I) over users + items (data/deprecated_data_base.py:331-353 +
-    # utils/common_util.py normalized_adj_single), built once on the host like the reference does
-    import scipy.sparse as sp
-
     n_nodes = U + I
     rows, cols = np.concatenate([eu, ei + U]), np.concatenate([ei + U, eu])
     a = sp.coo_matrix((np.ones(len(rows), dtype=np.float32), (rows, cols)), shape=(n_nodes, n_nodes)).tocsr()
     a = a + sp.eye(n_nodes, dtype=np.float32, format="csr")
     adj = sp.diags(1.0 / np.asarray(a.sum(1)).flatten()).dot(a).astype(np.float32).tocoo()
     assert adj.nnz == 2 * n_edges + n_nodes
+    return adj
+
+
+def bench_lightgcn(args, device, world=1, rank=0, dist_on=False):
+    """BASELINE configs[4]: LightGCN on an ML-1M-sized graph (~1M interactions, nnz ~2M), 3 layers,
+    dim 64, batch 1024 triples, keep_pro 0.6 (device-side edge dropout), Adam lr 0.05."""
+    import beta_recsys_amd as hp
+
+    L, Bl = 3, 1024
+    adj = c5_graph()
     idx = torch.from_numpy(np.vstack((adj.row, adj.col)).astype(np.int64))
     norm = torch.sparse_coo_tensor(idx, torch.from_numpy(adj.data), torch.Size(adj.shape))
     cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, layer_size=[D] * L, keep_pro=0.6, regs=[1e-5],
@@ -747,20 +752,9 @@ def bench_ngcf(args, device):
     """NGCF at configs/ngcf_default.json (emb 64, three hops of 64, mess_dropout 0.1,
     batch 1024, Adam lr 0.05) on the same ML-1M-sized graph as the LightGCN workload."""
     import beta_recsys_amd as hp
-    import scipy.sparse as sp
 
     L, Bn = 3, 1024
-    rng = np.random.default_rng(0)
-    n_edges = 1_000_000
-    p = 1.0 / np.arange(1, I + 1) ** 0.9
-    eu = rng.integers(0, U, n_edges)
-    ei = rng.permutation(I)[rng.choice(I, n_edges, p=p / p.sum())]
-    n_nodes = U + I
-    rows, cols = np.concatenate([eu, ei + U]), np.concatenate([ei + U, eu])
-    a = sp.coo_matrix((np.ones(len(rows), dtype=np.float32), (rows, cols)), shape=(n_nodes, n_nodes)).tocsr()
-    a.data[:] = 1.0
-    a = a + sp.eye(n_nodes, dtype=np.float32, format="csr")
-    adj = sp.diags(1.0 / np.asarray(a.sum(1)).flatten()).dot(a).astype(np.float32).tocoo()
+    adj = c5_graph()      # 988 k unique edges, nnz 1.99 M (rounds 1-2: 1.49 M)
     idx = torch.from_numpy(np.vstack((adj.row, adj.col)).astype(np.int64))
     norm = torch.sparse_coo_tensor(idx, torch.from_numpy(adj.data), torch.Size(adj.shape))
     cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, layer_size=[D] * L, mess_dropout=[0.1] * L, regs=[1e-5],

@@ -276,14 +276,32 @@ struct ColsumReduce {
   int N[kMaxGroup], slabs[kMaxGroup];
 };
 
-// out[n] += ws[0][n] + ws[1][n] + ... in slab order (one block per problem; a few thousand floats each)
-__global__ __launch_bounds__(kBlock) void colsum_reduce_kernel(ColsumReduce r) {
+// out[n] += the slabs' partial sums of column n, in a FIXED association: 16 thread groups each add every 16th slab
+// (their loads are independent: one memory round trip instead of `slabs` dependent ones -- the first version, one
+// thread per column walking all slabs, took 19.9 us for NGCF's 77 slabs), then the 16 partials are added in order.
+constexpr int kReduceThreads = 1024, kReduceParts = kReduceThreads / 64;
+__global__ __launch_bounds__(kReduceThreads) void colsum_reduce_kernel(ColsumReduce r) {
+  __shared__ float s_p[kReduceParts][64];
   const int i = blockIdx.x;
   const float* __restrict__ ws = r.ws[i];
-  for (int n = threadIdx.x; n < r.N[i]; n += kBlock) {
+  const int N = r.N[i], slabs = r.slabs[i];
+  const int tx = threadIdx.x & 63, part = threadIdx.x >> 6;
+  for (int n0 = 0; n0 < N; n0 += 64) {
+    const int n = n0 + tx;
     float t = 0.f;
-    for (int s = 0; s < r.slabs[i]; ++s) t += ws[static_cast<int64_t>(s) * r.N[i] + n];
-    r.out[i][n] += t;
+    if (n < N) {
+#pragma unroll 8
+      for (int s = part; s < slabs; s += kReduceParts) t += ws[static_cast<int64_t>(s) * N + n];
+    }
+    s_p[part][tx] = t;
+    __syncthreads();
+    if (part == 0 && n < N) {
+      float tot = 0.f;
+#pragma unroll
+      for (int q = 0; q < kReduceParts; ++q) tot += s_p[q][tx];
+      r.out[i][n] += tot;
+    }
+    __syncthreads();
   }
 }
 
@@ -299,7 +317,7 @@ int launch_colsum_reduce(const GemmGroup& g, hipStream_t st) {
     ++r.n;
   }
   if (r.n == 0) return 0;
-  colsum_reduce_kernel<<<r.n, kBlock, 0, st>>>(r);
+  colsum_reduce_kernel<<<r.n, kReduceThreads, 0, st>>>(r);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
