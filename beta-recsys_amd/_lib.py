@@ -124,7 +124,8 @@ class ShardPlan(Structure):
                 ("local_batch", c_int64), ("n_local", c_int64), ("users", c_void_p), ("pos_slot", c_void_p),
                 ("neg_slot", c_void_p), ("own", c_void_p), ("total", c_void_p), ("total_stride", c_int64),
                 ("in_idx", c_void_p), ("ex_req", c_void_p), ("ex_in", c_void_p), ("in_off_host", c_void_p),
-                ("n_slots_host", c_void_p), ("req_cnt_host", c_void_p), ("in_cnt_host", c_void_p)]
+                ("n_slots_host", c_void_p), ("req_cnt_host", c_void_p), ("in_cnt_host", c_void_p),
+                ("slot_shared", c_void_p), ("slot_stride", c_int64), ("dup_bits", c_void_p), ("dup_words", c_int64)]
 
 
 class ShardBufs(Structure):
@@ -346,10 +347,10 @@ SIGNATURES = {
     "hiprec_plan_place_triples": (c_int, [_P, c_int64, _P, c_int32, c_int64, c_int64, _P, _P, _P, _P, _P]),
     "hiprec_plan_slot_ws_ints": (c_int64, [c_int64, c_int32, c_int32]),
     "hiprec_plan_item_slots": (
-        c_int, [_P, c_int64, c_int64, c_int32, c_int64, c_int32] + [_P] * 16 + [_P]),
-    "hiprec_plan_place_requests": (c_int, [_P, c_int64, _P, c_int32, c_int64, _P, _P, _P, _P, _P]),
+        c_int, [_P, c_int64, c_int64, c_int32, c_int64, c_int32] + [_P] * 16 + [_P, _P, c_int64, _P, _P]),
+    "hiprec_plan_place_requests": (c_int, [_P, c_int64, _P, c_int32, c_int64, _P, _P, _P, _P, c_int64, _P, _P]),
     "hiprec_shard_payload_zero": (
-        c_int, [_P, _P, c_int64, c_int32, _P, c_int64, c_int64, c_int64, _P, _P, _P, c_int64, _P, _P]),
+        c_int, [_P, _P, c_int64, c_int32, _P, c_int64, c_int64, c_int64, _P, _P, _P, c_int64, _P, _P, _P]),
     "hiprec_mf_bpr_grad_remote_step": (
         c_int,
         [_P, _P, c_int64, c_int64, c_int32, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int64, c_float, c_float,
@@ -357,7 +358,7 @@ SIGNATURES = {
     ),
     "hiprec_shard_apply_finish": (
         c_int, [_P, _P, c_int64, c_int32, _P, _P, c_int64, c_int64, c_int64, _P, c_double, _P, c_int32, _P, c_double,
-                c_int32, _P, _P]),
+                c_int32, _P, _P, _P]),
     "hiprec_shard_planned_steps": (
         c_int, [POINTER(ShardPlan), POINTER(ShardBufs), c_int64, c_int64, c_int32, c_float, c_double, c_double,
                 c_double, c_double, POINTER(NcclFns), _P, _P, _P]),

@@ -174,7 +174,8 @@ __global__ __launch_bounds__(kPlanThreads) void plan_scan_groups_kernel(const in
                                                                          int32_t* __restrict__ start,
                                                                          int32_t* __restrict__ dst,
                                                                          int32_t* __restrict__ step_off,
-                                                                         int32_t* __restrict__ extra_pos) {
+                                                                         int32_t* __restrict__ extra_pos,
+                                                                         int32_t* __restrict__ step_fill) {
   __shared__ int s_q[kPlanMaxDest + 1];
   const int tid = static_cast<int>(threadIdx.x);
   if (tid < Q) {
@@ -230,6 +231,27 @@ __global__ __launch_bounds__(kPlanThreads) void plan_scan_groups_kernel(const in
         run += extra;
       }
     }
+    if (step_fill) step_fill[s] = run;   // elements of step s: what lies behind them in a fixed-size block is padding
+  }
+}
+
+// Padding of fixed-size step blocks: positions [fill[s], cap) of step s get user -1, slots / items 0 and (own != NULL)
+// ownership -1 -- only those: a memset of the whole arrays was most of the plan's fill traffic (no padding at all
+// when every step received exactly cap triples).
+__global__ __launch_bounds__(kBlock) void plan_pad_kernel(const int32_t* __restrict__ fill, int S, int64_t cap,
+                                                          int64_t* __restrict__ U, int64_t* __restrict__ P,
+                                                          int64_t* __restrict__ N, int32_t* __restrict__ own) {
+  const int64_t tot = static_cast<int64_t>(S) * cap;
+  for (int s = blockIdx.y; s < S; s += gridDim.y) {
+    const int64_t lo = fill[s];
+    for (int64_t i = lo + static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < cap;
+         i += static_cast<int64_t>(gridDim.x) * kBlock) {
+      const int64_t at = static_cast<int64_t>(s) * cap + i;
+      U[at] = -1;
+      P[at] = 0;
+      N[at] = 0;
+      if (own) own[at] = own[tot + at] = own[2 * tot + at] = -1;
+    }
   }
 }
 
@@ -266,6 +288,36 @@ __global__ __launch_bounds__(kBlock) void plan_place_values_kernel(const int32_t
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; j < n_in; j += stride)
     out[place_of(j, start, dst, n_groups)] = in[j];
+}
+
+// Which of the rows a step's peers ask for are asked for by MORE than one of them?  (Every peer's list is free of
+// duplicates, so a row occurs at most once per source.)  One bit per (step, local item row): the owner's apply pass
+// adds the gradients of the others with plain read-modify-writes instead of fp32 atomics.  seen / dup: [S][words],
+// zero on entry.
+constexpr int kDupWords = 16384;   // words of one bitmap a workgroup keeps in LDS (2 bitmaps: 128 KB)
+__global__ __launch_bounds__(kPlanThreads) void plan_mark_duplicates_kernel(const int32_t* __restrict__ in_idx,
+                                                                             const int32_t* __restrict__ step_off,
+                                                                             int64_t words, int n_parts,
+                                                                             uint32_t* __restrict__ dup) {
+  // block = (step, part): the bits of rows [part * 32 kDupWords, ...) of one step, built with LDS atomics from the
+  // step's list (global atomics on a 12 MB bitmap: 200 us per plan; this: one pass over an L2-resident list)
+  extern __shared__ uint32_t s_bits[];   // [w] seen, then [w] dup
+  const int s = static_cast<int>(blockIdx.x) / n_parts, part = static_cast<int>(blockIdx.x) % n_parts;
+  const int64_t w0 = static_cast<int64_t>(part) * kDupWords;
+  const int w = static_cast<int>(min<int64_t>(kDupWords, words - w0));
+  for (int i = threadIdx.x; i < 2 * w; i += kPlanThreads) s_bits[i] = 0u;
+  __syncthreads();
+  const int64_t lo = step_off[s], hi = step_off[s + 1];
+  const int64_t r0 = w0 * 32, r1 = r0 + static_cast<int64_t>(w) * 32;
+  for (int64_t k = lo + threadIdx.x; k < hi; k += kPlanThreads) {
+    const int64_t row = in_idx[k];
+    if (row < r0 || row >= r1) continue;
+    const int j = static_cast<int>((row - r0) >> 5);
+    const uint32_t bit = 1u << (row & 31);
+    if (atomicOr(s_bits + j, bit) & bit) atomicOr(s_bits + w + j, bit);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < w; i += kPlanThreads) dup[static_cast<int64_t>(s) * words + w0 + i] = s_bits[w + i];
 }
 
 // ---- slots ----------------------------------------------------------------------------------------------------
@@ -309,7 +361,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_slot_scan_kernel(
     const int32_t* __restrict__ part_cnt, int S, int n_parts, int R, int32_t* __restrict__ req_cnt,
     int32_t* __restrict__ req_ds, int32_t* __restrict__ chunk_start, int32_t* __restrict__ ex_req,
     int32_t* __restrict__ n_slots, int32_t* __restrict__ slot_base, int32_t* __restrict__ pos_base,
-    int32_t* __restrict__ send_base) {
+    int32_t* __restrict__ send_base, uint8_t* __restrict__ slot_shared, int64_t slot_stride) {
   __shared__ int s_q[kPlanMaxDest + 1];
   const int tid = static_cast<int>(threadIdx.x);
   for (int s = tid; s < S; s += kPlanThreads) {
@@ -325,6 +377,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_slot_scan_kernel(
       chunk_start[s * R + d] = run;
       run += c + 1;
       ex_req[s * R + d] = run - 1;
+      if (slot_shared) slot_shared[static_cast<int64_t>(s) * slot_stride + run - 1] = 1;   // the extra row: cleared too
     }
     n_slots[s] = run;
     int acc = 0;
@@ -368,7 +421,8 @@ __global__ __launch_bounds__(kPlanThreads) void plan_slot_assign_kernel(
     const int32_t* __restrict__ tab_keys, int32_t* __restrict__ pos_cnt, int table_bits, int n_parts, int R, int S,
     int32_t n_users_local, const int32_t* __restrict__ slot_base, const int32_t* __restrict__ pos_base,
     const int32_t* __restrict__ chunk_start, const int32_t* __restrict__ send_base, int32_t* __restrict__ slot_of,
-    int32_t* __restrict__ req_send) {
+    int32_t* __restrict__ req_send, const int32_t* __restrict__ total, uint8_t* __restrict__ slot_shared,
+    int64_t slot_stride) {
   constexpr int NW = kPlanThreads / kWave;
   __shared__ int s_wcnt[NW][kPlanMaxDest];
   __shared__ int s_wpos[NW];
@@ -433,6 +487,8 @@ __global__ __launch_bounds__(kPlanThreads) void plan_slot_assign_kernel(
       if (d >= 0) {
         const int item = key - n_users_local;
         req_send[send_base[d * S + s] + slot - chunk_start[s * R + d]] = item / R;
+        // a slot several triples reference receives atomic adds: only those have to be zero when the step starts
+        if (slot_shared) slot_shared[static_cast<int64_t>(s) * slot_stride + slot] = total[e0 + i] > 1 ? 1 : 0;
       }
     }
     pos_run += __builtin_amdgcn_readlane(incl, kWave - 1);
@@ -508,15 +564,14 @@ extern "C" int hiprec_plan_place_triples(const int32_t* recv, int64_t n_recv, co
   HIPREC_REQUIRE(n_steps * cap < (1ll << 31) && world * n_steps < (1ll << 30), "plan too large for 32-bit positions");
   HIPREC_REQUIRE(recv_cnt && group_ws && users && pos && neg && (n_recv == 0 || recv), "NULL pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int64_t tot = n_steps * cap;
-  HIPREC_TRY(hipMemsetAsync(users, 0xFF, sizeof(int64_t) * tot, st));  // padding: user -1, items 0
-  HIPREC_TRY(hipMemsetAsync(pos, 0, sizeof(int64_t) * tot, st));
-  HIPREC_TRY(hipMemsetAsync(neg, 0, sizeof(int64_t) * tot, st));
   const int G = static_cast<int>(world * n_steps);
   int32_t* start = group_ws;          // [G + 1]
   int32_t* dst = group_ws + G + 1;    // [G]
+  int32_t* fill = dst + G;            // [n_steps]: triples per step; behind them: padding (user -1, items 0)
   plan_scan_groups_kernel<<<1, kPlanThreads, 0, st>>>(recv_cnt, world, static_cast<int>(n_steps), cap, 0, start, dst,
-                                                      nullptr, nullptr);
+                                                      nullptr, nullptr, fill);
+  plan_pad_kernel<<<dim3(4, static_cast<unsigned>(std::min<int64_t>(n_steps, 1024))), kBlock, 0, st>>>(
+      fill, static_cast<int>(n_steps), cap, users, pos, neg, nullptr);
   if (n_recv > 0)
     plan_place_triples_kernel<<<grid_for_threads(n_recv), kBlock, 0, st>>>(recv, n_recv, start, dst, G, users, pos, neg);
   HIPREC_TRY(hipGetLastError());
@@ -525,7 +580,7 @@ extern "C" int hiprec_plan_place_triples(const int32_t* recv, int64_t n_recv, co
 
 extern "C" int hiprec_plan_place_requests(const int32_t* incoming, int64_t n_in, const int32_t* in_cnt, int32_t world,
                                           int64_t n_steps, int32_t* group_ws, int32_t* in_idx, int32_t* step_off,
-                                          int32_t* extra_pos, void* stream) {
+                                          int32_t* extra_pos, int64_t n_rows_local, uint32_t* dup_ws, void* stream) {
   HIPREC_REQUIRE(n_in >= 0 && world > 0 && world <= kPlanMaxDest && n_steps > 0, "bad sizes");
   HIPREC_REQUIRE(n_in + world * n_steps < (1ll << 31), "plan too large for 32-bit positions");
   HIPREC_REQUIRE(in_cnt && group_ws && in_idx && step_off && extra_pos && (n_in == 0 || incoming), "NULL pointer");
@@ -535,9 +590,25 @@ extern "C" int hiprec_plan_place_requests(const int32_t* incoming, int64_t n_in,
   int32_t* start = group_ws;
   int32_t* dst = group_ws + G + 1;
   plan_scan_groups_kernel<<<1, kPlanThreads, 0, st>>>(in_cnt, world, static_cast<int>(n_steps), 0, 1, start, dst,
-                                                      step_off, extra_pos);
+                                                      step_off, extra_pos, nullptr);
   if (n_in > 0)
     plan_place_values_kernel<<<grid_for_threads(n_in), kBlock, 0, st>>>(incoming, n_in, start, dst, G, in_idx);
+  if (dup_ws != nullptr) {   // [n_steps][words]: the duplicate bits the step driver reads (every word is written)
+    HIPREC_REQUIRE(n_rows_local >= 0, "bad n_rows_local");
+    const int64_t words = (n_rows_local + 31) / 32;
+    if (words > 0) {
+      const int n_parts = static_cast<int>((words + kDupWords - 1) / kDupWords);
+      const size_t lds = sizeof(uint32_t) * 2 * static_cast<size_t>(std::min<int64_t>(words, kDupWords));
+      static bool attr_set = false;
+      if (!attr_set) {
+        HIPREC_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_mark_duplicates_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(uint32_t) * 2 * kDupWords));
+        attr_set = true;
+      }
+      plan_mark_duplicates_kernel<<<static_cast<int>(n_steps) * n_parts, kPlanThreads, lds, st>>>(in_idx, step_off, words,
+                                                                                                n_parts, dup_ws);
+    }
+  }
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
@@ -554,7 +625,9 @@ extern "C" int hiprec_plan_item_slots(const int64_t* users, int64_t n_steps, int
                                       const int32_t* occ, const int32_t* tab_keys, int32_t* pos_cnt, int32_t* ws,
                                       int32_t* slot_of, int32_t* req_cnt, int32_t* req_ds, int32_t* ex_req,
                                       int32_t* n_slots, int32_t* send_base, int32_t* req_send, int64_t* users_out,
-                                      int64_t* pos_slot, int64_t* neg_slot, int32_t* own_out, void* stream) {
+                                      int64_t* pos_slot, int64_t* neg_slot, int32_t* own_out, const int32_t* total,
+                                      uint8_t* slot_shared, int64_t slot_stride, const int32_t* step_fill,
+                                      void* stream) {
   HIPREC_REQUIRE(n_steps > 0 && cap > 0 && world > 0 && world <= kPlanMaxDest && n_users_local >= 0, "bad sizes");
   HIPREC_REQUIRE(table_bits >= 2 && table_bits <= 30 && (n_steps << table_bits) < (1ll << 31) &&
                      n_steps * cap < (1ll << 31),
@@ -571,18 +644,26 @@ extern "C" int hiprec_plan_item_slots(const int64_t* users, int64_t n_steps, int
   int32_t* pos_base = slot_base + static_cast<int64_t>(S) * n_parts * R;
   int32_t* chunk_start = pos_base + static_cast<int64_t>(S) * n_parts;
   const int64_t tot = n_steps * cap;
-  HIPREC_TRY(hipMemsetAsync(users_out, 0xFF, sizeof(int64_t) * tot, st));
-  HIPREC_TRY(hipMemsetAsync(pos_slot, 0, sizeof(int64_t) * tot, st));
-  HIPREC_TRY(hipMemsetAsync(neg_slot, 0, sizeof(int64_t) * tot, st));
-  HIPREC_TRY(hipMemsetAsync(own_out, 0xFF, sizeof(int32_t) * 3 * tot, st));
+  if (step_fill != nullptr) {   // the live triples of a step end up in [0, step_fill[s]): pad only what lies behind
+    plan_pad_kernel<<<dim3(4, static_cast<unsigned>(std::min<int64_t>(n_steps, 1024))), kBlock, 0, st>>>(
+        step_fill, S, cap, users_out, pos_slot, neg_slot, own_out);
+  } else {
+    HIPREC_TRY(hipMemsetAsync(users_out, 0xFF, sizeof(int64_t) * tot, st));
+    HIPREC_TRY(hipMemsetAsync(pos_slot, 0, sizeof(int64_t) * tot, st));
+    HIPREC_TRY(hipMemsetAsync(neg_slot, 0, sizeof(int64_t) * tot, st));
+    HIPREC_TRY(hipMemsetAsync(own_out, 0xFF, sizeof(int32_t) * 3 * tot, st));
+  }
   const int grid = S * n_parts;
   plan_slot_count_kernel<<<grid, kPlanThreads, 0, st>>>(tab_keys, pos_cnt, table_bits, R,
                                                         static_cast<int32_t>(n_users_local), part_cnt);
+  HIPREC_REQUIRE(slot_shared == nullptr || (total != nullptr && slot_stride >= 2 * cap + world),
+                 "slot_shared needs total and a stride of at least 2 * cap + world");
   plan_slot_scan_kernel<<<1, kPlanThreads, 0, st>>>(part_cnt, S, n_parts, R, req_cnt, req_ds, chunk_start, ex_req,
-                                                    n_slots, slot_base, pos_base, send_base);
+                                                    n_slots, slot_base, pos_base, send_base, slot_shared, slot_stride);
   plan_slot_assign_kernel<<<grid, kPlanThreads, 0, st>>>(tab_keys, pos_cnt, table_bits, n_parts, R, S,
                                                          static_cast<int32_t>(n_users_local), slot_base, pos_base,
-                                                         chunk_start, send_base, slot_of, req_send);
+                                                         chunk_start, send_base, slot_of, req_send, total, slot_shared,
+                                                         slot_stride);
   plan_finalize_kernel<<<grid_for_threads(tot), kBlock, 0, st>>>(users, tot, cap, table_bits, own, occ + tot, pos_cnt,
                                                                  slot_of, users_out, pos_slot, neg_slot, own_out);
   HIPREC_TRY(hipGetLastError());

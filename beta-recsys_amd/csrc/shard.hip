@@ -247,10 +247,20 @@ __device__ __forceinline__ float* seg_row(float* other, float* self_base, int64_
 __global__ __launch_bounds__(kBlock) void shard_payload_zero_kernel(
     const float* __restrict__ item_emb, const float* __restrict__ item_bias, int64_t n_rows, int dim,
     const int32_t* __restrict__ idx, int64_t n, int64_t self_lo, int64_t self_hi, float* __restrict__ payload,
-    float* __restrict__ self_dst, float* __restrict__ zero, int64_t zero_floats, int n_row_blocks,
-    hiprec_stats* stats) {
+    float* __restrict__ self_dst, float* __restrict__ zero, int64_t zero_floats, const uint8_t* __restrict__ shared,
+    int n_row_blocks, hiprec_stats* stats) {
   if (static_cast<int>(blockIdx.x) >= n_row_blocks) {
     const int64_t nb = gridDim.x - n_row_blocks;
+    if (shared != nullptr) {  // only the slots several triples add into (and the extra rows) have to start from zero
+      const int ldz = dim + 1;
+      const int64_t n_slots = zero_floats / ldz;
+      const int64_t w0 = static_cast<int64_t>(blockIdx.x - n_row_blocks) * kWavesPerBlock + wave_in_block();
+      for (int64_t slot = w0; slot < n_slots; slot += nb * kWavesPerBlock) {
+        if (!shared[slot]) continue;
+        for (int c = lane_id(); c < ldz; c += kWave) zero[slot * ldz + c] = 0.f;
+      }
+      return;
+    }
     const int64_t tid = static_cast<int64_t>(blockIdx.x - n_row_blocks) * kBlock + threadIdx.x;
     float4* z4 = reinterpret_cast<float4*>(zero);
     const int64_t n4 = zero_floats >> 2;
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void shard_apply_finish_kernel(
     float* __restrict__ t_emb, float* __restrict__ t_bias, int64_t n_rows, int dim, const int32_t* __restrict__ idx,
     const float* __restrict__ g_recv, int64_t n, int64_t self_lo, int64_t self_hi, const float* __restrict__ g_self,
     float coef, const int32_t* __restrict__ extra_pos, int n_src, float* scalar_target, float scalar_coef,
-    int first_of_epoch, int n_row_blocks, hiprec_stats* stats) {
+    int first_of_epoch, const uint32_t* __restrict__ dup_bits, int n_row_blocks, hiprec_stats* stats) {
   const int ld = dim + 1;
   if (static_cast<int>(blockIdx.x) >= n_row_blocks) {
     if (threadIdx.x != 0) return;
@@ -321,8 +331,15 @@ __global__ __launch_bounds__(kBlock) void shard_apply_finish_kernel(
       continue;
     }
     const float* g = seg_row(const_cast<float*>(g_recv), const_cast<float*>(g_self), k, self_lo, self_hi, ld);
-    for (int c = lane; c < dim; c += kWave) atomic_add_f32(t_emb + r * dim + c, coef * g[c]);
-    if (lane == 0) atomic_add_f32(t_bias + r, coef * g[dim]);
+    // a row only ONE peer returns a gradient for (the plan's duplicate bits say so) has a single writer: plain RMW
+    const bool contended = dup_bits == nullptr || ((dup_bits[r >> 5] >> (r & 31)) & 1u);
+    if (contended) {
+      for (int c = lane; c < dim; c += kWave) atomic_add_f32(t_emb + r * dim + c, coef * g[c]);
+      if (lane == 0) atomic_add_f32(t_bias + r, coef * g[dim]);
+    } else {
+      for (int c = lane; c < dim; c += kWave) t_emb[r * dim + c] += coef * g[c];
+      if (lane == 0) t_bias[r] += coef * g[dim];
+    }
   }
 }
 
@@ -435,7 +452,7 @@ extern "C" int hiprec_shard_join_rows(const float* emb, const float* bias, int64
 extern "C" int hiprec_shard_payload_zero(const float* item_emb, const float* item_bias, int64_t n_rows, int32_t dim,
                                          const int32_t* idx, int64_t n, int64_t self_lo, int64_t self_hi,
                                          float* payload, float* self_dst, float* zero, int64_t zero_floats,
-                                         hiprec_stats* stats, void* stream) {
+                                         const uint8_t* shared, hiprec_stats* stats, void* stream) {
   HIPREC_REQUIRE(n >= 0 && n_rows >= 0 && dim > 0 && zero_floats >= 0 && self_lo >= 0 && self_lo <= self_hi, "bad sizes");
   HIPREC_REQUIRE(stats && (n == 0 || (idx && payload)) && (zero_floats == 0 || zero) && (self_lo == self_hi || self_dst),
                  "NULL pointer");
@@ -444,7 +461,8 @@ extern "C" int hiprec_shard_payload_zero(const float* item_emb, const float* ite
   const int rb = n > 0 ? grid_for_waves(n) : 0;
   const int zb = zero_floats > 0 ? grid_for_threads((zero_floats + 15) / 16) : 0;   // 4 x float4 per thread
   shard_payload_zero_kernel<<<rb + zb, kBlock, 0, static_cast<hipStream_t>(stream)>>>(
-      item_emb, item_bias, n_rows, dim, idx, n, self_lo, self_hi, payload, self_dst, zero, zero_floats, rb, stats);
+      item_emb, item_bias, n_rows, dim, idx, n, self_lo, self_hi, payload, self_dst, zero, zero_floats, shared, rb,
+      stats);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
@@ -453,7 +471,7 @@ extern "C" int hiprec_shard_apply_finish(float* t_emb, float* t_bias, int64_t n_
                                          const float* g_recv, int64_t n, int64_t self_lo, int64_t self_hi,
                                          const float* g_self, double coef, const int32_t* extra_pos, int32_t n_src,
                                          float* scalar_target, double scalar_coef, int32_t first_of_epoch,
-                                         hiprec_stats* stats, void* stream) {
+                                         const uint32_t* dup_bits, hiprec_stats* stats, void* stream) {
   HIPREC_REQUIRE(n >= 0 && n_rows >= 0 && n_src > 0 && self_lo >= 0 && self_lo <= self_hi, "bad sizes");
   HIPREC_REQUIRE(dim >= 2, "an extra row carries 3 floats: the planned sharded step needs emb_dim >= 2");
   HIPREC_REQUIRE(stats && extra_pos && scalar_target && idx && g_recv && (self_lo == self_hi || g_self), "NULL pointer");
@@ -461,7 +479,7 @@ extern "C" int hiprec_shard_apply_finish(float* t_emb, float* t_bias, int64_t n_
   const int rb = n > 0 ? grid_for_waves(n) : 0;
   shard_apply_finish_kernel<<<rb + 1, kBlock, 0, static_cast<hipStream_t>(stream)>>>(
       t_emb, t_bias, n_rows, dim, idx, g_recv, n, self_lo, self_hi, g_self, static_cast<float>(coef), extra_pos, n_src,
-      scalar_target, static_cast<float>(scalar_coef), first_of_epoch, rb, stats);
+      scalar_target, static_cast<float>(scalar_coef), first_of_epoch, dup_bits, rb, stats);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
@@ -533,8 +551,10 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
     const int64_t in_hi = in_lo + inc[me] + 1;
     float* self_fetched = bufs->fetched + req_lo * ld;
     float* self_g = bufs->g_send + req_lo * ld;
+    const uint8_t* shared = plan->slot_shared ? plan->slot_shared + s * plan->slot_stride : nullptr;
+    const uint32_t* dup = plan->dup_bits ? plan->dup_bits + s * plan->dup_words : nullptr;
     if (int rc = hiprec_shard_payload_zero(item_emb, item_bias, ni, D, idx, il, in_lo, in_hi, bufs->payload,
-                                           self_fetched, bufs->g_send, sl * ld, stats, stream))
+                                           self_fetched, bufs->g_send, sl * ld, shared, stats, stream))
       return rc;
     if (R > 1) {
       if (g_start()) return HIPREC_E_UNSUPPORTED;
@@ -594,7 +614,7 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
     float* scalar = dense ? g + (nu + ni) * static_cast<int64_t>(ld) : gbias;
     if ((rc = hiprec_shard_apply_finish(t_emb, t_bias, ni, D, idx, bufs->g_recv, il, in_lo, in_hi, self_g,
                                         dense ? 1.0 : -lr, plan->ex_in + s * R, R, scalar, dense ? 1.0 : -lr,
-                                        s == 0 ? 1 : 0, stats, stream)))
+                                        s == 0 ? 1 : 0, dup, stats, stream)))
       return rc;
     if (dense && (rc = hiprec_opt_dense_step(kind, w, g, bufs->m_flat, bufs->v_flat, n_flat, lr, beta1, beta2, eps,
                                              stats, nullptr, -1, stream)))

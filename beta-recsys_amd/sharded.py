@@ -185,13 +185,13 @@ class HipKernels:
     def plan_place_triples(self, recv, recv_cnt, S, cap):
         R = recv_cnt.shape[0]
         U, P, N = (torch.empty(S * cap, dtype=torch.int64, device=self.device) for _ in range(3))
-        ws = self._i32(2 * R * S + 1)
+        ws = self._i32(2 * R * S + 1 + S)
         _lib.check(self.lib.hiprec_plan_place_triples(
             _lib.ptr(recv), recv.shape[0], _lib.ptr(recv_cnt), R, S, cap, _lib.ptr(ws), _lib.ptr(U), _lib.ptr(P),
             _lib.ptr(N), self._st()))
-        return U, P, N
+        return U, P, N, ws[2 * R * S + 1:]      # + triples per step: plan_item_slots pads only behind them
 
-    def plan_item_slots(self, U, P, N, S, cap, world, n_users_local, n_items):
+    def plan_item_slots(self, U, P, N, S, cap, world, n_users_local, n_items, fill=None):
         """Ownership tables of the step blocks + slots of the exchange buffers + the blocks grouped by positive item."""
         lib, tot = self.lib, S * cap
         bits = lib.hiprec_ownership_table_bits(cap)
@@ -208,28 +208,34 @@ class HipKernels:
         req_send = self._i32(2 * tot)
         U2, SP, SN = (torch.empty(tot, dtype=torch.int64, device=self.device) for _ in range(3))
         own2 = self._i32(3, tot)
+        slot_stride = 2 * cap + world    # one flag per slot: "several triples of the step add into it"
+        slot_shared = torch.empty((S, slot_stride), dtype=torch.uint8, device=self.device)
         _lib.check(lib.hiprec_plan_item_slots(
             _lib.ptr(U), S, cap, world, max(n_users_local, 1), bits, _lib.ptr(own), _lib.ptr(occ), _lib.ptr(tab_keys),
             _lib.ptr(pos_cnt), _lib.ptr(ws), _lib.ptr(slot_of), _lib.ptr(req_cnt), _lib.ptr(req_ds), _lib.ptr(ex_req),
             _lib.ptr(n_slots), _lib.ptr(send_base), _lib.ptr(req_send), _lib.ptr(U2), _lib.ptr(SP), _lib.ptr(SN),
-            _lib.ptr(own2), self._st()))
+            _lib.ptr(own2), _lib.ptr(total), _lib.ptr(slot_shared), slot_stride,
+            _lib.ptr(fill) if fill is not None else None, self._st()))
         return {"U": U2, "SP": SP, "SN": SN, "own": own2, "total": total, "stride": T, "req_cnt": req_cnt,
-                "req_ds": req_ds, "ex_req": ex_req, "req_send": req_send}
+                "req_ds": req_ds, "ex_req": ex_req, "req_send": req_send, "slot_shared": slot_shared}
 
-    def plan_place_requests(self, incoming, in_qs, S):
+    def plan_place_requests(self, incoming, in_qs, S, n_rows_local=0):
+        """-> (in_idx, ex_in, dup_bits): dup_bits uint32 [S, words] = rows more than one peer asks for in a step."""
         R, n_in = in_qs.shape[0], incoming.numel()
         ws, in_idx = self._i32(2 * R * S + 1), self._i32(n_in + R * S)
         step_off, ex_in = self._i32(S + 1), self._i32(S, R)
+        words = (n_rows_local + 31) // 32
+        dup_ws = self._i32(S, max(words, 1)) if words > 0 else None
         _lib.check(self.lib.hiprec_plan_place_requests(
             _lib.ptr(incoming), n_in, _lib.ptr(in_qs), R, S, _lib.ptr(ws), _lib.ptr(in_idx), _lib.ptr(step_off),
-            _lib.ptr(ex_in), self._st()))
-        return in_idx, ex_in
+            _lib.ptr(ex_in), n_rows_local, _lib.ptr(dup_ws) if dup_ws is not None else None, self._st()))
+        return in_idx, ex_in, dup_ws
 
     def payload_zero(self, item_emb, item_bias, idx, payload, g_send):
         """payload[k] = [item_emb row | item_bias] of LOCAL row idx[k] (zeros for -1); g_send = 0."""
         _lib.check(self.lib.hiprec_shard_payload_zero(
             _lib.ptr(item_emb), _lib.ptr(item_bias), item_emb.shape[0], item_emb.shape[1], _lib.ptr(idx), idx.numel(),
-            0, 0, _lib.ptr(payload), None, _lib.ptr(g_send), g_send.numel(), _lib.ptr(self.stats), self._st()))
+            0, 0, _lib.ptr(payload), None, _lib.ptr(g_send), g_send.numel(), None, _lib.ptr(self.stats), self._st()))
 
     def owned_remote_step(self, model, fetched, g_send, n_slots, users, slot_pos, slot_neg, own, total, arrived, acc,
                           inv_batch, reg_coef, lr):
@@ -258,7 +264,7 @@ class HipKernels:
         _lib.check(self.lib.hiprec_shard_apply_finish(
             _lib.ptr(t_emb), _lib.ptr(t_bias), t_emb.shape[0], t_emb.shape[1], _lib.ptr(idx), _lib.ptr(g_recv),
             idx.numel(), 0, 0, None, coef, _lib.ptr(extra_pos), extra_pos.numel(), _lib.ptr(scalar_target), scalar_coef,
-            1 if first_of_epoch else 0, _lib.ptr(self.stats), self._st()))
+            1 if first_of_epoch else 0, None, _lib.ptr(self.stats), self._st()))
 
     def planned_steps(self, plan, bufs, model, g_flat, opt, a, b, reg, comm):
         """Steps [a, b) of a planned epoch -- kernels AND exchanges -- enqueued by ONE C call
@@ -274,7 +280,11 @@ class HipKernels:
                 plan["SP"].data_ptr(), plan["SN"].data_ptr(), plan["own"].data_ptr(), plan["total"].data_ptr(),
                 plan["stride"], plan["in_idx"].data_ptr(), plan["ex_req"].data_ptr(), plan["ex_in"].data_ptr(),
                 host["in_off_h"].ctypes.data, host["n_slots_h"].ctypes.data, host["req_cnt_h"].ctypes.data,
-                host["in_cnt_h"].ctypes.data)
+                host["in_cnt_h"].ctypes.data,
+                plan["slot_shared"].data_ptr() if plan.get("slot_shared") is not None else None,
+                plan["slot_shared"].shape[1] if plan.get("slot_shared") is not None else 0,
+                plan["dup_bits"].data_ptr() if plan.get("dup_bits") is not None else None,
+                plan["dup_bits"].shape[1] if plan.get("dup_bits") is not None else 0)
             c = plan["_c"] = (sp, host)
         dense = opt.name != "sgd"
         sb = _lib.ShardBufs(
@@ -657,11 +667,11 @@ class ShardedMFEngine:
             k.check_status()   # out-of-range ids: IndexError, as nn.Embedding raises (and the status word is cleared)
         send1, recv1, cap = host[:R], host[R:2 * R], max(int(host[2 * R]), 1)
         recv = self._a2a(send[:sum(send1)], send1, recv1, pg)               # (source, step)-ordered
-        U, P, N = k.plan_place_triples(recv, recv_cnt, S, cap)              # fixed-size blocks per step, user -1 = padding
+        U, P, N, fill = k.plan_place_triples(recv, recv_cnt, S, cap)        # fixed-size blocks per step, user -1 = padding
 
         # (2) the step's distinct items become slots of its exchange buffer ([rows asked of q ..., 1 extra row] per
         # owner q), the blocks are re-laid grouped by positive item with their row-ownership arrays
-        sl = k.plan_item_slots(U, P, N, S, cap, R, self.model.n_users, self.n_items)
+        sl = k.plan_item_slots(U, P, N, S, cap, R, self.model.n_users, self.n_items, fill)
 
         # (3) tell every owner which rows it will be asked for, step by step: one exchange
         req_ds = sl["req_ds"]
@@ -673,7 +683,8 @@ class ShardedMFEngine:
         req_l = [host[2 * R + j * R: 2 * R + (j + 1) * R] for j in range(S)]
         in_l = [host[2 * R + S * R + j * R: 2 * R + S * R + (j + 1) * R] for j in range(S)]
         incoming = self._a2a(sl["req_send"][:sum(send2)], send2, recv2, pg)  # (source, step)-ordered
-        in_idx, ex_in = k.plan_place_requests(incoming, in_qs, S)
+        placed = k.plan_place_requests(incoming, in_qs, S, self.model.n_items)
+        in_idx, ex_in, dup_bits = placed if len(placed) == 3 else (placed + (None,))
         in_len = [sum(c) + R for c in in_l]
         n_slots = [sum(c) + R for c in req_l]
         in_off = [0]
@@ -683,7 +694,7 @@ class ShardedMFEngine:
                 "SN": sl["SN"], "own": sl["own"], "total": sl["total"], "stride": sl["stride"], "in_idx": in_idx,
                 "in_off": in_off[:-1], "in_len": in_len, "n_slots": n_slots,
                 "req_split": [[c + 1 for c in row] for row in req_l], "in_split": [[c + 1 for c in row] for row in in_l],
-                "ex_req": sl["ex_req"], "ex_in": ex_in,
+                "ex_req": sl["ex_req"], "ex_in": ex_in, "slot_shared": sl.get("slot_shared"), "dup_bits": dup_bits,
                 "in_off_h": in_off, "n_slots_h": n_slots, "req_cnt_h": req_l, "in_cnt_h": in_l}
 
     def prefetch_setup(self):

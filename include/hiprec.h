@@ -371,7 +371,9 @@ int hiprec_shard_finish_step(const float* g_recv, int32_t dim, const int64_t* ex
  *      in stats->status and the triple is dropped (the host turns the bits into IndexError, like nn.Embedding).
  *  hiprec_plan_place_triples  recv[3 * n_recv]: what the triple exchange delivered, (source, step)-ordered with
  *      recv_cnt[world * n_steps] (source-major) elements per group -> users / pos / neg[n_steps * cap] (int64), step
- *      s in block [s * cap, (s + 1) * cap), sources in rank order, padding user = -1.  group_ws: 2 * world * n_steps + 1.
+ *      s in block [s * cap, (s + 1) * cap), sources in rank order, padding user = -1.  group_ws: 2 * world * n_steps + 1
+ *      + n_steps ints; its last n_steps ints return the triples per step (hiprec_plan_item_slots' step_fill: with it
+ *      only the padding behind a step's live triples is written, not the whole output arrays).
  *  hiprec_plan_item_slots  from the blocks above (users[] = local user rows) and their ownership tables (batch = cap,
  *      n_users = n_users_local, n_items = the GLOBAL item count; own / occ [3][n_steps * cap], tab_keys / pos_cnt
  *      [n_steps << table_bits]; pos_cnt is overwritten): every distinct item of a step gets one slot of the step's
@@ -383,7 +385,12 @@ int hiprec_shard_finish_step(const float* g_recv, int32_t dim, const int64_t* ex
  *      padding -1 / 0 / 0) and own_out[3][n_steps * cap].  ws: hiprec_plan_slot_ws_ints(...) ints.
  *  hiprec_plan_place_requests  incoming[n_in]: the rows peers will ask for, (source, step)-ordered with
  *      in_cnt[world * n_steps] (source-major) -> in_idx[n_in + world * n_steps] packed step by step, sources in rank
- *      order, each followed by one extra row (-1); step_off[n_steps + 1]; extra_pos[n_steps][world]. */
+ *      order, each followed by one extra row (-1); step_off[n_steps + 1]; extra_pos[n_steps][world].  dup_ws
+ *      (optional, [n_steps][(n_rows_local + 31) / 32] uint32) receives one bit per (step, local row) = "more than one
+ *      peer asks for this row in this step".
+ *  hiprec_plan_item_slots' slot_shared (optional, uint8 [n_steps][slot_stride >= 2 cap + world], with total = the
+ *      ownership tables' counts): 1 for the slots that several triples of the step reference and for the extra rows
+ *      -- the only rows of the gradient exchange buffer that must be zero when the step starts. */
 int hiprec_batch_row_ownership_tables(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
                                       int64_t batch, int64_t n_users, int64_t n_items, int32_t table_bits,
                                       int32_t* keys, int32_t* total, int32_t* own, int32_t* tab_keys, int32_t* pos_cnt,
@@ -400,23 +407,28 @@ int hiprec_plan_item_slots(const int64_t* users, int64_t n_steps, int64_t cap, i
                            int32_t table_bits, const int32_t* own, const int32_t* occ, const int32_t* tab_keys,
                            int32_t* pos_cnt, int32_t* ws, int32_t* slot_of, int32_t* req_cnt, int32_t* req_ds,
                            int32_t* ex_req, int32_t* n_slots, int32_t* send_base, int32_t* req_send,
-                           int64_t* users_out, int64_t* pos_slot, int64_t* neg_slot, int32_t* own_out, void* stream);
+                           int64_t* users_out, int64_t* pos_slot, int64_t* neg_slot, int32_t* own_out,
+                           const int32_t* total, uint8_t* slot_shared, int64_t slot_stride, const int32_t* step_fill,
+                           void* stream);
 int hiprec_plan_place_requests(const int32_t* incoming, int64_t n_in, const int32_t* in_cnt, int32_t world,
                                int64_t n_steps, int32_t* group_ws, int32_t* in_idx, int32_t* step_off,
-                               int32_t* extra_pos, void* stream);
+                               int32_t* extra_pos, int64_t n_rows_local, uint32_t* dup_ws, void* stream);
 
 /* The planned step in three launches.  Rows [self_lo, self_hi) of a step's incoming block are the ones this rank
  * asked of itself: they never travel (self_dst / g_self point into the fetched / the send buffer).
  *  hiprec_shard_payload_zero  payload[k] = [item_emb[idx[k]] | item_bias[idx[k]]] (zeros for idx -1) AND
- *      zero[0, zero_floats) = 0 (the gradient exchange buffer) in ONE launch;
+ *      zero[0, zero_floats) = 0 (the gradient exchange buffer; with `shared`, one byte per [dim + 1]-float row of it,
+ *      only the rows flagged 1) in ONE launch;
  *  hiprec_mf_bpr_grad_remote_step  hiprec_mf_bpr_owned_remote_step for Adam / RMSprop: nothing is updated, the local
  *      user rows' gradients go into g_flat (dense, laid out like w_flat, zero on entry);
  *  hiprec_shard_apply_finish  target row idx[k] += coef * g_recv[k] (SGD: the item table, coef = -lr; dense
  *      optimizers: the dense gradient, coef = 1) AND the step's bookkeeping (the peers' extra rows -> stats,
- *      *scalar_target += scalar_coef * d loss / d scalar bias, t <- t + 1) in ONE launch. */
+ *      *scalar_target += scalar_coef * d loss / d scalar bias, t <- t + 1) in ONE launch; dup_bits (optional): one
+ *      bit per target row, 0 = only one of this step's rows names it (plain read-modify-write instead of atomics). */
 int hiprec_shard_payload_zero(const float* item_emb, const float* item_bias, int64_t n_rows, int32_t dim,
                               const int32_t* idx, int64_t n, int64_t self_lo, int64_t self_hi, float* payload,
-                              float* self_dst, float* zero, int64_t zero_floats, hiprec_stats* stats, void* stream);
+                              float* self_dst, float* zero, int64_t zero_floats, const uint8_t* shared,
+                              hiprec_stats* stats, void* stream);
 int hiprec_mf_bpr_grad_remote_step(const float* w_flat, float* g_flat, int64_t n_users, int64_t n_items_local,
                                    int32_t dim, const float* fetched, float* g_send, int64_t n_slots,
                                    const int64_t* users, const int64_t* pos_slot, const int64_t* neg_slot,
@@ -426,7 +438,8 @@ int hiprec_mf_bpr_grad_remote_step(const float* w_flat, float* g_flat, int64_t n
 int hiprec_shard_apply_finish(float* t_emb, float* t_bias, int64_t n_rows, int32_t dim, const int32_t* idx,
                               const float* g_recv, int64_t n, int64_t self_lo, int64_t self_hi, const float* g_self,
                               double coef, const int32_t* extra_pos, int32_t n_src, float* scalar_target,
-                              double scalar_coef, int32_t first_of_epoch, hiprec_stats* stats, void* stream);
+                              double scalar_coef, int32_t first_of_epoch, const uint32_t* dup_bits, hiprec_stats* stats,
+                              void* stream);
 
 /* One epoch plan as the step driver reads it (device arrays as the planner wrote them; the *_host arrays are the
  * exact sizes of the exchanges, host integers: nothing is read back while the steps are enqueued). */
@@ -447,6 +460,10 @@ typedef struct hiprec_shard_plan {
   const int64_t* n_slots_host;   /* [n_steps] */
   const int64_t* req_cnt_host;   /* [n_steps][world] rows asked of each owner (extra row not counted) */
   const int64_t* in_cnt_host;    /* [n_steps][world] rows each peer asks for */
+  const uint8_t* slot_shared;    /* optional [n_steps][slot_stride]: hiprec_plan_item_slots */
+  int64_t slot_stride;
+  const uint32_t* dup_bits;      /* optional [n_steps][dup_words]: hiprec_plan_place_requests */
+  int64_t dup_words;
 } hiprec_shard_plan;
 
 typedef struct hiprec_shard_bufs {

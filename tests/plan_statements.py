@@ -154,6 +154,12 @@ def check_item_slots(out, U, P, N, S, cap, R, n_users_local):
                 c = cnt_of[int(ids[t])]
                 assert (slot < 0 and c == 1) or int(total[slot]) == c, "ownership does not match the batch"
         assert (own[:, n_live:] == -1).all()
+        if "slot_shared" in o and o["slot_shared"] is not None:   # 1 = several references (or an extra row)
+            flags = o["slot_shared"][s][:n_slots]
+            refs = np.bincount(np.concatenate([sp[:n_live], sn[:n_live]]), minlength=n_slots)
+            want_flags = (refs > 1).astype(np.uint8)
+            want_flags[o["ex_req"][s]] = 1
+            assert np.array_equal(flags, want_flags), "slot_shared does not say which slots several triples add into"
 
 
 def plan_place_requests(incoming, in_qs, S):

@@ -65,14 +65,30 @@ def test_plan_place_triples_and_requests(hip_device, R, S, mean):
     n = int(cnt.sum())
     recv = rng.integers(0, 1 << 20, (n, 3)).astype(np.int32)
     cap = int(cnt.sum(0).max()) + 3
-    U, P, N = k.plan_place_triples(torch.from_numpy(recv).cuda(), torch.from_numpy(cnt).cuda(), S, cap)
+    U, P, N, fill = k.plan_place_triples(torch.from_numpy(recv).cuda(), torch.from_numpy(cnt).cuda(), S, cap)
     rU, rP, rN = ps.plan_place_triples(recv, cnt, S, cap)
     for got, ref in ((U, rU), (P, rP), (N, rN)):
         assert np.array_equal(got.cpu().numpy(), ref)
-    incoming = rng.integers(0, 1 << 20, n).astype(np.int32)
-    in_idx, ex_in = k.plan_place_requests(torch.from_numpy(incoming).cuda(), torch.from_numpy(cnt).cuda(), S)
+    assert np.array_equal(fill.cpu().numpy(), cnt.sum(0))
+    # requests: every source's list is free of duplicates, rows repeat ACROSS sources (hot items)
+    n_local = 5000
+    incoming = np.concatenate([rng.choice(n_local, int(c), replace=False) if c <= n_local else rng.integers(0, n_local, int(c))
+                               for c in cnt.reshape(-1)] + [np.zeros(0, dtype=np.int64)]).astype(np.int32)
+    in_idx, ex_in, dup = k.plan_place_requests(torch.from_numpy(incoming).cuda(), torch.from_numpy(cnt).cuda(), S, n_local)
     r_idx, r_ex = ps.plan_place_requests(incoming, cnt, S)
     assert np.array_equal(in_idx.cpu().numpy(), r_idx) and np.array_equal(ex_in.cpu().numpy(), r_ex)
+    # the duplicate bits: a row more than one peer asks for in a step
+    step_len = cnt.sum(0).astype(np.int64) + R
+    off = np.concatenate([[0], np.cumsum(step_len)])
+    dup = dup.cpu().numpy().view(np.uint32)
+    for s in range(S):
+        rows = r_idx[off[s]:off[s + 1]]
+        rows = rows[rows >= 0]
+        want = np.zeros(n_local, dtype=bool)
+        vals, c = np.unique(rows, return_counts=True)
+        want[vals[c > 1]] = True
+        got = ((dup[s][np.arange(n_local) >> 5] >> (np.arange(n_local) & 31)) & 1).astype(bool)
+        assert np.array_equal(got, want), f"step {s}: duplicate bits"
 
 
 @pytest.mark.parametrize("R,S,cap,I", [(1, 3, 500, 97), (4, 5, 700, 211), (8, 4, 3000, 5003), (3, 2, 40, 7),
@@ -91,6 +107,11 @@ def test_plan_item_slots_properties(hip_device, R, S, cap, I):
         U[s * cap: s * cap + live], P[s * cap: s * cap + live], N[s * cap: s * cap + live] = u, p, q
     dev = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
     out = k.plan_item_slots(dev(U), dev(P), dev(N), S, cap, R, n_users_local, I)
+    torch.cuda.synchronize()
+    ps.check_item_slots(out, U, P, N, S, cap, R, n_users_local)
+    # with the triples per step given, only the padding behind them is written (no memset of the outputs)
+    live = torch.from_numpy((U.reshape(S, cap) >= 0).sum(1).astype(np.int32)).cuda()
+    out = k.plan_item_slots(dev(U), dev(P), dev(N), S, cap, R, n_users_local, I, live)
     torch.cuda.synchronize()
     ps.check_item_slots(out, U, P, N, S, cap, R, n_users_local)
     # the statement's own answer satisfies the same contract
@@ -118,7 +139,7 @@ def test_payload_zero_and_apply_finish_with_a_self_segment(hip_device):
     self_dst = torch.full((hi - lo, ld), 7.0, device="cuda")
     zero = torch.full((1234,), 5.0, device="cuda")
     _lib.check(lib.hiprec_shard_payload_zero(_lib.ptr(emb), _lib.ptr(bias), n_rows, D, _lib.ptr(idx), n, lo, hi,
-                                             _lib.ptr(payload), _lib.ptr(self_dst), _lib.ptr(zero), zero.numel(),
+                                             _lib.ptr(payload), _lib.ptr(self_dst), _lib.ptr(zero), zero.numel(), None,
                                              _lib.ptr(k.stats), k._st()))
     ref = np.concatenate([emb.cpu().numpy(), bias.cpu().numpy()], 1)[np.maximum(idx_np, 0)]
     ref[idx_np < 0] = 0.0
@@ -127,6 +148,13 @@ def test_payload_zero_and_apply_finish_with_a_self_segment(hip_device):
     assert (got[lo:hi] == 7.0).all(), "the self segment must not be written into the exchange buffer"
     assert np.array_equal(self_dst.cpu().numpy(), ref[lo:hi])
     assert float(zero.abs().max()) == 0.0
+    # with flags, only the flagged [D + 1]-float rows of the gradient buffer are cleared
+    gbuf = torch.full((40, ld), 5.0, device="cuda")
+    flags = torch.from_numpy((rng.random(40) < 0.3).astype(np.uint8)).cuda()
+    _lib.check(lib.hiprec_shard_payload_zero(_lib.ptr(emb), _lib.ptr(bias), n_rows, D, _lib.ptr(idx), n, lo, hi,
+                                             _lib.ptr(payload), _lib.ptr(self_dst), _lib.ptr(gbuf), gbuf.numel(),
+                                             _lib.ptr(flags), _lib.ptr(k.stats), k._st()))
+    assert torch.equal((gbuf == 0).all(1), flags.bool()) and torch.equal((gbuf == 5.0).all(1), ~flags.bool())
 
     g_np = rng.standard_normal((n, ld)).astype(np.float32)
     g_np[extra_pos, :3] = [[0.5, 0.25, 0.125], [1.0, 2.0, 4.0], [0.0625, 8.0, 16.0]]
@@ -136,9 +164,16 @@ def test_payload_zero_and_apply_finish_with_a_self_segment(hip_device):
     w_emb, w_bias, scalar = emb.clone(), bias.clone(), torch.tensor([3.0], device="cuda")
     k.reset_clock(0.9, 0.999)
     ep = torch.from_numpy(extra_pos).cuda()
+    # duplicate bits as the plan would set them: rows named more than once take the atomic path, the others a plain RMW
+    vals, cnts = np.unique(idx_np[idx_np >= 0], return_counts=True)
+    bits = np.zeros((n_rows + 31) // 32, dtype=np.uint32)
+    for r in vals[cnts > 1]:
+        bits[r >> 5] |= np.uint32(1) << np.uint32(r & 31)
+    assert (cnts > 1).any() and (cnts == 1).any()
+    dup_bits = torch.from_numpy(bits.view(np.int32)).cuda()
     _lib.check(lib.hiprec_shard_apply_finish(_lib.ptr(w_emb), _lib.ptr(w_bias), n_rows, D, _lib.ptr(idx),
                                              _lib.ptr(g_recv), n, lo, hi, _lib.ptr(g_self), -0.5, _lib.ptr(ep), n_src,
-                                             _lib.ptr(scalar), -0.5, 1, _lib.ptr(k.stats), k._st()))
+                                             _lib.ptr(scalar), -0.5, 1, _lib.ptr(dup_bits), _lib.ptr(k.stats), k._st()))
     ref_emb, ref_bias = emb.cpu().numpy().astype(np.float64), bias.cpu().numpy().astype(np.float64)
     keep = idx_np >= 0
     np.add.at(ref_emb, idx_np[keep], -0.5 * g_np[keep, :D].astype(np.float64))

@@ -454,14 +454,14 @@ class OraclePlannedKernels(OracleKernels):
         super().check_status()
 
     def plan_place_triples(self, recv, recv_cnt, S, cap):
-        return tuple(torch.from_numpy(a) for a in ps.plan_place_triples(recv.numpy(), recv_cnt.numpy(), S, cap))
+        return tuple(torch.from_numpy(a) for a in ps.plan_place_triples(recv.numpy(), recv_cnt.numpy(), S, cap)) + (None,)
 
-    def plan_item_slots(self, U, P, N, S, cap, world, n_users_local, n_items):
+    def plan_item_slots(self, U, P, N, S, cap, world, n_users_local, n_items, fill=None):
         out = ps.plan_item_slots(U.numpy(), P.numpy(), N.numpy(), S, cap, world, n_users_local)
         ps.check_item_slots(out, U.numpy(), P.numpy(), N.numpy(), S, cap, world, n_users_local)
         return {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in out.items()}
 
-    def plan_place_requests(self, incoming, in_qs, S):
+    def plan_place_requests(self, incoming, in_qs, S, n_rows_local=0):
         return tuple(torch.from_numpy(a) for a in ps.plan_place_requests(incoming.numpy(), in_qs.numpy(), S))
 
     def payload_zero(self, item_emb, item_bias, idx, payload, g_send):
