@@ -69,7 +69,7 @@ __device__ __forceinline__ SlicedEdges<FACTORED> load_sliced_edges(const uint16_
                                                                    const void* __restrict__ edges, int2 d, int q,
                                                                    uint32_t zero_row) {
   SlicedEdges<FACTORED> e;
-  const bool live = q * 16 < (d.y >> 16);
+  const bool live = q * 16 < ((d.y >> 16) & 0xFF);
   const int64_t base = static_cast<int64_t>(d.x) + q * 16;  // a multiple of 16: 32-B / 64-B aligned
   if constexpr (FACTORED) {
     const uint32_t z = zero_row | (zero_row << 16);
@@ -116,13 +116,16 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
   const uint32_t row_bytes = W * sizeof(float);
   const uint32_t lds_base =
       static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)s_x));
-  const int s = static_cast<int>(blockIdx.x) / a.n_groups, g = static_cast<int>(blockIdx.x) % a.n_groups;
+  const int n_slices = static_cast<int>(gridDim.x) / a.n_groups;
+  const int s = (fl.exp & 1) ? static_cast<int>(blockIdx.x) % n_slices : static_cast<int>(blockIdx.x) / a.n_groups;
+  const int g = (fl.exp & 1) ? static_cast<int>(blockIdx.x) / n_slices : static_cast<int>(blockIdx.x) % a.n_groups;
   const int64_t slice_off = static_cast<int64_t>(s) * n_rows * W;
   const int quad = static_cast<int>(threadIdx.x) >> 2, q = static_cast<int>(threadIdx.x) & 3;
+  const int lane = static_cast<int>(threadIdx.x) & 63;
   const int2* __restrict__ chunks = reinterpret_cast<const int2*>(a.chunks);
   const int sg_begin = g * a.subs_per_group, sg_end = sg_begin + a.subs_per_group;
   const int c_end = a.sub_chunk[sg_end];  // the block's chunks: sub_chunk[sg_begin] .. c_end
-  auto desc = [&](int c) { return c < c_end ? chunks[c] : int2{0, 0}; };  // {first slot, row | n_slots << 16}
+  auto desc = [&](int c) { return c < c_end ? chunks[c] : int2{0, 0}; };  // {first slot, row | n_slots << 16 | first chunk of its row << 24 | last << 25}
   // The chunk pipeline runs through the block's subgroups without draining: quad k takes chunks k, k + 256, ...
   // of the block, with its next chunks' descriptors and edge data in flight ahead of the arithmetic.
   // the slice: every thread's (at most kSlicedFill) 16-byte loads are issued together -- a load-store loop would pay
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
 #pragma unroll
   for (int k = 0; k < kSlicedFill; ++k) {
     const int i = static_cast<int>(threadIdx.x) + k * kSlicedThreads;
-    fill[k] = i < n4 ? x4[i] : float4{0.f, 0.f, 0.f, 0.f};
+    fill[k] = (i < n4 && !(fl.exp & 16)) ? x4[i] : float4{0.f, 0.f, 0.f, 0.f};
   }
   int c = a.sub_chunk[sg_begin] + quad;
   // P: edge data of P chunks in flight ahead of the arithmetic (descriptors one more).  Three instead of one
@@ -228,7 +231,49 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
         t = dpp_add<0x4E>(t);             // quad_perm [2,3,0,1]
         mine = q == w ? t : mine;
       }
-      if (q < W && (d0.y >> 16) > 0) lds_add_f32(&s_y[((d0.y & 0xFFFF) - r0) * W + q], mine);
+      // A row's chunks are consecutive, so the quads of a wave that work on one row are neighbours -- and LDS float
+      // atomics are slow (~3 cycles per LANE: with 64 lanes adding into ~5 rows' accumulators the ds_add was 11 of a
+      // pass's 27.5 us, profiles/r03_experiments.md 39).  So the wave sums a row's quads itself -- a segmented
+      // inclusive scan over its 16 quads: runs found by comparing neighbours (one ballot), two DPP steps inside every
+      // 16-lane row, totals carried from row to row through SGPRs; sources are always LOWER quads, which are still
+      // in this loop whenever this one is -- and the LAST quad of a run stores.  The descriptor says which chunk is
+      // the first / the last of its row: a run that holds both holds the whole row and takes a plain store; only
+      // rows cut by a 16-chunk window (or longer than one) still add atomically.
+      const int row = d0.y & 0xFFFF;
+      const int r16 = lane >> 4, qir = (lane >> 2) & 3;
+      int prev_row = __builtin_amdgcn_update_dpp(-1, row, 0x114, 0xF, 0xF, false);  // row_shr:4
+      {
+        const int e1 = __builtin_amdgcn_readlane(row, 12), e2 = __builtin_amdgcn_readlane(row, 28),
+                  e3 = __builtin_amdgcn_readlane(row, 44);
+        if (qir == 0) prev_row = r16 == 1 ? e1 : r16 == 2 ? e2 : r16 == 3 ? e3 : -1;
+      }
+      const uint64_t firsts = __ballot(prev_row != row), active = __ballot(true), heads = __ballot((d0.y >> 24) & 1);
+      const int run_quad = (63 - __clzll(static_cast<long long>(firsts & ((2ull << lane) - 1)))) >> 2;
+      const int behind = (lane >> 2) - run_quad;  // quads of my run before mine
+      {
+        const int in_row = behind < qir ? behind : qir;
+        const float o1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0x114, 0xF, 0xF, false));
+        if (in_row >= 1) mine += o1;
+        const float o2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0x118, 0xF, 0xF, false));  // row_shr:8
+        if (in_row >= 2) mine += o2;
+      }
+#pragma unroll
+      for (int r = 1; r < 4; ++r) {  // in order: row r - 1's last quad has its own carry by now
+        const bool need = r16 == r && behind > qir;
+        if (__ballot(need) != 0) {
+          const int mi = __builtin_bit_cast(int, mine);
+          const int c0 = __builtin_amdgcn_readlane(mi, 16 * r - 4), c1 = __builtin_amdgcn_readlane(mi, 16 * r - 3),
+                    c2 = __builtin_amdgcn_readlane(mi, 16 * r - 2), c3 = __builtin_amdgcn_readlane(mi, 16 * r - 1);
+          if (need) mine += __builtin_bit_cast(float, q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : c3);
+        }
+      }
+      const int nl = (lane + 4) & 63;
+      const bool last = lane >= 60 || !((active >> nl) & 1) || ((firsts >> nl) & 1);
+      if (q < W && ((d0.y >> 16) & 0xFF) > 0 && last) {
+        float* dst = &s_y[(row - r0) * W + q];
+        if (((heads >> (4 * run_quad)) & 1) && ((d0.y >> 25) & 1)) *dst = mine;
+        else lds_add_f32(dst, mine);
+      }
       c += kSlicedQuads;
 #pragma unroll
       for (int k = 0; k < P; ++k) dq[k] = dq[k + 1];
@@ -241,7 +286,7 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int i = static_cast<int>(threadIdx.x) + k * kSlicedThreads;
-      if (i < n_out) {
+      if (i < n_out && (!(fl.exp & 4) || s_y[i] == 1e30f)) {
         float y = s_y[i] * scale, y_next = y;
         if constexpr (FACTORED) {  // row factor now; the next pass wants its source scaled by the column factor
           const int r = r0 + (W == 4 ? i >> 2 : i >> 1);
@@ -415,6 +460,7 @@ int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scal
   const bool factored = a->col_scale != nullptr;
   if (edges == nullptr) edges = factored ? static_cast<const void*>(a->col16) : static_cast<const void*>(a->val);
   const int grid = (dim / W) * a->n_groups;
+  if (const char* e = getenv("HIPREC_SLICED_EXP")) fl.exp = atoi(e);
   if (W == 4 && factored)
     spmm_sliced_kernel<4, true><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, fl, dim);
   else if (W == 4)

@@ -128,7 +128,10 @@ def sliced_graph_host(rowptr, col, val, eid, n_groups, row_cap, max_subs=64, fac
     within = np.arange(n_chunks, dtype=np.int64) - first[chunk_row]
     start = slotptr[chunk_row] + SLICED_CHUNK * within
     clen = np.minimum(SLICED_CHUNK, padded[chunk_row] - SLICED_CHUNK * within)
-    chunks = np.stack([start, chunk_row | (clen << 16)], axis=1).astype(np.int32)
+    # descriptor: first slot, row | slots << 16 | (first chunk of its row) << 24 | (last chunk of its row) << 25 -- a
+    # wave that holds a row's first and last chunk holds the whole row and needs no atomics (csrc/spmm_sliced.hip)
+    ends = ((within == 0).astype(np.int64) << 24) | ((within == per_row[chunk_row] - 1).astype(np.int64) << 25)
+    chunks = np.stack([start, chunk_row | (clen << 16) | ends], axis=1).astype(np.int32)
     for k in range(1, max_subs + 1):
         n_sub = n_groups * k
         target = np.minimum((np.arange(n_sub + 1) * n_chunks) // n_sub, max(n_chunks - 1, 0))
@@ -163,7 +166,7 @@ def spread_bank_conflicts(host, n_groups, quads_per_block=256):
     if n_chunks == 0:
         return 1.0, 1.0
     start = chunks[:, 0].astype(np.int64)
-    clen = (chunks[:, 1] >> 16).astype(np.int64)
+    clen = ((chunks[:, 1] >> 16) & 0xFF).astype(np.int64)
     block_first = host["sub_chunk"][np.arange(n_groups + 1) * k].astype(np.int64)  # chunks of block g
     block_of = np.searchsorted(block_first, np.arange(n_chunks), side="right") - 1
     idx = np.arange(n_chunks) - block_first[block_of]

@@ -664,8 +664,8 @@ int hiprec_csr_slice_rows(const hiprec_csr* a, int32_t* out, int64_t n_out, void
 /* A graph stored for the column-sliced SpMM (n_rows < 65536).  Every row's edge list is padded to a multiple of 16
  * SLOTS: col16 / val / eid hold n_slots entries (padding: col 0, val 0, eid -1; eid = the edge's index into the keep
  * bytes of a step, i.e. its number in the FORWARD graph's CSR order).  Work items are chunks: at most 64 consecutive
- * slots of one row, chunks[2 * c] = first slot (a multiple of 16), chunks[2 * c + 1] = row | n_slots_of_chunk << 16,
- * sorted by row.  The rows are cut into n_groups * subs_per_group subgroups of consecutive rows and about equal
+ * slots of one row, chunks[2 * c] = first slot (a multiple of 16), chunks[2 * c + 1] = row | n_slots_of_chunk << 16
+ * | (1 << 24 if it is the first chunk of its row) | (1 << 25 if it is the last), sorted by row.  The rows are cut into n_groups * subs_per_group subgroups of consecutive rows and about equal
  * chunk count: subgroup k covers rows sub_row[k] .. sub_row[k + 1] (sub_row[0] = 0, the last = n_rows; at most
  * row_cap rows, so that their accumulators fit the LDS next to the slice: hiprec_sliced_row_cap) and chunks
  * sub_chunk[k] .. sub_chunk[k + 1].  n_groups should be a multiple of 8 with (dim / slice width) * n_groups = the

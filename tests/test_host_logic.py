@@ -802,8 +802,12 @@ def test_sliced_graph_host_covers_every_edge_once(n, n_groups, cap, heavy):
     h = sliced_graph_host(rowptr, col, val, eid, n_groups, cap)
     assert h is not None
     chunks, k = h["chunks"], h["subs_per_group"]
-    start, row, clen = chunks[:, 0], chunks[:, 1] & 0xFFFF, chunks[:, 1] >> 16
+    start, row, clen = chunks[:, 0], chunks[:, 1] & 0xFFFF, (chunks[:, 1] >> 16) & 0xFF
     assert np.all(clen >= SLICED_PAD) and np.all(clen <= SLICED_CHUNK) and np.all(np.diff(row) >= 0)
+    # bits 24 / 25: the first / the last chunk of its row (what lets a wave store a whole row without atomics)
+    head, tail = (chunks[:, 1] >> 24) & 1, (chunks[:, 1] >> 25) & 1
+    assert np.array_equal(head, np.concatenate([[1], np.diff(row) != 0]).astype(head.dtype))
+    assert np.array_equal(tail, np.concatenate([np.diff(row) != 0, [1]]).astype(tail.dtype))
     assert np.all(start % SLICED_PAD == 0) and np.all(clen % SLICED_PAD == 0) and h["n_slots"] % SLICED_PAD == 0
     covered = np.zeros(h["n_slots"], dtype=np.int32)
     slot_row = np.full(h["n_slots"], -1)
