@@ -170,6 +170,13 @@ __device__ __forceinline__ int run_head(const long long* s_item, int wv, long lo
   return head;
 }
 
+// ... and one past its last wave (n_waves = waves of the block)
+__device__ __forceinline__ int run_end(const long long* s_item, int wv, long long item, int n_waves) {
+  int end = wv + 1;
+  while (end < n_waves && s_item[end] == item) ++end;
+  return end;
+}
+
 __device__ __forceinline__ float sigmoid_f32(float s) { return 1.0f / (1.0f + expf(-s)); }
 
 // -logsigmoid(x) and sigmoid(-x) the way ATen computes them (min(x,0) - log1p(exp(-|x|)))

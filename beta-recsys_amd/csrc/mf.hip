@@ -133,6 +133,7 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
     lds_barrier();
     const int head = valid ? run_head(s_item, wv, p) : wv;
     const bool is_head = head == wv;
+    const int tail = (valid && is_head) ? run_end(s_item, wv, p, kAggWaves) : wv + 1;
 
     const float* ur = w.user_emb + u * D;
     const float* pr = w.item_emb + p * D;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
           if (c < D) {
             atomic_add_f32(gur + c, (dpos * pp[k] + dneg * nn[k]) + ru * uu[k]);
             atomic_add_f32(gnr + c, dneg * uu[k] + ri * nn[k]);
-            if (is_head) slot[c] = dpos * uu[k] + ri * pp[k];
+            slot[c] = dpos * uu[k] + ri * pp[k];
           }
         }
       } else {
@@ -196,38 +197,27 @@ __global__ __launch_bounds__(kAggBlock) void mf_bpr_grad_kernel(
           const float a = ur[c], b = pr[c], d = nr[c];
           atomic_add_f32(gur + c, (dpos * b + dneg * d) + ru * a);
           atomic_add_f32(gnr + c, dneg * a + ri * d);
-          if (is_head) slot[c] = dpos * a + ri * b;
+          slot[c] = dpos * a + ri * b;
         }
       }
       if (lane == 0) {
         atomic_add_f32(g.user_bias + u, (dpos + dneg) + ru * bu);
         atomic_add_f32(g.item_bias + n, dneg + ri * bn);
-        if (is_head) slot[D] = dpos + ri * bp;
+        slot[D] = dpos + ri * bp;
         reg_acc += 2.f * bu * bu + bp * bp + bn * bn;
       }
       loss_acc += nls;
       gb_acc += dpos + dneg;
     }
     lds_barrier();
-    if (valid && !is_head) {  // merge into the run head's slot
-      float* slot = s_acc + head * ld;
-      if constexpr (NPL > 0) {
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) {
-          const int c = lane + kWave * k;
-          if (c < D) lds_add_f32(slot + c, dpos * uu[k] + ri * pp[k]);
-        }
-      } else {
-        for (int c = lane; c < D; c += kWave) lds_add_f32(slot + c, dpos * ur[c] + ri * pr[c]);
-      }
-      if (lane == 0) lds_add_f32(slot + D, dpos + ri * bp);
-    }
-    lds_barrier();
-    if (valid && is_head) {  // one global atomic per run
-      const float* slot = s_acc + wv * ld;
+    if (valid && is_head) {  // the head sums its run's slots (plain LDS reads: LDS float atomics cost ~3 cycles per
+                             // lane, experiments 39) and issues one global atomic per element of the run
       float* gpr = g.item_emb + p * D;
-      for (int c = lane; c < D; c += kWave) atomic_add_f32(gpr + c, slot[c]);
-      if (lane == 0) atomic_add_f32(g.item_bias + p, slot[D]);
+      for (int c = lane; c <= D; c += kWave) {
+        float t = s_acc[wv * ld + c];
+        for (int j = wv + 1; j < tail; ++j) t += s_acc[j * ld + c];
+        atomic_add_f32(c < D ? gpr + c : g.item_bias + p, t);
+      }
     }
     cur = nxt;
   }
@@ -443,6 +433,7 @@ void mf_bpr_fused_kernel(
     lds_barrier();
     const int head = valid ? run_head(s_item, wv, p) : wv;
     const bool is_head = head == wv;
+    const int tail = (valid && is_head) ? run_end(s_item, wv, p, kAggWaves) : wv + 1;
 
     float uu[NPL], pp[NPL];
     float dpos = 0.f, bp = 0.f;
@@ -545,34 +536,26 @@ void mf_bpr_fused_kernel(
         if (c < D) {
           atomic_add_f32(gur + c, (dpos * pp[k] + dneg * nn[k]) + ru * uu[k]);
           atomic_add_f32(gnr + c, dneg * uu[k] + ri * nn[k]);
-          if (is_head) slot[c] = dpos * uu[k] + ri * pp[k];
+          slot[c] = dpos * uu[k] + ri * pp[k];
         }
       }
       if (lane == 0) {
         atomic_add_f32(gf + o_ub + u, (dpos + dneg) + ru * bu);
         atomic_add_f32(gf + o_ib + n, dneg + ri * bn);
-        if (is_head) slot[D] = dpos + ri * bp;
+        slot[D] = dpos + ri * bp;
         reg_acc += 2.f * bu * bu + bp * bp + bn * bn;
       }
       loss_acc += nls;
       gb_acc += dpos + dneg;
     }
     lds_barrier();
-    if (valid && !is_head) {
-      float* slot = s_acc + head * ld;
-#pragma unroll
-      for (int k = 0; k < NPL; ++k) {
-        const int c = lane + kWave * k;
-        if (c < D) lds_add_f32(slot + c, dpos * uu[k] + ri * pp[k]);
-      }
-      if (lane == 0) lds_add_f32(slot + D, dpos + ri * bp);
-    }
-    lds_barrier();
-    if (valid && is_head) {
-      const float* slot = s_acc + wv * ld;
+    if (valid && is_head) {  // the head sums its run's slots: plain LDS reads instead of LDS float atomics
       float* gpr = gf + o_ie + p * D;
-      for (int c = lane; c < D; c += kWave) atomic_add_f32(gpr + c, slot[c]);
-      if (lane == 0) atomic_add_f32(gf + o_ib + p, slot[D]);
+      for (int c = lane; c <= D; c += kWave) {
+        float t = s_acc[wv * ld + c];
+        for (int j = wv + 1; j < tail; ++j) t += s_acc[j * ld + c];
+        atomic_add_f32(c < D ? gpr + c : gf + o_ib + p, t);
+      }
     }
   }
   // publish this step's partials; n_partials = number of GATHER blocks
@@ -641,6 +624,7 @@ __global__ __launch_bounds__(kAggBlock) void mf_bce_grad_kernel(
     lds_barrier();
     const int head = valid ? run_head(s_item, wv, i) : wv;
     const bool is_head = head == wv;
+    const int tail = (valid && is_head) ? run_end(s_item, wv, i, kAggWaves) : wv + 1;
 
     const float* ur = w.user_emb + u * D;
     const float* ir = w.item_emb + i * D;
@@ -685,44 +669,32 @@ __global__ __launch_bounds__(kAggBlock) void mf_bce_grad_kernel(
           const int c = lane + kWave * k;
           if (c < D) {
             atomic_add_f32(gur + c, ds * ii[k] + rr * uu[k]);
-            if (is_head) slot[c] = ds * uu[k] + rr * ii[k];
+            slot[c] = ds * uu[k] + rr * ii[k];
           }
         }
       } else {
         for (int c = lane; c < D; c += kWave) {
           const float a = ur[c], b = ir[c];
           atomic_add_f32(gur + c, ds * b + rr * a);
-          if (is_head) slot[c] = ds * a + rr * b;
+          slot[c] = ds * a + rr * b;
         }
       }
       if (lane == 0) {
         atomic_add_f32(g.user_bias + u, ds + rr * bu);
-        if (is_head) slot[D] = ds + rr * bi;
+        slot[D] = ds + rr * bi;
         reg_acc += bu * bu + bi * bi;
       }
       loss_acc += loss_k;
       gb_acc += ds;
     }
     lds_barrier();
-    if (valid && !is_head) {
-      float* slot = s_acc + head * ld;
-      if constexpr (NPL > 0) {
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) {
-          const int c = lane + kWave * k;
-          if (c < D) lds_add_f32(slot + c, ds * uu[k] + rr * ii[k]);
-        }
-      } else {
-        for (int c = lane; c < D; c += kWave) lds_add_f32(slot + c, ds * ur[c] + rr * ir[c]);
-      }
-      if (lane == 0) lds_add_f32(slot + D, ds + rr * bi);
-    }
-    lds_barrier();
-    if (valid && is_head) {
-      const float* slot = s_acc + wv * ld;
+    if (valid && is_head) {  // the head sums its run's slots: plain LDS reads instead of LDS float atomics
       float* gir = g.item_emb + i * D;
-      for (int c = lane; c < D; c += kWave) atomic_add_f32(gir + c, slot[c]);
-      if (lane == 0) atomic_add_f32(g.item_bias + i, slot[D]);
+      for (int c = lane; c <= D; c += kWave) {
+        float t = s_acc[wv * ld + c];
+        for (int j = wv + 1; j < tail; ++j) t += s_acc[j * ld + c];
+        atomic_add_f32(c < D ? gir + c : g.item_bias + i, t);
+      }
     }
   }
   publish_partials<kAggWaves>(loss_acc, reg_acc, gb_acc, inv_batch, scratch);
