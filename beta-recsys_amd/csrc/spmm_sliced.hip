@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
   const int2* __restrict__ chunks = reinterpret_cast<const int2*>(a.chunks);
   const int sg_begin = g * a.subs_per_group, sg_end = sg_begin + a.subs_per_group;
   const int c_end = a.sub_chunk[sg_end];  // the block's chunks: sub_chunk[sg_begin] .. c_end
-  auto desc = [&](int c) { return c < c_end ? chunks[c] : int2{0, 0}; };  // {first slot, row | n_slots << 16 | first chunk of its row << 24 | last << 25}
+  auto desc = [&](int c) { return c < c_end ? chunks[c] : int2{0, 0}; };  // {first slot, row | n_slots << 16 | run flags}
   // The chunk pipeline runs through the block's subgroups without draining: quad k takes chunks k, k + 256, ...
   // of the block, with its next chunks' descriptors and edge data in flight ahead of the arithmetic.
   // the slice: every thread's (at most kSlicedFill) 16-byte loads are issued together -- a load-store loop would pay
@@ -233,33 +233,23 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
       }
       // A row's chunks are consecutive, so the quads of a wave that work on one row are neighbours -- and LDS float
       // atomics are slow (~3 cycles per LANE: with 64 lanes adding into ~5 rows' accumulators the ds_add was 11 of a
-      // pass's 27.5 us, profiles/r03_experiments.md 39).  So the wave sums a row's quads itself -- a segmented
-      // inclusive scan over its 16 quads: runs found by comparing neighbours (one ballot), two DPP steps inside every
-      // 16-lane row, totals carried from row to row through SGPRs; sources are always LOWER quads, which are still
-      // in this loop whenever this one is -- and the LAST quad of a run stores.  The descriptor says which chunk is
-      // the first / the last of its row: a run that holds both holds the whole row and takes a plain store; only
-      // rows cut by a 16-chunk window (or longer than one) still add atomically.
-      const int row = d0.y & 0xFFFF;
-      const int r16 = lane >> 4, qir = (lane >> 2) & 3;
-      int prev_row = __builtin_amdgcn_update_dpp(-1, row, 0x114, 0xF, 0xF, false);  // row_shr:4
+      // pass's 27.5 us, profiles/r03_experiments.md 39).  So the wave sums a row's quads itself: a segmented
+      // inclusive scan over its 16 quads -- two DPP steps inside every 16-lane row, then the total so far carried
+      // from row to row through SGPRs -- and the LAST quad of a run stores: plainly when the run is the whole row,
+      // with an LDS atomic when a 16-chunk window cut the row.  Which quad does what is static (subgroups start on
+      // window boundaries, so a wave's 16 quads always hold one window) and comes with the descriptor:
+      // lightgcn.py _windowed_chunks.
+      const uint32_t dy = static_cast<uint32_t>(d0.y);
       {
-        const int e1 = __builtin_amdgcn_readlane(row, 12), e2 = __builtin_amdgcn_readlane(row, 28),
-                  e3 = __builtin_amdgcn_readlane(row, 44);
-        if (qir == 0) prev_row = r16 == 1 ? e1 : r16 == 2 ? e2 : r16 == 3 ? e3 : -1;
-      }
-      const uint64_t firsts = __ballot(prev_row != row), active = __ballot(true), heads = __ballot((d0.y >> 24) & 1);
-      const int run_quad = (63 - __clzll(static_cast<long long>(firsts & ((2ull << lane) - 1)))) >> 2;
-      const int behind = (lane >> 2) - run_quad;  // quads of my run before mine
-      {
-        const int in_row = behind < qir ? behind : qir;
-        const float o1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0x114, 0xF, 0xF, false));
+        const int in_row = (dy >> 24) & 3;
+        const float o1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0x114, 0xF, 0xF, false));  // row_shr:4
         if (in_row >= 1) mine += o1;
         const float o2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0x118, 0xF, 0xF, false));  // row_shr:8
         if (in_row >= 2) mine += o2;
       }
 #pragma unroll
       for (int r = 1; r < 4; ++r) {  // in order: row r - 1's last quad has its own carry by now
-        const bool need = r16 == r && behind > qir;
+        const bool need = ((dy >> 26) & 1) && (lane >> 4) == r;
         if (__ballot(need) != 0) {
           const int mi = __builtin_bit_cast(int, mine);
           const int c0 = __builtin_amdgcn_readlane(mi, 16 * r - 4), c1 = __builtin_amdgcn_readlane(mi, 16 * r - 3),
@@ -267,11 +257,9 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
           if (need) mine += __builtin_bit_cast(float, q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : c3);
         }
       }
-      const int nl = (lane + 4) & 63;
-      const bool last = lane >= 60 || !((active >> nl) & 1) || ((firsts >> nl) & 1);
-      if (q < W && ((d0.y >> 16) & 0xFF) > 0 && last) {
-        float* dst = &s_y[(row - r0) * W + q];
-        if (((heads >> (4 * run_quad)) & 1) && ((d0.y >> 25) & 1)) *dst = mine;
+      if (q < W && ((dy >> 27) & 1)) {
+        float* dst = &s_y[(static_cast<int>(dy & 0xFFFF) - r0) * W + q];
+        if ((dy >> 28) & 1) *dst = mine;
         else lds_add_f32(dst, mine);
       }
       c += kSlicedQuads;

@@ -99,6 +99,46 @@ def factor_edge_values(rowptr, col, val, rel_tol=2e-6, max_rounds=256):
     return r32, c32
 
 
+def _windowed_chunks(start, chunk_row, clen, within, per_row, sub_chunk):
+    """Chunk descriptors as csrc/spmm_sliced.hip wants them.  A wave of the kernel works on a WINDOW of 16
+    consecutive chunks (one per quad of lanes) and sums the chunks of one row inside the window itself before anything
+    touches the LDS accumulators; what it has to do is static, so it is worked out here:
+      * every subgroup is padded with empty chunks (0 slots) to a multiple of 16, so that a window never straddles two
+        subgroups and the 16 quads of a wave always work on the same window;
+      * a RUN = the consecutive chunks of one row inside a window.  Per chunk: its position in the run counted inside
+        its 16-lane row of the wave (bits 24-25: how many of the two DPP scan steps apply), whether the run began in an
+        earlier 16-lane row (bit 26: take the carry of that row's last quad), whether it is the run's last chunk (bit
+        27: it stores) and whether the run is the whole row (bit 28: a plain store, else an LDS atomic add).
+    Descriptor: first slot, row | slots << 16 | flags.  Returns (chunks int32 [n, 2], sub_chunk)."""
+    sizes = np.diff(sub_chunk)
+    padded = (sizes + 15) // 16 * 16
+    new_sub = np.concatenate([[0], np.cumsum(padded)])
+    n_new = int(new_sub[-1])
+    sub_of_old = np.repeat(np.arange(sizes.size), sizes)
+    new_idx = new_sub[sub_of_old] + np.arange(sub_of_old.size) - sub_chunk[sub_of_old]
+    # an empty chunk carries the row of its subgroup's last real chunk (descriptors stay sorted by row)
+    last_row = chunk_row[np.maximum(sub_chunk[1:] - 1, 0)] if chunk_row.size else np.zeros(sizes.size, np.int64)
+    row2 = np.repeat(last_row, padded)
+    start2, clen2 = np.zeros(n_new, np.int64), np.zeros(n_new, np.int64)
+    within2, per2 = np.zeros(n_new, np.int64), np.ones(n_new, np.int64)
+    real = np.zeros(n_new, bool)
+    row2[new_idx], start2[new_idx], clen2[new_idx] = chunk_row, start, clen
+    within2[new_idx], per2[new_idx], real[new_idx] = within, per_row[chunk_row], True
+    idx = np.arange(n_new)
+    prev_real = np.concatenate([[False], real[:-1]])
+    prev_row = np.concatenate([[-1], row2[:-1]])
+    new_run = ((idx & 15) == 0) | (row2 != prev_row) | ~real | ~prev_real
+    run_start = np.maximum.accumulate(np.where(new_run, idx, 0))
+    behind, qir = idx - run_start, idx & 3
+    last = np.concatenate([new_run[1:], [True]]) & real
+    whole = last & (within2[run_start] == 0) & (within2 == per2 - 1)
+    flags = (np.minimum(behind, qir) << 24) | ((behind > qir).astype(np.int64) << 26) | (last.astype(np.int64) << 27) \
+        | (whole.astype(np.int64) << 28)
+    flags[~real] = 0
+    desc = (row2 | (clen2 << 16) | flags).astype(np.int64)
+    return np.stack([start2, desc], axis=1).astype(np.int32), new_sub
+
+
 def sliced_graph_host(rowptr, col, val, eid, n_groups, row_cap, max_subs=64, factor=True):
     """hiprec_sliced_csr (include/hiprec.h) of a CSR given as numpy arrays; eid = keep-byte index of every edge
     (None = the edge number itself).  factor: look for the rank-one form of the values (factor_edge_values); the
@@ -128,10 +168,6 @@ def sliced_graph_host(rowptr, col, val, eid, n_groups, row_cap, max_subs=64, fac
     within = np.arange(n_chunks, dtype=np.int64) - first[chunk_row]
     start = slotptr[chunk_row] + SLICED_CHUNK * within
     clen = np.minimum(SLICED_CHUNK, padded[chunk_row] - SLICED_CHUNK * within)
-    # descriptor: first slot, row | slots << 16 | (first chunk of its row) << 24 | (last chunk of its row) << 25 -- a
-    # wave that holds a row's first and last chunk holds the whole row and needs no atomics (csrc/spmm_sliced.hip)
-    ends = ((within == 0).astype(np.int64) << 24) | ((within == per_row[chunk_row] - 1).astype(np.int64) << 25)
-    chunks = np.stack([start, chunk_row | (clen << 16) | ends], axis=1).astype(np.int32)
     for k in range(1, max_subs + 1):
         n_sub = n_groups * k
         target = np.minimum((np.arange(n_sub + 1) * n_chunks) // n_sub, max(n_chunks - 1, 0))
@@ -140,8 +176,9 @@ def sliced_graph_host(rowptr, col, val, eid, n_groups, row_cap, max_subs=64, fac
         sub_row = np.maximum.accumulate(sub_row)
         sub_chunk = np.append(first, n_chunks)[sub_row]  # a subgroup starts at the first chunk of its first row
         if np.diff(sub_row).max() <= row_cap:
+            chunks, sub_chunk = _windowed_chunks(start, chunk_row, clen, within, per_row, sub_chunk)
             out = {"col16": col16, "val": valp, "eid": eidp, "chunks": chunks, "sub_row": sub_row.astype(np.int32),
-                   "sub_chunk": sub_chunk.astype(np.int32), "subs_per_group": k, "n_chunks": n_chunks,
+                   "sub_chunk": sub_chunk.astype(np.int32), "subs_per_group": k, "n_chunks": int(chunks.shape[0]),
                    "n_slots": n_slots}
             if scales is not None:
                 out["row_scale"], out["col_scale"] = scales

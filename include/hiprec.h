@@ -665,7 +665,11 @@ int hiprec_csr_slice_rows(const hiprec_csr* a, int32_t* out, int64_t n_out, void
  * SLOTS: col16 / val / eid hold n_slots entries (padding: col 0, val 0, eid -1; eid = the edge's index into the keep
  * bytes of a step, i.e. its number in the FORWARD graph's CSR order).  Work items are chunks: at most 64 consecutive
  * slots of one row, chunks[2 * c] = first slot (a multiple of 16), chunks[2 * c + 1] = row | n_slots_of_chunk << 16
- * | (1 << 24 if it is the first chunk of its row) | (1 << 25 if it is the last), sorted by row.  The rows are cut into n_groups * subs_per_group subgroups of consecutive rows and about equal
+ * | run flags, sorted by row; every subgroup is padded with empty chunks (0 slots) to a multiple of 16 chunks.  The
+ * kernel's workgroup of 1024 threads gives a WINDOW of 16 consecutive chunks to a wave (one per quad of lanes) and sums
+ * the chunks of one row inside the window (a RUN) before the LDS sees them; the flags say what a quad does: bits 24-25
+ * min(position in the run, quad index inside its 16-lane row), bit 26 the run began in an earlier 16-lane row, bit 27
+ * last chunk of the run (it stores), bit 28 the run is the whole row (plain store instead of an LDS atomic).  The rows are cut into n_groups * subs_per_group subgroups of consecutive rows and about equal
  * chunk count: subgroup k covers rows sub_row[k] .. sub_row[k + 1] (sub_row[0] = 0, the last = n_rows; at most
  * row_cap rows, so that their accumulators fit the LDS next to the slice: hiprec_sliced_row_cap) and chunks
  * sub_chunk[k] .. sub_chunk[k + 1].  n_groups should be a multiple of 8 with (dim / slice width) * n_groups = the

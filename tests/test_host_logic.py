@@ -803,12 +803,45 @@ def test_sliced_graph_host_covers_every_edge_once(n, n_groups, cap, heavy):
     assert h is not None
     chunks, k = h["chunks"], h["subs_per_group"]
     start, row, clen = chunks[:, 0], chunks[:, 1] & 0xFFFF, (chunks[:, 1] >> 16) & 0xFF
-    assert np.all(clen >= SLICED_PAD) and np.all(clen <= SLICED_CHUNK) and np.all(np.diff(row) >= 0)
-    # bits 24 / 25: the first / the last chunk of its row (what lets a wave store a whole row without atomics)
-    head, tail = (chunks[:, 1] >> 24) & 1, (chunks[:, 1] >> 25) & 1
-    assert np.array_equal(head, np.concatenate([[1], np.diff(row) != 0]).astype(head.dtype))
-    assert np.array_equal(tail, np.concatenate([np.diff(row) != 0, [1]]).astype(tail.dtype))
+    real = clen > 0  # subgroups are padded with empty chunks to a multiple of 16
+    assert np.all(clen[real] >= SLICED_PAD) and np.all(clen <= SLICED_CHUNK) and np.all(np.diff(row) >= 0)
     assert np.all(start % SLICED_PAD == 0) and np.all(clen % SLICED_PAD == 0) and h["n_slots"] % SLICED_PAD == 0
+    assert np.all(h["sub_chunk"] % 16 == 0) and chunks.shape[0] % 16 == 0
+    # the run flags, checked by doing what a wave of csrc/spmm_sliced.hip does with them on one number per chunk:
+    # two DPP steps inside groups of 4 quads, carries from group to group, the last quad of a run stores / adds
+    flags = chunks[:, 1].astype(np.int64) & 0xFFFFFFFF
+    in_row, carry, last, whole = (flags >> 24) & 3, (flags >> 26) & 1, (flags >> 27) & 1, (flags >> 28) & 1
+    value = rng.integers(1, 1000, chunks.shape[0]).astype(np.int64) * real
+    acc, plain_rows = np.zeros(n, dtype=np.int64), []
+    for w0 in range(0, chunks.shape[0], 16):
+        x = value[w0:w0 + 16].copy()
+        x1 = x.copy()
+        for j in range(16):
+            if in_row[w0 + j] >= 1:
+                assert j % 4 >= 1
+                x1[j] = x[j] + x[j - 1]
+        x2 = x1.copy()
+        for j in range(16):
+            if in_row[w0 + j] >= 2:
+                assert j % 4 >= 2
+                x2[j] = x1[j] + x1[j - 2]
+        for r in range(1, 4):
+            for j in range(4 * r, 4 * r + 4):
+                if carry[w0 + j]:
+                    x2[j] += x2[4 * r - 1]
+        for j in range(16):
+            if last[w0 + j]:
+                assert real[w0 + j]
+                acc[row[w0 + j]] += x2[j]
+                if whole[w0 + j]:
+                    plain_rows.append(row[w0 + j])
+    want = np.zeros(n, dtype=np.int64)
+    np.add.at(want, row[real], value[real])
+    assert np.array_equal(acc, want), "the runs do not add up to the rows"
+    assert len(set(plain_rows)) == len(plain_rows), "a row stored plainly twice"
+    stores = np.bincount(row[last == 1], minlength=n)
+    assert np.all(stores[np.array(plain_rows, dtype=np.int64)] == 1), "a plainly stored row has other contributions"
+    start, row, clen = start[real], row[real], clen[real]
     covered = np.zeros(h["n_slots"], dtype=np.int32)
     slot_row = np.full(h["n_slots"], -1)
     for s, r, c in zip(start, row, clen):
@@ -829,8 +862,9 @@ def test_sliced_graph_host_covers_every_edge_once(n, n_groups, cap, heavy):
     assert sub_row.size == n_groups * k + 1 and sub_row[0] == 0 and sub_row[-1] == n
     assert sub_chunk[0] == 0 and sub_chunk[-1] == h["n_chunks"] == chunks.shape[0]
     assert np.all(np.diff(sub_row) >= 0) and np.diff(sub_row).max() <= cap
+    all_rows = chunks[:, 1] & 0xFFFF
     for i in range(n_groups * k):
-        rows_of = row[sub_chunk[i]:sub_chunk[i + 1]]
+        rows_of = all_rows[sub_chunk[i]:sub_chunk[i + 1]]
         assert np.all((rows_of >= sub_row[i]) & (rows_of < sub_row[i + 1]))
     assert sliced_graph_host(rowptr, col, val, None, 1, 1, max_subs=4) is None
     empty = sliced_graph_host(np.zeros(11, dtype=np.int64), col[:0], val[:0], None, 8, 16)
