@@ -20,7 +20,7 @@ struct SlicedFlush {
   float* zero_out = nullptr;     // sliced buffer cleared row by row as a by-product
   float* final_out = nullptr;    // row-major: instead of ys / accs, the layer sum (accs + Y for acc_mode 1, Y otherwise)
   bool final_set = false;        //   is stored here (true) or added (false)
-  int exp = 0;                   // EXPERIMENT bits (HIPREC_SLICED_EXP): 1 = slice-major block map, 2 = no ds_add
+  int exp = 0;                   // experiment bits, -DHIPREC_SLICED_DEBUG builds only (spmm_sliced.hip)
 };
 int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scale, const float* xs, float* ys,
                        float* accs, int acc_mode, int dim, int W, hipStream_t st, SlicedFlush fl = SlicedFlush{});

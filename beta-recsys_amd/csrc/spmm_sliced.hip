@@ -39,6 +39,16 @@
 
 namespace hiprec {
 
+// Timing experiments (tools/exp_spmm_parts.py, profiles/r03_experiments.md 39): parts of the kernel switched off by the
+// bits of HIPREC_SLICED_EXP -- 1 slice-major block map, 4 no output stores, 16 no slice fill (results are wrong with
+// 4 / 16).  Only in builds made with -DHIPREC_SLICED_DEBUG (tools/build_debug_lib.sh); the product library has no
+// such switch.
+#ifdef HIPREC_SLICED_DEBUG
+#define HIPREC_SLICED_EXP(bit) ((fl.exp & (bit)) != 0)
+#else
+#define HIPREC_SLICED_EXP(bit) false
+#endif
+
 constexpr int kSlicedThreads = 1024;
 constexpr int kSlicedQuads = kSlicedThreads / 4;
 constexpr int64_t kSlicedLds = 160 * 1024 - 64;  // one workgroup's LDS, less the kernel's own few words
@@ -117,8 +127,8 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
   const uint32_t lds_base =
       static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)s_x));
   const int n_slices = static_cast<int>(gridDim.x) / a.n_groups;
-  const int s = (fl.exp & 1) ? static_cast<int>(blockIdx.x) % n_slices : static_cast<int>(blockIdx.x) / a.n_groups;
-  const int g = (fl.exp & 1) ? static_cast<int>(blockIdx.x) / n_slices : static_cast<int>(blockIdx.x) % a.n_groups;
+  const int s = HIPREC_SLICED_EXP(1) ? static_cast<int>(blockIdx.x) % n_slices : static_cast<int>(blockIdx.x) / a.n_groups;
+  const int g = HIPREC_SLICED_EXP(1) ? static_cast<int>(blockIdx.x) / n_slices : static_cast<int>(blockIdx.x) % a.n_groups;
   const int64_t slice_off = static_cast<int64_t>(s) * n_rows * W;
   const int quad = static_cast<int>(threadIdx.x) >> 2, q = static_cast<int>(threadIdx.x) & 3;
   const int lane = static_cast<int>(threadIdx.x) & 63;
@@ -136,7 +146,7 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
 #pragma unroll
   for (int k = 0; k < kSlicedFill; ++k) {
     const int i = static_cast<int>(threadIdx.x) + k * kSlicedThreads;
-    fill[k] = (i < n4 && !(fl.exp & 16)) ? x4[i] : float4{0.f, 0.f, 0.f, 0.f};
+    fill[k] = (i < n4 && !HIPREC_SLICED_EXP(16)) ? x4[i] : float4{0.f, 0.f, 0.f, 0.f};
   }
   int c = a.sub_chunk[sg_begin] + quad;
   // P: edge data of P chunks in flight ahead of the arithmetic (descriptors one more).  Three instead of one
@@ -162,12 +172,19 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
     const int r0 = a.sub_row[sg], r1 = a.sub_row[sg + 1], c1 = a.sub_chunk[sg + 1];
     const int n_out = (r1 - r0) * W;
     const int64_t out0 = slice_off + static_cast<int64_t>(r0) * W;
-    float old[2] = {0.f, 0.f};  // the layer sum's current values, fetched while the chunks are processed
-    if (acc_mode == 1) {
+    // fetched while the chunks are processed: the layer sum's current values and the rows' two factors (requested
+    // after the barrier they would put an L2 round trip in front of every flush)
+    float old[2] = {0.f, 0.f}, rs[2] = {1.f, 1.f}, cs[2] = {1.f, 1.f};
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int i = static_cast<int>(threadIdx.x) + k * kSlicedThreads;
-        if (i < n_out) old[k] = accs[out0 + i];
+    for (int k = 0; k < 2; ++k) {
+      const int i = static_cast<int>(threadIdx.x) + k * kSlicedThreads;
+      if (i < n_out) {
+        if (acc_mode == 1) old[k] = accs[out0 + i];
+        if constexpr (FACTORED) {
+          const int r = r0 + (W == 4 ? i >> 2 : i >> 1);
+          rs[k] = a.row_scale[r];
+          cs[k] = a.col_scale[r];
+        }
       }
     }
     while (c < c1) {
@@ -274,12 +291,11 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int i = static_cast<int>(threadIdx.x) + k * kSlicedThreads;
-      if (i < n_out && (!(fl.exp & 4) || s_y[i] == 1e30f)) {
+      if (i < n_out && (!HIPREC_SLICED_EXP(4) || s_y[i] == 1e30f)) {
         float y = s_y[i] * scale, y_next = y;
         if constexpr (FACTORED) {  // row factor now; the next pass wants its source scaled by the column factor
-          const int r = r0 + (W == 4 ? i >> 2 : i >> 1);
-          y *= a.row_scale[r];
-          y_next = y * a.col_scale[r];
+          y *= rs[k];
+          y_next = y * cs[k];
         }
         s_y[i] = 0.f;
         if (final_out != nullptr) {  // the result (plus the layer sum so far, acc_mode 1) goes straight to row-major
@@ -448,7 +464,9 @@ int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scal
   const bool factored = a->col_scale != nullptr;
   if (edges == nullptr) edges = factored ? static_cast<const void*>(a->col16) : static_cast<const void*>(a->val);
   const int grid = (dim / W) * a->n_groups;
+#ifdef HIPREC_SLICED_DEBUG
   if (const char* e = getenv("HIPREC_SLICED_EXP")) fl.exp = atoi(e);
+#endif
   if (W == 4 && factored)
     spmm_sliced_kernel<4, true><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, fl, dim);
   else if (W == 4)

@@ -1,7 +1,8 @@
 """Where a pass of the column-sliced SpMM spends its time on the C5 graph (nnz 1 985 746): the kernel's experiment bits
-(HIPREC_SLICED_EXP, read per launch: 1 slice-major block map, 2 no ds_add, 4 no output stores, 16 no slice fill;
-results are wrong with 2 / 4 / 16: timing only) and the two debug edge streams (every slot -> the zero row; lane-constant
-consecutive rows)."""
+(HIPREC_SLICED_EXP, read per launch, only in a library built by tools/build_debug_lib.sh and selected with
+HIPREC_LIB=libhiprec_debug.so: 1 slice-major block map, 4 no output stores, 16 no slice fill; results are wrong with
+4 / 16: timing only) and the debug edge streams (40 % of the slots -> the zero row as in a training step; every slot ->
+the zero row; lane-constant consecutive rows).  profiles/r03_experiments.md 39."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -47,7 +48,7 @@ train = torch.where(drop, torch.full_like(live, N), live).to(torch.int16)
 zero = torch.full((host["n_slots"],), N, dtype=torch.int16, device=dev)
 seq = (torch.arange(host["n_slots"], device=dev) // 16 % 9000).to(torch.int16)
 streams = {"graph": None, "training (40 % dropped)": train, "all zero row": zero, "conflict-free": seq}
-for exp in (0, 1, 2, 4, 16, 2 | 4, 2 | 4 | 16):
+for exp in (0, 0, 1, 4, 16, 4 | 16):
     os.environ["HIPREC_SLICED_EXP"] = str(exp)
     row = []
     for name, e in streams.items():
