@@ -326,20 +326,32 @@ __global__ __launch_bounds__(kBlock) void step_values_kernel(hiprec_sliced_csr a
                                                              float* __restrict__ out_b, SlicedInput in) {
   // eight consecutive slots per thread (n_slots is a multiple of 16): 16-byte loads and stores
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock, total = (a.n_slots + b.n_slots) >> 3;
-  // ... and, riding on the same launch, the step's input matrix into the sliced layout (to_sliced_kernel's work)
-  const int64_t n_in = in.x != nullptr ? in.n_rows * in.dim : 0;
+  // ... and, riding on the same launch (its FIRST threads: not a tail), the step's input matrix into the sliced layout
+  // (to_sliced_kernel's work): one W-float group per thread, 32-bit index arithmetic
+  const int per_row = in.x != nullptr ? in.dim / in.W : 0;
+  const int64_t n_in = static_cast<int64_t>(per_row) * in.n_rows;  // < 2^31: n_rows < 65536
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total + n_in; i += stride) {
-    if (i >= total) {
-      const int64_t j = i - total, r = j / in.dim;
-      const int c = static_cast<int>(j - r * in.dim);
-      const int64_t o = (static_cast<int64_t>(c / in.W) * in.n_rows + r) * in.W + c % in.W;
-      const float v = in.x[j];
-      in.xs[o] = in.row_scale ? v * in.row_scale[r] : v;
-      if (in.xs_copy) in.xs_copy[o] = v;
+    if (i < n_in) {
+      const uint32_t j = static_cast<uint32_t>(i), r = j / static_cast<uint32_t>(per_row),
+                     sl = j - r * static_cast<uint32_t>(per_row);
+      const float* src = in.x + static_cast<int64_t>(r) * in.dim + sl * in.W;
+      const int64_t o = (static_cast<int64_t>(sl) * in.n_rows + r) * in.W;
+      const float f = in.row_scale ? in.row_scale[r] : 1.f;
+      if (in.W == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        *reinterpret_cast<float4*>(in.xs + o) = float4{v.x * f, v.y * f, v.z * f, v.w * f};
+        if (in.xs_copy) *reinterpret_cast<float4*>(in.xs_copy + o) = v;
+      } else {
+        for (int c = 0; c < in.W; ++c) {
+          in.xs[o + c] = src[c] * f;
+          if (in.xs_copy) in.xs_copy[o + c] = src[c];
+        }
+      }
       continue;
     }
-    const bool first = (i << 3) < a.n_slots;
-    const int64_t e = first ? i << 3 : (i << 3) - a.n_slots;
+    const int64_t w8 = (i - n_in) << 3;
+    const bool first = w8 < a.n_slots;
+    const int64_t e = first ? w8 : w8 - a.n_slots;
     const hiprec_sliced_csr& gph = first ? a : b;
     const int4 k0 = *reinterpret_cast<const int4*>(gph.eid + e), k1 = *reinterpret_cast<const int4*>(gph.eid + e + 4);
     const int32_t k[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
@@ -487,7 +499,8 @@ int launch_step_values(const hiprec_sliced_csr* a, const hiprec_sliced_csr* b, u
   HIPREC_REQUIRE(a && out_a && (a->n_slots == 0 || (a->val && a->eid)), "bad sliced graph");
   HIPREC_REQUIRE(b->n_slots == 0 || (b->val && b->eid && out_b), "bad second sliced graph");
   HIPREC_REQUIRE(draw || keep, "keep bytes needed");
-  const int64_t n_in = in.x != nullptr ? in.n_rows * in.dim : 0;
+  HIPREC_REQUIRE(in.x == nullptr || (in.W > 0 && in.dim % in.W == 0 && in.n_rows < 65536), "bad sliced input");
+  const int64_t n_in = in.x != nullptr ? in.n_rows * (in.dim / in.W) : 0;
   if (a->n_slots + b->n_slots + n_in == 0) return 0;
   HIPREC_REQUIRE(a->n_slots % 16 == 0 && b->n_slots % 16 == 0, "n_slots is not a multiple of 16");
   step_values_kernel<<<grid_for_threads((a->n_slots + b->n_slots) / 8 + n_in), kBlock, 0, st>>>(
