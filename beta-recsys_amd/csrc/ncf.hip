@@ -595,169 +595,103 @@ static bool fusable_narrow(const hiprec_ncf_plan* p) {
   return true;
 }
 
-// (W is nn.Linear.weight, [N][K] row-major; K is a multiple of kFK).  Waves beyond N idle in the MFMAs
-// but still help staging.  Software pipeline, measured per chunk of 32 k with in-kernel timestamps:
-// staged naively (16 scalar loads issued, then 16 LDS stores, then the 16 dependent MFMAs) a chunk
-// took 2760 cycles of which the MFMAs are 1150 -- with one wave per SIMD nothing else fills the
-// matrix pipe while that wave issues memory instructions.  Hence: 16-byte weight loads (4 per chunk
-// instead of 16), a double-buffered LDS tile written one chunk ahead, two register stages, and the
-// memory instructions spread between the MFMAs with sched_group_barrier so they issue in the shadow
-// of the 64-cycle dependent MFMA chain.
-constexpr int kFW4 = kFMaxN * kFK / 4 / kFThreads;  // float4 weight loads per thread and chunk (2)
+// The tile GEMMs of the fused kernels: out[16][N] (N <= 128: one 16 x 16 tile per wave) = in[16][K] (LDS) x a weight
+// matrix that comes STRAIGHT FROM L2 INTO REGISTERS.  A sum over k does not care about the order of its terms, so the
+// k index a lane feeds to MFMA j of a 32-k chunk is permuted: lane group kq = lane >> 4 takes the 8 CONSECUTIVE
+// k = k0 + 8 kq + j (the 16x16x4 instruction only asks that A and B agree on it).  For nn.Linear's [N][K] weight the
+// B operand of a chunk is then two 16-byte loads of this lane's own row -- no transposing LDS tile, no barrier inside a
+// layer (rounds 1-2 staged every 32-k chunk through a double-buffered LDS tile: 8 scalar LDS stores per thread and a
+// workgroup barrier per chunk, 1 375 cycles per chunk for 512 cycles of MFMA, r02 experiments 29).  Three chunks of B
+// are in flight ahead of the MFMAs; begin() issues the first ones and depends on nothing the block computes, so the
+// caller places it before whatever produces `in` (the gather, the previous layer's epilogue).
+struct FusedGemm {  // forward: W = nn.Linear.weight [N][K] row-major, out = in W^T
+  const float* row;  // this lane's weight row, at its lane group's first k
+  bool ok;
+  int n_chunks;
+  float4 w[3][2];
 
-// begin(): staging coordinates and the loads of the first two weight chunks -- they depend on nothing the block
-// computes, so the caller issues them BEFORE whatever produces `in` (layer 0: before the embedding gather; layer
-// l + 1: before layer l's epilogue) and their latency is off the block's serial chain.  run(): the rest.
-// (All of a layer's weights requested up front into registers -- 16 float4 per thread for 256 x 128 -- instead of
-// this two-to-three-chunks-ahead stream: no faster, 85.5 against 84 us per step.)
-struct FusedGemm {
-  int s_n[kFW4], s_k4[kFW4];
-  const float4* s_src[kFW4];
-  bool s_ok[kFW4];
-  float4 w0[kFW4], w1[kFW4];
-  int K, N;
-
-  __device__ __forceinline__ void fetch(float4 (&w)[kFW4], int k0) {
-#pragma unroll
-    for (int i = 0; i < kFW4; ++i) w[i] = s_src[i][k0 >> 2];
+  __device__ __forceinline__ void fetch(float4 (&d)[2], int t) {
+    const float4* src = reinterpret_cast<const float4*>(row + t * kFK);
+    d[0] = ok ? src[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+    d[1] = ok ? src[1] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  __device__ __forceinline__ void stage(const float4 (&w)[kFW4], float* tile) {
-#pragma unroll
-    for (int i = 0; i < kFW4; ++i) {
-      float* d = tile + s_k4[i] * kFLdN + s_n[i];
-      const float4 v = s_ok[i] ? w[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-      d[0] = v.x;
-      d[kFLdN] = v.y;
-      d[2 * kFLdN] = v.z;
-      d[3 * kFLdN] = v.w;
-    }
+  __device__ __forceinline__ void begin(const float* __restrict__ W, int K, int N) {
+    const int lane = threadIdx.x & 63, n = (threadIdx.x >> 6) * 16 + (lane & 15);
+    ok = n < N;
+    row = W + static_cast<int64_t>(ok ? n : 0) * K + 8 * (lane >> 4);
+    n_chunks = K / kFK;
+    fetch(w[0], 0);
+    if (n_chunks > 1) fetch(w[1], 1);
+    if (n_chunks > 2) fetch(w[2], 2);
   }
-  __device__ __forceinline__ void begin(const float* __restrict__ W, int K_, int N_) {
-    K = K_;
-    N = N_;
-    const int tid = threadIdx.x;
-    // staging coordinates of this thread inside a [kFK x 128] tile (fixed across chunks): float4 q
-    // covers W[n][k4 .. k4+3]
-#pragma unroll
-    for (int i = 0; i < kFW4; ++i) {
-      const int q = tid + i * kFThreads;
-      s_n[i] = q / (kFK / 4);
-      s_k4[i] = (q % (kFK / 4)) * 4;
-      s_ok[i] = s_n[i] < N;
-      s_src[i] = reinterpret_cast<const float4*>(W + static_cast<int64_t>(s_ok[i] ? s_n[i] : 0) * K + s_k4[i]);
-    }
-    fetch(w0, 0);
-    if (K > kFK) fetch(w1, kFK);
-  }
-  __device__ __forceinline__ void run(f32x4& acc, const float* in, int ld_in, float* bs) {
-    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
-    const bool active = wn * 16 < N;
+  __device__ __forceinline__ void run(f32x4& acc, const float* in, int ld_in, float*) {
+    const int lane = threadIdx.x & 63;
+    const float* a_row = in + (lane & 15) * ld_in + 8 * (lane >> 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = 0.f;
-    const int n_chunks = K / kFK;
-    float* tile[2] = {bs, bs + kFK * kFLdN};
-    stage(w0, tile[0]);
-    if (n_chunks > 2) fetch(w0, 2 * kFK);
-    lds_barrier();
-    auto chunk = [&](float4 (&w_next)[kFW4], int t) {
-      // chunk t+1 goes to the other tile, chunk t+3 into the registers it frees, chunk t is multiplied
-      if (t + 1 < n_chunks) stage(w_next, tile[(t + 1) & 1]);
-      if (t + 3 < n_chunks) fetch(w_next, (t + 3) * kFK);
-      if (active) {
-        // 16x16x4 fp32 MFMA: lane l feeds A[row l & 15][k + (l >> 4)] and B[k + (l >> 4)][col l & 15].  All
-        // operands of the chunk are requested first, then the MFMA chain runs back to back (left alone the
-        // compiler sinks each pair of reads next to its MFMAs: four LDS round trips per chunk)
-        const float* cur = tile[t & 1];
-        const int i = lane & 15, kq = lane >> 4;
-        const int k0 = t * kFK;
-        float a[kFK / 4], b[kFK / 4];
+    if (!ok) return;  // wave-uniform (N is a multiple of 16): a wave beyond the pass's columns has nothing to do
+    auto chunk = [&](float4 (&b4)[2], int t) {
+      float a[8];
 #pragma unroll
-        for (int j = 0; j < kFK / 4; ++j) {
-          a[j] = in[i * ld_in + k0 + 4 * j + kq];
-          b[j] = cur[(4 * j + kq) * kFLdN + wn * 16 + i];
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < 8; ++j) a[j] = a_row[t * kFK + j];
+      const float b[8] = {b4[0].x, b4[0].y, b4[0].z, b4[0].w, b4[1].x, b4[1].y, b4[1].z, b4[1].w};
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < kFK / 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
-      }
-      lds_barrier();
+      for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+      if (t + 3 < n_chunks) fetch(b4, t + 3);
     };
-    for (int t = 0; t < n_chunks; t += 2) {
-      chunk(w1, t);
-      if (t + 1 < n_chunks) chunk(w0, t + 1);
+    for (int t = 0; t < n_chunks; t += 3) {
+      chunk(w[0], t);
+      if (t + 1 < n_chunks) chunk(w[1], t + 1);
+      if (t + 2 < n_chunks) chunk(w[2], t + 2);
     }
   }
 };
 
-// (weight tile rows of kFLdB = 136 floats: 16-byte aligned, two-way bank conflicts on the B reads)
+// (the head's per-wave partial sums of d affine_output.weight still meet in this LDS region)
 constexpr size_t kFusedBwdLdsBytes = sizeof(float) * (kFR * kFLdIn + kFR * kFLdN + 2 * kFK * kFLdB);
 
-struct FusedGemmNN {
-  int s_k[kFW4], s_n4[kFW4];
-  const float* s_src[kFW4];
-  bool s_ok[kFW4];
-  float4 w0[kFW4], w1[kFW4];
-  int K, N, ldw;
+struct FusedGemmNN {  // input gradients: W [K][ldw] row-major as it lies in memory, out = in W[:, n_off : n_off + N]
+  const float* col;   // this lane's column, at its lane group's first k
+  bool ok;
+  int n_chunks, ldw;
+  float w[3][8];
 
-  __device__ __forceinline__ void fetch(float4 (&w)[kFW4], int k0) {
+  __device__ __forceinline__ void fetch(float (&d)[8], int t) {
+    const float* src = col + static_cast<int64_t>(t) * kFK * ldw;
 #pragma unroll
-    for (int i = 0; i < kFW4; ++i)
-      w[i] = s_ok[i] ? *reinterpret_cast<const float4*>(s_src[i] + static_cast<int64_t>(k0) * ldw)
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  __device__ __forceinline__ void stage(const float4 (&w)[kFW4], float* tile) {
-#pragma unroll
-    for (int i = 0; i < kFW4; ++i) *reinterpret_cast<float4*>(tile + s_k[i] * kFLdB + s_n4[i]) = w[i];
+    for (int j = 0; j < 8; ++j) d[j] = ok ? src[static_cast<int64_t>(j) * ldw] : 0.f;
   }
   // columns n_off .. n_off + N (N <= 128, a multiple of 16) of W[K][ldw]
-  __device__ __forceinline__ void begin(const float* __restrict__ W, int ldw_, int K_, int N_, int n_off) {
-    K = K_;
-    N = N_;
+  __device__ __forceinline__ void begin(const float* __restrict__ W, int ldw_, int K, int N, int n_off) {
+    const int lane = threadIdx.x & 63, n = (threadIdx.x >> 6) * 16 + (lane & 15);
+    ok = n < N;
     ldw = ldw_;
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < kFW4; ++i) {
-      const int q = tid + i * kFThreads;  // float4 q of a [kFK x 128] tile
-      s_k[i] = q / (kFMaxN / 4);
-      s_n4[i] = (q % (kFMaxN / 4)) * 4;
-      s_ok[i] = s_n4[i] < N;
-      s_src[i] = W + static_cast<int64_t>(s_k[i]) * ldw + n_off + (s_ok[i] ? s_n4[i] : 0);
-    }
-    fetch(w0, 0);
-    if (K > kFK) fetch(w1, kFK);
+    col = W + static_cast<int64_t>(8 * (lane >> 4)) * ldw + n_off + (ok ? n : 0);
+    n_chunks = K / kFK;
+    fetch(w[0], 0);
+    if (n_chunks > 1) fetch(w[1], 1);
+    if (n_chunks > 2) fetch(w[2], 2);
   }
-  __device__ __forceinline__ void run(f32x4& acc, const float* in, int ld_in, float* bs) {
-    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
-    const bool active = wn * 16 < N;
+  __device__ __forceinline__ void run(f32x4& acc, const float* in, int ld_in, float*) {
+    const int lane = threadIdx.x & 63;
+    const float* a_row = in + (lane & 15) * ld_in + 8 * (lane >> 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = 0.f;
-    const int n_chunks = K / kFK;
-    float* tile[2] = {bs, bs + kFK * kFLdB};
-    stage(w0, tile[0]);
-    if (n_chunks > 2) fetch(w0, 2 * kFK);
-    lds_barrier();
-    auto chunk = [&](float4 (&w_next)[kFW4], int t) {
-      if (t + 1 < n_chunks) stage(w_next, tile[(t + 1) & 1]);
-      if (t + 3 < n_chunks) fetch(w_next, (t + 3) * kFK);
-      if (active) {
-        const float* cur = tile[t & 1];
-        const int i = lane & 15, kq = lane >> 4;
-        const int k0 = t * kFK;
-        float a[kFK / 4], b[kFK / 4];
+    if (!ok) return;
+    auto chunk = [&](float (&b)[8], int t) {
+      float a[8];
 #pragma unroll
-        for (int j = 0; j < kFK / 4; ++j) {
-          a[j] = in[i * ld_in + k0 + 4 * j + kq];
-          b[j] = cur[(4 * j + kq) * kFLdB + wn * 16 + i];
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < 8; ++j) a[j] = a_row[t * kFK + j];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < kFK / 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
-      }
-      lds_barrier();
+      for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+      if (t + 3 < n_chunks) fetch(b, t + 3);
     };
-    for (int t = 0; t < n_chunks; t += 2) {
-      chunk(w1, t);
-      if (t + 1 < n_chunks) chunk(w0, t + 1);
+    for (int t = 0; t < n_chunks; t += 3) {
+      chunk(w[0], t);
+      if (t + 1 < n_chunks) chunk(w[1], t + 1);
+      if (t + 2 < n_chunks) chunk(w[2], t + 2);
     }
   }
 };
