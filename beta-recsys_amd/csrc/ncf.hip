@@ -605,20 +605,27 @@ static bool fusable_narrow(const hiprec_ncf_plan* p) {
 // are in flight ahead of the MFMAs; begin() issues the first ones and depends on nothing the block computes, so the
 // caller places it before whatever produces `in` (the gather, the previous layer's epilogue).
 struct FusedGemm {  // forward: W = nn.Linear.weight [N][K] row-major, out = in W^T
-  const float* row;  // this lane's weight row, at its lane group's first k
+  // addresses = a wave-uniform pointer (scalar arithmetic) + ONE 32-bit lane offset: per-lane 64-bit pointer
+  // arithmetic for every load was a third of a layer's instructions
+  const float* base;  // W (uniform)
+  uint32_t lane_off;  // this lane's weight row, at its lane group's first k (BYTES: uniform base + 32-bit offset is
+                      // the global_load saddr form)
   bool ok;
   int n_chunks;
   float4 w[3][2];
 
   __device__ __forceinline__ void fetch(float4 (&d)[2], int t) {
-    const float4* src = reinterpret_cast<const float4*>(row + t * kFK);
-    d[0] = ok ? src[0] : make_float4(0.f, 0.f, 0.f, 0.f);
-    d[1] = ok ? src[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* src = base + t * kFK;  // uniform
+    if (!ok) return;  // a scalar branch (ok is wave-uniform): a per-lane select would cost the loads their saddr form
+    const char* at = reinterpret_cast<const char*>(src) + lane_off;
+    d[0] = *reinterpret_cast<const float4*>(at);
+    d[1] = *reinterpret_cast<const float4*>(at + 16);
   }
   __device__ __forceinline__ void begin(const float* __restrict__ W, int K, int N) {
-    const int lane = threadIdx.x & 63, n = (threadIdx.x >> 6) * 16 + (lane & 15);
-    ok = n < N;
-    row = W + static_cast<int64_t>(ok ? n : 0) * K + 8 * (lane >> 4);
+    const int lane = threadIdx.x & 63, wn = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    ok = wn * 16 < N;  // N is a multiple of 16: the wave's 16 columns exist or they do not
+    base = W;
+    lane_off = static_cast<uint32_t>((ok ? wn * 16 + (lane & 15) : 0) * K + 8 * (lane >> 4)) * 4u;
     n_chunks = K / kFK;
     fetch(w[0], 0);
     if (n_chunks > 1) fetch(w[1], 1);
@@ -652,22 +659,32 @@ struct FusedGemm {  // forward: W = nn.Linear.weight [N][K] row-major, out = in 
 constexpr size_t kFusedBwdLdsBytes = sizeof(float) * (kFR * kFLdIn + kFR * kFLdN + 2 * kFK * kFLdB);
 
 struct FusedGemmNN {  // input gradients: W [K][ldw] row-major as it lies in memory, out = in W[:, n_off : n_off + N]
-  const float* col;   // this lane's column, at its lane group's first k
+  // B operand k = a row of W: 8 single-dword loads per chunk, each lane group its own 8 rows.  As BUFFER loads: the
+  // resource (W + n_off) and the row's byte offset are scalars, the lane's offset one VGPR for the whole layer -- as
+  // global loads the compiler kept a 64-bit per-lane pointer per row (~6 VALU instructions per load, a third of the
+  // chain's instructions).
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t lane_off;  // this lane's column, at its lane group's first k (bytes)
   bool ok;
-  int n_chunks, ldw;
+  int n_chunks, ldw4;  // row pitch in bytes
+
   float w[3][8];
 
   __device__ __forceinline__ void fetch(float (&d)[8], int t) {
-    const float* src = col + static_cast<int64_t>(t) * kFK * ldw;
+    if (!ok) return;  // scalar branch
 #pragma unroll
-    for (int j = 0; j < 8; ++j) d[j] = ok ? src[static_cast<int64_t>(j) * ldw] : 0.f;
+    for (int j = 0; j < 8; ++j)
+      d[j] = __builtin_bit_cast(float, static_cast<uint32_t>(__builtin_amdgcn_raw_buffer_load_b32(
+                                           rsrc, static_cast<int>(lane_off), (t * kFK + j) * ldw4, 0)));
   }
   // columns n_off .. n_off + N (N <= 128, a multiple of 16) of W[K][ldw]
   __device__ __forceinline__ void begin(const float* __restrict__ W, int ldw_, int K, int N, int n_off) {
-    const int lane = threadIdx.x & 63, n = (threadIdx.x >> 6) * 16 + (lane & 15);
-    ok = n < N;
-    ldw = ldw_;
-    col = W + static_cast<int64_t>(8 * (lane >> 4)) * ldw + n_off + (ok ? n : 0);
+    const int lane = threadIdx.x & 63, wn = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    ok = wn * 16 < N;
+    ldw4 = ldw_ * 4;
+    // raw buffer over the rest of the address space from W + n_off (offsets stay below K * ldw * 4 < 2^31)
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + n_off), 0, 0x7FFFFFFF, 0x00027000);
+    lane_off = static_cast<uint32_t>(8 * (lane >> 4) * ldw_ + (ok ? wn * 16 + (lane & 15) : 0)) * 4u;
     n_chunks = K / kFK;
     fetch(w[0], 0);
     if (n_chunks > 1) fetch(w[1], 1);
@@ -696,6 +713,19 @@ struct FusedGemmNN {  // input gradients: W [K][ldw] row-major as it lies in mem
   }
 };
 
+// In-kernel timestamps of the fused launch (builds with -DHIPREC_NCF_DEBUG only, tools/build_debug_lib.sh): thread 0 of
+// two blocks notes the cycle counter at the phase boundaries; hiprec_debug_ncf_stamps reads them back.
+#ifdef HIPREC_NCF_DEBUG
+__device__ unsigned long long g_ncf_stamps[2][24];
+#define NCF_STAMP(k)                                                                                        \
+  do {                                                                                                      \
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 131) && (k) < 24)                             \
+      g_ncf_stamps[blockIdx.x == 0 ? 0 : 1][k] = __builtin_amdgcn_s_memtime();                              \
+  } while (0)
+#else
+#define NCF_STAMP(k) do {} while (0)
+#endif
+
 // ---- forward: gather -> tower -> affine_output -> sigmoid; writes act[0..L], mf, scores -----------------
 // TRAIN: the head's backward half rides along (BCELoss term, d loss / d logit, dZ_L, dMF, d w_out,
 // the loss / d b_out partials) -- everything it needs is already in LDS, and a separate head launch
@@ -723,6 +753,7 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
   float* tiles = lds_raw + (act_floats + (BWD ? 2 * kFR * ld_c : 0) + 3) / 4 * 4;
   float* s_mf = tiles + 2 * kFK * kFLdB;
 
+  NCF_STAMP(0);
   // Loads that depend on nothing the block computes go first, off its serial chain: layer 0's first weight chunks,
   // this lane's bias element of the first pass, the head's weights and targets.
   FusedGemm gemm;
@@ -768,6 +799,7 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
     s_i[tid] = it;
   }
   lds_barrier();
+  NCF_STAMP(1);
   constexpr int kPerE = kFR * kFMaxE / kFThreads;  // GMF elements per thread (2)
   float gmf_um[kPerE], gmf_im[kPerE];              // BWD: the two factors, for the GMF rows' gradients
   const int ld0 = K0 + 1;
@@ -827,6 +859,7 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
     }
   }
   lds_barrier();
+  NCF_STAMP(2);
 
   int in_off = 0, ld_in = ld0;  // act_l: lds_raw + in_off, [kFR][ld_in]
   for (int l = 0; l < n_layers; ++l) {
@@ -862,6 +895,7 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
       lds_barrier();
       bias_now = bias_next;
     }
+    NCF_STAMP(3 + l);
     in_off = out_off;
     ld_in = ld_out;
   }
@@ -923,6 +957,7 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
       }
     }
   }
+  NCF_STAMP(8);
   if (!TRAIN) return;
   if (stepper) step_store_advanced(stats, step_state);
   // d affine_output.weight: the waves' sums meet in LDS (the weight tile is free by now), one atomic
@@ -941,10 +976,12 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
     for (int w = 0; w < kFWaves; ++w) t += s_gw[w * (3 * kWave) + c];
     if (t != 0.f) atomic_add_f32(p.g_out_w + c, t);
   }
+  NCF_STAMP(9);
   if constexpr (BWD) {
     // ---- the input-gradient chain on the same 16 samples (ncf_fused_dgrad_kernel, with everything it loads from
     // HBM already here: ids, activations for the ReLU masks, dZ_L, the GMF factors) ----
     lds_barrier();  // s_gw lived in the weight tiles
+    NCF_STAMP(17);
     float* cin = chain_a;
     float* cout = chain_a + kFR * ld_c;
     int h_off = in_off;  // act_{l+1}; act_l sits right before it
@@ -968,10 +1005,12 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
         }
         f32x4 acc;
         gnn.run(acc, cin, ld_c, tiles);
+        if (l == n_layers - 1) NCF_STAMP(18);
         if (n_off + kFMaxN < nin)
           gnn.begin(p.fc_w[l], nin, nout, min(kFMaxN, nin - n_off - kFMaxN), n_off + kFMaxN);
         else if (l > 0)
           gnn.begin(p.fc_w[l - 1], p.layer_in[l - 1], p.layer_out[l - 1], min(p.layer_in[l - 1], kFMaxN), 0);
+        if (l == n_layers - 1) NCF_STAMP(19);
         if (live_col) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -988,11 +1027,13 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
             }
           }
         }
+        if (l == n_layers - 1) NCF_STAMP(20);
         lds_barrier();
       }
       float* t = cin;
       cin = cout;
       cout = t;
+      NCF_STAMP(10 + (n_layers - 1 - l));
     }
     // GMF rows: d user_mf = dmf * item_mf and the other way round (dmf sits where the product was)
     if ((tid & 63) < E) {
@@ -1007,6 +1048,7 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
         }
       }
     }
+    NCF_STAMP(16);
   }
 }
 
@@ -1434,3 +1476,11 @@ extern "C" int hiprec_ncf_step(const hiprec_ncf_plan* plan, const int64_t* users
                                v_flat ? v_flat + done : nullptr, n_flat - done, lr, beta1, beta2, eps, stats, scratch,
                                scalar_index >= 0 ? scalar_index - done : -1, stream);
 }
+
+#ifdef HIPREC_NCF_DEBUG
+extern "C" int hiprec_debug_ncf_stamps(unsigned long long* out48) {
+  HIPREC_TRY(hipDeviceSynchronize());
+  HIPREC_TRY(hipMemcpyFromSymbol(out48, HIP_SYMBOL(hiprec::g_ncf_stamps), sizeof(unsigned long long) * 48));
+  return 0;
+}
+#endif
