@@ -250,7 +250,7 @@ static size_t hop_bwd_lds_floats(int di, int dout) {
 
 template <bool ACCUMULATE>
 __global__ __launch_bounds__(kHopThreads) void ngcf_hop_backward_kernel(
-    const float* __restrict__ d_all, const float* __restrict__ all, int ld_all, int off, const float* __restrict__ nrm,
+    float* __restrict__ d_all, const float* __restrict__ all, int ld_all, int off, const float* __restrict__ nrm,
     const float* __restrict__ d_next, const uint8_t* __restrict__ keep, float scale,
     const float* __restrict__ sum_pre, const float* __restrict__ bi_pre, const float* __restrict__ gc_w,
     const float* __restrict__ bi_w, const float* __restrict__ side, const float* __restrict__ ego_in, int di, int dout,
@@ -297,6 +297,9 @@ __global__ __launch_bounds__(kHopThreads) void ngcf_hop_backward_kernel(
       const bool live = lane < dout;
       const float dy = live ? d_all[row * ld_all + off + lane] : 0.f;
       const float y = live ? all[row * ld_all + off + lane] : 0.f;
+      // d_all is read exactly once per step (each hop its own columns): whoever reads it leaves it zero for the
+      // next step's loss scatter -- the step had a 10 MB fill for this (5.4 us)
+      if (live) d_all[row * ld_all + off + lane] = 0.f;
       const float proj = wave_sum(y * dy);
       const float n = nrm[row];
       const bool big = n >= kNormEps;  // clamp_min passes the norm's gradient only where norm >= eps
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void ngcf_loss_kernel(const float* __restri
 // One wave per node row: backward of normalize, (+ the gradient arriving from the next hop), dropout and
 // the two leaky-ReLUs:  d_sum = d_x * keep * scale * lrelu'(sum_pre), d_bi likewise with bi_pre.
 __global__ __launch_bounds__(kBlock) void ngcf_act_bwd_kernel(
-    const float* __restrict__ d_all, const float* __restrict__ all, int ld_all, int off,
+    float* __restrict__ d_all, const float* __restrict__ all, int ld_all, int off,
     const float* __restrict__ nrm, const float* __restrict__ d_next, const uint8_t* __restrict__ keep,
     float scale, const float* __restrict__ sum_pre, const float* __restrict__ bi_pre,
     float* __restrict__ d_sum, float* __restrict__ d_bi, int64_t n_rows, int d) {
@@ -442,6 +445,7 @@ __global__ __launch_bounds__(kBlock) void ngcf_act_bwd_kernel(
       const int c = lane + kWave * k;
       dy[k] = c < d ? d_all[r * ld_all + off + c] : 0.f;
       y[k] = c < d ? all[r * ld_all + off + c] : 0.f;
+      if (c < d) d_all[r * ld_all + off + c] = 0.f;  // read once per step: left zero for the next step's scatter
       proj += y[k] * dy[k];
     }
     proj = wave_sum(proj);
@@ -584,8 +588,9 @@ inline int ngcf_forward(const hiprec_ngcf_plan* p, bool train, hipStream_t st) {
   const int dt = total_width(p);
   const bool sliced = ngcf_sliced(p);
   const bool zeroed = p->zero_ws != nullptr;  // ONE fill for every SpMM output (+ d_all) of the step
-  if (zeroed && sliced) HIPREC_TRY(hipMemsetAsync(p->d_all, 0, sizeof(float) * N * dt, st));  // (only the loss scatters)
-  else if (zeroed) HIPREC_TRY(hipMemsetAsync(p->zero_ws, 0, sizeof(float) * p->zero_ws_floats, st));
+  // sliced SpMMs write their outputs whole: nothing to clear (d_all, which only the loss scatters into, is zero on
+  // entry -- the caller allocates the workspace zeroed -- and the backward's readers leave it zero again)
+  if (zeroed && !sliced) HIPREC_TRY(hipMemsetAsync(p->zero_ws, 0, sizeof(float) * p->zero_ws_floats, st));
   const float* ego = p->e0;
   int off = p->dim[0];
   if (sliced) {

@@ -967,7 +967,9 @@ typedef struct hiprec_ngcf_plan {
    * hiprec_sliced_width(N, dim[l]) == slice_w): the two graphs stored for the column-sliced SpMM and one buffer of
    * N * max(dim[l]) floats for its sliced source.  The SpMMs of a step then run on hiprec_spmm_sliced's kernel: the
    * source is written in the sliced layout by the kernel that produces it, the result goes straight to side[l] /
-   * d_ego; spmm_tmp is unused and only d_all is cleared. */
+   * d_ego; spmm_tmp is unused and NOTHING is cleared per step: d_all (which only the loss scatters into) must be zero
+   * when the first step starts -- allocate the workspace zeroed -- and every backward leaves it zero again (its readers
+   * clear what they read). */
   hiprec_sliced_csr sa, sat;
   int32_t slice_w, _pad2;
   float* sliced_src;
