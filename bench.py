@@ -413,7 +413,7 @@ def bench_mf_c4shard(args, device, full=False):
     bpt = algorithmic_bytes_per_triple(Dc)
     if owned:
         kname, k_s = "mf_bpr_owned_kernel<2> (gather + score + BPR grad + in-place SGD rows, 1 launch/step)", alone_s
-        traffic, traffic_src = (None, None) if full else traffic_from_profiles("hiprec::mf_bpr_owned_kernel<2, false>", "mf-c4shard")
+        traffic, traffic_src = (None, None) if full else traffic_from_profiles("hiprec::mf_bpr_owned_kernel<2, false, false>", "mf-c4shard")
     else:
         # dominant kernel alone, back to back
         lib = eng._setup()

@@ -1,4 +1,4 @@
-"""column-sliced SpMM against the L2 row-gather SpMM on the BASELINE configs[4] graph (forward and transposed)"""
+"""column-sliced SpMM against the L2 row-gather SpMM on the BASELINE configs[4] graph (bench.c5_graph: nnz 1.99 M)"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp, torch
@@ -7,14 +7,11 @@ from beta_recsys_amd.lightgcn import (_csr_from_coo, _slice_rows, sliced_graph_d
                                       spread_bank_conflicts)
 from oracle import lightgcn_numpy as olg
 
-U, I, D = 6040, 3706, 64
-rng = np.random.default_rng(0)
-n_edges = 1_000_000
-p = 1.0 / np.arange(1, I + 1) ** 0.9
-eu = rng.integers(0, U, n_edges)
-ei = rng.permutation(I)[rng.choice(I, n_edges, p=p / p.sum())]
-N = U + I
-adj = olg.build_norm_adj(U, I, eu, ei).tocoo()
+import bench
+
+D = 64
+adj = bench.c5_graph()  # 988 k unique edges, nnz 1 985 746
+N = adj.shape[0]
 lib = _lib.load()
 dev = torch.device("cuda:0")
 st = _lib.stream_ptr(dev)

@@ -5,31 +5,8 @@ TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-# one line per BASELINE config WITH its cpu_baseline (VERDICT r2 #3): configs[1] adam / adam_20, configs[2] ncf,
-# configs[3] mf-c4shard (one rank's share) + mf-c4 (whole, one GPU) + mf-c4_sharded_w1, configs[4] lightgcn
-python bench.py --steps 20 --warmup 5 > $OUT/bench_adam_20.json 2> $OUT/bench_adam_20.err
-timeout 200 python bench.py > $OUT/bench_adam.json 2> $OUT/bench_adam.err
-for o in sgd rmsprop; do
-  timeout 200 python bench.py --optimizer $o --no-cpu-baseline > $OUT/bench_$o.json 2> $OUT/bench_$o.err
-done
-timeout 300 python bench.py --workload ncf > $OUT/bench_ncf.json 2> $OUT/bench_ncf.err
-timeout 300 python bench.py --workload ncf --emb-dim 64 --no-cpu-baseline > $OUT/bench_ncf64.json 2> $OUT/bench_ncf64.err
-timeout 300 python bench.py --workload lightgcn > $OUT/bench_lightgcn.json 2> $OUT/bench_lightgcn.err
-timeout 400 python bench.py --workload mf-c4shard > $OUT/bench_mf-c4shard.json 2> $OUT/bench_mf-c4shard.err
-for w in mf-c4 pgmf t2v ngcf; do
-  timeout 300 python bench.py --workload $w --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err
-done
-timeout 300 python bench.py --workload mf-c4shard --sgd-mode rows --no-cpu-baseline > $OUT/bench_mf-c4shard_rows.json 2> /dev/null
-HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --no-cpu-baseline --steps 200 2> /dev/null | grep metric > $OUT/bench_replicated_w1.json
-HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --no-cpu-baseline --steps 20 --warmup 5 2> /dev/null | grep metric > $OUT/bench_replicated_w1_20.json
-HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --no-cpu-baseline --steps 200 --dp-collective torch 2> /dev/null | grep metric > $OUT/bench_replicated_w1_torch.json
-HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload mf-c4 --no-cpu-baseline --steps 50 2> /dev/null | grep metric > $OUT/bench_mf-c4_sharded_w1.json
-HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload mf-c4 --no-cpu-baseline --steps 20 --warmup 5 2> /dev/null | grep metric > $OUT/bench_mf-c4_sharded_w1_20.json
-HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload mf-c4 --no-cpu-baseline --steps 50 --step-driver torch 2> /dev/null | grep metric > $OUT/bench_mf-c4_sharded_w1_torch.json
-HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload lightgcn --no-cpu-baseline --steps 100 --warmup 10 2> /dev/null | grep metric > $OUT/bench_lightgcn_dp_w1.json
-HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload ncf --no-cpu-baseline --steps 100 --warmup 10 2> /dev/null | grep metric > $OUT/bench_ncf_dp_w1.json
-CASES=sgd:c,sgd:torch,adam:c timeout 300 python tools/exp_planned.py 2>&1 | grep "\]" > $OUT/exp_planned.txt
-SIZE=full CASES=sgd:c,sgd:torch timeout 300 python tools/exp_planned.py 2>&1 | grep "\]" >> $OUT/exp_planned.txt
+# counters and kernel statistics FIRST: the bench lines below read roofline.traffic from profiles/<tag>_pmc_*.json,
+# which tools/collect_profiles.py makes from these passes (run here on the box, and again at home)
 cd /tmp && export TMPDIR=/tmp
 prof() {  # name, bench args...
   local name=$1; shift
@@ -57,6 +34,33 @@ pmc mf-c4shard --workload mf-c4shard --steps 50 --warmup 5
 pmc lightgcn --workload lightgcn --steps 50 --warmup 5
 pmc ncf --workload ncf --steps 50 --warmup 5
 pmc ncf64 --workload ncf --emb-dim 64 --steps 50 --warmup 5
+cd $GRAFT_REPO_ROOT && python tools/collect_profiles.py $TAG > /dev/null
+# one line per BASELINE config WITH its cpu_baseline (VERDICT r2 #3): configs[1] adam / adam_20, configs[2] ncf,
+# configs[3] mf-c4shard (one rank's share) + mf-c4 (whole, one GPU) + mf-c4_sharded_w1, configs[4] lightgcn
+python bench.py --steps 20 --warmup 5 > $OUT/bench_adam_20.json 2> $OUT/bench_adam_20.err
+timeout 200 python bench.py > $OUT/bench_adam.json 2> $OUT/bench_adam.err
+for o in sgd rmsprop; do
+  timeout 200 python bench.py --optimizer $o --no-cpu-baseline > $OUT/bench_$o.json 2> $OUT/bench_$o.err
+done
+timeout 300 python bench.py --workload ncf > $OUT/bench_ncf.json 2> $OUT/bench_ncf.err
+timeout 300 python bench.py --workload ncf --emb-dim 64 --no-cpu-baseline > $OUT/bench_ncf64.json 2> $OUT/bench_ncf64.err
+timeout 300 python bench.py --workload lightgcn > $OUT/bench_lightgcn.json 2> $OUT/bench_lightgcn.err
+timeout 400 python bench.py --workload mf-c4shard > $OUT/bench_mf-c4shard.json 2> $OUT/bench_mf-c4shard.err
+for w in mf-c4 pgmf t2v ngcf; do
+  timeout 300 python bench.py --workload $w --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err
+done
+timeout 300 python bench.py --workload mf-c4shard --sgd-mode rows --no-cpu-baseline > $OUT/bench_mf-c4shard_rows.json 2> /dev/null
+HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --no-cpu-baseline --steps 200 2> /dev/null | grep metric > $OUT/bench_replicated_w1.json
+HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --no-cpu-baseline --steps 20 --warmup 5 2> /dev/null | grep metric > $OUT/bench_replicated_w1_20.json
+HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --no-cpu-baseline --steps 200 --dp-collective torch 2> /dev/null | grep metric > $OUT/bench_replicated_w1_torch.json
+HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload mf-c4 --no-cpu-baseline --steps 50 2> /dev/null | grep metric > $OUT/bench_mf-c4_sharded_w1.json
+HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload mf-c4 --no-cpu-baseline --steps 20 --warmup 5 2> /dev/null | grep metric > $OUT/bench_mf-c4_sharded_w1_20.json
+HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload mf-c4 --no-cpu-baseline --steps 50 --step-driver torch 2> /dev/null | grep metric > $OUT/bench_mf-c4_sharded_w1_torch.json
+HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload lightgcn --no-cpu-baseline --steps 100 --warmup 10 2> /dev/null | grep metric > $OUT/bench_lightgcn_dp_w1.json
+HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload ncf --no-cpu-baseline --steps 100 --warmup 10 2> /dev/null | grep metric > $OUT/bench_ncf_dp_w1.json
+CASES=sgd:c,sgd:torch,adam:c timeout 300 python tools/exp_planned.py 2>&1 | grep "\]" > $OUT/exp_planned.txt
+SIZE=full CASES=sgd:c,sgd:torch timeout 300 python tools/exp_planned.py 2>&1 | grep "\]" >> $OUT/exp_planned.txt
+cd /tmp && export TMPDIR=/tmp
 # the planner and the planned sharded step (world 1)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_plan -o mf -- \
   python $GRAFT_REPO_ROOT/tools/exp_plan_cost.py > $OUT/prof_plan.log 2>&1
