@@ -456,6 +456,9 @@ int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scal
                  "bad sliced graph");
   HIPREC_REQUIRE(a->n_slots == 0 || (a->col16 && a->val && a->chunks), "sliced graph has NULL chunks / col16 / val");
   HIPREC_REQUIRE(a->n_slots % 16 == 0, "n_slots %lld is not a multiple of 16", (long long)a->n_slots);
+  HIPREC_REQUIRE(a->n_chunks % 16 == 0,
+                 "%d chunks: the descriptors must be laid out in windows of 16 with their run flags (include/hiprec.h, "
+                 "hiprec_sliced_csr; lightgcn._windowed_chunks builds them)", a->n_chunks);
   HIPREC_REQUIRE((a->row_scale == nullptr) == (a->col_scale == nullptr), "row_scale and col_scale go together");
   HIPREC_REQUIRE(W > 0 && W == sliced_width(a->n_rows, dim), "slice width %d does not fit %lld rows x dim %d", W,
                  (long long)a->n_rows, dim);
