@@ -157,10 +157,10 @@ __global__ __launch_bounds__(kBlock) void lightgcn_loss_kernel(
   const int D = p.dim;
   const int w_shift = p.slice_w == 4 ? 2 : 1;
   const int64_t n_rows = p.a.n_rows;
-  // offset of (row-major offset r = row * D, column c) in the layout of acc / da
-  auto at = [&](int64_t r, int c) -> int64_t {
-    if (!SLICED) return r + c;
-    return ((static_cast<int64_t>(c >> w_shift) * n_rows + r / D) << w_shift) + (c & ((1 << w_shift) - 1));
+  // offset of (node row, column c) in the layout of acc / da (no division: the node index comes with the call)
+  auto at = [&](int64_t row, int c) -> int64_t {
+    if (!SLICED) return row * D + c;
+    return ((static_cast<int64_t>(c >> w_shift) * n_rows + row) << w_shift) + (c & ((1 << w_shift) - 1));
   };
   const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
   const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
@@ -178,10 +178,11 @@ __global__ __launch_bounds__(kBlock) void lightgcn_loss_kernel(
                  (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
       continue;
     }
-    const int64_t ru = u * D, rp = (p.n_users + i) * D, rn = (p.n_users + j) * D;
+    const int64_t nu = u, np_ = p.n_users + i, nn_ = p.n_users + j;  // node rows
+    const int64_t ru = nu * D, rp = np_ * D, rn = nn_ * D;
     float dp = 0.f, dn = 0.f;
     for (int c = lane; c < D; c += kWave) {
-      const float ue = p.acc[at(ru, c)] * inv_l, pe = p.acc[at(rp, c)] * inv_l, ne = p.acc[at(rn, c)] * inv_l;
+      const float ue = p.acc[at(nu, c)] * inv_l, pe = p.acc[at(np_, c)] * inv_l, ne = p.acc[at(nn_, c)] * inv_l;
       dp += ue * pe;
       dn += ue * ne;
       const float u0 = p.e0[ru + c], p0 = p.e0[rp + c], n0 = p.e0[rn + c];
@@ -197,11 +198,11 @@ __global__ __launch_bounds__(kBlock) void lightgcn_loss_kernel(
     const float su = cs ? cs[u] : 1.f, sp = cs ? cs[p.n_users + i] : 1.f, sn = cs ? cs[p.n_users + j] : 1.f;
     const float cr = p.decay * inv_batch;                   // d reg / d row = decay * row / B
     for (int c = lane; c < D; c += kWave) {
-      const float ue = p.acc[at(ru, c)] * inv_l, pe = p.acc[at(rp, c)] * inv_l, ne = p.acc[at(rn, c)] * inv_l;
+      const float ue = p.acc[at(nu, c)] * inv_l, pe = p.acc[at(np_, c)] * inv_l, ne = p.acc[at(nn_, c)] * inv_l;
       const float gu = dx * (ne - pe), gp = -dx * ue, gn = dx * ue;
-      atomic_add_f32(p.da + at(ru, c), gu * su);
-      atomic_add_f32(p.da + at(rp, c), gp * sp);
-      atomic_add_f32(p.da + at(rn, c), gn * sn);
+      atomic_add_f32(p.da + at(nu, c), gu * su);
+      atomic_add_f32(p.da + at(np_, c), gp * sp);
+      atomic_add_f32(p.da + at(nn_, c), gn * sn);
       atomic_add_f32(p.g + ru + c, gu + cr * p.e0[ru + c]);
       atomic_add_f32(p.g + rp + c, gp + cr * p.e0[rp + c]);
       atomic_add_f32(p.g + rn + c, gn + cr * p.e0[rn + c]);
