@@ -103,8 +103,11 @@ __device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
 // rows this wave completed are swapped out kOwnedGroup at a time, re-read (a row still holds its pre-step value:
 // only its owner ever writes it) and written back as w - lr * g.
 // Waves never wait for each other inside the loop.
+// NPL <= 2 (dim <= 128): four waves per SIMD, i.e. <= 128 VGPRs -- left alone the local dim-128 instantiation took 131
+// and ran three (a quarter fewer rows in flight for a kernel that lives on memory-level parallelism).
 template <int NPL, bool REMOTE, bool GRAD>
-__global__ __launch_bounds__(kOwnedBlock) void mf_bpr_owned_kernel(
+__global__ __launch_bounds__(kOwnedBlock) __attribute__((amdgpu_waves_per_eu(NPL <= 2 ? 4 : 2)))
+void mf_bpr_owned_kernel(
     OwnedStep f, const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
     const int64_t* __restrict__ neg, int64_t batch, float inv_batch, float reg_coef, hiprec_stats* stats,
     Scratch* scratch) {
