@@ -413,7 +413,8 @@ def bench_mf_c4shard(args, device, full=False):
     bpt = algorithmic_bytes_per_triple(Dc)
     if owned:
         kname, k_s = "mf_bpr_owned_kernel<2> (gather + score + BPR grad + in-place SGD rows, 1 launch/step)", alone_s
-        traffic, traffic_src = (None, None) if full else traffic_from_profiles("hiprec::mf_bpr_owned_kernel<2, false, false>", "mf-c4shard")
+        traffic, traffic_src = traffic_from_profiles("hiprec::mf_bpr_owned_kernel<2, false, false>",
+                                                     "mf-c4" if full else "mf-c4shard")
     else:
         # dominant kernel alone, back to back
         lib = eng._setup()
@@ -801,6 +802,7 @@ def bench_ngcf(args, device):
                         "frac": bytes_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                         "gemm_tflops": flops / (dt / args.steps) / 1e12,
                         "note": "whole step (~35 launches); full-graph propagation per step like the reference"}}
+    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = traffic_step_from_profiles("ngcf")
     if not args.no_cpu_baseline:
         from oracle import torch_port
 

@@ -34,6 +34,8 @@ pmc mf-c4shard --workload mf-c4shard --steps 50 --warmup 5
 pmc lightgcn --workload lightgcn --steps 50 --warmup 5
 pmc ncf --workload ncf --steps 50 --warmup 5
 pmc ncf64 --workload ncf --emb-dim 64 --steps 50 --warmup 5
+pmc mf-c4 --workload mf-c4 --steps 50 --warmup 5
+pmc ngcf --workload ngcf --steps 50 --warmup 5
 cd $GRAFT_REPO_ROOT && python tools/collect_profiles.py $TAG > /dev/null
 # one line per BASELINE config WITH its cpu_baseline: configs[1] adam / adam_20, configs[2] ncf,
 # configs[3] mf-c4shard (one rank's share) + mf-c4 (whole, one GPU) + mf-c4_sharded_w1, configs[4] lightgcn
