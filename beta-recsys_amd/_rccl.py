@@ -12,7 +12,8 @@ import glob
 import os
 
 import torch
-import torch.distributed as dist
+
+from . import _dist as dist
 
 NCCL_UNIQUE_ID_BYTES = 128
 
@@ -85,7 +86,12 @@ class Communicator:
 
 def create_communicator(group, device):
     """Collective over ``group`` (every rank calls it, with its own cuda ``device`` current): a Communicator, or
-    None where it could not be made.  Use :func:`all_ranks_agree` before relying on it."""
+    None where it could not be made.  Use :func:`all_ranks_agree` before relying on it.  A group that carries its
+    own collectives (``_dist.own``: the single-GPU loopback world of the tests) makes its own communicator -- the
+    same surface, the addresses of ITS send / recv / group / all-reduce entry points."""
+    c = dist.own(group)
+    if c is not None:
+        return c.create_communicator(device)
     lib = _load()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     uid = _UniqueId()

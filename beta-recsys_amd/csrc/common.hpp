@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <initializer_list>
+
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -31,6 +34,12 @@ static_assert(sizeof(Scratch) == kScratchBytes, "scratch layout");
 
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
+
+// Kernels that want more dynamic LDS than HIP's 64 KB default: the limit is an attribute per (function, DEVICE), so
+// `done` keeps one bit per HIP device (thread-safe; ADVICE r3: a process-wide `static bool` was neither).  Checks what
+// the current device offers first: a part with less LDS gets HIPREC_E_UNSUPPORTED and a message, not a raw HIP error.
+int allow_dynamic_lds(std::initializer_list<const void*> kernels, size_t bytes, std::atomic<uint64_t>& done,
+                      const char* what);
 
 #define HIPREC_TRY(expr)                                   \
   do {                                                     \

@@ -1213,28 +1213,18 @@ static int check_plan(const hiprec_ncf_plan* p, int64_t batch, bool train) {
 }
 
 static int fused_attrs() {
-  static int rc = [] {
-    const void* fwd[] = {reinterpret_cast<const void*>(&ncf_fused_forward_kernel<false, false>),
-                         reinterpret_cast<const void*>(&ncf_fused_forward_kernel<false, true>),
-                         reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, false>),
-                         reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, true>),
-                         reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, false, true>),
-                         reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, true, true>)};
-    for (const void* k : fwd) {
-      const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               static_cast<int>(kFusedMaxLds));
-      if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-    }
-    const void* bwd[] = {reinterpret_cast<const void*>(&ncf_fused_dgrad_kernel<false>),
-                         reinterpret_cast<const void*>(&ncf_fused_dgrad_kernel<true>)};
-    for (const void* k : bwd) {
-      const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               static_cast<int>(kFusedBwdLdsBytes));
-      if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-    }
-    return 0;
-  }();
-  return rc;
+  static std::atomic<uint64_t> fwd_ok{0}, bwd_ok{0};
+  if (int rc = allow_dynamic_lds({reinterpret_cast<const void*>(&ncf_fused_forward_kernel<false, false>),
+                                  reinterpret_cast<const void*>(&ncf_fused_forward_kernel<false, true>),
+                                  reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, false>),
+                                  reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, true>),
+                                  reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, false, true>),
+                                  reinterpret_cast<const void*>(&ncf_fused_forward_kernel<true, true, true>)},
+                                 kFusedMaxLds, fwd_ok, "the fused NCF forward"))
+    return rc;
+  return allow_dynamic_lds({reinterpret_cast<const void*>(&ncf_fused_dgrad_kernel<false>),
+                            reinterpret_cast<const void*>(&ncf_fused_dgrad_kernel<true>)},
+                           kFusedBwdLdsBytes, bwd_ok, "the fused NCF input-gradient chain");
 }
 
 // Tower forward.  Returns (through *scored) whether plan->scores already holds the sigmoid outputs.

@@ -615,13 +615,10 @@ inline int ngcf_forward(const hiprec_ngcf_plan* p, bool train, hipStream_t st) {
     if (!unfused_hop && di <= kHopMaxIn && di % 4 == 0 && dout <= kHopMaxOut && dout % 16 == 0) {
       // bi = ego * side, both Linear layers, activation, dropout, norm: one launch, 16 node rows per workgroup
       const size_t lds = sizeof(float) * hop_lds_floats(di, dout);
-      static bool attr_set = false;
-      if (!attr_set) {
-        HIPREC_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ngcf_hop_forward_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(sizeof(float) * hop_lds_floats(kHopMaxIn, kHopMaxOut))));
-        attr_set = true;
-      }
+      static std::atomic<uint64_t> lds_ok{0};
+      if (int rc = allow_dynamic_lds({reinterpret_cast<const void*>(&ngcf_hop_forward_kernel)},
+                                     sizeof(float) * hop_lds_floats(kHopMaxIn, kHopMaxOut), lds_ok, "the fused NGCF hop"))
+        return rc;
       ngcf_hop_forward_kernel<<<static_cast<int>((N + kHopRows - 1) / kHopRows), kHopThreads, lds, st>>>(
           p->side[l], ego, p->gc_w[l], p->gc_b[l], p->bi_w[l], p->bi_b[l], di, dout, N, p->bi_in[l], p->sum_pre[l],
           p->bi_pre[l], keep, p->keep_scale[l], gen, p->ego[l], p->nrm[l], p->all, dt, off, next_src);
@@ -716,15 +713,12 @@ extern "C" int hiprec_ngcf_grad(const hiprec_ngcf_plan* plan, const int64_t* use
     const SlicedOut src = sliced ? ngcf_sliced_out(p, &p->sat) : SlicedOut{};
     if (hop_bwd) {
       const size_t lds = sizeof(float) * hop_bwd_lds_floats(di, dout);
-      static bool attr_set = false;
-      if (!attr_set) {
-        const int cap = static_cast<int>(sizeof(float) * hop_bwd_lds_floats(kHopBwdMax, kHopBwdMax));
-        HIPREC_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ngcf_hop_backward_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        HIPREC_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ngcf_hop_backward_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        attr_set = true;
-      }
+      static std::atomic<uint64_t> lds_ok{0};
+      if (int rc = allow_dynamic_lds({reinterpret_cast<const void*>(&ngcf_hop_backward_kernel<true>),
+                                      reinterpret_cast<const void*>(&ngcf_hop_backward_kernel<false>)},
+                                     sizeof(float) * hop_bwd_lds_floats(kHopBwdMax, kHopBwdMax), lds_ok,
+                                     "the fused NGCF hop (backward)"))
+        return rc;
       const int grid = static_cast<int>((N + kHopRows - 1) / kHopRows);
       if (l == 0)
         ngcf_hop_backward_kernel<true><<<grid, kHopThreads, lds, st>>>(

@@ -13,6 +13,8 @@
 // epoch, 1.5 ms; LDS atomics make it one pass over L2-resident keys per partition.
 #include <algorithm>
 
+#include <atomic>
+
 #include "common.hpp"
 
 namespace hiprec {
@@ -149,8 +151,12 @@ __global__ __launch_bounds__(kOwnThreads) void ownership_kernel(const int32_t* _
     }
     if (q_tail != q_head) drain(q_tail - q_head);
     __syncthreads();
-    if (phase == 0 && pos_cnt)
+    if (phase == 0 && pos_cnt) {
       for (uint32_t i = threadIdx.x; i < part_size; i += kOwnThreads) pos_cnt[tab0 + i] = s_cnt[i];
+      // the snapshot must be complete before any wave's phase 1 adds negative occurrences to s_cnt (a
+      // wave that finished its stride early raced the slower ones' reads)
+      __syncthreads();
+    }
   }
   for (uint32_t i = threadIdx.x; i < part_size; i += kOwnThreads) {
     total[tab0 + i] = s_cnt[i];
@@ -182,20 +188,10 @@ static int ownership_impl(const int64_t* users, const int64_t* pos, const int64_
   const int64_t grid = n_batches << (table_bits - part_bits);
   HIPREC_REQUIRE(grid < (1ll << 31), "too many (batch, partition) pairs");
   const size_t lds = sizeof(int32_t) * 2 * (static_cast<size_t>(1) << part_bits);
-  static bool attr_set = false;
-  if (!attr_set) {  // 128 KB of dynamic LDS (gfx950 has 160 KB per workgroup)
-    int dev = 0, lds_max = 0;
-    HIPREC_TRY(hipGetDevice(&dev));
-    HIPREC_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
-    if (static_cast<size_t>(lds_max) < (2 * sizeof(int32_t) << kOwnPartBits)) {
-      set_error("the ownership tables need %zu bytes of LDS per workgroup, this device offers %d (gfx950: 160 KB)",
-                2 * sizeof(int32_t) << kOwnPartBits, lds_max);
-      return HIPREC_E_UNSUPPORTED;
-    }
-    HIPREC_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ownership_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sizeof(int32_t) << kOwnPartBits));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ok{0};   // 128 KB of dynamic LDS (gfx950 has 160 KB per workgroup)
+  if (int rc = allow_dynamic_lds({reinterpret_cast<const void*>(ownership_kernel)}, 2 * sizeof(int32_t) << kOwnPartBits,
+                                 lds_ok, "the ownership tables"))
+    return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ownership_keys_kernel<<<grid_for_threads(n), kBlock, 0, st>>>(users, pos, neg, n, n_users, n_items, keys);
   ownership_kernel<<<static_cast<int>(grid), kOwnThreads, lds, st>>>(keys, n, batch, table_bits, total, own, tab_keys,

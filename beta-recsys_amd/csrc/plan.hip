@@ -599,12 +599,10 @@ extern "C" int hiprec_plan_place_requests(const int32_t* incoming, int64_t n_in,
     if (words > 0) {
       const int n_parts = static_cast<int>((words + kDupWords - 1) / kDupWords);
       const size_t lds = sizeof(uint32_t) * 2 * static_cast<size_t>(std::min<int64_t>(words, kDupWords));
-      static bool attr_set = false;
-      if (!attr_set) {
-        HIPREC_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan_mark_duplicates_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(uint32_t) * 2 * kDupWords));
-        attr_set = true;
-      }
+      static std::atomic<uint64_t> lds_ok{0};
+      if (int rc = allow_dynamic_lds({reinterpret_cast<const void*>(plan_mark_duplicates_kernel)},
+                                     sizeof(uint32_t) * 2 * kDupWords, lds_ok, "the planner's duplicate marks"))
+        return rc;
       plan_mark_duplicates_kernel<<<static_cast<int>(n_steps) * n_parts, kPlanThreads, lds, st>>>(in_idx, step_off, words,
                                                                                                 n_parts, dup_ws);
     }
@@ -635,6 +633,8 @@ extern "C" int hiprec_plan_item_slots(const int64_t* users, int64_t n_steps, int
   HIPREC_REQUIRE(users && own && occ && tab_keys && pos_cnt && ws && slot_of && req_cnt && req_ds && ex_req &&
                      n_slots && send_base && req_send && users_out && pos_slot && neg_slot && own_out,
                  "NULL pointer");
+  HIPREC_REQUIRE(slot_shared == nullptr || (total != nullptr && slot_stride >= 2 * cap + world),
+                 "slot_shared needs total and a stride of at least 2 * cap + world");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int part_bits = std::min<int>(table_bits, kPlanPartBits);
   const int n_parts = 1 << (table_bits - part_bits);
@@ -656,8 +656,6 @@ extern "C" int hiprec_plan_item_slots(const int64_t* users, int64_t n_steps, int
   const int grid = S * n_parts;
   plan_slot_count_kernel<<<grid, kPlanThreads, 0, st>>>(tab_keys, pos_cnt, table_bits, R,
                                                         static_cast<int32_t>(n_users_local), part_cnt);
-  HIPREC_REQUIRE(slot_shared == nullptr || (total != nullptr && slot_stride >= 2 * cap + world),
-                 "slot_shared needs total and a stride of at least 2 * cap + world");
   plan_slot_scan_kernel<<<1, kPlanThreads, 0, st>>>(part_cnt, S, n_parts, R, req_cnt, req_ds, chunk_start, ex_req,
                                                     n_slots, slot_base, pos_base, send_base, slot_shared, slot_stride);
   plan_slot_assign_kernel<<<grid, kPlanThreads, 0, st>>>(tab_keys, pos_cnt, table_bits, n_parts, R, S,

@@ -536,6 +536,23 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
   const auto recv = nccl ? reinterpret_cast<nccl_recv_fn>(nccl->recv) : nullptr;
   const auto g_start = nccl ? reinterpret_cast<nccl_group_fn>(nccl->group_start) : nullptr;
   const auto g_end = nccl ? reinterpret_cast<nccl_group_fn>(nccl->group_end) : nullptr;
+  // Every rank must post every exchange of the range: a rank that returned half-way would leave its peers waiting in
+  // theirs.  Whatever can be checked is therefore checked BEFORE the first launch.
+  for (int64_t s = step_begin; s < step_end; ++s) {
+    const int64_t* req = plan->req_cnt_host + s * R;
+    const int64_t* inc = plan->in_cnt_host + s * R;
+    int64_t in_rows = 0, req_rows = 0;
+    for (int q = 0; q < R; ++q) {
+      HIPREC_REQUIRE(req[q] >= 0 && inc[q] >= 0, "inconsistent plan: negative row count in step %lld", (long long)s);
+      in_rows += inc[q] + 1;
+      req_rows += req[q] + 1;
+    }
+    HIPREC_REQUIRE(inc[me] == req[me], "inconsistent plan: a rank asks itself for %lld rows and expects %lld",
+                   (long long)req[me], (long long)inc[me]);
+    HIPREC_REQUIRE(in_rows == plan->in_off_host[s + 1] - plan->in_off_host[s] && req_rows == plan->n_slots_host[s],
+                   "inconsistent plan: the per-peer row counts of step %lld do not add up to its block sizes",
+                   (long long)s);
+  }
   for (int64_t s = step_begin; s < step_end; ++s) {
     const int64_t* req = plan->req_cnt_host + s * R;
     const int64_t* inc = plan->in_cnt_host + s * R;
@@ -546,8 +563,6 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
       in_lo += inc[q] + 1;
       req_lo += req[q] + 1;
     }
-    HIPREC_REQUIRE(inc[me] == req[me], "inconsistent plan: a rank asks itself for %lld rows and expects %lld",
-                   (long long)req[me], (long long)inc[me]);
     const int64_t in_hi = in_lo + inc[me] + 1;
     float* self_fetched = bufs->fetched + req_lo * ld;
     float* self_g = bufs->g_send + req_lo * ld;
@@ -557,7 +572,10 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
                                            self_fetched, bufs->g_send, sl * ld, shared, stats, stream))
       return rc;
     if (R > 1) {
-      if (g_start()) return HIPREC_E_UNSUPPORTED;
+      if (g_start()) {
+        set_error("ncclGroupStart failed before the row exchange of step %lld", (long long)s);
+        return HIPREC_E_UNSUPPORTED;
+      }
       int64_t io = 0, ro = 0;
       for (int q = 0; q < R; ++q) {
         if (q != me) {
@@ -571,7 +589,10 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
         io += inc[q] + 1;
         ro += req[q] + 1;
       }
-      if (g_end()) return HIPREC_E_UNSUPPORTED;
+      if (g_end()) {
+        set_error("ncclGroupEnd failed in the row exchange of step %lld (peers disagree about its sizes?)", (long long)s);
+        return HIPREC_E_UNSUPPORTED;
+      }
     }
     const int64_t off = s * cap;
     const int64_t b_local = std::min<int64_t>(plan->local_batch, plan->n_local - s * plan->local_batch);
@@ -593,7 +614,10 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
     shard_publish_partials_kernel<<<1, kBlock, 0, st>>>(static_cast<const Scratch*>(bufs->scratch), bufs->g_send, ld,
                                                         nullptr, plan->ex_req + s * R, R);
     if (R > 1) {
-      if (g_start()) return HIPREC_E_UNSUPPORTED;
+      if (g_start()) {
+        set_error("ncclGroupStart failed before the gradient exchange of step %lld", (long long)s);
+        return HIPREC_E_UNSUPPORTED;
+      }
       int64_t io = 0, ro = 0;
       for (int q = 0; q < R; ++q) {
         if (q != me) {
@@ -607,7 +631,11 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
         io += inc[q] + 1;
         ro += req[q] + 1;
       }
-      if (g_end()) return HIPREC_E_UNSUPPORTED;
+      if (g_end()) {
+        set_error("ncclGroupEnd failed in the gradient exchange of step %lld (peers disagree about its sizes?)",
+                  (long long)s);
+        return HIPREC_E_UNSUPPORTED;
+      }
     }
     float* t_emb = dense ? g + nu * D : item_emb;
     float* t_bias = dense ? g + (nu + ni) * D + nu : item_bias;

@@ -467,15 +467,13 @@ int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scal
                  sliced_row_cap(a->n_rows, dim));
   HIPREC_REQUIRE(xs && (ys || fl.final_out) && (acc_mode == 0 || accs), "NULL sliced buffers");
   const size_t lds = static_cast<size_t>(a->n_rows + 1 + a->row_cap) * W * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    for (const void* k : {reinterpret_cast<const void*>(&spmm_sliced_kernel<4, false>),
-                          reinterpret_cast<const void*>(&spmm_sliced_kernel<2, false>),
-                          reinterpret_cast<const void*>(&spmm_sliced_kernel<4, true>),
-                          reinterpret_cast<const void*>(&spmm_sliced_kernel<2, true>)})
-      HIPREC_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSlicedLds)));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ok{0};
+  if (int rc = allow_dynamic_lds({reinterpret_cast<const void*>(&spmm_sliced_kernel<4, false>),
+                                  reinterpret_cast<const void*>(&spmm_sliced_kernel<2, false>),
+                                  reinterpret_cast<const void*>(&spmm_sliced_kernel<4, true>),
+                                  reinterpret_cast<const void*>(&spmm_sliced_kernel<2, true>)},
+                                 kSlicedLds, lds_ok, "the column-sliced SpMM"))
+    return rc;
   const bool factored = a->col_scale != nullptr;
   if (edges == nullptr) edges = factored ? static_cast<const void*>(a->col16) : static_cast<const void*>(a->val);
   const int grid = (dim / W) * a->n_groups;

@@ -23,6 +23,23 @@ int hip_fail(hipError_t e, const char* what) {
   return static_cast<int>(e);
 }
 
+int allow_dynamic_lds(std::initializer_list<const void*> kernels, size_t bytes, std::atomic<uint64_t>& done,
+                      const char* what) {
+  int dev = 0, lds_max = 0;
+  HIPREC_TRY(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return 0;
+  HIPREC_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+  if (static_cast<size_t>(lds_max) < bytes) {
+    set_error("%s needs %zu bytes of LDS per workgroup, this device offers %d (gfx950: 160 KB)", what, bytes, lds_max);
+    return HIPREC_E_UNSUPPORTED;
+  }
+  for (const void* k : kernels)
+    HIPREC_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+  done.fetch_or(bit, std::memory_order_release);
+  return 0;
+}
+
 __global__ void stats_reset_kernel(hiprec_stats* s, double b1, double b2) {
   s->loss = 0.f;
   s->reg = 0.f;

@@ -17,7 +17,7 @@ Large tables (BASELINE configs[3]) use the row-sharded engine instead.
 import ctypes
 
 import torch
-import torch.distributed as dist
+from . import _dist as dist
 
 from . import _lib
 from .mf import MFEngine

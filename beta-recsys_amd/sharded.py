@@ -27,7 +27,7 @@ import ctypes
 import io
 
 import torch
-import torch.distributed as dist
+from . import _dist as dist
 
 from . import _lib
 from .mf import MF, _new_stats, raise_on_status, read_stats
@@ -704,7 +704,7 @@ class ShardedMFEngine:
         if getattr(self, "_plan_stream", None) is None:
             self._plan_stream = torch.cuda.Stream(device=self.device)
             ranks = None if self.pg is None else dist.get_process_group_ranks(self.pg)
-            self._plan_pg = dist.new_group(ranks=ranks)
+            self._plan_pg = dist.new_group(ranks=ranks, like=self.pg)
             if dist.get_backend(self._plan_pg) == "nccl":   # RCCL creates the communicator lazily: do it now
                 with torch.cuda.stream(self._plan_stream):
                     t = torch.zeros(self.world, dtype=torch.int32, device=self.device)

@@ -26,7 +26,7 @@ import ctypes
 import io
 
 import torch
-import torch.distributed as dist
+from . import _dist as dist
 
 from . import _lib
 from . import ncf as ncf_mod
