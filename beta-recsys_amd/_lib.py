@@ -18,6 +18,7 @@ OPT_KINDS = {"sgd": OPT_SGD, "adam": OPT_ADAM, "rmsprop": OPT_RMSPROP}
 
 STATUS_USER_OOB, STATUS_ITEM_OOB, STATUS_ROW_OOB, STATUS_ROUTE_OVERFLOW = 1, 2, 4, 8
 STATUS_NEG_EXHAUSTED = 16
+STATUS_LAZY_TABLE = 32
 
 
 class MfTables(Structure):
@@ -134,7 +135,24 @@ class ShardBufs(Structure):
     _fields_ = [("w_flat", c_void_p), ("n_users_local", c_int64), ("n_items_local", c_int64), ("dim", c_int32),
                 ("_pad", c_int32), ("payload", c_void_p), ("g_recv", c_void_p), ("fetched", c_void_p),
                 ("g_send", c_void_p), ("arrived", c_void_p), ("acc", c_void_p), ("scratch", c_void_p),
-                ("g_flat", c_void_p), ("m_flat", c_void_p), ("v_flat", c_void_p)]
+                ("g_flat", c_void_p), ("m_flat", c_void_p), ("v_flat", c_void_p),
+                ("stamp_u", c_void_p), ("stamp_i", c_void_p), ("lazy_scalars", c_void_p), ("lazy_scalars_cap", c_int64)]
+
+
+class LazyState(Structure):
+    """hiprec_lazy_state (include/hiprec.h)."""
+
+    _fields_ = [("w", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n_users", c_int64),
+                ("n_items", c_int64), ("dim", c_int32), ("kind", c_int32), ("stamp_u", c_void_p), ("stamp_i", c_void_p),
+                ("scalars", c_void_p), ("scalars_cap", c_int32), ("_pad", c_int32), ("lr", c_double),
+                ("beta1", c_double), ("beta2", c_double), ("eps", c_double)]
+
+
+class LazyRows(Structure):
+    """hiprec_lazy_rows (include/hiprec.h)."""
+
+    _fields_ = [("users", c_void_p), ("n_users", c_int64), ("items_a", c_void_p), ("n_items_a", c_int64),
+                ("items_b", c_void_p), ("n_items_b", c_int64), ("items_c", c_void_p), ("n_items_c", c_int64)]
 
 
 class NcclFns(Structure):
@@ -362,6 +380,11 @@ SIGNATURES = {
     "hiprec_shard_planned_steps": (
         c_int, [POINTER(ShardPlan), POINTER(ShardBufs), c_int64, c_int64, c_int32, c_float, c_double, c_double,
                 c_double, c_double, POINTER(NcclFns), _P, _P, _P]),
+    "hiprec_lazy_state_bytes": (c_size_t, []),
+    "hiprec_lazy_catchup": (c_int, [POINTER(LazyState), POINTER(LazyRows), _P, _P]),
+    "hiprec_lazy_update": (c_int, [POINTER(LazyState), POINTER(LazyRows), _P, _P, _P]),
+    "hiprec_lazy_flush": (c_int, [POINTER(LazyState), _P, _P]),
+    "hiprec_lazy_mark_current": (c_int, [POINTER(LazyState), _P, _P]),
     "hiprec_shard_plan_bytes": (c_size_t, []),
     "hiprec_shard_bufs_bytes": (c_size_t, []),
     "hiprec_shard_publish_partials": (c_int, [_P, _P, c_int32, _P, c_int32, _P]),
@@ -420,6 +443,10 @@ def load():
         raise RuntimeError("hiprec_dp_step layout mismatch between _lib.py and libhiprec.so")
     if lib.hiprec_ngcf_plan_bytes() != ctypes.sizeof(NgcfPlan):
         raise RuntimeError("hiprec_ngcf_plan layout mismatch between _lib.py and libhiprec.so")
+    if lib.hiprec_lazy_state_bytes() != ctypes.sizeof(LazyState):
+        raise RuntimeError("hiprec_lazy_state layout mismatch between _lib.py and libhiprec.so")
+    if lib.hiprec_shard_bufs_bytes() != ctypes.sizeof(ShardBufs):
+        raise RuntimeError("hiprec_shard_bufs layout mismatch between _lib.py and libhiprec.so")
     if lib.hiprec_ncf_plan_bytes() != ctypes.sizeof(NcfPlan):
         raise RuntimeError("hiprec_ncf_plan layout mismatch between _lib.py and libhiprec.so")
     _lib = _DeviceGuardedLib(lib)

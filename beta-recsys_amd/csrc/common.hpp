@@ -286,36 +286,41 @@ struct OptScalars {
 // parity bar), and costs ~8 VALU issue slots instead of ~35 per element -- the IEEE sequences made
 // the fused Adam step VALU-bound (13.6 us per step, 2 us of it in these two functions).
 // Build with -DHIPREC_IEEE_DIV for the op-for-op ATen arithmetic.
-__device__ __forceinline__ float opt_div(float a, float b) {
-#ifdef HIPREC_IEEE_DIV
-  return a / b;
-#else
-  return a * __builtin_amdgcn_rcpf(b);
-#endif
-}
-
-__device__ __forceinline__ float opt_sqrt(float a) {
-#ifdef HIPREC_IEEE_DIV
-  return sqrtf(a);
-#else
-  return __builtin_amdgcn_sqrtf(a);
-#endif
-}
-
+//
+// Every multiply / add / fused multiply-add below is spelled out and contraction is OFF inside the function: which of
+// two products of `a * b + c * d` the compiler fuses depends on the code around the call, so two kernels inlining
+// the same expression differed in the last bit (the dense sweep against csrc/lazy_opt.hip's replay of it, round 4).
+// With the operations pinned, every kernel that steps an element -- dense sweep, fused MF step, lazy replay --
+// produces the same bits from the same inputs.  The fused forms are the ones the compiler chose for the dense sweep.
 template <int KIND>
 __device__ __forceinline__ void opt_update(float& w, float& g, float& m, float& v,
                                            const OptScalars s, float step_size, float bc2_sqrt) {
+#pragma clang fp contract(off)
   if constexpr (KIND == HIPREC_OPT_SGD) {
-    w = w - s.lr * g;  // param.add_(grad, alpha=-lr)
-  } else if constexpr (KIND == HIPREC_OPT_ADAM) {
-    m = m + s.omb1 * (g - m);                                 // exp_avg.lerp_(grad, 1 - beta1)
-    v = v * s.beta2 + (s.omb2 * g) * g;                         // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
-    const float denom = opt_div(opt_sqrt(v), bc2_sqrt) + s.eps;  // (sqrt(v)/sqrt(bc2)).add_(eps)
-    w = w + opt_div(-step_size * m, denom);                     // param.addcdiv_(m, denom, value=-step_size)
+    w = __builtin_fmaf(-s.lr, g, w);  // param.add_(grad, alpha=-lr)
   } else {
-    v = v * s.beta2 + (s.omb2 * g) * g;                         // square_avg.mul_(alpha).addcmul_(g,g,1-alpha)
-    const float avg = opt_sqrt(v) + s.eps;                      // square_avg.sqrt().add_(eps)
-    w = w + opt_div(-s.lr * g, avg);                            // param.addcdiv_(grad, avg, value=-lr)
+    // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)   /   square_avg.mul_(alpha).addcmul_(g, g, 1 - alpha)
+    v = __builtin_fmaf(s.omb2 * g, g, v * s.beta2);
+    if constexpr (KIND == HIPREC_OPT_ADAM) {
+      m = __builtin_fmaf(s.omb1, g - m, m);  // exp_avg.lerp_(grad, 1 - beta1)
+      const float num = -step_size * m;       // param.addcdiv_(m, denom, value=-step_size)
+#ifdef HIPREC_IEEE_DIV
+      const float denom = sqrtf(v) / bc2_sqrt + s.eps;  // (sqrt(v) / sqrt(bc2)).add_(eps)
+      w = w + num / denom;
+#else
+      const float denom = __builtin_fmaf(__builtin_amdgcn_sqrtf(v), __builtin_amdgcn_rcpf(bc2_sqrt), s.eps);
+      w = __builtin_fmaf(num, __builtin_amdgcn_rcpf(denom), w);
+#endif
+    } else {
+      const float num = -s.lr * g;  // param.addcdiv_(grad, avg, value=-lr)
+#ifdef HIPREC_IEEE_DIV
+      const float avg = sqrtf(v) + s.eps;  // square_avg.sqrt().add_(eps)
+      w = w + num / avg;
+#else
+      const float avg = __builtin_amdgcn_sqrtf(v) + s.eps;
+      w = __builtin_fmaf(num, __builtin_amdgcn_rcpf(avg), w);
+#endif
+    }
   }
   g = 0.f;
 }

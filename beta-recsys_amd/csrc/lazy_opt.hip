@@ -1,0 +1,286 @@
+// Exact lazy Adam / RMSprop for embedding tables that live in HBM (BASELINE configs[3]; SURVEY.md "Hard parts":
+// "exact lazy catch-up: replay k missed zero-grad steps per row on next touch -- needs per-row last-step stamps and a
+// flush before predict / state_dict").
+//
+// Reference semantics (beta_rec/models/torch_engine.py:30-39): nn.Embedding is dense, so torch.optim.Adam / RMSprop
+// step EVERY element EVERY step, with a zero gradient for rows the batch did not touch.  The dense sweep
+// (csrc/optim.hip) does exactly that and moves 28 bytes per parameter per step: 39.7 GB per step at configs[3],
+// 195 x the bytes of the rows a step touches.  A zero-gradient step of a row depends on nothing but the row's own
+// (w, m, v) and the step number, so it can be postponed until the row is needed again and then replayed -- the SAME
+// fp32 operations in the SAME order (opt_update<KIND> with g = 0 and the step's own bias-correction scalars), hence
+// bit-identical to the sweep:
+//   * stamp[row] (int32 per table row) = the step the row is current as of; -1 = never touched (m = v = 0: every
+//     zero-gradient step is the identity on it);
+//   * scalars[t] = (lr / (1 - beta1^t), sqrt(1 - beta2^t)) as the sweep of step t derived them from hiprec_stats: the
+//     update kernel of step t records them, the replays read them;
+//   * catch-up (before a step reads its rows): rows of the step that lag behind are replayed up to the last completed
+//     step; only w is stored (what the step reads) and the stamp is flagged "w ahead" -- the moments are replayed
+//     again (one fma + one multiply per step) by the same step's update instead of being written and re-read.  Adam
+//     only: RMSprop's zero-gradient step leaves w alone (w += -lr * 0 / avg) and only decays v;
+//   * update (after the step's gradients are complete in the dense gradient buffer): every row of the step takes
+//     its real step -- after replaying what is still behind --, its gradient row is cleared, stamp = t;
+//   * flush: every lagging row of the tables is replayed up to the clock (before predict / state_dict / checkpoint /
+//     any dense sweep).
+// The lists name a step's rows with duplicates (a user that occurs twice, an item several peers ask for); the first
+// wave to raise the row's stamp (atomicMax) owns it for that launch, the others skip.  One wave per list entry,
+// lane = column (+ kWave * j), the row's bias element rides in lane 0.
+#include "common.hpp"
+
+namespace hiprec {
+namespace {
+
+constexpr int kLazyMaxNpl = 4;  // dim <= 256
+// stamp bit 30: "w (only) has been caught up to the clock by this step's catch-up; m, v are as of the stamp".  The
+// state lasts from a step's catch-up to the same step's update, which every caught-up row goes through.
+constexpr int kWAhead = 1 << 30;
+
+struct LazyCtx {
+  float* w;
+  float* g;
+  float* m;
+  float* v;
+  int64_t n_users, n_items;
+  int32_t dim;
+  int32_t* stamp_u;
+  int32_t* stamp_i;
+  float2* scalars;
+  int32_t scalars_cap;
+};
+
+__device__ __forceinline__ float2 lazy_scalars_at(const LazyCtx& c, long long t) {
+  return c.scalars[t < c.scalars_cap ? t : c.scalars_cap - 1];
+}
+
+// MODE 0 = catch-up (to the clock), 1 = update (the step the clock shows), 2 = flush (all rows, to the clock)
+template <int KIND, int MODE>
+__global__ __launch_bounds__(kBlock) void lazy_rows_kernel(LazyCtx c, hiprec_lazy_rows rows, OptScalars s,
+                                                           hiprec_stats* stats, const Scratch* scratch) {
+  const int lane = lane_id();
+  const int D = c.dim;
+  const long long clock = stats->step;
+  float ss_now = s.lr, bc2_now = 1.f;
+  if constexpr (MODE == 1) step_scalars<KIND>(s, stats, &ss_now, &bc2_now);
+  const int64_t nu = c.n_users, ni = c.n_items;
+  const int64_t n0 = MODE == 2 ? nu : rows.n_users, n1 = MODE == 2 ? ni : rows.n_items_a;
+  const int64_t n2 = MODE == 2 ? 0 : rows.n_items_b, n3 = MODE == 2 ? 0 : rows.n_items_c;
+  const int64_t total = n0 + n1 + n2 + n3;
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block(); e < total; e += n_waves) {
+    bool is_item = true;
+    int64_t id;
+    if (e < n0) {
+      is_item = false;
+      id = MODE == 2 ? e : rows.users[e];
+    } else if (e < n0 + n1) {
+      id = MODE == 2 ? e - n0 : rows.items_a[e - n0];
+    } else if (e < n0 + n1 + n2) {
+      id = rows.items_b[e - n0 - n1];
+    } else {
+      id = rows.items_c[e - n0 - n1 - n2];
+    }
+    if (id < 0) continue;  // padding of a fixed-size block / an exchange's extra row
+    if (id >= (is_item ? ni : nu)) {
+      if (lane == 0) atomicOr(&stats->status, HIPREC_STATUS_ROW_OOB);
+      continue;
+    }
+    int32_t* sp = (is_item ? c.stamp_i : c.stamp_u) + id;
+    const int target = static_cast<int>(clock);
+    // lane 0 settles who works on the row; `old` = the stamp found, `go` = this wave owns the row for this launch
+    int old = 0, go = 0;
+    if (lane == 0) {
+      old = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (MODE == 0) {   // raise the W_AHEAD flag: the first to set it owns the row
+        if (old >= 0 && !(old & kWAhead) && old < target) {
+          old = atomicOr(sp, kWAhead);
+          go = !(old & kWAhead);
+        }
+      } else if constexpr (MODE == 1) {   // the first to write the step's number owns the row
+        if (old != target) {
+          old = atomicExch(sp, target);
+          go = old != target;
+        }
+      } else {                     // flush: one visitor per row; a never-touched row stays -1
+        go = old >= 0 && (old & ~kWAhead) < target;
+        if (go) *sp = target;
+      }
+    }
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (!__builtin_amdgcn_readfirstlane(go)) continue;
+    const bool w_ahead = old >= 0 && (old & kWAhead);   // catch-up already moved w (only) up to the clock
+    const int base = old < 0 ? -1 : (old & ~kWAhead);
+    const int64_t emb = (is_item ? nu * D : 0) + id * D;
+    const int64_t bias = (nu + ni) * static_cast<int64_t>(D) + (is_item ? nu : 0) + id;
+    // this lane's elements: columns lane + 64 j, and the bias element in lane 0
+    int64_t at[kLazyMaxNpl + 1];
+    bool on[kLazyMaxNpl + 1];
+    float w[kLazyMaxNpl + 1], m[kLazyMaxNpl + 1], v[kLazyMaxNpl + 1], g[kLazyMaxNpl + 1];
+#pragma unroll
+    for (int j = 0; j <= kLazyMaxNpl; ++j) {
+      const int col = lane + kWave * j;
+      on[j] = j < kLazyMaxNpl ? col < D : lane == 0;
+      at[j] = j < kLazyMaxNpl ? emb + col : bias;
+      w[j] = m[j] = v[j] = g[j] = 0.f;
+      if (on[j]) {
+        if (KIND == HIPREC_OPT_ADAM || MODE == 1) w[j] = c.w[at[j]];
+        if constexpr (KIND == HIPREC_OPT_ADAM) m[j] = c.m[at[j]];
+        v[j] = c.v[at[j]];
+        if constexpr (MODE == 1) g[j] = c.g[at[j]];
+      }
+    }
+    // the zero-gradient steps this row has missed: (base, last] with last = the last COMPLETED step.  A row whose
+    // moments are all zero (marked current by a dense sweep that never gave it a gradient) is a fixed point of them.
+    const long long last = MODE == 1 ? clock - 1 : clock;
+    bool moving = false;
+#pragma unroll
+    for (int j = 0; j <= kLazyMaxNpl; ++j) moving |= on[j] && (m[j] != 0.f || v[j] != 0.f);
+    const bool replay = base >= 0 && __ballot(moving) != 0ull;
+    if (MODE == 1 && w_ahead) {
+      // w is current already: only the moments are replayed (one fma and one multiply per step, no sqrt / rcp)
+      for (long long t = base + 1LL; replay && t <= last; ++t) {
+#pragma unroll
+        for (int j = 0; j <= kLazyMaxNpl; ++j) {
+          float zero = 0.f, w_unused = 0.f;
+          opt_update<KIND>(w_unused, zero, m[j], v[j], s, 1.f, 1.f);
+        }
+      }
+    } else {
+      for (long long t = base + 1LL; replay && t <= last; ++t) {
+        float2 sc = make_float2(s.lr, 1.f);
+        if constexpr (KIND == HIPREC_OPT_ADAM) sc = lazy_scalars_at(c, t);
+#pragma unroll
+        for (int j = 0; j <= kLazyMaxNpl; ++j) {
+          float zero = 0.f;
+          opt_update<KIND>(w[j], zero, m[j], v[j], s, sc.x, sc.y);
+        }
+      }
+    }
+    if constexpr (MODE == 1) {
+#pragma unroll
+      for (int j = 0; j <= kLazyMaxNpl; ++j) opt_update<KIND>(w[j], g[j], m[j], v[j], s, ss_now, bc2_now);
+    }
+    if constexpr (MODE == 0) {   // only w: the moments are replayed by this step's update, which follows in any case
+#pragma unroll
+      for (int j = 0; j <= kLazyMaxNpl; ++j)
+        if (on[j]) c.w[at[j]] = w[j];
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j <= kLazyMaxNpl; ++j) {
+      if (!on[j]) continue;
+      if (KIND == HIPREC_OPT_ADAM || MODE == 1) c.w[at[j]] = w[j];
+      if constexpr (KIND == HIPREC_OPT_ADAM) c.m[at[j]] = m[j];
+      c.v[at[j]] = v[j];
+      if constexpr (MODE == 1) c.g[at[j]] = 0.f;
+    }
+  }
+  if constexpr (MODE == 1) {
+    // the model's scalar (global_bias, the last element) takes a real step every step; its gradient is in g (the
+    // row-sharded step's bookkeeping put it there) plus, for callers that pass the gradient kernel's scratch, the
+    // per-block partials (which also books the step's loss, as the dense sweep does)
+    if (blockIdx.x == 0) {
+      float extra = 0.f;
+      if (scratch) extra = finalize_partials(stats, scratch);
+      if (threadIdx.x == 0) {
+        const int64_t i = (nu + ni) * (static_cast<int64_t>(D) + 1);
+        float wv = c.w[i], gv = c.g[i] + extra, mv = 0.f, vv = c.v[i];
+        if constexpr (KIND == HIPREC_OPT_ADAM) mv = c.m[i];
+        opt_update<KIND>(wv, gv, mv, vv, s, ss_now, bc2_now);
+        c.w[i] = wv;
+        c.g[i] = 0.f;
+        if constexpr (KIND == HIPREC_OPT_ADAM) c.m[i] = mv;
+        c.v[i] = vv;
+        // this step's scalars for the replays to come.  Beyond the table the powers must have converged (default
+        // betas: beta2^t < 2^-53 from t ~ 36 800 on): a later step with different scalars cannot be replayed.
+        if (clock < c.scalars_cap) {
+          c.scalars[clock] = make_float2(ss_now, bc2_now);
+        } else {
+          const float2 last = c.scalars[c.scalars_cap - 1];
+          if (last.x != ss_now || last.y != bc2_now) atomicOr(&stats->status, HIPREC_STATUS_LAZY_TABLE);
+        }
+      }
+    }
+  }
+}
+
+// A dense sweep was run while lazy state exists (the caller flushed first): every row is current as of the clock.
+__global__ __launch_bounds__(kBlock) void lazy_mark_current_kernel(int32_t* stamp, int64_t n, const hiprec_stats* stats) {
+  const int target = static_cast<int>(stats->step);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock)
+    stamp[i] = target;   // EVERY row: the sweep may have given any of them its first gradient
+}
+
+template <int MODE>
+int lazy_launch(const hiprec_lazy_state* st, const hiprec_lazy_rows* rows, const void* scratch, hiprec_stats* stats,
+                void* stream) {
+  HIPREC_REQUIRE(st && stats, "NULL pointer");
+  HIPREC_REQUIRE(st->kind == HIPREC_OPT_ADAM || st->kind == HIPREC_OPT_RMSPROP,
+                 "lazy optimizer state exists for Adam and RMSprop (SGD touches only the step's rows anyway)");
+  HIPREC_REQUIRE(st->w && st->g && st->v && (st->kind != HIPREC_OPT_ADAM || st->m) && st->stamp_u && st->stamp_i,
+                 "NULL buffer in the lazy optimizer state");
+  HIPREC_REQUIRE(st->n_users >= 0 && st->n_items >= 0 && st->dim > 0 && st->dim <= kLazyMaxNpl * kWave,
+                 "lazy optimizer rows need 0 < dim <= %d", kLazyMaxNpl * kWave);
+  HIPREC_REQUIRE(st->kind != HIPREC_OPT_ADAM || (st->scalars && st->scalars_cap >= 2), "Adam needs the scalars table");
+  hiprec_lazy_rows r{};
+  int64_t total = st->n_users + st->n_items;
+  if (MODE != 2) {
+    HIPREC_REQUIRE(rows, "NULL row lists");
+    r = *rows;
+    HIPREC_REQUIRE(r.n_users >= 0 && r.n_items_a >= 0 && r.n_items_b >= 0 && r.n_items_c >= 0, "negative list length");
+    HIPREC_REQUIRE((r.n_users == 0 || r.users) && (r.n_items_a == 0 || r.items_a) && (r.n_items_b == 0 || r.items_b) &&
+                       (r.n_items_c == 0 || r.items_c),
+                   "NULL row list");
+    total = r.n_users + r.n_items_a + r.n_items_b + r.n_items_c;
+  }
+  if (MODE == 0 && st->kind == HIPREC_OPT_RMSPROP) return 0;  // w does not move on a zero-gradient RMSprop step
+  if (MODE != 1 && total == 0) return 0;
+  const LazyCtx c{st->w, st->g, st->m, st->v, st->n_users, st->n_items, st->dim, st->stamp_u, st->stamp_i,
+                  reinterpret_cast<float2*>(st->scalars), st->scalars_cap};
+  const OptScalars s{st->lr,
+                     static_cast<float>(st->lr),
+                     static_cast<float>(st->beta2),
+                     static_cast<float>(1.0 - st->beta1),
+                     static_cast<float>(1.0 - st->beta2),
+                     static_cast<float>(st->eps)};
+  const int grid = grid_for_waves(total);
+  hipStream_t stm = static_cast<hipStream_t>(stream);
+  const auto* sc = static_cast<const Scratch*>(scratch);
+  if (st->kind == HIPREC_OPT_ADAM)
+    lazy_rows_kernel<HIPREC_OPT_ADAM, MODE><<<grid, kBlock, 0, stm>>>(c, r, s, stats, sc);
+  else
+    lazy_rows_kernel<HIPREC_OPT_RMSPROP, MODE><<<grid, kBlock, 0, stm>>>(c, r, s, stats, sc);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+}  // namespace hiprec
+
+using namespace hiprec;
+
+extern "C" int hiprec_lazy_catchup(const hiprec_lazy_state* state, const hiprec_lazy_rows* rows, hiprec_stats* stats,
+                                   void* stream) {
+  return lazy_launch<0>(state, rows, nullptr, stats, stream);
+}
+
+extern "C" int hiprec_lazy_update(const hiprec_lazy_state* state, const hiprec_lazy_rows* rows, const void* scratch,
+                                  hiprec_stats* stats, void* stream) {
+  return lazy_launch<1>(state, rows, scratch, stats, stream);
+}
+
+extern "C" int hiprec_lazy_flush(const hiprec_lazy_state* state, hiprec_stats* stats, void* stream) {
+  return lazy_launch<2>(state, nullptr, nullptr, stats, stream);
+}
+
+extern "C" int hiprec_lazy_mark_current(const hiprec_lazy_state* state, const hiprec_stats* stats, void* stream) {
+  HIPREC_REQUIRE(state && stats && state->stamp_u && state->stamp_i, "NULL pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (state->n_users > 0)
+    lazy_mark_current_kernel<<<grid_for_threads(state->n_users), kBlock, 0, st>>>(state->stamp_u, state->n_users, stats);
+  if (state->n_items > 0)
+    lazy_mark_current_kernel<<<grid_for_threads(state->n_items), kBlock, 0, st>>>(state->stamp_i, state->n_items, stats);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" size_t hiprec_lazy_state_bytes(void) { return sizeof(hiprec_lazy_state); }

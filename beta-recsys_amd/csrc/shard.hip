@@ -522,6 +522,11 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
   const bool dense = kind != HIPREC_OPT_SGD;
   HIPREC_REQUIRE(kind == HIPREC_OPT_SGD || kind == HIPREC_OPT_ADAM || kind == HIPREC_OPT_RMSPROP, "unknown optimizer");
   HIPREC_REQUIRE(dense ? (bufs->g_flat != nullptr) : (bufs->arrived && bufs->acc), "incomplete step buffers");
+  // exact lazy Adam / RMSprop (csrc/lazy_opt.hip): the step's rows are caught up before they are read and stepped
+  // after their gradients are complete -- the dense sweep of the whole shard goes
+  const bool lazy = dense && bufs->stamp_u != nullptr;
+  HIPREC_REQUIRE(!lazy || (bufs->stamp_i && bufs->v_flat && (kind != HIPREC_OPT_ADAM || (bufs->m_flat && bufs->lazy_scalars))),
+                 "incomplete lazy optimizer state");
   const int D = bufs->dim, ld = D + 1;
   HIPREC_REQUIRE(D >= 2 && D <= 256, "the planned sharded step needs 2 <= emb_dim <= 256");
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -536,6 +541,14 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
   const auto recv = nccl ? reinterpret_cast<nccl_recv_fn>(nccl->recv) : nullptr;
   const auto g_start = nccl ? reinterpret_cast<nccl_group_fn>(nccl->group_start) : nullptr;
   const auto g_end = nccl ? reinterpret_cast<nccl_group_fn>(nccl->group_end) : nullptr;
+  hiprec_lazy_state lz{};
+  if (lazy) {
+    lz.w = w, lz.g = g, lz.m = bufs->m_flat, lz.v = bufs->v_flat;
+    lz.n_users = nu, lz.n_items = ni, lz.dim = D, lz.kind = kind;
+    lz.stamp_u = bufs->stamp_u, lz.stamp_i = bufs->stamp_i;
+    lz.scalars = bufs->lazy_scalars, lz.scalars_cap = static_cast<int32_t>(std::min<int64_t>(bufs->lazy_scalars_cap, 1 << 30));
+    lz.lr = lr, lz.beta1 = beta1, lz.beta2 = beta2, lz.eps = eps;
+  }
   // Every rank must post every exchange of the range: a rank that returned half-way would leave its peers waiting in
   // theirs.  Whatever can be checked is therefore checked BEFORE the first launch.
   for (int64_t s = step_begin; s < step_end; ++s) {
@@ -568,6 +581,10 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
     float* self_g = bufs->g_send + req_lo * ld;
     const uint8_t* shared = plan->slot_shared ? plan->slot_shared + s * plan->slot_stride : nullptr;
     const uint32_t* dup = plan->dup_bits ? plan->dup_bits + s * plan->dup_words : nullptr;
+    // the rows this step touches here: the local users of its triples and the item rows its peers ask for
+    const hiprec_lazy_rows touched{plan->users + s * cap, cap, nullptr, 0, nullptr, 0, idx, il};
+    if (lazy)
+      if (int rc = hiprec_lazy_catchup(&lz, &touched, stats, stream)) return rc;
     if (int rc = hiprec_shard_payload_zero(item_emb, item_bias, ni, D, idx, il, in_lo, in_hi, bufs->payload,
                                            self_fetched, bufs->g_send, sl * ld, shared, stats, stream))
       return rc;
@@ -644,9 +661,12 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
                                         dense ? 1.0 : -lr, plan->ex_in + s * R, R, scalar, dense ? 1.0 : -lr,
                                         s == 0 ? 1 : 0, dup, stats, stream)))
       return rc;
-    if (dense && (rc = hiprec_opt_dense_step(kind, w, g, bufs->m_flat, bufs->v_flat, n_flat, lr, beta1, beta2, eps,
-                                             stats, nullptr, -1, stream)))
+    if (lazy) {
+      if ((rc = hiprec_lazy_update(&lz, &touched, nullptr, stats, stream))) return rc;
+    } else if (dense && (rc = hiprec_opt_dense_step(kind, w, g, bufs->m_flat, bufs->v_flat, n_flat, lr, beta1, beta2,
+                                                    eps, stats, nullptr, -1, stream))) {
       return rc;
+    }
   }
   HIPREC_TRY(hipGetLastError());
   return 0;

@@ -8,7 +8,7 @@ moments, ``hiprec_stats``, scratch) and the three things every one of them does 
 import torch
 
 from . import _lib
-from .mf import _new_stats, raise_on_status, read_stats
+from .mf import _new_stats, clear_status, raise_on_status, read_stats
 from .torch_engine import ModelEngine
 
 
@@ -66,10 +66,7 @@ class FlatModelEngine(ModelEngine):
         status word is cleared and a partially accumulated gradient dropped, so the engine stays usable)."""
         st = read_stats(self._stats)
         if st.status:
-            raw = self._stats.cpu()
-            off = _lib.Stats.status.offset
-            raw[off:off + 4] = 0
-            self._stats.copy_(raw)
+            clear_status(self._stats)
             self._g_flat.zero_()
             raise_on_status(st.status)
         return st

@@ -82,6 +82,14 @@ def read_stats(stats_tensor):
     return _lib.Stats.from_buffer_copy(raw)
 
 
+def clear_status(stats):
+    """Zero the 4-byte status word of a device hiprec_stats -- and only that: the struct also holds the optimizer
+    clock and the epoch sums, which kernels of other streams may be advancing (writing back a host copy of
+    the whole struct raced them)."""
+    off = _lib.Stats.status.offset
+    stats[off:off + 4].zero_()
+
+
 def raise_on_status(status):
     """Turn sticky device status bits into the IndexError PyTorch would have raised."""
     if status:
@@ -94,6 +102,10 @@ def raise_on_status(status):
             which.append("row")
         if status & _lib.STATUS_NEG_EXHAUSTED:
             raise ValueError("Sample larger than population or is negative")  # random.sample's message
+        if status & _lib.STATUS_LAZY_TABLE:
+            raise RuntimeError(
+                "lazy Adam: the optimizer ran past the bias-correction table while the corrections still moved "
+                "(non-default betas?): use config['model']['dense_opt'] = 'sweep'")
         if status & _lib.STATUS_ROUTE_OVERFLOW:
             raise RuntimeError(
                 "a fixed-capacity all-to-all bucket overflowed: raise the sharded engine's "
@@ -621,10 +633,7 @@ class MFEngine(ModelEngine):
         st = read_stats(self._stats)
         if st.status:
             # clear the sticky bits, keep the optimizer clock
-            raw = self._stats.cpu()
-            off = _lib.Stats.status.offset
-            raw[off:off + 4] = 0
-            self._stats.copy_(raw)
+            clear_status(self._stats)
             ob = getattr(self, "_owned_bufs", None)
             if ob is not None:   # a skipped (out-of-range) triple leaves its rows' counts incomplete
                 ob["arrived"].zero_()

@@ -24,7 +24,7 @@ import torch.nn as nn
 from torch.nn import Parameter
 
 from . import _lib
-from .mf import _new_stats, raise_on_status, read_stats, timeit
+from .mf import _new_stats, clear_status, raise_on_status, read_stats, timeit
 from .torch_engine import ModelEngine
 
 
@@ -432,10 +432,7 @@ class _NcfEngine(ModelEngine):
     def _sync_stats(self):
         st = read_stats(self._stats)
         if st.status:
-            raw = self._stats.cpu()
-            off = _lib.Stats.status.offset
-            raw[off:off + 4] = 0
-            self._stats.copy_(raw)
+            clear_status(self._stats)
             raise_on_status(st.status)
         return st
 

@@ -30,7 +30,7 @@ import torch
 from . import _dist as dist
 
 from . import _lib
-from .mf import MF, _new_stats, raise_on_status, read_stats
+from .mf import MF, _new_stats, clear_status, raise_on_status, read_stats
 from .torch_engine import HipOptimizer
 
 KEYS = ("global_bias", "user_emb.weight", "item_emb.weight", "user_bias.weight", "item_bias.weight")
@@ -266,7 +266,7 @@ class HipKernels:
             idx.numel(), 0, 0, None, coef, _lib.ptr(extra_pos), extra_pos.numel(), _lib.ptr(scalar_target), scalar_coef,
             1 if first_of_epoch else 0, None, _lib.ptr(self.stats), self._st()))
 
-    def planned_steps(self, plan, bufs, model, g_flat, opt, a, b, reg, comm):
+    def planned_steps(self, plan, bufs, model, g_flat, opt, a, b, reg, comm, lazy=None):
         """Steps [a, b) of a planned epoch -- kernels AND exchanges -- enqueued by ONE C call
         (hiprec_shard_planned_steps); comm: an _rccl.Communicator (None at world size 1)."""
         c = plan.get("_c")
@@ -293,7 +293,9 @@ class HipKernels:
             bufs["arrived"].data_ptr(), bufs["acc"].data_ptr(), self.scratch.data_ptr(),
             g_flat.data_ptr() if dense else None,
             opt.exp_avg.data_ptr() if opt.exp_avg is not None else None,
-            opt.exp_avg_sq.data_ptr() if opt.exp_avg_sq is not None else None)
+            opt.exp_avg_sq.data_ptr() if opt.exp_avg_sq is not None else None,
+            lazy["stamp_u"].data_ptr() if lazy else None, lazy["stamp_i"].data_ptr() if lazy else None,
+            lazy["scalars"].data_ptr() if lazy else None, lazy["scalars"].shape[0] if lazy else 0)
         fns = None
         if comm is not None:
             fns = ctypes.byref(_lib.NcclFns(comm.send_fn, comm.recv_fn, comm.group_start_fn, comm.group_end_fn))
@@ -301,6 +303,42 @@ class HipKernels:
             ctypes.byref(c[0]), ctypes.byref(sb), a, b, opt.kind, reg, opt.lr, opt.beta1, opt.beta2, opt.eps, fns,
             ctypes.c_void_p(comm.comm.value if comm is not None else None), _lib.ptr(self.stats),
             self._st()))
+
+    # ---- exact lazy Adam / RMSprop (csrc/lazy_opt.hip) -------------------------------------------------------------
+    LAZY_SCALARS = 1 << 16     # steps whose bias corrections are tabulated (default betas converge by t ~ 36 800)
+
+    def lazy_state(self, model, g_flat, opt):
+        """The per-row stamps (-1 = never touched) and Adam's per-step scalars table of a shard, with the C struct
+        that names them next to w / g / m / v."""
+        dev = self.device
+        lz = {"stamp_u": torch.full((max(model.n_users, 1),), -1, dtype=torch.int32, device=dev),
+              "stamp_i": torch.full((max(model.n_items, 1),), -1, dtype=torch.int32, device=dev),
+              "scalars": torch.zeros((self.LAZY_SCALARS, 2), dtype=torch.float32, device=dev), "dirty": False}
+        lz["c"] = _lib.LazyState(
+            model.flat.data_ptr(), g_flat.data_ptr(), opt.exp_avg.data_ptr() if opt.exp_avg is not None else None,
+            opt.exp_avg_sq.data_ptr(), model.n_users, model.n_items, model.emb_dim, opt.kind, lz["stamp_u"].data_ptr(),
+            lz["stamp_i"].data_ptr(), lz["scalars"].data_ptr(), self.LAZY_SCALARS, 0, opt.lr, opt.beta1, opt.beta2,
+            opt.eps)
+        return lz
+
+    @staticmethod
+    def _lazy_rows(users, items32):
+        return _lib.LazyRows(users.data_ptr(), users.numel(), None, 0, None, 0, items32.data_ptr(), items32.numel())
+
+    def lazy_catchup(self, lz, users, items32):
+        rows = self._lazy_rows(users, items32)
+        _lib.check(self.lib.hiprec_lazy_catchup(ctypes.byref(lz["c"]), ctypes.byref(rows), _lib.ptr(self.stats), self._st()))
+
+    def lazy_update(self, lz, users, items32):
+        rows = self._lazy_rows(users, items32)
+        _lib.check(self.lib.hiprec_lazy_update(ctypes.byref(lz["c"]), ctypes.byref(rows), None, _lib.ptr(self.stats),
+                                               self._st()))
+
+    def lazy_flush(self, lz):
+        _lib.check(self.lib.hiprec_lazy_flush(ctypes.byref(lz["c"]), _lib.ptr(self.stats), self._st()))
+
+    def lazy_mark_current(self, lz):
+        _lib.check(self.lib.hiprec_lazy_mark_current(ctypes.byref(lz["c"]), _lib.ptr(self.stats), self._st()))
 
     def epoch_stats(self):
         """(last loss, last reg, loss sum, reg sum) of the epoch (synchronises)."""
@@ -322,11 +360,11 @@ class HipKernels:
     def check_status(self):
         st = read_stats(self.stats)
         if st.status:
-            raw = self.stats.cpu()
-            off = _lib.Stats.status.offset
-            raw[off:off + 4] = 0
-            self.stats.copy_(raw)
+            clear_status(self.stats)
             raise_on_status(st.status)
+
+    def clear_status(self):
+        clear_status(self.stats)
 
 
 class ShardedMFEngine:
@@ -372,6 +410,16 @@ class ShardedMFEngine:
         self.optimizer.allocate_state(self.model.flat)
         self.step_count = 0
         self.last = (float("nan"), float("nan"))
+        # Adam / RMSprop on the planned epoch path: `dense_opt` = "sweep" (every element every step: 28 bytes per
+        # parameter per step), "lazy" (exact lazy replay, csrc/lazy_opt.hip: only the step's rows move; flushed before
+        # anybody reads the tables) or "auto" (lazy from 64 MB of shard on -- below that the sweep is cache traffic)
+        mode = mc["dense_opt"] if "dense_opt" in mc else "auto"
+        if mode not in ("sweep", "lazy", "auto"):
+            raise ValueError(f"dense_opt must be 'sweep', 'lazy' or 'auto', not {mode!r}")
+        self._lazy = None
+        if (self.optimizer.name != "sgd" and isinstance(self.k, HipKernels) and self.emb_dim <= 256
+                and (mode == "lazy" or (mode == "auto" and self.model.flat.numel() * 4 >= (64 << 20)))):
+            self._lazy = self.k.lazy_state(self.model, self._g_flat, self.optimizer)
         # "padded": fixed-capacity all-to-alls, bucketing on the device, no host sync per step (all
         # ranks must feed the same local batch size); "variable": exact-size all-to-alls with
         # host-side split sizes (any batch sizes, one host sync per exchange)
@@ -391,15 +439,33 @@ class ShardedMFEngine:
     def load_full_state_dict(self, full_state):
         """Keep rows ``rank::world`` of a full (reference-format) state_dict."""
         R, r = self.world, self.rank
+        if getattr(self, "_lazy", None) is not None:
+            self.flush_lazy()      # the moments stay: every row must be current before its weights are replaced
         local = {}
         for k in KEYS:
             v = torch.as_tensor(full_state[k], dtype=torch.float32)
             local[k] = v if k == "global_bias" else v[r::R]
         self.model.load_state_dict(local)
 
+    def flush_lazy(self):
+        """Lazy Adam / RMSprop: replay every lagging row up to the optimizer clock, so that the tables (and the
+        moments) hold what the dense sweep would have left.  Called before anything reads them; cheap when nothing
+        lags."""
+        if self._lazy is not None and self._lazy["dirty"]:
+            self.k.lazy_flush(self._lazy)
+            self._lazy["dirty"] = False
+
+    def _dense_opt_step(self):
+        """One dense sweep (the per-step paths); with lazy state around: flush first, then every row is current."""
+        self.flush_lazy()
+        self.k.opt_step(self.optimizer, self.model.flat, self._g_flat, self.step_count)
+        if self._lazy is not None:
+            self.k.lazy_mark_current(self._lazy)
+
     def gather_full_state_dict(self):
         """All-gather the shards into a reference-compatible state_dict (every rank gets it; rank 0
         typically ``torch.save``s it — the checkpoint format of torch_engine.py:70-73)."""
+        self.flush_lazy()
         R = self.world
         full = {}
         for k, v in self.model.state_dict().items():
@@ -534,7 +600,7 @@ class ShardedMFEngine:
                        self._item_stamp, self._stamp + 2)
             self._stamp += 2
         else:
-            k.opt_step(self.optimizer, m.flat, self._g_flat, self.step_count)
+            self._dense_opt_step()
         if not sync:
             self._pending = part
             return None
@@ -609,7 +675,7 @@ class ShardedMFEngine:
         dist.all_reduce(part, group=self.pg)
         ggb += part[2]
         self.step_count += 1
-        self.k.opt_step(self.optimizer, m.flat, self._g_flat, self.step_count)
+        self._dense_opt_step()
         if not sync:
             self._pending = part
             return None
@@ -660,11 +726,19 @@ class ShardedMFEngine:
         send, cnt_ds = k.plan_route(users, pos, neg, perm, bs, R, self.n_users, self.n_items)
         recv_cnt = torch.empty_like(cnt_ds)
         dist.all_to_all_single(recv_cnt, cnt_ds, group=pg)                 # [source, step]
-        host = torch.cat([cnt_ds.sum(1), recv_cnt.sum(1), recv_cnt.sum(0).max().reshape(1),
-                          k.plan_status().to(cnt_ds.device)]).tolist()     # host sync 1 of 2
+        # one rank's out-of-range id must stop EVERY rank here, between the same two collectives (raised
+        # by its holder only, the peers walked on into the next all-to-all and hung): the status words are OR-ed
+        # (bit masks: MAX would lose bits) over the group before the host reads them
+        status = k.plan_status().to(cnt_ds.device)
+        if R > 1:
+            bits = torch.stack([(status >> b) & 1 for b in range(8)]).reshape(-1)
+            dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=pg)
+            status = (bits << torch.arange(8, device=bits.device)).sum().reshape(1)
+        host = torch.cat([cnt_ds.sum(1), recv_cnt.sum(1), recv_cnt.sum(0).max().reshape(1), status]).tolist()  # host sync 1 of 2
         status = int(host[2 * R + 1])
         if status:
-            k.check_status()   # out-of-range ids: IndexError, as nn.Embedding raises (and the status word is cleared)
+            k.clear_status()
+            raise_on_status(status)   # IndexError, as nn.Embedding raises; the status word is cleared, the engine usable
         send1, recv1, cap = host[:R], host[R:2 * R], max(int(host[2 * R]), 1)
         recv = self._a2a(send[:sum(send1)], send1, recv1, pg)               # (source, step)-ordered
         U, P, N, fill = k.plan_place_triples(recv, recv_cnt, S, cap)        # fixed-size blocks per step, user -1 = padding
@@ -792,9 +866,14 @@ class ShardedMFEngine:
                 "acc": torch.zeros(plan["stride"] * ld, **f32)}
         lr, reg = self.optimizer.lr, float(self.reg)
         a, b = steps or (0, S)
+        lazy = self._lazy if dense else None
+        if lazy is not None:
+            lazy["dirty"] = True
         if self._step_comm() == "c":
-            k.planned_steps(plan, pb, m, self._g_flat, self.optimizer, a, b, reg, self._comm)
+            k.planned_steps(plan, pb, m, self._g_flat, self.optimizer, a, b, reg, self._comm, lazy)
             self.step_count += b - a
+            if b == S and self.config["model"].get("lazy_flush", "epoch") == "epoch":
+                self.flush_lazy()     # the epoch's callers (evaluation, checkpoints) read the tables
             return k.epoch_stats() if sync else None
         item_emb, item_bias = m.item_emb.weight.data, m.item_bias.weight.data
         gue, gie, gub, gib, ggb = m._views(self._g_flat)
@@ -803,6 +882,9 @@ class ShardedMFEngine:
             idx = plan["in_idx"][plan["in_off"][s]: plan["in_off"][s] + il]
             payload, fetched = pb["payload"][:il], pb["fetched"][:sl]
             g_send, g_recv = pb["g_send"][:sl], pb["g_recv"][:il]
+            blk = slice(s * cap, (s + 1) * cap)
+            if lazy is not None:
+                k.lazy_catchup(lazy, plan["U"][blk], idx)
             k.payload_zero(item_emb, item_bias, idx, payload, g_send)
             dist.all_to_all_single(fetched, payload, output_split_sizes=plan["req_split"][s],
                                    input_split_sizes=plan["in_split"][s], group=self.pg)
@@ -820,9 +902,14 @@ class ShardedMFEngine:
             self.step_count += 1
             if dense:
                 k.apply_finish(gie, gib, idx, g_recv, 1.0, plan["ex_in"][s], ggb, 1.0, s == 0)
-                k.opt_step(self.optimizer, m.flat, self._g_flat, self.step_count)
+                if lazy is not None:
+                    k.lazy_update(lazy, plan["U"][blk], idx)
+                else:
+                    k.opt_step(self.optimizer, m.flat, self._g_flat, self.step_count)
             else:
                 k.apply_finish(item_emb, item_bias, idx, g_recv, -lr, plan["ex_in"][s], m.global_bias.data, -lr, s == 0)
+        if b == S and self.config["model"].get("lazy_flush", "epoch") == "epoch":
+            self.flush_lazy()
         return k.epoch_stats() if sync else None
 
     def _equal_loaders(self, train_loader):

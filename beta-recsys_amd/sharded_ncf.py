@@ -30,7 +30,7 @@ from . import _dist as dist
 
 from . import _lib
 from . import ncf as ncf_mod
-from .mf import _new_stats, raise_on_status, read_stats
+from .mf import _new_stats, clear_status, raise_on_status, read_stats
 from .sharded import shard_rows
 from .torch_engine import HipOptimizer
 
@@ -98,10 +98,7 @@ class HipNcfKernels:
     def check_status(self):
         st = read_stats(self.stats)
         if st.status:
-            raw = self.stats.cpu()
-            off = _lib.Stats.status.offset
-            raw[off:off + 4] = 0
-            self.stats.copy_(raw)
+            clear_status(self.stats)
             raise_on_status(st.status)
 
 

@@ -44,6 +44,7 @@ extern "C" {
 #define HIPREC_STATUS_ROW_OOB 4u
 #define HIPREC_STATUS_ROUTE_OVERFLOW 8u /* a fixed-capacity all-to-all bucket was too small */
 #define HIPREC_STATUS_NEG_EXHAUSTED 16u /* a user has fewer untouched items than negatives were asked for */
+#define HIPREC_STATUS_LAZY_TABLE 32u    /* lazy Adam: a step beyond the scalars table whose bias corrections still move */
 
 /* optimizer kinds, beta_rec/models/torch_engine.py:23-39 (only `lr` is ever set there) */
 #define HIPREC_OPT_SGD 0
@@ -480,6 +481,12 @@ typedef struct hiprec_shard_bufs {
   float* g_flat;                 /* Adam / RMSprop: dense gradient (zero between steps) and moments, like w_flat */
   float* m_flat;
   float* v_flat;
+  /* exact lazy Adam / RMSprop (hiprec_lazy_state below): non-NULL stamps replace the dense sweep of every step by
+   * catch-up + update of the step's rows; the caller flushes (hiprec_lazy_flush) before anybody reads the tables */
+  int32_t* stamp_u;
+  int32_t* stamp_i;
+  float* lazy_scalars;
+  int64_t lazy_scalars_cap;
 } hiprec_shard_bufs;
 
 /* ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd of the RCCL the caller loaded (this library links none) */
@@ -499,6 +506,62 @@ size_t hiprec_shard_bufs_bytes(void);
 int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const hiprec_shard_bufs* bufs, int64_t step_begin,
                                int64_t step_end, int32_t kind, float reg_coef, double lr, double beta1, double beta2,
                                double eps, const hiprec_nccl_fns* nccl, void* comm, hiprec_stats* stats, void* stream);
+
+/* ---- exact lazy Adam / RMSprop for tables that live in HBM (csrc/lazy_opt.hip; reference semantics:
+ * beta_rec/models/torch_engine.py:30-39 -- nn.Embedding is dense, so torch.optim steps every element every step, a
+ * zero gradient for the rows a batch did not touch).  A zero-gradient step of a row depends on the row's own (w, m, v)
+ * and the step number only: it is postponed until the row is needed and then REPLAYED, the same fp32 operations in the
+ * same order as the dense sweep (hiprec_opt_dense_step) -- bit-identical to it after hiprec_lazy_flush.
+ *   stamp_u[n_users], stamp_i[n_items] (int32): the step a row is current as of; -1 = never touched (m = v = 0).
+ *     Initialise to -1 together with zeroed moments; after loading optimizer state call hiprec_lazy_mark_current.
+ *   scalars[scalars_cap][2] (fp32; Adam only): (lr / (1 - beta1^t), sqrt(1 - beta2^t)) of step t, recorded by
+ *     hiprec_lazy_update, read by the replays; steps >= scalars_cap must have converged bias corrections
+ *     (HIPREC_STATUS_LAZY_TABLE otherwise; 65 536 entries are plenty for the default betas).
+ * All buffers are flat and laid out like the MF parameters [user_emb | item_emb | user_bias | item_bias | global_bias];
+ * g is the dense gradient, zero except for the rows of the step in flight. */
+typedef struct hiprec_lazy_state {
+  float* w;
+  float* g;
+  float* m; /* Adam: exp_avg; NULL for RMSprop */
+  float* v; /* exp_avg_sq / square_avg */
+  int64_t n_users, n_items;
+  int32_t dim;
+  int32_t kind; /* HIPREC_OPT_ADAM | HIPREC_OPT_RMSPROP */
+  int32_t* stamp_u;
+  int32_t* stamp_i;
+  float* scalars;
+  int32_t scalars_cap, _pad;
+  double lr, beta1, beta2, eps;
+} hiprec_lazy_state;
+
+/* The rows one step touches, as id lists WITH duplicates (-1 = skip): local user rows, two int64 item lists (a batch's
+ * positives and negatives) and one int32 item list (the rows a planned step's peers ask for). */
+typedef struct hiprec_lazy_rows {
+  const int64_t* users;
+  int64_t n_users;
+  const int64_t* items_a;
+  int64_t n_items_a;
+  const int64_t* items_b;
+  int64_t n_items_b;
+  const int32_t* items_c;
+  int64_t n_items_c;
+} hiprec_lazy_rows;
+
+size_t hiprec_lazy_state_bytes(void);
+/* BEFORE a step reads its rows: the listed rows that lag behind the clock (stats->step = completed steps) are replayed
+ * up to it and stored.  No-op for RMSprop (a zero-gradient step leaves w alone; v is replayed by the update). */
+int hiprec_lazy_catchup(const hiprec_lazy_state* state, const hiprec_lazy_rows* rows, hiprec_stats* stats, void* stream);
+/* AFTER the step's gradients are complete in g and the clock has been advanced to the step: every listed row takes the
+ * step (g row cleared, stamp = clock), the scalar (last element) too -- its gradient is g's last element plus, if
+ * `scratch` is the gradient kernel's scratch block, the per-block partials (which also books loss / reg into stats, as
+ * hiprec_opt_dense_step does). */
+int hiprec_lazy_update(const hiprec_lazy_state* state, const hiprec_lazy_rows* rows, const void* scratch,
+                       hiprec_stats* stats, void* stream);
+/* Every lagging row of both tables replayed up to the clock: before predict / state_dict / checkpoints / a dense sweep. */
+int hiprec_lazy_flush(const hiprec_lazy_state* state, hiprec_stats* stats, void* stream);
+/* After a dense sweep over flushed tables (or after loading optimizer state): EVERY row is current as of the clock
+ * (the sweep may have given any row its first gradient; rows whose moments are still zero cost a replay nothing). */
+int hiprec_lazy_mark_current(const hiprec_lazy_state* state, const hiprec_stats* stats, void* stream);
 
 /* ---- ONE launch of that sequence, with the buffers of this step named explicitly: for callers that
  *      have to do something between two steps -- the data-parallel engine all-reduces

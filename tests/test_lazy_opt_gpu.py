@@ -1,0 +1,280 @@
+"""Exact lazy Adam / RMSprop (csrc/lazy_opt.hip) against the dense sweep it replaces.
+
+Reference semantics: beta_rec/models/torch_engine.py:30-39 -- torch.optim.Adam / RMSprop on DENSE nn.Embedding
+gradients step every element every step.  The lazy form postpones a row's zero-gradient steps and replays them
+(the same fp32 operations, the same per-step bias corrections) when the row is needed: after a flush the tables
+and the moments must equal the dense sweeps' BIT FOR BIT, and a row that a step reads must already hold the bits
+the sweeps would have given it."""
+import contextlib
+import ctypes
+import io
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import KEYS, assert_on_trajectory, assert_scalar_close, mf_trajectory
+from oracle import mf_numpy as onp
+
+pytestmark = pytest.mark.gpu
+KIND = {"adam": 1, "rmsprop": 2}
+
+
+def new_stats(lib, _lib, dev):
+    from beta_recsys_amd.mf import _new_stats
+
+    stats = _new_stats(dev)
+    _lib.check(lib.hiprec_stats_reset(_lib.ptr(stats), 0.9, 0.999, _lib.stream_ptr(dev)))
+    return stats
+
+
+class Lazy:
+    """hiprec_lazy_state over flat test buffers."""
+
+    def __init__(self, lib, _lib, w, g, m, v, U, I, D, kind, lr, cap=64):
+        self.lib, self._lib, self.dev = lib, _lib, w.device
+        self.stamp_u = torch.full((U,), -1, dtype=torch.int32, device=w.device)
+        self.stamp_i = torch.full((I,), -1, dtype=torch.int32, device=w.device)
+        self.scalars = torch.zeros((cap, 2), dtype=torch.float32, device=w.device)
+        self.c = _lib.LazyState(w.data_ptr(), g.data_ptr(), m.data_ptr() if m is not None else None, v.data_ptr(), U, I, D,
+                                kind, self.stamp_u.data_ptr(), self.stamp_i.data_ptr(), self.scalars.data_ptr(), cap, 0, lr,
+                                0.9, 0.999, 1e-8)
+
+    def rows(self, users, items_a, items_b, items_c):
+        self._keep = (users, items_a, items_b, items_c)
+        p = lambda t: t.data_ptr() if t is not None and t.numel() else None  # noqa: E731
+        n = lambda t: t.numel() if t is not None else 0  # noqa: E731
+        return self._lib.LazyRows(p(users), n(users), p(items_a), n(items_a), p(items_b), n(items_b), p(items_c),
+                                  n(items_c))
+
+    def catchup(self, stats, *lists):
+        r = self.rows(*lists)
+        self._lib.check(self.lib.hiprec_lazy_catchup(ctypes.byref(self.c), ctypes.byref(r), self._lib.ptr(stats),
+                                                     self._lib.stream_ptr(self.dev)))
+
+    def update(self, stats, *lists):
+        r = self.rows(*lists)
+        self._lib.check(self.lib.hiprec_lazy_update(ctypes.byref(self.c), ctypes.byref(r), None, self._lib.ptr(stats),
+                                                    self._lib.stream_ptr(self.dev)))
+
+    def flush(self, stats):
+        self._lib.check(self.lib.hiprec_lazy_flush(ctypes.byref(self.c), self._lib.ptr(stats),
+                                                   self._lib.stream_ptr(self.dev)))
+
+
+@pytest.mark.parametrize("D", [8, 64, 100, 128, 256])
+@pytest.mark.parametrize("opt", ["adam", "rmsprop"])
+def test_lazy_rows_equal_the_dense_sweeps_bit_for_bit(hip_device, opt, D):
+    """40 steps on a 50 x 30 table, each touching a few rows: some rows every step, some twice with a gap of 30+
+    steps, some never; the lists carry duplicates and -1 padding and use all four list kinds; the table of per-step
+    scalars is SHORTER than the run is long only where that is legal (not here: cap 64).  In lockstep with dense
+    sweeps fed the same gradients: (1) after every catch-up the step's rows hold the dense sweep's bits (what the
+    gradient kernel would read), (2) after the flush w, m, v are bit-identical everywhere and g is all zero, (3)
+    never-touched rows keep their stamp -1 and their bits."""
+    from beta_recsys_amd import _lib
+
+    lib, dev = _lib.load(), hip_device
+    U, I, T, lr = 50, 30, 40, 0.05
+    kind = KIND[opt]
+    P = (U + I) * (D + 1) + 1
+    gen = torch.Generator(device="cuda").manual_seed(D + kind)
+    w0 = torch.randn(P, device=dev, generator=gen) * 0.1
+    wd, md, vd, gd = w0.clone(), torch.zeros_like(w0), torch.zeros_like(w0), torch.zeros_like(w0)
+    wl, ml, vl, gl = w0.clone(), torch.zeros_like(w0), torch.zeros_like(w0), torch.zeros_like(w0)
+    sd, sl = new_stats(lib, _lib, dev), new_stats(lib, _lib, dev)
+    lazy = Lazy(lib, _lib, wl, gl, ml if opt == "adam" else None, vl, U, I, D, kind, lr)
+    st = _lib.stream_ptr(dev)
+    rng = np.random.default_rng(D)
+
+    def flat_index(users, items):
+        rows = []
+        for u in users:
+            rows += list(range(u * D, (u + 1) * D)) + [(U + I) * D + u]
+        for i in items:
+            rows += list(range(U * D + i * D, U * D + (i + 1) * D)) + [(U + I) * D + U + i]
+        return torch.tensor(sorted(set(rows)), dtype=torch.int64, device=dev)
+
+    hot_u, hot_i = [0, 1], [0]
+    for t in range(1, T + 1):
+        users = set(hot_u) | set(rng.integers(2, 20, 2).tolist())
+        items = set(hot_i) | set(rng.integers(1, 12, 3).tolist())
+        if t in (3, 36):
+            users |= {40, 41}
+            items |= {25}          # touched twice, 33 steps apart
+        if t == 39:
+            users |= {45}          # first touch near the end
+        users, items = sorted(users), sorted(items)
+        # lists with duplicates and padding, spread over the four list kinds
+        lu = torch.tensor(users + users[:2] + [-1], dtype=torch.int64, device=dev)
+        la = torch.tensor(items[::2] + [-1, items[0]], dtype=torch.int64, device=dev)
+        lb = torch.tensor(items[1::2], dtype=torch.int64, device=dev)
+        lc = torch.tensor(items[:1] + [-1] + items[-1:], dtype=torch.int32, device=dev)
+        idx = flat_index(users, items)
+        lazy.catchup(sl, lu, la, lb, lc)
+        # what the step's gradient kernel reads: w (the moments are replayed by the step's update)
+        assert torch.equal(wl[idx], wd[idx]), f"step {t}: a caught-up row's weights differ from the dense sweeps'"
+        g = torch.zeros(P, device=dev)
+        g[idx] = torch.randn(idx.numel(), device=dev, generator=gen) * 0.01
+        g[-1] = float(rng.normal()) * 0.01
+        gd.copy_(g)
+        gl.copy_(g)
+        for stats in (sd, sl):
+            _lib.check(lib.hiprec_stats_advance_step(_lib.ptr(stats), st))
+        _lib.check(lib.hiprec_opt_dense_step(kind, _lib.ptr(wd), _lib.ptr(gd), _lib.ptr(md), _lib.ptr(vd), P, lr, 0.9, 0.999,
+                                             1e-8, _lib.ptr(sd), None, -1, st))
+        lazy.update(sl, lu, la, lb, lc)
+        assert torch.equal(wl[idx], wd[idx]) and torch.equal(vl[idx], vd[idx]) and torch.equal(ml[idx], md[idx]), \
+            f"step {t}: an updated row differs"
+        assert float(gl.abs().max()) == 0.0
+    # untouched rows lag behind until the flush
+    lag = flat_index([40], [25])
+    assert not torch.equal(vl[lag], vd[lag])
+    lazy.flush(sl)
+    assert torch.equal(wl, wd), f"w differs in {int((wl != wd).sum())} elements after the flush"
+    assert torch.equal(vl, vd) and (opt != "adam" or torch.equal(ml, md))
+    never_u, never_i = [48, 49], [28, 29]
+    assert all(int(lazy.stamp_u[u]) == -1 for u in never_u) and all(int(lazy.stamp_i[i]) == -1 for i in never_i)
+    assert int(lazy.stamp_u[40]) == T and int(lazy.stamp_i[25]) == T and int(lazy.stamp_u[0]) == T
+    assert torch.equal(wl[flat_index(never_u, never_i)], w0[flat_index(never_u, never_i)])
+    # a second flush has nothing to do
+    before = wl.clone()
+    lazy.flush(sl)
+    assert torch.equal(wl, before)
+
+
+def test_lazy_adam_beyond_the_scalars_table(hip_device):
+    """A table of 8 entries and 12 steps: bias corrections still move at step 8, so the update kernel must raise
+    HIPREC_STATUS_LAZY_TABLE instead of letting a later replay use the wrong scalars."""
+    from beta_recsys_amd import _lib
+    from beta_recsys_amd.mf import read_stats
+
+    lib, dev = _lib.load(), hip_device
+    U, I, D = 4, 4, 8
+    P = (U + I) * (D + 1) + 1
+    w, g, m, v = (torch.zeros(P, device=dev) for _ in range(4))
+    stats = new_stats(lib, _lib, dev)
+    lazy = Lazy(lib, _lib, w, g, m, v, U, I, D, 1, 0.05, cap=8)
+    lu = torch.tensor([0], dtype=torch.int64, device=dev)
+    for t in range(12):
+        _lib.check(lib.hiprec_stats_advance_step(_lib.ptr(stats), _lib.stream_ptr(dev)))
+        lazy.update(stats, lu, None, None, None)
+        assert bool(read_stats(stats).status & _lib.STATUS_LAZY_TABLE) == (t + 1 >= 8)
+
+
+def planned_epochs(hip_device, optimizer, lr, dense_opt, epochs=2, D=64, driver="c"):
+    import beta_recsys_amd as hp
+    from beta_recsys_amd.sharded import ShardedMFEngine
+
+    U, I, B = 3000, 400, 256
+    n = 4 * B + B // 3
+    w0 = onp.init_params(U, I, D, seed=3)
+    rng = np.random.default_rng(D)
+    p = 1.0 / np.arange(1, I + 1)
+    users, pos, neg = rng.integers(0, U // 3, n) * 3 % U, rng.choice(I, n, p=p / p.sum()), rng.integers(0, I, n)
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer=optimizer, lr=lr, batch_size=B,
+                         loss="bpr", step_driver=driver, dense_opt=dense_opt), "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = ShardedMFEngine(cfg, full_state={k: torch.from_numpy(v) for k, v in w0.items()})
+    assert (eng._lazy is not None) == (dense_opt == "lazy")
+    loader = hp.DeviceTripleBatcher(*(torch.from_numpy(a).cuda() for a in (users, pos, neg)), B, shuffle=False)
+    sums = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for e in range(epochs):
+            sums.append(eng.train_an_epoch(loader, e))
+    batches = [(users[k:k + B], pos[k:k + B], neg[k:k + B]) for _ in range(epochs) for k in range(0, n, B)]
+    full = {k: v.cpu().numpy() for k, v in eng.gather_full_state_dict().items()}
+    state = (eng.model.flat.clone(), eng.optimizer.exp_avg_sq.clone(),
+             None if eng.optimizer.exp_avg is None else eng.optimizer.exp_avg.clone())
+    return eng, w0, batches, sums, full, state
+
+
+@pytest.fixture(scope="module")
+def nccl_group(hip_device):
+    import socket
+
+    import torch.distributed as dist
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=hip_device)
+    yield
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("driver", ["c", "torch"])
+@pytest.mark.parametrize("optimizer,lr", [("adam", 0.05), ("rmsprop", 0.01)])
+def test_planned_epochs_with_lazy_state_follow_the_oracle_and_the_sweep(nccl_group, hip_device, optimizer, lr, driver):
+    """ShardedMFEngine with ``dense_opt: "lazy"`` (two planned epochs, a third of the users never drawn, Zipf items):
+    the loss sums and the gathered state_dict lie on the oracle's trajectory like the sweep's; against the same engine
+    with ``dense_opt: "sweep"`` the never-touched rows are bit-identical and the rest agrees to the accuracy atomics
+    leave (the two runs add their gradients in different orders)."""
+    eng, w0, batches, sums, full, state = planned_epochs(hip_device, optimizer, lr, "lazy", driver=driver)
+    assert eng._step_mode == driver
+    per_epoch = len(batches) // 2
+    w = onp.copy_params(w0)
+    st = onp.new_opt_state(w, optimizer)
+    for e in range(2):
+        tot_loss = tot_reg = 0.0
+        for batch in batches[e * per_epoch:(e + 1) * per_epoch]:
+            loss, reg = onp.mf_train_step(w, st, batch, "bpr", optimizer, lr)
+            tot_loss += loss
+            tot_reg += reg
+        assert_scalar_close(sums[e][0], tot_loss, 2e-5, f"epoch {e} loss sum")
+        assert_scalar_close(sums[e][1], tot_reg, 2e-5, f"epoch {e} regularizer sum")
+    w_ref, env, upd = mf_trajectory(w0, batches, optimizer, lr)
+    assert_on_trajectory(full, w_ref, env, upd, f"lazy {optimizer}, {driver} driver")
+    assert float(eng._g_flat.abs().max()) == 0.0, "every consumed gradient row is cleared"
+    assert not eng._lazy["dirty"], "the epoch ends with a flush"
+    # users = 3k only: two thirds of the user rows are never touched -> stamp -1, weights bit-identical to the start
+    su = eng._lazy["stamp_u"].cpu().numpy()
+    assert (su[1::3] == -1).all() and (su[2::3] == -1).all() and (su[::3] >= -1).all()
+    assert np.array_equal(full["user_emb.weight"][1::3], w0["user_emb.weight"][1::3])
+    _, _, _, sums_s, full_s, _ = planned_epochs(hip_device, optimizer, lr, "sweep", driver=driver)
+    for e in range(2):
+        assert_scalar_close(sums[e][0], sums_s[e][0], 1e-5, "lazy vs sweep epoch loss")
+    assert_on_trajectory(full_s, w_ref, env, upd, f"sweep {optimizer}")
+    for k in KEYS:
+        assert np.array_equal(full[k] == w0[k], full_s[k] == w0[k]), f"{k}: lazy and sweep moved different elements"
+
+
+def test_lazy_state_survives_a_dense_step_in_between(nccl_group, hip_device):
+    """A per-batch step (dense sweep) between two lazy planned epochs: the engine flushes before the sweep and marks
+    every touched row current after it; the trajectory stays the oracle's."""
+    eng, w0, batches, _, _, _ = planned_epochs(hip_device, "adam", 0.05, "lazy", epochs=1)
+    rng = np.random.default_rng(5)
+    extra = (rng.integers(0, 3000, 256), rng.integers(0, 400, 256), rng.integers(0, 400, 256))
+    eng.train_single_batch(tuple(torch.from_numpy(a) for a in extra))
+    clock = int(eng.step_count)
+    su = eng._lazy["stamp_u"].cpu().numpy()
+    assert set(np.unique(su)) == {clock}, "after a dense sweep every row is current as of the clock"
+    import beta_recsys_amd as hp
+
+    users, pos, neg = (np.concatenate([b[j] for b in batches]) for j in range(3))
+    loader = hp.DeviceTripleBatcher(*(torch.from_numpy(a).cuda() for a in (users, pos, neg)), 256, shuffle=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng.train_an_epoch(loader, 1)
+    full = {k: v.cpu().numpy() for k, v in eng.gather_full_state_dict().items()}
+    w_ref, env, upd = mf_trajectory(w0, batches + [extra] + batches, "adam", 0.05)
+    assert_on_trajectory(full, w_ref, env, upd, "lazy epochs around a dense step")
+
+
+def test_lazy_parity_against_the_ieee_arithmetic_build(hip_device):
+    """The bit-for-bit test again with libhiprec_ieee.so (ATen's correctly rounded sqrt / division): the replay uses
+    whatever arithmetic the sweep uses."""
+    from beta_recsys_amd import _lib
+
+    if os.environ.get("HIPREC_LIB", "").endswith("ieee.so"):
+        pytest.skip("already running against the IEEE build")
+    ieee = os.path.join(os.path.dirname(_lib.LIB_PATH), "libhiprec_ieee.so")
+    assert os.path.exists(ieee), "libhiprec_ieee.so is missing: run __graft_entry__.build()"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                          "bit_for_bit"], env=dict(os.environ, HIPREC_LIB="libhiprec_ieee.so"), capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout

@@ -129,3 +129,35 @@ def test_planned_sharded_epoch_on_thread_ranks_equals_single_process(optimizer, 
     for stats, full, _ in res:
         check_planned({"stats": stats, "full": full, "w0": w0, "local": [r[2] for r in res], "bs": bs}, n_local, bs,
                       optimizer, lr)
+
+
+def test_an_out_of_range_id_on_one_rank_raises_on_every_rank():
+    """the plan's status word is OR-ed over the group before the host looks at it -- every rank raises
+    IndexError between the same two collectives (a rank-local raise left the peers hanging in the next all-to-all),
+    the status is cleared and the engines plan the corrected epoch afterwards."""
+    import beta_recsys_amd as hp
+    from beta_recsys_amd.sharded import ShardedMFEngine
+    from test_sharded_gloo import OraclePlannedKernels, make_config
+
+    world, n_local, bs, U, I, D = 3, 20, 8, 37, 23, 8
+    w0 = onp.init_params(U, I, D, seed=7)
+
+    def rank_fn(group):
+        rank = group.rank()
+        rng = np.random.default_rng(50 + rank)
+        users, pos, neg = rng.integers(0, U, n_local), rng.integers(0, I, n_local), rng.integers(0, I, n_local)
+        with contextlib.redirect_stdout(io.StringIO()):
+            eng = ShardedMFEngine(make_config(U, I, D, "sgd", 0.1, "padded", "rows"), process_group=group,
+                                  kernels=OraclePlannedKernels(),
+                                  full_state={k: torch.from_numpy(v) for k, v in w0.items()})
+        bad = pos.copy()
+        if rank == 1:
+            bad[5] = I          # only rank 1 holds the bad id
+        loader = hp.DeviceTripleBatcher(*(torch.from_numpy(a) for a in (users, bad, neg)), bs, shuffle=False)
+        with pytest.raises(IndexError, match="item index"):
+            eng.plan_epoch(loader)
+        loader = hp.DeviceTripleBatcher(*(torch.from_numpy(a) for a in (users, pos, neg)), bs, shuffle=False)
+        return eng.run_planned_epoch(eng.plan_epoch(loader))
+
+    res = VirtualWorld(world, device="cpu", timeout=20.0).run(rank_fn)
+    assert all(np.isfinite(r[2]) for r in res)

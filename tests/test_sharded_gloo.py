@@ -453,6 +453,9 @@ class OraclePlannedKernels(OracleKernels):
             raise IndexError("index out of range in self")
         super().check_status()
 
+    def clear_status(self):
+        self.status = 0
+
     def plan_place_triples(self, recv, recv_cnt, S, cap):
         return tuple(torch.from_numpy(a) for a in ps.plan_place_triples(recv.numpy(), recv_cnt.numpy(), S, cap)) + (None,)
 

@@ -40,16 +40,18 @@ def local_triples(rank, world, U, I, n_local, idle_rank=None):
     return users, zipf(rng, I, n_local), rng.integers(0, I, n_local)
 
 
-def planned_rank(group, w0, U, I, D, n_local, bs, shuffle, optimizer, lr, driver, idle_rank, epochs=1, prefetch=False):
+def planned_rank(group, w0, U, I, D, n_local, bs, shuffle, optimizer, lr, driver, idle_rank, epochs=1, prefetch=False,
+                 dense_opt="sweep"):
     import beta_recsys_amd as hp
     from beta_recsys_amd.sharded import ShardedMFEngine
 
     rank, world = group.rank(), group.size()
     users, pos, neg = local_triples(rank, world, U, I, n_local, idle_rank)
     cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer=optimizer, lr=lr, batch_size=bs,
-                         loss="bpr", sgd_mode="rows", step_driver=driver), "system": RUN_DIR}
+                         loss="bpr", sgd_mode="rows", step_driver=driver, dense_opt=dense_opt), "system": RUN_DIR}
     with contextlib.redirect_stdout(io.StringIO()):
         eng = ShardedMFEngine(cfg, process_group=group, full_state={k: torch.from_numpy(v) for k, v in w0.items()})
+    assert (eng._lazy is not None) == (dense_opt == "lazy" and optimizer != "sgd")
     gen = torch.Generator().manual_seed(9 + rank) if shuffle else None
     loader = hp.DeviceTripleBatcher(*(torch.from_numpy(a).cuda() for a in (users, pos, neg)), bs, shuffle=shuffle,
                                     generator=gen)
@@ -140,6 +142,25 @@ def test_planned_steps_exchange_between_virtual_ranks(hip_device, world, D, bs, 
     check_planned(res, w0, n_local, bs, optimizer, lr)
 
 
+@pytest.mark.parametrize("world,optimizer,lr,driver", [(4, "adam", 0.05, "c"), (8, "rmsprop", 0.01, "c"),
+                                                       (2, "adam", 0.05, "torch")])
+def test_lazy_optimizer_state_between_virtual_ranks(hip_device, world, optimizer, lr, driver):
+    """Exact lazy Adam / RMSprop (csrc/lazy_opt.hip) on the row-sharded planned path with R > 1: every owner catches
+    the item rows its peers ask for up before it serves them, the user rows before the gradient kernel reads them, and
+    steps the step's rows when the exchanged gradients have arrived -- two epochs, one rank idle, against the oracle's
+    dense optimizer on the global batches."""
+    U, I, D, bs, epochs = 3001, 403, 64, 200, 2
+    n_local = 3 * bs + 31
+    w0 = onp.init_params(U, I, D, seed=3)
+    vw = VirtualWorld(world)
+    try:
+        res = vw.run(lambda g: planned_rank(g, w0, U, I, D, n_local, bs, True, optimizer, lr, driver, 1, epochs=epochs,
+                                            dense_opt="lazy"))
+    finally:
+        vw.close()
+    check_planned(res, w0, n_local, bs, optimizer, lr, epochs=epochs)
+
+
 @pytest.mark.parametrize("optimizer,lr", [("sgd", 0.05), ("adam", 0.05)])
 def test_planned_steps_through_the_torch_loop_between_virtual_ranks(hip_device, optimizer, lr):
     """The same epoch through the torch.distributed-shaped loop (``step_driver: "torch"``): the per-step launches the
@@ -228,6 +249,39 @@ def test_a_mis_sized_plan_fails_instead_of_hanging(hip_device, consistent):
             assert "which sends" in vw.last_error()
     finally:
         vw.close()
+
+
+def test_an_out_of_range_id_on_one_rank_raises_on_every_rank(hip_device):
+    """The planner kernels flag rank 2's bad item id in ITS status word; the word is OR-ed over the group, so all four
+    ranks raise IndexError between the same two collectives, and all four plan and run the corrected epoch."""
+    import beta_recsys_amd as hp
+    from beta_recsys_amd.sharded import ShardedMFEngine
+
+    world, U, I, D, bs = 4, 301, 97, 16, 64
+    w0 = onp.init_params(U, I, D, seed=3)
+
+    def rank_fn(group):
+        rank = group.rank()
+        users, pos, neg = local_triples(rank, world, U, I, 3 * bs)
+        cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer="sgd", lr=0.05,
+                             batch_size=bs, loss="bpr", sgd_mode="rows"), "system": RUN_DIR}
+        with contextlib.redirect_stdout(io.StringIO()):
+            eng = ShardedMFEngine(cfg, process_group=group, full_state={k: torch.from_numpy(v) for k, v in w0.items()})
+        bad = pos.copy()
+        if rank == 2:
+            bad[7] = I
+        loader = hp.DeviceTripleBatcher(*(torch.from_numpy(a).cuda() for a in (users, bad, neg)), bs, shuffle=False)
+        with pytest.raises(IndexError, match="item index"):
+            eng.plan_epoch(loader)
+        loader = hp.DeviceTripleBatcher(*(torch.from_numpy(a).cuda() for a in (users, pos, neg)), bs, shuffle=False)
+        return eng.run_planned_epoch(eng.plan_epoch(loader))
+
+    vw = VirtualWorld(world, timeout=20.0)
+    try:
+        res = vw.run(rank_fn)
+    finally:
+        vw.close()
+    assert all(np.isfinite(r[2]) for r in res)
 
 
 def dp_rank(group, w0, U, I, D, n_local, bs, optimizer, lr, epochs, collective="rccl"):

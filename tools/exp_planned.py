@@ -20,7 +20,9 @@ neg = torch.randint(0, I, (S * B,), generator=g).cuda()
 loader = hp.DeviceTripleBatcher(users, pos, neg, B)
 for opt, driver in [c.split(":") for c in os.environ.get("CASES", "sgd:c,sgd:torch,adam:c").split(",")]:
     cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer=opt, lr=0.05, batch_size=B,
-                         loss="bpr", sgd_mode="rows", shard_init="local", step_driver=driver), "system": {"run_dir": "/tmp/x"}}
+                         loss="bpr", sgd_mode="rows", shard_init="local", step_driver=driver,
+                         dense_opt=os.environ.get("DENSE_OPT", "auto"), lazy_flush=os.environ.get("LAZY_FLUSH", "epoch")),
+           "system": {"run_dir": "/tmp/x"}}
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
         eng = ShardedMFEngine(cfg)
@@ -32,12 +34,14 @@ for opt, driver in [c.split(":") for c in os.environ.get("CASES", "sgd:c,sgd:tor
     eng.run_planned_epoch(plan)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
-    for _ in range(3):
+    E = int(os.environ.get("EPOCHS", "3"))
+    for _ in range(E):
         eng.run_planned_epoch(plan, sync=False)
     e1.record(); torch.cuda.synchronize()
-    dt = e0.elapsed_time(e1) * 1e-3 / (3 * plan["S"])
+    dt = e0.elapsed_time(e1) * 1e-3 / (E * plan["S"])
     eng.k.check_status()
-    print(f"[{'full' if full else 'shard'}] {opt} / {driver}: plan {t_plan * 1e3:.2f} ms per {plan['S']} steps "
+    lazy = "" if opt == "sgd" else (" lazy" if eng._lazy is not None else " sweep")
+    print(f"[{'full' if full else 'shard'}] {opt}{lazy} / {driver}: plan {t_plan * 1e3:.2f} ms per {plan['S']} steps "
           f"({t_plan / plan['S'] * 1e6:.0f} us/step), step {dt * 1e6:.1f} us = {B / dt / 1e6:.0f} M triples/s; "
           f"slots/step {sum(plan['n_slots']) / plan['S']:.0f} of {2 * B} references, cap {plan['cap']}", file=sys.stderr)
     del eng, plan
