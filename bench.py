@@ -483,7 +483,8 @@ def bench_mf_c4_sharded(args, device, world, rank):
 
     Uc, Ic, Dc, Bc = 10_000_000, 1_000_000, 128, 65536
     cfg = {"model": dict(n_users=Uc, n_items=Ic, emb_dim=Dc, device_str=str(device), optimizer=args.c4_optimizer, lr=LR,
-                         batch_size=Bc, loss="bpr", sgd_mode="rows", shard_init="local", step_driver=args.step_driver),
+                         batch_size=Bc, loss="bpr", sgd_mode="rows", shard_init="local", step_driver=args.step_driver,
+                         dense_opt=args.dense_opt),
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -523,14 +524,25 @@ def bench_mf_c4_sharded(args, device, world, rank):
     if rank != 0:
         return None
     bpt = algorithmic_bytes_per_triple(Dc)
+    lazy = eng._lazy is not None
+    opt = args.c4_optimizer
+    # the reference's dense optimizer adds 28 P (Adam) / 20 P (RMSprop) bytes per step on this rank's P
+    # parameters.  The exact lazy form moves the step's rows instead: per touched row w, m, v read and written
+    # (RMSprop: w, v) on top of the gradient round trip the SGD figure already counts.
+    p_local = eng.model.flat.numel()
+    sweep_bytes = optimizer_sweep_bytes(opt, p_local)
+    row_bytes = {"sgd": 0, "adam": 3 * 6, "rmsprop": 3 * 4}[opt] * 4 * (Dc + 1)   # per triple: 3 rows
+    moved_bpt = bpt + (row_bytes if lazy else sweep_bytes / Bc)
     out = {"metric": "training interactions/sec (BPR triples)", "unit": "triples/s"}
     out.update(timing_fields(per, wall, steps, Bc, world))
     out.update({"n_gpus": world, "steps": steps, "warmup": warm, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "BPR-MF, BASELINE configs[3]: 10M x 1M rows, dim 128, batch 65536 triples/GPU, "
                                        "uniform users, Zipf(1.0) positives, " +
-                                       ("exact SGD on touched rows" if args.c4_optimizer == "sgd" else
-                                        f"dense {args.c4_optimizer} sweep of every shard per step"),
+                                       ("exact SGD on touched rows" if opt == "sgd" else
+                                        f"exact lazy {opt}: the step's rows are caught up / stepped, lagging rows replayed "
+                                        "bit-identically to the dense sweep, one flush per 50-step epoch inside the clock"
+                                        if lazy else f"dense {opt} sweep of every shard per step"),
                            "parallelism": f"tables row-sharded over {world} GPUs (owner = row mod {world}); the epoch is "
                                           "routed once by the planner kernels (triples -> owner(user), de-duplicated item "
                                           "requests -> owner(item)); per step 2 exact-size exchanges (rows out, gradients + "
@@ -540,9 +552,15 @@ def bench_mf_c4_sharded(args, device, world, rank):
                            "step_driver": eng._step_mode, "optimizer": args.c4_optimizer,
                            "global_batch": world * Bc, "rccl_world_size": world},
                 "roofline": {"bound": "hbm", "kernel": "whole sharded step (per GPU)",
-                             "achieved": out["value"] / world * bpt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": out["value"] / world * bpt / (HBM_PEAK_GBS * 1e9),
-                             "algorithmic_bytes_per_launch": bpt * Bc, "traffic": None}})
+                             "achieved": out["value"] / world * moved_bpt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": out["value"] / world * moved_bpt / (HBM_PEAK_GBS * 1e9),
+                             "algorithmic_bytes_per_launch": moved_bpt * Bc,
+                             "bytes_model": ("rows of the step: 24 + 24 (D+1) per triple" +
+                                             ("" if opt == "sgd" else
+                                              f" + {row_bytes} (w, m, v of its 3 rows read and written)" if lazy else
+                                              f" + the dense sweep's {sweep_bytes} per step")),
+                             # what SURVEY 8d prices the reference's dense optimizer at, for comparison
+                             "dense_sweep_bytes_per_launch": bpt * Bc + sweep_bytes, "traffic": None}})
     return out
 
 
@@ -1030,6 +1048,9 @@ def main():
                          "(all-to-all routing); auto = replicated below 64 MB of parameters")
     ap.add_argument("--c4-optimizer", default="sgd", choices=["sgd", "adam", "rmsprop"],
                     help="mf-c4 row-sharded: sgd (SURVEY 8d primary: exact scatter) or the dense optimizers (secondary)")
+    ap.add_argument("--dense-opt", default="auto", choices=["auto", "lazy", "sweep"],
+                    help="mf-c4 (sharded) with Adam / RMSprop: exact lazy replay of the step's rows (csrc/lazy_opt.hip) "
+                         "or the dense sweep of the whole shard every step")
     ap.add_argument("--step-driver", default="c", choices=["c", "torch"],
                     help="row-sharded planned steps: c = kernels and grouped ncclSend/ncclRecv enqueued by one C call "
                          "per range of steps; torch = torch.distributed.all_to_all_single between the launches")

@@ -86,8 +86,11 @@ def ngcf_forward(w, adj, masks=None, drop=None, dt=F32):
     return np.concatenate(outs, axis=1), cache
 
 
-def ngcf_grads(w, adj, users, pos, neg, decay, batch_size, masks=None, drop=None, dt=F32):
-    """zero_grad + forward + bpr_loss + backward of train_single_batch: (loss, grads)."""
+def ngcf_grads(w, adj, users, pos, neg, decay, batch_size, masks=None, drop=None, dt=F32, terms=None):
+    """zero_grad + forward + bpr_loss + backward of train_single_batch: (loss, grads).  ``terms`` (a dict, optional)
+    receives, per bias tensor, the largest column sum of the ABSOLUTE values its gradient adds up: a bias gradient is a
+    cancelling sum over all N nodes, and the rounding error of any summation order is relative to that magnitude, not
+    to the cancelled result (tests/helpers.py::grad_scale_floor makes the same point for MF's biases)."""
     L = n_layers_of(w)
     U = w["user_embedding.weight"].shape[0]
     F32 = dt  # noqa: N806
@@ -129,6 +132,9 @@ def ngcf_grads(w, adj, users, pos, neg, decay, batch_size, masks=None, drop=None
         g[f"GC_weights.{l}.bias"] = d_sum.sum(0, dtype=F32)
         g[f"Bi_weights.{l}.weight"] = (d_bi.T @ cch["bi_in"]).astype(F32)
         g[f"Bi_weights.{l}.bias"] = d_bi.sum(0, dtype=F32)
+        if terms is not None:
+            terms[f"GC_weights.{l}.bias"] = float(np.abs(d_sum).sum(0).max())
+            terms[f"Bi_weights.{l}.bias"] = float(np.abs(d_bi).sum(0).max())
         d_side = (d_sum @ w[f"GC_weights.{l}.weight"]).astype(F32)
         d_bi_in = (d_bi @ w[f"Bi_weights.{l}.weight"]).astype(F32)
         d_ego = (d_bi_in * cch["side"]).astype(F32)

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from helpers import REL, assert_sgd_exact  # noqa: F401  (north_star: 1e-5 relative)
 from helpers import assert_scalar_close, assert_step_close, assert_tensor_close, load_golden
 from oracle import pgmf_numpy as onp
 from test_oracle_golden_pgmf import CASES, KEYS, pgmf_band, pgmf_opt_state, pgmf_params
@@ -85,7 +86,8 @@ def test_step_matches_reference(hip_device, case):
                 continue
             got = {k: v.cpu().numpy() for k, v in eng.model.views(views[name]).items()}
             for k in KEYS:
-                assert_tensor_close(got[k], nxt[ref_name][k], 4e-5, f"{name} {k} step {s}")
+                assert_tensor_close(got[k], nxt[ref_name][k], REL if name == "exp_avg" else 2 * REL,
+                                    f"{name} {k} step {s}")   # linear / quadratic in the gradient
         assert float(eng._g_flat.abs().max()) == 0.0, "the optimizer sweep leaves the gradient cleared"
 
 
@@ -97,10 +99,10 @@ def test_trajectory_matches_reference(hip_device):
     load_weights(eng, pgmf_params(g, "w0"))
     for s in range(n_steps):
         loss = eng.train_single_batch((g["users"][s], g["pos"][s], g["neg"][s]))
-        assert_scalar_close(loss, g["losses"][s], 5e-5, what=f"loss step {s}")
+        assert_scalar_close(loss, g["losses"][s], REL, what=f"loss step {s}")
     w = get_weights(eng)
-    for k in KEYS:
-        assert_tensor_close(w[k], g[f"w{n_steps}/{k}"], 5e-5, what=f"final {k}")
+    # plain SGD has no conditioning problem: every element within 1e-5 of the trajectory's total update (+ 4 ulp)
+    assert_sgd_exact(w, pgmf_params(g, f"w{n_steps}"), pgmf_params(g, "w0"), "final weights")
 
 
 def test_forward_scores(hip_device):
@@ -242,9 +244,9 @@ def test_train_an_epoch_uses_cmn_loader(hip_device):
     assert loader.calls == [(B, False, 4)]
     tag, total, epoch = eng.writer.scalars[-1]
     assert (tag, epoch) == ("model/loss", 3)
-    assert_scalar_close(total, sum(ref), 2e-5, "epoch loss sum")
+    assert_scalar_close(total, sum(ref), REL, "epoch loss sum")
     printed = float(out.getvalue().strip().rsplit("Loss ", 1)[1])
-    assert_scalar_close(printed, ref[-1], 2e-5, "printed last loss")
+    assert_scalar_close(printed, ref[-1], REL, "printed last loss")
     # every element inside the legal-trajectory envelope (oracle runs with each gradient moved by 1e-5 of its scale
     # BEFORE the clip, as an implementation's own gradient would be)
     from helpers import assert_on_trajectory, oracle_trajectory

@@ -11,6 +11,7 @@ import pytest
 import torch
 import torch.distributed as dist
 
+from helpers import REL  # noqa: F401  (north_star: 1e-5 relative)
 from helpers import KEYS, assert_mf_end_state, assert_ncf_end_state, assert_scalar_close
 from oracle import mf_numpy as onp
 
@@ -52,8 +53,8 @@ def test_sharded_step_with_hip_kernels(nccl_group, optimizer, lr, routing, sgd_m
         batches.append(batch)
         loss, reg = eng.train_single_batch(tuple(torch.from_numpy(a) for a in batch))
         ref_loss, ref_reg = onp.mf_train_step(w, st, batch, "bpr", optimizer, lr)
-        assert_scalar_close(loss, ref_loss, 2e-5, "loss")
-        assert_scalar_close(reg, ref_reg, 2e-5, "reg")
+        assert_scalar_close(loss, ref_loss, REL, "loss")
+        assert_scalar_close(reg, ref_reg, REL, "reg")
     full = {k: v.cpu().numpy() for k, v in eng.gather_full_state_dict().items()}
     assert_mf_end_state(full, w0, batches, optimizer, lr, f"{routing} routing")
 
@@ -81,8 +82,8 @@ def test_replicated_engine_with_hip_kernels(nccl_group, optimizer, lr):
         batches.append(tuple(torch.from_numpy(a) for a in batch))
         loss, reg = eng.train_single_batch(batches[-1])
         ref_loss, ref_reg = onp.mf_train_step(w, st, batch, "bpr", optimizer, lr)
-        assert_scalar_close(loss, ref_loss, 2e-5, "loss")
-        assert_scalar_close(reg, ref_reg, 2e-5, "reg")
+        assert_scalar_close(loss, ref_loss, REL, "loss")
+        assert_scalar_close(reg, ref_reg, REL, "reg")
     got = {k: v.cpu().numpy() for k, v in eng.model.state_dict().items()}
     assert_mf_end_state(got, w0, np_batches, optimizer, lr, "replicated steps")
     with contextlib.redirect_stdout(io.StringIO()):
@@ -147,7 +148,7 @@ def test_replicated_fused_epoch_with_hip_kernels(nccl_group, optimizer, lr):
             total += loss
         eng.fused_epoch_end()
         stats = eng.epoch_stats()
-        assert_scalar_close(stats.loss_sum, total, 2e-5, f"epoch {epoch} loss sum")
+        assert_scalar_close(stats.loss_sum, total, REL, f"epoch {epoch} loss sum")
         # every rotating gradient buffer is clean again
         assert all(float(b[eng._scratch.numel() // 4:].abs().max()) == 0.0 for b in eng._fe["bufs"])
     assert eng.epoch_stats().step == 7
@@ -157,7 +158,7 @@ def test_replicated_fused_epoch_with_hip_kernels(nccl_group, optimizer, lr):
     batch = tuple(torch.from_numpy(rng.integers(0, n, B)) for n in (U, I, I))
     loss, _ = eng.train_single_batch(batch)
     ref_loss, _ = onp.mf_train_step(w, st, tuple(t.numpy() for t in batch), "bpr", optimizer, lr)
-    assert_scalar_close(loss, ref_loss, 1e-4, "loss after the fused epochs")
+    assert_scalar_close(loss, ref_loss, REL, "loss after the fused epochs")
 
 
 def test_replicated_train_an_epoch_takes_the_fused_path_for_resident_loaders(nccl_group):
@@ -224,7 +225,7 @@ def test_replicated_epoch_driver_calls_rccl_itself(nccl_group, optimizer):
         assert eng.epoch_stats().step == 18
         out[mode] = (sums, {k: v.cpu().numpy() for k, v in eng.model.state_dict().items()}, w_start, visited)
     for a, b in zip(out["rccl"][0], out["torch"][0]):
-        assert_scalar_close(a, b, 2e-5, "epoch loss sums of the two drivers")
+        assert_scalar_close(a, b, REL, "epoch loss sums of the two drivers")
     # both drivers ran the same three epochs (same shuffle seeds): both end states lie on the oracle's trajectory
     for mode in ("rccl", "torch"):
         assert_mf_end_state(out[mode][1], out[mode][2], out[mode][3], optimizer, 0.02, f"{mode} driver")
@@ -256,7 +257,7 @@ def test_replicated_ncf_engine_with_hip_kernels(nccl_group):
         batches.append((users, items, ratings))
         loss = eng.train_single_batch(torch.from_numpy(users), torch.from_numpy(items), torch.from_numpy(ratings))
         ref = onc.ncf_train_step(w, st, (users, items, ratings), "neumf", "adam", 1e-3)
-        assert_scalar_close(loss, ref, 2e-5, "loss")
+        assert_scalar_close(loss, ref, REL, "loss")
     got = {k: v.cpu().numpy() for k, v in eng.model.state_dict().items()}
     assert_ncf_end_state(got, w_start, batches, "neumf", "adam", 1e-3, "replicated NeuMF")
 
@@ -292,7 +293,7 @@ def test_sharded_ncf_engine_with_hip_kernels(nccl_group, kind, emb):
         batches.append((users, items, ratings))
         loss = eng.train_single_batch(users, items, ratings)
         ref = onc.ncf_train_step(w, st, (users, items, ratings), kind, "adam", 0.01)
-        assert_scalar_close(loss, ref, 2e-5, "loss")
+        assert_scalar_close(loss, ref, REL, "loss")
     out = {k: v.cpu().numpy() for k, v in eng.gather_full_state_dict().items()}
     assert set(out) == set(w) and all(out[k].shape == w[k].shape for k in w)
     assert_ncf_end_state(out, w_start, batches, kind, "adam", 0.01, f"sharded {kind}")
@@ -339,8 +340,8 @@ def test_planned_sharded_epoch_with_hip_kernels(nccl_group, D, B, shuffle, optim
         loss, reg = onp.mf_train_step(w, st, batch, "bpr", optimizer, lr)
         ref_loss += loss
         ref_reg += reg
-    assert_scalar_close(total_loss, ref_loss, 2e-5, "epoch loss sum")
-    assert_scalar_close(total_reg, ref_reg, 2e-5, "epoch regularizer sum")
+    assert_scalar_close(total_loss, ref_loss, REL, "epoch loss sum")
+    assert_scalar_close(total_reg, ref_reg, REL, "epoch regularizer sum")
     full = {k: v.cpu().numpy() for k, v in eng.gather_full_state_dict().items()}
     if optimizer == "sgd":
         assert_sgd_exact(full, w, w0, "planned epoch", lr=lr, batch=B)
@@ -403,7 +404,7 @@ def test_planned_epochs_with_the_plan_prefetched_on_a_side_stream(nccl_group):
             sums.append(eng.k.epoch_stats()[2])
         results[mode] = (sums, {k: v.cpu().numpy() for k, v in eng.gather_full_state_dict().items()})
     for a, b in zip(*[results[m][0] for m in ("prefetch", "sync")]):
-        assert_scalar_close(a, b, 2e-5, "epoch loss sums")
+        assert_scalar_close(a, b, REL, "epoch loss sums")
     for k in KEYS:
         a, b = results["prefetch"][1][k], results["sync"][1][k]
         assert np.abs(a - b).max() <= 1e-5 * max(np.abs(b - w0[k]).max(), 1e-6) + 4 * 1.2e-7 * np.abs(b).max(), k
@@ -500,7 +501,7 @@ def test_planned_sharded_epoch_on_the_whole_configs3_table(nccl_group):
         ref_loss += loss
         ref_reg += reg
     assert_scalar_close(total_loss, ref_loss, 1e-5, "epoch loss sum vs the oracle on the compacted problem")
-    assert_scalar_close(total_reg, ref_reg, 2e-5, "epoch regularizer sum")
+    assert_scalar_close(total_reg, ref_reg, REL, "epoch regularizer sum")
     ue, ie, ub, ib, gb = m._views(m.flat)
     got = {"user_emb.weight": ue[tu].cpu().numpy(), "item_emb.weight": ie[ti].cpu().numpy(),
            "user_bias.weight": ub[tu].cpu().numpy(), "item_bias.weight": ib[ti].cpu().numpy(),

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from helpers import REL, assert_sgd_exact  # noqa: F401  (north_star: 1e-5 relative)
 from helpers import assert_scalar_close, assert_step_close, assert_tensor_close, load_golden
 from oracle import triple2vec_numpy as onp
 from test_oracle_golden_t2v import CASES, KEYS, bias_floor, t2v_band, t2v_batch, t2v_opt_state, t2v_params
@@ -84,7 +85,9 @@ def test_step_matches_reference(hip_device, case):
             got = {k: v.cpu().numpy() for k, v in eng.model.views(buf).items()}
             for k in KEYS:
                 floor = bias_floor(k, scale)
-                assert_tensor_close(got[k], nxt[ref_name][k], 4e-5, f"{name} {k} step {s}",
+                # the gradient itself is held to 2e-5 here (see below: sums of B * n_neg terms per row); exp_avg is
+                # linear in it, the second moments quadratic
+                assert_tensor_close(got[k], nxt[ref_name][k], 2e-5 if name == "exp_avg" else 4e-5, f"{name} {k} step {s}",
                                     scale_floor=floor if name == "exp_avg" else floor ** 2)
         assert float(eng._g_flat.abs().max()) == 0.0
     # predict on the reference's final weights
@@ -103,11 +106,11 @@ def test_first_forward_aliases_item_emb2_like_the_reference(hip_device):
     assert not eng.model.shared_items
     for s in range(n_steps):
         loss = eng.train_single_batch(t2v_batch(g, s))
-        assert_scalar_close(loss, g["losses"][s], 5e-5, what=f"loss step {s}")
+        assert_scalar_close(loss, g["losses"][s], REL, what=f"loss step {s}")
     assert eng.model.shared_items
     w = get_weights(eng)
-    for k in KEYS:
-        assert_tensor_close(w[k], g[f"w{n_steps}/{k}"], 5e-5, what=f"final {k}")
+    # plain SGD has no conditioning problem: every element within 1e-5 of the trajectory's total update (+ 4 ulp)
+    assert_sgd_exact(w, t2v_params(g, f"w{n_steps}"), t2v_params(g, "w0"), "final weights")
     # Triple2vec.forward returns the batch loss without touching the weights
     loss = eng.model(t2v_batch(g, 0))
     assert loss.dim() == 0 and loss.device.type == "cuda"
@@ -269,8 +272,8 @@ def test_train_an_epoch(hip_device, sampler):
                  Data.item_sampler.log[2 * b + 1])
         np_batches.append(batch)
         ref.append(onp.t2v_train_step(w, st, batch, B, "adam", 1e-2))
-    assert_scalar_close(total, sum(ref), 2e-5, "epoch loss sum")
-    assert_scalar_close(printed, ref[-1], 2e-5, "printed last loss")
+    assert_scalar_close(total, sum(ref), REL, "epoch loss sum")
+    assert_scalar_close(printed, ref[-1], REL, "printed last loss")
     # every element inside the legal-trajectory envelope (helpers.oracle_trajectory)
     from helpers import assert_on_trajectory, oracle_trajectory
 
