@@ -48,7 +48,7 @@ LR = 0.05
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec peak)
 MIN_TIMED_STEPS, MIN_REPEATS = 200, 5
 EPOCH_STEPS = 245  # N = 1 000 000 triples per epoch -> 245 batches of 4096 (1 003 520 triples)
-ROUND = "r03"
+ROUND = "r04"
 
 
 def algorithmic_bytes_per_triple(dim):
@@ -338,6 +338,7 @@ def bench_ncf(args, device, world=1, rank=0, dist_on=False):
                              "note": "whole step (all launches) against the dense fp32 MFMA peak; traffic = HBM bytes of "
                                      "the step's launches from the committed PMC passes",
                              "traffic": traffic, "traffic_source": traffic_src}})
+    out["roofline"].update(dominant_kernel_from_profiles("ncf" if E == 32 else "ncf64"))
     if not args.no_cpu_baseline and world == 1:
         from oracle.torch_port import TorchNeuMFPort   # the reference's ATen op sequence (ncf.py:52-71, 100-120)
 
@@ -650,6 +651,7 @@ def bench_lightgcn(args, device, world=1, rank=0, dist_on=False):
                              "achieved": bytes_step / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": bytes_step / step_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                              "traffic_source": traffic_src}})
+    out["roofline"].update(dominant_kernel_from_profiles("lightgcn"))
     if not args.no_cpu_baseline and world == 1:
         from oracle.torch_port import TorchLightGCNPort   # torch.sparse.mm, lightgcn.py:46-78, 119-152
 
@@ -821,6 +823,7 @@ def bench_ngcf(args, device):
                         "gemm_tflops": flops / (dt / args.steps) / 1e12,
                         "note": "whole step (~35 launches); full-graph propagation per step like the reference"}}
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = traffic_step_from_profiles("ngcf")
+    out["roofline"].update(dominant_kernel_from_profiles("ngcf"))
     if not args.no_cpu_baseline:
         from oracle import torch_port
 
@@ -852,6 +855,27 @@ def traffic_from_profiles(kernel, workload=None):
         except Exception:
             continue
     return None, None
+
+
+def dominant_kernel_from_profiles(workload):
+    """The kernel a workload spends most of its GPU time in, with its average launch duration, from the COMMITTED
+    `rocprofv3 --kernel-trace --stats` summary of the same bench command (profiles/rNN_kernel_stats_<workload>.csv:
+    rows sorted by total duration): {"kernel", "kernel_us", "kernel_share_pct", "kernel_us_source"} (empty when no
+    summary is there yet).  Not measured in this run -- the step is timed live, its kernels by the profiler."""
+    import csv
+
+    for rnd in (ROUND, "r03"):
+        name = f"{rnd}_kernel_stats_{workload}.csv"
+        try:
+            with open(os.path.join(ROOT, "profiles", name), newline="") as f:
+                rows = [r for r in csv.DictReader(f) if "hiprec::" in r["Name"]]
+            top = rows[0]
+            return {"kernel": top["Name"].split("(")[0].replace("void ", "").strip(),
+                    "kernel_us": float(top["AverageNs"]) / 1e3, "kernel_calls": int(top["Calls"]),
+                    "kernel_share_pct": float(top["Percentage"]), "kernel_us_source": "profiles/" + name}
+        except Exception:
+            continue
+    return {}
 
 
 def traffic_step_from_profiles(workload):

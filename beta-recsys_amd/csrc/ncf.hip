@@ -1340,11 +1340,17 @@ static int ncf_grad_impl(const hiprec_ncf_plan* plan, const int64_t* users, cons
   const hiprec_ncf_plan* p = plan;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int B = static_cast<int>(batch);
-  // HIPREC_NCF_BACKWARD (A/B switch, tests): "unfused" = one grouped launch per layer + scatter, "split" = the
-  // chain in its own launch after the forward; default: forward + chain in one launch
+  // The default is forward + chain in one launch; the two older forms it falls back to for shapes outside the fused
+  // limits -- "unfused" = one grouped launch per layer + scatter, "split" = the chain in its own launch after the
+  // forward -- can be FORCED through HIPREC_NCF_BACKWARD only in the test build (-DHIPREC_TEST_SWITCHES,
+  // libhiprec_test.so); the product library reads no environment variable.
+#ifdef HIPREC_TEST_SWITCHES
   static const char* bwd_env = getenv("HIPREC_NCF_BACKWARD");
   static const bool no_fused_bwd = bwd_env && strcmp(bwd_env, "unfused") == 0;
   static const bool split_bwd = bwd_env && strcmp(bwd_env, "split") == 0;
+#else
+  constexpr bool no_fused_bwd = false, split_bwd = false;
+#endif
   const bool group_ok = !no_fused_bwd && 2 * p->n_layers <= kMaxGroup;  // one grouped launch for all weight gradients
   const bool fuse_bwd = group_ok && (fusable(p, true) || fusable_narrow(p));
   bool scored = false, chained = false;

@@ -611,7 +611,11 @@ inline int ngcf_forward(const hiprec_ngcf_plan* p, bool train, hipStream_t st) {
     uint8_t* keep = train ? p->keep[l] : nullptr;
     const KeepGen gen{p->keep_gen, p->keep_prob[l], p->keep_seed * 64 + static_cast<uint64_t>(l), p->keep_step};
     const SlicedOut next_src = sliced && l + 1 < p->n_layers ? ngcf_sliced_out(p, &p->sa) : SlicedOut{};
-    static const bool unfused_hop = getenv("HIPREC_NGCF_UNFUSED_HOP") != nullptr;  // A/B switch, tests
+#ifdef HIPREC_TEST_SWITCHES   // A/B switch of the test build only (libhiprec_test.so); the product reads no environment
+    static const bool unfused_hop = getenv("HIPREC_NGCF_UNFUSED_HOP") != nullptr;
+#else
+    constexpr bool unfused_hop = false;
+#endif
     if (!unfused_hop && di <= kHopMaxIn && di % 4 == 0 && dout <= kHopMaxOut && dout % 16 == 0) {
       // bi = ego * side, both Linear layers, activation, dropout, norm: one launch, 16 node rows per workgroup
       const size_t lds = sizeof(float) * hop_lds_floats(di, dout);
@@ -698,7 +702,11 @@ extern "C" int hiprec_ngcf_grad(const hiprec_ngcf_plan* plan, const int64_t* use
   const float* d_next = nullptr;
   // per-hop d_sum / d_bi (optional workspaces) let the hop's backward chain ride one launch and ALL weight / bias
   // gradients one grouped launch at the end
+#ifdef HIPREC_TEST_SWITCHES
   static const bool unfused_bwd = getenv("HIPREC_NGCF_UNFUSED_HOP") != nullptr;
+#else
+  constexpr bool unfused_bwd = false;
+#endif
   bool hop_bwd = !unfused_bwd && 4 * p->n_layers <= kMaxGroup;
   for (int l = 0; l < p->n_layers; ++l)
     hop_bwd = hop_bwd && p->d_sum_l[l] && p->d_bi_l[l] && p->dim[l] <= kHopBwdMax && p->dim[l] % 16 == 0 &&

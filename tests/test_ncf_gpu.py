@@ -307,7 +307,8 @@ def test_older_backward_forms_stay_correct(hip_device, mode):
     """hiprec_ncf_grad's default is ONE launch for forward + head + input-gradient chain + scatter.  The two older
     forms it falls back to -- the chain in a launch of its own (forward on the launch-per-layer path: batch beyond
     32 768), one grouped launch per layer + scatter (shapes outside the fused limits) -- are selected here through
-    HIPREC_NCF_BACKWARD (read once per process: a fresh interpreter) and run the step / dropout / full-size tests."""
+    HIPREC_NCF_BACKWARD, which only libhiprec_test.so (-DHIPREC_TEST_SWITCHES) reads (once per process: a fresh
+    interpreter), and run the step / dropout / full-size tests."""
     import os
     import subprocess
     import sys
@@ -318,6 +319,7 @@ def test_older_backward_forms_stay_correct(hip_device, mode):
     out = subprocess.run(
         [sys.executable, "-m", "pytest", os.path.join(here, "test_ncf_gpu.py"), "-m", "gpu", "-x", "-q", "-k",
          "not older_backward_forms"],
-        env=dict(os.environ, HIPREC_NCF_BACKWARD=mode), capture_output=True, text=True, timeout=900)
+        env=dict(os.environ, HIPREC_NCF_BACKWARD=mode, HIPREC_LIB="libhiprec_test.so"), capture_output=True, text=True,
+        timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout

@@ -1,7 +1,7 @@
-# Refresh the judged evidence on a GPU box: bash tools/refresh_profiles.sh [round tag, default r03]
+# Refresh the judged evidence on a GPU box: bash tools/refresh_profiles.sh [round tag, default r04]
 # bench JSON lines, rocprofv3 kernel-trace stats and FETCH_SIZE / WRITE_SIZE passes, all under gpurun_out/<tag>/;
 # tools/collect_profiles.py copies the summaries into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
@@ -17,6 +17,7 @@ prof adam --steps 500 --warmup 50
 prof adam_20 --steps 20 --warmup 5
 prof sgd --optimizer sgd --steps 500 --warmup 50
 prof mf-c4shard --workload mf-c4shard --steps 50 --warmup 5
+prof mf-c4 --workload mf-c4 --steps 50 --warmup 5
 prof ncf --workload ncf --steps 100 --warmup 10
 prof ncf64 --workload ncf --emb-dim 64 --steps 100 --warmup 10
 prof lightgcn --workload lightgcn --steps 100 --warmup 10
@@ -45,10 +46,11 @@ for o in sgd rmsprop; do
   timeout 200 python bench.py --optimizer $o --no-cpu-baseline > $OUT/bench_$o.json 2> $OUT/bench_$o.err
 done
 timeout 300 python bench.py --workload ncf > $OUT/bench_ncf.json 2> $OUT/bench_ncf.err
-timeout 300 python bench.py --workload ncf --emb-dim 64 --no-cpu-baseline > $OUT/bench_ncf64.json 2> $OUT/bench_ncf64.err
+timeout 300 python bench.py --workload ncf --emb-dim 64 > $OUT/bench_ncf64.json 2> $OUT/bench_ncf64.err
 timeout 300 python bench.py --workload lightgcn > $OUT/bench_lightgcn.json 2> $OUT/bench_lightgcn.err
 timeout 400 python bench.py --workload mf-c4shard > $OUT/bench_mf-c4shard.json 2> $OUT/bench_mf-c4shard.err
-for w in mf-c4 pgmf t2v ngcf; do
+timeout 500 python bench.py --workload mf-c4 > $OUT/bench_mf-c4.json 2> $OUT/bench_mf-c4.err
+for w in pgmf t2v ngcf; do
   timeout 300 python bench.py --workload $w --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err
 done
 timeout 300 python bench.py --workload mf-c4shard --sgd-mode rows --no-cpu-baseline > $OUT/bench_mf-c4shard_rows.json 2> /dev/null
@@ -58,15 +60,25 @@ HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --no-cpu-baseline --ste
 HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload mf-c4 --no-cpu-baseline --steps 50 2> /dev/null | grep metric > $OUT/bench_mf-c4_sharded_w1.json
 HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload mf-c4 --no-cpu-baseline --steps 20 --warmup 5 2> /dev/null | grep metric > $OUT/bench_mf-c4_sharded_w1_20.json
 HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload mf-c4 --no-cpu-baseline --steps 50 --step-driver torch 2> /dev/null | grep metric > $OUT/bench_mf-c4_sharded_w1_torch.json
+# configs[3] with the dense optimizers at world 1: the exact lazy form (csrc/lazy_opt.hip) and the dense sweep it replaces
+for o in adam rmsprop; do
+  HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload mf-c4 --no-cpu-baseline --steps 50 --c4-optimizer $o 2> /dev/null | grep metric > $OUT/bench_mf-c4_sharded_w1_$o.json
+done
+HIPREC_BENCH_FORCE_SHARDED=1 timeout 400 python bench.py --workload mf-c4 --no-cpu-baseline --steps 20 --warmup 2 --c4-optimizer adam --dense-opt sweep 2> /dev/null | grep metric > $OUT/bench_mf-c4_sharded_w1_adam_sweep.json
 HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload lightgcn --no-cpu-baseline --steps 100 --warmup 10 2> /dev/null | grep metric > $OUT/bench_lightgcn_dp_w1.json
 HIPREC_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --workload ncf --no-cpu-baseline --steps 100 --warmup 10 2> /dev/null | grep metric > $OUT/bench_ncf_dp_w1.json
 CASES=sgd:c,sgd:torch,adam:c timeout 300 python tools/exp_planned.py 2>&1 | grep "\]" > $OUT/exp_planned.txt
 SIZE=full CASES=sgd:c,sgd:torch timeout 300 python tools/exp_planned.py 2>&1 | grep "\]" >> $OUT/exp_planned.txt
+for sz in shard full; do for d in lazy sweep; do
+  SIZE=$sz DENSE_OPT=$d CASES=adam:c,rmsprop:c EPOCHS=4 timeout 300 python tools/exp_planned.py 2>&1 | grep "\]" >> $OUT/exp_planned.txt
+done; done
 cd /tmp && export TMPDIR=/tmp
 # the planner and the planned sharded step (world 1)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_plan -o mf -- \
   python $GRAFT_REPO_ROOT/tools/exp_plan_cost.py > $OUT/prof_plan.log 2>&1
 SIZE=shard CASES=sgd:c timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_planned -o mf -- \
   python $GRAFT_REPO_ROOT/tools/exp_planned.py > $OUT/prof_planned.log 2>&1
+SIZE=shard DENSE_OPT=lazy CASES=adam:c EPOCHS=4 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_planned_lazy_adam -o mf -- \
+  python $GRAFT_REPO_ROOT/tools/exp_planned.py > $OUT/prof_planned_lazy_adam.log 2>&1
 cd $GRAFT_REPO_ROOT && timeout 200 python tools/exp_spmm_sliced.py 2>&1 | grep -v amdgpu.ids > $OUT/exp_spmm_sliced.txt
 ls $OUT | head -80
