@@ -363,9 +363,10 @@ def bench_mf_c4shard(args, device, full=False):
     from beta_recsys_amd import _lib
 
     Uc, Ic, Dc, Bc = (10_000_000, 1_000_000, 128, 65536) if full else (1_250_000, 125_000, 128, 65536)
-    owned = args.sgd_mode == "owned"
-    cfg = {"model": dict(n_users=Uc, n_items=Ic, emb_dim=Dc, device_str=str(device), optimizer="sgd",
-                         lr=LR, batch_size=Bc, loss="bpr", sgd_mode=args.sgd_mode),
+    c4opt = args.c4_optimizer                 # sgd (primary) | adam | rmsprop (dense-Adam secondary)
+    owned = args.sgd_mode == "owned" and c4opt == "sgd"
+    cfg = {"model": dict(n_users=Uc, n_items=Ic, emb_dim=Dc, device_str=str(device), optimizer=c4opt,
+                         lr=LR, batch_size=Bc, loss="bpr", sgd_mode=args.sgd_mode, dense_opt=args.dense_opt),
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -436,14 +437,22 @@ def bench_mf_c4shard(args, device, full=False):
         torch.cuda.synchronize()
         kname, k_s = "mf_bpr_grad_kernel<2>", a.elapsed_time(b) / 50 * 1e-3
         traffic, traffic_src = (None, None) if full else traffic_from_profiles("hiprec::mf_bpr_grad_kernel<2>", "mf-c4shard")
+        if c4opt != "sgd":      # the timed calls advanced the optimizer clock and left a gradient behind
+            eng._g_flat.zero_()
+            eng._lazy_mark_current()
     out = {"metric": "training interactions/sec (BPR triples)", "unit": "triples/s"}
     out.update(timing_fields(per, wall, steps, Bc))
     out.update({"n_gpus": 1, "steps": steps, "warmup": warm,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": ("BPR-MF, BASELINE configs[3] whole on one GPU: 10M x 1M rows, dim 128, batch "
-                                        "65536, plain SGD" if full else
+                                        "65536, " if full else
                                         "BPR-MF, one rank's shard of BASELINE configs[3]: 1.25M x 125k rows, dim 128, "
-                                        "batch 65536, plain SGD (no exchange timed)"),
+                                        "batch 65536 (no exchange timed), ") +
+                                       ("plain SGD" if c4opt == "sgd" else
+                                        f"{c4opt}, " + ("exact lazy replay (csrc/lazy_opt.hip): catch-up + gradient kernel + "
+                                                        "update of the batch's rows per step, one flush per epoch"
+                                                        if eng._lazy is not None else "dense sweep every step")),
+                           "optimizer": c4opt,
                            "sgd_mode": args.sgd_mode,
                            "epoch": f"{epoch_steps} steps = {n_total} triples",
                            "timed_region": "continuous training; per epoch one staging pass (device shuffle, per-batch "
@@ -470,8 +479,8 @@ def bench_mf_c4shard(args, device, full=False):
         cu, cp, cn = (t[: 4 * Bc].cpu() for t in (users, pos, neg))
         batches = [(cu[k * Bc:(k + 1) * Bc], cp[k * Bc:(k + 1) * Bc], cn[k * Bc:(k + 1) * Bc]) for k in range(4)]
         nt = min(32, torch.get_num_threads())
-        out["cpu_baseline"] = port_baseline(lambda: TorchMFPort(w0, "sgd", LR, "bpr"), batches, Bc,
-                                            f"BPR-MF {Uc} x {Ic} x {Dc}, batch {Bc}, torch.optim.SGD over dense gradients",
+        out["cpu_baseline"] = port_baseline(lambda: TorchMFPort(w0, c4opt, LR, "bpr"), batches, Bc,
+                                            f"BPR-MF {Uc} x {Ic} x {Dc}, batch {Bc}, torch.optim ({c4opt}) over dense gradients",
                                             budget_s=10.0, thread_counts=[nt])
     return out
 

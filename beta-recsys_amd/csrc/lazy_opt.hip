@@ -24,6 +24,8 @@
 // The lists name a step's rows with duplicates (a user that occurs twice, an item several peers ask for); the first
 // wave to raise the row's stamp (atomicMax) owns it for that launch, the others skip.  One wave per list entry,
 // lane = column (+ kWave * j), the row's bias element rides in lane 0.
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace hiprec {
@@ -284,3 +286,34 @@ extern "C" int hiprec_lazy_mark_current(const hiprec_lazy_state* state, const hi
 }
 
 extern "C" size_t hiprec_lazy_state_bytes(void) { return sizeof(hiprec_lazy_state); }
+
+// MFEngine.train_an_epoch (mf.py:121-139) over a staged epoch with the exact lazy optimizer: per step catch-up of the
+// batch's rows -> the gradient kernel (dense gradient, csrc/mf.hip) -> update of the batch's rows, which also folds
+// the loss partials and the scalar bias like the dense sweep does.  The caller flushes afterwards.
+extern "C" int hiprec_mf_epoch_lazy(const hiprec_lazy_state* state, const hiprec_mf_tables* w, const hiprec_mf_tables* g,
+                                    const int64_t* users, const int64_t* items_a, const void* third, int32_t loss_kind,
+                                    int64_t n, int64_t batch, int32_t first_of_epoch, float reg_coef,
+                                    hiprec_stats* stats, void* scratch, size_t scratch_bytes, void* stream) {
+  HIPREC_REQUIRE(state && w && g && stats && scratch, "NULL pointer");
+  HIPREC_REQUIRE(n >= 0 && batch > 0 && (loss_kind == 0 || loss_kind == 1), "bad n / batch / loss kind");
+  HIPREC_REQUIRE(n == 0 || (users && items_a && third), "NULL batch arrays");
+  if (first_of_epoch)
+    if (int rc = hiprec_stats_begin_epoch(stats, stream)) return rc;
+  for (int64_t off = 0; off < n; off += batch) {
+    const int64_t b = std::min<int64_t>(batch, n - off);  // drop_last = False
+    const float inv_b = 1.0f / static_cast<float>(b);
+    const int64_t* neg = loss_kind == 0 ? static_cast<const int64_t*>(third) + off : nullptr;
+    const hiprec_lazy_rows rows{users + off, b, items_a + off, b, neg, neg ? b : 0, nullptr, 0};
+    if (int rc = hiprec_lazy_catchup(state, &rows, stats, stream)) return rc;
+    int rc;
+    if (loss_kind == 0)
+      rc = hiprec_mf_bpr_grad(w, g, users + off, items_a + off, neg, nullptr, b, inv_b, reg_coef, stats, scratch,
+                              scratch_bytes, stream);
+    else
+      rc = hiprec_mf_bce_grad(w, g, users + off, items_a + off, static_cast<const float*>(third) + off, nullptr, b, inv_b,
+                              reg_coef, stats, scratch, scratch_bytes, stream);
+    if (rc) return rc;
+    if ((rc = hiprec_lazy_update(state, &rows, scratch, stats, stream))) return rc;
+  }
+  return 0;
+}

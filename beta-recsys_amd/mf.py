@@ -495,8 +495,44 @@ class MFEngine(ModelEngine):
             self._item_stamp = torch.zeros(self.model.n_items, dtype=torch.int32, device=dev)
         else:
             self._user_stamp = self._item_stamp = None
+        # Adam / RMSprop on tables beyond the caches: `dense_opt` = "sweep" (every element every step, as torch.optim
+        # does: 28 bytes per parameter per step), "lazy" (csrc/lazy_opt.hip: resident epochs step only the rows of the
+        # batch and replay a lagging row's zero-gradient steps when it is next needed -- bit-identical to the sweep
+        # after the flush that ends every epoch) or "auto" (lazy from 64 MB of parameters on)
+        mode = self.config["model"].get("dense_opt", "auto")
+        if mode not in ("sweep", "lazy", "auto"):
+            raise ValueError(f"dense_opt must be 'sweep', 'lazy' or 'auto', not {mode!r}")
+        self._lazy = None
+        if (self.optimizer.name != "sgd" and self.model.emb_dim <= 256 and self._lazy_capable
+                and (mode == "lazy" or (mode == "auto" and flat.numel() * 4 >= self.ROWS_SGD_MIN_BYTES))):
+            opt, m = self.optimizer, self.model
+            lz = {"stamp_u": torch.full((m.n_users,), -1, dtype=torch.int32, device=dev),
+                  "stamp_i": torch.full((m.n_items,), -1, dtype=torch.int32, device=dev),
+                  "scalars": torch.zeros((1 << 16, 2), dtype=torch.float32, device=dev), "dirty": False}
+            lz["c"] = _lib.LazyState(
+                flat.data_ptr(), self._g_flat.data_ptr(), opt.exp_avg.data_ptr() if opt.exp_avg is not None else None,
+                opt.exp_avg_sq.data_ptr(), m.n_users, m.n_items, m.emb_dim, opt.kind, lz["stamp_u"].data_ptr(),
+                lz["stamp_i"].data_ptr(), lz["scalars"].data_ptr(), 1 << 16, 0, opt.lr, opt.beta1, opt.beta2, opt.eps)
+            self._lazy = lz
         self._buffers_ready = True
         return lib
+
+    _lazy_capable = True    # (the data-parallel replicas always sweep: their gradient is dense after the all-reduce)
+
+    def flush_lazy(self):
+        """Lazy Adam / RMSprop: replay every lagging row up to the optimizer clock (no-op when nothing lags)."""
+        lz = getattr(self, "_lazy", None)
+        if lz is not None and lz["dirty"]:
+            _lib.check(_lib.load().hiprec_lazy_flush(ctypes.byref(lz["c"]), _lib.ptr(self._stats),
+                                                     _lib.stream_ptr(self.model.flat.device)))
+            lz["dirty"] = False
+
+    def _lazy_mark_current(self):
+        """After anything that moved the clock with a dense sweep (or reset it): every row is current as of it."""
+        lz = getattr(self, "_lazy", None)
+        if lz is not None:
+            _lib.check(_lib.load().hiprec_lazy_mark_current(ctypes.byref(lz["c"]), _lib.ptr(self._stats),
+                                                            _lib.stream_ptr(self.model.flat.device)))
 
     def _take_stamps(self, n):
         if self._stamp + n >= 2**31 - 1:
@@ -568,10 +604,12 @@ class MFEngine(ModelEngine):
                 _lib.ptr(self._item_stamp), self._take_stamps(1), _lib.ptr(self._stats),
                 _lib.ptr(self._scratch), st))
         else:
+            self.flush_lazy()   # (pieces of a lazy epoch may be pending)
             _lib.check(lib.hiprec_opt_dense_step(
                 opt.kind, _lib.ptr(m.flat), _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg),
                 _lib.ptr(opt.exp_avg_sq), m.flat.numel(), opt.lr, opt.beta1, opt.beta2, opt.eps,
                 _lib.ptr(self._stats), _lib.ptr(self._scratch), m.flat.numel() - 1, st))
+            self._lazy_mark_current()
 
     def backward_only(self, batch_data):
         """zero_grad + forward + backward WITHOUT the optimizer step (what autograd leaves in
@@ -613,10 +651,14 @@ class MFEngine(ModelEngine):
             for view, key in ((gb, "global_bias"), (ue, "user_emb.weight"), (ie, "item_emb.weight"),
                               (ub, "user_bias.weight"), (ib, "item_bias.weight")):
                 view.copy_(torch.as_tensor(src[key], dtype=torch.float32).reshape(view.shape))
+        if getattr(self, "_lazy", None) is not None:
+            self._lazy["dirty"] = False
+            self._lazy_mark_current()   # whatever was loaded is current as of the restored clock
 
     def optimizer_state(self):
         """(step, exp_avg dict | None, exp_avg_sq dict | None) — counterpart of the loader above."""
         self._setup()
+        self.flush_lazy()
         st = read_stats(self._stats)
         out = []
         for buf in (self.optimizer.exp_avg, self.optimizer.exp_avg_sq):
@@ -902,6 +944,15 @@ class MFEngine(ModelEngine):
                 raise IndexError(
                     "Dimension out of range (expected to be in range of [-1, 0], but got 1)")
             return st
+        if self._lazy is not None and perm is None and self.loss in ("bpr", "bce"):
+            self._run_lazy_epoch(lib, users, pos, neg, n_run, bs, steps)
+            if not sync:
+                return None
+            st = self._sync_stats()
+            if n_run != n:
+                raise IndexError(
+                    "Dimension out of range (expected to be in range of [-1, 0], but got 1)")
+            return st
         if self._fused_ok(perm):
             self._run_fused_epoch(lib, users, pos, neg, n_run, bs, steps)
             if not sync:
@@ -917,6 +968,25 @@ class MFEngine(ModelEngine):
             users, pos, neg, n_run = users[a:b], pos[a:b], neg[a:b], b - a
             perm = None if perm is None else perm[a:b]
         return self._run_unfused_epoch(lib, users, pos, neg, perm, bs, n, n_run, sync)
+
+    def _run_lazy_epoch(self, lib, users, items_a, third, n_run, bs, steps):
+        """hiprec_mf_epoch_lazy (csrc/lazy_opt.hip): per step catch-up of the batch's rows, the gradient kernel, the
+        update of the batch's rows; the piece that reaches the last step flushes, so the tables and the moments hold
+        what torch.optim's dense steps would have left whenever an epoch is over."""
+        m, lz = self.model, self._lazy
+        n_steps = (n_run + bs - 1) // bs
+        a, b = (0, n_steps) if steps is None else steps
+        lo, hi = a * bs, min(b * bs, n_run)
+        w, g = m.tables(), m.tables(self._g_flat)
+        el = third.element_size()
+        lz["dirty"] = True
+        _lib.check(lib.hiprec_mf_epoch_lazy(
+            ctypes.byref(lz["c"]), ctypes.byref(w), ctypes.byref(g), ctypes.c_void_p(users.data_ptr() + 8 * lo),
+            ctypes.c_void_p(items_a.data_ptr() + 8 * lo), ctypes.c_void_p(third.data_ptr() + el * lo),
+            0 if self.loss == "bpr" else 1, hi - lo, bs, 1 if a == 0 else 0, float(self.reg), _lib.ptr(self._stats),
+            _lib.ptr(self._scratch), self._scratch.numel(), _lib.stream_ptr(m.flat.device)))
+        if b == n_steps:
+            self.flush_lazy()
 
     def _run_owned_epoch(self, lib, prepared, n_run, steps):
         """hiprec_mf_bpr_epoch_owned (csrc/mf_owned.hip): plain SGD on tables beyond the caches, one launch per

@@ -57,6 +57,8 @@ class DirectAllReduce:
 class ReplicatedMFEngine(MFEngine):
     """``MFEngine`` whose step sums gradients over a process group before the optimizer sweep."""
 
+    _lazy_capable = False   # replicas are for cache-sized tables and sweep a gradient that is dense after the all-reduce
+
     def __init__(self, config, process_group=None):
         self.pg = process_group
         self.world = dist.get_world_size(process_group)

@@ -563,6 +563,16 @@ int hiprec_lazy_flush(const hiprec_lazy_state* state, hiprec_stats* stats, void*
  * (the sweep may have given any row its first gradient; rows whose moments are still zero cost a replay nothing). */
 int hiprec_lazy_mark_current(const hiprec_lazy_state* state, const hiprec_stats* stats, void* stream);
 
+/* MFEngine.train_an_epoch (mf.py:121-139) over a staged epoch (users / items_a / third contiguous in visiting order;
+ * loss_kind 0 = BPR with third = int64 negatives, 1 = BCE with third = fp32 ratings) with the exact lazy optimizer: per
+ * step hiprec_lazy_catchup of the batch's rows, the gradient kernel (hiprec_mf_bpr_grad / _bce_grad: dense gradient in
+ * g = state->g), hiprec_lazy_update with the kernel's scratch.  first_of_epoch != 0 clears the epoch sums first.  The
+ * caller flushes (hiprec_lazy_flush) before anybody reads the tables. */
+int hiprec_mf_epoch_lazy(const hiprec_lazy_state* state, const hiprec_mf_tables* w, const hiprec_mf_tables* g,
+                         const int64_t* users, const int64_t* items_a, const void* third, int32_t loss_kind, int64_t n,
+                         int64_t batch, int32_t first_of_epoch, float reg_coef, hiprec_stats* stats, void* scratch,
+                         size_t scratch_bytes, void* stream);
+
 /* ---- ONE launch of that sequence, with the buffers of this step named explicitly: for callers that
  *      have to do something between two steps -- the data-parallel engine all-reduces
  *      [partials of scratch_cur | g_cur] over RCCL before the next launch consumes them as

@@ -279,3 +279,83 @@ def test_lazy_parity_against_the_ieee_arithmetic_build(hip_device):
                          text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
+
+
+# ---- MFEngine (the un-sharded drop-in engine) with the lazy optimizer ------------------------------------------------
+
+def mf_lazy_run(optimizer, lr, loss, dense_opt, pieces=None, single_between=False, reg=None):
+    import beta_recsys_amd as hp
+    from test_mf_gpu import get_weights, load_weights, make_engine
+
+    U, I, D, B = 3000, 400, 64, 256
+    n = 5 * B + 77
+    w0 = onp.init_params(U, I, D, seed=4)
+    rng = np.random.default_rng(1)
+    p = 1.0 / np.arange(1, I + 1)
+    users, pos = rng.integers(0, U // 2, n) * 2, rng.choice(I, n, p=p / p.sum())      # odd users are never drawn
+    third = rng.integers(0, I, n) if loss == "bpr" else (rng.random(n) < 0.3).astype(np.float32)
+    eng = make_engine(U, I, D, optimizer, loss, lr, B, reg=reg, dense_opt=dense_opt, prefetch_epoch=False)
+    load_weights(eng, w0)
+    eng._setup()
+    assert (eng._lazy is not None) == (dense_opt == "lazy")
+    if loss == "bpr":
+        loader = hp.DeviceTripleBatcher(*(torch.from_numpy(a).cuda() for a in (users, pos, third)), B, shuffle=False)
+    else:
+        from beta_recsys_amd.data import DeviceTensorBatcher
+
+        loader = DeviceTensorBatcher((torch.from_numpy(users).cuda(), torch.from_numpy(pos).cuda(),
+                                      torch.from_numpy(third).cuda()), B, shuffle=False)
+    batches = [(users[k:k + B], pos[k:k + B], third[k:k + B]) for k in range(0, n, B)]
+    visited, sums = [], []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for epoch in range(2):
+            if pieces and epoch == 1:
+                prepared = eng.prepare_epoch(loader)
+                for piece in pieces:
+                    eng.run_prepared_epoch(prepared, sync=False, steps=piece)
+                sums.append(eng.epoch_stats().loss_sum)
+            else:
+                eng.train_an_epoch(loader, epoch)
+                sums.append(eng.writer.scalars[-2][1])
+            visited += batches
+            if single_between and epoch == 0:
+                extra = (rng.integers(0, U, B), rng.integers(0, I, B),
+                         rng.integers(0, I, B) if loss == "bpr" else (rng.random(B) < 0.3).astype(np.float32))
+                eng.train_single_batch(tuple(torch.from_numpy(a) for a in extra))
+                visited.append(extra)
+    return eng, w0, visited, sums, get_weights(eng)
+
+
+@pytest.mark.parametrize("optimizer,lr,loss", [("adam", 0.05, "bpr"), ("rmsprop", 0.01, "bpr"), ("adam", 0.02, "bce")])
+def test_mf_engine_epochs_with_the_lazy_optimizer(hip_device, optimizer, lr, loss):
+    """MFEngine.train_an_epoch with ``dense_opt: "lazy"`` (hiprec_mf_epoch_lazy: catch-up, gradient kernel, update per
+    step, flush at the end of the epoch): epoch sums to 1e-5 of the oracle's, every weight on the oracle's trajectory,
+    never-drawn users bit-identical with stamp -1, the gradient buffer clean -- like the dense-sweep engine."""
+    eng, w0, visited, sums, got = mf_lazy_run(optimizer, lr, loss, "lazy")
+    _, _, _, sums_s, got_s = mf_lazy_run(optimizer, lr, loss, "sweep")
+    per = len(visited) // 2
+    w = onp.copy_params(w0)
+    st = onp.new_opt_state(w, optimizer)
+    for e in range(2):
+        tot = sum(onp.mf_train_step(w, st, b, loss, optimizer, lr)[0] for b in visited[e * per:(e + 1) * per])
+        assert_scalar_close(sums[e], tot, REL, f"epoch {e} loss sum (lazy)")
+        assert_scalar_close(sums_s[e], tot, REL, f"epoch {e} loss sum (sweep)")
+    traj = mf_trajectory(w0, visited, optimizer, lr, loss=loss)
+    assert_on_trajectory(got, *traj, f"lazy {optimizer} {loss}")
+    assert_on_trajectory(got_s, *traj, f"sweep {optimizer} {loss}")
+    assert float(eng._g_flat.abs().max()) == 0.0 and not eng._lazy["dirty"]
+    su = eng._lazy["stamp_u"].cpu().numpy()
+    assert (su[1::2] == -1).all() and np.array_equal(got["user_emb.weight"][1::2], w0["user_emb.weight"][1::2])
+
+
+def test_mf_engine_lazy_epoch_in_pieces_and_around_a_dense_step(hip_device):
+    """The second epoch enqueued in pieces (the flush rides on the piece that reaches the last step) and a per-batch
+    step (dense sweep: flush before, every row marked current after) between the epochs; optimizer_state() reads
+    flushed moments."""
+    eng, w0, visited, _, got = mf_lazy_run("adam", 0.05, "bpr", "lazy", pieces=[(0, 2), (2, 2), (2, 5), (5, 6)],
+                                           single_between=True)
+    assert_on_trajectory(got, *mf_trajectory(w0, visited, "adam", 0.05), "lazy epochs in pieces around a dense step")
+    step, m, v = eng.optimizer_state()
+    assert step == len(visited) and not eng._lazy["dirty"]
+    # (that the flush leaves the dense sweeps' bits is test_lazy_rows_equal_the_dense_sweeps_bit_for_bit's business)
+    assert all(torch.isfinite(t).all() for t in list(m.values()) + list(v.values()))
