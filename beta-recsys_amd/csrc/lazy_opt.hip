@@ -53,7 +53,172 @@ __device__ __forceinline__ float2 lazy_scalars_at(const LazyCtx& c, long long t)
   return c.scalars[t < c.scalars_cap ? t : c.scalars_cap - 1];
 }
 
+// The model's scalar (global_bias, the last element) takes a real step every step; its gradient is in g (the row-sharded
+// step's bookkeeping put it there) plus, for callers that pass the gradient kernel's scratch, the per-block partials
+// (which also books the step's loss, as the dense sweep does).  Block 0 of an update launch.
+template <int KIND>
+__device__ __forceinline__ void lazy_scalar_step(const LazyCtx& c, const OptScalars& s, hiprec_stats* stats,
+                                                 const Scratch* scratch, long long clock, float ss_now, float bc2_now) {
+  if (blockIdx.x != 0) return;
+  float extra = 0.f;
+  if (scratch) extra = finalize_partials(stats, scratch);
+  if (threadIdx.x != 0) return;
+  const int64_t i = (c.n_users + c.n_items) * (static_cast<int64_t>(c.dim) + 1);
+  float wv = c.w[i], gv = c.g[i] + extra, mv = 0.f, vv = c.v[i];
+  if constexpr (KIND == HIPREC_OPT_ADAM) mv = c.m[i];
+  opt_update<KIND>(wv, gv, mv, vv, s, ss_now, bc2_now);
+  c.w[i] = wv;
+  c.g[i] = 0.f;
+  if constexpr (KIND == HIPREC_OPT_ADAM) c.m[i] = mv;
+  c.v[i] = vv;
+  // this step's scalars for the replays to come.  Beyond the table the powers must have converged (default betas:
+  // beta2^t < 2^-53 from t ~ 36 800 on): a later step with different scalars cannot be replayed.
+  if (clock < c.scalars_cap) {
+    c.scalars[clock] = make_float2(ss_now, bc2_now);
+  } else {
+    const float2 last = c.scalars[c.scalars_cap - 1];
+    if (last.x != ss_now || last.y != bc2_now) atomicOr(&stats->status, HIPREC_STATUS_LAZY_TABLE);
+  }
+}
+
+// One entry of the step's lists (or, flush, row e of the tables): which table, which row; id < 0 = nothing.
+template <int MODE>
+__device__ __forceinline__ int64_t lazy_entry(const LazyCtx& c, const hiprec_lazy_rows& rows, int64_t e, bool* is_item) {
+  const int64_t n0 = MODE == 2 ? c.n_users : rows.n_users, n1 = MODE == 2 ? c.n_items : rows.n_items_a;
+  const int64_t n2 = MODE == 2 ? 0 : rows.n_items_b;
+  *is_item = e >= n0;
+  if (e < n0) return MODE == 2 ? e : rows.users[e];
+  if (e < n0 + n1) return MODE == 2 ? e - n0 : rows.items_a[e - n0];
+  if (e < n0 + n1 + n2) return rows.items_b[e - n0 - n1];
+  return rows.items_c[e - n0 - n1 - n2];
+}
+
+// Who works on a row (one lane per row calls this): `old` = the stamp found, returns whether the caller owns the row
+// for this launch.
+template <int MODE>
+__device__ __forceinline__ bool lazy_claim(int32_t* sp, int target, int* old_out) {
+  int old = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool go = false;
+  if constexpr (MODE == 0) {   // raise the W_AHEAD flag: the first to set it owns the row
+    if (old >= 0 && !(old & kWAhead) && old < target) {
+      old = atomicOr(sp, kWAhead);
+      go = !(old & kWAhead);
+    }
+  } else if constexpr (MODE == 1) {   // the first to write the step's number owns the row
+    if (old != target) {
+      old = atomicExch(sp, target);
+      go = old != target;
+    }
+  } else {                     // flush: one visitor per row; a never-touched row stays -1
+    go = old >= 0 && (old & ~kWAhead) < target;
+    if (go) *sp = target;
+  }
+  *old_out = old;
+  return go;
+}
+
+// The same work with 64 / LPR rows per wave: LPR lanes per row, one float4 (16 bytes) of every array per lane, the bias
+// element in the row's first lane -- dim a multiple of 4 and <= 4 * LPR.  A wave of the one-row kernel walks its
+// entries one after the other with two or three dependent round trips each; here 2 (dim 128) or 4 (dim 64) rows'
+// chains overlap and the row loads are ISSUED BEFORE the claim (a lost claim wastes them, a won one has them in hand).
+template <int KIND, int MODE, int LPR>
+__global__ __launch_bounds__(kBlock) void lazy_rows_vec_kernel(LazyCtx c, hiprec_lazy_rows rows, OptScalars s,
+                                                               hiprec_stats* stats, const Scratch* scratch) {
+  constexpr int ROWS = kWave / LPR;
+  const int lane = lane_id(), sub = lane / LPR, sl = lane % LPR;
+  const int D = c.dim;
+  const long long clock = stats->step;
+  float ss_now = s.lr, bc2_now = 1.f;
+  if constexpr (MODE == 1) step_scalars<KIND>(s, stats, &ss_now, &bc2_now);
+  const int64_t nu = c.n_users, ni = c.n_items;
+  const int64_t total = MODE == 2 ? nu + ni : rows.n_users + rows.n_items_a + rows.n_items_b + rows.n_items_c;
+  const int64_t n_groups = (total + ROWS - 1) / ROWS;
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int target = static_cast<int>(clock);
+  const long long last = MODE == 1 ? clock - 1 : clock;
+  const uint64_t row_mask = (LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull)) << (sub * LPR);
+  for (int64_t gi = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block(); gi < n_groups; gi += n_waves) {
+    const int64_t e = gi * ROWS + sub;
+    bool is_item = true, valid = e < total;
+    int64_t id = valid ? lazy_entry<MODE>(c, rows, e, &is_item) : -1;
+    if (id >= (is_item ? ni : nu)) {
+      if (sl == 0) atomicOr(&stats->status, HIPREC_STATUS_ROW_OOB);
+      id = -1;
+    }
+    valid = id >= 0;
+    const int64_t emb = (is_item ? nu * D : 0) + (valid ? id : 0) * D + 4 * sl;
+    const int64_t bias = (nu + ni) * static_cast<int64_t>(D) + (is_item ? nu : 0) + (valid ? id : 0);
+    const bool col_on = valid && 4 * sl < D, bias_on = valid && sl == 0;
+    float w[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, m[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, v[5] = {0.f, 0.f, 0.f, 0.f, 0.f},
+          g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    auto load4 = [&](const float* p, float (&dst)[5]) {
+      if (col_on) {
+        const float4 x = *reinterpret_cast<const float4*>(p + emb);
+        dst[0] = x.x, dst[1] = x.y, dst[2] = x.z, dst[3] = x.w;
+      }
+      if (bias_on) dst[4] = p[bias];
+    };
+    if (KIND == HIPREC_OPT_ADAM || MODE == 1) load4(c.w, w);
+    if constexpr (KIND == HIPREC_OPT_ADAM) load4(c.m, m);
+    load4(c.v, v);
+    if constexpr (MODE == 1) load4(c.g, g);
+    int old = 0, go = 0;
+    if (bias_on) go = lazy_claim<MODE>((is_item ? c.stamp_i : c.stamp_u) + id, target, &old) ? 1 : 0;
+    old = __shfl(old, sub * LPR);
+    go = __shfl(go, sub * LPR);
+    if (MODE != 1 && old < 0) go = 0;   // never touched: m = v = 0, nothing to replay
+    if (__ballot(go != 0) == 0ull) continue;
+    const bool w_ahead = old >= 0 && (old & kWAhead);
+    const int base = old < 0 ? -1 : (old & ~kWAhead);
+    bool moving = false;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) moving |= m[j] != 0.f || v[j] != 0.f;
+    const bool replay = go && base >= 0 && (__ballot(moving) & row_mask) != 0ull;
+    // the wave replays from the oldest of its rows; a row joins when t passes its own stamp
+    int first = replay ? base + 1 : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off));
+    for (long long t = first; t <= last; ++t) {
+      float2 sc = make_float2(s.lr, 1.f);
+      if constexpr (KIND == HIPREC_OPT_ADAM) sc = lazy_scalars_at(c, t);
+      if (!(replay && t > base)) continue;
+      if (MODE == 1 && w_ahead) {   // w is current already: only the moments (one fma and one multiply per step)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          float zero = 0.f, w_unused = 0.f;
+          opt_update<KIND>(w_unused, zero, m[j], v[j], s, 1.f, 1.f);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          float zero = 0.f;
+          opt_update<KIND>(w[j], zero, m[j], v[j], s, sc.x, sc.y);
+        }
+      }
+    }
+    if (!go) continue;
+    if constexpr (MODE == 1) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) opt_update<KIND>(w[j], g[j], m[j], v[j], s, ss_now, bc2_now);
+    }
+    auto store4 = [&](float* p, const float (&src)[5]) {
+      if (col_on) *reinterpret_cast<float4*>(p + emb) = float4{src[0], src[1], src[2], src[3]};
+      if (bias_on) p[bias] = src[4];
+    };
+    if (KIND == HIPREC_OPT_ADAM || MODE == 1) store4(c.w, w);
+    if constexpr (MODE != 0) {   // catch-up stores only w: the moments are replayed by this step's update
+      if constexpr (KIND == HIPREC_OPT_ADAM) store4(c.m, m);
+      store4(c.v, v);
+      if constexpr (MODE == 1) store4(c.g, g);   // opt_update left g = 0
+    }
+  }
+  if constexpr (MODE == 1) lazy_scalar_step<KIND>(c, s, stats, scratch, clock, ss_now, bc2_now);
+}
+
+
 // MODE 0 = catch-up (to the clock), 1 = update (the step the clock shows), 2 = flush (all rows, to the clock)
+// (declared before the kernels that use them)
+
 template <int KIND, int MODE>
 __global__ __launch_bounds__(kBlock) void lazy_rows_kernel(LazyCtx c, hiprec_lazy_rows rows, OptScalars s,
                                                            hiprec_stats* stats, const Scratch* scratch) {
@@ -175,33 +340,7 @@ __global__ __launch_bounds__(kBlock) void lazy_rows_kernel(LazyCtx c, hiprec_laz
       if constexpr (MODE == 1) c.g[at[j]] = 0.f;
     }
   }
-  if constexpr (MODE == 1) {
-    // the model's scalar (global_bias, the last element) takes a real step every step; its gradient is in g (the
-    // row-sharded step's bookkeeping put it there) plus, for callers that pass the gradient kernel's scratch, the
-    // per-block partials (which also books the step's loss, as the dense sweep does)
-    if (blockIdx.x == 0) {
-      float extra = 0.f;
-      if (scratch) extra = finalize_partials(stats, scratch);
-      if (threadIdx.x == 0) {
-        const int64_t i = (nu + ni) * (static_cast<int64_t>(D) + 1);
-        float wv = c.w[i], gv = c.g[i] + extra, mv = 0.f, vv = c.v[i];
-        if constexpr (KIND == HIPREC_OPT_ADAM) mv = c.m[i];
-        opt_update<KIND>(wv, gv, mv, vv, s, ss_now, bc2_now);
-        c.w[i] = wv;
-        c.g[i] = 0.f;
-        if constexpr (KIND == HIPREC_OPT_ADAM) c.m[i] = mv;
-        c.v[i] = vv;
-        // this step's scalars for the replays to come.  Beyond the table the powers must have converged (default
-        // betas: beta2^t < 2^-53 from t ~ 36 800 on): a later step with different scalars cannot be replayed.
-        if (clock < c.scalars_cap) {
-          c.scalars[clock] = make_float2(ss_now, bc2_now);
-        } else {
-          const float2 last = c.scalars[c.scalars_cap - 1];
-          if (last.x != ss_now || last.y != bc2_now) atomicOr(&stats->status, HIPREC_STATUS_LAZY_TABLE);
-        }
-      }
-    }
-  }
+  if constexpr (MODE == 1) lazy_scalar_step<KIND>(c, s, stats, scratch, clock, ss_now, bc2_now);
 }
 
 // A dense sweep was run while lazy state exists (the caller flushed first): every row is current as of the clock.
@@ -244,13 +383,25 @@ int lazy_launch(const hiprec_lazy_state* st, const hiprec_lazy_rows* rows, const
                      static_cast<float>(1.0 - st->beta1),
                      static_cast<float>(1.0 - st->beta2),
                      static_cast<float>(st->eps)};
-  const int grid = grid_for_waves(total);
   hipStream_t stm = static_cast<hipStream_t>(stream);
   const auto* sc = static_cast<const Scratch*>(scratch);
-  if (st->kind == HIPREC_OPT_ADAM)
-    lazy_rows_kernel<HIPREC_OPT_ADAM, MODE><<<grid, kBlock, 0, stm>>>(c, r, s, stats, sc);
-  else
-    lazy_rows_kernel<HIPREC_OPT_RMSPROP, MODE><<<grid, kBlock, 0, stm>>>(c, r, s, stats, sc);
+  const bool adam = st->kind == HIPREC_OPT_ADAM;
+  if (st->dim % 4 == 0) {   // 16-byte vectors, several rows per wave
+#define HIPREC_LAZY_VEC(LPR)                                                                                         \
+  do {                                                                                                               \
+    const int grid = grid_for_waves((total + kWave / LPR - 1) / (kWave / LPR));                                      \
+    if (adam) lazy_rows_vec_kernel<HIPREC_OPT_ADAM, MODE, LPR><<<grid, kBlock, 0, stm>>>(c, r, s, stats, sc);        \
+    else lazy_rows_vec_kernel<HIPREC_OPT_RMSPROP, MODE, LPR><<<grid, kBlock, 0, stm>>>(c, r, s, stats, sc);          \
+  } while (0)
+    if (st->dim <= 64) HIPREC_LAZY_VEC(16);
+    else if (st->dim <= 128) HIPREC_LAZY_VEC(32);
+    else HIPREC_LAZY_VEC(64);
+#undef HIPREC_LAZY_VEC
+  } else {
+    const int grid = grid_for_waves(total);
+    if (adam) lazy_rows_kernel<HIPREC_OPT_ADAM, MODE><<<grid, kBlock, 0, stm>>>(c, r, s, stats, sc);
+    else lazy_rows_kernel<HIPREC_OPT_RMSPROP, MODE><<<grid, kBlock, 0, stm>>>(c, r, s, stats, sc);
+  }
   HIPREC_TRY(hipGetLastError());
   return 0;
 }

@@ -66,7 +66,7 @@ class Lazy:
                                                    self._lib.stream_ptr(self.dev)))
 
 
-@pytest.mark.parametrize("D", [8, 64, 100, 128, 256])
+@pytest.mark.parametrize("D", [8, 10, 64, 100, 128, 254, 256])
 @pytest.mark.parametrize("opt", ["adam", "rmsprop"])
 def test_lazy_rows_equal_the_dense_sweeps_bit_for_bit(hip_device, opt, D):
     """40 steps on a 50 x 30 table, each touching a few rows: some rows every step, some twice with a gap of 30+
