@@ -380,6 +380,10 @@ SIGNATURES = {
     "hiprec_shard_planned_steps": (
         c_int, [POINTER(ShardPlan), POINTER(ShardBufs), c_int64, c_int64, c_int32, c_float, c_double, c_double,
                 c_double, c_double, POINTER(NcclFns), _P, _P, _P]),
+    "hiprec_gather_epoch": (c_int, [_P, _P, _P, _P, c_int32, ctypes.c_uint64, _P, c_int64, _P, _P, _P, _P]),
+    "hiprec_stage_sort_keys": (c_int, [_P, _P, c_int32, ctypes.c_uint64, c_int64, c_int64, c_int64, c_int32, _P, _P]),
+    "hiprec_group_epoch_by_item": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P,
+                                           _P, _P]),
     "hiprec_lazy_state_bytes": (c_size_t, []),
     "hiprec_lazy_catchup": (c_int, [POINTER(LazyState), POINTER(LazyRows), _P, _P]),
     "hiprec_lazy_update": (c_int, [POINTER(LazyState), POINTER(LazyRows), _P, _P, _P]),

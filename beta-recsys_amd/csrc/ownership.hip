@@ -164,6 +164,111 @@ __global__ __launch_bounds__(kOwnThreads) void ownership_kernel(const int32_t* _
   }
 }
 
+// ---- an epoch laid out with every batch GROUPED BY POSITIVE ITEM, without a sort -----------------------------------------
+// (What torch.argsort + three index gathers did for batches too large for the staging kernel's LDS sort: the gradient
+// kernels sum adjacent equal positive items before they touch memory.)  The ownership tables already hold the counting
+// sort: after the first phase an ITEM entry's count is its number of positive occurrences (pos_cnt) and a positive
+// occurrence's arrival rank (occ) is its place inside the item's group.  An exclusive scan of pos_cnt over a batch's
+// table gives every item's first position; one scatter moves the triples and their ownership slots there.
+
+// position j of the epoch's visiting order -> index into the loader's arrays: perm[j] / P_seed(j) / j
+__device__ __forceinline__ int64_t visit_index(int64_t j, const int64_t* __restrict__ perm, int shuffle, int half_bits,
+                                               uint64_t seed, int64_t n) {
+  if (perm) return perm[j];
+  if (shuffle) return static_cast<int64_t>(feistel_permute(static_cast<uint64_t>(j), static_cast<uint64_t>(n), half_bits, seed));
+  return j;
+}
+
+// the epoch laid out: out[j] = in[visit(order ? order[j] : j)] for the three arrays, one launch
+__global__ __launch_bounds__(kBlock) void gather_epoch_kernel(const int64_t* __restrict__ users,
+                                                              const int64_t* __restrict__ pos,
+                                                              const int64_t* __restrict__ neg,
+                                                              const int64_t* __restrict__ perm, int shuffle,
+                                                              int half_bits, uint64_t seed,
+                                                              const int64_t* __restrict__ order, int64_t n,
+                                                              int64_t* __restrict__ ou, int64_t* __restrict__ op,
+                                                              int64_t* __restrict__ on) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; j < n; j += stride) {
+    const int64_t i = visit_index(order ? order[j] : j, perm, shuffle, half_bits, seed, n);
+    ou[j] = users[i];
+    op[j] = pos[i];
+    on[j] = neg[i];
+  }
+}
+
+// sort key of visiting position j: (its batch, its positive item) -- a stable sort by it groups every batch by item in
+// ascending row order (neighbouring groups are neighbouring table rows)
+template <class K>
+__global__ __launch_bounds__(kBlock) void stage_sort_keys_kernel(const int64_t* __restrict__ items,
+                                                                 const int64_t* __restrict__ perm, int shuffle,
+                                                                 int half_bits, uint64_t seed, int64_t n, int64_t batch,
+                                                                 int64_t n_items, K* __restrict__ keys) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; j < n; j += stride) {
+    int64_t it = items[visit_index(j, perm, shuffle, half_bits, seed, n)];
+    it = it < 0 ? 0 : it >= n_items ? n_items - 1 : it;   // out-of-range ids are flagged by the step, not here
+    keys[j] = static_cast<K>((j / batch) * n_items + it);
+  }
+}
+
+constexpr int kGroupThreads = 1024;
+constexpr int kGroupWaves = kGroupThreads / kWave;
+
+// one workgroup per batch: pos_cnt[entry] <- first position of the entry's item inside the batch (entries of user
+// rows and empty entries contribute nothing).  Every wave owns a contiguous share of the table: totals first, then the
+// prefix with the carry of the shares before it.
+__global__ __launch_bounds__(kGroupThreads) void group_scan_kernel(const int32_t* __restrict__ tab_keys,
+                                                                   int32_t* __restrict__ pos_cnt, int table_bits,
+                                                                   int32_t n_users) {
+  __shared__ int32_t s_tot[kGroupWaves];
+  const int64_t T = 1ll << table_bits, base = static_cast<int64_t>(blockIdx.x) << table_bits;
+  const int lane = lane_id(), wv = wave_in_block();
+  const int64_t share = (T + kGroupWaves - 1) / kGroupWaves, lo = wv * share, hi = min<int64_t>(T, lo + share);
+  auto count = [&](int64_t i) { return i < hi && tab_keys[base + i] >= n_users ? pos_cnt[base + i] : 0; };
+  int32_t tot = 0;
+  for (int64_t i = lo + lane; i < hi; i += kWave) tot += count(i);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+  if (lane == 0) s_tot[wv] = tot;
+  __syncthreads();
+  int32_t carry = 0;
+  for (int w = 0; w < wv; ++w) carry += s_tot[w];
+  for (int64_t i0 = lo; i0 < hi; i0 += kWave) {
+    const int64_t i = i0 + lane;
+    const int32_t c = count(i);
+    int32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int32_t up = __shfl_up(incl, off);
+      if (lane >= off) incl += up;
+    }
+    if (i < hi) pos_cnt[base + i] = carry + incl - c;
+    carry += __shfl(incl, kWave - 1);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void group_scatter_kernel(
+    const int64_t* __restrict__ users, const int64_t* __restrict__ pos, const int64_t* __restrict__ neg, int64_t n,
+    int64_t batch, int table_bits, const int32_t* __restrict__ own, const int32_t* __restrict__ occ,
+    const int32_t* __restrict__ pos_start, int32_t* __restrict__ invalid, int64_t* __restrict__ ou,
+    int64_t* __restrict__ op, int64_t* __restrict__ on, int32_t* __restrict__ own_out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < n; t += stride) {
+    const int64_t b = t / batch, t0 = b * batch, cnt = min<int64_t>(batch, n - t0);
+    const int32_t slot = own[n + t];   // the table entry of the triple's positive item; -1: an out-of-range id
+    int64_t at;
+    if (slot >= 0) at = t0 + pos_start[(b << table_bits) + slot] + occ[n + t];
+    else at = t0 + cnt - 1 - atomicAdd(invalid + b, 1);   // skipped by the step kernel anyway: parked at the batch's end
+    ou[at] = users[t];
+    op[at] = pos[t];
+    on[at] = neg[t];
+    own_out[at] = own[t];
+    own_out[n + at] = slot;
+    own_out[2 * n + at] = own[2 * n + t];
+  }
+}
+
 }  // namespace hiprec
 
 using namespace hiprec;
@@ -214,4 +319,67 @@ extern "C" int hiprec_batch_row_ownership_tables(const int64_t* users, const int
   HIPREC_REQUIRE(tab_keys && pos_cnt && occ, "NULL pointer");
   return ownership_impl(users, pos, neg, n, batch, n_users, n_items, table_bits, keys, total, own, tab_keys, pos_cnt,
                         occ, stream);
+}
+
+extern "C" int hiprec_gather_epoch(const int64_t* users, const int64_t* pos, const int64_t* neg, const int64_t* perm,
+                                   int32_t shuffle, uint64_t seed, const int64_t* order, int64_t n, int64_t* users_out,
+                                   int64_t* pos_out, int64_t* neg_out, void* stream) {
+  HIPREC_REQUIRE(n >= 0, "negative n");
+  if (n == 0) return 0;
+  HIPREC_REQUIRE(users && pos && neg && users_out && pos_out && neg_out, "NULL pointer");
+  int half_bits = 0;
+  if (!perm && shuffle) {
+    half_bits = feistel_half_bits(static_cast<uint64_t>(n));
+    HIPREC_REQUIRE(half_bits <= 31, "n too large for the 32-bit Feistel halves");
+  }
+  gather_epoch_kernel<<<grid_for_threads(n), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      users, pos, neg, perm, shuffle, half_bits, seed, order, n, users_out, pos_out, neg_out);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_stage_sort_keys(const int64_t* items, const int64_t* perm, int32_t shuffle, uint64_t seed, int64_t n,
+                                      int64_t batch, int64_t n_items, int32_t key_bytes, void* keys, void* stream) {
+  HIPREC_REQUIRE(n >= 0 && batch > 0 && n_items > 0 && (key_bytes == 4 || key_bytes == 8), "bad sizes");
+  if (n == 0) return 0;
+  HIPREC_REQUIRE(items && keys, "NULL pointer");
+  const int64_t n_batches = (n + batch - 1) / batch;
+  HIPREC_REQUIRE(key_bytes == 8 || n_batches * n_items < (1ll << 31), "32-bit keys need n_batches * n_items < 2^31");
+  int half_bits = 0;
+  if (!perm && shuffle) {
+    half_bits = feistel_half_bits(static_cast<uint64_t>(n));
+    HIPREC_REQUIRE(half_bits <= 31, "n too large for the 32-bit Feistel halves");
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (key_bytes == 4)
+    stage_sort_keys_kernel<int32_t><<<grid_for_threads(n), kBlock, 0, st>>>(items, perm, shuffle, half_bits, seed, n, batch,
+                                                                            n_items, static_cast<int32_t*>(keys));
+  else
+    stage_sort_keys_kernel<int64_t><<<grid_for_threads(n), kBlock, 0, st>>>(items, perm, shuffle, half_bits, seed, n, batch,
+                                                                            n_items, static_cast<int64_t*>(keys));
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_group_epoch_by_item(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
+                                          int64_t batch, int64_t n_users, int32_t table_bits, const int32_t* own,
+                                          const int32_t* occ, const int32_t* tab_keys, int32_t* pos_cnt,
+                                          int32_t* invalid_cnt, int64_t* users_out, int64_t* pos_out,
+                                          int64_t* neg_out, int32_t* own_out, void* stream) {
+  HIPREC_REQUIRE(n >= 0 && batch > 0 && n_users > 0 && table_bits >= 2 && table_bits <= 30, "bad sizes");
+  if (n == 0) return 0;
+  HIPREC_REQUIRE(users && pos && neg && own && occ && tab_keys && pos_cnt && invalid_cnt && users_out && pos_out &&
+                     neg_out && own_out,
+                 "NULL pointer");
+  HIPREC_REQUIRE(users_out != users && pos_out != pos && neg_out != neg && own_out != own, "the scatter is not in place");
+  const int64_t n_batches = (n + batch - 1) / batch;
+  HIPREC_REQUIRE(n_batches < (1ll << 31) && n_users < (1ll << 31), "too many batches / users");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIPREC_TRY(hipMemsetAsync(invalid_cnt, 0, sizeof(int32_t) * n_batches, st));
+  group_scan_kernel<<<static_cast<int>(n_batches), kGroupThreads, 0, st>>>(tab_keys, pos_cnt, table_bits,
+                                                                          static_cast<int32_t>(n_users));
+  group_scatter_kernel<<<grid_for_threads(n), kBlock, 0, st>>>(users, pos, neg, n, batch, table_bits, own, occ, pos_cnt,
+                                                               invalid_cnt, users_out, pos_out, neg_out, own_out);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
 }

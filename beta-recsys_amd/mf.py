@@ -330,6 +330,34 @@ def batch_row_ownership(users, pos, neg, batch_size, n_users, n_items):
     return own, total, stride
 
 
+def group_epoch_by_item(users, pos, neg, batch_size, n_users, n_items):
+    """An epoch in visiting order -> the same batches, each GROUPED BY POSITIVE ITEM (any order of the groups), plus the
+    row-ownership arrays of the owned-rows step for the new layout: ``(users, pos, neg, (own, total, stride))``.  No
+    sort: ``hiprec_batch_row_ownership_tables`` + ``hiprec_group_epoch_by_item`` (csrc/ownership.hip) -- the hash
+    tables the ownership needs anyway are a counting sort by item.  Batch composition is unchanged, so only the fp
+    summation order of a step moves (as with :func:`sort_within_batches`, which this replaces on the device)."""
+    lib = _lib.load()
+    n, dev = users.numel(), users.device
+    n_batches = max((n + batch_size - 1) // batch_size, 1)
+    bits = lib.hiprec_ownership_table_bits(batch_size)
+    stride = 1 << bits
+    i32 = dict(dtype=torch.int32, device=dev)
+    keys, occ = torch.empty(3 * n, **i32), torch.empty(3 * n, **i32)
+    own, own2 = torch.empty((3, n), **i32), torch.empty((3, n), **i32)
+    total, tab_keys, pos_cnt = (torch.empty((n_batches, stride), **i32) for _ in range(3))
+    invalid = torch.empty(n_batches, **i32)
+    st = _lib.stream_ptr(dev)
+    _lib.check(lib.hiprec_batch_row_ownership_tables(
+        _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), n, batch_size, n_users, n_items, bits, _lib.ptr(keys),
+        _lib.ptr(total), _lib.ptr(own), _lib.ptr(tab_keys), _lib.ptr(pos_cnt), _lib.ptr(occ), st))
+    ou, op, on = torch.empty_like(users), torch.empty_like(pos), torch.empty_like(neg)
+    _lib.check(lib.hiprec_group_epoch_by_item(
+        _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), n, batch_size, n_users, bits, _lib.ptr(own), _lib.ptr(occ),
+        _lib.ptr(tab_keys), _lib.ptr(pos_cnt), _lib.ptr(invalid), _lib.ptr(ou), _lib.ptr(op), _lib.ptr(on),
+        _lib.ptr(own2), st))
+    return ou, op, on, (own2, total, stride)
+
+
 def batch_row_ownership_torch(users, pos, neg, batch_size, n_users, n_items):
     """For an epoch laid out in visiting order: which rows occur ONCE in their batch and which several times.
 
@@ -695,8 +723,8 @@ class MFEngine(ModelEngine):
         """(users, pos, neg, perm) when the loader's data is resident and can be batched on device."""
         seed = None
         if isinstance(train_loader, DeviceTripleBatcher):
-            if (train_loader.native_shuffle() and train_loader.batch_size <= 8192
-                    and train_loader.user_tensor.device == self.model.flat.device):
+            if (train_loader.native_shuffle() and train_loader.user_tensor.device == self.model.flat.device
+                    and (train_loader.batch_size <= 8192 or self.loss == "bpr")):
                 ds, perm, seed = train_loader, None, train_loader.draw_seed()  # shuffle folded into the staging kernel
             else:
                 ds, perm = train_loader, train_loader.permutation()
@@ -737,6 +765,29 @@ class MFEngine(ModelEngine):
             ou, op, on = torch.empty_like(users), torch.empty_like(pos), torch.empty_like(neg)
             self._stage_into(users, pos, neg, perm, seed, bs, ou, op, on)
             return ou, op, on, None, bs
+        if dev.type == "cuda" and self.loss == "bpr" and users.numel() > 0 and bs >= self.SORT_MIN_BATCH:
+            # batches beyond the LDS sort (configs[3]: 65 536): sort keys (batch, item) in one launch with the shuffle
+            # evaluated on the fly, ONE device sort, one gather of the three arrays through its permutation (round 3:
+            # permutation, arange / div / add, argsort and five index gathers -- a dozen launches).  The sorted
+            # layout visits neighbouring table rows in neighbouring groups; grouping in hash order instead
+            # (group_epoch_by_item: no sort at all) measured 3 % slower per step.
+            lib, n = _lib.load(), users.numel()
+            n_batches = (n + bs - 1) // bs
+            small = n_batches * self.model.n_items < 2**31
+            keys = torch.empty(n, dtype=torch.int32 if small else torch.int64, device=dev)
+            shuffle = 1 if seed is not None else 0
+            _lib.check(lib.hiprec_stage_sort_keys(_lib.ptr(pos), _lib.ptr(perm), shuffle, seed or 0, n, bs,
+                                                  self.model.n_items, 4 if small else 8, _lib.ptr(keys),
+                                                  _lib.stream_ptr(dev)))
+            order = torch.sort(keys, stable=False).indices
+            ou, op, on = torch.empty_like(users), torch.empty_like(pos), torch.empty_like(neg)
+            _lib.check(lib.hiprec_gather_epoch(
+                _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), _lib.ptr(perm), shuffle, seed or 0, _lib.ptr(order), n,
+                _lib.ptr(ou), _lib.ptr(op), _lib.ptr(on), _lib.stream_ptr(dev)))
+            return ou, op, on, None, bs
+        if seed is not None and perm is None:   # (the sort-free path above did not apply: materialise the shuffle)
+            perm = torch.empty(users.numel(), dtype=torch.int64, device=dev)
+            _lib.check(_lib.load().hiprec_random_permutation(_lib.ptr(perm), perm.numel(), seed, _lib.stream_ptr(dev)))
         if bs >= self.SORT_MIN_BATCH:
             perm = sort_within_batches(perm, pos, bs, self.model.n_items)
         if perm is not None:
@@ -865,9 +916,14 @@ class MFEngine(ModelEngine):
         """Wrap a staged epoch; the owned-rows SGD step also needs to know which rows its batches share."""
         if staged is None:
             return None
+        owned = self._sgd_modes()[1] and self.loss == "bpr"
+        if getattr(staged, "own", None) is not None:     # the sort-free grouping made the ownership arrays on the way
+            if not owned:
+                staged.own = None
+            return staged
         prepared = PreparedEpoch(staged)
         users, pos, neg, perm, bs = prepared
-        if self._sgd_modes()[1] and self.loss == "bpr" and perm is None and users.device.type == "cuda":
+        if owned and perm is None and users.device.type == "cuda":
             prepared.own = batch_row_ownership(users, pos, neg, bs, self.model.n_users, self.model.n_items)
         return prepared
 

@@ -396,6 +396,29 @@ int hiprec_batch_row_ownership_tables(const int64_t* users, const int64_t* pos, 
                                       int64_t batch, int64_t n_users, int64_t n_items, int32_t table_bits,
                                       int32_t* keys, int32_t* total, int32_t* own, int32_t* tab_keys, int32_t* pos_cnt,
                                       int32_t* occ, void* stream);
+/* Staging of batches beyond hiprec_stage_epoch's 8192-key LDS sort, around ONE device sort of the caller's (the
+ * reference's loader collates per batch on the host, data/base_data.py:247-253).  visit(j) = perm[j], or P_seed(j)
+ * (perm NULL, shuffle != 0: hiprec_random_permutation's Feistel shuffle evaluated on the fly), or j.
+ *  hiprec_stage_sort_keys  keys[j] = (j / batch) * n_items + items[visit(j)] (int32 when key_bytes == 4: needs
+ *      n_batches * n_items < 2^31): sorting them groups every batch by item in ascending row order.
+ *  hiprec_gather_epoch     out[j] = in[visit(order ? order[j] : j)] for the three arrays in one launch (order = the
+ *      sort's permutation; NULL = the plain visiting order). */
+int hiprec_stage_sort_keys(const int64_t* items, const int64_t* perm, int32_t shuffle, uint64_t seed, int64_t n,
+                           int64_t batch, int64_t n_items, int32_t key_bytes, void* keys, void* stream);
+int hiprec_gather_epoch(const int64_t* users, const int64_t* pos, const int64_t* neg, const int64_t* perm,
+                        int32_t shuffle, uint64_t seed, const int64_t* order, int64_t n, int64_t* users_out,
+                        int64_t* pos_out, int64_t* neg_out, void* stream);
+/* A staged epoch re-laid with every batch GROUPED BY POSITIVE ITEM without any sort (groups in hash-table order, not row
+ * order: measured 3 % slower per step than the sorted layout at configs[3], so the engines keep the device sort and
+ * this stays an option for callers without one): from what
+ * hiprec_batch_row_ownership_tables made of the epoch -- own, occ, tab_keys, pos_cnt -- an exclusive scan of the item
+ * entries' pos_cnt per batch (pos_cnt is OVERWRITTEN with every item's first position) and one scatter of the triples
+ * and their ownership slots.  invalid_cnt[n_batches]: work space.  Triples with an out-of-range id (own = -1) are
+ * parked at the end of their batch.  Not in place. */
+int hiprec_group_epoch_by_item(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n, int64_t batch,
+                               int64_t n_users, int32_t table_bits, const int32_t* own, const int32_t* occ,
+                               const int32_t* tab_keys, int32_t* pos_cnt, int32_t* invalid_cnt, int64_t* users_out,
+                               int64_t* pos_out, int64_t* neg_out, int32_t* own_out, void* stream);
 int64_t hiprec_plan_route_tiles(int64_t n, int64_t batch);
 int hiprec_plan_route_triples(const int64_t* users, const int64_t* pos, const int64_t* neg, const int64_t* perm,
                               int64_t n, int64_t batch, int32_t world, int64_t n_users, int64_t n_items,

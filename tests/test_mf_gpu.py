@@ -1121,3 +1121,68 @@ def test_golden_suite_against_the_ieee_arithmetic_build(hip_device):
         env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
+
+
+@pytest.mark.parametrize("n,bs,U,I,shuffle", [(3 * 9000 + 77, 9000, 500, 300, True), (2 * 65536 + 5, 65536, 200_000, 20_000, True),
+                                             (20_000, 10_000, 50, 7, False)])
+def test_epoch_grouped_by_positive_item_without_a_sort(hip_device, n, bs, U, I, shuffle):
+    """Batches beyond the staging kernel's LDS sort (> 8192 triples): hiprec_gather_epoch + the ownership tables +
+    hiprec_group_epoch_by_item (csrc/ownership.hip) replace torch.argsort and the index gathers.  Every batch keeps its
+    triples (as a multiset), equal positive items are adjacent, the ownership arrays of the new layout meet their
+    contract (brute-force count), out-of-range triples are parked at the batch's end with own = -1, and the Feistel
+    shuffle evaluated on the fly equals hiprec_random_permutation's."""
+    from beta_recsys_amd import _lib
+    from beta_recsys_amd.mf import group_epoch_by_item
+    from test_host_logic import _brute_force_ownership_check
+
+    lib, dev = _lib.load(), hip_device
+    rng = np.random.default_rng(n)
+    users, pos, neg = _zipf_triples(rng, n, U, I)
+    bad = rng.integers(0, n, 3)
+    pos[bad[0]], users[bad[1]], neg[bad[2]] = I, U + 5, -1          # three triples with an out-of-range id
+    tu, tp, tn = (torch.from_numpy(a).to(dev) for a in (users, pos, neg))
+    seed = 12345
+    ou, op, on = torch.empty_like(tu), torch.empty_like(tp), torch.empty_like(tn)
+    _lib.check(lib.hiprec_gather_epoch(_lib.ptr(tu), _lib.ptr(tp), _lib.ptr(tn), None, 1 if shuffle else 0, seed, None, n,
+                                       _lib.ptr(ou), _lib.ptr(op), _lib.ptr(on), _lib.stream_ptr(dev)))
+    perm = torch.arange(n, device=dev)
+    if shuffle:
+        _lib.check(lib.hiprec_random_permutation(_lib.ptr(perm), n, seed, _lib.stream_ptr(dev)))
+    assert torch.equal(ou, tu[perm]) and torch.equal(op, tp[perm]) and torch.equal(on, tn[perm])
+    # the engines' path: sort keys (batch, clamped item) + one device sort + a gather through its permutation
+    keys = torch.empty(n, dtype=torch.int32, device=dev)
+    _lib.check(lib.hiprec_stage_sort_keys(_lib.ptr(tp), None, 1 if shuffle else 0, seed, n, bs, I, 4, _lib.ptr(keys),
+                                          _lib.stream_ptr(dev)))
+    assert torch.equal(keys.long(), torch.arange(n, device=dev) // bs * I + tp[perm].clamp(0, I - 1))
+    order = torch.sort(keys).indices
+    su, sp, sn = torch.empty_like(tu), torch.empty_like(tp), torch.empty_like(tn)
+    _lib.check(lib.hiprec_gather_epoch(_lib.ptr(tu), _lib.ptr(tp), _lib.ptr(tn), None, 1 if shuffle else 0, seed,
+                                       _lib.ptr(order), n, _lib.ptr(su), _lib.ptr(sp), _lib.ptr(sn), _lib.stream_ptr(dev)))
+    assert torch.equal(su, ou[order]) and torch.equal(sp, op[order]) and torch.equal(sn, on[order])
+    gu, gp, gn, (own, total, stride) = group_epoch_by_item(ou, op, on, bs, U, I)
+    vu, vp, vn = (t.cpu().numpy() for t in (ou, op, on))
+    hu, hp_, hn = (t.cpu().numpy() for t in (gu, gp, gn))
+    hown = own.cpu().numpy()
+    for k in range(0, n, bs):
+        a = np.stack([vu[k:k + bs], vp[k:k + bs], vn[k:k + bs]], 1)
+        b = np.stack([hu[k:k + bs], hp_[k:k + bs], hn[k:k + bs]], 1)
+        assert np.array_equal(a[np.lexsort(a.T)], b[np.lexsort(b.T)]), "a batch lost or gained triples"
+        ok = (b[:, 0] >= 0) & (b[:, 0] < U) & (b[:, 1] >= 0) & (b[:, 1] < I) & (b[:, 2] >= 0) & (b[:, 2] < I)
+        n_ok = int(ok.sum())
+        assert ok[:n_ok].all(), "out-of-range triples must sit at the end of their batch"
+        assert (hown[:, k + n_ok:k + len(b)] == -1).all()
+        p = b[:n_ok, 1]
+        starts = np.flatnonzero(np.r_[True, p[1:] != p[:-1]])
+        assert len(starts) == len(np.unique(p)), "equal positive items must be adjacent"
+    # the kernel gives every valid row a slot; one that occurs once has total == 1 (the step treats it like -1)
+    bid = (torch.arange(n, device=dev) // bs).repeat(3).view(3, n)
+    shared = (own >= 0) & (total[bid, own.clamp(min=0).long()] > 1)
+    assert bool(((own >= 0) | (total[bid, own.clamp(min=0).long()] >= 0)).all())
+    if n <= 30_000:
+        norm = torch.where(shared, own, torch.full_like(own, -1))
+        _brute_force_ownership_check(hu, hp_, hn, bs, U, I, norm.cpu().numpy(), total.cpu().numpy())
+    else:   # vectorised: a slot's total equals the number of occurrences that point at it, per batch
+        flat = (bid.long() * stride + own.clamp(min=0).long())[own >= 0]
+        cnt = torch.bincount(flat, minlength=total.numel()).view_as(total)
+        used = cnt > 0
+        assert torch.equal(cnt[used], total[used].long())
