@@ -359,3 +359,66 @@ def test_mf_engine_lazy_epoch_in_pieces_and_around_a_dense_step(hip_device):
     assert step == len(visited) and not eng._lazy["dirty"]
     # (that the flush leaves the dense sweeps' bits is test_lazy_rows_equal_the_dense_sweeps_bit_for_bit's business)
     assert all(torch.isfinite(t).all() for t in list(m.values()) + list(v.values()))
+
+
+@pytest.mark.parametrize("engine", ["sharded", "single"])
+def test_lazy_adam_at_the_configs3_shard_size(nccl_group, hip_device, engine):
+    """One rank's share of BASELINE configs[3] (1.25 M x 125 k rows, dim 128, 65 536 triples per step, Zipf positives)
+    with the reference's default optimizer: `dense_opt: "auto"` picks the lazy form at this size, on the row-sharded
+    planned path (world 1, C driver) and on MFEngine.  Two epochs of two steps against the numpy oracle's DENSE Adam on
+    the compacted problem (the rows the batches touch, renumbered: a never-touched row has zero moments and does not
+    move under dense Adam either): epoch loss sums to 1e-5, every touched element inside the legal-trajectory envelope,
+    every other row bit-identical with stamp -1, no gradient left behind."""
+    import beta_recsys_amd as hp
+    from beta_recsys_amd.sharded import ShardedMFEngine
+
+    U, I, D, B, steps, lr = 1_250_000, 125_000, 128, 65536, 2, 0.05
+    rng = np.random.default_rng(21)
+    pz = 1.0 / np.arange(1, I + 1)
+    users = rng.integers(0, U, steps * B)
+    pos = rng.permutation(I)[rng.choice(I, steps * B, p=pz / pz.sum())]
+    neg = rng.integers(0, I, steps * B)
+    cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer="adam", lr=lr, batch_size=B,
+                         loss="bpr", shard_init="local", prefetch_epoch=False), "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+    torch.manual_seed(5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = ShardedMFEngine(cfg) if engine == "sharded" else hp.MFEngine(cfg)
+    if engine == "single":
+        eng._setup()
+    assert eng._lazy is not None, "64 MB of parameters and more take the lazy optimizer"
+    m = eng.model
+    w0 = m.flat.clone()
+    loader = hp.DeviceTripleBatcher(*(torch.from_numpy(a).cuda() for a in (users, pos, neg)), B, shuffle=False)
+    sums = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for e in range(2):
+            out = eng.train_an_epoch(loader, e)
+            sums.append(out[0] if engine == "sharded" else eng.writer.scalars[-2][1])
+    uu, u_inv = np.unique(users, return_inverse=True)
+    ui, i_inv = np.unique(np.concatenate([pos, neg]), return_inverse=True)
+    tu, ti = torch.from_numpy(uu).cuda(), torch.from_numpy(ui).cuda()
+    ue0, ie0, ub0, ib0, gb0 = m._views(w0)
+    wc0 = {"user_emb.weight": ue0[tu].cpu().numpy(), "item_emb.weight": ie0[ti].cpu().numpy(),
+           "user_bias.weight": ub0[tu].cpu().numpy(), "item_bias.weight": ib0[ti].cpu().numpy(),
+           "global_bias": gb0.cpu().numpy().copy()}
+    batches = [(u_inv[k * B:(k + 1) * B], i_inv[:steps * B][k * B:(k + 1) * B], i_inv[steps * B:][k * B:(k + 1) * B])
+               for _ in range(2) for k in range(steps)]
+    w_ref, env, upd, (sums_ref, _) = mf_trajectory(wc0, batches, "adam", lr, trials=2, with_sums=True)
+    w = onp.copy_params(wc0)
+    st = onp.new_opt_state(w, "adam")
+    for e in range(2):
+        tot = sum(onp.mf_train_step(w, st, b, "bpr", "adam", lr)[0] for b in batches[e * steps:(e + 1) * steps])
+        assert_scalar_close(sums[e], tot, REL, f"epoch {e} loss sum vs the oracle on the compacted problem")
+    ue, ie, ub, ib, gb = m._views(m.flat)
+    got = {"user_emb.weight": ue[tu].cpu().numpy(), "item_emb.weight": ie[ti].cpu().numpy(),
+           "user_bias.weight": ub[tu].cpu().numpy(), "item_bias.weight": ib[ti].cpu().numpy(),
+           "global_bias": gb.cpu().numpy()}
+    assert_on_trajectory(got, w_ref, env, upd, f"lazy adam at the configs[3] shard size ({engine})", pool=True)
+    for emb, emb0, bias, bias0, ids, n_rows, stamp in ((ue, ue0, ub, ub0, tu, U, eng._lazy["stamp_u"]),
+                                                      (ie, ie0, ib, ib0, ti, I, eng._lazy["stamp_i"])):
+        idle = torch.ones(n_rows, dtype=torch.bool, device="cuda")
+        idle[ids] = False
+        assert int(idle.sum()) > 0
+        assert torch.equal(emb[idle], emb0[idle]) and torch.equal(bias[idle], bias0[idle]), "an idle row moved"
+        assert bool((stamp[idle] == -1).all()) and bool((stamp[~idle] == 2 * steps).all())
+    assert float(eng._g_flat.abs().max()) == 0.0 and not eng._lazy["dirty"]
