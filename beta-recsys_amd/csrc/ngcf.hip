@@ -674,9 +674,27 @@ extern "C" int hiprec_ngcf_predict(const hiprec_ngcf_plan* plan, const int64_t* 
   return 0;
 }
 
+static int ngcf_grad_impl(const hiprec_ngcf_plan* plan, const int64_t* users, const int64_t* pos, const int64_t* neg,
+                          int64_t batch, float inv_batch, hiprec_stats* stats, void* scratch, size_t scratch_bytes,
+                          void* stream);
+
 extern "C" int hiprec_ngcf_grad(const hiprec_ngcf_plan* plan, const int64_t* users, const int64_t* pos,
                                 const int64_t* neg, int64_t batch, float inv_batch, hiprec_stats* stats,
                                 void* scratch, size_t scratch_bytes, void* stream) {
+  if (int rc = check_ngcf_plan(plan, true)) return rc;   // (a plan that does not check out is not touched at all)
+  const int rc = ngcf_grad_impl(plan, users, pos, neg, batch, inv_batch, stats, scratch, scratch_bytes, stream);
+  // On the sliced path nothing clears d_all per step: the backward's readers leave it zero for the next step's loss
+  // scatter.  A step that failed between the scatter and those readers would leak its gradient rows into the next
+  // one: put the contract back before reporting the error.
+  if (rc != 0)
+    (void)hipMemsetAsync(plan->d_all, 0, sizeof(float) * (plan->n_users + plan->n_items) * total_width(plan),
+                         static_cast<hipStream_t>(stream));
+  return rc;
+}
+
+static int ngcf_grad_impl(const hiprec_ngcf_plan* plan, const int64_t* users, const int64_t* pos, const int64_t* neg,
+                          int64_t batch, float inv_batch, hiprec_stats* stats, void* scratch, size_t scratch_bytes,
+                          void* stream) {
   if (int rc = check_ngcf_plan(plan, true)) return rc;
   const hiprec_ngcf_plan* p = plan;
   HIPREC_REQUIRE(p->n_users + p->n_items < (1ll << 31), "too many nodes for the 32-bit GEMM extents");
