@@ -350,6 +350,7 @@ SIGNATURES = {
          c_int64, c_int64, c_int64, c_float, c_double, _P, _P],
     ),
     "hiprec_ownership_table_bits": (c_int32, [c_int64]),
+    "hiprec_ownership_ws_ints": (c_int64, [c_int64, c_int64, c_int32]),
     "hiprec_batch_row_ownership": (
         c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
     "hiprec_mf_bpr_owned_remote_step": (

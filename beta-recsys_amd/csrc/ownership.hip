@@ -4,13 +4,13 @@
 //
 // One open-addressing hash table per batch, 2^table_bits entries (>= 4 x batch: at most 3 x batch distinct rows
 // go in); the table position of a row IS its slot id -- no compaction, no sort.  The table is cut into
-// partitions of 2^14 entries by the top bits of the hash, and one workgroup builds one (batch, partition) in
-// LDS: it scans the 32-bit keys of the batch's 3 x batch row occurrences (key = user row, or n_users + item row,
-// made once by a streaming pre-pass), inserts the ones that hash into its partition with LDS compare-and-swap +
-// linear probing (inside the partition), counts them and hands every occurrence its slot; the partition's counts
-// go to total[] in one coalesced write.  A row that occurs once has total[slot] == 1: the step kernel treats it
-// exactly like own = -1.  A first version kept the tables in global memory: 20 M device atomics per 50-batch
-// epoch, 1.5 ms; LDS atomics make it one pass over L2-resident keys per partition.
+// partitions of 2^14 entries by the top bits of the hash.  A pre-pass (one workgroup per batch) makes the 32-bit
+// keys of the batch's 3 x batch row occurrences (key = user row, or n_users + item row) and buckets them by
+// partition; one workgroup then builds one (batch, partition) in LDS from ITS bucket: LDS compare-and-swap +
+// linear probing (inside the partition), counts, and every occurrence gets its slot; the partition's counts go to
+// total[] in one coalesced write.  A row that occurs once has total[slot] == 1: the step kernel treats it
+// exactly like own = -1.  History: tables in global memory, 20 M device atomics per 50-batch epoch, 1.5 ms; LDS
+// tables with every partition's workgroup scanning all of its batch's keys, 0.37-0.41 ms; bucketed (round 4).
 #include <algorithm>
 
 #include <atomic>
@@ -21,7 +21,6 @@ namespace hiprec {
 
 constexpr int kOwnPartBits = 14;              // 16 384 entries x (key + count) = 128 KB of LDS
 constexpr int kOwnThreads = 1024;
-constexpr int kOwnUnroll = 8;                // keys in flight per thread
 
 __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
   x ^= x >> 16;
@@ -32,22 +31,112 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
   return x;
 }
 
-// key of every row occurrence, role-major ([0,n) user rows, [n,2n) positive, [2n,3n) negative item rows):
-// user row, or n_users + item row; -1 when the triple has an out-of-range id (the step kernel skips it whole)
-__global__ __launch_bounds__(kBlock) void ownership_keys_kernel(const int64_t* __restrict__ users,
-                                                                const int64_t* __restrict__ pos,
-                                                                const int64_t* __restrict__ neg, int64_t n,
-                                                                int64_t n_users, int64_t n_items,
-                                                                int32_t* __restrict__ keys) {
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
-  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < n; t += stride) {
-    const int64_t u = users[t], p = pos[t], q = neg[t];
-    const bool ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(n_users) &&
-                    static_cast<uint64_t>(p) < static_cast<uint64_t>(n_items) &&
-                    static_cast<uint64_t>(q) < static_cast<uint64_t>(n_items);
-    keys[t] = ok ? static_cast<int32_t>(u) : -1;
-    keys[n + t] = ok ? static_cast<int32_t>(n_users + p) : -1;
-    keys[2 * n + t] = ok ? static_cast<int32_t>(n_users + q) : -1;
+constexpr int kOwnMaxParts = 1024;            // table_bits <= 24: batches of up to 4 M triples
+constexpr int kBucketThreads = 256;
+constexpr int kBucketSlice = 4096;            // triples per workgroup of the pre-pass
+
+__device__ __forceinline__ uint32_t own_part(int32_t key, int table_bits, int part_bits) {
+  return table_bits == part_bits ? 0u : hash_u32(static_cast<uint32_t>(key)) >> (32 - (table_bits - part_bits));
+}
+
+// Pre-pass (round 4): the batch's 3 x cnt row occurrences become 32-bit keys (user row, or n_users + item row)
+// BUCKETED by (phase, partition of the hash): phase 0 = user and positive rows, phase 1 = negative rows.  Occurrence i
+// of the batch (role-major inside the batch: [0,cnt) users, [cnt,2cnt) positives, [2cnt,3cnt) negatives) lands in
+// bkey / bidx at 3 * t0 + position; boff[b][phase * n_parts + part] = start of a bucket, boff[b][2 * n_parts] = number
+// of valid occurrences.  Triples with an out-of-range id get own = -1 and are not bucketed.  (Round 3: every (batch,
+// partition) workgroup scanned ALL keys of its batch and kept one in n_parts -- 16 x the key traffic and hash work at
+// configs[3].)  Two launches over slices of 4096 triples: COUNT (per-workgroup histogram in LDS -> one global add per
+// bucket) and SCATTER (histogram again, one global add per bucket reserves the workgroup's range, LDS cursors inside
+// it).  The order inside a bucket is arbitrary: the ownership kernel only needs every key once.
+struct BucketTriple {
+  int32_t key[3];
+  int bucket[3];
+  bool ok;
+};
+
+__device__ __forceinline__ BucketTriple bucket_triple(const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
+                                                      const int64_t* __restrict__ neg, int64_t t, int64_t n_users,
+                                                      int64_t n_items, int table_bits, int part_bits, int n_parts) {
+  BucketTriple r;
+  const int64_t u = users[t], p = pos[t], q = neg[t];
+  r.ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(n_users) && static_cast<uint64_t>(p) < static_cast<uint64_t>(n_items) &&
+         static_cast<uint64_t>(q) < static_cast<uint64_t>(n_items);
+  r.key[0] = static_cast<int32_t>(u);
+  r.key[1] = static_cast<int32_t>(n_users + p);
+  r.key[2] = static_cast<int32_t>(n_users + q);
+  r.bucket[0] = static_cast<int>(own_part(r.key[0], table_bits, part_bits));
+  r.bucket[1] = static_cast<int>(own_part(r.key[1], table_bits, part_bits));
+  r.bucket[2] = n_parts + static_cast<int>(own_part(r.key[2], table_bits, part_bits));
+  return r;
+}
+
+// SCATTER = false: counts[b][bucket] += this slice's occurrences (counts zero on entry), own = -1 for bad triples.
+// SCATTER = true: counts holds the batch's totals; cursor[b][bucket] (zero on entry) hands out ranges.
+template <bool SCATTER>
+__global__ __launch_bounds__(kBucketThreads) void ownership_bucket_kernel(
+    const int64_t* __restrict__ users, const int64_t* __restrict__ pos, const int64_t* __restrict__ neg, int64_t n,
+    int64_t batch, int64_t n_users, int64_t n_items, int table_bits, int slices, int32_t* __restrict__ counts,
+    int32_t* __restrict__ cursor, int32_t* __restrict__ bkey, uint32_t* __restrict__ bidx, int32_t* __restrict__ boff,
+    int32_t* __restrict__ own) {
+  __shared__ int32_t s_hist[2 * kOwnMaxParts];
+  __shared__ int32_t s_base[2 * kOwnMaxParts];
+  const int part_bits = table_bits < kOwnPartBits ? table_bits : kOwnPartBits;
+  const int n_parts = 1 << (table_bits - part_bits), nb = 2 * n_parts;
+  const int64_t b = blockIdx.x / slices, t0 = b * batch, cnt = min<int64_t>(batch, n - t0);
+  const int64_t j0 = static_cast<int64_t>(blockIdx.x % slices) * kBucketSlice, j1 = min<int64_t>(cnt, j0 + kBucketSlice);
+  if (j0 >= cnt && !(SCATTER && blockIdx.x % slices == 0)) return;
+  for (int i = threadIdx.x; i < nb; i += kBucketThreads) s_hist[i] = 0;
+  __syncthreads();
+  for (int64_t j = j0 + threadIdx.x; j < j1; j += kBucketThreads) {
+    const BucketTriple r = bucket_triple(users, pos, neg, t0 + j, n_users, n_items, table_bits, part_bits, n_parts);
+    if (!r.ok) {
+      if (!SCATTER) own[t0 + j] = own[n + t0 + j] = own[2 * n + t0 + j] = -1;
+      continue;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) atomicAdd(&s_hist[r.bucket[k]], 1);
+  }
+  __syncthreads();
+  int32_t* cb = counts + b * static_cast<int64_t>(nb);
+  if constexpr (!SCATTER) {
+    for (int i = threadIdx.x; i < nb; i += kBucketThreads)
+      if (s_hist[i]) atomicAdd(cb + i, s_hist[i]);
+    return;
+  } else {
+    // bucket starts of the batch (every workgroup scans the <= 2048 totals itself), this slice's range inside each
+    if (threadIdx.x == 0) {
+      int32_t run = 0;
+      for (int i = 0; i < nb; ++i) {
+        const int32_t c = cb[i];
+        s_base[i] = run;
+        run += c;
+      }
+      if (blockIdx.x % slices == 0) {
+        int32_t* bo = boff + b * (static_cast<int64_t>(nb) + 1);
+        for (int i = 0; i < nb; ++i) bo[i] = s_base[i];
+        bo[nb] = run;
+      }
+    }
+    __syncthreads();
+    int32_t* cur = cursor + b * static_cast<int64_t>(nb);
+    for (int i = threadIdx.x; i < nb; i += kBucketThreads) {
+      const int32_t h = s_hist[i];
+      s_base[i] += h ? atomicAdd(cur + i, h) : 0;
+      s_hist[i] = 0;   // now the cursor inside the slice's range
+    }
+    __syncthreads();
+    int32_t* k_out = bkey + 3 * t0;
+    uint32_t* i_out = bidx + 3 * t0;
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += kBucketThreads) {
+      const BucketTriple r = bucket_triple(users, pos, neg, t0 + j, n_users, n_items, table_bits, part_bits, n_parts);
+      if (!r.ok) continue;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int at = s_base[r.bucket[k]] + atomicAdd(&s_hist[r.bucket[k]], 1);
+        k_out[at] = r.key[k];
+        i_out[at] = static_cast<uint32_t>(k * cnt + j);
+      }
+    }
   }
 }
 
@@ -56,8 +145,12 @@ __global__ __launch_bounds__(kBlock) void ownership_keys_kernel(const int64_t* _
 // inserted BEFORE the negative ones, so that an entry's count at that point -- pos_cnt -- is the number of POSITIVE
 // occurrences of an item row, and occ[at] (the entry's count when occurrence `at` arrived) is, for a positive
 // occurrence, its rank among them: the planner lays every batch out grouped by positive item from these two,
-// without a sort and without a second pass of atomics.
-__global__ __launch_bounds__(kOwnThreads) void ownership_kernel(const int32_t* __restrict__ keys, int64_t n,
+// without a sort.
+// One workgroup per (batch, partition): it reads ITS bucket of the pre-pass, every lane inserts one key per trip (the
+// probe loop is a chain of LDS compare-and-swap round trips whose length is the longest chain among the active lanes).
+__global__ __launch_bounds__(kOwnThreads) void ownership_kernel(const int32_t* __restrict__ bkey,
+                                                                const uint32_t* __restrict__ bidx,
+                                                                const int32_t* __restrict__ boff, int64_t n,
                                                                 int64_t batch, int table_bits,
                                                                 int32_t* __restrict__ total,
                                                                 int32_t* __restrict__ own,
@@ -72,11 +165,6 @@ __global__ __launch_bounds__(kOwnThreads) void ownership_kernel(const int32_t* _
   const uint32_t part = static_cast<uint32_t>(blockIdx.x % n_parts);
   int32_t* s_key = s_tab;
   int32_t* s_cnt = s_tab + part_size;
-  __shared__ int32_t s_qkey[kOwnThreads / kWave][2 * kWave];   // per wave: ring of filtered keys ...
-  __shared__ uint32_t s_qidx[kOwnThreads / kWave][2 * kWave];  // ... and their occurrence index inside the batch
-  const int lane = lane_id();
-  int32_t* q_key = s_qkey[wave_in_block()];
-  uint32_t* q_idx = s_qidx[wave_in_block()];
   for (uint32_t i = threadIdx.x; i < part_size; i += kOwnThreads) {
     s_key[i] = -1;
     s_cnt[i] = 0;
@@ -85,22 +173,15 @@ __global__ __launch_bounds__(kOwnThreads) void ownership_kernel(const int32_t* _
   const int64_t t0 = b * batch;
   const int64_t cnt = min<int64_t>(batch, n - t0);
   const int64_t tab0 = (b << table_bits) + (static_cast<int64_t>(part) << part_bits);
-  // phase 0: user and positive rows ([0, 2 cnt)), phase 1: negative rows
+  const int32_t* off = boff + b * (2 * static_cast<int64_t>(n_parts) + 1);
+  const int32_t* keys = bkey + 3 * t0;
+  const uint32_t* idx = bidx + 3 * t0;
+  // phase 0: user and positive rows, phase 1: negative rows
   for (int phase = 0; phase < 2; ++phase) {
-    const int64_t lo = phase == 0 ? 0 : 2 * cnt, hi = phase == 0 ? 2 * cnt : 3 * cnt;
-    // Two stages per wave.  (1) Filter: kOwnUnroll keys per lane are requested together and the ones that hash into
-    // this partition (one in n_parts) are appended to the wave's queue in LDS (ballot + prefix: order of arrival).
-    // (2) Insert: as soon as 64 are queued, every lane takes one -- the probe loop is a chain of LDS compare-and-swap
-    // round trips whose length is the longest chain among the ACTIVE lanes; run straight on the filtered stream it
-    // had ~4 active lanes per wave instruction (560-760 us per 50 x 65 536-triple epoch).
-    uint32_t q_head = 0, q_tail = 0;  // wave-uniform; the ring holds q_tail - q_head <= 2 * kWave entries
-    auto drain = [&](uint32_t n_take) {
-      const bool on = static_cast<uint32_t>(lane) < n_take;
-      const uint32_t slot = (q_head + lane) & (2 * kWave - 1);
-      const int32_t key = on ? q_key[slot] : -1;
-      const uint32_t i = on ? q_idx[slot] : 0u;
-      q_head += n_take;
-      if (!on) return;
+    const int lo = off[phase * n_parts + part], hi = off[phase * n_parts + part + 1];
+    for (int j = lo + static_cast<int>(threadIdx.x); j < hi; j += kOwnThreads) {
+      const int32_t key = keys[j];
+      const uint32_t i = idx[j];
       const int role = i < cnt ? 0 : i < 2 * cnt ? 1 : 2;
       const int64_t at = role * n + t0 + (static_cast<int64_t>(i) - role * cnt);
       uint32_t h = hash_u32(static_cast<uint32_t>(key)) & part_mask;
@@ -115,46 +196,16 @@ __global__ __launch_bounds__(kOwnThreads) void ownership_kernel(const int32_t* _
       }
       if (h == part_size) {
         own[at] = -1;
-        return;
+        continue;
       }
       const int32_t before = atomicAdd(s_cnt + h, 1);
       own[at] = static_cast<int32_t>((part << part_bits) | h);
       if (occ) occ[at] = before;
-    };
-    for (int64_t i0 = lo + (threadIdx.x & ~(kWave - 1)); i0 < hi; i0 += static_cast<int64_t>(kOwnThreads) * kOwnUnroll) {
-      int32_t key[kOwnUnroll];
-#pragma unroll
-      for (int j = 0; j < kOwnUnroll; ++j) {
-        const int64_t i = i0 + lane + static_cast<int64_t>(j) * kOwnThreads;
-        const int role = i < cnt ? 0 : i < 2 * cnt ? 1 : 2;   // (no 64-bit division here)
-        key[j] = i < hi ? keys[role * n + t0 + (i - role * cnt)] : -2;
-      }
-#pragma unroll
-      for (int j = 0; j < kOwnUnroll; ++j) {
-        const int64_t i = i0 + lane + static_cast<int64_t>(j) * kOwnThreads;
-        if (key[j] == -1 && part == 0) {  // a triple with an out-of-range id: no slot
-          const int role = i < cnt ? 0 : i < 2 * cnt ? 1 : 2;
-          own[role * n + t0 + (i - role * cnt)] = -1;
-        }
-        const bool pass = key[j] >= 0 && (n_parts == 1 || (hash_u32(static_cast<uint32_t>(key[j])) >>
-                                                            (32 - (table_bits - part_bits))) == part);
-        const unsigned long long m = __ballot(pass);
-        if (m == 0) continue;
-        if (pass) {
-          const uint32_t slot = (q_tail + __popcll(m & ((1ull << lane) - 1ull))) & (2 * kWave - 1);
-          q_key[slot] = key[j];
-          q_idx[slot] = static_cast<uint32_t>(i);
-        }
-        q_tail += __popcll(m);
-        if (q_tail - q_head >= kWave) drain(kWave);
-      }
     }
-    if (q_tail != q_head) drain(q_tail - q_head);
     __syncthreads();
     if (phase == 0 && pos_cnt) {
       for (uint32_t i = threadIdx.x; i < part_size; i += kOwnThreads) pos_cnt[tab0 + i] = s_cnt[i];
-      // the snapshot must be complete before any wave's phase 1 adds negative occurrences to s_cnt (a
-      // wave that finished its stride early raced the slower ones' reads)
+      // the snapshot must be complete before any wave's phase 1 adds negative occurrences to s_cnt
       __syncthreads();
     }
   }
@@ -275,32 +326,55 @@ using namespace hiprec;
 
 extern "C" int32_t hiprec_ownership_table_bits(int64_t batch) {
   int bits = 6;
-  while ((1ll << bits) < 4 * batch && bits < 30) ++bits;
+  while ((1ll << bits) < 4 * batch && bits < 24) ++bits;   // (batches beyond 4 M triples are refused by the kernels)
   return bits;
 }
 
+extern "C" int64_t hiprec_ownership_ws_ints(int64_t n, int64_t batch, int32_t table_bits) {
+  if (n <= 0 || batch <= 0 || table_bits < 2 || table_bits > 24) return 0;
+  const int part_bits = std::min<int>(table_bits, kOwnPartBits);
+  const int64_t n_batches = (n + batch - 1) / batch, n_parts = 1ll << (table_bits - part_bits);
+  // bucketed keys, their occurrence indices, bucket offsets, bucket totals + cursors
+  return 6 * n + n_batches * (2 * n_parts + 1) + n_batches * 4 * n_parts;
+}
+
 static int ownership_impl(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n, int64_t batch,
-                          int64_t n_users, int64_t n_items, int32_t table_bits, int32_t* keys, int32_t* total,
+                          int64_t n_users, int64_t n_items, int32_t table_bits, int32_t* ws, int32_t* total,
                           int32_t* own, int32_t* tab_keys, int32_t* pos_cnt, int32_t* occ, void* stream) {
   HIPREC_REQUIRE(n >= 0 && batch > 0 && n_users > 0 && n_items > 0, "bad sizes");
   HIPREC_REQUIRE(n_users + n_items < (1ll << 31), "row keys need n_users + n_items < 2^31");
-  HIPREC_REQUIRE(table_bits >= 2 && table_bits <= 30 && (1ll << table_bits) >= 4 * std::min<int64_t>(batch, n > 0 ? n : 1),
-                 "table of 2^%d entries is too small for batches of %lld", table_bits, (long long)batch);
+  HIPREC_REQUIRE(table_bits >= 2 && table_bits <= 24 && (1ll << table_bits) >= 4 * std::min<int64_t>(batch, n > 0 ? n : 1),
+                 "table of 2^%d entries does not fit batches of %lld (at least 4 x the batch, at most 2^24 entries)",
+                 table_bits, (long long)batch);
+  HIPREC_REQUIRE(3 * batch < (1ll << 31), "batch too large for 32-bit occurrence indices");
   if (n == 0) return 0;
-  HIPREC_REQUIRE(users && pos && neg && keys && total && own, "NULL pointer");
+  HIPREC_REQUIRE(users && pos && neg && ws && total && own, "NULL pointer");
   const int64_t n_batches = (n + batch - 1) / batch;
   const int part_bits = std::min<int>(table_bits, kOwnPartBits);
-  const int64_t grid = n_batches << (table_bits - part_bits);
+  const int64_t n_parts = 1ll << (table_bits - part_bits);
+  const int64_t grid = n_batches * n_parts;
   HIPREC_REQUIRE(grid < (1ll << 31), "too many (batch, partition) pairs");
   const size_t lds = sizeof(int32_t) * 2 * (static_cast<size_t>(1) << part_bits);
   static std::atomic<uint64_t> lds_ok{0};   // 128 KB of dynamic LDS (gfx950 has 160 KB per workgroup)
   if (int rc = allow_dynamic_lds({reinterpret_cast<const void*>(ownership_kernel)}, 2 * sizeof(int32_t) << kOwnPartBits,
                                  lds_ok, "the ownership tables"))
     return rc;
+  int32_t* bkey = ws;
+  uint32_t* bidx = reinterpret_cast<uint32_t*>(ws + 3 * n);
+  int32_t* boff = ws + 6 * n;
+  int32_t* counts = boff + n_batches * (2 * n_parts + 1);
+  int32_t* cursor = counts + n_batches * 2 * n_parts;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  ownership_keys_kernel<<<grid_for_threads(n), kBlock, 0, st>>>(users, pos, neg, n, n_users, n_items, keys);
-  ownership_kernel<<<static_cast<int>(grid), kOwnThreads, lds, st>>>(keys, n, batch, table_bits, total, own, tab_keys,
-                                                                     pos_cnt, occ);
+  const int64_t slices = (std::min<int64_t>(batch, n) + kBucketSlice - 1) / kBucketSlice;
+  HIPREC_REQUIRE(n_batches * slices < (1ll << 31), "too many pre-pass workgroups");
+  HIPREC_TRY(hipMemsetAsync(counts, 0, sizeof(int32_t) * n_batches * 4 * n_parts, st));
+  const int pre = static_cast<int>(n_batches * slices);
+  ownership_bucket_kernel<false><<<pre, kBucketThreads, 0, st>>>(users, pos, neg, n, batch, n_users, n_items, table_bits,
+                                                                 static_cast<int>(slices), counts, cursor, bkey, bidx, boff, own);
+  ownership_bucket_kernel<true><<<pre, kBucketThreads, 0, st>>>(users, pos, neg, n, batch, n_users, n_items, table_bits,
+                                                                static_cast<int>(slices), counts, cursor, bkey, bidx, boff, own);
+  ownership_kernel<<<static_cast<int>(grid), kOwnThreads, lds, st>>>(bkey, bidx, boff, n, batch, table_bits, total, own,
+                                                                     tab_keys, pos_cnt, occ);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }

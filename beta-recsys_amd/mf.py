@@ -321,7 +321,7 @@ def batch_row_ownership(users, pos, neg, batch_size, n_users, n_items):
     n_batches = max((n + batch_size - 1) // batch_size, 1)
     bits = lib.hiprec_ownership_table_bits(batch_size)
     stride = 1 << bits
-    keys = torch.empty(3 * n, dtype=torch.int32, device=dev)
+    keys = torch.empty(max(lib.hiprec_ownership_ws_ints(n, batch_size, bits), 1), dtype=torch.int32, device=dev)
     total = torch.empty((n_batches, stride), dtype=torch.int32, device=dev)
     own = torch.empty((3, n), dtype=torch.int32, device=dev)
     _lib.check(lib.hiprec_batch_row_ownership(
@@ -342,7 +342,7 @@ def group_epoch_by_item(users, pos, neg, batch_size, n_users, n_items):
     bits = lib.hiprec_ownership_table_bits(batch_size)
     stride = 1 << bits
     i32 = dict(dtype=torch.int32, device=dev)
-    keys, occ = torch.empty(3 * n, **i32), torch.empty(3 * n, **i32)
+    keys, occ = torch.empty(max(lib.hiprec_ownership_ws_ints(n, batch_size, bits), 1), **i32), torch.empty(3 * n, **i32)
     own, own2 = torch.empty((3, n), **i32), torch.empty((3, n), **i32)
     total, tab_keys, pos_cnt = (torch.empty((n_batches, stride), **i32) for _ in range(3))
     invalid = torch.empty(n_batches, **i32)

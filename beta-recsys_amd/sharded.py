@@ -196,7 +196,7 @@ class HipKernels:
         lib, tot = self.lib, S * cap
         bits = lib.hiprec_ownership_table_bits(cap)
         T = 1 << bits
-        keys, own, occ = self._i32(3 * tot), self._i32(3, tot), self._i32(3 * tot)
+        keys, own, occ = self._i32(max(lib.hiprec_ownership_ws_ints(tot, cap, bits), 1)), self._i32(3, tot), self._i32(3 * tot)
         total, tab_keys, pos_cnt, slot_of = (self._i32(S, T) for _ in range(4))
         _lib.check(lib.hiprec_batch_row_ownership_tables(
             _lib.ptr(U), _lib.ptr(P), _lib.ptr(N), tot, cap, max(n_users_local, 1), n_items, bits, _lib.ptr(keys),

@@ -320,15 +320,17 @@ int hiprec_mf_bpr_epoch_owned(float* w_flat, int64_t n_users, int64_t n_items, i
 
 /* Row ownership of a staged epoch for hiprec_mf_bpr_epoch_owned (csrc/ownership.hip): one hash table of
  * 2^table_bits entries per batch (hiprec_ownership_table_bits(batch): >= 4 x batch) built in LDS, the table
- * position of a row IS its slot, so total_stride = n_slots = 2^table_bits.  keys[3 * n] is work space; outputs:
+ * position of a row IS its slot, so total_stride = n_slots = 2^table_bits.  ws is work space of
+ * hiprec_ownership_ws_ints(n, batch, table_bits) int32s (the occurrences' keys bucketed by table partition); outputs:
  * own[3 * n] (role-major: user, positive, negative row of every triple; its three thirds are the own_u / own_p /
  * own_n of the step) = the row's slot, and total[(batch index << table_bits) + slot] = its occurrences in that
  * batch (1 for a row that occurs once: the step treats it like own = -1; 0 for unused entries).  Triples with
  * an out-of-range id get -1.  Integer work, no sort, nothing read back by the host. */
-int32_t hiprec_ownership_table_bits(int64_t batch);
+int32_t hiprec_ownership_table_bits(int64_t batch);   /* <= 24: batches of up to 4 M triples */
+int64_t hiprec_ownership_ws_ints(int64_t n, int64_t batch, int32_t table_bits);
 int hiprec_batch_row_ownership(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
                                int64_t batch, int64_t n_users, int64_t n_items, int32_t table_bits,
-                               int32_t* keys, int32_t* total, int32_t* own, void* stream);
+                               int32_t* ws, int32_t* total, int32_t* own, void* stream);
 
 /* ---- the row-sharded engine's epoch-planned SGD step (beta-recsys_amd/sharded.py).  Per step and
  * rank: hiprec_shard_gather_payload (rows of the items peers asked for) -> all-to-all -> this call ->
@@ -394,7 +396,7 @@ int hiprec_shard_finish_step(const float* g_recv, int32_t dim, const int64_t* ex
  *      -- the only rows of the gradient exchange buffer that must be zero when the step starts. */
 int hiprec_batch_row_ownership_tables(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
                                       int64_t batch, int64_t n_users, int64_t n_items, int32_t table_bits,
-                                      int32_t* keys, int32_t* total, int32_t* own, int32_t* tab_keys, int32_t* pos_cnt,
+                                      int32_t* ws, int32_t* total, int32_t* own, int32_t* tab_keys, int32_t* pos_cnt,
                                       int32_t* occ, void* stream);
 /* Staging of batches beyond hiprec_stage_epoch's 8192-key LDS sort, around ONE device sort of the caller's (the
  * reference's loader collates per batch on the host, data/base_data.py:247-253).  visit(j) = perm[j], or P_seed(j)
