@@ -440,6 +440,20 @@ def bench_mf_c4shard(args, device, full=False):
         if c4opt != "sgd":      # the timed calls advanced the optimizer clock and left a gradient behind
             eng._g_flat.zero_()
             eng._lazy_mark_current()
+    lazy = getattr(eng, "_lazy", None) is not None
+    if c4opt != "sgd":
+        # SURVEY 8d prices the reference's dense optimizer at 28 P (Adam) / 20 P (RMSprop) bytes per step; the exact lazy
+        # form moves the step's rows instead: w, m, v of its 3 rows read and written (RMSprop: w, v) on top of the
+        # gradient round trip the SGD figure counts.  The roofline below is on the bytes the form that ran moves.
+        sweep_bytes = optimizer_sweep_bytes(c4opt, eng.model.flat.numel())
+        row_bytes = {"adam": 3 * 6, "rmsprop": 3 * 4}[c4opt] * 4 * (Dc + 1)
+        bpt_run = bpt + (row_bytes if lazy else sweep_bytes / Bc)
+        kname = ("lazy step: catch-up + mf_bpr_grad_kernel<2> + update (3 launches)" if lazy
+                 else "mf_bpr_fused_kernel / dense sweep")
+        k_s = alone_s
+        traffic, traffic_src = traffic_step_from_profiles(("mf-c4_" if full else "mf-c4shard_") + c4opt, "mf_bpr_grad_kernel")
+    else:
+        sweep_bytes, bpt_run = 0, bpt
     out = {"metric": "training interactions/sec (BPR triples)", "unit": "triples/s"}
     out.update(timing_fields(per, wall, steps, Bc))
     out.update({"n_gpus": 1, "steps": steps, "warmup": warm,
@@ -459,11 +473,12 @@ def bench_mf_c4shard(args, device, full=False):
                                            "sort, layout, row ownership) on a side stream during the previous epoch",
                            "ms_per_step_kernels_alone": alone_s * 1e3,
                            "last_loss": st.loss},
-                "roofline": {"bound": "hbm", "kernel": kname, "achieved": bpt * Bc / k_s / 1e9,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bpt * Bc / k_s / 1e9 / HBM_PEAK_GBS,
-                             "algorithmic_bytes_per_launch": bpt * Bc, "kernel_us": k_s * 1e6,
+                "roofline": {"bound": "hbm", "kernel": kname, "achieved": bpt_run * Bc / k_s / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bpt_run * Bc / k_s / 1e9 / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": bpt_run * Bc, "kernel_us": k_s * 1e6,
+                             "dense_sweep_bytes_per_launch": bpt * Bc + sweep_bytes,
                              "traffic": traffic, "traffic_source": traffic_src,
-                             "step_frac": out["value"] * bpt / (HBM_PEAK_GBS * 1e9)}})
+                             "step_frac": out["value"] * bpt_run / (HBM_PEAK_GBS * 1e9)}})
     if not args.no_cpu_baseline:
         # the reference's CPU path at this size: nn.Embedding is non-sparse, so every step materialises DENSE gradients
         # of both tables (mf.py:117) and torch.optim.SGD sweeps them -- a bounded sample of a few steps
@@ -887,17 +902,18 @@ def dominant_kernel_from_profiles(workload):
     return {}
 
 
-def traffic_step_from_profiles(workload):
+def traffic_step_from_profiles(workload, step_kernel="opt_dense_kernel"):
     """HBM bytes per STEP of a workload: (FETCH_SIZE + WRITE_SIZE) x launches per step summed over its kernels, from
     the committed per-workload PMC passes (profiles/rNN_pmc_other_workloads.json: KB per dispatch and the number
-    of dispatches of every kernel).  (bytes | None, source | None)."""
+    of dispatches of every kernel).  (bytes | None, source | None).  step_kernel: a kernel that runs exactly once per
+    step (its dispatch count is the number of steps)."""
     for rnd in (ROUND, "r02"):
         try:
             name = f"{rnd}_pmc_other_workloads.json"
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 ks = json.load(f)[workload]
             # every workload ends its step with ONE dense optimizer sweep: its dispatch count is the number of steps
-            steps = max(k["n"] for name_, k in ks.items() if "opt_dense_kernel" in name_)
+            steps = max(k["n"] for name_, k in ks.items() if step_kernel in name_)
             tot = sum((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 * k["n"] / steps for k in ks.values())
             return tot, "profiles/" + name
         except Exception:

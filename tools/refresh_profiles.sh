@@ -18,6 +18,8 @@ prof adam_20 --steps 20 --warmup 5
 prof sgd --optimizer sgd --steps 500 --warmup 50
 prof mf-c4shard --workload mf-c4shard --steps 50 --warmup 5
 prof mf-c4 --workload mf-c4 --steps 50 --warmup 5
+prof mf-c4shard_adam --workload mf-c4shard --c4-optimizer adam --steps 50 --warmup 5
+prof mf-c4_adam --workload mf-c4 --c4-optimizer adam --steps 50 --warmup 5
 prof ncf --workload ncf --steps 100 --warmup 10
 prof ncf64 --workload ncf --emb-dim 64 --steps 100 --warmup 10
 prof lightgcn --workload lightgcn --steps 100 --warmup 10
@@ -36,6 +38,8 @@ pmc lightgcn --workload lightgcn --steps 50 --warmup 5
 pmc ncf --workload ncf --steps 50 --warmup 5
 pmc ncf64 --workload ncf --emb-dim 64 --steps 50 --warmup 5
 pmc mf-c4 --workload mf-c4 --steps 50 --warmup 5
+pmc mf-c4shard_adam --workload mf-c4shard --c4-optimizer adam --steps 50 --warmup 5
+pmc mf-c4_adam --workload mf-c4 --c4-optimizer adam --steps 50 --warmup 5
 pmc ngcf --workload ngcf --steps 50 --warmup 5
 cd $GRAFT_REPO_ROOT && python tools/collect_profiles.py $TAG > /dev/null
 # one line per BASELINE config WITH its cpu_baseline: configs[1] adam / adam_20, configs[2] ncf,
@@ -50,6 +54,12 @@ timeout 300 python bench.py --workload ncf --emb-dim 64 > $OUT/bench_ncf64.json 
 timeout 300 python bench.py --workload lightgcn > $OUT/bench_lightgcn.json 2> $OUT/bench_lightgcn.err
 timeout 400 python bench.py --workload mf-c4shard > $OUT/bench_mf-c4shard.json 2> $OUT/bench_mf-c4shard.err
 timeout 500 python bench.py --workload mf-c4 > $OUT/bench_mf-c4.json 2> $OUT/bench_mf-c4.err
+# the reference's default optimizer on the big tables: MFEngine's exact lazy Adam / RMSprop, and the dense sweep it replaces
+for w in mf-c4shard mf-c4; do for o in adam rmsprop; do
+  timeout 300 python bench.py --workload $w --c4-optimizer $o --no-cpu-baseline --steps 50 --warmup 5 > $OUT/bench_${w}_$o.json 2> /dev/null
+done; done
+timeout 300 python bench.py --workload mf-c4shard --c4-optimizer adam --dense-opt sweep --no-cpu-baseline --steps 50 --warmup 5 > $OUT/bench_mf-c4shard_adam_sweep.json 2> /dev/null
+timeout 400 python bench.py --workload mf-c4 --c4-optimizer adam --dense-opt sweep --no-cpu-baseline --steps 20 --warmup 2 > $OUT/bench_mf-c4_adam_sweep.json 2> /dev/null
 for w in pgmf t2v ngcf; do
   timeout 300 python bench.py --workload $w --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err
 done
