@@ -451,7 +451,8 @@ def bench_mf_c4shard(args, device, full=False):
         kname = ("lazy step: catch-up + mf_bpr_grad_kernel<2> + update (3 launches)" if lazy
                  else "mf_bpr_fused_kernel / dense sweep")
         k_s = alone_s
-        traffic, traffic_src = traffic_step_from_profiles(("mf-c4_" if full else "mf-c4shard_") + c4opt, "mf_bpr_grad_kernel")
+        traffic, traffic_src = (traffic_step_from_profiles(("mf-c4_" if full else "mf-c4shard_") + c4opt, "mf_bpr_grad_kernel")
+                                if lazy else (None, None))   # the committed PMC passes ran the lazy form
     else:
         sweep_bytes, bpt_run = 0, bpt
     out = {"metric": "training interactions/sec (BPR triples)", "unit": "triples/s"}
