@@ -268,6 +268,8 @@ SIGNATURES = {
     "hiprec_edge_dropout_mask": (c_int, [_P, c_int64, c_float, ctypes.c_uint64, ctypes.c_uint64, _P]),
     "hiprec_lightgcn_step_values": (c_int, [POINTER(LightGcnPlan), _P, c_float, c_int32, ctypes.c_uint64,
                                             ctypes.c_uint64, _P]),
+    "hiprec_lightgcn_opt_stage": (c_int, [POINTER(LightGcnPlan), c_int32, _P, _P, _P, c_double, c_double, c_double,
+                                          c_double, _P, _P, c_float, ctypes.c_uint64, ctypes.c_uint64, _P]),
     "hiprec_lightgcn_propagate": (c_int, [POINTER(LightGcnPlan), _P, c_float, _P]),
     "hiprec_lightgcn_predict": (c_int, [POINTER(LightGcnPlan), _P, _P, c_int64, _P, _P, _P]),
     "hiprec_lightgcn_grad": (

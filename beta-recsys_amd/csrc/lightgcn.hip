@@ -435,6 +435,44 @@ extern "C" int hiprec_lightgcn_step_values(const hiprec_lightgcn_plan* plan, uin
                             sliced_buf(plan, 4) + plan->sa.n_slots, static_cast<hipStream_t>(stream), in);
 }
 
+// optimizer.step() of step t AND the preparation of step t + 1 in one launch (sliced plans, device draw): the dense
+// optimizer over the N x dim embedding matrix (plan->e0 = w) writes the fresh weights row-major and in the sliced layout
+// of the next step's first pass, the rest of the grid draws the next step's dropped edge streams.  The caller starts
+// step t + 1 with dropped_ready = 1 -- provided nothing touched the weights in between.
+extern "C" int hiprec_lightgcn_opt_stage(const hiprec_lightgcn_plan* plan, int32_t kind, float* g, float* m, float* v,
+                                         double lr, double beta1, double beta2, double eps, hiprec_stats* stats,
+                                         const void* scratch, float keep_prob, uint64_t seed, uint64_t next_step,
+                                         void* stream) {
+  if (int rc = check_lg_plan(plan, false)) return rc;
+  HIPREC_REQUIRE(use_sliced(plan) && plan->slice_w == 4, "the fused optimizer launch needs a sliced plan of width 4");
+  HIPREC_REQUIRE(plan->sat.n_rows == plan->a.n_rows && plan->sat.eid, "the plan has no transposed sliced graph");
+  HIPREC_REQUIRE(g && stats, "NULL g / stats");
+  SlicedInput in;
+  in.x = plan->e0;
+  in.n_rows = plan->a.n_rows;
+  in.dim = plan->dim;
+  in.W = plan->slice_w;
+  in.row_scale = plan->sa.col_scale;
+  in.xs = sliced_buf(plan, 0);
+  in.xs_copy = sliced_buf(plan, 1);
+  SlicedOpt f;
+  f.kind = kind;
+  f.w = plan->e0;
+  f.g = g;
+  f.m = m;
+  f.v = v;
+  f.s = OptScalars{lr,
+                   static_cast<float>(lr),
+                   static_cast<float>(beta2),
+                   static_cast<float>(1.0 - beta1),
+                   static_cast<float>(1.0 - beta2),
+                   static_cast<float>(eps)};
+  f.stats = stats;
+  f.scratch = static_cast<const Scratch*>(scratch);
+  return launch_step_values(&plan->sa, &plan->sat, nullptr, true, keep_prob, seed, next_step, sliced_buf(plan, 4),
+                            sliced_buf(plan, 4) + plan->sa.n_slots, static_cast<hipStream_t>(stream), in, &f);
+}
+
 extern "C" int hiprec_lightgcn_propagate(const hiprec_lightgcn_plan* plan, const uint8_t* keep,
                                          float keep_prob, void* stream) {
   if (int rc = check_lg_plan(plan, false)) return rc;

@@ -49,9 +49,20 @@ struct SlicedInput {
   float* xs = nullptr;
   float* xs_copy = nullptr;
 };
+// the dense optimizer riding in the step-values launch (spmm_sliced.hip): w == SlicedInput::x
+struct SlicedOpt {
+  int kind = -1;
+  float* w = nullptr;
+  float* g = nullptr;
+  float* m = nullptr;
+  float* v = nullptr;
+  OptScalars s = {};
+  hiprec_stats* stats = nullptr;
+  const Scratch* scratch = nullptr;
+};
 int launch_step_values(const hiprec_sliced_csr* a, const hiprec_sliced_csr* b, uint8_t* keep, bool draw,
                        float keep_prob, uint64_t seed, uint64_t step, float* out_a, float* out_b, hipStream_t st,
-                       SlicedInput in = SlicedInput{});
+                       SlicedInput in = SlicedInput{}, const SlicedOpt* fuse = nullptr);
 int launch_to_sliced(const float* x, int64_t n_rows, int dim, int W, const float* row_scale, float* xs,
                      float* xs_copy, hipStream_t st);
 int launch_from_sliced(const float* xs, int64_t n_rows, int dim, int W, float* y, bool add, hipStream_t st);

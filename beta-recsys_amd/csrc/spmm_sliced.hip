@@ -320,10 +320,17 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
 // stream is uint16 columns instead, col16[slot] or n_rows (the zero row).  One launch serves both graphs of a
 // plan (slots of `a`, then slots of `b`); with `draw` the keep decision is the counter-based device draw itself
 // (the same function of (seed, step, edge) in both graphs) and `a`'s slots publish it to keep[] when that is given.
+// OPT >= 0 (round 4): the launch is ALSO the dense optimizer step of the matrix it lays out -- in.x is the parameter
+// buffer w, `fuse` names g / m / v: a thread updates its W floats (the shared opt_update, block 0 folds the loss
+// partials like opt_dense_kernel) and writes the fresh values row-major AND sliced.  The optimizer launch of step t then
+// prepares step t + 1 (edge streams drawn for `step`, E0 laid out): one launch instead of two, no re-read of w.
+template <int OPT>
 __global__ __launch_bounds__(kBlock) void step_values_kernel(hiprec_sliced_csr a, hiprec_sliced_csr b,
                                                              uint8_t* __restrict__ keep, int draw, float keep_prob,
                                                              uint64_t seed, uint64_t step, float* __restrict__ out_a,
-                                                             float* __restrict__ out_b, SlicedInput in) {
+                                                             float* __restrict__ out_b, SlicedInput in, SlicedOpt fuse) {
+  float step_size = 0.f, bc2_sqrt = 1.f;
+  if constexpr (OPT >= 0) step_scalars<OPT>(fuse.s, fuse.stats, &step_size, &bc2_sqrt);
   // eight consecutive slots per thread (n_slots is a multiple of 16): 16-byte loads and stores
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock, total = (a.n_slots + b.n_slots) >> 3;
   // ... and, riding on the same launch (its FIRST threads: not a tail), the step's input matrix into the sliced layout
@@ -338,7 +345,22 @@ __global__ __launch_bounds__(kBlock) void step_values_kernel(hiprec_sliced_csr a
       const int64_t o = (static_cast<int64_t>(sl) * in.n_rows + r) * in.W;
       const float f = in.row_scale ? in.row_scale[r] : 1.f;
       if (in.W == 4) {
-        const float4 v = *reinterpret_cast<const float4*>(src);
+        float4 v = *reinterpret_cast<const float4*>(src);
+        if constexpr (OPT >= 0) {
+          const int64_t at = static_cast<int64_t>(r) * in.dim + sl * in.W;
+          float4 gv = *reinterpret_cast<const float4*>(fuse.g + at), mv = float4{0.f, 0.f, 0.f, 0.f},
+                 vv = float4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (OPT == HIPREC_OPT_ADAM) mv = *reinterpret_cast<const float4*>(fuse.m + at);
+          if constexpr (OPT != HIPREC_OPT_SGD) vv = *reinterpret_cast<const float4*>(fuse.v + at);
+          opt_update<OPT>(v.x, gv.x, mv.x, vv.x, fuse.s, step_size, bc2_sqrt);
+          opt_update<OPT>(v.y, gv.y, mv.y, vv.y, fuse.s, step_size, bc2_sqrt);
+          opt_update<OPT>(v.z, gv.z, mv.z, vv.z, fuse.s, step_size, bc2_sqrt);
+          opt_update<OPT>(v.w, gv.w, mv.w, vv.w, fuse.s, step_size, bc2_sqrt);
+          *reinterpret_cast<float4*>(fuse.w + at) = v;
+          *reinterpret_cast<float4*>(fuse.g + at) = gv;
+          if constexpr (OPT == HIPREC_OPT_ADAM) *reinterpret_cast<float4*>(fuse.m + at) = mv;
+          if constexpr (OPT != HIPREC_OPT_SGD) *reinterpret_cast<float4*>(fuse.v + at) = vv;
+        }
         *reinterpret_cast<float4*>(in.xs + o) = float4{v.x * f, v.y * f, v.z * f, v.w * f};
         if (in.xs_copy) *reinterpret_cast<float4*>(in.xs_copy + o) = v;
       } else {
@@ -384,6 +406,9 @@ __global__ __launch_bounds__(kBlock) void step_values_kernel(hiprec_sliced_csr a
       *reinterpret_cast<float4*>(out + e + 4) =
           float4{kept[4] ? v1.x : 0.f, kept[5] ? v1.y : 0.f, kept[6] ? v1.z : 0.f, kept[7] ? v1.w : 0.f};
     }
+  }
+  if constexpr (OPT >= 0) {
+    if (blockIdx.x == 0 && fuse.scratch) finalize_partials(fuse.stats, fuse.scratch);
   }
 }
 
@@ -494,7 +519,7 @@ int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scal
 
 int launch_step_values(const hiprec_sliced_csr* a, const hiprec_sliced_csr* b, uint8_t* keep, bool draw,
                        float keep_prob, uint64_t seed, uint64_t step, float* out_a, float* out_b, hipStream_t st,
-                       SlicedInput in) {
+                       SlicedInput in, const SlicedOpt* fuse) {
   hiprec_sliced_csr none = {};
   if (b == nullptr) b = &none;
   HIPREC_REQUIRE(a && out_a && (a->n_slots == 0 || (a->val && a->eid)), "bad sliced graph");
@@ -504,8 +529,30 @@ int launch_step_values(const hiprec_sliced_csr* a, const hiprec_sliced_csr* b, u
   const int64_t n_in = in.x != nullptr ? in.n_rows * (in.dim / in.W) : 0;
   if (a->n_slots + b->n_slots + n_in == 0) return 0;
   HIPREC_REQUIRE(a->n_slots % 16 == 0 && b->n_slots % 16 == 0, "n_slots is not a multiple of 16");
-  step_values_kernel<<<grid_for_threads((a->n_slots + b->n_slots) / 8 + n_in), kBlock, 0, st>>>(
-      *a, *b, keep, draw ? 1 : 0, keep_prob, seed, step, out_a, out_b, in);
+  const int grid = grid_for_threads((a->n_slots + b->n_slots) / 8 + n_in);
+  const int dr = draw ? 1 : 0;
+  if (fuse == nullptr) {
+    step_values_kernel<-1><<<grid, kBlock, 0, st>>>(*a, *b, keep, dr, keep_prob, seed, step, out_a, out_b, in, SlicedOpt{});
+  } else {
+    HIPREC_REQUIRE(in.x != nullptr && in.W == 4 && in.x == fuse->w && fuse->g && fuse->stats,
+                   "the fused optimizer needs the parameter buffer as the sliced input, slice width 4");
+    switch (fuse->kind) {
+      case HIPREC_OPT_SGD:
+        step_values_kernel<HIPREC_OPT_SGD><<<grid, kBlock, 0, st>>>(*a, *b, keep, dr, keep_prob, seed, step, out_a, out_b, in, *fuse);
+        break;
+      case HIPREC_OPT_ADAM:
+        HIPREC_REQUIRE(fuse->m && fuse->v, "adam needs exp_avg / exp_avg_sq buffers");
+        step_values_kernel<HIPREC_OPT_ADAM><<<grid, kBlock, 0, st>>>(*a, *b, keep, dr, keep_prob, seed, step, out_a, out_b, in, *fuse);
+        break;
+      case HIPREC_OPT_RMSPROP:
+        HIPREC_REQUIRE(fuse->v, "rmsprop needs a square_avg buffer");
+        step_values_kernel<HIPREC_OPT_RMSPROP><<<grid, kBlock, 0, st>>>(*a, *b, keep, dr, keep_prob, seed, step, out_a, out_b, in, *fuse);
+        break;
+      default:
+        set_error("unknown optimizer kind %d", fuse->kind);
+        return HIPREC_E_UNSUPPORTED;
+    }
+  }
   HIPREC_TRY(hipGetLastError());
   return 0;
 }

@@ -404,6 +404,7 @@ class LightGCN(_FlatModel):
         """Edge keep bytes of one training step (None in eval mode)."""
         self._dropped_ready = False
         if not self.training:
+            self._staged_for = None          # an eval-mode propagation overwrites the staged buffers
             return None
         lib = self._require_hip()
         ws, gr = self.workspace(), self.graph()
@@ -422,13 +423,33 @@ class LightGCN(_FlatModel):
         else:
             raise ValueError(f"unknown dropout_rng {self.dropout_rng!r}: 'torch_cpu' or 'device'")
         if sliced:
-            plan = self.plan()
             device_draw = self.dropout_rng == "device"  # the draw is folded into the launch; no keep bytes written
+            if device_draw and getattr(self, "_staged_for", None) == (self._step,) + self._weights_version():
+                # the previous step's optimizer launch drew this step's edge streams and laid the fresh E0 out
+                # (hiprec_lightgcn_opt_stage), and nothing has written the weights since (torch counts in-place writes)
+                self._staged_for = None      # (consumed: the passes overwrite the staged buffers)
+                self._dropped_ready = True
+                return ws["keep"]
+            self._staged_for = None
+            plan = self.plan()
             _lib.check(lib.hiprec_lightgcn_step_values(ctypes.byref(plan), None if device_draw else _lib.ptr(ws["keep"]),
                                                        keep_prob, 1 if device_draw else 0, self.dropout_seed,
                                                        self._step, st))
             self._dropped_ready = True
         return ws["keep"]
+
+    def _weights_version(self):
+        """Changes whenever torch writes the weights in place -- through the flat buffer or through a parameter (they
+        count separately: a parameter's ``.data`` is a view of the flat buffer with a version counter of its own) --
+        or the buffer moves.  The library's own kernels write through raw pointers and do not count."""
+        return (self._flat._version, self.user_embedding.weight._version, self.item_embedding.weight._version,
+                self._flat.data_ptr())
+
+    def can_stage_next_step(self):
+        """True when the optimizer launch may also prepare the next training step (sliced plan of width 4, device
+        draw, training mode): see LightGCNEngine._enqueue_opt."""
+        return (self.training and self.dropout_rng == "device" and self.graph().get("slice_w", 0) == 4
+                and self.config.get("stage_next_step", True))
 
     def last_keep_mask(self):
         """Keep bytes (uint8 [nnz], forward CSR order) of the last training step's edge dropout.  With the device
@@ -456,6 +477,7 @@ class LightGCN(_FlatModel):
     def predict(self, users, items):
         """lightgcn.py:80-101: eval mode, full propagation, sigmoid of the dot product."""
         self.eval()
+        self._staged_for = None              # the propagation below overwrites what an optimizer launch may have staged
         lib = self._require_hip()
         dev = self._flat.device
         users_t, items_t = (x.to(dev, torch.int64).reshape(-1).contiguous() if torch.is_tensor(x) else
@@ -505,6 +527,25 @@ class LightGCNEngine(FlatModelEngine):
             ctypes.byref(plan), _lib.ptr(keep), float(m.config["keep_pro"]) if keep is not None else 1.0,
             _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), B, self._batch_share() / B, _lib.ptr(self._stats),
             _lib.ptr(self._scratch), self._scratch.numel(), _lib.stream_ptr(dev)))
+
+    def _enqueue_opt(self, fold_partials=True):
+        """optimizer.step().  On the sliced path with the device draw the sweep ALSO prepares the next step -- its
+        dropped edge streams (a function of seed and step number only) and the sliced layout of the weights it has just
+        written -- in the same launch (hiprec_lightgcn_opt_stage: two launches of a step become one; a short launch
+        here never costs less than ~5 us).  The model remembers what was staged; a step that finds the weights
+        touched in between (load_state_dict, a checkpoint resume) prepares itself as before."""
+        m = self.model
+        if not m.can_stage_next_step():
+            m._staged_for = None
+            return super()._enqueue_opt(fold_partials)
+        lib, opt = _lib.load(), self.optimizer
+        m._dropped_ready = False
+        plan = m.plan()
+        _lib.check(lib.hiprec_lightgcn_opt_stage(
+            ctypes.byref(plan), opt.kind, _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg), _lib.ptr(opt.exp_avg_sq), opt.lr,
+            opt.beta1, opt.beta2, opt.eps, _lib.ptr(self._stats), _lib.ptr(self._scratch) if fold_partials else None,
+            float(m.config["keep_pro"]), m.dropout_seed, m._step + 1, _lib.stream_ptr(m.flat.device)))
+        m._staged_for = (m._step + 1,) + m._weights_version()
 
     def train_single_batch(self, batch_data):
         """lightgcn.py:119-152: one step, returns ``batch_mf_loss + batch_reg_loss`` as a float."""

@@ -853,6 +853,16 @@ int hiprec_edge_dropout_mask(uint8_t* keep, int64_t nnz, float keep_prob, uint64
 int hiprec_lightgcn_step_values(const hiprec_lightgcn_plan* plan, uint8_t* keep, float keep_prob, int32_t draw,
                                 uint64_t seed, uint64_t step, void* stream);
 
+/* ---- (sliced plans of width 4, device draw) optimizer.step() of step t and the preparation of step t + 1 in ONE
+ * launch: hiprec_opt_dense_step's arithmetic over the N x dim embedding matrix plan->e0 (g / m / v laid out alike;
+ * scratch as there: the loss partials of the step's gradient call, or NULL), with the fresh weights written row-major
+ * AND in the sliced layout of the next step's first pass, and the dropped edge streams of `next_step` drawn by the rest
+ * of the grid (hiprec_lightgcn_step_values's work).  Start step t + 1 with dropped_ready = 1 if nothing has touched the
+ * weights since. */
+int hiprec_lightgcn_opt_stage(const hiprec_lightgcn_plan* plan, int32_t kind, float* g, float* m, float* v, double lr,
+                              double beta1, double beta2, double eps, hiprec_stats* stats, const void* scratch,
+                              float keep_prob, uint64_t seed, uint64_t next_step, void* stream);
+
 /* ---- LightGCN.forward (lightgcn.py:46-78): plan->acc = sum_l A^l E0 (propagated = acc/(L+1)). */
 int hiprec_lightgcn_propagate(const hiprec_lightgcn_plan* plan, const uint8_t* keep, float keep_prob,
                               void* stream);

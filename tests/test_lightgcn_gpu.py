@@ -301,3 +301,57 @@ def test_lightgcn_full_size_c5_vs_oracle(hip_device, spmm):
     assert_tensor_close(scores, olg.lightgcn_predict(w, adj, L, batch[0][:500], batch[1][:500]), 1e-5, "scores")
     with pytest.raises(IndexError):
         eng.train_single_batch((torch.tensor([0, U]), torch.tensor([0, 1]), torch.tensor([1, 2])))
+
+
+@pytest.mark.parametrize("optimizer,lr", [("adam", 0.05), ("sgd", 0.1), ("rmsprop", 0.01)])
+def test_optimizer_launch_stages_the_next_step(hip_device, optimizer, lr):
+    """Sliced path, device draw: the optimizer launch of step t also draws step t + 1's edge streams and lays the fresh
+    weights out sliced (hiprec_lightgcn_opt_stage).  Six consecutive steps against the oracle fed with the masks the
+    engine used (read back statelessly after each step), an eval-mode predict and a load_state_dict in between (both
+    invalidate what was staged), and the same run with `stage_next_step: False`: identical losses to 1e-6."""
+    U, I, D, L, B = 300, 200, 64, 2, 256
+    rng = np.random.default_rng(3)
+    rows, cols = rng.integers(0, U, 4000), rng.integers(0, I, 4000)
+    a = sp.coo_matrix((np.ones(4000, dtype=np.float32), (rows, cols + U)), shape=(U + I, U + I)).tocsr()
+    a.data[:] = 1.0
+    a = (a + a.T + sp.eye(U + I, dtype=np.float32, format="csr")).tocsr()
+    a.data[:] = 1.0
+    adj = sp.diags(1.0 / np.asarray(a.sum(1)).flatten()).dot(a).astype(np.float32).tocsr()
+    adj.sort_indices()      # the keep bytes are in the engine's CSR order: rows, then ascending columns
+    batches = [(rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)) for _ in range(6)]
+    runs = {}
+    for staged in (True, False):
+        torch.manual_seed(3)
+        eng = make_engine(U, I, D, L, optimizer, lr, B, adj, dropout_rng="device", dropout_seed=5, stage_next_step=staged)
+        assert eng.model.graph()["slice_w"] == 4
+        w = get_weights(eng)
+        w0 = {k: v.copy() for k, v in w.items()}
+        st = olg.new_opt_state(w, optimizer)
+        from beta_recsys_amd import _lib
+
+        lib, calls = _lib.load(), []
+        plain = lib.hiprec_lightgcn_step_values
+        lib.hiprec_lightgcn_step_values = lambda *a: (calls.append(eng.model._step), plain(*a))[1]   # steps that prepare themselves
+        losses = []
+        for s, batch in enumerate(batches):
+            if s == 3:      # an evaluation between two training steps overwrites the staged buffers
+                eng.model.predict(batch[0][:10], batch[1][:10])
+                eng.model.train()
+            if s == 4:      # new weights: what the optimizer launch laid out is stale
+                load_weights(eng, w)
+            if s == 5:      # ... and so it is after an in-place write to a parameter
+                with torch.no_grad():
+                    eng.model.user_embedding.weight.mul_(1.0)
+            loss = eng.train_single_batch(tuple(torch.from_numpy(x) for x in batch))
+            keep = eng.model.last_keep_mask().cpu().numpy().astype(bool)
+            ref, g_ref = olg.lightgcn_grads(w, olg.apply_edge_dropout(adj, keep, 0.6), L, *batch, 1e-5)
+            olg.opt_step(w, g_ref, st, optimizer, lr)
+            assert_scalar_close(loss, ref, what=f"loss of step {s} (staged={staged})")
+            losses.append(loss)
+        lib.hiprec_lightgcn_step_values = plain
+        # staged: steps 0 (nothing staged yet), 3 (after the predict), 4 (after load_state_dict) and 5 (after an in-place
+        # write to a parameter) prepare themselves; steps 1 and 2 find their edge streams and E0 staged
+        assert calls == ([1, 4, 5, 6] if staged else [1, 2, 3, 4, 5, 6]), calls
+        runs[staged] = (losses, get_weights(eng))
+    for a_, b_ in zip(runs[True][0], runs[False][0]):
+        assert abs(a_ - b_) <= 1e-6 * abs(b_)
