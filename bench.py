@@ -656,7 +656,7 @@ def bench_lightgcn(args, device, world=1, rank=0, dist_on=False):
     if rank != 0:
         return None
     nnz, N = adj.nnz, U + I
-    traffic, traffic_src = traffic_step_from_profiles("lightgcn")
+    traffic, traffic_src = traffic_step_from_profiles("lightgcn", "lightgcn_loss_kernel")   # one loss launch per step
     # 2L SpMMs x [nnz*(4+4) + (N+1)*8 + 2*N*D*4] bytes (+ the keep byte per edge)
     bytes_step = 2 * L * (nnz * 9 + (N + 1) * 8 + 2 * N * D * 4)
     out = {"metric": "training interactions/sec (LightGCN triples)", "unit": "triples/s"}
