@@ -107,6 +107,65 @@ def test_newer_entry_points_validate_before_touching_the_gpu():
     assert rc == -1 and b"bad permutation" in lib.hiprec_last_error()
 
 
+def test_round4_entry_points_validate_before_touching_the_gpu():
+    """The lazy optimizer, the staging helpers of big batches, the bucketed ownership tables, the LightGCN optimizer +
+    staging launch and the planned-steps driver's up-front plan check: bad arguments come back as error codes with a
+    message, nothing is launched."""
+    from beta_recsys_amd import _lib
+
+    lib = _lib.load()
+    assert lib.hiprec_lazy_state_bytes() == ctypes.sizeof(_lib.LazyState)
+    assert lib.hiprec_shard_bufs_bytes() == ctypes.sizeof(_lib.ShardBufs)
+    st = _lib.LazyState(0, 0, 0, 0, 10, 5, 8, _lib.HIPREC_OPT_SGD if hasattr(_lib, "HIPREC_OPT_SGD") else 0, 0, 0, 0, 0, 0,
+                        0.05, 0.9, 0.999, 1e-8)
+    rows = _lib.LazyRows(None, 0, None, 0, None, 0, None, 0)
+    rc = lib.hiprec_lazy_update(ctypes.byref(st), ctypes.byref(rows), None, None, None)
+    assert rc == -1 and b"NULL pointer" in lib.hiprec_last_error()
+    stats = (ctypes.c_char * 128)()
+    rc = lib.hiprec_lazy_update(ctypes.byref(st), ctypes.byref(rows), None, stats, None)
+    assert rc == -1 and b"Adam and RMSprop" in lib.hiprec_last_error()
+    st.kind = 1
+    rc = lib.hiprec_lazy_catchup(ctypes.byref(st), ctypes.byref(rows), stats, None)
+    assert rc == -1 and b"NULL buffer in the lazy optimizer state" in lib.hiprec_last_error()
+    rc = lib.hiprec_lazy_flush(None, stats, None)
+    assert rc == -1
+    rc = lib.hiprec_mf_epoch_lazy(None, None, None, None, None, None, 0, 4, 2, 1, 0.0, None, None, 0, None)
+    assert rc == -1 and b"NULL pointer" in lib.hiprec_last_error()
+
+    rc = lib.hiprec_stage_sort_keys(None, None, 0, 0, 8, 4, 10, 3, None, None)
+    assert rc == -1 and b"bad sizes" in lib.hiprec_last_error()
+    rc = lib.hiprec_stage_sort_keys(None, None, 0, 0, 8, 1, 2**30, 4, None, None)
+    assert rc == -1                                     # 8 batches x 2^30 items do not fit 32-bit keys
+    rc = lib.hiprec_gather_epoch(None, None, None, None, 0, 0, None, 5, None, None, None, None)
+    assert rc == -1 and b"NULL pointer" in lib.hiprec_last_error()
+    assert lib.hiprec_gather_epoch(None, None, None, None, 0, 0, None, 0, None, None, None, None) == 0   # nothing to do
+    rc = lib.hiprec_group_epoch_by_item(None, None, None, 8, 4, 10, 6, None, None, None, None, None, None, None, None,
+                                        None, None)
+    assert rc == -1 and b"NULL pointer" in lib.hiprec_last_error()
+
+    bits = lib.hiprec_ownership_table_bits(65536)
+    assert bits == 18 and lib.hiprec_ownership_table_bits(1 << 30) == 24
+    assert lib.hiprec_ownership_ws_ints(3 * 65536, 65536, bits) == 6 * 3 * 65536 + 3 * 33 + 3 * 64
+    assert lib.hiprec_ownership_ws_ints(10, 4, 30) == 0
+    rc = lib.hiprec_batch_row_ownership(None, None, None, 8, 1 << 23, 10, 10, 26, None, None, None, None)
+    assert rc == -1 and b"at most 2^24" in lib.hiprec_last_error()
+
+    rc = lib.hiprec_lightgcn_opt_stage(None, 1, None, None, None, 0.05, 0.9, 0.999, 1e-8, None, None, 0.6, 0, 1, None)
+    assert rc == -1 and b"NULL plan" in lib.hiprec_last_error()
+
+    # the planned-steps driver refuses a plan that does not add up BEFORE it posts anything (ADVICE r3)
+    import numpy as np
+
+    one = np.ones(4, dtype=np.int64)
+    plan = _lib.ShardPlan(1, 0, 1, 4, 4, 4, 1, 1, 1, 1, 1, 64, 1, 1, 1, np.array([0, 3], dtype=np.int64).ctypes.data,
+                          one.ctypes.data, np.array([2], dtype=np.int64).ctypes.data, np.array([1], dtype=np.int64).ctypes.data,
+                          None, 0, None, 0)
+    bufs = _lib.ShardBufs(1, 4, 4, 8, 0, 1, 1, 1, 1, 1, 1, 1, None, None, None, None, None, None, 0)
+    rc = lib.hiprec_shard_planned_steps(ctypes.byref(plan), ctypes.byref(bufs), 0, 1, 0, 0.0, 0.05, 0.9, 0.999, 1e-8, None,
+                                        None, stats, None)
+    assert rc == -1 and b"inconsistent plan" in lib.hiprec_last_error()
+
+
 def test_mf_initial_weights_match_reference_for_same_seed():
     """MF.__init__ consumes the torch RNG like models/mf.py:21-30 -> bit-identical init."""
     g = load_golden("mf_init")
