@@ -82,15 +82,23 @@ __device__ __forceinline__ void lazy_scalar_step(const LazyCtx& c, const OptScal
 }
 
 // One entry of the step's lists (or, flush, row e of the tables): which table, which row; id < 0 = nothing.
+// An entry that names the same row as the entry before it in its list is skipped (-1): the batcher groups every batch
+// by positive item, so the duplicates of a Zipf-popular item are neighbours and all but the first would only load
+// rows to lose the claim.
 template <int MODE>
 __device__ __forceinline__ int64_t lazy_entry(const LazyCtx& c, const hiprec_lazy_rows& rows, int64_t e, bool* is_item) {
   const int64_t n0 = MODE == 2 ? c.n_users : rows.n_users, n1 = MODE == 2 ? c.n_items : rows.n_items_a;
   const int64_t n2 = MODE == 2 ? 0 : rows.n_items_b;
   *is_item = e >= n0;
-  if (e < n0) return MODE == 2 ? e : rows.users[e];
-  if (e < n0 + n1) return MODE == 2 ? e - n0 : rows.items_a[e - n0];
-  if (e < n0 + n1 + n2) return rows.items_b[e - n0 - n1];
-  return rows.items_c[e - n0 - n1 - n2];
+  if constexpr (MODE == 2) return e < n0 ? e : e - n0;
+  auto at = [&](auto* list, int64_t k) -> int64_t {
+    const int64_t id = list[k];
+    return k > 0 && static_cast<int64_t>(list[k - 1]) == id ? -1 : id;
+  };
+  if (e < n0) return at(rows.users, e);
+  if (e < n0 + n1) return at(rows.items_a, e - n0);
+  if (e < n0 + n1 + n2) return at(rows.items_b, e - n0 - n1);
+  return at(rows.items_c, e - n0 - n1 - n2);
 }
 
 // Who works on a row (one lane per row calls this): `old` = the stamp found, returns whether the caller owns the row
@@ -234,17 +242,7 @@ __global__ __launch_bounds__(kBlock) void lazy_rows_kernel(LazyCtx c, hiprec_laz
   const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block(); e < total; e += n_waves) {
     bool is_item = true;
-    int64_t id;
-    if (e < n0) {
-      is_item = false;
-      id = MODE == 2 ? e : rows.users[e];
-    } else if (e < n0 + n1) {
-      id = MODE == 2 ? e - n0 : rows.items_a[e - n0];
-    } else if (e < n0 + n1 + n2) {
-      id = rows.items_b[e - n0 - n1];
-    } else {
-      id = rows.items_c[e - n0 - n1 - n2];
-    }
+    const int64_t id = lazy_entry<MODE>(c, rows, e, &is_item);
     if (id < 0) continue;  // padding of a fixed-size block / an exchange's extra row
     if (id >= (is_item ? ni : nu)) {
       if (lane == 0) atomicOr(&stats->status, HIPREC_STATUS_ROW_OOB);
