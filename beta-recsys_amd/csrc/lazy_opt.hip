@@ -21,9 +21,12 @@
 //     its real step -- after replaying what is still behind --, its gradient row is cleared, stamp = t;
 //   * flush: every lagging row of the tables is replayed up to the clock (before predict / state_dict / checkpoint /
 //     any dense sweep).
-// The lists name a step's rows with duplicates (a user that occurs twice, an item several peers ask for); the first
-// wave to raise the row's stamp (atomicMax) owns it for that launch, the others skip.  One wave per list entry,
-// lane = column (+ kWave * j), the row's bias element rides in lane 0.
+// The lists name a step's rows with duplicates (a user that occurs twice, an item several peers ask for); whoever
+// changes the row's stamp first (atomicOr of the "w ahead" flag in the catch-up, atomicExch of the step number in the
+// update) owns it for that launch, the others skip; an entry that repeats its predecessor is not even looked at.
+// dim % 4 == 0: 64 / LPR rows per wave, LPR lanes x one float4 per row and array, the row's bias element in the row's
+// first lane, row loads issued before the claim (lazy_rows_vec_kernel).  Other widths: one row per wave, lane = column
+// (+ kWave * j) (lazy_rows_kernel).
 #include <algorithm>
 
 #include "common.hpp"
