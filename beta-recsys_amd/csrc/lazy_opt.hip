@@ -128,100 +128,228 @@ __device__ __forceinline__ bool lazy_claim(int32_t* sp, int target, int* old_out
   return go;
 }
 
-// The same work with 64 / LPR rows per wave: LPR lanes per row, one float4 (16 bytes) of every array per lane, the bias
-// element in the row's first lane -- dim a multiple of 4 and <= 4 * LPR.  A wave of the one-row kernel walks its
-// entries one after the other with two or three dependent round trips each; here 2 (dim 128) or 4 (dim 64) rows'
-// chains overlap and the row loads are ISSUED BEFORE the claim (a lost claim wastes them, a won one has them in hand).
+// dim % 4 == 0: a workgroup takes 64 entries at a time.
+//   phase A (wave 0, lane = entry): the list entry, the claim on its stamp and the row's BIAS element (one element per
+//     lane: its loads are issued before the claim, its replay runs with a per-lane start) -- the rows' embeddings then
+//     have exactly dim floats and no fifth slot that only one lane in LPR would use;
+//   the entries that won their claim are ordered by stamp, oldest first (a rank by counting, 64 v_readlane), and the
+//     workgroup's four waves deal them out ROWS = 64 / LPR at a time: the rows a wave replays together lag by about the
+//     same number of steps (a wave walks from the OLDEST of its rows: with rows in list order E[max of 2 gaps] is 1.5 x
+//     the mean gap, of 4 gaps 2.1 x);
+//   phase B (every wave): LPR lanes x one float4 per row and array, the next group's loads in flight while this one is
+//     replayed (two register sets, unconditional loads so that the wait counts stay exact), the per-step scalars of up
+//     to 64 steps fetched with ONE load (lane k holds step first + k) and handed out with v_readlane.
 template <int KIND, int MODE, int LPR>
 __global__ __launch_bounds__(kBlock) void lazy_rows_vec_kernel(LazyCtx c, hiprec_lazy_rows rows, OptScalars s,
                                                                hiprec_stats* stats, const Scratch* scratch) {
   constexpr int ROWS = kWave / LPR;
-  const int lane = lane_id(), sub = lane / LPR, sl = lane % LPR;
+  constexpr bool kHasW = KIND == HIPREC_OPT_ADAM || MODE == 1;
+  constexpr bool kAdam = KIND == HIPREC_OPT_ADAM;
+  __shared__ long long s_id[kWave];
+  __shared__ int s_old[kWave];
+  __shared__ int s_order[kWave];   // sorted position -> entry (phase A's lane), bit 8 = item table
+  __shared__ int s_active;
+  const int lane = lane_id(), wv = wave_in_block(), sub = lane / LPR, sl = lane % LPR;
   const int D = c.dim;
   const long long clock = stats->step;
   float ss_now = s.lr, bc2_now = 1.f;
   if constexpr (MODE == 1) step_scalars<KIND>(s, stats, &ss_now, &bc2_now);
   const int64_t nu = c.n_users, ni = c.n_items;
   const int64_t total = MODE == 2 ? nu + ni : rows.n_users + rows.n_items_a + rows.n_items_b + rows.n_items_c;
-  const int64_t n_groups = (total + ROWS - 1) / ROWS;
-  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int64_t n_chunks = (total + kWave - 1) / kWave;
   const int target = static_cast<int>(clock);
   const long long last = MODE == 1 ? clock - 1 : clock;
-  const uint64_t row_mask = (LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull)) << (sub * LPR);
-  for (int64_t gi = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block(); gi < n_groups; gi += n_waves) {
-    const int64_t e = gi * ROWS + sub;
-    bool is_item = true, valid = e < total;
-    int64_t id = valid ? lazy_entry<MODE>(c, rows, e, &is_item) : -1;
-    if (id >= (is_item ? ni : nu)) {
-      if (sl == 0) atomicOr(&stats->status, HIPREC_STATUS_ROW_OOB);
-      id = -1;
-    }
-    valid = id >= 0;
-    const int64_t emb = (is_item ? nu * D : 0) + (valid ? id : 0) * D + 4 * sl;
-    const int64_t bias = (nu + ni) * static_cast<int64_t>(D) + (is_item ? nu : 0) + (valid ? id : 0);
-    const bool col_on = valid && 4 * sl < D, bias_on = valid && sl == 0;
-    float w[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, m[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, v[5] = {0.f, 0.f, 0.f, 0.f, 0.f},
-          g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    auto load4 = [&](const float* p, float (&dst)[5]) {
-      if (col_on) {
-        const float4 x = *reinterpret_cast<const float4*>(p + emb);
-        dst[0] = x.x, dst[1] = x.y, dst[2] = x.z, dst[3] = x.w;
-      }
-      if (bias_on) dst[4] = p[bias];
-    };
-    if (KIND == HIPREC_OPT_ADAM || MODE == 1) load4(c.w, w);
-    if constexpr (KIND == HIPREC_OPT_ADAM) load4(c.m, m);
-    load4(c.v, v);
-    if constexpr (MODE == 1) load4(c.g, g);
-    int old = 0, go = 0;
-    if (bias_on) go = lazy_claim<MODE>((is_item ? c.stamp_i : c.stamp_u) + id, target, &old) ? 1 : 0;
-    old = __shfl(old, sub * LPR);
-    go = __shfl(go, sub * LPR);
-    if (MODE != 1 && old < 0) go = 0;   // never touched: m = v = 0, nothing to replay
-    if (__ballot(go != 0) == 0ull) continue;
-    const bool w_ahead = old >= 0 && (old & kWAhead);
-    const int base = old < 0 ? -1 : (old & ~kWAhead);
-    bool moving = false;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) moving |= m[j] != 0.f || v[j] != 0.f;
-    const bool replay = go && base >= 0 && (__ballot(moving) & row_mask) != 0ull;
-    // the wave replays from the oldest of its rows; a row joins when t passes its own stamp
-    int first = replay ? base + 1 : 0x7fffffff;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off));
-    for (long long t = first; t <= last; ++t) {
+  const int64_t bias0 = (nu + ni) * static_cast<int64_t>(D);
+
+  // The zero-gradient steps (base, last] of this lane's N elements; `on` = this lane has any, `first` (uniform) = the
+  // oldest stamp of the wave's lanes that are on, + 1: the wave walks from there in blocks of 64 steps (lane k of
+  // `mine` holds the scalars of step tb + k), a lane joins when t passes its own stamp.
+  auto replay_block = [&](auto& w, auto& m, auto& v, bool on, int base, bool w_ahead, long long tb, float2 mine)
+                          __attribute__((always_inline)) {
+    constexpr int N = sizeof(w) / sizeof(w[0]);
+    const int cnt = static_cast<int>(last - tb + 1 < kWave ? last - tb + 1 : kWave);
+    for (int k = 0; k < cnt; ++k) {
       float2 sc = make_float2(s.lr, 1.f);
-      if constexpr (KIND == HIPREC_OPT_ADAM) sc = lazy_scalars_at(c, t);
-      if (!(replay && t > base)) continue;
+      if constexpr (kAdam) {
+        sc.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), k));
+        sc.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), k));
+      }
+      if (!(on && tb + k > base)) continue;
       if (MODE == 1 && w_ahead) {   // w is current already: only the moments (one fma and one multiply per step)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < N; ++j) {
           float zero = 0.f, w_unused = 0.f;
           opt_update<KIND>(w_unused, zero, m[j], v[j], s, 1.f, 1.f);
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < N; ++j) {
           float zero = 0.f;
           opt_update<KIND>(w[j], zero, m[j], v[j], s, sc.x, sc.y);
         }
       }
     }
-    if (!go) continue;
-    if constexpr (MODE == 1) {
+  };
+  // `pre` = the scalars of steps pre_tb + lane, fetched by the caller ahead of time.  The walk starts at pre_tb unless
+  // the oldest row turned out to have nothing to replay (all its moments zero); that path and the blocks after the
+  // first fetch their scalars themselves -- kept apart so that the common path has no load between its waits.
+  auto replay = [&](auto& w, auto& m, auto& v, bool on, int base, bool w_ahead, int first, float2 pre, int pre_tb)
+                    __attribute__((always_inline)) {
+    if (first > last) return;
+    long long tb = first;
+    if (first == pre_tb) {
+      replay_block(w, m, v, on, base, w_ahead, tb, pre);
+      tb += kWave;
+    }
+    for (; tb <= last; tb += kWave) {
+      float2 mine = make_float2(s.lr, 1.f);
+      if constexpr (kAdam) mine = lazy_scalars_at(c, tb + lane);
+      replay_block(w, m, v, on, base, w_ahead, tb, mine);
+    }
+  };
+
+  struct Group {
+    int64_t emb;
+    int base, first;   // first (uniform): the oldest stamp of the group's rows + 1
+    bool col_on, w_ahead;
+    float2 sc;         // the scalars of steps first + lane
+    float w[4], m[4], v[4], g[4];
+  };
+
+  for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    // ---- phase A, part 1: entries, claims, order
+    int64_t bat = bias0;
+    float bw[1] = {0.f}, bm[1] = {0.f}, bv[1] = {0.f}, bg[1] = {0.f};
+    int old = 0;
+    bool go = false;
+    if (wv == 0) {
+      const int64_t e = ch * kWave + lane;
+      bool is_item = true;
+      int64_t id = e < total ? lazy_entry<MODE>(c, rows, e, &is_item) : -1;
+      if (id >= (is_item ? ni : nu)) {
+        atomicOr(&stats->status, HIPREC_STATUS_ROW_OOB);
+        id = -1;
+      }
+      const bool ent = id >= 0;
+      bat = bias0 + (is_item ? nu : 0) + (ent ? id : 0);
+      // the bias element, issued before the claim (a lost claim wastes the loads, a won one has them in hand)
+      if (kHasW) bw[0] = c.w[bat];
+      if constexpr (kAdam) bm[0] = c.m[bat];
+      bv[0] = c.v[bat];
+      if constexpr (MODE == 1) bg[0] = c.g[bat];
+      if (ent) go = lazy_claim<MODE>((is_item ? c.stamp_i : c.stamp_u) + id, target, &old);
+      if (MODE != 1 && old < 0) go = false;   // never touched: m = v = 0, nothing to replay
+      const int n_act = __popcll(__ballot(go));
+      if (n_act > 0) {
+        const int key = !go ? 0x7fffffff : (old < 0 ? 0x7ffffffe : (old & ~kWAhead));
+        int rank = 0;
+        for (int j = 0; j < kWave; ++j) {
+          const int kj = __builtin_amdgcn_readlane(key, j);
+          rank += (kj < key || (kj == key && j < lane)) ? 1 : 0;
+        }
+        s_order[rank] = lane | (is_item ? 256 : 0);
+        s_id[lane] = id;
+        s_old[lane] = old;
+      }
+      if (lane == 0) s_active = n_act;
+    }
+    __syncthreads();
+    const int n_active = s_active;
+    if (n_active > 0) {
+      // ---- phase A, part 2: the bias elements (wave 0; the other waves are already at their rows)
+      if (wv == 0) {
+        const bool w_ahead = old >= 0 && (old & kWAhead);
+        const int base = old < 0 ? -1 : (old & ~kWAhead);
+        const bool on = go && base >= 0 && (bm[0] != 0.f || bv[0] != 0.f);
+        int first = on ? base + 1 : 0x7fffffff;
 #pragma unroll
-      for (int j = 0; j < 5; ++j) opt_update<KIND>(w[j], g[j], m[j], v[j], s, ss_now, bc2_now);
+        for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off));
+        first = __builtin_amdgcn_readfirstlane(first);
+        replay(bw, bm, bv, on, base, w_ahead, first, make_float2(s.lr, 1.f), -1);
+        if (go) {
+          if constexpr (MODE == 1) opt_update<KIND>(bw[0], bg[0], bm[0], bv[0], s, ss_now, bc2_now);
+          if (kHasW) c.w[bat] = bw[0];
+          if constexpr (MODE != 0) {   // catch-up stores only w: the moments are replayed by this step's update
+            if constexpr (kAdam) c.m[bat] = bm[0];
+            c.v[bat] = bv[0];
+            if constexpr (MODE == 1) c.g[bat] = bg[0];   // opt_update left g = 0
+          }
+        }
+      }
+      // ---- phase B: the rows, ROWS at a time in stamp order, dealt out to the waves
+      auto fetch = [&](Group& G, int gi) __attribute__((always_inline)) {
+        const int p = gi * ROWS + sub;
+        const bool valid = p < n_active;
+        const int o = s_order[valid ? p : 0];
+        const long long rid = s_id[o & 63];
+        const int r_old = s_old[o & 63];
+        G.col_on = valid && 4 * sl < D;
+        G.w_ahead = r_old >= 0 && (r_old & kWAhead);
+        G.base = r_old < 0 ? -1 : (r_old & ~kWAhead);
+        G.emb = G.col_on ? ((o & 256) ? nu * D : 0) + rid * D + 4 * sl : 0;
+        G.first = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          const int b = __builtin_amdgcn_readlane(G.base, r * LPR);
+          if (gi * ROWS + r < n_active && b >= 0) G.first = min(G.first, b + 1);
+        }
+        G.sc = make_float2(s.lr, 1.f);
+        if constexpr (kAdam) G.sc = lazy_scalars_at(c, static_cast<long long>(G.first) + lane);
+        auto load4 = [&](const float* ptr, float (&dst)[4]) __attribute__((always_inline)) {
+          const float4 x = *reinterpret_cast<const float4*>(ptr + G.emb);   // unconditional: lanes that are off read row 0
+          dst[0] = G.col_on ? x.x : 0.f, dst[1] = G.col_on ? x.y : 0.f;
+          dst[2] = G.col_on ? x.z : 0.f, dst[3] = G.col_on ? x.w : 0.f;
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) G.w[j] = G.m[j] = G.g[j] = 0.f;
+        if (kHasW) load4(c.w, G.w);
+        if constexpr (kAdam) load4(c.m, G.m);
+        load4(c.v, G.v);
+        if constexpr (MODE == 1) load4(c.g, G.g);
+      };
+      auto process = [&](Group& G) __attribute__((always_inline)) {
+        bool moving = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) moving |= G.m[j] != 0.f || G.v[j] != 0.f;
+        const bool on = G.col_on && G.base >= 0 && moving;
+        const uint64_t on_mask = __ballot(on);
+        int first = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          const uint64_t row = (LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull)) << (r * LPR);
+          const int b = __builtin_amdgcn_readlane(G.base, r * LPR);
+          if (on_mask & row) first = min(first, b + 1);
+        }
+        replay(G.w, G.m, G.v, on, G.base, G.w_ahead, first, G.sc, G.first);
+        if (!G.col_on) return;
+        if constexpr (MODE == 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) opt_update<KIND>(G.w[j], G.g[j], G.m[j], G.v[j], s, ss_now, bc2_now);
+        }
+        auto store4 = [&](float* ptr, const float (&src)[4]) __attribute__((always_inline)) {
+          *reinterpret_cast<float4*>(ptr + G.emb) = float4{src[0], src[1], src[2], src[3]};
+        };
+        if (kHasW) store4(c.w, G.w);
+        if constexpr (MODE != 0) {
+          if constexpr (kAdam) store4(c.m, G.m);
+          store4(c.v, G.v);
+          if constexpr (MODE == 1) store4(c.g, G.g);
+        }
+      };
+      Group ga, gb;
+      int gi = wv;
+      fetch(ga, gi);
+      for (;;) {
+        fetch(gb, gi + kWavesPerBlock);
+        if (gi * ROWS >= n_active) break;
+        process(ga);
+        gi += 2 * kWavesPerBlock;
+        fetch(ga, gi);
+        if ((gi - kWavesPerBlock) * ROWS >= n_active) break;
+        process(gb);
+      }
     }
-    auto store4 = [&](float* p, const float (&src)[5]) {
-      if (col_on) *reinterpret_cast<float4*>(p + emb) = float4{src[0], src[1], src[2], src[3]};
-      if (bias_on) p[bias] = src[4];
-    };
-    if (KIND == HIPREC_OPT_ADAM || MODE == 1) store4(c.w, w);
-    if constexpr (MODE != 0) {   // catch-up stores only w: the moments are replayed by this step's update
-      if constexpr (KIND == HIPREC_OPT_ADAM) store4(c.m, m);
-      store4(c.v, v);
-      if constexpr (MODE == 1) store4(c.g, g);   // opt_update left g = 0
-    }
+    __syncthreads();   // the next chunk rewrites the shared arrays
   }
   if constexpr (MODE == 1) lazy_scalar_step<KIND>(c, s, stats, scratch, clock, ss_now, bc2_now);
 }
@@ -390,7 +518,7 @@ int lazy_launch(const hiprec_lazy_state* st, const hiprec_lazy_rows* rows, const
   if (st->dim % 4 == 0) {   // 16-byte vectors, several rows per wave
 #define HIPREC_LAZY_VEC(LPR)                                                                                         \
   do {                                                                                                               \
-    const int grid = grid_for_waves((total + kWave / LPR - 1) / (kWave / LPR));                                      \
+    const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((total + kWave - 1) / kWave, kMaxBlocks))); \
     if (adam) lazy_rows_vec_kernel<HIPREC_OPT_ADAM, MODE, LPR><<<grid, kBlock, 0, stm>>>(c, r, s, stats, sc);        \
     else lazy_rows_vec_kernel<HIPREC_OPT_RMSPROP, MODE, LPR><<<grid, kBlock, 0, stm>>>(c, r, s, stats, sc);          \
   } while (0)
