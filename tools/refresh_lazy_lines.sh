@@ -17,7 +17,10 @@ cd /tmp && export TMPDIR=/tmp
 for n in planned_lazy_adam; do rm -rf $OUT/prof_$n; done
 SIZE=shard DENSE_OPT=lazy CASES=adam:c EPOCHS=4 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_planned_lazy_adam -o mf -- \
   python $GRAFT_REPO_ROOT/tools/exp_planned.py > $OUT/prof_planned_lazy_adam.log 2>&1
-rm -rf $OUT/prof_mf-c4shard_adam
-timeout 250 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_mf-c4shard_adam -o mf -- \
-  python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --workload mf-c4shard --c4-optimizer adam --steps 50 --warmup 5 > $OUT/prof_mf-c4shard_adam.log 2>&1
+for w in mf-c4shard mf-c4; do
+  rm -rf $OUT/prof_${w}_adam
+  timeout 250 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${w}_adam -o mf -- \
+    python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --workload $w --c4-optimizer adam --steps 50 --warmup 5 > $OUT/prof_${w}_adam.log 2>&1
+done
+find $OUT -name "*kernel_trace.csv" -delete
 ls $OUT | wc -l
