@@ -394,6 +394,10 @@ SIGNATURES = {
     "hiprec_lazy_mark_current": (c_int, [POINTER(LazyState), _P, _P]),
     "hiprec_mf_epoch_lazy": (c_int, [POINTER(LazyState), _T, _T, _P, _P, _P, c_int32, c_int64, c_int64, c_int32, c_float,
                                      _P, _P, c_size_t, _P]),
+    "hiprec_mf_bpr_grad_owned": (c_int, [_P, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int64, c_float,
+                                         c_float, _P, _P, _P]),
+    "hiprec_mf_epoch_lazy_owned": (c_int, [POINTER(LazyState), _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int64,
+                                           c_int32, c_float, _P, _P, _P]),
     "hiprec_shard_plan_bytes": (c_size_t, []),
     "hiprec_shard_bufs_bytes": (c_size_t, []),
     "hiprec_shard_publish_partials": (c_int, [_P, _P, c_int32, _P, c_int32, _P]),

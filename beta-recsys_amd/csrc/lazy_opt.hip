@@ -597,3 +597,30 @@ extern "C" int hiprec_mf_epoch_lazy(const hiprec_lazy_state* state, const hiprec
   }
   return 0;
 }
+
+// The same epoch with the owned-rows gradient kernel (csrc/mf_owned.hip, hiprec_mf_bpr_grad_owned) in place of the
+// atomics of mf_bpr_grad_kernel: BPR only, needs the epoch's row-ownership arrays (hiprec_batch_row_ownership: own_*
+// [n], total [n_batches][total_stride]).
+extern "C" int hiprec_mf_epoch_lazy_owned(const hiprec_lazy_state* state, const int64_t* users, const int64_t* pos,
+                                          const int64_t* neg, const int32_t* own_u, const int32_t* own_p,
+                                          const int32_t* own_n, const int32_t* total, int64_t total_stride, int64_t n,
+                                          int64_t batch, int32_t first_of_epoch, float reg_coef, hiprec_stats* stats,
+                                          void* scratch, void* stream) {
+  HIPREC_REQUIRE(state && stats && scratch, "NULL pointer");
+  HIPREC_REQUIRE(n >= 0 && batch > 0 && total_stride >= 0, "bad n / batch / total_stride");
+  HIPREC_REQUIRE(n == 0 || (users && pos && neg && own_u && own_p && own_n && total), "NULL batch / ownership arrays");
+  if (first_of_epoch)
+    if (int rc = hiprec_stats_begin_epoch(stats, stream)) return rc;
+  for (int64_t off = 0, k = 0; off < n; off += batch, ++k) {
+    const int64_t b = std::min<int64_t>(batch, n - off);  // drop_last = False
+    const float inv_b = 1.0f / static_cast<float>(b);
+    const hiprec_lazy_rows rows{users + off, b, pos + off, b, neg + off, b, nullptr, 0};
+    if (int rc = hiprec_lazy_catchup(state, &rows, stats, stream)) return rc;
+    if (int rc = hiprec_mf_bpr_grad_owned(state->w, state->g, state->n_users, state->n_items, state->dim, users + off,
+                                          pos + off, neg + off, own_u + off, own_p + off, own_n + off,
+                                          total + k * total_stride, b, inv_b, reg_coef, stats, scratch, stream))
+      return rc;
+    if (int rc = hiprec_lazy_update(state, &rows, scratch, stats, stream)) return rc;
+  }
+  return 0;
+}

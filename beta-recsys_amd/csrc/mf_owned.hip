@@ -140,6 +140,11 @@ void mf_bpr_owned_kernel(
     return;
   }
 
+  // local tables + GRAD (hiprec_mf_bpr_grad_owned): this launch is the step's *_grad launch and counts it, as
+  // mf_bpr_grad_kernel's stepper thread does (nothing in this kernel reads the clock)
+  if constexpr (GRAD && !REMOTE) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) advance_step(stats);
+  }
   float* const wf = f.w;
   const int ld = D + 1;
   const float ru = 4.f * reg_coef * inv_batch, ri = 2.f * reg_coef * inv_batch;
@@ -647,4 +652,51 @@ extern "C" int hiprec_mf_bpr_grad_remote_step(const float* w_flat, float* g_flat
   return owned_remote_impl(const_cast<float*>(w_flat), g_flat, n_users, n_items_local, dim, fetched, g_send, n_slots,
                            users, pos_slot, neg_slot, own_u, own_p, own_n, total, nullptr, nullptr, batch, inv_batch,
                            reg_coef, 0.0, stats, scratch, stream);
+}
+
+// The same launch on LOCAL tables for MFEngine's exact lazy Adam / RMSprop epochs (csrc/lazy_opt.hip): nothing is
+// updated, the complete gradient of every row of the batch goes into g_flat (laid out like w_flat, zero on entry) --
+// a plain store for a row with a single writer (it occurs once in the batch, or all its occurrences are one run of
+// equal positive items inside a wave's chunk), an atomic add otherwise.  Against the atomics of mf_bpr_grad_kernel
+// (csrc/mf.hip) this is the row-sharded step's gradient kernel: 72 instead of 98 us at configs[3]'s batch.  The loss /
+// regulariser / scalar-bias partials are left in `scratch` for the update launch (hiprec_lazy_update folds them); the
+// optimizer clock advances by one, as in hiprec_mf_bpr_grad.
+extern "C" int hiprec_mf_bpr_grad_owned(const float* w_flat, float* g_flat, int64_t n_users, int64_t n_items,
+                                        int32_t dim, const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                        const int32_t* own_u, const int32_t* own_p, const int32_t* own_n,
+                                        const int32_t* total, int64_t batch, float inv_batch, float reg_coef,
+                                        hiprec_stats* stats, void* scratch, void* stream) {
+  HIPREC_REQUIRE(w_flat && g_flat && stats && scratch, "NULL pointer");
+  HIPREC_REQUIRE(n_users > 0 && n_items > 0 && dim > 0 && dim <= 256, "owned-rows step needs 0 < dim <= 256");
+  HIPREC_REQUIRE(batch >= 0, "negative batch");
+  if (batch == 0) return 0;
+  HIPREC_REQUIRE(users && pos && neg && own_u && own_p && own_n && total, "NULL index / ownership arrays");
+  OwnedStep f;
+  f.w = const_cast<float*>(w_flat);
+  f.n_users = n_users;
+  f.n_items = n_items;
+  f.dim = dim;
+  f.apply_prev = 0;
+  f.own_u = own_u;
+  f.own_p = own_p;
+  f.own_n = own_n;
+  f.total = total;
+  f.arrived = nullptr;
+  f.acc = nullptr;
+  f.gb_read = w_flat + (n_users + n_items) * (static_cast<int64_t>(dim) + 1);
+  f.gb_write = nullptr;
+  f.scratch_prev = static_cast<const Scratch*>(scratch);
+  f.n_prev_partials = 0;
+  f.n_gather_blocks = owned_blocks(dim, batch);
+  f.lr = 0.f;
+  f.dbg = 0;
+  f.o_ie = n_users * dim;
+  f.o_ub = (n_users + n_items) * static_cast<int64_t>(dim);
+  f.o_ib = f.o_ub + n_users;
+  f.item_stride = dim;
+  f.bias_stride = 1;
+  f.item_out = nullptr;
+  f.grad_out = g_flat;
+  return launch_owned<false, true>(f, f.n_gather_blocks, static_cast<hipStream_t>(stream), users, pos, neg, batch,
+                                   inv_batch, reg_coef, stats, static_cast<Scratch*>(scratch));
 }

@@ -916,7 +916,7 @@ class MFEngine(ModelEngine):
         """Wrap a staged epoch; the owned-rows SGD step also needs to know which rows its batches share."""
         if staged is None:
             return None
-        owned = self._sgd_modes()[1] and self.loss == "bpr"
+        owned = (self._sgd_modes()[1] or self._lazy_owned()) and self.loss == "bpr"
         if getattr(staged, "own", None) is not None:     # the sort-free grouping made the ownership arrays on the way
             if not owned:
                 staged.own = None
@@ -926,6 +926,18 @@ class MFEngine(ModelEngine):
         if owned and perm is None and users.device.type == "cuda":
             prepared.own = batch_row_ownership(users, pos, neg, bs, self.model.n_users, self.model.n_items)
         return prepared
+
+    def _lazy_owned(self):
+        """Lazy Adam / RMSprop epochs (BPR) take their gradients from the owned-rows kernel (csrc/mf_owned.hip: complete
+        row gradients, plain stores for rows with a single writer) instead of mf_bpr_grad_kernel's atomics; the staged
+        epoch then carries the row-ownership arrays.  ``lazy_grad``: "owned" (default) | "atomic"."""
+        if self.model.flat.device.type != "cuda" or self.optimizer.name == "sgd":
+            return False
+        self._setup()
+        mode = self.config["model"].get("lazy_grad", "owned")
+        if mode not in ("owned", "atomic"):
+            raise ValueError(f"lazy_grad must be 'owned' or 'atomic', not {mode!r}")
+        return self._lazy is not None and mode == "owned" and self.loss == "bpr"
 
     def _fused_ok(self, perm):
         """Cache-sized tables take the one-kernel-per-step epoch driver (any of the three optimizers)."""
@@ -1001,7 +1013,7 @@ class MFEngine(ModelEngine):
                     "Dimension out of range (expected to be in range of [-1, 0], but got 1)")
             return st
         if self._lazy is not None and perm is None and self.loss in ("bpr", "bce"):
-            self._run_lazy_epoch(lib, users, pos, neg, n_run, bs, steps)
+            self._run_lazy_epoch(lib, users, pos, neg, n_run, bs, steps, getattr(prepared, "own", None))
             if not sync:
                 return None
             st = self._sync_stats()
@@ -1025,7 +1037,7 @@ class MFEngine(ModelEngine):
             perm = None if perm is None else perm[a:b]
         return self._run_unfused_epoch(lib, users, pos, neg, perm, bs, n, n_run, sync)
 
-    def _run_lazy_epoch(self, lib, users, items_a, third, n_run, bs, steps):
+    def _run_lazy_epoch(self, lib, users, items_a, third, n_run, bs, steps, own=None):
         """hiprec_mf_epoch_lazy (csrc/lazy_opt.hip): per step catch-up of the batch's rows, the gradient kernel, the
         update of the batch's rows; the piece that reaches the last step flushes, so the tables and the moments hold
         what torch.optim's dense steps would have left whenever an epoch is over."""
@@ -1036,6 +1048,19 @@ class MFEngine(ModelEngine):
         w, g = m.tables(), m.tables(self._g_flat)
         el = third.element_size()
         lz["dirty"] = True
+        if own is not None and self.loss == "bpr" and self._lazy_owned():
+            # the owned-rows gradient kernel: the epoch's ownership arrays, sliced like the triples
+            o, total, stride = own
+            _lib.check(lib.hiprec_mf_epoch_lazy_owned(
+                ctypes.byref(lz["c"]), ctypes.c_void_p(users.data_ptr() + 8 * lo),
+                ctypes.c_void_p(items_a.data_ptr() + 8 * lo), ctypes.c_void_p(third.data_ptr() + 8 * lo),
+                ctypes.c_void_p(o[0].data_ptr() + 4 * lo), ctypes.c_void_p(o[1].data_ptr() + 4 * lo),
+                ctypes.c_void_p(o[2].data_ptr() + 4 * lo), ctypes.c_void_p(total.data_ptr() + 4 * a * stride), stride,
+                hi - lo, bs, 1 if a == 0 else 0, float(self.reg), _lib.ptr(self._stats), _lib.ptr(self._scratch),
+                _lib.stream_ptr(m.flat.device)))
+            if b == n_steps:
+                self.flush_lazy()
+            return
         _lib.check(lib.hiprec_mf_epoch_lazy(
             ctypes.byref(lz["c"]), ctypes.byref(w), ctypes.byref(g), ctypes.c_void_p(users.data_ptr() + 8 * lo),
             ctypes.c_void_p(items_a.data_ptr() + 8 * lo), ctypes.c_void_p(third.data_ptr() + el * lo),

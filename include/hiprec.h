@@ -597,6 +597,21 @@ int hiprec_mf_epoch_lazy(const hiprec_lazy_state* state, const hiprec_mf_tables*
                          const int64_t* users, const int64_t* items_a, const void* third, int32_t loss_kind, int64_t n,
                          int64_t batch, int32_t first_of_epoch, float reg_coef, hiprec_stats* stats, void* scratch,
                          size_t scratch_bytes, void* stream);
+/* The BPR gradient of one batch on LOCAL tables by the owned-rows kernel (csrc/mf_owned.hip) instead of the atomics of
+ * hiprec_mf_bpr_grad: the complete gradient of every row of the batch into g_flat (laid out like w_flat, zero on entry;
+ * plain stores for rows with a single writer), nothing updated, the partials left in `scratch`, the optimizer clock
+ * advanced by one (like hiprec_mf_bpr_grad).  own_* / total: this
+ * batch's slices of hiprec_batch_row_ownership's arrays.  Replaces the autograd backward of mf.py:128-135. */
+int hiprec_mf_bpr_grad_owned(const float* w_flat, float* g_flat, int64_t n_users, int64_t n_items, int32_t dim,
+                             const int64_t* users, const int64_t* pos, const int64_t* neg, const int32_t* own_u,
+                             const int32_t* own_p, const int32_t* own_n, const int32_t* total, int64_t batch,
+                             float inv_batch, float reg_coef, hiprec_stats* stats, void* scratch, void* stream);
+/* hiprec_mf_epoch_lazy for BPR with that gradient kernel: own_* [n], total [n_batches][total_stride] from
+ * hiprec_batch_row_ownership over the staged epoch. */
+int hiprec_mf_epoch_lazy_owned(const hiprec_lazy_state* state, const int64_t* users, const int64_t* pos,
+                               const int64_t* neg, const int32_t* own_u, const int32_t* own_p, const int32_t* own_n,
+                               const int32_t* total, int64_t total_stride, int64_t n, int64_t batch,
+                               int32_t first_of_epoch, float reg_coef, hiprec_stats* stats, void* scratch, void* stream);
 
 /* ---- ONE launch of that sequence, with the buffers of this step named explicitly: for callers that
  *      have to do something between two steps -- the data-parallel engine all-reduces

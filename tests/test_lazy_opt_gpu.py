@@ -283,7 +283,7 @@ def test_lazy_parity_against_the_ieee_arithmetic_build(hip_device):
 
 # ---- MFEngine (the un-sharded drop-in engine) with the lazy optimizer ------------------------------------------------
 
-def mf_lazy_run(optimizer, lr, loss, dense_opt, pieces=None, single_between=False, reg=None):
+def mf_lazy_run(optimizer, lr, loss, dense_opt, pieces=None, single_between=False, reg=None, lazy_grad="owned"):
     import beta_recsys_amd as hp
     from test_mf_gpu import get_weights, load_weights, make_engine
 
@@ -294,10 +294,12 @@ def mf_lazy_run(optimizer, lr, loss, dense_opt, pieces=None, single_between=Fals
     p = 1.0 / np.arange(1, I + 1)
     users, pos = rng.integers(0, U // 2, n) * 2, rng.choice(I, n, p=p / p.sum())      # odd users are never drawn
     third = rng.integers(0, I, n) if loss == "bpr" else (rng.random(n) < 0.3).astype(np.float32)
-    eng = make_engine(U, I, D, optimizer, loss, lr, B, reg=reg, dense_opt=dense_opt, prefetch_epoch=False)
+    eng = make_engine(U, I, D, optimizer, loss, lr, B, reg=reg, dense_opt=dense_opt, prefetch_epoch=False,
+                      lazy_grad=lazy_grad)
     load_weights(eng, w0)
     eng._setup()
     assert (eng._lazy is not None) == (dense_opt == "lazy")
+    assert eng._lazy_owned() == (dense_opt == "lazy" and loss == "bpr" and lazy_grad == "owned")
     if loss == "bpr":
         loader = hp.DeviceTripleBatcher(*(torch.from_numpy(a).cuda() for a in (users, pos, third)), B, shuffle=False)
     else:
@@ -326,12 +328,15 @@ def mf_lazy_run(optimizer, lr, loss, dense_opt, pieces=None, single_between=Fals
     return eng, w0, visited, sums, get_weights(eng)
 
 
-@pytest.mark.parametrize("optimizer,lr,loss", [("adam", 0.05, "bpr"), ("rmsprop", 0.01, "bpr"), ("adam", 0.02, "bce")])
-def test_mf_engine_epochs_with_the_lazy_optimizer(hip_device, optimizer, lr, loss):
-    """MFEngine.train_an_epoch with ``dense_opt: "lazy"`` (hiprec_mf_epoch_lazy: catch-up, gradient kernel, update per
-    step, flush at the end of the epoch): epoch sums to 1e-5 of the oracle's, every weight on the oracle's trajectory,
-    never-drawn users bit-identical with stamp -1, the gradient buffer clean -- like the dense-sweep engine."""
-    eng, w0, visited, sums, got = mf_lazy_run(optimizer, lr, loss, "lazy")
+@pytest.mark.parametrize("optimizer,lr,loss,lazy_grad", [
+    ("adam", 0.05, "bpr", "owned"), ("adam", 0.05, "bpr", "atomic"), ("rmsprop", 0.01, "bpr", "owned"),
+    ("rmsprop", 0.01, "bpr", "atomic"), ("adam", 0.02, "bce", "owned")])
+def test_mf_engine_epochs_with_the_lazy_optimizer(hip_device, optimizer, lr, loss, lazy_grad):
+    """MFEngine.train_an_epoch with ``dense_opt: "lazy"`` (hiprec_mf_epoch_lazy / _lazy_owned: catch-up, gradient kernel
+    -- the owned-rows kernel or mf_bpr_grad_kernel's atomics --, update per step, flush at the end of the epoch): epoch
+    sums to 1e-5 of the oracle's, every weight on the oracle's trajectory, never-drawn users bit-identical with stamp
+    -1, the gradient buffer clean -- like the dense-sweep engine."""
+    eng, w0, visited, sums, got = mf_lazy_run(optimizer, lr, loss, "lazy", lazy_grad=lazy_grad)
     _, _, _, sums_s, got_s = mf_lazy_run(optimizer, lr, loss, "sweep")
     per = len(visited) // 2
     w = onp.copy_params(w0)
@@ -422,3 +427,54 @@ def test_lazy_adam_at_the_configs3_shard_size(nccl_group, hip_device, engine):
         assert torch.equal(emb[idle], emb0[idle]) and torch.equal(bias[idle], bias0[idle]), "an idle row moved"
         assert bool((stamp[idle] == -1).all()) and bool((stamp[~idle] == 2 * steps).all())
     assert float(eng._g_flat.abs().max()) == 0.0 and not eng._lazy["dirty"]
+
+
+@pytest.mark.parametrize("D,B,grouped", [(64, 1000, True), (128, 4096, True), (100, 777, False), (256, 512, True)])
+def test_owned_gradient_kernel_on_local_tables(hip_device, D, B, grouped):
+    """hiprec_mf_bpr_grad_owned (the gradient launch of hiprec_mf_epoch_lazy_owned): the dense gradient of one batch
+    -- Zipf positives, so rows with one writer (plain stores) and shared rows (atomic adds) both occur; batches grouped
+    by positive item as the batcher leaves them, and in drawing order -- against the oracle's, judged like every
+    gradient (within 1e-5 of its scale of the exact fp64 gradient + twice the fp32 reference's own distance);
+    rows the batch does not name stay exactly zero; nothing is written to the parameters; the clock moves by one."""
+    from beta_recsys_amd import _lib
+    from beta_recsys_amd.mf import batch_row_ownership, read_stats
+    from helpers import assert_grads_as_accurate, float64_oracle, to64
+
+    lib, dev = _lib.load(), torch.device("cuda:0")
+    U, I = 5000, 300
+    w0 = onp.init_params(U, I, D, seed=7)
+    rng = np.random.default_rng(3)
+    p = 1.0 / np.arange(1, I + 1)
+    users, pos, neg = rng.integers(0, U, B), rng.choice(I, B, p=p / p.sum()), rng.integers(0, I, B)
+    if grouped:
+        order = np.argsort(pos, kind="stable")
+        users, pos, neg = users[order], pos[order], neg[order]
+    names = ["user_emb.weight", "item_emb.weight", "user_bias.weight", "item_bias.weight", "global_bias"]
+    flat = torch.from_numpy(np.concatenate([np.asarray(w0[k], dtype=np.float32).ravel() for k in names])).to(dev)
+    before = flat.clone()
+    g = torch.zeros_like(flat)
+    tu, tp, tn = (torch.from_numpy(a).to(dev) for a in (users, pos, neg))
+    own, total, stride = batch_row_ownership(tu, tp, tn, B, U, I)
+    stats = new_stats(lib, _lib, dev)
+    scratch = torch.zeros(lib.hiprec_scratch_bytes(0), dtype=torch.uint8, device=dev)
+    _lib.check(lib.hiprec_mf_bpr_grad_owned(
+        _lib.ptr(flat), _lib.ptr(g), U, I, D, _lib.ptr(tu), _lib.ptr(tp), _lib.ptr(tn), _lib.ptr(own[0]),
+        _lib.ptr(own[1]), _lib.ptr(own[2]), _lib.ptr(total), B, 1.0 / B, 0.0, _lib.ptr(stats), _lib.ptr(scratch),
+        _lib.stream_ptr(dev)))
+    torch.cuda.synchronize()
+    assert torch.equal(flat, before) and read_stats(stats).step == 1   # the launch counts the step
+    gh = g.cpu().numpy()
+    sizes = [U * D, I * D, U, I, 1]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    got = {k: gh[offs[j]:offs[j + 1]].reshape(np.shape(w0[k])) for j, k in enumerate(names[:4])}
+    _, _, ref = onp.mf_bpr_grads(w0, users, pos, neg)
+    with float64_oracle():
+        _, _, exact = onp.mf_bpr_grads(to64(w0), users, pos, neg)
+    keys = names[:4]
+    assert_grads_as_accurate(got, {k: ref[k] for k in keys}, {k: exact[k] for k in keys},
+                             f"owned gradient D={D} B={B}")
+    assert gh[offs[4]] == 0.0   # the scalar's gradient travels in the scratch partials
+    idle_u = np.setdiff1d(np.arange(U), users)
+    idle_i = np.setdiff1d(np.arange(I), np.concatenate([pos, neg]))
+    assert not got["user_emb.weight"][idle_u].any() and not got["item_emb.weight"][idle_i].any()
+    assert not got["user_bias.weight"].ravel()[idle_u].any() and not got["item_bias.weight"].ravel()[idle_i].any()
