@@ -417,6 +417,8 @@ def bench_mf_c4shard(args, device, full=False):
         kname, k_s = "mf_bpr_owned_kernel<2> (gather + score + BPR grad + in-place SGD rows, 1 launch/step)", alone_s
         traffic, traffic_src = traffic_from_profiles("hiprec::mf_bpr_owned_kernel<2, false, false>",
                                                      "mf-c4" if full else "mf-c4shard")
+    elif getattr(eng, "_lazy", None) is not None:
+        kname, k_s, traffic, traffic_src = None, alone_s, None, None   # the lazy step's three launches: named below
     else:
         # dominant kernel alone, back to back
         lib = eng._setup()
@@ -448,10 +450,11 @@ def bench_mf_c4shard(args, device, full=False):
         sweep_bytes = optimizer_sweep_bytes(c4opt, eng.model.flat.numel())
         row_bytes = {"adam": 3 * 6, "rmsprop": 3 * 4}[c4opt] * 4 * (Dc + 1)
         bpt_run = bpt + (row_bytes if lazy else sweep_bytes / Bc)
-        kname = ("lazy step: catch-up + mf_bpr_grad_kernel<2> + update (3 launches)" if lazy
+        kname = ("lazy step: catch-up + mf_bpr_owned_kernel<2,false,true> (gradients) + update (3 launches)" if lazy
                  else "mf_bpr_fused_kernel / dense sweep")
         k_s = alone_s
-        traffic, traffic_src = (traffic_step_from_profiles(("mf-c4_" if full else "mf-c4shard_") + c4opt, "mf_bpr_grad_kernel")
+        traffic, traffic_src = (traffic_step_from_profiles(("mf-c4_" if full else "mf-c4shard_") + c4opt,
+                                                              ("mf_bpr_owned_kernel", "mf_bpr_grad_kernel"))
                                 if lazy else (None, None))   # the committed PMC passes ran the lazy form
     else:
         sweep_bytes, bpt_run = 0, bpt
@@ -914,7 +917,8 @@ def traffic_step_from_profiles(workload, step_kernel="opt_dense_kernel"):
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 ks = json.load(f)[workload]
             # every workload ends its step with ONE dense optimizer sweep: its dispatch count is the number of steps
-            steps = max(k["n"] for name_, k in ks.items() if step_kernel in name_)
+            names = (step_kernel,) if isinstance(step_kernel, str) else tuple(step_kernel)
+            steps = max(k["n"] for name_, k in ks.items() if any(s_ in name_ for s_ in names))
             tot = sum((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 * k["n"] / steps for k in ks.values())
             return tot, "profiles/" + name
         except Exception:

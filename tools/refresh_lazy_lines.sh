@@ -3,6 +3,14 @@ TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
+# counters first: the bench lines read roofline.traffic from profiles/<tag>_pmc_other_workloads.json
+cd /tmp && export TMPDIR=/tmp
+for w in mf-c4shard mf-c4; do for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $OUT/pmc_${w}_adam_$c
+  timeout 250 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${w}_adam_$c -o mf -- \
+    python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --workload $w --c4-optimizer adam --steps 50 --warmup 5 > $OUT/pmc_${w}_adam_$c.log 2>&1
+done; done
+cd $GRAFT_REPO_ROOT && python tools/collect_profiles.py $TAG > /dev/null
 for w in mf-c4shard mf-c4; do for o in adam rmsprop; do
   timeout 300 python bench.py --workload $w --c4-optimizer $o --no-cpu-baseline --steps 50 --warmup 5 > $OUT/bench_${w}_$o.json 2> /dev/null
 done; done
