@@ -305,6 +305,11 @@ SIGNATURES = {
     ),
     "hiprec_clip_workspace_bytes": (c_size_t, []),
     "hiprec_clip_grad_norm": (c_int, [_P, c_int64, c_float, _P, c_size_t, _P]),
+    "hiprec_clip_opt_dense_step": (
+        c_int,
+        [c_int, _P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, _P, _P, c_int64, c_float, _P, c_size_t,
+         _P],
+    ),
     "hiprec_t2v_grad": (
         c_int,
         [POINTER(T2vTables), POINTER(T2vTables), _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_float, _P, _P,

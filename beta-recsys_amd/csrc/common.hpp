@@ -41,6 +41,12 @@ int hip_fail(hipError_t e, const char* what);
 int allow_dynamic_lds(std::initializer_list<const void*> kernels, size_t bytes, std::atomic<uint64_t>& done,
                       const char* what);
 
+// hiprec_opt_dense_step (csrc/optim.hip) with an optional gradient-norm clip riding in the sweep: clip_ws = the
+// workspace clip_sumsq_kernel filled (n_clip per-block sums behind two result slots), nullptr = no clip.
+int opt_dense_step_impl(int kind, float* w, float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                        double beta2, double eps, hiprec_stats* stats, const void* scratch, int64_t scalar_index,
+                        double* clip_ws, int n_clip, float max_norm, void* stream);
+
 #define HIPREC_TRY(expr)                                   \
   do {                                                     \
     hipError_t _e = (expr);                                \

@@ -304,8 +304,27 @@ extern "C" int hiprec_clip_grad_norm(float* g, int64_t n, float max_norm, void* 
   return 0;
 }
 
+// hiprec_clip_grad_norm + hiprec_opt_dense_step as two launches instead of three: the sums of squares, then ONE sweep
+// that scales and steps (csrc/optim.hip, opt_dense_kernel<KIND, true>); the scaled gradient is never written.  The
+// bits of w / m / v, of the cleared g and of workspace[0 .. 1] are those of the two calls.
+extern "C" int hiprec_clip_opt_dense_step(int kind, float* w, float* g, float* m, float* v, int64_t n, double lr,
+                                          double beta1, double beta2, double eps, hiprec_stats* stats,
+                                          const void* scratch, int64_t scalar_index, float max_norm, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  HIPREC_REQUIRE(n >= 0, "negative n");
+  HIPREC_REQUIRE(workspace && (n == 0 || g), "NULL pointer");
+  HIPREC_REQUIRE((reinterpret_cast<uintptr_t>(g) & 15) == 0, "gradient must be 16-byte aligned");
+  HIPREC_REQUIRE(workspace_bytes >= hiprec_clip_workspace_bytes(), "workspace %zu B < %zu B", workspace_bytes,
+                 hiprec_clip_workspace_bytes());
+  const int grid = clip_grid(n);
+  clip_sumsq_kernel<<<grid, kBlock, 0, static_cast<hipStream_t>(stream)>>>(g, n, static_cast<double*>(workspace));
+  HIPREC_TRY(hipGetLastError());
+  return opt_dense_step_impl(kind, w, g, m, v, n, lr, beta1, beta2, eps, stats, scratch, scalar_index,
+                             static_cast<double*>(workspace), grid, max_norm, stream);
+}
+
 // PairwiseGMFEngine.train_an_epoch (pairwise_gmf.py:118-142) over resident (user, pos, neg) arrays in
-// visiting order: every batch is hiprec_pgmf_bpr_grad + hiprec_clip_grad_norm + hiprec_opt_dense_step,
+// visiting order: every batch is hiprec_pgmf_bpr_grad + hiprec_clip_opt_dense_step (clip + sweep in two launches),
 // enqueued back to back from C (the python loop costs ~50 us per step, three times the kernels).
 extern "C" int hiprec_pgmf_epoch(const hiprec_pgmf_tables* w, const hiprec_pgmf_tables* g,
                                  const int64_t* users, const int64_t* pos, const int64_t* neg,
@@ -324,11 +343,8 @@ extern "C" int hiprec_pgmf_epoch(const hiprec_pgmf_tables* w, const hiprec_pgmf_
                                       1.0f / static_cast<float>(b), l2_lambda, stats, scratch,
                                       scratch_bytes, workspace, workspace_bytes, stream))
       return rc;
-    if (int rc = hiprec_clip_grad_norm(flat_g, n_flat, max_norm, clip_workspace, clip_workspace_bytes,
-                                       stream))
-      return rc;
-    if (int rc = hiprec_opt_dense_step(kind, flat_w, flat_g, flat_m, flat_v, n_flat, lr, beta1, beta2,
-                                       eps, stats, scratch, -1, stream))
+    if (int rc = hiprec_clip_opt_dense_step(kind, flat_w, flat_g, flat_m, flat_v, n_flat, lr, beta1, beta2, eps, stats,
+                                            scratch, -1, max_norm, clip_workspace, clip_workspace_bytes, stream))
       return rc;
   }
   return 0;

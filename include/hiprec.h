@@ -959,9 +959,9 @@ int hiprec_pgmf_bpr_grad(const hiprec_pgmf_tables* w, const hiprec_pgmf_tables* 
                          size_t scratch_bytes, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- PairwiseGMFEngine.train_an_epoch (pairwise_gmf.py:118-142) over resident (user, pos, neg) arrays
- * in visiting order (n_triples, last batch short): per batch hiprec_pgmf_bpr_grad, hiprec_clip_grad_norm
- * (max_norm) and hiprec_opt_dense_step over the flat buffers [user_memory | item_memory | v] that w / g
- * point into, enqueued back to back with no host work in between. */
+ * in visiting order (n_triples, last batch short): per batch hiprec_pgmf_bpr_grad and hiprec_clip_opt_dense_step
+ * (= hiprec_clip_grad_norm(max_norm) + hiprec_opt_dense_step) over the flat buffers [user_memory | item_memory | v]
+ * that w / g point into, enqueued back to back with no host work in between. */
 int hiprec_pgmf_epoch(const hiprec_pgmf_tables* w, const hiprec_pgmf_tables* g, const int64_t* users,
                       const int64_t* pos, const int64_t* neg, int64_t n_triples, int64_t batch,
                       float l2_lambda, float max_norm, int kind, double lr, double beta1, double beta2,
@@ -977,6 +977,13 @@ int hiprec_pgmf_epoch(const hiprec_pgmf_tables* w, const hiprec_pgmf_tables* g, 
 size_t hiprec_clip_workspace_bytes(void);
 int hiprec_clip_grad_norm(float* g, int64_t n, float max_norm, void* workspace,
                           size_t workspace_bytes, void* stream);
+/* hiprec_clip_grad_norm followed by hiprec_opt_dense_step (pairwise_gmf.py:137-139: clip_grad_norm_ then
+ * optimizer.step()) in two launches instead of three: the scaling rides in the optimizer sweep, the scaled gradient is
+ * never written.  Same bits in w / m / v / g (cleared) and in workspace[0 .. 1] = (total_norm, coef) as the two calls. */
+int hiprec_clip_opt_dense_step(int kind, float* w, float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                               double beta2, double eps, hiprec_stats* stats, const void* scratch,
+                               int64_t scalar_index, float max_norm, void* workspace, size_t workspace_bytes,
+                               void* stream);
 
 /* ================= Triple2vec (sibling models) ===============================
  * models/triple2vec.py:11-34 parameters.  item_emb2 may be the SAME pointer as item_emb1 (in w and in

@@ -196,6 +196,52 @@ def test_clip_grad_norm_entry_point(hip_device):
     assert float(ws[0]) == 0.0
 
 
+@pytest.mark.parametrize("kind,name", [(0, "sgd"), (1, "adam"), (2, "rmsprop")])
+def test_clip_riding_in_the_optimizer_sweep_leaves_the_same_bits(hip_device, kind, name):
+    """hiprec_clip_opt_dense_step (two launches: sums of squares, then a sweep that scales and steps) against
+    hiprec_clip_grad_norm + hiprec_opt_dense_step (three): w, m, v, the cleared g and the workspace's (total_norm, coef)
+    BIT FOR BIT -- with an active clip, an inactive one, a NaN in the gradient (torch poisons every element) and lengths
+    that exercise the scalar tail; two steps, so the second starts from non-zero moments."""
+    from beta_recsys_amd import _lib
+    from beta_recsys_amd.mf import _new_stats
+
+    lib = _lib.load()
+    st = _lib.stream_ptr(hip_device)
+    rng = np.random.default_rng(11 + kind)
+    for n, factor, poison in ((2_000_003, 0.25, False), (1027, 4.0, False), (4096, 0.5, True), (5, 0.3, False)):
+        x = [rng.standard_normal(n).astype(np.float32) for _ in range(3)]
+        if poison:
+            x[2][7] = np.nan
+        total = float(np.sqrt((x[1].astype(np.float64) ** 2).sum()))
+        out = []
+        for fused in (False, True):
+            w = torch.from_numpy(x[0]).cuda()
+            m, v = torch.zeros_like(w), torch.zeros_like(w)
+            ws = torch.zeros(lib.hiprec_clip_workspace_bytes() // 8, dtype=torch.float64, device="cuda")
+            stats = _new_stats(w.device)
+            _lib.check(lib.hiprec_stats_reset(_lib.ptr(stats), 0.9, 0.999, st))
+            norms = []
+            for step in (1, 2):
+                g = torch.from_numpy(x[step]).cuda()
+                _lib.check(lib.hiprec_stats_advance_step(_lib.ptr(stats), st))
+                args = (kind, _lib.ptr(w), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n, 0.01, 0.9, 0.999, 1e-8, _lib.ptr(stats),
+                        None, -1)
+                if fused:
+                    _lib.check(lib.hiprec_clip_opt_dense_step(*args, float(factor * total), _lib.ptr(ws), ws.numel() * 8, st))
+                else:
+                    _lib.check(lib.hiprec_clip_grad_norm(_lib.ptr(g), n, float(factor * total), _lib.ptr(ws),
+                                                         ws.numel() * 8, st))
+                    _lib.check(lib.hiprec_opt_dense_step(*args, st))
+                norms.append(ws[:2].cpu().numpy().copy())
+                assert not g.cpu().numpy().any() or poison   # the sweep leaves the gradient cleared
+            out.append([t.cpu().numpy() for t in (w, m, v)] + norms)
+        for a, b, what in zip(out[0], out[1], ("w", "m", "v", "norm step 1", "norm step 2")):
+            assert np.array_equal(a, b, equal_nan=True), f"{name} n={n} factor={factor}: {what} differs"
+        assert (out[1][3][1] < 1.0) == (factor < 1.0)
+        if poison:
+            assert np.isnan(out[1][0]).all()   # clip_grad_norm_ with a NaN norm scales everything by NaN
+
+
 def test_bad_indices_and_batches(hip_device):
     eng = make_engine(12, 9, 8, 4)
     with pytest.raises(IndexError):
