@@ -61,8 +61,9 @@ __device__ __forceinline__ float2 lazy_scalars_at(const LazyCtx& c, long long t)
 // (which also books the step's loss, as the dense sweep does).  Block 0 of an update launch.
 template <int KIND>
 __device__ __forceinline__ void lazy_scalar_step(const LazyCtx& c, const OptScalars& s, hiprec_stats* stats,
-                                                 const Scratch* scratch, long long clock, float ss_now, float bc2_now) {
-  if (blockIdx.x != 0) return;
+                                                 const Scratch* scratch, long long clock, float ss_now, float bc2_now,
+                                                 int bid = blockIdx.x) {
+  if (bid != 0) return;
   float extra = 0.f;
   if (scratch) extra = finalize_partials(stats, scratch);
   if (threadIdx.x != 0) return;
@@ -140,8 +141,8 @@ __device__ __forceinline__ bool lazy_claim(int32_t* sp, int target, int* old_out
 //     replayed (two register sets, unconditional loads so that the wait counts stay exact), the per-step scalars of up
 //     to 64 steps fetched with ONE load (lane k holds step first + k) and handed out with v_readlane.
 template <int KIND, int MODE, int LPR>
-__global__ __launch_bounds__(kBlock) void lazy_rows_vec_kernel(LazyCtx c, hiprec_lazy_rows rows, OptScalars s,
-                                                               hiprec_stats* stats, const Scratch* scratch) {
+__device__ __forceinline__ void lazy_rows_vec_body(const LazyCtx& c, const hiprec_lazy_rows& rows, const OptScalars& s,
+                                                   hiprec_stats* stats, const Scratch* scratch, int bid, int n_blocks) {
   constexpr int ROWS = kWave / LPR;
   constexpr bool kHasW = KIND == HIPREC_OPT_ADAM || MODE == 1;
   constexpr bool kAdam = KIND == HIPREC_OPT_ADAM;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void lazy_rows_vec_kernel(LazyCtx c, hiprec
     float w[4], m[4], v[4], g[4];
   };
 
-  for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+  for (int64_t ch = bid; ch < n_chunks; ch += n_blocks) {
     // ---- phase A, part 1: entries, claims, order
     int64_t bat = bias0;
     float bw[1] = {0.f}, bm[1] = {0.f}, bv[1] = {0.f}, bg[1] = {0.f};
@@ -351,8 +352,28 @@ __global__ __launch_bounds__(kBlock) void lazy_rows_vec_kernel(LazyCtx c, hiprec
     }
     __syncthreads();   // the next chunk rewrites the shared arrays
   }
-  if constexpr (MODE == 1) lazy_scalar_step<KIND>(c, s, stats, scratch, clock, ss_now, bc2_now);
+  if constexpr (MODE == 1) lazy_scalar_step<KIND>(c, s, stats, scratch, clock, ss_now, bc2_now, bid);
 }
+
+template <int KIND, int MODE, int LPR>
+__global__ __launch_bounds__(kBlock) void lazy_rows_vec_kernel(LazyCtx c, hiprec_lazy_rows rows, OptScalars s,
+                                                               hiprec_stats* stats, const Scratch* scratch) {
+  lazy_rows_vec_body<KIND, MODE, LPR>(c, rows, s, stats, scratch, static_cast<int>(blockIdx.x),
+                                      static_cast<int>(gridDim.x));
+}
+
+#ifdef HIPREC_TEST_SWITCHES
+// Timing experiment (tools/exp_lazy_overlap.py, libhiprec_test.so only): the update of one state (memory-bound) and the
+// catch-up of another (arithmetic-bound) in ONE launch, even / odd workgroups -- what merging the update of step t
+// with the catch-up of step t + 1 could buy.
+__global__ __launch_bounds__(kBlock) void lazy_dual_kernel(LazyCtx c1, hiprec_lazy_rows r1, OptScalars s1,
+                                                           hiprec_stats* st1, LazyCtx c2, hiprec_lazy_rows r2,
+                                                           OptScalars s2, hiprec_stats* st2) {
+  const int half = static_cast<int>(gridDim.x) / 2, bid = static_cast<int>(blockIdx.x) >> 1;
+  if (blockIdx.x & 1) lazy_rows_vec_body<HIPREC_OPT_ADAM, 0, 32>(c2, r2, s2, st2, nullptr, bid, half);
+  else lazy_rows_vec_body<HIPREC_OPT_ADAM, 1, 32>(c1, r1, s1, st1, nullptr, bid, half);
+}
+#endif
 
 
 // MODE 0 = catch-up (to the clock), 1 = update (the step the clock shows), 2 = flush (all rows, to the clock)
@@ -624,3 +645,26 @@ extern "C" int hiprec_mf_epoch_lazy_owned(const hiprec_lazy_state* state, const 
   }
   return 0;
 }
+
+#ifdef HIPREC_TEST_SWITCHES
+extern "C" int hiprec_debug_lazy_dual(const hiprec_lazy_state* a, const hiprec_lazy_rows* ra, hiprec_stats* sa,
+                                      const hiprec_lazy_state* b, const hiprec_lazy_rows* rb, hiprec_stats* sb,
+                                      void* stream) {
+  HIPREC_REQUIRE(a && b && ra && rb && sa && sb && a->dim == 128 && b->dim == 128 && a->kind == HIPREC_OPT_ADAM &&
+                     b->kind == HIPREC_OPT_ADAM,
+                 "two Adam states of dim 128");
+  auto ctx = [](const hiprec_lazy_state* st) {
+    return LazyCtx{st->w, st->g, st->m, st->v, st->n_users, st->n_items, st->dim, st->stamp_u, st->stamp_i,
+                   reinterpret_cast<float2*>(st->scalars), st->scalars_cap};
+  };
+  auto sc = [](const hiprec_lazy_state* st) {
+    return OptScalars{st->lr, static_cast<float>(st->lr), static_cast<float>(st->beta2),
+                      static_cast<float>(1.0 - st->beta1), static_cast<float>(1.0 - st->beta2),
+                      static_cast<float>(st->eps)};
+  };
+  lazy_dual_kernel<<<2 * kMaxBlocks, kBlock, 0, static_cast<hipStream_t>(stream)>>>(ctx(a), *ra, sc(a), sa, ctx(b), *rb,
+                                                                                  sc(b), sb);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+#endif
