@@ -298,7 +298,10 @@ struct OptScalars {
 // the same expression differed in the last bit (the dense sweep against csrc/lazy_opt.hip's replay of it, round 4).
 // With the operations pinned, every kernel that steps an element -- dense sweep, fused MF step, lazy replay --
 // produces the same bits from the same inputs.  The fused forms are the ones the compiler chose for the dense sweep.
-template <int KIND>
+// PRE_RCP (the lazy replay, csrc/lazy_opt.hip): `bc2_sqrt` already is what the denominator multiplies by -- the
+// v_rcp_f32 of the step's sqrt(1 - beta2^t), taken once when the step was recorded instead of once per replayed
+// step and lane (the correctly rounded build divides, and is handed the value itself).
+template <int KIND, bool PRE_RCP = false>
 __device__ __forceinline__ void opt_update(float& w, float& g, float& m, float& v,
                                            const OptScalars s, float step_size, float bc2_sqrt) {
 #pragma clang fp contract(off)
@@ -314,7 +317,8 @@ __device__ __forceinline__ void opt_update(float& w, float& g, float& m, float& 
       const float denom = sqrtf(v) / bc2_sqrt + s.eps;  // (sqrt(v) / sqrt(bc2)).add_(eps)
       w = w + num / denom;
 #else
-      const float denom = __builtin_fmaf(__builtin_amdgcn_sqrtf(v), __builtin_amdgcn_rcpf(bc2_sqrt), s.eps);
+      const float r_bc2 = PRE_RCP ? bc2_sqrt : __builtin_amdgcn_rcpf(bc2_sqrt);
+      const float denom = __builtin_fmaf(__builtin_amdgcn_sqrtf(v), r_bc2, s.eps);
       w = __builtin_fmaf(num, __builtin_amdgcn_rcpf(denom), w);
 #endif
     } else {

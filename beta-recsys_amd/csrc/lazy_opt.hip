@@ -11,8 +11,9 @@
 // bit-identical to the sweep:
 //   * stamp[row] (int32 per table row) = the step the row is current as of; -1 = never touched (m = v = 0: every
 //     zero-gradient step is the identity on it);
-//   * scalars[t] = (lr / (1 - beta1^t), sqrt(1 - beta2^t)) as the sweep of step t derived them from hiprec_stats: the
-//     update kernel of step t records them, the replays read them;
+//   * scalars[t] = (lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t) -- the v_rcp_f32 the sweep of step t takes of it; the value
+//     itself in the correctly rounded build, which divides) as step t derived them from hiprec_stats: the update kernel
+//     of step t records them, the replays read them;
 //   * catch-up (before a step reads its rows): rows of the step that lag behind are replayed up to the last completed
 //     step; only w is stored (what the step reads) and the stamp is flagged "w ahead" -- the moments are replayed
 //     again (one fma + one multiply per step) by the same step's update instead of being written and re-read.  Adam
@@ -77,11 +78,17 @@ __device__ __forceinline__ void lazy_scalar_step(const LazyCtx& c, const OptScal
   c.v[i] = vv;
   // this step's scalars for the replays to come.  Beyond the table the powers must have converged (default betas:
   // beta2^t < 2^-53 from t ~ 36 800 on): a later step with different scalars cannot be replayed.
+  // (the second scalar as the replay's opt_update<KIND, true> wants it: its v_rcp_f32, or itself where that build divides)
+#ifdef HIPREC_IEEE_DIV
+  const float bc2_rec = bc2_now;
+#else
+  const float bc2_rec = __builtin_amdgcn_rcpf(bc2_now);
+#endif
   if (clock < c.scalars_cap) {
-    c.scalars[clock] = make_float2(ss_now, bc2_now);
+    c.scalars[clock] = make_float2(ss_now, bc2_rec);
   } else {
     const float2 last = c.scalars[c.scalars_cap - 1];
-    if (last.x != ss_now || last.y != bc2_now) atomicOr(&stats->status, HIPREC_STATUS_LAZY_TABLE);
+    if (last.x != ss_now || last.y != bc2_rec) atomicOr(&stats->status, HIPREC_STATUS_LAZY_TABLE);
   }
 }
 
@@ -186,7 +193,7 @@ __device__ __forceinline__ void lazy_rows_vec_body(const LazyCtx& c, const hipre
 #pragma unroll
         for (int j = 0; j < N; ++j) {
           float zero = 0.f;
-          opt_update<KIND>(w[j], zero, m[j], v[j], s, sc.x, sc.y);
+          opt_update<KIND, true>(w[j], zero, m[j], v[j], s, sc.x, sc.y);
         }
       }
     }
@@ -467,7 +474,7 @@ __global__ __launch_bounds__(kBlock) void lazy_rows_kernel(LazyCtx c, hiprec_laz
 #pragma unroll
         for (int j = 0; j <= kLazyMaxNpl; ++j) {
           float zero = 0.f;
-          opt_update<KIND>(w[j], zero, m[j], v[j], s, sc.x, sc.y);
+          opt_update<KIND, true>(w[j], zero, m[j], v[j], s, sc.x, sc.y);
         }
       }
     }

@@ -539,7 +539,9 @@ int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const hiprec_shard
  * same order as the dense sweep (hiprec_opt_dense_step) -- bit-identical to it after hiprec_lazy_flush.
  *   stamp_u[n_users], stamp_i[n_items] (int32): the step a row is current as of; -1 = never touched (m = v = 0).
  *     Initialise to -1 together with zeroed moments; after loading optimizer state call hiprec_lazy_mark_current.
- *   scalars[scalars_cap][2] (fp32; Adam only): (lr / (1 - beta1^t), sqrt(1 - beta2^t)) of step t, recorded by
+ *   scalars[scalars_cap][2] (fp32; Adam only): (lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t) as the step's sweep takes
+ *     it -- its v_rcp_f32; libhiprec_ieee.so, which divides, keeps sqrt(1 - beta2^t) itself: the table belongs to the
+ *     library that wrote it) of step t, recorded by
  *     hiprec_lazy_update, read by the replays; steps >= scalars_cap must have converged bias corrections
  *     (HIPREC_STATUS_LAZY_TABLE otherwise; 65 536 entries are plenty for the default betas).
  * All buffers are flat and laid out like the MF parameters [user_emb | item_emb | user_bias | item_bias | global_bias];
