@@ -131,6 +131,34 @@ def test_round4_entry_points_validate_before_touching_the_gpu():
     assert rc == -1
     rc = lib.hiprec_mf_epoch_lazy(None, None, None, None, None, None, 0, 4, 2, 1, 0.0, None, None, 0, None)
     assert rc == -1 and b"NULL pointer" in lib.hiprec_last_error()
+    # ... and its owned-gradient form: the state, then the batch / ownership arrays
+    rc = lib.hiprec_mf_epoch_lazy_owned(None, None, None, None, None, None, None, None, 0, 4, 2, 1, 0.0, None, None, None)
+    assert rc == -1 and b"NULL pointer" in lib.hiprec_last_error()
+    scratch = (ctypes.c_char * 64)()
+    rc = lib.hiprec_mf_epoch_lazy_owned(ctypes.byref(st), None, None, None, None, None, None, None, 0, 4, 2, 1, 0.0,
+                                        stats, scratch, None)
+    assert rc == -1 and b"NULL batch / ownership arrays" in lib.hiprec_last_error()
+    assert lib.hiprec_mf_epoch_lazy_owned(ctypes.byref(st), None, None, None, None, None, None, None, 0, 0, 2, 0, 0.0,
+                                          stats, scratch, None) == 0      # an empty epoch that does not reset sums
+    rc = lib.hiprec_mf_bpr_grad_owned(None, None, 10, 5, 8, None, None, None, None, None, None, None, 4, 0.25, 0.0, None,
+                                      None, None)
+    assert rc == -1 and b"NULL pointer" in lib.hiprec_last_error()
+    w = (ctypes.c_float * 4)()
+    rc = lib.hiprec_mf_bpr_grad_owned(w, w, 10, 5, 300, None, None, None, None, None, None, None, 4, 0.25, 0.0, stats,
+                                      scratch, None)
+    assert rc == -1 and b"dim <= 256" in lib.hiprec_last_error()
+    rc = lib.hiprec_mf_bpr_grad_owned(w, w, 10, 5, 8, None, None, None, None, None, None, None, 4, 0.25, 0.0, stats,
+                                      scratch, None)
+    assert rc == -1 and b"NULL index / ownership arrays" in lib.hiprec_last_error()
+    assert lib.hiprec_mf_bpr_grad_owned(w, w, 10, 5, 8, None, None, None, None, None, None, None, 0, 0.25, 0.0, stats,
+                                        scratch, None) == 0              # an empty batch launches nothing
+    # clip + sweep in two launches: the clip's checks come first
+    rc = lib.hiprec_clip_opt_dense_step(1, None, None, None, None, 5, 1e-3, 0.9, 0.999, 1e-8, None, None, -1, 1.0, None, 0,
+                                        None)
+    assert rc == -1 and b"NULL pointer" in lib.hiprec_last_error()
+    rc = lib.hiprec_clip_opt_dense_step(1, None, w, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, None, None, -1, 1.0, scratch, 8,
+                                        None)
+    assert rc == -1 and b"workspace" in lib.hiprec_last_error()
 
     rc = lib.hiprec_stage_sort_keys(None, None, 0, 0, 8, 4, 10, 3, None, None)
     assert rc == -1 and b"bad sizes" in lib.hiprec_last_error()
