@@ -146,6 +146,74 @@ def test_lazy_rows_equal_the_dense_sweeps_bit_for_bit(hip_device, opt, D):
     assert torch.equal(wl, before)
 
 
+@pytest.mark.parametrize("opt,D", [("adam", 128), ("adam", 64), ("rmsprop", 128), ("adam", 256)])
+def test_lazy_rows_in_many_chunks_with_long_gaps_bit_for_bit(hip_device, opt, D):
+    """The same lockstep comparison where the vector kernel's machinery is all in play: 3 000 x 500 rows, 150 steps of
+    ~260 list entries each (several 64-entry chunks per launch, their rows ranked by stamp and dealt out to the waves),
+    gaps beyond 64 steps (the replay fetches its scalars in blocks of 64 steps), and -- after a flush + mark_current at
+    step 20, which stamps never-touched rows (all moments zero) as current -- groups whose OLDEST row has nothing to
+    replay (the walk then starts later than the scalars fetched with the rows).  After every catch-up the step's rows
+    hold the dense sweeps' weights; after the final flush w, m, v are bit-identical everywhere."""
+    from beta_recsys_amd import _lib
+
+    lib, dev = _lib.load(), hip_device
+    U, I, T, lr = 3000, 500, 150, 0.05
+    kind = KIND[opt]
+    P = (U + I) * (D + 1) + 1
+    gen = torch.Generator(device="cuda").manual_seed(7 * D + kind)
+    w0 = torch.randn(P, device=dev, generator=gen) * 0.1
+    wd, md, vd, gd = w0.clone(), torch.zeros_like(w0), torch.zeros_like(w0), torch.zeros_like(w0)
+    wl, ml, vl, gl = w0.clone(), torch.zeros_like(w0), torch.zeros_like(w0), torch.zeros_like(w0)
+    sd, sl = new_stats(lib, _lib, dev), new_stats(lib, _lib, dev)
+    lazy = Lazy(lib, _lib, wl, gl, ml if opt == "adam" else None, vl, U, I, D, kind, lr, cap=256)
+    st = _lib.stream_ptr(dev)
+    rng = np.random.default_rng(D + kind)
+    cols = torch.arange(D, device=dev)
+
+    def flat_index(users, items):
+        u = torch.as_tensor(users, dtype=torch.int64, device=dev)
+        i = torch.as_tensor(items, dtype=torch.int64, device=dev)
+        parts = [(u[:, None] * D + cols).ravel(), (U * D + i[:, None] * D + cols).ravel(), (U + I) * D + u,
+                 (U + I) * D + U + i]
+        return torch.unique(torch.cat(parts))
+
+    for t in range(1, T + 1):
+        # users: a hot set every step, a Zipf-ish draw, and a slice that comes back only every ~70 steps
+        users = set(range(5)) | set(rng.integers(5, 600, 150).tolist()) | set((600 + (t % 70) * 30 + np.arange(30)).tolist())
+        items = set(range(3)) | set(rng.integers(3, 400, 80).tolist())
+        if t > 20:
+            users |= set(rng.integers(2800, 3000, 6).tolist())   # stamped current at step 20 with zero moments
+        users, items = sorted(users), sorted(items)
+        lu = torch.tensor(users + users[:7] + [-1], dtype=torch.int64, device=dev)
+        la = torch.tensor(items[::2] + [-1, items[0]], dtype=torch.int64, device=dev)
+        lb = torch.tensor(items[1::2], dtype=torch.int64, device=dev)
+        lc = torch.tensor(items[:9] + [-1] + items[-3:], dtype=torch.int32, device=dev)
+        idx = flat_index(users, items)
+        lazy.catchup(sl, lu, la, lb, lc)
+        assert torch.equal(wl[idx], wd[idx]), f"step {t}: a caught-up row's weights differ from the dense sweeps'"
+        g = torch.zeros(P, device=dev)
+        g[idx] = torch.randn(idx.numel(), device=dev, generator=gen) * 0.01
+        g[-1] = float(rng.normal()) * 0.01
+        gd.copy_(g)
+        gl.copy_(g)
+        for stats in (sd, sl):
+            _lib.check(lib.hiprec_stats_advance_step(_lib.ptr(stats), st))
+        _lib.check(lib.hiprec_opt_dense_step(kind, _lib.ptr(wd), _lib.ptr(gd), _lib.ptr(md), _lib.ptr(vd), P, lr, 0.9, 0.999,
+                                             1e-8, _lib.ptr(sd), None, -1, st))
+        lazy.update(sl, lu, la, lb, lc)
+        assert torch.equal(wl[idx], wd[idx]) and torch.equal(vl[idx], vd[idx]) and torch.equal(ml[idx], md[idx]), \
+            f"step {t}: an updated row differs"
+        if t == 20:   # what a dense step in between leaves: everything flushed, EVERY row stamped current
+            lazy.flush(sl)
+            assert torch.equal(wl, wd) and torch.equal(vl, vd)
+            _lib.check(lib.hiprec_lazy_mark_current(ctypes.byref(lazy.c), _lib.ptr(sl), st))
+            assert int(lazy.stamp_u[2999]) == 20
+    assert float(gl.abs().max()) == 0.0
+    lazy.flush(sl)
+    assert torch.equal(wl, wd), f"w differs in {int((wl != wd).sum())} elements after the flush"
+    assert torch.equal(vl, vd) and (opt != "adam" or torch.equal(ml, md))
+
+
 def test_lazy_adam_beyond_the_scalars_table(hip_device):
     """A table of 8 entries and 12 steps: bias corrections still move at step 8, so the update kernel must raise
     HIPREC_STATUS_LAZY_TABLE instead of letting a later replay use the wrong scalars."""
