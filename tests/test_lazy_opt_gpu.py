@@ -396,24 +396,25 @@ def mf_lazy_run(optimizer, lr, loss, dense_opt, pieces=None, single_between=Fals
     return eng, w0, visited, sums, get_weights(eng)
 
 
-@pytest.mark.parametrize("optimizer,lr,loss,lazy_grad", [
-    ("adam", 0.05, "bpr", "owned"), ("adam", 0.05, "bpr", "atomic"), ("rmsprop", 0.01, "bpr", "owned"),
-    ("rmsprop", 0.01, "bpr", "atomic"), ("adam", 0.02, "bce", "owned")])
-def test_mf_engine_epochs_with_the_lazy_optimizer(hip_device, optimizer, lr, loss, lazy_grad):
+@pytest.mark.parametrize("optimizer,lr,loss,lazy_grad,reg", [
+    ("adam", 0.05, "bpr", "owned", None), ("adam", 0.05, "bpr", "atomic", None), ("rmsprop", 0.01, "bpr", "owned", None),
+    ("rmsprop", 0.01, "bpr", "atomic", None), ("adam", 0.02, "bce", "owned", None), ("adam", 0.05, "bpr", "owned", 0.02)])
+def test_mf_engine_epochs_with_the_lazy_optimizer(hip_device, optimizer, lr, loss, lazy_grad, reg):
     """MFEngine.train_an_epoch with ``dense_opt: "lazy"`` (hiprec_mf_epoch_lazy / _lazy_owned: catch-up, gradient kernel
     -- the owned-rows kernel or mf_bpr_grad_kernel's atomics --, update per step, flush at the end of the epoch): epoch
     sums to 1e-5 of the oracle's, every weight on the oracle's trajectory, never-drawn users bit-identical with stamp
     -1, the gradient buffer clean -- like the dense-sweep engine."""
-    eng, w0, visited, sums, got = mf_lazy_run(optimizer, lr, loss, "lazy", lazy_grad=lazy_grad)
-    _, _, _, sums_s, got_s = mf_lazy_run(optimizer, lr, loss, "sweep")
+    eng, w0, visited, sums, got = mf_lazy_run(optimizer, lr, loss, "lazy", lazy_grad=lazy_grad, reg=reg)
+    _, _, _, sums_s, got_s = mf_lazy_run(optimizer, lr, loss, "sweep", reg=reg)
     per = len(visited) // 2
     w = onp.copy_params(w0)
     st = onp.new_opt_state(w, optimizer)
+    rc = reg or 0.0
     for e in range(2):
-        tot = sum(onp.mf_train_step(w, st, b, loss, optimizer, lr)[0] for b in visited[e * per:(e + 1) * per])
+        tot = sum(onp.mf_train_step(w, st, b, loss, optimizer, lr, rc)[0] for b in visited[e * per:(e + 1) * per])
         assert_scalar_close(sums[e], tot, REL, f"epoch {e} loss sum (lazy)")
         assert_scalar_close(sums_s[e], tot, REL, f"epoch {e} loss sum (sweep)")
-    traj = mf_trajectory(w0, visited, optimizer, lr, loss=loss)
+    traj = mf_trajectory(w0, visited, optimizer, lr, reg_coef=rc, loss=loss)
     assert_on_trajectory(got, *traj, f"lazy {optimizer} {loss}")
     assert_on_trajectory(got_s, *traj, f"sweep {optimizer} {loss}")
     assert float(eng._g_flat.abs().max()) == 0.0 and not eng._lazy["dirty"]
