@@ -38,6 +38,9 @@ struct GemmProblem {
   // kColsum only: when set, the blocks leave their partial sums in ws[slab * N + n] (no atomics) and
   // launch_colsum_reduce adds them up in slab order afterwards -- a column sum that is the same from run to run
   float* ws;
+#ifdef HIPREC_TEST_SWITCHES
+  int exp_bits;                 // timing experiments (libhiprec_test.so, HIPREC_GEMM_EXP): 1 split-K with plain stores, 2 no GEMM tiles, 4 no column sums
+#endif
 };
 
 // A dense optimizer sweep that rides in the grouped launch as its first n_blocks blocks: elements [0, 4 * n4) of the

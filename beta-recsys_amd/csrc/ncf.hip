@@ -134,6 +134,12 @@ __device__ __forceinline__ void gemm_tile(float (*As)[kTK + 1], float (*Bs)[kTN 
       if (mask) v = mask[static_cast<int64_t>(gm) * ldm + gn] > 0.f ? v : 0.f;
       if (q.keep) v = q.keep[static_cast<int64_t>(gm) * q.ldk + gn] ? v * q.keep_scale : 0.f;
       if (q.split > 1) {
+#ifdef HIPREC_TEST_SWITCHES   // timing experiment only (tools/exp_ncf_wgrad_split.py): plain stores, wrong sums
+        if (q.exp_bits & 1) {
+          C[static_cast<int64_t>(gm) * ldc + gn] = v;
+          continue;
+        }
+#endif
         if (v != 0.f) atomic_add_f32(C + static_cast<int64_t>(gm) * ldc + gn, v);
       } else {
         C[static_cast<int64_t>(gm) * ldc + gn] = v;
@@ -216,6 +222,9 @@ __global__ __launch_bounds__(kBlock) void gemm_group_kernel(GemmGroup g) {
     if (i < g.n && static_cast<int>(blockIdx.x) >= g.p[i].first_block) qi = i;
   const GemmProblem& q = g.p[qi];
   const int local = static_cast<int>(blockIdx.x) - q.first_block;
+#ifdef HIPREC_TEST_SWITCHES   // timing experiment only: bit 1 = GEMM tiles return at once, bit 2 = column sums do
+  if (q.exp_bits & (q.mode == kColsum ? 4 : 2)) return;
+#endif
   if (q.mode == kColsum) {
     colsum_tile(&As[0][0], q, local);
     return;
@@ -254,6 +263,10 @@ GemmProblem make_gemm(int mode, int M, int N, int K, const float* A, int lda, co
     if (z > max_z) z = max_z;
     if (z > 1) q.split = z;
   }
+#ifdef HIPREC_TEST_SWITCHES
+  static const int plain = getenv("HIPREC_GEMM_EXP") ? atoi(getenv("HIPREC_GEMM_EXP")) : 0;  // 1 plain stores, 2 no GEMM tiles
+  q.exp_bits = plain;
+#endif
   return q;
 }
 
@@ -264,6 +277,10 @@ GemmProblem make_colsum(const float* X, int M, int N, int ldx, float* out, float
   q.tiles_m = (M + kColsumRows - 1) / kColsumRows;
   q.split = 1;
   q.ws = q.tiles_m > 1 ? ws : nullptr;   // a single block's one add into a zeroed gradient is already deterministic
+#ifdef HIPREC_TEST_SWITCHES
+  static const int exp = getenv("HIPREC_GEMM_EXP") ? atoi(getenv("HIPREC_GEMM_EXP")) : 0;   // 4: no column sums
+  q.exp_bits = exp;
+#endif
   return q;
 }
 
