@@ -37,6 +37,19 @@ constexpr int kTM = 64, kTN = 64, kTK = 32;
 
 constexpr int kColsumRows = 128;
 
+// In-kernel timestamps of one split-K weight-gradient tile (-DHIPREC_NCF_DEBUG builds only, tools/build_debug_lib.sh):
+// thread 0 of blocks 0 and 200 of the grouped launch; hiprec_debug_gemm_stamps reads them back.
+#ifdef HIPREC_NCF_DEBUG
+__device__ unsigned long long g_gemm_stamps[2][16];
+#define GEMM_STAMP(k)                                                                                       \
+  do {                                                                                                      \
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 200) && (k) < 16)                             \
+      g_gemm_stamps[blockIdx.x == 0 ? 0 : 1][k] = __builtin_amdgcn_s_memtime();                             \
+  } while (0)
+#else
+#define GEMM_STAMP(k) do {} while (0)
+#endif
+
 template <int MODE>
 __device__ __forceinline__ void gemm_tile(float (*As)[kTK + 1], float (*Bs)[kTN + 1], const GemmProblem& q,
                                           int tile_m, int tile_n, int z) {
@@ -52,6 +65,7 @@ __device__ __forceinline__ void gemm_tile(float (*As)[kTK + 1], float (*Bs)[kTN 
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = tile_m * kTM, n0 = tile_n * kTN;
 
+  GEMM_STAMP(0);
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -103,6 +117,7 @@ __device__ __forceinline__ void gemm_tile(float (*As)[kTK + 1], float (*Bs)[kTN 
       Bs[b_k[i]][b_n[i]] = rb[i];
     }
     lds_barrier();
+    GEMM_STAMP(2 + 2 * ((k0 - k_begin) / kTK));     // this step's operands have arrived and are in LDS
     if (k0 + 2 * kTK < k_end) fetch(ra, rb, k0 + 2 * kTK);  // this stage's registers are free again
     // lane l feeds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]
     const int i = lane & 31, kh = lane >> 5;
@@ -113,9 +128,11 @@ __device__ __forceinline__ void gemm_tile(float (*As)[kTK + 1], float (*Bs)[kTN 
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
     lds_barrier();
+    GEMM_STAMP(3 + 2 * ((k0 - k_begin) / kTK));     // ... and have been multiplied
   };
   if (k_begin < k_end) fetch(ra0, rb0, k_begin);
   if (k_begin + kTK < k_end) fetch(ra1, rb1, k_begin + kTK);
+  GEMM_STAMP(1);
   for (int k0 = k_begin; k0 < k_end; k0 += 2 * kTK) {
     step(ra0, rb0, k0);
     if (k0 + kTK < k_end) step(ra1, rb1, k0 + kTK);
@@ -123,6 +140,17 @@ __device__ __forceinline__ void gemm_tile(float (*As)[kTK + 1], float (*Bs)[kTN 
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int col = lane & 31;
   const int gn = n0 + wn * 32 + col;
+  // A split-K slice (the weight-gradient GEMMs) has no epilogue by construction (make_gemm): sixteen adds at fixed row
+  // offsets from one base pointer.  The general loop below -- per register the row arithmetic, four epilogue tests
+  // and a test for zero around the atomic -- took a third of such a tile's time (in-kernel timestamps,
+  // profiles/r04_experiments.md 60: 6.4 k of 20 k cycles).
+  if (q.split > 1 && !q.keep && m0 + kTM <= M && n0 + kTN <= N) {
+    float* cp = C + static_cast<int64_t>(m0 + wm * 32 + 4 * (lane >> 5)) * ldc + gn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) atomic_add_f32(cp + static_cast<int64_t>((r & 3) + 8 * (r >> 2)) * ldc, acc[r]);
+    GEMM_STAMP(12);
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -146,6 +174,7 @@ __device__ __forceinline__ void gemm_tile(float (*As)[kTK + 1], float (*Bs)[kTN 
       }
     }
   }
+  GEMM_STAMP(12);
 }
 
 // ---- column sums: out[n] += sum_m X[m, n]   (bias gradients) ---------------------------------------
@@ -1491,6 +1520,11 @@ extern "C" int hiprec_ncf_step(const hiprec_ncf_plan* plan, const int64_t* users
 }
 
 #ifdef HIPREC_NCF_DEBUG
+extern "C" int hiprec_debug_gemm_stamps(unsigned long long* out32) {
+  HIPREC_TRY(hipDeviceSynchronize());
+  HIPREC_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(hiprec::g_gemm_stamps), sizeof(unsigned long long) * 32));
+  return 0;
+}
 extern "C" int hiprec_debug_ncf_stamps(unsigned long long* out48) {
   HIPREC_TRY(hipDeviceSynchronize());
   HIPREC_TRY(hipMemcpyFromSymbol(out48, HIP_SYMBOL(hiprec::g_ncf_stamps), sizeof(unsigned long long) * 48));

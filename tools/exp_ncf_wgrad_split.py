@@ -34,3 +34,19 @@ for k in range(300):
                                        _lib.ptr(eng._stats), _lib.ptr(eng._scratch), eng._scratch.numel(), st))
 torch.cuda.synchronize()
 print("done", mode, E)
+if _lib.LIB_PATH.endswith("debug.so"):   # tools/build_debug_lib.sh: in-kernel timestamps of two weight-gradient tiles
+    dl = ctypes.CDLL(_lib.LIB_PATH)
+    out = (ctypes.c_ulonglong * 32)()
+    dl.hiprec_debug_gemm_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+    assert dl.hiprec_debug_gemm_stamps(out) == 0
+    names = {0: "entry", 1: "offsets, two stages of loads issued", 2: "step 0 operands in LDS", 3: "step 0 multiplied",
+             4: "step 1 in LDS", 5: "step 1 multiplied", 6: "step 2 in LDS", 7: "step 2 multiplied", 8: "step 3 in LDS",
+             9: "step 3 multiplied", 12: "epilogue issued"}
+    for blk in range(2):
+        st = list(out[blk * 16:(blk + 1) * 16])
+        print(f"block {'0' if blk == 0 else '200'}: total {st[12] - st[0]} ticks")
+        prev = st[0]
+        for k in names:
+            if st[k]:
+                print(f"   {names[k]:40s} +{st[k] - prev:7d}   (at {st[k] - st[0]})")
+                prev = st[k]
