@@ -144,10 +144,17 @@ __device__ __forceinline__ void gemm_tile(float (*As)[kTK + 1], float (*Bs)[kTN 
   // offsets from one base pointer.  The general loop below -- per register the row arithmetic, four epilogue tests
   // and a test for zero around the atomic -- took a third of such a tile's time (in-kernel timestamps,
   // profiles/r04_experiments.md 60: 6.4 k of 20 k cycles).
-  if (q.split > 1 && !q.keep && m0 + kTM <= M && n0 + kTN <= N) {
-    float* cp = C + static_cast<int64_t>(m0 + wm * 32 + 4 * (lane >> 5)) * ldc + gn;
+  // (A tile that sticks out of the matrix -- NeuMF emb 32's last layer has 32 output rows -- only adds a compare per
+  // register: those 32 tiles kept the general loop at first and stayed the launch's longest blocks.)
+  if (q.split > 1 && !q.keep) {
+    const int rb = m0 + wm * 32 + 4 * (lane >> 5);
+    float* cp = C + static_cast<int64_t>(rb) * ldc + gn;
+    const bool col_ok = gn < N;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) atomic_add_f32(cp + static_cast<int64_t>((r & 3) + 8 * (r >> 2)) * ldc, acc[r]);
+    for (int r = 0; r < 16; ++r) {
+      const int ro = (r & 3) + 8 * (r >> 2);
+      if (col_ok && rb + ro < M) atomic_add_f32(cp + static_cast<int64_t>(ro) * ldc, acc[r]);
+    }
     GEMM_STAMP(12);
     return;
   }
