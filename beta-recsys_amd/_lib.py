@@ -360,6 +360,15 @@ SIGNATURES = {
     "hiprec_ownership_ws_ints": (c_int64, [c_int64, c_int64, c_int32]),
     "hiprec_batch_row_ownership": (
         c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
+    "hiprec_mf_pull_chunk": (c_int32, [c_int32]),
+    "hiprec_contrib_row_cap": (c_int64, [c_int64]),
+    "hiprec_batch_row_contrib": (
+        c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, c_int64, _P, _P]),
+    "hiprec_mf_bpr_epoch_pull": (
+        c_int,
+        [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int64, c_int64,
+         c_int64, c_int64, c_float, c_double, _P, _P],
+    ),
     "hiprec_mf_bpr_owned_remote_step": (
         c_int,
         [_P, c_int64, c_int64, c_int32, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_float,

@@ -41,6 +41,11 @@ constexpr int kOwnedPartialLoads = kMaxBlocks / kOwnedBlock;  // per-thread load
 constexpr int kOwnedGroup = 4;            // completed rows swapped out together in the chunk's epilogue
 // consecutive triples of the batch handled by ONE wave, all of their rows in flight at once (registers)
 constexpr int owned_chunk(int npl) { return npl <= 2 ? 8 : 4; }
+// ... by the owner-pulls form, whose gradient launch carries no arrival protocol (107 VGPRs at dim 128 with 8)
+#ifndef HIPREC_PULL_CHUNK
+#define HIPREC_PULL_CHUNK 8
+#endif
+constexpr int pull_chunk(int npl) { return npl <= 2 ? HIPREC_PULL_CHUNK : 4; }
 
 // OwnedStep.dbg switches parts of the step off for TIMING experiments (1 = every row written directly, racy; 2 = no
 // weight writes at all).  It only exists in builds made with -DHIPREC_OWNED_DEBUG; the product library has no such
@@ -76,6 +81,11 @@ struct OwnedStep {
   // GRAD variant (Adam / RMSprop on the row-sharded planned path): the user rows are not updated; their gradient goes
   // into grad_out, a dense buffer laid out like w (zero on entry: a row that occurs once is a plain store)
   float* grad_out;
+  // PULL variant (hiprec_mf_bpr_epoch_pull): own_* hold the contribution index of hiprec_batch_row_contrib (-1 = this
+  // wave holds the row's complete gradient: plain store of w - lr * g; >= 0: the wave's part of the gradient goes to
+  // row cidx of cbuf [.., dim] / element cidx of cbias with plain stores, pull_apply_kernel sums and applies them)
+  float* cbuf;
+  float* cbias;
 };
 
 // Read a finished accumulator element and leave it zero for the next step: ONE device-scope exchange.  (A device-scope
@@ -105,13 +115,13 @@ __device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
 // Waves never wait for each other inside the loop.
 // NPL <= 2 (dim <= 128): four waves per SIMD, i.e. <= 128 VGPRs -- left alone the local dim-128 instantiation took 131
 // and ran three (a quarter fewer rows in flight for a kernel that lives on memory-level parallelism).
-template <int NPL, bool REMOTE, bool GRAD>
+template <int NPL, bool REMOTE, bool GRAD, bool PULL = false>
 __global__ __launch_bounds__(kOwnedBlock) __attribute__((amdgpu_waves_per_eu(NPL <= 2 ? 4 : 2)))
 void mf_bpr_owned_kernel(
     OwnedStep f, const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
     const int64_t* __restrict__ neg, int64_t batch, float inv_batch, float reg_coef, hiprec_stats* stats,
     Scratch* scratch) {
-  constexpr int CH = owned_chunk(NPL);
+  constexpr int CH = PULL ? pull_chunk(NPL) : owned_chunk(NPL);
   __shared__ float s_red[3 * kOwnedWaves];
   const int lane = lane_id();
   const int wv = wave_in_block();
@@ -120,7 +130,7 @@ void mf_bpr_owned_kernel(
   const int64_t o_ie = f.o_ie, o_ub = f.o_ub, o_ib = f.o_ib, i_st = f.item_stride, b_st = f.bias_stride;
 
   if (static_cast<int>(blockIdx.x) >= f.n_gather_blocks) {
-    if constexpr (REMOTE) return;  // the sharded step settles stats and the scalar bias after its exchange
+    if constexpr (REMOTE || PULL) return;  // the sharded step settles stats and the scalar bias after its exchange
     // ---- the extra block: previous step's partials -> stats and the scalar bias; count this step ----
     if (!apply && threadIdx.x == 0) {  // first launch of an epoch: hiprec_stats_begin_epoch, folded in
       stats->loss_sum = 0.0;
@@ -175,7 +185,7 @@ void mf_bpr_owned_kernel(
 
   // scalar bias after the previous step: the block sums that step's partials once (up to 2048 of them)
   float gb = load_scalar_param(f.gb_read);
-  {
+  if constexpr (!PULL) {   // (PULL: the apply launch of the previous step has updated the scalar already)
     const float4* pv = f.scratch_prev->partials;
     float part = 0.f;
 #pragma unroll
@@ -210,9 +220,11 @@ void mf_bpr_owned_kernel(
     int ltu = 1, ltp = 1, ltn = 1;
     float lbu = 0.f, lbp = 0.f, lbn = 0.f;
     if (lok) {
-      if (lsu >= 0) ltu = f.total[lsu];
-      if (lsp >= 0) ltp = f.total[lsp];
-      if (lsn >= 0) ltn = f.total[lsn];
+      if constexpr (!PULL) {
+        if (lsu >= 0) ltu = f.total[lsu];
+        if (lsp >= 0) ltp = f.total[lsp];
+        if (lsn >= 0) ltn = f.total[lsn];
+      }
       lbu = wf[o_ub + lu];
       lbp = wf[o_ib + lp * b_st];
       lbn = wf[o_ib + ln * b_st];
@@ -269,13 +281,21 @@ void mf_bpr_owned_kernel(
         return;
       }
       if (HIPREC_OWNED_DBG_BIT(2)) return;
-      if (slot < 0 || wt == tot || HIPREC_OWNED_DBG_BIT(1)) {
+      if (slot < 0 || (!PULL && wt == tot) || HIPREC_OWNED_DBG_BIT(1)) {
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
           const int c = lane + kWave * k;
           if (c < D) wf[row + c] = v[k] - f.lr * g[k];
         }
         if (lane == 0) wf[bias] = vb - f.lr * gb_;
+      } else if constexpr (PULL) {
+        float* a = f.cbuf + static_cast<int64_t>(slot) * D;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+          const int c = lane + kWave * k;
+          if (c < D) a[c] = g[k];
+        }
+        if (lane == 0) f.cbias[slot] = gb_;
       } else {
         float* a = f.acc + static_cast<int64_t>(slot) * ld;
 #pragma unroll
@@ -368,7 +388,10 @@ void mf_bpr_owned_kernel(
 
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      if (!((ok_mask >> i) & 1ull)) continue;  // beyond the chunk, padding, or out-of-range ids
+      if (!((ok_mask >> i) & 1ull)) {  // beyond the chunk, padding, or out-of-range ids: skipped
+        if constexpr (PULL) flush_run();  // ... and it ends a run: csrc/ownership.hip counts the runs' heads that way
+        continue;
+      }
       const int64_t u = readlane64(lu, i), p = readlane64(lp, i), n = readlane64(ln, i);
       const float bu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lbu), i));
       const float bp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lbp), i));
@@ -411,7 +434,7 @@ void mf_bpr_owned_kernel(
     flush_run();
 
     // ---- settle the shared rows of this chunk ----
-    if (n_pend > 0) {
+    if (!PULL && n_pend > 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the adds are performed before this wave reports in
       const bool mine = lane < n_pend;
       int old = 0;
@@ -483,21 +506,329 @@ void mf_bpr_owned_kernel(
   }
 }
 
-template <bool REMOTE, bool GRAD = false>
+// ---- owner pulls: the second launch of a hiprec_mf_bpr_epoch_pull step ------------------------------------------
+// One wave per row that several waves of the gradient launch contributed to (hiprec_batch_row_contrib's records):
+// g = the sum of its contiguous range of the contribution buffer, in range order; w - lr * g stored in place -- the
+// row still holds its pre-step value, nobody else writes it.  No float atomics, nothing to clear.  Rows with more than
+// kContribLongRow contributions (listed from the end of the batch's records) take a whole workgroup: every wave sums a
+// strided share, the shares meet in LDS.  Block 0 folds the step's loss partials into hiprec_stats, steps the
+// scalar bias and counts the step (what the extra block of mf_bpr_owned_kernel does one launch late).
+constexpr int kPullBlock = 1024;
+constexpr int kPullWaves = kPullBlock / kWave;
+constexpr int kPullDepth = 8;             // contribution rows a wave keeps in flight
+
+struct PullApply {
+  float* w;
+  int64_t n_users, o_ie, o_ub, o_ib;
+  int32_t dim, begin_epoch, count_step;
+  const float* cbuf;
+  const float* cbias;
+  const int4* rows;              // this batch's records
+  int64_t row_cap;
+  const int32_t* counts;         // this batch's {short rows, long rows, contributions, -}
+  float* gb;                     // the scalar bias
+  float lr;
+};
+
+template <int NPL>
+__device__ __forceinline__ void pull_sum(const PullApply& f, int start, int first, int cnt, int stride, int lane,
+                                         float (&g)[NPL], float& gb) {
+  const int D = f.dim;
+  // contributions first, first + stride, ... < cnt of the range at `start`; kPullDepth rows requested per trip
+  for (int j0 = first; j0 < cnt; j0 += kPullDepth * stride) {
+    float t[kPullDepth][NPL];
+#pragma unroll
+    for (int q = 0; q < kPullDepth; ++q) {
+      const int j = j0 + q * stride;
+      const float* a = f.cbuf + static_cast<int64_t>(start + (j < cnt ? j : first)) * D;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        const int c = lane + kWave * k;
+        t[q][k] = a[c < D ? c : D - 1];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kPullDepth; ++q) {
+      const bool on = j0 + q * stride < cnt;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) g[k] += on ? t[q][k] : 0.f;
+    }
+  }
+  // the bias parts: lane l takes elements first + (l, l + 64, ...) * stride
+  float b = 0.f;
+  for (int j = first + lane * stride; j < cnt; j += kWave * stride) b += f.cbias[start + j];
+  gb += wave_sum(b);
+}
+
+template <int NPL>
+__device__ __forceinline__ void pull_store(const PullApply& f, int key, int lane, const float (&g)[NPL], float gb) {
+  const int D = f.dim;
+  const bool user = key < f.n_users;
+  const int64_t r = user ? key : key - f.n_users;
+  float* row = f.w + (user ? r * D : f.o_ie + r * D);
+  float* bias = f.w + (user ? f.o_ub + r : f.o_ib + r);
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) {
+    const int c = lane + kWave * k;
+    if (c < D) row[c] = row[c] - f.lr * g[k];
+  }
+  if (lane == 0) *bias = *bias - f.lr * gb;
+}
+
+template <int NPL>
+__global__ __launch_bounds__(kPullBlock) void pull_apply_kernel(PullApply f, hiprec_stats* stats, Scratch* scratch) {
+  __shared__ float s_part[kPullWaves][NPL * kWave + 1];
+  const int lane = lane_id(), wv = wave_in_block();
+  const int nb = static_cast<int>(gridDim.x) - 1, blk = static_cast<int>(blockIdx.x) - 1;
+  if (blk < 0) {
+    // ---- the stats block ----
+    if (f.begin_epoch && threadIdx.x == 0) {  // hiprec_stats_begin_epoch, folded in
+      stats->loss_sum = 0.0;
+      stats->reg_sum = 0.0;
+    }
+    if (!f.count_step) return;
+    __syncthreads();
+    const float gb_part = finalize_partials<kPullBlock>(stats, scratch);
+    if (threadIdx.x == 0) {
+      *f.gb = *f.gb - f.lr * gb_part;
+      advance_step(stats);
+      scratch->n_partials = 0;
+    }
+    return;
+  }
+  const int n_short = f.counts[0], n_long = f.counts[1];
+  // long rows first (they are the critical path of the launch): one workgroup each
+  for (int i = blk; i < n_long; i += nb) {
+    const int4 rec = f.rows[f.row_cap - 1 - i];
+    float g[NPL], gb = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) g[k] = 0.f;
+    pull_sum<NPL>(f, rec.y, wv, rec.z, kPullWaves, lane, g, gb);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) s_part[wv][lane + kWave * k] = g[k];
+    if (lane == 0) s_part[wv][NPL * kWave] = gb;
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) g[k] = 0.f;
+      gb = 0.f;
+      for (int w = 0; w < kPullWaves; ++w) {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) g[k] += s_part[w][lane + kWave * k];
+        gb += s_part[w][NPL * kWave];
+      }
+      pull_store<NPL>(f, rec.x, lane, g, gb);
+    }
+    __syncthreads();
+  }
+  for (int i = blk * kPullWaves + wv; i < n_short; i += nb * kPullWaves) {
+    const int4 rec = f.rows[i];
+    float g[NPL], gb = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) g[k] = 0.f;
+    pull_sum<NPL>(f, rec.y, 0, rec.z, 1, lane, g, gb);
+    pull_store<NPL>(f, rec.x, lane, g, gb);
+  }
+}
+
+// The same launch for dim % 4 == 0 (every configuration BASELINE names): LPR lanes x 16 bytes cover one row, so a
+// wave takes 64 / LPR rows at a time with a quarter of the load instructions -- a short row is two dependent round
+// trips (its record, then its contributions and the row itself), and what bounds the launch is how many of those are
+// in flight; a long row's range is read by 16 x 64 / LPR lane groups at kPullDepth rows each per trip.
+template <int LPR>
+__global__ __launch_bounds__(kPullBlock) __attribute__((amdgpu_waves_per_eu(8)))
+void pull_apply_vec_kernel(PullApply f, hiprec_stats* stats, Scratch* scratch) {
+  constexpr int RPW = kWave / LPR;                  // rows a wave works on at once
+  constexpr int GROUPS = kPullWaves * RPW;          // lane groups of the workgroup
+  __shared__ float4 s_part[GROUPS][LPR];
+  __shared__ float s_pb[GROUPS];
+  const int lane = lane_id(), wv = wave_in_block();
+  const int nb = static_cast<int>(gridDim.x) - 1, blk = static_cast<int>(blockIdx.x) - 1;
+#ifdef HIPREC_PULL_EXP
+  if (blk < 0 && (HIPREC_PULL_EXP & 2)) return;
+#endif
+  if (blk < 0) {
+    // ---- the stats block ----
+    if (f.begin_epoch && threadIdx.x == 0) {  // hiprec_stats_begin_epoch, folded in
+      stats->loss_sum = 0.0;
+      stats->reg_sum = 0.0;
+    }
+    if (!f.count_step) return;
+    __syncthreads();
+    const float gb_part = finalize_partials<kPullBlock>(stats, scratch);
+    if (threadIdx.x == 0) {
+      *f.gb = *f.gb - f.lr * gb_part;
+      advance_step(stats);
+      scratch->n_partials = 0;
+    }
+    return;
+  }
+  const int D = f.dim;
+  const int sub = lane / LPR, sl = lane % LPR, grp = wv * RPW + sub;
+  const bool col = sl * 4 < D;
+#ifdef HIPREC_PULL_EXP   // timing experiments (tools/build_variant_lib.sh): 1 = no long rows, 4 = no short rows
+  const int n_short = f.counts[0], n_long = (HIPREC_PULL_EXP & 1) ? 0 : f.counts[1];
+#else
+  const int n_short = f.counts[0], n_long = f.counts[1];
+#endif
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto add4 = [](float4& a, const float4& b) {
+    a.x += b.x;
+    a.y += b.y;
+    a.z += b.z;
+    a.w += b.w;
+  };
+  // contributions first, first + stride, ... < cnt of the range at `start` -> g (this lane's 4 columns) and, summed
+  // over the lane group, gb; kPullDepth rows requested per trip.  `trips` is uniform over the wave.
+  auto sum_range = [&](int start, int first, int cnt, int stride, int trips, float4& g, float& gb) {
+    for (int t = 0; t < trips; ++t) {
+      const int j0 = first + t * kPullDepth * stride;
+      float4 v[kPullDepth];
+#pragma unroll
+      for (int q = 0; q < kPullDepth; ++q) {
+        const int j = j0 + q * stride;
+        v[q] = zero4;
+        if (col && j < cnt) v[q] = *reinterpret_cast<const float4*>(f.cbuf + static_cast<int64_t>(start + j) * D + sl * 4);
+      }
+#pragma unroll
+      for (int q = 0; q < kPullDepth; ++q) add4(g, v[q]);
+    }
+    float b = 0.f;
+    for (int j = first + sl * stride; j < cnt; j += LPR * stride) b += f.cbias[start + j];
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) b += __shfl_xor(b, o);
+    gb += b;
+  };
+  auto row_of = [&](int key, float*& row, float*& bias) {
+    const bool user = key < f.n_users;
+    const int64_t r = user ? key : key - f.n_users;
+    row = f.w + (user ? r * D : f.o_ie + r * D) + sl * 4;
+    bias = f.w + (user ? f.o_ub + r : f.o_ib + r);
+  };
+  // long rows first (they are the critical path of the launch): one workgroup each
+  for (int i = blk; i < n_long; i += nb) {
+    const int4 rec = f.rows[f.row_cap - 1 - i];
+    float4 g = zero4;
+    float gb = 0.f;
+    const int per_trip = kPullDepth * GROUPS;
+    sum_range(rec.y, grp, rec.z, GROUPS, (rec.z + per_trip - 1) / per_trip, g, gb);
+    s_part[grp][sl] = g;
+    if (sl == 0) s_pb[grp] = gb;
+    __syncthreads();
+    if (static_cast<int>(threadIdx.x) < LPR) {   // (one partial wave: GROUPS reads per lane, then the row itself)
+      float4 tot = zero4;
+      float tb = 0.f;
+#pragma unroll 4
+      for (int q = 0; q < GROUPS; ++q) {
+        add4(tot, s_part[q][sl]);
+        tb += s_pb[q];
+      }
+      float *row, *bias;
+      row_of(rec.x, row, bias);
+      if (col) {
+        float4 w4 = *reinterpret_cast<float4*>(row);
+        w4.x -= f.lr * tot.x;
+        w4.y -= f.lr * tot.y;
+        w4.z -= f.lr * tot.z;
+        w4.w -= f.lr * tot.w;
+        *reinterpret_cast<float4*>(row) = w4;
+      }
+      if (sl == 0) *bias = *bias - f.lr * tb;
+    }
+    __syncthreads();
+  }
+  // short rows, TWO per lane group and iteration (rows i and i + nb * GROUPS): their records are requested before the
+  // batch's counts are known (any index below row_cap is addressable), rows and contributions of both travel together
+  constexpr int HALF = 3;   // (most shared rows have 2 or 3 contributions; 64 VGPRs = two workgroups per CU)
+  const int i_first = blk * GROUPS + wv * RPW;
+  int4 rec[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int i = i_first + r * nb * GROUPS + sub;
+    rec[r] = i < f.row_cap ? f.rows[i] : make_int4(0, 0, 0, 0);
+  }
+#ifdef HIPREC_PULL_EXP
+  if (HIPREC_PULL_EXP & 4) return;
+#endif
+  for (int i0 = i_first; __builtin_amdgcn_readfirstlane(i0) < n_short; i0 += 2 * nb * GROUPS) {
+    bool on[2];
+    float4 w4[2], g[2];
+    float wb[2], gb[2];
+    int trips = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      on[r] = i0 + r * nb * GROUPS + sub < n_short;
+      if (!on[r]) rec[r] = make_int4(0, 0, 0, 0);
+      float *row, *bias;
+      row_of(rec[r].x, row, bias);
+      w4[r] = g[r] = zero4;
+      wb[r] = gb[r] = 0.f;
+      if (on[r] && col) w4[r] = *reinterpret_cast<const float4*>(row);
+      if (on[r] && sl == 0) wb[r] = *bias;
+      trips = max(trips, (rec[r].z + HALF - 1) / HALF);
+    }
+#pragma unroll
+    for (int o = LPR; o < kWave; o <<= 1) trips = max(trips, __shfl_xor(trips, o));
+    trips = __builtin_amdgcn_readfirstlane(trips);
+    for (int t = 0; t < trips; ++t) {
+      float4 v[2][HALF];
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < HALF; ++q) {
+          const int j = t * HALF + q;
+          v[r][q] = zero4;
+          if (col && j < rec[r].z)
+            v[r][q] = *reinterpret_cast<const float4*>(f.cbuf + static_cast<int64_t>(rec[r].y + j) * D + sl * 4);
+        }
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < HALF; ++q) add4(g[r], v[r][q]);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      float b = 0.f;
+      for (int j = sl; j < rec[r].z; j += LPR) b += f.cbias[rec[r].y + j];
+#pragma unroll
+      for (int o = 1; o < LPR; o <<= 1) b += __shfl_xor(b, o);
+      gb[r] = b;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      float *row, *bias;
+      row_of(rec[r].x, row, bias);
+      if (on[r] && col) {
+        w4[r].x -= f.lr * g[r].x;
+        w4[r].y -= f.lr * g[r].y;
+        w4[r].z -= f.lr * g[r].z;
+        w4[r].w -= f.lr * g[r].w;
+        *reinterpret_cast<float4*>(row) = w4[r];
+      }
+      if (on[r] && sl == 0) *bias = wb[r] - f.lr * gb[r];
+      // the next iteration's record (the stores above are fire and forget)
+      const int i = i0 + (2 + r) * nb * GROUPS + sub;
+      rec[r] = i < n_short ? f.rows[i] : make_int4(0, 0, 0, 0);
+    }
+  }
+}
+
+template <bool REMOTE, bool GRAD = false, bool PULL = false>
 static int launch_owned(const OwnedStep& f, int grid, hipStream_t st, const int64_t* uu, const int64_t* pp,
                         const int64_t* nn, int64_t b, float inv_b, float reg_coef, hiprec_stats* stats, Scratch* sc) {
   if (f.dim <= 64)
-    mf_bpr_owned_kernel<1, REMOTE, GRAD><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    mf_bpr_owned_kernel<1, REMOTE, GRAD, PULL><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
   else if (f.dim <= 128)
-    mf_bpr_owned_kernel<2, REMOTE, GRAD><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    mf_bpr_owned_kernel<2, REMOTE, GRAD, PULL><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
   else
-    mf_bpr_owned_kernel<4, REMOTE, GRAD><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
+    mf_bpr_owned_kernel<4, REMOTE, GRAD, PULL><<<grid, kOwnedBlock, 0, st>>>(f, uu, pp, nn, b, inv_b, reg_coef, stats, sc);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
 
-static int owned_blocks(int dim, int64_t bb) {
-  const int64_t per_block = static_cast<int64_t>(owned_chunk(dim <= 64 ? 1 : dim <= 128 ? 2 : 4)) * kOwnedWaves;
+static int owned_blocks(int dim, int64_t bb, bool pull = false) {
+  const int npl = dim <= 64 ? 1 : dim <= 128 ? 2 : 4;
+  const int64_t per_block = static_cast<int64_t>(pull ? pull_chunk(npl) : owned_chunk(npl)) * kOwnedWaves;
   return static_cast<int>(std::min<int64_t>((bb + per_block - 1) / per_block, kOwnedMaxGather));
 }
 
@@ -558,6 +889,7 @@ extern "C" int hiprec_mf_bpr_epoch_owned(float* w_flat, int64_t n_users, int64_t
     f.bias_stride = 1;
     f.item_out = nullptr;
     f.grad_out = nullptr;
+    f.cbuf = f.cbias = nullptr;
 #ifdef HIPREC_OWNED_DEBUG
     static const int dbg = getenv("HIPREC_OWNED_DBG") ? atoi(getenv("HIPREC_OWNED_DBG")) : 0;
     f.dbg = dbg;
@@ -569,6 +901,112 @@ extern "C" int hiprec_mf_bpr_epoch_owned(float* w_flat, int64_t n_users, int64_t
                               neg ? neg + off : nullptr, b, inv_b, reg_coef, stats,
                               static_cast<Scratch*>(scratch2[k & 1])))
       return rc;
+  }
+  return 0;
+}
+
+extern "C" int32_t hiprec_mf_pull_chunk(int32_t dim) { return pull_chunk(dim <= 64 ? 1 : dim <= 128 ? 2 : 4); }
+
+// Owner-pulls form of hiprec_mf_bpr_epoch_owned: TWO launches per step, no float atomics.  cidx / rows / counts are
+// hiprec_batch_row_contrib's arrays over the staged epoch (chunk = hiprec_mf_pull_chunk(dim); cidx_stride = the n they
+// were made for: the distance between the roles' thirds of cidx); cbuf [3 * batch, dim]
+// and cbias [3 * batch] are work space (nothing to initialise, nothing to clear).  Every step is complete when its
+// second launch is: the scalar bias element of w_flat and hiprec_stats are current after any piece of the epoch.
+extern "C" int hiprec_mf_bpr_epoch_pull(float* w_flat, int64_t n_users, int64_t n_items, int32_t dim,
+                                        const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                        const int32_t* cidx, int64_t cidx_stride, const int32_t* rows,
+                                        int64_t row_cap, const int32_t* counts, float* cbuf, float* cbias, void* scratch,
+                                        int64_t n_triples, int64_t batch, int64_t step_begin, int64_t step_end,
+                                        float reg_coef, double lr, hiprec_stats* stats, void* stream) {
+  HIPREC_REQUIRE(w_flat && scratch && stats, "NULL pointer");
+  HIPREC_REQUIRE(n_users > 0 && n_items > 0 && dim > 0 && dim <= 256, "owned-rows step needs 0 < dim <= 256");
+  HIPREC_REQUIRE(n_triples >= 0 && batch > 0, "bad n_triples/batch");
+  HIPREC_REQUIRE(n_triples == 0 || (users && pos && neg && cidx && rows && counts && cbuf && cbias),
+                 "NULL index / contribution arrays");
+  HIPREC_REQUIRE(n_triples == 0 || row_cap >= (3 * std::min(batch, n_triples) + 1) / 2, "row_cap too small");
+  HIPREC_REQUIRE(cidx_stride >= n_triples, "cidx_stride %lld < n_triples", (long long)cidx_stride);
+  const int64_t n_steps = (n_triples + batch - 1) / batch;
+  HIPREC_REQUIRE(0 <= step_begin && step_begin <= step_end && step_end <= n_steps,
+                 "bad step range [%lld, %lld) of %lld", (long long)step_begin, (long long)step_end, (long long)n_steps);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t o_gb = (n_users + n_items) * (static_cast<int64_t>(dim) + 1);
+  PullApply a;
+  a.w = w_flat;
+  a.n_users = n_users;
+  a.o_ie = n_users * dim;
+  a.o_ub = (n_users + n_items) * static_cast<int64_t>(dim);
+  a.o_ib = a.o_ub + n_users;
+  a.dim = dim;
+  a.cbuf = cbuf;
+  a.cbias = cbias;
+  a.row_cap = row_cap;
+  a.gb = w_flat + o_gb;
+  a.lr = static_cast<float>(lr);
+  auto launch_apply = [&](int grid) {
+    if (dim % 4 == 0) {
+      if (dim <= 64) pull_apply_vec_kernel<16><<<grid, kPullBlock, 0, st>>>(a, stats, static_cast<Scratch*>(scratch));
+      else if (dim <= 128) pull_apply_vec_kernel<32><<<grid, kPullBlock, 0, st>>>(a, stats, static_cast<Scratch*>(scratch));
+      else pull_apply_vec_kernel<64><<<grid, kPullBlock, 0, st>>>(a, stats, static_cast<Scratch*>(scratch));
+      return;
+    }
+    if (dim <= 64) pull_apply_kernel<1><<<grid, kPullBlock, 0, st>>>(a, stats, static_cast<Scratch*>(scratch));
+    else if (dim <= 128) pull_apply_kernel<2><<<grid, kPullBlock, 0, st>>>(a, stats, static_cast<Scratch*>(scratch));
+    else pull_apply_kernel<4><<<grid, kPullBlock, 0, st>>>(a, stats, static_cast<Scratch*>(scratch));
+  };
+  if (n_steps == 0) {   // an empty epoch still begins: the epoch sums are zero afterwards
+    a.begin_epoch = 1;
+    a.count_step = 0;
+    a.rows = nullptr;
+    a.counts = nullptr;
+    launch_apply(1);
+    HIPREC_TRY(hipGetLastError());
+    return 0;
+  }
+  for (int64_t k = step_begin; k < step_end; ++k) {
+    const int64_t off = k * batch;
+    const int64_t b = std::min<int64_t>(batch, n_triples - off);
+    OwnedStep f;
+    f.w = w_flat;
+    f.n_users = n_users;
+    f.n_items = n_items;
+    f.dim = dim;
+    f.apply_prev = 0;
+    f.own_u = cidx + off;
+    f.own_p = cidx + cidx_stride + off;
+    f.own_n = cidx + 2 * cidx_stride + off;
+    f.total = nullptr;
+    f.arrived = nullptr;
+    f.acc = nullptr;
+    f.gb_read = w_flat + o_gb;
+    f.gb_write = nullptr;
+    f.scratch_prev = static_cast<const Scratch*>(scratch);
+    f.n_prev_partials = 0;
+    f.n_gather_blocks = owned_blocks(dim, b, true);
+    f.lr = static_cast<float>(lr);
+    f.dbg = 0;
+    f.o_ie = n_users * dim;
+    f.o_ub = (n_users + n_items) * static_cast<int64_t>(dim);
+    f.o_ib = f.o_ub + n_users;
+    f.item_stride = dim;
+    f.bias_stride = 1;
+    f.item_out = nullptr;
+    f.grad_out = nullptr;
+    f.cbuf = cbuf;
+    f.cbias = cbias;
+    if (int rc = launch_owned<false, false, true>(f, f.n_gather_blocks, st, users + off, pos + off, neg + off, b,
+                                                  1.0f / static_cast<float>(b), reg_coef, stats,
+                                                  static_cast<Scratch*>(scratch)))
+      return rc;
+    a.begin_epoch = k == 0 ? 1 : 0;
+    a.count_step = 1;
+    a.rows = reinterpret_cast<const int4*>(rows) + k * row_cap;
+    a.counts = counts + 4 * k;
+    // one wave (lane group) per shared row and trip; a batch shares at most 3 b / 2 rows, typically a tenth of its
+    // 3 b; 512 workgroups = two per CU is all the chip holds at once
+    const int64_t per_block = dim % 4 ? kPullWaves : kPullWaves * (dim <= 64 ? 4 : dim <= 128 ? 2 : 1);
+    const int64_t waves = std::max<int64_t>(b / 4, 1);
+    launch_apply(static_cast<int>(std::min<int64_t>((waves + per_block - 1) / per_block, 512)) + 1);
+    HIPREC_TRY(hipGetLastError());
   }
   return 0;
 }
@@ -618,6 +1056,7 @@ static int owned_remote_impl(float* w_flat, float* g_flat, int64_t n_users, int6
   f.item_stride = f.bias_stride = dim + 1;
   f.item_out = g_send;
   f.grad_out = g_flat;
+  f.cbuf = f.cbias = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (g_flat)
     return launch_owned<true, true>(f, f.n_gather_blocks, st, users, pos_slot, neg_slot, batch, inv_batch, reg_coef,
@@ -697,6 +1136,7 @@ extern "C" int hiprec_mf_bpr_grad_owned(const float* w_flat, float* g_flat, int6
   f.bias_stride = 1;
   f.item_out = nullptr;
   f.grad_out = g_flat;
+  f.cbuf = f.cbias = nullptr;
   return launch_owned<false, true>(f, f.n_gather_blocks, static_cast<hipStream_t>(stream), users, pos, neg, batch,
                                    inv_batch, reg_coef, stats, static_cast<Scratch*>(scratch));
 }

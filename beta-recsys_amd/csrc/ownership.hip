@@ -52,15 +52,31 @@ struct BucketTriple {
   int32_t key[3];
   int bucket[3];
   bool ok;
+  bool pos_counts;   // false: a positive occurrence that rides in the run of equal items its chunk neighbour heads
 };
 
+__device__ __forceinline__ bool triple_in_range(const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
+                                                const int64_t* __restrict__ neg, int64_t t, int64_t n_users,
+                                                int64_t n_items) {
+  return static_cast<uint64_t>(users[t]) < static_cast<uint64_t>(n_users) &&
+         static_cast<uint64_t>(pos[t]) < static_cast<uint64_t>(n_items) &&
+         static_cast<uint64_t>(neg[t]) < static_cast<uint64_t>(n_items);
+}
+
+// chunk > 0 (the contribution lists of the owner-pulls step): the step kernel hands `chunk` consecutive triples of a
+// batch to one wave, which sums the run of equal positive items itself -- only the run's HEAD contributes to the row.
+// j = the triple's position inside its batch.  A triple with an out-of-range id ends a run (the kernel skips it).
 __device__ __forceinline__ BucketTriple bucket_triple(const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
                                                       const int64_t* __restrict__ neg, int64_t t, int64_t n_users,
-                                                      int64_t n_items, int table_bits, int part_bits, int n_parts) {
+                                                      int64_t n_items, int table_bits, int part_bits, int n_parts,
+                                                      int chunk = 0, int64_t j = 0) {
   BucketTriple r;
   const int64_t u = users[t], p = pos[t], q = neg[t];
   r.ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(n_users) && static_cast<uint64_t>(p) < static_cast<uint64_t>(n_items) &&
          static_cast<uint64_t>(q) < static_cast<uint64_t>(n_items);
+  r.pos_counts = true;
+  if (chunk > 0 && r.ok && j % chunk != 0)
+    r.pos_counts = pos[t - 1] != p || !triple_in_range(users, pos, neg, t - 1, n_users, n_items);
   r.key[0] = static_cast<int32_t>(u);
   r.key[1] = static_cast<int32_t>(n_users + p);
   r.key[2] = static_cast<int32_t>(n_users + q);
@@ -77,7 +93,7 @@ __global__ __launch_bounds__(kBucketThreads) void ownership_bucket_kernel(
     const int64_t* __restrict__ users, const int64_t* __restrict__ pos, const int64_t* __restrict__ neg, int64_t n,
     int64_t batch, int64_t n_users, int64_t n_items, int table_bits, int slices, int32_t* __restrict__ counts,
     int32_t* __restrict__ cursor, int32_t* __restrict__ bkey, uint32_t* __restrict__ bidx, int32_t* __restrict__ boff,
-    int32_t* __restrict__ own) {
+    int32_t* __restrict__ own, int chunk) {
   __shared__ int32_t s_hist[2 * kOwnMaxParts];
   __shared__ int32_t s_base[2 * kOwnMaxParts];
   const int part_bits = table_bits < kOwnPartBits ? table_bits : kOwnPartBits;
@@ -88,13 +104,15 @@ __global__ __launch_bounds__(kBucketThreads) void ownership_bucket_kernel(
   for (int i = threadIdx.x; i < nb; i += kBucketThreads) s_hist[i] = 0;
   __syncthreads();
   for (int64_t j = j0 + threadIdx.x; j < j1; j += kBucketThreads) {
-    const BucketTriple r = bucket_triple(users, pos, neg, t0 + j, n_users, n_items, table_bits, part_bits, n_parts);
+    const BucketTriple r = bucket_triple(users, pos, neg, t0 + j, n_users, n_items, table_bits, part_bits, n_parts, chunk, j);
     if (!r.ok) {
       if (!SCATTER) own[t0 + j] = own[n + t0 + j] = own[2 * n + t0 + j] = -1;
       continue;
     }
+    if (!SCATTER && !r.pos_counts) own[n + t0 + j] = -2;   // rides in its chunk neighbour's run
 #pragma unroll
-    for (int k = 0; k < 3; ++k) atomicAdd(&s_hist[r.bucket[k]], 1);
+    for (int k = 0; k < 3; ++k)
+      if (k != 1 || r.pos_counts) atomicAdd(&s_hist[r.bucket[k]], 1);
   }
   __syncthreads();
   int32_t* cb = counts + b * static_cast<int64_t>(nb);
@@ -128,10 +146,11 @@ __global__ __launch_bounds__(kBucketThreads) void ownership_bucket_kernel(
     int32_t* k_out = bkey + 3 * t0;
     uint32_t* i_out = bidx + 3 * t0;
     for (int64_t j = j0 + threadIdx.x; j < j1; j += kBucketThreads) {
-      const BucketTriple r = bucket_triple(users, pos, neg, t0 + j, n_users, n_items, table_bits, part_bits, n_parts);
+      const BucketTriple r = bucket_triple(users, pos, neg, t0 + j, n_users, n_items, table_bits, part_bits, n_parts, chunk, j);
       if (!r.ok) continue;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
+        if (k == 1 && !r.pos_counts) continue;
         const int at = s_base[r.bucket[k]] + atomicAdd(&s_hist[r.bucket[k]], 1);
         k_out[at] = r.key[k];
         i_out[at] = static_cast<uint32_t>(k * cnt + j);
@@ -212,6 +231,149 @@ __global__ __launch_bounds__(kOwnThreads) void ownership_kernel(const int32_t* _
   for (uint32_t i = threadIdx.x; i < part_size; i += kOwnThreads) {
     total[tab0 + i] = s_cnt[i];
     if (tab_keys) tab_keys[tab0 + i] = s_key[i];
+  }
+}
+
+// ---- contribution lists for the owner-pulls step (csrc/mf_owned.hip, hiprec_mf_bpr_epoch_pull) ------------------------
+// The same tables, counting CONTRIBUTIONS instead of occurrences (a wave's run of equal positive items is one
+// contribution, made by its head).  A row with one contribution is updated in place by its contributor (cidx = -1).
+// A row with several gets a contiguous range of the step's contribution buffer -- cidx = range start + arrival rank:
+// the contributor stores its part of the gradient THERE with plain stores -- and one record {row key, range start,
+// contributions} in the batch's row list; after the gradient launch one wave per record sums the range and writes
+// w - lr * g: no float atomics, no arrival counters, nothing to clear.  Records of rows with more than
+// kContribLongRow contributions (a Zipf head item at configs[3]: ~650 runs) are listed from the END of the list and
+// taken by a whole workgroup each.  counts[b] = {short rows, long rows, contributions, -}.
+constexpr int kContribLongRow = 32;
+
+__global__ __launch_bounds__(kOwnThreads) void contrib_kernel(int32_t* __restrict__ bkey,
+                                                              const uint32_t* __restrict__ bidx,
+                                                              const int32_t* __restrict__ boff, int64_t n,
+                                                              int64_t batch, int table_bits,
+                                                              int32_t* __restrict__ cidx, int4* __restrict__ rows,
+                                                              int64_t row_cap, int32_t* __restrict__ counts) {
+  extern __shared__ int32_t s_tab[];          // [part_size] keys, then [part_size] counts -> range starts
+  __shared__ int32_t s_wave[3][kOwnThreads / kWave];
+  __shared__ int32_t s_base[3];
+  const int part_bits = table_bits < kOwnPartBits ? table_bits : kOwnPartBits;
+  const uint32_t part_size = 1u << part_bits, part_mask = part_size - 1u;
+  const int n_parts = 1 << (table_bits - part_bits);
+  const int64_t b = blockIdx.x / n_parts;
+  const uint32_t part = static_cast<uint32_t>(blockIdx.x % n_parts);
+  int32_t* s_key = s_tab;
+  int32_t* s_cnt = s_tab + part_size;
+  for (uint32_t i = threadIdx.x; i < part_size; i += kOwnThreads) {
+    s_key[i] = -1;
+    s_cnt[i] = 0;
+  }
+  __syncthreads();
+  const int64_t t0 = b * batch;
+  const int64_t cnt = min<int64_t>(batch, n - t0);
+  const int32_t* off = boff + b * (2 * static_cast<int64_t>(n_parts) + 1);
+  int32_t* keys = bkey + 3 * t0;
+  const uint32_t* idx = bidx + 3 * t0;
+  auto where = [&](uint32_t i) {
+    const int role = i < cnt ? 0 : i < 2 * cnt ? 1 : 2;
+    return role * n + t0 + (static_cast<int64_t>(i) - role * cnt);
+  };
+  // pass 1: insert every contribution; its table entry replaces its key in the bucket, its arrival rank waits in cidx
+  for (int phase = 0; phase < 2; ++phase) {
+    const int lo = off[phase * n_parts + part], hi = off[phase * n_parts + part + 1];
+    for (int j = lo + static_cast<int>(threadIdx.x); j < hi; j += kOwnThreads) {
+      const int32_t key = keys[j];
+      uint32_t h = hash_u32(static_cast<uint32_t>(key)) & part_mask;
+      for (uint32_t probes = 0;; ++probes) {
+        const int32_t prev = atomicCAS(s_key + h, -1, key);
+        if (prev == -1 || prev == key) break;
+        h = (h + 1u) & part_mask;
+        if (probes > part_size) {  // a full partition (cannot happen at >= 4 x batch entries): give up, never spin
+          h = part_size;
+          break;
+        }
+      }
+      keys[j] = static_cast<int32_t>(h);
+      if (h != part_size) cidx[where(idx[j])] = atomicAdd(s_cnt + h, 1);
+    }
+  }
+  __syncthreads();
+  // scan: every thread owns kContribPerThread consecutive entries (fewer for small tables)
+  const uint32_t per = part_size >= kOwnThreads ? part_size / kOwnThreads : 1;
+  const uint32_t e0 = threadIdx.x * per;
+  int32_t my_c = 0, my_s = 0, my_l = 0;
+  if (e0 < part_size)
+    for (uint32_t e = e0; e < e0 + per; ++e) {
+      const int32_t c = s_cnt[e];
+      if (c >= 2) {
+        my_c += c;
+        if (c > kContribLongRow) ++my_l;
+        else ++my_s;
+      }
+    }
+  int32_t in_c = my_c, in_s = my_s, in_l = my_l;
+  const int lane = lane_id(), wv = wave_in_block();
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const int32_t uc = __shfl_up(in_c, o), us = __shfl_up(in_s, o), ul = __shfl_up(in_l, o);
+    if (lane >= o) {
+      in_c += uc;
+      in_s += us;
+      in_l += ul;
+    }
+  }
+  if (lane == kWave - 1) {
+    s_wave[0][wv] = in_c;
+    s_wave[1][wv] = in_s;
+    s_wave[2][wv] = in_l;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t tc = 0, ts = 0, tl = 0;
+    for (int w = 0; w < kOwnThreads / kWave; ++w) {
+      const int32_t c = s_wave[0][w], s_ = s_wave[1][w], l = s_wave[2][w];
+      s_wave[0][w] = tc;
+      s_wave[1][w] = ts;
+      s_wave[2][w] = tl;
+      tc += c;
+      ts += s_;
+      tl += l;
+    }
+    int32_t* cb = counts + 4 * b;
+    s_base[0] = tc ? atomicAdd(cb + 2, tc) : 0;
+    s_base[1] = ts ? atomicAdd(cb + 0, ts) : 0;
+    s_base[2] = tl ? atomicAdd(cb + 1, tl) : 0;
+  }
+  __syncthreads();
+  if (e0 < part_size) {
+    int32_t at_c = s_base[0] + s_wave[0][wv] + in_c - my_c;
+    int32_t at_s = s_base[1] + s_wave[1][wv] + in_s - my_s;
+    int32_t at_l = s_base[2] + s_wave[2][wv] + in_l - my_l;
+    int4* rb = rows + b * row_cap;
+    for (uint32_t e = e0; e < e0 + per; ++e) {
+      const int32_t c = s_cnt[e];
+      if (c >= 2) {
+        const int4 rec = make_int4(s_key[e], at_c, c, 0);
+        if (c > kContribLongRow) rb[row_cap - 1 - at_l++] = rec;
+        else rb[at_s++] = rec;
+        s_cnt[e] = at_c;
+        at_c += c;
+      } else {
+        s_cnt[e] = -1;
+      }
+    }
+  }
+  __syncthreads();
+  // pass 2: range start + arrival rank
+  for (int phase = 0; phase < 2; ++phase) {
+    const int lo = off[phase * n_parts + part], hi = off[phase * n_parts + part + 1];
+    for (int j = lo + static_cast<int>(threadIdx.x); j < hi; j += kOwnThreads) {
+      const uint32_t h = static_cast<uint32_t>(keys[j]);
+      const int64_t at = where(idx[j]);
+      if (h == part_size) {
+        cidx[at] = -1;
+        continue;
+      }
+      const int32_t start = s_cnt[h];
+      cidx[at] = start < 0 ? -1 : start + cidx[at];
+    }
   }
 }
 
@@ -370,9 +532,9 @@ static int ownership_impl(const int64_t* users, const int64_t* pos, const int64_
   HIPREC_TRY(hipMemsetAsync(counts, 0, sizeof(int32_t) * n_batches * 4 * n_parts, st));
   const int pre = static_cast<int>(n_batches * slices);
   ownership_bucket_kernel<false><<<pre, kBucketThreads, 0, st>>>(users, pos, neg, n, batch, n_users, n_items, table_bits,
-                                                                 static_cast<int>(slices), counts, cursor, bkey, bidx, boff, own);
+                                                                 static_cast<int>(slices), counts, cursor, bkey, bidx, boff, own, 0);
   ownership_bucket_kernel<true><<<pre, kBucketThreads, 0, st>>>(users, pos, neg, n, batch, n_users, n_items, table_bits,
-                                                                static_cast<int>(slices), counts, cursor, bkey, bidx, boff, own);
+                                                                static_cast<int>(slices), counts, cursor, bkey, bidx, boff, own, 0);
   ownership_kernel<<<static_cast<int>(grid), kOwnThreads, lds, st>>>(bkey, bidx, boff, n, batch, table_bits, total, own,
                                                                      tab_keys, pos_cnt, occ);
   HIPREC_TRY(hipGetLastError());
@@ -393,6 +555,57 @@ extern "C" int hiprec_batch_row_ownership_tables(const int64_t* users, const int
   HIPREC_REQUIRE(tab_keys && pos_cnt && occ, "NULL pointer");
   return ownership_impl(users, pos, neg, n, batch, n_users, n_items, table_bits, keys, total, own, tab_keys, pos_cnt,
                         occ, stream);
+}
+
+extern "C" int64_t hiprec_contrib_row_cap(int64_t batch) { return batch > 0 ? (3 * batch + 1) / 2 : 0; }
+
+extern "C" int hiprec_batch_row_contrib(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
+                                        int64_t batch, int64_t n_users, int64_t n_items, int32_t table_bits,
+                                        int32_t chunk, int32_t* ws, int32_t* cidx, int32_t* rows, int64_t row_cap,
+                                        int32_t* counts, void* stream) {
+  HIPREC_REQUIRE(n >= 0 && batch > 0 && n_users > 0 && n_items > 0, "bad sizes");
+  HIPREC_REQUIRE(chunk > 0, "chunk = the triples one wave of the step kernel takes (hiprec_mf_pull_chunk)");
+  HIPREC_REQUIRE(n_users + n_items < (1ll << 31), "row keys need n_users + n_items < 2^31");
+  HIPREC_REQUIRE(table_bits >= 2 && table_bits <= 24 && (1ll << table_bits) >= 4 * std::min<int64_t>(batch, n > 0 ? n : 1),
+                 "table of 2^%d entries does not fit batches of %lld (at least 4 x the batch, at most 2^24 entries)",
+                 table_bits, (long long)batch);
+  HIPREC_REQUIRE(3 * batch < (1ll << 31), "batch too large for 32-bit occurrence indices");
+  HIPREC_REQUIRE(row_cap >= hiprec_contrib_row_cap(std::min<int64_t>(batch, n > 0 ? n : 1)),
+                 "row_cap %lld: a batch can share up to %lld rows", (long long)row_cap,
+                 (long long)hiprec_contrib_row_cap(batch));
+  if (n == 0) return 0;
+  HIPREC_REQUIRE(users && pos && neg && ws && cidx && rows && counts, "NULL pointer");
+  const int64_t n_batches = (n + batch - 1) / batch;
+  const int part_bits = std::min<int>(table_bits, kOwnPartBits);
+  const int64_t n_parts = 1ll << (table_bits - part_bits);
+  const int64_t grid = n_batches * n_parts;
+  HIPREC_REQUIRE(grid < (1ll << 31), "too many (batch, partition) pairs");
+  const size_t lds = sizeof(int32_t) * 2 * (static_cast<size_t>(1) << part_bits);
+  static std::atomic<uint64_t> lds_ok{0};
+  if (int rc = allow_dynamic_lds({reinterpret_cast<const void*>(contrib_kernel)}, 2 * sizeof(int32_t) << kOwnPartBits,
+                                 lds_ok, "the contribution tables"))
+    return rc;
+  int32_t* bkey = ws;
+  uint32_t* bidx = reinterpret_cast<uint32_t*>(ws + 3 * n);
+  int32_t* boff = ws + 6 * n;
+  int32_t* bcounts = boff + n_batches * (2 * n_parts + 1);
+  int32_t* cursor = bcounts + n_batches * 2 * n_parts;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t slices = (std::min<int64_t>(batch, n) + kBucketSlice - 1) / kBucketSlice;
+  HIPREC_REQUIRE(n_batches * slices < (1ll << 31), "too many pre-pass workgroups");
+  HIPREC_TRY(hipMemsetAsync(bcounts, 0, sizeof(int32_t) * n_batches * 4 * n_parts, st));
+  HIPREC_TRY(hipMemsetAsync(counts, 0, sizeof(int32_t) * 4 * n_batches, st));
+  const int pre = static_cast<int>(n_batches * slices);
+  ownership_bucket_kernel<false><<<pre, kBucketThreads, 0, st>>>(users, pos, neg, n, batch, n_users, n_items, table_bits,
+                                                                 static_cast<int>(slices), bcounts, cursor, bkey, bidx, boff,
+                                                                 cidx, chunk);
+  ownership_bucket_kernel<true><<<pre, kBucketThreads, 0, st>>>(users, pos, neg, n, batch, n_users, n_items, table_bits,
+                                                                static_cast<int>(slices), bcounts, cursor, bkey, bidx, boff,
+                                                                cidx, chunk);
+  contrib_kernel<<<static_cast<int>(grid), kOwnThreads, lds, st>>>(bkey, bidx, boff, n, batch, table_bits, cidx,
+                                                                   reinterpret_cast<int4*>(rows), row_cap, counts);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
 }
 
 extern "C" int hiprec_gather_epoch(const int64_t* users, const int64_t* pos, const int64_t* neg, const int64_t* perm,

@@ -330,6 +330,33 @@ def batch_row_ownership(users, pos, neg, batch_size, n_users, n_items):
     return own, total, stride
 
 
+class RowContributions(tuple):
+    """(cidx int32 [3, n], rows int32 [n_batches, row_cap, 4], counts int32 [n_batches, 4], row_cap) of a staged
+    epoch: hiprec_batch_row_contrib's arrays for the owner-pulls step (hiprec_mf_bpr_epoch_pull)."""
+
+
+def batch_row_contributions(users, pos, neg, batch_size, n_users, n_items, dim):
+    """For an epoch laid out in visiting order: who contributes to which row of a batch (csrc/ownership.hip,
+    ``hiprec_batch_row_contrib``).  ``cidx`` -1: the row's only contribution (its contributor updates it in place);
+    >= 0: the contribution's place in the step's contribution buffer; -2: a positive occurrence inside its chunk
+    neighbour's run.  ``rows`` / ``counts``: the records of the rows with several contributions."""
+    lib = _lib.load()
+    n, dev = users.numel(), users.device
+    n_batches = max((n + batch_size - 1) // batch_size, 1)
+    bits = lib.hiprec_ownership_table_bits(batch_size)
+    row_cap = lib.hiprec_contrib_row_cap(batch_size)
+    i32 = dict(dtype=torch.int32, device=dev)
+    ws = torch.empty(max(lib.hiprec_ownership_ws_ints(n, batch_size, bits), 1), **i32)
+    cidx = torch.empty((3, n), **i32)
+    rows = torch.empty((n_batches, row_cap, 4), **i32)
+    counts = torch.zeros((n_batches, 4), **i32)
+    _lib.check(lib.hiprec_batch_row_contrib(
+        _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), n, batch_size, n_users, n_items, bits,
+        lib.hiprec_mf_pull_chunk(dim), _lib.ptr(ws), _lib.ptr(cidx), _lib.ptr(rows), row_cap, _lib.ptr(counts),
+        _lib.stream_ptr(dev)))
+    return RowContributions((cidx, rows, counts, row_cap))
+
+
 def group_epoch_by_item(users, pos, neg, batch_size, n_users, n_items):
     """An epoch in visiting order -> the same batches, each GROUPED BY POSITIVE ITEM (any order of the groups), plus the
     row-ownership arrays of the owned-rows step for the new layout: ``(users, pos, neg, (own, total, stride))``.  No
@@ -870,8 +897,9 @@ class MFEngine(ModelEngine):
             done = torch.cuda.Event()
             done.record(pf["side"])
         if prepared.own is not None:  # allocated on the side stream, read (and eventually freed) under the main one
-            for t in prepared.own[:2]:
-                t.record_stream(main)
+            for t in prepared.own:
+                if torch.is_tensor(t):
+                    t.record_stream(main)
         self._prefetched = (train_loader, done, prepared, self._loader_fingerprint(train_loader))
         return True
 
@@ -909,8 +937,8 @@ class MFEngine(ModelEngine):
         """(touched-rows SGD?, owned-rows resident step?) -- see _setup."""
         mode = self.config["model"].get("sgd_mode", "auto")
         big = self.model.flat.numel() * 4 >= self.ROWS_SGD_MIN_BYTES
-        rows = self.optimizer.name == "sgd" and (mode in ("rows", "owned") or (mode == "auto" and big))
-        return rows, rows and mode in ("owned", "auto") and self.model.emb_dim <= 256
+        rows = self.optimizer.name == "sgd" and (mode in ("rows", "owned", "owned_atomic") or (mode == "auto" and big))
+        return rows, rows and mode in ("owned", "owned_atomic", "auto") and self.model.emb_dim <= 256
 
     def _finish_staging(self, staged):
         """Wrap a staged epoch; the owned-rows SGD step also needs to know which rows its batches share."""
@@ -924,8 +952,18 @@ class MFEngine(ModelEngine):
         prepared = PreparedEpoch(staged)
         users, pos, neg, perm, bs = prepared
         if owned and perm is None and users.device.type == "cuda":
-            prepared.own = batch_row_ownership(users, pos, neg, bs, self.model.n_users, self.model.n_items)
+            if self._sgd_modes()[1] and self._owned_form() == "pull" and self.model.n_users + self.model.n_items < 2**31:
+                prepared.own = batch_row_contributions(users, pos, neg, bs, self.model.n_users, self.model.n_items,
+                                                       self.model.emb_dim)
+            else:
+                prepared.own = batch_row_ownership(users, pos, neg, bs, self.model.n_users, self.model.n_items)
         return prepared
+
+    def _owned_form(self):
+        """``sgd_mode``: "owned" / "auto" = owner pulls (two launches per step, no float atomics: rows several waves
+        contribute to are summed from a contribution buffer by one wave each); "owned_atomic" = the one-launch form
+        whose shared rows collect device-scope atomic adds (rounds 2-4)."""
+        return "atomic" if self.config["model"].get("sgd_mode", "auto") == "owned_atomic" else "pull"
 
     def _lazy_owned(self):
         """Lazy Adam / RMSprop epochs (BPR) take their gradients from the owned-rows kernel (csrc/mf_owned.hip: complete
@@ -1074,6 +1112,8 @@ class MFEngine(ModelEngine):
         step, rows updated in place by the wave that holds their complete gradient.  Work space: one compact
         accumulator row + arrival counter per shared row of a batch (zero between steps), nothing table-sized."""
         users, pos, neg, _, bs = prepared
+        if isinstance(prepared.own, RowContributions):
+            return self._run_pull_epoch(lib, prepared, n_run, steps)
         own, total, stride = prepared.own
         m = self.model
         dev = m.flat.device
@@ -1093,6 +1133,30 @@ class MFEngine(ModelEngine):
             _lib.ptr(own[0]), _lib.ptr(own[1]), _lib.ptr(own[2]), _lib.ptr(total), stride,
             _lib.ptr(ob["arrived"]), _lib.ptr(ob["acc"]), ob["stride"], _lib.ptr(ob["gb"]), s_arr, n_run, bs,
             a, b, float(self.reg), self.optimizer.lr, _lib.ptr(self._stats), _lib.stream_ptr(dev)))
+
+    def _run_pull_epoch(self, lib, prepared, n_run, steps):
+        """hiprec_mf_bpr_epoch_pull (csrc/mf_owned.hip): the owned-rows step as owner pulls.  Work space: one
+        contribution row per row occurrence of a batch (worst case; plain stores, never cleared)."""
+        users, pos, neg, _, bs = prepared
+        cidx, rows, counts, row_cap = prepared.own
+        m = self.model
+        dev = m.flat.device
+        n = users.numel()
+        cap = 3 * min(bs, max(n, 1))
+        pb = getattr(self, "_pull_bufs", None)
+        if pb is None or pb["dev"] != dev or pb["cap"] < cap:
+            pb = self._pull_bufs = {
+                "dev": dev, "cap": cap,
+                "cbuf": torch.empty(cap * m.emb_dim, dtype=torch.float32, device=dev),
+                "cbias": torch.empty(cap, dtype=torch.float32, device=dev),
+                "scratch": torch.zeros_like(self._scratch)}
+        n_steps = (n_run + bs - 1) // bs
+        a, b = (0, n_steps) if steps is None else steps
+        _lib.check(lib.hiprec_mf_bpr_epoch_pull(
+            _lib.ptr(m.flat), m.n_users, m.n_items, m.emb_dim, _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg),
+            _lib.ptr(cidx), n, _lib.ptr(rows), row_cap, _lib.ptr(counts), _lib.ptr(pb["cbuf"]), _lib.ptr(pb["cbias"]),
+            _lib.ptr(pb["scratch"]), n_run, bs, a, b, float(self.reg), self.optimizer.lr, _lib.ptr(self._stats),
+            _lib.stream_ptr(dev)))
 
     def _begin_epoch_marker(self, prepared, prefetch):
         self._ev_epoch_begin = torch.cuda.Event()

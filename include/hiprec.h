@@ -332,6 +332,37 @@ int hiprec_batch_row_ownership(const int64_t* users, const int64_t* pos, const i
                                int64_t batch, int64_t n_users, int64_t n_items, int32_t table_bits,
                                int32_t* ws, int32_t* total, int32_t* own, void* stream);
 
+/* ---- round 5: the same step as OWNER PULLS -- two launches per step, no float atomics (csrc/mf_owned.hip,
+ * csrc/ownership.hip).  Replaces, like hiprec_mf_bpr_epoch_owned, loss.backward() + torch.optim.SGD.step() of
+ * beta_rec/models/mf.py:101-118 and models/torch_engine.py:25-29 for tables beyond the caches.
+ * hiprec_batch_row_contrib (staging; integer work, weights not read) counts, per batch, the CONTRIBUTIONS to every
+ * row: a user or negative occurrence is one; of the positive occurrences only the head of a run of equal items inside
+ * one `chunk` of consecutive triples (chunk = hiprec_mf_pull_chunk(dim): what one wave of the step kernel takes; it
+ * sums the run itself).  Outputs: cidx[3 * n] (role-major like hiprec_batch_row_ownership's own[]): -1 = the row has
+ * this one contribution (its contributor stores w - lr * g in place), >= 0 = where the contribution goes in the
+ * step's contribution buffer, -2 = a positive occurrence that rides in its neighbour's run; rows[n_batches][row_cap]
+ * records {row key (user row, or n_users + item row), first contribution, contributions, 0} of the rows with several
+ * (row_cap >= hiprec_contrib_row_cap(batch); rows with more than 32 contributions are listed from the END of a
+ * batch's records); counts[n_batches][4] = {records from the front, records from the end, contributions, -}.  ws:
+ * hiprec_ownership_ws_ints(n, batch, table_bits) int32s.
+ * hiprec_mf_bpr_epoch_pull: per step the gradient launch (rows with one contribution updated in place, the others'
+ * parts stored to cbuf [3 * batch, dim] / cbias [3 * batch]: work space, never initialised or cleared; cidx_stride =
+ * the n hiprec_batch_row_contrib was called with, n_triples <= cidx_stride being the part of that epoch to run) and the apply
+ * launch (one wave per record sums its range and stores w - lr * g; its first block books loss / regulariser, steps
+ * the scalar bias and the clock).  Every step is complete when its second launch is.  Same semantics as
+ * hiprec_mf_bpr_epoch_owned; the order in which a row's contributions are summed is the order of the range. */
+int32_t hiprec_mf_pull_chunk(int32_t dim);
+int64_t hiprec_contrib_row_cap(int64_t batch);
+int hiprec_batch_row_contrib(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n, int64_t batch,
+                             int64_t n_users, int64_t n_items, int32_t table_bits, int32_t chunk, int32_t* ws,
+                             int32_t* cidx, int32_t* rows, int64_t row_cap, int32_t* counts, void* stream);
+int hiprec_mf_bpr_epoch_pull(float* w_flat, int64_t n_users, int64_t n_items, int32_t dim, const int64_t* users,
+                             const int64_t* pos, const int64_t* neg, const int32_t* cidx, int64_t cidx_stride,
+                             const int32_t* rows, int64_t row_cap, const int32_t* counts, float* cbuf, float* cbias,
+                             void* scratch,
+                             int64_t n_triples, int64_t batch, int64_t step_begin, int64_t step_end, float reg_coef,
+                             double lr, hiprec_stats* stats, void* stream);
+
 /* ---- the row-sharded engine's epoch-planned SGD step (beta-recsys_amd/sharded.py).  Per step and
  * rank: hiprec_shard_gather_payload (rows of the items peers asked for) -> all-to-all -> this call ->
  * hiprec_shard_publish_partials -> all-to-all back -> hiprec_shard_apply_rows + hiprec_shard_finish_step.

@@ -988,8 +988,11 @@ def _zipf_triples(rng, n, U, I, hot=None):
     (5_000, 4_000, 100, 1000, 3, None, 0.01),  # dim not a multiple of 64, short last batch, reg != 0
     (2_000, 1_500, 256, 512, 3, 0.1, None),
 ])
-def test_owned_rows_epoch_matches_the_oracle(hip_device, U, I, D, B, steps, hot, reg):
-    """sgd_mode 'owned': one launch per step, rows updated in place by whoever holds their complete gradient.
+@pytest.mark.parametrize("form", ["owned", "owned_atomic"])
+def test_owned_rows_epoch_matches_the_oracle(hip_device, U, I, D, B, steps, hot, reg, form):
+    """sgd_mode 'owned' (owner pulls: a gradient launch that stores the parts of shared rows plainly + one wave per
+    shared row that sums them; no float atomics) and 'owned_atomic' (one launch per step, shared rows collect
+    device-scope atomic adds): rows updated in place by whoever holds their complete gradient.
     Against oracle/mf_numpy.py step by step (mf.py:92-119 + torch.optim.SGD): per-epoch loss sum, every weight
     within 1e-5 of the update scale, rows the epoch never touched bit-identical, accumulators left clean; and
     the same epoch enqueued in pieces."""
@@ -1010,10 +1013,11 @@ def test_owned_rows_epoch_matches_the_oracle(hip_device, U, I, D, B, steps, hot,
                                     reg_coef=reg or 0.0)
         total += loss
     for pieces in (None, [(0, 1), (1, 2), (2, steps)]):
-        eng = make_engine(U, I, D, "sgd", "bpr", lr, B, reg=reg, sgd_mode="owned")
+        eng = make_engine(U, I, D, "sgd", "bpr", lr, B, reg=reg, sgd_mode=form)
         load_weights(eng, w0)
         prepared = eng.prepare_epoch(hp.DeviceTripleBatcher(*triples, B, shuffle=False))
         assert prepared.own is not None and eng._setup() and eng._owned_sgd
+        assert isinstance(prepared.own, hp.mf.RowContributions) == (form == "owned")
         if pieces is None:
             eng.run_prepared_epoch(prepared, sync=False)
         else:
@@ -1029,7 +1033,8 @@ def test_owned_rows_epoch_matches_the_oracle(hip_device, U, I, D, B, steps, hot,
             untouched = np.ones(w0[k].shape[0], dtype=bool)
             untouched[rows] = False
             assert np.array_equal(got[k][untouched], w0[k][untouched]), f"{k}: untouched rows moved"
-        assert float(eng._owned_bufs["acc"].abs().max()) == 0.0 and int(eng._owned_bufs["arrived"].abs().max()) == 0
+        if form == "owned_atomic":
+            assert float(eng._owned_bufs["acc"].abs().max()) == 0.0 and int(eng._owned_bufs["arrived"].abs().max()) == 0
 
 
 def test_owned_rows_step_at_c4_shard_size(hip_device):
@@ -1044,24 +1049,27 @@ def test_owned_rows_step_at_c4_shard_size(hip_device):
     users, pos, neg = _zipf_triples(rng, steps * B, U, I)
     triples = [torch.from_numpy(a).cuda() for a in (users, pos, neg)]
     out = {}
-    for mode in ("rows", "owned"):
+    for mode in ("rows", "owned", "owned_atomic"):
         torch.manual_seed(5)
         eng = make_engine(U, I, D, "sgd", "bpr", 0.05, B, sgd_mode=mode)
         w0 = eng.model.flat.clone()
         prepared = eng.prepare_epoch(hp.DeviceTripleBatcher(*triples, B, shuffle=False))
-        assert (prepared.own is not None) == (mode == "owned")
+        assert (prepared.own is not None) == (mode != "rows")
         st = eng.run_prepared_epoch(prepared)
         assert st.step == steps and 0.3 < st.loss < 1.4
         out[mode] = (eng.model.flat.clone(), st.loss_sum)
-        if mode == "owned":
+        if mode == "owned_atomic":
             assert float(eng._owned_bufs["acc"].abs().max()) == 0.0
             assert int(eng._owned_bufs["arrived"].abs().max()) == 0
         del eng
-    (wa, la), (wb, lb) = out["rows"], out["owned"]
-    assert_scalar_close(lb, la, 1e-5, "loss sum, owned vs touched-rows path")
+    (wa, la) = out["rows"]
     upd = float((wa - w0).abs().max())
-    assert float((wa - wb).abs().max()) <= 1e-5 * upd + 4 * 1.2e-7 * float(w0.abs().max())
-    moved = (wb != w0)
+    for mode in ("owned", "owned_atomic"):
+        wb, lb = out[mode]
+        assert_scalar_close(lb, la, 1e-5, f"loss sum, {mode} vs touched-rows path")
+        assert float((wa - wb).abs().max()) <= 1e-5 * upd + 4 * 1.2e-7 * float(w0.abs().max()), mode
+    wb = out["owned"][0]
+    moved = (wb != w0) | (out["owned_atomic"][0] != w0)
     touched = torch.zeros_like(moved)
     tu = torch.from_numpy(np.unique(users)).cuda()
     ti = torch.from_numpy(np.unique(np.concatenate([pos, neg]))).cuda()
@@ -1096,6 +1104,66 @@ def test_batch_row_ownership_kernel(hip_device, n, bs, U, I):
     assert torch.equal(total[bid[sh], own[sh].long()], total_t[bid[sh], own_t[sh].long()])
     if n <= 20_000:
         _brute_force_ownership_check(users, pos, neg, bs, U, I, own.cpu().numpy(), total.cpu().numpy())
+
+
+def _check_row_contributions(users, pos, neg, bs, U, I, chunk, cidx, rows, counts, row_cap, long_row=32):
+    """hiprec_batch_row_contrib's contract, batch by batch (numpy)."""
+    n = len(users)
+    for b in range((n + bs - 1) // bs):
+        lo, hi = b * bs, min(n, (b + 1) * bs)
+        u, p, q = users[lo:hi], pos[lo:hi], neg[lo:hi]
+        ok = (u >= 0) & (u < U) & (p >= 0) & (p < I) & (q >= 0) & (q < I)
+        j = np.arange(hi - lo)
+        head = np.ones(hi - lo, dtype=bool)
+        head[1:] = (p[1:] != p[:-1]) | ~ok[:-1]
+        head |= j % chunk == 0
+        c = cidx[:, lo:hi]
+        assert np.all(c[:, ~ok] == -1), "a triple with an out-of-range id contributes nothing"
+        assert np.all(c[1, ok & ~head] == -2), "a positive occurrence inside a run rides with the run's head"
+        keys = np.concatenate([u[ok], U + p[ok & head], U + q[ok]])
+        where = np.concatenate([c[0, ok], c[1, ok & head], c[2, ok]])
+        uniq, inv, cnt = np.unique(keys, return_inverse=True, return_counts=True)
+        shared = cnt[inv] > 1
+        assert np.all(where[~shared] == -1), "a row with one contribution is updated by its contributor"
+        n_short, n_long, n_contrib = (int(x) for x in counts[b, :3])
+        assert n_contrib == int(shared.sum()) and n_short + n_long == int((cnt > 1).sum()) <= row_cap
+        recs = np.concatenate([rows[b, :n_short], rows[b, row_cap - n_long:][::-1]]) if n_short + n_long else np.zeros((0, 4), np.int64)
+        assert np.all(recs[:n_short, 2] <= long_row) and np.all(recs[n_short:, 2] > long_row)
+        order = np.argsort(recs[:, 0])
+        recs = recs[order]
+        assert np.array_equal(recs[:, 0], uniq[cnt > 1]) and np.array_equal(recs[:, 2], cnt[cnt > 1])
+        # the ranges tile [0, n_contrib) and every contribution of a row has a place of its own inside the row's range
+        by_start = recs[np.argsort(recs[:, 1])]
+        assert np.array_equal(by_start[:, 1], np.concatenate([[0], np.cumsum(by_start[:, 2])[:-1]]))
+        assert np.array_equal(np.sort(where[shared]), np.arange(n_contrib))
+        start_of = np.full(len(uniq), -1, dtype=np.int64)
+        start_of[cnt > 1] = recs[:, 1]
+        s0 = start_of[inv[shared]]
+        assert np.all((where[shared] >= s0) & (where[shared] < s0 + cnt[inv[shared]]))
+
+
+@pytest.mark.parametrize("n,bs,U,I,D", [(1000, 128, 50, 30, 64), (3 * 4096 + 77, 4096, 100_000, 2_000, 256),
+                                        (2 * 65536, 65536, 1_250_000, 125_000, 128), (40, 64, 9, 5, 128)])
+def test_batch_row_contrib_kernel(hip_device, n, bs, U, I, D):
+    """hiprec_batch_row_contrib (csrc/ownership.hip): the contribution lists of the owner-pulls step against a numpy
+    statement of the contract -- heads of positive runs per chunk, one record and one contiguous range per row with
+    several contributions, long rows listed from the end, out-of-range triples left out (and they end a run)."""
+    from beta_recsys_amd import _lib
+    from beta_recsys_amd.mf import batch_row_contributions
+
+    rng = np.random.default_rng(n)
+    users, pos, neg = _zipf_triples(rng, n, U, I, hot=0.3 if n > 1000 else None)
+    # every batch sorted by positive item, as the batcher leaves it
+    for k in range(0, n, bs):
+        o = np.argsort(pos[k:k + bs], kind="stable")
+        users[k:k + bs], pos[k:k + bs], neg[k:k + bs] = users[k:k + bs][o], pos[k:k + bs][o], neg[k:k + bs][o]
+    users[3], pos[min(21, n - 1)], neg[min(30, n - 1)] = U, -1, I
+    chunk = _lib.load().hiprec_mf_pull_chunk(D)
+    assert chunk == (8 if D <= 128 else 4)
+    tu, tp, tn = (torch.from_numpy(a).cuda() for a in (users, pos, neg))
+    cidx, rows, counts, row_cap = batch_row_contributions(tu, tp, tn, bs, U, I, D)
+    _check_row_contributions(users, pos, neg, bs, U, I, chunk, cidx.cpu().numpy(), rows.cpu().numpy().astype(np.int64),
+                             counts.cpu().numpy(), row_cap)
 
 
 def test_golden_suite_against_the_ieee_arithmetic_build(hip_device):

@@ -5,10 +5,11 @@ import torch
 import beta_recsys_amd as hp
 
 full = "--full" in sys.argv
+form = next((a.split("=")[1] for a in sys.argv if a.startswith("--form=")), "owned")   # owned (pull) | owned_atomic
 U, I, D, B = (10_000_000, 1_000_000, 128, 65536) if full else (1_250_000, 125_000, 128, 65536)
 dev = torch.device("cuda:0")
 cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer="sgd", lr=0.05, batch_size=B,
-                     loss="bpr", sgd_mode="owned"), "system": {"run_dir": "/tmp/x"}}
+                     loss="bpr", sgd_mode=form), "system": {"run_dir": "/tmp/x"}}
 with contextlib.redirect_stdout(io.StringIO()):
     eng = hp.MFEngine(cfg)
 g = torch.Generator().manual_seed(5)
@@ -23,8 +24,10 @@ prep = eng.prepare_epoch(loader)
 torch.cuda.synchronize(); print("staging ms (20 steps)", (time.perf_counter() - t0) * 1e3)
 own = prep.own[0]
 print("shared fraction user/pos/neg:", [(own[r] >= 0).float().mean().item() for r in range(3)])
+if form == "owned":
+    print("records short / long / contributions per batch:", prep.own[2][:3, :3].tolist())
 for rep in range(2):
     eng.run_prepared_epoch(prep, sync=False)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); eng.run_prepared_epoch(prep, sync=False); e1.record(); torch.cuda.synchronize()
-print("dbg", os.environ.get("HIPREC_OWNED_DBG", "0"), "us/step", e0.elapsed_time(e1) * 1e3 / 20)
+print(form, "full" if full else "shard", "dbg", os.environ.get("HIPREC_OWNED_DBG", "0"), "us/step", e0.elapsed_time(e1) * 1e3 / 20)
