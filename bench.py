@@ -48,7 +48,7 @@ LR = 0.05
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec peak)
 MIN_TIMED_STEPS, MIN_REPEATS = 200, 5
 EPOCH_STEPS = 245  # N = 1 000 000 triples per epoch -> 245 batches of 4096 (1 003 520 triples)
-ROUND = "r04"
+ROUND = "r05"
 
 
 def algorithmic_bytes_per_triple(dim):
@@ -67,7 +67,17 @@ def n_repeats(steps):
     return max(MIN_REPEATS, -(-MIN_TIMED_STEPS // max(steps, 1)))
 
 
-def timed_repeats(run_epoch, steps, device, dist_on=False):
+def _barrier(group, device):
+    """Barrier over the ranks of `group` through the engines' collective seam (torch.distributed, or the loopback
+    world of the tests), bracketed by device synchronisation like the contract asks."""
+    from beta_recsys_amd import _dist
+
+    torch.cuda.synchronize()
+    _dist.all_reduce(torch.zeros(1, dtype=torch.int32, device=device), group=group)
+    torch.cuda.synchronize()
+
+
+def timed_repeats(run_epoch, steps, device, dist_on=False, group=None):
     """Run `run_epoch(r)` (which enqueues exactly `steps` steps incl. their per-epoch staging) R times.
     Returns (per-repeat seconds, wall seconds of the whole region).  See the module docstring."""
     R = n_repeats(steps)
@@ -82,7 +92,7 @@ def timed_repeats(run_epoch, steps, device, dist_on=False):
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         return [evs[r].elapsed_time(evs[r + 1]) * 1e-3 for r in range(R)], wall
-    import torch.distributed as dist
+    from beta_recsys_amd import _dist
 
     # N > 1: the WHOLE region (R x K steps) is bracketed by barrier + synchronize on both sides; inside it every
     # rank delimits its K-step windows with HIP events on the stream the steps run on -- exactly like N = 1 -- and
@@ -90,21 +100,17 @@ def timed_repeats(run_epoch, steps, device, dist_on=False):
     # synchronize + barrier + synchronize measured the brackets: 14.9 us/step at --steps 20 against 12.5 at 2000 for
     # the same world-1 replicated step)  The steps' own collectives keep the ranks in lock step.
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(R + 1)]
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
+    _barrier(group, device)
     t0 = time.perf_counter()
     evs[0].record()
     for r in range(R):
         run_epoch(r)
         evs[r + 1].record()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
+    _barrier(group, device)
     wall = time.perf_counter() - t0
     per = [evs[r].elapsed_time(evs[r + 1]) * 1e-3 for r in range(R)]
     t = torch.tensor(per + [wall], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank defines every repeat
+    _dist.all_reduce(t, op=_dist.ReduceOp.MAX, group=group)  # the slowest rank defines every repeat
     t = t.cpu().tolist()
     return t[:-1], t[-1]
 
@@ -364,7 +370,7 @@ def bench_mf_c4shard(args, device, full=False):
 
     Uc, Ic, Dc, Bc = (10_000_000, 1_000_000, 128, 65536) if full else (1_250_000, 125_000, 128, 65536)
     c4opt = args.c4_optimizer                 # sgd (primary) | adam | rmsprop (dense-Adam secondary)
-    owned = args.sgd_mode == "owned" and c4opt == "sgd"
+    owned = args.sgd_mode in ("owned", "owned_atomic") and c4opt == "sgd"
     cfg = {"model": dict(n_users=Uc, n_items=Ic, emb_dim=Dc, device_str=str(device), optimizer=c4opt,
                          lr=LR, batch_size=Bc, loss="bpr", sgd_mode=args.sgd_mode, dense_opt=args.dense_opt),
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
@@ -414,9 +420,15 @@ def bench_mf_c4shard(args, device, full=False):
     eng.epoch_stats()
     bpt = algorithmic_bytes_per_triple(Dc)
     if owned:
-        kname, k_s = "mf_bpr_owned_kernel<2> (gather + score + BPR grad + in-place SGD rows, 1 launch/step)", alone_s
-        traffic, traffic_src = traffic_from_profiles("hiprec::mf_bpr_owned_kernel<2, false, false>",
-                                                     "mf-c4" if full else "mf-c4shard")
+        # owner pulls (round 5): the gradient launch + the apply launch of a step, timed together -- the bytes of
+        # SURVEY 8d are the step's, so the period they are divided by is the step's two launches
+        kname = ("mf_bpr_owned_kernel<2> (1 launch/step, shared rows through device-scope atomics)"
+                 if args.sgd_mode == "owned_atomic" else
+                 "mf_bpr_owned_kernel<2,false,false,true> (gather + score + BPR grad; rows with one contributor "
+                 "updated in place, the others' parts stored) + pull_apply_vec_kernel<32> (one lane group per shared "
+                 "row sums its parts and stores w - lr g): 2 launches/step, no float atomics")
+        k_s = alone_s
+        traffic, traffic_src = traffic_step_from_profiles("mf-c4" if full else "mf-c4shard", "pull_apply")
     elif getattr(eng, "_lazy", None) is not None:
         kname, k_s, traffic, traffic_src = None, alone_s, None, None   # the lazy step's three launches: named below
     else:
@@ -504,7 +516,7 @@ def bench_mf_c4shard(args, device, full=False):
     return out
 
 
-def bench_mf_c4_sharded(args, device, world, rank):
+def bench_mf_c4_sharded(args, device, world, rank, group=None):
     """BASELINE configs[3] as specified: 10M users x 1M items, dim 128, tables ROW-SHARDED over the ranks
     (owner = row mod N), every rank feeds 65536 triples per step (global batch N x 65536), triples / item rows /
     item-row gradients routed with RCCL all-to-alls, exact SGD on the rows each shard's step touched."""
@@ -517,7 +529,7 @@ def bench_mf_c4_sharded(args, device, world, rank):
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
-        eng = ShardedMFEngine(cfg)
+        eng = ShardedMFEngine(cfg, process_group=group)
     eng._step_comm()   # (collective) the step driver's communicator is created here, not inside a timed window
     if not args.no_plan_prefetch:
         eng.prefetch_setup()   # likewise the side stream / process group of the prefetched plans
@@ -548,8 +560,9 @@ def bench_mf_c4_sharded(args, device, world, rank):
             n -= take
 
     advance(warm)
-    per, wall = timed_repeats(lambda r: advance(steps), steps, device, dist_on=True)
+    per, wall = timed_repeats(lambda r: advance(steps), steps, device, dist_on=True, group=group)
     eng.k.check_status()
+    exchange = plan_exchange_bytes(state["plan"], Dc)
     if rank != 0:
         return None
     bpt = algorithmic_bytes_per_triple(Dc)
@@ -579,7 +592,10 @@ def bench_mf_c4_sharded(args, device, world, rank):
                                           ("enqueued from C with grouped ncclSend/ncclRecv" if eng._step_mode == "c"
                                            else "through torch.distributed.all_to_all_single"),
                            "step_driver": eng._step_mode, "optimizer": args.c4_optimizer,
-                           "global_batch": world * Bc, "rccl_world_size": world},
+                           "global_batch": world * Bc, "rccl_world_size": world,
+                           "exchange_bytes_per_step": round(exchange["exchange_bytes_per_step"]),
+                           "exchange_bytes_per_step_off_gpu": round(exchange["exchange_bytes_per_step_off_gpu"]),
+                           "a2a_GBps_per_gpu": exchange["exchange_bytes_per_step_off_gpu"] / (out["ms_per_step"] * 1e-3) / 1e9},
                 "roofline": {"bound": "hbm", "kernel": "whole sharded step (per GPU)",
                              "achieved": out["value"] / world * moved_bpt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": out["value"] / world * moved_bpt / (HBM_PEAK_GBS * 1e9),
@@ -865,11 +881,50 @@ def bench_ngcf(args, device):
     return out
 
 
+_EVIDENCE = {}
+
+
+def evidence_stamp():
+    """{"commit", "source_hash", "stale"}: the stamp tools/collect_profiles.py left next to this round's committed
+    profiles (profiles/rNN_stamp.json: the commit they were collected at and the source hash of the library they were
+    measured with) against `hiprec_source_hash()` of the library THIS run loaded.  Counters and kernel durations read
+    from profiles/ are attached to a bench line only when the two hashes agree; otherwise the line says `stale` and
+    carries no profile-sourced number (a kernel changed after the last refresh used to ride along silently
+    with last round's counters)."""
+    if not _EVIDENCE:
+        st = {"commit": None, "source_hash": None, "stale": True}
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{ROUND}_stamp.json")) as f:
+                rec = json.load(f)
+            st["commit"], st["source_hash"] = rec.get("commit"), rec.get("source_hash")
+            from beta_recsys_amd import _lib
+
+            st["stale"] = _lib.load().hiprec_source_hash().decode() != rec.get("source_hash")
+        except Exception:
+            pass
+        _EVIDENCE.update(st)
+    return _EVIDENCE
+
+
+def stamp_roofline(out):
+    """Name, in the line itself, which build the profile-sourced fields of `roofline` belong to."""
+    roof = out.get("roofline") if out else None
+    if roof is None:
+        return out
+    st = evidence_stamp()
+    from_profiles = any(str(roof.get(k) or "").startswith("profiles/") for k in ("traffic_source", "kernel_us_source"))
+    roof["traffic_commit"] = st["commit"] if from_profiles else None
+    roof["stale"] = bool(st["stale"])
+    return out
+
+
 def traffic_from_profiles(kernel, workload=None):
     """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) of a kernel from the COMMITTED rocprofv3 PMC passes
-    -- this round's summary if it exists, else round 1's -- as (bytes | None, source file | None).  It is
-    not measured in this run: counters need their own rocprofv3 passes (tools/pmc_workload.sh)."""
-    for rnd in (ROUND, "r02", "r01"):
+    of THIS round (none when they were taken with another build of the sources: evidence_stamp) as (bytes | None,
+    source file | None).  It is not measured in this run: counters need their own rocprofv3 passes (tools/pmc_workload.sh)."""
+    if evidence_stamp()["stale"]:
+        return None, None
+    for rnd in (ROUND,):
         try:
             if workload is None:
                 name = f"{rnd}_pmc_summary.json"
@@ -892,7 +947,9 @@ def dominant_kernel_from_profiles(workload):
     summary is there yet).  Not measured in this run -- the step is timed live, its kernels by the profiler."""
     import csv
 
-    for rnd in (ROUND, "r03"):
+    if evidence_stamp()["stale"]:
+        return {}
+    for rnd in (ROUND,):
         name = f"{rnd}_kernel_stats_{workload}.csv"
         try:
             with open(os.path.join(ROOT, "profiles", name), newline="") as f:
@@ -911,7 +968,9 @@ def traffic_step_from_profiles(workload, step_kernel="opt_dense_kernel"):
     the committed per-workload PMC passes (profiles/rNN_pmc_other_workloads.json: KB per dispatch and the number
     of dispatches of every kernel).  (bytes | None, source | None).  step_kernel: a kernel that runs exactly once per
     step (its dispatch count is the number of steps)."""
-    for rnd in (ROUND, "r02"):
+    if evidence_stamp()["stale"]:
+        return None, None
+    for rnd in (ROUND,):
         try:
             name = f"{rnd}_pmc_other_workloads.json"
             with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -926,14 +985,28 @@ def traffic_step_from_profiles(workload, step_kernel="opt_dense_kernel"):
     return None, None
 
 
-def bench_mf(args, device, world, rank, dist_on):
+def plan_exchange_bytes(plan, dim):
+    """Per-step exchange volume of a planned row-sharded epoch on THIS rank (bytes, mean over the epoch's steps):
+    item rows out + gradients back, all of it and the part that leaves the GPU (the rank's own share of an exchange is
+    a device-to-device copy).  From the plan's host-side counts: in_cnt_h[s][q] rows go to peer q, req_cnt_h[s][q]
+    rows come from owner q; every (step, peer) pair carries one extra row (the loss partials)."""
+    ld, S, me = 4 * (dim + 1), plan["S"], plan["rank"]
+    out_rows = sum(sum(c) + len(c) for c in plan["in_cnt_h"])
+    back_rows = sum(sum(c) + len(c) for c in plan["req_cnt_h"])
+    own = sum(c[me] + 1 for c in plan["in_cnt_h"]) + sum(c[me] + 1 for c in plan["req_cnt_h"])
+    total = (out_rows + back_rows) * ld / S
+    return {"exchange_bytes_per_step": total, "exchange_bytes_per_step_off_gpu": total - own * ld / S}
+
+
+def bench_mf(args, device, world, rank, dist_on, force_mode=None, force_scaling=None, group=None):
     """BASELINE configs[1] (the headline).  N = 1: MFEngine's resident epoch (one fused launch per step).
-    N > 1: replicated tables + one all-reduce per step (auto below 64 MB of parameters) or row-sharded
-    tables with all-to-all routing (`--multi-gpu sharded`)."""
+    N > 1: row-sharded tables with planned all-to-all routing (north_star's split; `--multi-gpu sharded`, and what
+    `--multi-gpu auto` reports as the headline) or replicated tables + one all-reduce per step (`replicated`)."""
     import beta_recsys_amd as hp
 
     K, W = args.steps, args.warmup
-    strong = args.scaling == "strong" and world > 1
+    scaling = force_scaling or args.scaling
+    strong = scaling == "strong" and dist_on
     if strong and B % world:
         raise SystemExit(f"--scaling strong splits the batch of {B} over the ranks: {world} does not divide it")
     b_local = B // world if strong else B
@@ -945,17 +1018,21 @@ def bench_mf(args, device, world, rank, dist_on):
         from beta_recsys_amd.replicated import ReplicatedMFEngine
         from beta_recsys_amd.sharded import ShardedMFEngine
 
-        mode = args.multi_gpu
+        mode = force_mode or args.multi_gpu
         if mode == "auto":
-            mode = "replicated" if 4 * ((U + I) * (D + 1) + 1) < (64 << 20) else "sharded"
+            mode = "sharded"
         cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str=str(device), optimizer=args.optimizer,
                              lr=LR, batch_size=b_local, loss="bpr", dp_collective=args.dp_collective),
                "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
         torch.manual_seed(2020)
         with contextlib.redirect_stdout(io.StringIO()):
-            eng = ShardedMFEngine(cfg) if mode == "sharded" else ReplicatedMFEngine(cfg)
+            eng = (ShardedMFEngine(cfg, process_group=group) if mode == "sharded"
+                   else ReplicatedMFEngine(cfg, process_group=group))
         if mode != "sharded":
             eng._direct_communicator()   # (collective) created here, not inside a timed window when --warmup is 0
+        else:
+            eng._step_comm()             # likewise the step driver's communicator ...
+            eng.prefetch_setup()         # ... and the side stream / process group of the prefetched plans
     else:
         eng = make_engine(device, args.optimizer)
         eng.fused_step = not args.two_kernel
@@ -980,14 +1057,16 @@ def bench_mf(args, device, world, rank, dist_on):
                 assert eng.run_resident_epoch(loader, steps=piece)
             else:   # row-sharded: route the whole epoch once (ids only), then exact-size exchanges per step
                 if piece[0] == 0:
-                    state["prepared"] = eng.plan_epoch(loader)
+                    state["prepared"] = eng.take_plan(loader)   # prefetched during the previous epoch, if there was one
                 eng.run_planned_epoch(state["prepared"], steps=piece, sync=False)
+                if piece[1] == EPOCH_STEPS:
+                    eng.prefetch_plan(loader)   # the whole epoch is enqueued: route the next one on the side stream
             state["pos"] = piece[1] % EPOCH_STEPS
             n -= take
 
     advance(W)
     torch.cuda.synchronize()
-    per, wall = timed_repeats(lambda r: advance(K), K, device, dist_on)
+    per, wall = timed_repeats(lambda r: advance(K), K, device, dist_on, group)
     R = len(per)
     advance((EPOCH_STEPS - state["pos"]) % EPOCH_STEPS)   # finish the epoch in flight (flush) before reading back
     if mode == "sharded":
@@ -1025,6 +1104,9 @@ def bench_mf(args, device, world, rank, dist_on):
                        f"gradient per step, global batch = {world} x {b_local}; collective enqueued by "
                        + ("the C epoch driver (ncclAllReduce on the engine's own communicator)"
                           if getattr(eng, "_direct_comm", None) is not None else "torch.distributed"))
+    exchange = None
+    if mode == "sharded":
+        exchange = plan_exchange_bytes(state["prepared"], D)
     if rank != 0:
         return None
     n_params = (U + I) * (D + 1) + 1
@@ -1075,12 +1157,64 @@ def bench_mf(args, device, world, rank, dist_on):
                          / (HBM_PEAK_GBS * 1e9),
         },
     })
+    if exchange is not None:
+        step_s = out["ms_per_step"] * 1e-3
+        out["config"].update({k: round(v) for k, v in exchange.items()})
+        # bytes this rank sends + receives over xGMI per step / the step time: a LOWER bound of the link rate (the
+        # exchanges are two of the step's six stages)
+        out["config"]["a2a_GBps_per_gpu"] = exchange["exchange_bytes_per_step_off_gpu"] / step_s / 1e9
+        out["config"]["step_driver"] = eng._step_mode
+        # the sharded step has no single dominant launch: the roofline is the whole step per GPU on SURVEY 8d's bytes
+        per_gpu = out["value"] / world
+        moved = algorithmic_bytes_per_triple(D) + optimizer_sweep_bytes(args.optimizer, n_params // world) / b_local
+        out["roofline"] = {"bound": "hbm", "kernel": "whole row-sharded step (per GPU): payload, owned-rows kernel on "
+                                                      "(local users, fetched item slots), apply, optimizer",
+                           "achieved": per_gpu * moved / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": per_gpu * moved / (HBM_PEAK_GBS * 1e9),
+                           "algorithmic_bytes_per_launch": moved * b_local,
+                           "algorithmic_bytes_note": f"SURVEY 8(d): {algorithmic_bytes_per_triple(D)} B/triple x {b_local} "
+                                                     f"triples/GPU + this shard's dense {args.optimizer} sweep",
+                           "kernel_us": step_s * 1e6, "kernel_us_source": "the timed step itself (HIP events)",
+                           "traffic": None, "traffic_source": None}
     if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(args.optimizer)
     return out
 
 
-def main():
+def compact_line(out, keep=("value", "unit", "ms_per_step", "scaling", "n_gpus", "steps", "repeats")):
+    """A named sub-record of the one JSON line: the headline fields of another measurement of the same run."""
+    if out is None:
+        return None
+    rec = {k: out[k] for k in keep if k in out}
+    cfg = out.get("config", {})
+    rec.update({k: cfg[k] for k in ("workload", "parallelism", "global_batch", "rccl_world_size", "optimizer",
+                                    "exchange_bytes_per_step", "exchange_bytes_per_step_off_gpu", "a2a_GBps_per_gpu",
+                                    "step_driver") if k in cfg})
+    rec["roofline_frac"] = out.get("roofline", {}).get("frac")
+    return rec
+
+
+def bench_mf_multi_gpu(args, device, world, rank, group=None):
+    """`bench.py --gpus N` with no other flag: BASELINE.json's split is the headline -- tables ROW-SHARDED over the N
+    ranks (owner = row mod N), index minibatches routed to the owning rank by planned all-to-alls, at the reference's
+    own batch (global batch 4096 split over the ranks: `scaling: strong`, the single-GPU step's semantics) -- and the
+    two other N-GPU forms this repo has ride along as named sub-records: `alt.replicated` (data-parallel replicas of
+    the 2.5 MB tables, one all-reduce per step, weak scaling) and `alt.c4_sharded` (BASELINE configs[3], 10 M x 1 M x
+    128 row-sharded, 65 536 triples per GPU and step).  One JSON line."""
+    import copy
+
+    out = bench_mf(args, device, world, rank, True, force_mode="sharded", force_scaling="strong", group=group)
+    rep = bench_mf(args, device, world, rank, True, force_mode="replicated", force_scaling="weak", group=group)
+    c4args = copy.copy(args)
+    c4args.steps, c4args.warmup = min(args.steps, 50), min(args.warmup, 5)
+    c4 = bench_mf_c4_sharded(c4args, device, world, rank, group=group)
+    if rank != 0:
+        return None
+    out["alt"] = {"replicated": compact_line(rep), "c4_sharded": compact_line(c4)}
+    return out
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -1093,13 +1227,17 @@ def main():
     ap.add_argument("--workload", default="mf", choices=["mf", "ncf", "lightgcn", "mf-c4shard", "mf-c4", "pgmf", "t2v", "ngcf"],
                     help="mf = BASELINE configs[1] (the headline); ncf = configs[2]; mf-c4 = configs[3] "
                          "(whole on one GPU at --gpus 1, row-sharded over the ranks at --gpus N); lightgcn = configs[4]")
-    ap.add_argument("--sgd-mode", default="owned", choices=["owned", "rows", "dense"],
-                    help="mf-c4 / mf-c4shard: owned = one launch per step, rows updated in place (csrc/mf_owned.hip); "
+    ap.add_argument("--sgd-mode", default="owned", choices=["owned", "owned_atomic", "rows", "dense"],
+                    help="mf-c4 / mf-c4shard: owned = rows updated in place by their owner, shared rows pulled from a "
+                         "contribution buffer (2 launches, no float atomics); owned_atomic = rounds 2-4: one launch, "
+                         "shared rows collect device-scope atomics (csrc/mf_owned.hip); "
                          "rows = gradient kernel into a dense buffer + touched-rows pass (round 1)")
     ap.add_argument("--emb-dim", type=int, default=32, help="ncf: 32 (tower 256-128-64-32, primary) or 64")
     ap.add_argument("--multi-gpu", default="auto", choices=["auto", "replicated", "sharded"],
-                    help="mf, N>1: replicate small tables (gradient all-reduce) or row-shard them "
-                         "(all-to-all routing); auto = replicated below 64 MB of parameters")
+                    help="mf, N>1: auto = the row-sharded step (BASELINE.json's split: owner = row mod N, planned "
+                         "all-to-alls, the reference's batch split over the ranks) as the headline with the replicated "
+                         "and the configs[3] forms as `alt` sub-records; replicated / sharded = that form alone, "
+                         "under --scaling")
     ap.add_argument("--c4-optimizer", default="sgd", choices=["sgd", "adam", "rmsprop"],
                     help="mf-c4 row-sharded: sgd (SURVEY 8d primary: exact scatter) or the dense optimizers (secondary)")
     ap.add_argument("--dense-opt", default="auto", choices=["auto", "lazy", "sweep"],
@@ -1117,8 +1255,11 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = every rank feeds a full batch (global batch N x B); strong = the reference's "
                          "batch split over the ranks (global batch = B, identical semantics to one GPU)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1163,6 +1304,8 @@ def main():
     elif args.workload in ("mf-c4shard", "mf-c4"):
         out = (bench_mf_c4_sharded(args, device, world, rank) if dist_on and args.workload == "mf-c4"
                else bench_mf_c4shard(args, device, full=args.workload == "mf-c4"))
+    elif dist_on and args.multi_gpu == "auto":
+        out = bench_mf_multi_gpu(args, device, world, rank)
     else:
         out = bench_mf(args, device, world, rank, dist_on)
     if dist_on and args.workload in ("pgmf", "t2v", "ngcf"):
@@ -1171,6 +1314,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and out is not None:
+        stamp_roofline(out)
         if json_fd is not None:
             sys.stdout.flush()
             os.write(json_fd, (json.dumps(out) + "\n").encode())

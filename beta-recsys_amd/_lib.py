@@ -208,6 +208,7 @@ _P = c_void_p
 _T = POINTER(MfTables)
 SIGNATURES = {
     "hiprec_version": (c_int, []),
+    "hiprec_source_hash": (ctypes.c_char_p, []),
     "hiprec_last_error": (c_char_p, []),
     "hiprec_stats_bytes": (c_size_t, []),
     "hiprec_scratch_bytes": (c_size_t, [c_int64]),

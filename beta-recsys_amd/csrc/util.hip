@@ -408,6 +408,14 @@ extern "C" int hiprec_scatter_add_rows(float* table, int64_t n_rows, int32_t dim
 }
 
 extern "C" int hiprec_version(void) { return HIPREC_VERSION; }
+
+// sha256 over the sources this library was built from (csrc/*.hip, csrc/*.hpp, include/hiprec.h, in sorted order;
+// __graft_entry__.build() passes it).  bench.py compares it with the stamp of the committed profiles: counters taken
+// with another build of the kernels are reported as stale instead of being attached to this build's timings.
+#ifndef HIPREC_SOURCE_HASH
+#define HIPREC_SOURCE_HASH "unknown"
+#endif
+extern "C" const char* hiprec_source_hash(void) { return HIPREC_SOURCE_HASH; }
 extern "C" const char* hiprec_last_error(void) { return g_err; }
 extern "C" size_t hiprec_stats_bytes(void) { return sizeof(hiprec_stats); }
 extern "C" size_t hiprec_scratch_bytes(int64_t) { return kScratchBytes; }

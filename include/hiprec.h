@@ -83,6 +83,9 @@ typedef struct hiprec_stats {
 } hiprec_stats;
 
 int hiprec_version(void);
+/* sha256 (hex) over the sources the library was built from, "unknown" for a build that was not told (csrc/util.hip);
+ * the measurement evidence under profiles/ carries the hash of the build it was taken with. */
+const char* hiprec_source_hash(void);
 const char* hiprec_last_error(void);
 size_t hiprec_stats_bytes(void);            /* sizeof(hiprec_stats) for the host layer */
 /* bytes of scratch needed by any *_grad / *_step call on a batch of `batch` units */

@@ -43,3 +43,48 @@ def test_repeat_and_byte_accounting():
     assert bench.optimizer_sweep_bytes("adam", P) == 28 * 633491 and bench.optimizer_sweep_bytes("sgd", P) == 0
     assert 4096 * 1584 + bench.optimizer_sweep_bytes("adam", P) == 24225812      # the 24.23 MB of VERDICT r1
     assert json.dumps(f)   # every field is JSON-serialisable
+
+
+@pytest.mark.gpu
+def test_gpus_n_line_is_the_row_sharded_split_with_the_other_forms_as_sub_records():
+    """What `python bench.py --gpus 2` (no other flag) does on its ranks, run here on TWO virtual ranks of one GPU
+    (tests/loopback.py: the C step drivers post their exchanges through the loopback RCCL stand-in): the one JSON
+    line's headline is BASELINE.json's split -- tables row-sharded, owner = row mod N, planned all-to-alls, the
+    reference's batch of 4096 split over the ranks (`scaling: strong`) -- and the replicated and configs[3] forms are
+    named sub-records, each with its world size and exchange volume."""
+    import torch
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench
+    from loopback import VirtualWorld
+
+    args = bench.parse_args(["--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"])
+    device = torch.device("cuda:0")
+    world = VirtualWorld(2, timeout=120.0)
+    try:
+        outs = world.run(lambda group: bench.bench_mf_multi_gpu(args, device, 2, group.rank(), group))
+        counters = world.counters()
+    finally:
+        world.close()
+    line, other = outs
+    assert other is None and json.loads(json.dumps(line)) == line
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert line["metric"].startswith("training interactions/sec") and line["unit"] == "triples/s"
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 2 and line["higher_is_better"] is True
+    assert line["scaling"] == "strong" and line["dtype"] == "f32" and line["vs_baseline"] is None
+    cfg = line["config"]
+    assert cfg["global_batch"] == 4096 and cfg["batch_per_gpu"] == 2048 and cfg["rccl_world_size"] == 2
+    assert "row-sharded" in cfg["parallelism"] and "owner = row mod 2" in cfg["parallelism"]
+    assert cfg["exchange_bytes_per_step"] > cfg["exchange_bytes_per_step_off_gpu"] > 0 and cfg["a2a_GBps_per_gpu"] > 0
+    assert line["value"] == pytest.approx(4096 / (line["ms_per_step"] * 1e-3), rel=1e-6)
+    assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["bound"] == "hbm"
+    rep, c4 = line["alt"]["replicated"], line["alt"]["c4_sharded"]
+    assert rep["scaling"] == "weak" and rep["global_batch"] == 2 * 4096 and rep["rccl_world_size"] == 2 and rep["value"] > 0
+    assert rep["value"] == pytest.approx(2 * 4096 / (rep["ms_per_step"] * 1e-3), rel=1e-6)
+    assert c4["global_batch"] == 2 * 65536 and c4["rccl_world_size"] == 2 and c4["value"] > 0
+    assert c4["exchange_bytes_per_step_off_gpu"] > 0 and "10M x 1M" in c4["workload"]
+    # the C drivers really posted exchanges and all-reduces through the injected entry points
+    assert counters["sends"] > 0 and counters["recvs"] == counters["sends"] and counters["all_reduces"] > 0

@@ -53,6 +53,34 @@ if summary:
 if others:
     others["_note"] = note
     json.dump(others, open(os.path.join(dst, f"{tag}_pmc_other_workloads.json"), "w"), indent=1)
+# the stamp: which sources the measured library was built from (written on the GPU box by refresh_profiles.sh) and
+# the commit this collection is made at -- bench.py attaches profile-sourced numbers to a line only when the library
+# it loaded has the same source hash (evidence_stamp)
+import subprocess
+
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry
+
+stamp = {"source_hash": None, "round": tag}
+try:
+    stamp.update(json.load(open(os.path.join(src, "stamp.json"))))
+except Exception:
+    pass
+stamp["source_hash_of_this_tree"] = entry.source_hash()
+head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "beta-recsys_amd/csrc", "include"],
+                       capture_output=True, text=True).stdout.strip()
+stamp["commit"] = head + ("+uncommitted-kernel-sources" if dirty else "")
+if stamp["source_hash"] != stamp["source_hash_of_this_tree"]:
+    print(f"WARNING: the profiles under gpurun_out/{tag} were measured with sources {stamp['source_hash']}, "
+          f"this tree is {stamp['source_hash_of_this_tree']}: bench.py will report them as stale", file=sys.stderr)
+json.dump(stamp, open(os.path.join(dst, f"{tag}_stamp.json"), "w"), indent=1)
+for name in (f"{tag}_pmc_summary.json", f"{tag}_pmc_other_workloads.json"):
+    path = os.path.join(dst, name)
+    if os.path.exists(path):
+        rec = json.load(open(path))
+        rec["_stamp"] = {k: stamp[k] for k in ("commit", "source_hash")}
+        json.dump(rec, open(path, "w"), indent=1)
 for f in glob.glob(os.path.join(src, "exp_*.txt")):
     shutil.copy(f, os.path.join(dst, f"{tag}_{os.path.basename(f)}"))
 print(sorted(os.path.basename(p) for p in glob.glob(os.path.join(dst, f"{tag}_*"))))

@@ -1,10 +1,16 @@
-# Refresh the judged evidence on a GPU box: bash tools/refresh_profiles.sh [round tag, default r04]
+# Refresh the judged evidence on a GPU box: bash tools/refresh_profiles.sh [round tag, default r05]
 # bench JSON lines, rocprofv3 kernel-trace stats and FETCH_SIZE / WRITE_SIZE passes, all under gpurun_out/<tag>/;
 # tools/collect_profiles.py copies the summaries into profiles/.
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
+# which build of the kernels everything below is measured with (tools/collect_profiles.py -> profiles/<tag>_stamp.json)
+python -c "
+import json, sys
+sys.path.insert(0, '.')
+import beta_recsys_amd as hp
+print(json.dumps({'source_hash': hp._lib.load().hiprec_source_hash().decode()}))" > $OUT/stamp.json
 # counters and kernel statistics FIRST: the bench lines below read roofline.traffic from profiles/<tag>_pmc_*.json,
 # which tools/collect_profiles.py makes from these passes (run here on the box, and again at home)
 cd /tmp && export TMPDIR=/tmp
