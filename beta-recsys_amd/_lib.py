@@ -544,3 +544,34 @@ def stream_ptr(device):
     st = _Stream(torch.cuda.current_stream(device).cuda_stream)
     st.device_index = device.index if device.index is not None else torch.cuda.current_device()
     return st
+
+
+LAZY_SCALARS_CAP = 1 << 16     # steps whose Adam bias corrections are tabulated for the lazy replays (csrc/lazy_opt.hip)
+
+
+def lazy_betas_converge(opt, cap=LAZY_SCALARS_CAP):
+    """Beyond the scalars table a lazy replay reads its LAST entry: that is only right once the bias corrections no
+    longer move -- 1 - beta^t == 1.0 in double from t = cap - 1 on (default betas: t ~ 36 800).  RMSprop has no
+    bias correction.  Checked when the state is set up, not after 65 536 steps of training."""
+    if opt.name != "adam":
+        return True
+    return all(1.0 - float(b) ** (cap - 1) == 1.0 for b in (opt.beta1, opt.beta2))
+
+
+def lazy_scalars_table(opt, device, cap=LAZY_SCALARS_CAP):
+    """Adam's per-step scalars table [cap, 2], zero except for the last entry, which holds the CONVERGED pair
+    (lr, 1): steps at or beyond the table are checked against it and replays of such steps read it -- whether or not
+    step cap - 1 itself was ever taken by a lazy update (a restored clock beyond the table, or a dense sweep at that
+    step, used to leave it zero: a spurious HIPREC_STATUS_LAZY_TABLE)."""
+    import torch
+
+    if not lazy_betas_converge(opt, cap):
+        raise ValueError(
+            f"lazy Adam tabulates the bias corrections of {cap} steps and needs them converged by then "
+            f"(1 - beta^{cap - 1} == 1 in double); betas ({opt.beta1}, {opt.beta2}) do not: use dense_opt='sweep'")
+    table = torch.zeros((cap, 2), dtype=torch.float32, device=device)
+    if opt.name == "adam":
+        # (float)(lr / (1 - 0)) and the rcp of (float)sqrt(1 - 0): exactly what a step beyond convergence derives
+        table[cap - 1, 0] = float(opt.lr)
+        table[cap - 1, 1] = 1.0
+    return table

@@ -183,7 +183,10 @@ __device__ __forceinline__ void lazy_rows_vec_body(const LazyCtx& c, const hipre
         sc.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), k));
       }
       if (!(on && tb + k > base)) continue;
-      if (MODE == 1 && w_ahead) {   // w is current already: only the moments (one fma and one multiply per step)
+      // w is current already: only the moments (one fma and one multiply per step).  A flush meets the flag only when
+      // a step was abandoned between its catch-up and its update (an error return in between): w must not take the
+      // zero-gradient steps a second time
+      if (MODE != 0 && w_ahead) {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
           float zero = 0.f, w_unused = 0.f;
@@ -458,8 +461,9 @@ __global__ __launch_bounds__(kBlock) void lazy_rows_kernel(LazyCtx c, hiprec_laz
 #pragma unroll
     for (int j = 0; j <= kLazyMaxNpl; ++j) moving |= on[j] && (m[j] != 0.f || v[j] != 0.f);
     const bool replay = base >= 0 && __ballot(moving) != 0ull;
-    if (MODE == 1 && w_ahead) {
-      // w is current already: only the moments are replayed (one fma and one multiply per step, no sqrt / rcp)
+    if (MODE != 0 && w_ahead) {
+      // w is current already: only the moments are replayed (one fma and one multiply per step, no sqrt / rcp); a
+      // flush meets the flag only after an abandoned step (see lazy_rows_vec_body)
       for (long long t = base + 1LL; replay && t <= last; ++t) {
 #pragma unroll
         for (int j = 0; j <= kLazyMaxNpl; ++j) {

@@ -424,7 +424,7 @@ class LightGCN(_FlatModel):
             raise ValueError(f"unknown dropout_rng {self.dropout_rng!r}: 'torch_cpu' or 'device'")
         if sliced:
             device_draw = self.dropout_rng == "device"  # the draw is folded into the launch; no keep bytes written
-            if device_draw and getattr(self, "_staged_for", None) == (self._step,) + self._weights_version():
+            if device_draw and getattr(self, "_staged_for", None) == self._stage_key(self._step):
                 # the previous step's optimizer launch drew this step's edge streams and laid the fresh E0 out
                 # (hiprec_lightgcn_opt_stage), and nothing has written the weights since (torch counts in-place writes)
                 self._staged_for = None      # (consumed: the passes overwrite the staged buffers)
@@ -437,6 +437,13 @@ class LightGCN(_FlatModel):
                                                        self._step, st))
             self._dropped_ready = True
         return ws["keep"]
+
+    def _stage_key(self, step):
+        """What a staged next step was prepared FOR: the step number, the dropout draw's seed and keep probability, the
+        graph (its sliced layout), and the state of the weights (:meth:`_weights_version`).  Anything else the caller
+        changes between two steps makes the step prepare itself (seed / keep_pro used to be left out).
+        Library calls that write the weights through raw pointers invalidate explicitly (``_staged_for = None``)."""
+        return (step, int(self.dropout_seed), float(self.config["keep_pro"]), id(self.graph())) + self._weights_version()
 
     def _weights_version(self):
         """Changes whenever torch writes the weights in place -- through the flat buffer or through a parameter (they
@@ -545,7 +552,7 @@ class LightGCNEngine(FlatModelEngine):
             ctypes.byref(plan), opt.kind, _lib.ptr(self._g_flat), _lib.ptr(opt.exp_avg), _lib.ptr(opt.exp_avg_sq), opt.lr,
             opt.beta1, opt.beta2, opt.eps, _lib.ptr(self._stats), _lib.ptr(self._scratch) if fold_partials else None,
             float(m.config["keep_pro"]), m.dropout_seed, m._step + 1, _lib.stream_ptr(m.flat.device)))
-        m._staged_for = (m._step + 1,) + m._weights_version()
+        m._staged_for = m._stage_key(m._step + 1)
 
     def train_single_batch(self, batch_data):
         """lightgcn.py:119-152: one step, returns ``batch_mf_loss + batch_reg_loss`` as a float."""

@@ -559,15 +559,17 @@ class MFEngine(ModelEngine):
             raise ValueError(f"dense_opt must be 'sweep', 'lazy' or 'auto', not {mode!r}")
         self._lazy = None
         if (self.optimizer.name != "sgd" and self.model.emb_dim <= 256 and self._lazy_capable
-                and (mode == "lazy" or (mode == "auto" and flat.numel() * 4 >= self.ROWS_SGD_MIN_BYTES))):
+                and (mode == "lazy" or (mode == "auto" and flat.numel() * 4 >= self.ROWS_SGD_MIN_BYTES
+                                        and _lib.lazy_betas_converge(self.optimizer)))):   # auto: else the sweep
             opt, m = self.optimizer, self.model
             lz = {"stamp_u": torch.full((m.n_users,), -1, dtype=torch.int32, device=dev),
                   "stamp_i": torch.full((m.n_items,), -1, dtype=torch.int32, device=dev),
-                  "scalars": torch.zeros((1 << 16, 2), dtype=torch.float32, device=dev), "dirty": False}
+                  "scalars": _lib.lazy_scalars_table(opt, dev), "dirty": False}   # raises for betas it cannot tabulate
             lz["c"] = _lib.LazyState(
                 flat.data_ptr(), self._g_flat.data_ptr(), opt.exp_avg.data_ptr() if opt.exp_avg is not None else None,
                 opt.exp_avg_sq.data_ptr(), m.n_users, m.n_items, m.emb_dim, opt.kind, lz["stamp_u"].data_ptr(),
-                lz["stamp_i"].data_ptr(), lz["scalars"].data_ptr(), 1 << 16, 0, opt.lr, opt.beta1, opt.beta2, opt.eps)
+                lz["stamp_i"].data_ptr(), lz["scalars"].data_ptr(), _lib.LAZY_SCALARS_CAP, 0, opt.lr, opt.beta1,
+                opt.beta2, opt.eps)
             self._lazy = lz
         self._buffers_ready = True
         return lib

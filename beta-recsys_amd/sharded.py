@@ -305,7 +305,7 @@ class HipKernels:
             self._st()))
 
     # ---- exact lazy Adam / RMSprop (csrc/lazy_opt.hip) -------------------------------------------------------------
-    LAZY_SCALARS = 1 << 16     # steps whose bias corrections are tabulated (default betas converge by t ~ 36 800)
+    LAZY_SCALARS = _lib.LAZY_SCALARS_CAP     # steps whose bias corrections are tabulated (default betas converge by t ~ 36 800)
 
     def lazy_state(self, model, g_flat, opt):
         """The per-row stamps (-1 = never touched) and Adam's per-step scalars table of a shard, with the C struct
@@ -313,7 +313,7 @@ class HipKernels:
         dev = self.device
         lz = {"stamp_u": torch.full((max(model.n_users, 1),), -1, dtype=torch.int32, device=dev),
               "stamp_i": torch.full((max(model.n_items, 1),), -1, dtype=torch.int32, device=dev),
-              "scalars": torch.zeros((self.LAZY_SCALARS, 2), dtype=torch.float32, device=dev), "dirty": False}
+              "scalars": _lib.lazy_scalars_table(opt, dev, self.LAZY_SCALARS), "dirty": False}
         lz["c"] = _lib.LazyState(
             model.flat.data_ptr(), g_flat.data_ptr(), opt.exp_avg.data_ptr() if opt.exp_avg is not None else None,
             opt.exp_avg_sq.data_ptr(), model.n_users, model.n_items, model.emb_dim, opt.kind, lz["stamp_u"].data_ptr(),
@@ -418,7 +418,8 @@ class ShardedMFEngine:
             raise ValueError(f"dense_opt must be 'sweep', 'lazy' or 'auto', not {mode!r}")
         self._lazy = None
         if (self.optimizer.name != "sgd" and isinstance(self.k, HipKernels) and self.emb_dim <= 256
-                and (mode == "lazy" or (mode == "auto" and self.model.flat.numel() * 4 >= (64 << 20)))):
+                and (mode == "lazy" or (mode == "auto" and self.model.flat.numel() * 4 >= (64 << 20)
+                                        and _lib.lazy_betas_converge(self.optimizer)))):
             self._lazy = self.k.lazy_state(self.model, self._g_flat, self.optimizer)
         # "padded": fixed-capacity all-to-alls, bucketing on the device, no host sync per step (all
         # ranks must feed the same local batch size); "variable": exact-size all-to-alls with
@@ -446,6 +447,12 @@ class ShardedMFEngine:
             v = torch.as_tensor(full_state[k], dtype=torch.float32)
             local[k] = v if k == "global_bias" else v[r::R]
         self.model.load_state_dict(local)
+
+    # Lazy Adam / RMSprop: the piece that ends a planned epoch flushes, so whoever reads the shard afterwards
+    # (state_dict, predict, the moments) sees what the dense steps would have left.  Not a config key: a run that leaves
+    # rows lagging between epochs (tools/exp_planned.py, LAZY_FLUSH=demand) flips this attribute and flushes by hand
+    # before it reads anything (the config key made stale shards reachable from product configs).
+    flush_lazy_every_epoch = True
 
     def flush_lazy(self):
         """Lazy Adam / RMSprop: replay every lagging row up to the optimizer clock, so that the tables (and the
@@ -483,6 +490,54 @@ class ShardedMFEngine:
                 out[q::R] = parts[q][: shard_rows(n_total, q, R)]
             full[k] = out
         return full
+
+    # ---- checkpoints ------------------------------------------------------------------------
+    OPT_STATE_FORMAT = "hiprec-sharded-optimizer-state-1"
+
+    def save_checkpoint(self, model_dir, optimizer_state=False):
+        """Collective.  Rank 0 writes ONE reference-format file (torch_engine.py:70-73: the gathered state_dict, as a
+        single-GPU engine would) to ``model_dir``.  ``optimizer_state=True``: every rank also writes its shard's
+        optimizer state -- the clock as the device holds it, the moments, the lazy form's stamps and scalars after a
+        flush -- to ``model_dir + ".opt.rank<r>of<R>"`` (resumable at the same world size)."""
+        full = self.gather_full_state_dict()          # flushes the lazy rows first
+        if self.rank == 0:
+            torch.save({k: v.cpu() for k, v in full.items()}, model_dir)
+        if optimizer_state:
+            if not isinstance(self.k, HipKernels):
+                raise NotImplementedError("optimizer checkpoints need the HIP kernels' device state")
+            opt, lz = self.optimizer, self._lazy
+            cpu = lambda t: None if t is None else t.detach().to("cpu", copy=True)   # noqa: E731
+            torch.save({"format": self.OPT_STATE_FORMAT, "optimizer": opt.name, "world": self.world, "rank": self.rank,
+                        "n_params": int(self.model.flat.numel()), "step_count": int(self.step_count),
+                        "stats": cpu(self.k.stats), "exp_avg": cpu(opt.exp_avg), "exp_avg_sq": cpu(opt.exp_avg_sq),
+                        "lazy": None if lz is None else {k: cpu(lz[k]) for k in ("stamp_u", "stamp_i", "scalars")}},
+                       f"{model_dir}.opt.rank{self.rank}of{self.world}")
+
+    def resume_checkpoint(self, model_dir, optimizer_state=False):
+        """Every rank keeps its rows of the reference-format file; ``optimizer_state=True`` also restores this rank's
+        ``.opt.rank<r>of<R>`` file."""
+        self.load_full_state_dict(torch.load(model_dir, map_location="cpu"))
+        if not optimizer_state:
+            return self.model
+        payload = torch.load(f"{model_dir}.opt.rank{self.rank}of{self.world}", map_location="cpu")
+        opt = self.optimizer
+        if (payload.get("format") != self.OPT_STATE_FORMAT or payload["optimizer"] != opt.name
+                or payload["world"] != self.world or payload["n_params"] != self.model.flat.numel()):
+            raise ValueError("the optimizer state file does not fit this engine (format / optimizer / world size / shard size)")
+        dev = self.device
+        self.k.stats.copy_(payload["stats"].to(dev))
+        self.step_count = int(payload["step_count"])
+        for attr in ("exp_avg", "exp_avg_sq"):
+            if getattr(opt, attr) is not None:
+                getattr(opt, attr).copy_(payload[attr].to(dev))
+        if self._lazy is not None:
+            if payload["lazy"] is not None:
+                for k in ("stamp_u", "stamp_i", "scalars"):
+                    self._lazy[k].copy_(payload["lazy"][k].to(dev))
+            else:
+                self.k.lazy_mark_current(self._lazy)
+            self._lazy["dirty"] = False
+        return self.model
 
     # ---- exchange helpers -------------------------------------------------------------------
     def _exchange_counts(self, counts):
@@ -872,7 +927,7 @@ class ShardedMFEngine:
         if self._step_comm() == "c":
             k.planned_steps(plan, pb, m, self._g_flat, self.optimizer, a, b, reg, self._comm, lazy)
             self.step_count += b - a
-            if b == S and self.config["model"].get("lazy_flush", "epoch") == "epoch":
+            if b == S and self.flush_lazy_every_epoch:
                 self.flush_lazy()     # the epoch's callers (evaluation, checkpoints) read the tables
             return k.epoch_stats() if sync else None
         item_emb, item_bias = m.item_emb.weight.data, m.item_bias.weight.data
@@ -908,7 +963,7 @@ class ShardedMFEngine:
                     k.opt_step(self.optimizer, m.flat, self._g_flat, self.step_count)
             else:
                 k.apply_finish(item_emb, item_bias, idx, g_recv, -lr, plan["ex_in"][s], m.global_bias.data, -lr, s == 0)
-        if b == S and self.config["model"].get("lazy_flush", "epoch") == "epoch":
+        if b == S and self.flush_lazy_every_epoch:
             self.flush_lazy()
         return k.epoch_stats() if sync else None
 

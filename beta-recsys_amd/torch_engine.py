@@ -159,20 +159,81 @@ class ModelEngine(object):
         """torch_engine.py:58-68: likewise overridden by every engine."""
         raise NotImplementedError("engines implement train_an_epoch")
 
-    def save_checkpoint(self, model_dir):
-        """torch_engine.py:70-73: torch.save(model.state_dict(), path)."""
-        assert hasattr(self, "model"), "Please specify the exact model !"
-        torch.save(self.model.state_dict(), model_dir)
+    OPT_STATE_SUFFIX = ".opt"          # the optional second file of a checkpoint: optimizer clock + moments
+    OPT_STATE_FORMAT = "hiprec-optimizer-state-1"
 
-    def resume_checkpoint(self, model_dir, model=None):
-        """torch_engine.py:76-90."""
+    def save_checkpoint(self, model_dir, optimizer_state=False):
+        """torch_engine.py:70-73: torch.save(model.state_dict(), path) -- that file is all the reference writes and
+        stays byte-compatible with it.  ``optimizer_state=True`` (SURVEY 8f-3's optional half) also writes
+        ``model_dir + ".opt"``: the optimizer clock exactly as the device holds it, the moments and, for the lazy
+        Adam / RMSprop form, the per-row stamps and the per-step scalars table after a flush -- what
+        :meth:`resume_checkpoint` needs to continue the run bit for bit."""
+        assert hasattr(self, "model"), "Please specify the exact model !"
+        if hasattr(self, "flush_lazy"):
+            self.flush_lazy()           # a lagging row's weights on disk must be the dense steps' weights
+        torch.save(self.model.state_dict(), model_dir)
+        if optimizer_state:
+            torch.save(self.optimizer_checkpoint(), model_dir + self.OPT_STATE_SUFFIX)
+
+    def resume_checkpoint(self, model_dir, model=None, optimizer_state=False):
+        """torch_engine.py:76-90.  ``optimizer_state=True`` also restores ``model_dir + ".opt"`` (written by
+        ``save_checkpoint(..., optimizer_state=True)``) into this engine."""
         assert hasattr(self, "model"), "Please specify the exact model !"
         print("loading model from:", model_dir)
         state_dict = torch.load(model_dir, map_location=self.device)
         target = self.model if model is None else model
         target.load_state_dict(state_dict)
         target.to(self.device)
+        if optimizer_state:
+            if target is not self.model:
+                raise ValueError("the optimizer state belongs to the engine's own model")
+            self.load_optimizer_checkpoint(torch.load(model_dir + self.OPT_STATE_SUFFIX, map_location="cpu"))
         return target
+
+    def optimizer_checkpoint(self):
+        """Everything beyond the weights that the next step depends on, as CPU tensors: the raw ``hiprec_stats`` block
+        (step count and the running beta powers as the device's doubles -- recomputing them with pow() differs in the
+        last bits), the flat moment buffers, and the lazy form's stamps / scalars table (rows are flushed first: every
+        touched row is current as of the clock)."""
+        if not isinstance(getattr(self, "optimizer", None), HipOptimizer):
+            raise NotImplementedError("optimizer checkpoints exist for the flat-buffer engines")
+        self._setup()
+        if hasattr(self, "flush_lazy"):
+            self.flush_lazy()
+        opt = self.optimizer
+        cpu = lambda t: None if t is None else t.detach().to("cpu", copy=True)   # noqa: E731
+        lz = getattr(self, "_lazy", None)
+        return {"format": self.OPT_STATE_FORMAT, "optimizer": opt.name, "lr": opt.lr,
+                "n_params": int(self.model.flat.numel()),
+                "stats": cpu(self._stats.view(torch.uint8)),
+                "exp_avg": cpu(opt.exp_avg), "exp_avg_sq": cpu(opt.exp_avg_sq),
+                "lazy": None if lz is None else {k: cpu(lz[k]) for k in ("stamp_u", "stamp_i", "scalars")}}
+
+    def load_optimizer_checkpoint(self, payload):
+        """Counterpart of :meth:`optimizer_checkpoint`; the weights are restored by ``load_state_dict``."""
+        if payload.get("format") != self.OPT_STATE_FORMAT:
+            raise ValueError(f"not a {self.OPT_STATE_FORMAT} file")
+        self._setup()
+        opt = self.optimizer
+        if payload["optimizer"] != opt.name or payload["n_params"] != self.model.flat.numel():
+            raise ValueError(f"optimizer state of {payload['optimizer']!r} over {payload['n_params']} parameters does not "
+                             f"fit this engine ({opt.name!r}, {self.model.flat.numel()})")
+        if hasattr(self, "flush_lazy"):
+            self.flush_lazy()
+        dev = self.model.flat.device
+        self._stats.view(torch.uint8).copy_(payload["stats"].to(dev))
+        for attr in ("exp_avg", "exp_avg_sq"):
+            buf = getattr(opt, attr)
+            if buf is not None:
+                buf.copy_(payload[attr].to(dev))
+        lz = getattr(self, "_lazy", None)
+        if lz is not None:
+            if payload["lazy"] is not None:
+                for k in ("stamp_u", "stamp_i", "scalars"):
+                    lz[k].copy_(payload["lazy"][k].to(dev))
+            else:       # written by the sweeping form: every row is current as of the restored clock
+                self._lazy_mark_current()
+            lz["dirty"] = False
 
     def bpr_loss(self, pos_scores, neg_scores):
         """torch_engine.py:92-106 on caller-supplied score tensors (utility, not the fused path)."""

@@ -1035,3 +1035,21 @@ def test_spread_bank_conflicts_only_reorders_inside_lane_segments():
         by_eid_old = dict(zip(ref["eid"][ref["eid"] >= 0].tolist(), ref["val"][ref["eid"] >= 0].tolist()))
         assert by_eid_new == by_eid_old
         assert not np.array_equal(h["col16"], ref["col16"])
+
+
+def test_lazy_scalars_table_has_its_converged_tail_and_refuses_slow_betas():
+    """beyond the tabulated steps a lazy Adam replay reads the table's LAST entry -- created with the
+    converged pair (lr, 1) -- and betas whose bias corrections still move there are refused at set-up."""
+    from beta_recsys_amd import _lib
+    from beta_recsys_amd.torch_engine import HipOptimizer
+
+    adam = HipOptimizer("adam", 0.05)
+    assert _lib.lazy_betas_converge(adam) and _lib.lazy_betas_converge(HipOptimizer("rmsprop", 0.01))
+    t = _lib.lazy_scalars_table(adam, "cpu")
+    assert tuple(t.shape) == (1 << 16, 2) and t[:-1].abs().sum() == 0
+    assert t[-1, 0].item() == np.float32(0.05) and t[-1, 1].item() == 1.0
+    adam.beta2 = 0.9999      # 0.9999 ** 65535 = 1.4e-3: the corrections have not converged inside the table
+    assert not _lib.lazy_betas_converge(adam)
+    with pytest.raises(ValueError, match="converged"):
+        _lib.lazy_scalars_table(adam, "cpu")
+    assert _lib.lazy_scalars_table(HipOptimizer("rmsprop", 0.01), "cpu").abs().sum() == 0
