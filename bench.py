@@ -372,7 +372,8 @@ def bench_mf_c4shard(args, device, full=False):
     c4opt = args.c4_optimizer                 # sgd (primary) | adam | rmsprop (dense-Adam secondary)
     owned = args.sgd_mode in ("owned", "owned_atomic") and c4opt == "sgd"
     cfg = {"model": dict(n_users=Uc, n_items=Ic, emb_dim=Dc, device_str=str(device), optimizer=c4opt,
-                         lr=LR, batch_size=Bc, loss="bpr", sgd_mode=args.sgd_mode, dense_opt=args.dense_opt),
+                         lr=LR, batch_size=Bc, loss="bpr", sgd_mode=args.sgd_mode, dense_opt=args.dense_opt,
+                         lazy_grad=args.lazy_grad),
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -462,7 +463,10 @@ def bench_mf_c4shard(args, device, full=False):
         sweep_bytes = optimizer_sweep_bytes(c4opt, eng.model.flat.numel())
         row_bytes = {"adam": 3 * 6, "rmsprop": 3 * 4}[c4opt] * 4 * (Dc + 1)
         bpt_run = bpt + (row_bytes if lazy else sweep_bytes / Bc)
-        kname = ("lazy step: catch-up + mf_bpr_owned_kernel<2,false,true> (gradients) + update (3 launches)" if lazy
+        kname = (("lazy step: catch-up + mf_bpr_owned_kernel<2,false,false,true> (gradient parts -> contribution buffer) + "
+                  "lazy_pull_apply_kernel (sum, replay the moments, step, stamp): 3 launches, no dense gradient traffic"
+                  if eng._lazy_owned() == "pull" else
+                  "lazy step: catch-up + mf_bpr_owned_kernel<2,false,true> (gradients) + update (3 launches)") if lazy
                  else "mf_bpr_fused_kernel / dense sweep")
         k_s = alone_s
         traffic, traffic_src = (traffic_step_from_profiles(("mf-c4_" if full else "mf-c4shard_") + c4opt,
@@ -1243,6 +1247,10 @@ def parse_args(argv=None):
     ap.add_argument("--dense-opt", default="auto", choices=["auto", "lazy", "sweep"],
                     help="mf-c4 (sharded) with Adam / RMSprop: exact lazy replay of the step's rows (csrc/lazy_opt.hip) "
                          "or the dense sweep of the whole shard every step")
+    ap.add_argument("--lazy-grad", default="pull", choices=["pull", "owned", "atomic"],
+                    help="mf-c4 / mf-c4shard with lazy Adam / RMSprop: pull = gradient parts through the contribution "
+                         "buffer + one apply launch (round 5); owned / atomic = gradient kernel into the dense buffer + "
+                         "update launch (round 4)")
     ap.add_argument("--step-driver", default="c", choices=["c", "torch"],
                     help="row-sharded planned steps: c = kernels and grouped ncclSend/ncclRecv enqueued by one C call "
                          "per range of steps; torch = torch.distributed.all_to_all_single between the launches")

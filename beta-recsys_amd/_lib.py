@@ -361,10 +361,13 @@ SIGNATURES = {
     "hiprec_ownership_ws_ints": (c_int64, [c_int64, c_int64, c_int32]),
     "hiprec_batch_row_ownership": (
         c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
+    "hiprec_stage_grouped_ws_ints": (c_int64, [c_int64, c_int64, c_int64]),
+    "hiprec_stage_epoch_grouped": (
+        c_int, [_P, _P, _P, _P, c_int32, ctypes.c_uint64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P]),
     "hiprec_mf_pull_chunk": (c_int32, [c_int32]),
-    "hiprec_contrib_row_cap": (c_int64, [c_int64]),
+    "hiprec_contrib_row_cap": (c_int64, [c_int64, c_int32]),
     "hiprec_batch_row_contrib": (
-        c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, c_int64, _P, _P]),
+        c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P, _P]),
     "hiprec_mf_bpr_epoch_pull": (
         c_int,
         [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int64, c_int64,
@@ -411,6 +414,8 @@ SIGNATURES = {
                                      _P, _P, c_size_t, _P]),
     "hiprec_mf_bpr_grad_owned": (c_int, [_P, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int64, c_float,
                                          c_float, _P, _P, _P]),
+    "hiprec_mf_epoch_lazy_pull": (c_int, [POINTER(LazyState), _P, _P, _P, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64,
+                                          c_int64, c_int32, c_float, _P, _P, _P]),
     "hiprec_mf_epoch_lazy_owned": (c_int, [POINTER(LazyState), _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int64,
                                            c_int32, c_float, _P, _P, _P]),
     "hiprec_shard_plan_bytes": (c_size_t, []),
@@ -575,3 +580,13 @@ def lazy_scalars_table(opt, device, cap=LAZY_SCALARS_CAP):
         table[cap - 1, 0] = float(opt.lr)
         table[cap - 1, 1] = 1.0
     return table
+
+
+def grow(buf, numel, dtype, device):
+    """A work-space tensor of at least `numel` elements: `buf` if it is big enough (same device / dtype), else a new one.
+    (Staging buffers are allocated once and kept, not re-made every epoch.)"""
+    import torch
+
+    if buf is not None and buf.numel() >= numel and buf.dtype == dtype and buf.device == torch.device(device):
+        return buf
+    return torch.empty(max(int(numel), 1), dtype=dtype, device=device)

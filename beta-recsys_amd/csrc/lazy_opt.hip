@@ -31,6 +31,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "pull.hpp"
 
 namespace hiprec {
 namespace {
@@ -60,13 +61,13 @@ __device__ __forceinline__ float2 lazy_scalars_at(const LazyCtx& c, long long t)
 // The model's scalar (global_bias, the last element) takes a real step every step; its gradient is in g (the row-sharded
 // step's bookkeeping put it there) plus, for callers that pass the gradient kernel's scratch, the per-block partials
 // (which also books the step's loss, as the dense sweep does).  Block 0 of an update launch.
-template <int KIND>
+template <int KIND, int NT = kBlock>
 __device__ __forceinline__ void lazy_scalar_step(const LazyCtx& c, const OptScalars& s, hiprec_stats* stats,
                                                  const Scratch* scratch, long long clock, float ss_now, float bc2_now,
                                                  int bid = blockIdx.x) {
   if (bid != 0) return;
   float extra = 0.f;
-  if (scratch) extra = finalize_partials(stats, scratch);
+  if (scratch) extra = finalize_partials<NT>(stats, scratch);
   if (threadIdx.x != 0) return;
   const int64_t i = (c.n_users + c.n_items) * (static_cast<int64_t>(c.dim) + 1);
   float wv = c.w[i], gv = c.g[i] + extra, mv = 0.f, vv = c.v[i];
@@ -504,6 +505,160 @@ __global__ __launch_bounds__(kBlock) void lazy_rows_kernel(LazyCtx c, hiprec_laz
   if constexpr (MODE == 1) lazy_scalar_step<KIND>(c, s, stats, scratch, clock, ss_now, bc2_now);
 }
 
+// ---- owner pulls (round 5): the apply launch of a lazy Adam / RMSprop step ------------------------------------------
+// hiprec_mf_epoch_lazy_pull: catch-up (above) -> the gradient launch of csrc/mf_owned.hip with EVERY row's gradient
+// parts stored to the contribution buffer (hiprec_batch_row_contrib with min_contrib = 1; it also counts the step) ->
+// this launch: one lane group per row of the batch sums the row's range, replays the MOMENTS over the steps the row
+// lagged (its weights are current: the catch-up's w-ahead state, the same fma + multiply per step as the update launch
+// above), takes the real step and stamps the row.  Against catch-up + gradient kernel + update (three launches, the
+// gradient through a dense buffer: written with atomics where waves share a row, read and cleared by the update) a row's
+// gradient crosses memory once, nobody claims anything (a row has ONE record), and the gradient buffer is not touched.
+// The arithmetic of a row is the update launch's, operation for operation; what differs is the order in which the
+// parts of a shared row's gradient are summed.  dim % 4 == 0.
+template <int KIND, int LPR>
+__global__ __launch_bounds__(kPullBlock) __attribute__((amdgpu_waves_per_eu(8)))
+void lazy_pull_apply_kernel(PullApply f, LazyCtx c, OptScalars s,
+                                                                     hiprec_stats* stats, const Scratch* scratch) {
+  constexpr int RPW = kWave / LPR;
+  constexpr int GROUPS = kPullWaves * RPW;
+  constexpr int DEPTH = 2;   // (most rows of a batch have ONE part; 64 VGPRs = two workgroups per CU)
+  constexpr int kLongDepth = 4;
+  constexpr bool kAdam = KIND == HIPREC_OPT_ADAM;
+  __shared__ float4 s_part[GROUPS][LPR];
+  __shared__ float s_pb[GROUPS];
+  const int lane = lane_id(), wv = wave_in_block();
+  const int nb = static_cast<int>(gridDim.x) - 1, blk = static_cast<int>(blockIdx.x) - 1;
+  const long long clock = stats->step;          // the step being taken: the gradient launch has counted it
+  float ss_now = s.lr, bc2_now = 1.f;
+  step_scalars<KIND>(s, stats, &ss_now, &bc2_now);
+  if (blk < 0) {
+    lazy_scalar_step<KIND, kPullBlock>(c, s, stats, scratch, clock, ss_now, bc2_now, 0);
+    return;
+  }
+  const int D = f.dim;
+  const int sub = lane / LPR, sl = lane % LPR, grp = wv * RPW + sub;
+  const bool col = sl * 4 < D;
+  const int target = static_cast<int>(clock);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int n_short = f.counts[0], n_long = f.counts[1];
+
+  // A row of the batch in two halves, so that everything a row needs travels together: load_row requests its stamp,
+  // weights and moments (before the caller waits for the row's gradient parts), finish_row replays the moments over
+  // (base, clock - 1], takes the real step, stores and stamps.  `on`: this lane group holds a row; g / gb: the row's
+  // complete gradient (gb valid in every lane of the group).
+  struct Row {
+    int key, old;                // (addresses are derived again from the key when the row is stored: registers)
+    float w[5], m[5], v[5];
+  };
+  auto load_row = [&](bool on, int key) __attribute__((always_inline)) {
+    Row r;
+    r.key = key;
+    r.old = target - 1;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) r.w[j] = r.m[j] = r.v[j] = 0.f;
+    if (on) {
+      int64_t ro, bo;
+      pull_row_of(f, key, sl, &ro, &bo);
+      r.old = *(key < f.n_users ? c.stamp_u + key : c.stamp_i + (key - f.n_users));
+      if (col) {
+        const float4 w4 = *reinterpret_cast<const float4*>(c.w + ro), v4 = *reinterpret_cast<const float4*>(c.v + ro);
+        r.w[0] = w4.x, r.w[1] = w4.y, r.w[2] = w4.z, r.w[3] = w4.w;
+        r.v[0] = v4.x, r.v[1] = v4.y, r.v[2] = v4.z, r.v[3] = v4.w;
+        if constexpr (kAdam) {
+          const float4 m4 = *reinterpret_cast<const float4*>(c.m + ro);
+          r.m[0] = m4.x, r.m[1] = m4.y, r.m[2] = m4.z, r.m[3] = m4.w;
+        }
+      }
+      if (sl == 0) {
+        r.w[4] = c.w[bo];
+        r.v[4] = c.v[bo];
+        if constexpr (kAdam) r.m[4] = c.m[bo];
+      }
+    }
+    return r;
+  };
+  auto finish_row = [&](Row& r, bool on, float4 g, float gb) __attribute__((always_inline)) {
+    // zero-gradient steps (base, clock - 1]: the moments only (w is current: it was caught up before the gradients
+    // were taken, or the row did not lag; RMSprop's zero-gradient step leaves w alone)
+    const int base = r.old < 0 ? -1 : (r.old & ~kWAhead);
+    int n_rep = on && base >= 0 ? target - 1 - base : 0;
+    n_rep = n_rep > 0 ? n_rep : 0;
+    int n_max = n_rep;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_max = max(n_max, __shfl_xor(n_max, o));
+    n_max = __builtin_amdgcn_readfirstlane(n_max);
+    for (int k = 0; k < n_max; ++k) {
+      if (k >= n_rep) continue;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        float zero = 0.f, w_unused = 0.f;
+        opt_update<KIND>(w_unused, zero, r.m[j], r.v[j], s, 1.f, 1.f);
+      }
+    }
+    float gg[5] = {g.x, g.y, g.z, g.w, gb};
+#pragma unroll
+    for (int j = 0; j < 5; ++j) opt_update<KIND>(r.w[j], gg[j], r.m[j], r.v[j], s, ss_now, bc2_now);
+    if (!on) return;
+    int64_t ro, bo;
+    pull_row_of(f, r.key, sl, &ro, &bo);
+    if (col) {
+      *reinterpret_cast<float4*>(c.w + ro) = make_float4(r.w[0], r.w[1], r.w[2], r.w[3]);
+      *reinterpret_cast<float4*>(c.v + ro) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+      if constexpr (kAdam) *reinterpret_cast<float4*>(c.m + ro) = make_float4(r.m[0], r.m[1], r.m[2], r.m[3]);
+    }
+    if (sl == 0) {
+      c.w[bo] = r.w[4];
+      c.v[bo] = r.v[4];
+      if constexpr (kAdam) c.m[bo] = r.m[4];
+      *(r.key < f.n_users ? c.stamp_u + r.key : c.stamp_i + (r.key - f.n_users)) = target;
+    }
+  };
+
+  // long rows first: one workgroup each
+  for (int i = blk; i < n_long; i += nb) {
+    const int4 rec = f.rows[f.row_cap - 1 - i];
+    float4 g = zero4;
+    float gb = 0.f;
+    const int per_trip = kLongDepth * GROUPS;
+    pull_sum_range<LPR, kLongDepth>(f, rec.y, grp, rec.z, GROUPS, (rec.z + per_trip - 1) / per_trip, sl, col, g, gb);
+    s_part[grp][sl] = g;
+    if (sl == 0) s_pb[grp] = gb;
+    __syncthreads();
+    if (wv == 0) {
+      float4 tot = zero4;
+      float tb = 0.f;
+#pragma unroll 4
+      for (int q = 0; q < GROUPS; ++q) {
+        const float4 p = s_part[q][sl];
+        tot.x += p.x, tot.y += p.y, tot.z += p.z, tot.w += p.w;
+        tb += s_pb[q];
+      }
+      Row r = load_row(sub == 0, rec.x);
+      finish_row(r, sub == 0, tot, tb);
+    }
+    __syncthreads();
+  }
+  // the other rows: one lane group each, the next record requested before this one's row is stepped
+  const int i_first = blk * GROUPS + wv * RPW;
+  int4 rec = make_int4(0, 0, 0, 0);
+  if (i_first + sub < f.row_cap) rec = f.rows[i_first + sub];
+  for (int i0 = i_first; __builtin_amdgcn_readfirstlane(i0) < n_short; i0 += nb * GROUPS) {
+    const bool on = i0 + sub < n_short;
+    if (!on) rec = make_int4(0, 0, 0, 0);
+    int trips = (rec.z + DEPTH - 1) / DEPTH;
+#pragma unroll
+    for (int o = LPR; o < kWave; o <<= 1) trips = max(trips, __shfl_xor(trips, o));
+    trips = __builtin_amdgcn_readfirstlane(trips);
+    float4 g = zero4;
+    float gb = 0.f;
+    Row r = load_row(on, rec.x);                 // stamp, weights, moments: requested with the gradient parts
+    pull_sum_range<LPR, DEPTH>(f, rec.y, 0, rec.z, 1, trips, sl, col, g, gb);
+    const int nxt = i0 + nb * GROUPS + sub;
+    if (nxt < n_short) rec = f.rows[nxt];
+    finish_row(r, on, g, gb);
+  }
+}
+
 // A dense sweep was run while lazy state exists (the caller flushed first): every row is current as of the clock.
 __global__ __launch_bounds__(kBlock) void lazy_mark_current_kernel(int32_t* stamp, int64_t n, const hiprec_stats* stats) {
   const int target = static_cast<int>(stats->step);
@@ -653,6 +808,77 @@ extern "C" int hiprec_mf_epoch_lazy_owned(const hiprec_lazy_state* state, const 
                                           total + k * total_stride, b, inv_b, reg_coef, stats, scratch, stream))
       return rc;
     if (int rc = hiprec_lazy_update(state, &rows, scratch, stats, stream)) return rc;
+  }
+  return 0;
+}
+
+// The same epoch as owner pulls (round 5): per step catch-up -> gradient launch (every row's parts to the contribution
+// buffer; counts the step) -> lazy_pull_apply_kernel.  cidx / rows / counts: hiprec_batch_row_contrib's arrays made
+// with min_contrib = 1, already offset to this piece's first step (cidx_stride = the n they were made for); cbuf
+// [3 * batch, dim] / cbias [3 * batch]: work space.  BPR, dim % 4 == 0.  The dense gradient buffer of `state` is not
+// touched (its scalar-bias element is read: zero for this caller).
+extern "C" int hiprec_mf_epoch_lazy_pull(const hiprec_lazy_state* state, const int64_t* users, const int64_t* pos,
+                                         const int64_t* neg, const int32_t* cidx, int64_t cidx_stride,
+                                         const int32_t* rows, int64_t row_cap, const int32_t* counts, float* cbuf,
+                                         float* cbias, int64_t n, int64_t batch, int32_t first_of_epoch, float reg_coef,
+                                         hiprec_stats* stats, void* scratch, void* stream) {
+  HIPREC_REQUIRE(state && stats && scratch, "NULL pointer");
+  HIPREC_REQUIRE(state->kind == HIPREC_OPT_ADAM || state->kind == HIPREC_OPT_RMSPROP, "lazy state is Adam's or RMSprop's");
+  HIPREC_REQUIRE(state->w && state->g && state->v && (state->kind != HIPREC_OPT_ADAM || state->m) && state->stamp_u &&
+                     state->stamp_i, "NULL buffer in the lazy optimizer state");
+  HIPREC_REQUIRE(state->kind != HIPREC_OPT_ADAM || (state->scalars && state->scalars_cap >= 2), "Adam needs the scalars table");
+  HIPREC_REQUIRE(state->dim > 0 && state->dim <= 256 && state->dim % 4 == 0, "the pull form needs dim %% 4 == 0, dim <= 256");
+  HIPREC_REQUIRE(n >= 0 && batch > 0 && cidx_stride >= n, "bad n / batch / cidx_stride");
+  HIPREC_REQUIRE(n == 0 || (users && pos && neg && cidx && rows && counts && cbuf && cbias), "NULL batch / contribution arrays");
+  HIPREC_REQUIRE(n == 0 || row_cap >= 3 * std::min(batch, n), "row_cap too small: every row of a batch has a record");
+  if (first_of_epoch)
+    if (int rc = hiprec_stats_begin_epoch(stats, stream)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int32_t dim = state->dim;
+  const LazyCtx c{state->w, state->g, state->m, state->v, state->n_users, state->n_items, dim, state->stamp_u,
+                  state->stamp_i, reinterpret_cast<float2*>(state->scalars), state->scalars_cap};
+  const OptScalars s{state->lr, static_cast<float>(state->lr), static_cast<float>(state->beta2),
+                     static_cast<float>(1.0 - state->beta1), static_cast<float>(1.0 - state->beta2),
+                     static_cast<float>(state->eps)};
+  PullApply a;
+  a.w = state->w;
+  a.n_users = state->n_users;
+  a.o_ie = state->n_users * dim;
+  a.o_ub = (state->n_users + state->n_items) * static_cast<int64_t>(dim);
+  a.o_ib = a.o_ub + state->n_users;
+  a.dim = dim;
+  a.begin_epoch = 0;
+  a.count_step = 0;
+  a.cbuf = cbuf;
+  a.cbias = cbias;
+  a.row_cap = row_cap;
+  a.gb = nullptr;
+  a.lr = static_cast<float>(state->lr);
+  const bool adam = state->kind == HIPREC_OPT_ADAM;
+  for (int64_t off = 0, k = 0; off < n; off += batch, ++k) {
+    const int64_t b = std::min<int64_t>(batch, n - off);  // drop_last = False
+    const hiprec_lazy_rows lists{users + off, b, pos + off, b, neg + off, b, nullptr, 0};
+    if (int rc = hiprec_lazy_catchup(state, &lists, stats, stream)) return rc;
+    if (int rc = launch_pull_grad(state->w, state->n_users, state->n_items, dim, users + off, pos + off, neg + off,
+                                  cidx + off, cidx + cidx_stride + off, cidx + 2 * cidx_stride + off, cbuf, cbias, b,
+                                  reg_coef, 0.f, 1, stats, scratch, st))
+      return rc;
+    a.rows = reinterpret_cast<const int4*>(rows) + k * row_cap;
+    a.counts = counts + 4 * k;
+    // one lane group per row of the batch (at most 3 b), two workgroups per CU
+    const int64_t per_block = kPullWaves * (dim <= 64 ? 4 : dim <= 128 ? 2 : 1);
+    const int grid = static_cast<int>(std::min<int64_t>((3 * b + per_block - 1) / per_block, 512)) + 1;
+    const auto* sc = static_cast<const Scratch*>(scratch);
+#define HIPREC_LAZY_PULL(LPR)                                                                                      \
+  do {                                                                                                             \
+    if (adam) lazy_pull_apply_kernel<HIPREC_OPT_ADAM, LPR><<<grid, kPullBlock, 0, st>>>(a, c, s, stats, sc);        \
+    else lazy_pull_apply_kernel<HIPREC_OPT_RMSPROP, LPR><<<grid, kPullBlock, 0, st>>>(a, c, s, stats, sc);          \
+  } while (0)
+    if (dim <= 64) HIPREC_LAZY_PULL(16);
+    else if (dim <= 128) HIPREC_LAZY_PULL(32);
+    else HIPREC_LAZY_PULL(64);
+#undef HIPREC_LAZY_PULL
+    HIPREC_TRY(hipGetLastError());
   }
   return 0;
 }

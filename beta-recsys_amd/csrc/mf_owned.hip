@@ -31,6 +31,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "pull.hpp"
 
 namespace hiprec {
 
@@ -86,6 +87,7 @@ struct OwnedStep {
   // row cidx of cbuf [.., dim] / element cidx of cbias with plain stores, pull_apply_kernel sums and applies them)
   float* cbuf;
   float* cbias;
+  int32_t count_step;          // PULL: block 0 counts the step (the lazy optimizers' apply launch READS the clock)
 };
 
 // Read a finished accumulator element and leave it zero for the next step: ONE device-scope exchange.  (A device-scope
@@ -154,6 +156,9 @@ void mf_bpr_owned_kernel(
   // mf_bpr_grad_kernel's stepper thread does (nothing in this kernel reads the clock)
   if constexpr (GRAD && !REMOTE) {
     if (blockIdx.x == 0 && threadIdx.x == 0) advance_step(stats);
+  }
+  if constexpr (PULL) {
+    if (f.count_step && blockIdx.x == 0 && threadIdx.x == 0) advance_step(stats);
   }
   float* const wf = f.w;
   const int ld = D + 1;
@@ -513,23 +518,6 @@ void mf_bpr_owned_kernel(
 // kContribLongRow contributions (listed from the end of the batch's records) take a whole workgroup: every wave sums a
 // strided share, the shares meet in LDS.  Block 0 folds the step's loss partials into hiprec_stats, steps the
 // scalar bias and counts the step (what the extra block of mf_bpr_owned_kernel does one launch late).
-constexpr int kPullBlock = 1024;
-constexpr int kPullWaves = kPullBlock / kWave;
-constexpr int kPullDepth = 8;             // contribution rows a wave keeps in flight
-
-struct PullApply {
-  float* w;
-  int64_t n_users, o_ie, o_ub, o_ib;
-  int32_t dim, begin_epoch, count_step;
-  const float* cbuf;
-  const float* cbias;
-  const int4* rows;              // this batch's records
-  int64_t row_cap;
-  const int32_t* counts;         // this batch's {short rows, long rows, contributions, -}
-  float* gb;                     // the scalar bias
-  float lr;
-};
-
 template <int NPL>
 __device__ __forceinline__ void pull_sum(const PullApply& f, int start, int first, int cnt, int stride, int lane,
                                          float (&g)[NPL], float& gb) {
@@ -678,32 +666,11 @@ void pull_apply_vec_kernel(PullApply f, hiprec_stats* stats, Scratch* scratch) {
     a.z += b.z;
     a.w += b.w;
   };
-  // contributions first, first + stride, ... < cnt of the range at `start` -> g (this lane's 4 columns) and, summed
-  // over the lane group, gb; kPullDepth rows requested per trip.  `trips` is uniform over the wave.
-  auto sum_range = [&](int start, int first, int cnt, int stride, int trips, float4& g, float& gb) {
-    for (int t = 0; t < trips; ++t) {
-      const int j0 = first + t * kPullDepth * stride;
-      float4 v[kPullDepth];
-#pragma unroll
-      for (int q = 0; q < kPullDepth; ++q) {
-        const int j = j0 + q * stride;
-        v[q] = zero4;
-        if (col && j < cnt) v[q] = *reinterpret_cast<const float4*>(f.cbuf + static_cast<int64_t>(start + j) * D + sl * 4);
-      }
-#pragma unroll
-      for (int q = 0; q < kPullDepth; ++q) add4(g, v[q]);
-    }
-    float b = 0.f;
-    for (int j = first + sl * stride; j < cnt; j += LPR * stride) b += f.cbias[start + j];
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) b += __shfl_xor(b, o);
-    gb += b;
-  };
   auto row_of = [&](int key, float*& row, float*& bias) {
-    const bool user = key < f.n_users;
-    const int64_t r = user ? key : key - f.n_users;
-    row = f.w + (user ? r * D : f.o_ie + r * D) + sl * 4;
-    bias = f.w + (user ? f.o_ub + r : f.o_ib + r);
+    int64_t r, bo;
+    pull_row_of(f, key, sl, &r, &bo);
+    row = f.w + r;
+    bias = f.w + bo;
   };
   // long rows first (they are the critical path of the launch): one workgroup each
   for (int i = blk; i < n_long; i += nb) {
@@ -711,7 +678,7 @@ void pull_apply_vec_kernel(PullApply f, hiprec_stats* stats, Scratch* scratch) {
     float4 g = zero4;
     float gb = 0.f;
     const int per_trip = kPullDepth * GROUPS;
-    sum_range(rec.y, grp, rec.z, GROUPS, (rec.z + per_trip - 1) / per_trip, g, gb);
+    pull_sum_range<LPR, kPullDepth>(f, rec.y, grp, rec.z, GROUPS, (rec.z + per_trip - 1) / per_trip, sl, col, g, gb);
     s_part[grp][sl] = g;
     if (sl == 0) s_pb[grp] = gb;
     __syncthreads();
@@ -890,6 +857,7 @@ extern "C" int hiprec_mf_bpr_epoch_owned(float* w_flat, int64_t n_users, int64_t
     f.item_out = nullptr;
     f.grad_out = nullptr;
     f.cbuf = f.cbias = nullptr;
+    f.count_step = 0;
 #ifdef HIPREC_OWNED_DEBUG
     static const int dbg = getenv("HIPREC_OWNED_DBG") ? atoi(getenv("HIPREC_OWNED_DBG")) : 0;
     f.dbg = dbg;
@@ -903,6 +871,44 @@ extern "C" int hiprec_mf_bpr_epoch_owned(float* w_flat, int64_t n_users, int64_t
       return rc;
   }
   return 0;
+}
+
+int hiprec::launch_pull_grad(const float* w_flat, int64_t n_users, int64_t n_items, int32_t dim, const int64_t* users,
+                             const int64_t* pos, const int64_t* neg, const int32_t* cidx_u, const int32_t* cidx_p,
+                             const int32_t* cidx_n, float* cbuf, float* cbias, int64_t batch, float reg_coef, float lr,
+                             int32_t count_step, hiprec_stats* stats, void* scratch, hipStream_t stream) {
+  OwnedStep f;
+  f.w = const_cast<float*>(w_flat);   // written only where cidx says the launch updates a row in place (SGD form)
+  f.n_users = n_users;
+  f.n_items = n_items;
+  f.dim = dim;
+  f.apply_prev = 0;
+  f.own_u = cidx_u;
+  f.own_p = cidx_p;
+  f.own_n = cidx_n;
+  f.total = nullptr;
+  f.arrived = nullptr;
+  f.acc = nullptr;
+  f.gb_read = w_flat + (n_users + n_items) * (static_cast<int64_t>(dim) + 1);
+  f.gb_write = nullptr;
+  f.scratch_prev = static_cast<const Scratch*>(scratch);
+  f.n_prev_partials = 0;
+  f.n_gather_blocks = owned_blocks(dim, batch, true);
+  f.lr = lr;
+  f.dbg = 0;
+  f.o_ie = n_users * dim;
+  f.o_ub = (n_users + n_items) * static_cast<int64_t>(dim);
+  f.o_ib = f.o_ub + n_users;
+  f.item_stride = dim;
+  f.bias_stride = 1;
+  f.item_out = nullptr;
+  f.grad_out = nullptr;
+  f.cbuf = cbuf;
+  f.cbias = cbias;
+  f.count_step = count_step;
+  return launch_owned<false, false, true>(f, f.n_gather_blocks, stream, users, pos, neg, batch,
+                                          1.0f / static_cast<float>(batch), reg_coef, stats,
+                                          static_cast<Scratch*>(scratch));
 }
 
 extern "C" int32_t hiprec_mf_pull_chunk(int32_t dim) { return pull_chunk(dim <= 64 ? 1 : dim <= 128 ? 2 : 4); }
@@ -965,37 +971,9 @@ extern "C" int hiprec_mf_bpr_epoch_pull(float* w_flat, int64_t n_users, int64_t 
   for (int64_t k = step_begin; k < step_end; ++k) {
     const int64_t off = k * batch;
     const int64_t b = std::min<int64_t>(batch, n_triples - off);
-    OwnedStep f;
-    f.w = w_flat;
-    f.n_users = n_users;
-    f.n_items = n_items;
-    f.dim = dim;
-    f.apply_prev = 0;
-    f.own_u = cidx + off;
-    f.own_p = cidx + cidx_stride + off;
-    f.own_n = cidx + 2 * cidx_stride + off;
-    f.total = nullptr;
-    f.arrived = nullptr;
-    f.acc = nullptr;
-    f.gb_read = w_flat + o_gb;
-    f.gb_write = nullptr;
-    f.scratch_prev = static_cast<const Scratch*>(scratch);
-    f.n_prev_partials = 0;
-    f.n_gather_blocks = owned_blocks(dim, b, true);
-    f.lr = static_cast<float>(lr);
-    f.dbg = 0;
-    f.o_ie = n_users * dim;
-    f.o_ub = (n_users + n_items) * static_cast<int64_t>(dim);
-    f.o_ib = f.o_ub + n_users;
-    f.item_stride = dim;
-    f.bias_stride = 1;
-    f.item_out = nullptr;
-    f.grad_out = nullptr;
-    f.cbuf = cbuf;
-    f.cbias = cbias;
-    if (int rc = launch_owned<false, false, true>(f, f.n_gather_blocks, st, users + off, pos + off, neg + off, b,
-                                                  1.0f / static_cast<float>(b), reg_coef, stats,
-                                                  static_cast<Scratch*>(scratch)))
+    if (int rc = launch_pull_grad(w_flat, n_users, n_items, dim, users + off, pos + off, neg + off, cidx + off,
+                                  cidx + cidx_stride + off, cidx + 2 * cidx_stride + off, cbuf, cbias, b, reg_coef,
+                                  static_cast<float>(lr), 0, stats, scratch, st))
       return rc;
     a.begin_epoch = k == 0 ? 1 : 0;
     a.count_step = 1;
@@ -1057,6 +1035,7 @@ static int owned_remote_impl(float* w_flat, float* g_flat, int64_t n_users, int6
   f.item_out = g_send;
   f.grad_out = g_flat;
   f.cbuf = f.cbias = nullptr;
+  f.count_step = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (g_flat)
     return launch_owned<true, true>(f, f.n_gather_blocks, st, users, pos_slot, neg_slot, batch, inv_batch, reg_coef,
@@ -1137,6 +1116,7 @@ extern "C" int hiprec_mf_bpr_grad_owned(const float* w_flat, float* g_flat, int6
   f.item_out = nullptr;
   f.grad_out = g_flat;
   f.cbuf = f.cbias = nullptr;
+  f.count_step = 0;
   return launch_owned<false, true>(f, f.n_gather_blocks, static_cast<hipStream_t>(stream), users, pos, neg, batch,
                                    inv_batch, reg_coef, stats, static_cast<Scratch*>(scratch));
 }

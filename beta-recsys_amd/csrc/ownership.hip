@@ -240,7 +240,9 @@ __global__ __launch_bounds__(kOwnThreads) void ownership_kernel(const int32_t* _
 // A row with several gets a contiguous range of the step's contribution buffer -- cidx = range start + arrival rank:
 // the contributor stores its part of the gradient THERE with plain stores -- and one record {row key, range start,
 // contributions} in the batch's row list; after the gradient launch one wave per record sums the range and writes
-// w - lr * g: no float atomics, no arrival counters, nothing to clear.  Records of rows with more than
+// w - lr * g: no float atomics, no arrival counters, nothing to clear.  min_c = 1 (the lazy Adam / RMSprop form,
+// csrc/lazy_opt.hip): EVERY row gets a record and a range, a row with one contribution included -- its optimizer step
+// needs the moments, which the gradient launch does not carry.  Records of rows with more than
 // kContribLongRow contributions (a Zipf head item at configs[3]: ~650 runs) are listed from the END of the list and
 // taken by a whole workgroup each.  counts[b] = {short rows, long rows, contributions, -}.
 constexpr int kContribLongRow = 32;
@@ -250,7 +252,8 @@ __global__ __launch_bounds__(kOwnThreads) void contrib_kernel(int32_t* __restric
                                                               const int32_t* __restrict__ boff, int64_t n,
                                                               int64_t batch, int table_bits,
                                                               int32_t* __restrict__ cidx, int4* __restrict__ rows,
-                                                              int64_t row_cap, int32_t* __restrict__ counts) {
+                                                              int64_t row_cap, int32_t* __restrict__ counts,
+                                                              int min_c) {
   extern __shared__ int32_t s_tab[];          // [part_size] keys, then [part_size] counts -> range starts
   __shared__ int32_t s_wave[3][kOwnThreads / kWave];
   __shared__ int32_t s_base[3];
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(kOwnThreads) void contrib_kernel(int32_t* __restric
   if (e0 < part_size)
     for (uint32_t e = e0; e < e0 + per; ++e) {
       const int32_t c = s_cnt[e];
-      if (c >= 2) {
+      if (c >= min_c) {
         my_c += c;
         if (c > kContribLongRow) ++my_l;
         else ++my_s;
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(kOwnThreads) void contrib_kernel(int32_t* __restric
     int4* rb = rows + b * row_cap;
     for (uint32_t e = e0; e < e0 + per; ++e) {
       const int32_t c = s_cnt[e];
-      if (c >= 2) {
+      if (c >= min_c) {
         const int4 rec = make_int4(s_key[e], at_c, c, 0);
         if (c > kContribLongRow) rb[row_cap - 1 - at_l++] = rec;
         else rb[at_s++] = rec;
@@ -422,6 +425,134 @@ __global__ __launch_bounds__(kBlock) void stage_sort_keys_kernel(const int64_t* 
     int64_t it = items[visit_index(j, perm, shuffle, half_bits, seed, n)];
     it = it < 0 ? 0 : it >= n_items ? n_items - 1 : it;   // out-of-range ids are flagged by the step, not here
     keys[j] = static_cast<K>((j / batch) * n_items + it);
+  }
+}
+
+// ---- batches beyond the staging kernel's LDS sort, grouped by positive item WITHOUT a device sort (round 5) ---------
+// What hiprec_stage_sort_keys + torch.sort (rocprim onesweep: five launches) + hiprec_gather_epoch did, as a two-level
+// counting sort in three launches of this library: (1) histogram of the batch's positive items over RANGES of
+// kStageRange consecutive item ids, (2) the occurrences scattered into their range's bucket (position inside the batch
+// + item), (3) one workgroup per (batch, range) counts the range's items in LDS, scans the 4096 counters and writes
+// every triple of the bucket to its place -- reading users / pos / neg through the visiting order (perm[], the Feistel
+// shuffle evaluated on the fly, or sequential), i.e. the gather is folded in.  Result: every batch sorted by positive
+// item (ascending; the order INSIDE a group of equal items is whatever the LDS atomics make it: a batch's loss and
+// gradients are sums over its triples).  Out-of-range items are clamped for the grouping only (the step flags them).
+constexpr int kStageRange = 4096;             // item ids per range = LDS counters of the third launch
+constexpr int kStageMaxRanges = 2048;         // n_items <= 8 M (beyond: the caller keeps the sort)
+constexpr int kStageThreads = 1024;
+
+__device__ __forceinline__ int32_t stage_item(const int64_t* __restrict__ items, int64_t i, int64_t n_items) {
+  const int64_t it = items[i];
+  return static_cast<int32_t>(it < 0 ? 0 : it >= n_items ? n_items - 1 : it);
+}
+
+// SCATTER = false: counts[b][range] += this slice's occurrences.  SCATTER = true: counts holds the batch's totals; the
+// slice reserves its part of every bucket (cursor, zero on entry) and writes (position in the batch, item).
+template <bool SCATTER>
+__global__ __launch_bounds__(kBucketThreads) void stage_range_kernel(
+    const int64_t* __restrict__ pos, const int64_t* __restrict__ perm, int shuffle, int half_bits, uint64_t seed, int64_t n,
+    int64_t batch, int64_t n_items, int n_ranges, int slices, int32_t* __restrict__ counts, int32_t* __restrict__ cursor,
+    int32_t* __restrict__ boff, int32_t* __restrict__ bitem, uint32_t* __restrict__ bidx) {
+  __shared__ int32_t s_hist[kStageMaxRanges];
+  __shared__ int32_t s_base[kStageMaxRanges];
+  const int64_t b = blockIdx.x / slices, t0 = b * batch, cnt = min<int64_t>(batch, n - t0);
+  const int64_t j0 = static_cast<int64_t>(blockIdx.x % slices) * kBucketSlice, j1 = min<int64_t>(cnt, j0 + kBucketSlice);
+  if (j0 >= cnt && !(SCATTER && blockIdx.x % slices == 0)) return;
+  for (int i = threadIdx.x; i < n_ranges; i += kBucketThreads) s_hist[i] = 0;
+  __syncthreads();
+  for (int64_t j = j0 + threadIdx.x; j < j1; j += kBucketThreads) {
+    const int32_t it = stage_item(pos, visit_index(t0 + j, perm, shuffle, half_bits, seed, n), n_items);
+    atomicAdd(&s_hist[it / kStageRange], 1);
+  }
+  __syncthreads();
+  int32_t* cb = counts + b * static_cast<int64_t>(n_ranges);
+  if constexpr (!SCATTER) {
+    for (int i = threadIdx.x; i < n_ranges; i += kBucketThreads)
+      if (s_hist[i]) atomicAdd(cb + i, s_hist[i]);
+    return;
+  } else {
+    if (threadIdx.x == 0) {
+      int32_t run = 0;
+      for (int i = 0; i < n_ranges; ++i) {
+        const int32_t c = cb[i];
+        s_base[i] = run;
+        run += c;
+      }
+      if (blockIdx.x % slices == 0) {
+        int32_t* bo = boff + b * (static_cast<int64_t>(n_ranges) + 1);
+        for (int i = 0; i < n_ranges; ++i) bo[i] = s_base[i];
+        bo[n_ranges] = run;
+      }
+    }
+    __syncthreads();
+    int32_t* cur = cursor + b * static_cast<int64_t>(n_ranges);
+    for (int i = threadIdx.x; i < n_ranges; i += kBucketThreads) {
+      const int32_t h = s_hist[i];
+      s_base[i] += h ? atomicAdd(cur + i, h) : 0;
+      s_hist[i] = 0;
+    }
+    __syncthreads();
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += kBucketThreads) {
+      const int32_t it = stage_item(pos, visit_index(t0 + j, perm, shuffle, half_bits, seed, n), n_items);
+      const int r = it / kStageRange;
+      const int at = s_base[r] + atomicAdd(&s_hist[r], 1);
+      bitem[t0 + at] = it;
+      bidx[t0 + at] = static_cast<uint32_t>(j);
+    }
+  }
+}
+
+// one workgroup per (batch, range): counting sort of the bucket by item, the triples written to their places
+__global__ __launch_bounds__(kStageThreads) void stage_place_kernel(
+    const int64_t* __restrict__ users, const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
+    const int64_t* __restrict__ perm, int shuffle, int half_bits, uint64_t seed, int64_t n, int64_t batch, int n_ranges,
+    const int32_t* __restrict__ boff, const int32_t* __restrict__ bitem, const uint32_t* __restrict__ bidx,
+    int64_t* __restrict__ ou, int64_t* __restrict__ op, int64_t* __restrict__ on) {
+  __shared__ int32_t s_cnt[kStageRange];      // occurrences per item of the range -> running cursor
+  __shared__ int32_t s_wave[kStageThreads / kWave];
+  const int64_t b = blockIdx.x / n_ranges;
+  const int r = static_cast<int>(blockIdx.x % n_ranges);
+  const int64_t t0 = b * batch;
+  const int32_t* off = boff + b * (static_cast<int64_t>(n_ranges) + 1);
+  const int lo = off[r], hi = off[r + 1];
+  if (lo == hi) return;
+  for (int i = threadIdx.x; i < kStageRange; i += kStageThreads) s_cnt[i] = 0;
+  __syncthreads();
+  const int32_t first = r * kStageRange;
+  for (int e = lo + static_cast<int>(threadIdx.x); e < hi; e += kStageThreads) atomicAdd(&s_cnt[bitem[t0 + e] - first], 1);
+  __syncthreads();
+  // exclusive scan of the 4096 counters: 4 per thread, waves, workgroup
+  constexpr int PER = kStageRange / kStageThreads;
+  const int lane = lane_id(), wv = wave_in_block();
+  int32_t c[PER], mine = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    c[k] = s_cnt[threadIdx.x * PER + k];
+    mine += c[k];
+  }
+  int32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const int32_t up = __shfl_up(incl, o);
+    if (lane >= o) incl += up;
+  }
+  if (lane == kWave - 1) s_wave[wv] = incl;
+  __syncthreads();
+  int32_t carry = 0;
+  for (int w = 0; w < wv; ++w) carry += s_wave[w];
+  int32_t run = lo + carry + incl - mine;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    s_cnt[threadIdx.x * PER + k] = run;     // where the item's group starts inside the batch
+    run += c[k];
+  }
+  __syncthreads();
+  for (int e = lo + static_cast<int>(threadIdx.x); e < hi; e += kStageThreads) {
+    const int at = atomicAdd(&s_cnt[bitem[t0 + e] - first], 1);
+    const int64_t i = visit_index(t0 + bidx[t0 + e], perm, shuffle, half_bits, seed, n);
+    ou[t0 + at] = users[i];
+    op[t0 + at] = pos[i];
+    on[t0 + at] = neg[i];
   }
 }
 
@@ -557,22 +688,25 @@ extern "C" int hiprec_batch_row_ownership_tables(const int64_t* users, const int
                         occ, stream);
 }
 
-extern "C" int64_t hiprec_contrib_row_cap(int64_t batch) { return batch > 0 ? (3 * batch + 1) / 2 : 0; }
+extern "C" int64_t hiprec_contrib_row_cap(int64_t batch, int32_t min_contrib) {
+  return batch <= 0 ? 0 : min_contrib <= 1 ? 3 * batch : (3 * batch + 1) / 2;
+}
 
 extern "C" int hiprec_batch_row_contrib(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n,
                                         int64_t batch, int64_t n_users, int64_t n_items, int32_t table_bits,
-                                        int32_t chunk, int32_t* ws, int32_t* cidx, int32_t* rows, int64_t row_cap,
-                                        int32_t* counts, void* stream) {
+                                        int32_t chunk, int32_t min_contrib, int32_t* ws, int32_t* cidx, int32_t* rows,
+                                        int64_t row_cap, int32_t* counts, void* stream) {
   HIPREC_REQUIRE(n >= 0 && batch > 0 && n_users > 0 && n_items > 0, "bad sizes");
   HIPREC_REQUIRE(chunk > 0, "chunk = the triples one wave of the step kernel takes (hiprec_mf_pull_chunk)");
+  HIPREC_REQUIRE(min_contrib == 1 || min_contrib == 2, "min_contrib: 2 = records for shared rows only, 1 = for every row");
   HIPREC_REQUIRE(n_users + n_items < (1ll << 31), "row keys need n_users + n_items < 2^31");
   HIPREC_REQUIRE(table_bits >= 2 && table_bits <= 24 && (1ll << table_bits) >= 4 * std::min<int64_t>(batch, n > 0 ? n : 1),
                  "table of 2^%d entries does not fit batches of %lld (at least 4 x the batch, at most 2^24 entries)",
                  table_bits, (long long)batch);
   HIPREC_REQUIRE(3 * batch < (1ll << 31), "batch too large for 32-bit occurrence indices");
-  HIPREC_REQUIRE(row_cap >= hiprec_contrib_row_cap(std::min<int64_t>(batch, n > 0 ? n : 1)),
-                 "row_cap %lld: a batch can share up to %lld rows", (long long)row_cap,
-                 (long long)hiprec_contrib_row_cap(batch));
+  HIPREC_REQUIRE(row_cap >= hiprec_contrib_row_cap(std::min<int64_t>(batch, n > 0 ? n : 1), min_contrib),
+                 "row_cap %lld: a batch can need %lld records", (long long)row_cap,
+                 (long long)hiprec_contrib_row_cap(batch, min_contrib));
   if (n == 0) return 0;
   HIPREC_REQUIRE(users && pos && neg && ws && cidx && rows && counts, "NULL pointer");
   const int64_t n_batches = (n + batch - 1) / batch;
@@ -603,7 +737,8 @@ extern "C" int hiprec_batch_row_contrib(const int64_t* users, const int64_t* pos
                                                                 static_cast<int>(slices), bcounts, cursor, bkey, bidx, boff,
                                                                 cidx, chunk);
   contrib_kernel<<<static_cast<int>(grid), kOwnThreads, lds, st>>>(bkey, bidx, boff, n, batch, table_bits, cidx,
-                                                                   reinterpret_cast<int4*>(rows), row_cap, counts);
+                                                                   reinterpret_cast<int4*>(rows), row_cap, counts,
+                                                                   min_contrib);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }
@@ -644,6 +779,52 @@ extern "C" int hiprec_stage_sort_keys(const int64_t* items, const int64_t* perm,
   else
     stage_sort_keys_kernel<int64_t><<<grid_for_threads(n), kBlock, 0, st>>>(items, perm, shuffle, half_bits, seed, n, batch,
                                                                             n_items, static_cast<int64_t*>(keys));
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int64_t hiprec_stage_grouped_ws_ints(int64_t n, int64_t batch, int64_t n_items) {
+  if (n <= 0 || batch <= 0 || n_items <= 0) return 0;
+  const int64_t n_ranges = (n_items + kStageRange - 1) / kStageRange;
+  if (n_ranges > kStageMaxRanges) return 0;     // not supported at this size: the caller keeps its device sort
+  const int64_t n_batches = (n + batch - 1) / batch;
+  return 2 * n + n_batches * (3 * n_ranges + 1);
+}
+
+extern "C" int hiprec_stage_epoch_grouped(const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                          const int64_t* perm, int32_t shuffle, uint64_t seed, int64_t n, int64_t batch,
+                                          int64_t n_items, int32_t* ws, int64_t* users_out, int64_t* pos_out,
+                                          int64_t* neg_out, void* stream) {
+  HIPREC_REQUIRE(n >= 0 && batch > 0 && n_items > 0, "bad sizes");
+  if (n == 0) return 0;
+  HIPREC_REQUIRE(users && pos && neg && ws && users_out && pos_out && neg_out, "NULL pointer");
+  HIPREC_REQUIRE(users_out != users && pos_out != pos && neg_out != neg, "the layout is not made in place");
+  const int64_t n_ranges = (n_items + kStageRange - 1) / kStageRange;
+  HIPREC_REQUIRE(n_ranges <= kStageMaxRanges, "n_items %lld: more than %d ranges of %d items", (long long)n_items,
+                 kStageMaxRanges, kStageRange);
+  HIPREC_REQUIRE(batch < (1ll << 31), "batch too large for 32-bit positions");
+  int half_bits = 0;
+  if (!perm && shuffle) {
+    half_bits = feistel_half_bits(static_cast<uint64_t>(n));
+    HIPREC_REQUIRE(half_bits <= 31, "n too large for the 32-bit Feistel halves");
+  }
+  const int64_t n_batches = (n + batch - 1) / batch;
+  const int64_t slices = (std::min<int64_t>(batch, n) + kBucketSlice - 1) / kBucketSlice;
+  HIPREC_REQUIRE(n_batches * slices < (1ll << 31) && n_batches * n_ranges < (1ll << 31), "too many workgroups");
+  int32_t* bitem = ws;
+  uint32_t* bidx = reinterpret_cast<uint32_t*>(ws + n);
+  int32_t* boff = ws + 2 * n;
+  int32_t* counts = boff + n_batches * (n_ranges + 1);
+  int32_t* cursor = counts + n_batches * n_ranges;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIPREC_TRY(hipMemsetAsync(counts, 0, sizeof(int32_t) * n_batches * 2 * n_ranges, st));
+  const int pre = static_cast<int>(n_batches * slices), nr = static_cast<int>(n_ranges);
+  stage_range_kernel<false><<<pre, kBucketThreads, 0, st>>>(pos, perm, shuffle, half_bits, seed, n, batch, n_items, nr,
+                                                            static_cast<int>(slices), counts, cursor, boff, bitem, bidx);
+  stage_range_kernel<true><<<pre, kBucketThreads, 0, st>>>(pos, perm, shuffle, half_bits, seed, n, batch, n_items, nr,
+                                                           static_cast<int>(slices), counts, cursor, boff, bitem, bidx);
+  stage_place_kernel<<<static_cast<int>(n_batches * n_ranges), kStageThreads, 0, st>>>(
+      users, pos, neg, perm, shuffle, half_bits, seed, n, batch, nr, boff, bitem, bidx, users_out, pos_out, neg_out);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }

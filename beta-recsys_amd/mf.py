@@ -335,24 +335,26 @@ class RowContributions(tuple):
     epoch: hiprec_batch_row_contrib's arrays for the owner-pulls step (hiprec_mf_bpr_epoch_pull)."""
 
 
-def batch_row_contributions(users, pos, neg, batch_size, n_users, n_items, dim):
+def batch_row_contributions(users, pos, neg, batch_size, n_users, n_items, dim, every_row=False):
     """For an epoch laid out in visiting order: who contributes to which row of a batch (csrc/ownership.hip,
     ``hiprec_batch_row_contrib``).  ``cidx`` -1: the row's only contribution (its contributor updates it in place);
     >= 0: the contribution's place in the step's contribution buffer; -2: a positive occurrence inside its chunk
-    neighbour's run.  ``rows`` / ``counts``: the records of the rows with several contributions."""
+    neighbour's run.  ``rows`` / ``counts``: the records of the rows with several contributions -- or, ``every_row``
+    (the lazy Adam / RMSprop form), of every row of the batch: then no cidx is -1."""
     lib = _lib.load()
     n, dev = users.numel(), users.device
     n_batches = max((n + batch_size - 1) // batch_size, 1)
     bits = lib.hiprec_ownership_table_bits(batch_size)
-    row_cap = lib.hiprec_contrib_row_cap(batch_size)
+    min_contrib = 1 if every_row else 2
+    row_cap = lib.hiprec_contrib_row_cap(batch_size, min_contrib)
     i32 = dict(dtype=torch.int32, device=dev)
     ws = torch.empty(max(lib.hiprec_ownership_ws_ints(n, batch_size, bits), 1), **i32)
     cidx = torch.empty((3, n), **i32)
     rows = torch.empty((n_batches, row_cap, 4), **i32)
-    counts = torch.zeros((n_batches, 4), **i32)
+    counts = torch.empty((n_batches, 4), **i32)      # (cleared by the call itself)
     _lib.check(lib.hiprec_batch_row_contrib(
         _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), n, batch_size, n_users, n_items, bits,
-        lib.hiprec_mf_pull_chunk(dim), _lib.ptr(ws), _lib.ptr(cidx), _lib.ptr(rows), row_cap, _lib.ptr(counts),
+        lib.hiprec_mf_pull_chunk(dim), min_contrib, _lib.ptr(ws), _lib.ptr(cidx), _lib.ptr(rows), row_cap, _lib.ptr(counts),
         _lib.stream_ptr(dev)))
     return RowContributions((cidx, rows, counts, row_cap))
 
@@ -802,9 +804,19 @@ class MFEngine(ModelEngine):
             # (group_epoch_by_item: no sort at all) measured 3 % slower per step.
             lib, n = _lib.load(), users.numel()
             n_batches = (n + bs - 1) // bs
+            shuffle = 1 if seed is not None else 0
+            ws_ints = lib.hiprec_stage_grouped_ws_ints(n, bs, self.model.n_items)
+            if ws_ints > 0 and self.config["model"].get("stage_big_batches", "grouped") == "grouped":
+                # round 5: a two-level counting sort of this library (ranges of 4096 items, then LDS counters), the
+                # gather folded in: three launches, no rocprim, no key / permutation arrays
+                ws = self._stage_ws = _lib.grow(getattr(self, "_stage_ws", None), ws_ints, torch.int32, dev)
+                ou, op, on = torch.empty_like(users), torch.empty_like(pos), torch.empty_like(neg)
+                _lib.check(lib.hiprec_stage_epoch_grouped(
+                    _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), _lib.ptr(perm), shuffle, seed or 0, n, bs,
+                    self.model.n_items, _lib.ptr(ws), _lib.ptr(ou), _lib.ptr(op), _lib.ptr(on), _lib.stream_ptr(dev)))
+                return ou, op, on, None, bs
             small = n_batches * self.model.n_items < 2**31
             keys = torch.empty(n, dtype=torch.int32 if small else torch.int64, device=dev)
-            shuffle = 1 if seed is not None else 0
             _lib.check(lib.hiprec_stage_sort_keys(_lib.ptr(pos), _lib.ptr(perm), shuffle, seed or 0, n, bs,
                                                   self.model.n_items, 4 if small else 8, _lib.ptr(keys),
                                                   _lib.stream_ptr(dev)))
@@ -954,9 +966,13 @@ class MFEngine(ModelEngine):
         prepared = PreparedEpoch(staged)
         users, pos, neg, perm, bs = prepared
         if owned and perm is None and users.device.type == "cuda":
-            if self._sgd_modes()[1] and self._owned_form() == "pull" and self.model.n_users + self.model.n_items < 2**31:
+            small_keys = self.model.n_users + self.model.n_items < 2**31
+            if self._sgd_modes()[1] and self._owned_form() == "pull" and small_keys:
                 prepared.own = batch_row_contributions(users, pos, neg, bs, self.model.n_users, self.model.n_items,
                                                        self.model.emb_dim)
+            elif self._lazy_owned() == "pull" and small_keys:
+                prepared.own = batch_row_contributions(users, pos, neg, bs, self.model.n_users, self.model.n_items,
+                                                       self.model.emb_dim, every_row=True)
             else:
                 prepared.own = batch_row_ownership(users, pos, neg, bs, self.model.n_users, self.model.n_items)
         return prepared
@@ -968,16 +984,23 @@ class MFEngine(ModelEngine):
         return "atomic" if self.config["model"].get("sgd_mode", "auto") == "owned_atomic" else "pull"
 
     def _lazy_owned(self):
-        """Lazy Adam / RMSprop epochs (BPR) take their gradients from the owned-rows kernel (csrc/mf_owned.hip: complete
-        row gradients, plain stores for rows with a single writer) instead of mf_bpr_grad_kernel's atomics; the staged
-        epoch then carries the row-ownership arrays.  ``lazy_grad``: "owned" (default) | "atomic"."""
+        """How lazy Adam / RMSprop epochs (BPR) take their gradients -- ``lazy_grad``: "pull" (default, round 5: the
+        owner-pulls step of csrc/lazy_opt.hip -- every row's gradient parts through the contribution buffer, ONE launch
+        sums, replays the moments and steps a row; dim % 4 == 0, else "owned"), "owned" (round 4: the owned-rows
+        kernel writes complete row gradients into the dense buffer, atomics where waves share a row, + the update
+        launch) or "atomic" (mf_bpr_grad_kernel's atomics + the update launch).  Returns "pull" / "owned" (truthy: the
+        staged epoch carries the matching staging arrays) or False."""
         if self.model.flat.device.type != "cuda" or self.optimizer.name == "sgd":
             return False
         self._setup()
-        mode = self.config["model"].get("lazy_grad", "owned")
-        if mode not in ("owned", "atomic"):
-            raise ValueError(f"lazy_grad must be 'owned' or 'atomic', not {mode!r}")
-        return self._lazy is not None and mode == "owned" and self.loss == "bpr"
+        mode = self.config["model"].get("lazy_grad", "pull")
+        if mode not in ("pull", "owned", "atomic"):
+            raise ValueError(f"lazy_grad must be 'pull', 'owned' or 'atomic', not {mode!r}")
+        if self._lazy is None or mode == "atomic" or self.loss != "bpr":
+            return False
+        if mode == "pull" and self.model.emb_dim % 4 == 0:
+            return "pull"
+        return "owned"
 
     def _fused_ok(self, perm):
         """Cache-sized tables take the one-kernel-per-step epoch driver (any of the three optimizers)."""
@@ -1088,7 +1111,28 @@ class MFEngine(ModelEngine):
         w, g = m.tables(), m.tables(self._g_flat)
         el = third.element_size()
         lz["dirty"] = True
-        if own is not None and self.loss == "bpr" and self._lazy_owned():
+        if isinstance(own, RowContributions) and self.loss == "bpr" and self._lazy_owned() == "pull":
+            cidx, rows, counts, row_cap = own
+            n_all = cidx.shape[1]
+            cap = 3 * min(bs, max(n_all, 1))
+            pb = getattr(self, "_pull_bufs", None)
+            if pb is None or pb["dev"] != m.flat.device or pb["cap"] < cap:
+                pb = self._pull_bufs = {
+                    "dev": m.flat.device, "cap": cap,
+                    "cbuf": torch.empty(cap * m.emb_dim, dtype=torch.float32, device=m.flat.device),
+                    "cbias": torch.empty(cap, dtype=torch.float32, device=m.flat.device),
+                    "scratch": torch.zeros_like(self._scratch)}
+            _lib.check(lib.hiprec_mf_epoch_lazy_pull(
+                ctypes.byref(lz["c"]), ctypes.c_void_p(users.data_ptr() + 8 * lo),
+                ctypes.c_void_p(items_a.data_ptr() + 8 * lo), ctypes.c_void_p(third.data_ptr() + 8 * lo),
+                ctypes.c_void_p(cidx.data_ptr() + 4 * lo), n_all, ctypes.c_void_p(rows.data_ptr() + 16 * a * row_cap),
+                row_cap, ctypes.c_void_p(counts.data_ptr() + 16 * a), _lib.ptr(pb["cbuf"]), _lib.ptr(pb["cbias"]),
+                hi - lo, bs, 1 if a == 0 else 0, float(self.reg), _lib.ptr(self._stats), _lib.ptr(self._scratch),
+                _lib.stream_ptr(m.flat.device)))
+            if b == n_steps:
+                self.flush_lazy()
+            return
+        if own is not None and not isinstance(own, RowContributions) and self.loss == "bpr" and self._lazy_owned():
             # the owned-rows gradient kernel: the epoch's ownership arrays, sliced like the triples
             o, total, stride = own
             _lib.check(lib.hiprec_mf_epoch_lazy_owned(

@@ -335,6 +335,19 @@ int hiprec_batch_row_ownership(const int64_t* users, const int64_t* pos, const i
                                int64_t batch, int64_t n_users, int64_t n_items, int32_t table_bits,
                                int32_t* ws, int32_t* total, int32_t* own, void* stream);
 
+/* ---- round 5: batches beyond hiprec_stage_epoch's LDS sort (configs[3]: 65 536 triples), staged WITHOUT a device sort
+ * (csrc/ownership.hip).  What hiprec_stage_sort_keys + a radix sort + hiprec_gather_epoch produced -- the epoch in
+ * visiting order (perm[] | the Feistel shuffle of `seed`, evaluated on the fly | sequential), every batch sorted by
+ * positive item -- as a two-level counting sort in three launches: ranges of 4096 item ids, then the items of a range
+ * counted in LDS; the gather of the three arrays is folded into the last launch.  The order inside a group of equal
+ * items is unspecified.  ws: hiprec_stage_grouped_ws_ints(n, batch, n_items) int32s (0 = n_items beyond 8 M: not
+ * supported, keep the sort).  Replaces, like hiprec_stage_epoch, DataLoader(shuffle=True)'s batching
+ * (beta_rec/data/base_data.py:247-253). */
+int64_t hiprec_stage_grouped_ws_ints(int64_t n, int64_t batch, int64_t n_items);
+int hiprec_stage_epoch_grouped(const int64_t* users, const int64_t* pos, const int64_t* neg, const int64_t* perm,
+                               int32_t shuffle, uint64_t seed, int64_t n, int64_t batch, int64_t n_items, int32_t* ws,
+                               int64_t* users_out, int64_t* pos_out, int64_t* neg_out, void* stream);
+
 /* ---- round 5: the same step as OWNER PULLS -- two launches per step, no float atomics (csrc/mf_owned.hip,
  * csrc/ownership.hip).  Replaces, like hiprec_mf_bpr_epoch_owned, loss.backward() + torch.optim.SGD.step() of
  * beta_rec/models/mf.py:101-118 and models/torch_engine.py:25-29 for tables beyond the caches.
@@ -345,8 +358,10 @@ int hiprec_batch_row_ownership(const int64_t* users, const int64_t* pos, const i
  * this one contribution (its contributor stores w - lr * g in place), >= 0 = where the contribution goes in the
  * step's contribution buffer, -2 = a positive occurrence that rides in its neighbour's run; rows[n_batches][row_cap]
  * records {row key (user row, or n_users + item row), first contribution, contributions, 0} of the rows with several
- * (row_cap >= hiprec_contrib_row_cap(batch); rows with more than 32 contributions are listed from the END of a
- * batch's records); counts[n_batches][4] = {records from the front, records from the end, contributions, -}.  ws:
+ * (row_cap >= hiprec_contrib_row_cap(batch, min_contrib); rows with more than 32 contributions are listed from the
+ * END of a batch's records); counts[n_batches][4] = {records from the front, records from the end, contributions, -}.
+ * min_contrib = 2: as described; 1: every row gets a record and a range, cidx is never -1 (the lazy Adam / RMSprop
+ * form hiprec_mf_epoch_lazy_pull: a row's optimizer step is taken by the apply launch).  ws:
  * hiprec_ownership_ws_ints(n, batch, table_bits) int32s.
  * hiprec_mf_bpr_epoch_pull: per step the gradient launch (rows with one contribution updated in place, the others'
  * parts stored to cbuf [3 * batch, dim] / cbias [3 * batch]: work space, never initialised or cleared; cidx_stride =
@@ -355,10 +370,10 @@ int hiprec_batch_row_ownership(const int64_t* users, const int64_t* pos, const i
  * the scalar bias and the clock).  Every step is complete when its second launch is.  Same semantics as
  * hiprec_mf_bpr_epoch_owned; the order in which a row's contributions are summed is the order of the range. */
 int32_t hiprec_mf_pull_chunk(int32_t dim);
-int64_t hiprec_contrib_row_cap(int64_t batch);
+int64_t hiprec_contrib_row_cap(int64_t batch, int32_t min_contrib);
 int hiprec_batch_row_contrib(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n, int64_t batch,
-                             int64_t n_users, int64_t n_items, int32_t table_bits, int32_t chunk, int32_t* ws,
-                             int32_t* cidx, int32_t* rows, int64_t row_cap, int32_t* counts, void* stream);
+                             int64_t n_users, int64_t n_items, int32_t table_bits, int32_t chunk, int32_t min_contrib,
+                             int32_t* ws, int32_t* cidx, int32_t* rows, int64_t row_cap, int32_t* counts, void* stream);
 int hiprec_mf_bpr_epoch_pull(float* w_flat, int64_t n_users, int64_t n_items, int32_t dim, const int64_t* users,
                              const int64_t* pos, const int64_t* neg, const int32_t* cidx, int64_t cidx_stride,
                              const int32_t* rows, int64_t row_cap, const int32_t* counts, float* cbuf, float* cbias,
@@ -648,6 +663,20 @@ int hiprec_mf_epoch_lazy_owned(const hiprec_lazy_state* state, const int64_t* us
                                const int64_t* neg, const int32_t* own_u, const int32_t* own_p, const int32_t* own_n,
                                const int32_t* total, int64_t total_stride, int64_t n, int64_t batch,
                                int32_t first_of_epoch, float reg_coef, hiprec_stats* stats, void* scratch, void* stream);
+
+/* Round 5: the same epoch as OWNER PULLS (csrc/lazy_opt.hip, csrc/mf_owned.hip) -- per step catch-up -> gradient launch
+ * (the parts of EVERY row's gradient stored to the contribution buffer with plain stores; counts the step) -> one
+ * apply launch: a lane group per row sums the row's parts, replays the moments over the steps the row lagged, takes
+ * the real Adam / RMSprop step and stamps the row.  No dense gradient traffic, no float atomics, no claims.  cidx /
+ * rows / counts: hiprec_batch_row_contrib's arrays made with min_contrib = 1, offset to this piece's first step
+ * (cidx_stride = the n they were made for); cbuf [3 * batch, dim], cbias [3 * batch]: work space.  BPR, dim % 4 == 0.
+ * Same semantics as hiprec_mf_epoch_lazy_owned (beta_rec/models/mf.py:121-139 with torch.optim.Adam / RMSprop,
+ * models/torch_engine.py:30-39); the caller flushes afterwards. */
+int hiprec_mf_epoch_lazy_pull(const hiprec_lazy_state* state, const int64_t* users, const int64_t* pos,
+                              const int64_t* neg, const int32_t* cidx, int64_t cidx_stride, const int32_t* rows,
+                              int64_t row_cap, const int32_t* counts, float* cbuf, float* cbias, int64_t n,
+                              int64_t batch, int32_t first_of_epoch, float reg_coef, hiprec_stats* stats, void* scratch,
+                              void* stream);
 
 /* ---- ONE launch of that sequence, with the buffers of this step named explicitly: for callers that
  *      have to do something between two steps -- the data-parallel engine all-reduces

@@ -367,7 +367,7 @@ def mf_lazy_run(optimizer, lr, loss, dense_opt, pieces=None, single_between=Fals
     load_weights(eng, w0)
     eng._setup()
     assert (eng._lazy is not None) == (dense_opt == "lazy")
-    assert eng._lazy_owned() == (dense_opt == "lazy" and loss == "bpr" and lazy_grad == "owned")
+    assert eng._lazy_owned() == (lazy_grad if dense_opt == "lazy" and loss == "bpr" and lazy_grad != "atomic" else False)
     if loss == "bpr":
         loader = hp.DeviceTripleBatcher(*(torch.from_numpy(a).cuda() for a in (users, pos, third)), B, shuffle=False)
     else:
@@ -397,11 +397,14 @@ def mf_lazy_run(optimizer, lr, loss, dense_opt, pieces=None, single_between=Fals
 
 
 @pytest.mark.parametrize("optimizer,lr,loss,lazy_grad,reg", [
+    ("adam", 0.05, "bpr", "pull", None), ("rmsprop", 0.01, "bpr", "pull", None), ("adam", 0.05, "bpr", "pull", 0.02),
     ("adam", 0.05, "bpr", "owned", None), ("adam", 0.05, "bpr", "atomic", None), ("rmsprop", 0.01, "bpr", "owned", None),
     ("rmsprop", 0.01, "bpr", "atomic", None), ("adam", 0.02, "bce", "owned", None), ("adam", 0.05, "bpr", "owned", 0.02)])
 def test_mf_engine_epochs_with_the_lazy_optimizer(hip_device, optimizer, lr, loss, lazy_grad, reg):
-    """MFEngine.train_an_epoch with ``dense_opt: "lazy"`` (hiprec_mf_epoch_lazy / _lazy_owned: catch-up, gradient kernel
-    -- the owned-rows kernel or mf_bpr_grad_kernel's atomics --, update per step, flush at the end of the epoch): epoch
+    """MFEngine.train_an_epoch with ``dense_opt: "lazy"`` (hiprec_mf_epoch_lazy_pull: catch-up, gradient launch into the
+    contribution buffer, ONE launch that sums / replays the moments / steps every row of the batch; or
+    hiprec_mf_epoch_lazy / _lazy_owned: catch-up, gradient kernel -- the owned-rows kernel or mf_bpr_grad_kernel's
+    atomics --, update per step; flush at the end of the epoch): epoch
     sums to 1e-5 of the oracle's, every weight on the oracle's trajectory, never-drawn users bit-identical with stamp
     -1, the gradient buffer clean -- like the dense-sweep engine."""
     eng, w0, visited, sums, got = mf_lazy_run(optimizer, lr, loss, "lazy", lazy_grad=lazy_grad, reg=reg)
@@ -420,6 +423,46 @@ def test_mf_engine_epochs_with_the_lazy_optimizer(hip_device, optimizer, lr, los
     assert float(eng._g_flat.abs().max()) == 0.0 and not eng._lazy["dirty"]
     su = eng._lazy["stamp_u"].cpu().numpy()
     assert (su[1::2] == -1).all() and np.array_equal(got["user_emb.weight"][1::2], w0["user_emb.weight"][1::2])
+
+
+@pytest.mark.parametrize("optimizer,lr,D", [("adam", 0.05, 64), ("rmsprop", 0.01, 128), ("adam", 0.05, 256)])
+def test_lazy_pull_step_is_the_three_launch_step_bit_for_bit_where_no_row_repeats(hip_device, optimizer, lr, D):
+    """Batches in which no row occurs twice: every gradient element is ONE term, so the owner-pulls form (gradient parts
+    through the contribution buffer + lazy_pull_apply_kernel) and the round-4 form (complete row gradients into the
+    dense buffer + the update launch) must leave the same BITS -- weights, both moments, stamps -- including rows that
+    lag several steps between two visits (their moments are replayed by the apply launch / the update launch)."""
+    import beta_recsys_amd as hp
+    from test_mf_gpu import load_weights, make_engine
+
+    U, I, B, steps = 1500, 1200, 128, 4
+    rng = np.random.default_rng(D)
+    w0 = onp.init_params(U, I, D, seed=2)
+    epochs = []
+    for _ in range(3):
+        us, ps, ns = [], [], []
+        for _ in range(steps):
+            us.append(rng.permutation(U // 2)[:B] * 2)          # few users: rows come back after a gap of a few steps
+            items = rng.permutation(I)[: 2 * B]
+            ps.append(items[:B])
+            ns.append(items[B:])
+        epochs.append(tuple(torch.from_numpy(np.concatenate(a).astype(np.int64)).cuda() for a in (us, ps, ns)))
+    out = {}
+    for form in ("pull", "owned"):
+        eng = make_engine(U, I, D, optimizer, "bpr", lr, B, dense_opt="lazy", lazy_grad=form, prefetch_epoch=False)
+        load_weights(eng, w0)
+        eng._setup()
+        assert eng._lazy_owned() == form
+        with contextlib.redirect_stdout(io.StringIO()):
+            for e, triples in enumerate(epochs):
+                eng.train_an_epoch(hp.DeviceTripleBatcher(*triples, B, shuffle=False), e)
+        opt = eng.optimizer
+        out[form] = (eng.model.flat.clone(), opt.exp_avg_sq.clone(), None if opt.exp_avg is None else opt.exp_avg.clone(),
+                     eng._lazy["stamp_u"].clone(), eng._lazy["stamp_i"].clone(), eng.epoch_stats().loss_sum)
+        assert float(eng._g_flat.abs().max()) == 0.0
+    for name, a, b in zip(("w", "v", "m", "stamp_u", "stamp_i"), out["pull"], out["owned"]):
+        if a is not None:
+            assert torch.equal(a, b), f"{name}: {int((a != b).sum())} elements differ between the two forms"
+    assert out["pull"][5] == pytest.approx(out["owned"][5], rel=1e-6)
 
 
 def test_mf_engine_lazy_epoch_in_pieces_and_around_a_dense_step(hip_device):

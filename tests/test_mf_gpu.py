@@ -1106,7 +1106,7 @@ def test_batch_row_ownership_kernel(hip_device, n, bs, U, I):
         _brute_force_ownership_check(users, pos, neg, bs, U, I, own.cpu().numpy(), total.cpu().numpy())
 
 
-def _check_row_contributions(users, pos, neg, bs, U, I, chunk, cidx, rows, counts, row_cap, long_row=32):
+def _check_row_contributions(users, pos, neg, bs, U, I, chunk, cidx, rows, counts, row_cap, long_row=32, min_c=2):
     """hiprec_batch_row_contrib's contract, batch by batch (numpy)."""
     n = len(users)
     for b in range((n + bs - 1) // bs):
@@ -1123,21 +1123,21 @@ def _check_row_contributions(users, pos, neg, bs, U, I, chunk, cidx, rows, count
         keys = np.concatenate([u[ok], U + p[ok & head], U + q[ok]])
         where = np.concatenate([c[0, ok], c[1, ok & head], c[2, ok]])
         uniq, inv, cnt = np.unique(keys, return_inverse=True, return_counts=True)
-        shared = cnt[inv] > 1
+        shared = cnt[inv] >= min_c
         assert np.all(where[~shared] == -1), "a row with one contribution is updated by its contributor"
         n_short, n_long, n_contrib = (int(x) for x in counts[b, :3])
-        assert n_contrib == int(shared.sum()) and n_short + n_long == int((cnt > 1).sum()) <= row_cap
+        assert n_contrib == int(shared.sum()) and n_short + n_long == int((cnt >= min_c).sum()) <= row_cap
         recs = np.concatenate([rows[b, :n_short], rows[b, row_cap - n_long:][::-1]]) if n_short + n_long else np.zeros((0, 4), np.int64)
         assert np.all(recs[:n_short, 2] <= long_row) and np.all(recs[n_short:, 2] > long_row)
         order = np.argsort(recs[:, 0])
         recs = recs[order]
-        assert np.array_equal(recs[:, 0], uniq[cnt > 1]) and np.array_equal(recs[:, 2], cnt[cnt > 1])
+        assert np.array_equal(recs[:, 0], uniq[cnt >= min_c]) and np.array_equal(recs[:, 2], cnt[cnt >= min_c])
         # the ranges tile [0, n_contrib) and every contribution of a row has a place of its own inside the row's range
         by_start = recs[np.argsort(recs[:, 1])]
         assert np.array_equal(by_start[:, 1], np.concatenate([[0], np.cumsum(by_start[:, 2])[:-1]]))
         assert np.array_equal(np.sort(where[shared]), np.arange(n_contrib))
         start_of = np.full(len(uniq), -1, dtype=np.int64)
-        start_of[cnt > 1] = recs[:, 1]
+        start_of[cnt >= min_c] = recs[:, 1]
         s0 = start_of[inv[shared]]
         assert np.all((where[shared] >= s0) & (where[shared] < s0 + cnt[inv[shared]]))
 
@@ -1164,6 +1164,48 @@ def test_batch_row_contrib_kernel(hip_device, n, bs, U, I, D):
     cidx, rows, counts, row_cap = batch_row_contributions(tu, tp, tn, bs, U, I, D)
     _check_row_contributions(users, pos, neg, bs, U, I, chunk, cidx.cpu().numpy(), rows.cpu().numpy().astype(np.int64),
                              counts.cpu().numpy(), row_cap)
+    # the lazy Adam / RMSprop form: every row of a batch has a record, no contribution is applied in place
+    cidx, rows, counts, row_cap = batch_row_contributions(tu, tp, tn, bs, U, I, D, every_row=True)
+    assert row_cap == 3 * bs
+    _check_row_contributions(users, pos, neg, bs, U, I, chunk, cidx.cpu().numpy(), rows.cpu().numpy().astype(np.int64),
+                             counts.cpu().numpy(), row_cap, min_c=1)
+
+
+@pytest.mark.parametrize("n,bs,I,order", [(3 * 9000 + 77, 9000, 50, "perm"), (2 * 65536, 65536, 125_000, "seed"),
+                                          (65536 + 5, 65536, 1_000_000, "seq"), (20_000, 16384, 5000, "seed")])
+def test_stage_epoch_grouped_kernel(hip_device, n, bs, I, order):
+    """hiprec_stage_epoch_grouped (csrc/ownership.hip; batches beyond the LDS sort): every batch holds exactly the triples
+    its slice of the visiting order names (perm[] / the Feistel shuffle of a seed / sequential) and is sorted by positive
+    item -- what hiprec_stage_sort_keys + a device sort + hiprec_gather_epoch produced, without the sort.  Out-of-range
+    items are grouped at the ends (the step flags them)."""
+    from beta_recsys_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(n)
+    users, pos, neg = _zipf_triples(rng, n, 1000, I, hot=0.2)
+    pos[5], pos[n - 3] = -4, I + 7
+    tu, tp, tn = (torch.from_numpy(a).cuda() for a in (users, pos, neg))
+    perm = torch.from_numpy(rng.permutation(n)).cuda() if order == "perm" else None
+    shuffle, seed = (1, 12345) if order == "seed" else (0, 0)
+    st = _lib.stream_ptr(hip_device)
+    want = [torch.empty_like(t) for t in (tu, tp, tn)]
+    _lib.check(lib.hiprec_gather_epoch(_lib.ptr(tu), _lib.ptr(tp), _lib.ptr(tn), _lib.ptr(perm), shuffle, seed, None, n,
+                                       *(_lib.ptr(t) for t in want), st))
+    ws = torch.empty(lib.hiprec_stage_grouped_ws_ints(n, bs, I), dtype=torch.int32, device=hip_device)
+    assert ws.numel() > 0
+    got = [torch.empty_like(t) for t in (tu, tp, tn)]
+    _lib.check(lib.hiprec_stage_epoch_grouped(_lib.ptr(tu), _lib.ptr(tp), _lib.ptr(tn), _lib.ptr(perm), shuffle, seed, n,
+                                              bs, I, _lib.ptr(ws), *(_lib.ptr(t) for t in got), st))
+    gu, gp, gn = (t.cpu().numpy() for t in got)
+    wu, wp, wn = (t.cpu().numpy() for t in want)
+    for k in range(0, n, bs):
+        sl = slice(k, min(n, k + bs))
+        key = np.clip(gp[sl], 0, I - 1)
+        assert np.all(np.diff(key) >= 0), "a batch is not sorted by positive item"
+        a = np.stack([gu[sl], gp[sl], gn[sl]], 1)
+        b = np.stack([wu[sl], wp[sl], wn[sl]], 1)
+        assert np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])]), "a batch lost or gained a triple"
+    assert lib.hiprec_stage_grouped_ws_ints(n, bs, 9_000_000) == 0      # beyond 8 M items: the caller keeps its sort
 
 
 def test_golden_suite_against_the_ieee_arithmetic_build(hip_device):
