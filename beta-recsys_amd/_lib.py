@@ -225,6 +225,7 @@ SIGNATURES = {
     "hiprec_shard_join_rows": (c_int, [_P, _P, c_int64, c_int32, _P, _P]),
     "hiprec_scatter_add_rows": (c_int, [_P, c_int64, c_int32, _P, _P, c_int64, c_int64, _P, _P]),
     "hiprec_mf_predict": (c_int, [_T, _P, _P, c_int64, _P, _P, _P]),
+    "hiprec_mf_forward": (c_int, [_T, _P, _P, c_int64, _P, _P, _P, _P]),
     "hiprec_mf_bpr_grad": (
         c_int,
         [_T, _T, _P, _P, _P, _P, c_int64, c_float, c_float, _P, _P, c_size_t, _P],

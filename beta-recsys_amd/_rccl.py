@@ -48,6 +48,13 @@ def _load():
             for name in ("ncclSend", "ncclRecv", "ncclGroupStart", "ncclGroupEnd"):
                 if hasattr(lib, name):
                     getattr(lib, name).restype = ctypes.c_int
+            # the watchdog's two calls (optional as well)
+            if hasattr(lib, "ncclCommGetAsyncError"):
+                lib.ncclCommGetAsyncError.restype = ctypes.c_int
+                lib.ncclCommGetAsyncError.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+            if hasattr(lib, "ncclCommAbort"):
+                lib.ncclCommAbort.restype = ctypes.c_int
+                lib.ncclCommAbort.argtypes = [ctypes.c_void_p]
             _lib = lib
             return lib
         except (OSError, AttributeError):
@@ -77,6 +84,42 @@ class Communicator:
                                      torch.cuda.current_stream(tensor.device).cuda_stream)
         if rc != 0:
             raise RuntimeError(f"ncclAllReduce failed with code {rc}")
+
+    def async_error(self):
+        """ncclCommGetAsyncError: 0 (ncclSuccess) while the communicator is healthy, None when this librccl does not
+        export it.  ncclInProgress (7) is not an error."""
+        if not self.comm or not hasattr(self._lib, "ncclCommGetAsyncError"):
+            return None
+        code = ctypes.c_int(0)
+        rc = self._lib.ncclCommGetAsyncError(self.comm, ctypes.byref(code))
+        return rc if rc != 0 else code.value
+
+    def wait(self, stream, timeout_s=300.0, what="the enqueued exchanges"):
+        """Host-side wait for `stream` that cannot hang for ever: the steps' exchanges are posted from C (grouped
+        ncclSend / ncclRecv) long before anybody reads a result, and a peer that posts a different size -- or none --
+        leaves the matching kernel spinning.  Polls the stream, asks the communicator for asynchronous errors, and after
+        `timeout_s` aborts the communicator (ncclCommAbort releases the spinning kernels) and raises instead of
+        blocking in a synchronize (the loopback tests time out, real RCCL would have hung)."""
+        import time
+
+        t0 = time.monotonic()
+        pause = 1e-5
+        while not stream.query():
+            err = self.async_error()
+            if err not in (None, 0, 7):
+                self.abort()
+                raise RuntimeError(f"RCCL reported asynchronous error {err} while waiting for {what}")
+            if time.monotonic() - t0 > timeout_s:
+                self.abort()
+                raise RuntimeError(f"{what} did not complete within {timeout_s:.0f} s on rank {self.rank} of {self.world} "
+                                   "(a peer posted a different exchange, or none): the communicator was aborted")
+            time.sleep(pause)
+            pause = min(pause * 2, 1e-3)
+
+    def abort(self):
+        if self.comm and hasattr(self._lib, "ncclCommAbort"):
+            self._lib.ncclCommAbort(self.comm)
+            self.comm = None
 
     def destroy(self):
         if self.comm:

@@ -702,11 +702,13 @@ __global__ __launch_bounds__(kAggBlock) void mf_bce_grad_kernel(
 }
 
 // scores[k] = sigmoid(<U[u], I[i]> + bu + bi + g)   (MF.predict, mf.py:57-70)
+// sq (optional): sq[k] = |U[u]|^2 + |I[i]|^2 + bu^2 + bi^2, the sample's share of MF.forward's regularizer
+// (mf.py:46-53) -- the rows are in registers for the dot product anyway.
 __global__ __launch_bounds__(kBlock) void mf_predict_kernel(hiprec_mf_tables w,
                                                             const int64_t* __restrict__ users,
                                                             const int64_t* __restrict__ items,
                                                             int64_t n, float* __restrict__ scores,
-                                                            hiprec_stats* stats) {
+                                                            float* __restrict__ sq, hiprec_stats* stats) {
   const int lane = lane_id();
   const int D = w.dim;
   const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
@@ -721,15 +723,25 @@ __global__ __launch_bounds__(kBlock) void mf_predict_kernel(hiprec_mf_tables w,
         atomicOr(&stats->status,
                  (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
         scores[t] = __builtin_nanf("");
+        if (sq) sq[t] = 0.f;
       }
       continue;
     }
     const float* ur = w.user_emb + u * D;
     const float* ir = w.item_emb + i * D;
-    float dot = 0.f;
-    for (int c = lane; c < D; c += kWave) dot += ur[c] * ir[c];
+    float dot = 0.f, ss = 0.f;
+    for (int c = lane; c < D; c += kWave) {
+      const float a = ur[c], b = ir[c];
+      dot += a * b;
+      ss += a * a + b * b;
+    }
     dot = wave_sum(dot);
-    if (lane == 0) scores[t] = sigmoid_f32(((dot + w.user_bias[u]) + w.item_bias[i]) + gb);
+    if (sq) ss = wave_sum(ss);
+    if (lane == 0) {
+      const float bu = w.user_bias[u], bi = w.item_bias[i];
+      scores[t] = sigmoid_f32(((dot + bu) + bi) + gb);
+      if (sq) sq[t] = (ss + bu * bu) + bi * bi;
+    }
   }
 }
 
@@ -955,7 +967,19 @@ extern "C" int hiprec_mf_predict(const hiprec_mf_tables* w, const int64_t* users
   if (n == 0) return 0;
   HIPREC_REQUIRE(users && items && scores && stats, "NULL pointer");
   mf_predict_kernel<<<grid_for_waves(n), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
-      *w, users, items, n, scores, stats);
+      *w, users, items, n, scores, nullptr, stats);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hiprec_mf_forward(const hiprec_mf_tables* w, const int64_t* users, const int64_t* items, int64_t n,
+                                 float* scores, float* sq, hiprec_stats* stats, void* stream) {
+  if (int rc = check_tables(w, "w")) return rc;
+  HIPREC_REQUIRE(n >= 0, "negative n");
+  if (n == 0) return 0;
+  HIPREC_REQUIRE(users && items && scores && sq && stats, "NULL pointer");
+  mf_predict_kernel<<<grid_for_waves(n), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      *w, users, items, n, scores, sq, stats);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }

@@ -248,13 +248,16 @@ class MF(nn.Module):
         dev = self._flat.device
         users = torch.as_tensor(users, dtype=torch.int64, device=dev).contiguous()
         items = torch.as_tensor(items, dtype=torch.int64, device=dev).contiguous()
-        scores = self._scores(users, items)
-        u, i = self.user_emb(users), self.item_emb(items)
-        bu, bi = self.user_bias(users), self.item_bias(items)
-        regularizer = ((u ** 2).sum() + (i ** 2).sum() + (bu ** 2).sum() + (bi ** 2).sum()) / max(
-            users.numel(), 1
-        )
-        return scores, regularizer
+        # one launch: the rows are in registers for the dot product, their squared norms ride along (round 4 gathered the
+        # four tensors again and reduced each with torch)
+        lib, n = self._require_hip(), users.numel()
+        if items.numel() != n:
+            raise ValueError("users and items must have the same length")
+        scores, sq = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+        tabs = self.tables()
+        _lib.check(lib.hiprec_mf_forward(ctypes.byref(tabs), _lib.ptr(users), _lib.ptr(items), n, _lib.ptr(scores),
+                                         _lib.ptr(sq), _lib.ptr(self._stats), _lib.stream_ptr(dev)))
+        return scores, sq.sum() / max(n, 1)
 
     def _scores(self, users, items):
         lib = self._require_hip()

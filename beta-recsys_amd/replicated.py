@@ -231,6 +231,10 @@ class ReplicatedMFEngine(MFEngine):
 
     def _sync_stats(self):
         """Global (all-reduced) loss / reg of the last step replace the local shares in stats."""
+        comm = getattr(self, "_direct_comm", None)
+        if comm is not None and hasattr(comm, "wait"):   # the C driver's ncclAllReduce calls: a bounded wait (_rccl.py)
+            comm.wait(torch.cuda.current_stream(self.model.flat.device),
+                      float(self.config["model"].get("collective_timeout_s", 300.0)), "the epoch's all-reduces")
         st = super()._sync_stats()
         if not getattr(self, "_stats_are_global", False):
             loss, reg = (float(x) for x in self._tail.cpu())

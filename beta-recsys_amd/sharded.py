@@ -357,7 +357,18 @@ class HipKernels:
             _lib.ptr(opt.exp_avg_sq), flat_w.numel(), opt.lr, opt.beta1, opt.beta2, opt.eps,
             _lib.ptr(self.stats), None, -1, self._st()))
 
+    comm_watch = None       # (communicator, timeout in seconds): set by the engine whose C driver posts exchanges
+
+    def wait_exchanges(self):
+        """Before the host blocks on anything the steps produced: a wait that cannot hang for ever (``_rccl.Communicator
+        .wait``: polls the stream and the communicator's asynchronous error, aborts it after the timeout)."""
+        if self.comm_watch is not None:
+            comm, timeout = self.comm_watch
+            if comm is not None and hasattr(comm, "wait"):
+                comm.wait(torch.cuda.current_stream(self.device), timeout, "the planned steps' exchanges")
+
     def check_status(self):
+        self.wait_exchanges()
         st = read_stats(self.stats)
         if st.status:
             clear_status(self.stats)
@@ -896,6 +907,7 @@ class ShardedMFEngine:
             ok = comm is not None and comm.has_send_recv()
             if _rccl.all_ranks_agree(ok, self.pg, self.device):
                 self._comm = comm
+                self.k.comm_watch = (comm, float(self.config["model"].get("collective_timeout_s", 300.0)))
             else:
                 want_c = False
                 if comm is not None:

@@ -150,6 +150,10 @@ int hiprec_scatter_add_rows(float* table, int64_t n_rows, int32_t dim, const int
  *      scores[k] = sigmoid(<U[u_k], I[i_k]> + bu[u_k] + bi[i_k] + g) */
 int hiprec_mf_predict(const hiprec_mf_tables* w, const int64_t* users, const int64_t* items,
                       int64_t n, float* scores, hiprec_stats* stats, void* stream);
+/* MF.forward (beta_rec/models/mf.py:32-55) in one launch: the scores of hiprec_mf_predict and, per sample, sq[k] =
+ * |U[u]|^2 + |I[i]|^2 + bu^2 + bi^2 -- the regularizer is sum(sq) / n (the reference squares four gathered tensors). */
+int hiprec_mf_forward(const hiprec_mf_tables* w, const int64_t* users, const int64_t* items, int64_t n, float* scores,
+                      float* sq, hiprec_stats* stats, void* stream);
 
 /* ---- MF BPR forward + backward (mf.py:101-107,116-117; torch_engine.py:104-105).
  * Accumulates the DENSE gradient of the batch-mean BPR loss into `g` (same layout as `w`; the

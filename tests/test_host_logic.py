@@ -1053,3 +1053,47 @@ def test_lazy_scalars_table_has_its_converged_tail_and_refuses_slow_betas():
     with pytest.raises(ValueError, match="converged"):
         _lib.lazy_scalars_table(adam, "cpu")
     assert _lib.lazy_scalars_table(HipOptimizer("rmsprop", 0.01), "cpu").abs().sum() == 0
+
+
+def test_rccl_watchdog_wait_is_bounded_and_reports_asynchronous_errors():
+    """_rccl.Communicator.wait: the host never blocks for ever on exchanges the C drivers posted --
+    it polls the stream, raises on an asynchronous communicator error, and after the timeout aborts the communicator."""
+    import ctypes
+
+    from beta_recsys_amd import _rccl
+
+    class FakeLib:
+        def __init__(self, code):
+            self.code, self.aborted = code, 0
+            self.ncclAllReduce = ctypes.CFUNCTYPE(ctypes.c_int)(lambda: 0)   # (the constructor takes its address)
+
+        def ncclCommGetAsyncError(self, comm, out):
+            ctypes.cast(out, ctypes.POINTER(ctypes.c_int))[0] = self.code
+            return 0
+
+        def ncclCommAbort(self, comm):
+            self.aborted += 1
+            return 0
+
+    class Stream:
+        def __init__(self, done_after):
+            self.calls, self.done_after = 0, done_after
+
+        def query(self):
+            self.calls += 1
+            return self.calls > self.done_after
+
+    lib = FakeLib(0)
+    comm = _rccl.Communicator(lib, ctypes.c_void_p(1), 2, 0)
+    comm.wait(Stream(5), timeout_s=5.0)                       # completes: no error, nothing aborted
+    assert lib.aborted == 0 and comm.comm
+    with pytest.raises(RuntimeError, match="did not complete within"):
+        comm.wait(Stream(10**9), timeout_s=0.05)              # a peer never posts: bounded, communicator aborted
+    assert lib.aborted == 1 and comm.comm is None
+    lib2 = FakeLib(5)                                          # an asynchronous error code from the communicator
+    comm2 = _rccl.Communicator(lib2, ctypes.c_void_p(1), 2, 1)
+    with pytest.raises(RuntimeError, match="asynchronous error 5"):
+        comm2.wait(Stream(10**9), timeout_s=5.0)
+    assert lib2.aborted == 1
+    comm3 = _rccl.Communicator(FakeLib(7), ctypes.c_void_p(1), 2, 0)   # ncclInProgress is not an error
+    comm3.wait(Stream(3), timeout_s=5.0)
