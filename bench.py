@@ -379,13 +379,23 @@ def bench_mf_c4shard(args, device, full=False):
     with contextlib.redirect_stdout(io.StringIO()):
         eng = hp.MFEngine(cfg)
     steps, warm = min(args.steps, 100), min(args.warmup, 10)
-    epoch_steps = 50                                     # 3.3 M triples per epoch
+    full_cov = args.epoch_coverage == "full"
+    # "sample": 50 steps = 3.3 M triples per epoch, users drawn uniformly -- at the whole-table size an epoch meets
+    # 28 % of the users.  "full": EVERY user and item row occurs in every epoch (a data set in which every user has
+    # interactions, as the reference's do): the epoch is as long as that takes (whole table: 153 steps = 10 M triples),
+    # and what the exact lazy optimizers replay per step is the whole table's worth of zero-gradient steps.
+    epoch_steps = max(50, -(-max(Uc, Ic) // Bc)) if full_cov else 50
     g = torch.Generator().manual_seed(5)
     n_total = epoch_steps * Bc
-    users = torch.randint(0, Uc, (n_total,), generator=g).to(device)
+    users = torch.randint(0, Uc, (n_total,), generator=g)
     pz = 1.0 / torch.arange(1, Ic + 1, dtype=torch.float64)
-    pos = torch.randperm(Ic, generator=g)[torch.multinomial(pz / pz.sum(), n_total, True, generator=g)].to(device)
+    pos = torch.randperm(Ic, generator=g)[torch.multinomial(pz / pz.sum(), n_total, True, generator=g)]
+    if full_cov:     # one occurrence of every row, anywhere in the epoch (the batcher reshuffles every epoch anyway)
+        users[torch.randperm(n_total, generator=g)[:Uc]] = torch.randperm(Uc, generator=g)
+        pos[torch.randperm(n_total, generator=g)[:Ic]] = torch.randperm(Ic, generator=g)
+    users, pos = users.to(device), pos.to(device)
     neg = torch.randint(0, Ic, (n_total,), generator=g).to(device)
+    coverage = {"users": users.unique().numel() / Uc, "items": torch.cat([pos, neg]).unique().numel() / Ic}
     loader = hp.DeviceTripleBatcher(users, pos, neg, Bc)
     torch.manual_seed(7)
     # continuous training, epoch after epoch, K-step windows (see bench_mf): the staging of an epoch -- device
@@ -489,6 +499,8 @@ def bench_mf_c4shard(args, device, full=False):
                            "optimizer": c4opt,
                            "sgd_mode": args.sgd_mode,
                            "epoch": f"{epoch_steps} steps = {n_total} triples",
+                           "epoch_coverage": args.epoch_coverage,
+                           "rows_met_per_epoch": coverage,
                            "timed_region": "continuous training; per epoch one staging pass (device shuffle, per-batch "
                                            "sort, layout, row ownership) on a side stream during the previous epoch",
                            "ms_per_step_kernels_alone": alone_s * 1e3,
@@ -497,6 +509,9 @@ def bench_mf_c4shard(args, device, full=False):
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bpt_run * Bc / k_s / 1e9 / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_launch": bpt_run * Bc, "kernel_us": k_s * 1e6,
                              "dense_sweep_bytes_per_launch": bpt * Bc + sweep_bytes,
+                             # SURVEY 8d's own denominator for the optimizer that ran (28 P / 20 P of a dense sweep on
+                             # top of the rows): the rate a dense sweep would have to run at to match this step
+                             "dense_equivalent_GBps": (bpt * Bc + sweep_bytes) / k_s / 1e9,
                              "traffic": traffic, "traffic_source": traffic_src,
                              "step_frac": out["value"] * bpt_run / (HBM_PEAK_GBS * 1e9)}})
     if not args.no_cpu_baseline:
@@ -888,36 +903,47 @@ def bench_ngcf(args, device):
 _EVIDENCE = {}
 
 
-def evidence_stamp():
-    """{"commit", "source_hash", "stale"}: the stamp tools/collect_profiles.py left next to this round's committed
-    profiles (profiles/rNN_stamp.json: the commit they were collected at and the source hash of the library they were
-    measured with) against `hiprec_source_hash()` of the library THIS run loaded.  Counters and kernel durations read
-    from profiles/ are attached to a bench line only when the two hashes agree; otherwise the line says `stale` and
-    carries no profile-sourced number (a kernel changed after the last refresh used to ride along silently
-    with last round's counters)."""
-    if not _EVIDENCE:
-        st = {"commit": None, "source_hash": None, "stale": True}
+def evidence_stamp(workload=None):
+    """{"commit", "source_hash", "stale", "group"} for the committed profiles of `workload` (a profile file suffix:
+    adam, mf-c4shard_adam, ncf64 ...).  tools/collect_profiles.py leaves profiles/rNN_stamp.json: per evidence group
+    (__graft_entry__.EVIDENCE_GROUPS: the source files a workload's kernels are built from) the commit the group
+    was measured at and the sha256 of each of those files as measured.  A number read from profiles/ is attached to
+    a bench line only when (i) the library THIS run loaded was built from the sources of this tree
+    (`hiprec_source_hash()` == the hash of csrc/ + include/) and (ii) every file of the workload's group is
+    byte-identical to what was measured; otherwise the line says `stale` and carries no profile-sourced number
+    (a kernel changed after the last refresh used to ride along silently with last round's counters)."""
+    import __graft_entry__ as entry
+
+    group = entry.evidence_group(workload)
+    if group not in _EVIDENCE:
+        st = {"commit": None, "source_hash": None, "stale": True, "group": group}
         try:
             with open(os.path.join(ROOT, "profiles", f"{ROUND}_stamp.json")) as f:
-                rec = json.load(f)
+                rec = json.load(f)["groups"][group]
             st["commit"], st["source_hash"] = rec.get("commit"), rec.get("source_hash")
             from beta_recsys_amd import _lib
 
-            st["stale"] = _lib.load().hiprec_source_hash().decode() != rec.get("source_hash")
+            if "lib_matches_tree" not in _EVIDENCE:
+                _EVIDENCE["lib_matches_tree"] = _lib.load().hiprec_source_hash().decode() == entry.source_hash()
+                _EVIDENCE["tree_files"] = entry.source_file_hashes()
+            now = _EVIDENCE["tree_files"]
+            st["stale"] = not (_EVIDENCE["lib_matches_tree"] and
+                               all(now.get(f) == rec["files"].get(f) for f in entry.EVIDENCE_GROUPS[group]))
         except Exception:
             pass
-        _EVIDENCE.update(st)
-    return _EVIDENCE
+        _EVIDENCE[group] = st
+    return _EVIDENCE[group]
 
 
-def stamp_roofline(out):
+def stamp_roofline(out, workload=None):
     """Name, in the line itself, which build the profile-sourced fields of `roofline` belong to."""
     roof = out.get("roofline") if out else None
     if roof is None:
         return out
-    st = evidence_stamp()
+    st = evidence_stamp(workload)
     from_profiles = any(str(roof.get(k) or "").startswith("profiles/") for k in ("traffic_source", "kernel_us_source"))
     roof["traffic_commit"] = st["commit"] if from_profiles else None
+    roof["evidence_group"] = st["group"]
     roof["stale"] = bool(st["stale"])
     return out
 
@@ -926,7 +952,7 @@ def traffic_from_profiles(kernel, workload=None):
     """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) of a kernel from the COMMITTED rocprofv3 PMC passes
     of THIS round (none when they were taken with another build of the sources: evidence_stamp) as (bytes | None,
     source file | None).  It is not measured in this run: counters need their own rocprofv3 passes (tools/pmc_workload.sh)."""
-    if evidence_stamp()["stale"]:
+    if evidence_stamp(workload)["stale"]:
         return None, None
     for rnd in (ROUND,):
         try:
@@ -951,7 +977,7 @@ def dominant_kernel_from_profiles(workload):
     summary is there yet).  Not measured in this run -- the step is timed live, its kernels by the profiler."""
     import csv
 
-    if evidence_stamp()["stale"]:
+    if evidence_stamp(workload)["stale"]:
         return {}
     for rnd in (ROUND,):
         name = f"{rnd}_kernel_stats_{workload}.csv"
@@ -972,7 +998,7 @@ def traffic_step_from_profiles(workload, step_kernel="opt_dense_kernel"):
     the committed per-workload PMC passes (profiles/rNN_pmc_other_workloads.json: KB per dispatch and the number
     of dispatches of every kernel).  (bytes | None, source | None).  step_kernel: a kernel that runs exactly once per
     step (its dispatch count is the number of steps)."""
-    if evidence_stamp()["stale"]:
+    if evidence_stamp(workload)["stale"]:
         return None, None
     for rnd in (ROUND,):
         try:
@@ -1244,6 +1270,10 @@ def parse_args(argv=None):
                          "under --scaling")
     ap.add_argument("--c4-optimizer", default="sgd", choices=["sgd", "adam", "rmsprop"],
                     help="mf-c4 row-sharded: sgd (SURVEY 8d primary: exact scatter) or the dense optimizers (secondary)")
+    ap.add_argument("--epoch-coverage", default="sample", choices=["sample", "full"],
+                    help="mf-c4 / mf-c4shard: sample = 50-step epochs of uniformly drawn users (the whole table's epoch "
+                         "meets 28 %% of them); full = every user and item row occurs in every epoch (the lazy "
+                         "optimizers then replay the whole table's zero-gradient steps)")
     ap.add_argument("--dense-opt", default="auto", choices=["auto", "lazy", "sweep"],
                     help="mf-c4 (sharded) with Adam / RMSprop: exact lazy replay of the step's rows (csrc/lazy_opt.hip) "
                          "or the dense sweep of the whole shard every step")
@@ -1322,7 +1352,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and out is not None:
-        stamp_roofline(out)
+        stamp_roofline(out, {"mf": "adam", "mf-c4": "mf-c4_sharded" if dist_on else "mf-c4"}.get(args.workload, args.workload))
         if json_fd is not None:
             sys.stdout.flush()
             os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -45,6 +45,43 @@ def test_repeat_and_byte_accounting():
     assert json.dumps(f)   # every field is JSON-serialisable
 
 
+def test_profile_evidence_is_refused_per_group_when_its_sources_changed(tmp_path, monkeypatch):
+    """profiles/rNN_stamp.json names, per evidence group, the sha256 of every source file the group's kernels are built
+    from.  A profile-sourced number rides on a bench line only while those files are what was measured: changing one
+    model's kernel turns THAT model's evidence stale and leaves the others alone; a library that was not built from
+    this tree turns everything stale."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    import bench
+
+    files = entry.source_file_hashes()
+    assert set(f for deps in entry.EVIDENCE_GROUPS.values() for f in deps) <= set(files)
+    groups = {g: {"commit": "abc", "source_hash": entry.source_hash(), "files": {f: files[f] for f in deps}}
+              for g, deps in entry.EVIDENCE_GROUPS.items()}
+    groups["ncf"]["files"]["ncf.hip"] = "0" * 64          # measured with another ncf.hip
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / "rXX_stamp.json").write_text(json.dumps({"round": "rXX", "groups": groups}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "ROUND", "rXX")
+    monkeypatch.setattr(bench, "_EVIDENCE", {})
+    assert bench.evidence_stamp("adam") == {"commit": "abc", "source_hash": entry.source_hash(), "stale": False, "group": "mf"}
+    assert bench.evidence_stamp("mf-c4shard_adam")["stale"] is False and bench.evidence_stamp("mf-c4")["group"] == "c4"
+    assert bench.evidence_stamp("mf-c4_sharded_w1")["group"] == "sharded"
+    assert bench.evidence_stamp("ncf64")["stale"] is True and bench.evidence_stamp("ncf")["group"] == "ncf"
+    assert bench.evidence_stamp("lightgcn")["stale"] is False
+    line = bench.stamp_roofline({"roofline": {"traffic_source": "profiles/rXX_pmc_summary.json"}}, "adam")
+    assert line["roofline"]["traffic_commit"] == "abc" and line["roofline"]["stale"] is False
+    assert bench.traffic_step_from_profiles("ncf") == (None, None)       # stale: nothing is read from profiles/
+    # a library built from other sources than this tree: nothing counts
+    monkeypatch.setattr(bench, "_EVIDENCE", {})
+    monkeypatch.setattr(entry, "source_hash", lambda *a, **k: "not the library's")
+    assert bench.evidence_stamp("adam")["stale"] is True
+    # no stamp at all
+    monkeypatch.setattr(bench, "_EVIDENCE", {})
+    monkeypatch.setattr(bench, "ROUND", "rYY")
+    assert bench.evidence_stamp("adam")["stale"] is True and bench.evidence_stamp("adam")["commit"] is None
+
+
 @pytest.mark.gpu
 def test_gpus_n_line_is_the_row_sharded_split_with_the_other_forms_as_sub_records():
     """What `python bench.py --gpus 2` (no other flag) does on its ranks, run here on TWO virtual ranks of one GPU

@@ -32,7 +32,19 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
             if "hiprec::" in row["Kernel_Name"]:
                 short = row["Kernel_Name"].split("(")[0].replace("void ", "")
                 pmc[name][short][row["Counter_Name"]].append(float(row["Counter_Value"]))
-summary, others = {}, {}
+# groups that were not re-measured in this pass keep what is committed: start from the existing summaries
+def _existing(name):
+    try:
+        rec = json.load(open(os.path.join(dst, name)))
+        return {k: v for k, v in rec.items() if not k.startswith("_")}
+    except Exception:
+        return {}
+
+
+summary, others = _existing(f"{tag}_pmc_summary.json"), _existing(f"{tag}_pmc_other_workloads.json")
+for name in pmc:
+    if name not in ("adam", "sgd", "rmsprop"):
+        others.pop(name, None)        # a re-measured workload replaces its old kernels wholesale
 for name, kernels in pmc.items():
     for kern, c in kernels.items():
         entry = {f"{k}_KB_mean": round(sum(v) / len(v), 2) for k, v in c.items()}
@@ -53,33 +65,49 @@ if summary:
 if others:
     others["_note"] = note
     json.dump(others, open(os.path.join(dst, f"{tag}_pmc_other_workloads.json"), "w"), indent=1)
-# the stamp: which sources the measured library was built from (written on the GPU box by refresh_profiles.sh) and
-# the commit this collection is made at -- bench.py attaches profile-sourced numbers to a line only when the library
-# it loaded has the same source hash (evidence_stamp)
+# the stamps: which sources each evidence group (__graft_entry__.EVIDENCE_GROUPS) was measured with -- written on the
+# GPU box by refresh_profiles.sh as stamp_<group>.json (library hash + sha256 of every source file) -- and the commit
+# this collection is made at.  bench.py attaches profile-sourced numbers to a line only when the files of the
+# workload's group are unchanged (evidence_stamp).  Groups that were not re-measured keep their stamp.
 import subprocess
 
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 
-stamp = {"source_hash": None, "round": tag}
+stamp_path = os.path.join(dst, f"{tag}_stamp.json")
 try:
-    stamp.update(json.load(open(os.path.join(src, "stamp.json"))))
+    stamp = json.load(open(stamp_path))
+    assert "groups" in stamp
 except Exception:
-    pass
-stamp["source_hash_of_this_tree"] = entry.source_hash()
+    stamp = {"round": tag, "groups": {}}
 head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
 dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "beta-recsys_amd/csrc", "include"],
                        capture_output=True, text=True).stdout.strip()
-stamp["commit"] = head + ("+uncommitted-kernel-sources" if dirty else "")
-if stamp["source_hash"] != stamp["source_hash_of_this_tree"]:
-    print(f"WARNING: the profiles under gpurun_out/{tag} were measured with sources {stamp['source_hash']}, "
-          f"this tree is {stamp['source_hash_of_this_tree']}: bench.py will report them as stale", file=sys.stderr)
-json.dump(stamp, open(os.path.join(dst, f"{tag}_stamp.json"), "w"), indent=1)
+tree = entry.source_file_hashes()
+for f in sorted(glob.glob(os.path.join(src, "stamp_*.json"))):
+    group = os.path.basename(f)[6:-5]
+    if group not in entry.EVIDENCE_GROUPS:
+        continue
+    try:
+        rec = json.load(open(f))
+    except Exception:
+        continue
+    files = {k: rec["files"].get(k) for k in entry.EVIDENCE_GROUPS[group]}
+    prev = stamp["groups"].get(group)
+    if prev is not None and prev.get("files") == files:
+        continue        # measured earlier with the same sources: the commit it was collected at stands
+    current = all(tree.get(k) == v for k, v in files.items())
+    if not current:
+        print(f"WARNING: group {group} under gpurun_out/{tag} was measured with sources that differ from this tree: "
+              "bench.py will report its profiles as stale", file=sys.stderr)
+    stamp["groups"][group] = {"commit": (head + ("+uncommitted-kernel-sources" if dirty else "")) if current else None,
+                              "source_hash": rec.get("source_hash"), "files": files}
+json.dump(stamp, open(stamp_path, "w"), indent=1)
 for name in (f"{tag}_pmc_summary.json", f"{tag}_pmc_other_workloads.json"):
     path = os.path.join(dst, name)
     if os.path.exists(path):
         rec = json.load(open(path))
-        rec["_stamp"] = {k: stamp[k] for k in ("commit", "source_hash")}
+        rec["_stamp"] = {g: {k: v[k] for k in ("commit", "source_hash")} for g, v in stamp["groups"].items()}
         json.dump(rec, open(path, "w"), indent=1)
 for f in glob.glob(os.path.join(src, "exp_*.txt")):
     shutil.copy(f, os.path.join(dst, f"{tag}_{os.path.basename(f)}"))
