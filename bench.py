@@ -373,7 +373,7 @@ def bench_mf_c4shard(args, device, full=False):
     owned = args.sgd_mode in ("owned", "owned_atomic") and c4opt == "sgd"
     cfg = {"model": dict(n_users=Uc, n_items=Ic, emb_dim=Dc, device_str=str(device), optimizer=c4opt,
                          lr=LR, batch_size=Bc, loss="bpr", sgd_mode=args.sgd_mode, dense_opt=args.dense_opt,
-                         lazy_grad=args.lazy_grad),
+                         lazy_grad=args.lazy_grad, lazy_advance=args.lazy_advance),
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -393,9 +393,16 @@ def bench_mf_c4shard(args, device, full=False):
     if full_cov:     # one occurrence of every row, anywhere in the epoch (the batcher reshuffles every epoch anyway)
         users[torch.randperm(n_total, generator=g)[:Uc]] = torch.randperm(Uc, generator=g)
         pos[torch.randperm(n_total, generator=g)[:Ic]] = torch.randperm(Ic, generator=g)
-    users, pos = users.to(device), pos.to(device)
-    neg = torch.randint(0, Ic, (n_total,), generator=g).to(device)
-    coverage = {"users": users.unique().numel() / Uc, "items": torch.cat([pos, neg]).unique().numel() / Ic}
+    neg = torch.randint(0, Ic, (n_total,), generator=g)
+
+    def met(n_rows, *ids):     # fraction of a table's rows an epoch meets (host arithmetic: nothing of it on the GPU)
+        seen = torch.zeros(n_rows, dtype=torch.bool)
+        for t in ids:
+            seen[t] = True
+        return float(seen.sum()) / n_rows
+
+    coverage = {"users": met(Uc, users), "items": met(Ic, pos, neg)}
+    users, pos, neg = users.to(device), pos.to(device), neg.to(device)
     loader = hp.DeviceTripleBatcher(users, pos, neg, Bc)
     torch.manual_seed(7)
     # continuous training, epoch after epoch, K-step windows (see bench_mf): the staging of an epoch -- device
@@ -474,7 +481,8 @@ def bench_mf_c4shard(args, device, full=False):
         row_bytes = {"adam": 3 * 6, "rmsprop": 3 * 4}[c4opt] * 4 * (Dc + 1)
         bpt_run = bpt + (row_bytes if lazy else sweep_bytes / Bc)
         kname = (("lazy step: catch-up + mf_bpr_owned_kernel<2,false,false,true> (gradient parts -> contribution buffer) + "
-                  "lazy_pull_apply_kernel (sum, replay the moments, step, stamp): 3 launches, no dense gradient traffic"
+                  "lazy_pull_apply_kernel (sum, replay the moments, step, advance to the row's next use, stamp): 3 "
+                  "launches, no dense gradient traffic"
                   if eng._lazy_owned() == "pull" else
                   "lazy step: catch-up + mf_bpr_owned_kernel<2,false,true> (gradients) + update (3 launches)") if lazy
                  else "mf_bpr_fused_kernel / dense sweep")
@@ -500,6 +508,7 @@ def bench_mf_c4shard(args, device, full=False):
                            "sgd_mode": args.sgd_mode,
                            "epoch": f"{epoch_steps} steps = {n_total} triples",
                            "epoch_coverage": args.epoch_coverage,
+                           "lazy_advance": args.lazy_advance if lazy else None,
                            "rows_met_per_epoch": coverage,
                            "timed_region": "continuous training; per epoch one staging pass (device shuffle, per-batch "
                                            "sort, layout, row ownership) on a side stream during the previous epoch",
@@ -1234,13 +1243,22 @@ def bench_mf_multi_gpu(args, device, world, rank, group=None):
     import copy
 
     out = bench_mf(args, device, world, rank, True, force_mode="sharded", force_scaling="strong", group=group)
-    rep = bench_mf(args, device, world, rank, True, force_mode="replicated", force_scaling="weak", group=group)
+
+    def side(fn):
+        # a sub-record must not cost the run its headline: an error in one (the same code and shapes run on every
+        # rank, so it is raised by all of them) is reported in its place
+        try:
+            return compact_line(fn()) if rank == 0 else (fn() and None)
+        except Exception as e:  # noqa: BLE001
+            return {"error": f"{type(e).__name__}: {e}"[:400]}
+
+    rep = side(lambda: bench_mf(args, device, world, rank, True, force_mode="replicated", force_scaling="weak", group=group))
     c4args = copy.copy(args)
     c4args.steps, c4args.warmup = min(args.steps, 50), min(args.warmup, 5)
-    c4 = bench_mf_c4_sharded(c4args, device, world, rank, group=group)
+    c4 = side(lambda: bench_mf_c4_sharded(c4args, device, world, rank, group=group))
     if rank != 0:
         return None
-    out["alt"] = {"replicated": compact_line(rep), "c4_sharded": compact_line(c4)}
+    out["alt"] = {"replicated": rep, "c4_sharded": c4}
     return out
 
 
@@ -1281,6 +1299,10 @@ def parse_args(argv=None):
                     help="mf-c4 / mf-c4shard with lazy Adam / RMSprop: pull = gradient parts through the contribution "
                          "buffer + one apply launch (round 5); owned / atomic = gradient kernel into the dense buffer + "
                          "update launch (round 4)")
+    ap.add_argument("--lazy-advance", default="next_use", choices=["next_use", "none"],
+                    help="mf-c4 / mf-c4shard with lazy Adam / RMSprop (pull form): next_use = a row's step also takes the "
+                         "zero-gradient steps up to its next occurrence in the staged epoch (no catch-up for rows that "
+                         "recur, no flush for rows the epoch met); none = rows only lag (round 4: catch-up + flush)")
     ap.add_argument("--step-driver", default="c", choices=["c", "torch"],
                     help="row-sharded planned steps: c = kernels and grouped ncclSend/ncclRecv enqueued by one C call "
                          "per range of steps; torch = torch.distributed.all_to_all_single between the launches")

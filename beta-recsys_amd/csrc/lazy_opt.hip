@@ -29,6 +29,7 @@
 // first lane, row loads issued before the claim (lazy_rows_vec_kernel).  Other widths: one row per wave, lane = column
 // (+ kWave * j) (lazy_rows_kernel).
 #include <algorithm>
+#include <cmath>
 
 #include "common.hpp"
 #include "pull.hpp"
@@ -52,7 +53,40 @@ struct LazyCtx {
   int32_t* stamp_i;
   float2* scalars;
   int32_t scalars_cap;
+  // Adam: from this step number on a weight that a zero-gradient step left unchanged stays unchanged for good
+  // (lazy_freeze_from below); INT_MAX = never assume so
+  int32_t freeze_from;
+  float freeze_wmin;   // ... for weights of at least this magnitude (guard (ii) below)
 };
+
+// BOUNDED REPLAY (round 5).  A zero-gradient Adam step k of a row moves w by x_k = ss_t * m_k / (sqrt(v_k) * r_t + eps)
+// with m_k = (1 - (1 - beta1)) m_(k-1), v_k = beta2 v_(k-1): |x_(k+1)| / |x_k| <= beta1 / sqrt(beta2) *
+// sqrt((1 - beta2^(t+1)) / (1 - beta2^t)) (eps in the denominator only helps, ss_t falls with t), 0.90 for the default
+// betas once t > 16.  The x_k of an element all have the sign of its m.  So once fl(w - x_k) == w -- x_k is at most
+// half the gap to w's neighbour on that side -- every later x is smaller still and leaves w alone as well: the
+// remaining zero-gradient steps of that element are decays of m and v only (one fma + one multiply instead of sqrt +
+// rcp + 6 more), and a catch-up, which stores nothing but w, is DONE.  With lr 0.05 that happens ~150-200 steps after
+// the last gradient: the replay of a row costs at most that many full steps however long it lagged -- exactly, no
+// closed form.  Guards: (i) the step number is past lazy_freeze_from(beta1, beta2) (INT_MAX for betas whose ratio above
+// is not safely below one, or without an eps to bound the denominator from below); (ii) |w| >= freeze_wmin or m == 0: a
+// first moment that has decayed into the smallest denormals stops shrinking (0.9 x rounds back to x for x <= 4 units)
+// while the denominator still falls, so x can GROW again -- up to 1.25 lr * 8 * 1.4e-45 / eps, which is below half an ulp
+// of every |w| >= 2^26 times that (2.5e-30 for lr 0.05, eps 1e-8); an element with m == 0 does not move at all.
+int lazy_freeze_from(double b1, double b2, double lr, double eps, float* wmin) {
+  constexpr int kNever = 0x7fffffff;
+  *wmin = static_cast<float>(std::max(1e-30, std::ldexp(1.0, 26) * 1.25 * lr * 8.0 * 1.4012984643e-45 / std::max(eps, 1e-300)));
+  if (!(lr > 0.0 && eps >= 1e-12 && *wmin < 1e-20f)) return kNever;
+  if (!(b1 > 0.0 && b1 < 1.0 && b2 > 0.0 && b2 < 1.0)) return kNever;
+  if (b1 * b1 >= 0.96 * b2) return kNever;
+  double p = b2;   // beta2^t
+  for (int t = 1; t < (1 << 20); ++t) {
+    const double pn = p * b2;
+    if (b1 * b1 * (1.0 - pn) < 0.96 * b2 * (1.0 - p)) return std::max(t, 16);
+    p = pn;
+  }
+  return kNever;
+}
+constexpr int kFreezeEvery = 8;   // the test costs a compare per element and a ballot: taken every 8th step
 
 __device__ __forceinline__ float2 lazy_scalars_at(const LazyCtx& c, long long t) {
   return c.scalars[t < c.scalars_cap ? t : c.scalars_cap - 1];
@@ -173,8 +207,10 @@ __device__ __forceinline__ void lazy_rows_vec_body(const LazyCtx& c, const hipre
   // The zero-gradient steps (base, last] of this lane's N elements; `on` = this lane has any, `first` (uniform) = the
   // oldest stamp of the wave's lanes that are on, + 1: the wave walks from there in blocks of 64 steps (lane k of
   // `mine` holds the scalars of step tb + k), a lane joins when t passes its own stamp.
-  auto replay_block = [&](auto& w, auto& m, auto& v, bool on, int base, bool w_ahead, long long tb, float2 mine)
-                          __attribute__((always_inline)) {
+  // `frozen` (uniform over the wave): every lane's weights have stopped moving (see BOUNDED REPLAY above) -- from then on
+  // only the moments are replayed, and a catch-up is finished.  RMSprop's zero-gradient step never moves w.
+  auto replay_block = [&](auto& w, auto& m, auto& v, bool on, int base, bool w_ahead, long long tb, float2 mine,
+                          bool& frozen) __attribute__((always_inline)) {
     constexpr int N = sizeof(w) / sizeof(w[0]);
     const int cnt = static_cast<int>(last - tb + 1 < kWave ? last - tb + 1 : kWave);
     for (int k = 0; k < cnt; ++k) {
@@ -183,21 +219,35 @@ __device__ __forceinline__ void lazy_rows_vec_body(const LazyCtx& c, const hipre
         sc.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), k));
         sc.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), k));
       }
-      if (!(on && tb + k > base)) continue;
-      // w is current already: only the moments (one fma and one multiply per step).  A flush meets the flag only when
-      // a step was abandoned between its catch-up and its update (an error return in between): w must not take the
-      // zero-gradient steps a second time
-      if (MODE != 0 && w_ahead) {
+      const bool act = on && tb + k > base;
+      const bool check = kAdam && !frozen && (k % kFreezeEvery) == kFreezeEvery - 1 && tb + k >= c.freeze_from;
+      bool moved = false;
+      if (act) {
+        // w is current already: only the moments (one fma and one multiply per step).  A flush meets the w-ahead flag
+        // only when a step was abandoned between its catch-up and its update (an error return in between): w must not
+        // take the zero-gradient steps a second time
+        if (MODE != 0 && (w_ahead || frozen)) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-          float zero = 0.f, w_unused = 0.f;
-          opt_update<KIND>(w_unused, zero, m[j], v[j], s, 1.f, 1.f);
+          for (int j = 0; j < N; ++j) {
+            float zero = 0.f, w_unused = 0.f;
+            opt_update<KIND>(w_unused, zero, m[j], v[j], s, 1.f, 1.f);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            float zero = 0.f;
+            const float w0 = w[j];
+            opt_update<KIND, true>(w[j], zero, m[j], v[j], s, sc.x, sc.y);
+            if (check) moved |= w[j] != w0 || !(__builtin_fabsf(w0) >= c.freeze_wmin || m[j] == 0.f);
+          }
         }
-      } else {
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-          float zero = 0.f;
-          opt_update<KIND, true>(w[j], zero, m[j], v[j], s, sc.x, sc.y);
+      }
+      if (check) {
+        // a lane holds the wave back while it has yet to join the walk, or while a weight of its still moves
+        const bool pending = on && !(MODE != 0 && w_ahead) && (!act || moved);
+        if (__ballot(pending) == 0ull) {
+          frozen = true;
+          if constexpr (MODE == 0) return;   // a catch-up stores w only: nothing is left to do
         }
       }
     }
@@ -208,15 +258,19 @@ __device__ __forceinline__ void lazy_rows_vec_body(const LazyCtx& c, const hipre
   auto replay = [&](auto& w, auto& m, auto& v, bool on, int base, bool w_ahead, int first, float2 pre, int pre_tb)
                     __attribute__((always_inline)) {
     if (first > last) return;
+    bool frozen = !kAdam;
     long long tb = first;
     if (first == pre_tb) {
-      replay_block(w, m, v, on, base, w_ahead, tb, pre);
+      replay_block(w, m, v, on, base, w_ahead, tb, pre, frozen);
       tb += kWave;
     }
     for (; tb <= last; tb += kWave) {
+      if (MODE == 0 && frozen) return;
       float2 mine = make_float2(s.lr, 1.f);
-      if constexpr (kAdam) mine = lazy_scalars_at(c, tb + lane);
-      replay_block(w, m, v, on, base, w_ahead, tb, mine);
+      if constexpr (kAdam) {
+        if (!frozen) mine = lazy_scalars_at(c, tb + lane);   // (the moments' decay needs no per-step scalars)
+      }
+      replay_block(w, m, v, on, base, w_ahead, tb, mine, frozen);
     }
   };
 
@@ -462,26 +516,32 @@ __global__ __launch_bounds__(kBlock) void lazy_rows_kernel(LazyCtx c, hiprec_laz
 #pragma unroll
     for (int j = 0; j <= kLazyMaxNpl; ++j) moving |= on[j] && (m[j] != 0.f || v[j] != 0.f);
     const bool replay = base >= 0 && __ballot(moving) != 0ull;
-    if (MODE != 0 && w_ahead) {
-      // w is current already: only the moments are replayed (one fma and one multiply per step, no sqrt / rcp); a
-      // flush meets the flag only after an abandoned step (see lazy_rows_vec_body)
-      for (long long t = base + 1LL; replay && t <= last; ++t) {
+    // w is current already (w_ahead; a flush meets the flag only after an abandoned step, see lazy_rows_vec_body), or
+    // has stopped moving (BOUNDED REPLAY above; RMSprop's zero-gradient step never moves it): only the moments are
+    // replayed -- one fma and one multiply per step, no sqrt / rcp
+    bool frozen = (MODE != 0 && w_ahead) || KIND != HIPREC_OPT_ADAM;
+    for (long long t = base + 1LL; replay && t <= last; ++t) {
+      if (frozen) {
+        if constexpr (MODE == 0) break;   // a catch-up stores w only
 #pragma unroll
         for (int j = 0; j <= kLazyMaxNpl; ++j) {
           float zero = 0.f, w_unused = 0.f;
           opt_update<KIND>(w_unused, zero, m[j], v[j], s, 1.f, 1.f);
         }
+        continue;
       }
-    } else {
-      for (long long t = base + 1LL; replay && t <= last; ++t) {
-        float2 sc = make_float2(s.lr, 1.f);
-        if constexpr (KIND == HIPREC_OPT_ADAM) sc = lazy_scalars_at(c, t);
+      float2 sc = make_float2(s.lr, 1.f);
+      if constexpr (KIND == HIPREC_OPT_ADAM) sc = lazy_scalars_at(c, t);
+      const bool check = (t - base) % kFreezeEvery == 0 && t >= c.freeze_from;
+      bool moved = false;
 #pragma unroll
-        for (int j = 0; j <= kLazyMaxNpl; ++j) {
-          float zero = 0.f;
-          opt_update<KIND, true>(w[j], zero, m[j], v[j], s, sc.x, sc.y);
-        }
+      for (int j = 0; j <= kLazyMaxNpl; ++j) {
+        float zero = 0.f;
+        const float w0 = w[j];
+        opt_update<KIND, true>(w[j], zero, m[j], v[j], s, sc.x, sc.y);
+        if (check) moved |= on[j] && (w[j] != w0 || !(__builtin_fabsf(w0) >= c.freeze_wmin || m[j] == 0.f));
       }
+      if (check && __ballot(moved) == 0ull) frozen = true;
     }
     if constexpr (MODE == 1) {
 #pragma unroll
@@ -517,8 +577,8 @@ __global__ __launch_bounds__(kBlock) void lazy_rows_kernel(LazyCtx c, hiprec_laz
 // parts of a shared row's gradient are summed.  dim % 4 == 0.
 template <int KIND, int LPR>
 __global__ __launch_bounds__(kPullBlock) __attribute__((amdgpu_waves_per_eu(8)))
-void lazy_pull_apply_kernel(PullApply f, LazyCtx c, OptScalars s,
-                                                                     hiprec_stats* stats, const Scratch* scratch) {
+void lazy_pull_apply_kernel(PullApply f, LazyCtx c, OptScalars s, hiprec_stats* stats, const Scratch* scratch,
+                            int k_step, int n_steps_epoch) {
   constexpr int RPW = kWave / LPR;
   constexpr int GROUPS = kPullWaves * RPW;
   constexpr int DEPTH = 2;   // (most rows of a batch have ONE part; 64 VGPRs = two workgroups per CU)
@@ -577,7 +637,7 @@ void lazy_pull_apply_kernel(PullApply f, LazyCtx c, OptScalars s,
     }
     return r;
   };
-  auto finish_row = [&](Row& r, bool on, float4 g, float gb) __attribute__((always_inline)) {
+  auto finish_row = [&](Row& r, bool on, float4 g, float gb, int next_k) __attribute__((always_inline)) {
     // zero-gradient steps (base, clock - 1]: the moments only (w is current: it was caught up before the gradients
     // were taken, or the row did not lag; RMSprop's zero-gradient step leaves w alone)
     const int base = r.old < 0 ? -1 : (r.old & ~kWAhead);
@@ -598,6 +658,55 @@ void lazy_pull_apply_kernel(PullApply f, LazyCtx c, OptScalars s,
     float gg[5] = {g.x, g.y, g.z, g.w, gb};
 #pragma unroll
     for (int j = 0; j < 5; ++j) opt_update<KIND>(r.w[j], gg[j], r.m[j], r.v[j], s, ss_now, bc2_now);
+    // NEXT-USE ADVANCE (n_steps_epoch > 0): the staged epoch says in which of its steps the row is needed next (next_k;
+    // n_steps_epoch = not again).  The zero-gradient steps up to there are taken NOW, while the row is in registers --
+    // with the scalars of those future steps, which depend on the step number only (lazy_scalars_ahead_kernel has
+    // tabulated them): the row is current when its next step reads it (no catch-up: that launch then only has the
+    // rows an epoch meets for the first time), rows the epoch does not meet again are current as of its last step (no
+    // flush for them), and w, m, v cross memory once per occurrence instead of twice.  The same operations in the same
+    // order as the catch-up / the dense sweep would have made them; weights that stop moving are left alone as in
+    // lazy_rows_vec_body (BOUNDED REPLAY).
+    int n_fwd = on && n_steps_epoch > 0 && next_k > k_step && next_k <= n_steps_epoch ? next_k - k_step - 1 : 0;
+    int f_max = n_fwd;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) f_max = max(f_max, __shfl_xor(f_max, o));
+    f_max = __builtin_amdgcn_readfirstlane(f_max);
+    bool frozen = !kAdam;
+    for (int j0 = 0; j0 < f_max; j0 += kWave) {
+      float2 mine = make_float2(s.lr, 1.f);
+      if constexpr (kAdam) {
+        if (!frozen) mine = lazy_scalars_at(c, static_cast<long long>(target) + 1 + j0 + lane);
+      }
+      const int cnt = f_max - j0 < kWave ? f_max - j0 : kWave;
+      for (int k = 0; k < cnt; ++k) {
+        float2 sc = make_float2(s.lr, 1.f);
+        if constexpr (kAdam) {
+          sc.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), k));
+          sc.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), k));
+        }
+        const bool act = j0 + k < n_fwd;
+        const bool check = kAdam && !frozen && (k % kFreezeEvery) == kFreezeEvery - 1 && target + 1 + j0 + k >= c.freeze_from;
+        bool moved = false;
+        if (act) {
+          if (frozen) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+              float zero = 0.f, w_unused = 0.f;
+              opt_update<KIND>(w_unused, zero, r.m[j], r.v[j], s, 1.f, 1.f);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+              float zero = 0.f;
+              const float w0 = r.w[j];
+              opt_update<KIND, true>(r.w[j], zero, r.m[j], r.v[j], s, sc.x, sc.y);
+              if (check) moved |= r.w[j] != w0 || !(__builtin_fabsf(w0) >= c.freeze_wmin || r.m[j] == 0.f);
+            }
+          }
+        }
+        if (check && __ballot(act && moved) == 0ull) frozen = true;
+      }
+    }
     if (!on) return;
     int64_t ro, bo;
     pull_row_of(f, r.key, sl, &ro, &bo);
@@ -610,7 +719,7 @@ void lazy_pull_apply_kernel(PullApply f, LazyCtx c, OptScalars s,
       c.w[bo] = r.w[4];
       c.v[bo] = r.v[4];
       if constexpr (kAdam) c.m[bo] = r.m[4];
-      *(r.key < f.n_users ? c.stamp_u + r.key : c.stamp_i + (r.key - f.n_users)) = target;
+      *(r.key < f.n_users ? c.stamp_u + r.key : c.stamp_i + (r.key - f.n_users)) = target + n_fwd;
     }
   };
 
@@ -634,7 +743,7 @@ void lazy_pull_apply_kernel(PullApply f, LazyCtx c, OptScalars s,
         tb += s_pb[q];
       }
       Row r = load_row(sub == 0, rec.x);
-      finish_row(r, sub == 0, tot, tb);
+      finish_row(r, sub == 0, tot, tb, rec.w);
     }
     __syncthreads();
   }
@@ -653,9 +762,32 @@ void lazy_pull_apply_kernel(PullApply f, LazyCtx c, OptScalars s,
     float gb = 0.f;
     Row r = load_row(on, rec.x);                 // stamp, weights, moments: requested with the gradient parts
     pull_sum_range<LPR, DEPTH>(f, rec.y, 0, rec.z, 1, trips, sl, col, g, gb);
+    const int next_k = rec.w;
     const int nxt = i0 + nb * GROUPS + sub;
     if (nxt < n_short) rec = f.rows[nxt];
-    finish_row(r, on, g, gb);
+    finish_row(r, on, g, gb, next_k);
+  }
+}
+
+// The per-step scalars of the n_ahead steps AFTER the clock, tabulated before they are taken (the next-use advance of
+// lazy_pull_apply_kernel replays zero-gradient steps the clock has not reached yet): one thread walks the powers exactly
+// as the steps themselves will -- advance_step, step_scalars, the reciprocal lazy_scalar_step records -- so step t
+// later records the bits that are already there.  A few dozen nanoseconds per step, once per enqueued piece of an epoch.
+template <int KIND>
+__global__ void lazy_scalars_ahead_kernel(LazyCtx c, OptScalars s, const hiprec_stats* stats, int64_t n_ahead) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  hiprec_stats loc = *stats;
+  for (int64_t i = 0; i < n_ahead; ++i) {
+    advance_step(&loc);
+    if (loc.step >= c.scalars_cap) return;   // beyond the table the corrections have converged (validated at set-up)
+    float ss = s.lr, bc2 = 1.f;
+    step_scalars<KIND>(s, &loc, &ss, &bc2);
+#ifdef HIPREC_IEEE_DIV
+    const float bc2_rec = bc2;
+#else
+    const float bc2_rec = __builtin_amdgcn_rcpf(bc2);
+#endif
+    if (loc.step >= 0) c.scalars[loc.step] = make_float2(ss, bc2_rec);
   }
 }
 
@@ -691,8 +823,9 @@ int lazy_launch(const hiprec_lazy_state* st, const hiprec_lazy_rows* rows, const
   }
   if (MODE == 0 && st->kind == HIPREC_OPT_RMSPROP) return 0;  // w does not move on a zero-gradient RMSprop step
   if (MODE != 1 && total == 0) return 0;
-  const LazyCtx c{st->w, st->g, st->m, st->v, st->n_users, st->n_items, st->dim, st->stamp_u, st->stamp_i,
-                  reinterpret_cast<float2*>(st->scalars), st->scalars_cap};
+  LazyCtx c{st->w, st->g, st->m, st->v, st->n_users, st->n_items, st->dim, st->stamp_u, st->stamp_i,
+            reinterpret_cast<float2*>(st->scalars), st->scalars_cap, 0x7fffffff, 0.f};
+  c.freeze_from = lazy_freeze_from(st->beta1, st->beta2, st->lr, st->eps, &c.freeze_wmin);
   const OptScalars s{st->lr,
                      static_cast<float>(st->lr),
                      static_cast<float>(st->beta2),
@@ -820,10 +953,15 @@ extern "C" int hiprec_mf_epoch_lazy_owned(const hiprec_lazy_state* state, const 
 extern "C" int hiprec_mf_epoch_lazy_pull(const hiprec_lazy_state* state, const int64_t* users, const int64_t* pos,
                                          const int64_t* neg, const int32_t* cidx, int64_t cidx_stride,
                                          const int32_t* rows, int64_t row_cap, const int32_t* counts, float* cbuf,
-                                         float* cbias, int64_t n, int64_t batch, int32_t first_of_epoch, float reg_coef,
-                                         hiprec_stats* stats, void* scratch, void* stream) {
+                                         float* cbias, int64_t n, int64_t batch, int32_t first_of_epoch,
+                                         int64_t step0, int64_t n_steps_epoch, float reg_coef, hiprec_stats* stats,
+                                         void* scratch, void* stream) {
   HIPREC_REQUIRE(state && stats && scratch, "NULL pointer");
   HIPREC_REQUIRE(state->kind == HIPREC_OPT_ADAM || state->kind == HIPREC_OPT_RMSPROP, "lazy state is Adam's or RMSprop's");
+  HIPREC_REQUIRE(n_steps_epoch == 0 || (step0 >= 0 && step0 + (n + batch - 1) / batch <= n_steps_epoch &&
+                                        n_steps_epoch < (1ll << 30)),
+                 "next-use advance: steps [%lld, %lld) do not lie in an epoch of %lld steps", (long long)step0,
+                 (long long)(step0 + (n + batch - 1) / batch), (long long)n_steps_epoch);
   HIPREC_REQUIRE(state->w && state->g && state->v && (state->kind != HIPREC_OPT_ADAM || state->m) && state->stamp_u &&
                      state->stamp_i, "NULL buffer in the lazy optimizer state");
   HIPREC_REQUIRE(state->kind != HIPREC_OPT_ADAM || (state->scalars && state->scalars_cap >= 2), "Adam needs the scalars table");
@@ -835,8 +973,9 @@ extern "C" int hiprec_mf_epoch_lazy_pull(const hiprec_lazy_state* state, const i
     if (int rc = hiprec_stats_begin_epoch(stats, stream)) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int32_t dim = state->dim;
-  const LazyCtx c{state->w, state->g, state->m, state->v, state->n_users, state->n_items, dim, state->stamp_u,
-                  state->stamp_i, reinterpret_cast<float2*>(state->scalars), state->scalars_cap};
+  LazyCtx c{state->w, state->g, state->m, state->v, state->n_users, state->n_items, dim, state->stamp_u,
+            state->stamp_i, reinterpret_cast<float2*>(state->scalars), state->scalars_cap, 0x7fffffff, 0.f};
+  c.freeze_from = lazy_freeze_from(state->beta1, state->beta2, state->lr, state->eps, &c.freeze_wmin);
   const OptScalars s{state->lr, static_cast<float>(state->lr), static_cast<float>(state->beta2),
                      static_cast<float>(1.0 - state->beta1), static_cast<float>(1.0 - state->beta2),
                      static_cast<float>(state->eps)};
@@ -855,6 +994,8 @@ extern "C" int hiprec_mf_epoch_lazy_pull(const hiprec_lazy_state* state, const i
   a.gb = nullptr;
   a.lr = static_cast<float>(state->lr);
   const bool adam = state->kind == HIPREC_OPT_ADAM;
+  if (n_steps_epoch > 0 && adam && n > 0)   // the scalars of the steps this epoch has yet to take (RMSprop has none)
+    lazy_scalars_ahead_kernel<HIPREC_OPT_ADAM><<<1, 1, 0, st>>>(c, s, stats, n_steps_epoch - step0);
   for (int64_t off = 0, k = 0; off < n; off += batch, ++k) {
     const int64_t b = std::min<int64_t>(batch, n - off);  // drop_last = False
     const hiprec_lazy_rows lists{users + off, b, pos + off, b, neg + off, b, nullptr, 0};
@@ -869,10 +1010,11 @@ extern "C" int hiprec_mf_epoch_lazy_pull(const hiprec_lazy_state* state, const i
     const int64_t per_block = kPullWaves * (dim <= 64 ? 4 : dim <= 128 ? 2 : 1);
     const int grid = static_cast<int>(std::min<int64_t>((3 * b + per_block - 1) / per_block, 512)) + 1;
     const auto* sc = static_cast<const Scratch*>(scratch);
+    const int ks = static_cast<int>(step0 + k), ne = static_cast<int>(n_steps_epoch);
 #define HIPREC_LAZY_PULL(LPR)                                                                                      \
   do {                                                                                                             \
-    if (adam) lazy_pull_apply_kernel<HIPREC_OPT_ADAM, LPR><<<grid, kPullBlock, 0, st>>>(a, c, s, stats, sc);        \
-    else lazy_pull_apply_kernel<HIPREC_OPT_RMSPROP, LPR><<<grid, kPullBlock, 0, st>>>(a, c, s, stats, sc);          \
+    if (adam) lazy_pull_apply_kernel<HIPREC_OPT_ADAM, LPR><<<grid, kPullBlock, 0, st>>>(a, c, s, stats, sc, ks, ne); \
+    else lazy_pull_apply_kernel<HIPREC_OPT_RMSPROP, LPR><<<grid, kPullBlock, 0, st>>>(a, c, s, stats, sc, ks, ne);   \
   } while (0)
     if (dim <= 64) HIPREC_LAZY_PULL(16);
     else if (dim <= 128) HIPREC_LAZY_PULL(32);
@@ -892,7 +1034,7 @@ extern "C" int hiprec_debug_lazy_dual(const hiprec_lazy_state* a, const hiprec_l
                  "two Adam states of dim 128");
   auto ctx = [](const hiprec_lazy_state* st) {
     return LazyCtx{st->w, st->g, st->m, st->v, st->n_users, st->n_items, st->dim, st->stamp_u, st->stamp_i,
-                   reinterpret_cast<float2*>(st->scalars), st->scalars_cap};
+                   reinterpret_cast<float2*>(st->scalars), st->scalars_cap, 0x7fffffff, 0.f};
   };
   auto sc = [](const hiprec_lazy_state* st) {
     return OptScalars{st->lr, static_cast<float>(st->lr), static_cast<float>(st->beta2),

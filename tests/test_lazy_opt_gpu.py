@@ -214,6 +214,78 @@ def test_lazy_rows_in_many_chunks_with_long_gaps_bit_for_bit(hip_device, opt, D)
     assert torch.equal(vl, vd) and (opt != "adam" or torch.equal(ml, md))
 
 
+@pytest.mark.parametrize("opt,D", [("adam", 128), ("adam", 10), ("adam", 64), ("rmsprop", 64)])
+def test_bounded_replay_of_rows_that_lag_for_hundreds_of_steps_bit_for_bit(hip_device, opt, D):
+    """BOUNDED REPLAY (csrc/lazy_opt.hip): a row's zero-gradient steps are replayed in full only until its weights stop
+    moving, after that only the moments decay -- which must still be the dense sweeps' bits.  700 steps in lockstep with
+    dense sweeps; blocks of rows are touched once early (steps 3-8, 30-33) and again after 250-690 steps, others get
+    their first gradient late; among the weights are zeros, denormals and values around 1e-31 (below the magnitude
+    from which the early exit may be taken), and gradients from 1e-12 to 10 (moments that underflow, and moments that
+    keep the weights moving for longer than the typical 150-200 steps).  After every catch-up the step's rows hold the
+    dense sweeps' weights; after the final flush w, m, v are bit-identical everywhere."""
+    from beta_recsys_amd import _lib
+
+    lib, dev = _lib.load(), hip_device
+    U, I, T, lr = 260, 90, 700, 0.05
+    kind = KIND[opt]
+    P = (U + I) * (D + 1) + 1
+    gen = torch.Generator(device="cuda").manual_seed(11 * D + kind)
+    w0 = torch.randn(P, device=dev, generator=gen) * 0.1
+    w0[: 40 * D] = 0.0                                         # users 0-39: zero weights
+    w0[40 * D: 60 * D] *= 1e-30                                # users 40-59: around 1e-31
+    w0[60 * D: 70 * D] = 1e-42                                 # users 60-69: denormal
+    wd, md, vd, gd = w0.clone(), torch.zeros_like(w0), torch.zeros_like(w0), torch.zeros_like(w0)
+    wl, ml, vl, gl = w0.clone(), torch.zeros_like(w0), torch.zeros_like(w0), torch.zeros_like(w0)
+    sd, sl = new_stats(lib, _lib, dev), new_stats(lib, _lib, dev)
+    lazy = Lazy(lib, _lib, wl, gl, ml if opt == "adam" else None, vl, U, I, D, kind, lr, cap=1024)
+    st = _lib.stream_ptr(dev)
+    rng = np.random.default_rng(D + kind)
+    cols = torch.arange(D, device=dev)
+
+    def flat_index(users, items):
+        u = torch.as_tensor(users, dtype=torch.int64, device=dev)
+        i = torch.as_tensor(items, dtype=torch.int64, device=dev)
+        return torch.unique(torch.cat([(u[:, None] * D + cols).ravel(), (U * D + i[:, None] * D + cols).ravel(),
+                                       (U + I) * D + u, (U + I) * D + U + i]))
+
+    early = {3: range(0, 35), 4: range(35, 70), 5: range(70, 100), 8: range(100, 130), 30: range(130, 160),
+             33: range(160, 190)}
+    late = {260: range(0, 20), 400: range(20, 60), 520: range(60, 110), 640: range(110, 150), 690: range(150, 200)}
+    for t in range(1, T + 1):
+        users = set(range(250, 256)) | set(rng.integers(200, 250, 4).tolist())      # a hot set and a warm one
+        items = set(range(4)) | set(rng.integers(4, 40, 6).tolist())
+        for table in (early, late):
+            if t in table:
+                users |= set(table[t])
+                items |= {40 + (j % 50) for j in table[t]}
+        users, items = sorted(users), sorted(items)
+        lu = torch.tensor(users + users[:3] + [-1], dtype=torch.int64, device=dev)
+        la = torch.tensor(items[::2] + [-1, items[0]], dtype=torch.int64, device=dev)
+        lb = torch.tensor(items[1::2], dtype=torch.int64, device=dev)
+        lc = torch.tensor(items[:2] + [-1], dtype=torch.int32, device=dev)
+        idx = flat_index(users, items)
+        lazy.catchup(sl, lu, la, lb, lc)
+        assert torch.equal(wl[idx], wd[idx]), f"step {t}: a caught-up row's weights differ from the dense sweeps'"
+        g = torch.zeros(P, device=dev)
+        scale = 10.0 ** float(rng.integers(-12, 2)) if t in early or t in late else 0.01
+        g[idx] = torch.randn(idx.numel(), device=dev, generator=gen) * scale
+        g[-1] = float(rng.normal()) * 0.01
+        gd.copy_(g)
+        gl.copy_(g)
+        for stats in (sd, sl):
+            _lib.check(lib.hiprec_stats_advance_step(_lib.ptr(stats), st))
+        _lib.check(lib.hiprec_opt_dense_step(kind, _lib.ptr(wd), _lib.ptr(gd), _lib.ptr(md), _lib.ptr(vd), P, lr, 0.9, 0.999,
+                                             1e-8, _lib.ptr(sd), None, -1, st))
+        lazy.update(sl, lu, la, lb, lc)
+        if t in early or t in late or t % 50 == 0:
+            assert torch.equal(wl[idx], wd[idx]) and torch.equal(vl[idx], vd[idx]) and torch.equal(ml[idx], md[idx]), \
+                f"step {t}: an updated row differs"
+    lazy.flush(sl)
+    assert torch.equal(wl, wd), f"w differs in {int((wl != wd).sum())} elements after the flush"
+    assert torch.equal(vl, vd) and (opt != "adam" or torch.equal(ml, md))
+    assert float(gl.abs().max()) == 0.0
+
+
 def test_lazy_adam_beyond_the_scalars_table(hip_device):
     """A table of 8 entries and 12 steps: bias corrections still move at step 8, so the update kernel must raise
     HIPREC_STATUS_LAZY_TABLE instead of letting a later replay use the wrong scalars."""
@@ -463,6 +535,98 @@ def test_lazy_pull_step_is_the_three_launch_step_bit_for_bit_where_no_row_repeat
         if a is not None:
             assert torch.equal(a, b), f"{name}: {int((a != b).sum())} elements differ between the two forms"
     assert out["pull"][5] == pytest.approx(out["owned"][5], rel=1e-6)
+
+
+@pytest.mark.parametrize("optimizer,lr,D", [("adam", 0.05, 64), ("adam", 0.05, 128), ("rmsprop", 0.01, 64)])
+def test_next_use_advance_leaves_the_bits_of_the_lagging_form(hip_device, optimizer, lr, D):
+    """NEXT-USE ADVANCE (hiprec_mf_epoch_lazy_pull with n_steps_epoch > 0, hiprec_batch_row_next_use): a row's step also
+    takes the zero-gradient steps up to the row's next occurrence in the staged epoch -- with the scalars of steps the
+    clock has not reached (lazy_scalars_ahead_kernel) -- instead of a catch-up when that occurrence comes, and rows the
+    epoch does not meet again are advanced to its last step instead of flushed.  Three epochs of 12 steps (items that
+    recur nearly every step, users that come back after 1-11 steps, users met once per epoch, users never met), the
+    second epoch enqueued in pieces: weights, both moments and stamps must equal, BIT FOR BIT, the same engine with
+    `lazy_advance: "none"` (rows only lag: catch-up + flush).  While a pieced epoch is in flight the state cannot be
+    read and no other epoch can start."""
+    import beta_recsys_amd as hp
+    from test_mf_gpu import load_weights, make_engine
+
+    U, I, B, steps = 4000, 700, 256, 12
+    rng = np.random.default_rng(D + len(optimizer))
+    w0 = onp.init_params(U, I, D, seed=6)
+    epochs = []
+    for _ in range(3):
+        # no row twice in a batch (every gradient element is one term: the comparison below can ask for equal bits),
+        # but rows that come back: 192 of a pool of 800 users per step, items from all 700 every step, and 64 users per
+        # step that the epoch meets exactly once
+        once = 800 + rng.permutation(2200)
+        us, ps, ns = [], [], []
+        for k in range(steps):
+            u = np.concatenate([rng.permutation(800)[:192], once[64 * k:64 * (k + 1)]])
+            items = rng.permutation(I)[: 2 * B]
+            us.append(u[rng.permutation(B)])
+            ps.append(items[:B])
+            ns.append(items[B:])
+        epochs.append(tuple(torch.from_numpy(np.concatenate(a).astype(np.int64)).cuda() for a in (us, ps, ns)))
+    out = {}
+    for mode in ("next_use", "none"):
+        eng = make_engine(U, I, D, optimizer, "bpr", lr, B, dense_opt="lazy", lazy_grad="pull", lazy_advance=mode,
+                          prefetch_epoch=False)
+        load_weights(eng, w0)
+        eng._setup()
+        assert eng._lazy_owned() == "pull" and eng._lazy_advance() == (mode == "next_use")
+        with contextlib.redirect_stdout(io.StringIO()):
+            for e, triples in enumerate(epochs):
+                loader = hp.DeviceTripleBatcher(*triples, B, shuffle=False)
+                if e != 1:
+                    eng.train_an_epoch(loader, e)
+                    continue
+                prepared = eng.prepare_epoch(loader)
+                assert prepared.own.next_use == (mode == "next_use")
+                for piece in ((0, 5), (5, 5), (5, 6)):
+                    eng.run_prepared_epoch(prepared, sync=False, steps=piece)
+                if mode == "next_use":
+                    assert eng._lazy["ahead"]
+                    with pytest.raises(RuntimeError, match="ahead of the optimizer clock"):
+                        eng.flush_lazy()
+                    with pytest.raises(RuntimeError, match="left unfinished"):
+                        eng.run_prepared_epoch(prepared, sync=False, steps=(0, 2))
+                    # rows that recur are ahead of the clock, to the step before their next occurrence
+                    assert int(eng._lazy["stamp_i"].max()) >= 6 + steps and int(eng._lazy["stamp_u"].max()) > 6 + steps
+                eng.run_prepared_epoch(prepared, sync=False, steps=(6, steps))
+                assert not eng._lazy["ahead"] and not eng._lazy["dirty"]
+        opt = eng.optimizer
+        out[mode] = (eng.model.flat.clone(), opt.exp_avg_sq.clone(), None if opt.exp_avg is None else opt.exp_avg.clone(),
+                     eng._lazy["stamp_u"].clone(), eng._lazy["stamp_i"].clone(), eng.epoch_stats().loss_sum)
+        su = eng._lazy["stamp_u"]
+        assert bool((su[3000:] == -1).all()) and bool((su[:3000][su[:3000] >= 0] == 3 * steps).all())
+    for name, a, b in zip(("w", "v", "m", "stamp_u", "stamp_i"), out["next_use"], out["none"]):
+        if a is not None:
+            assert torch.equal(a, b), f"{name}: {int((a != b).sum())} elements differ with / without the advance"
+    assert out["next_use"][5] == pytest.approx(out["none"][5], rel=1e-6)
+
+
+def test_next_use_of_every_row_of_a_staged_epoch(hip_device):
+    """hiprec_batch_row_next_use against a plain restatement: for every record (row, batch) the smallest later batch that
+    names the row, n_batches if there is none."""
+    from beta_recsys_amd.mf import batch_row_contributions
+
+    U, I, B, D, n = 500, 120, 64, 64, 64 * 9 + 17
+    rng = np.random.default_rng(2)
+    users, pos, neg = rng.integers(0, U, n), rng.integers(0, I, n), rng.integers(0, I, n)
+    tu, tp, tn = (torch.from_numpy(a).cuda() for a in (users, pos, neg))
+    own = batch_row_contributions(tu, tp, tn, B, U, I, D, every_row=True, next_use=True)
+    assert own.next_use
+    cidx, rows, counts, row_cap = own
+    rows, counts = rows.cpu().numpy(), counts.cpu().numpy()
+    n_batches = (n + B - 1) // B
+    sets = [set(users[b * B:(b + 1) * B].tolist()) | {U + i for i in pos[b * B:(b + 1) * B].tolist()}
+            | {U + i for i in neg[b * B:(b + 1) * B].tolist()} for b in range(n_batches)]
+    for b in range(n_batches):
+        recs = np.concatenate([rows[b, :counts[b, 0]], rows[b, row_cap - counts[b, 1]:]]) if counts[b, 1] else rows[b, :counts[b, 0]]
+        assert set(recs[:, 0].tolist()) == sets[b] and len(recs) == len(sets[b])
+        for key, _, _, nxt in recs.tolist():
+            want = next((c for c in range(b + 1, n_batches) if key in sets[c]), n_batches)
+            assert nxt == want, (b, key, nxt, want)
 
 
 def test_mf_engine_lazy_epoch_in_pieces_and_around_a_dense_step(hip_device):
