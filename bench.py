@@ -373,7 +373,7 @@ def bench_mf_c4shard(args, device, full=False):
     owned = args.sgd_mode in ("owned", "owned_atomic") and c4opt == "sgd"
     cfg = {"model": dict(n_users=Uc, n_items=Ic, emb_dim=Dc, device_str=str(device), optimizer=c4opt,
                          lr=LR, batch_size=Bc, loss="bpr", sgd_mode=args.sgd_mode, dense_opt=args.dense_opt,
-                         lazy_grad=args.lazy_grad, lazy_advance=args.lazy_advance),
+                         lazy_grad=args.lazy_grad),
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -481,8 +481,7 @@ def bench_mf_c4shard(args, device, full=False):
         row_bytes = {"adam": 3 * 6, "rmsprop": 3 * 4}[c4opt] * 4 * (Dc + 1)
         bpt_run = bpt + (row_bytes if lazy else sweep_bytes / Bc)
         kname = (("lazy step: catch-up + mf_bpr_owned_kernel<2,false,false,true> (gradient parts -> contribution buffer) + "
-                  "lazy_pull_apply_kernel (sum, replay the moments, step, advance to the row's next use, stamp): 3 "
-                  "launches, no dense gradient traffic"
+                  "lazy_pull_apply_kernel (sum, replay the moments, step, stamp): 3 launches, no dense gradient traffic"
                   if eng._lazy_owned() == "pull" else
                   "lazy step: catch-up + mf_bpr_owned_kernel<2,false,true> (gradients) + update (3 launches)") if lazy
                  else "mf_bpr_fused_kernel / dense sweep")
@@ -508,7 +507,6 @@ def bench_mf_c4shard(args, device, full=False):
                            "sgd_mode": args.sgd_mode,
                            "epoch": f"{epoch_steps} steps = {n_total} triples",
                            "epoch_coverage": args.epoch_coverage,
-                           "lazy_advance": args.lazy_advance if lazy else None,
                            "rows_met_per_epoch": coverage,
                            "timed_region": "continuous training; per epoch one staging pass (device shuffle, per-batch "
                                            "sort, layout, row ownership) on a side stream during the previous epoch",
@@ -1299,10 +1297,6 @@ def parse_args(argv=None):
                     help="mf-c4 / mf-c4shard with lazy Adam / RMSprop: pull = gradient parts through the contribution "
                          "buffer + one apply launch (round 5); owned / atomic = gradient kernel into the dense buffer + "
                          "update launch (round 4)")
-    ap.add_argument("--lazy-advance", default="next_use", choices=["next_use", "none"],
-                    help="mf-c4 / mf-c4shard with lazy Adam / RMSprop (pull form): next_use = a row's step also takes the "
-                         "zero-gradient steps up to its next occurrence in the staged epoch (no catch-up for rows that "
-                         "recur, no flush for rows the epoch met); none = rows only lag (round 4: catch-up + flush)")
     ap.add_argument("--step-driver", default="c", choices=["c", "torch"],
                     help="row-sharded planned steps: c = kernels and grouped ncclSend/ncclRecv enqueued by one C call "
                          "per range of steps; torch = torch.distributed.all_to_all_single between the launches")

@@ -416,8 +416,7 @@ SIGNATURES = {
     "hiprec_mf_bpr_grad_owned": (c_int, [_P, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int64, c_float,
                                          c_float, _P, _P, _P]),
     "hiprec_mf_epoch_lazy_pull": (c_int, [POINTER(LazyState), _P, _P, _P, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64,
-                                          c_int64, c_int32, c_int64, c_int64, c_float, _P, _P, _P]),
-    "hiprec_batch_row_next_use": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P]),
+                                          c_int64, c_int32, c_float, _P, _P, _P]),
     "hiprec_mf_epoch_lazy_owned": (c_int, [POINTER(LazyState), _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int64,
                                            c_int32, c_float, _P, _P, _P]),
     "hiprec_shard_plan_bytes": (c_size_t, []),

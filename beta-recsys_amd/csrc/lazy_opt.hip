@@ -86,7 +86,8 @@ int lazy_freeze_from(double b1, double b2, double lr, double eps, float* wmin) {
   }
   return kNever;
 }
-constexpr int kFreezeEvery = 8;   // the test costs a compare per element and a ballot: taken every 8th step
+constexpr int kFreezeEvery = 8;   // the test costs a compare per element and a ballot: taken every 8th step ...
+constexpr int kFreezeStart = 192; // ... and not before a walk is this long (weights move for 150-200 steps at lr 0.05)
 
 __device__ __forceinline__ float2 lazy_scalars_at(const LazyCtx& c, long long t) {
   return c.scalars[t < c.scalars_cap ? t : c.scalars_cap - 1];
@@ -133,10 +134,10 @@ __device__ __forceinline__ void lazy_scalar_step(const LazyCtx& c, const OptScal
 // rows to lose the claim.
 template <int MODE>
 __device__ __forceinline__ int64_t lazy_entry(const LazyCtx& c, const hiprec_lazy_rows& rows, int64_t e, bool* is_item) {
-  const int64_t n0 = MODE == 2 ? c.n_users : rows.n_users, n1 = MODE == 2 ? c.n_items : rows.n_items_a;
-  const int64_t n2 = MODE == 2 ? 0 : rows.n_items_b;
+  const int64_t n0 = MODE >= 2 ? c.n_users : rows.n_users, n1 = MODE >= 2 ? c.n_items : rows.n_items_a;
+  const int64_t n2 = MODE >= 2 ? 0 : rows.n_items_b;
   *is_item = e >= n0;
-  if constexpr (MODE == 2) return e < n0 ? e : e - n0;
+  if constexpr (MODE >= 2) return e < n0 ? e : e - n0;
   auto at = [&](auto* list, int64_t k) -> int64_t {
     const int64_t id = list[k];
     return k > 0 && static_cast<int64_t>(list[k - 1]) == id ? -1 : id;
@@ -149,8 +150,11 @@ __device__ __forceinline__ int64_t lazy_entry(const LazyCtx& c, const hiprec_laz
 
 // Who works on a row (one lane per row calls this): `old` = the stamp found, returns whether the caller owns the row
 // for this launch.
+// MODE 2 / 3 = the two launches of a flush (vector kernels, Adam): 2 takes the rows that lag by at most max_gap steps
+// and runs the plain walk only, 3 takes whatever still lags afterwards with the bounded replay compiled in (its rows'
+// bias elements are fetched after the claim: on most flushes it claims nothing and only reads the stamps).
 template <int MODE>
-__device__ __forceinline__ bool lazy_claim(int32_t* sp, int target, int* old_out) {
+__device__ __forceinline__ bool lazy_claim(int32_t* sp, int target, int* old_out, int max_gap = 0x7fffffff) {
   int old = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   bool go = false;
   if constexpr (MODE == 0) {   // raise the W_AHEAD flag: the first to set it owns the row
@@ -164,7 +168,7 @@ __device__ __forceinline__ bool lazy_claim(int32_t* sp, int target, int* old_out
       go = old != target;
     }
   } else {                     // flush: one visitor per row; a never-touched row stays -1
-    go = old >= 0 && (old & ~kWAhead) < target;
+    go = old >= 0 && (old & ~kWAhead) < target && target - (old & ~kWAhead) <= max_gap;
     if (go) *sp = target;
   }
   *old_out = old;
@@ -198,7 +202,7 @@ __device__ __forceinline__ void lazy_rows_vec_body(const LazyCtx& c, const hipre
   float ss_now = s.lr, bc2_now = 1.f;
   if constexpr (MODE == 1) step_scalars<KIND>(s, stats, &ss_now, &bc2_now);
   const int64_t nu = c.n_users, ni = c.n_items;
-  const int64_t total = MODE == 2 ? nu + ni : rows.n_users + rows.n_items_a + rows.n_items_b + rows.n_items_c;
+  const int64_t total = MODE >= 2 ? nu + ni : rows.n_users + rows.n_items_a + rows.n_items_b + rows.n_items_c;
   const int64_t n_chunks = (total + kWave - 1) / kWave;
   const int target = static_cast<int>(clock);
   const long long last = MODE == 1 ? clock - 1 : clock;
@@ -207,10 +211,11 @@ __device__ __forceinline__ void lazy_rows_vec_body(const LazyCtx& c, const hipre
   // The zero-gradient steps (base, last] of this lane's N elements; `on` = this lane has any, `first` (uniform) = the
   // oldest stamp of the wave's lanes that are on, + 1: the wave walks from there in blocks of 64 steps (lane k of
   // `mine` holds the scalars of step tb + k), a lane joins when t passes its own stamp.
-  // `frozen` (uniform over the wave): every lane's weights have stopped moving (see BOUNDED REPLAY above) -- from then on
-  // only the moments are replayed, and a catch-up is finished.  RMSprop's zero-gradient step never moves w.
-  auto replay_block = [&](auto& w, auto& m, auto& v, bool on, int base, bool w_ahead, long long tb, float2 mine,
-                          bool& frozen) __attribute__((always_inline)) {
+  // The plain block: every zero-gradient step in full (or, for rows a catch-up already moved, the moments alone).  The
+  // first kFreezeStart steps of every walk take it -- the common case, a row that lags a few dozen steps, runs the
+  // instruction stream it always ran.
+  auto replay_block_plain = [&](auto& w, auto& m, auto& v, bool on, int base, bool w_ahead, long long tb, float2 mine)
+                                __attribute__((always_inline)) {
     constexpr int N = sizeof(w) / sizeof(w[0]);
     const int cnt = static_cast<int>(last - tb + 1 < kWave ? last - tb + 1 : kWave);
     for (int k = 0; k < cnt; ++k) {
@@ -219,14 +224,41 @@ __device__ __forceinline__ void lazy_rows_vec_body(const LazyCtx& c, const hipre
         sc.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), k));
         sc.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), k));
       }
+      if (!(on && tb + k > base)) continue;
+      // w is current already: only the moments (one fma and one multiply per step).  A flush meets the flag only when
+      // a step was abandoned between its catch-up and its update (an error return in between): w must not take the
+      // zero-gradient steps a second time
+      if (MODE != 0 && w_ahead) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          float zero = 0.f, w_unused = 0.f;
+          opt_update<KIND>(w_unused, zero, m[j], v[j], s, 1.f, 1.f);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          float zero = 0.f;
+          opt_update<KIND, true>(w[j], zero, m[j], v[j], s, sc.x, sc.y);
+        }
+      }
+    }
+  };
+  // The checked block (walks longer than kFreezeStart steps): the plain block plus, every kFreezeEvery-th step, the
+  // test of BOUNDED REPLAY.  Returns the index of the step after which no weight of the wave moves any more, -1 if
+  // there is none in this block.  (Kept apart from the moments-only loop below: folded into one loop the compiler
+  // predicates both paths and the frozen steps cost what the full ones do -- measured, call 9.)
+  auto replay_block_checked = [&](auto& w, auto& m, auto& v, bool on, int base, bool w_ahead, long long tb, float2 mine)
+                                  __attribute__((always_inline)) -> int {
+    constexpr int N = sizeof(w) / sizeof(w[0]);
+    const int cnt = static_cast<int>(last - tb + 1 < kWave ? last - tb + 1 : kWave);
+    for (int k = 0; k < cnt; ++k) {
+      const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), k));
+      const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), k));
       const bool act = on && tb + k > base;
-      const bool check = kAdam && !frozen && (k % kFreezeEvery) == kFreezeEvery - 1 && tb + k >= c.freeze_from;
+      const bool check = (k % kFreezeEvery) == kFreezeEvery - 1 && tb + k >= c.freeze_from;
       bool moved = false;
       if (act) {
-        // w is current already: only the moments (one fma and one multiply per step).  A flush meets the w-ahead flag
-        // only when a step was abandoned between its catch-up and its update (an error return in between): w must not
-        // take the zero-gradient steps a second time
-        if (MODE != 0 && (w_ahead || frozen)) {
+        if (MODE != 0 && w_ahead) {
 #pragma unroll
           for (int j = 0; j < N; ++j) {
             float zero = 0.f, w_unused = 0.f;
@@ -237,18 +269,29 @@ __device__ __forceinline__ void lazy_rows_vec_body(const LazyCtx& c, const hipre
           for (int j = 0; j < N; ++j) {
             float zero = 0.f;
             const float w0 = w[j];
-            opt_update<KIND, true>(w[j], zero, m[j], v[j], s, sc.x, sc.y);
+            opt_update<KIND, true>(w[j], zero, m[j], v[j], s, sx, sy);
             if (check) moved |= w[j] != w0 || !(__builtin_fabsf(w0) >= c.freeze_wmin || m[j] == 0.f);
           }
         }
       }
-      if (check) {
-        // a lane holds the wave back while it has yet to join the walk, or while a weight of its still moves
-        const bool pending = on && !(MODE != 0 && w_ahead) && (!act || moved);
-        if (__ballot(pending) == 0ull) {
-          frozen = true;
-          if constexpr (MODE == 0) return;   // a catch-up stores w only: nothing is left to do
-        }
+      // a lane holds the wave back while it has yet to join the walk, or while a weight of its still moves
+      if (check && __ballot(on && !(MODE != 0 && w_ahead) && (!act || moved)) == 0ull) return k;
+    }
+    return -1;
+  };
+  // n_lane zero-gradient steps of the MOMENTS alone (one fma + one multiply per element and step, no per-step scalars)
+  auto decay_only = [&](auto& m, auto& v, int n_lane) __attribute__((always_inline)) {
+    constexpr int N = sizeof(m) / sizeof(m[0]);
+    int n_max = n_lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_max = max(n_max, __shfl_xor(n_max, o));
+    n_max = __builtin_amdgcn_readfirstlane(n_max);
+    for (int i = 0; i < n_max; ++i) {
+      if (i >= n_lane) continue;
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        float zero = 0.f, w_unused = 0.f;
+        opt_update<KIND>(w_unused, zero, m[j], v[j], s, 1.f, 1.f);
       }
     }
   };
@@ -258,19 +301,29 @@ __device__ __forceinline__ void lazy_rows_vec_body(const LazyCtx& c, const hipre
   auto replay = [&](auto& w, auto& m, auto& v, bool on, int base, bool w_ahead, int first, float2 pre, int pre_tb)
                     __attribute__((always_inline)) {
     if (first > last) return;
-    bool frozen = !kAdam;
+    if constexpr (!kAdam) {   // RMSprop's zero-gradient step leaves w alone: v decays, that is all
+      decay_only(m, v, on ? static_cast<int>(last - base) : 0);
+      return;
+    }
     long long tb = first;
     if (first == pre_tb) {
-      replay_block(w, m, v, on, base, w_ahead, tb, pre, frozen);
+      replay_block_plain(w, m, v, on, base, w_ahead, tb, pre);
       tb += kWave;
     }
     for (; tb <= last; tb += kWave) {
-      if (MODE == 0 && frozen) return;
-      float2 mine = make_float2(s.lr, 1.f);
-      if constexpr (kAdam) {
-        if (!frozen) mine = lazy_scalars_at(c, tb + lane);   // (the moments' decay needs no per-step scalars)
+      const float2 mine = lazy_scalars_at(c, tb + lane);
+      // (an Adam update launch follows a catch-up: its rows are w-ahead, their replay is the moments' anyway; the first
+      // launch of a flush takes only rows whose walk is shorter than kFreezeStart)
+      if (MODE == 1 || MODE == 2 || tb - first < kFreezeStart) {
+        replay_block_plain(w, m, v, on, base, w_ahead, tb, mine);
+        continue;
       }
-      replay_block(w, m, v, on, base, w_ahead, tb, mine, frozen);
+      const int kz = replay_block_checked(w, m, v, on, base, w_ahead, tb, mine);
+      if (kz < 0) continue;
+      // no weight of the wave moves after step tb + kz, and every lane has joined the walk by then: a catch-up (which
+      // stores w only) is done, the others let the moments decay over the steps that are left
+      if constexpr (MODE != 0) decay_only(m, v, on ? static_cast<int>(last - (tb + kz)) : 0);
+      return;
     }
   };
 
@@ -299,12 +352,22 @@ __device__ __forceinline__ void lazy_rows_vec_body(const LazyCtx& c, const hipre
       const bool ent = id >= 0;
       bat = bias0 + (is_item ? nu : 0) + (ent ? id : 0);
       // the bias element, issued before the claim (a lost claim wastes the loads, a won one has them in hand)
-      if (kHasW) bw[0] = c.w[bat];
-      if constexpr (kAdam) bm[0] = c.m[bat];
-      bv[0] = c.v[bat];
-      if constexpr (MODE == 1) bg[0] = c.g[bat];
-      if (ent) go = lazy_claim<MODE>((is_item ? c.stamp_i : c.stamp_u) + id, target, &old);
+      if constexpr (MODE != 3) {
+        if (kHasW) bw[0] = c.w[bat];
+        if constexpr (kAdam) bm[0] = c.m[bat];
+        bv[0] = c.v[bat];
+        if constexpr (MODE == 1) bg[0] = c.g[bat];
+      }
+      if (ent) go = lazy_claim<MODE>((is_item ? c.stamp_i : c.stamp_u) + id, target, &old,
+                                     MODE == 2 && kAdam ? kFreezeStart : 0x7fffffff);
       if (MODE != 1 && old < 0) go = false;   // never touched: m = v = 0, nothing to replay
+      if constexpr (MODE == 3) {
+        if (go) {
+          bw[0] = c.w[bat];
+          if constexpr (kAdam) bm[0] = c.m[bat];
+          bv[0] = c.v[bat];
+        }
+      }
       const int n_act = __popcll(__ballot(go));
       if (n_act > 0) {
         const int key = !go ? 0x7fffffff : (old < 0 ? 0x7ffffffe : (old & ~kWAhead));
@@ -420,9 +483,11 @@ __device__ __forceinline__ void lazy_rows_vec_body(const LazyCtx& c, const hipre
   if constexpr (MODE == 1) lazy_scalar_step<KIND>(c, s, stats, scratch, clock, ss_now, bc2_now, bid);
 }
 
+// (the catch-up is the launch every step waits for: held to the 72 VGPRs = seven waves per SIMD it had before the
+// checked block was added)
 template <int KIND, int MODE, int LPR>
-__global__ __launch_bounds__(kBlock) void lazy_rows_vec_kernel(LazyCtx c, hiprec_lazy_rows rows, OptScalars s,
-                                                               hiprec_stats* stats, const Scratch* scratch) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? 7 : 1)))
+void lazy_rows_vec_kernel(LazyCtx c, hiprec_lazy_rows rows, OptScalars s, hiprec_stats* stats, const Scratch* scratch) {
   lazy_rows_vec_body<KIND, MODE, LPR>(c, rows, s, stats, scratch, static_cast<int>(blockIdx.x),
                                       static_cast<int>(gridDim.x));
 }
@@ -441,7 +506,8 @@ __global__ __launch_bounds__(kBlock) void lazy_dual_kernel(LazyCtx c1, hiprec_la
 #endif
 
 
-// MODE 0 = catch-up (to the clock), 1 = update (the step the clock shows), 2 = flush (all rows, to the clock)
+// MODE 0 = catch-up (to the clock), 1 = update (the step the clock shows), 2 = flush (all rows, to the clock; the vector
+// kernels take an Adam flush in two launches, MODE 2 then MODE 3: see lazy_claim)
 // (declared before the kernels that use them)
 
 template <int KIND, int MODE>
@@ -532,7 +598,7 @@ __global__ __launch_bounds__(kBlock) void lazy_rows_kernel(LazyCtx c, hiprec_laz
       }
       float2 sc = make_float2(s.lr, 1.f);
       if constexpr (KIND == HIPREC_OPT_ADAM) sc = lazy_scalars_at(c, t);
-      const bool check = (t - base) % kFreezeEvery == 0 && t >= c.freeze_from;
+      const bool check = t - base >= kFreezeStart && (t - base) % kFreezeEvery == 0 && t >= c.freeze_from;
       bool moved = false;
 #pragma unroll
       for (int j = 0; j <= kLazyMaxNpl; ++j) {
@@ -577,8 +643,8 @@ __global__ __launch_bounds__(kBlock) void lazy_rows_kernel(LazyCtx c, hiprec_laz
 // parts of a shared row's gradient are summed.  dim % 4 == 0.
 template <int KIND, int LPR>
 __global__ __launch_bounds__(kPullBlock) __attribute__((amdgpu_waves_per_eu(8)))
-void lazy_pull_apply_kernel(PullApply f, LazyCtx c, OptScalars s, hiprec_stats* stats, const Scratch* scratch,
-                            int k_step, int n_steps_epoch) {
+void lazy_pull_apply_kernel(PullApply f, LazyCtx c, OptScalars s,
+                                                                     hiprec_stats* stats, const Scratch* scratch) {
   constexpr int RPW = kWave / LPR;
   constexpr int GROUPS = kPullWaves * RPW;
   constexpr int DEPTH = 2;   // (most rows of a batch have ONE part; 64 VGPRs = two workgroups per CU)
@@ -637,7 +703,7 @@ void lazy_pull_apply_kernel(PullApply f, LazyCtx c, OptScalars s, hiprec_stats* 
     }
     return r;
   };
-  auto finish_row = [&](Row& r, bool on, float4 g, float gb, int next_k) __attribute__((always_inline)) {
+  auto finish_row = [&](Row& r, bool on, float4 g, float gb) __attribute__((always_inline)) {
     // zero-gradient steps (base, clock - 1]: the moments only (w is current: it was caught up before the gradients
     // were taken, or the row did not lag; RMSprop's zero-gradient step leaves w alone)
     const int base = r.old < 0 ? -1 : (r.old & ~kWAhead);
@@ -658,55 +724,6 @@ void lazy_pull_apply_kernel(PullApply f, LazyCtx c, OptScalars s, hiprec_stats* 
     float gg[5] = {g.x, g.y, g.z, g.w, gb};
 #pragma unroll
     for (int j = 0; j < 5; ++j) opt_update<KIND>(r.w[j], gg[j], r.m[j], r.v[j], s, ss_now, bc2_now);
-    // NEXT-USE ADVANCE (n_steps_epoch > 0): the staged epoch says in which of its steps the row is needed next (next_k;
-    // n_steps_epoch = not again).  The zero-gradient steps up to there are taken NOW, while the row is in registers --
-    // with the scalars of those future steps, which depend on the step number only (lazy_scalars_ahead_kernel has
-    // tabulated them): the row is current when its next step reads it (no catch-up: that launch then only has the
-    // rows an epoch meets for the first time), rows the epoch does not meet again are current as of its last step (no
-    // flush for them), and w, m, v cross memory once per occurrence instead of twice.  The same operations in the same
-    // order as the catch-up / the dense sweep would have made them; weights that stop moving are left alone as in
-    // lazy_rows_vec_body (BOUNDED REPLAY).
-    int n_fwd = on && n_steps_epoch > 0 && next_k > k_step && next_k <= n_steps_epoch ? next_k - k_step - 1 : 0;
-    int f_max = n_fwd;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) f_max = max(f_max, __shfl_xor(f_max, o));
-    f_max = __builtin_amdgcn_readfirstlane(f_max);
-    bool frozen = !kAdam;
-    for (int j0 = 0; j0 < f_max; j0 += kWave) {
-      float2 mine = make_float2(s.lr, 1.f);
-      if constexpr (kAdam) {
-        if (!frozen) mine = lazy_scalars_at(c, static_cast<long long>(target) + 1 + j0 + lane);
-      }
-      const int cnt = f_max - j0 < kWave ? f_max - j0 : kWave;
-      for (int k = 0; k < cnt; ++k) {
-        float2 sc = make_float2(s.lr, 1.f);
-        if constexpr (kAdam) {
-          sc.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), k));
-          sc.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), k));
-        }
-        const bool act = j0 + k < n_fwd;
-        const bool check = kAdam && !frozen && (k % kFreezeEvery) == kFreezeEvery - 1 && target + 1 + j0 + k >= c.freeze_from;
-        bool moved = false;
-        if (act) {
-          if (frozen) {
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-              float zero = 0.f, w_unused = 0.f;
-              opt_update<KIND>(w_unused, zero, r.m[j], r.v[j], s, 1.f, 1.f);
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-              float zero = 0.f;
-              const float w0 = r.w[j];
-              opt_update<KIND, true>(r.w[j], zero, r.m[j], r.v[j], s, sc.x, sc.y);
-              if (check) moved |= r.w[j] != w0 || !(__builtin_fabsf(w0) >= c.freeze_wmin || r.m[j] == 0.f);
-            }
-          }
-        }
-        if (check && __ballot(act && moved) == 0ull) frozen = true;
-      }
-    }
     if (!on) return;
     int64_t ro, bo;
     pull_row_of(f, r.key, sl, &ro, &bo);
@@ -719,7 +736,7 @@ void lazy_pull_apply_kernel(PullApply f, LazyCtx c, OptScalars s, hiprec_stats* 
       c.w[bo] = r.w[4];
       c.v[bo] = r.v[4];
       if constexpr (kAdam) c.m[bo] = r.m[4];
-      *(r.key < f.n_users ? c.stamp_u + r.key : c.stamp_i + (r.key - f.n_users)) = target + n_fwd;
+      *(r.key < f.n_users ? c.stamp_u + r.key : c.stamp_i + (r.key - f.n_users)) = target;
     }
   };
 
@@ -743,7 +760,7 @@ void lazy_pull_apply_kernel(PullApply f, LazyCtx c, OptScalars s, hiprec_stats* 
         tb += s_pb[q];
       }
       Row r = load_row(sub == 0, rec.x);
-      finish_row(r, sub == 0, tot, tb, rec.w);
+      finish_row(r, sub == 0, tot, tb);
     }
     __syncthreads();
   }
@@ -762,32 +779,9 @@ void lazy_pull_apply_kernel(PullApply f, LazyCtx c, OptScalars s, hiprec_stats* 
     float gb = 0.f;
     Row r = load_row(on, rec.x);                 // stamp, weights, moments: requested with the gradient parts
     pull_sum_range<LPR, DEPTH>(f, rec.y, 0, rec.z, 1, trips, sl, col, g, gb);
-    const int next_k = rec.w;
     const int nxt = i0 + nb * GROUPS + sub;
     if (nxt < n_short) rec = f.rows[nxt];
-    finish_row(r, on, g, gb, next_k);
-  }
-}
-
-// The per-step scalars of the n_ahead steps AFTER the clock, tabulated before they are taken (the next-use advance of
-// lazy_pull_apply_kernel replays zero-gradient steps the clock has not reached yet): one thread walks the powers exactly
-// as the steps themselves will -- advance_step, step_scalars, the reciprocal lazy_scalar_step records -- so step t
-// later records the bits that are already there.  A few dozen nanoseconds per step, once per enqueued piece of an epoch.
-template <int KIND>
-__global__ void lazy_scalars_ahead_kernel(LazyCtx c, OptScalars s, const hiprec_stats* stats, int64_t n_ahead) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  hiprec_stats loc = *stats;
-  for (int64_t i = 0; i < n_ahead; ++i) {
-    advance_step(&loc);
-    if (loc.step >= c.scalars_cap) return;   // beyond the table the corrections have converged (validated at set-up)
-    float ss = s.lr, bc2 = 1.f;
-    step_scalars<KIND>(s, &loc, &ss, &bc2);
-#ifdef HIPREC_IEEE_DIV
-    const float bc2_rec = bc2;
-#else
-    const float bc2_rec = __builtin_amdgcn_rcpf(bc2);
-#endif
-    if (loc.step >= 0) c.scalars[loc.step] = make_float2(ss, bc2_rec);
+    finish_row(r, on, g, gb);
   }
 }
 
@@ -841,6 +835,8 @@ int lazy_launch(const hiprec_lazy_state* st, const hiprec_lazy_rows* rows, const
     const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((total + kWave - 1) / kWave, kMaxBlocks))); \
     if (adam) lazy_rows_vec_kernel<HIPREC_OPT_ADAM, MODE, LPR><<<grid, kBlock, 0, stm>>>(c, r, s, stats, sc);        \
     else lazy_rows_vec_kernel<HIPREC_OPT_RMSPROP, MODE, LPR><<<grid, kBlock, 0, stm>>>(c, r, s, stats, sc);          \
+    if (adam && MODE == 2)   /* the rows that lag by more than kFreezeStart steps: bounded replay */                 \
+      lazy_rows_vec_kernel<HIPREC_OPT_ADAM, MODE == 2 ? 3 : MODE, LPR><<<grid, kBlock, 0, stm>>>(c, r, s, stats, sc); \
   } while (0)
     if (st->dim <= 64) HIPREC_LAZY_VEC(16);
     else if (st->dim <= 128) HIPREC_LAZY_VEC(32);
@@ -953,15 +949,10 @@ extern "C" int hiprec_mf_epoch_lazy_owned(const hiprec_lazy_state* state, const 
 extern "C" int hiprec_mf_epoch_lazy_pull(const hiprec_lazy_state* state, const int64_t* users, const int64_t* pos,
                                          const int64_t* neg, const int32_t* cidx, int64_t cidx_stride,
                                          const int32_t* rows, int64_t row_cap, const int32_t* counts, float* cbuf,
-                                         float* cbias, int64_t n, int64_t batch, int32_t first_of_epoch,
-                                         int64_t step0, int64_t n_steps_epoch, float reg_coef, hiprec_stats* stats,
-                                         void* scratch, void* stream) {
+                                         float* cbias, int64_t n, int64_t batch, int32_t first_of_epoch, float reg_coef,
+                                         hiprec_stats* stats, void* scratch, void* stream) {
   HIPREC_REQUIRE(state && stats && scratch, "NULL pointer");
   HIPREC_REQUIRE(state->kind == HIPREC_OPT_ADAM || state->kind == HIPREC_OPT_RMSPROP, "lazy state is Adam's or RMSprop's");
-  HIPREC_REQUIRE(n_steps_epoch == 0 || (step0 >= 0 && step0 + (n + batch - 1) / batch <= n_steps_epoch &&
-                                        n_steps_epoch < (1ll << 30)),
-                 "next-use advance: steps [%lld, %lld) do not lie in an epoch of %lld steps", (long long)step0,
-                 (long long)(step0 + (n + batch - 1) / batch), (long long)n_steps_epoch);
   HIPREC_REQUIRE(state->w && state->g && state->v && (state->kind != HIPREC_OPT_ADAM || state->m) && state->stamp_u &&
                      state->stamp_i, "NULL buffer in the lazy optimizer state");
   HIPREC_REQUIRE(state->kind != HIPREC_OPT_ADAM || (state->scalars && state->scalars_cap >= 2), "Adam needs the scalars table");
@@ -973,9 +964,8 @@ extern "C" int hiprec_mf_epoch_lazy_pull(const hiprec_lazy_state* state, const i
     if (int rc = hiprec_stats_begin_epoch(stats, stream)) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int32_t dim = state->dim;
-  LazyCtx c{state->w, state->g, state->m, state->v, state->n_users, state->n_items, dim, state->stamp_u,
-            state->stamp_i, reinterpret_cast<float2*>(state->scalars), state->scalars_cap, 0x7fffffff, 0.f};
-  c.freeze_from = lazy_freeze_from(state->beta1, state->beta2, state->lr, state->eps, &c.freeze_wmin);
+  const LazyCtx c{state->w, state->g, state->m, state->v, state->n_users, state->n_items, dim, state->stamp_u,
+                  state->stamp_i, reinterpret_cast<float2*>(state->scalars), state->scalars_cap, 0x7fffffff, 0.f};
   const OptScalars s{state->lr, static_cast<float>(state->lr), static_cast<float>(state->beta2),
                      static_cast<float>(1.0 - state->beta1), static_cast<float>(1.0 - state->beta2),
                      static_cast<float>(state->eps)};
@@ -994,8 +984,6 @@ extern "C" int hiprec_mf_epoch_lazy_pull(const hiprec_lazy_state* state, const i
   a.gb = nullptr;
   a.lr = static_cast<float>(state->lr);
   const bool adam = state->kind == HIPREC_OPT_ADAM;
-  if (n_steps_epoch > 0 && adam && n > 0)   // the scalars of the steps this epoch has yet to take (RMSprop has none)
-    lazy_scalars_ahead_kernel<HIPREC_OPT_ADAM><<<1, 1, 0, st>>>(c, s, stats, n_steps_epoch - step0);
   for (int64_t off = 0, k = 0; off < n; off += batch, ++k) {
     const int64_t b = std::min<int64_t>(batch, n - off);  // drop_last = False
     const hiprec_lazy_rows lists{users + off, b, pos + off, b, neg + off, b, nullptr, 0};
@@ -1010,11 +998,10 @@ extern "C" int hiprec_mf_epoch_lazy_pull(const hiprec_lazy_state* state, const i
     const int64_t per_block = kPullWaves * (dim <= 64 ? 4 : dim <= 128 ? 2 : 1);
     const int grid = static_cast<int>(std::min<int64_t>((3 * b + per_block - 1) / per_block, 512)) + 1;
     const auto* sc = static_cast<const Scratch*>(scratch);
-    const int ks = static_cast<int>(step0 + k), ne = static_cast<int>(n_steps_epoch);
 #define HIPREC_LAZY_PULL(LPR)                                                                                      \
   do {                                                                                                             \
-    if (adam) lazy_pull_apply_kernel<HIPREC_OPT_ADAM, LPR><<<grid, kPullBlock, 0, st>>>(a, c, s, stats, sc, ks, ne); \
-    else lazy_pull_apply_kernel<HIPREC_OPT_RMSPROP, LPR><<<grid, kPullBlock, 0, st>>>(a, c, s, stats, sc, ks, ne);   \
+    if (adam) lazy_pull_apply_kernel<HIPREC_OPT_ADAM, LPR><<<grid, kPullBlock, 0, st>>>(a, c, s, stats, sc);        \
+    else lazy_pull_apply_kernel<HIPREC_OPT_RMSPROP, LPR><<<grid, kPullBlock, 0, st>>>(a, c, s, stats, sc);          \
   } while (0)
     if (dim <= 64) HIPREC_LAZY_PULL(16);
     else if (dim <= 128) HIPREC_LAZY_PULL(32);

@@ -613,33 +613,6 @@ __global__ __launch_bounds__(kBlock) void group_scatter_kernel(
   }
 }
 
-// ---- when does a row of a batch occur NEXT in the staged epoch? (round 5: csrc/lazy_opt.hip's next-use advance) --------
-// The records of hiprec_batch_row_contrib made with min_contrib = 1 name every row of every batch exactly once.  Walking
-// the batches from the last to the first with one int per table row -- last_seen[key] = the nearest later batch the row
-// occurs in, n_batches = none -- gives every record the batch in which its row is needed next (record field w).  One
-// launch per batch (a batch's records have distinct keys: no two threads of a launch touch the same entry), in order on
-// the staging stream; each is a few microseconds of random 4-byte read-modify-writes.
-__global__ __launch_bounds__(kBlock) void fill_i32_kernel(int32_t* __restrict__ p, int64_t n, int32_t v) {
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock)
-    p[i] = v;
-}
-
-__global__ __launch_bounds__(kBlock) void next_use_kernel(int4* __restrict__ rows, int64_t row_cap,
-                                                          const int32_t* __restrict__ counts, int32_t b,
-                                                          int32_t* __restrict__ last_seen, int64_t n_keys) {
-  int4* rb = rows + static_cast<int64_t>(b) * row_cap;
-  const int n_short = counts[4 * static_cast<int64_t>(b)], n_long = counts[4 * static_cast<int64_t>(b) + 1];
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n_short + n_long;
-       i += static_cast<int64_t>(gridDim.x) * kBlock) {
-    int4* at = i < n_short ? rb + i : rb + (row_cap - 1 - (i - n_short));   // long rows are listed from the end
-    int4 rec = *at;
-    if (static_cast<uint64_t>(rec.x) >= static_cast<uint64_t>(n_keys)) continue;
-    rec.w = last_seen[rec.x];
-    last_seen[rec.x] = b;
-    *at = rec;
-  }
-}
-
 }  // namespace hiprec
 
 using namespace hiprec;
@@ -875,26 +848,6 @@ extern "C" int hiprec_group_epoch_by_item(const int64_t* users, const int64_t* p
                                                                           static_cast<int32_t>(n_users));
   group_scatter_kernel<<<grid_for_threads(n), kBlock, 0, st>>>(users, pos, neg, n, batch, table_bits, own, occ, pos_cnt,
                                                                invalid_cnt, users_out, pos_out, neg_out, own_out);
-  HIPREC_TRY(hipGetLastError());
-  return 0;
-}
-
-// rows / counts: hiprec_batch_row_contrib's arrays made with min_contrib = 1 (row_cap >= 3 * batch); last_seen: work
-// space, int32 [n_users + n_items].  Afterwards the fourth field of every record = the next batch (> its own) in which
-// the record's row occurs, n_batches if none does.
-extern "C" int hiprec_batch_row_next_use(int32_t* rows, int64_t row_cap, const int32_t* counts, int64_t n_batches,
-                                         int64_t n_users, int64_t n_items, int32_t* last_seen, void* stream) {
-  HIPREC_REQUIRE(n_batches >= 0 && n_batches < (1ll << 31) && row_cap > 0 && n_users > 0 && n_items > 0, "bad sizes");
-  HIPREC_REQUIRE(n_users + n_items < (1ll << 31), "row keys need n_users + n_items < 2^31");
-  if (n_batches == 0) return 0;
-  HIPREC_REQUIRE(rows && counts && last_seen, "NULL pointer");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int64_t n_keys = n_users + n_items;
-  fill_i32_kernel<<<grid_for_threads(n_keys), kBlock, 0, st>>>(last_seen, n_keys, static_cast<int32_t>(n_batches));
-  const int grid = static_cast<int>(std::min<int64_t>((row_cap + kBlock - 1) / kBlock, 1024));
-  for (int64_t b = n_batches - 1; b >= 0; --b)
-    next_use_kernel<<<grid, kBlock, 0, st>>>(reinterpret_cast<int4*>(rows), row_cap, counts, static_cast<int32_t>(b),
-                                             last_seen, n_keys);
   HIPREC_TRY(hipGetLastError());
   return 0;
 }

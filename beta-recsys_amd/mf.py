@@ -335,19 +335,15 @@ def batch_row_ownership(users, pos, neg, batch_size, n_users, n_items):
 
 class RowContributions(tuple):
     """(cidx int32 [3, n], rows int32 [n_batches, row_cap, 4], counts int32 [n_batches, 4], row_cap) of a staged
-    epoch: hiprec_batch_row_contrib's arrays for the owner-pulls step (hiprec_mf_bpr_epoch_pull).  ``next_use``: the
-    records also say in which later batch of the epoch their row occurs next (hiprec_batch_row_next_use)."""
-
-    next_use = False
+    epoch: hiprec_batch_row_contrib's arrays for the owner-pulls step (hiprec_mf_bpr_epoch_pull)."""
 
 
-def batch_row_contributions(users, pos, neg, batch_size, n_users, n_items, dim, every_row=False, next_use=False):
+def batch_row_contributions(users, pos, neg, batch_size, n_users, n_items, dim, every_row=False):
     """For an epoch laid out in visiting order: who contributes to which row of a batch (csrc/ownership.hip,
     ``hiprec_batch_row_contrib``).  ``cidx`` -1: the row's only contribution (its contributor updates it in place);
     >= 0: the contribution's place in the step's contribution buffer; -2: a positive occurrence inside its chunk
     neighbour's run.  ``rows`` / ``counts``: the records of the rows with several contributions -- or, ``every_row``
-    (the lazy Adam / RMSprop form), of every row of the batch: then no cidx is -1, and with ``next_use`` every record
-    also names the next batch of the epoch its row occurs in (``hiprec_batch_row_next_use``)."""
+    (the lazy Adam / RMSprop form), of every row of the batch: then no cidx is -1."""
     lib = _lib.load()
     n, dev = users.numel(), users.device
     n_batches = max((n + batch_size - 1) // batch_size, 1)
@@ -363,13 +359,7 @@ def batch_row_contributions(users, pos, neg, batch_size, n_users, n_items, dim, 
         _lib.ptr(users), _lib.ptr(pos), _lib.ptr(neg), n, batch_size, n_users, n_items, bits,
         lib.hiprec_mf_pull_chunk(dim), min_contrib, _lib.ptr(ws), _lib.ptr(cidx), _lib.ptr(rows), row_cap, _lib.ptr(counts),
         _lib.stream_ptr(dev)))
-    out = RowContributions((cidx, rows, counts, row_cap))
-    if every_row and next_use and n > 0:
-        last_seen = torch.empty(n_users + n_items, **i32)   # (work space of this call; the caching allocator keeps it)
-        _lib.check(lib.hiprec_batch_row_next_use(_lib.ptr(rows), row_cap, _lib.ptr(counts), n_batches, n_users, n_items,
-                                                 _lib.ptr(last_seen), _lib.stream_ptr(dev)))
-        out.next_use = True
-    return out
+    return RowContributions((cidx, rows, counts, row_cap))
 
 
 def group_epoch_by_item(users, pos, neg, batch_size, n_users, n_items):
@@ -594,10 +584,6 @@ class MFEngine(ModelEngine):
     def flush_lazy(self):
         """Lazy Adam / RMSprop: replay every lagging row up to the optimizer clock (no-op when nothing lags)."""
         lz = getattr(self, "_lazy", None)
-        if lz is not None and lz.get("ahead"):
-            raise RuntimeError("a lazy epoch is in flight: with next-use advance rows of the tables are ahead of the "
-                               "optimizer clock until the epoch's last step has run -- finish the epoch before reading "
-                               "or checkpointing the state (or train with config['model']['lazy_advance'] = 'none')")
         if lz is not None and lz["dirty"]:
             _lib.check(_lib.load().hiprec_lazy_flush(ctypes.byref(lz["c"]), _lib.ptr(self._stats),
                                                      _lib.stream_ptr(self.model.flat.device)))
@@ -607,7 +593,6 @@ class MFEngine(ModelEngine):
         """After anything that moved the clock with a dense sweep (or reset it): every row is current as of it."""
         lz = getattr(self, "_lazy", None)
         if lz is not None:
-            lz["ahead"] = False     # whatever an unfinished epoch left ahead of the clock has just been replaced
             _lib.check(_lib.load().hiprec_lazy_mark_current(ctypes.byref(lz["c"]), _lib.ptr(self._stats),
                                                             _lib.stream_ptr(self.model.flat.device)))
 
@@ -990,8 +975,7 @@ class MFEngine(ModelEngine):
                                                        self.model.emb_dim)
             elif self._lazy_owned() == "pull" and small_keys:
                 prepared.own = batch_row_contributions(users, pos, neg, bs, self.model.n_users, self.model.n_items,
-                                                       self.model.emb_dim, every_row=True,
-                                                       next_use=self._lazy_advance())
+                                                       self.model.emb_dim, every_row=True)
             else:
                 prepared.own = batch_row_ownership(users, pos, neg, bs, self.model.n_users, self.model.n_items)
         return prepared
@@ -1020,19 +1004,6 @@ class MFEngine(ModelEngine):
         if mode == "pull" and self.model.emb_dim % 4 == 0:
             return "pull"
         return "owned"
-
-    def _lazy_advance(self):
-        """``lazy_advance``: "next_use" (default) -- in a lazy Adam / RMSprop epoch of the owner-pulls form a row's
-        step also takes the zero-gradient steps up to the row's NEXT occurrence in the staged epoch (or up to the
-        epoch's last step), while the row is in registers: rows that recur need no catch-up, rows an epoch has met
-        need no flush, and the state is bit for bit the dense sweeps' once the epoch's last step is done.  Between the
-        first and the last piece of an epoch rows are ahead of the optimizer clock: the state must not be read and no
-        other epoch may start (both raise).  "none": rows only ever lag (round 4 semantics: any piece of an epoch may be
-        followed by a flush and a read)."""
-        mode = self.config["model"].get("lazy_advance", "next_use")
-        if mode not in ("next_use", "none"):
-            raise ValueError(f"lazy_advance must be 'next_use' or 'none', not {mode!r}")
-        return mode == "next_use"
 
     def _fused_ok(self, perm):
         """Cache-sized tables take the one-kernel-per-step epoch driver (any of the three optimizers)."""
@@ -1143,17 +1114,9 @@ class MFEngine(ModelEngine):
         w, g = m.tables(), m.tables(self._g_flat)
         el = third.element_size()
         lz["dirty"] = True
-        if lz.get("ahead") and a == 0:
-            raise RuntimeError("a lazy epoch with next-use advance was left unfinished: rows of the tables are ahead "
-                               "of the optimizer clock and no other epoch can start from them (run the remaining "
-                               "steps of that epoch, or train with config['model']['lazy_advance'] = 'none')")
         if isinstance(own, RowContributions) and self.loss == "bpr" and self._lazy_owned() == "pull":
             cidx, rows, counts, row_cap = own
             n_all = cidx.shape[1]
-            advance = bool(own.next_use) and n_run == n_all    # (a Q4 epoch that drops its last triple: no advance)
-            if lz.get("ahead") and not advance:
-                raise RuntimeError("the epoch in flight was staged with next-use advance: its remaining pieces need "
-                                   "the same staged epoch")
             cap = 3 * min(bs, max(n_all, 1))
             pb = getattr(self, "_pull_bufs", None)
             if pb is None or pb["dev"] != m.flat.device or pb["cap"] < cap:
@@ -1167,10 +1130,8 @@ class MFEngine(ModelEngine):
                 ctypes.c_void_p(items_a.data_ptr() + 8 * lo), ctypes.c_void_p(third.data_ptr() + 8 * lo),
                 ctypes.c_void_p(cidx.data_ptr() + 4 * lo), n_all, ctypes.c_void_p(rows.data_ptr() + 16 * a * row_cap),
                 row_cap, ctypes.c_void_p(counts.data_ptr() + 16 * a), _lib.ptr(pb["cbuf"]), _lib.ptr(pb["cbias"]),
-                hi - lo, bs, 1 if a == 0 else 0, a, n_steps if advance else 0, float(self.reg), _lib.ptr(self._stats),
-                _lib.ptr(self._scratch), _lib.stream_ptr(m.flat.device)))
-            if b > a:
-                lz["ahead"] = advance and b < n_steps
+                hi - lo, bs, 1 if a == 0 else 0, float(self.reg), _lib.ptr(self._stats), _lib.ptr(self._scratch),
+                _lib.stream_ptr(m.flat.device)))
             if b == n_steps:
                 self.flush_lazy()
             return

@@ -378,12 +378,6 @@ int64_t hiprec_contrib_row_cap(int64_t batch, int32_t min_contrib);
 int hiprec_batch_row_contrib(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t n, int64_t batch,
                              int64_t n_users, int64_t n_items, int32_t table_bits, int32_t chunk, int32_t min_contrib,
                              int32_t* ws, int32_t* cidx, int32_t* rows, int64_t row_cap, int32_t* counts, void* stream);
-/* The records of a min_contrib = 1 call name every row of every batch exactly once: afterwards field 3 of a record =
- * the next batch (> its own) of this staged epoch in which the record's row occurs, n_batches if none does (one short
- * launch per batch, last to first, over last_seen: int32 [n_users + n_items] of work space).  What the next-use
- * advance of hiprec_mf_epoch_lazy_pull reads. */
-int hiprec_batch_row_next_use(int32_t* rows, int64_t row_cap, const int32_t* counts, int64_t n_batches, int64_t n_users,
-                              int64_t n_items, int32_t* last_seen, void* stream);
 int hiprec_mf_bpr_epoch_pull(float* w_flat, int64_t n_users, int64_t n_items, int32_t dim, const int64_t* users,
                              const int64_t* pos, const int64_t* neg, const int32_t* cidx, int64_t cidx_stride,
                              const int32_t* rows, int64_t row_cap, const int32_t* counts, float* cbuf, float* cbias,
@@ -681,18 +675,12 @@ int hiprec_mf_epoch_lazy_owned(const hiprec_lazy_state* state, const int64_t* us
  * rows / counts: hiprec_batch_row_contrib's arrays made with min_contrib = 1, offset to this piece's first step
  * (cidx_stride = the n they were made for); cbuf [3 * batch, dim], cbias [3 * batch]: work space.  BPR, dim % 4 == 0.
  * Same semantics as hiprec_mf_epoch_lazy_owned (beta_rec/models/mf.py:121-139 with torch.optim.Adam / RMSprop,
- * models/torch_engine.py:30-39); the caller flushes afterwards.
- * NEXT-USE ADVANCE (n_steps_epoch > 0; the records carry hiprec_batch_row_next_use's field): this piece is steps
- * [step0, step0 + ceil(n / batch)) of an epoch of n_steps_epoch steps that WILL be run to its end.  A row's apply then
- * also takes the zero-gradient steps up to the row's next occurrence in the epoch (or up to the epoch's last step)
- * while the row is in registers: rows that recur need no catch-up, rows the epoch has met need no flush, bit for bit
- * the same state once the epoch's last step is done.  In between rows are AHEAD of the optimizer clock: nothing but
- * the remaining pieces of this epoch may touch the state.  n_steps_epoch = 0: no row ever runs ahead. */
+ * models/torch_engine.py:30-39); the caller flushes afterwards. */
 int hiprec_mf_epoch_lazy_pull(const hiprec_lazy_state* state, const int64_t* users, const int64_t* pos,
                               const int64_t* neg, const int32_t* cidx, int64_t cidx_stride, const int32_t* rows,
                               int64_t row_cap, const int32_t* counts, float* cbuf, float* cbias, int64_t n,
-                              int64_t batch, int32_t first_of_epoch, int64_t step0, int64_t n_steps_epoch,
-                              float reg_coef, hiprec_stats* stats, void* scratch, void* stream);
+                              int64_t batch, int32_t first_of_epoch, float reg_coef, hiprec_stats* stats, void* scratch,
+                              void* stream);
 
 /* ---- ONE launch of that sequence, with the buffers of this step named explicitly: for callers that
  *      have to do something between two steps -- the data-parallel engine all-reduces

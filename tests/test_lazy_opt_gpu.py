@@ -221,7 +221,8 @@ def test_bounded_replay_of_rows_that_lag_for_hundreds_of_steps_bit_for_bit(hip_d
     dense sweeps; blocks of rows are touched once early (steps 3-8, 30-33) and again after 250-690 steps, others get
     their first gradient late; among the weights are zeros, denormals and values around 1e-31 (below the magnitude
     from which the early exit may be taken), and gradients from 1e-12 to 10 (moments that underflow, and moments that
-    keep the weights moving for longer than the typical 150-200 steps).  After every catch-up the step's rows hold the
+    keep the weights moving for longer than the typical 150-200 steps; the exit is not looked for before a walk is 192
+    steps long).  After every catch-up the step's rows hold the
     dense sweeps' weights; after the final flush w, m, v are bit-identical everywhere."""
     from beta_recsys_amd import _lib
 
@@ -535,98 +536,6 @@ def test_lazy_pull_step_is_the_three_launch_step_bit_for_bit_where_no_row_repeat
         if a is not None:
             assert torch.equal(a, b), f"{name}: {int((a != b).sum())} elements differ between the two forms"
     assert out["pull"][5] == pytest.approx(out["owned"][5], rel=1e-6)
-
-
-@pytest.mark.parametrize("optimizer,lr,D", [("adam", 0.05, 64), ("adam", 0.05, 128), ("rmsprop", 0.01, 64)])
-def test_next_use_advance_leaves_the_bits_of_the_lagging_form(hip_device, optimizer, lr, D):
-    """NEXT-USE ADVANCE (hiprec_mf_epoch_lazy_pull with n_steps_epoch > 0, hiprec_batch_row_next_use): a row's step also
-    takes the zero-gradient steps up to the row's next occurrence in the staged epoch -- with the scalars of steps the
-    clock has not reached (lazy_scalars_ahead_kernel) -- instead of a catch-up when that occurrence comes, and rows the
-    epoch does not meet again are advanced to its last step instead of flushed.  Three epochs of 12 steps (items that
-    recur nearly every step, users that come back after 1-11 steps, users met once per epoch, users never met), the
-    second epoch enqueued in pieces: weights, both moments and stamps must equal, BIT FOR BIT, the same engine with
-    `lazy_advance: "none"` (rows only lag: catch-up + flush).  While a pieced epoch is in flight the state cannot be
-    read and no other epoch can start."""
-    import beta_recsys_amd as hp
-    from test_mf_gpu import load_weights, make_engine
-
-    U, I, B, steps = 4000, 700, 256, 12
-    rng = np.random.default_rng(D + len(optimizer))
-    w0 = onp.init_params(U, I, D, seed=6)
-    epochs = []
-    for _ in range(3):
-        # no row twice in a batch (every gradient element is one term: the comparison below can ask for equal bits),
-        # but rows that come back: 192 of a pool of 800 users per step, items from all 700 every step, and 64 users per
-        # step that the epoch meets exactly once
-        once = 800 + rng.permutation(2200)
-        us, ps, ns = [], [], []
-        for k in range(steps):
-            u = np.concatenate([rng.permutation(800)[:192], once[64 * k:64 * (k + 1)]])
-            items = rng.permutation(I)[: 2 * B]
-            us.append(u[rng.permutation(B)])
-            ps.append(items[:B])
-            ns.append(items[B:])
-        epochs.append(tuple(torch.from_numpy(np.concatenate(a).astype(np.int64)).cuda() for a in (us, ps, ns)))
-    out = {}
-    for mode in ("next_use", "none"):
-        eng = make_engine(U, I, D, optimizer, "bpr", lr, B, dense_opt="lazy", lazy_grad="pull", lazy_advance=mode,
-                          prefetch_epoch=False)
-        load_weights(eng, w0)
-        eng._setup()
-        assert eng._lazy_owned() == "pull" and eng._lazy_advance() == (mode == "next_use")
-        with contextlib.redirect_stdout(io.StringIO()):
-            for e, triples in enumerate(epochs):
-                loader = hp.DeviceTripleBatcher(*triples, B, shuffle=False)
-                if e != 1:
-                    eng.train_an_epoch(loader, e)
-                    continue
-                prepared = eng.prepare_epoch(loader)
-                assert prepared.own.next_use == (mode == "next_use")
-                for piece in ((0, 5), (5, 5), (5, 6)):
-                    eng.run_prepared_epoch(prepared, sync=False, steps=piece)
-                if mode == "next_use":
-                    assert eng._lazy["ahead"]
-                    with pytest.raises(RuntimeError, match="ahead of the optimizer clock"):
-                        eng.flush_lazy()
-                    with pytest.raises(RuntimeError, match="left unfinished"):
-                        eng.run_prepared_epoch(prepared, sync=False, steps=(0, 2))
-                    # rows that recur are ahead of the clock, to the step before their next occurrence
-                    assert int(eng._lazy["stamp_i"].max()) >= 6 + steps and int(eng._lazy["stamp_u"].max()) > 6 + steps
-                eng.run_prepared_epoch(prepared, sync=False, steps=(6, steps))
-                assert not eng._lazy["ahead"] and not eng._lazy["dirty"]
-        opt = eng.optimizer
-        out[mode] = (eng.model.flat.clone(), opt.exp_avg_sq.clone(), None if opt.exp_avg is None else opt.exp_avg.clone(),
-                     eng._lazy["stamp_u"].clone(), eng._lazy["stamp_i"].clone(), eng.epoch_stats().loss_sum)
-        su = eng._lazy["stamp_u"]
-        assert bool((su[3000:] == -1).all()) and bool((su[:3000][su[:3000] >= 0] == 3 * steps).all())
-    for name, a, b in zip(("w", "v", "m", "stamp_u", "stamp_i"), out["next_use"], out["none"]):
-        if a is not None:
-            assert torch.equal(a, b), f"{name}: {int((a != b).sum())} elements differ with / without the advance"
-    assert out["next_use"][5] == pytest.approx(out["none"][5], rel=1e-6)
-
-
-def test_next_use_of_every_row_of_a_staged_epoch(hip_device):
-    """hiprec_batch_row_next_use against a plain restatement: for every record (row, batch) the smallest later batch that
-    names the row, n_batches if there is none."""
-    from beta_recsys_amd.mf import batch_row_contributions
-
-    U, I, B, D, n = 500, 120, 64, 64, 64 * 9 + 17
-    rng = np.random.default_rng(2)
-    users, pos, neg = rng.integers(0, U, n), rng.integers(0, I, n), rng.integers(0, I, n)
-    tu, tp, tn = (torch.from_numpy(a).cuda() for a in (users, pos, neg))
-    own = batch_row_contributions(tu, tp, tn, B, U, I, D, every_row=True, next_use=True)
-    assert own.next_use
-    cidx, rows, counts, row_cap = own
-    rows, counts = rows.cpu().numpy(), counts.cpu().numpy()
-    n_batches = (n + B - 1) // B
-    sets = [set(users[b * B:(b + 1) * B].tolist()) | {U + i for i in pos[b * B:(b + 1) * B].tolist()}
-            | {U + i for i in neg[b * B:(b + 1) * B].tolist()} for b in range(n_batches)]
-    for b in range(n_batches):
-        recs = np.concatenate([rows[b, :counts[b, 0]], rows[b, row_cap - counts[b, 1]:]]) if counts[b, 1] else rows[b, :counts[b, 0]]
-        assert set(recs[:, 0].tolist()) == sets[b] and len(recs) == len(sets[b])
-        for key, _, _, nxt in recs.tolist():
-            want = next((c for c in range(b + 1, n_batches) if key in sets[c]), n_batches)
-            assert nxt == want, (b, key, nxt, want)
 
 
 def test_mf_engine_lazy_epoch_in_pieces_and_around_a_dense_step(hip_device):

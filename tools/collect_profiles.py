@@ -30,7 +30,8 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f, newline="")):
             if "hiprec::" in row["Kernel_Name"]:
-                short = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                # (kernels of an anonymous namespace: "hiprec::(anonymous namespace)::name<..>(args)")
+                short = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
                 pmc[name][short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 # groups that were not re-measured in this pass keep what is committed: start from the existing summaries
 def _existing(name):

@@ -54,9 +54,11 @@ mf)   # BASELINE configs[1], the headline (+ the replicated data-parallel step a
   line adam_20 200 --steps 20 --warmup 5
   line adam 200
   for o in sgd rmsprop; do line $o 200 --optimizer $o --no-cpu-baseline; done
-  sharded_line replicated_w1 300 --steps 200
-  sharded_line replicated_w1_20 300 --steps 20 --warmup 5
-  sharded_line replicated_w1_torch 300 --steps 200 --dp-collective torch
+  # `bench.py --gpus N` as the driver runs it, at world size 1: the row-sharded split as the headline, the replicated
+  # and the configs[3] forms as sub-records
+  sharded_line multi_w1 300 --steps 200
+  sharded_line multi_w1_20 300 --steps 20 --warmup 5
+  sharded_line multi_w1_torch 300 --steps 200 --dp-collective torch
   ;;
 c4)   # BASELINE configs[3] on one GPU: one rank's shard and the whole table; SGD (owner pulls) and exact lazy Adam / RMSprop
   stamp c4
@@ -81,6 +83,7 @@ c4)   # BASELINE configs[3] on one GPU: one rank's shard and the whole table; SG
   ;;
 sharded)   # configs[3] row-sharded at world 1: the planner and the planned step (4 launches around 2 exchanges)
   stamp sharded
+  collect
   sharded_line mf-c4_sharded_w1 300 --workload mf-c4 --steps 50
   sharded_line mf-c4_sharded_w1_20 300 --workload mf-c4 --steps 20 --warmup 5
   sharded_line mf-c4_sharded_w1_torch 300 --workload mf-c4 --steps 50 --step-driver torch
@@ -124,6 +127,7 @@ ngcf)
   ;;
 siblings)
   stamp siblings
+  collect
   for w in pgmf t2v; do line $w 300 --workload $w --no-cpu-baseline; done
   ;;
 esac
