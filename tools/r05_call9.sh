@@ -12,7 +12,7 @@ try:
 except Exception as e: print("FAILED", sys.argv[1:], e)
 PY
 }
-for rep in 1 2; do
+for rep in ${R05_REPS:-1 2}; do
 for L in libhiprec.so libhiprec_oldlazy.so; do
 for w in mf-c4shard mf-c4; do
   HIPREC_LIB=$L timeout 300 python bench.py --workload $w --c4-optimizer adam --no-cpu-baseline --steps 50 --warmup 5 > $OUT/bench_${w}_adam_$L.json 2> $OUT/bench_${w}_adam_$L.err; show $OUT/bench_${w}_adam_$L.json $w adam $L
