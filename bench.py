@@ -551,7 +551,7 @@ def bench_mf_c4_sharded(args, device, world, rank, group=None):
     Uc, Ic, Dc, Bc = 10_000_000, 1_000_000, 128, 65536
     cfg = {"model": dict(n_users=Uc, n_items=Ic, emb_dim=Dc, device_str=str(device), optimizer=args.c4_optimizer, lr=LR,
                          batch_size=Bc, loss="bpr", sgd_mode="rows", shard_init="local", step_driver=args.step_driver,
-                         dense_opt=args.dense_opt),
+                         dense_opt=args.dense_opt, shard_sgd=args.shard_sgd),
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -607,7 +607,8 @@ def bench_mf_c4_sharded(args, device, world, rank, group=None):
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "BPR-MF, BASELINE configs[3]: 10M x 1M rows, dim 128, batch 65536 triples/GPU, "
                                        "uniform users, Zipf(1.0) positives, " +
-                                       ("exact SGD on touched rows" if opt == "sgd" else
+                                       ("exact SGD on touched rows" + (", owner pulls (no float atomics)"
+                                                                        if eng._pull_steps() else "") if opt == "sgd" else
                                         f"exact lazy {opt}: the step's rows are caught up / stepped, lagging rows replayed "
                                         "bit-identically to the dense sweep, one flush per 50-step epoch inside the clock"
                                         if lazy else f"dense {opt} sweep of every shard per step"),
@@ -1297,6 +1298,9 @@ def parse_args(argv=None):
                     help="mf-c4 / mf-c4shard with lazy Adam / RMSprop: pull = gradient parts through the contribution "
                          "buffer + one apply launch (round 5); owned / atomic = gradient kernel into the dense buffer + "
                          "update launch (round 4)")
+    ap.add_argument("--shard-sgd", default="pull", choices=["pull", "atomic"],
+                    help="mf-c4 row-sharded with plain SGD: pull = the planned step as owner pulls (two launches, no float "
+                         "atomics, the partials' publish rides along); atomic = the round 2-4 step")
     ap.add_argument("--step-driver", default="c", choices=["c", "torch"],
                     help="row-sharded planned steps: c = kernels and grouped ncclSend/ncclRecv enqueued by one C call "
                          "per range of steps; torch = torch.distributed.all_to_all_single between the launches")

@@ -126,7 +126,8 @@ class ShardPlan(Structure):
                 ("neg_slot", c_void_p), ("own", c_void_p), ("total", c_void_p), ("total_stride", c_int64),
                 ("in_idx", c_void_p), ("ex_req", c_void_p), ("ex_in", c_void_p), ("in_off_host", c_void_p),
                 ("n_slots_host", c_void_p), ("req_cnt_host", c_void_p), ("in_cnt_host", c_void_p),
-                ("slot_shared", c_void_p), ("slot_stride", c_int64), ("dup_bits", c_void_p), ("dup_words", c_int64)]
+                ("slot_shared", c_void_p), ("slot_stride", c_int64), ("dup_bits", c_void_p), ("dup_words", c_int64),
+                ("cidx", c_void_p), ("rows", c_void_p), ("row_cap", c_int64), ("counts", c_void_p)]
 
 
 class ShardBufs(Structure):
@@ -136,7 +137,8 @@ class ShardBufs(Structure):
                 ("_pad", c_int32), ("payload", c_void_p), ("g_recv", c_void_p), ("fetched", c_void_p),
                 ("g_send", c_void_p), ("arrived", c_void_p), ("acc", c_void_p), ("scratch", c_void_p),
                 ("g_flat", c_void_p), ("m_flat", c_void_p), ("v_flat", c_void_p),
-                ("stamp_u", c_void_p), ("stamp_i", c_void_p), ("lazy_scalars", c_void_p), ("lazy_scalars_cap", c_int64)]
+                ("stamp_u", c_void_p), ("stamp_i", c_void_p), ("lazy_scalars", c_void_p), ("lazy_scalars_cap", c_int64),
+                ("cbuf", c_void_p), ("cbias", c_void_p)]
 
 
 class LazyState(Structure):
@@ -378,6 +380,11 @@ SIGNATURES = {
         c_int,
         [_P, c_int64, c_int64, c_int32, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_float,
          c_float, c_double, _P, _P, _P],
+    ),
+    "hiprec_mf_bpr_pull_remote_step": (
+        c_int,
+        [_P, c_int64, c_int64, c_int32, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int32,
+         c_int64, c_float, c_float, c_double, _P, _P, _P],
     ),
     "hiprec_batch_row_ownership_tables": (
         c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P]),

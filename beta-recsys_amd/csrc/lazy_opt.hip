@@ -983,6 +983,9 @@ extern "C" int hiprec_mf_epoch_lazy_pull(const hiprec_lazy_state* state, const i
   a.row_cap = row_cap;
   a.gb = nullptr;
   a.lr = static_cast<float>(state->lr);
+  a.slot_out = nullptr;
+  a.extra_rows = nullptr;
+  a.n_dest = 0;
   const bool adam = state->kind == HIPREC_OPT_ADAM;
   for (int64_t off = 0, k = 0; off < n; off += batch, ++k) {
     const int64_t b = std::min<int64_t>(batch, n - off);  // drop_last = False

@@ -324,6 +324,21 @@ void mf_bpr_owned_kernel(
     // every reference to the slot, an atomic add otherwise; the owner applies it after the exchange
     auto send_item = [&](int slot, int wt, int tot, int64_t item, const float (&g)[NPL], float gb_) {
       if (HIPREC_OWNED_DBG_BIT(2)) return;
+      if constexpr (PULL) {
+        // `slot` is the contribution index: < 0 = this wave holds the slot's complete gradient (straight into the
+        // exchange buffer), else its part goes to the contribution buffer and shard_pull_apply sums the slot
+        float* o = slot < 0 ? f.item_out + item * i_st : f.cbuf + static_cast<int64_t>(slot) * D;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+          const int c = lane + kWave * k;
+          if (c < D) o[c] = g[k];
+        }
+        if (lane == 0) {
+          if (slot < 0) o[D] = gb_;
+          else f.cbias[slot] = gb_;
+        }
+        return;
+      }
       float* o = f.item_out + item * i_st;
       const bool all_mine = slot < 0 || wt == tot;
 #pragma unroll
@@ -623,7 +638,52 @@ __global__ __launch_bounds__(kPullBlock) void pull_apply_kernel(PullApply f, hip
 // wave takes 64 / LPR rows at a time with a quarter of the load instructions -- a short row is two dependent round
 // trips (its record, then its contributions and the row itself), and what bounds the launch is how many of those are
 // in flight; a long row's range is read by 16 x 64 / LPR lane groups at kPullDepth rows each per trip.
-template <int LPR>
+// this rank's [loss, regulariser, d loss / d scalar bias] of the step -> the first three floats of the n_dest extra rows
+// of the gradient exchange buffer (what shard_publish_partials_kernel does in a launch of its own): called by one
+// whole workgroup of NT threads
+template <int NT>
+__device__ __forceinline__ void publish_partials_rows(const Scratch* scratch, float* g_send, int ld,
+                                                      const int32_t* extra_rows, int n_dest) {
+  __shared__ double s_pub[3][NT / kWave];
+  const uint32_t n = scratch->n_partials;
+  double l = 0.0, r = 0.0, b = 0.0;
+  for (uint32_t i = threadIdx.x; i < n; i += NT) {
+    const float4 p = scratch->partials[i];
+    l += p.x;
+    r += p.y;
+    b += p.z;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    l += __shfl_xor(l, o);
+    r += __shfl_xor(r, o);
+    b += __shfl_xor(b, o);
+  }
+  if (lane_id() == 0) {
+    s_pub[0][wave_in_block()] = l;
+    s_pub[1][wave_in_block()] = r;
+    s_pub[2][wave_in_block()] = b;
+  }
+  __syncthreads();
+  if (static_cast<int>(threadIdx.x) < n_dest) {
+    double tl = 0.0, tr = 0.0, tb = 0.0;
+    for (int w = 0; w < NT / kWave; ++w) {
+      tl += s_pub[0][w];
+      tr += s_pub[1][w];
+      tb += s_pub[2][w];
+    }
+    float* row = g_send + static_cast<int64_t>(extra_rows[threadIdx.x]) * ld;
+    row[0] = static_cast<float>(tl);
+    row[1] = static_cast<float>(tr);
+    row[2] = static_cast<float>(tb);
+  }
+}
+
+// REMOTE (the row-sharded step, hiprec_mf_bpr_pull_remote_step): a key below n_users is a LOCAL user row, updated in
+// place as above; a key from n_users on is a slot of the step's exchange buffer, whose summed gradient is STORED to
+// slot_out (row | bias, dim + 1 floats: no 16-byte alignment, four scalar stores per lane) for the way back to the
+// item's owner; the stats block publishes the loss partials into the exchange's extra rows (see PullApply).
+template <int LPR, bool REMOTE = false>
 __global__ __launch_bounds__(kPullBlock) __attribute__((amdgpu_waves_per_eu(8)))
 void pull_apply_vec_kernel(PullApply f, hiprec_stats* stats, Scratch* scratch) {
   constexpr int RPW = kWave / LPR;                  // rows a wave works on at once
@@ -637,6 +697,10 @@ void pull_apply_vec_kernel(PullApply f, hiprec_stats* stats, Scratch* scratch) {
 #endif
   if (blk < 0) {
     // ---- the stats block ----
+    if constexpr (REMOTE) {
+      publish_partials_rows<kPullBlock>(scratch, f.slot_out, f.dim + 1, f.extra_rows, f.n_dest);
+      return;
+    }
     if (f.begin_epoch && threadIdx.x == 0) {  // hiprec_stats_begin_epoch, folded in
       stats->loss_sum = 0.0;
       stats->reg_sum = 0.0;
@@ -672,6 +736,18 @@ void pull_apply_vec_kernel(PullApply f, hiprec_stats* stats, Scratch* scratch) {
     row = f.w + r;
     bias = f.w + bo;
   };
+  auto is_slot = [&](int key) { return REMOTE && key >= f.n_users; };
+  // a slot's sum goes to the exchange buffer: this lane's four columns, the bias behind the row
+  auto store_slot = [&](int key, const float4& g, float gb) {
+    float* o = f.slot_out + static_cast<int64_t>(key - f.n_users) * (D + 1);
+    if (col) {
+      o[sl * 4] = g.x;
+      o[sl * 4 + 1] = g.y;
+      o[sl * 4 + 2] = g.z;
+      o[sl * 4 + 3] = g.w;
+    }
+    if (sl == 0) o[D] = gb;
+  };
   // long rows first (they are the critical path of the launch): one workgroup each
   for (int i = blk; i < n_long; i += nb) {
     const int4 rec = f.rows[f.row_cap - 1 - i];
@@ -690,17 +766,21 @@ void pull_apply_vec_kernel(PullApply f, hiprec_stats* stats, Scratch* scratch) {
         add4(tot, s_part[q][sl]);
         tb += s_pb[q];
       }
-      float *row, *bias;
-      row_of(rec.x, row, bias);
-      if (col) {
-        float4 w4 = *reinterpret_cast<float4*>(row);
-        w4.x -= f.lr * tot.x;
-        w4.y -= f.lr * tot.y;
-        w4.z -= f.lr * tot.z;
-        w4.w -= f.lr * tot.w;
-        *reinterpret_cast<float4*>(row) = w4;
+      if (is_slot(rec.x)) {
+        store_slot(rec.x, tot, tb);
+      } else {
+        float *row, *bias;
+        row_of(rec.x, row, bias);
+        if (col) {
+          float4 w4 = *reinterpret_cast<float4*>(row);
+          w4.x -= f.lr * tot.x;
+          w4.y -= f.lr * tot.y;
+          w4.z -= f.lr * tot.z;
+          w4.w -= f.lr * tot.w;
+          *reinterpret_cast<float4*>(row) = w4;
+        }
+        if (sl == 0) *bias = *bias - f.lr * tb;
       }
-      if (sl == 0) *bias = *bias - f.lr * tb;
     }
     __syncthreads();
   }
@@ -718,7 +798,7 @@ void pull_apply_vec_kernel(PullApply f, hiprec_stats* stats, Scratch* scratch) {
   if (HIPREC_PULL_EXP & 4) return;
 #endif
   for (int i0 = i_first; __builtin_amdgcn_readfirstlane(i0) < n_short; i0 += 2 * nb * GROUPS) {
-    bool on[2];
+    bool on[2], slot[2];
     float4 w4[2], g[2];
     float wb[2], gb[2];
     int trips = 0;
@@ -726,12 +806,13 @@ void pull_apply_vec_kernel(PullApply f, hiprec_stats* stats, Scratch* scratch) {
     for (int r = 0; r < 2; ++r) {
       on[r] = i0 + r * nb * GROUPS + sub < n_short;
       if (!on[r]) rec[r] = make_int4(0, 0, 0, 0);
+      slot[r] = is_slot(rec[r].x);
       float *row, *bias;
-      row_of(rec[r].x, row, bias);
+      row_of(slot[r] ? 0 : rec[r].x, row, bias);
       w4[r] = g[r] = zero4;
       wb[r] = gb[r] = 0.f;
-      if (on[r] && col) w4[r] = *reinterpret_cast<const float4*>(row);
-      if (on[r] && sl == 0) wb[r] = *bias;
+      if (on[r] && !slot[r] && col) w4[r] = *reinterpret_cast<const float4*>(row);
+      if (on[r] && !slot[r] && sl == 0) wb[r] = *bias;
       trips = max(trips, (rec[r].z + HALF - 1) / HALF);
     }
 #pragma unroll
@@ -763,16 +844,20 @@ void pull_apply_vec_kernel(PullApply f, hiprec_stats* stats, Scratch* scratch) {
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      float *row, *bias;
-      row_of(rec[r].x, row, bias);
-      if (on[r] && col) {
-        w4[r].x -= f.lr * g[r].x;
-        w4[r].y -= f.lr * g[r].y;
-        w4[r].z -= f.lr * g[r].z;
-        w4[r].w -= f.lr * g[r].w;
-        *reinterpret_cast<float4*>(row) = w4[r];
+      if (on[r] && slot[r]) {
+        store_slot(rec[r].x, g[r], gb[r]);
+      } else {
+        float *row, *bias;
+        row_of(rec[r].x, row, bias);
+        if (on[r] && col) {
+          w4[r].x -= f.lr * g[r].x;
+          w4[r].y -= f.lr * g[r].y;
+          w4[r].z -= f.lr * g[r].z;
+          w4[r].w -= f.lr * g[r].w;
+          *reinterpret_cast<float4*>(row) = w4[r];
+        }
+        if (on[r] && sl == 0) *bias = wb[r] - f.lr * gb[r];
       }
-      if (on[r] && sl == 0) *bias = wb[r] - f.lr * gb[r];
       // the next iteration's record (the stores above are fire and forget)
       const int i = i0 + (2 + r) * nb * GROUPS + sub;
       rec[r] = i < n_short ? f.rows[i] : make_int4(0, 0, 0, 0);
@@ -948,6 +1033,9 @@ extern "C" int hiprec_mf_bpr_epoch_pull(float* w_flat, int64_t n_users, int64_t 
   a.row_cap = row_cap;
   a.gb = w_flat + o_gb;
   a.lr = static_cast<float>(lr);
+  a.slot_out = nullptr;
+  a.extra_rows = nullptr;
+  a.n_dest = 0;
   auto launch_apply = [&](int grid) {
     if (dim % 4 == 0) {
       if (dim <= 64) pull_apply_vec_kernel<16><<<grid, kPullBlock, 0, st>>>(a, stats, static_cast<Scratch*>(scratch));
@@ -1055,6 +1143,92 @@ extern "C" int hiprec_mf_bpr_owned_remote_step(float* w_flat, int64_t n_users, i
   return owned_remote_impl(w_flat, nullptr, n_users, n_items_local, dim, fetched, g_send, n_slots, users, pos_slot,
                            neg_slot, own_u, own_p, own_n, total, arrived, acc, batch, inv_batch, reg_coef, lr, stats,
                            scratch, stream);
+}
+
+// The row-sharded step as OWNER PULLS (round 5; plain SGD, dim % 4 == 0): the two launches of hiprec_mf_bpr_epoch_pull on
+// (local user shard, FETCHED item slots).  cidx_* / rows / counts: hiprec_batch_row_contrib's arrays over the step's
+// (local user, positive slot, negative slot) triples with n_users = the local user rows and n_items = a bound of the
+// slot ids (padding triples, user -1, contribute nothing).  Launch 1: a user row whose only contribution the wave holds
+// is updated in place, a slot it alone references gets its gradient stored straight into g_send; every other part goes
+// to cbuf / cbias with plain stores.  Launch 2: one lane group per shared row sums its range -- a user row takes
+// w - lr * sum, a slot's sum is stored to g_send -- and the stats block writes this rank's loss partials into the
+// exchange's extra rows (hiprec_shard_publish_partials's job).  No float atomics, g_send needs no clearing: every slot of
+// the step is written exactly once.
+extern "C" int hiprec_mf_bpr_pull_remote_step(float* w_flat, int64_t n_users, int64_t n_items_local, int32_t dim,
+                                              const float* fetched, float* g_send, int64_t n_slots,
+                                              const int64_t* users, const int64_t* pos_slot, const int64_t* neg_slot,
+                                              const int32_t* cidx_u, const int32_t* cidx_p, const int32_t* cidx_n,
+                                              const int32_t* rows, int64_t row_cap, const int32_t* counts, float* cbuf,
+                                              float* cbias, const int32_t* extra_rows, int32_t n_dest, int64_t batch,
+                                              float inv_batch, float reg_coef, double lr, hiprec_stats* stats,
+                                              void* scratch, void* stream) {
+  HIPREC_REQUIRE(w_flat && stats && scratch, "NULL pointer");
+  HIPREC_REQUIRE(n_users > 0 && n_items_local >= 0 && dim >= 4 && dim <= 256 && dim % 4 == 0,
+                 "the owner-pulls sharded step needs dim %% 4 == 0, 4 <= dim <= 256");
+  HIPREC_REQUIRE(batch > 0 && n_slots >= 0 && n_dest > 0 && n_dest <= kPullBlock, "bad batch / n_slots / n_dest");
+  HIPREC_REQUIRE(fetched && g_send && users && pos_slot && neg_slot && cidx_u && cidx_p && cidx_n && rows && counts &&
+                     cbuf && cbias && extra_rows, "NULL pointer");
+  HIPREC_REQUIRE(row_cap >= (3 * batch + 1) / 2, "row_cap too small");
+  OwnedStep f;
+  f.w = w_flat;
+  f.n_users = n_users;
+  f.n_items = n_slots;   // bound of the item ids the kernel sees
+  f.dim = dim;
+  f.apply_prev = 0;
+  f.own_u = cidx_u;
+  f.own_p = cidx_p;
+  f.own_n = cidx_n;
+  f.total = nullptr;
+  f.arrived = nullptr;
+  f.acc = nullptr;
+  const int64_t o_gb = (n_users + n_items_local) * (static_cast<int64_t>(dim) + 1);
+  f.gb_read = w_flat + o_gb;
+  f.gb_write = nullptr;
+  f.scratch_prev = static_cast<const Scratch*>(scratch);
+  f.n_prev_partials = 0;
+  f.n_gather_blocks = owned_blocks(dim, batch, true);
+  f.lr = static_cast<float>(lr);
+  f.dbg = 0;
+  f.o_ub = (n_users + n_items_local) * static_cast<int64_t>(dim);
+  f.o_ie = fetched - w_flat;   // the exchange buffer, addressed relative to the parameters (one flat address space)
+  f.o_ib = f.o_ie + dim;
+  f.item_stride = f.bias_stride = dim + 1;
+  f.item_out = g_send;
+  f.grad_out = nullptr;
+  f.cbuf = cbuf;
+  f.cbias = cbias;
+  f.count_step = 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (int rc = launch_owned<true, false, true>(f, f.n_gather_blocks, st, users, pos_slot, neg_slot, batch, inv_batch,
+                                               reg_coef, stats, static_cast<Scratch*>(scratch)))
+    return rc;
+  PullApply a;
+  a.w = w_flat;
+  a.n_users = n_users;
+  a.o_ie = 0;                  // (item keys are slots: they never address the table)
+  a.o_ub = f.o_ub;
+  a.o_ib = 0;
+  a.dim = dim;
+  a.begin_epoch = 0;
+  a.count_step = 0;
+  a.cbuf = cbuf;
+  a.cbias = cbias;
+  a.rows = reinterpret_cast<const int4*>(rows);
+  a.row_cap = row_cap;
+  a.counts = counts;
+  a.gb = nullptr;
+  a.lr = static_cast<float>(lr);
+  a.slot_out = g_send;
+  a.extra_rows = extra_rows;
+  a.n_dest = n_dest;
+  const int64_t per_block = kPullWaves * (dim <= 64 ? 4 : dim <= 128 ? 2 : 1);
+  const int64_t waves = std::max<int64_t>(batch / 4, 1);
+  const int grid = static_cast<int>(std::min<int64_t>((waves + per_block - 1) / per_block, 512)) + 1;
+  if (dim <= 64) pull_apply_vec_kernel<16, true><<<grid, kPullBlock, 0, st>>>(a, stats, static_cast<Scratch*>(scratch));
+  else if (dim <= 128) pull_apply_vec_kernel<32, true><<<grid, kPullBlock, 0, st>>>(a, stats, static_cast<Scratch*>(scratch));
+  else pull_apply_vec_kernel<64, true><<<grid, kPullBlock, 0, st>>>(a, stats, static_cast<Scratch*>(scratch));
+  HIPREC_TRY(hipGetLastError());
+  return 0;
 }
 
 // The same launch for the dense optimizers (Adam / RMSprop) of the row-sharded planned path: nothing is updated;

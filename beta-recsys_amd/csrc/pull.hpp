@@ -21,6 +21,13 @@ struct PullApply {
   const int32_t* counts;         // this batch's {short rows, long rows, contributions, -}
   float* gb;                     // the scalar bias
   float lr;
+  // the row-sharded step (REMOTE apply, csrc/mf_owned.hip): keys >= n_users are SLOTS of the step's exchange buffer --
+  // their sums are stored to slot_out [n_slots][dim + 1] (row | bias) for the way back to the items' owners -- and the
+  // stats block writes this rank's loss / regulariser / scalar-bias partials into the n_dest extra rows instead of
+  // booking them (the 3-float all-reduce rides in the gradient exchange)
+  float* slot_out;
+  const int32_t* extra_rows;
+  int32_t n_dest;
 };
 
 // The gradient launch of an owner-pulls step on local tables (csrc/mf_owned.hip): mf_bpr_owned_kernel<.., PULL> over

@@ -495,6 +495,11 @@ extern "C" int hiprec_mf_bpr_owned_remote_step(float*, int64_t, int64_t, int32_t
                                                const int64_t*, const int64_t*, const int64_t*, const int32_t*,
                                                const int32_t*, const int32_t*, const int32_t*, int32_t*, float*,
                                                int64_t, float, float, double, hiprec_stats*, void*, void*);
+extern "C" int hiprec_mf_bpr_pull_remote_step(float*, int64_t, int64_t, int32_t, const float*, float*, int64_t,
+                                              const int64_t*, const int64_t*, const int64_t*, const int32_t*,
+                                              const int32_t*, const int32_t*, const int32_t*, int64_t, const int32_t*,
+                                              float*, float*, const int32_t*, int32_t, int64_t, float, float, double,
+                                              hiprec_stats*, void*, void*);
 extern "C" int hiprec_mf_bpr_grad_remote_step(const float*, float*, int64_t, int64_t, int32_t, const float*, float*,
                                               int64_t, const int64_t*, const int64_t*, const int64_t*, const int32_t*,
                                               const int32_t*, const int32_t*, const int32_t*, int64_t, float, float,
@@ -521,7 +526,11 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
                  "incomplete step buffers");
   const bool dense = kind != HIPREC_OPT_SGD;
   HIPREC_REQUIRE(kind == HIPREC_OPT_SGD || kind == HIPREC_OPT_ADAM || kind == HIPREC_OPT_RMSPROP, "unknown optimizer");
-  HIPREC_REQUIRE(dense ? (bufs->g_flat != nullptr) : (bufs->arrived && bufs->acc), "incomplete step buffers");
+  // plain SGD as owner pulls (round 5): the plan carries the step blocks' contribution lists
+  const bool pull = !dense && plan->cidx != nullptr && bufs->dim % 4 == 0;
+  HIPREC_REQUIRE(!pull || (plan->rows && plan->counts && plan->row_cap >= (3 * plan->cap + 1) / 2 && bufs->cbuf && bufs->cbias),
+                 "incomplete contribution lists / buffers of the owner-pulls step");
+  HIPREC_REQUIRE(dense ? (bufs->g_flat != nullptr) : (pull || (bufs->arrived && bufs->acc)), "incomplete step buffers");
   // exact lazy Adam / RMSprop (csrc/lazy_opt.hip): the step's rows are caught up before they are read and stepped
   // after their gradients are complete -- the dense sweep of the whole shard goes
   const bool lazy = dense && bufs->stamp_u != nullptr;
@@ -585,8 +594,9 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
     const hiprec_lazy_rows touched{plan->users + s * cap, cap, nullptr, 0, nullptr, 0, idx, il};
     if (lazy)
       if (int rc = hiprec_lazy_catchup(&lz, &touched, stats, stream)) return rc;
+    // (the owner-pulls step writes every slot of g_send exactly once: nothing to clear)
     if (int rc = hiprec_shard_payload_zero(item_emb, item_bias, ni, D, idx, il, in_lo, in_hi, bufs->payload,
-                                           self_fetched, bufs->g_send, sl * ld, shared, stats, stream))
+                                           self_fetched, bufs->g_send, pull ? 0 : sl * ld, shared, stats, stream))
       return rc;
     if (R > 1) {
       if (g_start()) {
@@ -615,7 +625,14 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
     const int64_t b_local = std::min<int64_t>(plan->local_batch, plan->n_local - s * plan->local_batch);
     const float inv_b = 1.0f / static_cast<float>(static_cast<int64_t>(R) * b_local);
     int rc;
-    if (dense)
+    if (pull)
+      rc = hiprec_mf_bpr_pull_remote_step(w, nu, ni, D, bufs->fetched, bufs->g_send, sl, plan->users + off,
+                                          plan->pos_slot + off, plan->neg_slot + off, plan->cidx + off,
+                                          plan->cidx + tot + off, plan->cidx + 2 * tot + off,
+                                          plan->rows + s * plan->row_cap * 4, plan->row_cap, plan->counts + 4 * s,
+                                          bufs->cbuf, bufs->cbias, plan->ex_req + s * R, R, cap, inv_b, reg_coef, lr,
+                                          stats, bufs->scratch, stream);
+    else if (dense)
       rc = hiprec_mf_bpr_grad_remote_step(w, g, nu, ni, D, bufs->fetched, bufs->g_send, sl, plan->users + off,
                                           plan->pos_slot + off, plan->neg_slot + off, plan->own + off,
                                           plan->own + tot + off, plan->own + 2 * tot + off,
@@ -628,8 +645,9 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
                                            plan->total + s * plan->total_stride, bufs->arrived, bufs->acc, cap, inv_b,
                                            reg_coef, lr, stats, bufs->scratch, stream);
     if (rc) return rc;
-    shard_publish_partials_kernel<<<1, kBlock, 0, st>>>(static_cast<const Scratch*>(bufs->scratch), bufs->g_send, ld,
-                                                        nullptr, plan->ex_req + s * R, R);
+    if (!pull)   // (the pull launch has published the partials itself)
+      shard_publish_partials_kernel<<<1, kBlock, 0, st>>>(static_cast<const Scratch*>(bufs->scratch), bufs->g_send, ld,
+                                                          nullptr, plan->ex_req + s * R, R);
     if (R > 1) {
       if (g_start()) {
         set_error("ncclGroupStart failed before the gradient exchange of step %lld", (long long)s);

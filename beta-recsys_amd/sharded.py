@@ -217,7 +217,8 @@ class HipKernels:
             _lib.ptr(own2), _lib.ptr(total), _lib.ptr(slot_shared), slot_stride,
             _lib.ptr(fill) if fill is not None else None, self._st()))
         return {"U": U2, "SP": SP, "SN": SN, "own": own2, "total": total, "stride": T, "req_cnt": req_cnt,
-                "req_ds": req_ds, "ex_req": ex_req, "req_send": req_send, "slot_shared": slot_shared}
+                "req_ds": req_ds, "ex_req": ex_req, "req_send": req_send, "slot_shared": slot_shared,
+                "slot_bound": slot_stride}
 
     def plan_place_requests(self, incoming, in_qs, S, n_rows_local=0):
         """-> (in_idx, ex_in, dup_bits): dup_bits uint32 [S, words] = rows more than one peer asks for in a step."""
@@ -284,7 +285,9 @@ class HipKernels:
                 plan["slot_shared"].data_ptr() if plan.get("slot_shared") is not None else None,
                 plan["slot_shared"].shape[1] if plan.get("slot_shared") is not None else 0,
                 plan["dup_bits"].data_ptr() if plan.get("dup_bits") is not None else None,
-                plan["dup_bits"].shape[1] if plan.get("dup_bits") is not None else 0)
+                plan["dup_bits"].shape[1] if plan.get("dup_bits") is not None else 0,
+                *((pc[0].data_ptr(), pc[1].data_ptr(), pc[3], pc[2].data_ptr()) if (pc := plan.get("contrib")) is not None
+                  else (None, None, 0, None)))
             c = plan["_c"] = (sp, host)
         dense = opt.name != "sgd"
         sb = _lib.ShardBufs(
@@ -295,7 +298,9 @@ class HipKernels:
             opt.exp_avg.data_ptr() if opt.exp_avg is not None else None,
             opt.exp_avg_sq.data_ptr() if opt.exp_avg_sq is not None else None,
             lazy["stamp_u"].data_ptr() if lazy else None, lazy["stamp_i"].data_ptr() if lazy else None,
-            lazy["scalars"].data_ptr() if lazy else None, lazy["scalars"].shape[0] if lazy else 0)
+            lazy["scalars"].data_ptr() if lazy else None, lazy["scalars"].shape[0] if lazy else 0,
+            bufs["cbuf"].data_ptr() if bufs.get("cbuf") is not None else None,
+            bufs["cbias"].data_ptr() if bufs.get("cbias") is not None else None)
         fns = None
         if comm is not None:
             fns = ctypes.byref(_lib.NcclFns(comm.send_fn, comm.recv_fn, comm.group_start_fn, comm.group_end_fn))
@@ -813,6 +818,15 @@ class ShardedMFEngine:
         # owner q), the blocks are re-laid grouped by positive item with their row-ownership arrays
         sl = k.plan_item_slots(U, P, N, S, cap, R, self.model.n_users, self.n_items, fill)
 
+        # (2b) plain SGD, C step driver: the step blocks' contribution lists -- the step then runs as owner pulls
+        # (hiprec_mf_bpr_pull_remote_step: no float atomics, nothing to clear, the partials' publish rides along)
+        contrib = None
+        if self._pull_steps():
+            from .mf import batch_row_contributions
+
+            contrib = batch_row_contributions(sl["U"], sl["SP"], sl["SN"], cap, max(self.model.n_users, 1),
+                                              sl["slot_bound"], self.emb_dim)
+
         # (3) tell every owner which rows it will be asked for, step by step: one exchange
         req_ds = sl["req_ds"]
         in_qs = torch.empty_like(req_ds)
@@ -835,7 +849,18 @@ class ShardedMFEngine:
                 "in_off": in_off[:-1], "in_len": in_len, "n_slots": n_slots,
                 "req_split": [[c + 1 for c in row] for row in req_l], "in_split": [[c + 1 for c in row] for row in in_l],
                 "ex_req": sl["ex_req"], "ex_in": ex_in, "slot_shared": sl.get("slot_shared"), "dup_bits": dup_bits,
-                "in_off_h": in_off, "n_slots_h": n_slots, "req_cnt_h": req_l, "in_cnt_h": in_l}
+                "in_off_h": in_off, "n_slots_h": n_slots, "req_cnt_h": req_l, "in_cnt_h": in_l, "contrib": contrib}
+
+    def _pull_steps(self):
+        """``shard_sgd``: "pull" (default) -- a planned epoch's plain-SGD steps run as owner pulls when the C step
+        driver enqueues them and emb_dim % 4 == 0 (two launches without float atomics, csrc/mf_owned.hip); "atomic" --
+        the round 2-4 step (shared rows and shared slots through device-scope atomics).  The torch step loop and the
+        dense optimizers keep the atomic kernel."""
+        mode = self.config["model"].get("shard_sgd", "pull")
+        if mode not in ("pull", "atomic"):
+            raise ValueError(f"shard_sgd must be 'pull' or 'atomic', not {mode!r}")
+        return (mode == "pull" and self.optimizer.name == "sgd" and self.emb_dim % 4 == 0 and self.emb_dim >= 4
+                and self._step_comm() == "c")
 
     def prefetch_setup(self):
         """Collective, one-off: the side stream and the process group (a communicator of its own: no ordering against
@@ -882,7 +907,7 @@ class ShardedMFEngine:
             # the plan's tensors come from the side stream's allocator pool and are read by the training stream:
             # the allocator must not hand their memory to a later plan before the steps that read them are done
             # (r02 experiments 24; with the C step driver the host is far ahead of the GPU)
-            for v in plan.values():
+            for v in list(plan.values()) + list(plan.get("contrib") or ()):
                 if torch.is_tensor(v) and v.is_cuda:
                     v.record_stream(main)
         self._ev_epoch_begin = torch.cuda.Event()
@@ -931,6 +956,9 @@ class ShardedMFEngine:
                 "fetched": torch.empty((max_slots, ld), **f32), "g_send": torch.empty((max_slots, ld), **f32),
                 "arrived": torch.zeros(plan["stride"], dtype=torch.int32, device=dev),
                 "acc": torch.zeros(plan["stride"] * ld, **f32)}
+        if plan.get("contrib") is not None and (pb.get("cbuf") is None or pb["cbuf"].numel() < 3 * cap * D):
+            pb["cbuf"] = torch.empty(3 * cap * D, dtype=torch.float32, device=dev)    # (work space: never cleared)
+            pb["cbias"] = torch.empty(3 * cap, dtype=torch.float32, device=dev)
         lr, reg = self.optimizer.lr, float(self.reg)
         a, b = steps or (0, S)
         lazy = self._lazy if dense else None

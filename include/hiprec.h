@@ -493,6 +493,20 @@ int hiprec_plan_place_requests(const int32_t* incoming, int64_t n_in, const int3
                                int64_t n_steps, int32_t* group_ws, int32_t* in_idx, int32_t* step_off,
                                int32_t* extra_pos, int64_t n_rows_local, uint32_t* dup_ws, void* stream);
 
+/* The same step as OWNER PULLS (round 5; plain SGD, dim % 4 == 0): two launches, no float atomics.  cidx_* / rows / counts:
+ * hiprec_batch_row_contrib's arrays of this step (n_users = local user rows, n_items = a bound of the slot ids,
+ * min_contrib = 2).  Launch 1 updates in place the user rows whose only contribution a wave holds and stores the
+ * gradient of slots it alone references straight into g_send; the other parts go to cbuf [3 * batch][dim] / cbias
+ * [3 * batch].  Launch 2 sums every shared row's range (a user row takes w - lr * sum, a slot's sum goes to g_send) and
+ * writes [loss, reg, d loss / d global_bias] of this rank into rows extra_rows[0 .. n_dest) of g_send
+ * (hiprec_shard_publish_partials is not needed).  g_send needs no clearing; the optimizer clock is not touched. */
+int hiprec_mf_bpr_pull_remote_step(float* w_flat, int64_t n_users, int64_t n_items_local, int32_t dim,
+                                   const float* fetched, float* g_send, int64_t n_slots, const int64_t* users,
+                                   const int64_t* pos_slot, const int64_t* neg_slot, const int32_t* cidx_u,
+                                   const int32_t* cidx_p, const int32_t* cidx_n, const int32_t* rows, int64_t row_cap,
+                                   const int32_t* counts, float* cbuf, float* cbias, const int32_t* extra_rows,
+                                   int32_t n_dest, int64_t batch, float inv_batch, float reg_coef, double lr,
+                                   hiprec_stats* stats, void* scratch, void* stream);
 /* The planned step in three launches.  Rows [self_lo, self_hi) of a step's incoming block are the ones this rank
  * asked of itself: they never travel (self_dst / g_self point into the fetched / the send buffer).
  *  hiprec_shard_payload_zero  payload[k] = [item_emb[idx[k]] | item_bias[idx[k]]] (zeros for idx -1) AND
@@ -543,6 +557,14 @@ typedef struct hiprec_shard_plan {
   int64_t slot_stride;
   const uint32_t* dup_bits;      /* optional [n_steps][dup_words]: hiprec_plan_place_requests */
   int64_t dup_words;
+  /* optional (round 5, plain SGD, dim % 4 == 0): hiprec_batch_row_contrib's arrays over (users, pos_slot, neg_slot) with
+   * batch = cap, n_users = the local user rows, n_items = a bound of the slot ids, min_contrib = 2 -- the step then runs
+   * as owner pulls (hiprec_mf_bpr_pull_remote_step): no float atomics, no clearing of the gradient exchange buffer, the
+   * partials' publish rides in the pull launch */
+  const int32_t* cidx;           /* [3][n_steps * cap] */
+  const int32_t* rows;           /* [n_steps][row_cap][4] */
+  int64_t row_cap;
+  const int32_t* counts;         /* [n_steps][4] */
 } hiprec_shard_plan;
 
 typedef struct hiprec_shard_bufs {
@@ -565,6 +587,8 @@ typedef struct hiprec_shard_bufs {
   int32_t* stamp_i;
   float* lazy_scalars;
   int64_t lazy_scalars_cap;
+  float* cbuf;                   /* owner-pulls SGD step: [3 * cap][dim] / [3 * cap] contribution buffers (work space) */
+  float* cbias;
 } hiprec_shard_bufs;
 
 /* ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd of the RCCL the caller loaded (this library links none) */

@@ -42,14 +42,15 @@ def local_triples(rank, world, U, I, n_local, idle_rank=None):
 
 
 def planned_rank(group, w0, U, I, D, n_local, bs, shuffle, optimizer, lr, driver, idle_rank, epochs=1, prefetch=False,
-                 dense_opt="sweep"):
+                 dense_opt="sweep", shard_sgd="pull"):
     import beta_recsys_amd as hp
     from beta_recsys_amd.sharded import ShardedMFEngine
 
     rank, world = group.rank(), group.size()
     users, pos, neg = local_triples(rank, world, U, I, n_local, idle_rank)
     cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer=optimizer, lr=lr, batch_size=bs,
-                         loss="bpr", sgd_mode="rows", step_driver=driver, dense_opt=dense_opt), "system": RUN_DIR}
+                         loss="bpr", sgd_mode="rows", step_driver=driver, dense_opt=dense_opt, shard_sgd=shard_sgd),
+           "system": RUN_DIR}
     with contextlib.redirect_stdout(io.StringIO()):
         eng = ShardedMFEngine(cfg, process_group=group, full_state={k: torch.from_numpy(v) for k, v in w0.items()})
     assert (eng._lazy is not None) == (dense_opt == "lazy" and optimizer != "sgd")
@@ -68,6 +69,9 @@ def planned_rank(group, w0, U, I, D, n_local, bs, shuffle, optimizer, lr, driver
         else:
             plan = eng.plan_epoch(loader)
         received = int((plan["U"] >= 0).sum())
+        # plain SGD through the C driver runs as owner pulls (contribution lists in the plan) unless told otherwise
+        assert (plan.get("contrib") is not None) == (optimizer == "sgd" and driver == "c" and shard_sgd == "pull"
+                                                     and D % 4 == 0)
         stats = eng.run_planned_epoch(plan)
     full = eng.gather_full_state_dict()
     pb = eng._planned_bufs
@@ -141,6 +145,24 @@ def test_planned_steps_exchange_between_virtual_ranks(hip_device, world, D, bs, 
     assert counters["sends"] == counters["recvs"] == 2 * steps * world * (world - 1), counters
     assert counters["bytes"] > 0
     check_planned(res, w0, n_local, bs, optimizer, lr)
+
+
+@pytest.mark.parametrize("world,D,bs", [(2, 64, 256), (4, 128, 300)])
+def test_planned_sgd_steps_in_the_atomic_form_between_virtual_ranks(hip_device, world, D, bs):
+    """`shard_sgd: "atomic"`: the round 2-4 step (shared user rows and shared item slots through device-scope atomics,
+    the partials' publish as a launch of its own) still is what it was -- the default since round 5 is the owner-pulls
+    step, which the tests above run."""
+    U, I = 3001, 403
+    n_local = 4 * bs + bs // 3
+    w0 = onp.init_params(U, I, D, seed=3)
+    vw = VirtualWorld(world)
+    try:
+        res = vw.run(lambda g: planned_rank(g, w0, U, I, D, n_local, bs, True, "sgd", 0.05, "c", None,
+                                            shard_sgd="atomic"))
+    finally:
+        vw.close()
+    assert all(r["mode"] == "c" for r in res)
+    check_planned(res, w0, n_local, bs, "sgd", 0.05)
 
 
 @pytest.mark.parametrize("world,optimizer,lr,driver", [(4, "adam", 0.05, "c"), (8, "rmsprop", 0.01, "c"),

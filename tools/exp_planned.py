@@ -21,7 +21,7 @@ loader = hp.DeviceTripleBatcher(users, pos, neg, B)
 for opt, driver in [c.split(":") for c in os.environ.get("CASES", "sgd:c,sgd:torch,adam:c").split(",")]:
     cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer=opt, lr=0.05, batch_size=B,
                          loss="bpr", sgd_mode="rows", shard_init="local", step_driver=driver,
-                         dense_opt=os.environ.get("DENSE_OPT", "auto")),
+                         dense_opt=os.environ.get("DENSE_OPT", "auto"), shard_sgd=os.environ.get("SHARD_SGD", "pull")),
            "system": {"run_dir": "/tmp/x"}}
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
