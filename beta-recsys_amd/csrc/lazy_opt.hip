@@ -61,8 +61,8 @@ struct LazyCtx {
 
 // BOUNDED REPLAY (round 5).  A zero-gradient Adam step k of a row moves w by x_k = ss_t * m_k / (sqrt(v_k) * r_t + eps)
 // with m_k = (1 - (1 - beta1)) m_(k-1), v_k = beta2 v_(k-1): |x_(k+1)| / |x_k| <= beta1 / sqrt(beta2) *
-// sqrt((1 - beta2^(t+1)) / (1 - beta2^t)) (eps in the denominator only helps, ss_t falls with t), 0.90 for the default
-// betas once t > 16.  The x_k of an element all have the sign of its m.  So once fl(w - x_k) == w -- x_k is at most
+// sqrt((1 - beta2^(t+1)) / (1 - beta2^t)) (eps in the denominator only helps, ss_t falls with t): 0.93 at t = 16 for
+// the default betas, 0.90 in the limit.  The x_k of an element all have the sign of its m.  So once fl(w - x_k) == w -- x_k is at most
 // half the gap to w's neighbour on that side -- every later x is smaller still and leaves w alone as well: the
 // remaining zero-gradient steps of that element are decays of m and v only (one fma + one multiply instead of sqrt +
 // rcp + 6 more), and a catch-up, which stores nothing but w, is DONE.  With lr 0.05 that happens ~150-200 steps after

@@ -1,5 +1,5 @@
 // BPR-MF step with plain SGD for tables that do NOT fit the caches (BASELINE configs[3]: 10 M x 1 M x 128,
-// or one rank's shard of it): ONE launch per step, no dense gradient buffer, every touched row written once.
+// or one rank's shard of it): no dense gradient buffer, every touched row written once, in place.
 //
 // Reference semantics (beta_rec/models/mf.py:92-119 + torch.optim.SGD, torch_engine.py:26-29): all gradients of
 // a batch come from the pre-step weights, then every touched row r becomes w_r - lr * g_r with g_r the SUM of
@@ -7,12 +7,26 @@
 // mf_sgd_rows_kernel) keeps a dense gradient buffer: atomics read-modify-write it, a second pass reads it, reads
 // and writes the weights and clears it -- 347 MB of HBM traffic per 65 536-triple step for 204 MB algorithmic.
 //
-// Here a row is updated IN PLACE by whichever wave holds its complete gradient:
-//  * the device batcher (beta-recsys_amd/mf.py, torch ops on the side stream) tells every triple, for each of
-//    its three rows, whether the row occurs ONCE in the batch (own = -1) or several times (own = a slot id, with
-//    total[slot] = its number of occurrences).
-//  * a row that occurs once: the wave that read it for the dot products writes w - lr * g straight back -- a
-//    plain store, no atomic, no gradient memory at all.  Nobody else in the batch reads that row.
+// Here a row is updated IN PLACE by whoever holds its complete gradient.  Two forms of one kernel template:
+//
+// OWNER PULLS (round 5, the default: hiprec_mf_bpr_epoch_pull; PULL = true; also the gradient launch of the lazy
+// Adam / RMSprop epochs, csrc/lazy_opt.hip, and of the row-sharded planned step, hiprec_mf_bpr_pull_remote_step).
+//  * the staging (csrc/ownership.hip, hiprec_batch_row_contrib) counts every row's CONTRIBUTIONS in a batch -- a user or
+//    negative occurrence is one, of the positive occurrences only the head of a run of equal items inside the chunk of
+//    consecutive triples one wave takes -- and tells every contribution where it goes: -1 = it is the row's only one,
+//    otherwise an index into the step's contribution buffer, where a row's parts lie in one contiguous range.
+//  * launch 1 (mf_bpr_owned_kernel<.., PULL>): the wave that holds a row's only contribution writes w - lr * g
+//    straight back -- a plain store, no gradient memory at all; nobody else in the batch reads that row.  Every other
+//    contribution is stored to its place in the contribution buffer, again with plain stores.
+//  * launch 2 (pull_apply_vec_kernel / pull_apply_kernel): one lane group (one wave, or a whole workgroup for a Zipf
+//    head item's hundreds of runs) per shared row sums the row's range and stores w - lr * g; the row still holds its
+//    pre-step value, only its owner ever writes it.  No float atomics, no arrival counters, nothing to clear.
+//
+// PUSH WITH ATOMICS (rounds 2-4: hiprec_mf_bpr_epoch_owned, `sgd_mode: "owned_atomic"`; the dense optimizers' remote
+// gradient launch still works this way): ONE launch per step.
+//  * the staging (hiprec_batch_row_ownership) tells every triple, for each of its three rows, whether the row occurs
+//    ONCE in the batch (own = -1) or several times (own = a slot id, with total[slot] = its number of occurrences).
+//  * a row that occurs once is written straight back as above.
 //  * a row that occurs several times: every occurrence READS the row (pre-step) and CONTRIBUTES its part of the
 //    gradient, so "all readers have read" == "all contributions have arrived".  Contributions are added with
 //    device-scope atomics into a compact accumulator row acc[slot] (a few tens of MB for the whole batch: it
@@ -20,13 +34,13 @@
 //    that completes the count takes the accumulated gradient out (atomic exchange with 0: read and clear in one
 //    operation, the accumulators are clean for the next step) and applies it to the row, which still holds its
 //    pre-step value.  No fence is needed: accumulator and counter are only ever touched by device-scope atomics,
-//    and a contributor waits for its adds to be acknowledged before it bumps the counter.
-//  * positive items follow a Zipf law; as in mf_bpr_grad_kernel adjacent equal items of a block (the batcher
-//    sorts every batch by positive item) are first merged in LDS and only the run head contributes, with the
-//    run length as its weight; a run that holds ALL occurrences of its item is applied directly.
-// The scalar bias is handled like the fused cache-resident step does it: its gradient travels in the per-block
-// partials, every wave evaluates bias - lr * (sum of the previous step's partials) on the fly, and one extra
-// block of the grid folds the partials into hiprec_stats and writes the updated scalar to a ping-pong slot.
+//    and a contributor waits for its adds to be acknowledged before it bumps the counter.  (+42 us per 65 536-triple
+//    step for the 27 % of rows that are shared: what the owner-pulls form removes.)
+// Both: positive items follow a Zipf law; as in mf_bpr_grad_kernel adjacent equal items of a chunk (the batcher
+// groups every batch by positive item) are summed in registers and only the run's head contributes.
+// The scalar bias: its gradient travels in the per-block partials; the pull form's apply launch folds them into
+// hiprec_stats and steps the scalar (the atomic form does it one launch late, in an extra block, through a ping-pong
+// slot).
 #include <algorithm>
 #include <cstdlib>
 

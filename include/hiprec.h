@@ -653,7 +653,11 @@ typedef struct hiprec_lazy_rows {
 
 size_t hiprec_lazy_state_bytes(void);
 /* BEFORE a step reads its rows: the listed rows that lag behind the clock (stats->step = completed steps) are replayed
- * up to it and stored.  No-op for RMSprop (a zero-gradient step leaves w alone; v is replayed by the update). */
+ * up to it and stored.  No-op for RMSprop (a zero-gradient step leaves w alone; v is replayed by the update).
+ * The replay is BOUNDED (round 5): once a row's weights have stopped moving under zero-gradient steps -- exactly:
+ * fl(w - x) == w for a sequence of x that only shrinks; ~150-200 steps after the row's last gradient at lr 0.05 --
+ * the remaining steps cannot move them either, so a catch-up stops there and a flush only lets the moments decay.
+ * Same bits as replaying every step; switched off for betas / eps for which the argument does not hold. */
 int hiprec_lazy_catchup(const hiprec_lazy_state* state, const hiprec_lazy_rows* rows, hiprec_stats* stats, void* stream);
 /* AFTER the step's gradients are complete in g and the clock has been advanced to the step: every listed row takes the
  * step (g row cleared, stamp = clock), the scalar (last element) too -- its gradient is g's last element plus, if
