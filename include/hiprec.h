@@ -604,7 +604,9 @@ size_t hiprec_shard_bufs_bytes(void);
 
 /* Steps [step_begin, step_end) of a planned epoch, kernels and exchanges, enqueued on `stream`: per step payload +
  * clear -> grouped send / recv of rows -> gradient kernel -> partials into the extra rows -> grouped send / recv of
- * gradients -> apply + bookkeeping (-> dense sweep for kind != HIPREC_OPT_SGD).  world == 1 needs no communicator. */
+ * gradients -> apply + bookkeeping (-> dense sweep for kind != HIPREC_OPT_SGD).  With plain SGD and the plan's
+ * contribution lists (cidx / rows / counts, dim % 4 == 0) the gradient side is hiprec_mf_bpr_pull_remote_step: nothing is
+ * cleared, no float atomics, the partials are published by its second launch.  world == 1 needs no communicator. */
 int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const hiprec_shard_bufs* bufs, int64_t step_begin,
                                int64_t step_end, int32_t kind, float reg_coef, double lr, double beta1, double beta2,
                                double eps, const hiprec_nccl_fns* nccl, void* comm, hiprec_stats* stats, void* stream);
