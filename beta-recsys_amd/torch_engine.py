@@ -182,12 +182,21 @@ class ModelEngine(object):
         print("loading model from:", model_dir)
         state_dict = torch.load(model_dir, map_location=self.device)
         target = self.model if model is None else model
+        own = target is self.model
+        if optimizer_state and not own:
+            raise ValueError("the optimizer state belongs to the engine's own model")
+        if own and hasattr(self, "flush_lazy"):
+            # a lagging row's pending zero-gradient steps belong to the OLD weights and moments: replay them before
+            # the weights are replaced, never onto the restored ones
+            self.flush_lazy()
         target.load_state_dict(state_dict)
         target.to(self.device)
         if optimizer_state:
-            if target is not self.model:
-                raise ValueError("the optimizer state belongs to the engine's own model")
             self.load_optimizer_checkpoint(torch.load(model_dir + self.OPT_STATE_SUFFIX, map_location="cpu"))
+        elif own and getattr(self, "_lazy", None) is not None:
+            # weights alone were restored: they are what they are as of the engine's clock, nothing is owed to them
+            self._lazy_mark_current()
+            self._lazy["dirty"] = False
         return target
 
     def optimizer_checkpoint(self):
@@ -218,8 +227,8 @@ class ModelEngine(object):
         if payload["optimizer"] != opt.name or payload["n_params"] != self.model.flat.numel():
             raise ValueError(f"optimizer state of {payload['optimizer']!r} over {payload['n_params']} parameters does not "
                              f"fit this engine ({opt.name!r}, {self.model.flat.numel()})")
-        if hasattr(self, "flush_lazy"):
-            self.flush_lazy()
+        # (no flush here: the caller restored the weights already, and a replay of the OLD moments onto them would
+        # perturb them -- resume_checkpoint flushes BEFORE it replaces the weights; moments and stamps are overwritten)
         dev = self.model.flat.device
         self._stats.view(torch.uint8).copy_(payload["stats"].to(dev))
         for attr in ("exp_avg", "exp_avg_sq"):

@@ -94,6 +94,41 @@ def test_resume_continues_the_run_bit_for_bit(hip_device, tmp_path, optimizer, e
         assert not torch.equal(_state(c)[0], want[0])
 
 
+@pytest.mark.parametrize("optimizer_state", [True, False])
+def test_resume_into_an_engine_with_pending_lazy_replays(hip_device, tmp_path, optimizer_state):
+    """resume_checkpoint used to replace the weights FIRST and flush afterwards, so an engine whose lazy
+    state was dirty (an epoch run in pieces) replayed its OLD moments onto the just-restored weights.  The restored
+    weights must be the file's, bit for bit, and a later flush must leave them alone."""
+    import beta_recsys_amd as hp
+
+    U, I, D, B, steps = 900, 700, 64, 128, 4
+    rng = np.random.default_rng(11)
+    w0 = onp.init_params(U, I, D, seed=8)
+    triples = tuple(torch.from_numpy(a).cuda() for a in _unique_row_batches(rng, U, I, B, steps))
+    src = _engine(U, I, D, B, "adam", dense_opt="lazy")
+    src.model.load_state_dict({k: torch.from_numpy(v) for k, v in w0.items()})
+    with contextlib.redirect_stdout(io.StringIO()):
+        src.train_an_epoch(hp.DeviceTripleBatcher(*triples, B, shuffle=False), 0)
+    path = str(tmp_path / "mf.ckpt")
+    src.save_checkpoint(path, optimizer_state=True)
+    want = {k: v.clone() for k, v in src.model.state_dict().items()}
+
+    dirty = _engine(U, I, D, B, "adam", dense_opt="lazy")
+    other = tuple(torch.from_numpy(a).cuda() for a in _unique_row_batches(np.random.default_rng(12), U, I, B, steps))
+    with contextlib.redirect_stdout(io.StringIO()):
+        prepared = dirty.prepare_epoch(hp.DeviceTripleBatcher(*other, B, shuffle=False))
+        dirty.run_prepared_epoch(prepared, sync=False, steps=(0, steps - 1))     # the epoch's flush has not run
+    assert dirty._lazy["dirty"]
+    dirty.resume_checkpoint(path, optimizer_state=optimizer_state)
+    assert not dirty._lazy["dirty"]
+    dirty.flush_lazy()
+    dirty._lazy["dirty"] = True      # force the flush launch itself: nothing may be owed to any row
+    dirty.flush_lazy()
+    torch.cuda.synchronize()
+    for k, v in dirty.model.state_dict().items():
+        assert torch.equal(v, want[k]), f"{k}: {int((v != want[k]).sum())} restored elements were perturbed"
+
+
 def test_lazy_adam_resumes_beyond_the_scalars_table(hip_device):
     """a restored clock beyond the 65 536 tabulated steps (or a dense sweep at step 65 535) left the table's
     last entry zero and every later lazy step raised HIPREC_STATUS_LAZY_TABLE.  The table is created with its converged

@@ -1079,6 +1079,32 @@ def test_owned_rows_step_at_c4_shard_size(hip_device):
     touched[(U + I) * D + U:(U + I) * D + U + I][ti] = True
     touched[-1] = True
     assert not bool((moved & ~touched).any()), "a row outside the batches moved"
+    # ... and each form against the ORACLE at this size, on the compacted problem: SGD neither reads nor
+    # writes a row the three batches do not name, so oracle/mf_numpy.py runs on the touched rows renumbered
+    from helpers import assert_sgd_exact
+
+    uu, u_inv = np.unique(users, return_inverse=True)
+    ui, i_inv = np.unique(np.concatenate([pos, neg]), return_inverse=True)
+
+    def compact(flat):
+        o = np.cumsum([0, U * D, I * D, U, I, 1])
+        ue, ie = flat[o[0]:o[1]].view(U, D), flat[o[1]:o[2]].view(I, D)
+        return {"user_emb.weight": ue[tu].cpu().numpy(), "item_emb.weight": ie[ti].cpu().numpy(),
+                "user_bias.weight": flat[o[2]:o[3]][tu].cpu().numpy().reshape(-1, 1),
+                "item_bias.weight": flat[o[3]:o[4]][ti].cpu().numpy().reshape(-1, 1),
+                "global_bias": flat[o[4]:o[5]].cpu().numpy().copy()}
+
+    wc0 = compact(w0)
+    w = onp.copy_params(wc0)
+    st = onp.new_opt_state(w, "sgd")
+    ref_loss = 0.0
+    for k in range(steps):
+        sl = slice(k * B, (k + 1) * B)
+        loss, _ = onp.mf_train_step(w, st, (u_inv[sl], i_inv[:steps * B][sl], i_inv[steps * B:][sl]), "bpr", "sgd", 0.05)
+        ref_loss += loss
+    for mode in ("owned", "owned_atomic", "rows"):
+        assert_scalar_close(out[mode][1], ref_loss, 1e-5, f"loss sum, {mode} vs the oracle on the compacted problem")
+        assert_sgd_exact(compact(out[mode][0]), w, wc0, f"configs[3] shard size, {mode}, touched rows", lr=0.05, batch=B)
 
 
 @pytest.mark.parametrize("n,bs,U,I", [(1000, 128, 50, 30), (3 * 4096 + 77, 4096, 100_000, 2_000), (65536, 65536, 1_250_000, 125_000)])
