@@ -48,7 +48,7 @@ LR = 0.05
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec peak)
 MIN_TIMED_STEPS, MIN_REPEATS = 200, 5
 EPOCH_STEPS = 245  # N = 1 000 000 triples per epoch -> 245 batches of 4096 (1 003 520 triples)
-ROUND = "r05"
+ROUND = "r06"
 
 
 def algorithmic_bytes_per_triple(dim):
@@ -423,6 +423,14 @@ def bench_mf_c4shard(args, device, full=False):
     advance(warm)
     per, wall = timed_repeats(lambda r: advance(steps), steps, device)
     advance((epoch_steps - state["pos"]) % epoch_steps)
+    # two WHOLE epochs of continuous training between one event pair (staging on the side stream, every step, the
+    # epoch's flush): what a K-step window's median hides when K is shorter than an epoch
+    w0_, w1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    w0_.record()
+    advance(2 * epoch_steps)
+    w1_.record()
+    torch.cuda.synchronize()
+    whole_epochs_s = w0_.elapsed_time(w1_) * 1e-3 / (2 * epoch_steps)
     st = eng.epoch_stats()
     # the same steps with the epoch staged beforehand (nothing else on the GPU): the step kernels alone
     prepared = eng.prepare_epoch(loader)
@@ -511,6 +519,7 @@ def bench_mf_c4shard(args, device, full=False):
                            "timed_region": "continuous training; per epoch one staging pass (device shuffle, per-batch "
                                            "sort, layout, row ownership) on a side stream during the previous epoch",
                            "ms_per_step_kernels_alone": alone_s * 1e3,
+                           "ms_per_step_whole_epochs": whole_epochs_s * 1e3,
                            "last_loss": st.loss},
                 "roofline": {"bound": "hbm", "kernel": kname, "achieved": bpt_run * Bc / k_s / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bpt_run * Bc / k_s / 1e9 / HBM_PEAK_GBS,
@@ -551,7 +560,8 @@ def bench_mf_c4_sharded(args, device, world, rank, group=None):
     Uc, Ic, Dc, Bc = 10_000_000, 1_000_000, 128, 65536
     cfg = {"model": dict(n_users=Uc, n_items=Ic, emb_dim=Dc, device_str=str(device), optimizer=args.c4_optimizer, lr=LR,
                          batch_size=Bc, loss="bpr", sgd_mode="rows", shard_init="local", step_driver=args.step_driver,
-                         dense_opt=args.dense_opt, shard_sgd=args.shard_sgd),
+                         dense_opt=args.dense_opt, shard_sgd=args.shard_sgd,
+                         shard_self_exchange=bool(getattr(args, "force_exchange", False))),
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -622,7 +632,8 @@ def bench_mf_c4_sharded(args, device, world, rank, group=None):
                            "global_batch": world * Bc, "rccl_world_size": world,
                            "exchange_bytes_per_step": round(exchange["exchange_bytes_per_step"]),
                            "exchange_bytes_per_step_off_gpu": round(exchange["exchange_bytes_per_step_off_gpu"]),
-                           "a2a_GBps_per_gpu": exchange["exchange_bytes_per_step_off_gpu"] / (out["ms_per_step"] * 1e-3) / 1e9},
+                           "a2a_GBps_per_gpu": exchange["exchange_bytes_per_step_off_gpu"] / (out["ms_per_step"] * 1e-3) / 1e9,
+                           **self_exchange_fields(eng, exchange, out["ms_per_step"] * 1e-3)},
                 "roofline": {"bound": "hbm", "kernel": "whole sharded step (per GPU)",
                              "achieved": out["value"] / world * moved_bpt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": out["value"] / world * moved_bpt / (HBM_PEAK_GBS * 1e9),
@@ -1036,6 +1047,19 @@ def plan_exchange_bytes(plan, dim):
     return {"exchange_bytes_per_step": total, "exchange_bytes_per_step_off_gpu": total - own * ld / S}
 
 
+def self_exchange_fields(eng, exchange, step_s):
+    """--force-exchange: the rank's own share of both exchanges went through RCCL as well (grouped ncclSend + ncclRecv to
+    itself), so ALL of `exchange_bytes_per_step` crossed the communicator; at world 1 that is a measured loop-back
+    rate of the real send / recv path (a device-to-device copy by RCCL's kernels, not xGMI)."""
+    if not getattr(eng, "_self_exchange", False):
+        return {}
+    return {"self_exchange": True,
+            "a2a_GBps_per_gpu": exchange["exchange_bytes_per_step"] / step_s / 1e9,
+            "a2a_note": "own segment included: sent to and received from this rank itself through the real RCCL "
+                        "communicator (loop-back), a lower bound like the off-GPU figure (the exchanges are two of the "
+                        "step's six stages)"}
+
+
 def bench_mf(args, device, world, rank, dist_on, force_mode=None, force_scaling=None, group=None):
     """BASELINE configs[1] (the headline).  N = 1: MFEngine's resident epoch (one fused launch per step).
     N > 1: row-sharded tables with planned all-to-all routing (north_star's split; `--multi-gpu sharded`, and what
@@ -1060,7 +1084,9 @@ def bench_mf(args, device, world, rank, dist_on, force_mode=None, force_scaling=
         if mode == "auto":
             mode = "sharded"
         cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str=str(device), optimizer=args.optimizer,
-                             lr=LR, batch_size=b_local, loss="bpr", dp_collective=args.dp_collective),
+                             lr=LR, batch_size=b_local, loss="bpr", dp_collective=args.dp_collective,
+                             **({"shard_self_exchange": True} if mode == "sharded" and getattr(args, "force_exchange", False)
+                                else {})),
                "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
         torch.manual_seed(2020)
         with contextlib.redirect_stdout(io.StringIO()):
@@ -1202,6 +1228,7 @@ def bench_mf(args, device, world, rank, dist_on, force_mode=None, force_scaling=
         # exchanges are two of the step's six stages)
         out["config"]["a2a_GBps_per_gpu"] = exchange["exchange_bytes_per_step_off_gpu"] / step_s / 1e9
         out["config"]["step_driver"] = eng._step_mode
+        out["config"].update(self_exchange_fields(eng, exchange, step_s))
         # the sharded step has no single dominant launch: the roofline is the whole step per GPU on SURVEY 8d's bytes
         per_gpu = out["value"] / world
         moved = algorithmic_bytes_per_triple(D) + optimizer_sweep_bytes(args.optimizer, n_params // world) / b_local
@@ -1258,7 +1285,97 @@ def bench_mf_multi_gpu(args, device, world, rank, group=None):
     if rank != 0:
         return None
     out["alt"] = {"replicated": rep, "c4_sharded": c4}
+    # the step every N > 1 figure of this line is to be compared with, measured in the SAME run on rank 0's GPU while the
+    # other ranks wait at the final barrier: configs[1] on the single-GPU fused engine
+    try:
+        one = copy.copy(args)
+        one.no_cpu_baseline, one.two_kernel = True, False
+        with contextlib.redirect_stdout(io.StringIO()):
+            single = bench_mf(one, device, 1, 0, False)
+        out["single_gpu_ms_per_step"] = single["ms_per_step"]
+        out["single_gpu_value"] = single["value"]
+    except Exception as e:  # noqa: BLE001
+        out["single_gpu_ms_per_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
+
+
+ALT_WORKLOADS = ("ncf", "mf_c4shard_sgd", "mf_c4shard_adam", "mf_c4_adam_fullcov", "lightgcn")
+
+
+def alt_single_gpu(args, device, only=None):
+    """The other BASELINE.json configs under the SAME clock as the headline: the stock
+    `python bench.py --gpus 1 --steps K --warmup W` keeps configs[1] as its line and carries, as `alt`, one sub-record
+    per remaining config measured LIVE in this process -- `ncf` (configs[2], emb_dim 32), `mf_c4shard_sgd` /
+    `mf_c4shard_adam` (one rank's share of configs[3]; SGD as owner pulls, Adam as the exact lazy form),
+    `mf_c4_adam_fullcov` (configs[3] WHOLE on this GPU with the reference's default optimizer, every row met in every
+    epoch) and `lightgcn` (configs[4]).  Every record: `value`, `unit`, `ms_per_step`, `steps`, `repeats`, the
+    workload, and `roofline` with the byte / flop model named and `kernel_us` from HIP events of this run.  No CPU
+    legs, at most 50-step windows; an error in one record is reported in its place.  `--no-alt` skips all of it."""
+    import copy
+    import gc
+
+    def sub(**kw):
+        a = copy.copy(args)
+        a.steps, a.warmup, a.no_cpu_baseline = min(args.steps, 50), min(args.warmup, 10), True
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+
+    def record(out, model):
+        roof = out.get("roofline", {})
+        live_us = roof.get("kernel_us") if str(roof.get("kernel_us_source", "HIP")).startswith("HIP") else None
+        rec = {k: out[k] for k in ("value", "unit", "ms_per_step", "steps", "repeats", "wall_ms_per_step") if k in out}
+        rec["workload"] = out.get("config", {}).get("workload")
+        for k in ("ms_per_step_kernels_alone", "ms_per_step_whole_epochs", "epoch", "rows_met_per_epoch", "last_loss"):
+            if k in out.get("config", {}):
+                rec[k] = out["config"][k]
+        rec["roofline"] = {"bound": roof.get("bound"), "frac": roof.get("frac"), "achieved": roof.get("achieved"),
+                           "peak": roof.get("peak"), "unit": roof.get("unit"), "model": model,
+                           # measured in THIS run: the period of the step's launches between two HIP events
+                           "kernel_us": live_us if live_us is not None else out["ms_per_step"] * 1e3,
+                           "kernel_us_source": ("HIP events around an epoch staged beforehand (the step's launches alone)"
+                                                if live_us is not None else "HIP events around the K-step windows"),
+                           "kernel": roof.get("kernel")}
+        for k in ("step_frac", "algorithmic_bytes_per_launch", "flops_per_sample", "algorithmic_bytes_per_step",
+                  "dense_equivalent_GBps"):
+            if k in roof:
+                rec["roofline"][k] = roof[k]
+        return rec
+
+    jobs = {
+        "ncf": (lambda: bench_ncf(sub(emb_dim=32), device),
+                "fwd + dgrad + wgrad flops of the tower and head per sample (SURVEY 8d: 258 432 at emb_dim 32) over the "
+                "whole step, against the dense fp32 MFMA peak"),
+        "mf_c4shard_sgd": (lambda: bench_mf_c4shard(sub(c4_optimizer="sgd", sgd_mode="owned"), device, full=False),
+                           "SURVEY 8d: 24 + 24 (D+1) = 3 120 B per triple x 65 536 triples over the step's two launches "
+                           "(frac) and over the step with the staging in the clock (step_frac)"),
+        "mf_c4shard_adam": (lambda: bench_mf_c4shard(sub(c4_optimizer="adam"), device, full=False),
+                            "rows of the step: 3 120 B per triple + w, m, v of its 3 rows read and written (exact lazy "
+                            "Adam); SURVEY 8d's dense 28 P per step is `dense_equivalent_GBps`"),
+        "mf_c4_adam_fullcov": (lambda: bench_mf_c4shard(sub(c4_optimizer="adam", epoch_coverage="full"), device, full=True),
+                               "as mf_c4shard_adam, on the whole 10 M x 1 M x 128 table, every row met in every epoch; "
+                               "value / ms_per_step are the median K-step window, ms_per_step_whole_epochs counts the "
+                               "epoch's flush too"),
+        "lightgcn": (lambda: bench_lightgcn(sub(), device),
+                     "SURVEY 8d: 2 L SpMMs x [nnz (4 + 4 + 1) + (N + 1) 8 + 2 N D 4] B per step over the whole step"),
+    }
+    alt, t_all = {}, time.perf_counter()
+    for name in ALT_WORKLOADS:
+        if only is not None and name not in only:
+            continue
+        t0 = time.perf_counter()
+        try:
+            fn, model = jobs[name]
+            with contextlib.redirect_stdout(io.StringIO()):
+                out = fn()
+            alt[name] = record(out, model)
+        except Exception as e:  # noqa: BLE001   a sub-record must not cost the run its headline
+            alt[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
+        alt[name]["wall_s"] = round(time.perf_counter() - t0, 1)
+        gc.collect()
+        torch.cuda.empty_cache()
+    alt["wall_s"] = round(time.perf_counter() - t_all, 1)
+    return alt
 
 
 def parse_args(argv=None):
@@ -1269,6 +1386,10 @@ def parse_args(argv=None):
     ap.add_argument("--optimizer", default="adam", choices=["sgd", "adam", "rmsprop"],
                     help="mf: adam is the reference's own default (configs/mf_default.json); sgd / rmsprop are the other two torch_engine.py:23-39 builds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true",
+                    help="mf at --gpus 1: skip the `alt` sub-records (the other BASELINE configs measured in the same run)")
+    ap.add_argument("--alt-only", default=None,
+                    help="mf at --gpus 1: comma-separated subset of the `alt` sub-records (%s)" % ", ".join(ALT_WORKLOADS))
     ap.add_argument("--two-kernel", action="store_true",
                     help="mf: gradient kernel + dense optimizer sweep per step instead of the fused one-kernel step")
     ap.add_argument("--workload", default="mf", choices=["mf", "ncf", "lightgcn", "mf-c4shard", "mf-c4", "pgmf", "t2v", "ngcf"],
@@ -1304,6 +1425,11 @@ def parse_args(argv=None):
     ap.add_argument("--step-driver", default="c", choices=["c", "torch"],
                     help="row-sharded planned steps: c = kernels and grouped ncclSend/ncclRecv enqueued by one C call "
                          "per range of steps; torch = torch.distributed.all_to_all_single between the launches")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="row-sharded planned steps: every rank ALSO sends its own segment of both exchanges to itself "
+                         "through the RCCL communicator (HIPREC_SHARD_EXCHANGE_SELF; bit-identical results).  At --gpus 1 "
+                         "it runs the N > 1 code on one rank, so the grouped ncclSend / ncclRecv of the C step driver "
+                         "execute against the real library and a2a_GBps_per_gpu is a measured loop-back rate")
     ap.add_argument("--no-plan-prefetch", action="store_true",
                     help="mf-c4 on N > 1 GPUs: plan every epoch synchronously instead of during the previous one")
     ap.add_argument("--dp-collective", default=os.environ.get("HIPREC_DP_COLLECTIVE", "rccl"), choices=["rccl", "torch"],
@@ -1332,7 +1458,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     # HIPREC_BENCH_FORCE_SHARDED=1 exercises the N>1 code path on a single GPU (world size 1)
-    dist_on = world > 1 or os.environ.get("HIPREC_BENCH_FORCE_SHARDED") == "1"
+    dist_on = world > 1 or os.environ.get("HIPREC_BENCH_FORCE_SHARDED") == "1" or args.force_exchange
     json_fd = None
     if dist_on:
         import torch.distributed as dist
@@ -1366,6 +1492,8 @@ def main():
         out = bench_mf_multi_gpu(args, device, world, rank)
     else:
         out = bench_mf(args, device, world, rank, dist_on)
+        if not dist_on and out is not None and not args.no_alt and not args.two_kernel:
+            out["alt"] = alt_single_gpu(args, device, only=args.alt_only.split(",") if args.alt_only else None)
     if dist_on and args.workload in ("pgmf", "t2v", "ngcf"):
         raise SystemExit(f"--workload {args.workload} is single-GPU (no data-parallel wrapper)")
     if dist_on:

@@ -157,6 +157,9 @@ class LazyRows(Structure):
                 ("items_b", c_void_p), ("n_items_b", c_int64), ("items_c", c_void_p), ("n_items_c", c_int64)]
 
 
+SHARD_EXCHANGE_SELF = 1   # include/hiprec.h HIPREC_SHARD_EXCHANGE_SELF
+
+
 class NcclFns(Structure):
     """hiprec_nccl_fns (include/hiprec.h)."""
 
@@ -409,6 +412,9 @@ SIGNATURES = {
     "hiprec_shard_planned_steps": (
         c_int, [POINTER(ShardPlan), POINTER(ShardBufs), c_int64, c_int64, c_int32, c_float, c_double, c_double,
                 c_double, c_double, POINTER(NcclFns), _P, _P, _P]),
+    "hiprec_shard_planned_steps_ex": (
+        c_int, [POINTER(ShardPlan), POINTER(ShardBufs), c_int64, c_int64, c_int32, c_float, c_double, c_double,
+                c_double, c_double, POINTER(NcclFns), _P, ctypes.c_uint32, _P, _P]),
     "hiprec_gather_epoch": (c_int, [_P, _P, _P, _P, c_int32, ctypes.c_uint64, _P, c_int64, _P, _P, _P, _P]),
     "hiprec_stage_sort_keys": (c_int, [_P, _P, c_int32, ctypes.c_uint64, c_int64, c_int64, c_int64, c_int32, _P, _P]),
     "hiprec_group_epoch_by_item": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P,

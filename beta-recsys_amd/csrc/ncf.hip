@@ -614,18 +614,16 @@ constexpr int kFLdIn = kFNarrowIn + 1;
 constexpr size_t kFusedMaxLds = 160 * 1024 - 2048;  // (the kernels also hold a few hundred bytes of static LDS)
 
 // LDS of the fused launch, in floats: every layer's input stays ([16][width + 1] each: the tower input, then each
-// layer's output) -- the next layer reads it, the backward masks with it --, with BWD two buffers for the
-// input-gradient chain, then the weight tiles (both directions share them) and the GMF tile.
+// layer's output) -- the next layer reads it, the backward masks with it, the last phase stores it --, with BWD one
+// dZ_l buffer per layer laid out like the activations plus the layer-0 input gradient [16][2 dim_mlp + 1], then the GMF
+// tile, the waves' partial sums of d affine_output.weight and the logits / d logits of the 16 samples.
 static size_t fused_lds_floats(const hiprec_ncf_plan* p, bool bwd) {
-  size_t n = static_cast<size_t>(kFR) * (2 * p->dim_mlp + 1);
-  int maxw = 0;
-  for (int l = 0; l < p->n_layers; ++l) {
-    n += static_cast<size_t>(kFR) * (p->layer_out[l] + 1);
-    maxw = std::max(maxw, p->layer_out[l]);
-  }
-  if (bwd) n += 2 * static_cast<size_t>(kFR) * (maxw + 1);
-  n = (n + 3) / 4 * 4;  // 16-byte aligned tiles
-  return n + 2 * kFK * kFLdB + kFR * kFLdE;
+  const size_t a0 = static_cast<size_t>(kFR) * (2 * p->dim_mlp + 1);
+  size_t layers = 0;
+  for (int l = 0; l < p->n_layers; ++l) layers += static_cast<size_t>(kFR) * (p->layer_out[l] + 1);
+  size_t n = a0 + layers + (bwd ? layers + a0 : 0);
+  n = (n + 3) / 4 * 4;
+  return n + kFR * kFLdE + kFWaves * 3 * kWave + 2 * kFR;
 }
 
 static bool fusable(const hiprec_ncf_plan* p, bool bwd = false) {
@@ -779,35 +777,73 @@ __device__ unsigned long long g_ncf_stamps[2][24];
 #define NCF_STAMP(k) do {} while (0)
 #endif
 
-// ---- forward: gather -> tower -> affine_output -> sigmoid; writes act[0..L], mf, scores -----------------
+// ---- forward: gather -> tower -> affine_output -> sigmoid; writes act[0..L], scores -------------------------------
 // TRAIN: the head's backward half rides along (BCELoss term, d loss / d logit, dZ_L, dMF, d w_out,
 // the loss / d b_out partials) -- everything it needs is already in LDS, and a separate head launch
 // cost 12 us.  BWD: so does the tower's input-gradient chain and the embedding scatter (see the header).
 // A layer wider than 128 columns takes passes of 128 (8 waves x 16); LDS layout: fused_lds_floats.
+//
+// Round 6: NOTHING is stored to global memory before the block's last phase.  gfx950 counts loads, stores and
+// atomics in ONE counter (vmcnt) and the compiler, once both kinds are in flight across a branch, waits for
+// vmcnt(0): every weight chunk a layer waited for also waited for the acknowledgement of whatever the previous
+// epilogue had stored -- activations, dZ_l, the embedding-gradient atomics of a layer-0 pass, and the 64
+// same-address atomics per block of d affine_output.weight (256 blocks serialise on them: the first chain pass waited
+// 5-8 k cycles for its 8 weight dwords, in-kernel timestamps r06).  Everything the later launches need stays in LDS
+// (activations, one dZ_l buffer per layer, the layer-0 input gradient) and leaves in one sweep at the end (spreading
+// the stores over the head and the chain's last layer moved their cost, it did not hide it: same-box A/B 50.5
+// against 49.0 us); d w_out leaves as one plain row of per-block partial sums (`gw_ws`) that the grouped launch's
+// column-sum path adds up.
+// The head's scalar arithmetic (sigmoid, two logs, the BCE quotient: ~300 VALU instructions) ran once per SAMPLE on
+// all 64 lanes of a wave, two samples per wave one after the other; now lane r of wave 0 does sample r.
 template <bool TRAIN, bool DROP, bool BWD = false>
 __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
     hiprec_ncf_plan p, const int64_t* __restrict__ users, const int64_t* __restrict__ items,
     const float* __restrict__ ratings, int64_t batch, float inv_batch, hiprec_stats* stats,
-    Scratch* scratch) {
+    Scratch* scratch, float* __restrict__ gw_ws) {
   static_assert(!BWD || TRAIN, "the backward rides on the training forward");
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave;
   const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kFR;
   const int Dm = p.dim_mlp, E = p.dim_mf, K0 = 2 * Dm, n_layers = p.n_layers;
-  // LDS: act_0 (the gathered rows) | act_1 | ... | act_L | [chain A | chain B] | weight tiles | GMF tile
-  int act_floats = kFR * (K0 + 1), maxw = 0;
-  for (int l = 0; l < n_layers; ++l) {
-    act_floats += kFR * (p.layer_out[l] + 1);
-    maxw = max(maxw, p.layer_out[l]);
-  }
-  const int ld_c = maxw + 1;
-  float* chain_a = lds_raw + act_floats;  // BWD: dZ_L of the tile, then the chain's ping-pong partner
-  float* tiles = lds_raw + (act_floats + (BWD ? 2 * kFR * ld_c : 0) + 3) / 4 * 4;
-  float* s_mf = tiles + 2 * kFK * kFLdB;
+  // LDS: act_0 (the gathered rows) | act_1 | ... | act_L | [BWD: dZ_1 .. dZ_L laid out like act_1 .. act_L | the
+  // layer-0 input gradient [kFR][K0 + 1]] | GMF tile | d w_out partials of the waves | logits, d logits
+  const int ld0 = K0 + 1;
+  int act_floats = kFR * ld0;
+  for (int l = 0; l < n_layers; ++l) act_floats += kFR * (p.layer_out[l] + 1);
+  const int dz_shift = act_floats - kFR * ld0;          // dZ_l sits dz_shift floats behind act_l (l >= 1)
+  float* d0 = lds_raw + act_floats + dz_shift;          // BWD only
+  float* s_mf = lds_raw + (act_floats + (BWD ? dz_shift + kFR * ld0 : 0) + 3) / 4 * 4;
+  float* s_gw = s_mf + kFR * kFLdE;                     // [kFWaves][3 * kWave]
+  float* s_logit = s_gw + kFWaves * 3 * kWave;          // [kFR]
+  float* s_dl = s_logit + kFR;                          // [kFR]
 
   NCF_STAMP(0);
-  // Loads that depend on nothing the block computes go first, off its serial chain: layer 0's first weight chunks,
+  // The index pairs are fetched by the LAST wave before it requests anything else: it then waits for exactly these two
+  // loads (vmcnt counts in order: behind the weight prefetch the fetching wave waited for the tower's cold lines as
+  // well, 5.5 k cycles instead of one miss), the other seven go straight to their prefetch.
+  // gather, element-parallel: 16 threads fetch the index pairs, then every thread owns one column of 8 (tower input
+  // up to 256 wide: the two halves of the block take 8 rows each) or 16 rows; all its loads are requested before
+  // anything is stored (one round trip for the whole tile instead of one per row)
+  __shared__ long long s_u[kFR], s_i[kFR];
+  if (wave == kFWaves - 1 && lane < kFR) {
+    const int64_t b = m0 + lane;
+    long long u = -1, it = -1;
+    if (b < batch) {
+      u = users[b];
+      it = items[b];
+      const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(p.n_users);
+      const bool i_ok = static_cast<uint64_t>(it) < static_cast<uint64_t>(p.n_items);
+      if (!(u_ok && i_ok)) {
+        atomicOr(&stats->status,
+                 (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
+        u = it = -1;
+      }
+    }
+    s_u[lane] = u;
+    s_i[lane] = it;
+  }
+  // Loads that depend on nothing the block computes go next, off its serial chain: layer 0's first weight chunks,
   // this lane's bias element of the first pass, the head's weights and targets.
   FusedGemm gemm;
   gemm.begin(p.fc_w[0], p.layer_in[0], min(p.layer_out[0], kFMaxN));
@@ -821,41 +857,19 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
   float wout[3];  // nV <= 192
 #pragma unroll
   for (int k = 0; k < 3; ++k) wout[k] = lane + kWave * k < nV ? p.out_w[lane + kWave * k] : 0.f;
-  float rt[kFR / kFWaves];
-  if (TRAIN) {
-#pragma unroll
-    for (int j = 0; j < kFR / kFWaves; ++j) {
-      const int64_t b = m0 + wave + j * kFWaves;
-      rt[j] = ratings[b < batch ? b : batch - 1];
-    }
+  float rt = 0.f;  // lane r of wave 0: the target of sample r
+  if (TRAIN && wave == 0 && lane < kFR) {
+    const int64_t b = m0 + lane;
+    rt = ratings[b < batch ? b : batch - 1];
   }
+  const bool stepper = TRAIN && blockIdx.x == 0 && tid == 0;
+  StepState step_state{};
+  if (stepper) step_state = step_load(stats);
 
-  // gather, element-parallel: 16 threads fetch the index pairs, then every thread owns one column of 8 (tower input
-  // up to 256 wide: the two halves of the block take 8 rows each) or 16 rows; all its loads are requested before
-  // anything is stored (one round trip for the whole tile instead of one per row)
-  __shared__ long long s_u[kFR], s_i[kFR];
-  if (tid < kFR) {
-    const int64_t b = m0 + tid;
-    long long u = -1, it = -1;
-    if (b < batch) {
-      u = users[b];
-      it = items[b];
-      const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(p.n_users);
-      const bool i_ok = static_cast<uint64_t>(it) < static_cast<uint64_t>(p.n_items);
-      if (!(u_ok && i_ok)) {
-        atomicOr(&stats->status,
-                 (u_ok ? 0u : HIPREC_STATUS_USER_OOB) | (i_ok ? 0u : HIPREC_STATUS_ITEM_OOB));
-        u = it = -1;
-      }
-    }
-    s_u[tid] = u;
-    s_i[tid] = it;
-  }
   lds_barrier();
   NCF_STAMP(1);
   constexpr int kPerE = kFR * kFMaxE / kFThreads;  // GMF elements per thread (2)
   float gmf_um[kPerE], gmf_im[kPerE];              // BWD: the two factors, for the GMF rows' gradients
-  const int ld0 = K0 + 1;
   {
     static_assert(kFMaxIn == kFThreads && kFMaxE == kWave, "gather mapping");
     const bool halves = K0 <= kFThreads / 2;  // block-uniform
@@ -887,6 +901,16 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
         gmf_im[j] = im;
       }
     }
+    // the Dropout in front of the first Linear (ncf.py:42-45, mlp.py:30-33): one keep byte per element
+    uint8_t k0[kFR];
+    if constexpr (DROP) {
+#pragma unroll
+      for (int j = 0; j < kFR; ++j) {
+        k0[j] = 1;
+        if (j < n_rows_t && p.keep[0] && col_t < K0 && m0 + row0 + j < batch)
+          k0[j] = p.keep[0][(m0 + row0 + j) * K0 + col_t];
+      }
+    }
     if (col_t < K0) {
 #pragma unroll
       for (int j = 0; j < kFR; ++j) {
@@ -894,20 +918,16 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
         const int r = row0 + j;
         float x = s_u[r] >= 0 ? v[j] : 0.f;
         if (p.relu_input) x = fmaxf(x, 0.f);
-        // the Dropout in front of the first Linear (ncf.py:42-45, mlp.py:30-33): one keep byte per element
         if constexpr (DROP)
-          if (p.keep[0] && m0 + r < batch) x = p.keep[0][(m0 + r) * K0 + col_t] ? x * p.keep_scale : 0.f;
+          if (p.keep[0]) x = k0[j] ? x * p.keep_scale : 0.f;
         lds_raw[r * ld0 + col_t] = x;
-        if (m0 + r < batch) p.act[0][(m0 + r) * K0 + col_t] = x;
       }
     }
     if ((tid & 63) < E) {
 #pragma unroll
       for (int j = 0; j < kPerE; ++j) {
         const int r = j * (kFThreads / kWave) + (tid >> 6);
-        const float x = s_u[r] >= 0 ? w[j] : 0.f;
-        s_mf[r * kFLdE + (tid & 63)] = x;
-        if (m0 + r < batch) p.mf[(m0 + r) * E + (tid & 63)] = x;
+        s_mf[r * kFLdE + (tid & 63)] = s_u[r] >= 0 ? w[j] : 0.f;
       }
     }
   }
@@ -920,8 +940,19 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
     const int out_off = in_off + kFR * ld_in, ld_out = N + 1;
     float* out = lds_raw + out_off;
     for (int n_off = 0; n_off < N; n_off += kFMaxN) {
+      // the keep bytes of this pass's outputs (the NEXT Linear's Dropout) are requested before the GEMM
+      uint8_t kb[4] = {1, 1, 1, 1};
+      if constexpr (DROP) {
+        if (l + 1 < n_layers && p.keep[l + 1] && wn * 16 < N - n_off) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t row = m0 + 4 * (lane >> 4) + r;
+            if (row < batch) kb[r] = p.keep[l + 1][row * N + n_off + wn * 16 + (lane & 15)];
+          }
+        }
+      }
       f32x4 acc;
-      gemm.run(acc, lds_raw + in_off, ld_in, tiles);
+      gemm.run(acc, lds_raw + in_off, ld_in, nullptr);
       // the next pass's (or layer's) first weight chunks and bias travel under this epilogue
       if (n_off + kFMaxN < N) {
         gemm.begin(p.fc_w[l] + static_cast<int64_t>(n_off + kFMaxN) * K, K, min(kFMaxN, N - n_off - kFMaxN));
@@ -939,10 +970,8 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
           // act[l + 1] is what the NEXT Linear sees: its Dropout is applied here (the backward's dgrad epilogue
           // applies the same keep bytes)
           if constexpr (DROP)
-            if (l + 1 < n_layers && p.keep[l + 1] && m0 + row < batch)
-              v = p.keep[l + 1][(m0 + row) * N + col] ? v * p.keep_scale : 0.f;
+            if (l + 1 < n_layers && p.keep[l + 1]) v = kb[r] ? v * p.keep_scale : 0.f;
           out[row * ld_out + col] = v;
-          if (m0 + row < batch) p.act[l + 1][(m0 + row) * N + col] = v;
         }
       }
       lds_barrier();
@@ -957,136 +986,193 @@ __global__ __launch_bounds__(kFThreads) void ncf_fused_forward_kernel(
   if constexpr (BWD)
     gnn.begin(p.fc_w[n_layers - 1], p.layer_in[n_layers - 1], p.layer_out[n_layers - 1],
               min(p.layer_in[n_layers - 1], kFMaxN), 0);
-  // affine_output + sigmoid: wave w scores rows w, w + 8, ...
+  // affine_output: wave w takes the dot products of rows w, w + 8, ...
   const float* in = lds_raw + in_off;  // act_L
   const int ld_h = ld_in;
-  const bool stepper = TRAIN && blockIdx.x == 0 && tid == 0;
-  StepState step_state{};
-  if (stepper) step_state = step_load(stats);
-  float loss_acc = 0.f, gb_acc = 0.f;
-  float gw[3] = {0.f, 0.f, 0.f};
+  float vec[kFR / kFWaves][3];
 #pragma unroll
   for (int j = 0; j < kFR / kFWaves; ++j) {
     const int r = wave + j * kFWaves;
-    const int64_t b = m0 + r;
-    if (b >= batch) {
-      if constexpr (BWD) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (lane + kWave * k < nH) chain_a[r * ld_c + lane + kWave * k] = 0.f;
-      }
-      continue;
-    }
-    float vec[3];
     float part = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int c = lane + kWave * k;
-      vec[k] = c < nH ? in[r * ld_h + c] : (c < nV ? s_mf[r * kFLdE + (c - nH)] : 0.f);
-      part += vec[k] * wout[k];
+      vec[j][k] = c < nH ? in[r * ld_h + c] : (c < nV ? s_mf[r * kFLdE + (c - nH)] : 0.f);
+      part += vec[j][k] * wout[k];
     }
     const float logit = wave_sum(part) + bo;
-    const float y = sigmoid_f32(logit);
-    if (lane == 0) p.scores[b] = y;
-    if (!TRAIN) continue;
-    const float ly = fmaxf(logf(y), -100.f);
-    const float l1y = fmaxf(log1pf(-y), -100.f);
-    loss_acc += -(rt[j] * ly + (1.f - rt[j]) * l1y);
-    const float gy = (y - rt[j]) / fmaxf((1.f - y) * y, 1e-12f) * inv_batch;
-    const float dl = gy * ((1.f - y) * y);
-    gb_acc += dl;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int c = lane + kWave * k;
-      if (c < nV) gw[k] += dl * vec[k];
-      if (c < nH) {
-        // d loss / d z_L = d h_L * [h_L > 0]  (ReLU of the last Linear, applied twice in NeuMF)
-        const float dz = vec[k] > 0.f ? dl * wout[k] : 0.f;
-        p.dact[n_layers][b * nH + c] = dz;
-        if constexpr (BWD) chain_a[r * ld_c + c] = dz;
-      } else if (c < nV) {
-        p.dmf[b * E + (c - nH)] = dl * wout[k];
-        if constexpr (BWD) s_mf[r * kFLdE + (c - nH)] = dl * wout[k];  // (this lane just read the product there)
+    if (lane == 0) s_logit[r] = logit;
+  }
+  lds_barrier();
+  // sigmoid, BCELoss (PyTorch's -100 clamp) and d loss / d logit: lane r of wave 0 = sample r
+  float y_mine = 0.f, loss_w = 0.f, gb_w = 0.f;
+  if (wave == 0) {
+    float loss_l = 0.f, dl = 0.f;
+    if (lane < kFR && m0 + lane < batch) {
+      y_mine = sigmoid_f32(s_logit[lane]);
+      if constexpr (TRAIN) {
+        const float ly = fmaxf(logf(y_mine), -100.f);
+        const float l1y = fmaxf(log1pf(-y_mine), -100.f);
+        loss_l = -(rt * ly + (1.f - rt) * l1y);
+        const float gy = (y_mine - rt) / fmaxf((1.f - y_mine) * y_mine, 1e-12f) * inv_batch;
+        dl = gy * ((1.f - y_mine) * y_mine);
       }
+    }
+    if constexpr (TRAIN) {
+      if (lane < kFR) s_dl[lane] = dl;
+      loss_w = wave_sum(loss_l);
+      gb_w = wave_sum(dl);
     }
   }
   NCF_STAMP(8);
-  if (!TRAIN) return;
-  if (stepper) step_store_advanced(stats, step_state);
-  // d affine_output.weight: the waves' sums meet in LDS (the weight tile is free by now), one atomic
-  // per (block, column); loss partial (reg slot unused = 0), d b_out in the scalar-gradient slot
-  float* s_gw = tiles;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int c = lane + kWave * k;
-    if (c < nV) s_gw[wave * (3 * kWave) + c] = gw[k];
+  if constexpr (!TRAIN) {
+    if (wave == 0 && lane < kFR && m0 + lane < batch) p.scores[m0 + lane] = y_mine;
   }
-  publish_partials<kFWaves>(loss_acc, 0.f, gb_acc, inv_batch, scratch);  // barriers inside
-  lds_barrier();
-  for (int c = tid; c < nV; c += kFThreads) {
-    float t = 0.f;
+  if constexpr (TRAIN) {
+    lds_barrier();
+    // dZ_L (the ReLU of the last Linear, applied twice in NeuMF, masks it), dMF, this wave's share of d w_out
+    float gw[3] = {0.f, 0.f, 0.f};
+    float* dz_top = lds_raw + in_off + dz_shift;   // BWD: dZ_L, laid out like act_L
 #pragma unroll
-    for (int w = 0; w < kFWaves; ++w) t += s_gw[w * (3 * kWave) + c];
-    if (t != 0.f) atomic_add_f32(p.g_out_w + c, t);
-  }
-  NCF_STAMP(9);
-  if constexpr (BWD) {
-    // ---- the input-gradient chain on the same 16 samples (ncf_fused_dgrad_kernel, with everything it loads from
-    // HBM already here: ids, activations for the ReLU masks, dZ_L, the GMF factors) ----
-    lds_barrier();  // s_gw lived in the weight tiles
-    NCF_STAMP(17);
-    float* cin = chain_a;
-    float* cout = chain_a + kFR * ld_c;
-    int h_off = in_off;  // act_{l+1}; act_l sits right before it
-    for (int l = n_layers - 1; l >= 0; --l) {
-      const int nin = p.layer_in[l], nout = p.layer_out[l];
-      const bool masked = l > 0 || p.relu_input;
-      const int ld_h_l = nin + 1;
-      h_off -= kFR * ld_h_l;
-      const float* h_l = lds_raw + h_off;
-      for (int n_off = 0; n_off < nin; n_off += kFMaxN) {
-        const int n_pass = min(kFMaxN, nin - n_off);
-        const int col = n_off + wn * 16 + (lane & 15);
-        const bool live_col = wn * 16 < n_pass;
-        uint8_t kb[4] = {1, 1, 1, 1};
-        if constexpr (DROP) {
+    for (int j = 0; j < kFR / kFWaves; ++j) {
+      const int r = wave + j * kFWaves;
+      const int64_t b = m0 + r;
+      const float dl = s_dl[r];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int64_t row = m0 + 4 * (lane >> 4) + r;
-            if (p.keep[l] && live_col && row < batch) kb[r] = p.keep[l][row * nin + col];
-          }
+      for (int k = 0; k < 3; ++k) {
+        const int c = lane + kWave * k;
+        if (c < nV) gw[k] += dl * vec[j][k];
+        if (c < nH) {
+          const float dz = vec[j][k] > 0.f ? dl * wout[k] : 0.f;
+          if constexpr (BWD) dz_top[r * ld_h + c] = dz;
+          else if (b < batch) p.dact[n_layers][b * nH + c] = dz;
+        } else if (c < nV) {
+          if constexpr (BWD) s_mf[r * kFLdE + (c - nH)] = dl * wout[k];  // (this lane read the product there)
+          else if (b < batch) p.dmf[b * E + (c - nH)] = dl * wout[k];
         }
-        f32x4 acc;
-        gnn.run(acc, cin, ld_c, tiles);
-        if (l == n_layers - 1) NCF_STAMP(18);
-        if (n_off + kFMaxN < nin)
-          gnn.begin(p.fc_w[l], nin, nout, min(kFMaxN, nin - n_off - kFMaxN), n_off + kFMaxN);
-        else if (l > 0)
-          gnn.begin(p.fc_w[l - 1], p.layer_in[l - 1], p.layer_out[l - 1], min(p.layer_in[l - 1], kFMaxN), 0);
-        if (l == n_layers - 1) NCF_STAMP(19);
-        if (live_col) {
+      }
+    }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int lrow = 4 * (lane >> 4) + r;
-            float v = (!masked || h_l[lrow * ld_h_l + col] > 0.f) ? acc[r] : 0.f;
-            if constexpr (DROP)
-              if (p.keep[l]) v = kb[r] ? v * p.keep_scale : 0.f;
-            if (l > 0) {
-              cout[lrow * ld_c + col] = v;
-              if (m0 + lrow < batch) p.dact[l][(m0 + lrow) * nin + col] = v;
-            } else if (s_u[lrow] >= 0 && v != 0.f) {  // tower input = [user_mlp row | item_mlp row]
-              if (col < Dm) atomic_add_f32(p.g_user_mlp + s_u[lrow] * Dm + col, v);
-              else atomic_add_f32(p.g_item_mlp + s_i[lrow] * Dm + (col - Dm), v);
+    for (int k = 0; k < 3; ++k) {
+      const int c = lane + kWave * k;
+      if (c < nV) s_gw[wave * (3 * kWave) + c] = gw[k];
+    }
+    NCF_STAMP(9);
+    if constexpr (BWD) {
+      // ---- the input-gradient chain on the same 16 samples: dZ_{l} = (dZ_{l+1} W_l) * [act_l > 0] (and the Dropout
+      // in front of Linear l), every dZ_l kept in LDS; layer 0's result is the gradient of the gathered rows ----
+      lds_barrier();
+      NCF_STAMP(17);
+      int h_off = in_off;  // act_{l+1}; act_l sits right before it
+      for (int l = n_layers - 1; l >= 0; --l) {
+        const int nin = p.layer_in[l], nout = p.layer_out[l];
+        const bool masked = l > 0 || p.relu_input;
+        const int ld_h_l = nin + 1, ld_c = nout + 1;
+        const float* cin = lds_raw + h_off + dz_shift;   // dZ_{l+1}
+        h_off -= kFR * ld_h_l;
+        const float* h_l = lds_raw + h_off;
+        float* cout = l > 0 ? lds_raw + h_off + dz_shift : d0;   // dZ_l like act_l; layer 0: [kFR][K0 + 1]
+        for (int n_off = 0; n_off < nin; n_off += kFMaxN) {
+          const int n_pass = min(kFMaxN, nin - n_off);
+          const int col = n_off + wn * 16 + (lane & 15);
+          const bool live_col = wn * 16 < n_pass;
+          uint8_t kb[4] = {1, 1, 1, 1};
+          if constexpr (DROP) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int64_t row = m0 + 4 * (lane >> 4) + r;
+              if (p.keep[l] && live_col && row < batch) kb[r] = p.keep[l][row * nin + col];
             }
           }
+          f32x4 acc;
+          gnn.run(acc, cin, ld_c, nullptr);
+#ifdef NCF_PRINTF
+          if (blockIdx.x == 0 && (tid == 0 || tid == 17) && n_off == 0)
+            printf("l %d tid %d: cin[0..2] %g %g %g (off %d) ld_c %d nchunks %d ok %d acc %g %g %g %g mask %g col %d ld_h_l %d w0 %g %g\n", l, tid,
+                   cin[0], cin[1], cin[2], (int)(cin - lds_raw), ld_c, gnn.n_chunks, (int)gnn.ok, acc[0], acc[1], acc[2], acc[3],
+                   h_l[(4 * (lane >> 4)) * ld_h_l + col], col, ld_h_l, gnn.w[0][0], gnn.w[0][1]);
+#endif
+          if (l == n_layers - 1) NCF_STAMP(18);
+          if (n_off + kFMaxN < nin)
+            gnn.begin(p.fc_w[l], nin, nout, min(kFMaxN, nin - n_off - kFMaxN), n_off + kFMaxN);
+          else if (l > 0)
+            gnn.begin(p.fc_w[l - 1], p.layer_in[l - 1], p.layer_out[l - 1], min(p.layer_in[l - 1], kFMaxN), 0);
+          if (l == n_layers - 1) NCF_STAMP(19);
+          if (live_col) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int lrow = 4 * (lane >> 4) + r;
+              // (the mask as a factor: hipcc 7.2 compiled `mask ? acc[r] : 0.f` into "acc[r] = 0" for BOTH arms once the
+              // value went to LDS only -- the select's true arm was coalesced away; r06 experiments)
+              const float hm = masked ? h_l[lrow * ld_h_l + col] : 1.f;
+              float v = acc[r] * (hm > 0.f ? 1.f : 0.f);
+              if constexpr (DROP)
+                if (p.keep[l]) v = kb[r] ? v * p.keep_scale : 0.f;
+              cout[lrow * ld_h_l + col] = v;
+            }
+          }
+          if (l == n_layers - 1) NCF_STAMP(20);
+          lds_barrier();
+#ifdef NCF_PRINTF
+          if (blockIdx.x == 0 && (tid == 0 || tid == 17) && n_off == 0)
+            printf("   after l %d tid %d: cout off %d live %d cout[0..2] %g %g %g  row1: %g %g\n", l, tid, (int)(cout - lds_raw), (int)live_col,
+                   cout[0], cout[1], cout[2], cout[ld_h_l], cout[ld_h_l + 1]);
+#endif
         }
-        if (l == n_layers - 1) NCF_STAMP(20);
-        lds_barrier();
+        NCF_STAMP(10 + (n_layers - 1 - l));
       }
-      float* t = cin;
-      cin = cout;
-      cout = t;
-      NCF_STAMP(10 + (n_layers - 1 - l));
+    }
+  }
+
+  // ---- the block's only stores: one sweep, rows by wave, 256-byte row segments -------------------------------------
+  if constexpr (TRAIN) {
+    publish_partials<kFWaves>(loss_w, 0.f, gb_w, inv_batch, scratch);  // (barrier inside: s_gw is complete after it)
+    lds_barrier();
+    if (wave == 0 && lane < kFR && m0 + lane < batch) p.scores[m0 + lane] = y_mine;
+    if (stepper) step_store_advanced(stats, step_state);
+    // d affine_output.weight: the waves' sums, one row of per-block partial sums for the grouped launch's column sums
+    // (or, without the work space, one atomic per block and column)
+    for (int c = tid; c < nV; c += kFThreads) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < kFWaves; ++w) t += s_gw[w * (3 * kWave) + c];
+      if (gw_ws) gw_ws[static_cast<int64_t>(blockIdx.x) * nV + c] = t;
+      else if (t != 0.f) atomic_add_f32(p.g_out_w + c, t);
+    }
+  }
+  // Activations (and, BWD, every dZ_l) for the weight-gradient launch: rows by wave, 256-byte row segments.  (16 bytes
+  // per lane, eight pieces read from LDS together and stored together, was SLOWER: 51.0 against 49.3 us, same box.)
+  // act_L feeds the head only, whose weight gradient this launch has already formed: with BWD it stays in LDS.
+#pragma unroll
+  for (int j = 0; j < kFR / kFWaves; ++j) {
+    const int r = wave + j * kFWaves;
+    const int64_t b = m0 + r;
+    if (b >= batch) continue;
+    for (int c = lane; c < K0; c += kWave) p.act[0][b * K0 + c] = lds_raw[r * ld0 + c];
+    int off = kFR * ld0;
+    for (int l = 0; l < n_layers; ++l) {
+      const int N = p.layer_out[l], ld = N + 1;
+      for (int c = lane; c < N; c += kWave) {
+        if (!BWD || l + 1 < n_layers) p.act[l + 1][b * N + c] = lds_raw[off + r * ld + c];
+        if constexpr (BWD) p.dact[l + 1][b * N + c] = lds_raw[off + dz_shift + r * ld + c];
+      }
+      off += kFR * ld;
+    }
+  }
+  if constexpr (BWD) {
+    // tower input = [user_mlp row | item_mlp row]: the embedding-row gradients, 256-byte runs of one row
+#pragma unroll
+    for (int j = 0; j < kFR / kFWaves; ++j) {
+      const int r = wave + j * kFWaves;
+      const long long u = s_u[r], it = s_i[r];
+      if (m0 + r >= batch || u < 0) continue;
+      for (int c = lane; c < K0; c += kWave) {
+        const float v = d0[r * ld0 + c];
+        if (v != 0.f) {
+          if (c < Dm) atomic_add_f32(p.g_user_mlp + u * Dm + c, v);
+          else atomic_add_f32(p.g_item_mlp + it * Dm + (c - Dm), v);
+        }
+      }
     }
     // GMF rows: d user_mf = dmf * item_mf and the other way round (dmf sits where the product was)
     if ((tid & 63) < E) {
@@ -1286,7 +1372,7 @@ static int fused_attrs() {
 static int forward(const hiprec_ncf_plan* p, const int64_t* users, const int64_t* items,
                    int64_t batch, hiprec_stats* stats, hipStream_t st, bool* scored,
                    const float* ratings = nullptr, float inv_batch = 0.f, Scratch* scratch = nullptr,
-                   bool* chained = nullptr) {
+                   bool* chained = nullptr, float* gw_ws = nullptr) {
   // chained (training only): if given and the fused launch is taken, it also runs the tower's input-gradient chain
   // and the embedding scatter (*chained = true); the caller then only owes the weight / bias gradients
   *scored = false;
@@ -1302,23 +1388,23 @@ static int forward(const hiprec_ncf_plan* p, const int64_t* users, const int64_t
     if (chain) {
       if (drop)
         ncf_fused_forward_kernel<true, true, true><<<grid, kFThreads, lds, st>>>(
-            *p, users, items, ratings, batch, inv_batch, stats, scratch);
+            *p, users, items, ratings, batch, inv_batch, stats, scratch, gw_ws);
       else
         ncf_fused_forward_kernel<true, false, true><<<grid, kFThreads, lds, st>>>(
-            *p, users, items, ratings, batch, inv_batch, stats, scratch);
+            *p, users, items, ratings, batch, inv_batch, stats, scratch, gw_ws);
       *chained = true;
     } else if (ratings && drop)
       ncf_fused_forward_kernel<true, true><<<grid, kFThreads, lds, st>>>(
-          *p, users, items, ratings, batch, inv_batch, stats, scratch);
+          *p, users, items, ratings, batch, inv_batch, stats, scratch, nullptr);
     else if (ratings)
       ncf_fused_forward_kernel<true, false><<<grid, kFThreads, lds, st>>>(
-          *p, users, items, ratings, batch, inv_batch, stats, scratch);
+          *p, users, items, ratings, batch, inv_batch, stats, scratch, nullptr);
     else if (drop)   // model.train() + forward(): the reference applies dropout there too
       ncf_fused_forward_kernel<false, true><<<grid, kFThreads, lds, st>>>(
-          *p, users, items, nullptr, batch, 0.f, stats, nullptr);
+          *p, users, items, nullptr, batch, 0.f, stats, nullptr, nullptr);
     else
       ncf_fused_forward_kernel<false, false><<<grid, kFThreads, lds, st>>>(
-          *p, users, items, nullptr, batch, 0.f, stats, nullptr);
+          *p, users, items, nullptr, batch, 0.f, stats, nullptr, nullptr);
     HIPREC_TRY(hipGetLastError());
     *scored = true;
     return 0;
@@ -1404,11 +1490,17 @@ static int ncf_grad_impl(const hiprec_ncf_plan* plan, const int64_t* users, cons
 #else
   constexpr bool no_fused_bwd = false, split_bwd = false;
 #endif
-  const bool group_ok = !no_fused_bwd && 2 * p->n_layers <= kMaxGroup;  // one grouped launch for all weight gradients
+  const bool group_ok = !no_fused_bwd && 2 * p->n_layers + 1 <= kMaxGroup;  // one grouped launch for all weight gradients
   const bool fuse_bwd = group_ok && (fusable(p, true) || fusable_narrow(p));
+  // d affine_output.weight leaves the chained launch as one row of partial sums per 16-sample block; plan->dact[0]
+  // (the tower input's gradient: that launch scatters it straight into the embedding gradients and never writes it)
+  // is the work space, the grouped launch adds the rows up.  (A batch too small for its dact[0] to hold them: atomics.)
+  const int nV_head = p->layer_out[p->n_layers > 0 ? p->n_layers - 1 : 0] + p->dim_mf;
+  const int64_t n_tiles = (batch + kFR - 1) / kFR;
+  float* gw_ws = (p->dim_mlp > 0 && n_tiles * nV_head <= batch * 2 * p->dim_mlp) ? p->dact[0] : nullptr;
   bool scored = false, chained = false;
   if (int rc = forward(p, users, items, batch, stats, st, &scored, ratings, inv_batch,
-                       static_cast<Scratch*>(scratch), fuse_bwd && !split_bwd ? &chained : nullptr))
+                       static_cast<Scratch*>(scratch), fuse_bwd && !split_bwd ? &chained : nullptr, gw_ws))
     return rc;
   // not chained onto the forward (batch beyond its limit, "split"): the chain's own launch has narrower limits
   const bool bwd_two_launches = fuse_bwd && (chained || fusable_narrow(p));
@@ -1440,6 +1532,8 @@ static int ncf_grad_impl(const hiprec_ncf_plan* plan, const int64_t* users, cons
                              nullptr, 0, /*split_k=*/true);
       g.p[g.n++] = make_colsum(p->dact[l + 1], B, nout, nout, p->g_fc_b[l]);
     }
+    if (chained && gw_ws)
+      g.p[g.n++] = make_colsum(gw_ws, static_cast<int>(n_tiles), nV_head, nV_head, p->g_out_w);
     if (sweep && sweep->n_blocks > 0) {
       g.sweep = *sweep;
       *swept = true;

@@ -508,15 +508,24 @@ extern "C" int hiprec_mf_bpr_grad_remote_step(const float*, float*, int64_t, int
 extern "C" size_t hiprec_shard_plan_bytes(void) { return sizeof(hiprec_shard_plan); }
 extern "C" size_t hiprec_shard_bufs_bytes(void) { return sizeof(hiprec_shard_bufs); }
 
-extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const hiprec_shard_bufs* bufs,
-                                          int64_t step_begin, int64_t step_end, int32_t kind, float reg_coef,
-                                          double lr, double beta1, double beta2, double eps,
-                                          const hiprec_nccl_fns* nccl, void* comm, hiprec_stats* stats, void* stream) {
+extern "C" int hiprec_shard_planned_steps_ex(const hiprec_shard_plan* plan, const hiprec_shard_bufs* bufs,
+                                             int64_t step_begin, int64_t step_end, int32_t kind, float reg_coef,
+                                             double lr, double beta1, double beta2, double eps,
+                                             const hiprec_nccl_fns* nccl, void* comm, uint32_t flags,
+                                             hiprec_stats* stats, void* stream) {
   HIPREC_REQUIRE(plan && bufs && stats, "NULL pointer");
   const int R = plan->world, me = plan->rank;
   HIPREC_REQUIRE(R >= 1 && R <= 64 && me >= 0 && me < R, "bad world / rank");
-  HIPREC_REQUIRE(R == 1 || (nccl && comm && nccl->send && nccl->recv && nccl->group_start && nccl->group_end),
-                 "a world of %d ranks needs the RCCL entry points and a communicator", R);
+  HIPREC_REQUIRE((flags & ~static_cast<uint32_t>(HIPREC_SHARD_EXCHANGE_SELF)) == 0, "unknown flag bits %#x", flags);
+  // HIPREC_SHARD_EXCHANGE_SELF: this rank's OWN segment of both exchanges travels through the communicator as well (a
+  // grouped send to + recv from itself) instead of being written in place by the payload / read in place by the apply
+  // launch.  Same results bit for bit (the exchange is a copy); it is how a single GPU executes the ncclSend / ncclRecv
+  // path of this driver against the real library, and a self-test of the binding on any rank of a larger world.
+  const bool self_x = (flags & HIPREC_SHARD_EXCHANGE_SELF) != 0;
+  const bool exchange = R > 1 || self_x;
+  HIPREC_REQUIRE(!exchange || (nccl && comm && nccl->send && nccl->recv && nccl->group_start && nccl->group_end),
+                 "a world of %d ranks%s needs the RCCL entry points and a communicator", R,
+                 self_x ? " exchanging with itself" : "");
   HIPREC_REQUIRE(0 <= step_begin && step_begin <= step_end && step_end <= plan->n_steps, "bad step range");
   HIPREC_REQUIRE(plan->users && plan->pos_slot && plan->neg_slot && plan->own && plan->total && plan->in_idx &&
                      plan->ex_req && plan->ex_in && plan->in_off_host && plan->n_slots_host && plan->req_cnt_host &&
@@ -585,7 +594,8 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
       in_lo += inc[q] + 1;
       req_lo += req[q] + 1;
     }
-    const int64_t in_hi = in_lo + inc[me] + 1;
+    if (self_x) in_lo = 0;   // no segment is "self": [0, 0)
+    const int64_t in_hi = self_x ? 0 : in_lo + inc[me] + 1;
     float* self_fetched = bufs->fetched + req_lo * ld;
     float* self_g = bufs->g_send + req_lo * ld;
     const uint8_t* shared = plan->slot_shared ? plan->slot_shared + s * plan->slot_stride : nullptr;
@@ -598,14 +608,14 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
     if (int rc = hiprec_shard_payload_zero(item_emb, item_bias, ni, D, idx, il, in_lo, in_hi, bufs->payload,
                                            self_fetched, bufs->g_send, pull ? 0 : sl * ld, shared, stats, stream))
       return rc;
-    if (R > 1) {
+    if (exchange) {
       if (g_start()) {
         set_error("ncclGroupStart failed before the row exchange of step %lld", (long long)s);
         return HIPREC_E_UNSUPPORTED;
       }
       int64_t io = 0, ro = 0;
       for (int q = 0; q < R; ++q) {
-        if (q != me) {
+        if (q != me || self_x) {
           if (send(bufs->payload + io * ld, static_cast<size_t>((inc[q] + 1) * ld), kNcclFloat32, q, comm, st) ||
               recv(bufs->fetched + ro * ld, static_cast<size_t>((req[q] + 1) * ld), kNcclFloat32, q, comm, st)) {
             g_end();
@@ -648,14 +658,14 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
     if (!pull)   // (the pull launch has published the partials itself)
       shard_publish_partials_kernel<<<1, kBlock, 0, st>>>(static_cast<const Scratch*>(bufs->scratch), bufs->g_send, ld,
                                                           nullptr, plan->ex_req + s * R, R);
-    if (R > 1) {
+    if (exchange) {
       if (g_start()) {
         set_error("ncclGroupStart failed before the gradient exchange of step %lld", (long long)s);
         return HIPREC_E_UNSUPPORTED;
       }
       int64_t io = 0, ro = 0;
       for (int q = 0; q < R; ++q) {
-        if (q != me) {
+        if (q != me || self_x) {
           if (send(bufs->g_send + ro * ld, static_cast<size_t>((req[q] + 1) * ld), kNcclFloat32, q, comm, st) ||
               recv(bufs->g_recv + io * ld, static_cast<size_t>((inc[q] + 1) * ld), kNcclFloat32, q, comm, st)) {
             g_end();
@@ -688,4 +698,12 @@ extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const h
   }
   HIPREC_TRY(hipGetLastError());
   return 0;
+}
+
+extern "C" int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const hiprec_shard_bufs* bufs,
+                                          int64_t step_begin, int64_t step_end, int32_t kind, float reg_coef,
+                                          double lr, double beta1, double beta2, double eps,
+                                          const hiprec_nccl_fns* nccl, void* comm, hiprec_stats* stats, void* stream) {
+  return hiprec_shard_planned_steps_ex(plan, bufs, step_begin, step_end, kind, reg_coef, lr, beta1, beta2, eps, nccl,
+                                       comm, 0u, stats, stream);
 }

@@ -267,9 +267,10 @@ class HipKernels:
             idx.numel(), 0, 0, None, coef, _lib.ptr(extra_pos), extra_pos.numel(), _lib.ptr(scalar_target), scalar_coef,
             1 if first_of_epoch else 0, None, _lib.ptr(self.stats), self._st()))
 
-    def planned_steps(self, plan, bufs, model, g_flat, opt, a, b, reg, comm, lazy=None):
+    def planned_steps(self, plan, bufs, model, g_flat, opt, a, b, reg, comm, lazy=None, self_exchange=False):
         """Steps [a, b) of a planned epoch -- kernels AND exchanges -- enqueued by ONE C call
-        (hiprec_shard_planned_steps); comm: an _rccl.Communicator (None at world size 1)."""
+        (hiprec_shard_planned_steps_ex); comm: an _rccl.Communicator (None at world size 1).  ``self_exchange``: the
+        rank's own segment of both exchanges goes through the communicator too (HIPREC_SHARD_EXCHANGE_SELF)."""
         c = plan.get("_c")
         if c is None:   # the structs and the host arrays they point at live as long as the plan
             import numpy as np
@@ -304,10 +305,12 @@ class HipKernels:
         fns = None
         if comm is not None:
             fns = ctypes.byref(_lib.NcclFns(comm.send_fn, comm.recv_fn, comm.group_start_fn, comm.group_end_fn))
-        _lib.check(self.lib.hiprec_shard_planned_steps(
+        if self_exchange and comm is None:
+            raise RuntimeError("shard_self_exchange needs the RCCL binding (a communicator with ncclSend / ncclRecv)")
+        _lib.check(self.lib.hiprec_shard_planned_steps_ex(
             ctypes.byref(c[0]), ctypes.byref(sb), a, b, opt.kind, reg, opt.lr, opt.beta1, opt.beta2, opt.eps, fns,
-            ctypes.c_void_p(comm.comm.value if comm is not None else None), _lib.ptr(self.stats),
-            self._st()))
+            ctypes.c_void_p(comm.comm.value if comm is not None else None),
+            _lib.SHARD_EXCHANGE_SELF if self_exchange else 0, _lib.ptr(self.stats), self._st()))
 
     # ---- exact lazy Adam / RMSprop (csrc/lazy_opt.hip) -------------------------------------------------------------
     LAZY_SCALARS = _lib.LAZY_SCALARS_CAP     # steps whose bias corrections are tabulated (default betas converge by t ~ 36 800)
@@ -925,7 +928,12 @@ class ShardedMFEngine:
             return mode
         self._comm = None
         want_c = isinstance(self.k, HipKernels) and self.config["model"].get("step_driver", "c") == "c"
-        if want_c and self.world > 1:
+        # `shard_self_exchange: True`: every rank also sends its own segment of the two exchanges to itself through
+        # the communicator (bit-identical; at world size 1 it is what executes the real ncclSend / ncclRecv path)
+        self._self_exchange = bool(self.config["model"].get("shard_self_exchange", False))
+        if self._self_exchange and not want_c:
+            raise ValueError("shard_self_exchange is an option of the C step driver (step_driver: 'c')")
+        if want_c and (self.world > 1 or self._self_exchange):
             from . import _rccl
 
             comm = _rccl.create_communicator(self.pg, self.device)
@@ -937,6 +945,8 @@ class ShardedMFEngine:
                 want_c = False
                 if comm is not None:
                     comm.destroy()
+                if self._self_exchange:
+                    raise RuntimeError("shard_self_exchange: no RCCL communicator with ncclSend / ncclRecv could be made")
         self._step_mode = "c" if want_c else "torch"
         return self._step_mode
 
@@ -965,7 +975,8 @@ class ShardedMFEngine:
         if lazy is not None:
             lazy["dirty"] = True
         if self._step_comm() == "c":
-            k.planned_steps(plan, pb, m, self._g_flat, self.optimizer, a, b, reg, self._comm, lazy)
+            k.planned_steps(plan, pb, m, self._g_flat, self.optimizer, a, b, reg, self._comm, lazy,
+                            self_exchange=self._self_exchange)
             self.step_count += b - a
             if b == S and self.flush_lazy_every_epoch:
                 self.flush_lazy()     # the epoch's callers (evaluation, checkpoints) read the tables

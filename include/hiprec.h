@@ -611,6 +611,17 @@ int hiprec_shard_planned_steps(const hiprec_shard_plan* plan, const hiprec_shard
                                int64_t step_end, int32_t kind, float reg_coef, double lr, double beta1, double beta2,
                                double eps, const hiprec_nccl_fns* nccl, void* comm, hiprec_stats* stats, void* stream);
 
+/* The same with flags.  HIPREC_SHARD_EXCHANGE_SELF: the rank's own segment of both exchanges is sent to and received
+ * from ITSELF through the communicator (grouped ncclSend + ncclRecv to its own rank) instead of being handed over in
+ * place -- bit-identical results; at world == 1 (which then needs the entry points and a one-rank communicator) this
+ * executes the driver's real send / recv path on a single GPU.  New capability; the semantics of the step
+ * are beta_rec/models/mf.py:92-119. */
+#define HIPREC_SHARD_EXCHANGE_SELF 1u
+int hiprec_shard_planned_steps_ex(const hiprec_shard_plan* plan, const hiprec_shard_bufs* bufs, int64_t step_begin,
+                                  int64_t step_end, int32_t kind, float reg_coef, double lr, double beta1, double beta2,
+                                  double eps, const hiprec_nccl_fns* nccl, void* comm, uint32_t flags,
+                                  hiprec_stats* stats, void* stream);
+
 /* ---- exact lazy Adam / RMSprop for tables that live in HBM (csrc/lazy_opt.hip; reference semantics:
  * beta_rec/models/torch_engine.py:30-39 -- nn.Embedding is dense, so torch.optim steps every element every step, a
  * zero gradient for the rows a batch did not touch).  A zero-gradient step of a row depends on the row's own (w, m, v)

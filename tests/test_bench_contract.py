@@ -125,3 +125,39 @@ def test_gpus_n_line_is_the_row_sharded_split_with_the_other_forms_as_sub_record
     assert c4["exchange_bytes_per_step_off_gpu"] > 0 and "10M x 1M" in c4["workload"]
     # the C drivers really posted exchanges and all-reduces through the injected entry points
     assert counters["sends"] > 0 and counters["recvs"] == counters["sends"] and counters["all_reduces"] > 0
+    # the same-run single-GPU step the N > 1 figures are to be compared with
+    assert 0 < line["single_gpu_ms_per_step"] < line["ms_per_step"] and line["single_gpu_value"] > line["value"]
+
+
+def test_alt_records_are_the_remaining_baseline_configs():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert bench.ALT_WORKLOADS == ("ncf", "mf_c4shard_sgd", "mf_c4shard_adam", "mf_c4_adam_fullcov", "lightgcn")
+    args = bench.parse_args([])
+    assert args.no_alt is False and args.alt_only is None and bench.parse_args(["--no-alt"]).no_alt is True
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_carries_live_sub_records_of_the_other_configs():
+    """the stock single-GPU command times every BASELINE config in the same process.  Two of the five
+    sub-records here (the others are the same code with other sizes): each has the step time, the throughput that
+    follows from it, and a roofline whose `kernel_us` was measured with HIP events in this run."""
+    import torch
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    args = bench.parse_args(["--steps", "4", "--warmup", "2", "--no-cpu-baseline"])
+    alt = bench.alt_single_gpu(args, torch.device("cuda:0"), only=("ncf", "mf_c4shard_sgd"))
+    assert json.loads(json.dumps(alt)) == alt and set(alt) == {"ncf", "mf_c4shard_sgd", "wall_s"}
+    for name, units in (("ncf", 4096), ("mf_c4shard_sgd", 65536)):
+        rec = alt[name]
+        assert "error" not in rec, rec
+        for key in ("value", "unit", "ms_per_step", "steps", "repeats", "workload", "roofline", "wall_s"):
+            assert key in rec, (name, key)
+        assert rec["value"] == pytest.approx(units / (rec["ms_per_step"] * 1e-3), rel=1e-6)
+        roof = rec["roofline"]
+        assert 0 < roof["frac"] < 1 and roof["kernel_us"] > 0 and roof["kernel_us_source"].startswith("HIP events")
+        assert roof["model"] and roof["bound"] in ("hbm", "mfma")
+    assert alt["mf_c4shard_sgd"]["ms_per_step_whole_epochs"] > 0 and alt["mf_c4shard_sgd"]["roofline"]["step_frac"] > 0

@@ -597,3 +597,84 @@ def test_replicated_flat_engines_with_hip_kernels(nccl_group, model, collective)
     w_ref, env, upd = oracle_trajectory(w0, batches, grads, step, lambda w: omf.new_opt_state(w, "adam"))
     got = {k: v.detach().cpu().numpy() for k, v in eng.model.state_dict().items()}
     assert_on_trajectory(got, w_ref, env, upd, f"replicated {model}")
+
+
+def _zipf_epoch(rng, U, I, B, steps, unique=False):
+    if unique:      # no row twice in a batch: a gradient element receives one add, the run is reproducible to the bit
+        users = np.concatenate([rng.permutation(U)[:B] for _ in range(steps)])
+        items = [rng.permutation(I)[: 2 * B] for _ in range(steps)]
+        return users, np.concatenate([i[:B] for i in items]), np.concatenate([i[B:] for i in items])
+    p = 1.0 / np.arange(1, I + 1)
+    return (rng.integers(0, U, steps * B), rng.permutation(I)[rng.choice(I, steps * B, p=p / p.sum())],
+            rng.integers(0, I, steps * B))
+
+
+@pytest.mark.parametrize("optimizer,dense_opt,unique", [("sgd", "auto", True), ("sgd", "auto", False), ("adam", "lazy", True),
+                                                        ("adam", "sweep", True)])
+def test_self_exchange_executes_the_real_rccl_send_recv_path(nccl_group, optimizer, dense_opt, unique):
+    """at world size 1 the C step driver posts no exchange, so its grouped ncclSend / ncclRecv had only
+    ever run against the loopback stand-in.  ``shard_self_exchange`` (HIPREC_SHARD_EXCHANGE_SELF) makes the rank send
+    its own segment of BOTH exchanges of every step to itself on the real communicator of ``_rccl.create_communicator``:
+    the binding, the argument marshalling and the stream ordering run against librccl.  An exchange is a copy, so the
+    epoch must equal the no-exchange run bit for bit -- weights, moments, loss sums -- wherever a run is reproducible
+    to the bit in the first place (batches without a repeated row); with Zipf items the planner lays shared rows'
+    contributions out in hash-table arrival order, two runs of ANY form differ in the last bits of a sum, and the two
+    forms are held to 1e-5 of the update like every other pair of forms."""
+    import beta_recsys_amd as hp
+    from beta_recsys_amd.sharded import ShardedMFEngine
+
+    U, I, D, B, steps = 3000, 1200, 64, 256, 5
+    users, pos, neg = _zipf_epoch(np.random.default_rng(21), U, I, B, steps, unique)
+    w0 = {k: torch.from_numpy(v) for k, v in onp.init_params(U, I, D, seed=7).items()}
+    triples = tuple(torch.from_numpy(a).cuda() for a in (users, pos, neg))
+    out = {}
+    for self_x in (False, True):
+        cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer=optimizer, lr=0.05,
+                             batch_size=B, loss="bpr", sgd_mode="rows", dense_opt=dense_opt, shard_self_exchange=self_x),
+               "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+        with contextlib.redirect_stdout(io.StringIO()):
+            eng = ShardedMFEngine(cfg, full_state=w0)
+            sums = eng.train_an_epoch(hp.DeviceTripleBatcher(*triples, B, shuffle=False), 0)
+        assert eng._step_mode == "c" and eng._self_exchange == self_x
+        # the communicator exists exactly when exchanges are posted, and it is RCCL's, not a test double's
+        assert (eng._comm is not None) == self_x
+        if self_x:
+            from beta_recsys_amd import _rccl
+
+            assert isinstance(eng._comm, _rccl.Communicator) and eng._comm.has_send_recv() and eng._comm.async_error() in (0, None)
+        eng.flush_lazy()
+        opt = eng.optimizer
+        out[self_x] = (eng.model.flat.clone(), sums, [t.clone() for t in (opt.exp_avg, opt.exp_avg_sq) if t is not None])
+        if self_x:
+            eng._comm.destroy()
+    (wa, sa, ma), (wb, sb, mb) = out[False], out[True]
+    if unique:
+        assert sa == sb, (sa, sb)
+        assert torch.equal(wa, wb), f"{int((wa != wb).sum())} weights differ between the in-place and the RCCL self-exchange"
+        for x, y in zip(ma, mb):
+            assert torch.equal(x, y)
+    else:
+        flat0 = torch.cat([w0[k].reshape(-1) for k in ("user_emb.weight", "item_emb.weight", "user_bias.weight",
+                                                       "item_bias.weight", "global_bias")]).cuda()
+        upd = float((wa - flat0).abs().max())
+        assert_scalar_close(sb[0], sa[0], 1e-5, "epoch loss sum, self-exchange vs in place")
+        assert float((wa - wb).abs().max()) <= 1e-5 * upd + 4 * 1.2e-7 * float(flat0.abs().max())
+    # ... and the run is the oracle's (the plain-SGD case; the Adam cases are held to it by the tests above)
+    if optimizer == "sgd":
+        w = onp.copy_params({k: v.numpy() for k, v in w0.items()})
+        st = onp.new_opt_state(w, "sgd")
+        total = sum(onp.mf_train_step(w, st, (users[k:k + B], pos[k:k + B], neg[k:k + B]), "bpr", "sgd", 0.05)[0]
+                    for k in range(0, steps * B, B))
+        assert_scalar_close(sb[0], total, 1e-5, "epoch loss sum vs the oracle")
+
+
+def test_self_exchange_needs_the_c_driver(nccl_group):
+    from beta_recsys_amd.sharded import ShardedMFEngine
+
+    cfg = {"model": dict(n_users=50, n_items=40, emb_dim=8, device_str="cuda:0", optimizer="sgd", lr=0.05, batch_size=16,
+                         loss="bpr", shard_self_exchange=True, step_driver="torch"),
+           "system": {"run_dir": "/tmp/hiprec_test_runs"}}
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = ShardedMFEngine(cfg)
+    with pytest.raises(ValueError, match="C step driver"):
+        eng._step_comm()
