@@ -19,6 +19,7 @@ OPT_KINDS = {"sgd": OPT_SGD, "adam": OPT_ADAM, "rmsprop": OPT_RMSPROP}
 STATUS_USER_OOB, STATUS_ITEM_OOB, STATUS_ROW_OOB, STATUS_ROUTE_OVERFLOW = 1, 2, 4, 8
 STATUS_NEG_EXHAUSTED = 16
 STATUS_LAZY_TABLE = 32
+STATUS_TABLE_FULL = 64
 
 
 class MfTables(Structure):

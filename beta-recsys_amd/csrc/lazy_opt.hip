@@ -322,7 +322,10 @@ __device__ __forceinline__ void lazy_rows_vec_body(const LazyCtx& c, const hipre
       if (kz < 0) continue;
       // no weight of the wave moves after step tb + kz, and every lane has joined the walk by then: a catch-up (which
       // stores w only) is done, the others let the moments decay over the steps that are left
-      if constexpr (MODE != 0) decay_only(m, v, on ? static_cast<int>(last - (tb + kz)) : 0);
+      // (a w-ahead lane does not hold the wave back -- its weights are current -- so it may not have joined the walk at
+      // step tb + kz: its moments then decay over the steps IT lagged, last - base, not over last - (tb + kz): ADVICE r5)
+      if constexpr (MODE != 0)
+        decay_only(m, v, on ? static_cast<int>(last - (tb + kz > base ? tb + kz : static_cast<long long>(base))) : 0);
       return;
     }
   };
@@ -658,6 +661,7 @@ void lazy_pull_apply_kernel(PullApply f, LazyCtx c, OptScalars s,
   float ss_now = s.lr, bc2_now = 1.f;
   step_scalars<KIND>(s, stats, &ss_now, &bc2_now);
   if (blk < 0) {
+    if (threadIdx.x == 0 && f.counts[3] != 0) atomicOr(&stats->status, HIPREC_STATUS_TABLE_FULL);   // incomplete lists
     lazy_scalar_step<KIND, kPullBlock>(c, s, stats, scratch, clock, ss_now, bc2_now, 0);
     return;
   }

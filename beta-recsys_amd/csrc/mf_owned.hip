@@ -599,6 +599,7 @@ __global__ __launch_bounds__(kPullBlock) void pull_apply_kernel(PullApply f, hip
   const int nb = static_cast<int>(gridDim.x) - 1, blk = static_cast<int>(blockIdx.x) - 1;
   if (blk < 0) {
     // ---- the stats block ----
+    if (threadIdx.x == 0 && f.counts[3] != 0) atomicOr(&stats->status, HIPREC_STATUS_TABLE_FULL);   // incomplete lists
     if (f.begin_epoch && threadIdx.x == 0) {  // hiprec_stats_begin_epoch, folded in
       stats->loss_sum = 0.0;
       stats->reg_sum = 0.0;
@@ -711,6 +712,9 @@ void pull_apply_vec_kernel(PullApply f, hiprec_stats* stats, Scratch* scratch) {
 #endif
   if (blk < 0) {
     // ---- the stats block ----
+    // (a batch whose contribution lists are incomplete -- a hash partition overflowed when they were built -- must not
+    // pass for a step: its unlisted rows would be written by several waves or not at all)
+    if (threadIdx.x == 0 && f.counts[3] != 0) atomicOr(&stats->status, HIPREC_STATUS_TABLE_FULL);
     if constexpr (REMOTE) {
       publish_partials_rows<kPullBlock>(scratch, f.slot_out, f.dim + 1, f.extra_rows, f.n_dest);
       return;

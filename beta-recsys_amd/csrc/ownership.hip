@@ -288,8 +288,9 @@ __global__ __launch_bounds__(kOwnThreads) void contrib_kernel(int32_t* __restric
         const int32_t prev = atomicCAS(s_key + h, -1, key);
         if (prev == -1 || prev == key) break;
         h = (h + 1u) & part_mask;
-        if (probes > part_size) {  // a full partition (cannot happen at >= 4 x batch entries): give up, never spin
-          h = part_size;
+        if (probes > part_size) {  // a full partition (cannot happen at >= 4 x batch entries): give up, never spin --
+          h = part_size;           // and say so: the step that consumes this batch's lists raises HIPREC_STATUS_TABLE_FULL
+          atomicOr(counts + 4 * b + 3, 1);
           break;
         }
       }

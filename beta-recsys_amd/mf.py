@@ -106,6 +106,10 @@ def raise_on_status(status):
             raise RuntimeError(
                 "lazy Adam: the optimizer ran past the bias-correction table while the corrections still moved "
                 "(non-default betas?): use config['model']['dense_opt'] = 'sweep'")
+        if status & _lib.STATUS_TABLE_FULL:
+            raise RuntimeError(
+                "a batch's row-contribution hash partition overflowed while the epoch was staged: the step's lists are "
+                "incomplete (should be impossible at >= 4 table entries per triple; please report the batch)")
         if status & _lib.STATUS_ROUTE_OVERFLOW:
             raise RuntimeError(
                 "a fixed-capacity all-to-all bucket overflowed: raise the sharded engine's "
@@ -257,6 +261,11 @@ class MF(nn.Module):
         tabs = self.tables()
         _lib.check(lib.hiprec_mf_forward(ctypes.byref(tabs), _lib.ptr(users), _lib.ptr(items), n, _lib.ptr(scores),
                                          _lib.ptr(sq), _lib.ptr(self._stats), _lib.stream_ptr(dev)))
+        # nn.Embedding raises IndexError for an id outside its table (mf.py:41-42); the kernel flags it (NaN score)
+        st = read_stats(self._stats)
+        if st.status:
+            clear_status(self._stats)
+            raise_on_status(st.status)
         return scores, sq.sum() / max(n, 1)
 
     def _scores(self, users, items):

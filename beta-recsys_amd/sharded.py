@@ -24,6 +24,7 @@ exchange is expressed as all-to-all rather than ring collectives.
 """
 import contextlib
 import ctypes
+import os
 import io
 
 import torch
@@ -520,7 +521,14 @@ class ShardedMFEngine:
         flush -- to ``model_dir + ".opt.rank<r>of<R>"`` (resumable at the same world size)."""
         full = self.gather_full_state_dict()          # flushes the lazy rows first
         if self.rank == 0:
-            torch.save({k: v.cpu() for k, v in full.items()}, model_dir)
+            # written beside its final name and renamed: no rank can ever open a half-written file
+            tmp = f"{model_dir}.tmp{os.getpid()}"
+            torch.save({k: v.cpu() for k, v in full.items()}, tmp)
+            os.replace(tmp, model_dir)
+        # ... and nobody returns before it is there: an immediate resume_checkpoint runs torch.load on every rank
+        token = torch.zeros(1, dtype=torch.int32, device=self.device if dist.get_backend(self.pg) == "nccl" else "cpu")
+        dist.all_reduce(token, group=self.pg)
+        token.cpu()                                   # the host waits: rank 0 reduces only after its rename
         if optimizer_state:
             if not isinstance(self.k, HipKernels):
                 raise NotImplementedError("optimizer checkpoints need the HIP kernels' device state")
@@ -528,6 +536,7 @@ class ShardedMFEngine:
             cpu = lambda t: None if t is None else t.detach().to("cpu", copy=True)   # noqa: E731
             torch.save({"format": self.OPT_STATE_FORMAT, "optimizer": opt.name, "world": self.world, "rank": self.rank,
                         "n_params": int(self.model.flat.numel()), "step_count": int(self.step_count),
+                        "hyper": {"lr": opt.lr, "beta1": opt.beta1, "beta2": opt.beta2, "eps": opt.eps},
                         "stats": cpu(self.k.stats), "exp_avg": cpu(opt.exp_avg), "exp_avg_sq": cpu(opt.exp_avg_sq),
                         "lazy": None if lz is None else {k: cpu(lz[k]) for k in ("stamp_u", "stamp_i", "scalars")}},
                        f"{model_dir}.opt.rank{self.rank}of{self.world}")
@@ -543,6 +552,12 @@ class ShardedMFEngine:
         if (payload.get("format") != self.OPT_STATE_FORMAT or payload["optimizer"] != opt.name
                 or payload["world"] != self.world or payload["n_params"] != self.model.flat.numel()):
             raise ValueError("the optimizer state file does not fit this engine (format / optimizer / world size / shard size)")
+        # the raw stats block carries the running beta powers and the lazy scalars table the per-step learning rates: a
+        # file written under other hyper-parameters would continue THAT run under this engine's name
+        hyper = payload.get("hyper")
+        mine = {"lr": opt.lr, "beta1": opt.beta1, "beta2": opt.beta2, "eps": opt.eps}
+        if hyper is not None and any(float(hyper[k]) != float(mine[k]) for k in mine):
+            raise ValueError(f"the optimizer state was saved with {hyper}, this engine runs {mine}")
         dev = self.device
         self.k.stats.copy_(payload["stats"].to(dev))
         self.step_count = int(payload["step_count"])

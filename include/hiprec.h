@@ -45,6 +45,8 @@ extern "C" {
 #define HIPREC_STATUS_ROUTE_OVERFLOW 8u /* a fixed-capacity all-to-all bucket was too small */
 #define HIPREC_STATUS_NEG_EXHAUSTED 16u /* a user has fewer untouched items than negatives were asked for */
 #define HIPREC_STATUS_LAZY_TABLE 32u    /* lazy Adam: a step beyond the scalars table whose bias corrections still move */
+#define HIPREC_STATUS_TABLE_FULL 64u    /* a batch's contribution hash partition overflowed: some row's gradient parts were
+                                         * not listed (hiprec_batch_row_contrib flags the batch, the step that uses it raises) */
 
 /* optimizer kinds, beta_rec/models/torch_engine.py:23-39 (only `lr` is ever set there) */
 #define HIPREC_OPT_SGD 0
