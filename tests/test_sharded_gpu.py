@@ -652,7 +652,10 @@ def test_self_exchange_executes_the_real_rccl_send_recv_path(nccl_group, optimiz
             eng._comm.destroy()
     (wa, sa, ma), (wb, sb, mb) = out[False], out[True]
     if unique:
-        assert sa == sb, (sa, sb)
+        # (the epoch's loss / regularizer sums add the triples in the plan's layout order, which hash-table arrival
+        # decides: last-bit differences between ANY two runs; the weights and moments are what must not move)
+        for x, y in zip(sa, sb):
+            assert_scalar_close(y, x, 1e-6, "epoch sums, self-exchange vs in place")
         assert torch.equal(wa, wb), f"{int((wa != wb).sum())} weights differ between the in-place and the RCCL self-exchange"
         for x, y in zip(ma, mb):
             assert torch.equal(x, y)
