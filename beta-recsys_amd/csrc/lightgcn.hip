@@ -148,7 +148,11 @@ __global__ __launch_bounds__(kBlock) void edge_dropout_kernel(uint8_t* __restric
 // AND to `g` (its l = 0 term); the L2 gradient goes to `g` only.
 // SLICED: the propagated sums are read from, and d_out is scattered into, the sliced layout [D / W][N][W] of the
 // column-sliced SpMM (p.acc / p.da then point at sliced buffers): no transposes around the loss.
-template <bool SLICED>
+// NPL: columns per lane (dim <= 64 * NPL).  The nine rows of a triple (three propagated sums, three layer-0 rows, and
+// for the transposed graph's column factors three scalars) are requested together and stay in registers: the gradient
+// half of the wave's work starts from them, not from a second round trip (round 5: 9.0 us for 1024 triples, the second
+// loop re-read all six rows because the atomics in between may alias them).
+template <bool SLICED, int NPL>
 __global__ __launch_bounds__(kBlock) void lightgcn_loss_kernel(
     hiprec_lightgcn_plan p, const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
     const int64_t* __restrict__ neg, int64_t batch, float inv_batch, hiprec_stats* stats,
@@ -165,8 +169,14 @@ __global__ __launch_bounds__(kBlock) void lightgcn_loss_kernel(
   const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
   const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
   const float inv_l = 1.0f / static_cast<float>(p.n_layers + 1);
+  const float* __restrict__ acc = p.acc;
+  const float* __restrict__ e0 = p.e0;
+  // (sliced, factored transposed graph: its passes take their source scaled by the column factor)
+  const float* __restrict__ cs = SLICED ? p.sat.col_scale : nullptr;
   float loss_acc = 0.f, reg_acc = 0.f;
-  if (blockIdx.x == 0 && threadIdx.x == 0) advance_step(stats);
+  const bool stepper = blockIdx.x == 0 && threadIdx.x == 0;
+  StepState ss{};
+  if (stepper) ss = step_load(stats);
   for (int64_t t = wave0; t < batch; t += n_waves) {
     const int64_t u = users[t], i = pos[t], j = neg[t];
     const bool u_ok = static_cast<uint64_t>(u) < static_cast<uint64_t>(p.n_users);
@@ -180,37 +190,73 @@ __global__ __launch_bounds__(kBlock) void lightgcn_loss_kernel(
     }
     const int64_t nu = u, np_ = p.n_users + i, nn_ = p.n_users + j;  // node rows
     const int64_t ru = nu * D, rp = np_ * D, rn = nn_ * D;
+    float ue[NPL], pe[NPL], ne[NPL], u0[NPL], p0[NPL], n0[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+      const int c = lane + kWave * k;
+      const bool in = c < D;
+      const int cc = in ? c : 0;
+      ue[k] = in ? acc[at(nu, cc)] : 0.f;
+      pe[k] = in ? acc[at(np_, cc)] : 0.f;
+      ne[k] = in ? acc[at(nn_, cc)] : 0.f;
+      u0[k] = in ? e0[ru + cc] : 0.f;
+      p0[k] = in ? e0[rp + cc] : 0.f;
+      n0[k] = in ? e0[rn + cc] : 0.f;
+    }
+    const float su = cs ? cs[nu] : 1.f, sp = cs ? cs[np_] : 1.f, sn = cs ? cs[nn_] : 1.f;
     float dp = 0.f, dn = 0.f;
-    for (int c = lane; c < D; c += kWave) {
-      const float ue = p.acc[at(nu, c)] * inv_l, pe = p.acc[at(np_, c)] * inv_l, ne = p.acc[at(nn_, c)] * inv_l;
-      dp += ue * pe;
-      dn += ue * ne;
-      const float u0 = p.e0[ru + c], p0 = p.e0[rp + c], n0 = p.e0[rn + c];
-      reg_acc += u0 * u0 + p0 * p0 + n0 * n0;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+      ue[k] *= inv_l;
+      pe[k] *= inv_l;
+      ne[k] *= inv_l;
+      dp += ue[k] * pe[k];
+      dn += ue[k] * ne[k];
+      reg_acc += u0[k] * u0[k] + p0[k] * p0[k] + n0[k] * n0[k];
     }
     dp = wave_sum(dp);
     dn = wave_sum(dn);
     const float xx = dn - dp;  // softplus(neg - pos)
     loss_acc += xx > 20.f ? xx : log1pf(expf(xx));
     const float dx = sigmoid_f32(xx) * inv_batch * inv_l;  // d mf / d x, pre-scaled by 1/(L+1)
-    // (sliced, factored transposed graph: its passes take their source scaled by the column factor)
-    const float* cs = SLICED ? p.sat.col_scale : nullptr;
-    const float su = cs ? cs[u] : 1.f, sp = cs ? cs[p.n_users + i] : 1.f, sn = cs ? cs[p.n_users + j] : 1.f;
     const float cr = p.decay * inv_batch;                   // d reg / d row = decay * row / B
-    for (int c = lane; c < D; c += kWave) {
-      const float ue = p.acc[at(nu, c)] * inv_l, pe = p.acc[at(np_, c)] * inv_l, ne = p.acc[at(nn_, c)] * inv_l;
-      const float gu = dx * (ne - pe), gp = -dx * ue, gn = dx * ue;
-      atomic_add_f32(p.da + at(nu, c), gu * su);
-      atomic_add_f32(p.da + at(np_, c), gp * sp);
-      atomic_add_f32(p.da + at(nn_, c), gn * sn);
-      atomic_add_f32(p.g + ru + c, gu + cr * p.e0[ru + c]);
-      atomic_add_f32(p.g + rp + c, gp + cr * p.e0[rp + c]);
-      atomic_add_f32(p.g + rn + c, gn + cr * p.e0[rn + c]);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+      const int c = lane + kWave * k;
+      if (c < D) {
+        const float gu = dx * (ne[k] - pe[k]), gp = -dx * ue[k], gn = dx * ue[k];
+        atomic_add_f32(p.da + at(nu, c), gu * su);
+        atomic_add_f32(p.da + at(np_, c), gp * sp);
+        atomic_add_f32(p.da + at(nn_, c), gn * sn);
+        atomic_add_f32(p.g + ru + c, gu + cr * u0[k]);
+        atomic_add_f32(p.g + rp + c, gp + cr * p0[k]);
+        atomic_add_f32(p.g + rn + c, gn + cr * n0[k]);
+      }
     }
   }
+  if (stepper) step_store_advanced(stats, ss);
   // loss = mean softplus + decay * 0.5 * sum(...) / B ; published as ONE number (loss slot)
   const float reg_w = wave_sum(reg_acc);
   publish_partials<kWavesPerBlock>(loss_acc + 0.5f * p.decay * reg_w, 0.f, 0.f, inv_batch, scratch);
+}
+
+template <bool SLICED>
+static int launch_lightgcn_loss(const hiprec_lightgcn_plan& q, const int64_t* users, const int64_t* pos,
+                                const int64_t* neg, int64_t batch, float inv_batch, hiprec_stats* stats,
+                                Scratch* scratch, hipStream_t st) {
+  const int grid = grid_for_waves(batch);
+  if (q.dim <= 64)
+    lightgcn_loss_kernel<SLICED, 1><<<grid, kBlock, 0, st>>>(q, users, pos, neg, batch, inv_batch, stats, scratch);
+  else if (q.dim <= 128)
+    lightgcn_loss_kernel<SLICED, 2><<<grid, kBlock, 0, st>>>(q, users, pos, neg, batch, inv_batch, stats, scratch);
+  else if (q.dim <= 256)
+    lightgcn_loss_kernel<SLICED, 4><<<grid, kBlock, 0, st>>>(q, users, pos, neg, batch, inv_batch, stats, scratch);
+  else {
+    set_error("LightGCN embedding dim %d > 256 is not supported", q.dim);
+    return HIPREC_E_UNSUPPORTED;
+  }
+  HIPREC_TRY(hipGetLastError());
+  return 0;
 }
 
 // scores[k] = sigmoid(<out[u], out[U + i]>) with out = acc / (L+1)   (LightGCN.predict :98-100)
@@ -515,9 +561,8 @@ extern "C" int hiprec_lightgcn_grad(const hiprec_lightgcn_plan* plan, const uint
       return rc;
     q.acc = sliced_buf(p, 1);
     q.da = sliced_buf(p, 0);
-    lightgcn_loss_kernel<true><<<grid_for_waves(batch), kBlock, 0, st>>>(q, users, pos, neg, batch, inv_batch, stats,
-                                                                        static_cast<Scratch*>(scratch));
-    HIPREC_TRY(hipGetLastError());
+    if (int rc = launch_lightgcn_loss<true>(q, users, pos, neg, batch, inv_batch, stats, static_cast<Scratch*>(scratch), st))
+      return rc;
     return propagate_sliced(p, &p->sat, keep, keep_prob, nullptr, p->g, false, true, st);
   }
   if (ws) {
@@ -527,9 +572,8 @@ extern "C" int hiprec_lightgcn_grad(const hiprec_lightgcn_plan* plan, const uint
   }
   if (int rc = propagate(p, keep, keep_prob, st, /*ws_zeroed=*/ws)) return rc;
   if (!ws) HIPREC_TRY(hipMemsetAsync(q.da, 0, bytes, st));
-  lightgcn_loss_kernel<false><<<grid_for_waves(batch), kBlock, 0, st>>>(
-      q, users, pos, neg, batch, inv_batch, stats, static_cast<Scratch*>(scratch));
-  HIPREC_TRY(hipGetLastError());
+  if (int rc = launch_lightgcn_loss<false>(q, users, pos, neg, batch, inv_batch, stats, static_cast<Scratch*>(scratch), st))
+    return rc;
   // g = sum_{l=0..L} (A^T)^l d_out : the l = 0 term is already in g
   const float scale = keep ? 1.0f / keep_prob : 1.0f;
   float* cur = q.da;

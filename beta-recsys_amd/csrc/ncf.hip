@@ -35,6 +35,9 @@ constexpr int kTM = 64, kTN = 64, kTK = 32;
 // every k-step on a full memory round trip.
 
 
+#ifndef HIPREC_SWEEP_CAP
+#define HIPREC_SWEEP_CAP 2048
+#endif
 constexpr int kColsumRows = 128;
 
 // In-kernel timestamps of one split-K weight-gradient tile (-DHIPREC_NCF_DEBUG builds only, tools/build_debug_lib.sh):
@@ -294,8 +297,10 @@ GemmProblem make_gemm(int mode, int M, int N, int K, const float* A, int lda, co
   // into a zero-initialised C: the weight-gradient GEMMs)
   if (split_k && !bias && !relu && !mask) {
     const int tiles = q.tiles_n * q.tiles_m;
-    int z = (512 + tiles - 1) / tiles;
-    const int max_z = (K + 4 * kTK - 1) / (4 * kTK);  // at least 4 k-tiles per slice (2: NCF 58.8 -> 65.1 us; 8: 60.2, emb 64 127.6 -> 120.0)
+    // ~384 blocks in all (round 6, same-box A/B: 256 / 384 / 512 / 1024 / 1536 blocks -> NeuMF emb 64 100.0 / 98.3 / 102.4 /
+    // 107.5 / 107.5 us per step; emb 32 and NGCF are bound by max_z below and do not move)
+    int z = (384 + tiles - 1) / tiles;
+    const int max_z = (K + 4 * kTK - 1) / (4 * kTK);  // at least 4 k-tiles per slice (2: NCF 58.8 -> 65.1 us; 8: 60.2, emb 64 127.6 -> 120.0; r06: 3 / 6: 50.7 against 48.8)
     if (z > max_z) z = max_z;
     if (z > 1) q.split = z;
   }
@@ -1605,7 +1610,7 @@ extern "C" int hiprec_ncf_step(const hiprec_ncf_plan* plan, const int64_t* users
     sw.v = v_flat;
     sw.n4 = table_floats >> 2;
     sw.kind = kind;
-    sw.n_blocks = static_cast<int>(std::min<int64_t>((sw.n4 + kBlock - 1) / kBlock, 2048));  // one 16-byte vector per thread
+    sw.n_blocks = static_cast<int>(std::min<int64_t>((sw.n4 + kBlock - 1) / kBlock, HIPREC_SWEEP_CAP));  // one 16-byte vector per thread
     sw.s = OptScalars{lr, static_cast<float>(lr), static_cast<float>(beta2), static_cast<float>(1.0 - beta1),
                       static_cast<float>(1.0 - beta2), static_cast<float>(eps)};
     sw.stats = stats;

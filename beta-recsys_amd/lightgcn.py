@@ -99,6 +99,9 @@ def factor_edge_values(rowptr, col, val, rel_tol=2e-6, max_rounds=256):
     return r32, c32
 
 
+SLICED_RUNS = "carry"   # experiment knob (tools/exp_sliced_runs.py): "cut" ends every run at its 16-lane row
+
+
 def _windowed_chunks(start, chunk_row, clen, within, per_row, sub_chunk):
     """Chunk descriptors as csrc/spmm_sliced.hip wants them.  A wave of the kernel works on a WINDOW of 16
     consecutive chunks (one per quad of lanes) and sums the chunks of one row inside the window itself before anything
@@ -128,6 +131,8 @@ def _windowed_chunks(start, chunk_row, clen, within, per_row, sub_chunk):
     prev_real = np.concatenate([[False], real[:-1]])
     prev_row = np.concatenate([[-1], row2[:-1]])
     new_run = ((idx & 15) == 0) | (row2 != prev_row) | ~real | ~prev_real
+    if SLICED_RUNS == "cut":
+        new_run |= (idx & 3) == 0
     run_start = np.maximum.accumulate(np.where(new_run, idx, 0))
     behind, qir = idx - run_start, idx & 3
     last = np.concatenate([new_run[1:], [True]]) & real

@@ -279,7 +279,8 @@ static int post(bool is_send, void* ptr, size_t count, int dtype, int peer, void
   Comm* c = static_cast<Comm*>(comm);
   if (!c) return kInvalidArgument;
   if (c->w->failed) return kInternal;
-  if (peer < 0 || peer >= c->w->world || peer == c->rank || dtype_size(dtype) == 0 || (count && !ptr))
+  // (peer == own rank is legal inside a group, as in RCCL: the send is matched by the same group's recv)
+  if (peer < 0 || peer >= c->w->world || (peer == c->rank && t_depth <= 0) || dtype_size(dtype) == 0 || (count && !ptr))
     return fail(c->w, kInvalidArgument, "rank %d: bad %s (peer %d, dtype %d, %zu elements)", c->rank,
                 is_send ? "send" : "recv", peer, dtype, count);
   t_ops.push_back(Op{is_send, ptr, count, dtype, peer, c, stream});

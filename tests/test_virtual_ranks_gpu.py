@@ -42,14 +42,15 @@ def local_triples(rank, world, U, I, n_local, idle_rank=None):
 
 
 def planned_rank(group, w0, U, I, D, n_local, bs, shuffle, optimizer, lr, driver, idle_rank, epochs=1, prefetch=False,
-                 dense_opt="sweep", shard_sgd="pull"):
+                 dense_opt="sweep", shard_sgd="pull", self_exchange=False):
     import beta_recsys_amd as hp
     from beta_recsys_amd.sharded import ShardedMFEngine
 
     rank, world = group.rank(), group.size()
     users, pos, neg = local_triples(rank, world, U, I, n_local, idle_rank)
     cfg = {"model": dict(n_users=U, n_items=I, emb_dim=D, device_str="cuda:0", optimizer=optimizer, lr=lr, batch_size=bs,
-                         loss="bpr", sgd_mode="rows", step_driver=driver, dense_opt=dense_opt, shard_sgd=shard_sgd),
+                         loss="bpr", sgd_mode="rows", step_driver=driver, dense_opt=dense_opt, shard_sgd=shard_sgd,
+                         shard_self_exchange=self_exchange),
            "system": RUN_DIR}
     with contextlib.redirect_stdout(io.StringIO()):
         eng = ShardedMFEngine(cfg, process_group=group, full_state={k: torch.from_numpy(v) for k, v in w0.items()})
@@ -144,6 +145,28 @@ def test_planned_steps_exchange_between_virtual_ranks(hip_device, world, D, bs, 
     assert counters["groups"] == 2 * steps * world, counters
     assert counters["sends"] == counters["recvs"] == 2 * steps * world * (world - 1), counters
     assert counters["bytes"] > 0
+    check_planned(res, w0, n_local, bs, optimizer, lr)
+
+
+@pytest.mark.parametrize("world,optimizer,lr,dense_opt", [(2, "sgd", 0.05, "sweep"), (3, "adam", 0.05, "lazy"),
+                                                          (4, "rmsprop", 0.01, "sweep")])
+def test_planned_steps_with_the_own_segment_exchanged_too(hip_device, world, optimizer, lr, dense_opt):
+    """HIPREC_SHARD_EXCHANGE_SELF (`shard_self_exchange`) on a world of several ranks: every rank's own segment of both
+    exchanges goes through the communicator as well -- one more send and one more recv per rank, exchange and step,
+    posted to itself inside the same group -- and the epoch is the oracle's like the in-place form's."""
+    U, I, D, bs = 3001, 403, 64, 256
+    n_local = 3 * bs + bs // 3
+    w0 = onp.init_params(U, I, D, seed=3)
+    vw = VirtualWorld(world)
+    try:
+        res = vw.run(lambda g: planned_rank(g, w0, U, I, D, n_local, bs, True, optimizer, lr, "c", None,
+                                            dense_opt=dense_opt, self_exchange=True))
+        counters = vw.counters()
+    finally:
+        vw.close()
+    steps = (n_local + bs - 1) // bs
+    assert all(r["mode"] == "c" for r in res)
+    assert counters["groups"] == 2 * steps * world and counters["sends"] == counters["recvs"] == 2 * steps * world * world
     check_planned(res, w0, n_local, bs, optimizer, lr)
 
 

@@ -1,0 +1,28 @@
+"""Same-box A/B of run layouts of the column-sliced SpMM's chunk descriptors (beta-recsys_amd/lightgcn.py:
+SLICED_RUNS) on the LightGCN step of BASELINE configs[4]: python tools/exp_sliced_runs.py carry cut [...]
+Alternates the variants ROUNDS times in one process; prints us per step of every run."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import beta_recsys_amd.lightgcn as lg  # noqa: E402
+
+
+def main():
+    variants = sys.argv[1:] or ["carry", "cut"]
+    rounds = int(os.environ.get("ROUNDS", "3"))
+    device = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    for r in range(rounds):
+        for v in variants:
+            lg.SLICED_RUNS = v
+            args = bench.parse_args(["--workload", "lightgcn", "--steps", "100", "--warmup", "20", "--no-cpu-baseline"])
+            out = bench.bench_lightgcn(args, device)
+            print(f"{v} round {r}: {out['ms_per_step'] * 1e3:.2f} us/step  loss {out['config']['last_loss']:.6f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
