@@ -687,6 +687,8 @@ def bench_lightgcn(args, device, world=1, rank=0, dist_on=False):
                          device_str=str(device), optimizer="adam", lr=0.05, batch_size=Bl, norm_adj=norm,
                          dropout_rng="device"),
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
+    if getattr(args, "lane_slots", None):
+        cfg["model"]["spmm_lane_slots"] = args.lane_slots
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
         if dist_on:   # data-parallel replicas: every rank its own 1024 triples of the global batch, one all-reduce
@@ -1401,6 +1403,8 @@ def parse_args(argv=None):
                          "shared rows collect device-scope atomics (csrc/mf_owned.hip); "
                          "rows = gradient kernel into a dense buffer + touched-rows pass (round 1)")
     ap.add_argument("--emb-dim", type=int, default=32, help="ncf: 32 (tower 256-128-64-32, primary) or 64")
+    ap.add_argument("--lane-slots", type=int, default=None, choices=[16, 24, 32, 48],
+                    help="lightgcn: slots per lane of the column-sliced SpMM's chunks (default: the host's choice for the graph)")
     ap.add_argument("--multi-gpu", default="auto", choices=["auto", "replicated", "sharded"],
                     help="mf, N>1: auto = the row-sharded step (BASELINE.json's split: owner = row mod N, planned "
                          "all-to-alls, the reference's batch split over the ranks) as the headline with the replicated "

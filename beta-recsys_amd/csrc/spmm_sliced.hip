@@ -40,8 +40,8 @@
 namespace hiprec {
 
 // Timing experiments (tools/exp_spmm_parts.py, profiles/r03_experiments.md 39): parts of the kernel switched off by the
-// bits of HIPREC_SLICED_EXP -- 1 slice-major block map, 4 no output stores, 16 no slice fill (results are wrong with
-// 4 / 16).  Only in builds made with -DHIPREC_SLICED_DEBUG (tools/build_debug_lib.sh); the product library has no
+// bits of HIPREC_SLICED_EXP -- 1 slice-major block map, 4 no output stores, 16 no slice fill, 32 no chunks at all
+// (results are wrong with 4 / 16 / 32).  Only in builds made with -DHIPREC_SLICED_DEBUG (tools/build_debug_lib.sh); the product library has no
 // such switch.
 #ifdef HIPREC_SLICED_DEBUG
 #define HIPREC_SLICED_EXP(bit) ((fl.exp & (bit)) != 0)
@@ -63,66 +63,61 @@ struct SlicedVec<4> { using type = float __attribute__((ext_vector_type(4))); };
 template <>
 struct SlicedVec<2> { using type = float __attribute__((ext_vector_type(2))); };
 
-template <bool FACTORED>
-struct SlicedEdges {  // the 16 slots of one lane
-  uint4 c[2];
-  float4 v[4];
+// The S slots of one lane: S / 8 16-byte loads of 2-byte columns, and for a graph that keeps its values S / 4 more.
+template <bool FACTORED, int S>
+struct SlicedEdges {
+  uint4 c[S / 8];
+  float4 v[S / 4];
 };
-template <>
-struct SlicedEdges<true> {
-  uint4 c[2];
+template <int S>
+struct SlicedEdges<true, S> {
+  uint4 c[S / 8];
 };
 
-// `edges`: float values [n_slots] (general graph) or uint16 columns [n_slots] (factored graph)
-template <bool FACTORED>
-__device__ __forceinline__ SlicedEdges<FACTORED> load_sliced_edges(const uint16_t* __restrict__ col16,
-                                                                   const void* __restrict__ edges, int2 d, int q,
-                                                                   uint32_t zero_row) {
-  SlicedEdges<FACTORED> e;
-  const bool live = q * 16 < ((d.y >> 16) & 0xFF);
-  const int64_t base = static_cast<int64_t>(d.x) + q * 16;  // a multiple of 16: 32-B / 64-B aligned
-  if constexpr (FACTORED) {
-    const uint32_t z = zero_row | (zero_row << 16);
-    e.c[0] = e.c[1] = uint4{z, z, z, z};
-    if (live) {
-      const uint4* pc = reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(edges) + base);
-      e.c[0] = pc[0];
-      e.c[1] = pc[1];
-    }
-  } else {
-    e.c[0] = e.c[1] = uint4{0, 0, 0, 0};
+// `edges`: float values [n_slots] (general graph) or uint16 columns [n_slots] (factored graph).  A lane without slots
+// of its own (a chunk of fewer than 4 lanes' worth, or no chunk at all) reads the graph's all-padding tail instead of
+// branching around its loads: every load of the loop is unconditional.
+template <bool FACTORED, int S>
+__device__ __forceinline__ SlicedEdges<FACTORED, S> load_sliced_edges(const uint16_t* __restrict__ col16,
+                                                                      const void* __restrict__ edges, int2 d, int q,
+                                                                      int pad_slot) {
+  SlicedEdges<FACTORED, S> e;
+  const bool live = q * S < ((d.y >> 16) & 0xFF);
+  const int base = live ? d.x + q * S : pad_slot;  // a multiple of 8 slots: 16-B / 32-B aligned
+  const uint4* pc = reinterpret_cast<const uint4*>((FACTORED ? static_cast<const uint16_t*>(edges) : col16) + base);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) e.v[k] = float4{0.f, 0.f, 0.f, 0.f};
-    if (live) {
-      const uint4* pc = reinterpret_cast<const uint4*>(col16 + base);
-      const float4* pv = reinterpret_cast<const float4*>(static_cast<const float*>(edges) + base);
-      e.c[0] = pc[0];
-      e.c[1] = pc[1];
+  for (int k = 0; k < S / 8; ++k) e.c[k] = pc[k];
+  if constexpr (!FACTORED) {
+    const float4* pv = reinterpret_cast<const float4*>(static_cast<const float*>(edges) + base);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) e.v[k] = pv[k];
-    }
+    for (int k = 0; k < S / 4; ++k) e.v[k] = pv[k];
   }
   return e;
 }
 
 // acc_mode: 0 = none, 1 = accs += y, 2 = accs = y
-template <int W, bool FACTORED>
+// S = slots per lane and trip (hiprec_sliced_csr.lane_slots): a chunk is 4 S slots of one row.  What a trip does besides
+// its S LDS reads per lane -- descriptor and edge prefetch, the quad's reduction, the run logic, the store -- costs about
+// as many VALU instructions as 16 slots' address arithmetic and additions do, and at S = 16 the kernel was bound by the
+// VALU (round 6, SQ counters: 59 % VALU busy, LDS 49 %): the host picks S per graph so that typical rows are few chunks.
+template <int W, bool FACTORED, int S>
 __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_sliced_csr a,
                                                                      const void* __restrict__ edges, float scale,
                                                                      const float* __restrict__ xs,
                                                                      float* __restrict__ ys, float* __restrict__ accs,
                                                                      int acc_mode, SlicedFlush fl, int dim) {
+  static_assert(S % 8 == 0 && S >= 16 && 4 * S < 256, "slots per lane");
   float* __restrict__ zero_out = fl.zero_out;
   float* __restrict__ final_out = fl.final_out;
   const int final_set = fl.final_set ? 1 : 0;
   using Vec = typename SlicedVec<W>::type;
   using LdsVec = const __attribute__((address_space(3))) Vec;
   using Pair = float __attribute__((ext_vector_type(2)));
+  using Edges = SlicedEdges<FACTORED, S>;
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
   const int64_t n_rows = a.n_rows;
   float* s_x = s_mem;                     // [n_rows + 1][W]: slice s of the source, then an all-zero row
   float* s_y = s_mem + (n_rows + 1) * W;  // [row_cap][W]: accumulators of the current subgroup's rows
-  const uint32_t zero_row = static_cast<uint32_t>(n_rows);
   const uint32_t row_bytes = W * sizeof(float);
   const uint32_t lds_base =
       static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)s_x));
@@ -132,12 +127,13 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
   const int64_t slice_off = static_cast<int64_t>(s) * n_rows * W;
   const int quad = static_cast<int>(threadIdx.x) >> 2, q = static_cast<int>(threadIdx.x) & 3;
   const int lane = static_cast<int>(threadIdx.x) & 63;
+  const int pad_slot = a.pad_slot;
   const int2* __restrict__ chunks = reinterpret_cast<const int2*>(a.chunks);
   const int sg_begin = g * a.subs_per_group, sg_end = sg_begin + a.subs_per_group;
   const int c_end = a.sub_chunk[sg_end];  // the block's chunks: sub_chunk[sg_begin] .. c_end
   auto desc = [&](int c) { return c < c_end ? chunks[c] : int2{0, 0}; };  // {first slot, row | n_slots << 16 | run flags}
   // The chunk pipeline runs through the block's subgroups without draining: quad k takes chunks k, k + 256, ...
-  // of the block, with its next chunks' descriptors and edge data in flight ahead of the arithmetic.
+  // of the block, with its next chunk's edge data and the descriptor after that in flight ahead of the arithmetic.
   // the slice: every thread's (at most kSlicedFill) 16-byte loads are issued together -- a load-store loop would pay
   // the memory latency once per trip
   const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xs + slice_off);
@@ -149,12 +145,8 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
     fill[k] = (i < n4 && !HIPREC_SLICED_EXP(16)) ? x4[i] : float4{0.f, 0.f, 0.f, 0.f};
   }
   int c = a.sub_chunk[sg_begin] + quad;
-  // P: edge data of P chunks in flight ahead of the arithmetic (descriptors one more).  Three instead of one
-  // (a factored graph's 8 registers per chunk allow it) changed nothing: 27.2 against 26.9 us.
-  constexpr int P = 1;
-  int2 dq[P + 1];
-#pragma unroll
-  for (int k = 0; k <= P; ++k) dq[k] = desc(c + k * kSlicedQuads);
+  // d0 / e0: the chunk about to be summed; d1: the one after it (its edge data is requested while e0 is summed)
+  int2 d0 = desc(c), d1 = desc(c + kSlicedQuads);
 #pragma unroll
   for (int k = 0; k < kSlicedFill; ++k) {
     const int i = static_cast<int>(threadIdx.x) + k * kSlicedThreads;
@@ -162,12 +154,97 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
   }
   if (static_cast<int>(threadIdx.x) < n_tail) s_x[4 * n4 + threadIdx.x] = xs[slice_off + 4 * n4 + threadIdx.x];
   if (static_cast<int>(threadIdx.x) < W) s_x[n_rows * W + threadIdx.x] = 0.f;
-  SlicedEdges<FACTORED> eq[P];
-#pragma unroll
-  for (int k = 0; k < P; ++k) eq[k] = load_sliced_edges<FACTORED>(a.col16, edges, dq[k], q, zero_row);
+  Edges e0 = load_sliced_edges<FACTORED, S>(a.col16, edges, d0, q, pad_slot);
   const int n_acc = a.row_cap * W;  // <= kSlicedMaxRowCap * 4 = 2 per thread
   for (int i = threadIdx.x; i < n_acc; i += kSlicedThreads) s_y[i] = 0.f;
   __syncthreads();
+
+  // One chunk: S random source rows out of the LDS per lane (~2-way bank conflicts after the host's slot
+  // permutation), summed; the quad's four partial sums folded so that lane q holds component q; the wave's runs of
+  // chunks of one row summed; the last quad of a run stores.
+  auto sum_chunk = [&](const Edges& e, const int2 d, int r0) {
+    const uint32_t* cw = reinterpret_cast<const uint32_t*>(e.c);  // two columns per word
+    Vec src[2][4];
+    Pair acc[W / 2];  // two floats per register pair: v_pk_add_f32 / v_pk_fma_f32
+#pragma unroll
+    for (int h = 0; h < W / 2; ++h) acc[h] = Pair{0.f, 0.f};
+    // LDS byte address of slot j's source row: column (low / high half of a word) * row bytes + base, one
+    // v_mad_u32_u16 each; four reads are requested at a time, eight are in flight while the previous four are added --
+    // left alone the compiler keeps two reads in flight and waits for each
+    auto request = [&](int grp) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int slot = 4 * grp + j;
+        uint32_t addr;
+        if (slot & 1)
+          asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(addr) : "v"(cw[slot >> 1]), "v"(row_bytes), "v"(lds_base));
+        else
+          asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(addr) : "v"(cw[slot >> 1]), "v"(row_bytes), "v"(lds_base));
+        src[grp & 1][j] = *reinterpret_cast<LdsVec*>(addr);
+      }
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    request(0);
+#pragma unroll
+    for (int b = 0; b < S / 4; ++b) {
+      if (b + 1 < S / 4) request(b + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const Pair* f = reinterpret_cast<const Pair*>(&src[b & 1][j]);
+#pragma unroll
+        for (int h = 0; h < W / 2; ++h) {
+          if constexpr (FACTORED) {
+            acc[h] += f[h];
+          } else {
+            const float* vv = reinterpret_cast<const float*>(e.v);
+            acc[h] += Pair{vv[4 * b + j], vv[4 * b + j]} * f[h];
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float mine = 0.f;  // lane q < W of the quad adds component q
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      float t = dpp_add<0xB1>(acc[w >> 1][w & 1]);  // quad_perm [1,0,3,2]
+      t = dpp_add<0x4E>(t);             // quad_perm [2,3,0,1]
+      mine = q == w ? t : mine;
+    }
+    // A row's chunks are consecutive, so the quads of a wave that work on one row are neighbours -- and LDS float
+    // atomics are slow (~3 cycles per LANE: with 64 lanes adding into ~5 rows' accumulators the ds_add was 11 of a
+    // pass's 27.5 us, profiles/r03_experiments.md 39).  So the wave sums a row's quads itself: a segmented
+    // inclusive scan over its 16 quads -- two DPP steps inside every 16-lane row, then the total so far carried
+    // from row to row through SGPRs -- and the LAST quad of a run stores: plainly when the run is the whole row,
+    // with an LDS atomic when a 16-chunk window cut the row.  Which quad does what is static (subgroups start on
+    // window boundaries, so a wave's 16 quads always hold one window) and comes with the descriptor:
+    // lightgcn.py _windowed_chunks.  A window of one-chunk rows (the common one once S fits the typical row) skips
+    // all of it.
+    const uint32_t dy = static_cast<uint32_t>(d.y);
+    if (__ballot(((dy >> 24) & 7) != 0) != 0) {
+      const int in_row = (dy >> 24) & 3;
+      const float o1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0x114, 0xF, 0xF, false));  // row_shr:4
+      if (in_row >= 1) mine += o1;
+      const float o2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0x118, 0xF, 0xF, false));  // row_shr:8
+      if (in_row >= 2) mine += o2;
+#pragma unroll
+      for (int r = 1; r < 4; ++r) {  // in order: row r - 1's last quad has its own carry by now
+        const bool need = ((dy >> 26) & 1) && (lane >> 4) == r;
+        if (__ballot(need) != 0) {
+          const int mi = __builtin_bit_cast(int, mine);
+          const int k0 = __builtin_amdgcn_readlane(mi, 16 * r - 4), k1 = __builtin_amdgcn_readlane(mi, 16 * r - 3),
+                    k2 = __builtin_amdgcn_readlane(mi, 16 * r - 2), k3 = __builtin_amdgcn_readlane(mi, 16 * r - 1);
+          if (need) mine += __builtin_bit_cast(float, q == 0 ? k0 : q == 1 ? k1 : q == 2 ? k2 : k3);
+        }
+      }
+    }
+    if (q < W && ((dy >> 27) & 1)) {
+      float* dst = &s_y[(static_cast<int>(dy & 0xFFFF) - r0) * W + q];
+      if ((dy >> 28) & 1) *dst = mine;
+      else lds_add_f32(dst, mine);
+    }
+  };
+
   for (int sg = sg_begin; sg < sg_end; ++sg) {
     const int r0 = a.sub_row[sg], r1 = a.sub_row[sg + 1], c1 = a.sub_chunk[sg + 1];
     const int n_out = (r1 - r0) * W;
@@ -187,105 +264,28 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
         }
       }
     }
+    // two trips per turn of the loop, the edge registers of one filled while the other's are summed: written as a
+    // one-deep rotation the compiler copied every edge register once per trip (25 v_mov of a 16-slot trip's 165)
+    if (HIPREC_SLICED_EXP(32)) c = c1 + quad;
     while (c < c1) {
-      const int2 d0 = dq[0], d_new = desc(c + (P + 1) * kSlicedQuads);
-      const SlicedEdges<FACTORED> e0 = eq[0], e_new = load_sliced_edges<FACTORED>(a.col16, edges, dq[P], q, zero_row);
-      // 16 random source rows out of the LDS (~3-way bank conflicts: the kernel's floor): addresses first, then
-      // reads four at a time with eight in flight while the previous four are multiplied -- left alone the compiler
-      // keeps two reads in flight and waits for each
-      const uint32_t cw[8] = {e0.c[0].x, e0.c[0].y, e0.c[0].z, e0.c[0].w, e0.c[1].x, e0.c[1].y, e0.c[1].z, e0.c[1].w};
-      float vv[16];
-      if constexpr (!FACTORED) {
-        const float4* pv = e0.v;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          vv[4 * k] = pv[k].x;
-          vv[4 * k + 1] = pv[k].y;
-          vv[4 * k + 2] = pv[k].z;
-          vv[4 * k + 3] = pv[k].w;
-        }
-      }
-      // LDS byte address of slot j's source row: column (low / high half of a word) * row bytes + base, one
-      // v_mad_u32_u16 each (the compiler's and / bfe + shift-add pairs were a quarter of the loop's VALU work)
-      uint32_t addr[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if (j & 1)
-          asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(addr[j]) : "v"(cw[j >> 1]), "v"(row_bytes), "v"(lds_base));
-        else
-          asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(addr[j]) : "v"(cw[j >> 1]), "v"(row_bytes), "v"(lds_base));
-      }
-      auto source = [&](int j) { return *reinterpret_cast<LdsVec*>(addr[j]); };
-      Vec src[2][4];
-      Pair acc[W / 2];  // two floats per register pair: v_pk_add_f32 / v_pk_fma_f32
-#pragma unroll
-      for (int h = 0; h < W / 2; ++h) acc[h] = Pair{0.f, 0.f};
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) src[0][j] = source(j);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        if (b < 3) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) src[(b + 1) & 1][j] = source(4 * (b + 1) + j);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const Pair* f = reinterpret_cast<const Pair*>(&src[b & 1][j]);
-#pragma unroll
-          for (int h = 0; h < W / 2; ++h) {
-            if constexpr (FACTORED) acc[h] += f[h];
-            else acc[h] += Pair{vv[4 * b + j], vv[4 * b + j]} * f[h];
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      float mine = 0.f;  // lane q < W of the quad adds component q
-#pragma unroll
-      for (int w = 0; w < W; ++w) {
-        float t = dpp_add<0xB1>(acc[w >> 1][w & 1]);  // quad_perm [1,0,3,2]
-        t = dpp_add<0x4E>(t);             // quad_perm [2,3,0,1]
-        mine = q == w ? t : mine;
-      }
-      // A row's chunks are consecutive, so the quads of a wave that work on one row are neighbours -- and LDS float
-      // atomics are slow (~3 cycles per LANE: with 64 lanes adding into ~5 rows' accumulators the ds_add was 11 of a
-      // pass's 27.5 us, profiles/r03_experiments.md 39).  So the wave sums a row's quads itself: a segmented
-      // inclusive scan over its 16 quads -- two DPP steps inside every 16-lane row, then the total so far carried
-      // from row to row through SGPRs -- and the LAST quad of a run stores: plainly when the run is the whole row,
-      // with an LDS atomic when a 16-chunk window cut the row.  Which quad does what is static (subgroups start on
-      // window boundaries, so a wave's 16 quads always hold one window) and comes with the descriptor:
-      // lightgcn.py _windowed_chunks.
-      const uint32_t dy = static_cast<uint32_t>(d0.y);
       {
-        const int in_row = (dy >> 24) & 3;
-        const float o1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0x114, 0xF, 0xF, false));  // row_shr:4
-        if (in_row >= 1) mine += o1;
-        const float o2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0x118, 0xF, 0xF, false));  // row_shr:8
-        if (in_row >= 2) mine += o2;
-      }
-#pragma unroll
-      for (int r = 1; r < 4; ++r) {  // in order: row r - 1's last quad has its own carry by now
-        const bool need = ((dy >> 26) & 1) && (lane >> 4) == r;
-        if (__ballot(need) != 0) {
-          const int mi = __builtin_bit_cast(int, mine);
-          const int c0 = __builtin_amdgcn_readlane(mi, 16 * r - 4), c1 = __builtin_amdgcn_readlane(mi, 16 * r - 3),
-                    c2 = __builtin_amdgcn_readlane(mi, 16 * r - 2), c3 = __builtin_amdgcn_readlane(mi, 16 * r - 1);
-          if (need) mine += __builtin_bit_cast(float, q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : c3);
+        const int2 d2 = desc(c + 2 * kSlicedQuads);
+        const Edges e1 = load_sliced_edges<FACTORED, S>(a.col16, edges, d1, q, pad_slot);
+        sum_chunk(e0, d0, r0);
+        c += kSlicedQuads;
+        if (!(c < c1)) {
+          e0 = e1;
+          d0 = d1;
+          d1 = d2;
+          break;
         }
+        const int2 d3 = desc(c + 2 * kSlicedQuads);
+        e0 = load_sliced_edges<FACTORED, S>(a.col16, edges, d2, q, pad_slot);
+        sum_chunk(e1, d1, r0);
+        c += kSlicedQuads;
+        d0 = d2;
+        d1 = d3;
       }
-      if (q < W && ((dy >> 27) & 1)) {
-        float* dst = &s_y[(static_cast<int>(dy & 0xFFFF) - r0) * W + q];
-        if ((dy >> 28) & 1) *dst = mine;
-        else lds_add_f32(dst, mine);
-      }
-      c += kSlicedQuads;
-#pragma unroll
-      for (int k = 0; k < P; ++k) dq[k] = dq[k + 1];
-      dq[P] = d_new;
-#pragma unroll
-      for (int k = 0; k + 1 < P; ++k) eq[k] = eq[k + 1];
-      eq[P - 1] = e_new;
     }
     __syncthreads();
 #pragma unroll
@@ -475,16 +475,37 @@ int sliced_row_cap(int64_t n_rows, int dim) {
   return static_cast<int>(std::min<int64_t>(kSlicedLds / (w * sizeof(float)) - n_rows - 1, kSlicedMaxRowCap));
 }
 
+template <int W, bool FACTORED, int S>
+static int launch_sliced_as(const hiprec_sliced_csr* a, const void* edges, float scale, const float* xs, float* ys,
+                            float* accs, int acc_mode, int dim, size_t lds, hipStream_t st, const SlicedFlush& fl) {
+  static std::atomic<uint64_t> lds_ok{0};  // per instantiation: the limit is an attribute of the function
+  if (int rc = allow_dynamic_lds({reinterpret_cast<const void*>(&spmm_sliced_kernel<W, FACTORED, S>)}, kSlicedLds, lds_ok,
+                                 "the column-sliced SpMM"))
+    return rc;
+  const int grid = (dim / W) * a->n_groups;
+  spmm_sliced_kernel<W, FACTORED, S><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, fl, dim);
+  HIPREC_TRY(hipGetLastError());
+  return 0;
+}
+
 int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scale, const float* xs, float* ys,
                        float* accs, int acc_mode, int dim, int W, hipStream_t st, SlicedFlush fl) {
   HIPREC_REQUIRE(a && a->sub_row && a->sub_chunk && a->n_rows > 0 && a->n_groups > 0 && a->subs_per_group > 0,
                  "bad sliced graph");
-  HIPREC_REQUIRE(a->n_slots == 0 || (a->col16 && a->val && a->chunks), "sliced graph has NULL chunks / col16 / val");
+  HIPREC_REQUIRE(a->n_slots > 0 && a->col16 && a->val && (a->n_chunks == 0 || a->chunks),
+                 "sliced graph has NULL chunks / col16 / val");
   HIPREC_REQUIRE(a->n_slots % 16 == 0, "n_slots %lld is not a multiple of 16", (long long)a->n_slots);
   HIPREC_REQUIRE(a->n_chunks % 16 == 0,
                  "%d chunks: the descriptors must be laid out in windows of 16 with their run flags (include/hiprec.h, "
                  "hiprec_sliced_csr; lightgcn._windowed_chunks builds them)", a->n_chunks);
   HIPREC_REQUIRE((a->row_scale == nullptr) == (a->col_scale == nullptr), "row_scale and col_scale go together");
+  const bool factored = a->col_scale != nullptr;
+  const int S = a->lane_slots;
+  HIPREC_REQUIRE(S == 16 || (factored && (S == 24 || S == 32 || S == 48)),
+                 "lane_slots %d: 16, or 24 / 32 / 48 for a factored graph", S);
+  HIPREC_REQUIRE(a->pad_slot >= 0 && a->pad_slot % 8 == 0 && a->pad_slot + S <= a->n_slots,
+                 "pad_slot %d: the graph must end with lane_slots = %d padding slots (n_slots %lld)", a->pad_slot, S,
+                 (long long)a->n_slots);
   HIPREC_REQUIRE(W > 0 && W == sliced_width(a->n_rows, dim), "slice width %d does not fit %lld rows x dim %d", W,
                  (long long)a->n_rows, dim);
   HIPREC_REQUIRE(a->row_cap > 0 && a->row_cap <= sliced_row_cap(a->n_rows, dim),
@@ -492,29 +513,26 @@ int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scal
                  sliced_row_cap(a->n_rows, dim));
   HIPREC_REQUIRE(xs && (ys || fl.final_out) && (acc_mode == 0 || accs), "NULL sliced buffers");
   const size_t lds = static_cast<size_t>(a->n_rows + 1 + a->row_cap) * W * sizeof(float);
-  static std::atomic<uint64_t> lds_ok{0};
-  if (int rc = allow_dynamic_lds({reinterpret_cast<const void*>(&spmm_sliced_kernel<4, false>),
-                                  reinterpret_cast<const void*>(&spmm_sliced_kernel<2, false>),
-                                  reinterpret_cast<const void*>(&spmm_sliced_kernel<4, true>),
-                                  reinterpret_cast<const void*>(&spmm_sliced_kernel<2, true>)},
-                                 kSlicedLds, lds_ok, "the column-sliced SpMM"))
-    return rc;
-  const bool factored = a->col_scale != nullptr;
   if (edges == nullptr) edges = factored ? static_cast<const void*>(a->col16) : static_cast<const void*>(a->val);
-  const int grid = (dim / W) * a->n_groups;
 #ifdef HIPREC_SLICED_DEBUG
   if (const char* e = getenv("HIPREC_SLICED_EXP")) fl.exp = atoi(e);
 #endif
-  if (W == 4 && factored)
-    spmm_sliced_kernel<4, true><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, fl, dim);
-  else if (W == 4)
-    spmm_sliced_kernel<4, false><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, fl, dim);
-  else if (factored)
-    spmm_sliced_kernel<2, true><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, fl, dim);
-  else
-    spmm_sliced_kernel<2, false><<<grid, kSlicedThreads, lds, st>>>(*a, edges, scale, xs, ys, accs, acc_mode, fl, dim);
-  HIPREC_TRY(hipGetLastError());
-  return 0;
+#define HIPREC_SLICED_CASE(w, f, sl) \
+  if (W == w && factored == f && S == sl) \
+    return launch_sliced_as<w, f, sl>(a, edges, scale, xs, ys, accs, acc_mode, dim, lds, st, fl);
+  HIPREC_SLICED_CASE(4, true, 16)
+  HIPREC_SLICED_CASE(4, true, 24)
+  HIPREC_SLICED_CASE(4, true, 32)
+  HIPREC_SLICED_CASE(4, true, 48)
+  HIPREC_SLICED_CASE(2, true, 16)
+  HIPREC_SLICED_CASE(2, true, 24)
+  HIPREC_SLICED_CASE(2, true, 32)
+  HIPREC_SLICED_CASE(2, true, 48)
+  HIPREC_SLICED_CASE(4, false, 16)
+  HIPREC_SLICED_CASE(2, false, 16)
+#undef HIPREC_SLICED_CASE
+  set_error("no column-sliced SpMM for width %d, lane_slots %d", W, S);
+  return HIPREC_E_UNSUPPORTED;
 }
 
 int launch_step_values(const hiprec_sliced_csr* a, const hiprec_sliced_csr* b, uint8_t* keep, bool draw,

@@ -43,7 +43,34 @@ def _csr_from_coo(rows, cols, vals, n, device):
     return (rowptr.to(device), c.to(torch.int32).to(device), v.to(torch.float32).to(device), order)
 
 
-SLICED_CHUNK, SLICED_PAD = 64, 16  # slots per work item / row padding of the column-sliced SpMM (csrc/spmm_sliced.hip)
+# Column-sliced SpMM (csrc/spmm_sliced.hip): a row is padded to a multiple of S = lane_slots slots and cut into chunks
+# of 4 S (S per lane of a quad).  S = 16 always works; a factored graph may use the larger ones.
+SLICED_LANE_SLOTS = (16, 24, 32, 48)
+SLICED_PAD, SLICED_CHUNK = 16, 64  # the S = 16 geometry
+
+
+def choose_lane_slots(lens, n_groups, factored):
+    """S for a graph with these row lengths: the one that minimises a workgroup's modelled time.  A chunk costs its
+    3 S VALU instructions for the slots (address + two packed adds each) plus ~60 for everything else (descriptor,
+    loads, the quad's reduction, the store; ~40 more when the row has several chunks: scan and carries), a wave takes
+    every 16th window of 16 chunks, and the slowest wave of a 16-wave workgroup sets the time -- so few, long chunks
+    win until the rows stop filling them or the waves' trip counts quantise badly (round 6: at S = 16 the kernel was
+    VALU-bound, 165 instructions per 16-slot trip)."""
+    if not factored:
+        return 16
+    lens = np.asarray(lens, dtype=np.int64)
+    best = None
+    for S in SLICED_LANE_SLOTS:
+        per_row = (((lens + S - 1) // S) + 3) // 4
+        n_chunks = int(per_row.sum())
+        multi = int(per_row[per_row > 1].sum())
+        windows = -(-n_chunks // (16 * max(n_groups, 1)))          # per workgroup
+        trips = -(-windows // 16)                                   # of its slowest wave
+        mean_cost = 3 * S + 60 + 40 * (multi / max(n_chunks, 1))
+        cost = trips * mean_cost
+        if best is None or cost < best[0]:
+            best = (cost, S)
+    return best[1]
 
 
 def factor_edge_values(rowptr, col, val, rel_tol=2e-6, max_rounds=256):
@@ -144,21 +171,27 @@ def _windowed_chunks(start, chunk_row, clen, within, per_row, sub_chunk):
     return np.stack([start2, desc], axis=1).astype(np.int32), new_sub
 
 
-def sliced_graph_host(rowptr, col, val, eid, n_groups, row_cap, max_subs=64, factor=True):
+def sliced_graph_host(rowptr, col, val, eid, n_groups, row_cap, max_subs=64, factor=True, lane_slots=None):
     """hiprec_sliced_csr (include/hiprec.h) of a CSR given as numpy arrays; eid = keep-byte index of every edge
     (None = the edge number itself).  factor: look for the rank-one form of the values (factor_edge_values); the
-    graph is then stored with row_scale / col_scale and its padding slots point at the zero row n.
+    graph is then stored with row_scale / col_scale and its padding slots point at the zero row n.  lane_slots: S
+    (None: choose_lane_slots).
 
     Returns dict(col16 uint16, val float32, eid int32 [n_slots]; chunks int32 [n_chunks, 2]; sub_row, sub_chunk
-    int32 [n_groups * k + 1]; subs_per_group k; n_chunks; n_slots; optionally row_scale, col_scale float32 [n]) or
-    None when no k <= max_subs keeps every subgroup within row_cap rows."""
+    int32 [n_groups * k + 1]; subs_per_group k; n_chunks; n_slots; lane_slots; pad_slot; optionally row_scale,
+    col_scale float32 [n]) or None when no k <= max_subs keeps every subgroup within row_cap rows."""
     rowptr = np.asarray(rowptr, dtype=np.int64)
     n, nnz = rowptr.size - 1, int(rowptr[-1])
     scales = factor_edge_values(rowptr, col, val) if factor else None
     lens = np.diff(rowptr)
-    padded = (lens + SLICED_PAD - 1) // SLICED_PAD * SLICED_PAD
+    S = int(lane_slots) if lane_slots is not None else choose_lane_slots(lens, n_groups, scales is not None)
+    if S not in SLICED_LANE_SLOTS or (scales is None and S != 16):
+        raise ValueError(f"lane_slots {S}: 16, or one of {SLICED_LANE_SLOTS} for a factored graph")
+    chunk = 4 * S
+    padded = (lens + S - 1) // S * S
     slotptr = np.concatenate([[0], np.cumsum(padded)])
-    n_slots = int(slotptr[-1])
+    pad_slot = int(slotptr[-1])                      # rows' slots, then the all-padding tail lanes without slots read
+    n_slots = (pad_slot + S + 15) // 16 * 16
     edge_row = np.repeat(np.arange(n, dtype=np.int64), lens)
     slot = np.arange(nnz, dtype=np.int64) + (slotptr[:-1] - rowptr[:-1])[edge_row]
     col16 = np.full(n_slots, n if scales is not None else 0, np.uint16)
@@ -166,13 +199,13 @@ def sliced_graph_host(rowptr, col, val, eid, n_groups, row_cap, max_subs=64, fac
     col16[slot] = np.asarray(col)[:nnz]
     valp[slot] = np.asarray(val)[:nnz]
     eidp[slot] = np.arange(nnz) if eid is None else np.asarray(eid)[:nnz]
-    per_row = (padded + SLICED_CHUNK - 1) // SLICED_CHUNK
+    per_row = (padded + chunk - 1) // chunk
     first = np.cumsum(per_row) - per_row  # first chunk of every row
     n_chunks = int(per_row.sum())
     chunk_row = np.repeat(np.arange(n, dtype=np.int64), per_row)
     within = np.arange(n_chunks, dtype=np.int64) - first[chunk_row]
-    start = slotptr[chunk_row] + SLICED_CHUNK * within
-    clen = np.minimum(SLICED_CHUNK, padded[chunk_row] - SLICED_CHUNK * within)
+    start = slotptr[chunk_row] + chunk * within
+    clen = np.minimum(chunk, padded[chunk_row] - chunk * within)
     for k in range(1, max_subs + 1):
         n_sub = n_groups * k
         target = np.minimum((np.arange(n_sub + 1) * n_chunks) // n_sub, max(n_chunks - 1, 0))
@@ -184,7 +217,7 @@ def sliced_graph_host(rowptr, col, val, eid, n_groups, row_cap, max_subs=64, fac
             chunks, sub_chunk = _windowed_chunks(start, chunk_row, clen, within, per_row, sub_chunk)
             out = {"col16": col16, "val": valp, "eid": eidp, "chunks": chunks, "sub_row": sub_row.astype(np.int32),
                    "sub_chunk": sub_chunk.astype(np.int32), "subs_per_group": k, "n_chunks": int(chunks.shape[0]),
-                   "n_slots": n_slots}
+                   "n_slots": n_slots, "lane_slots": S, "pad_slot": pad_slot}
             if scales is not None:
                 out["row_scale"], out["col_scale"] = scales
             return out
@@ -197,13 +230,13 @@ _B128_QUAD_GROUPS = ((0, 3, 5, 6), (1, 2, 4, 7), (8, 11, 13, 14), (9, 10, 12, 15
 
 
 def spread_bank_conflicts(host, n_groups, quads_per_block=256):
-    """Reorder the 16 slots inside every lane's segment of a sliced graph (in place) so that the source rows the 16
+    """Reorder the S slots inside every lane's segment of a sliced graph (in place) so that the source rows the 16
     lanes of one `ds_read_b128` cycle read at the same time fall into different bank quads (column mod 16) where
     possible.  The kernel's chunk -> (block, wave, quad, trip) assignment is static, so which lanes read together
-    is known here; a lane sums its 16 slots anyway, so their order is free.  Greedy: trip by trip, lane by lane, take
+    is known here; a lane sums its S slots anyway, so their order is free.  Greedy: read by read, lane by lane, take
     the unused slot whose bank quad is least used in this cycle.  Random columns conflict 3.0-way on average on the
     BASELINE configs[4] graph, 2.0-way after this.  Returns (mean ways before, after)."""
-    chunks, k = host["chunks"], host["subs_per_group"]
+    chunks, k, S = host["chunks"], host["subs_per_group"], host["lane_slots"]
     col16, n_chunks = host["col16"], host["n_chunks"]
     if n_chunks == 0:
         return 1.0, 1.0
@@ -219,34 +252,34 @@ def spread_bank_conflicts(host, n_groups, quads_per_block=256):
     for gi, quads in enumerate(_B128_QUAD_GROUPS):
         for pi, qq in enumerate(quads):
             group_of_quad[qq], pos_in_group[qq] = gi, pi
-    # instance = (block, trip, wave, lane group): 4 chunks x 4 lanes = 16 lanes of 16 slots
+    # instance = (block, trip, wave, lane group): 4 chunks x 4 lanes = 16 lanes of S slots
     n_trips = int(trip.max()) + 1
     inst = ((block_of * n_trips + trip) * 16 + wave) * 4 + group_of_quad[qiw]
     uniq, inst = np.unique(inst, return_inverse=True)
     n_inst = uniq.size
-    slot_of = np.full((n_inst, 16, 16), -1, np.int64)  # [instance, lane, j] -> slot (-1: no such slot)
+    slot_of = np.full((n_inst, 16, S), -1, np.int64)  # [instance, lane, j] -> slot (-1: no such slot)
     lane0 = pos_in_group[qiw] * 4
     for q in range(4):
-        live = clen > 16 * q
-        base = start[live] + 16 * q
-        slot_of[inst[live], lane0[live] + q] = base[:, None] + np.arange(16)[None, :]
+        live = clen > S * q
+        base = start[live] + S * q
+        slot_of[inst[live], lane0[live] + q] = base[:, None] + np.arange(S)[None, :]
     valid = slot_of >= 0
     # bank quad of every slot; 16 = costs nothing (no slot, or a padding slot: those all read one address, a broadcast)
     real = valid & (host["eid"][np.maximum(slot_of, 0)] >= 0)
     bank = np.where(real, col16[np.maximum(slot_of, 0)].astype(np.int64) & 15, 16)
 
     def mean_ways(b):
-        cnt = np.zeros((n_inst, 16, 17), np.int64)  # [instance, j, bank]
-        np.add.at(cnt, (np.arange(n_inst)[:, None, None], np.arange(16)[None, None, :], b), 1)
+        cnt = np.zeros((n_inst, S, 17), np.int64)  # [instance, j, bank]
+        np.add.at(cnt, (np.arange(n_inst)[:, None, None], np.arange(S)[None, None, :], b), 1)
         ways = cnt[:, :, :16].max(2)
         busy = ways > 0
         return float(ways[busy].mean()) if busy.any() else 1.0
 
     before = mean_ways(bank)
-    order = np.zeros((n_inst, 16, 16), np.int64)
-    remaining = np.ones((n_inst, 16, 16), bool)
+    order = np.zeros((n_inst, 16, S), np.int64)
+    remaining = np.ones((n_inst, 16, S), bool)
     ar = np.arange(n_inst)
-    for j in range(16):
+    for j in range(S):
         cnt = np.zeros((n_inst, 17), np.int64)
         for lane in range(16):
             b = bank[:, lane]
@@ -263,8 +296,8 @@ def spread_bank_conflicts(host, n_groups, quads_per_block=256):
     src = np.take_along_axis(slot_of, order, 2)  # slot whose contents move to position [instance, lane, j]
     dst = slot_of
     ok = (dst >= 0) & (src >= 0)
-    # a lane with fewer than 16 real slots: `order` may pair a real position with an empty source; such lanes do
-    # not exist (segments are whole: a lane either has all 16 slots or none)
+    # a lane with fewer than S real slots: `order` may pair a real position with an empty source; such lanes do
+    # not exist (segments are whole: a lane either has all S slots or none)
     assert np.array_equal(dst >= 0, src >= 0)
     for name in ("col16", "val", "eid"):
         arr = host[name]
@@ -280,11 +313,12 @@ def sliced_graph_device(host, n_rows, n_groups, row_cap, device):
     sc = _lib.SlicedCsr(hold["chunks"].data_ptr(), hold["col16"].data_ptr(), hold["val"].data_ptr(),
                         hold["eid"].data_ptr(), hold["sub_row"].data_ptr(), hold["sub_chunk"].data_ptr(),
                         _lib.ptr(hold.get("row_scale")), _lib.ptr(hold.get("col_scale")), n_rows,
-                        host["n_slots"], n_groups, host["subs_per_group"], host["n_chunks"], row_cap)
+                        host["n_slots"], n_groups, host["subs_per_group"], host["n_chunks"], row_cap,
+                        host["lane_slots"], host["pad_slot"])
     return sc, hold
 
 
-def build_sliced_graphs(csr, csr_t, order_t, n, dim, dev, mode="auto"):
+def build_sliced_graphs(csr, csr_t, order_t, n, dim, dev, mode="auto", lane_slots=None):
     """{"slice_w": W, "sliced": (SlicedCsr, tensors), "sliced_t": ..., "n_groups", "row_cap"} for a graph and its
     transpose (device CSR triples; order_t: forward edge number of every transposed edge), or {"slice_w": 0} when the
     column-sliced SpMM (csrc/spmm_sliced.hip) does not apply: 65 536 nodes or more, a slice that does not fit the
@@ -301,7 +335,8 @@ def build_sliced_graphs(csr, csr_t, order_t, n, dim, dev, mode="auto"):
     cap = int(lib.hiprec_sliced_row_cap(n, dim))
     for tag, (rowptr, col, val), eid in (("", csr, None), ("_t", csr_t, order_t)):
         host = sliced_graph_host(rowptr.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy(),
-                                 None if eid is None else eid.cpu().numpy(), n_groups, cap, factor=mode == "auto")
+                                 None if eid is None else eid.cpu().numpy(), n_groups, cap, factor=mode == "auto",
+                                 lane_slots=lane_slots)
         if host is None:
             return {"slice_w": 0}
         spread_bank_conflicts(host, n_groups)
@@ -363,7 +398,8 @@ class LightGCN(_FlatModel):
             self._graph["slice_row"] = _slice_rows(rp, c, v, N, nnz)
             self._graph["slice_row_t"] = _slice_rows(rpt, ct, vt, N, nnz)
             self._graph.update(build_sliced_graphs((rp, c, v), (rpt, ct, vt), order_t, N, self.emb_dim, dev,
-                                                   self.config.get("spmm", "auto")))
+                                                   self.config.get("spmm", "auto"),
+                                                   self.config.get("spmm_lane_slots")))
         return self._graph
 
     def workspace(self):

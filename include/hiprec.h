@@ -886,15 +886,19 @@ int hiprec_csr_slice_rows(const hiprec_csr* a, int32_t* out, int64_t n_out, void
 /* Everything one LightGCN step touches.  e0 / g are the flat parameter / gradient buffers
  * [user_embedding | item_embedding] = [(n_users + n_items), dim]; the rest is caller-owned
  * workspace of the same shape. */
-/* A graph stored for the column-sliced SpMM (n_rows < 65536).  Every row's edge list is padded to a multiple of 16
- * SLOTS: col16 / val / eid hold n_slots entries (padding: col 0, val 0, eid -1; eid = the edge's index into the keep
- * bytes of a step, i.e. its number in the FORWARD graph's CSR order).  Work items are chunks: at most 64 consecutive
- * slots of one row, chunks[2 * c] = first slot (a multiple of 16), chunks[2 * c + 1] = row | n_slots_of_chunk << 16
- * | run flags, sorted by row; every subgroup is padded with empty chunks (0 slots) to a multiple of 16 chunks.  The
- * kernel's workgroup of 1024 threads gives a WINDOW of 16 consecutive chunks to a wave (one per quad of lanes) and sums
- * the chunks of one row inside the window (a RUN) before the LDS sees them; the flags say what a quad does: bits 24-25
- * min(position in the run, quad index inside its 16-lane row), bit 26 the run began in an earlier 16-lane row, bit 27
- * last chunk of the run (it stores), bit 28 the run is the whole row (plain store instead of an LDS atomic).  The rows are cut into n_groups * subs_per_group subgroups of consecutive rows and about equal
+/* A graph stored for the column-sliced SpMM (n_rows < 65536).  Every row's edge list is padded to a multiple of
+ * S = lane_slots SLOTS (16; a factored graph may use 24, 32 or 48 -- the host picks the S that makes typical rows few
+ * chunks, because a chunk's fixed cost is that of ~16 slots): col16 / val / eid hold n_slots entries (padding: col 0,
+ * val 0, eid -1; eid = the edge's index into the keep bytes of a step, i.e. its number in the FORWARD graph's CSR
+ * order), n_slots a multiple of 16, and the arrays END with at least S padding slots starting at pad_slot (a multiple
+ * of 8): lanes that have no slots of their own read those.  Work items are chunks: at most 4 S consecutive slots of one
+ * row (S per lane of a quad), chunks[2 * c] = first slot (a multiple of S), chunks[2 * c + 1] = row |
+ * n_slots_of_chunk << 16 | run flags, sorted by row; every subgroup is padded with empty chunks (0 slots) to a
+ * multiple of 16 chunks.  The kernel's workgroup of 1024 threads gives a WINDOW of 16 consecutive chunks to a wave (one
+ * per quad of lanes) and sums the chunks of one row inside the window (a RUN) before the LDS sees them; the flags say
+ * what a quad does: bits 24-25 min(position in the run, quad index inside its 16-lane row), bit 26 the run began in an
+ * earlier 16-lane row, bit 27 last chunk of the run (it stores), bit 28 the run is the whole row (plain store instead
+ * of an LDS atomic).  The rows are cut into n_groups * subs_per_group subgroups of consecutive rows and about equal
  * chunk count: subgroup k covers rows sub_row[k] .. sub_row[k + 1] (sub_row[0] = 0, the last = n_rows; at most
  * row_cap rows, so that their accumulators fit the LDS next to the slice: hiprec_sliced_row_cap) and chunks
  * sub_chunk[k] .. sub_chunk[k + 1].  n_groups should be a multiple of 8 with (dim / slice width) * n_groups = the
@@ -912,6 +916,9 @@ typedef struct hiprec_sliced_csr {
   const float* col_scale; /* padding slots then hold column n_rows (an all-zero source row), not 0           */
   int64_t n_rows, n_slots;
   int32_t n_groups, subs_per_group, n_chunks, row_cap;
+  int32_t lane_slots; /* S: slots per lane and chunk quarter -- 16, or 24 / 32 / 48 for a factored graph */
+  int32_t pad_slot;   /* first of (at least) S all-padding slots at the end of the slot arrays: what a lane without
+                       * slots of its own reads */
 } hiprec_sliced_csr;
 
 /* slice width (floats) the sliced SpMM uses for n_rows x dim: 4 or 2, the largest that divides dim and lets one

@@ -865,14 +865,17 @@ def test_batch_row_ownership_contract():
     assert own0.shape == (3, 0)
 
 
-@pytest.mark.parametrize("n,n_groups,cap,heavy", [(700, 16, 60, True), (9746, 16, 490, True), (50, 8, 128, False),
-                                                 (3000, 8, 100, False)])
-def test_sliced_graph_host_covers_every_edge_once(n, n_groups, cap, heavy):
-    """hiprec_sliced_csr as lightgcn.sliced_graph_host builds it: rows padded to 16 slots, every edge in exactly one
-    slot of one chunk of its row with its column / value / keep index, padding slots inert, chunks sorted by row,
-    subgroups = consecutive rows within the cap holding exactly their rows' chunks, empty rows (leading, interior,
-    trailing) inside some subgroup."""
-    from beta_recsys_amd.lightgcn import SLICED_CHUNK, SLICED_PAD, sliced_graph_host
+@pytest.mark.parametrize("n,n_groups,cap,heavy,lane_slots", [(700, 16, 60, True, 16), (9746, 16, 490, True, 48),
+                                                            (50, 8, 128, False, 24), (3000, 8, 100, False, 32),
+                                                            (700, 16, 60, True, 48)])
+def test_sliced_graph_host_covers_every_edge_once(n, n_groups, cap, heavy, lane_slots):
+    """hiprec_sliced_csr as lightgcn.sliced_graph_host builds it: rows padded to lane_slots slots, every edge in exactly
+    one slot of one chunk (at most 4 x lane_slots slots) of its row with its column / value / keep index, padding slots
+    inert, the all-padding tail behind the rows, chunks sorted by row, subgroups = consecutive rows within the cap
+    holding exactly their rows' chunks, empty rows (leading, interior, trailing) inside some subgroup."""
+    from beta_recsys_amd.lightgcn import sliced_graph_host
+
+    SLICED_PAD, SLICED_CHUNK = lane_slots, 4 * lane_slots
 
     rng = np.random.default_rng(n)
     lens = rng.integers(0, 200, n)
@@ -886,13 +889,22 @@ def test_sliced_graph_host_covers_every_edge_once(n, n_groups, cap, heavy):
     col = rng.integers(0, n, nnz)
     val = rng.standard_normal(nnz).astype(np.float32)
     eid = rng.permutation(nnz).astype(np.int64)
-    h = sliced_graph_host(rowptr, col, val, eid, n_groups, cap)
-    assert h is not None
+    h = sliced_graph_host(rowptr, col, val, eid, n_groups, cap, factor=False) if lane_slots == 16 else None
+    if lane_slots != 16:   # the wider geometries are for factored graphs: rank-one values
+        fr, fc = rng.random(n).astype(np.float32) + 0.5, rng.random(n).astype(np.float32) + 0.5
+        val = (fr[np.repeat(np.arange(n), lens)] * fc[col]).astype(np.float32)
+        with pytest.raises(ValueError, match="lane_slots"):
+            sliced_graph_host(rowptr, col, rng.standard_normal(nnz).astype(np.float32), eid, n_groups, cap,
+                              lane_slots=lane_slots)
+        h = sliced_graph_host(rowptr, col, val, eid, n_groups, cap, lane_slots=lane_slots)
+        assert "col_scale" in h
+    assert h is not None and h["lane_slots"] == lane_slots
     chunks, k = h["chunks"], h["subs_per_group"]
     start, row, clen = chunks[:, 0], chunks[:, 1] & 0xFFFF, (chunks[:, 1] >> 16) & 0xFF
     real = clen > 0  # subgroups are padded with empty chunks to a multiple of 16
     assert np.all(clen[real] >= SLICED_PAD) and np.all(clen <= SLICED_CHUNK) and np.all(np.diff(row) >= 0)
-    assert np.all(start % SLICED_PAD == 0) and np.all(clen % SLICED_PAD == 0) and h["n_slots"] % SLICED_PAD == 0
+    assert np.all(start % SLICED_PAD == 0) and np.all(clen % SLICED_PAD == 0) and h["n_slots"] % 16 == 0
+    assert h["pad_slot"] % SLICED_PAD == 0 and h["pad_slot"] + SLICED_PAD <= h["n_slots"]
     assert np.all(h["sub_chunk"] % 16 == 0) and chunks.shape[0] % 16 == 0
     # the run flags, checked by doing what a wave of csrc/spmm_sliced.hip does with them on one number per chunk:
     # two DPP steps inside groups of 4 quads, carries from group to group, the last quad of a run stores / adds
@@ -934,16 +946,17 @@ def test_sliced_graph_host_covers_every_edge_once(n, n_groups, cap, heavy):
     for s, r, c in zip(start, row, clen):
         covered[s:s + c] += 1
         slot_row[s:s + c] = r
-    assert np.all(covered == 1)
+    assert np.all(covered[:h["pad_slot"]] == 1) and np.all(covered[h["pad_slot"]:] == 0)
     live = h["eid"] >= 0
-    assert live.sum() == nnz and np.all(h["val"][~live] == 0) and np.all(h["col16"][~live] == 0)
+    pad_col = n if "col_scale" in h else 0     # a factored graph's padding reads the all-zero source row
+    assert live.sum() == nnz and np.all(h["val"][~live] == 0) and np.all(h["col16"][~live] == pad_col)
     back = np.argsort(eid)  # edge whose keep index is j
     edge_of_slot = back[h["eid"][live]]
     assert np.array_equal(np.sort(edge_of_slot), np.arange(nnz))
     assert np.array_equal(h["col16"][live], col[edge_of_slot].astype(np.uint16))
     assert np.array_equal(h["val"][live], val[edge_of_slot])
     assert np.array_equal(slot_row[live], np.repeat(np.arange(n), lens)[edge_of_slot])
-    plain = sliced_graph_host(rowptr, col, val, None, n_groups, cap)
+    plain = sliced_graph_host(rowptr, col, val, None, n_groups, cap, lane_slots=lane_slots)
     assert np.array_equal(plain["eid"][live], np.arange(nnz))
     sub_row, sub_chunk = h["sub_row"], h["sub_chunk"]
     assert sub_row.size == n_groups * k + 1 and sub_row[0] == 0 and sub_row[-1] == n
@@ -955,7 +968,7 @@ def test_sliced_graph_host_covers_every_edge_once(n, n_groups, cap, heavy):
         assert np.all((rows_of >= sub_row[i]) & (rows_of < sub_row[i + 1]))
     assert sliced_graph_host(rowptr, col, val, None, 1, 1, max_subs=4) is None
     empty = sliced_graph_host(np.zeros(11, dtype=np.int64), col[:0], val[:0], None, 8, 16)
-    assert empty["n_chunks"] == 0 and empty["n_slots"] == 0 and empty["sub_row"][-1] == 10
+    assert empty["n_chunks"] == 0 and empty["pad_slot"] == 0 and empty["n_slots"] == 16 and empty["sub_row"][-1] == 10
     assert np.all(empty["sub_chunk"] == 0)
 
 
@@ -1011,21 +1024,24 @@ def test_factor_edge_values():
 
 
 def test_spread_bank_conflicts_only_reorders_inside_lane_segments():
-    """The LDS bank-conflict permutation of a sliced graph: every 16-slot lane segment keeps its multiset of
-    (column, value, keep index) -- sums are unchanged -- and the simulated conflict ways go down."""
+    """The LDS bank-conflict permutation of a sliced graph: every lane segment (lane_slots slots) keeps its multiset
+    of (column, value, keep index) -- sums are unchanged -- and the simulated conflict ways go down."""
     from beta_recsys_amd.lightgcn import sliced_graph_host, spread_bank_conflicts
     from oracle import lightgcn_numpy as olg
 
     rng = np.random.default_rng(9)
     U, I = 1500, 900
     adj = olg.build_norm_adj(U, I, rng.integers(0, U, 120_000), rng.integers(0, I, 120_000))
-    for factor in (True, False):
-        h = sliced_graph_host(adj.indptr, adj.indices, adj.data, None, 16, 256, factor=factor)
+    for factor, S in ((True, None), (False, 16), (True, 16), (True, 24), (True, 48)):
+        h = sliced_graph_host(adj.indptr, adj.indices, adj.data, None, 16, 256, factor=factor, lane_slots=S)
+        S = h["lane_slots"]
         ref = {k: h[k].copy() for k in ("col16", "val", "eid")}
         before, after = spread_bank_conflicts(h, 16)
         assert after < 0.8 * before and after >= 1.0, (before, after)
-        key_new = np.stack([h["col16"].astype(np.int64), h["eid"].astype(np.int64)], 1).reshape(-1, 16, 2)
-        key_old = np.stack([ref["col16"].astype(np.int64), ref["eid"].astype(np.int64)], 1).reshape(-1, 16, 2)
+        rows_end = h["pad_slot"]     # whole lane segments up to here, then the padding tail (left alone)
+        assert all(np.array_equal(h[k][rows_end:], ref[k][rows_end:]) for k in ref)
+        key_new = np.stack([h["col16"].astype(np.int64), h["eid"].astype(np.int64)], 1)[:rows_end].reshape(-1, S, 2)
+        key_old = np.stack([ref["col16"].astype(np.int64), ref["eid"].astype(np.int64)], 1)[:rows_end].reshape(-1, S, 2)
         order_new = np.lexsort((key_new[:, :, 1], key_new[:, :, 0]), axis=1)
         order_old = np.lexsort((key_old[:, :, 1], key_old[:, :, 0]), axis=1)
         assert np.array_equal(np.take_along_axis(key_new, order_new[:, :, None], 1),

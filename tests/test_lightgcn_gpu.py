@@ -86,26 +86,29 @@ def test_spmm_csr_vs_scipy(hip_device, dim):
     assert np.all(np.abs(y.cpu().numpy() - ref2) <= 64 * EPS32 * (abs(a).astype(np.float64) @ np.abs(x)) + 1e-6)
 
 
-def sliced_graph(rp, col, val, eid, n, nnz, dim, n_groups, factor=True):
+def sliced_graph(rp, col, val, eid, n, nnz, dim, n_groups, factor=True, lane_slots=None):
     """hiprec_sliced_csr of a CSR already on the device, as LightGCN.graph() builds it (+ the arrays it points to)."""
     from beta_recsys_amd import _lib
     from beta_recsys_amd.lightgcn import sliced_graph_device, sliced_graph_host
 
     cap = _lib.load().hiprec_sliced_row_cap(n, dim)
     host = sliced_graph_host(rp.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy(),
-                             None if eid is None else eid.cpu().numpy(), n_groups, cap, factor=factor)
+                             None if eid is None else eid.cpu().numpy(), n_groups, cap, factor=factor,
+                             lane_slots=lane_slots)
     assert host is not None
     sc, hold = sliced_graph_device(host, n, n_groups, cap, "cuda")
     return sc, hold, host
 
 
-@pytest.mark.parametrize("factored", [False, True])
+@pytest.mark.parametrize("lane_slots", [None, 16, 24, 32, 48])   # None: the geometry the host picks for the graph
 @pytest.mark.parametrize("n,dim,width,n_groups", [(700, 64, 4, 16), (9746, 64, 4, 16), (10100, 100, 4, 3),
                                                   (15001, 32, 2, 7), (19000, 8, 2, 1), (500, 6, 2, 40)])
-def test_spmm_sliced_vs_scipy(hip_device, n, dim, width, n_groups, factored):
+def test_spmm_sliced_vs_scipy(hip_device, n, dim, width, n_groups, lane_slots):
     """The column-sliced SpMM (source slice in LDS, rows owned by one workgroup): forward graph and transposed graph
     with the forward keep bytes, heavy and empty rows, every accumulate mode, the layout transposes; general values
-    (the step's stream = dropped values) and rank-one values (stream = dropped columns, scaled source / result)."""
+    (the step's stream = dropped values; lane_slots None) and rank-one values (stream = dropped columns, scaled source
+    / result) at every number of slots per lane the kernel is built for."""
+    factored = lane_slots is not None
     from beta_recsys_amd import _lib
     from beta_recsys_amd.lightgcn import _csr_from_coo
 
@@ -145,12 +148,16 @@ def test_spmm_sliced_vs_scipy(hip_device, n, dim, width, n_groups, factored):
     assert np.array_equal(back.cpu().numpy(), x + 1.0)
     dropped = olg.apply_edge_dropout(a, keep, 0.6)
     for graph, (rowptr, col, val, eid) in (("a", (rp, c, v, None)), ("at", (rpt, ct, vt, eid_t))):
-        sc, hold, host = sliced_graph(rowptr, col, val, eid, n, a.nnz, dim, n_groups)
+        sc, hold, host = sliced_graph(rowptr, col, val, eid, n, a.nnz, dim, n_groups, lane_slots=lane_slots)
         assert ("col_scale" in host) == factored
+        S = host["lane_slots"]
+        assert S == (lane_slots or 16)
         assert np.diff(host["sub_row"]).max() <= lib.hiprec_sliced_row_cap(n, dim)
         lens = np.diff(rowptr.cpu().numpy())
         live_chunks = int((((host["chunks"][:, 1] >> 16) & 0xFF) > 0).sum())  # + empty chunks that pad the subgroups
-        assert live_chunks == int(((lens + 63) // 64).sum()) and host["n_slots"] == int(((lens + 15) // 16 * 16).sum())
+        assert live_chunks == int(((lens + 4 * S - 1) // (4 * S)).sum())
+        assert host["pad_slot"] == int(((lens + S - 1) // S * S).sum())   # then the all-padding tail
+        assert host["pad_slot"] + S <= host["n_slots"] < host["pad_slot"] + S + 16 and host["n_slots"] % 16 == 0
         assert host["n_chunks"] % 16 == 0 and host["n_chunks"] >= live_chunks
         step_edges = torch.full((host["n_slots"],), 9.0, device="cuda")
         _lib.check(lib.hiprec_sliced_drop_values(ctypes.byref(sc), _lib.ptr(kt), _lib.ptr(step_edges), st))

@@ -1,6 +1,7 @@
-"""Same-box A/B of run layouts of the column-sliced SpMM's chunk descriptors (beta-recsys_amd/lightgcn.py:
-SLICED_RUNS) on the LightGCN step of BASELINE configs[4]: python tools/exp_sliced_runs.py carry cut [...]
-Alternates the variants ROUNDS times in one process; prints us per step of every run."""
+"""Same-box A/B of layouts of the column-sliced SpMM's graph (beta-recsys_amd/lightgcn.py) on the LightGCN step of
+BASELINE configs[4]: python tools/exp_sliced_runs.py S16 S24 S32 S48 auto [carry cut]
+S<n> = n slots per lane (hiprec_sliced_csr.lane_slots), auto = the host's choice; carry / cut = SLICED_RUNS at the
+host's choice.  Alternates the variants ROUNDS times in one process; prints us per step of every run."""
 import os
 import sys
 
@@ -12,14 +13,15 @@ import beta_recsys_amd.lightgcn as lg  # noqa: E402
 
 
 def main():
-    variants = sys.argv[1:] or ["carry", "cut"]
+    variants = sys.argv[1:] or ["S16", "S24", "S32", "S48", "auto"]
     rounds = int(os.environ.get("ROUNDS", "3"))
     device = torch.device("cuda:0")
     torch.cuda.set_device(0)
     for r in range(rounds):
         for v in variants:
-            lg.SLICED_RUNS = v
-            args = bench.parse_args(["--workload", "lightgcn", "--steps", "100", "--warmup", "20", "--no-cpu-baseline"])
+            lg.SLICED_RUNS = v if v in ("carry", "cut") else "carry"
+            extra = ["--lane-slots", v[1:]] if v.startswith("S") else []
+            args = bench.parse_args(["--workload", "lightgcn", "--steps", "100", "--warmup", "20", "--no-cpu-baseline"] + extra)
             out = bench.bench_lightgcn(args, device)
             print(f"{v} round {r}: {out['ms_per_step'] * 1e3:.2f} us/step  loss {out['config']['last_loss']:.6f}", flush=True)
 

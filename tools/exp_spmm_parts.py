@@ -35,7 +35,9 @@ def timed(fn, n=200):
 W = lib.hiprec_sliced_width(N, D)
 cap = lib.hiprec_sliced_row_cap(N, D)
 n_groups = 16
-host = sliced_graph_host(rp.cpu().numpy(), cc.cpu().numpy(), vv.cpu().numpy(), None, n_groups, cap, factor=True)
+S = int(sys.argv[1]) if len(sys.argv) > 1 else None   # slots per lane (None: the host's choice)
+host = sliced_graph_host(rp.cpu().numpy(), cc.cpu().numpy(), vv.cpu().numpy(), None, n_groups, cap, factor=True, lane_slots=S)
+print("lane_slots", host["lane_slots"])
 print("bank-conflict ways before / after the slot permutation: %.2f / %.2f" % spread_bank_conflicts(host, n_groups))
 sc, hold = sliced_graph_device(host, N, n_groups, cap, dev)
 xs, ys, accs = (torch.zeros(N * D, device=dev) for _ in range(3))
@@ -48,7 +50,7 @@ train = torch.where(drop, torch.full_like(live, N), live).to(torch.int16)
 zero = torch.full((host["n_slots"],), N, dtype=torch.int16, device=dev)
 seq = (torch.arange(host["n_slots"], device=dev) // 16 % 9000).to(torch.int16)
 streams = {"graph": None, "training (40 % dropped)": train, "all zero row": zero, "conflict-free": seq}
-for exp in (0, 0, 1, 4, 16, 4 | 16):
+for exp in (0, 0, 1, 4, 16, 4 | 16, 32, 4 | 16 | 32):
     os.environ["HIPREC_SLICED_EXP"] = str(exp)
     row = []
     for name, e in streams.items():
