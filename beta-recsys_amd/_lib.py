@@ -89,7 +89,8 @@ class SlicedCsr(Structure):
     """hiprec_sliced_csr (include/hiprec.h)."""
 
     _fields_ = [("chunks", c_void_p), ("col16", c_void_p), ("val", c_void_p), ("eid", c_void_p),
-                ("sub_row", c_void_p), ("sub_chunk", c_void_p), ("row_scale", c_void_p), ("col_scale", c_void_p),
+                ("sub_row", c_void_p), ("sub_chunk", c_void_p), ("spill_row", c_void_p), ("spill_ptr", c_void_p),
+                ("empty_row", c_void_p), ("empty_ptr", c_void_p), ("row_scale", c_void_p), ("col_scale", c_void_p),
                 ("n_rows", c_int64), ("n_slots", c_int64),
                 ("n_groups", c_int32), ("subs_per_group", c_int32), ("n_chunks", c_int32), ("row_cap", c_int32),
                 ("lane_slots", c_int32), ("pad_slot", c_int32)]

@@ -49,6 +49,19 @@ namespace hiprec {
 #define HIPREC_SLICED_EXP(bit) false
 #endif
 
+// In-kernel timestamps (same builds): a first-wave and a last-wave thread of two workgroups note the cycle counter at the
+// phase boundaries of the last launch; hiprec_debug_sliced_stamps reads them back (tools/exp_sliced_stamps.py).
+#ifdef HIPREC_SLICED_DEBUG
+__device__ unsigned long long g_sliced_stamps[4][16];
+#define SLICED_STAMP(k)                                                                                          \
+  do {                                                                                                           \
+    if ((threadIdx.x == 0 || threadIdx.x == 960) && (blockIdx.x == 0 || blockIdx.x == 131) && (k) < 16)          \
+      g_sliced_stamps[(blockIdx.x == 0 ? 0 : 2) + (threadIdx.x == 0 ? 0 : 1)][k] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define SLICED_STAMP(k) do {} while (0)
+#endif
+
 constexpr int kSlicedThreads = 1024;
 constexpr int kSlicedQuads = kSlicedThreads / 4;
 constexpr int64_t kSlicedLds = 160 * 1024 - 64;  // one workgroup's LDS, less the kernel's own few words
@@ -83,7 +96,7 @@ __device__ __forceinline__ SlicedEdges<FACTORED, S> load_sliced_edges(const uint
                                                                       int pad_slot) {
   SlicedEdges<FACTORED, S> e;
   const bool live = q * S < ((d.y >> 16) & 0xFF);
-  const int base = live ? d.x + q * S : pad_slot;  // a multiple of 8 slots: 16-B / 32-B aligned
+  const int base = live ? (d.x & 0x3FFFFF) + q * S : pad_slot;  // a multiple of 8 slots: 16-B / 32-B aligned
   const uint4* pc = reinterpret_cast<const uint4*>((FACTORED ? static_cast<const uint16_t*>(edges) : col16) + base);
 #pragma unroll
   for (int k = 0; k < S / 8; ++k) e.c[k] = pc[k];
@@ -100,6 +113,15 @@ __device__ __forceinline__ SlicedEdges<FACTORED, S> load_sliced_edges(const uint
 // its S LDS reads per lane -- descriptor and edge prefetch, the quad's reduction, the run logic, the store -- costs about
 // as many VALU instructions as 16 slots' address arithmetic and additions do, and at S = 16 the kernel was bound by the
 // VALU (round 6, SQ counters: 59 % VALU busy, LDS 49 %): the host picks S per graph so that typical rows are few chunks.
+//
+// Where a finished row goes (round 6).  Rounds 2-5 summed every row in an LDS accumulator and wrote the accumulators
+// of a SUBGROUP of rows in a flush phase between two workgroup barriers; in-kernel timestamps showed two subgroups'
+// barriers and flushes plus the waves' wait for the slowest one taking 7 k of a pass's 31 k cycles.  Now the last quad
+// of a run that IS its whole row (every row of at most 16 chunks that a window boundary does not cut) writes the row's
+// four values itself, straight to global memory, with the row's factors and the layer sum's old values requested a
+// trip ahead: a window of one-chunk rows stores 256 contiguous bytes.  Only rows that are several runs -- cut by a
+// window boundary, or longer than a window -- still meet in LDS accumulators (`spill` rows, listed per workgroup by the
+// host, index in the descriptor), flushed once at the end together with the rows that have no edges at all.
 template <int W, bool FACTORED, int S>
 __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_sliced_csr a,
                                                                      const void* __restrict__ edges, float scale,
@@ -107,6 +129,7 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
                                                                      float* __restrict__ ys, float* __restrict__ accs,
                                                                      int acc_mode, SlicedFlush fl, int dim) {
   static_assert(S % 8 == 0 && S >= 16 && 4 * S < 256, "slots per lane");
+  SLICED_STAMP(0);
   float* __restrict__ zero_out = fl.zero_out;
   float* __restrict__ final_out = fl.final_out;
   const int final_set = fl.final_set ? 1 : 0;
@@ -117,7 +140,7 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
   const int64_t n_rows = a.n_rows;
   float* s_x = s_mem;                     // [n_rows + 1][W]: slice s of the source, then an all-zero row
-  float* s_y = s_mem + (n_rows + 1) * W;  // [row_cap][W]: accumulators of the current subgroup's rows
+  float* s_y = s_mem + (n_rows + 1) * W;  // [row_cap][W]: accumulators of the workgroup's spill rows
   const uint32_t row_bytes = W * sizeof(float);
   const uint32_t lds_base =
       static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)s_x));
@@ -129,11 +152,12 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
   const int lane = static_cast<int>(threadIdx.x) & 63;
   const int pad_slot = a.pad_slot;
   const int2* __restrict__ chunks = reinterpret_cast<const int2*>(a.chunks);
-  const int sg_begin = g * a.subs_per_group, sg_end = sg_begin + a.subs_per_group;
-  const int c_end = a.sub_chunk[sg_end];  // the block's chunks: sub_chunk[sg_begin] .. c_end
-  auto desc = [&](int c) { return c < c_end ? chunks[c] : int2{0, 0}; };  // {first slot, row | n_slots << 16 | run flags}
-  // The chunk pipeline runs through the block's subgroups without draining: quad k takes chunks k, k + 256, ...
-  // of the block, with its next chunk's edge data and the descriptor after that in flight ahead of the arithmetic.
+  const int c_begin = a.sub_chunk[g], c_end = a.sub_chunk[g + 1];  // the workgroup's chunks
+  const int sp0 = a.spill_ptr[g], n_spill = a.spill_ptr[g + 1] - sp0;
+  const int em0 = a.empty_ptr[g], n_empty = a.empty_ptr[g + 1] - em0;
+  auto desc = [&](int c) { return c < c_end ? chunks[c] : int2{0, 0}; };  // {first slot | spill << 22, row | n_slots << 16 | run flags}
+  // Quad k takes chunks k, k + 256, ... of the workgroup, with its next chunk's edge data and the descriptor after
+  // that in flight ahead of the arithmetic.
   // the slice: every thread's (at most kSlicedFill) 16-byte loads are issued together -- a load-store loop would pay
   // the memory latency once per trip
   const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xs + slice_off);
@@ -144,25 +168,66 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
     const int i = static_cast<int>(threadIdx.x) + k * kSlicedThreads;
     fill[k] = (i < n4 && !HIPREC_SLICED_EXP(16)) ? x4[i] : float4{0.f, 0.f, 0.f, 0.f};
   }
-  int c = a.sub_chunk[sg_begin] + quad;
+  int c = c_begin + quad;
   // d0 / e0: the chunk about to be summed; d1: the one after it (its edge data is requested while e0 is summed)
   int2 d0 = desc(c), d1 = desc(c + kSlicedQuads);
+  SLICED_STAMP(1);
 #pragma unroll
   for (int k = 0; k < kSlicedFill; ++k) {
     const int i = static_cast<int>(threadIdx.x) + k * kSlicedThreads;
     if (i < n4) reinterpret_cast<float4*>(s_x)[i] = fill[k];
   }
+  SLICED_STAMP(2);
   if (static_cast<int>(threadIdx.x) < n_tail) s_x[4 * n4 + threadIdx.x] = xs[slice_off + 4 * n4 + threadIdx.x];
   if (static_cast<int>(threadIdx.x) < W) s_x[n_rows * W + threadIdx.x] = 0.f;
   Edges e0 = load_sliced_edges<FACTORED, S>(a.col16, edges, d0, q, pad_slot);
-  const int n_acc = a.row_cap * W;  // <= kSlicedMaxRowCap * 4 = 2 per thread
-  for (int i = threadIdx.x; i < n_acc; i += kSlicedThreads) s_y[i] = 0.f;
+  for (int i = threadIdx.x; i < n_spill * W; i += kSlicedThreads) s_y[i] = 0.f;
   __syncthreads();
+  SLICED_STAMP(3);
 
-  // One chunk: S random source rows out of the LDS per lane (~2-way bank conflicts after the host's slot
+  // What becomes of component q of row r's sum v: the layer output (times the factors of a factored graph), the layer
+  // sum, or -- the last pass of a propagation -- the finished sum in the row-major result.
+  struct RowIn {  // what emit needs of the row besides its sum, requested before the sum is there
+    float old = 0.f, rs = 1.f, cs = 1.f, fin = 0.f;
+  };
+  auto row_in = [&](int r, int cq) {
+    RowIn in;
+    if (acc_mode == 1) in.old = accs[slice_off + static_cast<int64_t>(r) * W + cq];
+    if constexpr (FACTORED) {
+      in.rs = a.row_scale[r];
+      in.cs = a.col_scale[r];
+    }
+    if (final_out != nullptr && !final_set) in.fin = final_out[static_cast<int64_t>(r) * dim + s * W + cq];
+    return in;
+  };
+  auto emit = [&](int r, int cq, float v, const RowIn& in) {
+    if (HIPREC_SLICED_EXP(4) && v != 1e30f) return;
+    float y = v * scale, y_next = y;
+    if constexpr (FACTORED) {  // row factor now; the next pass wants its source scaled by the column factor
+      y *= in.rs;
+      y_next = y * in.cs;
+    }
+    const int64_t o = slice_off + static_cast<int64_t>(r) * W + cq;
+    if (final_out != nullptr) {  // the result (plus the layer sum so far, acc_mode 1) goes straight to row-major
+      float* dst = final_out + static_cast<int64_t>(r) * dim + s * W + cq;
+      *dst = final_set ? in.old + y : in.fin + (in.old + y);
+    } else {
+      ys[o] = y_next;
+      if (acc_mode == 1) accs[o] = in.old + y;
+      else if (acc_mode == 2) accs[o] = y;
+    }
+    if (zero_out != nullptr) zero_out[o] = 0.f;
+  };
+
+  // One chunk: S random source rows out of the LDS per lane (~1.3-way bank conflicts after the host's slot
   // permutation), summed; the quad's four partial sums folded so that lane q holds component q; the wave's runs of
   // chunks of one row summed; the last quad of a run stores.
-  auto sum_chunk = [&](const Edges& e, const int2 d, int r0) {
+  auto sum_chunk = [&](const Edges& e, const int2 d) {
+    const uint32_t dy = static_cast<uint32_t>(d.y);
+    const int row = static_cast<int>(dy & 0xFFFF);
+    const bool ends = q < W && ((dy >> 27) & 1), direct = ends && ((dy >> 28) & 1);
+    RowIn in;
+    if (direct) in = row_in(row, q);  // (the loads return while the slots are summed)
     const uint32_t* cw = reinterpret_cast<const uint32_t*>(e.c);  // two columns per word
     Vec src[2][4];
     Pair acc[W / 2];  // two floats per register pair: v_pk_add_f32 / v_pk_fma_f32
@@ -212,15 +277,11 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
       mine = q == w ? t : mine;
     }
     // A row's chunks are consecutive, so the quads of a wave that work on one row are neighbours -- and LDS float
-    // atomics are slow (~3 cycles per LANE: with 64 lanes adding into ~5 rows' accumulators the ds_add was 11 of a
-    // pass's 27.5 us, profiles/r03_experiments.md 39).  So the wave sums a row's quads itself: a segmented
-    // inclusive scan over its 16 quads -- two DPP steps inside every 16-lane row, then the total so far carried
-    // from row to row through SGPRs -- and the LAST quad of a run stores: plainly when the run is the whole row,
-    // with an LDS atomic when a 16-chunk window cut the row.  Which quad does what is static (subgroups start on
-    // window boundaries, so a wave's 16 quads always hold one window) and comes with the descriptor:
-    // lightgcn.py _windowed_chunks.  A window of one-chunk rows (the common one once S fits the typical row) skips
-    // all of it.
-    const uint32_t dy = static_cast<uint32_t>(d.y);
+    // atomics are slow (~3 cycles per LANE, profiles/r03_experiments.md 39).  So the wave sums a row's quads itself:
+    // a segmented inclusive scan over its 16 quads -- two DPP steps inside every 16-lane row, then the total so far
+    // carried from row to row through SGPRs -- and the LAST quad of a run stores.  Which quad does what is static (a
+    // wave's 16 quads always hold one window of 16 chunks) and comes with the descriptor: lightgcn.py
+    // _windowed_chunks.  A window of one-chunk rows (the common one once S fits the typical row) skips all of it.
     if (__ballot(((dy >> 24) & 7) != 0) != 0) {
       const int in_row = (dy >> 24) & 3;
       const float o1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0x114, 0xF, 0xF, false));  // row_shr:4
@@ -238,81 +299,43 @@ __global__ __launch_bounds__(kSlicedThreads) void spmm_sliced_kernel(hiprec_slic
         }
       }
     }
-    if (q < W && ((dy >> 27) & 1)) {
-      float* dst = &s_y[(static_cast<int>(dy & 0xFFFF) - r0) * W + q];
-      if ((dy >> 28) & 1) *dst = mine;
-      else lds_add_f32(dst, mine);
-    }
+    if (direct) emit(row, q, mine, in);
+    else if (ends) lds_add_f32(&s_y[((static_cast<uint32_t>(d.x) >> 22) & 0x1FF) * W + q], mine);
   };
 
-  for (int sg = sg_begin; sg < sg_end; ++sg) {
-    const int r0 = a.sub_row[sg], r1 = a.sub_row[sg + 1], c1 = a.sub_chunk[sg + 1];
-    const int n_out = (r1 - r0) * W;
-    const int64_t out0 = slice_off + static_cast<int64_t>(r0) * W;
-    // fetched while the chunks are processed: the layer sum's current values and the rows' two factors (requested
-    // after the barrier they would put an L2 round trip in front of every flush)
-    float old[2] = {0.f, 0.f}, rs[2] = {1.f, 1.f}, cs[2] = {1.f, 1.f};
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int i = static_cast<int>(threadIdx.x) + k * kSlicedThreads;
-      if (i < n_out) {
-        if (acc_mode == 1) old[k] = accs[out0 + i];
-        if constexpr (FACTORED) {
-          const int r = r0 + (W == 4 ? i >> 2 : i >> 1);
-          rs[k] = a.row_scale[r];
-          cs[k] = a.col_scale[r];
-        }
-      }
-    }
-    // two trips per turn of the loop, the edge registers of one filled while the other's are summed: written as a
-    // one-deep rotation the compiler copied every edge register once per trip (25 v_mov of a 16-slot trip's 165)
-    if (HIPREC_SLICED_EXP(32)) c = c1 + quad;
-    while (c < c1) {
-      {
-        const int2 d2 = desc(c + 2 * kSlicedQuads);
-        const Edges e1 = load_sliced_edges<FACTORED, S>(a.col16, edges, d1, q, pad_slot);
-        sum_chunk(e0, d0, r0);
-        c += kSlicedQuads;
-        if (!(c < c1)) {
-          e0 = e1;
-          d0 = d1;
-          d1 = d2;
-          break;
-        }
-        const int2 d3 = desc(c + 2 * kSlicedQuads);
-        e0 = load_sliced_edges<FACTORED, S>(a.col16, edges, d2, q, pad_slot);
-        sum_chunk(e1, d1, r0);
-        c += kSlicedQuads;
-        d0 = d2;
-        d1 = d3;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int i = static_cast<int>(threadIdx.x) + k * kSlicedThreads;
-      if (i < n_out && (!HIPREC_SLICED_EXP(4) || s_y[i] == 1e30f)) {
-        float y = s_y[i] * scale, y_next = y;
-        if constexpr (FACTORED) {  // row factor now; the next pass wants its source scaled by the column factor
-          y *= rs[k];
-          y_next = y * cs[k];
-        }
-        s_y[i] = 0.f;
-        if (final_out != nullptr) {  // the result (plus the layer sum so far, acc_mode 1) goes straight to row-major
-          const int r = r0 + (W == 4 ? i >> 2 : i >> 1);
-          float* dst = final_out + static_cast<int64_t>(r) * dim + s * W + (i & (W - 1));
-          if (final_set) *dst = old[k] + y;
-          else *dst += old[k] + y;
-        } else {
-          ys[out0 + i] = y_next;
-          if (acc_mode == 1) accs[out0 + i] = old[k] + y;
-          else if (acc_mode == 2) accs[out0 + i] = y;
-        }
-        if (zero_out != nullptr) zero_out[out0 + i] = 0.f;
-      }
-    }
-    __syncthreads();
+  // two trips per turn of the loop, the edge registers of one filled while the other's are summed: written as a
+  // one-deep rotation the compiler copied every edge register once per trip (25 v_mov of a 16-slot trip's 165)
+  if (HIPREC_SLICED_EXP(32)) c = c_end + quad;
+  SLICED_STAMP(4);
+  while (c < c_end) {
+    const int2 d2 = desc(c + 2 * kSlicedQuads);
+    const Edges e1 = load_sliced_edges<FACTORED, S>(a.col16, edges, d1, q, pad_slot);
+    sum_chunk(e0, d0);
+    c += kSlicedQuads;
+    if (!(c < c_end)) break;
+    const int2 d3 = desc(c + 2 * kSlicedQuads);
+    e0 = load_sliced_edges<FACTORED, S>(a.col16, edges, d2, q, pad_slot);
+    sum_chunk(e1, d1);
+    c += kSlicedQuads;
+    d0 = d2;
+    d1 = d3;
   }
+  SLICED_STAMP(5);
+  // the rows that are not one run, and the rows without edges: threads 0 .. (n_spill + n_empty) W take one value each
+  const int n_late = (n_spill + n_empty) * W;
+  if (n_late == 0) {
+    SLICED_STAMP(15);
+    return;
+  }
+  __syncthreads();
+  SLICED_STAMP(6);
+  for (int i = threadIdx.x; i < n_late; i += kSlicedThreads) {
+    const int k = W == 4 ? i >> 2 : i >> 1, cq = i & (W - 1);
+    const int r = k < n_spill ? a.spill_row[sp0 + k] : a.empty_row[em0 + k - n_spill];
+    const RowIn in = row_in(r, cq);
+    emit(r, cq, k < n_spill ? s_y[i] : 0.f, in);
+  }
+  SLICED_STAMP(15);
 }
 
 // out[slot] = keep[eid[slot]] ? val[slot] : 0 (padding slots: eid < 0, value 0) -- the dropped edge values of a
@@ -490,8 +513,10 @@ static int launch_sliced_as(const hiprec_sliced_csr* a, const void* edges, float
 
 int launch_spmm_sliced(const hiprec_sliced_csr* a, const void* edges, float scale, const float* xs, float* ys,
                        float* accs, int acc_mode, int dim, int W, hipStream_t st, SlicedFlush fl) {
-  HIPREC_REQUIRE(a && a->sub_row && a->sub_chunk && a->n_rows > 0 && a->n_groups > 0 && a->subs_per_group > 0,
-                 "bad sliced graph");
+  HIPREC_REQUIRE(a && a->sub_row && a->sub_chunk && a->n_rows > 0 && a->n_groups > 0 && a->subs_per_group == 1,
+                 "bad sliced graph (one range of chunks per workgroup: subs_per_group == 1)");
+  HIPREC_REQUIRE(a->spill_ptr && a->empty_ptr && a->spill_row && a->empty_row, "sliced graph without spill / empty row lists");
+  HIPREC_REQUIRE(a->n_slots < (1ll << 22), "%lld slots: the descriptors hold 22 bits of first slot", (long long)a->n_slots);
   HIPREC_REQUIRE(a->n_slots > 0 && a->col16 && a->val && (a->n_chunks == 0 || a->chunks),
                  "sliced graph has NULL chunks / col16 / val");
   HIPREC_REQUIRE(a->n_slots % 16 == 0, "n_slots %lld is not a multiple of 16", (long long)a->n_slots);
@@ -591,6 +616,14 @@ int launch_from_sliced(const float* xs, int64_t n_rows, int dim, int W, float* y
 }  // namespace hiprec
 
 using namespace hiprec;
+
+#ifdef HIPREC_SLICED_DEBUG
+extern "C" int hiprec_debug_sliced_stamps(unsigned long long* out64) {
+  HIPREC_TRY(hipDeviceSynchronize());
+  HIPREC_TRY(hipMemcpyFromSymbol(out64, HIP_SYMBOL(hiprec::g_sliced_stamps), sizeof(unsigned long long) * 64));
+  return 0;
+}
+#endif
 
 extern "C" int32_t hiprec_sliced_width(int64_t n_rows, int32_t dim) { return sliced_width(n_rows, dim); }
 

@@ -126,9 +126,6 @@ def factor_edge_values(rowptr, col, val, rel_tol=2e-6, max_rounds=256):
     return r32, c32
 
 
-SLICED_RUNS = "carry"   # experiment knob (tools/exp_sliced_runs.py): "cut" ends every run at its 16-lane row
-
-
 def _windowed_chunks(start, chunk_row, clen, within, per_row, sub_chunk):
     """Chunk descriptors as csrc/spmm_sliced.hip wants them.  A wave of the kernel works on a WINDOW of 16
     consecutive chunks (one per quad of lanes) and sums the chunks of one row inside the window itself before anything
@@ -158,8 +155,6 @@ def _windowed_chunks(start, chunk_row, clen, within, per_row, sub_chunk):
     prev_real = np.concatenate([[False], real[:-1]])
     prev_row = np.concatenate([[-1], row2[:-1]])
     new_run = ((idx & 15) == 0) | (row2 != prev_row) | ~real | ~prev_real
-    if SLICED_RUNS == "cut":
-        new_run |= (idx & 3) == 0
     run_start = np.maximum.accumulate(np.where(new_run, idx, 0))
     behind, qir = idx - run_start, idx & 3
     last = np.concatenate([new_run[1:], [True]]) & real
@@ -171,15 +166,18 @@ def _windowed_chunks(start, chunk_row, clen, within, per_row, sub_chunk):
     return np.stack([start2, desc], axis=1).astype(np.int32), new_sub
 
 
-def sliced_graph_host(rowptr, col, val, eid, n_groups, row_cap, max_subs=64, factor=True, lane_slots=None):
+def sliced_graph_host(rowptr, col, val, eid, n_groups, row_cap, factor=True, lane_slots=None):
     """hiprec_sliced_csr (include/hiprec.h) of a CSR given as numpy arrays; eid = keep-byte index of every edge
     (None = the edge number itself).  factor: look for the rank-one form of the values (factor_edge_values); the
     graph is then stored with row_scale / col_scale and its padding slots point at the zero row n.  lane_slots: S
-    (None: choose_lane_slots).
+    (None: choose_lane_slots).  Workgroup g of a slice takes the chunks of rows sub_row[g] .. sub_row[g + 1] (about
+    equal chunk counts).  A row whose chunks are one run of a window is written by the kernel directly; the others are
+    the workgroup's SPILL rows (summed in LDS: at most row_cap of them) or its EMPTY rows.
 
-    Returns dict(col16 uint16, val float32, eid int32 [n_slots]; chunks int32 [n_chunks, 2]; sub_row, sub_chunk
-    int32 [n_groups * k + 1]; subs_per_group k; n_chunks; n_slots; lane_slots; pad_slot; optionally row_scale,
-    col_scale float32 [n]) or None when no k <= max_subs keeps every subgroup within row_cap rows."""
+    Returns dict(col16 uint16, val float32, eid int32 [n_slots]; chunks int32 [n_chunks, 2]; sub_row, sub_chunk,
+    spill_ptr, empty_ptr int32 [n_groups + 1]; spill_row, empty_row int32; subs_per_group 1; n_chunks; n_slots;
+    lane_slots; pad_slot; optionally row_scale, col_scale float32 [n]) or None when a workgroup would have more than
+    row_cap spill rows or the graph more than 2^22 slots."""
     rowptr = np.asarray(rowptr, dtype=np.int64)
     n, nnz = rowptr.size - 1, int(rowptr[-1])
     scales = factor_edge_values(rowptr, col, val) if factor else None
@@ -192,6 +190,8 @@ def sliced_graph_host(rowptr, col, val, eid, n_groups, row_cap, max_subs=64, fac
     slotptr = np.concatenate([[0], np.cumsum(padded)])
     pad_slot = int(slotptr[-1])                      # rows' slots, then the all-padding tail lanes without slots read
     n_slots = (pad_slot + S + 15) // 16 * 16
+    if n_slots >= 1 << 22:                           # a descriptor holds 22 bits of first slot
+        return None
     edge_row = np.repeat(np.arange(n, dtype=np.int64), lens)
     slot = np.arange(nnz, dtype=np.int64) + (slotptr[:-1] - rowptr[:-1])[edge_row]
     col16 = np.full(n_slots, n if scales is not None else 0, np.uint16)
@@ -206,22 +206,33 @@ def sliced_graph_host(rowptr, col, val, eid, n_groups, row_cap, max_subs=64, fac
     within = np.arange(n_chunks, dtype=np.int64) - first[chunk_row]
     start = slotptr[chunk_row] + chunk * within
     clen = np.minimum(chunk, padded[chunk_row] - chunk * within)
-    for k in range(1, max_subs + 1):
-        n_sub = n_groups * k
-        target = np.minimum((np.arange(n_sub + 1) * n_chunks) // n_sub, max(n_chunks - 1, 0))
-        sub_row = chunk_row[target] if n_chunks else np.zeros(n_sub + 1, dtype=np.int64)
-        sub_row[0], sub_row[-1] = 0, n
-        sub_row = np.maximum.accumulate(sub_row)
-        sub_chunk = np.append(first, n_chunks)[sub_row]  # a subgroup starts at the first chunk of its first row
-        if np.diff(sub_row).max() <= row_cap:
-            chunks, sub_chunk = _windowed_chunks(start, chunk_row, clen, within, per_row, sub_chunk)
-            out = {"col16": col16, "val": valp, "eid": eidp, "chunks": chunks, "sub_row": sub_row.astype(np.int32),
-                   "sub_chunk": sub_chunk.astype(np.int32), "subs_per_group": k, "n_chunks": int(chunks.shape[0]),
-                   "n_slots": n_slots, "lane_slots": S, "pad_slot": pad_slot}
-            if scales is not None:
-                out["row_scale"], out["col_scale"] = scales
-            return out
-    return None
+    target = np.minimum((np.arange(n_groups + 1) * n_chunks) // n_groups, max(n_chunks - 1, 0))
+    sub_row = chunk_row[target] if n_chunks else np.zeros(n_groups + 1, dtype=np.int64)
+    sub_row[0], sub_row[-1] = 0, n
+    sub_row = np.maximum.accumulate(sub_row)
+    sub_chunk = np.append(first, n_chunks)[sub_row]  # a workgroup starts at the first chunk of its first row
+    chunks, sub_chunk = _windowed_chunks(start, chunk_row, clen, within, per_row, sub_chunk)
+    # spill rows: the rows with a run that is not the whole row (its last chunk has bit 27 but not bit 28)
+    flags = chunks[:, 1].astype(np.int64)
+    part_end = ((flags >> 27) & 1).astype(bool) & ~((flags >> 28) & 1).astype(bool)
+    spill_rows = np.unique(flags[part_end] & 0xFFFF)               # sorted, so grouped by workgroup
+    spill_ptr = np.searchsorted(spill_rows, sub_row)
+    if spill_rows.size and np.diff(spill_ptr).max() > row_cap:
+        return None
+    idx_of = np.zeros(n + 1, dtype=np.int64)                        # index inside its workgroup's list
+    group_of = np.searchsorted(sub_row, spill_rows, side="right") - 1
+    idx_of[spill_rows] = np.arange(spill_rows.size) - spill_ptr[group_of]
+    chunks[:, 0] |= np.where(part_end, idx_of[flags & 0xFFFF] << 22, 0).astype(np.int32)
+    empty_rows = np.nonzero(per_row == 0)[0]
+    out = {"col16": col16, "val": valp, "eid": eidp, "chunks": chunks, "sub_row": sub_row.astype(np.int32),
+           "sub_chunk": sub_chunk.astype(np.int32), "subs_per_group": 1, "n_chunks": int(chunks.shape[0]),
+           "spill_row": spill_rows.astype(np.int32), "spill_ptr": spill_ptr.astype(np.int32),
+           "empty_row": empty_rows.astype(np.int32),
+           "empty_ptr": np.searchsorted(empty_rows, sub_row).astype(np.int32),
+           "n_slots": n_slots, "lane_slots": S, "pad_slot": pad_slot}
+    if scales is not None:
+        out["row_scale"], out["col_scale"] = scales
+    return out
 
 
 # quads (of a wave's 16) whose lanes one ds_read_b128 serves in the same LDS cycle (MI355X_MICROARCH, LDS table:
@@ -240,7 +251,7 @@ def spread_bank_conflicts(host, n_groups, quads_per_block=256):
     col16, n_chunks = host["col16"], host["n_chunks"]
     if n_chunks == 0:
         return 1.0, 1.0
-    start = chunks[:, 0].astype(np.int64)
+    start = (chunks[:, 0] & 0x3FFFFF).astype(np.int64)
     clen = ((chunks[:, 1] >> 16) & 0xFF).astype(np.int64)
     block_first = host["sub_chunk"][np.arange(n_groups + 1) * k].astype(np.int64)  # chunks of block g
     block_of = np.searchsorted(block_first, np.arange(n_chunks), side="right") - 1
@@ -310,9 +321,13 @@ def sliced_graph_device(host, n_rows, n_groups, row_cap, device):
     """(_lib.SlicedCsr, the device tensors it points to) of sliced_graph_host's arrays."""
     hold = {k: torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else v).to(device)
             for k, v in host.items() if isinstance(v, np.ndarray)}
+    for name in ("spill_row", "empty_row", "chunks"):   # (an empty tensor has no address; the kernel reads none of it)
+        if hold[name].numel() == 0:
+            hold[name] = torch.zeros(2, dtype=torch.int32, device=device)
     sc = _lib.SlicedCsr(hold["chunks"].data_ptr(), hold["col16"].data_ptr(), hold["val"].data_ptr(),
                         hold["eid"].data_ptr(), hold["sub_row"].data_ptr(), hold["sub_chunk"].data_ptr(),
-                        _lib.ptr(hold.get("row_scale")), _lib.ptr(hold.get("col_scale")), n_rows,
+                        hold["spill_row"].data_ptr(), hold["spill_ptr"].data_ptr(), hold["empty_row"].data_ptr(),
+                        hold["empty_ptr"].data_ptr(), _lib.ptr(hold.get("row_scale")), _lib.ptr(hold.get("col_scale")), n_rows,
                         host["n_slots"], n_groups, host["subs_per_group"], host["n_chunks"], row_cap,
                         host["lane_slots"], host["pad_slot"])
     return sc, hold

@@ -912,6 +912,10 @@ typedef struct hiprec_sliced_csr {
   const int32_t* eid;
   const int32_t* sub_row;
   const int32_t* sub_chunk;
+  const int32_t* spill_row;  /* rows that are summed in LDS (several runs), workgroup g's: spill_ptr[g] .. spill_ptr[g + 1] */
+  const int32_t* spill_ptr;  /* [n_groups + 1] */
+  const int32_t* empty_row;  /* rows without edges (written as zeros), workgroup g's: empty_ptr[g] .. empty_ptr[g + 1] */
+  const int32_t* empty_ptr;  /* [n_groups + 1] */
   const float* row_scale; /* both NULL, or the FACTORED form: val of edge (i, j) == row_scale[i] * col_scale[j]; */
   const float* col_scale; /* padding slots then hold column n_rows (an all-zero source row), not 0           */
   int64_t n_rows, n_slots;

@@ -900,7 +900,9 @@ def test_sliced_graph_host_covers_every_edge_once(n, n_groups, cap, heavy, lane_
         assert "col_scale" in h
     assert h is not None and h["lane_slots"] == lane_slots
     chunks, k = h["chunks"], h["subs_per_group"]
-    start, row, clen = chunks[:, 0], chunks[:, 1] & 0xFFFF, (chunks[:, 1] >> 16) & 0xFF
+    assert k == 1
+    start, row, clen = chunks[:, 0] & 0x3FFFFF, chunks[:, 1] & 0xFFFF, (chunks[:, 1] >> 16) & 0xFF
+    spill_idx = (chunks[:, 0].astype(np.int64) >> 22) & 0x1FF
     real = clen > 0  # subgroups are padded with empty chunks to a multiple of 16
     assert np.all(clen[real] >= SLICED_PAD) and np.all(clen <= SLICED_CHUNK) and np.all(np.diff(row) >= 0)
     assert np.all(start % SLICED_PAD == 0) and np.all(clen % SLICED_PAD == 0) and h["n_slots"] % 16 == 0
@@ -912,6 +914,7 @@ def test_sliced_graph_host_covers_every_edge_once(n, n_groups, cap, heavy, lane_
     in_row, carry, last, whole = (flags >> 24) & 3, (flags >> 26) & 1, (flags >> 27) & 1, (flags >> 28) & 1
     value = rng.integers(1, 1000, chunks.shape[0]).astype(np.int64) * real
     acc, plain_rows = np.zeros(n, dtype=np.int64), []
+    group_of_chunk = np.searchsorted(h["sub_chunk"], np.arange(chunks.shape[0]), side="right") - 1
     for w0 in range(0, chunks.shape[0], 16):
         x = value[w0:w0 + 16].copy()
         x1 = x.copy()
@@ -932,14 +935,28 @@ def test_sliced_graph_host_covers_every_edge_once(n, n_groups, cap, heavy, lane_
             if last[w0 + j]:
                 assert real[w0 + j]
                 acc[row[w0 + j]] += x2[j]
-                if whole[w0 + j]:
+                if whole[w0 + j]:     # the kernel writes this row itself
                     plain_rows.append(row[w0 + j])
+                else:                 # ... and sums this one in the workgroup's LDS accumulator `spill_idx`
+                    gq = group_of_chunk[w0 + j]
+                    assert spill_idx[w0 + j] < h["spill_ptr"][gq + 1] - h["spill_ptr"][gq] <= cap
+                    assert h["spill_row"][h["spill_ptr"][gq] + spill_idx[w0 + j]] == row[w0 + j]
     want = np.zeros(n, dtype=np.int64)
     np.add.at(want, row[real], value[real])
     assert np.array_equal(acc, want), "the runs do not add up to the rows"
     assert len(set(plain_rows)) == len(plain_rows), "a row stored plainly twice"
     stores = np.bincount(row[last == 1], minlength=n)
     assert np.all(stores[np.array(plain_rows, dtype=np.int64)] == 1), "a plainly stored row has other contributions"
+    # every row is written exactly once: by its one run, as a spill row of its workgroup, or as an empty row
+    written = np.concatenate([np.array(plain_rows, dtype=np.int64), h["spill_row"], h["empty_row"]])
+    assert np.array_equal(np.sort(written), np.arange(n))
+    assert np.array_equal(h["empty_row"], np.nonzero(lens == 0)[0])
+    for name in ("spill", "empty"):
+        rows_of, ptr = h[name + "_row"], h[name + "_ptr"]
+        assert ptr.size == n_groups + 1 and ptr[0] == 0 and ptr[-1] == rows_of.size
+        for gq in range(n_groups):
+            mine = rows_of[ptr[gq]:ptr[gq + 1]]
+            assert np.all((mine >= h["sub_row"][gq]) & (mine < h["sub_row"][gq + 1]))
     start, row, clen = start[real], row[real], clen[real]
     covered = np.zeros(h["n_slots"], dtype=np.int32)
     slot_row = np.full(h["n_slots"], -1)
@@ -961,12 +978,13 @@ def test_sliced_graph_host_covers_every_edge_once(n, n_groups, cap, heavy, lane_
     sub_row, sub_chunk = h["sub_row"], h["sub_chunk"]
     assert sub_row.size == n_groups * k + 1 and sub_row[0] == 0 and sub_row[-1] == n
     assert sub_chunk[0] == 0 and sub_chunk[-1] == h["n_chunks"] == chunks.shape[0]
-    assert np.all(np.diff(sub_row) >= 0) and np.diff(sub_row).max() <= cap
+    assert np.all(np.diff(sub_row) >= 0)
     all_rows = chunks[:, 1] & 0xFFFF
     for i in range(n_groups * k):
         rows_of = all_rows[sub_chunk[i]:sub_chunk[i + 1]]
         assert np.all((rows_of >= sub_row[i]) & (rows_of < sub_row[i + 1]))
-    assert sliced_graph_host(rowptr, col, val, None, 1, 1, max_subs=4) is None
+    if heavy:   # the heavy row alone is several windows: a spill row, and so are the rows the window boundaries cut
+        assert sliced_graph_host(rowptr, col, val, None, 1, 1, lane_slots=lane_slots) is None
     empty = sliced_graph_host(np.zeros(11, dtype=np.int64), col[:0], val[:0], None, 8, 16)
     assert empty["n_chunks"] == 0 and empty["pad_slot"] == 0 and empty["n_slots"] == 16 and empty["sub_row"][-1] == 10
     assert np.all(empty["sub_chunk"] == 0)

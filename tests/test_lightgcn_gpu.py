@@ -152,7 +152,7 @@ def test_spmm_sliced_vs_scipy(hip_device, n, dim, width, n_groups, lane_slots):
         assert ("col_scale" in host) == factored
         S = host["lane_slots"]
         assert S == (lane_slots or 16)
-        assert np.diff(host["sub_row"]).max() <= lib.hiprec_sliced_row_cap(n, dim)
+        assert np.diff(host["spill_ptr"]).max() <= lib.hiprec_sliced_row_cap(n, dim)
         lens = np.diff(rowptr.cpu().numpy())
         live_chunks = int((((host["chunks"][:, 1] >> 16) & 0xFF) > 0).sum())  # + empty chunks that pad the subgroups
         assert live_chunks == int(((lens + 4 * S - 1) // (4 * S)).sum())

@@ -1,7 +1,8 @@
 """Same-box A/B of layouts of the column-sliced SpMM's graph (beta-recsys_amd/lightgcn.py) on the LightGCN step of
-BASELINE configs[4]: python tools/exp_sliced_runs.py S16 S24 S32 S48 auto [carry cut]
-S<n> = n slots per lane (hiprec_sliced_csr.lane_slots), auto = the host's choice; carry / cut = SLICED_RUNS at the
-host's choice.  Alternates the variants ROUNDS times in one process; prints us per step of every run."""
+BASELINE configs[4]: python tools/exp_sliced_runs.py S16 S24 S32 S48 auto
+S<n> = n slots per lane (hiprec_sliced_csr.lane_slots), auto = the host's choice.  Alternates the variants ROUNDS
+times in one process; prints us per step of every run.  (Round 6 also tried ending every run at its 16-lane row --
+LDS atomics instead of the carries from row to row: 136.4 against 130.0 us per step, profiles/r06_experiments.md.)"""
 import os
 import sys
 
@@ -9,7 +10,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-import beta_recsys_amd.lightgcn as lg  # noqa: E402
 
 
 def main():
@@ -19,7 +19,6 @@ def main():
     torch.cuda.set_device(0)
     for r in range(rounds):
         for v in variants:
-            lg.SLICED_RUNS = v if v in ("carry", "cut") else "carry"
             extra = ["--lane-slots", v[1:]] if v.startswith("S") else []
             args = bench.parse_args(["--workload", "lightgcn", "--steps", "100", "--warmup", "20", "--no-cpu-baseline"] + extra)
             out = bench.bench_lightgcn(args, device)
