@@ -30,7 +30,7 @@ lib.hiprec_debug_ncf_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 assert lib.hiprec_debug_ncf_stamps(out) == 0
 names = {0: "start", 1: "indices in LDS", 2: "gathered rows in LDS", 3: "layer 1", 4: "layer 2", 5: "layer 3", 8: "head",
          9: "d w_out, partials", 17: " (barrier)", 18: " (chain 3 gemm)", 19: " (next layer's loads issued)",
-         20: " (chain 3 epilogue)", 10: "chain layer 3", 11: "chain layer 2", 12: "chain layer 1", 16: "GMF scatter, end"}
+         20: " (chain 3 epilogue)", 10: "chain layer 3", 11: "chain layer 2", 12: "chain layer 1", 13: "partials, d w_out rows", 14: "(non-chained: act stores)", 16: "last pass of the tower-input atomics, end"}
 for blk in range(2):
     st = list(out[blk * 24:(blk + 1) * 24])
     print(f"block {'0' if blk == 0 else '131'}: total {st[16] - st[0]} ticks")
