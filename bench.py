@@ -285,8 +285,6 @@ def bench_ncf(args, device, world=1, rank=0, dist_on=False):
                          optimizer="adam", lr=1e-3, batch_size=B, model="ncf_end",
                          mlp_config={"n_layers": L}, gmf_config={}),
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
-    if getattr(args, "ncf_grad_lists", None) is not None:
-        cfg["model"]["grad_lists"] = args.ncf_grad_lists == "on"
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
         if dist_on and args.multi_gpu == "sharded":
@@ -1405,9 +1403,6 @@ def parse_args(argv=None):
                          "shared rows collect device-scope atomics (csrc/mf_owned.hip); "
                          "rows = gradient kernel into a dense buffer + touched-rows pass (round 1)")
     ap.add_argument("--emb-dim", type=int, default=32, help="ncf: 32 (tower 256-128-64-32, primary) or 64")
-    ap.add_argument("--ncf-grad-lists", default=None, choices=["on", "off"],
-                    help="ncf: embedding-row gradients as per-sample rows + per-row contribution lists (on, the engine's "
-                         "default) or as float atomics into the dense gradient (off)")
     ap.add_argument("--lane-slots", type=int, default=None, choices=[16, 24, 32, 48],
                     help="lightgcn: slots per lane of the column-sliced SpMM's chunks (default: the host's choice for the graph)")
     ap.add_argument("--multi-gpu", default="auto", choices=["auto", "replicated", "sharded"],

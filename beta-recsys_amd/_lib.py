@@ -57,7 +57,6 @@ class Stats(Structure):
 
 
 NCF_MAX_LAYERS = 8
-NCF_LIST_CAP = 8      # HIPREC_NCF_LIST_CAP
 
 
 class NcfPlan(Structure):
@@ -75,8 +74,7 @@ class NcfPlan(Structure):
            ("max_batch", c_int64),
            ("act", c_void_p * (NCF_MAX_LAYERS + 1)), ("dact", c_void_p * (NCF_MAX_LAYERS + 1)),
            ("mf", c_void_p), ("dmf", c_void_p), ("scores", c_void_p),
-           ("keep", c_void_p * NCF_MAX_LAYERS), ("keep_scale", c_float), ("list_cap", c_int32),
-           ("row_cnt", c_void_p), ("row_list", c_void_p)]
+           ("keep", c_void_p * NCF_MAX_LAYERS), ("keep_scale", c_float), ("_pad", c_int32)]
     )
 
 

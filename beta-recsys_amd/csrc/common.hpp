@@ -45,8 +45,7 @@ int allow_dynamic_lds(std::initializer_list<const void*> kernels, size_t bytes, 
 // workspace clip_sumsq_kernel filled (n_clip per-block sums behind two result slots), nullptr = no clip.
 int opt_dense_step_impl(int kind, float* w, float* g, float* m, float* v, int64_t n, double lr, double beta1,
                         double beta2, double eps, hiprec_stats* stats, const void* scratch, int64_t scalar_index,
-                        double* clip_ws, int n_clip, float max_norm, void* stream, int32_t* zero_buf = nullptr,
-                        int64_t zero_n = 0);   // zero_buf: zero_n counters the launch also clears (not with a clip)
+                        double* clip_ws, int n_clip, float max_norm, void* stream);
 
 #define HIPREC_TRY(expr)                                   \
   do {                                                     \

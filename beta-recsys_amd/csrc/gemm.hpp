@@ -46,32 +46,12 @@ struct GemmProblem {
 // A dense optimizer sweep that rides in the grouped launch as its first n_blocks blocks: elements [0, 4 * n4) of the
 // flat buffers (parameters whose gradient is already complete when the grouped launch starts -- the embedding tables
 // of an NCF step -- while the GEMM problems of the same grid still produce the other gradients).  n_blocks = 0: none.
-// lists (cnt != NULL; the NCF step, hiprec_ncf_plan.row_cnt): the gradient of a table row is not read from g but summed
-// from the per-sample rows its contribution list names -- element c of row r of table t is
-//   sum over k < min(cnt[row0[t] + r], cap) of src[t][list[(row0[t] + r) * cap + k] * src_ld[t] + c]
-// (+ g, which is then cleared, only when the row was met more than cap times: the excess went through atomics).
-// The tables tile [0, 4 * n4) of the flat buffers in the order t = 0 .. n_tables - 1 and every table has blocks of
-// its own (first_block + tbl_block[t] ...), so that everything about a table is uniform in a block.
-constexpr int kSweepTables = 4;
-struct SweepLists {
-  const int32_t* cnt;
-  const int32_t* list;
-  int cap, n_tables;
-  int64_t begin4[kSweepTables];   // first 16-byte vector of table t in the flat buffers
-  int64_t n4[kSweepTables];       // its vectors
-  int dim4[kSweepTables];         // vectors per row
-  int row0[kSweepTables];         // its first row's counter
-  int tbl_block[kSweepTables + 1];  // its first block, relative to the sweep's first block
-  const float* src[kSweepTables];
-  int src_ld[kSweepTables];
-};
 struct SweepArgs {
   float *w, *g, *m, *v;
   int64_t n4;
   int kind, n_blocks, first_block;
   OptScalars s;
   const hiprec_stats* stats;
-  SweepLists lists;
 };
 
 constexpr int kMaxGroup = 16;

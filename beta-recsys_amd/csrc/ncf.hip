@@ -245,88 +245,11 @@ __device__ __forceinline__ void sweep_blocks(const SweepArgs& a) {
   }
 }
 
-// The same sweep over tables whose gradients are contribution lists (SweepLists, gemm.hpp): a thread's vector of w, m
-// and v is requested first, with the row's count and its 8 sample ids, then the listed samples' vectors -- two
-// dependent round trips where the dense form has one, no read and no clearing write of g.
-template <int KIND>
-__device__ __forceinline__ void sweep_list_blocks(const SweepArgs& a) {
-  float step_size, bc2_sqrt;
-  step_scalars<KIND>(a.s, a.stats, &step_size, &bc2_sqrt);
-  const SweepLists& L = a.lists;
-  const int sb = static_cast<int>(blockIdx.x) - a.first_block;
-  int t = 0;
-#pragma unroll
-  for (int k = 1; k < kSweepTables; ++k)
-    if (k < L.n_tables && sb >= L.tbl_block[k]) t = k;
-  const int64_t begin4 = L.begin4[t], n4 = L.n4[t];
-  const uint32_t dim4 = static_cast<uint32_t>(L.dim4[t]);
-  const int row0 = L.row0[t], ld = L.src_ld[t], cap = L.cap;
-  const float* __restrict__ src = L.src[t];
-  const int64_t stride = static_cast<int64_t>(L.tbl_block[t + 1] - L.tbl_block[t]) * kBlock;
-  float4* w4 = reinterpret_cast<float4*>(a.w) + begin4;
-  float4* g4 = reinterpret_cast<float4*>(a.g) + begin4;
-  float4* m4 = reinterpret_cast<float4*>(a.m) + begin4;
-  float4* v4 = reinterpret_cast<float4*>(a.v) + begin4;
-  for (int64_t i = static_cast<int64_t>(sb - L.tbl_block[t]) * kBlock + threadIdx.x; i < n4; i += stride) {
-    float4 wv = w4[i];
-    float4 mv = make_float4(0, 0, 0, 0), vv = make_float4(0, 0, 0, 0);
-    if constexpr (KIND == HIPREC_OPT_ADAM) mv = m4[i];
-    if constexpr (KIND != HIPREC_OPT_SGD) vv = v4[i];
-    const uint32_t r = static_cast<uint32_t>(i) / dim4, c4 = static_cast<uint32_t>(i) - r * dim4;  // n4 < 2^32: host
-    const int row = row0 + static_cast<int>(r);
-    // the row's count and its list (stale beyond the count) are requested together: two dependent round trips, not three
-    const int4* ids4 = reinterpret_cast<const int4*>(L.list + static_cast<int64_t>(row) * cap);
-    const int cnt = L.cnt[row];
-    const int4 i0 = ids4[0], i1 = ids4[1];
-    float4 gv = make_float4(0, 0, 0, 0);
-    if (cnt > 0) {
-      const int n = cnt < cap ? cnt : cap;
-      const int ids[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
-      float4 x[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        x[k] = make_float4(0, 0, 0, 0);
-        if (k < n) x[k] = *reinterpret_cast<const float4*>(src + static_cast<int64_t>(ids[k]) * ld + 4 * c4);
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (k < n) {
-          gv.x += x[k].x;
-          gv.y += x[k].y;
-          gv.z += x[k].z;
-          gv.w += x[k].w;
-        }
-      }
-      if (cnt > cap) {  // the excess of a row met more than cap times arrived through atomics
-        const float4 o = g4[i];
-        gv.x += o.x;
-        gv.y += o.y;
-        gv.z += o.z;
-        gv.w += o.w;
-        g4[i] = make_float4(0, 0, 0, 0);
-      }
-    }
-    opt_update<KIND>(wv.x, gv.x, mv.x, vv.x, a.s, step_size, bc2_sqrt);
-    opt_update<KIND>(wv.y, gv.y, mv.y, vv.y, a.s, step_size, bc2_sqrt);
-    opt_update<KIND>(wv.z, gv.z, mv.z, vv.z, a.s, step_size, bc2_sqrt);
-    opt_update<KIND>(wv.w, gv.w, mv.w, vv.w, a.s, step_size, bc2_sqrt);
-    w4[i] = wv;
-    if constexpr (KIND == HIPREC_OPT_ADAM) m4[i] = mv;
-    if constexpr (KIND != HIPREC_OPT_SGD) v4[i] = vv;
-  }
-}
-
 __global__ __launch_bounds__(kBlock) void gemm_group_kernel(GemmGroup g) {
   __shared__ float As[kTM][kTK + 1];
   __shared__ float Bs[kTK][kTN + 1];
   const int sweep_lo = g.sweep.first_block;
   if (static_cast<int>(blockIdx.x) >= sweep_lo && static_cast<int>(blockIdx.x) < sweep_lo + g.sweep.n_blocks) {
-    if (g.sweep.lists.cnt != nullptr) {
-      if (g.sweep.kind == HIPREC_OPT_ADAM) sweep_list_blocks<HIPREC_OPT_ADAM>(g.sweep);
-      else if (g.sweep.kind == HIPREC_OPT_RMSPROP) sweep_list_blocks<HIPREC_OPT_RMSPROP>(g.sweep);
-      else sweep_list_blocks<HIPREC_OPT_SGD>(g.sweep);
-      return;
-    }
     if (g.sweep.kind == HIPREC_OPT_ADAM) sweep_blocks<HIPREC_OPT_ADAM>(g.sweep);
     else if (g.sweep.kind == HIPREC_OPT_RMSPROP) sweep_blocks<HIPREC_OPT_RMSPROP>(g.sweep);
     else sweep_blocks<HIPREC_OPT_SGD>(g.sweep);
@@ -866,16 +789,13 @@ __device__ unsigned long long g_ncf_stamps[2][24];
 // waves' phases only moved the cost (gfx950 counts loads and stores in one vmcnt: a wave that has stores in flight waits
 // for them at its next weight chunk).  This wave loads no weights and computes nothing: it keeps the compute waves'
 // barrier sequence and, behind each barrier that completes a tile in LDS (which nobody overwrites), copies that tile
-// out -- act_l during layer l + 1, dZ_l during the chain's next layer and, with contribution lists, the samples' GMF-row
-// gradients and the layer-0 input gradient's finished passes.  Plain stores only: atomics issued from here hold up the
-// compute waves' weight loads behind them in the CU's memory pipeline.
+// out -- act_l during layer l + 1, dZ_l during the chain's next layer.  Plain stores only: atomics issued from here hold
+// up the compute waves' weight loads behind them in the CU's memory pipeline.
 // Its barriers MUST mirror ncf_fused_forward_kernel<TRAIN, DROP, BWD = true> one for one.
 __device__ __forceinline__ void fused_store_wave(const hiprec_ncf_plan& p, const float* lds_raw, int64_t m0,
-                                                 int64_t batch, int dz_shift, const float* d0, const float* s_mf,
-                                                 const float* s_um, const float* s_im, const long long* s_u,
-                                                 const long long* s_i) {
+                                                 int64_t batch, int dz_shift) {
   const int lane = threadIdx.x & 63;
-  const int E = p.dim_mf, K0 = 2 * p.dim_mlp, L = p.n_layers, ld0 = K0 + 1;
+  const int K0 = 2 * p.dim_mlp, L = p.n_layers, ld0 = K0 + 1;
   const int n_rows = static_cast<int>(batch - m0 < kFR ? batch - m0 : kFR);
   // dst[m0 + r][0 .. N) = src[r][0 .. N), r < n_rows.  Few instructions per store, the wave shares its SIMD with two
   // compute waves: eight rows' values of a column read from LDS together, then stored through a buffer resource over
@@ -916,44 +836,10 @@ __device__ __forceinline__ void fused_store_wave(const hiprec_ncf_plan& p, const
   lds_barrier();
   const int nH = p.layer_out[L - 1];
   store_tile(p.dact[L], lds_raw + off + dz_shift, nH, nH + 1);
-  const bool lists = p.list_cap > 0;
-  if (lists && E > 0) {
-    // the GMF rows' gradients of the samples: d user_mf = dmf * item_mf -> dmf[b], the other way round -> mf[b] (dmf
-    // sits where the product was, the gather left the two factors in s_um / s_im: nothing here waits for memory)
-    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(p.dmf + m0 * E, 0, n_rows * E * 4, 0x00027000);
-    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(p.mf + m0 * E, 0, n_rows * E * 4, 0x00027000);
-    if (lane < E) {
-#pragma unroll 4
-      for (int r = 0; r < kFR; ++r) {
-        const float d = s_mf[r * kFLdE + lane];
-        const float gu = d * s_im[r * kFLdE + lane], gi = d * s_um[r * kFLdE + lane];
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, gu), ru, lane * 4, r * E * 4, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, gi), ri, lane * 4, r * E * 4, 0);
-      }
-    }
-  }
   for (int l = L - 1; l >= 0; --l) {
     const int nin = p.layer_in[l];
     for (int n_off = 0; n_off < nin; n_off += kFMaxN) {
       lds_barrier();
-      if (lists && l == 0 && n_off + kFMaxN < nin) {
-        // the columns of the tower input's gradient this pass finished (the last pass's: the compute waves)
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(p.dact[0] + m0 * K0 + n_off, 0, n_rows * K0 * 4, 0x00027000);
-        for (int c0 = 0; c0 < kFMaxN; c0 += kWave) {
-          const float* sp = d0 + n_off + c0 + lane;
-#pragma unroll
-          for (int r0 = 0; r0 < kFR; r0 += 8) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = sp[(r0 + j) * ld0];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v[j]), rs, (c0 + lane) * 4,
-                                                    (r0 + j) * K0 * 4, 0);
-          }
-        }
-      }
     }
     if (l > 0) {
       off -= kFR * (nin + 1);   // act_l; dZ_l lies dz_shift behind it
@@ -1015,11 +901,9 @@ __global__ __launch_bounds__(kFThreads + (BWD ? kWave : 0)) void ncf_fused_forwa
   // up to 256 wide: the two halves of the block take 8 rows each) or 16 rows; all its loads are requested before
   // anything is stored (one round trip for the whole tile instead of one per row)
   __shared__ long long s_u[kFR], s_i[kFR];
-  __shared__ unsigned char s_over[2][kFR];   // lists: the sample's user / item row had no slot left (-> atomics)
-  int slot_u = 0, slot_i = 0;                // lists: lane r of the last compute wave, sample r
   if constexpr (BWD) {
     if (wave == kFWaves) {  // the store wave (fused_store_wave): this kernel's barriers, none of its arithmetic
-      fused_store_wave(p, lds_raw, m0, batch, dz_shift, d0, s_mf, s_um, s_im, s_u, s_i);
+      fused_store_wave(p, lds_raw, m0, batch, dz_shift);
       return;
     }
   }
@@ -1039,14 +923,6 @@ __global__ __launch_bounds__(kFThreads + (BWD ? kWave : 0)) void ncf_fused_forwa
     }
     s_u[lane] = u;
     s_i[lane] = it;
-    // contribution lists (hiprec_ncf_plan.row_cnt): the sample takes a slot of each of its two rows now -- the
-    // answers travel under the gather's round trip and are looked at in the block's last phase
-    if constexpr (BWD) {
-      if (p.list_cap > 0 && u >= 0) {
-        slot_u = atomicAdd(p.row_cnt + u, 1);
-        slot_i = atomicAdd(p.row_cnt + p.n_users + it, 1);
-      }
-    }
   }
   // Loads that depend on nothing the block computes go next, off its serial chain: layer 0's first weight chunks,
   // this lane's bias element of the first pass, the head's weights and targets.
@@ -1331,21 +1207,6 @@ __global__ __launch_bounds__(kFThreads + (BWD ? kWave : 0)) void ncf_fused_forwa
   }
 
   // ---- the block's only stores: one sweep, rows by wave, 256-byte row segments -------------------------------------
-  const bool lists = BWD && p.list_cap > 0;   // block-uniform
-  if constexpr (BWD) {
-    if (lists && wave == kFWaves - 1 && lane < kFR) {
-      const long long u = s_u[lane], it = s_i[lane];
-      bool ou = false, oi = false;
-      if (u >= 0) {
-        ou = slot_u >= p.list_cap;
-        oi = slot_i >= p.list_cap;
-        if (!ou) p.row_list[u * p.list_cap + slot_u] = static_cast<int>(m0 + lane);
-        if (!oi) p.row_list[(p.n_users + it) * p.list_cap + slot_i] = static_cast<int>(m0 + lane);
-      }
-      s_over[0][lane] = ou;
-      s_over[1][lane] = oi;
-    }
-  }
   if constexpr (TRAIN) {
     publish_partials<kFWaves>(loss_w, 0.f, gb_w, inv_batch, scratch);  // (barrier inside: s_gw is complete after it)
     lds_barrier();
@@ -1382,38 +1243,30 @@ __global__ __launch_bounds__(kFThreads + (BWD ? kWave : 0)) void ncf_fused_forwa
   }
   NCF_STAMP(14);
   if constexpr (BWD) {
-    // The embedding rows' gradients.  tower input = [user_mlp row | item_mlp row], 256-byte runs of one row; GMF rows:
+    // The embedding rows' gradients: tower input = [user_mlp row | item_mlp row], 256-byte runs of one row; GMF rows:
     // d user_mf = dmf * item_mf and the other way round (dmf sits where the product was, the factors in s_um / s_im).
-    //   lists   every sample's rows leave as plain rows of the workspace (dact[0] | dmf | mf) that the tables' sweep
-    //           finds through the rows' lists: the store wave has sent the GMF rows and the layer-0 chain's earlier
-    //           passes, here go the last pass's columns -- and, through atomics into the dense gradient, the rows of
-    //           samples that found no slot (a row met more than list_cap times in the batch)
-    //   else    float atomics into the dense gradient, 5 120 per block: one L2 operation per element (~300 G/s over
-    //           the chip, 4.5 us of this launch), and no wave can hide them -- issued earlier they hold up the weight
-    //           loads behind them in the CU's memory pipeline (the store wave tried: chain layer 1 9.4 k -> 18.6 k cycles)
-    const int c_last = (K0 - 1) / kFMaxN * kFMaxN;
+    // 5 120 float atomics per block, one L2 operation per element (~300 G/s over the chip: 4.5 us of this launch), and
+    // no wave can hide them -- issued earlier, by the store wave, they hold up the weight loads behind them in the
+    // CU's memory pipeline (chain layer 1: 9.4 k -> 18.6 k cycles).  What replaces them -- every sample's rows as plain
+    // rows of the workspace + per-row contribution lists that the tables' sweep walks -- saves 2 us here and costs 3.7 in
+    // the sweep (profiles/r06_experiments.md 75).
 #pragma unroll
     for (int j = 0; j < kFR / kFWaves; ++j) {
       const int r = wave + j * kFWaves;
       const long long u = s_u[r], it = s_i[r];
       if (m0 + r >= batch || u < 0) continue;
-      const bool ou = !lists || s_over[0][r], oi = !lists || s_over[1][r];
       for (int c = lane; c < K0; c += kWave) {
         const float v = d0[r * ld0 + c];
-        if (lists && c >= c_last) p.dact[0][(m0 + r) * K0 + c] = v;
         if (v != 0.f) {
-          if (c < Dm) {
-            if (ou) atomic_add_f32(p.g_user_mlp + u * Dm + c, v);
-          } else if (oi) {
-            atomic_add_f32(p.g_item_mlp + it * Dm + (c - Dm), v);
-          }
+          if (c < Dm) atomic_add_f32(p.g_user_mlp + u * Dm + c, v);
+          else atomic_add_f32(p.g_item_mlp + it * Dm + (c - Dm), v);
         }
       }
-      if (lane < E && (ou || oi)) {
+      if (lane < E) {
         const float d = s_mf[r * kFLdE + lane];
         if (d != 0.f) {
-          if (ou) atomic_add_f32(p.g_user_mf + u * E + lane, d * s_im[r * kFLdE + lane]);
-          if (oi) atomic_add_f32(p.g_item_mf + it * E + lane, d * s_um[r * kFLdE + lane]);
+          atomic_add_f32(p.g_user_mf + u * E + lane, d * s_im[r * kFLdE + lane]);
+          atomic_add_f32(p.g_item_mf + it * E + lane, d * s_um[r * kFLdE + lane]);
         }
       }
     }
@@ -1602,7 +1455,7 @@ static int fused_attrs() {
 static int forward(const hiprec_ncf_plan* p, const int64_t* users, const int64_t* items,
                    int64_t batch, hiprec_stats* stats, hipStream_t st, bool* scored,
                    const float* ratings = nullptr, float inv_batch = 0.f, Scratch* scratch = nullptr,
-                   bool* chained = nullptr, float* gw_ws = nullptr, bool lists = false) {
+                   bool* chained = nullptr, float* gw_ws = nullptr) {
   // chained (training only): if given and the fused launch is taken, it also runs the tower's input-gradient chain
   // and the embedding scatter (*chained = true); the caller then only owes the weight / bias gradients
   *scored = false;
@@ -1616,14 +1469,12 @@ static int forward(const hiprec_ncf_plan* p, const int64_t* users, const int64_t
     bool drop = false;
     for (int l = 0; l < p->n_layers; ++l) drop = drop || p->keep[l] != nullptr;
     if (chain) {
-      hiprec_ncf_plan q = *p;
-      if (!lists) q.list_cap = 0;   // the launch takes the contribution lists only when the caller's sweep reads them
       if (drop)
         ncf_fused_forward_kernel<true, true, true><<<grid, kFThreads + kWave, lds, st>>>(
-            q, users, items, ratings, batch, inv_batch, stats, scratch, gw_ws);
+            *p, users, items, ratings, batch, inv_batch, stats, scratch, gw_ws);
       else
         ncf_fused_forward_kernel<true, false, true><<<grid, kFThreads + kWave, lds, st>>>(
-            q, users, items, ratings, batch, inv_batch, stats, scratch, gw_ws);
+            *p, users, items, ratings, batch, inv_batch, stats, scratch, gw_ws);
       *chained = true;
     } else if (ratings && drop)
       ncf_fused_forward_kernel<true, true><<<grid, kFThreads, lds, st>>>(
@@ -1729,23 +1580,11 @@ static int ncf_grad_impl(const hiprec_ncf_plan* plan, const int64_t* users, cons
   // is the work space, the grouped launch adds the rows up.  (A batch too small for its dact[0] to hold them: atomics.)
   const int nV_head = p->layer_out[p->n_layers > 0 ? p->n_layers - 1 : 0] + p->dim_mf;
   const int64_t n_tiles = (batch + kFR - 1) / kFR;
-  // Contribution lists (SweepLists, gemm.hpp) when this call's grouped launch carries the tables' sweep that reads
-  // them -- i.e. when the forward below is going to chain (forward()'s own conditions).  The tower input's gradient
-  // then does have a use for dact[0] (a row per sample), and the partial rows of d affine_output.weight go to act[L],
-  // which a chained launch never writes.
-  const bool lists = sweep && sweep->n_blocks > 0 && sweep->lists.cnt != nullptr && fuse_bwd && !split_bwd &&
-                     fusable(p, true) && fusable(p) && n_tiles <= kMaxBlocks;
   float* gw_ws = (p->dim_mlp > 0 && n_tiles * nV_head <= batch * 2 * p->dim_mlp) ? p->dact[0] : nullptr;
-  if (lists)
-    gw_ws = n_tiles * nV_head <= batch * p->layer_out[p->n_layers - 1] ? p->act[p->n_layers] : nullptr;
   bool scored = false, chained = false;
   if (int rc = forward(p, users, items, batch, stats, st, &scored, ratings, inv_batch,
-                       static_cast<Scratch*>(scratch), fuse_bwd && !split_bwd ? &chained : nullptr, gw_ws, lists))
+                       static_cast<Scratch*>(scratch), fuse_bwd && !split_bwd ? &chained : nullptr, gw_ws))
     return rc;
-  if (lists && !chained) {
-    set_error("internal: contribution lists without the chained launch");
-    return HIPREC_E_BADARG;
-  }
   // not chained onto the forward (batch beyond its limit, "split"): the chain's own launch has narrower limits
   const bool bwd_two_launches = fuse_bwd && (chained || fusable_narrow(p));
   if (!scored) {
@@ -1780,7 +1619,6 @@ static int ncf_grad_impl(const hiprec_ncf_plan* plan, const int64_t* users, cons
       g.p[g.n++] = make_colsum(gw_ws, static_cast<int>(n_tiles), nV_head, nV_head, p->g_out_w);
     if (sweep && sweep->n_blocks > 0) {
       g.sweep = *sweep;
-      if (!lists) g.sweep.lists.cnt = nullptr;
       *swept = true;
     }
     return launch_group(g, st);
@@ -1823,62 +1661,6 @@ extern "C" int hiprec_ncf_grad(const hiprec_ncf_plan* plan, const int64_t* users
                        nullptr);
 }
 
-// The tables of `plan` as SweepLists of the sweep `sw` (its blocks re-dealt, a range per table), or nothing (lists.cnt
-// stays NULL) when the plan has no lists or its tables do not tile the first table_floats elements of the flat buffers
-// the way the lists' sweep assumes.
-static void sweep_lists_of(const hiprec_ncf_plan* p, const float* w_flat, const float* g_flat, int64_t table_floats,
-                           int64_t batch, SweepArgs* sw) {
-  if (p->list_cap != HIPREC_NCF_LIST_CAP || !p->row_cnt || !p->row_list) return;
-  if (p->n_users + p->n_items >= (int64_t{1} << 31) || batch >= (int64_t{1} << 31)) return;
-  struct T { const float *w, *g, *src; int64_t rows; int dim, row0, ld; };
-  T t[kSweepTables];
-  int n = 0;
-  const int Dm = p->dim_mlp, E = p->dim_mf;
-  if (Dm > 0) {
-    if (!p->dact[0]) return;
-    t[n++] = T{p->user_mlp, p->g_user_mlp, p->dact[0], p->n_users, Dm, 0, 2 * Dm};
-    t[n++] = T{p->item_mlp, p->g_item_mlp, p->dact[0] + Dm, p->n_items, Dm, static_cast<int>(p->n_users), 2 * Dm};
-  }
-  if (E > 0) {
-    if (!p->dmf || !p->mf) return;
-    t[n++] = T{p->user_mf, p->g_user_mf, p->dmf, p->n_users, E, 0, E};
-    t[n++] = T{p->item_mf, p->g_item_mf, p->mf, p->n_items, E, static_cast<int>(p->n_users), E};
-  }
-  std::sort(t, t + n, [](const T& a, const T& b) { return a.w < b.w; });
-  const float* at = w_flat;
-  SweepLists L{};
-  int64_t blocks = 0;
-  for (int k = 0; k < n; ++k) {
-    const int64_t floats = t[k].rows * t[k].dim;
-    if (!t[k].w || t[k].w != at || t[k].g != g_flat + (t[k].w - w_flat) || (t[k].dim & 3) || floats >= (int64_t{1} << 33) ||
-        (reinterpret_cast<uintptr_t>(t[k].src) & 15))
-      return;
-    L.begin4[k] = (t[k].w - w_flat) >> 2;
-    L.n4[k] = floats >> 2;
-    L.dim4[k] = t[k].dim >> 2;
-    L.row0[k] = t[k].row0;
-    L.src[k] = t[k].src;
-    L.src_ld[k] = t[k].ld;
-    blocks += (L.n4[k] + kBlock - 1) / kBlock;
-    at += floats;
-  }
-  if (n == 0 || at != w_flat + table_floats) return;
-  // a vector per thread, a range of blocks per table; beyond the cap every table keeps its share
-  const double scale = blocks > HIPREC_SWEEP_CAP ? static_cast<double>(HIPREC_SWEEP_CAP) / blocks : 1.0;
-  int first = 0;
-  for (int k = 0; k < n; ++k) {
-    L.tbl_block[k] = first;
-    first += std::max<int>(1, static_cast<int>(((L.n4[k] + kBlock - 1) / kBlock) * scale));
-  }
-  for (int k = n; k <= kSweepTables; ++k) L.tbl_block[k] = first;
-  L.cnt = p->row_cnt;
-  L.list = p->row_list;
-  L.cap = p->list_cap;
-  L.n_tables = n;
-  sw->lists = L;
-  sw->n_blocks = first;
-}
-
 // hiprec_ncf_grad + optimizer.step() (ncf.py:100-120) as ONE call.  The flat buffers hold [tables | tower | head];
 // the first table_floats elements (a multiple of 4) are the embedding tables, whose gradients are complete after
 // the forward + chain launch: their share of the dense sweep -- 97 % of the parameters at ncf_default.json's shape --
@@ -1911,18 +1693,14 @@ extern "C" int hiprec_ncf_step(const hiprec_ncf_plan* plan, const int64_t* users
                       static_cast<float>(1.0 - beta2), static_cast<float>(eps)};
     sw.stats = stats;
   }
-  if (sw.n_blocks > 0 && plan) sweep_lists_of(plan, w_flat, g_flat, table_floats, batch, &sw);
-  const bool with_lists = sw.lists.cnt != nullptr;
   bool swept = false;
   if (int rc = ncf_grad_impl(plan, users, items, ratings, batch, inv_batch, stats, scratch, scratch_bytes, stream, &sw,
                              &swept))
     return rc;
   const int64_t done = swept ? table_floats : 0;
-  // (the tail launch also returns the rows' counters to zero: every reader of them has finished by then)
-  return opt_dense_step_impl(kind, w_flat + done, g_flat + done, m_flat ? m_flat + done : nullptr,
-                             v_flat ? v_flat + done : nullptr, n_flat - done, lr, beta1, beta2, eps, stats, scratch,
-                             scalar_index >= 0 ? scalar_index - done : -1, nullptr, 0, 0.f, stream,
-                             with_lists ? plan->row_cnt : nullptr, with_lists ? plan->n_users + plan->n_items : 0);
+  return hiprec_opt_dense_step(kind, w_flat + done, g_flat + done, m_flat ? m_flat + done : nullptr,
+                               v_flat ? v_flat + done : nullptr, n_flat - done, lr, beta1, beta2, eps, stats, scratch,
+                               scalar_index >= 0 ? scalar_index - done : -1, stream);
 }
 
 #ifdef HIPREC_NCF_DEBUG

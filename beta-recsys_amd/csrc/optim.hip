@@ -28,8 +28,7 @@ __global__ __launch_bounds__(kBlock) void opt_dense_kernel(float* __restrict__ w
                                                            OptScalars s, hiprec_stats* stats,
                                                            const Scratch* scratch,
                                                            int64_t scalar_index, double* clip_ws = nullptr,
-                                                           int n_clip = 0, float max_norm = 0.f,
-                                                           int32_t* zero_buf = nullptr, int64_t zero_n = 0) {
+                                                           int n_clip = 0, float max_norm = 0.f) {
   float step_size, bc2_sqrt;
   step_scalars<KIND>(s, stats, &step_size, &bc2_sqrt);
   float coef = 1.f;
@@ -101,8 +100,6 @@ __global__ __launch_bounds__(kBlock) void opt_dense_kernel(float* __restrict__ w
   for (int64_t i = (n4 << 2) + tid; i < n; i += stride) {  // scalar tail (< 4 elements)
     if (i != skip1) scalar_update(i, 0.f);
   }
-  // a caller's counters that this launch returns to zero (the NCF step's contribution counts, csrc/ncf.hip)
-  for (int64_t i = tid; i < zero_n; i += stride) zero_buf[i] = 0;
   if (blockIdx.x == 0 && scratch) {
     const float gb_part = finalize_partials(stats, scratch);
     if (threadIdx.x == 0 && deferred) {
@@ -123,8 +120,7 @@ using namespace hiprec;
 namespace hiprec {
 int opt_dense_step_impl(int kind, float* w, float* g, float* m, float* v, int64_t n, double lr, double beta1,
                         double beta2, double eps, hiprec_stats* stats, const void* scratch, int64_t scalar_index,
-                        double* clip_ws, int n_clip, float max_norm, void* stream, int32_t* zero_buf,
-                        int64_t zero_n) {
+                        double* clip_ws, int n_clip, float max_norm, void* stream) {
   HIPREC_REQUIRE(w && g && stats, "NULL w/g/stats");
   HIPREC_REQUIRE(n >= 0, "negative n");
   HIPREC_REQUIRE((reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
@@ -147,8 +143,7 @@ int opt_dense_step_impl(int kind, float* w, float* g, float* m, float* v, int64_
       opt_dense_kernel<KIND, true><<<grid, kBlock, 0, st>>>(w, g, m, v, n, s, stats, sc, scalar_index, clip_ws,    \
                                                             n_clip, max_norm);                                    \
     else                                                                                                           \
-      opt_dense_kernel<KIND><<<grid, kBlock, 0, st>>>(w, g, m, v, n, s, stats, sc, scalar_index, nullptr, 0, 0.f,  \
-                                                      zero_buf, zero_n);                                          \
+      opt_dense_kernel<KIND><<<grid, kBlock, 0, st>>>(w, g, m, v, n, s, stats, sc, scalar_index);                  \
   } while (0)
   switch (kind) {
     case HIPREC_OPT_SGD:

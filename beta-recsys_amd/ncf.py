@@ -154,11 +154,6 @@ class _NcfBase(_FlatModel):
         ws["mf"] = torch.empty(batch, max(self.dim_mf, 1), device=dev)
         ws["dmf"] = torch.empty(batch, max(self.dim_mf, 1), device=dev)
         ws["scores"] = torch.empty(batch, device=dev)
-        # contribution lists of the training step (hiprec_ncf_plan.row_cnt / row_list): one counter per user and per
-        # item, all zero between steps, and list_cap sample ids per row
-        rows = self.n_users + self.n_items
-        ws["row_cnt"] = torch.zeros(rows, dtype=torch.int32, device=dev)
-        ws["row_list"] = torch.empty(rows * _lib.NCF_LIST_CAP, dtype=torch.int32, device=dev)
         self._ws = ws
         self._plan_cache = None
         return ws
@@ -201,10 +196,6 @@ class _NcfBase(_FlatModel):
             p.dact[l] = ws["dact"][l].data_ptr()
         p.mf, p.dmf, p.scores = ws["mf"].data_ptr(), ws["dmf"].data_ptr(), ws["scores"].data_ptr()
         p.keep_scale = 1.0
-        if g is not None and (self.config["grad_lists"] if "grad_lists" in self.config else True):
-            # hiprec_ncf_step: embedding-row gradients as per-sample rows + per-row lists instead of float atomics
-            p.list_cap = _lib.NCF_LIST_CAP
-            p.row_cnt, p.row_list = ws["row_cnt"].data_ptr(), ws["row_list"].data_ptr()
         if len(self._plan_cache) > 4:
             self._plan_cache.clear()
         self._plan_cache[key] = p

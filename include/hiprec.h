@@ -825,18 +825,8 @@ typedef struct hiprec_ncf_plan {
    * (the fused tower kernel has no mask input); act[l] then holds the input AFTER its Dropout. */
   const uint8_t* keep[HIPREC_NCF_MAX_LAYERS];
   float keep_scale;
-  /* Contribution lists of hiprec_ncf_step (optional; list_cap = 0 / NULL: the embedding-row gradients are float
-   * atomics into the g_* tables).  With them the chained launch stores every sample's embedding-row gradients as
-   * plain rows of the workspace (dact[0], dmf, mf), takes a slot of each of its two rows (row_cnt: one counter per
-   * user, then one per item, ALL ZERO between steps -- the step leaves them so) and notes its sample id in
-   * row_list[row * list_cap + slot]; the tables' optimizer sweep sums a row's listed samples instead of reading a
-   * dense gradient.  A row met more than list_cap times in a batch sends the excess through the atomics as before.
-   * list_cap must be HIPREC_NCF_LIST_CAP. */
-  int32_t list_cap;
-  int32_t* row_cnt;  /* [n_users + n_items] */
-  int32_t* row_list; /* [(n_users + n_items) * list_cap] */
+  int32_t _pad;
 } hiprec_ncf_plan;
-#define HIPREC_NCF_LIST_CAP 8
 
 size_t hiprec_ncf_plan_bytes(void); /* sizeof(hiprec_ncf_plan), for binding-layout checks */
 
