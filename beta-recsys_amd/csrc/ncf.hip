@@ -607,6 +607,12 @@ constexpr int kFWaves = 8;                 // one wave per 16 output columns of 
                                            // of 32 columns a 32-k chunk took ~1800 cycles for 512 cycles of MFMA)
 constexpr int kFThreads = kFWaves * kWave; // 512
 constexpr int kFK = 32;                    // k-chunk of the weight tiles (64: same step time)
+constexpr int kFPre = 3;                   // weight chunks a wave keeps in flight (8 VGPRs each; the kernel has 95 of
+                                           // 168).  r06, same box, us per step at emb 32 / 64: 2 chunks 47.8 / 95.6,
+                                           // 3: 47.0 / 94.8, 5: 48.2 / 96.8, 8: 49.9 / 101.4 -- more requests in flight
+                                           // queue up in front of the L2s.  Every block walks k in the same order on
+                                           // purpose: with each block starting at chunk blockIdx % n_chunks (no two
+                                           // neighbours asking for the same lines at the same time) 48.8 / 96.6
 constexpr int kFMaxIn = 512;               // widest tower input (2 * dim_mlp): emb_dim 64's 512-256-128-64 tower fits
 constexpr int kFMaxN = 128;                // output columns of one pass (8 waves x 16)
 constexpr int kFMaxW = 256;                // widest layer output (two passes)
@@ -668,7 +674,7 @@ struct FusedGemm {  // forward: W = nn.Linear.weight [N][K] row-major, out = in 
                       // the global_load saddr form)
   bool ok;
   int n_chunks;
-  float4 w[3][2];
+  float4 w[kFPre][2];
 
   __device__ __forceinline__ void fetch(float4 (&d)[2], int t) {
     const float* src = base + t * kFK;  // uniform
@@ -684,8 +690,9 @@ struct FusedGemm {  // forward: W = nn.Linear.weight [N][K] row-major, out = in 
     lane_off = static_cast<uint32_t>((ok ? wn * 16 + (lane & 15) : 0) * K + 8 * (lane >> 4)) * 4u;
     n_chunks = K / kFK;
     fetch(w[0], 0);
-    if (n_chunks > 1) fetch(w[1], 1);
-    if (n_chunks > 2) fetch(w[2], 2);
+#pragma unroll
+    for (int k = 1; k < kFPre; ++k)
+      if (n_chunks > k) fetch(w[k], k);
   }
   __device__ __forceinline__ void run(f32x4& acc, const float* in, int ld_in, float*) {
     const int lane = threadIdx.x & 63;
@@ -701,12 +708,13 @@ struct FusedGemm {  // forward: W = nn.Linear.weight [N][K] row-major, out = in 
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
-      if (t + 3 < n_chunks) fetch(b4, t + 3);
+      if (t + kFPre < n_chunks) fetch(b4, t + kFPre);
     };
-    for (int t = 0; t < n_chunks; t += 3) {
+    for (int t = 0; t < n_chunks; t += kFPre) {
       chunk(w[0], t);
-      if (t + 1 < n_chunks) chunk(w[1], t + 1);
-      if (t + 2 < n_chunks) chunk(w[2], t + 2);
+#pragma unroll
+      for (int k = 1; k < kFPre; ++k)
+        if (t + k < n_chunks) chunk(w[k], t + k);
     }
   }
 };
@@ -724,7 +732,7 @@ struct FusedGemmNN {  // input gradients: W [K][ldw] row-major as it lies in mem
   bool ok;
   int n_chunks, ldw4;  // row pitch in bytes
 
-  float w[3][8];
+  float w[kFPre][8];
 
   __device__ __forceinline__ void fetch(float (&d)[8], int t) {
     if (!ok) return;  // scalar branch
@@ -743,8 +751,9 @@ struct FusedGemmNN {  // input gradients: W [K][ldw] row-major as it lies in mem
     lane_off = static_cast<uint32_t>(8 * (lane >> 4) * ldw_ + (ok ? wn * 16 + (lane & 15) : 0)) * 4u;
     n_chunks = K / kFK;
     fetch(w[0], 0);
-    if (n_chunks > 1) fetch(w[1], 1);
-    if (n_chunks > 2) fetch(w[2], 2);
+#pragma unroll
+    for (int k = 1; k < kFPre; ++k)
+      if (n_chunks > k) fetch(w[k], k);
   }
   __device__ __forceinline__ void run(f32x4& acc, const float* in, int ld_in, float*) {
     const int lane = threadIdx.x & 63;
@@ -759,12 +768,13 @@ struct FusedGemmNN {  // input gradients: W [K][ldw] row-major as it lies in mem
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
-      if (t + 3 < n_chunks) fetch(b, t + 3);
+      if (t + kFPre < n_chunks) fetch(b, t + kFPre);
     };
-    for (int t = 0; t < n_chunks; t += 3) {
+    for (int t = 0; t < n_chunks; t += kFPre) {
       chunk(w[0], t);
-      if (t + 1 < n_chunks) chunk(w[1], t + 1);
-      if (t + 2 < n_chunks) chunk(w[2], t + 2);
+#pragma unroll
+      for (int k = 1; k < kFPre; ++k)
+        if (t + k < n_chunks) chunk(w[k], t + k);
     }
   }
 };
