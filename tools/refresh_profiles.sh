@@ -1,9 +1,9 @@
-# Refresh the judged evidence on a GPU box:  [EV_GROUPS="mf c4 ..."] bash tools/refresh_profiles.sh [round tag, default r05]
+# Refresh the judged evidence on a GPU box:  [EV_GROUPS="mf c4 ..."] bash tools/refresh_profiles.sh [round tag, default r06]
 # Per evidence group (__graft_entry__.EVIDENCE_GROUPS: the sources a workload's kernels are built from): rocprofv3
 # kernel-trace stats, FETCH_SIZE / WRITE_SIZE passes (their own runs), then the bench JSON lines -- all under
 # gpurun_out/<tag>/; tools/collect_profiles.py copies the summaries into profiles/ and stamps every group with the
 # sha256 of the files it was measured with.  A group whose sources did not change need not be measured again.
-TAG=${1:-r05}
+TAG=${1:-r06}
 EV_GROUPS=${EV_GROUPS:-"mf c4 sharded ncf lightgcn ngcf siblings"}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -133,4 +133,6 @@ siblings)
 esac
 done
 collect
+# (the merge back from the GPU box is capped: the per-dispatch traces of the long runs stay there, the stats are what is judged)
+find $OUT -name "*kernel_trace.csv" -size +1M -delete
 ls $OUT | head -120
