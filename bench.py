@@ -375,8 +375,6 @@ def bench_mf_c4shard(args, device, full=False):
                          lr=LR, batch_size=Bc, loss="bpr", sgd_mode=args.sgd_mode, dense_opt=args.dense_opt,
                          lazy_grad=args.lazy_grad),
            "system": {"run_dir": "/tmp/hiprec_bench_runs"}}
-    if getattr(args, "lazy_epoch_flush", None) is not None:
-        cfg["model"]["lazy_epoch_flush"] = args.lazy_epoch_flush == "on"
     torch.manual_seed(2020)
     with contextlib.redirect_stdout(io.StringIO()):
         eng = hp.MFEngine(cfg)
@@ -1418,9 +1416,6 @@ def parse_args(argv=None):
                     help="mf-c4 / mf-c4shard: sample = 50-step epochs of uniformly drawn users (the whole table's epoch "
                          "meets 28 %% of them); full = every user and item row occurs in every epoch (the lazy "
                          "optimizers then replay the whole table's zero-gradient steps)")
-    ap.add_argument("--lazy-epoch-flush", default=None, choices=["on", "off"],
-                    help="mf-c4 / mf-c4shard with the exact lazy optimizers: end every epoch with a flush of all lagging "
-                         "rows (on, the engine's default) or let them lag into the next epoch (off)")
     ap.add_argument("--dense-opt", default="auto", choices=["auto", "lazy", "sweep"],
                     help="mf-c4 (sharded) with Adam / RMSprop: exact lazy replay of the step's rows (csrc/lazy_opt.hip) "
                          "or the dense sweep of the whole shard every step")

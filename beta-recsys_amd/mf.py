@@ -590,10 +590,6 @@ class MFEngine(ModelEngine):
 
     _lazy_capable = True    # (the data-parallel replicas always sweep: their gradient is dense after the all-reduce)
 
-    def _epoch_flush(self):
-        """Does an epoch of lazy steps end with a flush?  ``lazy_epoch_flush`` (default True)."""
-        return bool(self.config["model"].get("lazy_epoch_flush", True))
-
     def flush_lazy(self):
         """Lazy Adam / RMSprop: replay every lagging row up to the optimizer clock (no-op when nothing lags)."""
         lz = getattr(self, "_lazy", None)
@@ -1145,7 +1141,7 @@ class MFEngine(ModelEngine):
                 row_cap, ctypes.c_void_p(counts.data_ptr() + 16 * a), _lib.ptr(pb["cbuf"]), _lib.ptr(pb["cbias"]),
                 hi - lo, bs, 1 if a == 0 else 0, float(self.reg), _lib.ptr(self._stats), _lib.ptr(self._scratch),
                 _lib.stream_ptr(m.flat.device)))
-            if b == n_steps and self._epoch_flush():
+            if b == n_steps:
                 self.flush_lazy()
             return
         if own is not None and not isinstance(own, RowContributions) and self.loss == "bpr" and self._lazy_owned():
@@ -1158,7 +1154,7 @@ class MFEngine(ModelEngine):
                 ctypes.c_void_p(o[2].data_ptr() + 4 * lo), ctypes.c_void_p(total.data_ptr() + 4 * a * stride), stride,
                 hi - lo, bs, 1 if a == 0 else 0, float(self.reg), _lib.ptr(self._stats), _lib.ptr(self._scratch),
                 _lib.stream_ptr(m.flat.device)))
-            if b == n_steps and self._epoch_flush():
+            if b == n_steps:
                 self.flush_lazy()
             return
         _lib.check(lib.hiprec_mf_epoch_lazy(
@@ -1166,7 +1162,7 @@ class MFEngine(ModelEngine):
             ctypes.c_void_p(items_a.data_ptr() + 8 * lo), ctypes.c_void_p(third.data_ptr() + el * lo),
             0 if self.loss == "bpr" else 1, hi - lo, bs, 1 if a == 0 else 0, float(self.reg), _lib.ptr(self._stats),
             _lib.ptr(self._scratch), self._scratch.numel(), _lib.stream_ptr(m.flat.device)))
-        if b == n_steps and self._epoch_flush():
+        if b == n_steps:
             self.flush_lazy()
 
     def _run_owned_epoch(self, lib, prepared, n_run, steps):
