@@ -22,14 +22,14 @@ prof() {  # name, bench args...
   local name=$1; shift
   rm -rf $OUT/prof_$name
   (cd /tmp && TMPDIR=/tmp timeout 250 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o mf -- \
-    python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline "$@" > $OUT/prof_$name.log 2>&1)
+    python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-alt "$@" > $OUT/prof_$name.log 2>&1)
 }
 pmc() {  # name, bench args...   (counters in passes of their own: --pmc with --kernel-trace only)
   local name=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $OUT/pmc_${name}_$c
     (cd /tmp && TMPDIR=/tmp timeout 250 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${name}_$c -o mf -- \
-      python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline "$@" > $OUT/pmc_${name}_$c.log 2>&1)
+      python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-alt "$@" > $OUT/pmc_${name}_$c.log 2>&1)
   done
 }
 collect() { (cd $GRAFT_REPO_ROOT && python tools/collect_profiles.py $TAG > /dev/null); }
