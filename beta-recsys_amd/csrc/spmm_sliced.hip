@@ -62,7 +62,11 @@ __device__ unsigned long long g_sliced_stamps[4][16];
 #define SLICED_STAMP(k) do {} while (0)
 #endif
 
-constexpr int kSlicedThreads = 1024;
+// 12 waves per workgroup (one workgroup per CU: the slice fills its LDS): three per SIMD keep the LDS pipe as busy as
+// four did and a pass has a quarter fewer waves to launch, to meet at its barriers and to retire.  Same box, us per
+// LightGCN / NGCF step: 1024 threads 115.3 / 216.9, 768: 113.9 / 215.8, 512: 118.3 (r06 experiments 79).  Any
+// multiple of 64: a wave's 16 quads take one 16-chunk window per trip whatever the count.
+constexpr int kSlicedThreads = 768;
 constexpr int kSlicedQuads = kSlicedThreads / 4;
 constexpr int64_t kSlicedLds = 160 * 1024 - 64;  // one workgroup's LDS, less the kernel's own few words
 constexpr int kSlicedMinRowCap = 128;            // accumulator rows a subgroup must at least be able to hold

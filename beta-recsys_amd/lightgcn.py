@@ -240,7 +240,7 @@ def sliced_graph_host(rowptr, col, val, eid, n_groups, row_cap, factor=True, lan
 _B128_QUAD_GROUPS = ((0, 3, 5, 6), (1, 2, 4, 7), (8, 11, 13, 14), (9, 10, 12, 15))
 
 
-def spread_bank_conflicts(host, n_groups, quads_per_block=256):
+def spread_bank_conflicts(host, n_groups, quads_per_block=192):
     """Reorder the S slots inside every lane's segment of a sliced graph (in place) so that the source rows the 16
     lanes of one `ds_read_b128` cycle read at the same time fall into different bank quads (column mod 16) where
     possible.  The kernel's chunk -> (block, wave, quad, trip) assignment is static, so which lanes read together
