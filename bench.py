@@ -1326,7 +1326,7 @@ def alt_single_gpu(args, device, only=None):
     def record(out, model):
         roof = out.get("roofline", {})
         live_us = roof.get("kernel_us") if str(roof.get("kernel_us_source", "HIP")).startswith("HIP") else None
-        rec = {k: out[k] for k in ("value", "unit", "ms_per_step", "steps", "repeats", "wall_ms_per_step") if k in out}
+        rec = {k: out[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "repeats", "wall_ms_per_step") if k in out}
         rec["workload"] = out.get("config", {}).get("workload")
         for k in ("ms_per_step_kernels_alone", "ms_per_step_whole_epochs", "epoch", "rows_met_per_epoch", "last_loss"):
             if k in out.get("config", {}):
@@ -1345,7 +1345,10 @@ def alt_single_gpu(args, device, only=None):
         return rec
 
     jobs = {
-        "ncf": (lambda: bench_ncf(sub(emb_dim=32), device),
+        # (ncf / lightgcn: 200 untimed steps first -- the GPU comes out of the seconds of host-side set-up (graph
+        # factoring, table initialisation) at idle clocks and the first ~200 LightGCN steps of a process run 124 -> 113 us,
+        # profiles/r06_experiments.md 81; the record states its warm-up)
+        "ncf": (lambda: bench_ncf(sub(emb_dim=32, warmup=max(args.warmup, 200)), device),
                 "fwd + dgrad + wgrad flops of the tower and head per sample (SURVEY 8d: 258 432 at emb_dim 32) over the "
                 "whole step, against the dense fp32 MFMA peak"),
         "mf_c4shard_sgd": (lambda: bench_mf_c4shard(sub(c4_optimizer="sgd", sgd_mode="owned"), device, full=False),
@@ -1358,7 +1361,7 @@ def alt_single_gpu(args, device, only=None):
                                "as mf_c4shard_adam, on the whole 10 M x 1 M x 128 table, every row met in every epoch; "
                                "value / ms_per_step are the median K-step window, ms_per_step_whole_epochs counts the "
                                "epoch's flush too"),
-        "lightgcn": (lambda: bench_lightgcn(sub(), device),
+        "lightgcn": (lambda: bench_lightgcn(sub(warmup=max(args.warmup, 200)), device),
                      "SURVEY 8d: 2 L SpMMs x [nnz (4 + 4 + 1) + (N + 1) 8 + 2 N D 4] B per step over the whole step"),
     }
     alt, t_all = {}, time.perf_counter()
