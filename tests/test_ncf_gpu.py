@@ -270,11 +270,13 @@ def test_tower_dropout_matches_reference(hip_device, case, engine):
     assert abs(float(k1.float().mean()) - (1 - p)) < 0.12 and not torch.equal(k1, dev_eng.model._ws["keep"][0][:B])
 
 
-@pytest.mark.parametrize("kind,engine,E,p", [("neumf", "NeuMFEngine", 32, 0.3), ("mlp", "MLPEngine", 32, 0.5)])
+@pytest.mark.parametrize("kind,engine,E,p", [("neumf", "NeuMFEngine", 32, 0.3), ("mlp", "MLPEngine", 32, 0.5),
+                                             ("neumf", "NeuMFEngine", 64, 0.2)])
 def test_tower_dropout_inside_the_fused_forward(hip_device, kind, engine, E, p):
     """Tower dropout at a shape the FUSED tower kernel takes (emb_dim 32: 256 -> 128 -> 64 -> 32, batch 4096 + a
-    ragged tail): the keep bytes of every Linear's input are applied inside the fused launch (gather for layer 0,
-    layer epilogues after that).  Loss, every gradient and the scores' keep rate against oracle/ncf_numpy.py fed
+    ragged tail; emb_dim 64: the 512-wide input, two output passes in layer 1 and four in the chain's last layer, the
+    ninth wave copying tiles of every width): the keep bytes of every Linear's input are applied inside the fused
+    launch (gather for layer 0, layer epilogues after that).  Loss, every gradient and the scores' keep rate against oracle/ncf_numpy.py fed
     with the very masks the engine drew (read back from its workspace)."""
     import beta_recsys_amd as hp
 
